@@ -1,0 +1,294 @@
+/*
+ * cmlhip.h — C ABI of the MI355X (gfx950) photometric hot path for libCML / MODSLAM.
+ *
+ * This is the drop-in boundary: the unchanged cml:: host classes (DSOTracker,
+ * DSOBundleAdjustment) keep their public C++ API and call these entry points from
+ * the bodies of computeResidual/computeHessian (tracker) and
+ * linearizeAll/solveSystem (bundle adjustment).  The reference has no C ABI for
+ * this path; each entry point below cites the reference code
+ * (path:line under the reference tree, abbreviations: BA.cpp =
+ * src/cml/optimization/dso/DSOBundleAdjustment.cpp, TR.cpp =
+ * src/cml/optimization/dso/DSOTracker.cpp, ACC.h =
+ * src/cml/optimization/dso/MatrixAccumulators.h) whose inner loop it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer argument is HOST memory that is
+ *    borrowed for the duration of the call, unless its name ends in _dev;
+ *  - all matrices are ROW-MAJOR unless stated; poses are world->camera (R, t),
+ *    p_cam = R p_world + t (src/cml/map/Camera.h:307-315);
+ *  - every function returns a cmlhip_status (0 = ok); nothing throws or aborts;
+ *    non-finite results are reported as CMLHIP_ERR_NONFINITE so the host branches
+ *    at BA.cpp:836-841,1484-1492 and TR.cpp:121-138 still fire;
+ *  - one context owns one HIP stream; contexts are independent and re-entrant
+ *    (tracker ctx and BA ctx may be driven from two host threads);
+ *  - there is NO CPU fallback: if no gfx950 device is usable, create() fails.
+ */
+#ifndef CMLHIP_H
+#define CMLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMLHIP_ABI_VERSION 1
+#define CMLHIP_PATTERN 8        /* star8, src/cml/types.h:1381-1407; DSOMAXRESPERPOINT, DSOResidual.h:10 */
+#define CMLHIP_CPARS 4          /* calibration block size, ACC.h:26 */
+#define CMLHIP_MAX_FRAMES 32    /* window size limit of this layer (reference default maxFrames = 6, BA.h:271) */
+#define CMLHIP_RJ_FLOATS 74     /* sizeof(DSORawResidualJacobian)/4, DSOResidual.h:22-69 */
+
+typedef enum {
+    CMLHIP_OK = 0,
+    CMLHIP_ERR_INVALID = 1,      /* bad argument / size over the limits given at create */
+    CMLHIP_ERR_HIP = 2,          /* HIP runtime error, see cmlhip_last_error */
+    CMLHIP_ERR_NONFINITE = 3,    /* a result contains NaN/Inf */
+    CMLHIP_ERR_NOT_FOUND = 4,    /* unknown image id / level */
+    CMLHIP_ERR_STATE = 5         /* call order violated (e.g. linearize before upload) */
+} cmlhip_status;
+
+/* residual states, DSOResidual.h:14-16 */
+enum { CMLHIP_RES_IN = 0, CMLHIP_RES_OOB = 1, CMLHIP_RES_OUTLIER = 2 };
+/* accumulation modes, DSOResidual.h:18-20 */
+enum { CMLHIP_MODE_ACTIVE = 0, CMLHIP_MODE_LINEARIZED = 1, CMLHIP_MODE_MARGINALIZED = 2 };
+/* pyramid texel storage */
+enum { CMLHIP_TEXEL_F32 = 0, CMLHIP_TEXEL_F16 = 1 };
+
+typedef struct cmlhip_ctx cmlhip_ctx;
+
+typedef struct {
+    int device_id;       /* HIP device ordinal */
+    int max_frames;      /* N  <= CMLHIP_MAX_FRAMES */
+    int max_points;      /* P  */
+    int max_residuals;   /* R  */
+    int max_tracker_points; /* per level, upper bound of DSOTrackerPrivateLevel::n() (TR.h:62) */
+    int max_reproj_obs;  /* ORB observations (BA.cpp:2607-2659) */
+    int texel_format;    /* CMLHIP_TEXEL_F32 | CMLHIP_TEXEL_F16 (config E: fp16 taps, fp32 accumulate) */
+} cmlhip_limits;
+
+/* ---------------------------------------------------------------- context */
+int  cmlhip_abi_version(void);
+int  cmlhip_device_count(void);
+int  cmlhip_create(cmlhip_ctx** out, const cmlhip_limits* limits);
+void cmlhip_destroy(cmlhip_ctx* ctx);
+const char* cmlhip_last_error(const cmlhip_ctx* ctx);
+int  cmlhip_synchronize(cmlhip_ctx* ctx);
+/* raw hipStream_t of the context (for hipEvent timing by the caller) */
+void* cmlhip_stream(cmlhip_ctx* ctx);
+
+/* ---------------------------------------------------------------- pyramids
+ * Device cache of GradientImage = Array2D<Vector3f>{I, dI/dx, dI/dy}
+ * (src/cml/types.h:915, src/cml/image/Array2D.h:288-327), keyed by the host
+ * image id (Array2D::getId(), src/cml/capture/CaptureImage.cpp:12-18,264).
+ * Host layout: AoS, 3 floats per texel, x fastest, data[(y*w+x)*3 + c].
+ * Device layout: 4 floats (or 4 halves) per texel {I,dx,dy,0} so one texel is one
+ * aligned 16-B (8-B) load and a bilinear tap pair is one aligned 32-B segment.
+ */
+int cmlhip_pyramid_put(cmlhip_ctx* ctx, uint64_t image_id, int level,
+                       const float* aos3, int w, int h);
+/* Build the whole pyramid on the device from the level-0 gray image: 2x2 box mean
+ * (Array2D.h:388-401), central-difference gradient with a zero 1-px border
+ * (Array2D.h:288-327), level sizes by integer halving
+ * (src/cml/capture/CaptureImage.cpp:39-78).  levels <= 8. Also keeps the gray
+ * levels (needed by tracker reference colors, TR.cpp:702). */
+int cmlhip_pyramid_build(cmlhip_ctx* ctx, uint64_t image_id, const float* gray,
+                         int w, int h, int levels);
+int cmlhip_pyramid_drop(cmlhip_ctx* ctx, uint64_t image_id);   /* CaptureImage::makeUnactive, CaptureImage.cpp:364-403 */
+int cmlhip_pyramid_level_size(cmlhip_ctx* ctx, uint64_t image_id, int level, int* w, int* h);
+/* read one level back as AoS3 floats (tests) */
+int cmlhip_pyramid_get(cmlhip_ctx* ctx, uint64_t image_id, int level, float* aos3_out);
+
+/* ---------------------------------------------------------------- tracker (a2-a5)
+ * Replaces DSOTracker::computeResidual + computeHessian (TR.cpp:248-492) and
+ * makeCoarseDepthL0 (TR.cpp:494-724).
+ */
+typedef struct {
+    float huber;             /* mHuberThreshold 9 (TR.h:478) */
+    float cutoff;            /* mCutoffThreshold * levelCutoffRepeat (TR.cpp:63,74) */
+    float cutoff_base;       /* mCutoffThreshold 20 (numRobust test, TR.cpp:386) */
+    float scale_rot, scale_trans, scale_a, scale_b; /* 1, 0.5, 10, 1000 (TR.h:484-487) */
+} cmlhip_tracker_params;
+
+typedef struct {
+    float  E;                /* TR.cpp:410 */
+    int    numTermsInE;
+    int    numSaturated;
+    int    numRobust;
+    int    numWarped;        /* survivors written to the warped buffer before padding (TR.cpp:372-384) */
+    float  flow[3];          /* TR.cpp:412-414 */
+    double H[64];            /* trackerContext->hessian, scaled (TR.cpp:474-484); valid if want_hessian */
+    double b[8];             /* trackerContext->jacobian, scaled (TR.cpp:475,485-488) */
+    float  H9[81];           /* raw Accumulator9::H before /n and scaling (ACC.h:1026-1045) */
+} cmlhip_tracker_result;
+
+/* reference point list of one level: n x {u, v, idepth, color} (TR.h:46-60) */
+int cmlhip_tracker_set_reference(cmlhip_ctx* ctx, int level, const float* uvic, int n);
+/* Build the per-level lists on the device from the active points (makeCoarseDepthL0).
+ * pts: n x {Ku, Kv, new_idepth, weight} (doubles) already projected into the reference frame by
+ * the host (TR.cpp:521-553 uses Frame/MapPoint accessors that stay on the host);
+ * the splat, 2x2 sum, dilation, normalisation and compaction (TR.cpp:550-719) run on
+ * the device against pyramid `ref_image_id` (gray levels). n_out[level] = list sizes. */
+int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* ctx, uint64_t ref_image_id, int levels,
+                                     const double* pts, int n, int* n_out);
+/* read a level's list back (tests): uvic_out has room for w*h*4 floats; returns n */
+int cmlhip_tracker_get_reference(cmlhip_ctx* ctx, int level, float* uvic_out, int* n_out);
+
+/* One computeResidual (+ computeHessian when want_hessian) at `level` of image
+ * `new_image_id`.  R, t = refToNew (double, cast to float as TR.cpp:270-271);
+ * K = {fx, fy, cx, cy} of that level (src/cml/map/InternalCalibration.h:116-127);
+ * aff = mLastReferenceExposure.to(exposure) = {a, b} (TR.cpp:272); b0 = reference
+ * exposure parameter b (TR.cpp:428). */
+int cmlhip_tracker_eval(cmlhip_ctx* ctx, uint64_t new_image_id, int level,
+                        const double R[9], const double t[3], const double K[4],
+                        const double aff[2], double b0,
+                        const cmlhip_tracker_params* prm, int want_hessian,
+                        cmlhip_tracker_result* out);
+/* warped buffer readback (tests): SoA rows idepth,u,v,dx,dy,residual,weight,refcolor
+ * (TR.h:98-135), each numWarped long, in reference-list order. */
+int cmlhip_tracker_get_warped(cmlhip_ctx* ctx, float* out8xn, int capacity, int* n_out);
+
+/* ---------------------------------------------------------------- bundle adjustment (a6-a15) */
+typedef struct {
+    double fx, fy, cx, cy;   /* level-0 pinhole cached by BA (BA.cpp:419-425) */
+    int    w, h;
+    float  huber;            /* 9    BA.h:243 */
+    float  outlier_th_sum;   /* 2500 BA.h:244 */
+    double scale_f, scale_c; /* 50, 50 BA.h:252-253 */
+    int    optimize_a, optimize_b; /* BA.h:276-277 */
+} cmlhip_ba_params;
+
+typedef struct {
+    uint64_t image_id;       /* target image of residuals into this frame */
+    float    frame_energy_th;/* DSOFrame::frameEnergyTH (DSOFrame.h:35) */
+    float    b0;             /* DSOFrame::getB0 = state_zero[7]*scaleB (DSOFrame.h:197-199) */
+} cmlhip_ba_frame;
+
+typedef struct {
+    float  x, y;             /* Corner mX,mY (src/cml/types.h:1254) */
+    double idepth;           /* MapPoint::getReferenceInverseDepth (MapObject.h:110) */
+    float  idepth_zero;      /* DSOPoint::idepth_zero (DSOPoint.h:73) */
+    float  prior;            /* DSOPoint::priorF (BA.cpp:1182) */
+    float  colors[CMLHIP_PATTERN];   /* DSOPoint::colors (DSOPoint.h:54, DSOContext.h:87-91) */
+    float  weights[CMLHIP_PATTERN];  /* DSOPoint::weights (BA.cpp:410) */
+    int    host;             /* DSOFrame::id of the reference frame */
+} cmlhip_ba_point;
+
+typedef struct {
+    int point;               /* index into points[] */
+    int target;              /* DSOFrame::id of elements.frame */
+    int state;               /* state_state      (DSOResidual.h:152) */
+    int is_linearized;       /* DSOResidual.h:96 */
+} cmlhip_ba_residual;
+
+/* DSOFramePrecomputed for one (host,target) pair (DSOFrame.h:248-291), index host*N+target */
+typedef struct {
+    double R[9], t[3];       /* trialRefToTarget (current state)           */
+    double R0[9], t0[3];     /* PRE_RTll_0, PRE_tTll_0 (evaluation point)  */
+    double aff_a, aff_b;     /* exposureTransition = host.aff_g2l().to(target.aff_g2l()) */
+} cmlhip_ba_pair;
+
+typedef struct {
+    double energy;           /* sum of returned energies (BA.cpp:1565,1608) */
+    int    n_in, n_oob, n_outlier;   /* counts of state_NewState after the pass */
+    float  new_frame_energy_th;      /* setNewFrameEnergyTH result for frame N-1 (BA.cpp:2419-2464) */
+} cmlhip_ba_lin_result;
+
+int cmlhip_ba_set_params(cmlhip_ctx* ctx, const cmlhip_ba_params* prm);
+/* Upload the window (BA::run preamble, BA.cpp:753-779).  Builds the two index maps the
+ * kernels use: residuals grouped by point (CSR) and by (host,target) pair with
+ * pair index htIDX = host + target*N (BA.cpp:1677). */
+int cmlhip_ba_upload_window(cmlhip_ctx* ctx, int N, const cmlhip_ba_frame* frames,
+                            int P, const cmlhip_ba_point* points,
+                            int R, const cmlhip_ba_residual* residuals);
+/* per-iteration state: N*N pair transforms + frame thresholds (ba_update_state) */
+int cmlhip_ba_set_pairs(cmlhip_ctx* ctx, const cmlhip_ba_pair* pairs /* N*N, host*N+target */);
+int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* ctx, const float* th /* N */);
+int cmlhip_ba_set_idepth(cmlhip_ctx* ctx, const double* idepth /* P */, const float* idepth_zero /* P or NULL */);
+int cmlhip_ba_get_idepth(cmlhip_ctx* ctx, double* idepth /* P */);
+
+/* linearizeAll(false) minus the host bookkeeping: DSOBundleAdjustmentLinearizationContext::linearize
+ * for every active (non-linearized) residual (BA.cpp:62-316,1551-1565) followed by
+ * setNewFrameEnergyTH (BA.cpp:2419-2464; the new threshold is stored for frame N-1). */
+int cmlhip_ba_linearize(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);
+/* applyActiveRes(copyJacobians) (BA.cpp:2045-2093) */
+int cmlhip_ba_apply(cmlhip_ctx* ctx, int copy_jacobians);
+
+/* solveSystem accumulation (BA.cpp:1354-1385): addToHessianTop (ACTIVE and LINEARIZED),
+ * stitchDoubleTop, addToHessianSC, stitchDoubleSC.
+ * adHost/adTarget: N*N 8x8 row-major, index h + t*N (BA.cpp:1094-1095);
+ * adHTdeltaF: N*N x 8 (BA.cpp:1113); cdelta: mCDeltaF (BA.cpp:1118);
+ * prior: N x 8 DSOFrame::prior, delta_prior: N x 8 (BA.cpp:1169-1175); cprior: mCPrior.
+ * Outputs are (8N+4)^2 / (8N+4) doubles, row-major; any may be NULL. */
+typedef struct {
+    const double* adHost; const double* adTarget; const float* adHTdeltaF;
+    const double* cdelta;         /* 4 */
+    const double* prior;          /* N*8 */
+    const double* delta_prior;    /* N*8 */
+    const double* cprior;         /* 4 */
+} cmlhip_ba_accum_in;
+int cmlhip_ba_accumulate(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in,
+                         double* HA, double* bA, double* HL, double* bL,
+                         double* Hsc, double* bsc);
+/* solveLevenbergMarquardt (BA.cpp:1284-1320): H = HL+HM+HA, diag*(1+lambda),
+ * -Hsc/(1+lambda), Jacobi scaling, factorisation of the trailing 8N block
+ * (or the full system when optimize_calibration), x[0:4] = 0 otherwise.
+ * HM/bM may be NULL (disableMarginalization, BA.cpp:1395-1398). x: 8N+4. */
+int cmlhip_ba_solve(cmlhip_ctx* ctx, double lambda, const double* HM, const double* bM,
+                    int optimize_calibration, double* x);
+/* resubstitution (BA.cpp:1427-1487): x is the (possibly orthogonalised) solution;
+ * step[p] = -HdiF * (bdSum - cstep.Hcd - sum xAd[h,t].JpJdF). Returns NONFINITE like
+ * BA.cpp:1484-1491. */
+int cmlhip_ba_backsub(cmlhip_ctx* ctx, const double* x, double* step /* P, may be NULL */);
+/* point part of doStepFromBackup (BA.cpp:976-994): idepth = backup + step if finite and > 0;
+ * also returns sumID, sumNID, numID (float accumulators of BA.cpp:988-990). */
+int cmlhip_ba_backup_points(cmlhip_ctx* ctx);                      /* BA.cpp:919-922 */
+int cmlhip_ba_step_points(cmlhip_ctx* ctx, float sums_out[3]);
+
+/* ---- readbacks (parity tests, Statistic norms BA.cpp:1415-1425, host bookkeeping) */
+int cmlhip_ba_get_states(cmlhip_ctx* ctx, int* state, int* new_state, float* energy,
+                         float* new_energy, float* new_energy_with_outlier,
+                         unsigned char* is_good /* isActiveAndIsGoodNEW */);
+/* raw Jacobian records in the reference layout (DSOResidual.h:22-69):
+ * resF[8] Jpdxi[2][6] Jpdc[2][4] Jpdd[2] JIdx[2][8] JabF[2][8] JIdx2[4] JabJIdx[4] Jab2[4]
+ * (2x2 blocks column-major as Eigen stores them). which: 0 = rJ (latest linearize), 1 = efsJ. */
+int cmlhip_ba_get_rj(cmlhip_ctx* ctx, int which, float* out /* R*74 */);
+int cmlhip_ba_get_jpjdf(cmlhip_ctx* ctx, float* out /* R*8 */);
+int cmlhip_ba_get_center_projected(cmlhip_ctx* ctx, float* out /* R*3 */);
+/* per point: Hdd_accAF, bd_accAF, Hcd_accAF[4], Hdd_accLF, bd_accLF, Hcd_accLF[4], HdiF, bdSumF (14 floats) */
+int cmlhip_ba_get_point_acc(cmlhip_ctx* ctx, float* out /* P*14 */);
+/* raw per-pair 13x13 accumulators (AccumulatorApprox::H after finish, ACC.h:639-673), index h + t*N */
+int cmlhip_ba_get_pair_acc(cmlhip_ctx* ctx, int mode, float* out /* N*N*169 */);
+/* index maps built by upload_window (bit-exact bookkeeping):
+ * pair_of[r] = host + target*N; by_point_offsets[P+1], by_point[R]; by_pair_offsets[N*N+1], by_pair[R] */
+int cmlhip_ba_get_index_maps(cmlhip_ctx* ctx, int* pair_of, int* by_point_offsets, int* by_point,
+                             int* by_pair_offsets, int* by_pair);
+
+/* ---------------------------------------------------------------- hybrid ORB term (a16)
+ * addIndirectToProblem (BA.cpp:2574-2729) + ReprojectionError::jacobian
+ * (src/cml/optimization/Residual.h:59-100).  obs: n x {frame, point, gt_x, gt_y}
+ * (gt = undistorted feature position, Residual.h:15); poses: N x {R[9], t[3]} world->cam;
+ * points: M x 3 world coordinates; fxfy: level-0 focal lengths (Tukey threshold 3/|(fx,fy)|).
+ * Outputs: M6 = pose block of J J^T (6N x 6N, before damping), b6 = 6N, used[n] = 1 when the
+ * observation passed the res/finite tests (BA.cpp:2630). */
+typedef struct { int frame; int point; double gx, gy; } cmlhip_reproj_obs;
+int cmlhip_reproj_accumulate(cmlhip_ctx* ctx, int N, const double* poses /* N*12 */,
+                             int M, const double* points /* M*3 */,
+                             int n, const cmlhip_reproj_obs* obs, double fx, double fy,
+                             double* M6 /* (6N)^2 */, double* b6 /* 6N */,
+                             double* Jpoints /* M*3 or NULL */, unsigned char* used /* n or NULL */);
+/* indirectX = ldlt(M6 with diag*(1+lambda)).solve(-b6) (BA.cpp:2695-2700) on the device */
+int cmlhip_reproj_solve(cmlhip_ctx* ctx, int N, double lambda, double* x6 /* 6N */);
+
+/* ---------------------------------------------------------------- timing helpers (bench.py)
+ * HIP events on the context stream; ms between the two most recent marks. */
+int cmlhip_event_mark(cmlhip_ctx* ctx, int which /* 0 = start, 1 = stop */);
+int cmlhip_event_elapsed_ms(cmlhip_ctx* ctx, float* ms);
+/* enqueue-only variants for throughput measurement: no host readback, no sync */
+int cmlhip_ba_linearize_async(cmlhip_ctx* ctx);
+int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);   /* linearize→apply→accumulate→solve→backsub */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMLHIP_H */

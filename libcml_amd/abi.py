@@ -1,0 +1,113 @@
+"""ctypes mirror of include/cmlhip.h (struct layouts + function prototypes).
+
+The C header is authoritative; tests/test_abi.py checks that every symbol declared there is
+exported by libcmlhip.so and that the struct sizes here match the compiled ones
+(cmlhip_sizeof_*).
+"""
+import ctypes as C
+
+PATTERN = 8
+CPARS = 4
+MAX_FRAMES = 32
+RJ_FLOATS = 74
+
+OK, ERR_INVALID, ERR_HIP, ERR_NONFINITE, ERR_NOT_FOUND, ERR_STATE = range(6)
+RES_IN, RES_OOB, RES_OUTLIER = 0, 1, 2
+MODE_ACTIVE, MODE_LINEARIZED, MODE_MARGINALIZED = 0, 1, 2
+TEXEL_F32, TEXEL_F16 = 0, 1
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_ubyte_p = C.POINTER(C.c_ubyte)
+
+
+class Limits(C.Structure):
+    _fields_ = [("device_id", C.c_int), ("max_frames", C.c_int), ("max_points", C.c_int),
+                ("max_residuals", C.c_int), ("max_tracker_points", C.c_int),
+                ("max_reproj_obs", C.c_int), ("texel_format", C.c_int)]
+
+
+class TrackerParams(C.Structure):
+    _fields_ = [("huber", C.c_float), ("cutoff", C.c_float), ("cutoff_base", C.c_float),
+                ("scale_rot", C.c_float), ("scale_trans", C.c_float), ("scale_a", C.c_float),
+                ("scale_b", C.c_float)]
+
+
+class TrackerResult(C.Structure):
+    _fields_ = [("E", C.c_float), ("numTermsInE", C.c_int), ("numSaturated", C.c_int),
+                ("numRobust", C.c_int), ("numWarped", C.c_int), ("flow", C.c_float * 3),
+                ("H", C.c_double * 64), ("b", C.c_double * 8), ("H9", C.c_float * 81)]
+
+
+class BAParams(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("w", C.c_int), ("h", C.c_int), ("huber", C.c_float), ("outlier_th_sum", C.c_float),
+                ("scale_f", C.c_double), ("scale_c", C.c_double),
+                ("optimize_a", C.c_int), ("optimize_b", C.c_int)]
+
+
+class BAFrame(C.Structure):
+    _fields_ = [("image_id", C.c_uint64), ("frame_energy_th", C.c_float), ("b0", C.c_float)]
+
+
+class BAPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("idepth", C.c_double),
+                ("idepth_zero", C.c_float), ("prior", C.c_float),
+                ("colors", C.c_float * PATTERN), ("weights", C.c_float * PATTERN), ("host", C.c_int)]
+
+
+class BAResidual(C.Structure):
+    _fields_ = [("point", C.c_int), ("target", C.c_int), ("state", C.c_int), ("is_linearized", C.c_int)]
+
+
+class BAPair(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("R0", C.c_double * 9),
+                ("t0", C.c_double * 3), ("aff_a", C.c_double), ("aff_b", C.c_double)]
+
+
+class BALinResult(C.Structure):
+    _fields_ = [("energy", C.c_double), ("n_in", C.c_int), ("n_oob", C.c_int), ("n_outlier", C.c_int),
+                ("new_frame_energy_th", C.c_float)]
+
+
+class BAAccumIn(C.Structure):
+    _fields_ = [("adHost", c_double_p), ("adTarget", c_double_p), ("adHTdeltaF", c_float_p),
+                ("cdelta", c_double_p), ("prior", c_double_p), ("delta_prior", c_double_p),
+                ("cprior", c_double_p)]
+
+
+class ReprojObs(C.Structure):
+    _fields_ = [("frame", C.c_int), ("point", C.c_int), ("gx", C.c_double), ("gy", C.c_double)]
+
+
+# numpy dtypes with the same layout (align=True reproduces the C padding)
+import numpy as np  # noqa: E402
+
+BA_POINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("idepth", "f8"), ("idepth_zero", "f4"),
+                           ("prior", "f4"), ("colors", "f4", (PATTERN,)), ("weights", "f4", (PATTERN,)),
+                           ("host", "i4")], align=True)
+BA_RESIDUAL_DTYPE = np.dtype([("point", "i4"), ("target", "i4"), ("state", "i4"), ("is_linearized", "i4")],
+                             align=True)
+BA_FRAME_DTYPE = np.dtype([("image_id", "u8"), ("frame_energy_th", "f4"), ("b0", "f4")], align=True)
+BA_PAIR_DTYPE = np.dtype([("R", "f8", (9,)), ("t", "f8", (3,)), ("R0", "f8", (9,)), ("t0", "f8", (3,)),
+                          ("aff_a", "f8"), ("aff_b", "f8")], align=True)
+REPROJ_OBS_DTYPE = np.dtype([("frame", "i4"), ("point", "i4"), ("gx", "f8"), ("gy", "f8")], align=True)
+
+assert BA_POINT_DTYPE.itemsize == C.sizeof(BAPoint)
+assert BA_RESIDUAL_DTYPE.itemsize == C.sizeof(BAResidual)
+assert BA_FRAME_DTYPE.itemsize == C.sizeof(BAFrame)
+assert BA_PAIR_DTYPE.itemsize == C.sizeof(BAPair)
+assert REPROJ_OBS_DTYPE.itemsize == C.sizeof(ReprojObs)
+
+
+def default_ba_params(fx, fy, cx, cy, w, h):
+    """Appendix A of SURVEY.md / BA.h:235-288 defaults."""
+    return BAParams(fx=fx, fy=fy, cx=cx, cy=cy, w=w, h=h, huber=9.0, outlier_th_sum=2500.0,
+                    scale_f=50.0, scale_c=50.0, optimize_a=1, optimize_b=1)
+
+
+def default_tracker_params(cutoff_repeat=1.0):
+    """TR.h:473-520 defaults."""
+    return TrackerParams(huber=9.0, cutoff=20.0 * cutoff_repeat, cutoff_base=20.0,
+                         scale_rot=1.0, scale_trans=0.5, scale_a=10.0, scale_b=1000.0)

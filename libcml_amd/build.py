@@ -1,0 +1,87 @@
+"""Build the gfx950 device layer (libcml_amd/libcmlhip.so) with hipcc.  No CUDA, no Triton, no JIT cache:
+the .so is built in-tree so it travels with the repo snapshot to the GPU box."""
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libcmlhip.so")
+HOSTLIB = os.path.join(HERE, "libcmlhost.so")
+SOURCES = ["cmlhip_ctx.hip", "ba_linearize.hip", "ba_accumulate.hip", "ba_api.hip", "tracker.hip", "reproj.hip"]
+HEADERS = ["cmlhip_internal.h", "ba_common.h", os.path.join("..", "..", "include", "cmlhip.h")]
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+         "-Wno-unused-but-set-variable", "-Wno-unused-value"]
+
+
+def _stamp(paths):
+    h = hashlib.sha1()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+    stamp = obj + ".stamp"
+    want = _stamp([os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS])
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
+        return obj
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        print(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return obj
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link libcmlhip.so (+ the C++ host mirror)."""
+    if force:
+        for s in SOURCES:
+            for ext in (".o", ".o.stamp"):
+                p = os.path.join(CSRC, s.replace(".hip", ext))
+                if os.path.exists(p):
+                    os.remove(p)
+    with cf.ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    build_host(force)
+    if verbose:
+        print("built", OUT)
+    return OUT
+
+
+def build_host(force=False):
+    """C++ host mirror of the reference operator interface (libcml_amd/host), linked against libcmlhip.so."""
+    hdir = os.path.join(HERE, "host")
+    srcs = [os.path.join(hdir, f) for f in sorted(os.listdir(hdir)) if f.endswith(".cpp")] if os.path.isdir(hdir) else []
+    if not srcs:
+        return None
+    deps = srcs + [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".h")] + [OUT]
+    if not force and os.path.exists(HOSTLIB) and all(os.path.getmtime(HOSTLIB) >= os.path.getmtime(d) for d in deps):
+        return HOSTLIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOSTLIB] + srcs + \
+          ["-I", os.path.join(HERE, "..", "include"), "-L", HERE, "-lcmlhip", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("host build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return HOSTLIB
+
+
+if __name__ == "__main__":
+    import sys
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,420 @@
+// ba_api.hip — extern "C" entry points of the bundle-adjustment part of include/cmlhip.h.
+// Host side: index bookkeeping (bit-exact maps), uploads, launches, readbacks.  No CPU compute fallback.
+#include "cmlhip_internal.h"
+#include "ba_common.h"
+#include <cmath>
+
+static int ba_check(cmlhip_ctx* c, bool need_pairs) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, c->ba_prm_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_params not called");
+    CML_REQUIRE(c, c->ba_uploaded, CMLHIP_ERR_STATE, "cmlhip_ba_upload_window not called");
+    if (need_pairs) CML_REQUIRE(c, c->ba_pairs_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_pairs not called");
+    return CMLHIP_OK;
+}
+
+int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
+    const cmlhip_ba_params& p = c->ba_prm;
+    A.N = c->N; A.P = c->P; A.R = c->R; A.w = p.w; A.h = p.h; A.opt_a = p.optimize_a; A.opt_b = p.optimize_b; A.n = 8 * c->N + 4;
+    A.fx = p.fx; A.fy = p.fy; A.cx = p.cx; A.cy = p.cy; A.fxi = 1.0 / p.fx; A.fyi = 1.0 / p.fy;
+    A.huber_d = (double)p.huber; A.oth_d = (double)p.outlier_th_sum; A.scale_f = p.scale_f; A.scale_c = p.scale_c;
+    A.frames = c->frames.as<FrameDev>(); A.pairs = c->pairs.as<cmlhip_ba_pair>();
+    A.pt_x = c->pt_x.as<float>(); A.pt_y = c->pt_y.as<float>(); A.pt_idepth = c->pt_idepth.as<double>();
+    A.pt_idepth_zero = c->pt_idepth_zero.as<float>(); A.pt_prior = c->pt_prior.as<float>(); A.pt_host = c->pt_host.as<int>();
+    A.pt_colors = c->pt_colors.as<float>(); A.pt_weights = c->pt_weights.as<float>(); A.pt_backup = c->pt_backup.as<float>();
+    A.pt_acc = c->pt_acc.as<float>(); A.pt_step = c->pt_step.as<double>();
+    A.r_point = c->r_point.as<int>(); A.r_target = c->r_target.as<int>(); A.r_state = c->r_state.as<int>();
+    A.r_new_state = c->r_new_state.as<int>(); A.r_energy = c->r_energy.as<float>(); A.r_new_energy = c->r_new_energy.as<float>();
+    A.r_new_energy_wo = c->r_new_energy_wo.as<float>(); A.r_ret_energy = c->r_ret_energy.as<float>();
+    A.r_good = c->r_good.as<unsigned char>(); A.r_lin = c->r_lin.as<unsigned char>(); A.r_sel = c->r_sel.as<unsigned char>();
+    A.r_center = c->r_center.as<float>(); A.r_jpjdf = c->r_jpjdf.as<float>(); A.r_rtz = c->r_rtz.as<float>();
+    A.rj0 = c->rj[0].as<float>(); A.rj1 = c->rj[1].as<float>();
+    A.by_point_off = c->by_point_off.as<int>(); A.by_point = c->by_point.as<int>();
+    A.by_pair_off = c->by_pair_off.as<int>(); A.by_pair = c->by_pair.as<int>();
+    return CMLHIP_OK;
+}
+
+static inline int ldg_of(int n) { return ((n + 1 + 15) / 16) * 16; }
+
+extern "C" {
+
+int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) {
+    if (!c || !prm) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, prm->w > 4 && prm->h > 4 && prm->fx != 0 && prm->fy != 0, CMLHIP_ERR_INVALID, "bad BA params");
+    c->ba_prm = *prm;
+    c->ba_prm_set = true;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames, int P, const cmlhip_ba_point* points,
+                            int R, const cmlhip_ba_residual* res) {
+    if (!c || !frames || (P > 0 && !points) || (R > 0 && !res)) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, c->ba_prm_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_params not called");
+    CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P >= 0 && P <= c->lim.max_points && R >= 0 && R <= c->lim.max_residuals,
+                CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
+    hipSetDevice(c->device);
+    // ---- frames: resolve pyramids
+    std::vector<FrameDev> fd(N);
+    for (int i = 0; i < N; i++) {
+        const Pyramid* py = cml_find_pyr(c, frames[i].image_id);
+        CML_REQUIRE(c, py && py->lv[0].grad, CMLHIP_ERR_NOT_FOUND, "frame image not in the pyramid cache");
+        CML_REQUIRE(c, py->lv[0].w == c->ba_prm.w && py->lv[0].h == c->ba_prm.h, CMLHIP_ERR_INVALID, "image size != BA params");
+        fd[i].grad0 = py->lv[0].grad; fd[i].frame_energy_th = frames[i].frame_energy_th; fd[i].b0 = frames[i].b0;
+    }
+    // ---- index bookkeeping (exact): htIDX = host + target*N (BA.cpp:1677), CSR by point and by pair
+    c->h_pair_of.assign(R, 0);
+    c->h_by_point_off.assign(P + 1, 0); c->h_by_point.assign(R, 0);
+    c->h_by_pair_off.assign(N * N + 1, 0); c->h_by_pair.assign(R, 0);
+    std::vector<int> newframe;
+    int n_lin = 0;
+    for (int r = 0; r < R; r++) {
+        CML_REQUIRE(c, res[r].point >= 0 && res[r].point < P && res[r].target >= 0 && res[r].target < N, CMLHIP_ERR_INVALID,
+                    "residual index out of range");
+        const int host = points[res[r].point].host;
+        CML_REQUIRE(c, host >= 0 && host < N && host != res[r].target, CMLHIP_ERR_INVALID, "bad host frame (BA.cpp:338-340)");
+        c->h_pair_of[r] = host + res[r].target * N;
+        c->h_by_point_off[res[r].point + 1]++;
+        c->h_by_pair_off[c->h_pair_of[r] + 1]++;
+        if (res[r].target == N - 1) newframe.push_back(r);
+        n_lin += res[r].is_linearized != 0;
+    }
+    for (int p = 0; p < P; p++) c->h_by_point_off[p + 1] += c->h_by_point_off[p];
+    for (int q = 0; q < N * N; q++) c->h_by_pair_off[q + 1] += c->h_by_pair_off[q];
+    {
+        std::vector<int> c1(P, 0), c2(N * N, 0);
+        for (int r = 0; r < R; r++) {
+            const int p = res[r].point, q = c->h_pair_of[r];
+            c->h_by_point[c->h_by_point_off[p] + c1[p]++] = r;
+            c->h_by_pair[c->h_by_pair_off[q] + c2[q]++] = r;
+        }
+    }
+    c->N = N; c->P = P; c->R = R; c->n_lin = n_lin; c->n_newframe = (int)newframe.size();
+    const int n = 8 * N + 4, ldg = ldg_of(n), ntile = ldg / 16;
+    // ---- allocations
+    int rc = 0;
+#define ENS(buf, bytes) if ((rc = cml_ensure(c, buf, (size_t)(bytes)))) return rc
+    ENS(c->frames, sizeof(FrameDev) * N); ENS(c->pairs, sizeof(cmlhip_ba_pair) * N * N);
+    ENS(c->pt_x, 4 * P); ENS(c->pt_y, 4 * P); ENS(c->pt_idepth, 8 * P); ENS(c->pt_idepth_zero, 4 * P); ENS(c->pt_prior, 4 * P);
+    ENS(c->pt_host, 4 * P); ENS(c->pt_colors, 32 * P); ENS(c->pt_weights, 32 * P); ENS(c->pt_backup, 4 * P);
+    ENS(c->pt_acc, 4 * PT_ACC_STRIDE * P); ENS(c->pt_step, 8 * P);
+    ENS(c->r_point, 4 * R); ENS(c->r_target, 4 * R); ENS(c->r_state, 4 * R); ENS(c->r_new_state, 4 * R);
+    ENS(c->r_energy, 4 * R); ENS(c->r_new_energy, 4 * R); ENS(c->r_new_energy_wo, 4 * R); ENS(c->r_ret_energy, 4 * R);
+    ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 32 * R); ENS(c->r_rtz, 32 * R);
+    ENS(c->rj[0], 4 * (size_t)RJ_STRIDE * R); ENS(c->rj[1], 4 * (size_t)RJ_STRIDE * R);
+    ENS(c->by_point_off, 4 * (P + 1)); ENS(c->by_point, 4 * R); ENS(c->by_pair_off, 4 * (N * N + 1)); ENS(c->by_pair, 4 * R);
+    ENS(c->newframe_res, 4 * newframe.size());
+    for (int m = 0; m < 2; m++) { ENS(c->acc_pair[m], 4 * ACC_STRIDE * N * N); ENS(c->acc_num[m], 4 * N * N); }
+    ENS(c->pair_blocks, 8 * (size_t)PB_STRIDE * N * N);
+    ENS(c->adH, 8 * 64 * N * N); ENS(c->adT, 8 * 64 * N * N); ENS(c->adHTd, 4 * 8 * N * N); ENS(c->vec_small, 8 * (8 + 16 * N));
+    ENS(c->HA, 8 * n * n); ENS(c->HL, 8 * n * n); ENS(c->Hsc, 8 * n * n); ENS(c->HM, 8 * n * n);
+    ENS(c->bA, 8 * n); ENS(c->bL, 8 * n); ENS(c->bsc, 8 * n); ENS(c->bM, 8 * n); ENS(c->xvec, 8 * n);
+    ENS(c->G, 8 * ((size_t)P * ldg + P));
+    ENS(c->syrk_part, 8 * (size_t)256 * (ntile * (ntile + 1) / 2) * ((P + 63) / 64 + 1));
+    ENS(c->scal, 1024);
+#undef ENS
+    // ---- SoA staging + upload
+    std::vector<float> fx(P), fy(P), fz(P), fp(P), col(8 * (size_t)P), wgt(8 * (size_t)P);
+    std::vector<double> idp(P);
+    std::vector<int> hst(P);
+    for (int p = 0; p < P; p++) {
+        fx[p] = points[p].x; fy[p] = points[p].y; idp[p] = points[p].idepth; fz[p] = points[p].idepth_zero; fp[p] = points[p].prior;
+        hst[p] = points[p].host;
+        memcpy(&col[8 * (size_t)p], points[p].colors, 32); memcpy(&wgt[8 * (size_t)p], points[p].weights, 32);
+    }
+    std::vector<int> rp(R), rt(R), rs(R), rns(R, CMLHIP_RES_OUTLIER);
+    std::vector<unsigned char> rl(R);
+    for (int r = 0; r < R; r++) { rp[r] = res[r].point; rt[r] = res[r].target; rs[r] = res[r].state; rl[r] = res[r].is_linearized != 0; }
+#define UP(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
+    UP(c->frames, fd);
+    UP(c->pt_x, fx); UP(c->pt_y, fy); UP(c->pt_idepth, idp); UP(c->pt_idepth_zero, fz); UP(c->pt_prior, fp); UP(c->pt_host, hst);
+    UP(c->pt_colors, col); UP(c->pt_weights, wgt);
+    UP(c->r_point, rp); UP(c->r_target, rt); UP(c->r_state, rs); UP(c->r_new_state, rns); UP(c->r_lin, rl);
+    UP(c->by_point_off, c->h_by_point_off); UP(c->by_point, c->h_by_point);
+    UP(c->by_pair_off, c->h_by_pair_off); UP(c->by_pair, c->h_by_pair);
+    UP(c->newframe_res, newframe);
+#undef UP
+    // resetOOB (DSOResidual.h:83-88): energies 0, flags cleared
+    CML_CHECK(c, hipMemsetAsync(c->r_energy.p, 0, c->r_energy.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_new_energy.p, 0, c->r_new_energy.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_new_energy_wo.p, 0, c->r_new_energy_wo.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_ret_energy.p, 0, c->r_ret_energy.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_good.p, 0, c->r_good.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_sel.p, 0, c->r_sel.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_center.p, 0, c->r_center.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_jpjdf.p, 0, c->r_jpjdf.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->r_rtz.p, 0, c->r_rtz.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->rj[0].p, 0, c->rj[0].bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->rj[1].p, 0, c->rj[1].bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->pt_acc.p, 0, c->pt_acc.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->pt_step.p, 0, c->pt_step.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->pt_backup.p, 0, c->pt_backup.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->scal.p, 0, c->scal.bytes, c->stream));
+    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    c->ba_uploaded = true;
+    c->ba_pairs_set = false;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!pairs) return CMLHIP_ERR_INVALID;
+    rc = cml_h2d(c, c->pairs.p, pairs, sizeof(cmlhip_ba_pair) * c->N * c->N);
+    if (rc) return rc;
+    c->ba_pairs_set = true;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!th) return CMLHIP_ERR_INVALID;
+    std::vector<FrameDev> fd(c->N);
+    rc = cml_d2h(c, fd.data(), c->frames.p, sizeof(FrameDev) * c->N);
+    if (rc) return rc;
+    for (int i = 0; i < c->N; i++) fd[i].frame_energy_th = th[i];
+    return cml_h2d(c, c->frames.p, fd.data(), sizeof(FrameDev) * c->N);
+}
+
+int cmlhip_ba_set_idepth(cmlhip_ctx* c, const double* idepth, const float* idepth_zero) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!idepth) return CMLHIP_ERR_INVALID;
+    rc = cml_h2d(c, c->pt_idepth.p, idepth, 8 * (size_t)c->P);
+    if (!rc && idepth_zero) rc = cml_h2d(c, c->pt_idepth_zero.p, idepth_zero, 4 * (size_t)c->P);
+    return rc;
+}
+int cmlhip_ba_get_idepth(cmlhip_ctx* c, double* idepth) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    return cml_d2h(c, idepth, c->pt_idepth.p, 8 * (size_t)c->P);
+}
+
+int cmlhip_ba_linearize_async(cmlhip_ctx* c) {
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_linearize(c, A);
+    cml_launch_lin_finish(c, A);
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_linearize(cmlhip_ctx* c, cmlhip_ba_lin_result* out) {
+    int rc = cmlhip_ba_linearize_async(c);
+    if (rc) return rc;
+    LinSummary S;
+    rc = cml_d2h(c, &S, c->scal.p, sizeof S);
+    if (rc) return rc;
+    if (out) {
+        out->energy = S.energy; out->n_in = S.n_in; out->n_oob = S.n_oob; out->n_outlier = S.n_outlier;
+        out->new_frame_energy_th = S.new_frame_energy_th;
+    }
+    return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
+}
+
+int cmlhip_ba_apply(cmlhip_ctx* c, int copy) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_apply(c, A, copy);
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+static int upload_accum_in(cmlhip_ctx* c, const cmlhip_ba_accum_in* in) {
+    const int N = c->N;
+    int rc;
+    if ((rc = cml_h2d(c, c->adH.p, in->adHost, 8 * 64 * (size_t)N * N))) return rc;
+    if ((rc = cml_h2d(c, c->adT.p, in->adTarget, 8 * 64 * (size_t)N * N))) return rc;
+    if ((rc = cml_h2d(c, c->adHTd.p, in->adHTdeltaF, 4 * 8 * (size_t)N * N))) return rc;
+    std::vector<double> v(8 + 16 * N);
+    for (int i = 0; i < 4; i++) { v[i] = in->cdelta[i]; v[4 + i] = in->cprior[i]; }
+    for (int i = 0; i < 8 * N; i++) { v[8 + i] = in->prior[i]; v[8 + 8 * N + i] = in->delta_prior[i]; }
+    return cml_h2d(c, c->vec_small.p, v.data(), v.size() * 8);
+}
+
+int cmlhip_ba_accumulate(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* HA, double* bA, double* HL, double* bL,
+                         double* Hsc, double* bsc) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior)
+        return CMLHIP_ERR_INVALID;
+    if ((rc = upload_accum_in(c, in))) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_accumulate(c, A);
+    CML_CHECK(c, hipGetLastError());
+    const size_t n = 8 * (size_t)c->N + 4;
+    if (HA && (rc = cml_d2h(c, HA, c->HA.p, 8 * n * n))) return rc;
+    if (bA && (rc = cml_d2h(c, bA, c->bA.p, 8 * n))) return rc;
+    if (HL && (rc = cml_d2h(c, HL, c->HL.p, 8 * n * n))) return rc;
+    if (bL && (rc = cml_d2h(c, bL, c->bL.p, 8 * n))) return rc;
+    if (Hsc && (rc = cml_d2h(c, Hsc, c->Hsc.p, 8 * n * n))) return rc;
+    if (bsc && (rc = cml_d2h(c, bsc, c->bsc.p, 8 * n))) return rc;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_solve(cmlhip_ctx* c, double lambda, const double* HM, const double* bM, int optcal, double* x) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    const size_t n = 8 * (size_t)c->N + 4;
+    const bool have = HM && bM;
+    if (have) {
+        if ((rc = cml_h2d(c, c->HM.p, HM, 8 * n * n))) return rc;
+        if ((rc = cml_h2d(c, c->bM.p, bM, 8 * n))) return rc;
+    }
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_solve(c, A, lambda, have, optcal);
+    CML_CHECK(c, hipGetLastError());
+    int flag = 0;
+    if ((rc = cml_d2h(c, &flag, c->scal.as<char>() + 256, sizeof(int)))) return rc;
+    if (x && (rc = cml_d2h(c, x, c->xvec.p, 8 * n))) return rc;
+    return flag ? CMLHIP_ERR_NONFINITE : CMLHIP_OK;
+}
+
+int cmlhip_ba_backsub(cmlhip_ctx* c, const double* x, double* step) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    const size_t n = 8 * (size_t)c->N + 4;
+    if (x && (rc = cml_h2d(c, c->xvec.p, x, 8 * n))) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_backsub(c, A);
+    CML_CHECK(c, hipGetLastError());
+    LinSummary S;
+    if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
+    if (step && (rc = cml_d2h(c, step, c->pt_step.p, 8 * (size_t)c->P))) return rc;
+    return S.nonfinite ? CMLHIP_ERR_NONFINITE : CMLHIP_OK;
+}
+
+int cmlhip_ba_backup_points(cmlhip_ctx* c) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_backup_points(c, A);
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_step_points(c, A);
+    CML_CHECK(c, hipGetLastError());
+    if (sums) {
+        LinSummary S;
+        if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
+        sums[0] = S.sums[0]; sums[1] = S.sums[1]; sums[2] = S.sums[2];
+    }
+    return CMLHIP_OK;
+}
+
+// one Gauss-Newton iteration enqueued back to back, no host round trip (iterations 0 and 1 of BA::run, which do
+// not orthogonalise: BA.cpp:1404 `iteration >= 2`): backup -> accumulate -> solve -> backsub -> step -> linearize -> apply.
+// The adjoints / priors of the last cmlhip_ba_accumulate call are reused.
+int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_backup_points(c, A);
+    cml_launch_accumulate(c, A);
+    cml_launch_solve(c, A, lambda, false, 0);
+    cml_launch_backsub(c, A);
+    cml_launch_step_points(c, A);
+    cml_launch_linearize(c, A);
+    cml_launch_lin_finish(c, A);
+    cml_launch_apply(c, A, 1);
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- readbacks
+int cmlhip_ba_get_states(cmlhip_ctx* c, int* state, int* new_state, float* energy, float* new_energy, float* new_energy_wo,
+                         unsigned char* is_good) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    const size_t R = c->R;
+    if (state && (rc = cml_d2h(c, state, c->r_state.p, 4 * R))) return rc;
+    if (new_state && (rc = cml_d2h(c, new_state, c->r_new_state.p, 4 * R))) return rc;
+    if (energy && (rc = cml_d2h(c, energy, c->r_energy.p, 4 * R))) return rc;
+    if (new_energy && (rc = cml_d2h(c, new_energy, c->r_new_energy.p, 4 * R))) return rc;
+    if (new_energy_wo && (rc = cml_d2h(c, new_energy_wo, c->r_new_energy_wo.p, 4 * R))) return rc;
+    if (is_good && (rc = cml_d2h(c, is_good, c->r_good.p, R))) return rc;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!out) return CMLHIP_ERR_INVALID;
+    const size_t R = c->R;
+    std::vector<float> b0(RJ_STRIDE * R), b1(RJ_STRIDE * R);
+    std::vector<unsigned char> sel(R);
+    if ((rc = cml_d2h(c, b0.data(), c->rj[0].p, 4 * RJ_STRIDE * R))) return rc;
+    if ((rc = cml_d2h(c, b1.data(), c->rj[1].p, 4 * RJ_STRIDE * R))) return rc;
+    if ((rc = cml_d2h(c, sel.data(), c->r_sel.p, R))) return rc;
+    for (size_t r = 0; r < R; r++) {
+        const bool efs_in_1 = sel[r] != 0;
+        const float* src = ((which == 1) == efs_in_1 ? b1.data() : b0.data()) + RJ_STRIDE * r;
+        memcpy(out + CMLHIP_RJ_FLOATS * r, src, 4 * CMLHIP_RJ_FLOATS);
+    }
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_get_jpjdf(cmlhip_ctx* c, float* out) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    return cml_d2h(c, out, c->r_jpjdf.p, 32 * (size_t)c->R);
+}
+int cmlhip_ba_get_center_projected(cmlhip_ctx* c, float* out) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    return cml_d2h(c, out, c->r_center.p, 12 * (size_t)c->R);
+}
+int cmlhip_ba_get_point_acc(cmlhip_ctx* c, float* out) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    std::vector<float> t(PT_ACC_STRIDE * (size_t)c->P);
+    if ((rc = cml_d2h(c, t.data(), c->pt_acc.p, 4 * t.size()))) return rc;
+    for (int p = 0; p < c->P; p++) memcpy(out + 14 * (size_t)p, &t[PT_ACC_STRIDE * (size_t)p], 14 * 4);
+    return CMLHIP_OK;
+}
+int cmlhip_ba_get_pair_acc(cmlhip_ctx* c, int mode, float* out) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (mode < 0 || mode > 1 || !out) return CMLHIP_ERR_INVALID;
+    const int NN = c->N * c->N;
+    std::vector<float> t(ACC_STRIDE * (size_t)NN);
+    if ((rc = cml_d2h(c, t.data(), c->acc_pair[mode].p, 4 * t.size()))) return rc;
+    for (int q = 0; q < NN; q++) {
+        float* H = out + 169 * (size_t)q;
+        const float* a = &t[ACC_STRIDE * (size_t)q];
+        memset(H, 0, 169 * 4);
+        int idx = 0;
+        for (int r = 0; r < 10; r++) for (int cc = r; cc < 10; cc++) { H[r * 13 + cc] = H[cc * 13 + r] = a[idx]; idx++; }
+        idx = 0;
+        for (int r = 0; r < 10; r++) for (int cc = 0; cc < 3; cc++) { H[r * 13 + cc + 10] = H[(cc + 10) * 13 + r] = a[55 + idx]; idx++; }
+        H[10 * 13 + 10] = a[85]; H[10 * 13 + 11] = H[11 * 13 + 10] = a[86]; H[10 * 13 + 12] = H[12 * 13 + 10] = a[87];
+        H[11 * 13 + 11] = a[88]; H[11 * 13 + 12] = H[12 * 13 + 11] = a[89]; H[12 * 13 + 12] = a[90];
+    }
+    return CMLHIP_OK;
+}
+int cmlhip_ba_get_index_maps(cmlhip_ctx* c, int* pair_of, int* bpo, int* bp, int* bqo, int* bq) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (pair_of) memcpy(pair_of, c->h_pair_of.data(), 4 * (size_t)c->R);
+    if (bpo) memcpy(bpo, c->h_by_point_off.data(), 4 * (size_t)(c->P + 1));
+    if (bp) memcpy(bp, c->h_by_point.data(), 4 * (size_t)c->R);
+    if (bqo) memcpy(bqo, c->h_by_pair_off.data(), 4 * (size_t)(c->N * c->N + 1));
+    if (bq) memcpy(bq, c->h_by_pair.data(), 4 * (size_t)c->R);
+    return CMLHIP_OK;
+}
+
+}  // extern "C"

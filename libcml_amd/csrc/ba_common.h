@@ -1,0 +1,49 @@
+// ba_common.h — kernel argument block and record layout shared by the BA kernels.
+#pragma once
+#include "cmlhip_internal.h"
+
+// 74-float DSORawResidualJacobian (DSOResidual.h:44-68) + 6 extra floats, padded to 80 (320 B, 16-B aligned)
+enum { O_RES = 0, O_XI0 = 8, O_XI1 = 14, O_C0 = 20, O_C1 = 24, O_DD = 28, O_JI0 = 30, O_JI1 = 38,
+       O_JAB0 = 46, O_JAB1 = 54, O_JI2 = 62, O_JABJI = 66, O_JAB2 = 70,
+       O_X_JIR = 74,    // JI^T r   (2)  ACTIVE-mode inner products of BA.cpp:1719-1729, produced by linearize
+       O_X_JABR = 76,   // Jab^T r  (2)
+       O_X_RR = 78,     // r^T r    (1) + pad
+       RJ_STRIDE = 80 };
+
+#define ACC_STRIDE 96          // floats per (host,target) accumulator: 55 (10x10 upper) + 30 (10x3) + 6 (3x3 upper) = 91
+#define PT_ACC_STRIDE 16       // HddA bdA HcdA[4] HddL bdL HcdL[4] HdiF bdSum pad pad
+// per-pair stitched fp64 blocks (stitchDoubleTop, BA.cpp:1827-1843): HH TT HT (64 each) HC TC (32 each) bH bT (8 each) CC (16) bC (4)
+enum { PB_HH = 0, PB_TT = 64, PB_HT = 128, PB_HC = 192, PB_TC = 224, PB_BH = 256, PB_BT = 264, PB_CC = 272, PB_BC = 288, PB_STRIDE = 296 };
+
+struct LinSummary {
+    double energy;
+    int n_in, n_oob, n_outlier;
+    float new_frame_energy_th;
+    float sums[4];            // step_points: sumID sumNID numID, pad
+    int nonfinite;            // backsub: #points with a non-finite step
+    int pad;
+};
+
+struct BAArgs {
+    int N, P, R, w, h, opt_a, opt_b, n;            // n = 8N+4
+    double fx, fy, cx, cy, fxi, fyi, huber_d, oth_d, scale_f, scale_c;
+    const FrameDev* frames;
+    const cmlhip_ba_pair* pairs;
+    const float* pt_x; const float* pt_y; double* pt_idepth; float* pt_idepth_zero; const float* pt_prior;
+    const int* pt_host; const float* pt_colors; const float* pt_weights; float* pt_backup; float* pt_acc; double* pt_step;
+    const int* r_point; const int* r_target; int* r_state; int* r_new_state;
+    float* r_energy; float* r_new_energy; float* r_new_energy_wo; float* r_ret_energy;
+    unsigned char* r_good; const unsigned char* r_lin; unsigned char* r_sel;
+    float* r_center; float* r_jpjdf; float* r_rtz; float* rj0; float* rj1;
+    const int* by_point_off; const int* by_point; const int* by_pair_off; const int* by_pair;
+};
+
+int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A);
+int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy);
+int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A);                 // top (ACTIVE + LINEARIZED) + Schur, outputs in ctx buffers
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, int optcal);
+int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A);

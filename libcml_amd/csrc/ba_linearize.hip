@@ -1,0 +1,363 @@
+// ba_linearize.hip — photometric residual / Jacobian evaluation of the sliding-window BA.
+// Replaces DSOBundleAdjustmentLinearizationContext::linearize (BA.cpp:62-316), the linearizeAll loop
+// (BA.cpp:1551-1565), setNewFrameEnergyTH (BA.cpp:2419-2464) and applyRes (BA.cpp:2051-2093).
+//
+// Mapping (gfx950, wave64): one lane per pattern pixel, 8 lanes per point-residual, 8 residuals per
+// wave, 32 per 256-thread workgroup.  Geometry in fp64 and photometrics in fp32 exactly where the
+// reference mixes them (its context members are float, Parameter::f() is double), FP contraction off,
+// and the 8-pixel inner products are summed in pattern order — so a record is bit-identical to the
+// CPU statement order.  Per-pixel terms are exchanged through a 2.3 KB LDS tile (7 floats x 8 lanes
+// per residual, ds_read_b128 broadcast reads); the finished 80-float records are staged in LDS and
+// leave the CU as coalesced 16-B stores.
+#include "cmlhip_internal.h"
+#include "ba_common.h"
+
+#pragma clang fp contract(off)
+
+template <bool HALF>
+__device__ __forceinline__ float4 load_texel(const void* img, size_t i) {
+    if (HALF) {
+        uint2 v = reinterpret_cast<const uint2*>(img)[i];
+        __half2 a = *reinterpret_cast<__half2*>(&v.x), b = *reinterpret_cast<__half2*>(&v.y);
+        return make_float4(__low2float(a), __high2float(a), __low2float(b), 0.f);
+    }
+    return reinterpret_cast<const float4*>(img)[i];
+}
+
+// GradientImage::interpolate, src/cml/image/Array2D.h:265-286
+template <bool HALF>
+__device__ __forceinline__ void tap3(const void* img, int w, float x, float y, float& I, float& gx, float& gy) {
+    const int ix = (int)x, iy = (int)y;
+    const float dx = x - (float)ix, dy = y - (float)iy;
+    const float dxdy = dx * dy;
+    const float w00 = 1 - dx - dy + dxdy, w01 = dx - dxdy, w10 = dy - dxdy, w11 = dxdy;
+    const size_t i1 = (size_t)iy * w + ix;
+    const float4 a = load_texel<HALF>(img, i1), b = load_texel<HALF>(img, i1 + 1);
+    const float4 c = load_texel<HALF>(img, i1 + w), d = load_texel<HALF>(img, i1 + w + 1);
+    I = a.x * w00 + b.x * w01 + c.x * w10 + d.x * w11;
+    gx = a.y * w00 + b.y * w01 + c.y * w10 + d.y * w11;
+    gy = a.z * w00 + b.z * w01 + c.z * w10 + d.z * w11;
+}
+
+__constant__ int c_star8[16] = {0, -2, -1, -1, 1, -1, -2, 0, 0, 0, 2, 0, -1, 1, 0, 2};   // types.h:1381-1393
+
+#define RES_PER_BLOCK 32
+#define NSHARE 8          // floats exchanged per pattern pixel
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
+    __shared__ __attribute__((aligned(16))) float s_share[RES_PER_BLOCK][NSHARE][8];   // [residual][quantity][pixel]
+    __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE];
+    __shared__ int s_write[RES_PER_BLOCK];
+    const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
+    const int r = blockIdx.x * RES_PER_BLOCK + g;
+    const bool live = (r < A.R) && !A.r_lin[r];
+    const int st = live ? A.r_state[r] : CMLHIP_RES_OOB;
+    const bool run = live && st != CMLHIP_RES_OOB;
+
+    // ---- per-residual inputs (all 8 lanes of the group read the same addresses: broadcast)
+    const int p = live ? A.r_point[r] : 0;
+    const int host = A.pt_host[p], target = live ? A.r_target[r] : 0;
+    const cmlhip_ba_pair* pc = &A.pairs[host * A.N + target];
+    const FrameDev fh = A.frames[host], ft = A.frames[target];
+    const double cxd = (double)A.pt_x[p], cyd = (double)A.pt_y[p];
+    const double idepth = A.pt_idepth[p];
+    const double R0_ = pc->R[0], R1_ = pc->R[1], R2_ = pc->R[2], R3_ = pc->R[3], R4_ = pc->R[4], R5_ = pc->R[5],
+                 R6_ = pc->R[6], R7_ = pc->R[7], R8_ = pc->R[8];
+    const double t0_ = pc->t[0], t1_ = pc->t[1], t2_ = pc->t[2];
+
+    // ---- centre projection, BA.cpp:102-131 (identical on the 8 lanes)
+    const double rx = (cxd - A.cx) * A.fxi, ry = (cyd - A.cy) * A.fyi;
+    const double px = (R0_ * rx + R1_ * ry + R2_ * 1.0) + t0_ * idepth;
+    const double py = (R3_ * rx + R4_ * ry + R5_ * 1.0) + t1_ * idepth;
+    const double pz = (R6_ * rx + R7_ * ry + R8_ * 1.0) + t2_ * idepth;
+    const double Kud = (px / pz) * A.fx + A.cx, Kvd = (py / pz) * A.fy + A.cy;
+    const float drescale = (float)(1.0 / pz);
+    const bool centre_in = (Kud >= 2 && Kvd >= 2 && Kud < A.w - 2 && Kvd < A.h - 2);
+
+    // ---- this lane's pattern pixel, BA.cpp:193-212
+    const double sx = cxd + c_star8[2 * k], sy = cyd + c_star8[2 * k + 1];
+    const double qx = (sx - A.cx) * A.fxi, qy = (sy - A.cy) * A.fyi;
+    const double ppx = (R0_ * qx + R1_ * qy + R2_ * 1.0) + t0_ * idepth;
+    const double ppy = (R3_ * qx + R4_ * qy + R5_ * 1.0) + t1_ * idepth;
+    const double ppz = (R6_ * qx + R7_ * qy + R8_ * 1.0) + t2_ * idepth;
+    const double kx = (ppx / ppz) * A.fx + A.cx, ky = (ppy / ppz) * A.fy + A.cy;
+    const bool pix_in = (kx >= 2 && ky >= 2 && kx < A.w - 2 && ky < A.h - 2);
+
+    float I = 0.f, gx = 0.f, gy = 0.f;
+    const bool sample = run && centre_in && pix_in;
+    if (sample) tap3<HALF>(ft.grad0, A.w, (float)kx, (float)ky, I, gx, gy);     // BA.cpp:218
+    const bool finite = isfinite(I) && isfinite(gx) && isfinite(gy);
+
+    // first failing pixel in pattern order decides between setNewState(OOB) (:209-212) and setState(OOB) (:220-223)
+    const unsigned long long bal_oob = __ballot(!pix_in), bal_nf = __ballot(pix_in && !finite);
+    const int shift = (tid & 63) & ~7;
+    const unsigned m_oob = (unsigned)(bal_oob >> shift) & 0xFFu, m_nf = (unsigned)(bal_nf >> shift) & 0xFFu;
+    const unsigned m_bad = m_oob | m_nf;
+    const int first_bad = m_bad ? __ffs((int)m_bad) - 1 : 8;
+    const bool fail_new_oob = !centre_in || (m_bad && ((m_oob >> first_bad) & 1u));
+    const bool fail_state_oob = centre_in && m_bad && !((m_oob >> first_bad) & 1u);
+    const bool ok = run && !fail_new_oob && !fail_state_oob;
+
+    // ---- photometric terms of this pixel, BA.cpp:214-255
+    const float refColor = A.pt_colors[8 * (size_t)p + k];
+    const float refRealColor = (float)(pc->aff_a * (double)refColor + pc->aff_b);
+    const float residual = I - refRealColor;
+    float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
+    float wgt = sqrtf((float)(A.oth_d / (A.oth_d + (double)(gx * gx + gy * gy))));
+    wgt = (float)(0.5f * ((double)wgt + (double)A.pt_weights[8 * (size_t)p + k]));
+    const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
+    const float hw0 = hw;
+    if (hw < 1) hw = sqrtf(hw);
+    hw = hw * wgt;
+    const float f1 = gx * hw, f2 = gy * hw;                     // hitColor[1], hitColor[2]
+    const float drdA = I - fh.b0;
+    const float a_ = drdA * hw;
+    const float rF = residual * hw;
+
+    s_share[g][0][k] = f1; s_share[g][1][k] = f2; s_share[g][2][k] = a_; s_share[g][3][k] = hw;
+    s_share[g][4][k] = drdA; s_share[g][5][k] = pf; s_share[g][6][k] = hw0; s_share[g][7][k] = rF;
+    __syncthreads();
+
+    // ---- pattern-order sums, BA.cpp:237,257-271 and the ACTIVE-mode inner products of BA.cpp:1719-1729
+    float J00 = 0, J11 = 0, J10 = 0, Q00 = 0, Q01 = 0, Q10 = 0, Q11 = 0, B00 = 0, B01 = 0, B11 = 0, wJI2 = 0, E = 0;
+    double JIr0 = 0, JIr1 = 0, Jabr0 = 0, Jabr1 = 0;
+    float rr = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float F1 = s_share[g][0][j], F2 = s_share[g][1][j], AA = s_share[g][2][j], HW = s_share[g][3][j];
+        const float DA = s_share[g][4][j], PF = s_share[g][5][j], HW0 = s_share[g][6][j], RF = s_share[g][7][j];
+        const double h1 = (double)F1, h2 = (double)F2;
+        E = (float)((double)E + (double)PF * (2.0 - (double)HW0));
+        J00 = (float)(J00 + h1 * h1);
+        J11 = (float)(J11 + h2 * h2);
+        J10 = (float)(J10 + h1 * h2);
+        Q00 = (float)(Q00 + (double)AA * h1);
+        Q01 = (float)(Q01 + (double)AA * h2);
+        Q10 = (float)(Q10 + (double)HW * h1);
+        Q11 = (float)(Q11 + (double)HW * h2);
+        B00 += DA * DA * HW * HW;
+        B01 += DA * HW * HW;
+        B11 += HW * HW;
+        wJI2 = (float)(wJI2 + (double)(HW * HW) * (h1 * h1 + h2 * h2));
+        const float ja = A.opt_a ? AA : 0.f, jb = A.opt_b ? HW : 0.f;       // BA.cpp:273-278
+        JIr0 += (double)RF * h1;
+        JIr1 += (double)RF * h2;
+        Jabr0 += (double)RF * (double)ja;
+        Jabr1 += (double)RF * (double)jb;
+        rr = (float)((double)rr + (double)RF * (double)RF);
+    }
+
+    // ---- geometric Jacobians, BA.cpp:120-188 (computed by every lane, each stores its share)
+    const float new_idepth = (float)(drescale * idepth);
+    const float u = (float)px, v = (float)py;            // BA.cpp:121-122: un-normalised x,y, literal
+    const float fxf = (float)A.fx, fyf = (float)A.fy;
+    float* rec = s_rec[g];
+    if (k == 0) {
+        rec[O_XI0 + 0] = new_idepth * fxf; rec[O_XI0 + 1] = 0; rec[O_XI0 + 2] = -new_idepth * u * fxf;
+        rec[O_XI0 + 3] = -u * v * fxf; rec[O_XI0 + 4] = (1 + u * u) * fxf; rec[O_XI0 + 5] = -v * fxf;
+    } else if (k == 1) {
+        rec[O_XI1 + 0] = 0; rec[O_XI1 + 1] = new_idepth * fyf; rec[O_XI1 + 2] = -new_idepth * v * fyf;
+        rec[O_XI1 + 3] = -(1 + v * v) * fyf; rec[O_XI1 + 4] = u * v * fyf; rec[O_XI1 + 5] = u * fyf;
+    } else if (k == 2) {
+        const double* R0 = pc->R0; const double* t0 = pc->t0;
+        double c2 = drescale * (R0[6] * u - R0[0]);
+        double c3 = (fxf * drescale) * (R0[7] * u - R0[1]) / fyf;
+        double c0 = rx * c2, c1 = ry * c3;
+        rec[O_C0 + 0] = (float)((c0 + u) * A.scale_f); rec[O_C0 + 1] = (float)(c1 * A.scale_f);
+        rec[O_C0 + 2] = (float)((c2 + 1) * A.scale_c); rec[O_C0 + 3] = (float)(c3 * A.scale_c);
+        rec[O_DD + 0] = (float)(drescale * (t0[0] - t0[2] * u) * fxf);
+        rec[O_DD + 1] = (float)(drescale * (t0[1] - t0[2] * v) * fyf);
+    } else if (k == 3) {
+        const double* R0 = pc->R0;
+        double d2 = (fyf * drescale) * (R0[6] * v - R0[3]) / fxf;
+        double d3 = drescale * (R0[7] * v - R0[4]);
+        double d0 = rx * d2, d1 = ry * d3;
+        rec[O_C1 + 0] = (float)(d0 * A.scale_f); rec[O_C1 + 1] = (float)((d1 + v) * A.scale_f);
+        rec[O_C1 + 2] = (float)(d2 * A.scale_c); rec[O_C1 + 3] = (float)((d3 + 1) * A.scale_c);
+    } else if (k == 4) {
+        rec[O_JI2 + 0] = J00; rec[O_JI2 + 1] = J10; rec[O_JI2 + 2] = J10; rec[O_JI2 + 3] = J11;
+        rec[O_JABJI + 0] = Q00; rec[O_JABJI + 1] = Q10; rec[O_JABJI + 2] = Q01; rec[O_JABJI + 3] = Q11;
+    } else if (k == 5) {
+        rec[O_JAB2 + 0] = B00; rec[O_JAB2 + 1] = B01; rec[O_JAB2 + 2] = B01; rec[O_JAB2 + 3] = B11;
+        rec[O_X_JIR + 0] = (float)JIr0; rec[O_X_JIR + 1] = (float)JIr1;
+        rec[O_X_JABR + 0] = (float)Jabr0; rec[O_X_JABR + 1] = (float)Jabr1;
+        rec[O_X_RR] = rr; rec[O_X_RR + 1] = 0.f;
+    }
+    rec[O_RES + k] = rF;
+    rec[O_JI0 + k] = f1;
+    rec[O_JI1 + k] = f2;
+    rec[O_JAB0 + k] = A.opt_a ? a_ : 0.f;
+    rec[O_JAB1 + k] = A.opt_b ? hw : 0.f;
+
+    // ---- classification, BA.cpp:66-72,115-118,297-314
+    if (k == 0) s_write[g] = run ? 1 : 0;    // a residual that entered OOB keeps its record untouched (early return, :68-72)
+    if (live && k == 0) {
+        float ret = A.r_energy[r];
+        float nwo = -1.f;
+        if (run) {
+            if (centre_in) {                                        // setCenterProjectedTo, :131
+                A.r_center[3 * (size_t)r] = (float)Kud; A.r_center[3 * (size_t)r + 1] = (float)Kvd;
+                A.r_center[3 * (size_t)r + 2] = new_idepth;
+            }
+            if (fail_new_oob) {
+                A.r_new_state[r] = CMLHIP_RES_OOB;
+            } else if (fail_state_oob) {
+                A.r_state[r] = CMLHIP_RES_OOB;
+            } else if (!isfinite(E)) {
+                A.r_new_state[r] = CMLHIP_RES_OOB;
+            } else {
+                nwo = E;
+                const float th = fh.frame_energy_th > ft.frame_energy_th ? fh.frame_energy_th : ft.frame_energy_th;
+                float e = E;
+                int ns = CMLHIP_RES_IN;
+                if (E > th || wJI2 < 2) { e = th; ns = CMLHIP_RES_OUTLIER; }
+                A.r_new_state[r] = ns;
+                A.r_new_energy[r] = e;
+                ret = e;
+            }
+        }
+        A.r_new_energy_wo[r] = nwo;
+        A.r_ret_energy[r] = ret;
+    }
+    __syncthreads();
+
+    // ---- coalesced copy-out of the finished records into the residual's rJ buffer (the one that is not efsJ)
+    const int r0 = blockIdx.x * RES_PER_BLOCK;
+    for (int i = tid; i < RES_PER_BLOCK * (RJ_STRIDE / 4); i += 256) {
+        const int gg = i / (RJ_STRIDE / 4), q = i % (RJ_STRIDE / 4);
+        const int rr_ = r0 + gg;
+        if (rr_ >= A.R) break;
+        if (!s_write[gg]) continue;
+        float* dst = (A.r_sel[rr_] ? A.rj0 : A.rj1) + (size_t)rr_ * RJ_STRIDE;
+        reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(s_rec[gg])[q];
+    }
+    (void)ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// energy sum (BA.cpp:1565,1608), state census and setNewFrameEnergyTH (BA.cpp:2419-2464) in ONE workgroup:
+// fixed-order fp64 tree for the energy, exact radix select (4 x 8-bit passes over the float bit patterns;
+// energies are >= 0 so the unsigned order is the float order) for the 70th percentile.
+__global__ __launch_bounds__(1024) void k_ba_lin_finish(BAArgs A, const int* __restrict__ newframe_res, int n_newframe,
+                                                        LinSummary* __restrict__ out, FrameDev* __restrict__ frames_rw) {
+    __shared__ double s_sum[1024];
+    __shared__ int s_cnt[3][16];
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_prefix, s_k, s_nvalid;
+    const int tid = threadIdx.x;
+    double e = 0;
+    int cin = 0, coob = 0, cout = 0;
+    for (int r = tid; r < A.R; r += 1024) {
+        if (A.r_lin[r]) continue;
+        e += (double)A.r_ret_energy[r];
+        const int ns = A.r_new_state[r];
+        cin += ns == CMLHIP_RES_IN; coob += ns == CMLHIP_RES_OOB; cout += ns == CMLHIP_RES_OUTLIER;
+    }
+    s_sum[tid] = e;
+    for (int o = 32; o > 0; o >>= 1) { cin += __shfl_down(cin, o); coob += __shfl_down(coob, o); cout += __shfl_down(cout, o); }
+    if ((tid & 63) == 0) { s_cnt[0][tid >> 6] = cin; s_cnt[1][tid >> 6] = coob; s_cnt[2][tid >> 6] = cout; }
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) s_sum[tid] += s_sum[tid + s];
+        __syncthreads();
+    }
+    // ---- radix select over new_energy_wo of the residuals that target the newest frame
+    unsigned nvalid = 0;
+    for (int i = tid; i < n_newframe; i += 1024) {
+        const int r = newframe_res[i];
+        nvalid += (!A.r_lin[r] && A.r_new_energy_wo[r] >= 0.f);
+    }
+    if (tid == 0) s_nvalid = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o);
+    if ((tid & 63) == 0) atomicAdd(&s_nvalid, nvalid);
+    __syncthreads();
+    const unsigned n = s_nvalid;
+    float th;
+    if (n == 0) {
+        th = 12 * 12 * 8;                                  // :2432-2436
+    } else {
+        if (tid == 0) { s_prefix = 0; s_k = (unsigned)(int)(0.7f * (float)n); }   // nthIdx, :2448
+        __syncthreads();
+        for (int pass = 3; pass >= 0; pass--) {
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            const unsigned hmask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+            for (int i = tid; i < n_newframe; i += 1024) {
+                const int r = newframe_res[i];
+                const float v = A.r_new_energy_wo[r];
+                if (A.r_lin[r] || !(v >= 0.f)) continue;
+                const unsigned b = __float_as_uint(v);
+                if ((b & hmask) == prefix) atomicAdd(&s_hist[(b >> (8 * pass)) & 0xFFu], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned kk = s_k, acc = 0;
+                int d = 0;
+                for (; d < 256; d++) { if (acc + s_hist[d] > kk) break; acc += s_hist[d]; }
+                s_k = kk - acc;
+                s_prefix = prefix | ((unsigned)d << (8 * pass));
+            }
+            __syncthreads();
+        }
+        const float nthElement = sqrtf(__uint_as_float(s_prefix));      // :2455
+        double t = (double)(nthElement * 1.5f);                         // :2458
+        t = (double)(26.0f * 0.5f) + t * (double)(1 - 0.5f);
+        t = t * t;
+        t *= (double)(1.0f * 1.0f);
+        th = (float)t;
+    }
+    if (tid == 0) {
+        int a = 0, b = 0, c = 0;
+        for (int i = 0; i < 16; i++) { a += s_cnt[0][i]; b += s_cnt[1][i]; c += s_cnt[2][i]; }
+        out->energy = s_sum[0]; out->n_in = a; out->n_oob = b; out->n_outlier = c; out->new_frame_energy_th = th;
+        frames_rw[A.N - 1].frame_energy_th = th;                        // takes effect from the next linearize
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// applyRes, BA.cpp:2051-2093.  "swap(rJ, efsJ)" is a flip of the residual's buffer selector.
+__global__ void k_ba_apply(BAArgs A, int copy) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.R || A.r_lin[r]) return;
+    if (copy) {
+        if (A.r_state[r] == CMLHIP_RES_OOB) return;
+        if (A.r_new_state[r] == CMLHIP_RES_IN) {
+            A.r_good[r] = 1;
+            const unsigned char sel = A.r_sel[r] ^ 1;
+            A.r_sel[r] = sel;
+            const float* J = (sel ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
+            const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
+            const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
+            float* o = A.r_jpjdf + 8 * (size_t)r;
+#pragma unroll
+            for (int i = 0; i < 6; i++) o[i] = J[O_XI0 + i] * g0 + J[O_XI1 + i] * g1;
+            o[6] = J[O_JABJI + 0] * J[O_DD] + J[O_JABJI + 2] * J[O_DD + 1];
+            o[7] = J[O_JABJI + 1] * J[O_DD] + J[O_JABJI + 3] * J[O_DD + 1];
+        } else {
+            A.r_good[r] = 0;
+        }
+    }
+    A.r_state[r] = A.r_new_state[r];
+    A.r_energy[r] = A.r_new_energy[r];
+}
+
+int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A) {
+    const int blocks = cml_div_up(A.R, RES_PER_BLOCK);
+    if (blocks == 0) return CMLHIP_OK;
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_ba_linearize<true><<<blocks, 256, 0, c->stream>>>(A);
+    else k_ba_linearize<false><<<blocks, 256, 0, c->stream>>>(A);
+    return CMLHIP_OK;
+}
+int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A) {
+    k_ba_lin_finish<<<1, 1024, 0, c->stream>>>(A, c->newframe_res.as<int>(), c->n_newframe, c->scal.as<LinSummary>(),
+                                                c->frames.as<FrameDev>());
+    return CMLHIP_OK;
+}
+int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy) {
+    if (A.R == 0) return CMLHIP_OK;
+    k_ba_apply<<<cml_div_up(A.R, 256), 256, 0, c->stream>>>(A, copy);
+    return CMLHIP_OK;
+}

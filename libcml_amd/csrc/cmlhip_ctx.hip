@@ -1,0 +1,267 @@
+// cmlhip_ctx.hip — context, device memory, pyramid cache and the image kernels.
+// Reference: GradientImage layout/ownership src/cml/types.h:915, src/cml/capture/CaptureImage.cpp:209-403;
+// image ops src/cml/image/Array2D.h:288-327 (gradient), :388-401 (reduceByTwo).
+#include "cmlhip_internal.h"
+
+int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return CMLHIP_OK;
+    if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    size_t cap = (bytes + 255) & ~size_t(255);
+    CML_CHECK(c, hipMalloc(&b.p, cap));
+    b.bytes = cap;
+    return CMLHIP_OK;
+}
+void cml_free(DevBuf& b) {
+    if (b.p) hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+}
+int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return CMLHIP_OK;
+    // pageable source: the runtime stages it before returning, so the borrowed host buffer may be reused by the caller
+    CML_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return CMLHIP_OK;
+}
+int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return CMLHIP_OK;
+    CML_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    return CMLHIP_OK;
+}
+const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id) {
+    auto it = c->pyr.find(id);
+    return it == c->pyr.end() ? nullptr : &it->second;
+}
+
+extern "C" {
+
+int cmlhip_abi_version(void) { return CMLHIP_ABI_VERSION; }
+
+int cmlhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cmlhip_create(cmlhip_ctx** out, const cmlhip_limits* lim) {
+    if (!out || !lim) return CMLHIP_ERR_INVALID;
+    *out = nullptr;
+    if (lim->max_frames < 1 || lim->max_frames > CMLHIP_MAX_FRAMES) return CMLHIP_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || lim->device_id >= n) return CMLHIP_ERR_HIP;   // no CPU fallback
+    if (hipSetDevice(lim->device_id) != hipSuccess) return CMLHIP_ERR_HIP;
+    cmlhip_ctx* c = new cmlhip_ctx();
+    c->lim = *lim;
+    c->device = lim->device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CMLHIP_ERR_HIP; }
+    hipEventCreate(&c->ev[0]);
+    hipEventCreate(&c->ev[1]);
+    *out = c;
+    return CMLHIP_OK;
+}
+
+void cmlhip_destroy(cmlhip_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pyr)
+        for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) hipFree(kv.second.lv[l].gray); }
+    DevBuf* all[] = {&c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
+                     &c->pt_colors, &c->pt_weights, &c->pt_backup, &c->pt_acc, &c->pt_step, &c->r_point, &c->r_target,
+                     &c->r_state, &c->r_new_state, &c->r_energy, &c->r_new_energy, &c->r_new_energy_wo, &c->r_ret_energy,
+                     &c->r_good, &c->r_lin, &c->r_sel, &c->r_center, &c->r_jpjdf, &c->r_rtz, &c->rj[0], &c->rj[1],
+                     &c->by_point_off, &c->by_point, &c->by_pair_off, &c->by_pair, &c->newframe_res, &c->acc_pair[0],
+                     &c->acc_pair[1], &c->acc_num[0], &c->acc_num[1], &c->pair_blocks, &c->adH, &c->adT, &c->adHTd,
+                     &c->vec_small, &c->HA, &c->bA, &c->HL, &c->bL, &c->Hsc, &c->bsc, &c->HM, &c->bM, &c->xvec, &c->G,
+                     &c->syrk_part, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt,
+                     &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x};
+    for (DevBuf* b : all) cml_free(*b);
+    for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
+    if (c->pinned) hipHostFree(c->pinned);
+    hipEventDestroy(c->ev[0]);
+    hipEventDestroy(c->ev[1]);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* cmlhip_last_error(const cmlhip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int cmlhip_synchronize(cmlhip_ctx* c) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    return CMLHIP_OK;
+}
+void* cmlhip_stream(cmlhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int cmlhip_event_mark(cmlhip_ctx* c, int which) {
+    if (!c || which < 0 || which > 1) return CMLHIP_ERR_INVALID;
+    CML_CHECK(c, hipEventRecord(c->ev[which], c->stream));
+    return CMLHIP_OK;
+}
+int cmlhip_event_elapsed_ms(cmlhip_ctx* c, float* ms) {
+    if (!c || !ms) return CMLHIP_ERR_INVALID;
+    CML_CHECK(c, hipEventSynchronize(c->ev[1]));
+    CML_CHECK(c, hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
+    return CMLHIP_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ image kernels
+template <bool HALF>
+__device__ __forceinline__ void store_texel(void* img, size_t idx, float I, float dx, float dy) {
+    if (HALF) {
+        __half2 a = __floats2half2_rn(I, dx), b = __floats2half2_rn(dy, 0.f);
+        uint2 v;
+        v.x = *reinterpret_cast<unsigned*>(&a);
+        v.y = *reinterpret_cast<unsigned*>(&b);
+        reinterpret_cast<uint2*>(img)[idx] = v;
+    } else {
+        reinterpret_cast<float4*>(img)[idx] = make_float4(I, dx, dy, 0.f);
+    }
+}
+
+// AoS3 host layout -> device texels
+template <bool HALF>
+__global__ void k_expand_aos3(const float* __restrict__ aos3, void* __restrict__ img, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_texel<HALF>(img, i, aos3[3 * (size_t)i], aos3[3 * (size_t)i + 1], aos3[3 * (size_t)i + 2]);
+}
+
+// Array2D::reduceByTwo, Array2D.h:388-401
+__global__ void k_reduce_by_two(const float* __restrict__ in, int w, int h, float* __restrict__ out) {
+    int nw = w / 2, nh = h / 2;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nw || y >= nh) return;
+    const float* r0 = in + (size_t)(2 * y) * w + 2 * x;
+    const float* r1 = r0 + w;
+    out[(size_t)y * nw + x] = (((r0[0] + r0[1]) + r1[0]) + r1[1]) / 4.0f;
+}
+
+// Array2D::gradientImage, Array2D.h:288-327 (zero 1-px border)
+template <bool HALF>
+__global__ void k_gradient(const float* __restrict__ g, int w, int h, void* __restrict__ img) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    size_t i = (size_t)y * w + x;
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) { store_texel<HALF>(img, i, 0.f, 0.f, 0.f); return; }
+    store_texel<HALF>(img, i, g[i], (g[i + 1] - g[i - 1]) * 0.5f, (g[i + w] - g[i - w]) * 0.5f);
+}
+
+template <bool HALF>
+__global__ void k_collapse_aos3(const void* __restrict__ img, float* __restrict__ aos3, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float I, dx, dy;
+    if (HALF) {
+        uint2 v = reinterpret_cast<const uint2*>(img)[i];
+        __half2 a = *reinterpret_cast<__half2*>(&v.x), b = *reinterpret_cast<__half2*>(&v.y);
+        I = __low2float(a); dx = __high2float(a); dy = __low2float(b);
+    } else {
+        float4 v = reinterpret_cast<const float4*>(img)[i];
+        I = v.x; dx = v.y; dy = v.z;
+    }
+    aos3[3 * (size_t)i] = I; aos3[3 * (size_t)i + 1] = dx; aos3[3 * (size_t)i + 2] = dy;
+}
+
+static size_t texel_bytes(const cmlhip_ctx* c) { return c->lim.texel_format == CMLHIP_TEXEL_F16 ? 8 : 16; }
+
+static void free_level(PyrLevel& L) {
+    if (L.grad) hipFree(L.grad);
+    if (L.gray) hipFree(L.gray);
+    L = PyrLevel();
+}
+
+extern "C" {
+
+int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3, int w, int h) {
+    if (!c || !aos3 || level < 0 || level >= 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
+    Pyramid& P = c->pyr[id];
+    PyrLevel& L = P.lv[level];
+    hipStreamSynchronize(c->stream);
+    if (L.w != w || L.h != h) free_level(L);
+    size_t n = (size_t)w * h;
+    if (!L.grad) CML_CHECK(c, hipMalloc(&L.grad, n * texel_bytes(c)));
+    L.w = w; L.h = h;
+    if (level + 1 > P.levels) P.levels = level + 1;
+    float* tmp = nullptr;
+    CML_CHECK(c, hipMalloc((void**)&tmp, n * 3 * sizeof(float)));
+    int rc = cml_h2d(c, tmp, aos3, n * 3 * sizeof(float));
+    if (rc) { hipFree(tmp); return rc; }
+    int blocks = cml_div_up((int)n, 256);
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_expand_aos3<true><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
+    else k_expand_aos3<false><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
+    hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, int h, int levels) {
+    if (!c || !gray || levels < 1 || levels > 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
+    Pyramid& P = c->pyr[id];
+    hipStreamSynchronize(c->stream);
+    for (int l = 0; l < 8; l++) free_level(P.lv[l]);
+    P.levels = levels;
+    int cw = w, ch = h;
+    for (int l = 0; l < levels; l++) {
+        PyrLevel& L = P.lv[l];
+        L.w = cw; L.h = ch;
+        size_t n = (size_t)cw * ch;
+        CML_CHECK(c, hipMalloc((void**)&L.gray, n * sizeof(float)));
+        CML_CHECK(c, hipMalloc(&L.grad, n * texel_bytes(c)));
+        if (l == 0) {
+            int rc = cml_h2d(c, L.gray, gray, n * sizeof(float));
+            if (rc) return rc;
+        } else {
+            const PyrLevel& U = P.lv[l - 1];
+            dim3 g(cml_div_up(cw, 256), ch);
+            k_reduce_by_two<<<g, 256, 0, c->stream>>>(U.gray, U.w, U.h, L.gray);
+        }
+        dim3 g(cml_div_up(cw, 256), ch);
+        if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_gradient<true><<<g, 256, 0, c->stream>>>(L.gray, cw, ch, L.grad);
+        else k_gradient<false><<<g, 256, 0, c->stream>>>(L.gray, cw, ch, L.grad);
+        cw /= 2; ch /= 2;      // == (int)(w / 2^l) of CaptureImage.cpp:39-78 (floor of a floor)
+        if (cw < 1 || ch < 1) { P.levels = l + 1; break; }
+    }
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    auto it = c->pyr.find(id);
+    if (it == c->pyr.end()) return CMLHIP_ERR_NOT_FOUND;
+    hipStreamSynchronize(c->stream);
+    for (int l = 0; l < 8; l++) free_level(it->second.lv[l]);
+    c->pyr.erase(it);
+    return CMLHIP_OK;
+}
+
+int cmlhip_pyramid_level_size(cmlhip_ctx* c, uint64_t id, int level, int* w, int* h) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    const Pyramid* P = cml_find_pyr(c, id);
+    if (!P || level < 0 || level >= P->levels || !P->lv[level].grad) return CMLHIP_ERR_NOT_FOUND;
+    if (w) *w = P->lv[level].w;
+    if (h) *h = P->lv[level].h;
+    return CMLHIP_OK;
+}
+
+int cmlhip_pyramid_get(cmlhip_ctx* c, uint64_t id, int level, float* out) {
+    if (!c || !out) return CMLHIP_ERR_INVALID;
+    const Pyramid* P = cml_find_pyr(c, id);
+    if (!P || level < 0 || level >= P->levels || !P->lv[level].grad) return CMLHIP_ERR_NOT_FOUND;
+    const PyrLevel& L = P->lv[level];
+    size_t n = (size_t)L.w * L.h;
+    float* tmp = nullptr;
+    CML_CHECK(c, hipMalloc((void**)&tmp, n * 3 * sizeof(float)));
+    int blocks = cml_div_up((int)n, 256);
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_collapse_aos3<true><<<blocks, 256, 0, c->stream>>>(L.grad, tmp, (int)n);
+    else k_collapse_aos3<false><<<blocks, 256, 0, c->stream>>>(L.grad, tmp, (int)n);
+    int rc = cml_d2h(c, out, tmp, n * 3 * sizeof(float));
+    hipFree(tmp);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// cmlhip_internal.h — shared declarations of the gfx950 device layer behind include/cmlhip.h.
+// MI355X only: wave = 64 lanes, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/cmlhip.h"
+
+#define CML_WAVE 64
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PyrLevel {
+    int w = 0, h = 0;
+    void* grad = nullptr;   // float4 {I,dx,dy,0} (or 4 halves) per texel, x fastest
+    float* gray = nullptr;  // may be null when only the gradient image was put
+};
+struct Pyramid {
+    int levels = 0;
+    PyrLevel lv[8];
+};
+
+// per-frame device descriptor used by the BA kernels
+struct FrameDev {
+    const void* grad0;      // level-0 gradient image of the frame
+    float frame_energy_th;
+    float b0;
+};
+
+struct cmlhip_ctx {
+    cmlhip_limits lim{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::string err;
+    std::unordered_map<uint64_t, Pyramid> pyr;
+    void* pinned = nullptr;       // pinned host staging (readbacks / small uploads)
+    size_t pinned_bytes = 0;
+
+    // ---------------- BA window
+    cmlhip_ba_params ba_prm{};
+    bool ba_prm_set = false, ba_uploaded = false, ba_pairs_set = false;
+    int N = 0, P = 0, R = 0, n_lin = 0, n_newframe = 0;
+    std::vector<int> h_pair_of, h_by_point_off, h_by_point, h_by_pair_off, h_by_pair;
+    DevBuf frames, pairs;                                     // FrameDev[N], cmlhip_ba_pair[N*N]
+    DevBuf pt_x, pt_y, pt_idepth, pt_idepth_zero, pt_prior, pt_host, pt_colors, pt_weights, pt_backup;
+    DevBuf pt_acc;                                            // P x 16 floats: HddA bdA HcdA[4] HddL bdL HcdL[4] HdiF bdSum pad pad
+    DevBuf pt_step;                                           // P doubles
+    DevBuf r_point, r_target, r_state, r_new_state, r_energy, r_new_energy, r_new_energy_wo, r_ret_energy;
+    DevBuf r_good, r_lin, r_sel, r_center, r_jpjdf, r_rtz, rj[2];
+    DevBuf by_point_off, by_point, by_pair_off, by_pair, newframe_res;
+    DevBuf acc_pair[2];                                       // N*N x 96 floats (91 used) ACTIVE / LINEARIZED
+    DevBuf acc_num[2];                                        // N*N ints
+    DevBuf pair_blocks;                                       // N*N x PAIR_BLK doubles (stitched per-pair blocks)
+    DevBuf adH, adT, adHTd, vec_small;                        // adjoints, adHTdeltaF, {cdelta,cprior,prior,delta_prior}
+    DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec;            // (8N+4)^2 / (8N+4) doubles
+    DevBuf G;                                                 // P x ldg doubles (Schur rows [g | bdSum])
+    DevBuf syrk_part;                                         // partial SYRK tiles
+    DevBuf scal;                                              // small scalar scratch (energy partials, counters, th)
+    DevBuf lin_partial;                                       // per-block energy / count partials
+    // ---------------- tracker
+    DevBuf trk_ref[8]; int trk_n[8] = {0}; int trk_last_n = 0;                    // per-level uvic lists
+    DevBuf trk_warped;                                        // n x 8 floats + flag
+    DevBuf trk_partial, trk_out;
+    DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt;      // makeCoarseDepth scratch
+    // ---------------- reproj
+    DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x;
+};
+
+#define CML_CHECK(ctx, call)                                                                      \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return CMLHIP_ERR_HIP;                                                                \
+        }                                                                                         \
+    } while (0)
+
+#define CML_REQUIRE(ctx, cond, code, msg)                                                         \
+    do {                                                                                          \
+        if (!(cond)) { (ctx)->err = (msg); return (code); }                                       \
+    } while (0)
+
+int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes);          // grow-only device allocation
+void cml_free(DevBuf& b);
+int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // async on ctx stream via pinned staging
+int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // sync readback
+const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id);
+
+static inline int cml_div_up(int a, int b) { return (a + b - 1) / b; }

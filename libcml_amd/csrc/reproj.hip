@@ -1,0 +1,312 @@
+// reproj.hip — hybrid ORB term: reprojection Jacobian accumulation into the pose system.
+// Replaces DSOBundleAdjustment::addIndirectToProblem's accumulation (BA.cpp:2607-2700) and
+// ReprojectionError::jacobian (src/cml/optimization/Residual.h:59-100, src/cml/map/Camera.h:317-386,
+// src/cml/maths/Derivative.h:28-116, src/cml/maths/Rotation.cpp:205-290).
+//
+// The reference builds a sparse J of size (6N+3M) x (N*M), forms the DENSE H = J J^T ((6N+3M)^2 doubles, tens of
+// MB) and then keeps only the 6N x 6N pose block.  Each column of J touches one frame and one point, so that pose
+// block is block-diagonal: M6[i,i] = sum_j f_ij f_ij^T.  Here each observation is one lane; the 21+6 unique sums
+// per frame are reduced in LDS per workgroup and added to global with fp64 atomics.  All arithmetic is fp64.
+#include "cmlhip_internal.h"
+
+struct FramePre { double q[4]; double D[42]; };      // CML quaternion (w,x,y,z) of R, and Dx_exp_x(log(T)) 7x6
+
+__device__ void d_hat(const double w[3], double O[9]) {
+    O[0] = 0; O[1] = -w[2]; O[2] = w[1]; O[3] = w[2]; O[4] = 0; O[5] = -w[0]; O[6] = -w[1]; O[7] = w[0]; O[8] = 0;
+}
+__device__ void d_mm3(const double A[9], const double B[9], double C[9]) {
+    double r[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    for (int i = 0; i < 9; i++) C[i] = r[i];
+}
+__device__ void d_mv3(const double A[9], const double v[3], double o[3]) {
+    double r[3];
+    for (int i = 0; i < 3; i++) r[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+}
+
+// SE3(R,t).log() — rotation matrix -> unit quaternion (Shoemake) -> atan-based log, then V^-1 t (Sophus 1.1.0 semantics)
+__device__ void d_se3_log(const double R[9], const double t[3], double xi[6]) {
+    double q[4];
+    double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        double s = sqrt(tr + 1.0);
+        q[0] = 0.5 * s; s = 0.5 / s;
+        q[1] = (R[7] - R[5]) * s; q[2] = (R[2] - R[6]) * s; q[3] = (R[3] - R[1]) * s;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        q[1 + i] = 0.5 * s; s = 0.5 / s;
+        q[0] = (R[k * 3 + j] - R[j * 3 + k]) * s;
+        q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) * s;
+        q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+    }
+    const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= nq;
+    const double eps = 1e-10;
+    const double sq = q[1] * q[1] + q[2] * q[2] + q[3] * q[3], w = q[0];
+    double f, theta;
+    if (sq < eps * eps) {
+        f = 2.0 / w - (2.0 / 3.0) * sq / (w * w * w);
+        theta = 2.0 * sq / w;
+    } else {
+        const double n = sqrt(sq);
+        const double at = (w < 0) ? atan2(-n, -w) : atan2(n, w);
+        f = 2.0 * at / n;
+        theta = f * n;
+    }
+    const double om[3] = {f * q[1], f * q[2], f * q[3]};
+    double O[9], O2[9], Vi[9];
+    d_hat(om, O);
+    d_mm3(O, O, O2);
+    double c;
+    if (fabs(theta) < eps) c = 1.0 / 12.0;
+    else { const double ht = 0.5 * theta; c = (1.0 - theta * cos(ht) / (2.0 * sin(ht))) / (theta * theta); }
+    for (int i = 0; i < 9; i++) Vi[i] = ((i % 4 == 0) ? 1.0 : 0.0) - 0.5 * O[i] + c * O2[i];
+    d_mv3(Vi, t, xi);
+    xi[3] = om[0]; xi[4] = om[1]; xi[5] = om[2];
+}
+
+// d[qx qy qz qw tx ty tz]/d[upsilon omega] of SE3::exp (rows in Sophus parameter order), from the definitions
+// q = (cos(th/2), sin(th/2)/th w), t = V(w) u, V = I + B W + C W^2.
+__device__ void d_dx_exp_x(const double xi[6], double J[42]) {
+    const double* u = xi; const double* w = xi + 3;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    for (int i = 0; i < 42; i++) J[i] = 0;
+    if (th2 < 1e-10) {
+        J[0 * 6 + 3] = 0.5; J[1 * 6 + 4] = 0.5; J[2 * 6 + 5] = 0.5;
+        J[4 * 6 + 0] = 1; J[5 * 6 + 1] = 1; J[6 * 6 + 2] = 1;
+        const double ux = 0.5 * u[0], uy = 0.5 * u[1], uz = 0.5 * u[2];
+        J[4 * 6 + 4] = uz; J[4 * 6 + 5] = -uy; J[5 * 6 + 3] = -uz; J[5 * 6 + 5] = ux; J[6 * 6 + 3] = uy; J[6 * 6 + 4] = -ux;
+        return;
+    }
+    const double th = sqrt(th2), hth = 0.5 * th;
+    const double a = sin(hth) / th, c = cos(hth), da = (0.5 * c - a) / th;
+    for (int j = 0; j < 3; j++) {
+        for (int i = 0; i < 3; i++) J[i * 6 + 3 + j] = (i == j ? a : 0.0) + w[i] * w[j] * da / th;
+        J[3 * 6 + 3 + j] = -0.5 * a * w[j];
+    }
+    const double B = (1.0 - cos(th)) / th2, C = (th - sin(th)) / (th2 * th);
+    const double dB = (th * sin(th) - 2.0 * (1.0 - cos(th))) / (th2 * th);
+    const double dC = ((1.0 - cos(th)) * th - 3.0 * (th - sin(th))) / (th2 * th2);
+    double W[9], W2[9];
+    d_hat(w, W);
+    d_mm3(W, W, W2);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[(4 + i) * 6 + j] = ((i == j) ? 1.0 : 0.0) + B * W[i * 3 + j] + C * W2[i * 3 + j];
+    for (int j = 0; j < 3; j++) {
+        double e[3] = {0, 0, 0}, G[9], GW[9], WG[9], dV[9], dt[3];
+        e[j] = 1;
+        d_hat(e, G);
+        d_mm3(G, W, GW);
+        d_mm3(W, G, WG);
+        for (int i = 0; i < 9; i++) dV[i] = dB * (w[j] / th) * W[i] + B * G[i] + dC * (w[j] / th) * W2[i] + C * (GW[i] + WG[i]);
+        d_mv3(dV, u, dt);
+        for (int i = 0; i < 3; i++) J[(4 + i) * 6 + 3 + j] = dt[i];
+    }
+}
+
+__global__ void k_reproj_frames(int N, const double* __restrict__ poses, FramePre* __restrict__ pre) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double* R = poses + 12 * (size_t)i; const double* t = R + 9;
+    // Quaternion::logHati + normalise, Rotation.cpp:205-221, Rotation.h:246-252
+    double q[4];
+    q[0] = sqrt(fmax(0.0, 1.0 + R[0] + R[4] + R[8])) / 2.0;
+    q[1] = sqrt(fmax(0.0, 1.0 + R[0] - R[4] - R[8])) / 2.0;
+    q[2] = sqrt(fmax(0.0, 1.0 - R[0] + R[4] - R[8])) / 2.0;
+    q[3] = sqrt(fmax(0.0, 1.0 - R[0] - R[4] + R[8])) / 2.0;
+    q[1] = copysign(q[1], R[7] - R[5]); q[2] = copysign(q[2], R[2] - R[6]); q[3] = copysign(q[3], R[3] - R[1]);
+    const double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; k++) pre[i].q[k] = q[k] / nn;
+    double xi[6];
+    d_se3_log(R, t, xi);                // BA.cpp:2621-2622
+    d_dx_exp_x(xi, pre[i].D);           // BA.cpp:2623
+}
+
+__device__ __forceinline__ double d_tukey(double v, double th) {            // Derivative.h:35-39
+    if (fabs(v) > th) return 0;
+    const double l = 1.0 - (v * v) / (th * th);
+    return v * l * l;
+}
+__device__ __forceinline__ double d_dtukey(double v, double d, double th) { // Derivative.h:108-113 (v is the loss value, literal)
+    if (fabs(v) > th) return 0;
+    const double v2 = v * v, o = 1.0 - v2;
+    return d * (-4.0 * v2 * o + o * o);
+}
+
+#define RP_MAXN CMLHIP_MAX_FRAMES
+__global__ __launch_bounds__(256) void k_reproj_obs(int N, const double* __restrict__ poses, const FramePre* __restrict__ pre,
+                                                    const double* __restrict__ points, int n, const cmlhip_reproj_obs* __restrict__ obs,
+                                                    double fx, double fy, double* __restrict__ M6, double* __restrict__ b6,
+                                                    double* __restrict__ Jpoints, unsigned char* __restrict__ used) {
+    extern __shared__ double s_acc[];                 // N x 27 : 21 upper-tri of f f^T + 6 of f*res
+    for (int e = threadIdx.x; e < N * 27; e += blockDim.x) s_acc[e] = 0.0;
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const int i = obs[k].frame, j = obs[k].point;
+        const double* R = poses + 12 * (size_t)i; const double* t = R + 9; const double* X = points + 3 * (size_t)j;
+        double T[3];
+        for (int a = 0; a < 3; a++) T[a] = (R[a * 3] * X[0] + R[a * 3 + 1] * X[1] + R[a * 3 + 2] * X[2]) + t[a];
+        const double dx = T[0] / T[2] - obs[k].gx, dy = T[1] / T[2] - obs[k].gy;
+        const double norm = sqrt(dx * dx + dy * dy);
+        const double th = 3.0 / sqrt(fx * fx + fy * fy);
+        const double res = d_tukey(norm, th);
+        double cam[7], Jp[3];
+        bool ok = true;
+        for (int a = 0; a < 3; a++) {
+            const double d[3] = {R[a], R[3 + a], R[6 + a]};                                   // Camera.h:317-321: R e_a
+            const double hx = (d[0] * T[2] - T[0] * d[2]) / (T[2] * T[2]), hy = (d[1] * T[2] - T[1] * d[2]) / (T[2] * T[2]);
+            const double dsq = 2.0 * hx * dx + 2.0 * hy * dy;
+            double v = (norm == 0) ? 0 : dsq / (2.0 * norm);
+            v = d_dtukey(res, v, th);
+            ok = ok && isfinite(v);
+            cam[a] = v; Jp[a] = -v;
+        }
+        const double* q = pre[i].q;
+        const double Pt[3] = {X[0] + t[0], X[1] + t[1], X[2] + t[2]};                         // Camera.h:323-325: R'(q)_a (P + t)
+        for (int a = 0; a < 4; a++) {
+            const double qa = q[0], qb = q[1], qc = q[2], qd = q[3];
+            double _2b2 = 0, _2c2 = 0, _2d2 = 0, _2bc = 0, _2ad = 0, _2bd = 0, _2ac = 0, _2cd = 0, _2ab = 0;
+            if (a == 0) { _2ad = 2 * qd; _2ac = 2 * qc; _2ab = 2 * qb; }
+            else if (a == 1) { _2b2 = 4 * qb; _2bc = 2 * qc; _2bd = 2 * qd; _2ab = 2 * qa; }
+            else if (a == 2) { _2c2 = 4 * qc; _2bc = 2 * qb; _2ac = 2 * qa; _2cd = 2 * qd; }
+            else { _2d2 = 4 * qd; _2ad = 2 * qa; _2bd = 2 * qb; _2cd = 2 * qc; }
+            const double D[9] = {-_2c2 - _2d2, _2bc - _2ad, _2bd + _2ac, _2bc + _2ad, -_2b2 - _2d2, _2cd - _2ab,
+                                 _2bd - _2ac, _2cd + _2ab, -_2b2 - _2c2};
+            double d[3];
+            for (int b = 0; b < 3; b++) d[b] = D[b * 3] * Pt[0] + D[b * 3 + 1] * Pt[1] + D[b * 3 + 2] * Pt[2];
+            const double hx = (d[0] * T[2] - T[0] * d[2]) / (T[2] * T[2]), hy = (d[1] * T[2] - T[1] * d[2]) / (T[2] * T[2]);
+            const double dsq = 2.0 * hx * dx + 2.0 * hy * dy;
+            double v = (norm == 0) ? 0 : dsq / (2.0 * norm);
+            v = d_dtukey(res, v, th);
+            ok = ok && isfinite(v);
+            cam[3 + a] = v;
+        }
+        const bool use = ok && !(res > 4 * 4);                                               // BA.cpp:2630
+        if (used) used[k] = use ? 1 : 0;
+        if (use) {
+            double f[6];
+            for (int c = 0; c < 6; c++) {                                                     // BA.cpp:2641
+                double s = 0;
+                for (int r = 0; r < 7; r++) s += cam[r] * pre[i].D[r * 6 + c];
+                f[c] = s;
+            }
+            int idx = 0;
+            for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { atomicAdd(&s_acc[i * 27 + idx], f[a] * f[c]); idx++; }
+            for (int a = 0; a < 6; a++) atomicAdd(&s_acc[i * 27 + 21 + a], f[a] * res);       // BA.cpp:2655
+            if (Jpoints) for (int c = 0; c < 3; c++) atomicAdd(&Jpoints[3 * (size_t)j + c], Jp[c]);
+        }
+    }
+    __syncthreads();
+    const int m = 6 * N;
+    for (int e = threadIdx.x; e < N * 27; e += blockDim.x) {
+        const double v = s_acc[e];
+        if (v == 0.0) continue;
+        const int i = e / 27, r = e % 27;
+        if (r >= 21) { atomicAdd(&b6[6 * i + r - 21], v); continue; }
+        int a = 0, rem = r;
+        while (rem >= 6 - a) { rem -= 6 - a; a++; }
+        const int c = a + rem;
+        atomicAdd(&M6[(size_t)(6 * i + a) * m + 6 * i + c], v);
+        if (c != a) atomicAdd(&M6[(size_t)(6 * i + c) * m + 6 * i + a], v);
+    }
+}
+
+// indirectX = M.ldlt().solve(-bM) with M(i,i) *= (1+lambda) (BA.cpp:2695-2700); M is block diagonal, so one 6x6
+// diagonally-pivoted LDL^T per frame (Eigen LDLT.h:300-396 / :560-600 semantics incl. the zero-pivot rule).
+__global__ void k_reproj_solve(int N, double lambda, const double* __restrict__ M6, const double* __restrict__ b6, double* __restrict__ x6) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= N) return;
+    const int m = 6 * N;
+    double A[36], x[6];
+    int tr[6];
+    for (int i = 0; i < 6; i++) {
+        for (int j = 0; j < 6; j++) A[i * 6 + j] = M6[(size_t)(6 * f + i) * m + 6 * f + j];
+        A[i * 6 + i] *= (1 + lambda);
+        x[i] = -b6[6 * f + i];
+    }
+    for (int k = 0; k < 6; k++) {
+        int big = k; double best = fabs(A[k * 6 + k]);
+        for (int i = k + 1; i < 6; i++) if (fabs(A[i * 6 + i]) > best) { best = fabs(A[i * 6 + i]); big = i; }
+        tr[k] = big;
+        if (k != big) {
+            for (int j = 0; j < k; j++) { double t = A[k * 6 + j]; A[k * 6 + j] = A[big * 6 + j]; A[big * 6 + j] = t; }
+            for (int i = big + 1; i < 6; i++) { double t = A[i * 6 + k]; A[i * 6 + k] = A[i * 6 + big]; A[i * 6 + big] = t; }
+            { double t = A[k * 6 + k]; A[k * 6 + k] = A[big * 6 + big]; A[big * 6 + big] = t; }
+            for (int i = k + 1; i < big; i++) { double t = A[i * 6 + k]; A[i * 6 + k] = A[big * 6 + i]; A[big * 6 + i] = t; }
+        }
+        if (k > 0) {
+            double temp[6], s = 0;
+            for (int j = 0; j < k; j++) { temp[j] = A[j * 6 + j] * A[k * 6 + j]; s += A[k * 6 + j] * temp[j]; }
+            A[k * 6 + k] -= s;
+            for (int i = k + 1; i < 6; i++) {
+                double s2 = 0;
+                for (int j = 0; j < k; j++) s2 += A[i * 6 + j] * temp[j];
+                A[i * 6 + k] -= s2;
+            }
+        }
+        const double akk = A[k * 6 + k];
+        if (k == 0 && !(fabs(akk) > 0.0)) { for (int j = 0; j < 6; j++) tr[j] = j; break; }
+        if (fabs(akk) > 0.0) for (int i = k + 1; i < 6; i++) A[i * 6 + k] /= akk;
+    }
+    for (int k = 0; k < 6; k++) if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+    for (int i = 0; i < 6; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= A[i * 6 + j] * x[j]; x[i] = s; }
+    for (int i = 0; i < 6; i++) x[i] = (fabs(A[i * 6 + i]) > 2.2250738585072014e-308) ? x[i] / A[i * 6 + i] : 0.0;
+    for (int i = 5; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < 6; j++) s -= A[j * 6 + i] * x[j]; x[i] = s; }
+    for (int k = 5; k >= 0; k--) if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+    for (int i = 0; i < 6; i++) x6[6 * f + i] = x[i];
+}
+
+extern "C" {
+
+int cmlhip_reproj_accumulate(cmlhip_ctx* c, int N, const double* poses, int M, const double* points, int n,
+                             const cmlhip_reproj_obs* obs, double fx, double fy, double* M6, double* b6, double* Jpoints,
+                             unsigned char* used) {
+    if (!c || N < 1 || N > CMLHIP_MAX_FRAMES || M < 0 || n < 0 || !poses || (M > 0 && !points) || (n > 0 && !obs)) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, n <= c->lim.max_reproj_obs, CMLHIP_ERR_INVALID, "observations exceed max_reproj_obs");
+    for (int k = 0; k < n; k++)
+        CML_REQUIRE(c, obs[k].frame >= 0 && obs[k].frame < N && obs[k].point >= 0 && obs[k].point < M, CMLHIP_ERR_INVALID, "bad observation index");
+    const int m = 6 * N;
+    int rc;
+#define ENS(buf, bytes) if ((rc = cml_ensure(c, buf, (size_t)(bytes)))) return rc
+    ENS(c->rp_obs, sizeof(cmlhip_reproj_obs) * (size_t)(n ? n : 1)); ENS(c->rp_poses, 8 * 12 * (size_t)N + sizeof(FramePre) * (size_t)N);
+    ENS(c->rp_points, 8 * 3 * (size_t)(M ? M : 1)); ENS(c->rp_M, 8 * (size_t)m * m); ENS(c->rp_b, 8 * (size_t)m);
+    ENS(c->rp_Jp, 8 * 3 * (size_t)(M ? M : 1)); ENS(c->rp_used, (size_t)(n ? n : 1)); ENS(c->rp_x, 8 * (size_t)m);
+#undef ENS
+    if ((rc = cml_h2d(c, c->rp_poses.p, poses, 8 * 12 * (size_t)N))) return rc;
+    if (M && (rc = cml_h2d(c, c->rp_points.p, points, 8 * 3 * (size_t)M))) return rc;
+    if (n && (rc = cml_h2d(c, c->rp_obs.p, obs, sizeof(cmlhip_reproj_obs) * (size_t)n))) return rc;
+    CML_CHECK(c, hipMemsetAsync(c->rp_M.p, 0, 8 * (size_t)m * m, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->rp_b.p, 0, 8 * (size_t)m, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->rp_Jp.p, 0, 8 * 3 * (size_t)(M ? M : 1), c->stream));
+    FramePre* pre = reinterpret_cast<FramePre*>(c->rp_poses.as<double>() + 12 * (size_t)N);
+    k_reproj_frames<<<1, 64, 0, c->stream>>>(N, c->rp_poses.as<double>(), pre);
+    if (n > 0)
+        k_reproj_obs<<<cml_div_up(n, 256), 256, 27 * N * sizeof(double), c->stream>>>(N, c->rp_poses.as<double>(), pre, c->rp_points.as<double>(), n,
+                                                                                     c->rp_obs.as<cmlhip_reproj_obs>(), fx, fy, c->rp_M.as<double>(),
+                                                                                     c->rp_b.as<double>(), c->rp_Jp.as<double>(),
+                                                                                     c->rp_used.as<unsigned char>());
+    CML_CHECK(c, hipGetLastError());
+    if (M6 && (rc = cml_d2h(c, M6, c->rp_M.p, 8 * (size_t)m * m))) return rc;
+    if (b6 && (rc = cml_d2h(c, b6, c->rp_b.p, 8 * (size_t)m))) return rc;
+    if (Jpoints && M && (rc = cml_d2h(c, Jpoints, c->rp_Jp.p, 8 * 3 * (size_t)M))) return rc;
+    if (used && n && (rc = cml_d2h(c, used, c->rp_used.p, (size_t)n))) return rc;
+    return CMLHIP_OK;
+}
+
+int cmlhip_reproj_solve(cmlhip_ctx* c, int N, double lambda, double* x6) {
+    if (!c || N < 1 || N > CMLHIP_MAX_FRAMES || !x6) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, c->rp_M.p && c->rp_x.p, CMLHIP_ERR_STATE, "cmlhip_reproj_accumulate not called");
+    k_reproj_solve<<<1, 64, 0, c->stream>>>(N, lambda, c->rp_M.as<double>(), c->rp_b.as<double>(), c->rp_x.as<double>());
+    CML_CHECK(c, hipGetLastError());
+    int rc = cml_d2h(c, x6, c->rp_x.p, 8 * 6 * (size_t)N);
+    if (rc) return rc;
+    for (int i = 0; i < 6 * N; i++) if (!std::isfinite(x6[i])) return CMLHIP_ERR_NONFINITE;   // BA.cpp:2702-2704
+    return CMLHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,403 @@
+// tracker.hip — coarse photometric tracker on the device.
+// Replaces DSOTracker::computeResidual + computeHessian (TR.cpp:248-492, Accumulator9 ACC.h:1006-1211) and the
+// image-sized part of makeCoarseDepthL0 (TR.cpp:550-719).
+//
+// tracker_eval is ONE fused launch per LM iteration: warp + bilinear gather + Huber/cutoff + the 45 unique entries
+// of the weighted 9x9 JJ^T, reduced with wave shuffles, one LDS hop, one fp32 partial row per workgroup, and a
+// last-block finish (agent-scope release/acquire, MI355X per-XCD L2s) — so the host gets E, counts, flow and the
+// scaled 8x8 system from a single readback.  The reference's compaction into the warped buffer is unnecessary
+// here (the Hessian is accumulated where the residual is computed); the per-point warped record is still
+// written, uncompacted, for parity tests and for callers that want it.
+#include "cmlhip_internal.h"
+
+#pragma clang fp contract(off)
+
+struct TrkArgs {
+    const void* img; int w, h, level, n, want_h, half;
+    const float* uvic;
+    float RKi[9], Ki[9], t[3], fxl, fyl, cxl, cyl, a0, a1;
+    float fxh, fyh, b0, a_h;                 // computeHessian constants (TR.cpp:426-429)
+    float maxEnergy; double huber_d, cutoff_d, cutoff_base_d;
+    float* warped;                           // n x 8 floats {idepth,u,v,dx,dy,residual,weight,refcolor}
+    unsigned char* flag;                     // n: 1 = written to the warped buffer
+    float* partial;                          // gridDim x TRK_NRED
+    unsigned* counter;
+    float* out;                              // TRK_NRED floats (final sums)
+};
+#define TRK_NRED 56   // 45 (H upper) + E + sT + sRT + sN + numTerms + numSat + numRobust + numWarped + pad(3)
+
+template <bool HALF>
+__device__ __forceinline__ float4 trk_texel(const void* img, size_t i) {
+    if (HALF) {
+        uint2 v = reinterpret_cast<const uint2*>(img)[i];
+        __half2 a = *reinterpret_cast<__half2*>(&v.x), b = *reinterpret_cast<__half2*>(&v.y);
+        return make_float4(__low2float(a), __high2float(a), __low2float(b), 0.f);
+    }
+    return reinterpret_cast<const float4*>(img)[i];
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
+    __shared__ float s_red[4][TRK_NRED];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    float v[TRK_NRED];
+#pragma unroll
+    for (int k = 0; k < TRK_NRED; k++) v[k] = 0.f;
+    if (i < A.n) {
+        const float x = A.uvic[4 * (size_t)i], y = A.uvic[4 * (size_t)i + 1], id = A.uvic[4 * (size_t)i + 2], refColor = A.uvic[4 * (size_t)i + 3];
+        bool wrote = false;
+        if (isfinite(refColor)) {                                           // TR.cpp:301-303
+            float pt[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) pt[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) + A.t[k] * id;
+            const float u = pt[0] / pt[2], vv = pt[1] / pt[2];
+            const float Ku = A.fxl * u + A.cxl, Kv = A.fyl * vv + A.cyl;
+            const float new_idepth = id / pt[2];
+            if (A.level == 0 && (i % 32) == 0) {                           // flow statistic, TR.cpp:313-344
+                float a[3], b[3], c[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float kp = (A.Ki[k * 3] * x + A.Ki[k * 3 + 1] * y) + A.Ki[k * 3 + 2] * 1.0f;
+                    a[k] = kp + A.t[k] * id; b[k] = kp - A.t[k] * id;
+                    c[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) - A.t[k] * id;
+                }
+                const float KuT = A.fxl * (a[0] / a[2]) + A.cxl, KvT = A.fyl * (a[1] / a[2]) + A.cyl;
+                const float KuT2 = A.fxl * (b[0] / b[2]) + A.cxl, KvT2 = A.fyl * (b[1] / b[2]) + A.cyl;
+                const float Ku3 = A.fxl * (c[0] / c[2]) + A.cxl, Kv3 = A.fyl * (c[1] / c[2]) + A.cyl;
+                float sT = 0, sRT = 0;
+                sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+                sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+                sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+                sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+                v[46] = sT; v[47] = sRT; v[48] = 2.f;
+            }
+            if (Ku > 2 && Kv > 2 && Ku < A.w - 3 && Kv < A.h - 3 && new_idepth > 0) {     // TR.cpp:346
+                const int ix = (int)Ku, iy = (int)Kv;
+                const float dx = Ku - (float)ix, dy = Kv - (float)iy, dxdy = dx * dy;
+                const float w00 = 1 - dx - dy + dxdy, w01 = dx - dxdy, w10 = dy - dxdy, w11 = dxdy;
+                const size_t i1 = (size_t)iy * A.w + ix;
+                const float4 ta = trk_texel<HALF>(A.img, i1), tb = trk_texel<HALF>(A.img, i1 + 1);
+                const float4 tc = trk_texel<HALF>(A.img, i1 + A.w), td = trk_texel<HALF>(A.img, i1 + A.w + 1);
+                const float h0 = ta.x * w00 + tb.x * w01 + tc.x * w10 + td.x * w11;
+                const float h1 = ta.y * w00 + tb.y * w01 + tc.y * w10 + td.y * w11;
+                const float h2 = ta.z * w00 + tb.z * w01 + tc.z * w10 + td.z * w11;
+                if (isfinite(h0) && isfinite(h1) && isfinite(h2)) {
+                    const float residual = h0 - (float)(A.a0 * refColor + A.a1);
+                    const float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / fabs((double)residual));
+                    if (fabs((double)residual) > A.cutoff_d) {
+                        v[45] = A.maxEnergy; v[49] = 1.f; v[50] = 1.f;
+                    } else {
+                        v[45] = hw * residual * residual * (2 - hw); v[49] = 1.f; v[52] = 1.f;
+                        wrote = true;
+                        float* W = A.warped + 8 * (size_t)i;
+                        W[0] = new_idepth; W[1] = u; W[2] = vv; W[3] = h1; W[4] = h2; W[5] = residual; W[6] = hw; W[7] = refColor;
+                        if (A.want_h) {                                       // computeHessian lanes, TR.cpp:443-470
+                            const float ddx = h1 * A.fxh, ddy = h2 * A.fyh;
+                            float J[9];
+                            J[0] = new_idepth * ddx;
+                            J[1] = new_idepth * ddy;
+                            J[2] = 0.0f - (new_idepth * (u * ddx + vv * ddy));
+                            J[3] = 0.0f - ((u * vv * ddx) + ddy * (1.0f + vv * vv));
+                            J[4] = (u * vv * ddy) + (ddx * (1.0f + u * u));
+                            J[5] = u * ddy - vv * ddx;
+                            J[6] = A.a_h * (A.b0 - refColor);
+                            J[7] = -1.0f;
+                            J[8] = residual;
+                            int idx = 0;
+#pragma unroll
+                            for (int r = 0; r < 9; r++) {
+                                const float Jw = J[r] * hw;
+#pragma unroll
+                                for (int c = r; c < 9; c++) { v[idx] = Jw * J[c]; idx++; }
+                            }
+                        }
+                    }
+                    if (fabs((double)residual) <= A.cutoff_base_d) v[51] = 1.f;
+                }
+            }
+        }
+        A.flag[i] = wrote ? 1 : 0;
+    }
+    // ---- block reduction: wave shuffles, then one LDS hop
+    const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll
+    for (int k = 0; k < TRK_NRED; k++) {
+        float s = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (ln == 0) s_red[wv][k] = s;
+    }
+    __syncthreads();
+    if (tid < TRK_NRED) A.partial[(size_t)blockIdx.x * TRK_NRED + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    // ---- last-block finish (agent-scope publish: per-XCD L2s are not coherent)
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_last && tid < TRK_NRED) {
+        double s = 0;                                     // fixed block order, fp64 combine of the fp32 block sums
+        for (unsigned b = 0; b < gridDim.x; b++) s += (double)A.partial[(size_t)b * TRK_NRED + tid];
+        A.out[tid] = (float)s;
+        if (tid == 0) *A.counter = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ makeCoarseDepthL0
+__global__ void k_cd_splat(const double* __restrict__ pts, int n, int w0, int h0, float* idepth, float* wsum) {   // TR.cpp:538-551
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double Ku = pts[4 * (size_t)i], Kv = pts[4 * (size_t)i + 1], nid = pts[4 * (size_t)i + 2];
+    const float weight = (float)pts[4 * (size_t)i + 3];
+    const int u = (int)(Ku + 0.5), v = (int)(Kv + 0.5);
+    if (u < 0 || u >= w0 || v < 0 || v >= h0) return;
+    atomicAdd(&idepth[u + w0 * v], (float)(nid * (double)weight));
+    atomicAdd(&wsum[u + w0 * v], weight);
+}
+__global__ void k_cd_down(const float* __restrict__ idm, const float* __restrict__ wm, int wm1, int wl, int hl,
+                          float* __restrict__ idl, float* __restrict__ wsl) {                                      // TR.cpp:571-584
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wl || y >= hl) return;
+    const int b = 2 * x + 2 * y * wm1;
+    idl[x + y * wl] = ((idm[b] + idm[b + 1]) + idm[b + wm1]) + idm[b + wm1 + 1];
+    wsl[x + y * wl] = ((wm[b] + wm[b + 1]) + wm[b + wm1]) + wm[b + wm1 + 1];
+}
+// dilation, TR.cpp:589-665: reads only cells with weightSumBak > 0, writes only cells with weightSumBak <= 0
+__global__ void k_cd_dilate(float* idepth, float* wsum, const float* __restrict__ wbak, int wl, int hl, int diag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + wl;
+    const int wh = wl * hl - wl, size = wl * hl;
+    if (i >= wh) return;
+    if (wbak[i] > 0) return;
+    int d[4];
+    if (diag) { d[0] = 1 + wl; d[1] = -1 - wl; d[2] = wl - 1; d[3] = -wl + 1; }
+    else { d[0] = 1; d[1] = -1; d[2] = wl; d[3] = -wl; }
+    float sum = 0, num = 0, numn = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = i + d[k];
+        if (j >= 0 && j < size && wbak[j] > 0) { sum += idepth[j]; num += wbak[j]; numn++; }
+    }
+    if (numn > 0) { idepth[i] = sum / numn; wsum[i] = num / numn; }
+}
+// normalise + ordered compaction (raster order of TR.cpp:688-716), 3 passes: count / scan / scatter
+__device__ __forceinline__ bool cd_valid(const float* idepth, const float* wsum, const float* gray, int wl, int hl, int i, float& id, float& col) {
+    const int x = i % wl, y = i / wl;
+    if (x < 2 || y < 2 || x >= wl - 2 || y >= hl - 2) return false;
+    if (!(wsum[i] > 0)) return false;
+    id = idepth[i] / wsum[i];
+    col = gray[i];
+    return isfinite(col) && (id > 0);
+}
+__global__ __launch_bounds__(1024) void k_cd_count(const float* idepth, const float* wsum, const float* gray, int wl, int hl, int* counts) {
+    __shared__ int s[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    float id, col;
+    const bool ok = (i < wl * hl) && cd_valid(idepth, wsum, gray, wl, hl, i, id, col);
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; k++) t += s[k]; counts[blockIdx.x] = t; }
+}
+__global__ void k_cd_scan(int* counts, int nb, int* total) {      // single thread: nb <= a few thousand
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < nb; b++) { const int c = counts[b]; counts[b] = acc; acc += c; }
+        *total = acc;
+    }
+}
+__global__ __launch_bounds__(1024) void k_cd_scatter(const float* idepth, const float* wsum, const float* gray, int wl, int hl,
+                                                     const int* offs, float* uvic) {
+    __shared__ int s[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    float id = 0, col = 0;
+    const bool ok = (i < wl * hl) && cd_valid(idepth, wsum, gray, wl, hl, i, id, col);
+    const unsigned long long m = __ballot(ok);
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (ln == 0) s[wv] = __popcll(m);
+    __syncthreads();
+    int base = offs[blockIdx.x];
+    for (int k = 0; k < wv; k++) base += s[k];
+    if (ok) {
+        const int pos = base + __popcll(m & ((1ull << ln) - 1ull));
+        uvic[4 * (size_t)pos] = (float)(i % wl); uvic[4 * (size_t)pos + 1] = (float)(i / wl);
+        uvic[4 * (size_t)pos + 2] = id; uvic[4 * (size_t)pos + 3] = col;
+    }
+}
+
+// Eigen compute_inverse_size3 (cofactors * 1/det) in float, as Matrix33f::inverse() at TR.cpp:261
+static void inv3f(const float m[9], float o[9]) {
+#define MM(i, j) m[(i) * 3 + (j)]
+#define COF(i, j) (MM(((i) + 1) % 3, ((j) + 1) % 3) * MM(((i) + 2) % 3, ((j) + 2) % 3) - MM(((i) + 1) % 3, ((j) + 2) % 3) * MM(((i) + 2) % 3, ((j) + 1) % 3))
+    const float c0 = COF(0, 0), c1 = COF(1, 0), c2 = COF(2, 0);
+    const float det = (c0 * MM(0, 0) + c1 * MM(1, 0)) + c2 * MM(2, 0);
+    const float invdet = 1.0f / det;
+    o[0] = c0 * invdet; o[1] = c1 * invdet; o[2] = c2 * invdet;
+    o[3] = COF(0, 1) * invdet; o[4] = COF(1, 1) * invdet; o[5] = COF(2, 1) * invdet;
+    o[6] = COF(0, 2) * invdet; o[7] = COF(1, 2) * invdet; o[8] = COF(2, 2) * invdet;
+#undef COF
+#undef MM
+}
+
+extern "C" {
+
+int cmlhip_tracker_set_reference(cmlhip_ctx* c, int level, const float* uvic, int n) {
+    if (!c || level < 0 || level >= 8 || n < 0 || (n > 0 && !uvic)) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, n <= c->lim.max_tracker_points, CMLHIP_ERR_INVALID, "tracker list exceeds max_tracker_points");
+    int rc = cml_ensure(c, c->trk_ref[level], 16 * (size_t)(n ? n : 1));
+    if (rc) return rc;
+    if ((rc = cml_h2d(c, c->trk_ref[level].p, uvic, 16 * (size_t)n))) return rc;
+    c->trk_n[level] = n;
+    return CMLHIP_OK;
+}
+
+int cmlhip_tracker_get_reference(cmlhip_ctx* c, int level, float* out, int* n_out) {
+    if (!c || level < 0 || level >= 8) return CMLHIP_ERR_INVALID;
+    if (n_out) *n_out = c->trk_n[level];
+    if (out && c->trk_n[level] > 0) return cml_d2h(c, out, c->trk_ref[level].p, 16 * (size_t)c->trk_n[level]);
+    return CMLHIP_OK;
+}
+
+int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const double R[9], const double t[3], const double K[4],
+                        const double aff[2], double b0, const cmlhip_tracker_params* prm, int want_hessian,
+                        cmlhip_tracker_result* out) {
+    if (!c || !R || !t || !K || !aff || !prm || !out || level < 0 || level >= 8) return CMLHIP_ERR_INVALID;
+    const Pyramid* py = cml_find_pyr(c, image_id);
+    CML_REQUIRE(c, py && level < py->levels && py->lv[level].grad, CMLHIP_ERR_NOT_FOUND, "tracker image/level not in the pyramid cache");
+    const int n = c->trk_n[level];
+    TrkArgs A;
+    memset(&A, 0, sizeof A);
+    A.img = py->lv[level].grad; A.w = py->lv[level].w; A.h = py->lv[level].h; A.level = level; A.n = n; A.want_h = want_hessian;
+    A.uvic = c->trk_ref[level].as<float>();
+    // host-side constants exactly as TR.cpp:260-278,426-429 forms them (float)
+    float Kf[9] = {(float)K[0], 0, (float)K[2], 0, (float)K[1], (float)K[3], 0, 0, 1}, Rf[9];
+    inv3f(Kf, A.Ki);
+    for (int i = 0; i < 9; i++) Rf[i] = (float)R[i];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) A.RKi[i * 3 + j] = (Rf[i * 3] * A.Ki[j] + Rf[i * 3 + 1] * A.Ki[3 + j]) + Rf[i * 3 + 2] * A.Ki[6 + j];
+    for (int i = 0; i < 3; i++) A.t[i] = (float)t[i];
+    A.fxl = Kf[0]; A.fyl = Kf[4]; A.cxl = Kf[2]; A.cyl = Kf[5];
+    A.a0 = (float)aff[0]; A.a1 = (float)aff[1];
+    A.fxh = (float)K[0]; A.fyh = (float)K[1]; A.b0 = (float)b0; A.a_h = (float)aff[0];
+    A.huber_d = (double)prm->huber; A.cutoff_d = (double)prm->cutoff; A.cutoff_base_d = (double)prm->cutoff_base;
+    A.maxEnergy = (float)(2.0f * A.huber_d * A.cutoff_d - A.huber_d * A.huber_d);
+    const int blocks = cml_div_up(n > 0 ? n : 1, 256);
+    int rc;
+    if ((rc = cml_ensure(c, c->trk_warped, (size_t)(n ? n : 1) * 36))) return rc;
+    if ((rc = cml_ensure(c, c->trk_partial, (size_t)blocks * TRK_NRED * 4))) return rc;
+    if ((rc = cml_ensure(c, c->trk_out, 1024))) return rc;
+    A.warped = c->trk_warped.as<float>();
+    A.flag = reinterpret_cast<unsigned char*>(c->trk_warped.as<float>() + 8 * (size_t)(n ? n : 1));
+    A.partial = c->trk_partial.as<float>();
+    A.out = c->trk_out.as<float>();
+    A.counter = reinterpret_cast<unsigned*>(c->trk_out.as<float>() + 64);
+    if (!c->trk_out.bytes) return CMLHIP_ERR_HIP;
+    c->trk_last_n = n;
+    CML_CHECK(c, hipMemsetAsync(A.counter, 0, sizeof(unsigned), c->stream));
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_tracker_eval<true><<<blocks, 256, 0, c->stream>>>(A);
+    else k_tracker_eval<false><<<blocks, 256, 0, c->stream>>>(A);
+    CML_CHECK(c, hipGetLastError());
+    float s[TRK_NRED];
+    if ((rc = cml_d2h(c, s, c->trk_out.p, sizeof s))) return rc;
+    memset(out, 0, sizeof *out);
+    out->E = s[45]; out->numTermsInE = (int)s[49]; out->numSaturated = (int)s[50]; out->numRobust = (int)s[51]; out->numWarped = (int)s[52];
+    out->flow[0] = s[46] / (s[48] + 0.1f); out->flow[1] = 0; out->flow[2] = s[47] / (s[48] + 0.1f);       // TR.cpp:412-414
+    if (want_hessian) {
+        int idx = 0;
+        for (int r = 0; r < 9; r++) for (int cc = r; cc < 9; cc++) { out->H9[r * 9 + cc] = out->H9[cc * 9 + r] = s[idx]; idx++; }
+        int npad = out->numWarped;
+        while (npad % 4 != 0) npad++;                                                                       // TR.cpp:391-403,436
+        const double sc[8] = {prm->scale_rot, prm->scale_rot, prm->scale_rot, prm->scale_trans, prm->scale_trans, prm->scale_trans,
+                              prm->scale_a, prm->scale_b};                                                  // TR.cpp:477-488 (literal lane/scale pairing)
+        for (int r = 0; r < 8; r++) {
+            for (int cc = 0; cc < 8; cc++) out->H[r * 8 + cc] = ((double)out->H9[r * 9 + cc] / (double)npad) * sc[cc] * sc[r];
+            out->b[r] = ((double)out->H9[r * 9 + 8] / (double)npad) * sc[r];
+        }
+        for (int k = 0; k < 64; k++) if (!std::isfinite(out->H[k])) return CMLHIP_ERR_NONFINITE;
+    }
+    return CMLHIP_OK;
+}
+
+int cmlhip_tracker_get_warped(cmlhip_ctx* c, float* out, int capacity, int* n_out) {
+    if (!c || !out || capacity < 0) return CMLHIP_ERR_INVALID;
+    const int n = c->trk_last_n;
+    if (n_out) *n_out = 0;
+    if (n == 0) return CMLHIP_OK;
+    std::vector<float> w(8 * (size_t)n);
+    std::vector<unsigned char> f(n);
+    int rc;
+    if ((rc = cml_d2h(c, w.data(), c->trk_warped.p, 32 * (size_t)n))) return rc;
+    if ((rc = cml_d2h(c, f.data(), c->trk_warped.as<float>() + 8 * (size_t)n, (size_t)n))) return rc;
+    int m = 0;                                  // compaction in reference-list order (TR.cpp:372-380)
+    for (int i = 0; i < n; i++) {
+        if (!f[i]) continue;
+        if (m < capacity) for (int k = 0; k < 8; k++) out[(size_t)k * capacity + m] = w[8 * (size_t)i + k];
+        m++;
+    }
+    if (n_out) *n_out = m;
+    return CMLHIP_OK;
+}
+
+int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int levels, const double* pts, int n, int* n_out) {
+    if (!c || levels < 1 || levels > 8 || n < 0 || (n > 0 && !pts) || !n_out) return CMLHIP_ERR_INVALID;
+    const Pyramid* py = cml_find_pyr(c, ref_image_id);
+    CML_REQUIRE(c, py && py->levels >= levels && py->lv[0].gray, CMLHIP_ERR_NOT_FOUND, "reference pyramid (with gray levels) not cached");
+    int rc;
+    int maxblocks = 1;
+    for (int l = 0; l < levels; l++) {
+        const size_t sz = (size_t)py->lv[l].w * py->lv[l].h;
+        if ((rc = cml_ensure(c, c->cd_idepth[l], 4 * sz))) return rc;
+        if ((rc = cml_ensure(c, c->cd_wsum[l], 4 * sz))) return rc;
+        if ((rc = cml_ensure(c, c->cd_wbak[l], 4 * sz))) return rc;
+        if ((rc = cml_ensure(c, c->trk_ref[l], 16 * sz))) return rc;
+        CML_CHECK(c, hipMemsetAsync(c->cd_idepth[l].p, 0, 4 * sz, c->stream));
+        CML_CHECK(c, hipMemsetAsync(c->cd_wsum[l].p, 0, 4 * sz, c->stream));
+        const int nb = cml_div_up((int)sz, 1024);
+        if (nb > maxblocks) maxblocks = nb;
+    }
+    if ((rc = cml_ensure(c, c->cd_cnt, 4 * (size_t)(maxblocks + 16)))) return rc;
+    DevBuf dpts;
+    if (n > 0) {
+        if ((rc = cml_ensure(c, dpts, 32 * (size_t)n))) return rc;
+        if ((rc = cml_h2d(c, dpts.p, pts, 32 * (size_t)n))) { cml_free(dpts); return rc; }
+        k_cd_splat<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, c->cd_idepth[0].as<float>(),
+                                                              c->cd_wsum[0].as<float>());
+    }
+    for (int l = 1; l < levels; l++) {
+        dim3 g(cml_div_up(py->lv[l].w, 256), py->lv[l].h);
+        k_cd_down<<<g, 256, 0, c->stream>>>(c->cd_idepth[l - 1].as<float>(), c->cd_wsum[l - 1].as<float>(), py->lv[l - 1].w, py->lv[l].w,
+                                            py->lv[l].h, c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>());
+    }
+    for (int l = 0; l < levels; l++) {
+        const int wl = py->lv[l].w, hl = py->lv[l].h;
+        const size_t sz = (size_t)wl * hl;
+        CML_CHECK(c, hipMemcpyAsync(c->cd_wbak[l].p, c->cd_wsum[l].p, 4 * sz, hipMemcpyDeviceToDevice, c->stream));   // backupWeightSum
+        const int cnt = wl * hl - 2 * wl;
+        if (cnt > 0)
+            k_cd_dilate<<<cml_div_up(cnt, 256), 256, 0, c->stream>>>(c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>(),
+                                                                     c->cd_wbak[l].as<float>(), wl, hl, l < 2 ? 1 : 0);
+    }
+    for (int l = 0; l < levels; l++) {
+        const int wl = py->lv[l].w, hl = py->lv[l].h;
+        const int nb = cml_div_up(wl * hl, 1024);
+        int* counts = c->cd_cnt.as<int>();
+        int* total = counts + nb;
+        k_cd_count<<<nb, 1024, 0, c->stream>>>(c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>(), py->lv[l].gray, wl, hl, counts);
+        k_cd_scan<<<1, 64, 0, c->stream>>>(counts, nb, total);
+        k_cd_scatter<<<nb, 1024, 0, c->stream>>>(c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>(), py->lv[l].gray, wl, hl, counts,
+                                                 c->trk_ref[l].as<float>());
+        int tot = 0;
+        if ((rc = cml_d2h(c, &tot, total, sizeof(int)))) { cml_free(dpts); return rc; }
+        c->trk_n[l] = tot;
+        n_out[l] = tot;
+    }
+    CML_CHECK(c, hipGetLastError());
+    cml_free(dpts);
+    return CMLHIP_OK;
+}
+
+}  // extern "C"

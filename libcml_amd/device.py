@@ -1,0 +1,321 @@
+"""ctypes binding of libcmlhip.so (the C ABI of include/cmlhip.h) + a thin numpy convenience class.
+
+This is plumbing for tests/bench/smoke: every call goes through the extern "C" boundary a C++ host would use.
+There is no CPU fallback: loading fails loudly when the HIP library is missing, and Ctx() fails when no
+gfx950 device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcmlhip.so")
+
+_lib = None
+
+_d, _f, _i, _u8 = C.c_double, C.c_float, C.c_int, C.c_ubyte
+_P = C.POINTER
+_ctx = C.c_void_p
+
+PROTOTYPES = {
+    "cmlhip_abi_version": (C.c_int, []),
+    "cmlhip_device_count": (C.c_int, []),
+    "cmlhip_create": (C.c_int, [_P(_ctx), _P(abi.Limits)]),
+    "cmlhip_destroy": (None, [_ctx]),
+    "cmlhip_last_error": (C.c_char_p, [_ctx]),
+    "cmlhip_synchronize": (C.c_int, [_ctx]),
+    "cmlhip_stream": (C.c_void_p, [_ctx]),
+    "cmlhip_pyramid_put": (C.c_int, [_ctx, C.c_uint64, _i, _P(_f), _i, _i]),
+    "cmlhip_pyramid_build": (C.c_int, [_ctx, C.c_uint64, _P(_f), _i, _i, _i]),
+    "cmlhip_pyramid_drop": (C.c_int, [_ctx, C.c_uint64]),
+    "cmlhip_pyramid_level_size": (C.c_int, [_ctx, C.c_uint64, _i, _P(_i), _P(_i)]),
+    "cmlhip_pyramid_get": (C.c_int, [_ctx, C.c_uint64, _i, _P(_f)]),
+    "cmlhip_tracker_set_reference": (C.c_int, [_ctx, _i, _P(_f), _i]),
+    "cmlhip_tracker_make_coarse_depth": (C.c_int, [_ctx, C.c_uint64, _i, _P(_d), _i, _P(_i)]),
+    "cmlhip_tracker_get_reference": (C.c_int, [_ctx, _i, _P(_f), _P(_i)]),
+    "cmlhip_tracker_eval": (C.c_int, [_ctx, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(_d), _d,
+                                      _P(abi.TrackerParams), _i, _P(abi.TrackerResult)]),
+    "cmlhip_tracker_get_warped": (C.c_int, [_ctx, _P(_f), _i, _P(_i)]),
+    "cmlhip_ba_set_params": (C.c_int, [_ctx, _P(abi.BAParams)]),
+    "cmlhip_ba_upload_window": (C.c_int, [_ctx, _i, _P(abi.BAFrame), _i, _P(abi.BAPoint), _i, _P(abi.BAResidual)]),
+    "cmlhip_ba_set_pairs": (C.c_int, [_ctx, _P(abi.BAPair)]),
+    "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
+    "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
+    "cmlhip_ba_linearize": (C.c_int, [_ctx, _P(abi.BALinResult)]),
+    "cmlhip_ba_apply": (C.c_int, [_ctx, _i]),
+    "cmlhip_ba_accumulate": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d)]),
+    "cmlhip_ba_solve": (C.c_int, [_ctx, _d, _P(_d), _P(_d), _i, _P(_d)]),
+    "cmlhip_ba_backsub": (C.c_int, [_ctx, _P(_d), _P(_d)]),
+    "cmlhip_ba_backup_points": (C.c_int, [_ctx]),
+    "cmlhip_ba_step_points": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_get_states": (C.c_int, [_ctx, _P(_i), _P(_i), _P(_f), _P(_f), _P(_f), _P(_u8)]),
+    "cmlhip_ba_get_rj": (C.c_int, [_ctx, _i, _P(_f)]),
+    "cmlhip_ba_get_jpjdf": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_get_center_projected": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_get_point_acc": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_get_pair_acc": (C.c_int, [_ctx, _i, _P(_f)]),
+    "cmlhip_ba_get_index_maps": (C.c_int, [_ctx, _P(_i), _P(_i), _P(_i), _P(_i), _P(_i)]),
+    "cmlhip_reproj_accumulate": (C.c_int, [_ctx, _i, _P(_d), _i, _P(_d), _i, _P(abi.ReprojObs), _d, _d, _P(_d), _P(_d),
+                                           _P(_d), _P(_u8)]),
+    "cmlhip_reproj_solve": (C.c_int, [_ctx, _i, _d, _P(_d)]),
+    "cmlhip_event_mark": (C.c_int, [_ctx, _i]),
+    "cmlhip_event_elapsed_ms": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_linearize_async": (C.c_int, [_ctx]),
+    "cmlhip_ba_iteration_async": (C.c_int, [_ctx, _d]),
+}
+
+
+def lib():
+    """Load libcmlhip.so (built in-tree by libcml_amd.build). Raises when it is missing — no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcml_amd/libcmlhip.so is missing: run `python -m libcml_amd.build` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback for the device path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class CmlHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cmlhip status %d: %s" % (code, msg))
+        self.code = code
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(_P(t))
+
+
+class Ctx:
+    """One device context (one HIP stream)."""
+
+    def __init__(self, device_id=0, max_frames=8, max_points=4096, max_residuals=65536, max_tracker_points=1 << 20,
+                 max_reproj_obs=1 << 16, texel_format=abi.TEXEL_F32):
+        self.L = lib()
+        self.h = _ctx()
+        lim = abi.Limits(device_id, max_frames, max_points, max_residuals, max_tracker_points, max_reproj_obs, texel_format)
+        rc = self.L.cmlhip_create(C.byref(self.h), C.byref(lim))
+        if rc != 0:
+            raise CmlHipError(rc, "cmlhip_create failed (no usable gfx950 device? there is no CPU fallback)")
+        self.N = self.P = self.R = 0
+
+    def close(self):
+        if self.h:
+            self.L.cmlhip_destroy(self.h)
+            self.h = _ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ck(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise CmlHipError(rc, (self.L.cmlhip_last_error(self.h) or b"").decode())
+        return rc
+
+    # ------------------------------------------------------------------ pyramids
+    def pyramid_put(self, image_id, level, aos3):
+        a = np.ascontiguousarray(aos3, np.float32)
+        self.ck(self.L.cmlhip_pyramid_put(self.h, image_id, level, _p(a, _f), a.shape[1], a.shape[0]))
+
+    def pyramid_build(self, image_id, gray, levels):
+        g = np.ascontiguousarray(gray, np.float32)
+        self.ck(self.L.cmlhip_pyramid_build(self.h, image_id, _p(g, _f), g.shape[1], g.shape[0], levels))
+
+    def pyramid_get(self, image_id, level):
+        w, h = _i(), _i()
+        self.ck(self.L.cmlhip_pyramid_level_size(self.h, image_id, level, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value, 3), np.float32)
+        self.ck(self.L.cmlhip_pyramid_get(self.h, image_id, level, _p(out, _f)))
+        return out
+
+    def pyramid_drop(self, image_id):
+        return self.L.cmlhip_pyramid_drop(self.h, image_id)
+
+    # ------------------------------------------------------------------ BA
+    def ba_set_params(self, prm):
+        self.ck(self.L.cmlhip_ba_set_params(self.h, C.byref(prm)))
+
+    def ba_upload_window(self, frames, points, residuals):
+        frames = np.ascontiguousarray(frames); points = np.ascontiguousarray(points); residuals = np.ascontiguousarray(residuals)
+        self.N, self.P, self.R = len(frames), len(points), len(residuals)
+        self.ck(self.L.cmlhip_ba_upload_window(self.h, self.N, frames.ctypes.data_as(_P(abi.BAFrame)), self.P,
+                                                points.ctypes.data_as(_P(abi.BAPoint)), self.R,
+                                                residuals.ctypes.data_as(_P(abi.BAResidual))))
+
+    def ba_set_pairs(self, pairs):
+        pairs = np.ascontiguousarray(pairs)
+        self.ck(self.L.cmlhip_ba_set_pairs(self.h, pairs.ctypes.data_as(_P(abi.BAPair))))
+
+    def ba_set_frame_energy_th(self, th):
+        th = np.ascontiguousarray(th, np.float32)
+        self.ck(self.L.cmlhip_ba_set_frame_energy_th(self.h, _p(th, _f)))
+
+    def ba_get_idepth(self):
+        out = np.zeros(self.P)
+        self.ck(self.L.cmlhip_ba_get_idepth(self.h, _p(out, _d)))
+        return out
+
+    def ba_set_idepth(self, idepth, idepth_zero=None):
+        a = np.ascontiguousarray(idepth, np.float64)
+        z = None if idepth_zero is None else np.ascontiguousarray(idepth_zero, np.float32)
+        self.ck(self.L.cmlhip_ba_set_idepth(self.h, _p(a, _d), _p(z, _f)))
+
+    def ba_linearize(self):
+        out = abi.BALinResult()
+        self.ck(self.L.cmlhip_ba_linearize(self.h, C.byref(out)), allow=(abi.ERR_NONFINITE,))
+        return out
+
+    def ba_apply(self, copy=1):
+        self.ck(self.L.cmlhip_ba_apply(self.h, copy))
+
+    def ba_accumulate(self, adH, adT, adHTd, cdelta, prior, dprior, cprior):
+        n = 8 * self.N + 4
+        self._keep = [np.ascontiguousarray(adH, np.float64), np.ascontiguousarray(adT, np.float64),
+                      np.ascontiguousarray(adHTd, np.float32), np.ascontiguousarray(cdelta, np.float64),
+                      np.ascontiguousarray(prior, np.float64), np.ascontiguousarray(dprior, np.float64),
+                      np.ascontiguousarray(cprior, np.float64)]
+        k = self._keep
+        ain = abi.BAAccumIn(_p(k[0], _d), _p(k[1], _d), _p(k[2], _f), _p(k[3], _d), _p(k[4], _d), _p(k[5], _d), _p(k[6], _d))
+        HA = np.zeros((n, n)); bA = np.zeros(n); HL = np.zeros((n, n)); bL = np.zeros(n); Hsc = np.zeros((n, n)); bsc = np.zeros(n)
+        self.ck(self.L.cmlhip_ba_accumulate(self.h, C.byref(ain), _p(HA, _d), _p(bA, _d), _p(HL, _d), _p(bL, _d), _p(Hsc, _d), _p(bsc, _d)))
+        return HA, bA, HL, bL, Hsc, bsc
+
+    def ba_solve(self, lam, HM=None, bM=None, optcal=0):
+        n = 8 * self.N + 4
+        x = np.zeros(n)
+        HM = None if HM is None else np.ascontiguousarray(HM, np.float64)
+        bM = None if bM is None else np.ascontiguousarray(bM, np.float64)
+        rc = self.ck(self.L.cmlhip_ba_solve(self.h, lam, _p(HM, _d), _p(bM, _d), optcal, _p(x, _d)), allow=(abi.ERR_NONFINITE,))
+        return x, rc
+
+    def ba_backsub(self, x=None):
+        step = np.zeros(self.P)
+        xx = None if x is None else np.ascontiguousarray(x, np.float64)
+        rc = self.ck(self.L.cmlhip_ba_backsub(self.h, _p(xx, _d), _p(step, _d)), allow=(abi.ERR_NONFINITE,))
+        return step, rc
+
+    def ba_backup_points(self):
+        self.ck(self.L.cmlhip_ba_backup_points(self.h))
+
+    def ba_step_points(self):
+        s = np.zeros(3, np.float32)
+        self.ck(self.L.cmlhip_ba_step_points(self.h, _p(s, _f)))
+        return s
+
+    def ba_states(self):
+        R = self.R
+        st = np.zeros(R, np.int32); ns = np.zeros(R, np.int32); e = np.zeros(R, np.float32); ne = np.zeros(R, np.float32)
+        nw = np.zeros(R, np.float32); g = np.zeros(R, np.uint8)
+        self.ck(self.L.cmlhip_ba_get_states(self.h, _p(st, _i), _p(ns, _i), _p(e, _f), _p(ne, _f), _p(nw, _f), _p(g, _u8)))
+        return dict(state=st, new_state=ns, energy=e, new_energy=ne, new_energy_wo=nw, good=g)
+
+    def ba_rj(self, which=0):
+        out = np.zeros((self.R, abi.RJ_FLOATS), np.float32)
+        self.ck(self.L.cmlhip_ba_get_rj(self.h, which, _p(out, _f)))
+        return out
+
+    def ba_jpjdf(self):
+        out = np.zeros((self.R, 8), np.float32)
+        self.ck(self.L.cmlhip_ba_get_jpjdf(self.h, _p(out, _f)))
+        return out
+
+    def ba_center(self):
+        out = np.zeros((self.R, 3), np.float32)
+        self.ck(self.L.cmlhip_ba_get_center_projected(self.h, _p(out, _f)))
+        return out
+
+    def ba_point_acc(self):
+        out = np.zeros((self.P, 14), np.float32)
+        self.ck(self.L.cmlhip_ba_get_point_acc(self.h, _p(out, _f)))
+        return out
+
+    def ba_pair_acc(self, mode=0):
+        out = np.zeros((self.N * self.N, 13, 13), np.float32)
+        self.ck(self.L.cmlhip_ba_get_pair_acc(self.h, mode, _p(out, _f)))
+        return out
+
+    def ba_index_maps(self):
+        R, P, NN = self.R, self.P, self.N * self.N
+        a = np.zeros(R, np.int32); b = np.zeros(P + 1, np.int32); c = np.zeros(R, np.int32)
+        d = np.zeros(NN + 1, np.int32); e = np.zeros(R, np.int32)
+        self.ck(self.L.cmlhip_ba_get_index_maps(self.h, _p(a, _i), _p(b, _i), _p(c, _i), _p(d, _i), _p(e, _i)))
+        return dict(pair_of=a, by_point_off=b, by_point=c, by_pair_off=d, by_pair=e)
+
+    def ba_linearize_async(self):
+        self.ck(self.L.cmlhip_ba_linearize_async(self.h))
+
+    def ba_iteration_async(self, lam):
+        self.ck(self.L.cmlhip_ba_iteration_async(self.h, lam))
+
+    # ------------------------------------------------------------------ tracker
+    def tracker_set_reference(self, level, uvic):
+        a = np.ascontiguousarray(uvic, np.float32)
+        self.ck(self.L.cmlhip_tracker_set_reference(self.h, level, _p(a, _f), len(a)))
+
+    def tracker_get_reference(self, level):
+        n = _i()
+        self.ck(self.L.cmlhip_tracker_get_reference(self.h, level, None, C.byref(n)))
+        out = np.zeros((n.value, 4), np.float32)
+        if n.value:
+            self.ck(self.L.cmlhip_tracker_get_reference(self.h, level, _p(out, _f), C.byref(n)))
+        return out
+
+    def tracker_make_coarse_depth(self, image_id, levels, pts):
+        a = np.ascontiguousarray(pts, np.float64)
+        nout = (C.c_int * 8)()
+        self.ck(self.L.cmlhip_tracker_make_coarse_depth(self.h, image_id, levels, _p(a, _d), len(a), nout))
+        return list(nout[:levels])
+
+    def tracker_eval(self, image_id, level, R, t, K, aff, b0, prm, want_hessian=1):
+        R = np.ascontiguousarray(R, np.float64).ravel(); t = np.ascontiguousarray(t, np.float64)
+        K = np.ascontiguousarray(K, np.float64); aff = np.ascontiguousarray(aff, np.float64)
+        out = abi.TrackerResult()
+        rc = self.ck(self.L.cmlhip_tracker_eval(self.h, image_id, level, _p(R, _d), _p(t, _d), _p(K, _d), _p(aff, _d), b0,
+                                                C.byref(prm), want_hessian, C.byref(out)), allow=(abi.ERR_NONFINITE,))
+        return out, rc
+
+    def tracker_get_warped(self, capacity):
+        out = np.zeros((8, capacity), np.float32)
+        n = _i()
+        self.ck(self.L.cmlhip_tracker_get_warped(self.h, _p(out, _f), capacity, C.byref(n)))
+        return out[:, :min(n.value, capacity)], n.value
+
+    # ------------------------------------------------------------------ reproj
+    def reproj_accumulate(self, poses, points, obs, fx, fy):
+        poses = np.ascontiguousarray(poses, np.float64); points = np.ascontiguousarray(points, np.float64)
+        obs = np.ascontiguousarray(obs)
+        N, M, n = len(poses), len(points), len(obs)
+        M6 = np.zeros((6 * N, 6 * N)); b6 = np.zeros(6 * N); Jp = np.zeros((M, 3)); used = np.zeros(n, np.uint8)
+        self.ck(self.L.cmlhip_reproj_accumulate(self.h, N, _p(poses, _d), M, _p(points, _d), n,
+                                                 obs.ctypes.data_as(_P(abi.ReprojObs)), fx, fy, _p(M6, _d), _p(b6, _d), _p(Jp, _d),
+                                                 _p(used, _u8)))
+        return M6, b6, Jp, used
+
+    def reproj_solve(self, N, lam):
+        x = np.zeros(6 * N)
+        rc = self.ck(self.L.cmlhip_reproj_solve(self.h, N, lam, _p(x, _d)), allow=(abi.ERR_NONFINITE,))
+        return x, rc
+
+    # ------------------------------------------------------------------ timing
+    def sync(self):
+        self.ck(self.L.cmlhip_synchronize(self.h))
+
+    def mark(self, which):
+        self.ck(self.L.cmlhip_event_mark(self.h, which))
+
+    def elapsed_ms(self):
+        ms = _f()
+        self.ck(self.L.cmlhip_event_elapsed_ms(self.h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,200 @@
+"""Seeded synthetic windows for the hot path: procedural textured plane rendered into
+N keyframes, active points with known inverse depth, residual lists as BA::addPoints/createResidual
+(BA.cpp:336-415) would build them.  numpy only; used by tests/, bench.py and smoke().
+
+The images are renderings of ONE textured plane seen from the N keyframe poses, so photometric
+residuals are small at the true state and the optimiser has something real to do once poses / idepths
+are perturbed.  Texture = 6 octaves of value noise + 40 random step edges, range [0,255].
+"""
+import numpy as np
+
+STAR8 = np.array([[0, -2], [-1, -1], [1, -1], [-2, 0], [0, 0], [2, 0], [-1, 1], [0, 2]], np.int32)  # types.h:1381-1393
+
+CONFIGS = {
+    # name: (N, P, w, h, levels, fx, fy, cx, cy)
+    "A": (2, 200, 640, 480, 2, 525.0, 525.0, 319.5, 239.5),
+    "B": (8, 2000, 1241, 376, 4, 718.856, 718.856, 607.19 - 0.5, 185.22 - 0.5),
+    "E": (20, 8000, 1920, 1080, 4, 1400.0, 1400.0, 959.5, 539.5),
+    "tiny": (3, 64, 160, 120, 2, 140.0, 140.0, 79.5, 59.5),
+    "small": (4, 300, 320, 240, 3, 260.0, 260.0, 159.5, 119.5),
+}
+
+
+def so3_exp(w):
+    th = np.linalg.norm(w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + W
+    return np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * (W @ W)
+
+
+class Texture:
+    """Continuous procedural texture tex(a, b) on plane coordinates (metres)."""
+
+    def __init__(self, rng, scale=1.0):
+        self.lat = [rng.uniform(0, 1, size=(64, 64)) for _ in range(6)]
+        self.freq = [scale * 2 ** o for o in range(6)]
+        self.amp = [0.5 ** o for o in range(6)]
+        ang = rng.uniform(0, np.pi, size=40)
+        self.en = np.stack([np.cos(ang), np.sin(ang)], 1)
+        self.eo = rng.uniform(-12, 12, size=40)
+        self.ea = rng.uniform(-0.12, 0.12, size=40)
+        self.ebias = 0.5 * float(self.ea.sum())
+
+    def __call__(self, a, b):
+        v = np.zeros_like(a)
+        for lat, f, amp in zip(self.lat, self.freq, self.amp):
+            x = a * f + 1000.0
+            y = b * f + 1000.0
+            x0 = np.floor(x); y0 = np.floor(y)
+            fx = x - x0; fy = y - y0
+            sx = fx * fx * (3 - 2 * fx); sy = fy * fy * (3 - 2 * fy)
+            i0 = x0.astype(np.int64) % 64; j0 = y0.astype(np.int64) % 64
+            i1 = (i0 + 1) % 64; j1 = (j0 + 1) % 64
+            v += amp * ((lat[j0, i0] * (1 - sx) + lat[j0, i1] * sx) * (1 - sy)
+                        + (lat[j1, i0] * (1 - sx) + lat[j1, i1] * sx) * sy)
+        v = v / sum(self.amp)
+        for n, o, amp in zip(self.en, self.eo, self.ea):
+            v = v + amp * (a * n[0] + b * n[1] > o)
+        # fixed (view-independent) tone mapping: the same world point must get the same value in every keyframe
+        v = np.clip(0.5 + 1.6 * (v - 0.5 - self.ebias), 0.0, 1.0)
+        return (255.0 * v).astype(np.float32)
+
+
+def render(tex, K, R, t, w, h, n, d):
+    """Image of the plane {X: n.X = d} from the camera Xc = R Xw + t."""
+    fx, fy, cx, cy = K
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    r = np.stack([(xs - cx) / fx, (ys - cy) / fy, np.ones_like(xs)], -1)
+    Rt = R.T
+    nR = Rt.T @ n                       # n^T R^T
+    s = (d + n @ (Rt @ t)) / (r @ nR)   # depth along the ray (r_z = 1)
+    Xw = (s[..., None] * r - t) @ Rt.T
+    e1 = np.cross(n, [0, 1, 0]); e1 /= np.linalg.norm(e1)
+    e2 = np.cross(n, e1)
+    return tex(Xw @ e1, Xw @ e2), s
+
+
+class Window:
+    """A synthetic sliding window: everything a DSOBundleAdjustment::run would see, as flat arrays."""
+    pass
+
+
+def make_window(config="B", seed=0xC0FFEE, shard=0, pose_noise=1.0, idepth_noise=0.03, state_noise=2e-3,
+                eval_noise=1.0):
+    N, P, w, h, levels, fx, fy, cx, cy = CONFIGS[config] if isinstance(config, str) else config
+    rng = np.random.default_rng(seed + shard)
+    W = Window()
+    W.config = config; W.N, W.P, W.w, W.h, W.levels = N, P, w, h, levels
+    W.K = (fx, fy, cx, cy)
+    n = np.array([0.12, -0.08, 1.0]); n /= np.linalg.norm(n)
+    d = 9.0
+    # highest octave (x32) at ~0.07 cycles/pixel at the plane distance, so the renderings are not aliased
+    tex = Texture(rng, scale=0.07 * fx / (d * 32.0))
+    # true keyframe poses (world -> cam): forward motion 0.8 m / KF + jitter, SURVEY §8d
+    W.R_true, W.t_true, W.aff_true, W.gray, W.depth = [], [], [], [], []
+    step = 0.8 if N <= 8 else 0.3
+    for k in range(N):
+        c = np.array([0, 0, step * k]) + rng.uniform(-0.05, 0.05, 3) * pose_noise
+        Rk = so3_exp(np.deg2rad(rng.uniform(-1, 1, 3)) * pose_noise)
+        tk = -Rk @ c
+        a = rng.uniform(-0.05, 0.05); b = rng.uniform(-5, 5)
+        img, s = render(tex, W.K, Rk, tk, w, h, n, d)
+        # the photometric model of the reference: I_k = exp(a_k) * (I_true) + b_k  (exposure time 1)
+        W.gray.append((np.exp(a) * img + b).astype(np.float32))
+        W.depth.append(s)
+        W.R_true.append(Rk); W.t_true.append(tk); W.aff_true.append((a, b))
+    # evaluation-point poses = truth perturbed (what tracking would have delivered)
+    W.R_eval, W.t_eval, W.aff_eval = [], [], []
+    for k in range(N):
+        dR = so3_exp(rng.normal(0, 0.0015, 3) * eval_noise) if k else np.eye(3)
+        dt = rng.normal(0, 0.004, 3) * eval_noise if k else np.zeros(3)
+        W.R_eval.append(dR @ W.R_true[k]); W.t_eval.append(dR @ W.t_true[k] + dt)
+        a, b = W.aff_true[k]
+        W.aff_eval.append((a + rng.normal(0, 0.01) * eval_noise, b + rng.normal(0, 0.5) * eval_noise))
+    # states: older keyframes have drifted from their linearisation point, the newest has not
+    W.state = np.zeros((N, 10))
+    for k in range(1, N - 1):
+        W.state[k, :6] = rng.normal(0, state_noise, 6)
+        W.state[k, 6] = rng.normal(0, 2e-4); W.state[k, 7] = rng.normal(0, 2e-4)
+    W.state_zero = np.zeros((N, 10))
+    for k in range(N):   # setEvalPT_scaled: state_scaled[6:8] = (a, b) -> state = scaled / scale, state_zero = state
+        a, b = W.aff_eval[k]
+        W.state_zero[k, 6] = a / 10.0; W.state_zero[k, 7] = b / 1000.0
+        W.state[k, 6] += W.state_zero[k, 6]; W.state[k, 7] += W.state_zero[k, 7]
+    W.ab_exposure = np.ones(N)
+    W.keyid = np.arange(N)
+    W.frame_energy_th = np.full(N, 8.0 * 8 * 8, np.float32)   # DSOFrame.h:35
+    # points: uniform pixels of a round-robin host, keep those seen by >= 1 other keyframe (truth geometry)
+    pts = np.zeros(P, dtype=[("x", "f4"), ("y", "f4"), ("idepth", "f8"), ("idepth_true", "f8"), ("host", "i4")])
+    k = 0
+    tries = 0
+    while k < P and tries < 50 * P:
+        tries += 1
+        hst = k % N
+        # stand-in for the reference's PixelSelector (out of scope): best gradient of 12 random candidates
+        cx_ = rng.integers(8, w - 8, size=12); cy_ = rng.integers(8, h - 8, size=12)
+        g = W.gray[hst]
+        mag = np.abs(g[cy_, cx_ + 1] - g[cy_, cx_ - 1]) + np.abs(g[cy_ + 1, cx_] - g[cy_ - 1, cx_])
+        best = int(np.argmax(mag))
+        x = np.float32(cx_[best]); y = np.float32(cy_[best])
+        z = W.depth[hst][int(y), int(x)]
+        idt = 1.0 / z
+        ray = np.array([(x - cx) / fx, (y - cy) / fy, 1.0])
+        Xw = W.R_true[hst].T @ (ray * z - W.t_true[hst])
+        seen = 0
+        for t_ in range(N):
+            if t_ == hst:
+                continue
+            Xc = W.R_true[t_] @ Xw + W.t_true[t_]
+            if Xc[2] <= 0.1:
+                continue
+            u = fx * Xc[0] / Xc[2] + cx; v = fy * Xc[1] / Xc[2] + cy
+            if 4 <= u < w - 4 and 4 <= v < h - 4:
+                seen += 1
+        if seen == 0:
+            continue
+        pts[k] = (x, y, idt * (1 + rng.normal(0, idepth_noise)), idt, hst)
+        k += 1
+    assert k == P, "could not place the requested number of points"
+    W.pts = pts
+    return W
+
+
+def point_colors_weights(W, grads0):
+    """DSOContext::addPoint colours (gray at the integer pixel + shift, DSOContext.h:87-91 / MapObject.h:398-399)
+    and BA::addPoints gradient weights sqrt(c / (c + |grad|^2)) (BA.cpp:405-411), c = 2500."""
+    P = W.P
+    colors = np.zeros((P, 8), np.float32)
+    weights = np.zeros((P, 8), np.float32)
+    for i in range(P):
+        hst = W.pts["host"][i]
+        x = int(W.pts["x"][i]); y = int(W.pts["y"][i])
+        g = grads0[hst]
+        for k, (dx, dy) in enumerate(STAR8):
+            colors[i, k] = W.gray[hst][y + dy, x + dx]
+            # corners are integer pixels here, so interpolate() reduces to the texel itself
+            gx, gy = np.float64(g[y + dy, x + dx, 1]), np.float64(g[y + dy, x + dx, 2])
+            weights[i, k] = np.float32(np.sqrt(2500.0 / (2500.0 + (gx * gx + gy * gy))))
+    return colors, weights
+
+
+def residual_list(W, R_eval, t_eval):
+    """createResidual (BA.cpp:336-380): one residual per (point, target != host); initial state IN when the
+    centre projects inside the image at the evaluation-point poses, else OOB."""
+    fx, fy, cx, cy = W.K
+    res = []
+    for i in range(W.P):
+        hst = int(W.pts["host"][i])
+        x, y, idp = float(W.pts["x"][i]), float(W.pts["y"][i]), float(W.pts["idepth"][i])
+        p = np.array([(x - cx) * (1.0 / fx), (y - cy) * (1.0 / fy), 1.0])
+        for t_ in range(W.N):
+            if t_ == hst:
+                continue
+            Rht = R_eval[t_] @ R_eval[hst].T
+            tht = t_eval[t_] - Rht @ t_eval[hst]
+            q = Rht @ p + tht * idp
+            u = fx * q[0] / q[2] + cx; v = fy * q[1] / q[2] + cy
+            inside = (0 <= u <= W.w - 1) and (0 <= v <= W.h - 1)   # Frame::isInside(p, 0, 0)
+            res.append((i, t_, 0 if inside else 1, 0))
+    return np.array(res, dtype=[("point", "i4"), ("target", "i4"), ("state", "i4"), ("is_linearized", "i4")])

@@ -1,0 +1,69 @@
+"""Generate tests/golden/thirdparty_vectors.npz from oracle/_ref (the reference's vendored Eigen 3.4.0 and
+Sophus 1.1.0, compiled where they lie under /root/reference/thirdparty by oracle/Makefile `ref`).
+
+Run in the build container only:  python tests/golden/make_thirdparty_vectors.py
+The .npz holds inputs and the outputs of the REAL third-party code for the calls the hot path makes
+(SE3::exp/log/Adj/Dx_exp_x/product/inverse, LDLT solve, inverse, the JacobiSVD nullspace projection),
+so the oracle's plain-C restatements stay pinned on the GPU box where neither /root/reference nor
+(necessarily) oracle/_ref exist.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from tests import oracle_lib as O  # noqa: E402
+
+R = O.ref()
+assert R, "oracle/_ref not built (needs /root/reference)"
+d = C.c_double
+rng = np.random.default_rng(20260929)
+P = O.ptr
+
+xi = rng.normal(size=(48, 6)) * np.array([1, 1, 1, .6, .6, .6])
+xi[:8, 3:] *= 1e-7          # small-angle branch
+xi[8:12, 3:] = 0            # exact zero rotation
+xi[12:16, 3:] *= 4.5        # angles near/over pi
+q = np.zeros((48, 4)); t = np.zeros((48, 3)); lg = np.zeros((48, 6)); adj = np.zeros((48, 36)); dx = np.zeros((48, 42))
+Rm = np.zeros((48, 9)); qi = np.zeros((48, 4)); ti = np.zeros((48, 3)); qm = np.zeros((48, 4)); tm = np.zeros((48, 3))
+qr = np.zeros((48, 4))
+for i in range(48):
+    R.ref_se3_exp(P(xi[i], d), P(q[i], d), P(t[i], d))
+    R.ref_se3_log(P(q[i], d), P(t[i], d), P(lg[i], d))
+    R.ref_se3_adj(P(q[i], d), P(t[i], d), P(adj[i], d))
+    R.ref_se3_dx_exp_x(P(xi[i], d), P(dx[i], d))
+    R.ref_se3_matrix(P(q[i], d), P(Rm[i], d))
+    R.ref_se3_inv(P(q[i], d), P(t[i], d), P(qi[i], d), P(ti[i], d))
+for i in range(48):   # products need all q/t filled first
+    j = (i + 7) % 48
+    R.ref_se3_mul(P(q[i], d), P(t[i], d), P(q[j], d), P(t[j], d), P(qm[i], d), P(tm[i], d))
+    R.ref_se3_from_Rt(P(Rm[i], d), P(t[i], d), P(qr[i], d))
+
+out = dict(xi=xi, q=q, t=t, log=lg, adj=adj, dx_exp_x=dx, R=Rm, q_inv=qi, t_inv=ti, q_mul=qm, t_mul=tm, q_from_R=qr)
+for n in (6, 7, 8, 64, 160):
+    M = rng.normal(size=(n, n + 3))
+    A = M @ M.T
+    if n >= 64:   # badly scaled like the Jacobi-scaled BA system with gauge priors
+        s = 10.0 ** rng.uniform(-3, 3, size=n)
+        A = A * s[:, None] * s[None, :]
+    b = rng.normal(size=n)
+    x = np.zeros(n); Ai = np.zeros(n * n)
+    R.ref_ldlt_solve(P(A.ravel(), d), P(b, d), n, P(x, d))
+    R.ref_inverse(P(A.ravel(), d), n, P(Ai, d))
+    out[f"ldlt_A{n}"] = A; out[f"ldlt_b{n}"] = b; out[f"ldlt_x{n}"] = x; out[f"inv{n}"] = Ai.reshape(n, n)
+# indefinite + singular LDLT cases (pivoting / zero-pivot paths)
+A = rng.normal(size=(8, 8)); A = A + A.T; b = rng.normal(size=8); x = np.zeros(8)
+R.ref_ldlt_solve(P(A.ravel(), d), P(b, d), 8, P(x, d)); out["ldlt_indef_A"] = A; out["ldlt_indef_b"] = b; out["ldlt_indef_x"] = x
+v = rng.normal(size=(8, 5)); A = v @ v.T; b = A @ rng.normal(size=8); x = np.zeros(8)
+R.ref_ldlt_solve(P(A.ravel(), d), P(b, d), 8, P(x, d)); out["ldlt_sing_A"] = A; out["ldlt_sing_b"] = b; out["ldlt_sing_x"] = x
+for name, n, dup in (("orth68", 68, False), ("orth164", 164, False), ("orth_rankdef", 68, True)):
+    Nc = rng.normal(size=(7, n)); Nc[:, :4] = 0
+    if dup:
+        Nc[6] = 3.0 * Nc[1]
+    b = rng.normal(size=n); b2 = b.copy()
+    R.ref_orthogonalize(P(b2, d), n, P(Nc.ravel(), d), 7, d(1e-5))
+    out[name + "_N"] = Nc; out[name + "_b"] = b; out[name + "_out"] = b2
+np.savez_compressed(os.path.join(os.path.dirname(__file__), "thirdparty_vectors.npz"), **out)
+print("wrote", len(out), "arrays")

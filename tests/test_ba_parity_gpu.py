@@ -1,0 +1,94 @@
+"""GPU parity of the bundle-adjustment hot path against the oracle, through the C ABI.
+Bars: per-residual records, states, energies, thresholds: BIT-EXACT (the kernel keeps the reference's
+statement order, fp contraction off).  Reductions over residuals/points (13x13 pair blocks, Schur, solve,
+back-substitution): fp32 accumulation-order tolerance, stated per test."""
+import numpy as np
+import pytest
+
+from tests import ba_setup as S
+from tests import dev_setup as D
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["tiny", "small"])
+def pair(request):
+    I = S.make_inputs(request.param)
+    ob = S.OracleBA(I)
+    ctx = D.make_ctx(I)
+    yield I, ob, ctx
+    ctx.close()
+
+
+def test_index_maps_exact(pair):
+    I, ob, ctx = pair
+    m = ctx.ba_index_maps()
+    w = ob.w.contents
+    assert np.array_equal(m["pair_of"], ob.view("pair_of", I.R, np.int32))
+    assert np.array_equal(m["by_point_off"], np.ctypeslib.as_array(w.by_point_off, shape=(I.P + 1,)))
+    assert np.array_equal(m["by_point"], ob.view("by_point", I.R, np.int32))
+    assert np.array_equal(m["by_pair_off"], np.ctypeslib.as_array(w.by_pair_off, shape=(I.N * I.N + 1,)))
+    assert np.array_equal(m["by_pair"], ob.view("by_pair", I.R, np.int32))
+    hosts = I.points["host"][I.residuals["point"]]
+    assert np.array_equal(m["pair_of"], hosts + I.residuals["target"] * I.N)      # htIDX, BA.cpp:1677
+
+
+def test_linearize_bit_exact(pair):
+    I, ob, ctx = pair
+    ro = ob.linearize()
+    rd = ctx.ba_linearize()
+    so, sd = ob.states(), ctx.ba_states()
+    assert np.array_equal(so["new_state"], sd["new_state"])
+    assert np.array_equal(so["state"], sd["state"])
+    assert np.array_equal(so["new_energy_wo"].view(np.uint32), sd["new_energy_wo"].view(np.uint32))
+    IN = so["new_state"] == 0
+    assert IN.sum() > 10
+    assert np.array_equal(so["new_energy"][IN].view(np.uint32), sd["new_energy"][IN].view(np.uint32))
+    jo, jd = ob.rJ(0), ctx.ba_rj(0)
+    assert np.array_equal(jo[IN].view(np.uint32), jd[IN].view(np.uint32)), "raw Jacobian records differ"
+    co = ob.view("r_center", 3 * I.R, np.float32).reshape(-1, 3)
+    assert np.array_equal(co[IN].view(np.uint32), ctx.ba_center()[IN].view(np.uint32))
+    assert (ro.n_in, ro.n_oob, ro.n_outlier) == (rd.n_in, rd.n_oob, rd.n_outlier)
+    assert np.float32(ro.new_frame_energy_th).view(np.uint32) == np.float32(rd.new_frame_energy_th).view(np.uint32)
+    assert abs(ro.energy - rd.energy) <= 1e-12 * abs(ro.energy)      # fp64 sum, order differs
+
+
+def test_apply_and_accumulate(pair):
+    I, ob, ctx = pair
+    ob.apply(1); ctx.ba_apply(1)
+    so, sd = ob.states(), ctx.ba_states()
+    for k in ("state", "good"):
+        assert np.array_equal(so[k], sd[k])
+    assert np.array_equal(so["energy"].view(np.uint32), sd["energy"].view(np.uint32))
+    g = so["good"] == 1
+    assert np.array_equal(ob.rJ(1)[g].view(np.uint32), ctx.ba_rj(1)[g].view(np.uint32))
+    jo = ob.view("JpJdF", 8 * I.R, np.float32).reshape(-1, 8)
+    assert np.abs(jo[g] - ctx.ba_jpjdf()[g]).max() <= 2e-6 * np.abs(jo[g]).max()      # fma contraction in apply
+    HAo, bAo, HLo, bLo, Hso, bso = ob.accumulate()
+    HAd, bAd, HLd, bLd, Hsd, bsd = D.accumulate(ctx, I)
+    # raw fp32 13x13 pair accumulators: tiered sequential sums (oracle) vs tree sums (device)
+    ao = ob.view("accA", 169 * I.N * I.N, np.float32).reshape(-1, 13, 13)
+    ad = ctx.ba_pair_acc(0)
+    for q in range(I.N * I.N):
+        assert np.abs(ao[q] - ad[q]).max() <= 2e-5 * max(np.abs(ao[q]).max(), 1e-30), q
+    assert D.rel(HAd, HAo) < 2e-5 and D.rel(bAd, bAo) < 2e-5
+    assert D.rel(HLd, HLo) < 1e-12 and D.rel(bLd, bLo) < 1e-12          # priors only
+    assert D.rel(Hsd, Hso) < 5e-5 and D.rel(bsd, bso) < 5e-5
+    assert np.abs(HAd - HAd.T).max() <= 1e-9 * np.abs(HAd).max()
+    # per-point scalars
+    pa = ctx.ba_point_acc()
+    P = I.P
+    for name, col in (("Hdd_accAF", 0), ("bd_accAF", 1), ("HdiF", 12), ("bdSumF", 13)):
+        o = ob.view(name, P, np.float32)
+        assert np.abs(o - pa[:, col]).max() <= 2e-5 * max(np.abs(o).max(), 1e-30), name
+    # solve + back-substitution
+    lam = 1e-5
+    xo, rco = ob.solve(lam, HAo, bAo, HLo, bLo, Hso, bso)
+    xd, rcd = ctx.ba_solve(lam)
+    assert rco == 0 and rcd == 0
+    assert D.rel(xd, xo) < 2e-3, D.rel(xd, xo)      # gauge-near-singular system: fp32 input noise is amplified
+    # same x into both back-substitutions isolates that kernel
+    sto, _ = ob.backsub(xo)
+    std, rc = ctx.ba_backsub(xo)
+    assert rc == 0
+    assert np.abs(sto - std).max() <= 5e-5 * np.abs(sto).max()
