@@ -244,6 +244,8 @@ int cmlhip_ba_backsub(cmlhip_ctx* ctx, const double* x, double* step /* P, may b
  * also returns sumID, sumNID, numID (float accumulators of BA.cpp:988-990). */
 int cmlhip_ba_backup_points(cmlhip_ctx* ctx);                      /* BA.cpp:919-922 */
 int cmlhip_ba_step_points(cmlhip_ctx* ctx, float sums_out[3]);
+/* point part of loadSateBackup (BA.cpp:938-942): idepth = idepth_zero = idepth_backup */
+int cmlhip_ba_restore_points(cmlhip_ctx* ctx);
 
 /* ---- readbacks (parity tests, Statistic norms BA.cpp:1415-1425, host bookkeeping) */
 int cmlhip_ba_get_states(cmlhip_ctx* ctx, int* state, int* new_state, float* energy,

@@ -467,6 +467,11 @@ __global__ void k_ba_backup_points(BAArgs A) {          // BA.cpp:919-922
     if (p < A.P) A.pt_backup[p] = (float)A.pt_idepth[p];
 }
 
+__global__ void k_ba_restore_points(BAArgs A) {         // loadSateBackup, BA.cpp:938-942
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < A.P) { A.pt_idepth[p] = (double)A.pt_backup[p]; A.pt_idepth_zero[p] = A.pt_backup[p]; }
+}
+
 // doStepFromBackup, point part (BA.cpp:976-994); sums are tree-reduced (float)
 __global__ __launch_bounds__(1024) void k_ba_step_points(BAArgs A, LinSummary* __restrict__ sum) {
     __shared__ float s[3][16];
@@ -573,6 +578,10 @@ int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A) {
 }
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A) {
     k_ba_backup_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A);
+    return CMLHIP_OK;
+}
+int cml_launch_restore_points(cmlhip_ctx* c, const BAArgs& A) {
+    k_ba_restore_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A);
     return CMLHIP_OK;
 }
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A) {

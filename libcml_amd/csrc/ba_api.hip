@@ -300,6 +300,16 @@ int cmlhip_ba_backup_points(cmlhip_ctx* c) {
     return CMLHIP_OK;
 }
 
+int cmlhip_ba_restore_points(cmlhip_ctx* c) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_restore_points(c, A);
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
 int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) {
     int rc = ba_check(c, false);
     if (rc) return rc;

@@ -47,3 +47,4 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm
 int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_restore_points(cmlhip_ctx* c, const BAArgs& A);

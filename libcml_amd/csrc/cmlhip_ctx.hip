@@ -18,8 +18,27 @@ void cml_free(DevBuf& b) {
 }
 int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return CMLHIP_OK;
-    // pageable source: the runtime stages it before returning, so the borrowed host buffer may be reused by the caller
-    CML_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    // The source is a borrowed (usually pageable) host buffer that the caller may free or reuse as soon as we return,
+    // so it is copied into a pinned staging ring owned by the context first; the device copy is then truly async.
+    const size_t cap = 8u << 20;
+    if (!c->pinned) {
+        CML_CHECK(c, hipHostMalloc(&c->pinned, cap, hipHostMallocDefault));
+        c->pinned_bytes = cap;
+        c->pinned_off = 0;
+    }
+    if (bytes > cap / 2) {                          // big uploads (images): synchronous copy, no staging
+        CML_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        CML_CHECK(c, hipStreamSynchronize(c->stream));
+        return CMLHIP_OK;
+    }
+    if (c->pinned_off + bytes > cap) {              // ring wrap: everything staged so far must have been consumed
+        CML_CHECK(c, hipStreamSynchronize(c->stream));
+        c->pinned_off = 0;
+    }
+    char* stage = static_cast<char*>(c->pinned) + c->pinned_off;
+    memcpy(stage, src, bytes);
+    c->pinned_off += (bytes + 255) & ~size_t(255);
+    CML_CHECK(c, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, c->stream));
     return CMLHIP_OK;
 }
 int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {

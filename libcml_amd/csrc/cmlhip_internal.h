@@ -44,7 +44,7 @@ struct cmlhip_ctx {
     std::string err;
     std::unordered_map<uint64_t, Pyramid> pyr;
     void* pinned = nullptr;       // pinned host staging (readbacks / small uploads)
-    size_t pinned_bytes = 0;
+    size_t pinned_bytes = 0, pinned_off = 0;
 
     // ---------------- BA window
     cmlhip_ba_params ba_prm{};

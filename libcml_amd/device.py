@@ -52,6 +52,7 @@ PROTOTYPES = {
     "cmlhip_ba_backsub": (C.c_int, [_ctx, _P(_d), _P(_d)]),
     "cmlhip_ba_backup_points": (C.c_int, [_ctx]),
     "cmlhip_ba_step_points": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_restore_points": (C.c_int, [_ctx]),
     "cmlhip_ba_get_states": (C.c_int, [_ctx, _P(_i), _P(_i), _P(_f), _P(_f), _P(_f), _P(_u8)]),
     "cmlhip_ba_get_rj": (C.c_int, [_ctx, _i, _P(_f)]),
     "cmlhip_ba_get_jpjdf": (C.c_int, [_ctx, _P(_f)]),

@@ -1,0 +1,212 @@
+"""ctypes access to the C++ host mirror (libcmlhost.so: cml_amd::DSOBundleAdjustment / DSOTracker over the C ABI).
+Product-side plumbing for tests and bench.py; a C++ caller would use the classes in libcml_amd/host/*.h directly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi, device, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcmlhost.so")
+_lib = None
+_d, _f, _i, _u8, _vp = C.c_double, C.c_float, C.c_int, C.c_ubyte, C.c_void_p
+_P = C.POINTER
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        device.lib()     # libcmlhip.so first (rpath $ORIGIN also covers it)
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcml_amd/libcmlhost.so is missing: run `python -m libcml_amd.build`")
+        L = C.CDLL(LIB_PATH)
+        L.cmlhost_ba_create.restype = _vp; L.cmlhost_ba_create.argtypes = [_vp]
+        L.cmlhost_ba_destroy.argtypes = [_vp]
+        L.cmlhost_ba_set_calibration.argtypes = [_vp, _d, _d, _d, _d, _i, _i]
+        L.cmlhost_ba_set_param.argtypes = [_vp, C.c_char_p, _d]
+        L.cmlhost_ba_add_frame.argtypes = [_vp, C.c_uint64, _P(_d), _P(_d), _d, _d, _d]
+        L.cmlhost_ba_set_frame_state.argtypes = [_vp, _i, _P(_d)]
+        L.cmlhost_ba_set_frame_energy_th.argtypes = [_vp, _i, _d]
+        L.cmlhost_ba_add_point.argtypes = [_vp, _f, _f, _d, _i, _P(_f), _P(_f), _i]
+        L.cmlhost_ba_run.argtypes = [_vp, _i]
+        L.cmlhost_ba_last_error.restype = C.c_char_p; L.cmlhost_ba_last_error.argtypes = [_vp]
+        L.cmlhost_ba_counts.argtypes = [_vp] + [_P(_i)] * 5
+        L.cmlhost_ba_get_frame.argtypes = [_vp, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d)]
+        L.cmlhost_ba_get_points.argtypes = [_vp, _P(_d), _P(_u8), _P(_i)]
+        L.cmlhost_ba_get_residual_states.argtypes = [_vp, _P(_i), _P(_u8), _P(_u8)]
+        L.cmlhost_ba_get_outliers.argtypes = [_vp, _P(_i)]
+        L.cmlhost_ba_get_algebra.argtypes = [_vp, _P(_d), _P(_d), _P(_f), _P(abi.BAPair), _P(_d), _P(_d), _P(_d)]
+        L.cmlhost_ba_orthogonalize.argtypes = [_vp, _P(_d), _i]
+        L.cmlhost_ba_stats.argtypes = [_vp, _P(_d), _i]
+        L.cmlhost_tracker_create.restype = _vp; L.cmlhost_tracker_create.argtypes = [_vp]
+        L.cmlhost_tracker_destroy.argtypes = [_vp]
+        L.cmlhost_tracker_set_calibration.argtypes = [_vp, _d, _d, _d, _d]
+        L.cmlhost_tracker_set_param.argtypes = [_vp, C.c_char_p, _d]
+        L.cmlhost_tracker_make_coarse_depth.argtypes = [_vp, C.c_uint64, _i, _P(_d), _i, _P(_i)]
+        L.cmlhost_tracker_optimize.argtypes = [_vp, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_i), _P(_i), _P(_d),
+                                               _P(_d), _P(_d), _P(_i), _P(_i), _P(_i)]
+        L.cmlhost_tracker_last_error.restype = C.c_char_p; L.cmlhost_tracker_last_error.argtypes = [_vp]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(_P(t))
+
+
+class HostBA:
+    """cml_amd::DSOBundleAdjustment (flat-window mirror of the reference class)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = lib()
+        self.h = self.L.cmlhost_ba_create(ctx.h)
+
+    def close(self):
+        if self.h:
+            self.L.cmlhost_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_calibration(self, fx, fy, cx, cy, w, h):
+        self.L.cmlhost_ba_set_calibration(self.h, fx, fy, cx, cy, w, h)
+
+    def set_param(self, name, value):
+        if self.L.cmlhost_ba_set_param(self.h, name.encode(), float(value)) != 0:
+            raise KeyError(name)
+
+    def add_frame(self, image_id, R, t, a, b, exposure=1.0):
+        R = np.ascontiguousarray(R, np.float64).ravel(); t = np.ascontiguousarray(t, np.float64)
+        return self.L.cmlhost_ba_add_frame(self.h, int(image_id), _p(R, _d), _p(t, _d), a, b, exposure)
+
+    def set_frame_state(self, f, state):
+        s = np.ascontiguousarray(state, np.float64)
+        self.L.cmlhost_ba_set_frame_state(self.h, f, _p(s, _d))
+
+    def add_point(self, x, y, idepth, host, colors, weights, prior=False):
+        c = np.ascontiguousarray(colors, np.float32); w = np.ascontiguousarray(weights, np.float32)
+        return self.L.cmlhost_ba_add_point(self.h, float(x), float(y), float(idepth), int(host), _p(c, _f), _p(w, _f), int(prior))
+
+    def run(self, update_points_only=False):
+        return bool(self.L.cmlhost_ba_run(self.h, int(update_points_only)))
+
+    def last_error(self):
+        return (self.L.cmlhost_ba_last_error(self.h) or b"").decode()
+
+    def counts(self):
+        v = [_i() for _ in range(5)]
+        self.L.cmlhost_ba_counts(self.h, *[C.byref(x) for x in v])
+        return dict(zip(("frames", "points", "residuals", "outliers", "iterations"), [x.value for x in v]))
+
+    def frame(self, f):
+        R = np.zeros(9); t = np.zeros(3); ab = np.zeros(2); st = np.zeros(10); th = _d()
+        self.L.cmlhost_ba_get_frame(self.h, f, _p(R, _d), _p(t, _d), _p(ab, _d), _p(st, _d), C.byref(th))
+        return dict(R=R.reshape(3, 3), t=t, ab=ab, state=st, th=th.value)
+
+    def points(self):
+        n = self.counts()["points"]
+        idp = np.zeros(n); alive = np.zeros(n, np.uint8); ng = np.zeros(n, np.int32)
+        self.L.cmlhost_ba_get_points(self.h, _p(idp, _d), _p(alive, _u8), _p(ng, _i))
+        return idp, alive, ng
+
+    def residual_states(self):
+        n = self.counts()["residuals"]
+        st = np.zeros(n, np.int32); alive = np.zeros(n, np.uint8); good = np.zeros(n, np.uint8)
+        self.L.cmlhost_ba_get_residual_states(self.h, _p(st, _i), _p(alive, _u8), _p(good, _u8))
+        return st, alive, good
+
+    def outliers(self):
+        n = self.counts()["outliers"]
+        o = np.zeros(max(n, 1), np.int32)
+        self.L.cmlhost_ba_get_outliers(self.h, _p(o, _i))
+        return o[:n]
+
+    def algebra(self):
+        N = self.counts()["frames"]
+        n = 8 * N + 4
+        adH = np.zeros(N * N * 64); adT = np.zeros(N * N * 64); adHTd = np.zeros(N * N * 8, np.float32)
+        pairs = np.zeros(N * N, abi.BA_PAIR_DTYPE); prior = np.zeros(8 * N); dprior = np.zeros(8 * N); ns = np.zeros(7 * n)
+        self.L.cmlhost_ba_get_algebra(self.h, _p(adH, _d), _p(adT, _d), _p(adHTd, _f), pairs.ctypes.data_as(_P(abi.BAPair)),
+                                      _p(prior, _d), _p(dprior, _d), _p(ns, _d))
+        return dict(adH=adH, adT=adT, adHTd=adHTd, pairs=pairs, prior=prior, dprior=dprior, nullspaces=ns.reshape(7, n))
+
+    def orthogonalize(self, x):
+        x = np.ascontiguousarray(x, np.float64).copy()
+        self.L.cmlhost_ba_orthogonalize(self.h, _p(x, _d), len(x))
+        return x
+
+    def energies(self, cap=16):
+        e = np.zeros(cap)
+        n = self.L.cmlhost_ba_stats(self.h, _p(e, _d), cap)
+        return e[:n]
+
+
+class HostTracker:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = lib()
+        self.h = self.L.cmlhost_tracker_create(ctx.h)
+
+    def close(self):
+        if self.h:
+            self.L.cmlhost_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_calibration(self, fx, fy, cx, cy):
+        self.L.cmlhost_tracker_set_calibration(self.h, fx, fy, cx, cy)
+
+    def set_param(self, name, value):
+        if self.L.cmlhost_tracker_set_param(self.h, name.encode(), float(value)) != 0:
+            raise KeyError(name)
+
+    def make_coarse_depth(self, ref_image, levels, pts):
+        a = np.ascontiguousarray(pts, np.float64)
+        nout = (C.c_int * 8)()
+        ok = self.L.cmlhost_tracker_make_coarse_depth(self.h, int(ref_image), levels, _p(a, _d), len(a), nout)
+        if not ok:
+            raise RuntimeError(self.L.cmlhost_tracker_last_error(self.h).decode())
+        return list(nout[:levels])
+
+    def optimize(self, new_image, levels, R, t, ref_exp, cur_exp):
+        R = np.ascontiguousarray(R, np.float64).ravel().copy(); t = np.ascontiguousarray(t, np.float64).copy()
+        re = np.ascontiguousarray(ref_exp, np.float64); ce = np.ascontiguousarray(cur_exp, np.float64).copy()
+        E = np.zeros(8); nt = np.zeros(8, np.int32); nsat = np.zeros(8, np.int32); flow = np.zeros(3); rel = np.zeros(2); cov = np.zeros(6)
+        ok, sat = _i(), _i(); its = np.zeros(8, np.int32)
+        self.L.cmlhost_tracker_optimize(self.h, int(new_image), levels, _p(R, _d), _p(t, _d), _p(re, _d), _p(ce, _d), _p(E, _d), _p(nt, _i),
+                                        _p(nsat, _i), _p(flow, _d), _p(rel, _d), _p(cov, _d), C.byref(ok), C.byref(sat), _p(its, _i))
+        return dict(R=R.reshape(3, 3), t=t, exposure=ce, E=E, numTerms=nt, numSat=nsat, flow=flow, relAff=rel, covariance=cov,
+                    isCorrect=bool(ok.value), tooManySaturated=bool(sat.value), iterations=its)
+
+
+def window_to_host_ba(ctx, W, image_id_base=1000, levels=1):
+    """Upload a synthetic window (libcml_amd.synth) and register it with a HostBA the way Hybrid::directMap would:
+    device-side pyramid build, addNewFrame per keyframe, addPoint per active point (colours / gradient weights read
+    back from the device pyramid, DSOContext.h:87-91 / BA.cpp:405-411)."""
+    ba = HostBA(ctx)
+    fx, fy, cx, cy = W.K
+    ba.set_calibration(fx, fy, cx, cy, W.w, W.h)
+    grads0 = []
+    for k in range(W.N):
+        ctx.pyramid_build(image_id_base + k, W.gray[k], levels)
+        grads0.append(ctx.pyramid_get(image_id_base + k, 0))
+    for k in range(W.N):
+        a, b = W.aff_eval[k]
+        ba.add_frame(image_id_base + k, W.R_eval[k], W.t_eval[k], a, b, float(W.ab_exposure[k]))
+    for k in range(W.N):
+        ba.set_frame_state(k, W.state[k])
+    colors, weights = synth.point_colors_weights(W, grads0)
+    for i in range(W.P):
+        ba.add_point(W.pts["x"][i], W.pts["y"][i], W.pts["idepth"][i], W.pts["host"][i], colors[i], weights[i])
+    return ba

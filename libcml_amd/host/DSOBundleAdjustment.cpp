@@ -1,0 +1,539 @@
+// DSOBundleAdjustment.cpp — host mirror of CML::Optimization::DSOBundleAdjustment over the C ABI.
+// BA.cpp = src/cml/optimization/dso/DSOBundleAdjustment.cpp in the reference tree.
+#include "DSOBundleAdjustment.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+namespace cml_amd {
+
+// ------------------------------------------------------------------------------------------------ DSOFrame
+static void updatePRE(DSOFrame& f) {                                           // DSOFrame.h:119-120
+    f.PRE_worldToCam = SE3::exp(f.state_scaled) * f.worldToCam_evalPT;
+    f.PRE_camToWorld = f.PRE_worldToCam.inverse();
+}
+void DSOFrame::setState(const double s[10], const double sc[4]) {             // DSOFrame.h:110-124
+    double tmp[10];
+    std::memcpy(tmp, s, sizeof tmp);
+    std::memcpy(state, tmp, sizeof tmp);
+    for (int i = 0; i < 3; i++) { state_scaled[i] = sc[0] * tmp[i]; state_scaled[3 + i] = sc[1] * tmp[3 + i]; }
+    state_scaled[6] = sc[2] * tmp[6]; state_scaled[7] = sc[3] * tmp[7]; state_scaled[8] = sc[2] * tmp[8]; state_scaled[9] = sc[3] * tmp[9];
+    updatePRE(*this);
+}
+void DSOFrame::setStateScaled(const double ss[10], const double sc[4]) {      // DSOFrame.h:126-142
+    double tmp[10];
+    std::memcpy(tmp, ss, sizeof tmp);
+    std::memcpy(state_scaled, tmp, sizeof tmp);
+    for (int i = 0; i < 3; i++) { state[i] = tmp[i] / sc[0]; state[3 + i] = tmp[3 + i] / sc[1]; }
+    state[6] = tmp[6] / sc[2]; state[7] = tmp[7] / sc[3]; state[8] = tmp[8] / sc[2]; state[9] = tmp[9] / sc[3];
+    updatePRE(*this);
+}
+void DSOFrame::setStateZero(const double sz[10], const double sc[4]) {        // DSOFrame.h:154-186
+    double tmp[10];
+    std::memcpy(tmp, sz, sizeof tmp);
+    std::memcpy(state_zero, tmp, sizeof tmp);
+    const SE3 Ti = worldToCam_evalPT.inverse();
+    for (int i = 0; i < 6; i++) {
+        double eps[6] = {0, 0, 0, 0, 0, 0}, lp[6], lm[6];
+        eps[i] = 1e-3;
+        const SE3 Ep = SE3::exp(eps);
+        eps[i] = -1e-3;
+        const SE3 Em = SE3::exp(eps);
+        ((worldToCam_evalPT * Ep) * Ti).log(lp);
+        ((worldToCam_evalPT * Em) * Ti).log(lm);
+        for (int k = 0; k < 6; k++) nullspaces_pose[i * 6 + k] = (lp[k] - lm[k]) / (2e-3);
+    }
+    SE3 Pp = worldToCam_evalPT, Pm = worldToCam_evalPT;
+    for (int k = 0; k < 3; k++) { Pp.t[k] *= 1.00001; Pm.t[k] /= 1.00001; }
+    double lp[6], lm[6];
+    (Pp * Ti).log(lp);
+    (Pm * Ti).log(lm);
+    for (int k = 0; k < 6; k++) nullspaces_scale[k] = (lp[k] - lm[k]) / (2e-3);
+    std::memset(nullspaces_affine, 0, sizeof nullspaces_affine);
+    nullspaces_affine[0] = 1;
+    nullspaces_affine[4 + 1] = (double)std::exp((float)(state_zero[6] * sc[2])) * ab_exposure;
+}
+void DSOFrame::setEvalPT(const SE3& w2c, const double s[10], const double sc[4]) {     // DSOFrame.h:88-95
+    worldToCam_evalPT = w2c;
+    setState(s, sc);
+    setStateZero(s, sc);
+}
+void DSOFrame::setEvalPT_scaled(const SE3& w2c, const Exposure& aff, const double sc[4]) {   // DSOFrame.h:99-108
+    double init[10] = {0, 0, 0, 0, 0, 0, aff.a, aff.b, 0, 0};
+    worldToCam_evalPT = w2c;
+    setStateScaled(init, sc);
+    setStateZero(state, sc);
+}
+void DSOFrame::doStepFromBackup(const double sc[4]) {                         // DSOFrame.h:82-84
+    double s[10];
+    for (int i = 0; i < 10; i++) s[i] = state_backup[i] + step[i];
+    setState(s, sc);
+}
+void DSOFrame::setStep(const double s[10]) {                                  // DSOFrame.h:205-214
+    for (int i = 0; i < 10; i++)
+        if (!std::isfinite(s[i])) { std::memset(step, 0, sizeof step); return; }
+    std::memcpy(step, s, sizeof step);
+}
+
+// ------------------------------------------------------------------------------------------------ BA
+DSOBundleAdjustment::DSOBundleAdjustment(cmlhip_ctx* ctx) : mCtx(ctx) {
+    mMarginalizedHessian.assign((CMLHIP_CPARS + 8) * (CMLHIP_CPARS + 8), 0.0);      // BA.cpp:323-327
+    mMarginalizedB.assign(CMLHIP_CPARS + 8, 0.0);
+}
+
+bool DSOBundleAdjustment::fail(const std::string& what, int rc) {
+    mError = what + " (status " + std::to_string(rc) + "): " + (mCtx ? cmlhip_last_error(mCtx) : "no context");
+    return false;
+}
+
+void DSOBundleAdjustment::setCalibration(double fx, double fy, double cx, double cy, int w, int h) {
+    mPrm.fx = fx; mPrm.fy = fy; mPrm.cx = cx; mPrm.cy = cy; mPrm.w = w; mPrm.h = h;
+    mHaveCalib = true;
+}
+
+int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, const Exposure& exposure) {
+    double sc[4];
+    scales(sc);
+    DSOFrame f;
+    f.id = (int)mFrames.size();
+    f.keyid = mFrameKeyCounter++;                                   // DSOContext.h:49-50
+    f.image_id = image_id;
+    f.ab_exposure = exposure.t;
+    f.setEvalPT_scaled(worldToCam, exposure, sc);                   // BA.cpp:434
+    mFrames.push_back(f);
+    // grow the marginalisation prior by one 8-block of zeros, BA.cpp:439-443
+    const int n = 8 * (int)mFrames.size() + CMLHIP_CPARS, o = n - 8;
+    std::vector<double> H((size_t)n * n, 0.0), b(n, 0.0);
+    for (int i = 0; i < o && (size_t)o * o == mMarginalizedHessian.size(); i++) {
+        for (int j = 0; j < o; j++) H[(size_t)i * n + j] = mMarginalizedHessian[(size_t)i * o + j];
+        b[i] = mMarginalizedB[i];
+    }
+    mMarginalizedHessian.swap(H);
+    mMarginalizedB.swap(b);
+    computeAdjoints();
+    computeDelta();
+    // residuals of the existing points into the new frame, BA.cpp:456-460 (createResidual, :336-380)
+    const int t = f.id;
+    for (int p = 0; p < (int)mPoints.size(); p++) {
+        if (!mPoints[p].alive || mPoints[p].host == t) continue;
+        const DSOPoint& P = mPoints[p];
+        const SE3 ht = mFrames[t].worldToCam_evalPT * mFrames[P.host].worldToCam_evalPT.inverse();
+        double R[9];
+        ht.matrix(R);
+        const double rx = ((double)P.x - mPrm.cx) * (1.0 / mPrm.fx), ry = ((double)P.y - mPrm.cy) * (1.0 / mPrm.fy);
+        const double px = R[0] * rx + R[1] * ry + R[2] + ht.t[0] * P.idepth, py = R[3] * rx + R[4] * ry + R[5] + ht.t[1] * P.idepth,
+                     pz = R[6] * rx + R[7] * ry + R[8] + ht.t[2] * P.idepth;
+        const double Ku = (px / pz) * mPrm.fx + mPrm.cx, Kv = (py / pz) * mPrm.fy + mPrm.cy;
+        DSOResidual r;
+        r.point = p; r.target = t;
+        r.centerProjectedTo[0] = (float)Ku; r.centerProjectedTo[1] = (float)Kv; r.centerProjectedTo[2] = (float)((1.0 / pz) * P.idepth);
+        const bool inside = Ku >= 0 && Kv >= 0 && Ku < mPrm.w && Kv < mPrm.h;     // Frame::isInside(p, 0, 0), src/cml/map/Frame.h:136-138
+        r.state_state = inside ? DSORES_IN : DSORES_OOB;
+        r.state_NewState = DSORES_OUTLIER;
+        mResiduals.push_back(r);
+    }
+    return f.id;
+}
+
+int DSOBundleAdjustment::addPoint(float x, float y, double idepth, int host, const float colors[8], const float weights[8],
+                                  bool hasDepthPrior) {
+    DSOPoint P;
+    P.x = x; P.y = y; P.idepth = idepth; P.host = host;
+    std::memcpy(P.colors, colors, sizeof P.colors);
+    std::memcpy(P.weights, weights, sizeof P.weights);
+    P.idepth_zero = (float)idepth;                                   // BA.cpp:394
+    P.hasDepthPrior = hasDepthPrior;
+    const int p = (int)mPoints.size();
+    mPoints.push_back(P);
+    for (int t = 0; t < (int)mFrames.size(); t++) {                  // BA.cpp:398-400
+        if (t == host) continue;
+        const SE3 ht = mFrames[t].worldToCam_evalPT * mFrames[host].worldToCam_evalPT.inverse();
+        double R[9];
+        ht.matrix(R);
+        const double rx = ((double)x - mPrm.cx) * (1.0 / mPrm.fx), ry = ((double)y - mPrm.cy) * (1.0 / mPrm.fy);
+        const double px = R[0] * rx + R[1] * ry + R[2] + ht.t[0] * idepth, py = R[3] * rx + R[4] * ry + R[5] + ht.t[1] * idepth,
+                     pz = R[6] * rx + R[7] * ry + R[8] + ht.t[2] * idepth;
+        const double Ku = (px / pz) * mPrm.fx + mPrm.cx, Kv = (py / pz) * mPrm.fy + mPrm.cy;
+        DSOResidual r;
+        r.point = p; r.target = t;
+        r.centerProjectedTo[0] = (float)Ku; r.centerProjectedTo[1] = (float)Kv; r.centerProjectedTo[2] = (float)((1.0 / pz) * idepth);
+        const bool inside = Ku >= 0 && Kv >= 0 && Ku < mPrm.w && Kv < mPrm.h;
+        r.state_state = inside ? DSORES_IN : DSORES_OOB;
+        mResiduals.push_back(r);
+    }
+    return p;
+}
+
+void DSOBundleAdjustment::computeAdjoints() {                                 // BA.cpp:1030-1101
+    const int N = (int)mFrames.size();
+    double sc[4];
+    scales(sc);
+    mAdHost.assign((size_t)N * N * 64, 0.0);
+    mAdTarget.assign((size_t)N * N * 64, 0.0);
+    for (int h = 0; h < N; h++)
+        for (int t = 0; t < N; t++) {
+            const SE3 ht = mFrames[t].worldToCam_evalPT * mFrames[h].worldToCam_evalPT.inverse();
+            double Adj[36], la, lb;
+            ht.Adj(Adj);
+            mFrames[h].aff_g2l_0(sc).to(mFrames[t].aff_g2l_0(sc), la, lb);
+            double* AH = &mAdHost[64 * (size_t)(h + t * N)];
+            double* AT = &mAdTarget[64 * (size_t)(h + t * N)];
+            for (int i = 0; i < 6; i++) {
+                for (int j = 0; j < 6; j++) AH[i * 8 + j] = -Adj[j * 6 + i];
+                AT[i * 8 + i] = 1;
+            }
+            AT[6 * 8 + 6] = -la; AH[6 * 8 + 6] = la; AT[7 * 8 + 7] = -1; AH[7 * 8 + 7] = la;
+            const double rs[8] = {sc[0], sc[0], sc[0], sc[1], sc[1], sc[1], sc[2], sc[3]};
+            for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { AH[i * 8 + j] *= rs[i]; AT[i * 8 + j] *= rs[i]; }
+        }
+}
+
+void DSOBundleAdjustment::computeDelta() {                                    // BA.cpp:1103-1194
+    const int N = (int)mFrames.size();
+    mAdHTdeltaF.assign((size_t)N * N * 8, 0.f);
+    for (int h = 0; h < N; h++)
+        for (int t = 0; t < N; t++) {
+            const int idx = h + t * N;
+            for (int j = 0; j < 8; j++) {
+                double s = 0, s2 = 0;
+                for (int i = 0; i < 8; i++) {
+                    s += (mFrames[h].state[i] - mFrames[h].state_zero[i]) * mAdHost[64 * (size_t)idx + i * 8 + j];
+                    s2 += (mFrames[t].state[i] - mFrames[t].state_zero[i]) * mAdTarget[64 * (size_t)idx + i * 8 + j];
+                }
+                mAdHTdeltaF[8 * (size_t)idx + j] = (float)(s + s2);
+            }
+        }
+    // mCDeltaF = calibration - mCalibZero: the calibration is not optimised by this path, it stays 0 (BA.cpp:1118)
+    const float rotPrior = 1e11f, transPrior = 1e10f, affBPrior = 1e14f, affAPrior = 1e14f;
+    float modeA = 1e12f, modeB = 1e8f;
+    if (!mOptimizeA) modeA = -1;
+    if (!mOptimizeB) modeB = -1;
+    for (auto& f : mFrames) {
+        std::memset(f.prior, 0, sizeof f.prior);
+        if (f.keyid == 0) {
+            f.prior[0] = f.prior[1] = f.prior[2] = transPrior; f.prior[3] = f.prior[4] = f.prior[5] = rotPrior;
+            f.prior[6] = affAPrior; f.prior[7] = affBPrior;
+        } else {
+            f.prior[6] = modeA < 0 ? affAPrior : modeA;
+            f.prior[7] = modeB < 0 ? affBPrior : modeB;
+        }
+        for (int i = 0; i < 8; i++) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i] - f.prior_zero[i]; }
+    }
+    for (auto& p : mPoints) {                                                 // :1179-1184
+        p.priorF = p.hasDepthPrior ? (float)mIdepthFixPrior : 0.f;
+        p.deltaF = (float)(p.idepth - (double)p.idepth_zero);
+    }
+}
+
+void DSOBundleAdjustment::framePairs(std::vector<cmlhip_ba_pair>& out) const {   // DSOFrame.h:259-273
+    const int N = (int)mFrames.size();
+    out.resize((size_t)N * N);
+    for (int h = 0; h < N; h++)
+        for (int t = 0; t < N; t++) {
+            cmlhip_ba_pair& p = out[(size_t)h * N + t];
+            const SE3 ll = mFrames[t].PRE_worldToCam * mFrames[h].PRE_camToWorld;
+            ll.matrix(p.R);
+            std::memcpy(p.t, ll.t, sizeof p.t);
+            const SE3 l0 = mFrames[t].worldToCam_evalPT * mFrames[h].worldToCam_evalPT.inverse();
+            l0.matrix(p.R0);
+            std::memcpy(p.t0, l0.t, sizeof p.t0);
+            mFrames[h].aff_g2l().to(mFrames[t].aff_g2l(), p.aff_a, p.aff_b);
+        }
+}
+
+void DSOBundleAdjustment::computeNullspaces(std::vector<double>& out) const {    // BA.cpp:2365-2417 (pose x6 + scale)
+    const int N = (int)mFrames.size(), n = 8 * N + CMLHIP_CPARS;
+    out.assign((size_t)7 * n, 0.0);
+    for (int i = 0; i < 6; i++)
+        for (int f = 0; f < N; f++)
+            for (int k = 0; k < 6; k++)
+                out[(size_t)i * n + 4 + 8 * f + k] = mFrames[f].nullspaces_pose[i * 6 + k] * (k < 3 ? 1.0 / mScaleTranslation : 1.0 / mScaleRotation);
+    for (int f = 0; f < N; f++)
+        for (int k = 0; k < 6; k++)
+            out[(size_t)6 * n + 4 + 8 * f + k] = mFrames[f].nullspaces_scale[k] * (k < 3 ? 1.0 / mScaleTranslation : 1.0 / mScaleRotation);
+}
+
+// symmetric Jacobi eigen-decomposition (m <= 16)
+static void jacobiEig(double* A, int m, double* V) {
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) V[i * m + j] = (i == j);
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0;
+        for (int i = 0; i < m; i++) for (int j = i + 1; j < m; j++) off += A[i * m + j] * A[i * m + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < m; p++)
+            for (int q = p + 1; q < m; q++) {
+                const double apq = A[p * m + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double tau = (A[q * m + q] - A[p * m + p]) / (2 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1 + tau * tau));
+                const double c = 1 / std::sqrt(1 + t * t), s = t * c;
+                for (int k = 0; k < m; k++) { const double a = A[k * m + p], b = A[k * m + q]; A[k * m + p] = c * a - s * b; A[k * m + q] = s * a + c * b; }
+                for (int k = 0; k < m; k++) { const double a = A[p * m + k], b = A[q * m + k]; A[p * m + k] = c * a - s * b; A[q * m + k] = s * a + c * b; }
+                for (int k = 0; k < m; k++) { const double a = V[k * m + p], b = V[k * m + q]; V[k * m + p] = c * a - s * b; V[k * m + q] = s * a + c * b; }
+            }
+    }
+}
+
+// b -= N (N^T N)^+ N^T b, singular values <= delta*max dropped (BA.cpp:1196-1261).  With N = U S V^T the reference's
+// 0.5 (N Npi^T + (N Npi^T)^T) is U_kept U_kept^T; U_kept is built from the eigen-decomposition of N^T N.
+void DSOBundleAdjustment::orthogonalize(std::vector<double>& x) const {
+    std::vector<double> ns;
+    computeNullspaces(ns);
+    const int m = 7, n = (int)x.size();
+    for (int j = 0; j < m; j++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += ns[(size_t)j * n + i] * ns[(size_t)j * n + i];
+        s = std::sqrt(s);
+        for (int i = 0; i < n; i++) ns[(size_t)j * n + i] /= s;
+    }
+    double G[49], V[49];
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += ns[(size_t)i * n + k] * ns[(size_t)j * n + k];
+            G[i * m + j] = s;
+        }
+    jacobiEig(G, m, V);
+    double smax = 0;
+    for (int i = 0; i < m; i++) smax = std::max(smax, G[i * m + i] > 0 ? std::sqrt(G[i * m + i]) : 0.0);
+    std::vector<double> proj(n, 0.0), ue(n);
+    for (int e = 0; e < m; e++) {
+        const double sv = G[e * m + e] > 0 ? std::sqrt(G[e * m + e]) : 0.0;
+        if (!(sv > mSolverModeDelta * smax)) continue;
+        double dot = 0;
+        for (int i = 0; i < n; i++) {
+            double s = 0;
+            for (int j = 0; j < m; j++) s += ns[(size_t)j * n + i] * V[j * m + e];
+            ue[i] = s / sv;
+            dot += ue[i] * x[i];
+        }
+        for (int i = 0; i < n; i++) proj[i] += ue[i] * dot;
+    }
+    for (int i = 0; i < n; i++) x[i] -= proj[i];
+}
+
+bool DSOBundleAdjustment::uploadWindow() {
+    if (!mHaveCalib) { mError = "setCalibration not called"; return false; }
+    mPrm.huber = (float)mHuberThreshold; mPrm.outlier_th_sum = (float)mSettingOutlierTHSumComponent;
+    mPrm.scale_f = mScaleF; mPrm.scale_c = mScaleC; mPrm.optimize_a = mOptimizeA; mPrm.optimize_b = mOptimizeB;
+    int rc = cmlhip_ba_set_params(mCtx, &mPrm);
+    if (rc) return fail("cmlhip_ba_set_params", rc);
+    const int N = (int)mFrames.size();
+    std::vector<cmlhip_ba_frame> fr(N);
+    for (int i = 0; i < N; i++) {
+        fr[i].image_id = mFrames[i].image_id;
+        fr[i].frame_energy_th = (float)mFrames[i].frameEnergyTH;
+        fr[i].b0 = mFrames[i].getB0((float)mScaleLightB);
+    }
+    mActivePoints.clear();
+    mPointSlot.assign(mPoints.size(), -1);
+    std::vector<cmlhip_ba_point> pts;
+    for (int p = 0; p < (int)mPoints.size(); p++) {
+        if (!mPoints[p].alive) continue;
+        const DSOPoint& P = mPoints[p];
+        cmlhip_ba_point q;
+        q.x = P.x; q.y = P.y; q.idepth = P.idepth; q.idepth_zero = P.idepth_zero; q.prior = P.priorF; q.host = P.host;
+        std::memcpy(q.colors, P.colors, sizeof q.colors);
+        std::memcpy(q.weights, P.weights, sizeof q.weights);
+        mPointSlot[p] = (int)pts.size();
+        mActivePoints.push_back(p);
+        pts.push_back(q);
+    }
+    mActive.clear();
+    std::vector<cmlhip_ba_residual> rs;
+    for (int r = 0; r < (int)mResiduals.size(); r++) {
+        DSOResidual& R = mResiduals[r];
+        if (!R.alive || !mPoints[R.point].alive) continue;
+        if (!R.isLinearized || mAddLinearizedPoints) {                   // BA.cpp:766-779: resetOOB
+            R.state_NewEnergy = R.state_energy = 0;
+            R.state_NewState = DSORES_OUTLIER;
+            R.state_state = DSORES_IN;
+            if (R.isLinearized) R.isLinearized = false;
+        }
+        cmlhip_ba_residual q;
+        q.point = mPointSlot[R.point]; q.target = R.target; q.state = R.state_state; q.is_linearized = R.isLinearized;
+        mActive.push_back(r);
+        rs.push_back(q);
+    }
+    rc = cmlhip_ba_upload_window(mCtx, N, fr.data(), (int)pts.size(), pts.data(), (int)rs.size(), rs.data());
+    if (rc) return fail("cmlhip_ba_upload_window", rc);
+    return true;
+}
+
+bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3]) {   // BA.cpp:1497-1646
+    std::vector<cmlhip_ba_pair> pairs;
+    framePairs(pairs);
+    int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+    if (rc) return fail("cmlhip_ba_set_pairs", rc);
+    cmlhip_ba_lin_result lr;
+    rc = cmlhip_ba_linearize(mCtx, &lr);
+    if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_linearize", rc);
+    energy[0] = lr.energy; energy[1] = 0; energy[2] = 0;
+    mFrames.back().frameEnergyTH = lr.new_frame_energy_th;                // setNewFrameEnergyTH, :1610
+    if (fixLinearization) {
+        rc = cmlhip_ba_apply(mCtx, 1);                                    // applyRes(r, true) per residual, :1568-1569
+        if (rc) return fail("cmlhip_ba_apply", rc);
+        const int R = (int)mActive.size();
+        std::vector<int> st(R), ns(R);
+        std::vector<float> e(R), ne(R), nw(R);
+        std::vector<unsigned char> good(R);
+        rc = cmlhip_ba_get_states(mCtx, st.data(), ns.data(), e.data(), ne.data(), nw.data(), good.data());
+        if (rc) return fail("cmlhip_ba_get_states", rc);
+        std::vector<int> nres(mPoints.size(), 0);
+        for (int k = 0; k < R; k++) {
+            DSOResidual& Rr = mResiduals[mActive[k]];
+            Rr.state_state = st[k]; Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k];
+            Rr.state_NewEnergyWithOutlier = nw[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
+            if (Rr.isLinearized) continue;
+            if (Rr.isActiveAndIsGoodNEW) mPoints[Rr.point].numGoodResiduals++;      // :1592
+            else Rr.alive = false;                                                  // toRemove, :1595-1598,1638
+        }
+        for (const auto& Rr : mResiduals) if (Rr.alive) nres[Rr.point]++;
+        for (int p = 0; p < (int)mPoints.size(); p++)                               // points left without residual, :1638-1640
+            if (mPoints[p].alive && nres[p] == 0) { mPoints[p].alive = false; mOutliers.push_back(p); }
+    }
+    return true;
+}
+
+void DSOBundleAdjustment::backupState() {                                     // BA.cpp:912-926
+    for (auto& f : mFrames) f.backupState();
+    cmlhip_ba_backup_points(mCtx);
+}
+
+bool DSOBundleAdjustment::solveSystem(int iteration, double lambda) {         // BA.cpp:1339-1495
+    const int N = (int)mFrames.size(), n = 8 * N + CMLHIP_CPARS;
+    if (mFixLambda) lambda = mFixedLambda;
+    std::vector<double> prior(8 * (size_t)N), dprior(8 * (size_t)N);
+    for (int i = 0; i < N; i++) for (int k = 0; k < 8; k++) { prior[8 * i + k] = mFrames[i].prior[k]; dprior[8 * i + k] = mFrames[i].delta_prior[k]; }
+    double cdelta[4] = {mCDeltaF[0], mCDeltaF[1], mCDeltaF[2], mCDeltaF[3]}, cprior[4] = {mCPriorValue, mCPriorValue, mCPriorValue, mCPriorValue};
+    cmlhip_ba_accum_in in{mAdHost.data(), mAdTarget.data(), mAdHTdeltaF.data(), cdelta, prior.data(), dprior.data(), cprior};
+    const bool wantStats = true;
+    std::vector<double> HA, bA, Hsc, bsc;
+    if (wantStats) { HA.resize((size_t)n * n); bA.resize(n); Hsc.resize((size_t)n * n); bsc.resize(n); }
+    int rc = cmlhip_ba_accumulate(mCtx, &in, wantStats ? HA.data() : nullptr, wantStats ? bA.data() : nullptr, nullptr, nullptr,
+                                  wantStats ? Hsc.data() : nullptr, wantStats ? bsc.data() : nullptr);
+    if (rc) return fail("cmlhip_ba_accumulate", rc);
+    const double* HM = nullptr; const double* bM = nullptr;
+    std::vector<double> bMtop;
+    if (!mDisableMarginalization) {                                           // BA.cpp:1389-1401
+        bMtop.assign(n, 0.0);
+        std::vector<double> d(n, 0.0);
+        for (int h = 0; h < N; h++) for (int k = 0; k < 8; k++) d[4 + 8 * h + k] = mFrames[h].delta[k];
+        for (int i = 0; i < n; i++) {
+            double s = mMarginalizedB[i];
+            for (int j = 0; j < n; j++) s += mMarginalizedHessian[(size_t)i * n + j] * d[j];
+            bMtop[i] = s;
+        }
+        HM = mMarginalizedHessian.data(); bM = bMtop.data();
+    } else {
+        std::fill(mMarginalizedHessian.begin(), mMarginalizedHessian.end(), 0.0);     // :1395-1398
+        std::fill(mMarginalizedB.begin(), mMarginalizedB.end(), 0.0);
+    }
+    mX.assign(n, 0.0);
+    rc = cmlhip_ba_solve(mCtx, lambda, HM, bM, mOptimizeCalibration ? 1 : 0, mX.data());
+    if (rc == CMLHIP_ERR_NONFINITE) { mError = "non-finite solution"; /* the reference dumps the system and carries on, :1323-1325 */ }
+    else if (rc) return fail("cmlhip_ba_solve", rc);
+    if (iteration >= 2) orthogonalize(mX);                                    // :1404 mustOrthogonalize
+    auto norm = [](const std::vector<double>& v) { double s = 0; for (double a : v) s += a * a; return std::sqrt(s); };
+    if (wantStats) { statHessianP.push_back(norm(HA)); statHessianSC.push_back(norm(Hsc)); statBP.push_back(norm(bA)); statBSC.push_back(norm(bsc)); }
+    statXNorm.push_back(norm(mX));
+    for (int h = 0; h < N; h++) {                                             // :1433-1441
+        double st[10] = {0};
+        for (int k = 0; k < 8; k++) st[k] = -mX[4 + 8 * h + k];
+        mFrames[h].setStep(st);
+    }
+    rc = cmlhip_ba_backsub(mCtx, mX.data(), nullptr);                          // :1455-1487
+    if (rc == CMLHIP_ERR_NONFINITE) { mError = "points without a finite step"; return false; }   // :1489-1492
+    if (rc) return fail("cmlhip_ba_backsub", rc);
+    return true;
+}
+
+bool DSOBundleAdjustment::doStepFromBackup(bool fixCamera) {                  // BA.cpp:948-1028
+    double sc[4];
+    scales(sc);
+    float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+    for (auto& f : mFrames) {
+        if (fixCamera) for (int i = 0; i < 6; i++) f.step[i] = 0;
+        f.doStepFromBackup(sc);
+        sumA += (float)(f.step[6] * f.step[6]);
+        sumB += (float)(f.step[7] * f.step[7]);
+        sumT += (float)(f.step[0] * f.step[0] + f.step[1] * f.step[1] + f.step[2] * f.step[2]);
+        sumR += (float)(f.step[3] * f.step[3] + f.step[4] * f.step[4] + f.step[5] * f.step[5]);
+    }
+    float sums[3] = {0, 0, 0};
+    cmlhip_ba_step_points(mCtx, sums);
+    float sumID = sums[0], sumNID = sums[1];
+    const float numID = sums[2];
+    const float nf = (float)mFrames.size();
+    sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf; sumID /= numID; sumNID /= numID;
+    (void)sumID;
+    computeDelta();
+    return std::sqrt(sumA) < 0.0005 * mThOptIterations && std::sqrt(sumB) < 0.00005 * mThOptIterations &&
+           std::sqrt(sumR) < 0.00005 * mThOptIterations && std::sqrt(sumT) * sumNID < 0.00005 * mThOptIterations;
+}
+
+bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        // BA.cpp:744-910
+    mOutliers.clear();
+    mError.clear();
+    lastIterations = 0;
+    double sc[4];
+    scales(sc);
+    int alivePts = 0;
+    for (const auto& p : mPoints) alivePts += p.alive;
+    if (alivePts == 0) { mError = "No points..."; return false; }             // :759-762
+    computeAdjoints();
+    computeDelta();
+    if (!uploadWindow()) return false;
+    double lastEnergy[3], newEnergy[3];
+    if (!linearizeAll(false, lastEnergy)) return false;
+    int rc = cmlhip_ba_apply(mCtx, 1);                                        // applyActiveRes(true), :790
+    if (rc) return fail("cmlhip_ba_apply", rc);
+    double lambda = mFixedLambda;
+    statEnergyP.push_back(lastEnergy[0] / std::max<size_t>(1, mActive.size()));
+    for (int it = 0; it < mNumIterations; it++) {
+        lastIterations = it + 1;
+        backupState();
+        if (!solveSystem(it, lambda)) return false;                           // :813-816
+        const bool canbreak = doStepFromBackup(updatePointsOnly);
+        if (!linearizeAll(false, newEnergy)) return false;
+        const double newTotal = newEnergy[0] + newEnergy[1], lastTotal = lastEnergy[0] + lastEnergy[1];   // L and M energies are 0 under forceAccept (:2100-2102,2123-2125)
+        if (!std::isfinite(newTotal)) { mError = "non finite energy"; return false; }     // :836-841
+        if (newTotal < lastTotal || mForceAccept) {
+            statEnergyP.push_back(newEnergy[0]);
+            rc = cmlhip_ba_apply(mCtx, 1);
+            if (rc) return fail("cmlhip_ba_apply", rc);
+            for (int k = 0; k < 3; k++) lastEnergy[k] = newEnergy[k];
+            lambda *= 0.25;
+        } else {                                                              // loadSateBackup, :871-875
+            for (auto& f : mFrames) f.loadSateBackup(sc);
+            rc = cmlhip_ba_restore_points(mCtx);
+            if (rc) return fail("cmlhip_ba_restore_points", rc);
+            computeDelta();
+            if (!linearizeAll(false, lastEnergy)) return false;
+            lambda *= 1e2;
+        }
+        lastLambda = lambda;
+        if (canbreak && it >= 1) break;                                       // :879
+    }
+    // re-anchor the newest frame's evaluation point, :885-894
+    DSOFrame& fb = mFrames.back();
+    double nz[10] = {0};
+    nz[6] = fb.state[6]; nz[7] = fb.state[7];
+    fb.setEvalPT(fb.PRE_worldToCam, nz, sc);
+    computeAdjoints();
+    computeDelta();
+    if (!linearizeAll(true, lastEnergy)) return false;                        // :896
+    if (!std::isfinite(lastEnergy[0])) { mError = "Not finite energy"; return false; }
+    // write the optimised inverse depths back (MapPoint::setReferenceInverseDepth in the reference)
+    std::vector<double> idp(mActivePoints.size());
+    rc = cmlhip_ba_get_idepth(mCtx, idp.data());
+    if (rc) return fail("cmlhip_ba_get_idepth", rc);
+    for (size_t k = 0; k < mActivePoints.size(); k++) {
+        DSOPoint& P = mPoints[mActivePoints[k]];
+        P.idepth = idp[k];
+        P.idepth_zero = (float)idp[k];
+    }
+    return true;
+}
+
+}  // namespace cml_amd

@@ -1,0 +1,139 @@
+// DSOBundleAdjustment.h — host-side mirror of the reference operator interface for the sliding-window BA,
+// driving the gfx950 device layer through the C ABI (include/cmlhip.h).
+//
+// Mirrors CML::Optimization::DSOBundleAdjustment (src/cml/optimization/dso/DSOBundleAdjustment.h:26-101,235-288)
+// and its helper types DSOFrame / DSOPoint / DSOResidual (DSOFrame.h, DSOPoint.h, DSOResidual.h): same method
+// names, argument meaning, parameter names/defaults and error behaviour (bool returns, never throws).  The
+// reference reaches frames/points through Map/Frame/MapPoint/PrivateData objects; this mirror takes the same
+// quantities as flat values (image id, pose, exposure, corner, idepth, colours, weights), which is exactly what
+// the modified bodies of the reference methods would pass down.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/cmlhip.h"
+#include "se3.h"
+
+namespace cml_amd {
+
+enum DSOResidualState { DSORES_IN = 0, DSORES_OOB, DSORES_OUTLIER };          // DSOResidual.h:14-16
+
+struct DSOFrame {                                                              // DSOFrame.h:17-246
+    int id = -1, keyid = -1;
+    uint64_t image_id = 0;
+    double delta[8] = {0}, delta_prior[8] = {0}, prior[8] = {0}, prior_zero[10] = {0};
+    double frameEnergyTH = 8 * 8 * 8;
+    double nullspaces_pose[36] = {0}, nullspaces_scale[6] = {0}, nullspaces_affine[8] = {0};   // column-major like Eigen
+    SE3 PRE_worldToCam, PRE_camToWorld;
+    double ab_exposure = 1;
+    bool flaggedForMarginalization = false;
+    double state[10] = {0}, state_zero[10] = {0}, state_backup[10] = {0}, state_scaled[10] = {0}, step[10] = {0};
+    SE3 worldToCam_evalPT;
+
+    void setState(const double s[10], const double sc[4]);
+    void setStateScaled(const double ss[10], const double sc[4]);
+    void setStateZero(const double sz[10], const double sc[4]);
+    void setEvalPT(const SE3& w2c, const double s[10], const double sc[4]);
+    void setEvalPT_scaled(const SE3& w2c, const Exposure& aff, const double sc[4]);
+    void backupState() { for (int i = 0; i < 10; i++) state_backup[i] = state[i]; }
+    void loadSateBackup(const double sc[4]) { setState(state_backup, sc); }
+    void doStepFromBackup(const double sc[4]);
+    void setStep(const double s[10]);
+    Exposure aff_g2l() const { return Exposure(ab_exposure, state_scaled[6], state_scaled[7]); }
+    Exposure aff_g2l_0(const double sc[4]) const { return Exposure(ab_exposure, state_zero[6] * sc[2], state_zero[7] * sc[3]); }
+    float getB0(float scaleB) const { return (float)(state_zero[7] * scaleB); }
+};
+
+struct DSOPoint {                                                              // DSOPoint.h:44-167 (+ the MapPoint fields BA reads)
+    float x = 0, y = 0;
+    double idepth = 0;
+    int host = -1;
+    float colors[8] = {0}, weights[8] = {0};
+    float idepth_zero = 0, idepth_backup = 0, deltaF = 0, priorF = 0;
+    float HdiF = 0, bdSumF = 0;
+    double step = 0;
+    bool hasDepthPrior = false;
+    int numGoodResiduals = 0;
+    float idepth_hessian = 0, maxRelBaseline = 0;
+    double uncertainty = 0;
+    bool alive = true;
+};
+
+struct DSOResidual {                                                           // DSOResidual.h:72-156
+    int point = -1, target = -1;
+    int state_state = DSORES_IN, state_NewState = DSORES_OUTLIER;
+    double state_energy = 0, state_NewEnergy = 0, state_NewEnergyWithOutlier = 0;
+    bool isLinearized = false, isActiveAndIsGoodNEW = false;
+    float centerProjectedTo[3] = {0, 0, 0};
+    bool alive = true;
+};
+
+class DSOBundleAdjustment {
+public:
+    explicit DSOBundleAdjustment(cmlhip_ctx* ctx);
+
+    // ---- parameters, names and defaults of BA.h:235-288
+    int    mNumIterations = 4;
+    double mHuberThreshold = 9.0, mSettingOutlierTHSumComponent = 50.0 * 50.0, mThOptIterations = 1.2;
+    double mScaleRotation = 1.0, mScaleTranslation = 0.5, mScaleLightA = 10.0, mScaleLightB = 1000.0, mScaleF = 50.0, mScaleC = 50.0;
+    bool   mForceAccept = true, mFixLambda = true;
+    double mFixedLambda = 1e-5;
+    int    mIdepthFixPrior = 50 * 50;
+    double mSolverModeDelta = 0.00001;
+    bool   mOptimizeA = true, mOptimizeB = true, mMixedBundleAdjustment = false, mAddLinearizedPoints = false;
+    bool   mDisableMarginalization = true, mOptimizeCalibration = false, mAbortBAOnFailture = false;
+    double mCPriorValue = 5e9;                               // BA.cpp:2136-2137 (mCPrior is only assigned inside calcLEnergy)
+
+    // ---- reference interface (BA.h:28-85), flat arguments
+    void setCalibration(double fx, double fy, double cx, double cy, int w, int h);      // BA.cpp:419-425
+    int  addNewFrame(uint64_t image_id, const SE3& worldToCam, const Exposure& exposure);       // BA.cpp:417-462; returns DSOFrame::id
+    int  addPoint(float x, float y, double idepth, int host, const float colors[8], const float weights[8], bool hasDepthPrior);  // addPoints, BA.cpp:382-415
+    bool run(bool updatePointsOnly = false);                                                     // BA.cpp:744-910
+    const std::vector<int>& getOutliers() const { return mOutliers; }                            // point indices dropped by the last run
+    void computeNullspaces(std::vector<double>& out7) const;                                     // BA.cpp:2365-2417
+
+    // ---- state access for the caller (what the reference writes back through Frame/MapPoint setters)
+    std::vector<DSOFrame>& getFrames() { return mFrames; }
+    std::vector<DSOPoint>& getPoints() { return mPoints; }
+    std::vector<DSOResidual>& getResiduals() { return mResiduals; }
+    const std::string& lastError() const { return mError; }
+
+    // ---- statistics of the last run (BA.h:215-233)
+    std::vector<double> statEnergyP, statXNorm, statHessianP, statHessianSC, statBP, statBSC;
+    int lastIterations = 0;
+    double lastLambda = 0;
+    // exposed for tests
+    void computeAdjoints();
+    void computeDelta();
+    const std::vector<double>& adHost() const { return mAdHost; }
+    const std::vector<double>& adTarget() const { return mAdTarget; }
+    const std::vector<float>& adHTdeltaF() const { return mAdHTdeltaF; }
+    void framePairs(std::vector<cmlhip_ba_pair>& out) const;                                     // DSOFramePrecomputed, DSOFrame.h:248-291
+    void orthogonalize(std::vector<double>& x) const;                                            // BA.cpp:1196-1261
+
+private:
+    bool uploadWindow();
+    bool linearizeAll(bool fixLinearization, double energy[3]);
+    bool solveSystem(int iteration, double lambda);
+    bool doStepFromBackup(bool fixCamera);
+    void backupState();
+    void scales(double sc[4]) const { sc[0] = mScaleTranslation; sc[1] = mScaleRotation; sc[2] = mScaleLightA; sc[3] = mScaleLightB; }
+    bool fail(const std::string& what, int rc);
+
+    cmlhip_ctx* mCtx;
+    cmlhip_ba_params mPrm{};
+    bool mHaveCalib = false;
+    int mFrameKeyCounter = 0;
+    std::vector<DSOFrame> mFrames;
+    std::vector<DSOPoint> mPoints;
+    std::vector<DSOResidual> mResiduals;
+    std::vector<int> mActive;                       // indices of residuals uploaded (alive), device order
+    std::vector<int> mActivePoints, mPointSlot;     // device point order <-> mPoints
+    std::vector<int> mOutliers;
+    std::vector<double> mAdHost, mAdTarget, mMarginalizedHessian, mMarginalizedB, mX;
+    std::vector<float> mAdHTdeltaF;
+    double mCDeltaF[4] = {0, 0, 0, 0};
+    std::string mError;
+};
+
+}  // namespace cml_amd

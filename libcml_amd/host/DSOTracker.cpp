@@ -1,0 +1,196 @@
+// DSOTracker.cpp — host mirror of DSOTracker::optimize (TR.cpp = src/cml/optimization/dso/DSOTracker.cpp).
+#include "DSOTracker.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace cml_amd {
+
+bool ldltSolveSmall(const double* Ain, const double* b, int n, double* x) {
+    double A[64], temp[8];
+    int tr[8];
+    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
+#define M(i, j) A[(i) * n + (j)]
+    if (n == 1) tr[0] = 0;
+    else
+        for (int k = 0; k < n; k++) {
+            int big = k; double best = std::fabs(M(k, k));
+            for (int i = k + 1; i < n; i++) if (std::fabs(M(i, i)) > best) { best = std::fabs(M(i, i)); big = i; }
+            tr[k] = big;
+            if (k != big) {
+                for (int j = 0; j < k; j++) std::swap(M(k, j), M(big, j));
+                for (int i = big + 1; i < n; i++) std::swap(M(i, k), M(i, big));
+                std::swap(M(k, k), M(big, big));
+                for (int i = k + 1; i < big; i++) std::swap(M(i, k), M(big, i));
+            }
+            if (k > 0) {
+                double s = 0;
+                for (int j = 0; j < k; j++) { temp[j] = M(j, j) * M(k, j); s += M(k, j) * temp[j]; }
+                M(k, k) -= s;
+                for (int i = k + 1; i < n; i++) { double s2 = 0; for (int j = 0; j < k; j++) s2 += M(i, j) * temp[j]; M(i, k) -= s2; }
+            }
+            const double akk = M(k, k);
+            if (k == 0 && !(std::fabs(akk) > 0.0)) { for (int j = 0; j < n; j++) tr[j] = j; break; }
+            if (std::fabs(akk) > 0.0) for (int i = k + 1; i < n; i++) M(i, k) /= akk;
+        }
+    for (int i = 0; i < n; i++) x[i] = b[i];
+    for (int k = 0; k < n; k++) if (tr[k] != k) std::swap(x[k], x[tr[k]]);
+    for (int i = 0; i < n; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= M(i, j) * x[j]; x[i] = s; }
+    for (int i = 0; i < n; i++) x[i] = (std::fabs(M(i, i)) > 2.2250738585072014e-308) ? x[i] / M(i, i) : 0.0;
+    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < n; j++) s -= M(j, i) * x[j]; x[i] = s; }
+    for (int k = n - 1; k >= 0; k--) if (tr[k] != k) std::swap(x[k], x[tr[k]]);
+#undef M
+    for (int i = 0; i < n; i++) if (!std::isfinite(x[i])) return false;
+    return true;
+}
+
+void inverseSmall(const double* Ain, int n, double* Ai) {
+    double A[64];
+    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Ai[i * n + j] = (i == j);
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        for (int i = k + 1; i < n; i++) if (std::fabs(A[i * n + k]) > std::fabs(A[p * n + k])) p = i;
+        if (p != k) for (int j = 0; j < n; j++) { std::swap(A[k * n + j], A[p * n + j]); std::swap(Ai[k * n + j], Ai[p * n + j]); }
+        const double d = A[k * n + k];
+        for (int j = 0; j < n; j++) { A[k * n + j] /= d; Ai[k * n + j] /= d; }
+        for (int i = 0; i < n; i++)
+            if (i != k) {
+                const double f = A[i * n + k];
+                if (f != 0) for (int j = 0; j < n; j++) { A[i * n + j] -= f * A[k * n + j]; Ai[i * n + j] -= f * Ai[k * n + j]; }
+            }
+    }
+}
+
+bool DSOTracker::makeCoarseDepthL0(uint64_t ref_image_id, int levels, const double* pts, int n, int* n_out) {
+    const int rc = cmlhip_tracker_make_coarse_depth(mCtx, ref_image_id, levels, pts, n, n_out);
+    if (rc) { mError = std::string("cmlhip_tracker_make_coarse_depth: ") + cmlhip_last_error(mCtx); return false; }
+    return true;
+}
+
+DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLevels, SE3& currentRefToNew,
+                                          const Exposure& refExposure, Exposure& currentExposure) {
+    const int maxIterations[] = {10, 20, 50, 50, 50};                     // TR.cpp:23
+    int maxLevel = std::min(pyramidLevels - 1, 4);
+    if (maxLevelOverride >= 0) maxLevel = std::min(maxLevel, maxLevelOverride);
+    Residual oldR, newR;
+    for (Residual* r : {&oldR, &newR}) {
+        r->numTermsInE.assign(maxLevel + 1, 0); r->numRobust.assign(maxLevel + 1, 0); r->numSaturated.assign(maxLevel + 1, 0);
+        r->E.assign(maxLevel + 1, 0.0); r->iterations.assign(maxLevel + 1, 0);
+    }
+    std::vector<double> levelCutoffRepeat(maxLevel + 1, 1.0);
+    bool haveRepeated = false;
+    SE3 newRefToNew;
+    Exposure newExposure = currentExposure;
+    double H[64] = {0}, bvec[8] = {0}, Hn[64], bn[8];
+    cmlhip_tracker_params prm;
+    prm.huber = (float)mHuberThreshold; prm.cutoff_base = (float)mCutoffThreshold;
+    prm.scale_rot = (float)mScaleRotation; prm.scale_trans = (float)mScaleTranslation; prm.scale_a = (float)mScaleLightA; prm.scale_b = (float)mScaleLightB;
+
+    auto eval = [&](int level, const SE3& T, const Exposure& ex, Residual& out, bool wantH, double* Ho, double* bo) -> bool {
+        double R[9], K[4], aff[2];
+        T.matrix(R);
+        const double d = (double)(1 << level);
+        K[0] = mK[0] / d; K[1] = mK[1] / d; K[2] = (mK[2] + 0.5) / d - 0.5; K[3] = (mK[3] + 0.5) / d - 0.5;   // InternalCalibration.h:116-127
+        refExposure.to(ex, aff[0], aff[1]);
+        prm.cutoff = (float)(mCutoffThreshold * levelCutoffRepeat[level]);
+        cmlhip_tracker_result tr;
+        const int rc = cmlhip_tracker_eval(mCtx, new_image_id, level, R, T.t, K, aff, refExposure.b, &prm, wantH ? 1 : 0, &tr);
+        if (rc && rc != CMLHIP_ERR_NONFINITE) { mError = std::string("cmlhip_tracker_eval: ") + cmlhip_last_error(mCtx); return false; }
+        out.E[level] = tr.E; out.numTermsInE[level] = tr.numTermsInE; out.numSaturated[level] = tr.numSaturated; out.numRobust[level] = tr.numRobust;
+        for (int k = 0; k < 3; k++) out.flowVector[k] = tr.flow[k];
+        if (wantH) { std::memcpy(Ho, tr.H, sizeof tr.H); std::memcpy(bo, tr.b, sizeof tr.b); }
+        return true;
+    };
+
+    for (int level = maxLevel; level >= 0; level--) {
+        levelCutoffRepeat[level] = 1;
+        if (!eval(level, currentRefToNew, currentExposure, oldR, true, H, bvec)) { oldR.isCorrect = false; return oldR; }
+        if (oldR.numTermsInE[level] < 20) { oldR.isCorrect = false; return oldR; }                        // TR.cpp:65-69
+        while ((oldR.numSaturated[level] / (double)oldR.numTermsInE[level]) > 0.6 && levelCutoffRepeat[level] < 50) {   // :71-75
+            levelCutoffRepeat[level] *= 2;
+            if (!eval(level, currentRefToNew, currentExposure, oldR, true, H, bvec)) { oldR.isCorrect = false; return oldR; }
+        }
+        if (oldR.numTermsInE[level] - oldR.numSaturated[level] < 10) { oldR.isCorrect = false; return oldR; }            // :77-81
+        double lambda = 0.01;
+        const double lambdaExtrapolationLimit = 0.001;
+        for (int iteration = 0; iteration < maxIterations[level]; iteration++) {
+            oldR.iterations[level] = iteration + 1;
+            double D[64], inc[8] = {0};
+            std::memcpy(D, H, sizeof D);
+            for (int i = 0; i < 8; i++) D[i * 8 + i] *= (1 + lambda);
+            bool ok = true;
+            double nb[8];
+            for (int i = 0; i < 8; i++) nb[i] = -bvec[i];
+            if (mOptimizeA && mOptimizeB) ok = ldltSolveSmall(D, nb, 8, inc);                               // :96-98
+            else if (mOptimizeA && !mOptimizeB) {                                                        // :99-102
+                double S[49], x7[7];
+                for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) S[i * 7 + j] = D[i * 8 + j];
+                ok = ldltSolveSmall(S, nb, 7, x7);
+                for (int i = 0; i < 7; i++) inc[i] = x7[i];
+                inc[7] = 0;
+            } else if (!mOptimizeA && mOptimizeB) {                                                      // :103-114
+                double Hs[64], bs[8], S[49], nb7[7], x7[7];
+                std::memcpy(Hs, D, sizeof Hs); std::memcpy(bs, bvec, sizeof bs);
+                for (int i = 0; i < 8; i++) Hs[i * 8 + 6] = Hs[i * 8 + 7];
+                for (int j = 0; j < 8; j++) Hs[6 * 8 + j] = Hs[7 * 8 + j];
+                bs[6] = bs[7];
+                for (int i = 0; i < 7; i++) { for (int j = 0; j < 7; j++) S[i * 7 + j] = Hs[i * 8 + j]; nb7[i] = -bs[i]; }
+                ok = ldltSolveSmall(S, nb7, 7, x7);
+                for (int i = 0; i < 6; i++) inc[i] = x7[i];
+                inc[6] = 0; inc[7] = x7[6];
+            } else {                                                                                     // :115-119
+                double S[36], x6[6];
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S[i * 6 + j] = D[i * 8 + j];
+                ok = ldltSolveSmall(S, nb, 6, x6);
+                for (int i = 0; i < 6; i++) inc[i] = x6[i];
+            }
+            if (!ok) { oldR.isCorrect = false; return oldR; }                                            // :121-138
+            double extrapFac = 1;
+            if (lambda < lambdaExtrapolationLimit) extrapFac = std::sqrt(std::sqrt(lambdaExtrapolationLimit / lambda));
+            for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+            double incS[8];
+            std::memcpy(incS, inc, sizeof incS);
+            for (int i = 0; i < 3; i++) { incS[i] *= mScaleRotation; incS[3 + i] *= mScaleTranslation; }   // the literal lane/scale pairing, :144-148
+            incS[6] *= mScaleLightA; incS[7] *= mScaleLightB;
+            newRefToNew = SE3::exp(incS) * currentRefToNew;                                              // :155-157
+            newExposure = currentExposure;
+            newExposure.a += incS[6]; newExposure.b += incS[7];                                          // :159
+            if (!eval(level, newRefToNew, newExposure, newR, true, Hn, bn)) { oldR.isCorrect = false; return oldR; }
+            const bool accept = (newR.E[level] / (double)newR.numTermsInE[level]) < (oldR.E[level] / (double)oldR.numTermsInE[level]);   // :163
+            if (accept) {
+                std::memcpy(H, Hn, sizeof H); std::memcpy(bvec, bn, sizeof bvec);                        // computeHessian at the accepted state, :166
+                const std::vector<int> its = oldR.iterations;
+                oldR = newR; oldR.iterations = its;
+                currentRefToNew = newRefToNew;
+                currentExposure.a = newExposure.a; currentExposure.b = newExposure.b;
+                lambda *= 0.5;
+            } else {
+                lambda *= 4;
+            }
+            double nrm = 0;
+            for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+            if (std::sqrt(nrm) < 1e-3) break;                                                             // :176-179
+        }
+        if (levelCutoffRepeat[level] > 1 && !haveRepeated) { level++; haveRepeated = true; }            // :192-195
+    }
+    double relA, relB;
+    refExposure.to(currentExposure, relA, relB);                                                         // :203
+    bool haveGoodLight = true;
+    if (mOptimizeA) { if (std::fabs(currentExposure.a) > 1.2) haveGoodLight = false; }
+    else if (std::fabs(std::log((float)relA)) > 1.5) haveGoodLight = false;
+    if (mOptimizeB) { if (std::fabs(currentExposure.b) > 200) haveGoodLight = false; }
+    else if (std::fabs((float)relB) > 200) haveGoodLight = false;
+    bool haveGoodPoints = true;
+    if ((double)oldR.numSaturated[0] / (double)oldR.numTermsInE[0] > mSaturatedRatioThreshold) haveGoodPoints = false;   // :231-235
+    oldR.isCorrect = haveGoodLight;
+    oldR.tooManySaturated = haveGoodPoints;                                                              // sic, :240
+    oldR.levelCutoffRepeat = levelCutoffRepeat;
+    oldR.relAff[0] = relA; oldR.relAff[1] = relB;
+    double Hi[64];
+    inverseSmall(H, 8, Hi);                                                                              // :243
+    for (int k = 0; k < 6; k++) oldR.covariance[k] = Hi[k * 8 + k];
+    return oldR;
+}
+
+}  // namespace cml_amd

@@ -17,6 +17,7 @@ CONFIGS = {
     "E": (20, 8000, 1920, 1080, 4, 1400.0, 1400.0, 959.5, 539.5),
     "tiny": (3, 64, 160, 120, 2, 140.0, 140.0, 79.5, 59.5),
     "small": (4, 300, 320, 240, 3, 260.0, 260.0, 159.5, 119.5),
+    "medium": (5, 600, 480, 360, 4, 390.0, 390.0, 239.5, 179.5),
 }
 
 
@@ -195,6 +196,6 @@ def residual_list(W, R_eval, t_eval):
             tht = t_eval[t_] - Rht @ t_eval[hst]
             q = Rht @ p + tht * idp
             u = fx * q[0] / q[2] + cx; v = fy * q[1] / q[2] + cy
-            inside = (0 <= u <= W.w - 1) and (0 <= v <= W.h - 1)   # Frame::isInside(p, 0, 0)
+            inside = (0 <= u < W.w) and (0 <= v < W.h)   # Frame::isInside(p, 0, 0), src/cml/map/Frame.h:136-138
             res.append((i, t_, 0 if inside else 1, 0))
     return np.array(res, dtype=[("point", "i4"), ("target", "i4"), ("state", "i4"), ("is_linearized", "i4")])
