@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""bench.py — point-residuals/s (+ Schur-reduce+solve ms) of the sliding-window photometric BA hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 8-keyframe window, 2000 active points (R = 14 000 point-residuals), 1241x376
+KITTI-shape level-0 gradient images, fp32.  One STEP = one Gauss-Newton iteration of DSOBundleAdjustment::run on the
+window, entirely on the device, enqueued back to back on the context stream:
+    backup -> accumulate (13x13 pair blocks, fp64 stitch) -> point Schur rows + fp64 SYRK -> dense 8N solve ->
+    back-substitution -> point step -> residual/Jacobian evaluation of all R residuals -> energy threshold -> apply.
+value = (point-residuals evaluated by all ranks) / (max-over-ranks wall time), inputs resident in HBM.
+N > 1: one process per GPU (torchrun), one independent window (sequence shard) per rank, RCCL used only as the
+start/stop barrier — weak scaling, no data-path collective.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READ_BYTES_PER_RESIDUAL = 468          # 8 px x 4 taps x 12 B + colours 32 + weights 32 + (x,y,idepth) 12 + ids 8
+HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(config, seed, budget_s=12.0):
+    """The oracle (plain-C port of the reference CPU path) timed on this box's host cores, 1 thread, bounded sample."""
+    from tests import ba_setup as S
+    from tests import oracle_lib as O
+    so = os.path.join(ROOT, "oracle", "libcml_oracle_fast.so")
+    try:            # -O3 -march=native build on the box it is timed on (falls back to the portable -O2 build)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        O._lib = None
+        L = C.CDLL(so)
+        L.orc_ba_create.restype = C.POINTER(O.OrcBAWindow)
+        L.orc_ba_linearize_one.restype = C.c_double
+        O._lib = L
+        build = "-O3 -march=native"
+    except Exception:
+        build = "-O2"
+    I = S.make_inputs(config, seed=seed)
+    ob = S.OracleBA(I)
+    ob.linearize(); ob.apply(1)
+    t_lin = t_rest = 0.0
+    iters = 0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < budget_s or iters < 3:
+        t0 = time.perf_counter()
+        O.lib().orc_ba_backup_points(ob.w)
+        H = ob.accumulate()
+        x, rc = ob.solve(1e-5, *H)
+        ob.backsub(x)
+        O.lib().orc_ba_step_points(ob.w, None)
+        t1 = time.perf_counter()
+        ob.linearize(); ob.apply(1)
+        t2 = time.perf_counter()
+        t_rest += t1 - t0; t_lin += t2 - t1
+        iters += 1
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": I.R * iters / (t_lin + t_rest), "unit": "point-residuals/s", "cores": 1, "kind": "port",
+            "sample": "%d Gauss-Newton iterations of the same window (R=%d), oracle C port %s, single thread" % (iters, I.R, build),
+            "linearize_residuals_per_s": I.R * iters / t_lin, "schur_solve_ms": 1e3 * t_rest / iters,
+            "host_cpu": model, "host_logical_cpus": os.cpu_count()}
+
+
+def _dbg(*a):
+    if os.environ.get("CML_BENCH_DEBUG"):
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="B", help="synthetic window (libcml_amd.synth.CONFIGS); B is the benchmark workload")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from libcml_amd import device, host, shard, synth
+    rank, local_rank, world = shard.env_world()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    import torch
+    dev = None
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    group = shard.Group(device=dev)
+
+    _dbg('group ready')
+    seed = 0xC0FFEE
+    W = synth.make_window(args.config, seed=seed, shard=rank)             # one independent sequence shard per rank
+    N, P = W.N, W.P
+    _dbg('window made')
+    ctx = device.Ctx(device_id=local_rank, max_frames=max(N, 2), max_points=P, max_residuals=P * N)
+    ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (rank + 1), levels=1)
+    _dbg('ba built')
+    ba.set_param("iterations", 1)
+    if not ba.run():                                                      # uploads the window, leaves adjoints/priors resident
+        raise RuntimeError("BA run failed: " + ba.last_error())
+    _dbg('run done')
+    _, _, R = ctx.refresh_window_size()      # the window was uploaded by the C++ host mirror
+    lam = 1e-5
+    for _ in range(args.warmup):
+        ctx.ba_iteration_async(lam)
+    _dbg('warmup queued')
+    ctx.profile_enable(args.steps)
+
+    def run_steps():
+        for _ in range(args.steps):
+            ctx.ba_iteration_async(lam)
+
+    def sync():
+        ctx.sync()
+        if dev is not None:
+            torch.cuda.synchronize()
+
+    _dbg('profile enabled')
+    dt = shard.timed_region(group, sync, run_steps)
+    _dbg('timed region done')
+    lin_v, ss_v, _n = ctx.profile_read()
+    lin_ms, ss_ms = C.c_float(lin_v), C.c_float(ss_v)
+    _dbg('profile read')
+    st = ctx.ba_states()
+    n_good = int(st["good"].sum())
+    total_units = group.sum(float(R) * args.steps)
+    lin_ms_max = group.max(lin_ms.value)
+    ss_ms_max = group.max(ss_ms.value)
+
+    _dbg('reductions done')
+    if rank == 0:
+        achieved = R * READ_BYTES_PER_RESIDUAL / (lin_ms.value * 1e-3) / 1e9 if lin_ms.value > 0 else 0.0
+        out = {
+            "metric": "point-residuals/sec + Schur-reduce+solve ms, 8 KF x 2000 pts window",
+            "value": total_units / dt, "unit": "point-residuals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "
+                                   "gradient images, fp32; 1 step = 1 full Gauss-Newton BA iteration on device" % (args.config, N, P, R, W.w, W.h),
+                       "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
+            "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
+            "roofline": {"bound": "hbm", "kernel": "k_ba_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": R * READ_BYTES_PER_RESIDUAL, "launch_us": 1e3 * lin_ms.value},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.config, seed)
+            except Exception as e:      # the checker must never take the measurement down
+                out["cpu_baseline"] = {"value": None, "unit": "point-residuals/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    group.barrier()
+    ba.close(); ctx.close(); group.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -201,6 +201,8 @@ int cmlhip_ba_set_params(cmlhip_ctx* ctx, const cmlhip_ba_params* prm);
 int cmlhip_ba_upload_window(cmlhip_ctx* ctx, int N, const cmlhip_ba_frame* frames,
                             int P, const cmlhip_ba_point* points,
                             int R, const cmlhip_ba_residual* residuals);
+/* sizes of the uploaded window (N frames, P points, R residuals) */
+int cmlhip_ba_window_size(cmlhip_ctx* ctx, int* N, int* P, int* R);
 /* per-iteration state: N*N pair transforms + frame thresholds (ba_update_state) */
 int cmlhip_ba_set_pairs(cmlhip_ctx* ctx, const cmlhip_ba_pair* pairs /* N*N, host*N+target */);
 int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* ctx, const float* th /* N */);
@@ -289,6 +291,11 @@ int cmlhip_event_elapsed_ms(cmlhip_ctx* ctx, float* ms);
 /* enqueue-only variants for throughput measurement: no host readback, no sync */
 int cmlhip_ba_linearize_async(cmlhip_ctx* ctx);
 int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);   /* linearize→apply→accumulate→solve→backsub */
+/* Per-kernel HIP-event timing of the iteration pipeline: when enabled, cmlhip_ba_iteration_async brackets (a) the
+ * residual/Jacobian kernel and (b) the accumulate+Schur+solve+back-substitution group with events on the context
+ * stream.  read returns the mean durations in ms over the recorded iterations and resets the recorder. */
+int cmlhip_profile_enable(cmlhip_ctx* ctx, int max_iterations);
+int cmlhip_profile_read(cmlhip_ctx* ctx, float* linearize_ms, float* schur_solve_ms, int* n_recorded);
 
 #ifdef __cplusplus
 }

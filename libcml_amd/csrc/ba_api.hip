@@ -154,6 +154,14 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     return CMLHIP_OK;
 }
 
+int cmlhip_ba_window_size(cmlhip_ctx* c, int* N, int* P, int* R) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    if (N) *N = c->ba_uploaded ? c->N : 0;
+    if (P) *P = c->ba_uploaded ? c->P : 0;
+    if (R) *R = c->ba_uploaded ? c->R : 0;
+    return CMLHIP_OK;
+}
+
 int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) {
     int rc = ba_check(c, false);
     if (rc) return rc;
@@ -333,15 +341,48 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     if (rc) return rc;
     BAArgs A;
     cml_make_ba_args(c, A);
+    const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap;
+    hipEvent_t* ev = prof ? &c->prof_ev[4 * (size_t)c->prof_n] : nullptr;
+    if (prof) hipEventRecord(ev[0], c->stream);
     cml_launch_backup_points(c, A);
     cml_launch_accumulate(c, A);
     cml_launch_solve(c, A, lambda, false, 0);
     cml_launch_backsub(c, A);
     cml_launch_step_points(c, A);
+    if (prof) { hipEventRecord(ev[1], c->stream); hipEventRecord(ev[2], c->stream); }
     cml_launch_linearize(c, A);
+    if (prof) { hipEventRecord(ev[3], c->stream); c->prof_n++; }
     cml_launch_lin_finish(c, A);
     cml_launch_apply(c, A, 1);
     CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) {
+    if (!c || max_iterations < 0) return CMLHIP_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
+    c->prof_ev.clear();
+    c->prof_cap = max_iterations; c->prof_n = 0;
+    c->prof_ev.resize(4 * (size_t)max_iterations);
+    for (auto& e : c->prof_ev) CML_CHECK(c, hipEventCreate(&e));
+    return CMLHIP_OK;
+}
+
+int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, int* n) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    double a = 0, b = 0;
+    for (int i = 0; i < c->prof_n; i++) {
+        float m0 = 0, m1 = 0;
+        CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[4 * (size_t)i + 0], c->prof_ev[4 * (size_t)i + 1]));
+        CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[4 * (size_t)i + 2], c->prof_ev[4 * (size_t)i + 3]));
+        b += m0; a += m1;
+    }
+    if (n) *n = c->prof_n;
+    if (lin_ms) *lin_ms = c->prof_n ? (float)(a / c->prof_n) : 0.f;
+    if (ss_ms) *ss_ms = c->prof_n ? (float)(b / c->prof_n) : 0.f;
+    c->prof_n = 0;
     return CMLHIP_OK;
 }
 

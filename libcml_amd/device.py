@@ -42,6 +42,9 @@ PROTOTYPES = {
     "cmlhip_ba_set_params": (C.c_int, [_ctx, _P(abi.BAParams)]),
     "cmlhip_ba_upload_window": (C.c_int, [_ctx, _i, _P(abi.BAFrame), _i, _P(abi.BAPoint), _i, _P(abi.BAResidual)]),
     "cmlhip_ba_set_pairs": (C.c_int, [_ctx, _P(abi.BAPair)]),
+    "cmlhip_ba_window_size": (C.c_int, [_ctx, _P(_i), _P(_i), _P(_i)]),
+    "cmlhip_profile_enable": (C.c_int, [_ctx, _i]),
+    "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
     "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
@@ -124,6 +127,21 @@ class Ctx:
         if rc != 0 and rc not in allow:
             raise CmlHipError(rc, (self.L.cmlhip_last_error(self.h) or b"").decode())
         return rc
+
+    def refresh_window_size(self):
+        """N, P, R of the window currently uploaded (it may have been uploaded by the C++ host mirror)."""
+        n, p, r = _i(), _i(), _i()
+        self.ck(self.L.cmlhip_ba_window_size(self.h, C.byref(n), C.byref(p), C.byref(r)))
+        self.N, self.P, self.R = n.value, p.value, r.value
+        return self.N, self.P, self.R
+
+    def profile_enable(self, max_iterations):
+        self.ck(self.L.cmlhip_profile_enable(self.h, max_iterations))
+
+    def profile_read(self):
+        a, b, n = _f(), _f(), _i()
+        self.ck(self.L.cmlhip_profile_read(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     # ------------------------------------------------------------------ pyramids
     def pyramid_put(self, image_id, level, aos3):

@@ -1,0 +1,202 @@
+"""CPU tests of the oracle: pinned against the committed golden vectors (outputs of the reference's vendored
+Eigen 3.4.0 / Sophus 1.1.0, tests/golden/make_thirdparty_vectors.py), against oracle/_ref when it is built, and
+against mathematical identities for the DSO-specific restatements (no reference outputs exist for those)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import ba_setup as S
+from tests import oracle_lib as O
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "thirdparty_vectors.npz"))
+
+
+def test_se3_against_golden_sophus():
+    for i in range(len(G["xi"])):
+        T = O.se3_exp(G["xi"][i])
+        assert np.abs(np.array(T.q[:]) - G["q"][i]).max() < 1e-14
+        assert np.abs(np.array(T.t[:]) - G["t"][i]).max() < 1e-13
+        assert np.abs(O.se3_log(T) - G["log"][i]).max() < 1e-12
+        assert np.abs(O.se3_adj(T).ravel() - G["adj"][i]).max() < 1e-13
+        R, t = O.se3_matrix(T)
+        assert np.abs(R.ravel() - G["R"][i]).max() < 1e-14
+        Ti = O.se3_inv(T)
+        assert np.abs(np.array(Ti.q[:]) - G["q_inv"][i]).max() < 1e-14 and np.abs(np.array(Ti.t[:]) - G["t_inv"][i]).max() < 1e-13
+        j = (i + 7) % len(G["xi"])
+        Tm = O.se3_mul(T, O.se3_exp(G["xi"][j]))
+        assert np.abs(np.array(Tm.q[:]) - G["q_mul"][i]).max() < 1e-14 and np.abs(np.array(Tm.t[:]) - G["t_mul"][i]).max() < 1e-12
+        Tr = O.se3_from_Rt(R, t)
+        q = np.array(Tr.q[:]); qg = G["q_from_R"][i]
+        assert min(np.abs(q - qg).max(), np.abs(q + qg).max()) < 1e-13
+        D = O.se3_dx_exp_x(G["xi"][i])
+        assert np.abs(D.ravel() - G["dx_exp_x"][i]).max() < 1e-9 * max(1.0, np.abs(G["dx_exp_x"][i]).max())
+
+
+def test_ldlt_inverse_orthogonalize_against_golden_eigen():
+    for n in (6, 7, 8, 64, 160):
+        A, b, x = G[f"ldlt_A{n}"], G[f"ldlt_b{n}"], G[f"ldlt_x{n}"]
+        xo, rc = O.ldlt_solve(A, b)
+        assert rc == 0
+        assert np.abs(xo - x).max() <= 1e-9 * np.abs(x).max()
+        assert np.abs(O.inverse(A) - G[f"inv{n}"]).max() <= 1e-8 * np.abs(G[f"inv{n}"]).max()
+    xo, rc = O.ldlt_solve(G["ldlt_indef_A"], G["ldlt_indef_b"])
+    assert np.abs(xo - G["ldlt_indef_x"]).max() <= 1e-10 * np.abs(G["ldlt_indef_x"]).max()
+    xo, rc = O.ldlt_solve(G["ldlt_sing_A"], G["ldlt_sing_b"])         # rank-deficient: same pivot order, same answer class
+    r = G["ldlt_sing_A"] @ xo - G["ldlt_sing_b"]
+    rg = G["ldlt_sing_A"] @ G["ldlt_sing_x"] - G["ldlt_sing_b"]
+    assert np.linalg.norm(r) <= 10 * np.linalg.norm(rg) + 1e-9
+    for name in ("orth68", "orth164", "orth_rankdef"):
+        out = O.orthogonalize(G[name + "_b"], G[name + "_N"], 1e-5)
+        assert np.abs(out - G[name + "_out"]).max() < 1e-12
+
+
+@pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_against_live_reference_thirdparty():
+    R = O.ref()
+    rng = np.random.default_rng(7)
+    d = C.c_double
+    for _ in range(50):
+        xi = rng.normal(size=6) * np.array([2, 2, 2, 1, 1, 1])
+        T = O.se3_exp(xi)
+        q = np.zeros(4); t = np.zeros(3)
+        R.ref_se3_exp(O.ptr(xi, d), O.ptr(q, d), O.ptr(t, d))
+        assert np.abs(np.array(T.q[:]) - q).max() < 1e-14 and np.abs(np.array(T.t[:]) - t).max() < 1e-13
+        D2 = np.zeros(42)
+        R.ref_se3_dx_exp_x(O.ptr(xi, d), O.ptr(D2, d))
+        assert np.abs(O.se3_dx_exp_x(xi).ravel() - D2).max() < 1e-9 * max(1, np.abs(D2).max())
+
+
+def test_pyramid_rules():
+    ws, hs = O.pyramid_sizes(1241, 376)
+    assert ws == [1241, 620, 310, 155, 77] and hs == [376, 188, 94, 47, 23]
+    ws, hs = O.pyramid_sizes(640, 480)
+    assert ws == [640, 320, 160, 80, 40] and hs == [480, 240, 120, 60, 30]
+    rng = np.random.default_rng(0)
+    g = rng.uniform(0, 255, size=(9, 11)).astype(np.float32)
+    grays, grads = O.build_pyramid(g, 2)
+    assert grays[1].shape == (4, 5)
+    assert grays[1][1, 2] == np.float32((((g[2, 4] + g[2, 5]) + g[3, 4]) + g[3, 5]) / np.float32(4))
+    assert np.all(grads[0][0] == 0) and np.all(grads[0][:, 0] == 0) and np.all(grads[0][-1] == 0)
+    assert grads[0][3, 4, 1] == np.float32((g[3, 5] - g[3, 3]) * np.float32(0.5))
+    assert grads[0][3, 4, 2] == np.float32((g[4, 4] - g[2, 4]) * np.float32(0.5))
+    v = O.interpolate3(grads[0], 4.25, 3.5)
+    a = grads[0]
+    expect = a[3, 4] * np.float32(1 - .25 - .5 + .125) + a[3, 5] * np.float32(.25 - .125) + a[4, 4] * np.float32(.5 - .125) + a[4, 5] * np.float32(.125)
+    assert np.allclose(v, expect, rtol=1e-6)
+
+
+def _dense_system(I, ob):
+    """Build J (one row per pattern pixel) from the oracle's raw records and the adjoints: the textbook form of the
+    system that addToHessianTop / addToHessianSC / stitch* assemble blockwise."""
+    N, P, R = I.N, I.P, I.R
+    st = ob.states(); J = ob.rJ(1)
+    n = 8 * N
+    AH = I.adH.reshape(N * N, 8, 8); AT = I.adT.reshape(N * N, 8, 8)
+    rows, rhs = [], []
+    for r in range(R):
+        if not st["good"][r]:
+            continue
+        p = I.residuals["point"][r]; t = I.residuals["target"][r]; h = I.points["host"][p]
+        j = J[r]
+        for k in range(8):
+            jp = np.zeros(8)
+            jp[:6] = j[30 + k] * j[8:14] + j[38 + k] * j[14:20]
+            jp[6] = j[46 + k]; jp[7] = j[54 + k]
+            row = np.zeros(n + P)
+            row[8 * h:8 * h + 8] += AH[h + t * N] @ jp
+            row[8 * t:8 * t + 8] += AT[h + t * N] @ jp
+            row[n + p] = j[30 + k] * j[28] + j[38 + k] * j[29]
+            rows.append(row); rhs.append(j[k])
+    return np.array(rows), np.array(rhs)
+
+
+@pytest.mark.parametrize("config", ["tiny", "small"])
+def test_accumulate_schur_equal_dense_normal_equations(config):
+    I = S.make_inputs(config)
+    ob = S.OracleBA(I)
+    ob.linearize(); ob.apply(1)
+    HA, bA, HL, bL, Hsc, bsc = ob.accumulate()
+    Jm, rv = _dense_system(I, ob)
+    n = 8 * I.N
+    H = Jm.T @ Jm; b = Jm.T @ rv
+    assert np.abs(HA[4:, 4:] - H[:n, :n]).max() <= 2e-6 * np.abs(H[:n, :n]).max()
+    assert np.abs(bA[4:] - b[:n]).max() <= 2e-6 * np.abs(b[:n]).max()
+    Hdd = np.diag(H[n:, n:]).copy()
+    Hdi = np.where(Hdd > 0, 1 / np.maximum(Hdd, 1e-10), 0)
+    Hpd = H[:n, n:]
+    assert np.abs(Hsc[4:, 4:] - (Hpd * Hdi) @ Hpd.T).max() <= 5e-6 * np.abs(Hsc).max()
+    assert np.abs(bsc[4:] - (Hpd * Hdi) @ b[n:]).max() <= 5e-6 * np.abs(bsc).max()
+    assert np.allclose(HL[4:, 4:], np.diag(I.prior)) and np.allclose(bL[4:], I.prior * I.dprior)
+    # back-substitution = the point rows of the full solve
+    x, rc = ob.solve(1e-5, HA, bA, HL, bL, Hsc, bsc)
+    step, rc = ob.backsub(x)
+    sd = -Hdi * (b[n:] - Hpd.T @ x[4:])
+    assert np.abs(step - sd).max() <= 1e-4 * np.abs(sd).max()
+
+
+def test_geometric_jacobians_match_finite_differences():
+    """At a relative pose with unit depth scale (q_z = 1) the reference's un-normalised u,v (BA.cpp:121-122) coincide with
+    the normalised ones, so Jpdxi / Jpdd / the image gradient must be the true derivatives there."""
+    I = S.make_inputs("tiny", eval_noise=0.0, idepth_noise=0.0, state_noise=0.0)
+    ob = S.OracleBA(I)
+    fx, fy, cx, cy = I.W.K
+    base = I.pairs.copy()
+    hst = int(I.points["host"][I.residuals["point"][0]]); tgt = int(I.residuals["target"][0])
+    q = hst * I.N + tgt
+    base["R"][q] = np.eye(3).ravel(); base["t"][q] = [0.2, -0.1, 0.0]
+    base["R0"][q] = base["R"][q]; base["t0"][q] = base["t"][q]
+    base["aff_a"][q] = 1.0; base["aff_b"][q] = 0.0
+
+    def centre(pairs):
+        ob.set_pairs(pairs)
+        w = ob.w.contents
+        w.r_state[0] = 0
+        O.lib().orc_ba_linearize_one(ob.w, 0)
+        return np.array([w.r_center[0], w.r_center[1]], np.float64), ob.rJ(0)[0].copy()
+
+    c0, rj = centre(base)
+    assert ob.w.contents.r_new_state[0] != 1, "test residual must project inside"
+    eps = 2e-3
+    for k in range(6):
+        xi = np.zeros(6); xi[k] = eps
+        T = O.se3_mul(O.se3_exp(xi), O.se3_from_Rt(np.eye(3), base["t"][q]))
+        Rm, tm = O.se3_matrix(T)
+        pp = base.copy(); pp["R"][q] = Rm.ravel(); pp["t"][q] = tm
+        cp, _ = centre(pp)
+        xi[k] = -eps
+        T = O.se3_mul(O.se3_exp(xi), O.se3_from_Rt(np.eye(3), base["t"][q]))
+        Rm, tm = O.se3_matrix(T)
+        pm = base.copy(); pm["R"][q] = Rm.ravel(); pm["t"][q] = tm
+        cm, _ = centre(pm)
+        fd = (cp - cm) / (2 * eps)
+        an = np.array([rj[8 + k], rj[14 + k]])
+        assert np.abs(fd - an).max() <= 2e-2 * max(1.0, np.abs(an).max()), (k, fd, an)
+    # d(Ku,Kv)/d(idepth) = Jpdd
+    p = int(I.residuals["point"][0])
+    id0 = ob.w.contents.points[p].idepth
+    ob.w.contents.points[p].idepth = id0 * (1 + 1e-3); cp, _ = centre(base)
+    ob.w.contents.points[p].idepth = id0 * (1 - 1e-3); cm, _ = centre(base)
+    ob.w.contents.points[p].idepth = id0
+    fd = (cp - cm) / (2e-3 * id0)
+    assert np.abs(fd - rj[28:30]).max() <= 2e-2 * max(1.0, np.abs(rj[28:30]).max())
+
+
+def test_linearize_edge_cases():
+    I = S.make_inputs("tiny")
+    ob = S.OracleBA(I)
+    w = ob.w.contents
+    # a residual that enters OOB stays OOB, keeps its energy, record untouched (BA.cpp:68-72)
+    w.r_state[3] = 1; w.r_energy[3] = 42.0
+    before = ob.rJ(0)[3].copy()
+    e = O.lib().orc_ba_linearize_one(ob.w, 3)
+    assert e == 42.0 and w.r_new_energy_wo[3] == -1 and np.array_equal(ob.rJ(0)[3], before)
+    # centre projected out of the image -> NewState OOB (BA.cpp:115-118)
+    p = int(I.residuals["point"][5])
+    w.points[p].x = np.float32(I.W.w + 50.0)
+    w.r_state[5] = 0
+    O.lib().orc_ba_linearize_one(ob.w, 5)
+    assert w.r_new_state[5] == 1
+    # empty window
+    ob.linearize()
