@@ -3,17 +3,24 @@
 // stitchDoubleTop (BA.cpp:1781-1878), addToHessianSC + stitchDoubleSC (BA.cpp:1880-2043),
 // solveLevenbergMarquardt's factorisation (BA.cpp:1284-1320) and the resubstitution loop (BA.cpp:1427-1487).
 //
-// Design (MI355X-first, not a translation):
-//  * top: residuals are grouped by (host,target) on upload; one workgroup per pair keeps the 91 unique entries
-//    of the 13x13 block in registers per lane, reduces them with wave shuffles + one LDS hop, and immediately
-//    applies the fp64 adjoint sandwiches (AH B AH^T, ...) so the 13x13 never leaves the CU in fp32 only.
-//  * Schur: the reference buckets rank-1 8x8 tiles into N^3 accumulators and then does an O(N^3) stitch.  Here
-//    each point's coupling row g_p = dH/d(idepth) is formed directly in frame coordinates (AH/AT applied per
-//    residual, 8 lanes per point), and H_sc = G^T diag(HdiF) [G | bdSum] is one fp64 SYRK on the matrix cores
-//    (v_mfma_f64_16x16x4_f64), K-split over point chunks with a fixed-order reduction.  Same sums, no N^3 pass.
-//  * solve: Jacobi-scaled LDL^T of the trailing 8N block in LDS (fp64, packed lower storage), one workgroup.
+// Design (MI355X-first, not a translation).  One Gauss-Newton iteration is FOUR dependent launches after the
+// residual kernel, each of them horizontally fused so that no single-workgroup stage sits alone on the chip:
+//  K3 k_ba_acc      blocks [0,N^2): one workgroup per (host,target) pair — 4 lanes per residual, each wave owns a
+//                   quarter of the 91 unique entries of the 13x13 block, wave-shuffle reduction, then the fp64
+//                   adjoint sandwiches (AH B AH^T, ...) straight from LDS.
+//                   blocks [N^2,..): 8 lanes per point — Hdd/bd/Hcd, HdiF, and the point's coupling row
+//                   g_p = dH/d(idepth) in FRAME coordinates (AH/AT applied per residual).
+//  K4 k_ba_system   one workgroup per 16x16 tile of the (8N+4)^2 system: H_sc = G^T diag(HdiF) [G | bdSum] as an
+//                   fp64 SYRK on the matrix cores (v_mfma_f64_16x16x4_f64, waves split the point range, fixed-order
+//                   LDS reduction), plus the tile of H_A / H_L (pair blocks + priors) and of the final LM system.
+//                   The reference's N^3 bucket accumulators and O(N^3) stitch (BA.cpp:1939-2043) do not exist here.
+//  K5 k_ba_solve    workgroup 0: Jacobi scaling + blocked LDL^T of the trailing 8N block in LDS (fp64, block-packed
+//                   lower storage, MFMA trailing updates); workgroup 1: energy sum + exact 70th-percentile
+//                   threshold of the newest frame (radix select) for the NEXT residual pass.
+//  K6 k_ba_backsub  xAd in LDS, per-point step, point update (doStepFromBackup), fixed-order partial sums.
 #include "cmlhip_internal.h"
 #include "ba_common.h"
+#include "ba_finish.h"
 
 typedef double double4_ __attribute__((ext_vector_type(4)));
 
@@ -23,24 +30,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// ------------------------------------------------------------------------------------------------ top
-// grid = N*N workgroups (pair q = host + target*N, BA.cpp:1677), 256 threads.
-template <bool LIN>
-__global__ __launch_bounds__(256) void k_ba_acc_top(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
-                                                    const float* __restrict__ adHTd, const double* __restrict__ cdelta,
-                                                    float* __restrict__ acc_out, int* __restrict__ num_out,
-                                                    double* __restrict__ pair_blocks) {
-    __shared__ float s_red[4][ACC_STRIDE];
-    __shared__ int s_cnt[4];
+struct AccArgs {
+    const double* adH; const double* adT; const float* adHTd; const double* cdelta;
+    float* acc_out; int* num_out; double* pair_blocks;
+    double* G; double* Wt; int ldg; int do_backup;
+};
+
+// ------------------------------------------------------------------------------------------------ K3
+__device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const bool LIN) {
+    __shared__ float s_acc[ACC_STRIDE];
+    __shared__ int s_cnt;
     __shared__ double s_H[13][13];
     __shared__ double s_AH[64], s_AT[64], s_T1[64], s_T2[64];
-    const int q = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-    float acc[91];
+    const int tid = threadIdx.x, part = tid >> 6, ln = tid & 63;
+    // up to 25 accumulators per lane; which 13x13 entries they are depends on the wave (part):
+    //   part 0: upper-triangle rows 0,1 (19) + bottom-right 3x3 (6)       part 1: rows 2,3,4 (21)
+    //   part 2: rows 5..9 (15) + top-right rows 0..2 (9)                   part 3: top-right rows 3..9 (21)
+    float acc[25];
 #pragma unroll
-    for (int i = 0; i < 91; i++) acc[i] = 0.f;
+    for (int i = 0; i < 25; i++) acc[i] = 0.f;
     int cnt = 0;
     const int beg = A.by_pair_off[q], end = A.by_pair_off[q + 1];
-    for (int i = beg + tid; i < end; i += 256) {
+    for (int i = beg + ln; i < end; i += 64) {
         const int r = A.by_pair[i];
         const bool lin = A.r_lin[r] != 0;
         if (LIN ? (!lin || !A.r_good[r]) : (lin || !A.r_good[r])) continue;      // BA.cpp:1662-1669
@@ -56,12 +67,12 @@ __global__ __launch_bounds__(256) void k_ba_acc_top(BAArgs A, const double* __re
             JIr0 = J[O_X_JIR]; JIr1 = J[O_X_JIR + 1]; Jabr0 = J[O_X_JABR]; Jabr1 = J[O_X_JABR + 1]; rr = J[O_X_RR];
         } else {
             // BA.cpp:1699-1729 (res_toZero + J*delta; see oracle note on the reference's float*/double[8] store)
-            const float* dp = adHTd + 8 * q;
+            const float* dp = X.adHTd + 8 * q;
             const int p = A.r_point[r];
             const float dd = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
             float jdx = 0, jdy = 0, cx = 0, cy = 0;
             for (int j = 0; j < 6; j++) { jdx += J[O_XI0 + j] * dp[j]; jdy += J[O_XI1 + j] * dp[j]; }
-            for (int j = 0; j < 4; j++) { cx += J[O_C0 + j] * (float)cdelta[j]; cy += J[O_C1 + j] * (float)cdelta[j]; }
+            for (int j = 0; j < 4; j++) { cx += J[O_C0 + j] * (float)X.cdelta[j]; cy += J[O_C1 + j] * (float)X.cdelta[j]; }
             const float Jpx = jdx + cx + J[O_DD] * dd, Jpy = jdy + cy + J[O_DD + 1] * dd;
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0; float srr = 0;
             for (int j = 0; j < 8; j++) {
@@ -75,41 +86,65 @@ __global__ __launch_bounds__(256) void k_ba_acc_top(BAArgs A, const double* __re
             }
             JIr0 = (float)s0; JIr1 = (float)s1; Jabr0 = (float)s2; Jabr1 = (float)s3; rr = srr;
         }
-        // AccumulatorApprox::update, ACC.h:776-858: 10x10 upper triangle of [x y][a b; b c][x y]^T
-        int idx = 0;
+        // AccumulatorApprox::update (ACC.h:776-858): entry (r_,c_) of the 10x10 upper triangle of [x y][a b; b c][x y]^T
+#define UP(k, r_, c_) acc[k] += a * x[c_] * x[r_] + c * y[c_] * y[r_] + b * (x[c_] * y[r_] + y[c_] * x[r_])
+        // updateTopRight (ACC.h:861-916): row j, columns {JabJIdx(0,.), JabJIdx(1,.), JI^T r}
+#define TRW(k, j) { acc[k] += x[j] * J[O_JABJI + 0] + y[j] * J[O_JABJI + 2]; acc[(k) + 1] += x[j] * J[O_JABJI + 1] + y[j] * J[O_JABJI + 3]; \
+                    acc[(k) + 2] += x[j] * JIr0 + y[j] * JIr1; }
+        if (part == 0) {
 #pragma unroll
-        for (int rr_ = 0; rr_ < 10; rr_++)
+            for (int cc = 0; cc < 10; cc++) UP(cc, 0, cc);
 #pragma unroll
-            for (int cc = rr_; cc < 10; cc++) {
-                acc[idx] += a * x[cc] * x[rr_] + c * y[cc] * y[rr_] + b * (x[cc] * y[rr_] + y[cc] * x[rr_]);
-                idx++;
-            }
-        // updateTopRight, ACC.h:861-916 (TR00,TR10 = JabJIdx(0,0),(0,1); TR01,TR11 = (1,0),(1,1); TR02,TR12 = JI^T r)
-        const float TR00 = J[O_JABJI + 0], TR10 = J[O_JABJI + 2], TR01 = J[O_JABJI + 1], TR11 = J[O_JABJI + 3];
+            for (int cc = 1; cc < 10; cc++) UP(9 + cc, 1, cc);
+            // updateBotRight, ACC.h:918-932
+            acc[19] += J[O_JAB2 + 0]; acc[20] += J[O_JAB2 + 2]; acc[21] += Jabr0;
+            acc[22] += J[O_JAB2 + 3]; acc[23] += Jabr1; acc[24] += rr;
+            cnt++;
+        } else if (part == 1) {
 #pragma unroll
-        for (int j = 0; j < 10; j++) {
-            acc[55 + 3 * j + 0] += x[j] * TR00 + y[j] * TR10;
-            acc[55 + 3 * j + 1] += x[j] * TR01 + y[j] * TR11;
-            acc[55 + 3 * j + 2] += x[j] * JIr0 + y[j] * JIr1;
+            for (int cc = 2; cc < 10; cc++) UP(cc - 2, 2, cc);
+#pragma unroll
+            for (int cc = 3; cc < 10; cc++) UP(8 + cc - 3, 3, cc);
+#pragma unroll
+            for (int cc = 4; cc < 10; cc++) UP(15 + cc - 4, 4, cc);
+        } else if (part == 2) {
+#pragma unroll
+            for (int cc = 5; cc < 10; cc++) UP(cc - 5, 5, cc);
+#pragma unroll
+            for (int cc = 6; cc < 10; cc++) UP(5 + cc - 6, 6, cc);
+#pragma unroll
+            for (int cc = 7; cc < 10; cc++) UP(9 + cc - 7, 7, cc);
+            UP(12, 8, 8); UP(13, 8, 9); UP(14, 9, 9);
+            TRW(15, 0); TRW(18, 1); TRW(21, 2);
+        } else {
+            TRW(0, 3); TRW(3, 4); TRW(6, 5); TRW(9, 6); TRW(12, 7); TRW(15, 8); TRW(18, 9);
         }
-        // updateBotRight, ACC.h:918-932
-        acc[85] += J[O_JAB2 + 0]; acc[86] += J[O_JAB2 + 2]; acc[87] += Jabr0;
-        acc[88] += J[O_JAB2 + 3]; acc[89] += Jabr1; acc[90] += rr;
-        cnt++;
+#undef UP
+#undef TRW
     }
+    // wave reduction and scatter into the canonical 91-entry order (55 upper-tri row-major, 30 top-right, 6 bottom-right)
 #pragma unroll
-    for (int i = 0; i < 91; i++) {
-        const float v = wave_sum(acc[i]);
-        if (ln == 0) s_red[wv][i] = v;
+    for (int k = 0; k < 25; k++) {
+        const float v = wave_sum(acc[k]);
+        if (ln == 0) {
+            int dst = -1;
+            if (part == 0) dst = k < 19 ? k : 85 + (k - 19);
+            else if (part == 1) { if (k < 21) dst = 19 + k; }
+            else if (part == 2) { if (k < 15) dst = 40 + k; else if (k < 24) dst = 55 + (k - 15); }
+            else { if (k < 21) dst = 64 + k; }
+            if (dst >= 0) s_acc[dst] = v;
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if (ln == 0) s_cnt[wv] = cnt;
-    if (tid < 64) { s_AH[tid] = adH[64 * (size_t)q + tid]; s_AT[tid] = adT[64 * (size_t)q + tid]; }
+    if (part == 0) {
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (ln == 0) s_cnt = cnt;
+    }
+    if (tid < 64) { s_AH[tid] = X.adH[64 * (size_t)q + tid]; s_AT[tid] = X.adT[64 * (size_t)q + tid]; }
     __syncthreads();
     if (tid < 91) {
-        const float v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
-        acc_out[(size_t)q * ACC_STRIDE + tid] = v;
-        // scatter into the symmetric 13x13 (AccumulatorApprox::finish, ACC.h:639-673)
+        const float v = s_acc[tid];
+        X.acc_out[(size_t)q * ACC_STRIDE + tid] = v;
+        // symmetric 13x13 (AccumulatorApprox::finish, ACC.h:639-673)
         int rr_, cc;
         if (tid < 55) {
             int k = tid; rr_ = 0;
@@ -118,15 +153,16 @@ __global__ __launch_bounds__(256) void k_ba_acc_top(BAArgs A, const double* __re
         } else if (tid < 85) {
             rr_ = (tid - 55) / 3; cc = 10 + (tid - 55) % 3;
         } else {
-            const int m[6][2] = {{10, 10}, {10, 11}, {10, 12}, {11, 11}, {11, 12}, {12, 12}};
-            rr_ = m[tid - 85][0]; cc = m[tid - 85][1];
+            const int e = tid - 85;
+            rr_ = e < 3 ? 10 : (e < 5 ? 11 : 12);
+            cc = e < 3 ? 10 + e : (e < 5 ? 11 + (e - 3) : 12);
         }
         s_H[rr_][cc] = (double)v; s_H[cc][rr_] = (double)v;
     }
-    if (tid == 0) num_out[q] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (tid == 0) X.num_out[q] = s_cnt;
     __syncthreads();
     // ---- stitchDoubleTop per-pair products, BA.cpp:1827-1843 (fp64)
-    double* pb = pair_blocks + (size_t)q * PB_STRIDE;
+    double* pb = X.pair_blocks + (size_t)q * PB_STRIDE;
     if (tid < 64) {
         const int a = tid >> 3, b = tid & 7;
         double t1 = 0, t2 = 0;
@@ -165,76 +201,22 @@ __global__ __launch_bounds__(256) void k_ba_acc_top(BAArgs A, const double* __re
     }
 }
 
-// assemble (8N+4)^2 from the per-pair blocks, incl. priors and the symmetrisation of BA.cpp:1857-1876.
-// one thread per output element (+ n threads for b).  use_blocks = 0 gives the prior-only matrix.
-__global__ void k_ba_assemble_top(int N, const double* __restrict__ pb, int use_blocks, int use_prior,
-                                  const double* __restrict__ cdelta, const double* __restrict__ cprior,
-                                  const double* __restrict__ prior, const double* __restrict__ dprior,
-                                  double* __restrict__ H, double* __restrict__ bvec) {
-    const int n = 8 * N + 4;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * n + n) return;
-    if (e >= n * n) {                                   // b
-        const int I = e - n * n;
-        double s = 0;
-        if (I < 4) {
-            if (use_blocks) for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + PB_BC + I];
-            if (use_prior) s += cprior[I] * cdelta[I];
-        } else {
-            const int a = (I - 4) >> 3, i = (I - 4) & 7;
-            if (use_blocks) {
-                for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_BH + i];
-                for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_BT + i];
-            }
-            if (use_prior) s += prior[8 * a + i] * dprior[8 * a + i];
-        }
-        bvec[I] = s;
-        return;
-    }
-    int I = e / n, Jc = e % n;
-    double s = 0;
-    if (I < 4 && Jc < 4) {
-        if (use_blocks) for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + PB_CC + I * 4 + Jc];
-        if (use_prior && I == Jc) s += cprior[I];
-    } else if (I < 4 || Jc < 4) {
-        const int F = I < 4 ? Jc : I, C = I < 4 ? I : Jc;       // frame row, calib column (mirrored, :1869)
-        const int a = (F - 4) >> 3, i = (F - 4) & 7;
-        if (use_blocks) {
-            for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_HC + i * 4 + C];
-            for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_TC + i * 4 + C];
-        }
-    } else {
-        const int a = (I - 4) >> 3, i = (I - 4) & 7, b = (Jc - 4) >> 3, j = (Jc - 4) & 7;
-        if (a == b) {
-            if (use_blocks) {
-                for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_HH + i * 8 + j];
-                for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_TT + i * 8 + j];
-            }
-            if (use_prior && i == j) s += prior[8 * a + i];
-        } else if (use_blocks) {
-            s = pb[(size_t)(a + b * N) * PB_STRIDE + PB_HT + i * 8 + j] + pb[(size_t)(b + a * N) * PB_STRIDE + PB_HT + j * 8 + i];
-        }
-    }
-    H[(size_t)I * n + Jc] = s;
-}
-
-// ------------------------------------------------------------------------------------------------ Schur rows
 // 8 lanes per point.  Per point: Hdd/bd/Hcd sums (BA.cpp:1747-1750), HdiF, bdSum (BA.cpp:1895-1905); row
 // g_p[0:4] = Hcd, g_p[4+8h+i] = sum_r (AH_ht JpJdF_r)_i, g_p[4+8t+i] = (AT_ht JpJdF_r)_i, G[p][n] = bdSum.
-__global__ __launch_bounds__(256) void k_ba_point_schur(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
-                                                        double* __restrict__ G, double* __restrict__ Wt, int ldg) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs& X, const int blk) {
+    const int gid = blk * 256 + threadIdx.x;
     const int p = gid >> 3, i = gid & 7;
     if (p >= A.P) return;
     const int host = A.pt_host[p];
     const int beg = A.by_point_off[p], end = A.by_point_off[p + 1];
-    double* row = G + (size_t)p * ldg;
+    double* row = X.G + (size_t)p * X.ldg;
     // zero-fill: every lane clears exactly the columns it may write below, so store order is per-lane program order
     for (int f = 0; f < A.N; f++) row[4 + 8 * f + i] = 0.0;
     if (i < 4) row[i] = 0.0;
     if (i == 4) row[A.n] = 0.0;
-    if (i == 5) for (int cix = A.n + 1; cix < ldg; cix++) row[cix] = 0.0;
-    float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, bdL = 0, HcdL[4] = {0, 0, 0, 0};
+    if (i == 5) for (int cix = A.n + 1; cix < X.ldg; cix++) row[cix] = 0.0;
+    if (X.do_backup && i == 6) A.pt_backup[p] = (float)A.pt_idepth[p];          // backupState, BA.cpp:919-922
+    float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, HcdL[4] = {0, 0, 0, 0};
     int ngood = 0;
     double hostacc = 0;
     for (int kk = beg; kk < end; kk++) {
@@ -244,7 +226,6 @@ __global__ __launch_bounds__(256) void k_ba_point_schur(BAArgs A, const double* 
         const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
         const int t = A.r_target[r];
         const int q = host + t * A.N;
-        // per-point scalars: ACTIVE residuals use the linearize-time JI^T r; LINEARIZED ones are folded by the host path
         const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
         const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
         if (!A.r_lin[r]) {
@@ -253,23 +234,18 @@ __global__ __launch_bounds__(256) void k_ba_point_schur(BAArgs A, const double* 
 #pragma unroll
             for (int j = 0; j < 4; j++) HcdA[j] += J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
         } else {
-            // BA.cpp:1699-1729 in LINEARIZED mode: JI^T r with r = res_toZero + J*delta is recomputed here
             HddL += g0 * J[O_DD] + g1 * J[O_DD + 1];
 #pragma unroll
             for (int j = 0; j < 4; j++) HcdL[j] += J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
-            // bdL needs adHTdeltaF/cdelta; it is accumulated by k_ba_point_bdL (rare path)
+            // bdL needs adHTdeltaF/cdelta: accumulated by k_ba_point_bdL (rare path) into pt_acc[7]
         }
         const float* v = A.r_jpjdf + 8 * (size_t)r;
-        const double* AH = adH + 64 * (size_t)q + 8 * i;
-        double ah = 0;
+        const double* AH = X.adH + 64 * (size_t)q + 8 * i;
+        const double* AT = X.adT + 64 * (size_t)q + 8 * i;
+        double ah = 0, at = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) ah += AH[j] * (double)v[j];
+        for (int j = 0; j < 8; j++) { ah += AH[j] * (double)v[j]; at += AT[j] * (double)v[j]; }
         hostacc += ah;
-        // AT is diagonal by construction (BA.cpp:1078-1092) but is applied as a full row for generality
-        const double* AT = adT + 64 * (size_t)q + 8 * i;
-        double at = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) at += AT[j] * (double)v[j];
         row[4 + 8 * t + i] = at;
     }
     float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
@@ -290,211 +266,15 @@ __global__ __launch_bounds__(256) void k_ba_point_schur(BAArgs A, const double* 
         pa[0] = HddA; pa[1] = bdA; pa[2] = HcdA[0]; pa[3] = HcdA[1]; pa[4] = HcdA[2]; pa[5] = HcdA[3];
         pa[6] = HddL; pa[8] = HcdL[0]; pa[9] = HcdL[1]; pa[10] = HcdL[2]; pa[11] = HcdL[3];
         pa[12] = HdiF; pa[13] = bdSum;
-        Wt[p] = (double)HdiF;
+        X.Wt[p] = (double)HdiF;
     }
 }
 
-// H_aug = G^T diag(w) [G | bdSum] : one wave per (tile_i <= tile_j, point chunk); fp64 matrix cores.
-// A[i][k] = G[p0+k][i0+i], B[k][j] = w[p0+k] G[p0+k][j0+j]; D: col = lane&15, row = (lane>>4) + 4*reg.
-#define SYRK_CHUNK 64
-__global__ __launch_bounds__(64) void k_ba_schur_syrk(const double* __restrict__ G, const double* __restrict__ Wt, int P,
-                                                      int ldg, int ntile, double* __restrict__ part) {
-    const int tile = blockIdx.x, chunk = blockIdx.y, l = threadIdx.x;
-    // unrank the upper-triangular tile index
-    int ti = 0, rem = tile;
-    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
-    const int tj = ti + rem;
-    const int p0 = chunk * SYRK_CHUNK;
-    double4_ acc = {0.0, 0.0, 0.0, 0.0};
-    const int kk = l >> 4, c = l & 15;
-#pragma unroll 4
-    for (int s = 0; s < SYRK_CHUNK; s += 4) {
-        const int p = p0 + s + kk;
-        double a = 0.0, b = 0.0;
-        if (p < P) {
-            const double* row = G + (size_t)p * ldg;
-            a = row[16 * ti + c];
-            b = Wt[p] * row[16 * tj + c];
-        }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    double* o = part + ((size_t)chunk * gridDim.x + tile) * 256;
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) o[(kk + 4 * rg) * 16 + c] = acc[rg];
-}
-
-// fixed-order reduction of the chunk partials into H_sc (mirrored) and b_sc
-__global__ void k_ba_schur_finish(const double* __restrict__ part, int nchunk, int ntile, int ntiles_ut, int n,
-                                  double* __restrict__ Hsc, double* __restrict__ bsc) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * (n + 1)) return;
-    const int I = e / (n + 1), Jc = e % (n + 1);
-    int r = I, c = Jc;
-    if (Jc < n && Jc < I) { r = Jc; c = I; }           // lower triangle: read the mirrored element
-    const int ti = r >> 4, tj = c >> 4;
-    // rank of (ti,tj), ti <= tj
-    int tile = 0;
-    for (int k = 0; k < ti; k++) tile += ntile - k;
-    tile += tj - ti;
-    const int off = (r & 15) * 16 + (c & 15);
-    double s = 0;
-    for (int ch = 0; ch < nchunk; ch++) s += part[((size_t)ch * ntiles_ut + tile) * 256 + off];
-    if (Jc == n) bsc[I] = s;
-    else Hsc[(size_t)I * n + Jc] = s;
-}
-
-// ------------------------------------------------------------------------------------------------ solve
-// One workgroup.  H = HL + HM + HA, diag*(1+lambda), - Hsc/(1+lambda); S = 1/sqrt(diag+10); LDL^T (no pivoting:
-// the scaled matrix is SPD with unit-order diagonal) of rows/cols [off, n) in packed lower LDS storage.
-__global__ __launch_bounds__(256) void k_ba_solve(int n, int off, double lambda, const double* __restrict__ HA,
-                                                  const double* __restrict__ bA, const double* __restrict__ HL,
-                                                  const double* __restrict__ bL, const double* __restrict__ HM,
-                                                  const double* __restrict__ bM, const double* __restrict__ Hsc,
-                                                  const double* __restrict__ bsc, double* __restrict__ x, int* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int m = n - off, tid = threadIdx.x;
-    double* L = sm;                              // m(m+1)/2
-    double* S = L + (size_t)m * (m + 1) / 2;     // m
-    double* y = S + m;                           // m
-    const double f = 1.0 / (1 + lambda);
-#define LT(i, j) L[(size_t)(i) * ((i) + 1) / 2 + (j)]
-    for (int i = tid; i < m; i += 256) {
-        const size_t d = (size_t)(off + i) * n + off + i;
-        double h = (HL[d] + (HM ? HM[d] : 0.0)) + HA[d];
-        h *= (1 + lambda);
-        h -= Hsc[d] * f;
-        S[i] = 1.0 / sqrt(h + 10.0);
-    }
-    __syncthreads();
-    for (int e = tid; e < m * m; e += 256) {
-        const int i = e / m, j = e % m;
-        if (j > i) continue;
-        const size_t d = (size_t)(off + i) * n + off + j;
-        double h = (HL[d] + (HM ? HM[d] : 0.0)) + HA[d];
-        if (i == j) h *= (1 + lambda);
-        h -= Hsc[d] * f;
-        LT(i, j) = S[i] * h * S[j];
-    }
-    for (int i = tid; i < m; i += 256) {
-        const int I = off + i;
-        y[i] = S[i] * (((bL[I] + (bM ? bM[I] : 0.0)) + bA[I]) - bsc[I]);
-    }
-    __syncthreads();
-    // right-looking LDL^T: after step k column k holds l_ik, LT(k,k) holds d_k
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int k = 0; k < m; k++) {
-        const double d = LT(k, k);
-        const double dinv = 1.0 / d;
-        for (int i = k + 1 + ty; i < m; i += 16) {
-            const double ci = LT(i, k);
-            for (int j = k + 1 + tx; j <= i; j += 16) LT(i, j) -= ci * LT(j, k) * dinv;
-        }
-        __syncthreads();
-        for (int i = k + 1 + tid; i < m; i += 256) LT(i, k) *= dinv;
-        __syncthreads();
-    }
-    // forward substitution L z = y
-    for (int k = 0; k < m; k++) {
-        const double yk = y[k];
-        for (int i = k + 1 + tid; i < m; i += 256) y[i] -= LT(i, k) * yk;
-        __syncthreads();
-    }
-    for (int i = tid; i < m; i += 256) {
-        const double d = LT(i, i);
-        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;     // Eigen LDLT.h:580-587 pseudo-inverse of D
-    }
-    __syncthreads();
-    // back substitution L^T x = z
-    for (int k = m - 1; k >= 0; k--) {
-        const double xk = y[k];
-        for (int i = tid; i < k; i += 256) y[i] -= LT(k, i) * xk;
-        __syncthreads();
-    }
-    int bad = 0;
-    for (int i = tid; i < n; i += 256) {
-        const double v = (i < off) ? 0.0 : S[i - off] * y[i - off];
-        x[i] = v;
-        bad |= !isfinite(v);
-    }
-    if (bad) atomicOr(flag, 1);
-#undef LT
-}
-
-// ------------------------------------------------------------------------------------------------ back-substitution
-__global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
-                                                    const double* __restrict__ x, LinSummary* __restrict__ sum) {
-    extern __shared__ __attribute__((aligned(16))) double s_xAd[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
-    const int N = A.N;
-    for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) {
-        const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N;
-        const double* AH = adH + 64 * (size_t)(h + N * t); const double* AT = adT + 64 * (size_t)(h + N * t);
-        double s = 0, s2 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { s += x[4 + 8 * h + i] * AH[i * 8 + j]; s2 += x[4 + 8 * t + i] * AT[i * 8 + j]; }
-        s_xAd[e] = s + s2;
-    }
-    __syncthreads();
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.P) return;
-    const float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
-    const int beg = A.by_point_off[p], end = A.by_point_off[p + 1];
-    int ngood = 0;
-    for (int kk = beg; kk < end; kk++) ngood += A.r_good[A.by_point[kk]] != 0;
-    if (ngood == 0) { A.pt_step[p] = 0.0; return; }
-    double b = (double)pa[13];
-    double s = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) s += (-x[i]) * ((double)pa[2 + i] + (double)pa[8 + i]);     // mCalibStep . (Hcd_accAF + Hcd_accLF)
-    b -= s;
-    const int host = A.pt_host[p];
-    for (int kk = beg; kk < end; kk++) {
-        const int r = A.by_point[kk];
-        if (!A.r_good[r]) continue;
-        const double* xa = s_xAd + 8 * (host * N + A.r_target[r]);
-        const float* v = A.r_jpjdf + 8 * (size_t)r;
-        double d = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) d += xa[i] * (double)v[i];
-        b -= d;
-    }
-    const double st = -b * (double)pa[12];
-    A.pt_step[p] = st;
-    if (!isfinite(st)) atomicAdd(&sum->nonfinite, 1);
-}
-
-__global__ void k_ba_backup_points(BAArgs A) {          // BA.cpp:919-922
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < A.P) A.pt_backup[p] = (float)A.pt_idepth[p];
-}
-
-__global__ void k_ba_restore_points(BAArgs A) {         // loadSateBackup, BA.cpp:938-942
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < A.P) { A.pt_idepth[p] = (double)A.pt_backup[p]; A.pt_idepth_zero[p] = A.pt_backup[p]; }
-}
-
-// doStepFromBackup, point part (BA.cpp:976-994); sums are tree-reduced (float)
-__global__ __launch_bounds__(1024) void k_ba_step_points(BAArgs A, LinSummary* __restrict__ sum) {
-    __shared__ float s[3][16];
-    float sumID = 0, sumNID = 0, numID = 0;
-    for (int p = threadIdx.x; p < A.P; p += 1024) {
-        const double st = A.pt_step[p];
-        const double nid = (double)A.pt_backup[p] + st;
-        if (isfinite(nid) && nid > 0) {
-            A.pt_idepth[p] = nid;
-            sumID += (float)(st * st);
-            sumNID += (float)fabs((double)A.pt_backup[p]);
-            numID += 1.f;
-            A.pt_idepth_zero[p] = (float)nid;
-        }
-    }
-    sumID = wave_sum(sumID); sumNID = wave_sum(sumNID); numID = wave_sum(numID);
-    if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = sumID; s[1][threadIdx.x >> 6] = sumNID; s[2][threadIdx.x >> 6] = numID; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0, b = 0, c = 0;
-        for (int i = 0; i < 16; i++) { a += s[0][i]; b += s[1][i]; c += s[2][i]; }
-        sum->sums[0] = a; sum->sums[1] = b; sum->sums[2] = c;
-    }
+// mode: 0 = ACTIVE pair blocks + point rows, 1 = LINEARIZED pair blocks only (rare path)
+__global__ __launch_bounds__(256) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
+    const int NN = A.N * A.N;
+    if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode == 1);
+    else point_rows_block(A, X, blockIdx.x - NN);
 }
 
 // LINEARIZED-mode bd (BA.cpp:1699-1750), rare path: one thread per point
@@ -525,55 +305,443 @@ __global__ void k_ba_point_bdL(BAArgs A, const float* __restrict__ adHTd, const 
     A.pt_acc[(size_t)p * PT_ACC_STRIDE + 7] = bd;
 }
 
+// ------------------------------------------------------------------------------------------------ K4
+struct SysArgs {
+    int N, n, ldg, ntile, P, use_lin_blocks;
+    const double* G; const double* Wt;
+    const double* pbA; const double* pbL;                   // per-pair stitched blocks (ACTIVE / LINEARIZED)
+    const double* cdelta; const double* cprior; const double* prior; const double* dprior;
+    const double* HM; const double* bM;                     // may be null
+    double lambda;
+    double* HA; double* bA; double* HL; double* bL; double* Hsc; double* bsc;
+    double* Hf; double* bf;                                 // final LM system (unscaled): (HL+HM+HA) diag*(1+l) - Hsc/(1+l), bL+bM+bA-bsc
+};
+
+// element (I,Jc) of stitchDoubleTop's result (incl. the mirroring/symmetrisation of BA.cpp:1857-1876) from pair blocks
+__device__ double top_elem(const SysArgs& S, const double* pb, int use_blocks, int use_prior, int I, int Jc) {
+    const int N = S.N;
+    double s = 0;
+    if (I < 4 && Jc < 4) {
+        if (use_blocks) for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + PB_CC + I * 4 + Jc];
+        if (use_prior && I == Jc) s += S.cprior[I];
+    } else if (I < 4 || Jc < 4) {
+        const int F = I < 4 ? Jc : I, C = I < 4 ? I : Jc;
+        const int a = (F - 4) >> 3, i = (F - 4) & 7;
+        if (use_blocks) {
+            for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_HC + i * 4 + C];
+            for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_TC + i * 4 + C];
+        }
+    } else {
+        const int a = (I - 4) >> 3, i = (I - 4) & 7, b = (Jc - 4) >> 3, j = (Jc - 4) & 7;
+        if (a == b) {
+            if (use_blocks) {
+                for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_HH + i * 8 + j];
+                for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_TT + i * 8 + j];
+            }
+            if (use_prior && i == j) s += S.prior[8 * a + i];
+        } else if (use_blocks) {
+            s = pb[(size_t)(a + b * N) * PB_STRIDE + PB_HT + i * 8 + j] + pb[(size_t)(b + a * N) * PB_STRIDE + PB_HT + j * 8 + i];
+        }
+    }
+    return s;
+}
+__device__ double top_b(const SysArgs& S, const double* pb, int use_blocks, int use_prior, int I) {
+    const int N = S.N;
+    double s = 0;
+    if (I < 4) {
+        if (use_blocks) for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + PB_BC + I];
+        if (use_prior) s += S.cprior[I] * S.cdelta[I];
+    } else {
+        const int a = (I - 4) >> 3, i = (I - 4) & 7;
+        if (use_blocks) {
+            for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_BH + i];
+            for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_BT + i];
+        }
+        if (use_prior) s += S.prior[8 * a + i] * S.dprior[8 * a + i];
+    }
+    return s;
+}
+
+// grid = upper-triangular tiles of the padded (n+1) system; block = 64*NW threads.
+// A[i][k] = G[p][16 ti + i], B[k][j] = w[p] G[p][16 tj + j]; D: col = lane&15, row = (lane>>4) + 4*reg.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_ba_system(SysArgs S) {
+    __shared__ double s_part[NW][256];
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
+    const int tj = ti + rem;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    const int kk = l >> 4, c = l & 15;
+    double4_ acc = {0.0, 0.0, 0.0, 0.0};
+    const int per = ((S.P + NW - 1) / NW + 3) & ~3;           // points per wave, multiple of 4
+    const int p_beg = wv * per, p_end = min(S.P, p_beg + per);
+    for (int s = p_beg; s < p_end; s += 16) {                  // 4 MFMAs per trip, loads issued ahead of the chain
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = s + 4 * u + kk;
+            a[u] = 0.0; b[u] = 0.0;
+            if (p < p_end) {
+                const double* row = S.G + (size_t)p * S.ldg;
+                a[u] = row[16 * ti + c];
+                b[u] = S.Wt[p] * row[16 * tj + c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) s_part[wv][(kk + 4 * rg) * 16 + c] = acc[rg];
+    __syncthreads();
+    // one thread per tile element: fixed-order wave sum, then every matrix of the system at (r,c) and (c,r)
+    for (int e = tid; e < 256; e += 64 * NW) {
+        double hsc = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) hsc += s_part[w][e];
+        const int r = 16 * ti + (e >> 4), cc = 16 * tj + (e & 15);
+        const int n = S.n;
+        if (r >= n || cc > n) continue;
+        if (cc == n) {                                                  // the augmented column = right-hand sides
+            const double ba = top_b(S, S.pbA, 1, 0, r), bl = top_b(S, S.pbL, S.use_lin_blocks, 1, r);
+            S.bsc[r] = hsc; S.bA[r] = ba; S.bL[r] = bl;
+            S.bf[r] = ((bl + (S.bM ? S.bM[r] : 0.0)) + ba) - hsc;       // BA.cpp:1300
+            continue;
+        }
+        if (ti == tj && cc < r) continue;                               // lower half of a diagonal tile: written by its mirror
+        const double ha = top_elem(S, S.pbA, 1, 0, r, cc), hl = top_elem(S, S.pbL, S.use_lin_blocks, 1, r, cc);
+        double hf = (hl + (S.HM ? S.HM[(size_t)r * n + cc] : 0.0)) + ha; // BA.cpp:1299
+        if (r == cc) hf *= (1 + S.lambda);                              // :1306-1308
+        hf -= hsc * (1.0 / (1 + S.lambda));                             // :1309
+        S.Hsc[(size_t)r * n + cc] = hsc; S.HA[(size_t)r * n + cc] = ha; S.HL[(size_t)r * n + cc] = hl; S.Hf[(size_t)r * n + cc] = hf;
+        if (r != cc) {
+            double hfm = hf;
+            if (S.HM) {                                                 // HM need not be exactly symmetric: mirror element recomputed
+                hfm = (hl + S.HM[(size_t)cc * n + r]) + ha;
+                hfm -= hsc * (1.0 / (1 + S.lambda));
+            }
+            S.Hsc[(size_t)cc * n + r] = hsc; S.HA[(size_t)cc * n + r] = ha; S.HL[(size_t)cc * n + r] = hl; S.Hf[(size_t)cc * n + r] = hfm;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K5
+// Workgroup 0: x = S LDLT(S Hf S)^-1 S bf on rows/cols [off, n) (BA.cpp:1312-1320).  Block-packed lower storage in LDS:
+// block (I,J), J <= I, 16x16 doubles row-major at ((I(I+1)/2)+J)*256.  Right-looking, per block column K:
+//   (1) wave 0 factors the diagonal block (16 sequential rank-1 steps, lanes own 4 entries each),
+//   (2) one thread per row below solves L_IK = A_IK L_KK^-T D_K^-1 and keeps W_IK = L_IK D_K,
+//   (3) trailing tiles A_IJ -= W_IK L_JK^T on the matrix cores (4 x v_mfma_f64_16x16x4_f64 per tile, tiles round-robin on waves).
+// Workgroup 1 (blockIdx.x == 1): energy/census sums of the last residual pass + setNewFrameEnergyTH (see ba_linearize.hip).
+#define SOLVE_THREADS 512
+__device__ __forceinline__ int blk_off(int I, int J) { return ((I * (I + 1)) / 2 + J) * 256; }
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, const double* __restrict__ Hf,
+                                                            const double* __restrict__ bf, double* __restrict__ x, int* __restrict__ flag,
+                                                            const int* newframe_res, int n_newframe, const double* lin_partial,
+                                                            int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 1) {
+        if (do_finish) lin_finish_block(A, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw,
+                                        reinterpret_cast<unsigned*>(sm), sm + 2048);
+        return;
+    }
+    const int m = n - off, nb = (m + 15) / 16, mp = nb * 16;
+    if (tid == 0) lin_out->nonfinite = 0;            // consumed by the back-substitution launch that follows
+    double* L = sm;                                  // nb(nb+1)/2 blocks
+    double* Wk = L + (size_t)(nb * (nb + 1) / 2) * 256;   // panel W_IK: nb blocks of 16x16
+    double* Sv = Wk + (size_t)nb * 256;              // mp
+    double* y = Sv + mp;                             // mp
+    double* dvec = y + mp;                           // mp (D)
+    for (int i = tid; i < mp; i += SOLVE_THREADS) {
+        double s = 0.0;
+        if (i < m) s = 1.0 / sqrt(Hf[(size_t)(off + i) * n + off + i] + 10.0);      // SVecI, :1312
+        Sv[i] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < mp * mp; e += SOLVE_THREADS) {
+        const int i = e / mp, j = e % mp;
+        if (j > i) continue;
+        double v = (i == j) ? 1.0 : 0.0;                     // identity padding keeps the padded system SPD
+        if (i < m && j < m) v = Sv[i] * Hf[(size_t)(off + i) * n + off + j] * Sv[j];
+        L[blk_off(i >> 4, j >> 4) + (i & 15) * 16 + (j & 15)] = v;
+    }
+    for (int i = tid; i < mp; i += SOLVE_THREADS) y[i] = (i < m) ? Sv[i] * bf[off + i] : 0.0;
+    __syncthreads();
+    const int wv = tid >> 6, l = tid & 63, NWV = SOLVE_THREADS / 64;
+    for (int K = 0; K < nb; K++) {
+        double* D = L + blk_off(K, K);
+        if (wv == 0) {                                       // (1) diagonal block: LDL^T in place, lower part
+            for (int k = 0; k < 16; k++) {
+                const double d = D[k * 16 + k];
+                const double dinv = 1.0 / d;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = l + 64 * u, i = e >> 4, j = e & 15;
+                    if (i > k && j > k && j <= i) D[e] -= D[i * 16 + k] * D[j * 16 + k] * dinv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (l < 16 && l > k) D[l * 16 + k] *= dinv;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (l < 16) dvec[16 * K + l] = D[l * 16 + l];
+        }
+        __syncthreads();
+        // (2) panel rows: solve X L_KK^T D = A_IK  ->  W = X D (kept), L_IK = X
+        for (int rr = tid; rr < (nb - K - 1) * 16; rr += SOLVE_THREADS) {
+            const int I = K + 1 + (rr >> 4), i = rr & 15;
+            double* Arow = L + blk_off(I, K) + i * 16;
+            double wrow[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                double s = Arow[j];
+#pragma unroll
+                for (int t = 0; t < 16; t++) if (t < j) s -= wrow[t] * D[j * 16 + t];      // W_ij = A_ij - sum_t W_it L_jt
+                wrow[j] = s;
+            }
+            double* Wrow = Wk + (size_t)(I - K - 1) * 256 + i * 16;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { Wrow[j] = wrow[j]; Arow[j] = wrow[j] / D[j * 16 + j]; }
+        }
+        __syncthreads();
+        // (3) trailing update on the matrix cores: A_IJ -= W_IK L_JK^T, K < J <= I
+        const int nt = nb - K - 1, ntiles = nt * (nt + 1) / 2;
+        for (int tix = wv; tix < ntiles; tix += NWV) {
+            int a = 0, rem = tix;
+            while (rem >= a + 1) { rem -= a + 1; a++; }       // tile (a, rem), rem <= a
+            const int I = K + 1 + a, J = K + 1 + rem;
+            double* C = L + blk_off(I, J);
+            const double* W = Wk + (size_t)a * 256;
+            const double* Lj = L + blk_off(J, K);
+            const int kq = l >> 4, cidx = l & 15;
+            double4_ acc;
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) acc[rg] = C[(kq + 4 * rg) * 16 + cidx];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const double av = -W[cidx * 16 + 4 * s + kq];            // A[i = l&15][k]
+                const double bv = Lj[cidx * 16 + 4 * s + kq];            // B[k][j = l&15] = L_JK[j][k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) C[(kq + 4 * rg) * 16 + cidx] = acc[rg];
+        }
+        __syncthreads();
+    }
+    // forward substitution L z = y (block rows), then D^-1 (Eigen LDLT.h:580-587 pseudo-inverse rule), then L^T x = z
+    for (int K = 0; K < nb; K++) {
+        if (wv == 0) {
+            const double* D = L + blk_off(K, K);
+            for (int k = 0; k < 16; k++) {
+                const double yk = y[16 * K + k];
+                if (l < 16 && l > k) y[16 * K + l] -= D[l * 16 + k] * yk;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int rr = tid; rr < (nb - K - 1) * 16; rr += SOLVE_THREADS) {
+            const int I = K + 1 + (rr >> 4), i = rr & 15;
+            const double* Lr = L + blk_off(I, K) + i * 16;
+            double s = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) s += Lr[j] * y[16 * K + j];
+            y[16 * I + i] -= s;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < mp; i += SOLVE_THREADS) {
+        const double d = dvec[i];
+        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
+    }
+    __syncthreads();
+    for (int K = nb - 1; K >= 0; K--) {
+        if (wv == 0) {
+            const double* D = L + blk_off(K, K);
+            for (int k = 15; k >= 0; k--) {
+                const double xk = y[16 * K + k];
+                if (l < k) y[16 * K + l] -= D[k * 16 + l] * xk;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int rr = tid; rr < K * 16; rr += SOLVE_THREADS) {      // rows of blocks J < K: y_J -= L_KJ^T x_K
+            const int J = rr >> 4, j = rr & 15;
+            const double* Lb = L + blk_off(K, J);
+            double s = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) s += Lb[i * 16 + j] * y[16 * K + i];
+            y[16 * J + j] -= s;
+        }
+        __syncthreads();
+    }
+    int bad = 0;
+    for (int i = tid; i < n; i += SOLVE_THREADS) {
+        const double v = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
+        x[i] = v;
+        bad |= !isfinite(v);
+    }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (bad) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------ K6
+// back-substitution (BA.cpp:1427-1487) + optional point update (doStepFromBackup, BA.cpp:976-994)
+__global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
+                                                    const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
+                                                    int do_step) {
+    extern __shared__ __attribute__((aligned(16))) double s_xAd[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
+    __shared__ float s_red[3][4];
+    const int N = A.N;
+    for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) {
+        const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N;
+        const double* AH = adH + 64 * (size_t)(h + N * t); const double* AT = adT + 64 * (size_t)(h + N * t);
+        double s = 0, s2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { s += x[4 + 8 * h + i] * AH[i * 8 + j]; s2 += x[4 + 8 * t + i] * AT[i * 8 + j]; }
+        s_xAd[e] = s + s2;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sum->nonfinite = 0;
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float sumID = 0, sumNID = 0, numID = 0;
+    if (p < A.P) {
+        const float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
+        const int beg = A.by_point_off[p], end = A.by_point_off[p + 1];
+        int ngood = 0;
+        for (int kk = beg; kk < end; kk++) ngood += A.r_good[A.by_point[kk]] != 0;
+        double st = 0.0;
+        if (ngood > 0) {
+            double b = (double)pa[13];
+            double s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) s += (-x[i]) * ((double)pa[2 + i] + (double)pa[8 + i]);     // mCalibStep . (Hcd_accAF + Hcd_accLF)
+            b -= s;
+            const int host = A.pt_host[p];
+            for (int kk = beg; kk < end; kk++) {
+                const int r = A.by_point[kk];
+                if (!A.r_good[r]) continue;
+                const double* xa = s_xAd + 8 * (host * N + A.r_target[r]);
+                const float* v = A.r_jpjdf + 8 * (size_t)r;
+                double d = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) d += xa[i] * (double)v[i];
+                b -= d;
+            }
+            st = -b * (double)pa[12];
+            if (!isfinite(st)) atomicAdd(&sum->nonfinite, 1);
+        }
+        A.pt_step[p] = st;
+        if (do_step) {
+            const double nid = (double)A.pt_backup[p] + st;
+            if (isfinite(nid) && nid > 0) {
+                A.pt_idepth[p] = nid;
+                sumID = (float)(st * st); sumNID = (float)fabs((double)A.pt_backup[p]); numID = 1.f;
+                A.pt_idepth_zero[p] = (float)nid;
+            }
+        }
+    }
+    if (do_step) {                                           // fixed-order block partials; the host adds the few blocks
+        sumID = wave_sum(sumID); sumNID = wave_sum(sumNID); numID = wave_sum(numID);
+        if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = sumID; s_red[1][threadIdx.x >> 6] = sumNID; s_red[2][threadIdx.x >> 6] = numID; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k = threadIdx.x;
+            step_partial[4 * blockIdx.x + k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
+        }
+    }
+}
+
+__global__ void k_ba_backup_points(BAArgs A) {          // BA.cpp:919-922
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < A.P) A.pt_backup[p] = (float)A.pt_idepth[p];
+}
+__global__ void k_ba_restore_points(BAArgs A) {         // loadSateBackup, BA.cpp:938-942
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < A.P) { A.pt_idepth[p] = (double)A.pt_backup[p]; A.pt_idepth_zero[p] = A.pt_backup[p]; }
+}
+// doStepFromBackup, point part (BA.cpp:976-994), standalone form
+__global__ __launch_bounds__(256) void k_ba_step_points(BAArgs A, float* __restrict__ step_partial) {
+    __shared__ float s_red[3][4];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float sumID = 0, sumNID = 0, numID = 0;
+    if (p < A.P) {
+        const double st = A.pt_step[p];
+        const double nid = (double)A.pt_backup[p] + st;
+        if (isfinite(nid) && nid > 0) {
+            A.pt_idepth[p] = nid;
+            sumID = (float)(st * st); sumNID = (float)fabs((double)A.pt_backup[p]); numID = 1.f;
+            A.pt_idepth_zero[p] = (float)nid;
+        }
+    }
+    sumID = wave_sum(sumID); sumNID = wave_sum(sumNID); numID = wave_sum(numID);
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = sumID; s_red[1][threadIdx.x >> 6] = sumNID; s_red[2][threadIdx.x >> 6] = numID; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        step_partial[4 * blockIdx.x + k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static inline int ldg_of(int n) { return ((n + 1 + 15) / 16) * 16; }
+static size_t solve_lds_bytes(int m) {
+    const int nb = (m + 15) / 16, mp = nb * 16;
+    size_t d = (size_t)(nb * (nb + 1) / 2) * 256 + (size_t)nb * 256 + 3 * (size_t)mp;
+    if (d < 2048 + 1024) d = 2048 + 1024;                     // lin_finish_block scratch: 2048 u32-pairs + 1024 doubles
+    return d * sizeof(double);
+}
 
-int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A) {
+int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only) {
     const int N = A.N, n = A.n, NN = N * N;
     const double* vs = c->vec_small.as<double>();        // cdelta[4] cprior[4] prior[8N] dprior[8N]
-    const double* cdelta = vs; const double* cprior = vs + 4; const double* prior = vs + 8; const double* dprior = vs + 8 + 8 * N;
-    const int asm_threads = n * n + n;
-    // ACTIVE
-    k_ba_acc_top<false><<<NN, 256, 0, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->adHTd.as<float>(), cdelta,
-                                                   c->acc_pair[0].as<float>(), c->acc_num[0].as<int>(), c->pair_blocks.as<double>());
-    k_ba_assemble_top<<<cml_div_up(asm_threads, 256), 256, 0, c->stream>>>(N, c->pair_blocks.as<double>(), 1, 0, cdelta, cprior, prior,
-                                                                            dprior, c->HA.as<double>(), c->bA.as<double>());
-    // LINEARIZED (prior-only when the window holds no linearized residual)
-    if (c->n_lin > 0) {
-        k_ba_acc_top<true><<<NN, 256, 0, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->adHTd.as<float>(), cdelta,
-                                                      c->acc_pair[1].as<float>(), c->acc_num[1].as<int>(), c->pair_blocks.as<double>());
-        k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), cdelta);
+    AccArgs X;
+    X.adH = c->adH.as<double>(); X.adT = c->adT.as<double>(); X.adHTd = c->adHTd.as<float>(); X.cdelta = vs;
+    X.acc_out = c->acc_pair[0].as<float>(); X.num_out = c->acc_num[0].as<int>(); X.pair_blocks = c->pair_blocks.as<double>();
+    X.ldg = ldg_of(n); X.G = c->G.as<double>(); X.Wt = X.G + (size_t)A.P * X.ldg; X.do_backup = do_backup ? 1 : 0;
+    double* pbL = c->pair_blocks.as<double>() + (size_t)PB_STRIDE * NN;
+    if (!system_only) {
+        if (c->n_lin > 0) {                              // rare path: LINEARIZED residuals present
+            AccArgs XL = X;
+            XL.acc_out = c->acc_pair[1].as<float>(); XL.num_out = c->acc_num[1].as<int>(); XL.pair_blocks = pbL;
+            k_ba_acc<<<NN, 256, 0, c->stream>>>(A, XL, 1);
+            k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
+        }
+        k_ba_acc<<<NN + cml_div_up(A.P * 8, 256), 256, 0, c->stream>>>(A, X, 0);
     }
-    k_ba_assemble_top<<<cml_div_up(asm_threads, 256), 256, 0, c->stream>>>(N, c->pair_blocks.as<double>(), c->n_lin > 0 ? 1 : 0, 1, cdelta,
-                                                                            cprior, prior, dprior, c->HL.as<double>(), c->bL.as<double>());
-    // Schur
-    const int ldg = ldg_of(n), ntile = ldg / 16, ntiles_ut = ntile * (ntile + 1) / 2;
-    const int nchunk = cml_div_up(A.P, SYRK_CHUNK);
-    double* Wt = c->G.as<double>() + (size_t)A.P * ldg;
-    k_ba_point_schur<<<cml_div_up(A.P * 8, 256), 256, 0, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->G.as<double>(), Wt, ldg);
-    k_ba_schur_syrk<<<dim3(ntiles_ut, nchunk), 64, 0, c->stream>>>(c->G.as<double>(), Wt, A.P, ldg, ntile, c->syrk_part.as<double>());
-    k_ba_schur_finish<<<cml_div_up(n * (n + 1), 256), 256, 0, c->stream>>>(c->syrk_part.as<double>(), nchunk, ntile, ntiles_ut, n,
-                                                                            c->Hsc.as<double>(), c->bsc.as<double>());
+    SysArgs S;
+    S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = c->n_lin > 0 ? 1 : 0;
+    S.G = X.G; S.Wt = X.Wt; S.pbA = c->pair_blocks.as<double>(); S.pbL = pbL;
+    S.cdelta = vs; S.cprior = vs + 4; S.prior = vs + 8; S.dprior = vs + 8 + 8 * N;
+    S.HM = have_hm ? c->HM.as<double>() : nullptr; S.bM = have_hm ? c->bM.as<double>() : nullptr;
+    S.lambda = lambda;
+    S.HA = c->HA.as<double>(); S.bA = c->bA.as<double>(); S.HL = c->HL.as<double>(); S.bL = c->bL.as<double>();
+    S.Hsc = c->Hsc.as<double>(); S.bsc = c->bsc.as<double>(); S.Hf = c->Hf.as<double>(); S.bf = c->bf.as<double>();
+    const int ntiles = S.ntile * (S.ntile + 1) / 2;
+    if (A.P > 4096) k_ba_system<16><<<ntiles, 1024, 0, c->stream>>>(S);
+    else k_ba_system<4><<<ntiles, 256, 0, c->stream>>>(S);
     return CMLHIP_OK;
 }
 
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, int optcal) {
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish) {
     const int n = A.n, off = optcal ? 0 : 4, m = n - off;
-    const size_t sh = ((size_t)m * (m + 1) / 2 + 2 * (size_t)m) * sizeof(double);
+    const size_t sh = solve_lds_bytes(m);
     int* flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
-    hipMemsetAsync(flag, 0, sizeof(int), c->stream);
-    if (sh > 64 * 1024) hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    k_ba_solve<<<1, 256, sh, c->stream>>>(n, off, lambda, c->HA.as<double>(), c->bA.as<double>(), c->HL.as<double>(), c->bL.as<double>(),
-                                          have_hm ? c->HM.as<double>() : nullptr, have_hm ? c->bM.as<double>() : nullptr,
-                                          c->Hsc.as<double>(), c->bsc.as<double>(), c->xvec.as<double>(), flag);
+    static bool attr_set = false;
+    if (!attr_set || sh > 64 * 1024) {
+        hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    k_ba_solve<<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, c->Hf.as<double>(), c->bf.as<double>(), c->xvec.as<double>(), flag,
+                                                                          c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(),
+                                                                          c->n_lin_partial, c->scal.as<LinSummary>(), c->frames.as<FrameDev>(),
+                                                                          with_lin_finish ? 1 : 0);
     return CMLHIP_OK;
 }
 
-int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A) {
-    LinSummary* S = c->scal.as<LinSummary>();
-    hipMemsetAsync(&S->nonfinite, 0, sizeof(int), c->stream);
+int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
     const size_t sh = (size_t)A.N * A.N * 8 * sizeof(double);
-    k_ba_backsub<<<cml_div_up(A.P, 256), 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(), S);
+    k_ba_backsub<<<cml_div_up(A.P, 256), 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
+                                                               c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0);
     return CMLHIP_OK;
 }
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A) {
@@ -585,6 +753,6 @@ int cml_launch_restore_points(cmlhip_ctx* c, const BAArgs& A) {
     return CMLHIP_OK;
 }
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A) {
-    k_ba_step_points<<<1, 1024, 0, c->stream>>>(A, c->scal.as<LinSummary>());
+    k_ba_step_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->step_partial.as<float>());
     return CMLHIP_OK;
 }

@@ -30,6 +30,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.rj0 = c->rj[0].as<float>(); A.rj1 = c->rj[1].as<float>();
     A.by_point_off = c->by_point_off.as<int>(); A.by_point = c->by_point.as<int>();
     A.by_pair_off = c->by_pair_off.as<int>(); A.by_pair = c->by_pair.as<int>();
+    A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0;
     return CMLHIP_OK;
 }
 
@@ -103,12 +104,15 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->by_point_off, 4 * (P + 1)); ENS(c->by_point, 4 * R); ENS(c->by_pair_off, 4 * (N * N + 1)); ENS(c->by_pair, 4 * R);
     ENS(c->newframe_res, 4 * newframe.size());
     for (int m = 0; m < 2; m++) { ENS(c->acc_pair[m], 4 * ACC_STRIDE * N * N); ENS(c->acc_num[m], 4 * N * N); }
-    ENS(c->pair_blocks, 8 * (size_t)PB_STRIDE * N * N);
+    ENS(c->pair_blocks, 2 * 8 * (size_t)PB_STRIDE * N * N);
     ENS(c->adH, 8 * 64 * N * N); ENS(c->adT, 8 * 64 * N * N); ENS(c->adHTd, 4 * 8 * N * N); ENS(c->vec_small, 8 * (8 + 16 * N));
     ENS(c->HA, 8 * n * n); ENS(c->HL, 8 * n * n); ENS(c->Hsc, 8 * n * n); ENS(c->HM, 8 * n * n);
     ENS(c->bA, 8 * n); ENS(c->bL, 8 * n); ENS(c->bsc, 8 * n); ENS(c->bM, 8 * n); ENS(c->xvec, 8 * n);
+    ENS(c->Hf, 8 * n * n); ENS(c->bf, 8 * n);
+    c->n_lin_partial = (R + 31) / 32;
+    ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 255) / 256 + 1));
     ENS(c->G, 8 * ((size_t)P * ldg + P));
-    ENS(c->syrk_part, 8 * (size_t)256 * (ntile * (ntile + 1) / 2) * ((P + 63) / 64 + 1));
+    (void)ntile;
     ENS(c->scal, 1024);
 #undef ENS
     // ---- SoA staging + upload
@@ -148,6 +152,9 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     CML_CHECK(c, hipMemsetAsync(c->pt_step.p, 0, c->pt_step.bytes, c->stream));
     CML_CHECK(c, hipMemsetAsync(c->pt_backup.p, 0, c->pt_backup.bytes, c->stream));
     CML_CHECK(c, hipMemsetAsync(c->scal.p, 0, c->scal.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->pair_blocks.p, 0, c->pair_blocks.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->lin_partial.p, 0, c->lin_partial.bytes, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->step_partial.p, 0, c->step_partial.bytes, c->stream));
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     c->ba_uploaded = true;
     c->ba_pairs_set = false;
@@ -252,7 +259,7 @@ int cmlhip_ba_accumulate(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* HA
     if ((rc = upload_accum_in(c, in))) return rc;
     BAArgs A;
     cml_make_ba_args(c, A);
-    cml_launch_accumulate(c, A);
+    cml_launch_accumulate(c, A, c->last_lambda, false, false);
     CML_CHECK(c, hipGetLastError());
     const size_t n = 8 * (size_t)c->N + 4;
     if (HA && (rc = cml_d2h(c, HA, c->HA.p, 8 * n * n))) return rc;
@@ -275,7 +282,9 @@ int cmlhip_ba_solve(cmlhip_ctx* c, double lambda, const double* HM, const double
     }
     BAArgs A;
     cml_make_ba_args(c, A);
-    cml_launch_solve(c, A, lambda, have, optcal);
+    c->last_lambda = lambda; c->last_have_hm = have;
+    cml_launch_accumulate(c, A, lambda, have, false, true); // pair blocks / Schur rows are current; rebuilds the final system for this lambda / HM
+    cml_launch_solve(c, A, optcal, false);
     CML_CHECK(c, hipGetLastError());
     int flag = 0;
     if ((rc = cml_d2h(c, &flag, c->scal.as<char>() + 256, sizeof(int)))) return rc;
@@ -290,7 +299,8 @@ int cmlhip_ba_backsub(cmlhip_ctx* c, const double* x, double* step) {
     if (x && (rc = cml_h2d(c, c->xvec.p, x, 8 * n))) return rc;
     BAArgs A;
     cml_make_ba_args(c, A);
-    cml_launch_backsub(c, A);
+    CML_CHECK(c, hipMemsetAsync(&c->scal.as<LinSummary>()->nonfinite, 0, sizeof(int), c->stream));
+    cml_launch_backsub(c, A, false);
     CML_CHECK(c, hipGetLastError());
     LinSummary S;
     if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
@@ -318,6 +328,17 @@ int cmlhip_ba_restore_points(cmlhip_ctx* c) {
     return CMLHIP_OK;
 }
 
+static int read_step_sums(cmlhip_ctx* c, float sums[3]) {
+    const int nb = (c->P + 255) / 256;
+    std::vector<float> part(4 * (size_t)(nb ? nb : 1));
+    int rc = cml_d2h(c, part.data(), c->step_partial.p, 16 * (size_t)nb);
+    if (rc) return rc;
+    float a = 0, b = 0, n = 0;
+    for (int i = 0; i < nb; i++) { a += part[4 * i]; b += part[4 * i + 1]; n += part[4 * i + 2]; }
+    sums[0] = a; sums[1] = b; sums[2] = n;
+    return CMLHIP_OK;
+}
+
 int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) {
     int rc = ba_check(c, false);
     if (rc) return rc;
@@ -325,11 +346,7 @@ int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) {
     cml_make_ba_args(c, A);
     cml_launch_step_points(c, A);
     CML_CHECK(c, hipGetLastError());
-    if (sums) {
-        LinSummary S;
-        if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
-        sums[0] = S.sums[0]; sums[1] = S.sums[1]; sums[2] = S.sums[2];
-    }
+    if (sums) return read_step_sums(c, sums);
     return CMLHIP_OK;
 }
 
@@ -341,19 +358,16 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     if (rc) return rc;
     BAArgs A;
     cml_make_ba_args(c, A);
+    A.fuse_apply = 1;                                        // the step is always accepted here (forceAccept, BA.h:265)
     const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap;
-    hipEvent_t* ev = prof ? &c->prof_ev[4 * (size_t)c->prof_n] : nullptr;
+    hipEvent_t* ev = prof ? &c->prof_ev[6 * (size_t)c->prof_n] : nullptr;
     if (prof) hipEventRecord(ev[0], c->stream);
-    cml_launch_backup_points(c, A);
-    cml_launch_accumulate(c, A);
-    cml_launch_solve(c, A, lambda, false, 0);
-    cml_launch_backsub(c, A);
-    cml_launch_step_points(c, A);
+    cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
+    cml_launch_solve(c, A, 0, true);                         // K5: solve || energy-threshold of the previous residual pass
+    cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
     if (prof) { hipEventRecord(ev[1], c->stream); hipEventRecord(ev[2], c->stream); }
-    cml_launch_linearize(c, A);
-    if (prof) { hipEventRecord(ev[3], c->stream); c->prof_n++; }
-    cml_launch_lin_finish(c, A);
-    cml_launch_apply(c, A, 1);
+    cml_launch_linearize(c, A);                              // K1: residuals + Jacobians (+ applyRes)
+    if (prof) { hipEventRecord(ev[3], c->stream); hipEventRecord(ev[4], c->stream); hipEventRecord(ev[5], c->stream); c->prof_n++; }
     CML_CHECK(c, hipGetLastError());
     return CMLHIP_OK;
 }
@@ -364,7 +378,7 @@ int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) {
     for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
     c->prof_ev.clear();
     c->prof_cap = max_iterations; c->prof_n = 0;
-    c->prof_ev.resize(4 * (size_t)max_iterations);
+    c->prof_ev.resize(6 * (size_t)max_iterations);
     for (auto& e : c->prof_ev) CML_CHECK(c, hipEventCreate(&e));
     return CMLHIP_OK;
 }
@@ -374,10 +388,11 @@ int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, int* n) {
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     double a = 0, b = 0;
     for (int i = 0; i < c->prof_n; i++) {
-        float m0 = 0, m1 = 0;
-        CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[4 * (size_t)i + 0], c->prof_ev[4 * (size_t)i + 1]));
-        CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[4 * (size_t)i + 2], c->prof_ev[4 * (size_t)i + 3]));
-        b += m0; a += m1;
+        float m0 = 0, m1 = 0, m2 = 0;
+        CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[6 * (size_t)i + 0], c->prof_ev[6 * (size_t)i + 1]));
+        CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[6 * (size_t)i + 2], c->prof_ev[6 * (size_t)i + 3]));
+        CML_CHECK(c, hipEventElapsedTime(&m2, c->prof_ev[6 * (size_t)i + 4], c->prof_ev[6 * (size_t)i + 5]));   // empty bracket = event overhead
+        b += m0 - m2; a += m1 - m2;
     }
     if (n) *n = c->prof_n;
     if (lin_ms) *lin_ms = c->prof_n ? (float)(a / c->prof_n) : 0.f;

@@ -36,15 +36,18 @@ struct BAArgs {
     unsigned char* r_good; const unsigned char* r_lin; unsigned char* r_sel;
     float* r_center; float* r_jpjdf; float* r_rtz; float* rj0; float* rj1;
     const int* by_point_off; const int* by_point; const int* by_pair_off; const int* by_pair;
+    double* lin_partial;          // per-block {energy, n_in, n_oob, n_outlier} of the residual kernel (may be null)
+    int fuse_apply;               // residual kernel also performs applyRes(copyJacobians=true) (valid when the step is always accepted)
 };
 
 int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A);
 int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy);
-int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A);                 // top (ACTIVE + LINEARIZED) + Schur, outputs in ctx buffers
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, int optcal);
-int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A);
+// K3 (pair blocks + point rows) and K4 (system tiles: H_A, H_L, H_sc and the final LM system for `lambda` / optional HM)
+int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only = false);
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish);
+int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step);
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_restore_points(cmlhip_ctx* c, const BAArgs& A);

@@ -11,6 +11,7 @@
 // leave the CU as coalesced 16-B stores.
 #include "cmlhip_internal.h"
 #include "ba_common.h"
+#include "ba_finish.h"
 
 #pragma clang fp contract(off)
 
@@ -48,7 +49,8 @@ template <bool HALF>
 __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     __shared__ __attribute__((aligned(16))) float s_share[RES_PER_BLOCK][NSHARE][8];   // [residual][quantity][pixel]
     __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE];
-    __shared__ int s_write[RES_PER_BLOCK];
+    __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK];
+    __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
     const int r = blockIdx.x * RES_PER_BLOCK + g;
     const bool live = (r < A.R) && !A.r_lin[r];
@@ -191,36 +193,59 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     rec[O_JAB1 + k] = A.opt_b ? hw : 0.f;
 
     // ---- classification, BA.cpp:66-72,115-118,297-314
-    if (k == 0) s_write[g] = run ? 1 : 0;    // a residual that entered OOB keeps its record untouched (early return, :68-72)
+    if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; }
     if (live && k == 0) {
         float ret = A.r_energy[r];
         float nwo = -1.f;
+        int ns_final = A.r_new_state[r];
+        bool state_now_oob = (st == CMLHIP_RES_OOB), wrote_e = false;
         if (run) {
             if (centre_in) {                                        // setCenterProjectedTo, :131
                 A.r_center[3 * (size_t)r] = (float)Kud; A.r_center[3 * (size_t)r + 1] = (float)Kvd;
                 A.r_center[3 * (size_t)r + 2] = new_idepth;
             }
             if (fail_new_oob) {
-                A.r_new_state[r] = CMLHIP_RES_OOB;
+                ns_final = CMLHIP_RES_OOB;
             } else if (fail_state_oob) {
                 A.r_state[r] = CMLHIP_RES_OOB;
+                state_now_oob = true;
             } else if (!isfinite(E)) {
-                A.r_new_state[r] = CMLHIP_RES_OOB;
+                ns_final = CMLHIP_RES_OOB;
             } else {
                 nwo = E;
                 const float th = fh.frame_energy_th > ft.frame_energy_th ? fh.frame_energy_th : ft.frame_energy_th;
                 float e = E;
-                int ns = CMLHIP_RES_IN;
-                if (E > th || wJI2 < 2) { e = th; ns = CMLHIP_RES_OUTLIER; }
-                A.r_new_state[r] = ns;
+                ns_final = CMLHIP_RES_IN;
+                if (E > th || wJI2 < 2) { e = th; ns_final = CMLHIP_RES_OUTLIER; }
                 A.r_new_energy[r] = e;
                 ret = e;
+                wrote_e = true;
             }
+            A.r_new_state[r] = ns_final;
         }
         A.r_new_energy_wo[r] = nwo;
         A.r_ret_energy[r] = ret;
+        s_ret[g] = (double)ret; s_ns[g] = ns_final;
+        if (A.fuse_apply && !state_now_oob) {                       // applyRes(copyJacobians = true), BA.cpp:2051-2093
+            if (ns_final == CMLHIP_RES_IN) { A.r_good[r] = 1; s_flip[g] = 1; }
+            else A.r_good[r] = 0;
+            A.r_state[r] = ns_final;
+            A.r_energy[r] = wrote_e ? ret : A.r_new_energy[r];      // state_energy = state_NewEnergy
+        }
     }
     __syncthreads();
+
+    // ---- fused applyRes: swap(rJ, efsJ) = flip of the buffer selector, JpJdF from the fresh record (BA.cpp:2064-2080)
+    if (A.fuse_apply && s_flip[g]) {
+        const float* Jn = s_rec[g];
+        const float g0 = Jn[O_JI2 + 0] * Jn[O_DD] + Jn[O_JI2 + 2] * Jn[O_DD + 1];
+        const float g1 = Jn[O_JI2 + 1] * Jn[O_DD] + Jn[O_JI2 + 3] * Jn[O_DD + 1];
+        float v;
+        if (k < 6) v = Jn[O_XI0 + k] * g0 + Jn[O_XI1 + k] * g1;
+        else if (k == 6) v = Jn[O_JABJI + 0] * Jn[O_DD] + Jn[O_JABJI + 2] * Jn[O_DD + 1];
+        else v = Jn[O_JABJI + 1] * Jn[O_DD] + Jn[O_JABJI + 3] * Jn[O_DD + 1];
+        A.r_jpjdf[8 * (size_t)r + k] = v;
+    }
 
     // ---- coalesced copy-out of the finished records into the residual's rJ buffer (the one that is not efsJ)
     const int r0 = blockIdx.x * RES_PER_BLOCK;
@@ -232,89 +257,29 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         float* dst = (A.r_sel[rr_] ? A.rj0 : A.rj1) + (size_t)rr_ * RJ_STRIDE;
         reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(s_rec[gg])[q];
     }
+    __syncthreads();                                                // every lane has read r_sel before it is flipped
+    if (tid < RES_PER_BLOCK && s_flip[tid]) A.r_sel[r0 + tid] ^= 1;
+    // ---- per-block partials {energy, n_in, n_oob, n_outlier} in residual order (BA.cpp:1565)
+    if (tid == 0 && A.lin_partial) {
+        double e = 0, c0 = 0, c1 = 0, c2 = 0;
+        for (int gg = 0; gg < RES_PER_BLOCK; gg++) {
+            e += s_ret[gg];
+            c0 += s_ns[gg] == CMLHIP_RES_IN; c1 += s_ns[gg] == CMLHIP_RES_OOB; c2 += s_ns[gg] == CMLHIP_RES_OUTLIER;
+        }
+        double* o = A.lin_partial + 4 * (size_t)blockIdx.x;
+        o[0] = e; o[1] = c0; o[2] = c1; o[3] = c2;
+    }
     (void)ok;
 }
 
 // ------------------------------------------------------------------------------------------------
-// energy sum (BA.cpp:1565,1608), state census and setNewFrameEnergyTH (BA.cpp:2419-2464) in ONE workgroup:
-// fixed-order fp64 tree for the energy, exact radix select (4 x 8-bit passes over the float bit patterns;
-// energies are >= 0 so the unsigned order is the float order) for the 70th percentile.
+// standalone tail of a residual pass (the iteration pipeline runs it as the second workgroup of the solve launch)
 __global__ __launch_bounds__(1024) void k_ba_lin_finish(BAArgs A, const int* __restrict__ newframe_res, int n_newframe,
+                                                        const double* __restrict__ lin_partial, int n_partial,
                                                         LinSummary* __restrict__ out, FrameDev* __restrict__ frames_rw) {
-    __shared__ double s_sum[1024];
-    __shared__ int s_cnt[3][16];
-    __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_prefix, s_k, s_nvalid;
-    const int tid = threadIdx.x;
-    double e = 0;
-    int cin = 0, coob = 0, cout = 0;
-    for (int r = tid; r < A.R; r += 1024) {
-        if (A.r_lin[r]) continue;
-        e += (double)A.r_ret_energy[r];
-        const int ns = A.r_new_state[r];
-        cin += ns == CMLHIP_RES_IN; coob += ns == CMLHIP_RES_OOB; cout += ns == CMLHIP_RES_OUTLIER;
-    }
-    s_sum[tid] = e;
-    for (int o = 32; o > 0; o >>= 1) { cin += __shfl_down(cin, o); coob += __shfl_down(coob, o); cout += __shfl_down(cout, o); }
-    if ((tid & 63) == 0) { s_cnt[0][tid >> 6] = cin; s_cnt[1][tid >> 6] = coob; s_cnt[2][tid >> 6] = cout; }
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) s_sum[tid] += s_sum[tid + s];
-        __syncthreads();
-    }
-    // ---- radix select over new_energy_wo of the residuals that target the newest frame
-    unsigned nvalid = 0;
-    for (int i = tid; i < n_newframe; i += 1024) {
-        const int r = newframe_res[i];
-        nvalid += (!A.r_lin[r] && A.r_new_energy_wo[r] >= 0.f);
-    }
-    if (tid == 0) s_nvalid = 0;
-    __syncthreads();
-    for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o);
-    if ((tid & 63) == 0) atomicAdd(&s_nvalid, nvalid);
-    __syncthreads();
-    const unsigned n = s_nvalid;
-    float th;
-    if (n == 0) {
-        th = 12 * 12 * 8;                                  // :2432-2436
-    } else {
-        if (tid == 0) { s_prefix = 0; s_k = (unsigned)(int)(0.7f * (float)n); }   // nthIdx, :2448
-        __syncthreads();
-        for (int pass = 3; pass >= 0; pass--) {
-            if (tid < 256) s_hist[tid] = 0;
-            __syncthreads();
-            const unsigned prefix = s_prefix;
-            const unsigned hmask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
-            for (int i = tid; i < n_newframe; i += 1024) {
-                const int r = newframe_res[i];
-                const float v = A.r_new_energy_wo[r];
-                if (A.r_lin[r] || !(v >= 0.f)) continue;
-                const unsigned b = __float_as_uint(v);
-                if ((b & hmask) == prefix) atomicAdd(&s_hist[(b >> (8 * pass)) & 0xFFu], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                unsigned kk = s_k, acc = 0;
-                int d = 0;
-                for (; d < 256; d++) { if (acc + s_hist[d] > kk) break; acc += s_hist[d]; }
-                s_k = kk - acc;
-                s_prefix = prefix | ((unsigned)d << (8 * pass));
-            }
-            __syncthreads();
-        }
-        const float nthElement = sqrtf(__uint_as_float(s_prefix));      // :2455
-        double t = (double)(nthElement * 1.5f);                         // :2458
-        t = (double)(26.0f * 0.5f) + t * (double)(1 - 0.5f);
-        t = t * t;
-        t *= (double)(1.0f * 1.0f);
-        th = (float)t;
-    }
-    if (tid == 0) {
-        int a = 0, b = 0, c = 0;
-        for (int i = 0; i < 16; i++) { a += s_cnt[0][i]; b += s_cnt[1][i]; c += s_cnt[2][i]; }
-        out->energy = s_sum[0]; out->n_in = a; out->n_oob = b; out->n_outlier = c; out->new_frame_energy_th = th;
-        frames_rw[A.N - 1].frame_energy_th = th;                        // takes effect from the next linearize
-    }
+    __shared__ unsigned s_u32[264];
+    __shared__ double s_f64[1024];
+    lin_finish_block(A, newframe_res, n_newframe, lin_partial, n_partial, out, frames_rw, s_u32, s_f64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,8 +317,8 @@ int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A) {
     return CMLHIP_OK;
 }
 int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A) {
-    k_ba_lin_finish<<<1, 1024, 0, c->stream>>>(A, c->newframe_res.as<int>(), c->n_newframe, c->scal.as<LinSummary>(),
-                                                c->frames.as<FrameDev>());
+    k_ba_lin_finish<<<1, 1024, 0, c->stream>>>(A, c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->n_lin_partial,
+                                                c->scal.as<LinSummary>(), c->frames.as<FrameDev>());
     return CMLHIP_OK;
 }
 int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy) {

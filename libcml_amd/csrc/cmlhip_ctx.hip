@@ -93,7 +93,7 @@ void cmlhip_destroy(cmlhip_ctx* c) {
                      &c->acc_pair[1], &c->acc_num[0], &c->acc_num[1], &c->pair_blocks, &c->adH, &c->adT, &c->adHTd,
                      &c->vec_small, &c->HA, &c->bA, &c->HL, &c->bL, &c->Hsc, &c->bsc, &c->HM, &c->bM, &c->xvec, &c->G,
                      &c->syrk_part, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt,
-                     &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x};
+                     &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
     if (c->pinned) hipHostFree(c->pinned);
