@@ -295,6 +295,9 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);   /* linearize→
  * residual/Jacobian kernel and (b) the accumulate+Schur+solve+back-substitution group with events on the context
  * stream.  read returns the mean durations in ms over the recorded iterations and resets the recorder. */
 int cmlhip_profile_enable(cmlhip_ctx* ctx, int max_iterations);
+/* development aid: in-kernel phase timestamps (wall clock, 10 ns ticks), 16 slots per kernel: [0,16) residual kernel,
+ * [16,32) accumulate, [32,48) system tiles, [48,64) solve, [64,80) back-substitution. Reads the previous values, then (re)arms. */
+int cmlhip_debug_timestamps(cmlhip_ctx* ctx, int enable, long long* out128);
 int cmlhip_profile_read(cmlhip_ctx* ctx, float* linearize_ms, float* schur_solve_ms, int* n_recorded);
 
 #ifdef __cplusplus

@@ -29,6 +29,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// wave64 sum on the DPP path (no LDS crossbar): row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 and
+// row_bcast:31 carry the row totals forward.  The TOTAL IS VALID IN LANE 63 ONLY.
+__device__ __forceinline__ float wave_sum_dpp63(float v) {
+#define DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
+    DPP_ADD(0x111, 0xf);      // row_shr:1
+    DPP_ADD(0x112, 0xf);      // row_shr:2
+    DPP_ADD(0x114, 0xf);      // row_shr:4
+    DPP_ADD(0x118, 0xf);      // row_shr:8
+    DPP_ADD(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2 and 3
+#undef DPP_ADD
+    return v;
+}
 
 struct AccArgs {
     const double* adH; const double* adT; const float* adHTd; const double* cdelta;
@@ -38,11 +51,14 @@ struct AccArgs {
 
 // ------------------------------------------------------------------------------------------------ K3
 __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const bool LIN) {
+    __shared__ float s_acc4[4][ACC_STRIDE];
     __shared__ float s_acc[ACC_STRIDE];
+    __shared__ int s_cnt4[4];
     __shared__ int s_cnt;
     __shared__ double s_H[13][13];
     __shared__ double s_AH[64], s_AT[64], s_T1[64], s_T2[64];
-    const int tid = threadIdx.x, part = tid >> 6, ln = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, part = wave & 3, grp = wave >> 2, ln = tid & 63;
+    // 16 waves = 4 parts x 4 residual groups (256 residuals of the pair in flight per trip).
     // up to 25 accumulators per lane; which 13x13 entries they are depends on the wave (part):
     //   part 0: upper-triangle rows 0,1 (19) + bottom-right 3x3 (6)       part 1: rows 2,3,4 (21)
     //   part 2: rows 5..9 (15) + top-right rows 0..2 (9)                   part 3: top-right rows 3..9 (21)
@@ -51,7 +67,8 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     for (int i = 0; i < 25; i++) acc[i] = 0.f;
     int cnt = 0;
     const int beg = A.by_pair_off[q], end = A.by_pair_off[q + 1];
-    for (int i = beg + ln; i < end; i += 64) {
+    if (A.dbg && tid == 0 && q == 1) A.dbg[16] = wall_clock64();
+    for (int i = beg + grp * 64 + ln; i < end; i += 256) {
         const int r = A.by_pair[i];
         const bool lin = A.r_lin[r] != 0;
         if (LIN ? (!lin || !A.r_good[r]) : (lin || !A.r_good[r])) continue;      // BA.cpp:1662-1669
@@ -122,23 +139,27 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
 #undef UP
 #undef TRW
     }
-    // wave reduction and scatter into the canonical 91-entry order (55 upper-tri row-major, 30 top-right, 6 bottom-right)
+    if (A.dbg && tid == 0 && q == 1) A.dbg[17] = wall_clock64();
+    // wave reduction (DPP) and scatter into the canonical 91-entry order (55 upper-tri row-major, 30 top-right, 6 bottom-right)
 #pragma unroll
     for (int k = 0; k < 25; k++) {
-        const float v = wave_sum(acc[k]);
-        if (ln == 0) {
+        const float v = wave_sum_dpp63(acc[k]);
+        if (ln == 63) {
             int dst = -1;
             if (part == 0) dst = k < 19 ? k : 85 + (k - 19);
             else if (part == 1) { if (k < 21) dst = 19 + k; }
             else if (part == 2) { if (k < 15) dst = 40 + k; else if (k < 24) dst = 55 + (k - 15); }
             else { if (k < 21) dst = 64 + k; }
-            if (dst >= 0) s_acc[dst] = v;
+            if (dst >= 0) s_acc4[grp][dst] = v;
         }
     }
     if (part == 0) {
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (ln == 0) s_cnt = cnt;
+        if (ln == 0) s_cnt4[grp] = cnt;
     }
+    __syncthreads();
+    if (tid < 91) s_acc[tid] = ((s_acc4[0][tid] + s_acc4[1][tid]) + s_acc4[2][tid]) + s_acc4[3][tid];
+    if (tid == 0) s_cnt = s_cnt4[0] + s_cnt4[1] + s_cnt4[2] + s_cnt4[3];
     if (tid < 64) { s_AH[tid] = X.adH[64 * (size_t)q + tid]; s_AT[tid] = X.adT[64 * (size_t)q + tid]; }
     __syncthreads();
     if (tid < 91) {
@@ -161,6 +182,7 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     }
     if (tid == 0) X.num_out[q] = s_cnt;
     __syncthreads();
+    if (A.dbg && tid == 0 && q == 1) A.dbg[18] = wall_clock64();
     // ---- stitchDoubleTop per-pair products, BA.cpp:1827-1843 (fp64)
     double* pb = X.pair_blocks + (size_t)q * PB_STRIDE;
     if (tid < 64) {
@@ -199,55 +221,83 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     } else if (tid < 124) {
         pb[PB_BC + tid - 120] = s_H[tid - 120][12];
     }
+    if (A.dbg && tid == 0 && q == 1) A.dbg[19] = wall_clock64();
 }
 
-// 8 lanes per point.  Per point: Hdd/bd/Hcd sums (BA.cpp:1747-1750), HdiF, bdSum (BA.cpp:1895-1905); row
+// 8 lanes per point, ONE RESIDUAL PER LANE per pass (a point has at most N-1 residuals), so the dependent load chain
+// by_point -> r -> {good, sel, target} -> record is walked once per point instead of once per residual.
+// Per point: Hdd/bd/Hcd sums (BA.cpp:1747-1750), HdiF, bdSum (BA.cpp:1895-1905); coupling row in FRAME coordinates:
 // g_p[0:4] = Hcd, g_p[4+8h+i] = sum_r (AH_ht JpJdF_r)_i, g_p[4+8t+i] = (AT_ht JpJdF_r)_i, G[p][n] = bdSum.
+__device__ __forceinline__ float sum8(float v) {          // sum over the 8 lanes of a point (xor butterflies stay inside the group)
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+__device__ __forceinline__ double sum8d(double v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
 __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs& X, const int blk) {
-    const int gid = blk * 256 + threadIdx.x;
+    const int gid = blk * 1024 + threadIdx.x;
     const int p = gid >> 3, i = gid & 7;
-    if (p >= A.P) return;
-    const int host = A.pt_host[p];
-    const int beg = A.by_point_off[p], end = A.by_point_off[p + 1];
-    double* row = X.G + (size_t)p * X.ldg;
-    // zero-fill: every lane clears exactly the columns it may write below, so store order is per-lane program order
-    for (int f = 0; f < A.N; f++) row[4 + 8 * f + i] = 0.0;
-    if (i < 4) row[i] = 0.0;
-    if (i == 4) row[A.n] = 0.0;
-    if (i == 5) for (int cix = A.n + 1; cix < X.ldg; cix++) row[cix] = 0.0;
-    if (X.do_backup && i == 6) A.pt_backup[p] = (float)A.pt_idepth[p];          // backupState, BA.cpp:919-922
+    const bool pv = p < A.P;
+    const int pp = pv ? p : 0;
+    const int host = A.pt_host[pp];
+    const int beg = A.by_point_off[pp], end = pv ? A.by_point_off[pp + 1] : beg;
+    double* row = X.G + (size_t)pp * X.ldg;
+    if (pv) {   // zero-fill: lane i owns columns {4+8f+i}, lanes 0-3 the calibration columns, lane 4 the rhs column, lane 5 the padding
+        for (int f = 0; f < A.N; f++) row[4 + 8 * f + i] = 0.0;
+        if (i < 4) row[i] = 0.0;
+        if (i == 4) row[A.n] = 0.0;
+        if (i == 5) for (int cix = A.n + 1; cix < X.ldg; cix++) row[cix] = 0.0;
+        if (X.do_backup && i == 6) A.pt_backup[p] = (float)A.pt_idepth[p];          // backupState, BA.cpp:919-922
+    }
     float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, HcdL[4] = {0, 0, 0, 0};
     int ngood = 0;
-    double hostacc = 0;
-    for (int kk = beg; kk < end; kk++) {
-        const int r = A.by_point[kk];
-        if (!A.r_good[r]) continue;
-        ngood++;
+    double hostacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int base = beg; base < end; base += 8) {            // one pass for N <= 9
+        const int kk = base + i;
+        const bool have = kk < end;
+        const int r = have ? A.by_point[kk] : 0;
+        const bool good = have && A.r_good[r];
+        const bool lin = good && A.r_lin[r];
         const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
         const int t = A.r_target[r];
         const int q = host + t * A.N;
-        const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
-        const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
-        if (!A.r_lin[r]) {
-            bdA = (float)((double)bdA + ((double)J[O_X_JIR] * (double)J[O_DD] + (double)J[O_X_JIR + 1] * (double)J[O_DD + 1]));
-            HddA += g0 * J[O_DD] + g1 * J[O_DD + 1];
+        float hdd = 0, bd = 0, hcd[4] = {0, 0, 0, 0};
+        double ah[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (good) {
+            const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
+            const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
+            hdd = g0 * J[O_DD] + g1 * J[O_DD + 1];
 #pragma unroll
-            for (int j = 0; j < 4; j++) HcdA[j] += J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
-        } else {
-            HddL += g0 * J[O_DD] + g1 * J[O_DD + 1];
+            for (int j = 0; j < 4; j++) hcd[j] = J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
+            if (!lin) bd = (float)((double)J[O_X_JIR] * (double)J[O_DD] + (double)J[O_X_JIR + 1] * (double)J[O_DD + 1]);
+            float v[8];
+            const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r + 4);
+            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+            const double* AH = X.adH + 64 * (size_t)q;
+            const double* AT = X.adT + 64 * (size_t)q;
+            double* dst = row + 4 + 8 * t;
 #pragma unroll
-            for (int j = 0; j < 4; j++) HcdL[j] += J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
-            // bdL needs adHTdeltaF/cdelta: accumulated by k_ba_point_bdL (rare path) into pt_acc[7]
+            for (int a = 0; a < 8; a++) {
+                double sh = 0, st = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { sh += AH[a * 8 + j] * (double)v[j]; st += AT[a * 8 + j] * (double)v[j]; }
+                ah[a] = sh;
+                dst[a] = st;                                   // one residual per (point, target): plain store
+            }
         }
-        const float* v = A.r_jpjdf + 8 * (size_t)r;
-        const double* AH = X.adH + 64 * (size_t)q + 8 * i;
-        const double* AT = X.adT + 64 * (size_t)q + 8 * i;
-        double ah = 0, at = 0;
+        // every lane takes part in every shuffle; LINEARIZED residuals (rare) are routed to the L sums by masking
+        ngood += (int)sum8(good ? 1.f : 0.f);
+        HddA += sum8(lin ? 0.f : hdd);
+        bdA += sum8(lin ? 0.f : bd);                          // bdL comes from k_ba_point_bdL
+        HddL += sum8(lin ? hdd : 0.f);
 #pragma unroll
-        for (int j = 0; j < 8; j++) { ah += AH[j] * (double)v[j]; at += AT[j] * (double)v[j]; }
-        hostacc += ah;
-        row[4 + 8 * t + i] = at;
+        for (int j = 0; j < 4; j++) { HcdA[j] += sum8(lin ? 0.f : hcd[j]); HcdL[j] += sum8(lin ? hcd[j] : 0.f); }
+#pragma unroll
+        for (int a = 0; a < 8; a++) hostacc[a] += sum8d(ah[a]);
     }
+    if (!pv) return;
     float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
     float HdiF = 0.f, bdSum = 0.f;
     if (ngood > 0) {
@@ -258,8 +308,14 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
         bdSum = bdA + bdLv;
         const float deltaF = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
         bdSum += A.pt_prior[p] * deltaF;                   // shiftPriorToZero, :1904
-        row[4 + 8 * host + i] = hostacc;
-        if (i < 4) row[i] = (double)(HcdA[i] + HcdL[i]);
+        double hv = 0.0;
+        float cv = 0.f;
+#pragma unroll
+        for (int a = 0; a < 8; a++) if (a == i) hv = hostacc[a];
+#pragma unroll
+        for (int a = 0; a < 4; a++) if (a == i) cv = HcdA[a] + HcdL[a];
+        row[4 + 8 * host + i] = hv;
+        if (i < 4) row[i] = (double)cv;
         if (i == 4) row[A.n] = (double)bdSum;
     }
     if (i == 0) {
@@ -271,10 +327,10 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
 }
 
 // mode: 0 = ACTIVE pair blocks + point rows, 1 = LINEARIZED pair blocks only (rare path)
-__global__ __launch_bounds__(256) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
+__global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
     const int NN = A.N * A.N;
     if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode == 1);
-    else point_rows_block(A, X, blockIdx.x - NN);
+    else point_rows_block(A, X, blockIdx.x - NN);      // 128 points per 1024-thread block
 }
 
 // LINEARIZED-mode bd (BA.cpp:1699-1750), rare path: one thread per point
@@ -317,48 +373,19 @@ struct SysArgs {
     double* Hf; double* bf;                                 // final LM system (unscaled): (HL+HM+HA) diag*(1+l) - Hsc/(1+l), bL+bM+bA-bsc
 };
 
-// element (I,Jc) of stitchDoubleTop's result (incl. the mirroring/symmetrisation of BA.cpp:1857-1876) from pair blocks
-__device__ double top_elem(const SysArgs& S, const double* pb, int use_blocks, int use_prior, int I, int Jc) {
-    const int N = S.N;
+// Per-frame sums of the stitched pair blocks (the accumulation order of stitchDoubleTop, BA.cpp:1827-1843, per frame):
+//   D_a = sum_t HH[a,t] + sum_h TT[h,a]   (8x8, diagonal block of frame a)
+//   C_a = sum_t HC[a,t] + sum_h TC[h,a]   (8x4, frame-calibration coupling)      B_a = sum_t bH[a,t] + sum_h bT[h,a]
+// Each tile workgroup builds the few it needs cooperatively in LDS (one summed value per task, loads pipelined).
+#define FS_STRIDE 104     // 64 (D) + 32 (C) + 8 (B)
+__device__ __forceinline__ double frame_sum(const double* pb, int N, int a, int v) {
+    const int offH = v < 64 ? PB_HH + v : (v < 96 ? PB_HC + (v - 64) : PB_BH + (v - 96));
+    const int offT = v < 64 ? PB_TT + v : (v < 96 ? PB_TC + (v - 64) : PB_BT + (v - 96));
     double s = 0;
-    if (I < 4 && Jc < 4) {
-        if (use_blocks) for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + PB_CC + I * 4 + Jc];
-        if (use_prior && I == Jc) s += S.cprior[I];
-    } else if (I < 4 || Jc < 4) {
-        const int F = I < 4 ? Jc : I, C = I < 4 ? I : Jc;
-        const int a = (F - 4) >> 3, i = (F - 4) & 7;
-        if (use_blocks) {
-            for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_HC + i * 4 + C];
-            for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_TC + i * 4 + C];
-        }
-    } else {
-        const int a = (I - 4) >> 3, i = (I - 4) & 7, b = (Jc - 4) >> 3, j = (Jc - 4) & 7;
-        if (a == b) {
-            if (use_blocks) {
-                for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_HH + i * 8 + j];
-                for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_TT + i * 8 + j];
-            }
-            if (use_prior && i == j) s += S.prior[8 * a + i];
-        } else if (use_blocks) {
-            s = pb[(size_t)(a + b * N) * PB_STRIDE + PB_HT + i * 8 + j] + pb[(size_t)(b + a * N) * PB_STRIDE + PB_HT + j * 8 + i];
-        }
-    }
-    return s;
-}
-__device__ double top_b(const SysArgs& S, const double* pb, int use_blocks, int use_prior, int I) {
-    const int N = S.N;
-    double s = 0;
-    if (I < 4) {
-        if (use_blocks) for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + PB_BC + I];
-        if (use_prior) s += S.cprior[I] * S.cdelta[I];
-    } else {
-        const int a = (I - 4) >> 3, i = (I - 4) & 7;
-        if (use_blocks) {
-            for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + PB_BH + i];
-            for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + PB_BT + i];
-        }
-        if (use_prior) s += S.prior[8 * a + i] * S.dprior[8 * a + i];
-    }
+#pragma unroll 4
+    for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + offH];
+#pragma unroll 4
+    for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + offT];
     return s;
 }
 
@@ -367,18 +394,50 @@ __device__ double top_b(const SysArgs& S, const double* pb, int use_blocks, int 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_ba_system(SysArgs S) {
     __shared__ double s_part[NW][256];
+    __shared__ double s_fs[2][6][FS_STRIDE];      // [ACTIVE | LINEARIZED][row frames 0..2, col frames 3..5]
+    __shared__ double s_cc[2][20];                // calibration block CC (16) + bC (4)
     int ti = 0, rem = blockIdx.x;
     while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
     const int tj = ti + rem;
-    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, NT = 64 * NW;
+    const int N = S.N, n = S.n;
+    // ---- which frame sums does this tile need?
+    const int fr0 = (16 * ti - 4) >> 3, fc0 = (16 * tj - 4) >> 3;       // first frame touching the tile's rows / cols (may be -1)
+    const bool has_bcol = (16 * tj <= n) && (n < 16 * tj + 16);
+    const bool calib_rows = ti == 0, calib_cols = tj == 0;
+    const int nmat = S.use_lin_blocks ? 2 : 1;
+    for (int task = tid; task < nmat * 6 * FS_STRIDE; task += NT) {
+        const int v = task % FS_STRIDE, slot = (task / FS_STRIDE) % 6, mat = task / (6 * FS_STRIDE);
+        const int f = slot < 3 ? fr0 + slot : fc0 + (slot - 3);
+        if (f < 0 || f >= N) continue;
+        bool need;
+        if (v < 64) need = slot < 3 && f >= fc0 && f <= fc0 + 2;                       // D: frame in rows AND cols
+        else if (v < 96) need = slot < 3 ? calib_cols : calib_rows;                     // C
+        else need = slot < 3 && has_bcol;                                               // B
+        if (!need) continue;
+        s_fs[mat][slot][v] = frame_sum(mat == 0 ? S.pbA : S.pbL, N, f, v);
+    }
+    if (calib_rows && (calib_cols || has_bcol)) {
+        for (int task = tid; task < nmat * 20; task += NT) {
+            const int v = task % 20, mat = task / 20;
+            const double* pb = mat == 0 ? S.pbA : S.pbL;
+            const int off = v < 16 ? PB_CC + v : PB_BC + (v - 16);
+            double s = 0;
+#pragma unroll 4
+            for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + off];
+            s_cc[mat][v] = s;
+        }
+    }
+    // ---- SYRK on the matrix cores: every wave owns a contiguous point range, loads issued ahead of the MFMA chain
     const int kk = l >> 4, c = l & 15;
     double4_ acc = {0.0, 0.0, 0.0, 0.0};
     const int per = ((S.P + NW - 1) / NW + 3) & ~3;           // points per wave, multiple of 4
     const int p_beg = wv * per, p_end = min(S.P, p_beg + per);
-    for (int s = p_beg; s < p_end; s += 16) {                  // 4 MFMAs per trip, loads issued ahead of the chain
-        double a[4], b[4];
+    double4_ acc2 = {0.0, 0.0, 0.0, 0.0};
+    for (int s = p_beg; s < p_end; s += 64) {                  // 16 MFMAs per trip on two independent accumulators
+        double a[16], b[16];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 16; u++) {
             const int p = s + 4 * u + kk;
             a[u] = 0.0; b[u] = 0.0;
             if (p < p_end) {
@@ -388,34 +447,54 @@ __global__ __launch_bounds__(64 * NW) void k_ba_system(SysArgs S) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < 16; u += 2) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], b[u + 1], acc2, 0, 0, 0);
+        }
     }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) acc[rg] += acc2[rg];
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) s_part[wv][(kk + 4 * rg) * 16 + c] = acc[rg];
     __syncthreads();
-    // one thread per tile element: fixed-order wave sum, then every matrix of the system at (r,c) and (c,r)
-    for (int e = tid; e < 256; e += 64 * NW) {
+    // ---- one thread per tile element: fixed-order wave sum, then every matrix of the system at (r,c) and (c,r)
+    for (int e = tid; e < 256; e += NT) {
         double hsc = 0;
 #pragma unroll
         for (int w = 0; w < NW; w++) hsc += s_part[w][e];
         const int r = 16 * ti + (e >> 4), cc = 16 * tj + (e & 15);
-        const int n = S.n;
         if (r >= n || cc > n) continue;
-        if (cc == n) {                                                  // the augmented column = right-hand sides
-            const double ba = top_b(S, S.pbA, 1, 0, r), bl = top_b(S, S.pbL, S.use_lin_blocks, 1, r);
+        const int a = (r - 4) >> 3, i = (r - 4) & 7, rs = a - fr0;                      // row frame / slot (valid when r >= 4)
+        if (cc == n) {                                                                  // augmented column = right-hand sides
+            double ba, bl;
+            if (r < 4) { ba = s_cc[0][16 + r]; bl = (S.use_lin_blocks ? s_cc[1][16 + r] : 0.0) + S.cprior[r] * S.cdelta[r]; }
+            else { ba = s_fs[0][rs][96 + i]; bl = (S.use_lin_blocks ? s_fs[1][rs][96 + i] : 0.0) + S.prior[8 * a + i] * S.dprior[8 * a + i]; }
             S.bsc[r] = hsc; S.bA[r] = ba; S.bL[r] = bl;
-            S.bf[r] = ((bl + (S.bM ? S.bM[r] : 0.0)) + ba) - hsc;       // BA.cpp:1300
+            S.bf[r] = ((bl + (S.bM ? S.bM[r] : 0.0)) + ba) - hsc;                       // BA.cpp:1300
             continue;
         }
-        if (ti == tj && cc < r) continue;                               // lower half of a diagonal tile: written by its mirror
-        const double ha = top_elem(S, S.pbA, 1, 0, r, cc), hl = top_elem(S, S.pbL, S.use_lin_blocks, 1, r, cc);
-        double hf = (hl + (S.HM ? S.HM[(size_t)r * n + cc] : 0.0)) + ha; // BA.cpp:1299
-        if (r == cc) hf *= (1 + S.lambda);                              // :1306-1308
-        hf -= hsc * (1.0 / (1 + S.lambda));                             // :1309
+        if (ti == tj && cc < r) continue;                                               // lower half of a diagonal tile: written by its mirror
+        const int b = (cc - 4) >> 3, j = (cc - 4) & 7, cs = 3 + (b - fc0);
+        double ha, hl;
+        if (r < 4 && cc < 4) {
+            ha = s_cc[0][r * 4 + cc]; hl = (S.use_lin_blocks ? s_cc[1][r * 4 + cc] : 0.0) + (r == cc ? S.cprior[r] : 0.0);
+        } else if (r < 4) {                                                             // calib row, frame col: mirror of H[frame, C] (:1869)
+            ha = s_fs[0][cs][64 + j * 4 + r]; hl = S.use_lin_blocks ? s_fs[1][cs][64 + j * 4 + r] : 0.0;
+        } else if (cc < 4) {
+            ha = s_fs[0][rs][64 + i * 4 + cc]; hl = S.use_lin_blocks ? s_fs[1][rs][64 + i * 4 + cc] : 0.0;
+        } else if (a == b) {
+            ha = s_fs[0][rs][i * 8 + j]; hl = (S.use_lin_blocks ? s_fs[1][rs][i * 8 + j] : 0.0) + (i == j ? S.prior[8 * a + i] : 0.0);
+        } else {                                                                        // symmetrisation of :1871-1875
+            ha = S.pbA[(size_t)(a + b * N) * PB_STRIDE + PB_HT + i * 8 + j] + S.pbA[(size_t)(b + a * N) * PB_STRIDE + PB_HT + j * 8 + i];
+            hl = S.use_lin_blocks ? S.pbL[(size_t)(a + b * N) * PB_STRIDE + PB_HT + i * 8 + j] + S.pbL[(size_t)(b + a * N) * PB_STRIDE + PB_HT + j * 8 + i] : 0.0;
+        }
+        double hf = (hl + (S.HM ? S.HM[(size_t)r * n + cc] : 0.0)) + ha;                // BA.cpp:1299
+        if (r == cc) hf *= (1 + S.lambda);                                              // :1306-1308
+        hf -= hsc * (1.0 / (1 + S.lambda));                                             // :1309
         S.Hsc[(size_t)r * n + cc] = hsc; S.HA[(size_t)r * n + cc] = ha; S.HL[(size_t)r * n + cc] = hl; S.Hf[(size_t)r * n + cc] = hf;
         if (r != cc) {
             double hfm = hf;
-            if (S.HM) {                                                 // HM need not be exactly symmetric: mirror element recomputed
+            if (S.HM) {                                                                 // HM need not be exactly symmetric
                 hfm = (hl + S.HM[(size_t)cc * n + r]) + ha;
                 hfm -= hsc * (1.0 / (1 + S.lambda));
             }
@@ -432,7 +511,25 @@ __global__ __launch_bounds__(64 * NW) void k_ba_system(SysArgs S) {
 //   (3) trailing tiles A_IJ -= W_IK L_JK^T on the matrix cores (4 x v_mfma_f64_16x16x4_f64 per tile, tiles round-robin on waves).
 // Workgroup 1 (blockIdx.x == 1): energy/census sums of the last residual pass + setNewFrameEnergyTH (see ba_linearize.hip).
 #define SOLVE_THREADS 512
-__device__ __forceinline__ int blk_off(int I, int J) { return ((I * (I + 1)) / 2 + J) * 256; }
+#define BLD 17                      // leading dimension of a 16x16 LDS block (+1 double: conflict-free column access)
+#define BSZ (16 * BLD)
+
+__device__ __forceinline__ int blk_off(int I, int J) { return ((I * (I + 1)) / 2 + J) * BSZ; }
+// broadcast of one lane's double (lane is wave-uniform): two v_readlane_b32, no LDS round trip
+// 1/d: v_rcp_f64 seed + two Newton steps (error ~ eps); the IEEE division expansion is ~3x longer on the pivot chain
+__device__ __forceinline__ double fast_rcp(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = x * (2.0 - d * x);
+    x = x * (2.0 - d * x);
+    return x;
+}
+__device__ __forceinline__ double rl(double v, int lane) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
 
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, const double* __restrict__ Hf,
                                                             const double* __restrict__ bf, double* __restrict__ x, int* __restrict__ flag,
@@ -446,12 +543,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
         return;
     }
     const int m = n - off, nb = (m + 15) / 16, mp = nb * 16;
+    DBG_T(A, 48);
     if (tid == 0) lin_out->nonfinite = 0;            // consumed by the back-substitution launch that follows
     double* L = sm;                                  // nb(nb+1)/2 blocks
-    double* Wk = L + (size_t)(nb * (nb + 1) / 2) * 256;   // panel W_IK: nb blocks of 16x16
-    double* Sv = Wk + (size_t)nb * 256;              // mp
+    double* Wk = L + (size_t)(nb * (nb + 1) / 2) * BSZ;   // panel W_IK: nb blocks
+    double* Sv = Wk + (size_t)nb * BSZ;              // mp
     double* y = Sv + mp;                             // mp
     double* dvec = y + mp;                           // mp (D)
+    double* dinv = dvec + mp;                        // mp (1/D)
     for (int i = tid; i < mp; i += SOLVE_THREADS) {
         double s = 0.0;
         if (i < m) s = 1.0 / sqrt(Hf[(size_t)(off + i) * n + off + i] + 10.0);      // SVecI, :1312
@@ -463,44 +562,49 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
         if (j > i) continue;
         double v = (i == j) ? 1.0 : 0.0;                     // identity padding keeps the padded system SPD
         if (i < m && j < m) v = Sv[i] * Hf[(size_t)(off + i) * n + off + j] * Sv[j];
-        L[blk_off(i >> 4, j >> 4) + (i & 15) * 16 + (j & 15)] = v;
+        L[blk_off(i >> 4, j >> 4) + (i & 15) * BLD + (j & 15)] = v;
     }
     for (int i = tid; i < mp; i += SOLVE_THREADS) y[i] = (i < m) ? Sv[i] * bf[off + i] : 0.0;
     __syncthreads();
+    DBG_T(A, 49);
     const int wv = tid >> 6, l = tid & 63, NWV = SOLVE_THREADS / 64;
     for (int K = 0; K < nb; K++) {
         double* D = L + blk_off(K, K);
-        if (wv == 0) {                                       // (1) diagonal block: LDL^T in place, lower part
-            for (int k = 0; k < 16; k++) {
-                const double d = D[k * 16 + k];
-                const double dinv = 1.0 / d;
+        if (wv == 0) {                                       // (1) diagonal block: LDL^T with one ROW PER LANE in registers;
+            double row[16];                                   //     pivots / column entries travel by v_readlane (no LDS latency chain)
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int e = l + 64 * u, i = e >> 4, j = e & 15;
-                    if (i > k && j > k && j <= i) D[e] -= D[i * 16 + k] * D[j * 16 + k] * dinv;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (l < 16 && l > k) D[l * 16 + k] *= dinv;
-                __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < 16; j++) row[j] = (l < 16) ? D[l * BLD + j] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const double dk = rl(row[k], k);
+                const double di = fast_rcp(dk);
+                const double cid = row[k] * di;                 // l_ik (meaningful for lanes i > k)
+#pragma unroll
+                for (int j = k + 1; j < 16; j++) row[j] -= cid * rl(row[k], j);   // upper-triangle lanes compute unused values
+                if (l > k) row[k] = cid;
+                if (l == 0) { dvec[16 * K + k] = dk; dinv[16 * K + k] = di; }
             }
-            if (l < 16) dvec[16 * K + l] = D[l * 16 + l];
+            if (l < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) D[l * BLD + j] = row[j];
+            }
         }
         __syncthreads();
-        // (2) panel rows: solve X L_KK^T D = A_IK  ->  W = X D (kept), L_IK = X
+        // (2) panel rows: solve W L_KK^T = A_IK (W = L_IK D kept for the update), L_IK = W D^-1
         for (int rr = tid; rr < (nb - K - 1) * 16; rr += SOLVE_THREADS) {
             const int I = K + 1 + (rr >> 4), i = rr & 15;
-            double* Arow = L + blk_off(I, K) + i * 16;
+            double* Arow = L + blk_off(I, K) + i * BLD;
             double wrow[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 double s = Arow[j];
 #pragma unroll
-                for (int t = 0; t < 16; t++) if (t < j) s -= wrow[t] * D[j * 16 + t];      // W_ij = A_ij - sum_t W_it L_jt
+                for (int t = 0; t < 16; t++) if (t < j) s -= wrow[t] * D[j * BLD + t];
                 wrow[j] = s;
             }
-            double* Wrow = Wk + (size_t)(I - K - 1) * 256 + i * 16;
+            double* Wrow = Wk + (size_t)(I - K - 1) * BSZ + i * BLD;
 #pragma unroll
-            for (int j = 0; j < 16; j++) { Wrow[j] = wrow[j]; Arow[j] = wrow[j] / D[j * 16 + j]; }
+            for (int j = 0; j < 16; j++) { Wrow[j] = wrow[j]; Arow[j] = wrow[j] * dinv[16 * K + j]; }
         }
         __syncthreads();
         // (3) trailing update on the matrix cores: A_IJ -= W_IK L_JK^T, K < J <= I
@@ -510,37 +614,43 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
             while (rem >= a + 1) { rem -= a + 1; a++; }       // tile (a, rem), rem <= a
             const int I = K + 1 + a, J = K + 1 + rem;
             double* C = L + blk_off(I, J);
-            const double* W = Wk + (size_t)a * 256;
+            const double* W = Wk + (size_t)a * BSZ;
             const double* Lj = L + blk_off(J, K);
             const int kq = l >> 4, cidx = l & 15;
             double4_ acc;
 #pragma unroll
-            for (int rg = 0; rg < 4; rg++) acc[rg] = C[(kq + 4 * rg) * 16 + cidx];
+            for (int rg = 0; rg < 4; rg++) acc[rg] = C[(kq + 4 * rg) * BLD + cidx];
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const double av = -W[cidx * 16 + 4 * s + kq];            // A[i = l&15][k]
-                const double bv = Lj[cidx * 16 + 4 * s + kq];            // B[k][j = l&15] = L_JK[j][k]
+                const double av = -W[cidx * BLD + 4 * s + kq];           // A[i = l&15][k]
+                const double bv = Lj[cidx * BLD + 4 * s + kq];           // B[k][j = l&15] = L_JK[j][k]
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int rg = 0; rg < 4; rg++) C[(kq + 4 * rg) * 16 + cidx] = acc[rg];
+            for (int rg = 0; rg < 4; rg++) C[(kq + 4 * rg) * BLD + cidx] = acc[rg];
         }
         __syncthreads();
     }
+    DBG_T(A, 50);
     // forward substitution L z = y (block rows), then D^-1 (Eigen LDLT.h:580-587 pseudo-inverse rule), then L^T x = z
     for (int K = 0; K < nb; K++) {
-        if (wv == 0) {
+        if (wv == 0) {                                       // unit-lower solve of the diagonal block, row per lane in registers
             const double* D = L + blk_off(K, K);
+            double row[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) row[j] = (l < 16) ? D[l * BLD + j] : 0.0;
+            double yv = (l < 16) ? y[16 * K + l] : 0.0;
+#pragma unroll
             for (int k = 0; k < 16; k++) {
-                const double yk = y[16 * K + k];
-                if (l < 16 && l > k) y[16 * K + l] -= D[l * 16 + k] * yk;
-                __builtin_amdgcn_wave_barrier();
+                const double yk = rl(yv, k);
+                if (l > k) yv -= row[k] * yk;
             }
+            if (l < 16) y[16 * K + l] = yv;
         }
         __syncthreads();
         for (int rr = tid; rr < (nb - K - 1) * 16; rr += SOLVE_THREADS) {
             const int I = K + 1 + (rr >> 4), i = rr & 15;
-            const double* Lr = L + blk_off(I, K) + i * 16;
+            const double* Lr = L + blk_off(I, K) + i * BLD;
             double s = 0;
 #pragma unroll
             for (int j = 0; j < 16; j++) s += Lr[j] * y[16 * K + j];
@@ -548,19 +658,25 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
         }
         __syncthreads();
     }
+    DBG_T(A, 51);
     for (int i = tid; i < mp; i += SOLVE_THREADS) {
         const double d = dvec[i];
-        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
+        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] * dinv[i] : 0.0;
     }
     __syncthreads();
     for (int K = nb - 1; K >= 0; K--) {
-        if (wv == 0) {
+        if (wv == 0) {                                       // L_KK^T x = z: COLUMN per lane in registers
             const double* D = L + blk_off(K, K);
+            double col[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) col[k] = (l < 16) ? D[k * BLD + l] : 0.0;
+            double yv = (l < 16) ? y[16 * K + l] : 0.0;
+#pragma unroll
             for (int k = 15; k >= 0; k--) {
-                const double xk = y[16 * K + k];
-                if (l < k) y[16 * K + l] -= D[k * 16 + l] * xk;
-                __builtin_amdgcn_wave_barrier();
+                const double xk = rl(yv, k);
+                if (l < k) yv -= col[k] * xk;
             }
+            if (l < 16) y[16 * K + l] = yv;
         }
         __syncthreads();
         for (int rr = tid; rr < K * 16; rr += SOLVE_THREADS) {      // rows of blocks J < K: y_J -= L_KJ^T x_K
@@ -568,11 +684,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
             const double* Lb = L + blk_off(K, J);
             double s = 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) s += Lb[i * 16 + j] * y[16 * K + i];
+            for (int i = 0; i < 16; i++) s += Lb[i * BLD + j] * y[16 * K + i];
             y[16 * J + j] -= s;
         }
         __syncthreads();
     }
+    DBG_T(A, 52);
     int bad = 0;
     for (int i = tid; i < n; i += SOLVE_THREADS) {
         const double v = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
@@ -582,6 +699,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     if (tid == 0) *flag = 0;
     __syncthreads();
     if (bad) atomicOr(flag, 1);
+    DBG_T(A, 53);
 }
 
 // ------------------------------------------------------------------------------------------------ K6
@@ -686,7 +804,7 @@ __global__ __launch_bounds__(256) void k_ba_step_points(BAArgs A, float* __restr
 static inline int ldg_of(int n) { return ((n + 1 + 15) / 16) * 16; }
 static size_t solve_lds_bytes(int m) {
     const int nb = (m + 15) / 16, mp = nb * 16;
-    size_t d = (size_t)(nb * (nb + 1) / 2) * 256 + (size_t)nb * 256 + 3 * (size_t)mp;
+    size_t d = (size_t)(nb * (nb + 1) / 2) * BSZ + (size_t)nb * BSZ + 4 * (size_t)mp;
     if (d < 2048 + 1024) d = 2048 + 1024;                     // lin_finish_block scratch: 2048 u32-pairs + 1024 doubles
     return d * sizeof(double);
 }
@@ -703,10 +821,10 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
         if (c->n_lin > 0) {                              // rare path: LINEARIZED residuals present
             AccArgs XL = X;
             XL.acc_out = c->acc_pair[1].as<float>(); XL.num_out = c->acc_num[1].as<int>(); XL.pair_blocks = pbL;
-            k_ba_acc<<<NN, 256, 0, c->stream>>>(A, XL, 1);
+            k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
             k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
         }
-        k_ba_acc<<<NN + cml_div_up(A.P * 8, 256), 256, 0, c->stream>>>(A, X, 0);
+        k_ba_acc<<<NN + cml_div_up(A.P * 8, 1024), 1024, 0, c->stream>>>(A, X, 0);
     }
     SysArgs S;
     S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = c->n_lin > 0 ? 1 : 0;
@@ -717,7 +835,7 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     S.HA = c->HA.as<double>(); S.bA = c->bA.as<double>(); S.HL = c->HL.as<double>(); S.bL = c->bL.as<double>();
     S.Hsc = c->Hsc.as<double>(); S.bsc = c->bsc.as<double>(); S.Hf = c->Hf.as<double>(); S.bf = c->bf.as<double>();
     const int ntiles = S.ntile * (S.ntile + 1) / 2;
-    if (A.P > 4096) k_ba_system<16><<<ntiles, 1024, 0, c->stream>>>(S);
+    if (A.P > 1024) k_ba_system<16><<<ntiles, 1024, 0, c->stream>>>(S);
     else k_ba_system<4><<<ntiles, 256, 0, c->stream>>>(S);
     return CMLHIP_OK;
 }

@@ -31,6 +31,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.by_point_off = c->by_point_off.as<int>(); A.by_point = c->by_point.as<int>();
     A.by_pair_off = c->by_pair_off.as<int>(); A.by_pair = c->by_pair.as<int>();
     A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0;
+    A.dbg = c->dbg_on ? c->dbg.as<long long>() : nullptr;
     return CMLHIP_OK;
 }
 
@@ -369,6 +370,16 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     cml_launch_linearize(c, A);                              // K1: residuals + Jacobians (+ applyRes)
     if (prof) { hipEventRecord(ev[3], c->stream); hipEventRecord(ev[4], c->stream); hipEventRecord(ev[5], c->stream); c->prof_n++; }
     CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+int cmlhip_debug_timestamps(cmlhip_ctx* c, int enable, long long* out128) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    int rc = cml_ensure(c, c->dbg, 128 * sizeof(long long));
+    if (rc) return rc;
+    if (out128 && (rc = cml_d2h(c, out128, c->dbg.p, 128 * sizeof(long long)))) return rc;
+    c->dbg_on = enable != 0;
+    if (enable) CML_CHECK(c, hipMemsetAsync(c->dbg.p, 0, 128 * sizeof(long long), c->stream));
     return CMLHIP_OK;
 }
 

@@ -15,6 +15,8 @@ enum { O_RES = 0, O_XI0 = 8, O_XI1 = 14, O_C0 = 20, O_C1 = 24, O_DD = 28, O_JI0 
 // per-pair stitched fp64 blocks (stitchDoubleTop, BA.cpp:1827-1843): HH TT HT (64 each) HC TC (32 each) bH bT (8 each) CC (16) bC (4)
 enum { PB_HH = 0, PB_TT = 64, PB_HT = 128, PB_HC = 192, PB_TC = 224, PB_BH = 256, PB_BT = 264, PB_CC = 272, PB_BC = 288, PB_STRIDE = 296 };
 
+#define DBG_T(A, slot) do { if ((A).dbg && threadIdx.x == 0 && blockIdx.x == 0) (A).dbg[slot] = wall_clock64(); } while (0)
+
 struct LinSummary {
     double energy;
     int n_in, n_oob, n_outlier;
@@ -37,6 +39,7 @@ struct BAArgs {
     float* r_center; float* r_jpjdf; float* r_rtz; float* rj0; float* rj1;
     const int* by_point_off; const int* by_point; const int* by_pair_off; const int* by_pair;
     double* lin_partial;          // per-block {energy, n_in, n_oob, n_outlier} of the residual kernel (may be null)
+    long long* dbg;               // optional phase timestamps (wall_clock64, 100 MHz): 16 slots per kernel, see cmlhip_debug_read
     int fuse_apply;               // residual kernel also performs applyRes(copyJacobians=true) (valid when the step is always accepted)
 };
 

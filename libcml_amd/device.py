@@ -44,6 +44,7 @@ PROTOTYPES = {
     "cmlhip_ba_set_pairs": (C.c_int, [_ctx, _P(abi.BAPair)]),
     "cmlhip_ba_window_size": (C.c_int, [_ctx, _P(_i), _P(_i), _P(_i)]),
     "cmlhip_profile_enable": (C.c_int, [_ctx, _i]),
+    "cmlhip_debug_timestamps": (C.c_int, [_ctx, _i, _P(C.c_longlong)]),
     "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
