@@ -296,8 +296,11 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);   /* linearize→
  * stream.  read returns the mean durations in ms over the recorded iterations and resets the recorder. */
 int cmlhip_profile_enable(cmlhip_ctx* ctx, int max_iterations);
 /* development aid: in-kernel phase timestamps (wall clock, 10 ns ticks), 16 slots per kernel: [0,16) residual kernel,
- * [16,32) accumulate, [32,48) system tiles, [48,64) solve, [64,80) back-substitution. Reads the previous values, then (re)arms. */
-int cmlhip_debug_timestamps(cmlhip_ctx* ctx, int enable, long long* out128);
+ * [16,32) accumulate, [32,48) system tiles, [48,64) solve, [64,80) back-substitution; then, from slot 128, per-workgroup
+ * {begin, end} pairs for the five kernels (1024 workgroups each).  `out` holds CMLHIP_DEBUG_SLOTS values.
+ * Reads the previous values, then (re)arms. */
+#define CMLHIP_DEBUG_SLOTS (128 + 5 * 1024 * 2)
+int cmlhip_debug_timestamps(cmlhip_ctx* ctx, int enable, long long* out);
 int cmlhip_profile_read(cmlhip_ctx* ctx, float* linearize_ms, float* schur_solve_ms, int* n_recorded);
 
 #ifdef __cplusplus

@@ -224,80 +224,76 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     if (A.dbg && tid == 0 && q == 1) A.dbg[19] = wall_clock64();
 }
 
-// 8 lanes per point, ONE RESIDUAL PER LANE per pass (a point has at most N-1 residuals), so the dependent load chain
-// by_point -> r -> {good, sel, target} -> record is walked once per point instead of once per residual.
+// One WAVE per point: lane = (slot s = lane>>3, component a = lane&7); slot s walks the point's s-th residual (a point
+// has at most N-1 of them, so one pass for N <= 9), component a owns output a of the two 8x8 adjoint products.  The
+// dependent chain by_point -> r -> {good, sel, target} -> record is walked once per point, the 1 KB of AH/AT a residual
+// needs is spread over 8 lanes x 128 B, and 16 points per workgroup put the rows on >= P/16 CUs.
 // Per point: Hdd/bd/Hcd sums (BA.cpp:1747-1750), HdiF, bdSum (BA.cpp:1895-1905); coupling row in FRAME coordinates:
 // g_p[0:4] = Hcd, g_p[4+8h+i] = sum_r (AH_ht JpJdF_r)_i, g_p[4+8t+i] = (AT_ht JpJdF_r)_i, G[p][n] = bdSum.
-__device__ __forceinline__ float sum8(float v) {          // sum over the 8 lanes of a point (xor butterflies stay inside the group)
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+// The row is assembled in LDS and leaves the CU as one coalesced store.
+#define PT_PER_BLOCK 16
+#define LDG_MAX (((8 * CMLHIP_MAX_FRAMES + 4) + 1 + 15) / 16 * 16)
+__device__ __forceinline__ float sum_slots(float v) {     // sum over the 8 slots (xor butterflies over lane bits 3..5)
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     return v;
 }
-__device__ __forceinline__ double sum8d(double v) {
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+__device__ __forceinline__ double sum_slots_d(double v) {
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs& X, const int blk) {
-    const int gid = blk * 1024 + threadIdx.x;
-    const int p = gid >> 3, i = gid & 7;
-    const bool pv = p < A.P;
-    const int pp = pv ? p : 0;
-    const int host = A.pt_host[pp];
-    const int beg = A.by_point_off[pp], end = pv ? A.by_point_off[pp + 1] : beg;
-    double* row = X.G + (size_t)pp * X.ldg;
-    if (pv) {   // zero-fill: lane i owns columns {4+8f+i}, lanes 0-3 the calibration columns, lane 4 the rhs column, lane 5 the padding
-        for (int f = 0; f < A.N; f++) row[4 + 8 * f + i] = 0.0;
-        if (i < 4) row[i] = 0.0;
-        if (i == 4) row[A.n] = 0.0;
-        if (i == 5) for (int cix = A.n + 1; cix < X.ldg; cix++) row[cix] = 0.0;
-        if (X.do_backup && i == 6) A.pt_backup[p] = (float)A.pt_idepth[p];          // backupState, BA.cpp:919-922
-    }
-    float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, HcdL[4] = {0, 0, 0, 0};
-    int ngood = 0;
-    double hostacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ __attribute__((aligned(16))) double s_row[PT_PER_BLOCK][LDG_MAX];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, s = l >> 3, a = l & 7;
+    const int p = blk * PT_PER_BLOCK + wv;
+    if (p >= A.P) return;                                    // wave-uniform
+    double* srow = s_row[wv];
+    for (int c = l; c < X.ldg; c += 64) srow[c] = 0.0;
+    const int host = A.pt_host[p];
+    const int beg = A.by_point_off[p], end = A.by_point_off[p + 1];
+    // component a of a slot computes one of the per-residual scalars: a<4 Hcd[a], a=4 Hdd, a=5 bd, a=6 good count
+    float accA = 0.f, accL = 0.f;
+    double hostacc = 0.0;
     for (int base = beg; base < end; base += 8) {            // one pass for N <= 9
-        const int kk = base + i;
+        const int kk = base + s;
         const bool have = kk < end;
         const int r = have ? A.by_point[kk] : 0;
         const bool good = have && A.r_good[r];
         const bool lin = good && A.r_lin[r];
-        const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
-        const int t = A.r_target[r];
-        const int q = host + t * A.N;
-        float hdd = 0, bd = 0, hcd[4] = {0, 0, 0, 0};
-        double ah[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double sh = 0.0;
+        float val = 0.f;
         if (good) {
-            const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
-            const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
-            hdd = g0 * J[O_DD] + g1 * J[O_DD + 1];
-#pragma unroll
-            for (int j = 0; j < 4; j++) hcd[j] = J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
-            if (!lin) bd = (float)((double)J[O_X_JIR] * (double)J[O_DD] + (double)J[O_X_JIR + 1] * (double)J[O_DD + 1]);
-            float v[8];
+            const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
+            const int t = A.r_target[r];
+            const int q = host + t * A.N;
             const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r + 4);
-            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-            const double* AH = X.adH + 64 * (size_t)q;
-            const double* AT = X.adT + 64 * (size_t)q;
-            double* dst = row + 4 + 8 * t;
+            const double4_* AH = reinterpret_cast<const double4_*>(X.adH + 64 * (size_t)q + 8 * a);
+            const double4_* AT = reinterpret_cast<const double4_*>(X.adT + 64 * (size_t)q + 8 * a);
+            const double4_ h0 = AH[0], h1 = AH[1], t0 = AT[0], t1 = AT[1];
+            const float d0 = J[O_DD], d1 = J[O_DD + 1];
+            const float g0 = J[O_JI2 + 0] * d0 + J[O_JI2 + 2] * d1;
+            const float g1 = J[O_JI2 + 1] * d0 + J[O_JI2 + 3] * d1;
+            const float c0 = a < 4 ? J[O_C0 + (a & 3)] : d0, c1 = a < 4 ? J[O_C1 + (a & 3)] : d1;
+            val = c0 * g0 + c1 * g1;                          // Hcd[a] (a < 4), Hdd (a == 4)
+            if (a == 5) val = lin ? 0.f : (float)((double)J[O_X_JIR] * (double)d0 + (double)J[O_X_JIR + 1] * (double)d1);   // bdL: k_ba_point_bdL
+            if (a == 6) val = 1.f;
+            if (a == 7) val = 0.f;
+            double st = 0.0;
+            const double v[8] = {(double)v0.x, (double)v0.y, (double)v0.z, (double)v0.w, (double)v1.x, (double)v1.y, (double)v1.z, (double)v1.w};
 #pragma unroll
-            for (int a = 0; a < 8; a++) {
-                double sh = 0, st = 0;
+            for (int j = 0; j < 4; j++) { sh += h0[j] * v[j]; st += t0[j] * v[j]; }
 #pragma unroll
-                for (int j = 0; j < 8; j++) { sh += AH[a * 8 + j] * (double)v[j]; st += AT[a * 8 + j] * (double)v[j]; }
-                ah[a] = sh;
-                dst[a] = st;                                   // one residual per (point, target): plain store
-            }
+            for (int j = 0; j < 4; j++) { sh += h1[j] * v[4 + j]; st += t1[j] * v[4 + j]; }
+            srow[4 + 8 * t + a] = st;                          // one residual per (point, target): plain store
         }
         // every lane takes part in every shuffle; LINEARIZED residuals (rare) are routed to the L sums by masking
-        ngood += (int)sum8(good ? 1.f : 0.f);
-        HddA += sum8(lin ? 0.f : hdd);
-        bdA += sum8(lin ? 0.f : bd);                          // bdL comes from k_ba_point_bdL
-        HddL += sum8(lin ? hdd : 0.f);
-#pragma unroll
-        for (int j = 0; j < 4; j++) { HcdA[j] += sum8(lin ? 0.f : hcd[j]); HcdL[j] += sum8(lin ? hcd[j] : 0.f); }
-#pragma unroll
-        for (int a = 0; a < 8; a++) hostacc[a] += sum8d(ah[a]);
+        accA += sum_slots(lin ? 0.f : val);
+        accL += sum_slots(lin ? val : 0.f);
+        hostacc += sum_slots_d(sh);
     }
-    if (!pv) return;
+    // gather the point's scalars (valid in every lane): lanes 0..6 of slot 0 hold items 0..6
+    const float HcdA_a = __shfl(accA, a & 3), HcdL_a = __shfl(accL, a & 3);
+    const float HddA = __shfl(accA, 4), HddL = __shfl(accL, 4), bdA = __shfl(accA, 5);
+    const int ngood = (int)(__shfl(accA, 6) + __shfl(accL, 6));
     float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
     float HdiF = 0.f, bdSum = 0.f;
     if (ngood > 0) {
@@ -308,29 +304,31 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
         bdSum = bdA + bdLv;
         const float deltaF = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
         bdSum += A.pt_prior[p] * deltaF;                   // shiftPriorToZero, :1904
-        double hv = 0.0;
-        float cv = 0.f;
-#pragma unroll
-        for (int a = 0; a < 8; a++) if (a == i) hv = hostacc[a];
-#pragma unroll
-        for (int a = 0; a < 4; a++) if (a == i) cv = HcdA[a] + HcdL[a];
-        row[4 + 8 * host + i] = hv;
-        if (i < 4) row[i] = (double)cv;
-        if (i == 4) row[A.n] = (double)bdSum;
+        if (s == 0) {
+            srow[4 + 8 * host + a] = hostacc;
+            if (a < 4) srow[a] = (double)(HcdA_a + HcdL_a);
+            if (a == 4) srow[A.n] = (double)bdSum;
+        }
     }
-    if (i == 0) {
-        pa[0] = HddA; pa[1] = bdA; pa[2] = HcdA[0]; pa[3] = HcdA[1]; pa[4] = HcdA[2]; pa[5] = HcdA[3];
-        pa[6] = HddL; pa[8] = HcdL[0]; pa[9] = HcdL[1]; pa[10] = HcdL[2]; pa[11] = HcdL[3];
-        pa[12] = HdiF; pa[13] = bdSum;
-        X.Wt[p] = (double)HdiF;
+    if (s == 0) {
+        // pt_acc: HddA bdA HcdA[4] HddL bdL HcdL[4] HdiF bdSum
+        if (a < 4) { pa[2 + a] = HcdA_a; pa[8 + a] = HcdL_a; }
+        else if (a == 4) { pa[0] = HddA; pa[6] = HddL; }
+        else if (a == 5) { pa[1] = bdA; pa[12] = HdiF; }
+        else if (a == 6) { pa[13] = bdSum; X.Wt[p] = (double)HdiF; }
+        else if (X.do_backup) A.pt_backup[p] = (float)A.pt_idepth[p];          // backupState, BA.cpp:919-922
     }
+    double* row = X.G + (size_t)p * X.ldg;                 // LDS accesses of one wave are ordered: no barrier needed
+    for (int c = l; c < X.ldg; c += 64) row[c] = srow[c];
 }
 
 // mode: 0 = ACTIVE pair blocks + point rows, 1 = LINEARIZED pair blocks only (rare path)
 __global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
     const int NN = A.N * A.N;
+    DBG_BLK(A.dbg, 1, 0);
     if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode == 1);
-    else point_rows_block(A, X, blockIdx.x - NN);      // 128 points per 1024-thread block
+    else point_rows_block(A, X, blockIdx.x - NN);      // 16 points per 1024-thread block
+    DBG_BLK_END(A.dbg, 1);
 }
 
 // LINEARIZED-mode bd (BA.cpp:1699-1750), rare path: one thread per point
@@ -370,6 +368,7 @@ struct SysArgs {
     const double* HM; const double* bM;                     // may be null
     double lambda;
     double* HA; double* bA; double* HL; double* bL; double* Hsc; double* bsc;
+    long long* dbg;
     double* Hf; double* bf;                                 // final LM system (unscaled): (HL+HM+HA) diag*(1+l) - Hsc/(1+l), bL+bM+bA-bsc
 };
 
@@ -396,6 +395,7 @@ __global__ __launch_bounds__(64 * NW) void k_ba_system(SysArgs S) {
     __shared__ double s_part[NW][256];
     __shared__ double s_fs[2][6][FS_STRIDE];      // [ACTIVE | LINEARIZED][row frames 0..2, col frames 3..5]
     __shared__ double s_cc[2][20];                // calibration block CC (16) + bC (4)
+    DBG_BLK(S.dbg, 2, 0);
     int ti = 0, rem = blockIdx.x;
     while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
     const int tj = ti + rem;
@@ -501,6 +501,7 @@ __global__ __launch_bounds__(64 * NW) void k_ba_system(SysArgs S) {
             S.Hsc[(size_t)cc * n + r] = hsc; S.HA[(size_t)cc * n + r] = ha; S.HL[(size_t)cc * n + r] = hl; S.Hf[(size_t)cc * n + r] = hfm;
         }
     }
+    DBG_BLK_END(S.dbg, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ K5
@@ -537,9 +538,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
                                                             int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
+    DBG_BLK(A.dbg, 3, 0);
     if (blockIdx.x == 1) {
         if (do_finish) lin_finish_block(A, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw,
                                         reinterpret_cast<unsigned*>(sm), sm + 2048);
+        DBG_BLK_END(A.dbg, 3);
         return;
     }
     const int m = n - off, nb = (m + 15) / 16, mp = nb * 16;
@@ -700,6 +703,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     __syncthreads();
     if (bad) atomicOr(flag, 1);
     DBG_T(A, 53);
+    DBG_BLK_END(A.dbg, 3);
 }
 
 // ------------------------------------------------------------------------------------------------ K6
@@ -710,6 +714,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
     extern __shared__ __attribute__((aligned(16))) double s_xAd[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
     __shared__ float s_red[3][4];
     const int N = A.N;
+    DBG_BLK(A.dbg, 4, 0);
     for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) {
         const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N;
         const double* AH = adH + 64 * (size_t)(h + N * t); const double* AT = adT + 64 * (size_t)(h + N * t);
@@ -767,6 +772,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
             step_partial[4 * blockIdx.x + k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
         }
     }
+    DBG_BLK_END(A.dbg, 4);
 }
 
 __global__ void k_ba_backup_points(BAArgs A) {          // BA.cpp:919-922
@@ -824,11 +830,11 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
             k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
             k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
         }
-        k_ba_acc<<<NN + cml_div_up(A.P * 8, 1024), 1024, 0, c->stream>>>(A, X, 0);
+        k_ba_acc<<<NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, c->stream>>>(A, X, 0);
     }
     SysArgs S;
     S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = c->n_lin > 0 ? 1 : 0;
-    S.G = X.G; S.Wt = X.Wt; S.pbA = c->pair_blocks.as<double>(); S.pbL = pbL;
+    S.G = X.G; S.Wt = X.Wt; S.pbA = c->pair_blocks.as<double>(); S.pbL = pbL; S.dbg = A.dbg;
     S.cdelta = vs; S.cprior = vs + 4; S.prior = vs + 8; S.dprior = vs + 8 + 8 * N;
     S.HM = have_hm ? c->HM.as<double>() : nullptr; S.bM = have_hm ? c->bM.as<double>() : nullptr;
     S.lambda = lambda;

@@ -374,12 +374,13 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
 }
 
 int cmlhip_debug_timestamps(cmlhip_ctx* c, int enable, long long* out128) {
+    const size_t NS = CMLHIP_DEBUG_SLOTS;
     if (!c) return CMLHIP_ERR_INVALID;
-    int rc = cml_ensure(c, c->dbg, 128 * sizeof(long long));
+    int rc = cml_ensure(c, c->dbg, NS * sizeof(long long));
     if (rc) return rc;
-    if (out128 && (rc = cml_d2h(c, out128, c->dbg.p, 128 * sizeof(long long)))) return rc;
+    if (out128 && (rc = cml_d2h(c, out128, c->dbg.p, NS * sizeof(long long)))) return rc;
     c->dbg_on = enable != 0;
-    if (enable) CML_CHECK(c, hipMemsetAsync(c->dbg.p, 0, 128 * sizeof(long long), c->stream));
+    if (enable) CML_CHECK(c, hipMemsetAsync(c->dbg.p, 0, NS * sizeof(long long), c->stream));
     return CMLHIP_OK;
 }
 

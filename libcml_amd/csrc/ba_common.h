@@ -17,6 +17,10 @@ enum { PB_HH = 0, PB_TT = 64, PB_HT = 128, PB_HC = 192, PB_TC = 224, PB_BH = 256
 
 #define DBG_T(A, slot) do { if ((A).dbg && threadIdx.x == 0 && blockIdx.x == 0) (A).dbg[slot] = wall_clock64(); } while (0)
 
+// per-workgroup {begin,end} stamps: kernel k in 0..4 (linearize, acc, system, solve, backsub)
+#define DBG_BLK(dbgp, k, which) do { if ((dbgp) && threadIdx.x == 0 && blockIdx.x < 1024) (dbgp)[128 + ((k) * 1024 + blockIdx.x) * 2 + (which)] = wall_clock64(); } while (0)
+#define DBG_BLK_END(dbgp, k) do { if (dbgp) { __syncthreads(); DBG_BLK(dbgp, k, 1); } } while (0)
+
 struct LinSummary {
     double energy;
     int n_in, n_oob, n_outlier;

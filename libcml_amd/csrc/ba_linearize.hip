@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK];
     __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
+    DBG_BLK(A.dbg, 0, 0);
     const int r = blockIdx.x * RES_PER_BLOCK + g;
     const bool live = (r < A.R) && !A.r_lin[r];
     const int st = live ? A.r_state[r] : CMLHIP_RES_OOB;
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         o[0] = e; o[1] = c0; o[2] = c1; o[3] = c2;
     }
     (void)ok;
+    DBG_BLK_END(A.dbg, 0);
 }
 
 // ------------------------------------------------------------------------------------------------

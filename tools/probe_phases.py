@@ -8,12 +8,26 @@ ctx = device.Ctx(max_frames=W.N, max_points=W.P, max_residuals=W.P * W.N)
 ba = host.window_to_host_ba(ctx, W, levels=1); ba.set_param("iterations", 1); assert ba.run()
 for _ in range(10): ctx.ba_iteration_async(1e-5)
 ctx.sync()
-out = np.zeros(128, np.int64)
+NS = 128 + 5 * 1024 * 2
+out = np.zeros(NS, np.int64)
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 1, None))
-for _ in range(3): ctx.ba_iteration_async(1e-5)
+for _ in range(1): ctx.ba_iteration_async(1e-5)
 ctx.sync()
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 0, out.ctypes.data_as(C.POINTER(C.c_longlong))))
 def seg(name, a, b): print("%-34s %7.2f us" % (name, (out[b] - out[a]) * 0.01))
 seg("acc pair: load+accumulate loop", 16, 17); seg("acc pair: wave reduce", 17, 18); seg("acc pair: fp64 stitch", 18, 19)
 seg("solve: load+scale", 48, 49); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
 seg("solve: total", 48, 53)
+
+names = ["linearize", "acc", "system", "solve", "backsub"]
+blk = out[128:].reshape(5, 1024, 2)
+# pipeline order inside one iteration: acc, system, solve, backsub, linearize
+t0 = min(b[b[:, 0] > 0, 0].min() for b in blk)
+for k in (1, 2, 3, 4, 0):
+    b = blk[k]; b = b[b[:, 0] > 0]
+    st = (b[:, 0] - t0) * 0.01; en = (b[:, 1] - t0) * 0.01; d = en - st
+    print("%-10s blocks %4d  first start %7.2f  last start %7.2f  last end %7.2f | block us: min %6.2f med %6.2f max %6.2f" %
+          (names[k], len(b), st.min(), st.max(), en.max(), d.min(), np.median(d), d.max()))
+    if k == 1:
+        NN = W.N * W.N
+        print("   pair blocks: med %.2f max %.2f ; point blocks: med %.2f max %.2f" % (np.median(d[:NN]), d[:NN].max(), np.median(d[NN:]), d[NN:].max()))
