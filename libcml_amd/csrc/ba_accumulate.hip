@@ -361,7 +361,8 @@ __global__ void k_ba_point_bdL(BAArgs A, const float* __restrict__ adHTd, const 
 
 // ------------------------------------------------------------------------------------------------ K4
 struct SysArgs {
-    int N, n, ldg, ntile, P, use_lin_blocks;
+    int N, n, ldg, ntile, P, use_lin_blocks, nsl, nsyrk;    // nsl point slices per tile, nsyrk = ntiles*nsl SYRK workgroups (0: row blocks only)
+    double* part;                                           // SYRK partial tiles [tile][slice][256]
     const double* G; const double* Wt;
     const double* pbA; const double* pbL;                   // per-pair stitched blocks (ACTIVE / LINEARIZED)
     const double* cdelta; const double* cprior; const double* prior; const double* dprior;
@@ -369,7 +370,7 @@ struct SysArgs {
     double lambda;
     double* HA; double* bA; double* HL; double* bL; double* Hsc; double* bsc;
     long long* dbg;
-    double* Hf; double* bf;                                 // final LM system (unscaled): (HL+HM+HA) diag*(1+l) - Hsc/(1+l), bL+bM+bA-bsc
+    double* Hb; double* bb;                                 // lambda-independent part of the final LM system: (HL+HM)+HA, (bL+bM)+bA
 };
 
 // Per-frame sums of the stitched pair blocks (the accumulation order of stitchDoubleTop, BA.cpp:1827-1843, per frame):
@@ -388,120 +389,146 @@ __device__ __forceinline__ double frame_sum(const double* pb, int N, int a, int 
     return s;
 }
 
-// grid = upper-triangular tiles of the padded (n+1) system; block = 64*NW threads.
-// A[i][k] = G[p][16 ti + i], B[k][j] = w[p] G[p][16 tj + j]; D: col = lane&15, row = (lane>>4) + 4*reg.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_ba_system(SysArgs S) {
-    __shared__ double s_part[NW][256];
-    __shared__ double s_fs[2][6][FS_STRIDE];      // [ACTIVE | LINEARIZED][row frames 0..2, col frames 3..5]
-    __shared__ double s_cc[2][20];                // calibration block CC (16) + bC (4)
+// k_ba_system, 256 threads per workgroup, two kinds of workgroup, no communication between them:
+//   [0, ntiles*nsl)  SYRK: the 16x16 tile (ti <= tj) of H_sc = G^T diag(HdiF) [G | bdSum] over slice sl of the points, on the
+//                    matrix cores (A[i][k] = G[p][16 ti + i], B[k][j] = w[p] G[p][16 tj + j]; D: col = lane&15,
+//                    row = (lane>>4) + 4*reg) -> part[(tile*nsl + sl)*256 + e].  The slices are added in slice order by
+//                    the consumer (k_ba_solve / k_ba_schur_out), so no workgroup pulls more than P/nsl rows through its CU
+//                    and nothing depends on arrival order.
+//   then N+1         row blocks of H_A, H_L (+ priors) and Hb = (H_L + H_M) + H_A (BA.cpp:1299), the lambda-independent part of
+//                    the final system: workgroup 0 = calibration rows, workgroup 1+a = the 8 rows of frame a.
+#define SYS_NW 8
+__device__ __forceinline__ int sys_tile_index(int ti, int tj, int ntile) { return ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti); }
+
+__global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
+    __shared__ double s_part[SYS_NW][256];
+    __shared__ double s_f[2][FS_STRIDE];          // [ACTIVE | LINEARIZED] D (64) C (32) B (8) of this frame, or CC (16) bC (4)
     DBG_BLK(S.dbg, 2, 0);
-    int ti = 0, rem = blockIdx.x;
-    while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
-    const int tj = ti + rem;
-    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, NT = 64 * NW;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, NT = 64 * SYS_NW;
     const int N = S.N, n = S.n;
-    // ---- which frame sums does this tile need?
-    const int fr0 = (16 * ti - 4) >> 3, fc0 = (16 * tj - 4) >> 3;       // first frame touching the tile's rows / cols (may be -1)
-    const bool has_bcol = (16 * tj <= n) && (n < 16 * tj + 16);
-    const bool calib_rows = ti == 0, calib_cols = tj == 0;
-    const int nmat = S.use_lin_blocks ? 2 : 1;
-    for (int task = tid; task < nmat * 6 * FS_STRIDE; task += NT) {
-        const int v = task % FS_STRIDE, slot = (task / FS_STRIDE) % 6, mat = task / (6 * FS_STRIDE);
-        const int f = slot < 3 ? fr0 + slot : fc0 + (slot - 3);
-        if (f < 0 || f >= N) continue;
-        bool need;
-        if (v < 64) need = slot < 3 && f >= fc0 && f <= fc0 + 2;                       // D: frame in rows AND cols
-        else if (v < 96) need = slot < 3 ? calib_cols : calib_rows;                     // C
-        else need = slot < 3 && has_bcol;                                               // B
-        if (!need) continue;
-        s_fs[mat][slot][v] = frame_sum(mat == 0 ? S.pbA : S.pbL, N, f, v);
+    if ((int)blockIdx.x < S.nsyrk) {
+        const int tile = blockIdx.x / S.nsl, sl = blockIdx.x % S.nsl;
+        int ti = 0, rem = tile;
+        while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
+        const int tj = ti + rem;
+        // every wave owns a contiguous point range, loads issued ahead of the MFMA chain
+        const int kk = l >> 4, c = l & 15;
+        const int per_s = ((S.P + S.nsl - 1) / S.nsl + 3) & ~3;             // points per slice, multiple of 4
+        const int s_beg = sl * per_s, s_end = min(S.P, s_beg + per_s);
+        const int per = ((max(s_end - s_beg, 0) + SYS_NW - 1) / SYS_NW + 3) & ~3;
+        const int p_beg = s_beg + wv * per, p_end = min(s_end, p_beg + per);
+        double4_ acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        for (int sp = p_beg; sp < p_end; sp += 64) {               // 16 MFMAs per trip on two independent accumulators
+            double a[16], b[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int p = sp + 4 * u + kk;
+                a[u] = 0.0; b[u] = 0.0;
+                if (p < p_end) {
+                    const double* row = S.G + (size_t)p * S.ldg;
+                    a[u] = row[16 * ti + c];
+                    b[u] = S.Wt[p] * row[16 * tj + c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], b[u + 1], acc2, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) acc[rg] += acc2[rg];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) s_part[wv][(kk + 4 * rg) * 16 + c] = acc[rg];
+        __syncthreads();
+        if (tid < 256) {
+            double sum = s_part[0][tid];
+#pragma unroll
+            for (int w = 1; w < SYS_NW; w++) sum += s_part[w][tid];
+            S.part[(size_t)blockIdx.x * 256 + tid] = sum;
+        }
+        DBG_BLK_END(S.dbg, 2);
+        return;
     }
-    if (calib_rows && (calib_cols || has_bcol)) {
+    const int a = (int)blockIdx.x - S.nsyrk - 1;                             // -1: calibration rows
+    const int nmat = S.use_lin_blocks ? 2 : 1;
+    if (a < 0) {
         for (int task = tid; task < nmat * 20; task += NT) {
             const int v = task % 20, mat = task / 20;
             const double* pb = mat == 0 ? S.pbA : S.pbL;
             const int off = v < 16 ? PB_CC + v : PB_BC + (v - 16);
-            double s = 0;
-#pragma unroll 4
-            for (int q = 0; q < N * N; q++) s += pb[(size_t)q * PB_STRIDE + off];
-            s_cc[mat][v] = s;
+            double sum = 0;
+#pragma unroll 8
+            for (int q = 0; q < N * N; q++) sum += pb[(size_t)q * PB_STRIDE + off];
+            s_f[mat][v] = sum;
         }
-    }
-    // ---- SYRK on the matrix cores: every wave owns a contiguous point range, loads issued ahead of the MFMA chain
-    const int kk = l >> 4, c = l & 15;
-    double4_ acc = {0.0, 0.0, 0.0, 0.0};
-    const int per = ((S.P + NW - 1) / NW + 3) & ~3;           // points per wave, multiple of 4
-    const int p_beg = wv * per, p_end = min(S.P, p_beg + per);
-    double4_ acc2 = {0.0, 0.0, 0.0, 0.0};
-    for (int s = p_beg; s < p_end; s += 64) {                  // 16 MFMAs per trip on two independent accumulators
-        double a[16], b[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const int p = s + 4 * u + kk;
-            a[u] = 0.0; b[u] = 0.0;
-            if (p < p_end) {
-                const double* row = S.G + (size_t)p * S.ldg;
-                a[u] = row[16 * ti + c];
-                b[u] = S.Wt[p] * row[16 * tj + c];
+        __syncthreads();
+        for (int e = tid; e < 4 * 5; e += NT) {
+            const int r = e / 5, cq = e % 5;
+            if (cq == 4) {                                                                  // right-hand sides, BA.cpp:1300
+                const double ba = s_f[0][16 + r], bl = (S.use_lin_blocks ? s_f[1][16 + r] : 0.0) + S.cprior[r] * S.cdelta[r];
+                S.bA[r] = ba; S.bL[r] = bl;
+                S.bb[r] = (bl + (S.bM ? S.bM[r] : 0.0)) + ba;
+            } else {
+                const int lo = min(r, cq), hi = max(r, cq);                                 // lower half mirrors the upper one
+                const double ha = s_f[0][lo * 4 + hi], hl = (S.use_lin_blocks ? s_f[1][lo * 4 + hi] : 0.0) + (r == cq ? S.cprior[r] : 0.0);
+                S.HA[(size_t)r * n + cq] = ha; S.HL[(size_t)r * n + cq] = hl;
+                S.Hb[(size_t)r * n + cq] = (hl + (S.HM ? S.HM[(size_t)r * n + cq] : 0.0)) + ha;
             }
         }
-#pragma unroll
-        for (int u = 0; u < 16; u += 2) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], b[u + 1], acc2, 0, 0, 0);
-        }
+        DBG_BLK_END(S.dbg, 2);
+        return;
     }
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) acc[rg] += acc2[rg];
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) s_part[wv][(kk + 4 * rg) * 16 + c] = acc[rg];
+    for (int task = tid; task < nmat * FS_STRIDE; task += NT) {
+        const int v = task % FS_STRIDE, mat = task / FS_STRIDE;
+        s_f[mat][v] = frame_sum(mat == 0 ? S.pbA : S.pbL, N, a, v);
+    }
     __syncthreads();
-    // ---- one thread per tile element: fixed-order wave sum, then every matrix of the system at (r,c) and (c,r)
-    for (int e = tid; e < 256; e += NT) {
-        double hsc = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) hsc += s_part[w][e];
-        const int r = 16 * ti + (e >> 4), cc = 16 * tj + (e & 15);
-        if (r >= n || cc > n) continue;
-        const int a = (r - 4) >> 3, i = (r - 4) & 7, rs = a - fr0;                      // row frame / slot (valid when r >= 4)
-        if (cc == n) {                                                                  // augmented column = right-hand sides
-            double ba, bl;
-            if (r < 4) { ba = s_cc[0][16 + r]; bl = (S.use_lin_blocks ? s_cc[1][16 + r] : 0.0) + S.cprior[r] * S.cdelta[r]; }
-            else { ba = s_fs[0][rs][96 + i]; bl = (S.use_lin_blocks ? s_fs[1][rs][96 + i] : 0.0) + S.prior[8 * a + i] * S.dprior[8 * a + i]; }
-            S.bsc[r] = hsc; S.bA[r] = ba; S.bL[r] = bl;
-            S.bf[r] = ((bl + (S.bM ? S.bM[r] : 0.0)) + ba) - hsc;                       // BA.cpp:1300
+    for (int e = tid; e < 8 * (n + 1); e += NT) {
+        const int i = e / (n + 1), cc = e % (n + 1), r = 4 + 8 * a + i;
+        if (cc == n) {
+            const double ba = s_f[0][96 + i], bl = (S.use_lin_blocks ? s_f[1][96 + i] : 0.0) + S.prior[8 * a + i] * S.dprior[8 * a + i];
+            S.bA[r] = ba; S.bL[r] = bl;
+            S.bb[r] = (bl + (S.bM ? S.bM[r] : 0.0)) + ba;
             continue;
         }
-        if (ti == tj && cc < r) continue;                                               // lower half of a diagonal tile: written by its mirror
-        const int b = (cc - 4) >> 3, j = (cc - 4) & 7, cs = 3 + (b - fc0);
         double ha, hl;
-        if (r < 4 && cc < 4) {
-            ha = s_cc[0][r * 4 + cc]; hl = (S.use_lin_blocks ? s_cc[1][r * 4 + cc] : 0.0) + (r == cc ? S.cprior[r] : 0.0);
-        } else if (r < 4) {                                                             // calib row, frame col: mirror of H[frame, C] (:1869)
-            ha = s_fs[0][cs][64 + j * 4 + r]; hl = S.use_lin_blocks ? s_fs[1][cs][64 + j * 4 + r] : 0.0;
-        } else if (cc < 4) {
-            ha = s_fs[0][rs][64 + i * 4 + cc]; hl = S.use_lin_blocks ? s_fs[1][rs][64 + i * 4 + cc] : 0.0;
-        } else if (a == b) {
-            ha = s_fs[0][rs][i * 8 + j]; hl = (S.use_lin_blocks ? s_fs[1][rs][i * 8 + j] : 0.0) + (i == j ? S.prior[8 * a + i] : 0.0);
-        } else {                                                                        // symmetrisation of :1871-1875
-            ha = S.pbA[(size_t)(a + b * N) * PB_STRIDE + PB_HT + i * 8 + j] + S.pbA[(size_t)(b + a * N) * PB_STRIDE + PB_HT + j * 8 + i];
-            hl = S.use_lin_blocks ? S.pbL[(size_t)(a + b * N) * PB_STRIDE + PB_HT + i * 8 + j] + S.pbL[(size_t)(b + a * N) * PB_STRIDE + PB_HT + j * 8 + i] : 0.0;
-        }
-        double hf = (hl + (S.HM ? S.HM[(size_t)r * n + cc] : 0.0)) + ha;                // BA.cpp:1299
-        if (r == cc) hf *= (1 + S.lambda);                                              // :1306-1308
-        hf -= hsc * (1.0 / (1 + S.lambda));                                             // :1309
-        S.Hsc[(size_t)r * n + cc] = hsc; S.HA[(size_t)r * n + cc] = ha; S.HL[(size_t)r * n + cc] = hl; S.Hf[(size_t)r * n + cc] = hf;
-        if (r != cc) {
-            double hfm = hf;
-            if (S.HM) {                                                                 // HM need not be exactly symmetric
-                hfm = (hl + S.HM[(size_t)cc * n + r]) + ha;
-                hfm -= hsc * (1.0 / (1 + S.lambda));
+        if (cc < 4) {                                                                       // frame-calibration coupling and its mirror (:1869)
+            ha = s_f[0][64 + i * 4 + cc]; hl = S.use_lin_blocks ? s_f[1][64 + i * 4 + cc] : 0.0;
+            S.HA[(size_t)cc * n + r] = ha; S.HL[(size_t)cc * n + r] = hl;
+            S.Hb[(size_t)cc * n + r] = (hl + (S.HM ? S.HM[(size_t)cc * n + r] : 0.0)) + ha;
+        } else {
+            const int b = (cc - 4) >> 3, j = (cc - 4) & 7;
+            if (a == b) {
+                const int lo = min(i, j), hi = max(i, j);                                   // lower half mirrors the upper one
+                ha = s_f[0][lo * 8 + hi]; hl = (S.use_lin_blocks ? s_f[1][lo * 8 + hi] : 0.0) + (i == j ? S.prior[8 * a + i] : 0.0);
+            } else {                                                                        // symmetrisation of :1871-1875 (the sum commutes: (r,c) == (c,r) bitwise)
+                const int lo = min(a, b), hi = max(a, b), ii = a < b ? i : j, jj = a < b ? j : i;
+                const size_t q0 = (size_t)(lo + hi * N) * PB_STRIDE + PB_HT + ii * 8 + jj, q1 = (size_t)(hi + lo * N) * PB_STRIDE + PB_HT + jj * 8 + ii;
+                ha = S.pbA[q0] + S.pbA[q1];
+                hl = S.use_lin_blocks ? S.pbL[q0] + S.pbL[q1] : 0.0;
             }
-            S.Hsc[(size_t)cc * n + r] = hsc; S.HA[(size_t)cc * n + r] = ha; S.HL[(size_t)cc * n + r] = hl; S.Hf[(size_t)cc * n + r] = hfm;
         }
+        S.HA[(size_t)r * n + cc] = ha; S.HL[(size_t)r * n + cc] = hl;
+        S.Hb[(size_t)r * n + cc] = (hl + (S.HM ? S.HM[(size_t)r * n + cc] : 0.0)) + ha;
     }
     DBG_BLK_END(S.dbg, 2);
+}
+
+// H_sc / b_sc for the host (statistics, tests): slices added in slice order.  Not on the iteration path.
+__global__ __launch_bounds__(256) void k_ba_schur_out(SysArgs S) {
+    const int tile = blockIdx.x, e = threadIdx.x, n = S.n;
+    int ti = 0, rem = tile;
+    while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
+    const int tj = ti + rem;
+    double hsc = 0;
+    for (int k = 0; k < S.nsl; k++) hsc += S.part[((size_t)tile * S.nsl + k) * 256 + e];
+    const int r = 16 * ti + (e >> 4), cc = 16 * tj + (e & 15);
+    if (r >= n || cc > n) return;
+    if (cc == n) { S.bsc[r] = hsc; return; }
+    if (ti == tj && cc < r) return;
+    S.Hsc[(size_t)r * n + cc] = hsc;
+    if (r != cc) S.Hsc[(size_t)cc * n + r] = hsc;
 }
 
 // ------------------------------------------------------------------------------------------------ K5
@@ -532,8 +559,61 @@ __device__ __forceinline__ double rl(double v, int lane) {
     return u.d;
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, const double* __restrict__ Hf,
-                                                            const double* __restrict__ bf, double* __restrict__ x, int* __restrict__ flag,
+struct SolveSys {            // the final LM system, assembled while it is loaded (BA.cpp:1299-1312)
+    const double* Hb; const double* bb; const double* part; int nsl, ntile; double lambda;
+};
+// H_sc(gi, gj), gj <= gi or the rhs column gi == n: slices added in slice order
+__device__ __forceinline__ double schur_entry(const SolveSys& Y, int grow, int gcol) {     // grow <= gcol (upper tile storage)
+    const int ti = grow >> 4, tj = gcol >> 4;
+    const double* q = Y.part + ((size_t)sys_tile_index(ti, tj, Y.ntile) * Y.nsl) * 256 + (grow & 15) * 16 + (gcol & 15);
+    double ps[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ps[k] = q[(size_t)min(k, Y.nsl - 1) * 256] * (k < Y.nsl ? 1.0 : 0.0);   // cml_sys_slices() <= 8: all loads in flight
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += ps[k];
+    return sum;
+}
+
+// SOLVE_IPT (lower block, element) items of the final system for one thread: item it0 + u*SOLVE_THREADS, u < SOLVE_IPT.
+// Hf = Hb (diagonal * (1+lambda)) - H_sc / (1+lambda)  (:1306-1309); identity on the padding keeps the padded system SPD.
+// Every load is unconditional (clamped address, mask multiplied in): a select would let the compiler sink each load
+// behind its own branch + s_waitcnt, i.e. one memory round trip per load instead of one per thread.
+#define SOLVE_IPT 8
+__device__ __forceinline__ void solve_load_items(const SolveSys& Y, int n, int off, int m, int items, int it0,
+                                                 double (&val)[SOLVE_IPT], int (&dst)[SOLVE_IPT], int (&ij)[SOLVE_IPT]) {
+    const double il = 1.0 / (1 + Y.lambda);
+    double hb[SOLVE_IPT], ps[SOLVE_IPT][8];
+    bool diag[SOLVE_IPT];
+#pragma unroll
+    for (int u = 0; u < SOLVE_IPT; u++) {
+        const int it = it0 + u * SOLVE_THREADS;
+        int I = 0, rem = it >> 8;
+        while (rem >= I + 1) { rem -= I + 1; I++; }
+        const int J = rem, i = 16 * I + (it & 15), j = 16 * J + ((it >> 4) & 15);      // i fastest: the slices are stored (j, i) row-major
+        const bool live = it < items && j <= i;
+        const bool real = live && i < m;                      // (j <= i < m)
+        dst[u] = live ? blk_off(I, J) + (i & 15) * BLD + (j & 15) : -1;
+        ij[u] = (i << 16) | j;
+        diag[u] = real && i == j;
+        const int gr = off + j, gc = off + i;                 // upper-tile storage of the Schur slices: row <= col
+        const double* q = real ? Y.part + ((size_t)sys_tile_index(gr >> 4, gc >> 4, Y.ntile) * Y.nsl) * 256 + (gr & 15) * 16 + (gc & 15) : Y.part;
+        const double hv = Y.Hb[real ? (size_t)gc * n + gr : 0];
+        hb[u] = real ? hv : (i == j ? 1.0 : 0.0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) ps[u][k] = q[(size_t)min(k, Y.nsl - 1) * 256] * ((real && k < Y.nsl) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < SOLVE_IPT; u++) {
+        double hsc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) hsc += ps[u][k];
+        double v = hb[u];
+        if (diag[u]) v *= (1 + Y.lambda);
+        val[u] = v - hsc * il;
+    }
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
                                                             const int* newframe_res, int n_newframe, const double* lin_partial,
                                                             int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -554,20 +634,46 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     double* y = Sv + mp;                             // mp
     double* dvec = y + mp;                           // mp (D)
     double* dinv = dvec + mp;                        // mp (1/D)
-    for (int i = tid; i < mp; i += SOLVE_THREADS) {
-        double s = 0.0;
-        if (i < m) s = 1.0 / sqrt(Hf[(size_t)(off + i) * n + off + i] + 10.0);      // SVecI, :1312
-        Sv[i] = s;
+    // one global round trip for the whole system, then the Jacobi scaling SVecI = (diag + 10)^-1/2 (:1312)
+    const int items = (nb * (nb + 1) / 2) * 256;                 // (lower block, element) pairs
+    if (items <= SOLVE_IPT * SOLVE_THREADS) {                    // usual window sizes: values stay in registers across the scaling
+        double val[SOLVE_IPT]; int dst[SOLVE_IPT], ij[SOLVE_IPT];
+        const int yi = SOLVE_THREADS - 1 - tid;                  // rhs on the last waves (fewest live matrix items), issued first
+        const double yraw = (Y.bb[off + min(yi, m - 1)] - schur_entry(Y, off + min(yi, m - 1), n)) * (yi < m ? 1.0 : 0.0);
+        solve_load_items(Y, n, off, m, items, tid, val, dst, ij);
+        if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(A, 54); }
+#pragma unroll
+        for (int u = 0; u < SOLVE_IPT; u++) {
+            const int i = ij[u] >> 16, j = ij[u] & 0xffff;
+            if (dst[u] >= 0 && i == j) Sv[i] = (i < m) ? 1.0 / sqrt(val[u] + 10.0) : 0.0;      // SVecI, :1312
+        }
+        __syncthreads();
+        DBG_T(A, 55);
+#pragma unroll
+        for (int u = 0; u < SOLVE_IPT; u++) {
+            const int i = ij[u] >> 16, j = ij[u] & 0xffff;
+            if (dst[u] >= 0) L[dst[u]] = (i < m) ? (Sv[i] * val[u]) * Sv[j] : val[u];
+        }
+        if (yi < mp) y[yi] = (yi < m) ? Sv[yi] * yraw : 0.0;
+    } else {
+        for (int it0 = tid; it0 < items; it0 += SOLVE_IPT * SOLVE_THREADS) {
+            double val[SOLVE_IPT]; int dst[SOLVE_IPT], ij[SOLVE_IPT];
+            solve_load_items(Y, n, off, m, items, it0, val, dst, ij);
+#pragma unroll
+            for (int u = 0; u < SOLVE_IPT; u++) if (dst[u] >= 0) L[dst[u]] = val[u];
+        }
+        for (int i = tid; i < mp; i += SOLVE_THREADS) y[i] = (i < m) ? Y.bb[off + i] - schur_entry(Y, off + i, n) : 0.0;
+        __syncthreads();
+        for (int i = tid; i < mp; i += SOLVE_THREADS) Sv[i] = (i < m) ? 1.0 / sqrt(L[blk_off(i >> 4, i >> 4) + (i & 15) * (BLD + 1)] + 10.0) : 0.0;
+        __syncthreads();
+        for (int e = tid; e < mp * mp; e += SOLVE_THREADS) {
+            const int i = e / mp, j = e % mp;
+            if (j > i || i >= m) continue;
+            double* q = &L[blk_off(i >> 4, j >> 4) + (i & 15) * BLD + (j & 15)];
+            *q = (Sv[i] * *q) * Sv[j];
+        }
+        for (int i = tid; i < m; i += SOLVE_THREADS) y[i] *= Sv[i];
     }
-    __syncthreads();
-    for (int e = tid; e < mp * mp; e += SOLVE_THREADS) {
-        const int i = e / mp, j = e % mp;
-        if (j > i) continue;
-        double v = (i == j) ? 1.0 : 0.0;                     // identity padding keeps the padded system SPD
-        if (i < m && j < m) v = Sv[i] * Hf[(size_t)(off + i) * n + off + j] * Sv[j];
-        L[blk_off(i >> 4, j >> 4) + (i & 15) * BLD + (j & 15)] = v;
-    }
-    for (int i = tid; i < mp; i += SOLVE_THREADS) y[i] = (i < m) ? Sv[i] * bf[off + i] : 0.0;
     __syncthreads();
     DBG_T(A, 49);
     const int wv = tid >> 6, l = tid & 63, NWV = SOLVE_THREADS / 64;
@@ -839,10 +945,21 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     S.HM = have_hm ? c->HM.as<double>() : nullptr; S.bM = have_hm ? c->bM.as<double>() : nullptr;
     S.lambda = lambda;
     S.HA = c->HA.as<double>(); S.bA = c->bA.as<double>(); S.HL = c->HL.as<double>(); S.bL = c->bL.as<double>();
-    S.Hsc = c->Hsc.as<double>(); S.bsc = c->bsc.as<double>(); S.Hf = c->Hf.as<double>(); S.bf = c->bf.as<double>();
+    S.Hsc = c->Hsc.as<double>(); S.bsc = c->bsc.as<double>(); S.Hb = c->Hf.as<double>(); S.bb = c->bf.as<double>();
     const int ntiles = S.ntile * (S.ntile + 1) / 2;
-    if (A.P > 1024) k_ba_system<16><<<ntiles, 1024, 0, c->stream>>>(S);
-    else k_ba_system<4><<<ntiles, 256, 0, c->stream>>>(S);
+    S.nsl = cml_sys_slices(A.P);
+    S.nsyrk = system_only ? 0 : ntiles * S.nsl;             // the Schur slices only change with the residuals
+    S.part = c->syrk_part.as<double>();
+    c->sys_lambda = lambda;
+    k_ba_system<<<S.nsyrk + N + 1, 64 * SYS_NW, 0, c->stream>>>(S);
+    return CMLHIP_OK;
+}
+
+int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A) {
+    SysArgs S = {};
+    S.n = A.n; S.ntile = ldg_of(A.n) / 16; S.nsl = cml_sys_slices(A.P); S.part = c->syrk_part.as<double>();
+    S.Hsc = c->Hsc.as<double>(); S.bsc = c->bsc.as<double>();
+    k_ba_schur_out<<<S.ntile * (S.ntile + 1) / 2, 256, 0, c->stream>>>(S);
     return CMLHIP_OK;
 }
 
@@ -855,7 +972,10 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
         hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    k_ba_solve<<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, c->Hf.as<double>(), c->bf.as<double>(), c->xvec.as<double>(), flag,
+    SolveSys Y;
+    Y.Hb = c->Hf.as<double>(); Y.bb = c->bf.as<double>(); Y.part = c->syrk_part.as<double>();
+    Y.nsl = cml_sys_slices(A.P); Y.ntile = ldg_of(n) / 16; Y.lambda = c->sys_lambda;
+    k_ba_solve<<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag,
                                                                           c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(),
                                                                           c->n_lin_partial, c->scal.as<LinSummary>(), c->frames.as<FrameDev>(),
                                                                           with_lin_finish ? 1 : 0);

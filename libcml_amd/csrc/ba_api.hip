@@ -113,7 +113,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     c->n_lin_partial = (R + 31) / 32;
     ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 255) / 256 + 1));
     ENS(c->G, 8 * ((size_t)P * ldg + P));
-    (void)ntile;
+    ENS(c->syrk_part, 8 * 256 * (size_t)(ntile * (ntile + 1) / 2) * cml_sys_slices(P));
     ENS(c->scal, 1024);
 #undef ENS
     // ---- SoA staging + upload
@@ -261,6 +261,7 @@ int cmlhip_ba_accumulate(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* HA
     BAArgs A;
     cml_make_ba_args(c, A);
     cml_launch_accumulate(c, A, c->last_lambda, false, false);
+    if (Hsc || bsc) cml_launch_schur_out(c, A);
     CML_CHECK(c, hipGetLastError());
     const size_t n = 8 * (size_t)c->N + 4;
     if (HA && (rc = cml_d2h(c, HA, c->HA.p, 8 * n * n))) return rc;

@@ -67,7 +67,7 @@ struct cmlhip_ctx {
     DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec, Hf, bf;    // (8N+4)^2 / (8N+4) doubles; Hf/bf = final LM system
     DevBuf dbg; bool dbg_on = false;                          // phase timestamps (tools)
     DevBuf step_partial;                                      // per-block {sumID, sumNID, numID, pad} of the point update
-    int n_lin_partial = 0; double last_lambda = 1e-5; bool last_have_hm = false;
+    int n_lin_partial = 0; double last_lambda = 1e-5; bool last_have_hm = false; double sys_lambda = 1e-5;
     DevBuf G;                                                 // P x ldg doubles (Schur rows [g | bdSum])
     DevBuf syrk_part;                                         // partial SYRK tiles
     DevBuf scal;                                              // small scalar scratch (energy partials, counters, th)

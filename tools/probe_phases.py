@@ -16,7 +16,7 @@ ctx.sync()
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 0, out.ctypes.data_as(C.POINTER(C.c_longlong))))
 def seg(name, a, b): print("%-34s %7.2f us" % (name, (out[b] - out[a]) * 0.01))
 seg("acc pair: load+accumulate loop", 16, 17); seg("acc pair: wave reduce", 17, 18); seg("acc pair: fp64 stitch", 18, 19)
-seg("solve: load+scale", 48, 49); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
+seg("solve: loads landed (wave 0)", 48, 54); seg("solve: Sv + barrier", 54, 55); seg("solve: scaled store", 55, 49); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
 seg("solve: total", 48, 53)
 
 names = ["linearize", "acc", "system", "solve", "backsub"]
@@ -31,3 +31,6 @@ for k in (1, 2, 3, 4, 0):
     if k == 1:
         NN = W.N * W.N
         print("   pair blocks: med %.2f max %.2f ; point blocks: med %.2f max %.2f" % (np.median(d[:NN]), d[:NN].max(), np.median(d[NN:]), d[NN:].max()))
+b = blk[2]; nb_ = int((b[:, 0] > 0).sum()); d = (b[:nb_, 1] - b[:nb_, 0]) * 0.01
+nrow = W.N + 1
+print("system: SYRK blocks %d dur med %.2f max %.2f ; row blocks dur med %.2f max %.2f" % (nb_ - nrow, np.median(d[:-nrow]), d[:-nrow].max(), np.median(d[-nrow:]), d[-nrow:].max()))
