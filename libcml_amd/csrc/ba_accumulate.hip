@@ -678,45 +678,48 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     DBG_T(A, 49);
     const int wv = tid >> 6, l = tid & 63, NWV = SOLVE_THREADS / 64;
     for (int K = 0; K < nb; K++) {
-        double* D = L + blk_off(K, K);
-        if (wv == 0) {                                       // (1) diagonal block: LDL^T with one ROW PER LANE in registers;
-            double row[16];                                   //     pivots / column entries travel by v_readlane (no LDS latency chain)
+        // (1) block column K, ONE ROW PER LANE in registers: lanes 0-15 carry the diagonal block, lanes 16-63 up to 48 rows
+        //     of the panel below it (further waves repeat the diagonal rows and take the next 48 panel rows).  The 16
+        //     elimination steps of the diagonal block — pivots and column entries travel by v_readlane from lanes 0-15, no
+        //     LDS latency on the chain — update the panel rows in the same instructions, and the right-hand side rides
+        //     along as a 17th column (forward substitution L z = y).  W_IK = L_IK D is the pre-scaling value of each entry.
+        const int nbelow = (nb - K - 1) * 16;
+        const int gi = (l < 16) ? 16 * K + l : 16 * (K + 1) + wv * 48 + (l - 16);
+        const bool prow = l >= 16 && (wv * 48 + (l - 16)) < nbelow;                 // a live panel row
+        const bool active = wv * 48 < nbelow || wv == 0;                             // wave-uniform
+        if (active) {
+            const bool have = l < 16 || prow;
+            double* Rrow = L + blk_off(have ? gi >> 4 : K, K) + (gi & 15) * BLD;
+            double row[16], w[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) row[j] = (l < 16) ? D[l * BLD + j] : 0.0;
+            for (int j = 0; j < 16; j++) row[j] = have ? Rrow[j] : 0.0;
+            double yv = have ? y[gi] : 0.0, mydk = 0.0, mydi = 0.0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const double dk = rl(row[k], k);
                 const double di = fast_rcp(dk);
-                const double cid = row[k] * di;                 // l_ik (meaningful for lanes i > k)
+                const double cid = row[k] * di;                 // l_ik (meaningful for rows below row k)
+                const double zk = rl(yv, k);
+                w[k] = row[k];
 #pragma unroll
-                for (int j = k + 1; j < 16; j++) row[j] -= cid * rl(row[k], j);   // upper-triangle lanes compute unused values
-                if (l > k) row[k] = cid;
-                if (l == 0) { dvec[16 * K + k] = dk; dinv[16 * K + k] = di; }
+                for (int j = k + 1; j < 16; j++) row[j] -= cid * rl(row[k], j);   // lanes above the pivot compute unused values
+                if (l > k) { row[k] = cid; yv -= cid * zk; }
+                if (l == k) { mydk = dk; mydi = di; }
             }
-            if (l < 16) {
+            if (have && (l >= 16 || wv == 0)) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) D[l * BLD + j] = row[j];
+                for (int j = 0; j < 16; j++) Rrow[j] = row[j];
+                y[gi] = yv;
             }
+            if (prow) {
+                double* Wrow = Wk + (size_t)((gi >> 4) - K - 1) * BSZ + (gi & 15) * BLD;
+#pragma unroll
+                for (int j = 0; j < 16; j++) Wrow[j] = w[j];
+            }
+            if (wv == 0 && l < 16) { dvec[16 * K + l] = mydk; dinv[16 * K + l] = mydi; }
         }
         __syncthreads();
-        // (2) panel rows: solve W L_KK^T = A_IK (W = L_IK D kept for the update), L_IK = W D^-1
-        for (int rr = tid; rr < (nb - K - 1) * 16; rr += SOLVE_THREADS) {
-            const int I = K + 1 + (rr >> 4), i = rr & 15;
-            double* Arow = L + blk_off(I, K) + i * BLD;
-            double wrow[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                double s = Arow[j];
-#pragma unroll
-                for (int t = 0; t < 16; t++) if (t < j) s -= wrow[t] * D[j * BLD + t];
-                wrow[j] = s;
-            }
-            double* Wrow = Wk + (size_t)(I - K - 1) * BSZ + i * BLD;
-#pragma unroll
-            for (int j = 0; j < 16; j++) { Wrow[j] = wrow[j]; Arow[j] = wrow[j] * dinv[16 * K + j]; }
-        }
-        __syncthreads();
-        // (3) trailing update on the matrix cores: A_IJ -= W_IK L_JK^T, K < J <= I
+        // (2) trailing update on the matrix cores: A_IJ -= W_IK L_JK^T, K < J <= I
         const int nt = nb - K - 1, ntiles = nt * (nt + 1) / 2;
         for (int tix = wv; tix < ntiles; tix += NWV) {
             int a = 0, rem = tix;
@@ -741,32 +744,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
         __syncthreads();
     }
     DBG_T(A, 50);
-    // forward substitution L z = y (block rows), then D^-1 (Eigen LDLT.h:580-587 pseudo-inverse rule), then L^T x = z
-    for (int K = 0; K < nb; K++) {
-        if (wv == 0) {                                       // unit-lower solve of the diagonal block, row per lane in registers
-            const double* D = L + blk_off(K, K);
-            double row[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) row[j] = (l < 16) ? D[l * BLD + j] : 0.0;
-            double yv = (l < 16) ? y[16 * K + l] : 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const double yk = rl(yv, k);
-                if (l > k) yv -= row[k] * yk;
-            }
-            if (l < 16) y[16 * K + l] = yv;
-        }
-        __syncthreads();
-        for (int rr = tid; rr < (nb - K - 1) * 16; rr += SOLVE_THREADS) {
-            const int I = K + 1 + (rr >> 4), i = rr & 15;
-            const double* Lr = L + blk_off(I, K) + i * BLD;
-            double s = 0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) s += Lr[j] * y[16 * K + j];
-            y[16 * I + i] -= s;
-        }
-        __syncthreads();
-    }
     DBG_T(A, 51);
     for (int i = tid; i < mp; i += SOLVE_THREADS) {
         const double d = dvec[i];

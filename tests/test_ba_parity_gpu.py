@@ -105,3 +105,36 @@ def test_apply_and_accumulate(pair):
     std, rc = ctx.ba_backsub(xo)
     assert rc == 0
     assert np.abs(sto - std).max() <= 5e-5 * np.abs(sto).max()
+
+
+@pytest.mark.parametrize("N,P", [(12, 1100), (9, 700)])
+def test_system_and_solver_wide_window(N, P):
+    """Windows wider than the default: several Schur slices per tile (P > 512), block columns whose panel does not fit
+    one wave (8N+4 > 64+...), with and without the calibration block and a marginalisation prior.  Bars as above:
+    Schur/Hessian blocks at fp32 accumulation tolerance, the factorisation isolated on the DEVICE's matrices at 1e-7."""
+    I = S.make_inputs((N, P, 320, 240, 3, 260.0, 260.0, 159.5, 119.5))
+    ob = S.OracleBA(I)
+    ctx = D.make_ctx(I)
+    try:
+        ob.linearize(); ctx.ba_linearize()
+        ob.apply(1); ctx.ba_apply(1)
+        HAo, bAo, HLo, bLo, Hso, bso = ob.accumulate()
+        HAd, bAd, HLd, bLd, Hsd, bsd = D.accumulate(ctx, I)
+        assert D.rel(HAd, HAo) < 2e-5 and D.rel(bAd, bAo) < 2e-5
+        assert D.rel(Hsd, Hso) < 5e-5 and D.rel(bsd, bso) < 5e-5
+        assert np.array_equal(Hsd, Hsd.T)
+        n = 8 * N + 4
+        rng = np.random.default_rng(7)
+        Q = rng.standard_normal((n, n)) * 30.0
+        HM = Q @ Q.T
+        bM = rng.standard_normal(n) * 100.0
+        for optcal in (0, 1):
+            for hm, bm in ((None, None), (HM, bM)):
+                xd, rcd = ctx.ba_solve(1e-4, hm, bm, optcal)
+                xo, rco = ob.solve(1e-4, HAd, bAd, HLd, bLd, Hsd, bsd, hm, bm, optcal)
+                assert rcd == 0 and rco == 0
+                assert D.rel(xd, xo) < 1e-7, (optcal, hm is not None, D.rel(xd, xo))
+                if not optcal:
+                    assert np.all(xd[:4] == 0)
+    finally:
+        ctx.close()
