@@ -295,6 +295,8 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);   /* linearize→
  * residual/Jacobian kernel and (b) the accumulate+Schur+solve+back-substitution group with events on the context
  * stream.  read returns the mean durations in ms over the recorded iterations and resets the recorder. */
 int cmlhip_profile_enable(cmlhip_ctx* ctx, int max_iterations);
+/* record only every stride-th iteration (default 1), so that the event records do not perturb a timed run */
+int cmlhip_profile_stride(cmlhip_ctx* ctx, int stride);
 /* development aid: in-kernel phase timestamps (wall clock, 10 ns ticks), 16 slots per kernel: [0,16) residual kernel,
  * [16,32) accumulate, [32,48) system tiles, [48,64) solve, [64,80) back-substitution; then, from slot 128, per-workgroup
  * {begin, end} pairs for the five kernels (1024 workgroups each).  `out` holds CMLHIP_DEBUG_SLOTS values.

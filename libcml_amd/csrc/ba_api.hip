@@ -361,7 +361,7 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     BAArgs A;
     cml_make_ba_args(c, A);
     A.fuse_apply = 1;                                        // the step is always accepted here (forceAccept, BA.h:265)
-    const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap;
+    const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap && (c->prof_tick++ % c->prof_stride) == 0;
     hipEvent_t* ev = prof ? &c->prof_ev[6 * (size_t)c->prof_n] : nullptr;
     if (prof) hipEventRecord(ev[0], c->stream);
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
@@ -390,9 +390,15 @@ int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) {
     hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
     c->prof_ev.clear();
-    c->prof_cap = max_iterations; c->prof_n = 0;
+    c->prof_cap = max_iterations; c->prof_n = 0; c->prof_tick = 0;
     c->prof_ev.resize(6 * (size_t)max_iterations);
     for (auto& e : c->prof_ev) CML_CHECK(c, hipEventCreate(&e));
+    return CMLHIP_OK;
+}
+
+int cmlhip_profile_stride(cmlhip_ctx* c, int stride) {
+    if (!c || stride < 1) return CMLHIP_ERR_INVALID;
+    c->prof_stride = stride; c->prof_tick = 0;
     return CMLHIP_OK;
 }
 

@@ -46,7 +46,7 @@ struct cmlhip_ctx {
     void* pinned = nullptr;       // pinned host staging (readbacks / small uploads)
     size_t pinned_bytes = 0, pinned_off = 0;
     std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration (cmlhip_profile_enable)
-    int prof_cap = 0, prof_n = 0;
+    int prof_cap = 0, prof_n = 0, prof_stride = 1, prof_tick = 0;
 
     // ---------------- BA window
     cmlhip_ba_params ba_prm{};

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "cmlhip_ba_window_size": (C.c_int, [_ctx, _P(_i), _P(_i), _P(_i)]),
     "cmlhip_profile_enable": (C.c_int, [_ctx, _i]),
     "cmlhip_debug_timestamps": (C.c_int, [_ctx, _i, _P(C.c_longlong)]),
+    "cmlhip_profile_stride": (C.c_int, [_ctx, _i]),
     "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
@@ -135,6 +136,9 @@ class Ctx:
         self.ck(self.L.cmlhip_ba_window_size(self.h, C.byref(n), C.byref(p), C.byref(r)))
         self.N, self.P, self.R = n.value, p.value, r.value
         return self.N, self.P, self.R
+
+    def profile_stride(self, stride):
+        self.ck(self.L.cmlhip_profile_stride(self.h, stride))
 
     def profile_enable(self, max_iterations):
         self.ck(self.L.cmlhip_profile_enable(self.h, max_iterations))
