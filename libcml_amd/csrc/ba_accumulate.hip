@@ -50,134 +50,142 @@ struct AccArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ K3
+#define PAIR_TRIP 256          // residuals of a pair staged per trip (4 groups x 64 lanes)
+#define PAIR_REC 41            // staged floats per record (40 used) + 1: odd stride, conflict-free lane-per-record reads
+typedef float float4_ __attribute__((ext_vector_type(4)));
+
+// One workgroup per (host,target) pair.  The 13x13 block of AccumulatorApprox (ACC.h:776-932) is a sum of small outer
+// products per residual, which is one v_mfma_f32_16x16x4_f32 (IEEE fp32) per residual:
+//   k = 0:  A = x (10)        B = [a x + b y (10) | JabJIdx(0,0) JabJIdx(0,1) JI^T r(0)]          x = [dC0 | dXi0], y = [dC1 | dXi1]
+//   k = 1:  A = y (10)        B = [b x + c y (10) | JabJIdx(1,0) JabJIdx(1,1) JI^T r(1)]          [a b; b c] = JIdx2
+//   k = 2:  A = e_10          B = [0 (10) | Jab2(0,0) Jab2(0,1) Jab^T r(0) Jab2(1,1) Jab^T r(1) r^T r]   (updateBotRight)
+// so D[i][j], i,j < 10 is the top-left block, D[i][10..12] the top-right one and D[10][10..15] the six bottom-right sums.
+// The reduction over the residuals is the K dimension of the matrix core: no per-lane accumulators, no wave reductions.
+// The 38 floats of a record that are needed ([8,28) and [60,80) of the 80) are staged in LDS with coalesced 16-B loads
+// (10 per record), PAIR_TRIP residuals per trip; wave w takes residuals w, w+16, ... of the trip and every lane reads its
+// operand elements from the staged record (distinct banks or broadcast).  The 16 wave tiles are added in wave order.
+// LINEARIZED mode (rare) computes res_toZero + J*delta per residual (BA.cpp:1699-1729) and stages the same 38 floats.
 __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const bool LIN) {
-    __shared__ float s_acc4[4][ACC_STRIDE];
-    __shared__ float s_acc[ACC_STRIDE];
-    __shared__ int s_cnt4[4];
+    __shared__ float s_rec[PAIR_TRIP][PAIR_REC];
+    __shared__ float s_tile[16][256];
     __shared__ int s_cnt;
     __shared__ double s_H[13][13];
     __shared__ double s_AH[64], s_AT[64], s_T1[64], s_T2[64];
-    const int tid = threadIdx.x, wave = tid >> 6, part = wave & 3, grp = wave >> 2, ln = tid & 63;
-    // 16 waves = 4 parts x 4 residual groups (256 residuals of the pair in flight per trip).
-    // up to 25 accumulators per lane; which 13x13 entries they are depends on the wave (part):
-    //   part 0: upper-triangle rows 0,1 (19) + bottom-right 3x3 (6)       part 1: rows 2,3,4 (21)
-    //   part 2: rows 5..9 (15) + top-right rows 0..2 (9)                   part 3: top-right rows 3..9 (21)
-    float acc[25];
-#pragma unroll
-    for (int i = 0; i < 25; i++) acc[i] = 0.f;
-    int cnt = 0;
+    const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63;
     const int beg = A.by_pair_off[q], end = A.by_pair_off[q + 1];
+    const double ahv = X.adH[64 * (size_t)q + ln], atv = X.adT[64 * (size_t)q + ln];      // adjoints for the stitch: in flight under the loop
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
     if (A.dbg && tid == 0 && q == 1) A.dbg[16] = wall_clock64();
-    for (int i = beg + grp * 64 + ln; i < end; i += 256) {
-        const int r = A.by_pair[i];
-        const bool lin = A.r_lin[r] != 0;
-        if (LIN ? (!lin || !A.r_good[r]) : (lin || !A.r_good[r])) continue;      // BA.cpp:1662-1669
-        const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;    // efsJ
-        float x[10], y[10];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { x[j] = J[O_C0 + j]; y[j] = J[O_C1 + j]; }
-#pragma unroll
-        for (int j = 0; j < 6; j++) { x[4 + j] = J[O_XI0 + j]; y[4 + j] = J[O_XI1 + j]; }
-        const float a = J[O_JI2 + 0], b = J[O_JI2 + 2], c = J[O_JI2 + 3];
-        float JIr0, JIr1, Jabr0, Jabr1, rr;
+    // ---- this lane's operand elements: i = j = lane & 15, k = lane >> 4; staged offsets of x_i, y_i and the two multipliers
+    const int e = ln & 15, kq = ln >> 4;
+    const int ox = e < 4 ? 12 + e : e - 4, oy = e < 4 ? 16 + e : 2 + e;       // x = [O_C0 | O_XI0], y = [O_C1 | O_XI1] (e < 10)
+    int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+    bool prod = false, field = false;
+    if (kq < 2 && e < 10) { prod = true; o1 = ox; o2 = oy; o3 = kq == 0 ? 22 : 24; o4 = kq == 0 ? 24 : 25; }   // (a,b) / (b,c)
+    else if (kq < 2 && e < 13) { field = true; o1 = e < 12 ? 26 + (e - 10) + 2 * kq : 34 + kq; }               // JabJIdx(k, .), JI^T r(k)
+    else if (kq == 2 && e >= 10) { field = true; o1 = e == 10 ? 30 : e == 11 ? 32 : e == 12 ? 36 : e == 13 ? 33 : e == 14 ? 37 : 38; }
+    const float a_const = (kq == 2 && e == 10) ? 1.f : 0.f;
+    float4_ acc = {0.f, 0.f, 0.f, 0.f};
+    const int span = LIN ? end - beg : A.pair_stride;            // ACTIVE mode walks the fixed-stride list: no offset round trip
+    for (int t0 = 0; t0 < span; t0 += PAIR_TRIP) {
+        const int trip = beg + t0;
+        const int ntrip = min(PAIR_TRIP, span - t0);
         if (!LIN) {
-            JIr0 = J[O_X_JIR]; JIr1 = J[O_X_JIR + 1]; Jabr0 = J[O_X_JABR]; Jabr1 = J[O_X_JABR + 1]; rr = J[O_X_RR];
-        } else {
-            // BA.cpp:1699-1729 (res_toZero + J*delta; see oracle note on the reference's float*/double[8] store)
-            const float* dp = X.adHTd + 8 * q;
-            const int p = A.r_point[r];
-            const float dd = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
-            float jdx = 0, jdy = 0, cx = 0, cy = 0;
-            for (int j = 0; j < 6; j++) { jdx += J[O_XI0 + j] * dp[j]; jdy += J[O_XI1 + j] * dp[j]; }
-            for (int j = 0; j < 4; j++) { cx += J[O_C0 + j] * (float)X.cdelta[j]; cy += J[O_C1 + j] * (float)X.cdelta[j]; }
-            const float Jpx = jdx + cx + J[O_DD] * dd, Jpy = jdy + cy + J[O_DD + 1] * dd;
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0; float srr = 0;
-            for (int j = 0; j < 8; j++) {
-                float rtz = A.r_rtz[8 * (size_t)r + j];
-                rtz = rtz + J[O_JI0 + j] * Jpx; rtz = rtz + J[O_JI1 + j] * Jpy;
-                rtz = rtz + J[O_JAB0 + j] * dp[6]; rtz = rtz + J[O_JAB1 + j] * dp[7];
-                const double ra = (double)rtz;
-                s0 += ra * (double)J[O_JI0 + j]; s1 += ra * (double)J[O_JI1 + j];
-                s2 += ra * (double)J[O_JAB0 + j]; s3 += ra * (double)J[O_JAB1 + j];
-                srr = (float)((double)srr + ra * ra);
+            // two memory round trips per trip: the efsJ codes applyRes keeps per pair slot (2r+sel, -1 = not good / not
+            // ACTIVE, BA.cpp:1662-1669), then 16 B of the record per thread (every load unconditional, addresses clamped)
+            const int* codes = A.pair_code + (size_t)q * A.pair_stride + t0;
+            int code[3], rec[3], part[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int idx = tid + 1024 * u;
+                rec[u] = idx / 10; part[u] = idx % 10;
+                code[u] = codes[min(rec[u], ntrip - 1)];
             }
-            JIr0 = (float)s0; JIr1 = (float)s1; Jabr0 = (float)s2; Jabr1 = (float)s3; rr = srr;
+            float4 v[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int cu = max(code[u], 0);
+                const float4* J4 = reinterpret_cast<const float4*>(((cu & 1) ? A.rj1 : A.rj0) + (size_t)(cu >> 1) * RJ_STRIDE);   // efsJ
+                v[u] = J4[part[u] < 5 ? 2 + part[u] : 10 + part[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                if (rec[u] < ntrip) {
+                    float* d = &s_rec[rec[u]][4 * part[u]];
+                    const bool ok = code[u] >= 0;                     // a slot that is not summed is staged as zeros: the MFMA loop is branch-free
+                    d[0] = ok ? v[u].x : 0.f; d[1] = ok ? v[u].y : 0.f; d[2] = ok ? v[u].z : 0.f; d[3] = ok ? v[u].w : 0.f;
+                    if (part[u] == 0 && ok) atomicAdd(&s_cnt, 1);
+                }
+            }
+        } else if (tid < ntrip) {
+            const int r = A.by_pair[trip + tid];
+            const bool ok = A.r_lin[r] && A.r_good[r];
+            if (!ok) { for (int j = 0; j < 40; j++) s_rec[tid][j] = 0.f; }
+            if (ok) {
+                atomicAdd(&s_cnt, 1);
+                const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;    // efsJ
+                float* S = s_rec[tid];
+                for (int j = 0; j < 20; j++) S[j] = J[8 + j];
+                for (int j = 0; j < 14; j++) S[20 + j] = J[60 + j];
+                // BA.cpp:1699-1729 (res_toZero + J*delta; see oracle note on the reference's float*/double[8] store)
+                const float* dp = X.adHTd + 8 * q;
+                const int p = A.r_point[r];
+                const float dd = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
+                float jdx = 0, jdy = 0, cx = 0, cy = 0;
+                for (int j = 0; j < 6; j++) { jdx += J[O_XI0 + j] * dp[j]; jdy += J[O_XI1 + j] * dp[j]; }
+                for (int j = 0; j < 4; j++) { cx += J[O_C0 + j] * (float)X.cdelta[j]; cy += J[O_C1 + j] * (float)X.cdelta[j]; }
+                const float Jpx = jdx + cx + J[O_DD] * dd, Jpy = jdy + cy + J[O_DD + 1] * dd;
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0; float srr = 0;
+                for (int j = 0; j < 8; j++) {
+                    float rtz = A.r_rtz[8 * (size_t)r + j];
+                    rtz = rtz + J[O_JI0 + j] * Jpx; rtz = rtz + J[O_JI1 + j] * Jpy;
+                    rtz = rtz + J[O_JAB0 + j] * dp[6]; rtz = rtz + J[O_JAB1 + j] * dp[7];
+                    const double ra = (double)rtz;
+                    s0 += ra * (double)J[O_JI0 + j]; s1 += ra * (double)J[O_JI1 + j];
+                    s2 += ra * (double)J[O_JAB0 + j]; s3 += ra * (double)J[O_JAB1 + j];
+                    srr = (float)((double)srr + ra * ra);
+                }
+                S[34] = (float)s0; S[35] = (float)s1; S[36] = (float)s2; S[37] = (float)s3; S[38] = srr;
+            }
         }
-        // AccumulatorApprox::update (ACC.h:776-858): entry (r_,c_) of the 10x10 upper triangle of [x y][a b; b c][x y]^T
-#define UP(k, r_, c_) acc[k] += a * x[c_] * x[r_] + c * y[c_] * y[r_] + b * (x[c_] * y[r_] + y[c_] * x[r_])
-        // updateTopRight (ACC.h:861-916): row j, columns {JabJIdx(0,.), JabJIdx(1,.), JI^T r}
-#define TRW(k, j) { acc[k] += x[j] * J[O_JABJI + 0] + y[j] * J[O_JABJI + 2]; acc[(k) + 1] += x[j] * J[O_JABJI + 1] + y[j] * J[O_JABJI + 3]; \
-                    acc[(k) + 2] += x[j] * JIr0 + y[j] * JIr1; }
-        if (part == 0) {
-#pragma unroll
-            for (int cc = 0; cc < 10; cc++) UP(cc, 0, cc);
-#pragma unroll
-            for (int cc = 1; cc < 10; cc++) UP(9 + cc, 1, cc);
-            // updateBotRight, ACC.h:918-932
-            acc[19] += J[O_JAB2 + 0]; acc[20] += J[O_JAB2 + 2]; acc[21] += Jabr0;
-            acc[22] += J[O_JAB2 + 3]; acc[23] += Jabr1; acc[24] += rr;
-            cnt++;
-        } else if (part == 1) {
-#pragma unroll
-            for (int cc = 2; cc < 10; cc++) UP(cc - 2, 2, cc);
-#pragma unroll
-            for (int cc = 3; cc < 10; cc++) UP(8 + cc - 3, 3, cc);
-#pragma unroll
-            for (int cc = 4; cc < 10; cc++) UP(15 + cc - 4, 4, cc);
-        } else if (part == 2) {
-#pragma unroll
-            for (int cc = 5; cc < 10; cc++) UP(cc - 5, 5, cc);
-#pragma unroll
-            for (int cc = 6; cc < 10; cc++) UP(5 + cc - 6, 6, cc);
-#pragma unroll
-            for (int cc = 7; cc < 10; cc++) UP(9 + cc - 7, 7, cc);
-            UP(12, 8, 8); UP(13, 8, 9); UP(14, 9, 9);
-            TRW(15, 0); TRW(18, 1); TRW(21, 2);
-        } else {
-            TRW(0, 3); TRW(3, 4); TRW(6, 5); TRW(9, 6); TRW(12, 7); TRW(15, 8); TRW(18, 9);
+        __syncthreads();
+#pragma unroll 4
+        for (int li = wave; li < ntrip; li += 16) {
+            const float* S = s_rec[li];
+            const float v1 = S[o1], v2 = S[o2], m1 = S[o3], m2 = S[o4];
+            const float av = prod ? (kq == 0 ? v1 : v2) : a_const;
+            const float bv = prod ? m1 * v1 + m2 * v2 : (field ? v1 : 0.f);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
-#undef UP
-#undef TRW
+        if (t0 + PAIR_TRIP < span) __syncthreads();               // the staging tile is reused
     }
     if (A.dbg && tid == 0 && q == 1) A.dbg[17] = wall_clock64();
-    // wave reduction (DPP) and scatter into the canonical 91-entry order (55 upper-tri row-major, 30 top-right, 6 bottom-right)
+    // D: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-    for (int k = 0; k < 25; k++) {
-        const float v = wave_sum_dpp63(acc[k]);
-        if (ln == 63) {
-            int dst = -1;
-            if (part == 0) dst = k < 19 ? k : 85 + (k - 19);
-            else if (part == 1) { if (k < 21) dst = 19 + k; }
-            else if (part == 2) { if (k < 15) dst = 40 + k; else if (k < 24) dst = 55 + (k - 15); }
-            else { if (k < 21) dst = 64 + k; }
-            if (dst >= 0) s_acc4[grp][dst] = v;
-        }
-    }
-    if (part == 0) {
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (ln == 0) s_cnt4[grp] = cnt;
-    }
-    __syncthreads();
-    if (tid < 91) s_acc[tid] = ((s_acc4[0][tid] + s_acc4[1][tid]) + s_acc4[2][tid]) + s_acc4[3][tid];
-    if (tid == 0) s_cnt = s_cnt4[0] + s_cnt4[1] + s_cnt4[2] + s_cnt4[3];
-    if (tid < 64) { s_AH[tid] = X.adH[64 * (size_t)q + tid]; s_AT[tid] = X.adT[64 * (size_t)q + tid]; }
+    for (int rg = 0; rg < 4; rg++) s_tile[wave][(4 * kq + rg) * 16 + e] = acc[rg];
+    if (tid < 64) { s_AH[tid] = ahv; s_AT[tid] = atv; }
     __syncthreads();
     if (tid < 91) {
-        const float v = s_acc[tid];
-        X.acc_out[(size_t)q * ACC_STRIDE + tid] = v;
+        // canonical 91-entry order: 55 upper-tri row-major of the 10x10, 30 top-right (row-major 10x3), 6 bottom-right;
         // symmetric 13x13 (AccumulatorApprox::finish, ACC.h:639-673)
-        int rr_, cc;
+        int rr_, cc, src;
         if (tid < 55) {
             int k = tid; rr_ = 0;
             while (k >= 10 - rr_) { k -= 10 - rr_; rr_++; }
-            cc = rr_ + k;
+            cc = rr_ + k; src = rr_ * 16 + cc;
         } else if (tid < 85) {
-            rr_ = (tid - 55) / 3; cc = 10 + (tid - 55) % 3;
+            rr_ = (tid - 55) / 3; cc = 10 + (tid - 55) % 3; src = rr_ * 16 + cc;
         } else {
-            const int e = tid - 85;
-            rr_ = e < 3 ? 10 : (e < 5 ? 11 : 12);
-            cc = e < 3 ? 10 + e : (e < 5 ? 11 + (e - 3) : 12);
+            const int ee = tid - 85;
+            rr_ = ee < 3 ? 10 : (ee < 5 ? 11 : 12);
+            cc = ee < 3 ? 10 + ee : (ee < 5 ? 11 + (ee - 3) : 12);
+            src = 10 * 16 + 10 + ee;
         }
+        float v = s_tile[0][src];
+#pragma unroll
+        for (int w = 1; w < 16; w++) v += s_tile[w][src];
+        X.acc_out[(size_t)q * ACC_STRIDE + tid] = v;
         s_H[rr_][cc] = (double)v; s_H[cc][rr_] = (double)v;
     }
     if (tid == 0) X.num_out[q] = s_cnt;

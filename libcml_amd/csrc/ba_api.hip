@@ -30,6 +30,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.rj0 = c->rj[0].as<float>(); A.rj1 = c->rj[1].as<float>();
     A.by_point_off = c->by_point_off.as<int>(); A.by_point = c->by_point.as<int>();
     A.by_pair_off = c->by_pair_off.as<int>(); A.by_pair = c->by_pair.as<int>();
+    A.pair_code = c->pair_code.as<int>(); A.pair_pos = c->pair_pos.as<int>(); A.pair_stride = c->pair_stride;
     A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0;
     A.dbg = c->dbg_on ? c->dbg.as<long long>() : nullptr;
     return CMLHIP_OK;
@@ -135,6 +136,17 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     UP(c->r_point, rp); UP(c->r_target, rt); UP(c->r_state, rs); UP(c->r_new_state, rns); UP(c->r_lin, rl);
     UP(c->by_point_off, c->h_by_point_off); UP(c->by_point, c->h_by_point);
     UP(c->by_pair_off, c->h_by_pair_off); UP(c->by_pair, c->h_by_pair);
+    {
+        int mx = 1;
+        for (int q = 0; q < N * N; q++) mx = std::max(mx, c->h_by_pair_off[q + 1] - c->h_by_pair_off[q]);
+        c->pair_stride = (mx + 3) & ~3;
+        std::vector<int> code((size_t)N * N * c->pair_stride, -1), pos(std::max(R, 1), 0);   // nothing is good before the first applyRes
+        for (int q = 0; q < N * N; q++)
+            for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i++) pos[c->h_by_pair[i]] = q * c->pair_stride + (i - c->h_by_pair_off[q]);
+        if ((rc = cml_ensure(c, c->pair_code, 4 * code.size()))) return rc;
+        if ((rc = cml_ensure(c, c->pair_pos, 4 * pos.size()))) return rc;
+        UP(c->pair_code, code); UP(c->pair_pos, pos);
+    }
     UP(c->newframe_res, newframe);
 #undef UP
     // resetOOB (DSOResidual.h:83-88): energies 0, flags cleared

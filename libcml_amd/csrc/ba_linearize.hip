@@ -49,7 +49,7 @@ template <bool HALF>
 __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     __shared__ __attribute__((aligned(16))) float s_share[RES_PER_BLOCK][NSHARE][8];   // [residual][quantity][pixel]
     __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE];
-    __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK];
+    __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK], s_app[RES_PER_BLOCK];
     __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
     DBG_BLK(A.dbg, 0, 0);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     rec[O_JAB1 + k] = A.opt_b ? hw : 0.f;
 
     // ---- classification, BA.cpp:66-72,115-118,297-314
-    if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; }
+    if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; s_app[g] = 0; }
     if (live && k == 0) {
         float ret = A.r_energy[r];
         float nwo = -1.f;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         if (A.fuse_apply && !state_now_oob) {                       // applyRes(copyJacobians = true), BA.cpp:2051-2093
             if (ns_final == CMLHIP_RES_IN) { A.r_good[r] = 1; s_flip[g] = 1; }
             else A.r_good[r] = 0;
+            s_app[g] = 1;
             A.r_state[r] = ns_final;
             A.r_energy[r] = wrote_e ? ret : A.r_new_energy[r];      // state_energy = state_NewEnergy
         }
@@ -259,7 +260,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(s_rec[gg])[q];
     }
     __syncthreads();                                                // every lane has read r_sel before it is flipped
-    if (tid < RES_PER_BLOCK && s_flip[tid]) A.r_sel[r0 + tid] ^= 1;
+    if (tid < RES_PER_BLOCK && s_app[tid]) {                        // efsJ code of the pair list (read by the accumulate kernel)
+        const int rr_ = r0 + tid;
+        int code = -1;
+        if (s_flip[tid]) { const unsigned char sl = A.r_sel[rr_] ^ 1; A.r_sel[rr_] = sl; code = 2 * rr_ + sl; }
+        A.pair_code[A.pair_pos[rr_]] = code;
+    }
     // ---- per-block partials {energy, n_in, n_oob, n_outlier} in residual order (BA.cpp:1565)
     if (tid == 0 && A.lin_partial) {
         double e = 0, c0 = 0, c1 = 0, c2 = 0;
@@ -295,6 +301,7 @@ __global__ void k_ba_apply(BAArgs A, int copy) {
             A.r_good[r] = 1;
             const unsigned char sel = A.r_sel[r] ^ 1;
             A.r_sel[r] = sel;
+            A.pair_code[A.pair_pos[r]] = 2 * r + sel;
             const float* J = (sel ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
             const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
             const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
@@ -305,6 +312,7 @@ __global__ void k_ba_apply(BAArgs A, int copy) {
             o[7] = J[O_JABJI + 1] * J[O_DD] + J[O_JABJI + 3] * J[O_DD + 1];
         } else {
             A.r_good[r] = 0;
+            A.pair_code[A.pair_pos[r]] = -1;
         }
     }
     A.r_state[r] = A.r_new_state[r];

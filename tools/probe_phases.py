@@ -15,7 +15,7 @@ for _ in range(1): ctx.ba_iteration_async(1e-5)
 ctx.sync()
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 0, out.ctypes.data_as(C.POINTER(C.c_longlong))))
 def seg(name, a, b): print("%-34s %7.2f us" % (name, (out[b] - out[a]) * 0.01))
-seg("acc pair: load+accumulate loop", 16, 17); seg("acc pair: wave reduce", 17, 18); seg("acc pair: fp64 stitch", 18, 19)
+seg("acc pair: load+accumulate loop", 16, 17); seg("acc pair: tile sum + H", 17, 18); seg("acc pair: fp64 stitch", 18, 19)
 seg("solve: loads landed (wave 0)", 48, 54); seg("solve: Sv + barrier", 54, 55); seg("solve: scaled store", 55, 49); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
 seg("solve: total", 48, 53)
 
