@@ -43,6 +43,15 @@ __device__ __forceinline__ float wave_sum_dpp63(float v) {
     return v;
 }
 
+__device__ __forceinline__ float sum8(float v) {          // sum over 8 consecutive lanes (xor butterflies stay inside the group)
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+__device__ __forceinline__ double sum8d(double v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+
 struct AccArgs {
     const double* adH; const double* adT; const float* adHTd; const double* cdelta;
     float* acc_out; int* num_out; double* pair_blocks;
@@ -816,41 +825,51 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) sum->nonfinite = 0;
     __syncthreads();
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    // 8 lanes per point, one residual per lane per pass (a point has at most N-1 residuals): the chain by_point -> r ->
+    // {good, target, JpJdF} is walked once per point, every load unconditional (clamped), masks multiplied in.
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = gid >> 3, i = gid & 7;
+    const bool pv = p < A.P;
+    const int pp = pv ? p : 0;
     float sumID = 0, sumNID = 0, numID = 0;
-    if (p < A.P) {
-        const float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
-        const int beg = A.by_point_off[p], end = A.by_point_off[p + 1];
+    {
+        const float* pa = A.pt_acc + (size_t)pp * PT_ACC_STRIDE;
+        const int beg = A.by_point_off[pp], end = pv ? A.by_point_off[pp + 1] : beg;
+        const int host = A.pt_host[pp];
+        const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
+        const double xc = x[i & 3];
         int ngood = 0;
-        for (int kk = beg; kk < end; kk++) ngood += A.r_good[A.by_point[kk]] != 0;
+        double dsum = 0.0;
+        for (int base = beg; base < end; base += 8) {
+            const int kk = base + i;
+            const bool have = kk < end;
+            const int r = A.by_point[have ? kk : beg];
+            const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r + 4);
+            const bool good = have && A.r_good[r];
+            const double* xa = s_xAd + 8 * (host * N + A.r_target[r]);
+            double d = ((xa[0] * (double)v0.x + xa[1] * (double)v0.y) + (xa[2] * (double)v0.z + xa[3] * (double)v0.w))
+                     + ((xa[4] * (double)v1.x + xa[5] * (double)v1.y) + (xa[6] * (double)v1.z + xa[7] * (double)v1.w));
+            d = good ? d : 0.0;
+            ngood += (int)sum8(good ? 1.f : 0.f);
+            dsum += sum8d(d);
+        }
+        // mCalibStep . (Hcd_accAF + Hcd_accLF), BA.cpp:1455-1487
+        const double cs = sum8d(i < 4 ? (-xc) * ((double)hcd + (double)hcl) : 0.0);
         double st = 0.0;
         if (ngood > 0) {
-            double b = (double)pa[13];
-            double s = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) s += (-x[i]) * ((double)pa[2 + i] + (double)pa[8 + i]);     // mCalibStep . (Hcd_accAF + Hcd_accLF)
-            b -= s;
-            const int host = A.pt_host[p];
-            for (int kk = beg; kk < end; kk++) {
-                const int r = A.by_point[kk];
-                if (!A.r_good[r]) continue;
-                const double* xa = s_xAd + 8 * (host * N + A.r_target[r]);
-                const float* v = A.r_jpjdf + 8 * (size_t)r;
-                double d = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) d += xa[i] * (double)v[i];
-                b -= d;
-            }
-            st = -b * (double)pa[12];
-            if (!isfinite(st)) atomicAdd(&sum->nonfinite, 1);
+            const double bb = ((double)pa13 - cs) - dsum;
+            st = -bb * (double)pa12;
+            if (pv && i == 0 && !isfinite(st)) atomicAdd(&sum->nonfinite, 1);
         }
-        A.pt_step[p] = st;
-        if (do_step) {
-            const double nid = (double)A.pt_backup[p] + st;
-            if (isfinite(nid) && nid > 0) {
-                A.pt_idepth[p] = nid;
-                sumID = (float)(st * st); sumNID = (float)fabs((double)A.pt_backup[p]); numID = 1.f;
-                A.pt_idepth_zero[p] = (float)nid;
+        if (pv && i == 0) {
+            A.pt_step[p] = st;
+            if (do_step) {
+                const double nid = (double)A.pt_backup[p] + st;
+                if (isfinite(nid) && nid > 0) {
+                    A.pt_idepth[p] = nid;
+                    sumID = (float)(st * st); sumNID = (float)fabs((double)A.pt_backup[p]); numID = 1.f;
+                    A.pt_idepth_zero[p] = (float)nid;
+                }
             }
         }
     }
@@ -969,7 +988,7 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
 
 int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
     const size_t sh = (size_t)A.N * A.N * 8 * sizeof(double);
-    k_ba_backsub<<<cml_div_up(A.P, 256), 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
+    k_ba_backsub<<<cml_div_up(A.P * 8, 256), 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
                                                                c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0);
     return CMLHIP_OK;
 }

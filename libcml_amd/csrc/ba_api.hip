@@ -112,7 +112,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->bA, 8 * n); ENS(c->bL, 8 * n); ENS(c->bsc, 8 * n); ENS(c->bM, 8 * n); ENS(c->xvec, 8 * n);
     ENS(c->Hf, 8 * n * n); ENS(c->bf, 8 * n);
     c->n_lin_partial = (R + 31) / 32;
-    ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 255) / 256 + 1));
+    ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 31) / 32 + 1));
     ENS(c->G, 8 * ((size_t)P * ldg + P));
     ENS(c->syrk_part, 8 * 256 * (size_t)(ntile * (ntile + 1) / 2) * cml_sys_slices(P));
     ENS(c->scal, 1024);
