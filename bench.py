@@ -110,6 +110,8 @@ def main():
         raise RuntimeError("BA run failed: " + ba.last_error())
     _dbg('run done')
     _, _, R = ctx.refresh_window_size()      # the window was uploaded by the C++ host mirror
+    if not ba.begin_resident():                                           # frame states, adjoints, priors, gauge basis -> device
+        raise RuntimeError("begin_resident failed: " + ba.last_error())
     lam = 1e-5
     for _ in range(args.warmup):
         ctx.ba_iteration_async(lam)
@@ -148,7 +150,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "
-                                   "gradient images, fp32; 1 step = 1 full Gauss-Newton BA iteration on device" % (args.config, N, P, R, W.w, W.h),
+                                   "gradient images, fp32; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (args.config, N, P, R, W.w, W.h),
                        "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
             "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
             "roofline": {"bound": "hbm", "kernel": "k_ba_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

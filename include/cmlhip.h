@@ -284,13 +284,39 @@ int cmlhip_reproj_accumulate(cmlhip_ctx* ctx, int N, const double* poses /* N*12
 /* indirectX = ldlt(M6 with diag*(1+lambda)).solve(-b6) (BA.cpp:2695-2700) on the device */
 int cmlhip_reproj_solve(cmlhip_ctx* ctx, int N, double lambda, double* x6 /* 6N */);
 
+/* ---------------------------------------------------------------- device-resident Gauss-Newton iterations
+ * The loop body of BA::run (BA.cpp:804-880) under forceAccept / fixLambda without a host round trip per iteration:
+ *   accumulate -> Schur + system -> solve (+ orthogonalize) -> back-substitution + doStepFromBackup of the points AND of the
+ *   frames (state += -x, PRE_worldToCam = exp(state_scaled) * worldToCam_evalPT, DSOFramePrecomputed of the N^2 pairs,
+ *   adHTdeltaF / delta_prior of computeDelta) -> linearizeAll + applyRes(true) + setNewFrameEnergyTH.
+ * The host sets the frame states once (after BA::run's preamble), enqueues k iterations, and reads the states back. */
+typedef struct {
+    double eval_q[4], eval_t[3];   /* worldToCam_evalPT as Sophus stores it: unit quaternion (w,x,y,z) + translation (DSOFrame.h:88) */
+    double state[10];              /* DSOFrame::state, unscaled (DSOFrame.h:110-124); [8],[9] unused by the BA */
+    double state_zero[10];         /* DSOFrame::state_zero */
+    double prior_zero[8];          /* DSOFrame::prior_zero */
+    double ab_exposure;            /* exposure time of the frame (aff_g2l, DSOFrame.h:216-222) */
+    int    fix_pose;               /* doStepFromBackup(fixCamera): pose part of the step dropped (BA.cpp:957-960) */
+    int    pad;
+} cmlhip_ba_frame_state;
+
+/* everything an iteration reads besides the residuals: adjoints and priors (as cmlhip_ba_accumulate takes them), the frame
+ * states, the state scales {translation, rotation, a, b} (BA.h:246-251) and, optionally, an orthonormal basis U (7 x (8N+4),
+ * row-major, zero rows allowed) of the gauge nullspace: from the third iteration on x -= U^T (U x) (BA.cpp:1196-1261,1404). */
+int cmlhip_ba_set_resident_state(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, const cmlhip_ba_frame_state* frames,
+                                 const double scales[4], const double* nullspace_basis /* 7*(8N+4) or NULL */);
+/* frame states after the iterations enqueued so far (synchronises); pre_w2c: N x 7 (q, t) of PRE_worldToCam, may be NULL;
+ * last_pass: energy / census / setNewFrameEnergyTH of the last residual pass (what cmlhip_ba_linearize returns), may be NULL */
+int cmlhip_ba_get_resident_state(cmlhip_ctx* ctx, cmlhip_ba_frame_state* frames, double* pre_w2c, cmlhip_ba_lin_result* last_pass);
+
 /* ---------------------------------------------------------------- timing helpers (bench.py)
  * HIP events on the context stream; ms between the two most recent marks. */
 int cmlhip_event_mark(cmlhip_ctx* ctx, int which /* 0 = start, 1 = stop */);
 int cmlhip_event_elapsed_ms(cmlhip_ctx* ctx, float* ms);
 /* enqueue-only variants for throughput measurement: no host readback, no sync */
 int cmlhip_ba_linearize_async(cmlhip_ctx* ctx);
-int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);   /* linearize→apply→accumulate→solve→backsub */
+/* one resident iteration (see above); without cmlhip_ba_set_resident_state only the points are stepped */
+int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);
 /* Per-kernel HIP-event timing of the iteration pipeline: when enabled, cmlhip_ba_iteration_async brackets (a) the
  * residual/Jacobian kernel and (b) the accumulate+Schur+solve+back-substitution group with events on the context
  * stream.  read returns the mean durations in ms over the recorded iterations and resets the recorder. */

@@ -111,3 +111,9 @@ def default_tracker_params(cutoff_repeat=1.0):
     """TR.h:473-520 defaults."""
     return TrackerParams(huber=9.0, cutoff=20.0 * cutoff_repeat, cutoff_base=20.0,
                          scale_rot=1.0, scale_trans=0.5, scale_a=10.0, scale_b=1000.0)
+
+
+class BAFrameState(C.Structure):
+    """cmlhip_ba_frame_state (device-resident iterations)."""
+    _fields_ = [("eval_q", C.c_double * 4), ("eval_t", C.c_double * 3), ("state", C.c_double * 10), ("state_zero", C.c_double * 10),
+                ("prior_zero", C.c_double * 8), ("ab_exposure", C.c_double), ("fix_pose", C.c_int), ("pad", C.c_int)]

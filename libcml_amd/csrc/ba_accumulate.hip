@@ -21,6 +21,7 @@
 #include "cmlhip_internal.h"
 #include "ba_common.h"
 #include "ba_finish.h"
+#include "ba_frames.h"
 
 typedef double double4_ __attribute__((ext_vector_type(4)));
 
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_out(SysArgs S) {
 //   (3) trailing tiles A_IJ -= W_IK L_JK^T on the matrix cores (4 x v_mfma_f64_16x16x4_f64 per tile, tiles round-robin on waves).
 // Workgroup 1 (blockIdx.x == 1): energy/census sums of the last residual pass + setNewFrameEnergyTH (see ba_linearize.hip).
 #define SOLVE_THREADS 512
+#define ORTHO_K 2                    // 64-column chunks of the nullspace basis prefetched per lane (covers 8N+4 <= 128)
 #define BLD 17                      // leading dimension of a 16x16 LDS block (+1 double: conflict-free column access)
 #define BSZ (16 * BLD)
 
@@ -632,7 +634,8 @@ __device__ __forceinline__ void solve_load_items(const SolveSys& Y, int n, int o
 
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
                                                             const int* newframe_res, int n_newframe, const double* lin_partial,
-                                                            int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish) {
+                                                            int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
+                                                            const double* __restrict__ nullU) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
     DBG_BLK(A.dbg, 3, 0);
@@ -644,6 +647,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     }
     const int m = n - off, nb = (m + 15) / 16, mp = nb * 16;
     DBG_T(A, 48);
+    double u_dot[ORTHO_K], u_upd[7];                            // nullspace basis entries this thread will need at the very end
+#pragma unroll
+    for (int k = 0; k < ORTHO_K; k++) u_dot[k] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 7; e++) u_upd[e] = 0.0;
+    if (nullU) {
+        const int w7 = min(tid >> 6, 6), ln = tid & 63;
+#pragma unroll
+        for (int k = 0; k < ORTHO_K; k++) { const int i = ln + 64 * k; u_dot[k] = nullU[(size_t)w7 * n + min(i, n - 1)] * (i < n ? 1.0 : 0.0); }
+#pragma unroll
+        for (int e = 0; e < 7; e++) u_upd[e] = nullU[(size_t)e * n + min(tid, n - 1)];
+    }
     if (tid == 0) lin_out->nonfinite = 0;            // consumed by the back-substitution launch that follows
     double* L = sm;                                  // nb(nb+1)/2 blocks
     double* Wk = L + (size_t)(nb * (nb + 1) / 2) * BSZ;   // panel W_IK: nb blocks
@@ -794,10 +809,40 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     }
     DBG_T(A, 52);
     int bad = 0;
-    for (int i = tid; i < n; i += SOLVE_THREADS) {
-        const double v = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
-        x[i] = v;
-        bad |= !isfinite(v);
+    if (nullU) {
+        // orthogonalize (BA.cpp:1196-1261): x -= U^T (U x), U = orthonormal basis of the kept gauge directions (7 x n).
+        // The basis entries were fetched at kernel start (registers), the products only wait for x.
+        double* xs = Wk;                                    // n
+        double* dots = Wk + mp + 16;                        // 7
+        for (int i = tid; i < n; i += SOLVE_THREADS) xs[i] = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
+        __syncthreads();
+        if (wv < 7) {
+            double sdot = 0;
+#pragma unroll
+            for (int k = 0; k < ORTHO_K; k++) { const int i = l + 64 * k; sdot += u_dot[k] * xs[min(i, n - 1)]; }
+            for (int i = l + 64 * ORTHO_K; i < n; i += 64) sdot += nullU[(size_t)wv * n + i] * xs[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
+            if (l == 0) dots[wv] = sdot;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += SOLVE_THREADS) {
+            double v = xs[i];
+            if (i == tid) {
+#pragma unroll
+                for (int e = 0; e < 7; e++) v -= u_upd[e] * dots[e];
+            } else {
+                for (int e = 0; e < 7; e++) v -= nullU[(size_t)e * n + i] * dots[e];
+            }
+            x[i] = v;
+            bad |= !isfinite(v);
+        }
+    } else {
+        for (int i = tid; i < n; i += SOLVE_THREADS) {
+            const double v = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
+            x[i] = v;
+            bad |= !isfinite(v);
+        }
     }
     if (tid == 0) *flag = 0;
     __syncthreads();
@@ -810,11 +855,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
 // back-substitution (BA.cpp:1427-1487) + optional point update (doStepFromBackup, BA.cpp:976-994)
 __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
                                                     const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
-                                                    int do_step) {
+                                                    int do_step, FrameStepArgs F) {
     extern __shared__ __attribute__((aligned(16))) double s_xAd[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
     __shared__ float s_red[3][4];
     const int N = A.N;
     DBG_BLK(A.dbg, 4, 0);
+    if (F.on && blockIdx.x == gridDim.x - 1) {               // last workgroup: the frames' half of doStepFromBackup
+        frame_step_block(F, x);
+        DBG_BLK_END(A.dbg, 4);
+        return;
+    }
     for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) {
         const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N;
         const double* AH = adH + 64 * (size_t)(h + N * t); const double* AT = adT + 64 * (size_t)(h + N * t);
@@ -967,7 +1017,7 @@ int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A) {
     return CMLHIP_OK;
 }
 
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish) {
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho) {
     const int n = A.n, off = optcal ? 0 : 4, m = n - off;
     const size_t sh = solve_lds_bytes(m);
     int* flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
@@ -982,14 +1032,23 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
     k_ba_solve<<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag,
                                                                           c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(),
                                                                           c->n_lin_partial, c->scal.as<LinSummary>(), c->frames.as<FrameDev>(),
-                                                                          with_lin_finish ? 1 : 0);
+                                                                          with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr);
     return CMLHIP_OK;
 }
 
 int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
     const size_t sh = (size_t)A.N * A.N * 8 * sizeof(double);
-    k_ba_backsub<<<cml_div_up(A.P * 8, 256), 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
-                                                               c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0);
+    FrameStepArgs F = {};
+    F.on = (do_step && c->resident_on) ? 1 : 0;
+    if (F.on) {
+        F.fs = c->frame_state.as<cmlhip_ba_frame_state>(); F.pairs = c->pairs.as<cmlhip_ba_pair>(); F.pre_w2c = c->pre_w2c.as<double>();
+        F.adH = c->adH.as<double>(); F.adT = c->adT.as<double>(); F.adHTd = c->adHTd.as<float>();
+        F.dprior = c->vec_small.as<double>() + 8 + 8 * A.N;
+        for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
+        F.N = A.N;
+    }
+    k_ba_backsub<<<cml_div_up(A.P * 8, 256) + F.on, 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
+                                                                      c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0, F);
     return CMLHIP_OK;
 }
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A) {

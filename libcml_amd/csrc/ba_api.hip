@@ -171,6 +171,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     c->ba_uploaded = true;
     c->ba_pairs_set = false;
+    c->resident_on = false; c->resident_iter = 0;
     return CMLHIP_OK;
 }
 
@@ -377,12 +378,58 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     hipEvent_t* ev = prof ? &c->prof_ev[6 * (size_t)c->prof_n] : nullptr;
     if (prof) hipEventRecord(ev[0], c->stream);
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
-    cml_launch_solve(c, A, 0, true);                         // K5: solve || energy-threshold of the previous residual pass
+    cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2);   // K5: solve (+ orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
+    c->resident_iter++;
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
     if (prof) { hipEventRecord(ev[1], c->stream); hipEventRecord(ev[2], c->stream); }
     cml_launch_linearize(c, A);                              // K1: residuals + Jacobians (+ applyRes)
+    c->lin_finish_pending = true;
     if (prof) { hipEventRecord(ev[3], c->stream); hipEventRecord(ev[4], c->stream); hipEventRecord(ev[5], c->stream); c->prof_n++; }
     CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, const cmlhip_ba_frame_state* frames, const double scales[4],
+                                 const double* nullspace_basis) {
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || !frames || !scales)
+        return CMLHIP_ERR_INVALID;
+    const int N = c->N, n = 8 * N + 4;
+    if ((rc = upload_accum_in(c, in))) return rc;
+    if ((rc = cml_ensure(c, c->frame_state, sizeof(cmlhip_ba_frame_state) * (size_t)N))) return rc;
+    if ((rc = cml_ensure(c, c->pre_w2c, 8 * 7 * (size_t)N))) return rc;
+    if ((rc = cml_h2d(c, c->frame_state.p, frames, sizeof(cmlhip_ba_frame_state) * (size_t)N))) return rc;
+    CML_CHECK(c, hipMemsetAsync(c->pre_w2c.p, 0, 8 * 7 * (size_t)N, c->stream));
+    for (int i = 0; i < 4; i++) c->res_scales[i] = scales[i];
+    c->have_null = nullspace_basis != nullptr;
+    if (c->have_null) {
+        if ((rc = cml_ensure(c, c->null_basis, 8 * 7 * (size_t)n))) return rc;
+        if ((rc = cml_h2d(c, c->null_basis.p, nullspace_basis, 8 * 7 * (size_t)n))) return rc;
+    }
+    c->resident_on = true; c->resident_iter = 0;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_get_resident_state(cmlhip_ctx* c, cmlhip_ba_frame_state* frames, double* pre_w2c, cmlhip_ba_lin_result* last) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
+    if (c->lin_finish_pending) {                             // the tail of the last residual pass normally rides in the NEXT solve launch
+        BAArgs A;
+        cml_make_ba_args(c, A);
+        cml_launch_lin_finish(c, A);
+        CML_CHECK(c, hipGetLastError());
+        c->lin_finish_pending = false;
+    }
+    if (last) {
+        LinSummary S;
+        if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
+        last->energy = S.energy; last->n_in = S.n_in; last->n_oob = S.n_oob; last->n_outlier = S.n_outlier;
+        last->new_frame_energy_th = S.new_frame_energy_th;
+    }
+    if (frames && (rc = cml_d2h(c, frames, c->frame_state.p, sizeof(cmlhip_ba_frame_state) * (size_t)c->N))) return rc;
+    if (pre_w2c && (rc = cml_d2h(c, pre_w2c, c->pre_w2c.p, 8 * 7 * (size_t)c->N))) return rc;
     return CMLHIP_OK;
 }
 

@@ -59,7 +59,7 @@ int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy);
 // K3 (pair blocks + point rows) and K4 (system tiles: H_A, H_L, H_sc and the final LM system for `lambda` / optional HM)
 int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only = false);
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish);
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho = false);
 int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A);     // H_sc / b_sc for host readback
 int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step);
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A);

@@ -1,0 +1,84 @@
+// ba_frames.h — the frame half of doStepFromBackup on the device (one workgroup of the back-substitution launch).
+// Replaces, for the device-resident iterations, DSOFrame::setStep / doStepFromBackup / setState (DSOFrame.h:82-84,
+// 110-124,205-214), the N^2 DSOFramePrecomputed (DSOFrame.h:248-291) and the frame part of computeDelta
+// (BA.cpp:1103-1194).  The SE(3) algebra is the host mirror's (host/se3.h, Sophus 1.1.0 semantics), compiled for gfx950.
+#pragma once
+#include "cmlhip_internal.h"
+#pragma clang fp contract(off)          // the host mirror runs the same algebra without fused multiply-adds
+#include "../host/se3.h"
+
+struct FrameStepArgs {
+    cmlhip_ba_frame_state* fs;     // N
+    cmlhip_ba_pair* pairs;         // N*N, host*N + target (R0, t0 stay: evaluation point)
+    double* pre_w2c;               // N x 7 (q, t) of PRE_worldToCam, for readback
+    const double* adH; const double* adT;
+    float* adHTd;                  // N*N x 8, index host + target*N
+    double* dprior;                // 8N: state - prior_zero
+    double sc[4];                  // scale translation / rotation / a / b
+    int N, on;
+};
+
+__device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const double* __restrict__ x) {
+    using cml_amd::SE3;
+    using cml_amd::Exposure;
+    __shared__ double s_w2c[CMLHIP_MAX_FRAMES][7], s_c2w[CMLHIP_MAX_FRAMES][7], s_aff[CMLHIP_MAX_FRAMES][3], s_delta[CMLHIP_MAX_FRAMES][8];
+    const int tid = threadIdx.x, N = F.N;
+    if (tid < N) {
+        cmlhip_ba_frame_state& S = F.fs[tid];
+        double step[8], st[8];
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { step[k] = -x[4 + 8 * tid + k]; fin = fin && isfinite(step[k]); }     // BA.cpp:1433-1441
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (!fin) step[k] = 0.0;                                   // setStep, DSOFrame.h:205-214
+            if (S.fix_pose && k < 6) step[k] = 0.0;                    // BA.cpp:957-960
+            st[k] = S.state[k] + step[k];                              // state_backup == state: every step is accepted here
+            S.state[k] = st[k];
+            s_delta[tid][k] = st[k] - S.state_zero[k];
+            F.dprior[8 * tid + k] = st[k] - S.prior_zero[k];
+        }
+        const double ss[6] = {F.sc[0] * st[0], F.sc[0] * st[1], F.sc[0] * st[2], F.sc[1] * st[3], F.sc[1] * st[4], F.sc[1] * st[5]};
+        SE3 ev;
+#pragma unroll
+        for (int k = 0; k < 4; k++) ev.q[k] = S.eval_q[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ev.t[k] = S.eval_t[k];
+        const SE3 W = SE3::exp(ss) * ev;                               // PRE_worldToCam, DSOFrame.h:119
+        const SE3 Ci = W.inverse();
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s_w2c[tid][k] = W.q[k]; s_c2w[tid][k] = Ci.q[k]; F.pre_w2c[7 * tid + k] = W.q[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_w2c[tid][4 + k] = W.t[k]; s_c2w[tid][4 + k] = Ci.t[k]; F.pre_w2c[7 * tid + 4 + k] = W.t[k]; }
+        s_aff[tid][0] = S.ab_exposure; s_aff[tid][1] = F.sc[2] * st[6]; s_aff[tid][2] = F.sc[3] * st[7];    // aff_g2l
+    }
+    __syncthreads();
+    for (int q = tid; q < N * N; q += blockDim.x) {
+        const int h = q / N, t = q % N;
+        SE3 Wt, Ch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Wt.q[k] = s_w2c[t][k]; Ch.q[k] = s_c2w[h][k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Wt.t[k] = s_w2c[t][4 + k]; Ch.t[k] = s_c2w[h][4 + k]; }
+        const SE3 ll = Wt * Ch;                                        // DSOFrame.h:259-273
+        cmlhip_ba_pair& P = F.pairs[q];
+        double R[9];
+        ll.matrix(R);
+#pragma unroll
+        for (int k = 0; k < 9; k++) P.R[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) P.t[k] = ll.t[k];
+        double a, b;
+        Exposure(s_aff[h][0], s_aff[h][1], s_aff[h][2]).to(Exposure(s_aff[t][0], s_aff[t][1], s_aff[t][2]), a, b);
+        P.aff_a = a; P.aff_b = b;
+        const int idx = h + t * N;                                     // computeDelta, BA.cpp:1120-1135
+        const double* AH = F.adH + 64 * (size_t)idx; const double* AT = F.adT + 64 * (size_t)idx;
+        for (int j = 0; j < 8; j++) {
+            double s = 0, s2 = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { s += s_delta[h][i] * AH[i * 8 + j]; s2 += s_delta[t][i] * AT[i * 8 + j]; }
+            F.adHTd[8 * (size_t)idx + j] = (float)(s + s2);
+        }
+    }
+}
+#pragma clang fp contract(fast)

@@ -46,6 +46,8 @@ PROTOTYPES = {
     "cmlhip_profile_enable": (C.c_int, [_ctx, _i]),
     "cmlhip_debug_timestamps": (C.c_int, [_ctx, _i, _P(C.c_longlong)]),
     "cmlhip_profile_stride": (C.c_int, [_ctx, _i]),
+    "cmlhip_ba_set_resident_state": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(abi.BAFrameState), _P(C.c_double), _P(C.c_double)]),
+    "cmlhip_ba_get_resident_state": (C.c_int, [_ctx, _P(abi.BAFrameState), _P(C.c_double), _P(abi.BALinResult)]),
     "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),

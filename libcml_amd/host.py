@@ -30,6 +30,10 @@ def lib():
         L.cmlhost_ba_set_frame_energy_th.argtypes = [_vp, _i, _d]
         L.cmlhost_ba_add_point.argtypes = [_vp, _f, _f, _d, _i, _P(_f), _P(_f), _i]
         L.cmlhost_ba_run.argtypes = [_vp, _i]
+        L.cmlhost_ba_run_resident.argtypes = [_vp, _i]
+        L.cmlhost_ba_begin_resident.argtypes = [_vp, _i]
+        L.cmlhost_ba_iterate_resident.argtypes = [_vp, _i, _d]
+        L.cmlhost_ba_end_resident.argtypes = [_vp, _P(_d)]
         L.cmlhost_ba_last_error.restype = C.c_char_p; L.cmlhost_ba_last_error.argtypes = [_vp]
         L.cmlhost_ba_counts.argtypes = [_vp] + [_P(_i)] * 5
         L.cmlhost_ba_get_frame.argtypes = [_vp, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d)]
@@ -95,6 +99,21 @@ class HostBA:
 
     def run(self, update_points_only=False):
         return bool(self.L.cmlhost_ba_run(self.h, int(update_points_only)))
+
+    def run_resident(self, update_points_only=False):
+        """run() with the iteration loop resident on the device (forceAccept + fixLambda, no early break)."""
+        return bool(self.L.cmlhost_ba_run_resident(self.h, int(update_points_only)))
+
+    def begin_resident(self, update_points_only=False):
+        return bool(self.L.cmlhost_ba_begin_resident(self.h, int(update_points_only)))
+
+    def iterate_resident(self, k, lam):
+        return bool(self.L.cmlhost_ba_iterate_resident(self.h, int(k), float(lam)))
+
+    def end_resident(self):
+        e = _d()
+        ok = bool(self.L.cmlhost_ba_end_resident(self.h, C.byref(e)))
+        return ok, e.value
 
     def last_error(self):
         return (self.L.cmlhost_ba_last_error(self.h) or b"").decode()

@@ -276,10 +276,10 @@ static void jacobiEig(double* A, int m, double* V) {
 
 // b -= N (N^T N)^+ N^T b, singular values <= delta*max dropped (BA.cpp:1196-1261).  With N = U S V^T the reference's
 // 0.5 (N Npi^T + (N Npi^T)^T) is U_kept U_kept^T; U_kept is built from the eigen-decomposition of N^T N.
-void DSOBundleAdjustment::orthogonalize(std::vector<double>& x) const {
+void DSOBundleAdjustment::nullspaceBasis(std::vector<double>& U) const {
     std::vector<double> ns;
     computeNullspaces(ns);
-    const int m = 7, n = (int)x.size();
+    const int m = 7, n = 8 * (int)mFrames.size() + CMLHIP_CPARS;
     for (int j = 0; j < m; j++) {
         double s = 0;
         for (int i = 0; i < n; i++) s += ns[(size_t)j * n + i] * ns[(size_t)j * n + i];
@@ -296,18 +296,27 @@ void DSOBundleAdjustment::orthogonalize(std::vector<double>& x) const {
     jacobiEig(G, m, V);
     double smax = 0;
     for (int i = 0; i < m; i++) smax = std::max(smax, G[i * m + i] > 0 ? std::sqrt(G[i * m + i]) : 0.0);
-    std::vector<double> proj(n, 0.0), ue(n);
+    U.assign((size_t)m * n, 0.0);
     for (int e = 0; e < m; e++) {
         const double sv = G[e * m + e] > 0 ? std::sqrt(G[e * m + e]) : 0.0;
-        if (!(sv > mSolverModeDelta * smax)) continue;
-        double dot = 0;
+        if (!(sv > mSolverModeDelta * smax)) continue;                         // dropped direction: zero row
         for (int i = 0; i < n; i++) {
             double s = 0;
             for (int j = 0; j < m; j++) s += ns[(size_t)j * n + i] * V[j * m + e];
-            ue[i] = s / sv;
-            dot += ue[i] * x[i];
+            U[(size_t)e * n + i] = s / sv;
         }
-        for (int i = 0; i < n; i++) proj[i] += ue[i] * dot;
+    }
+}
+
+void DSOBundleAdjustment::orthogonalize(std::vector<double>& x) const {
+    std::vector<double> U;
+    nullspaceBasis(U);
+    const int m = 7, n = (int)x.size();
+    std::vector<double> proj(n, 0.0);
+    for (int e = 0; e < m; e++) {
+        double dot = 0;
+        for (int i = 0; i < n; i++) dot += U[(size_t)e * n + i] * x[i];
+        for (int i = 0; i < n; i++) proj[i] += U[(size_t)e * n + i] * dot;
     }
     for (int i = 0; i < n; i++) x[i] -= proj[i];
 }
@@ -472,24 +481,54 @@ bool DSOBundleAdjustment::doStepFromBackup(bool fixCamera) {                  //
            std::sqrt(sumR) < 0.00005 * mThOptIterations && std::sqrt(sumT) * sumNID < 0.00005 * mThOptIterations;
 }
 
-bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        // BA.cpp:744-910
+bool DSOBundleAdjustment::runPreamble(double lastEnergy[3]) {                // BA.cpp:744-802
     mOutliers.clear();
     mError.clear();
     lastIterations = 0;
-    double sc[4];
-    scales(sc);
     int alivePts = 0;
     for (const auto& p : mPoints) alivePts += p.alive;
     if (alivePts == 0) { mError = "No points..."; return false; }             // :759-762
     computeAdjoints();
     computeDelta();
     if (!uploadWindow()) return false;
-    double lastEnergy[3], newEnergy[3];
     if (!linearizeAll(false, lastEnergy)) return false;
     int rc = cmlhip_ba_apply(mCtx, 1);                                        // applyActiveRes(true), :790
     if (rc) return fail("cmlhip_ba_apply", rc);
-    double lambda = mFixedLambda;
     statEnergyP.push_back(lastEnergy[0] / std::max<size_t>(1, mActive.size()));
+    return true;
+}
+
+bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // BA.cpp:882-910
+    double sc[4];
+    scales(sc);
+    // re-anchor the newest frame's evaluation point, :885-894
+    DSOFrame& fb = mFrames.back();
+    double nz[10] = {0};
+    nz[6] = fb.state[6]; nz[7] = fb.state[7];
+    fb.setEvalPT(fb.PRE_worldToCam, nz, sc);
+    computeAdjoints();
+    computeDelta();
+    if (!linearizeAll(true, lastEnergy)) return false;                        // :896
+    if (!std::isfinite(lastEnergy[0])) { mError = "Not finite energy"; return false; }
+    // write the optimised inverse depths back (MapPoint::setReferenceInverseDepth in the reference)
+    std::vector<double> idp(mActivePoints.size());
+    int rc = cmlhip_ba_get_idepth(mCtx, idp.data());
+    if (rc) return fail("cmlhip_ba_get_idepth", rc);
+    for (size_t k = 0; k < mActivePoints.size(); k++) {
+        DSOPoint& P = mPoints[mActivePoints[k]];
+        P.idepth = idp[k];
+        P.idepth_zero = (float)idp[k];
+    }
+    return true;
+}
+
+bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        // BA.cpp:744-910
+    double sc[4];
+    scales(sc);
+    double lastEnergy[3], newEnergy[3];
+    if (!runPreamble(lastEnergy)) return false;
+    int rc;
+    double lambda = mFixedLambda;
     for (int it = 0; it < mNumIterations; it++) {
         lastIterations = it + 1;
         backupState();
@@ -515,25 +554,83 @@ bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        //
         lastLambda = lambda;
         if (canbreak && it >= 1) break;                                       // :879
     }
-    // re-anchor the newest frame's evaluation point, :885-894
-    DSOFrame& fb = mFrames.back();
-    double nz[10] = {0};
-    nz[6] = fb.state[6]; nz[7] = fb.state[7];
-    fb.setEvalPT(fb.PRE_worldToCam, nz, sc);
-    computeAdjoints();
+    return runEpilogue(lastEnergy);
+}
+
+// ------------------------------------------------------------------------------------------------ device-resident loop
+bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
+    if (!mForceAccept || !mFixLambda) { mError = "resident iterations need forceAccept and fixLambda (every step accepted, BA.h:265-267)"; return false; }
+    if (!mDisableMarginalization) { mError = "resident iterations do not carry the marginalisation prior"; return false; }
+    const int N = (int)mFrames.size();
+    double sc[4];
+    scales(sc);
     computeDelta();
-    if (!linearizeAll(true, lastEnergy)) return false;                        // :896
-    if (!std::isfinite(lastEnergy[0])) { mError = "Not finite energy"; return false; }
-    // write the optimised inverse depths back (MapPoint::setReferenceInverseDepth in the reference)
-    std::vector<double> idp(mActivePoints.size());
-    rc = cmlhip_ba_get_idepth(mCtx, idp.data());
-    if (rc) return fail("cmlhip_ba_get_idepth", rc);
-    for (size_t k = 0; k < mActivePoints.size(); k++) {
-        DSOPoint& P = mPoints[mActivePoints[k]];
-        P.idepth = idp[k];
-        P.idepth_zero = (float)idp[k];
+    std::vector<cmlhip_ba_pair> pairs;
+    framePairs(pairs);
+    int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+    if (rc) return fail("cmlhip_ba_set_pairs", rc);
+    std::vector<double> prior(8 * (size_t)N), dprior(8 * (size_t)N);
+    for (int i = 0; i < N; i++) for (int k = 0; k < 8; k++) { prior[8 * i + k] = mFrames[i].prior[k]; dprior[8 * i + k] = mFrames[i].delta_prior[k]; }
+    double cdelta[4] = {mCDeltaF[0], mCDeltaF[1], mCDeltaF[2], mCDeltaF[3]}, cprior[4] = {mCPriorValue, mCPriorValue, mCPriorValue, mCPriorValue};
+    cmlhip_ba_accum_in in{mAdHost.data(), mAdTarget.data(), mAdHTdeltaF.data(), cdelta, prior.data(), dprior.data(), cprior};
+    std::vector<cmlhip_ba_frame_state> fs(N);
+    for (int i = 0; i < N; i++) {
+        const DSOFrame& f = mFrames[i];
+        std::memcpy(fs[i].eval_q, f.worldToCam_evalPT.q, sizeof fs[i].eval_q);
+        std::memcpy(fs[i].eval_t, f.worldToCam_evalPT.t, sizeof fs[i].eval_t);
+        std::memcpy(fs[i].state, f.state, sizeof fs[i].state);
+        std::memcpy(fs[i].state_zero, f.state_zero, sizeof fs[i].state_zero);
+        std::memcpy(fs[i].prior_zero, f.prior_zero, sizeof fs[i].prior_zero);
+        fs[i].ab_exposure = f.ab_exposure;
+        fs[i].fix_pose = updatePointsOnly ? 1 : 0;
+        fs[i].pad = 0;
+    }
+    std::vector<double> U;
+    nullspaceBasis(U);
+    rc = cmlhip_ba_set_resident_state(mCtx, &in, fs.data(), sc, U.data());
+    if (rc) return fail("cmlhip_ba_set_resident_state", rc);
+    return true;
+}
+
+bool DSOBundleAdjustment::iterateResident(int k, double lambda) {
+    for (int i = 0; i < k; i++) {
+        const int rc = cmlhip_ba_iteration_async(mCtx, lambda);
+        if (rc) return fail("cmlhip_ba_iteration_async", rc);
     }
     return true;
+}
+
+bool DSOBundleAdjustment::endResident(double* lastEnergy) {
+    const int N = (int)mFrames.size();
+    double sc[4];
+    scales(sc);
+    std::vector<cmlhip_ba_frame_state> fs(N);
+    cmlhip_ba_lin_result last{};
+    int rc = cmlhip_ba_get_resident_state(mCtx, fs.data(), nullptr, &last);
+    if (rc) return fail("cmlhip_ba_get_resident_state", rc);
+    for (int i = 0; i < N; i++) {
+        DSOFrame& f = mFrames[i];
+        for (int k = 0; k < 10; k++) { f.step[k] = fs[i].state[k] - f.state[k]; }
+        f.setState(fs[i].state, sc);
+    }
+    mFrames.back().frameEnergyTH = last.new_frame_energy_th;                  // setNewFrameEnergyTH of the last pass
+    if (lastEnergy) *lastEnergy = last.energy;
+    computeDelta();
+    return std::isfinite(last.energy);
+}
+
+bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
+    double lastEnergy[3];
+    if (!runPreamble(lastEnergy)) return false;
+    if (!beginResident(updatePointsOnly)) return false;
+    if (!iterateResident(mNumIterations, mFixedLambda)) return false;
+    lastIterations = mNumIterations;
+    lastLambda = mFixedLambda;
+    double e = 0;
+    if (!endResident(&e)) { mError = "non finite energy"; return false; }
+    statEnergyP.push_back(e);
+    lastEnergy[0] = e;
+    return runEpilogue(lastEnergy);
 }
 
 }  // namespace cml_amd

@@ -89,6 +89,14 @@ public:
     int  addNewFrame(uint64_t image_id, const SE3& worldToCam, const Exposure& exposure);       // BA.cpp:417-462; returns DSOFrame::id
     int  addPoint(float x, float y, double idepth, int host, const float colors[8], const float weights[8], bool hasDepthPrior);  // addPoints, BA.cpp:382-415
     bool run(bool updatePointsOnly = false);                                                     // BA.cpp:744-910
+    // The same run with the iteration loop resident on the device (forceAccept + fixLambda, no early break):
+    // preamble and epilogue as run(), mNumIterations x cmlhip_ba_iteration_async in between, no host round trip per iteration.
+    bool runResident(bool updatePointsOnly = false);
+    // pieces of runResident, for callers that keep iterating (bench): states to the device / k iterations / states back
+    bool beginResident(bool updatePointsOnly = false);
+    bool iterateResident(int k, double lambda);
+    bool endResident(double* lastEnergy = nullptr);
+    void nullspaceBasis(std::vector<double>& U7n) const;                                         // orthonormal basis used by orthogonalize
     const std::vector<int>& getOutliers() const { return mOutliers; }                            // point indices dropped by the last run
     void computeNullspaces(std::vector<double>& out7) const;                                     // BA.cpp:2365-2417
 
@@ -113,6 +121,8 @@ public:
 
 private:
     bool uploadWindow();
+    bool runPreamble(double lastEnergy[3]);
+    bool runEpilogue(double lastEnergy[3]);
     bool linearizeAll(bool fixLinearization, double energy[3]);
     bool solveSystem(int iteration, double lambda);
     bool doStepFromBackup(bool fixCamera);

@@ -47,6 +47,10 @@ int cmlhost_ba_add_point(void* h, float x, float y, double idepth, int host, con
     return static_cast<DSOBundleAdjustment*>(h)->addPoint(x, y, idepth, host, colors, weights, prior != 0);
 }
 int cmlhost_ba_run(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->run(updatePointsOnly != 0) ? 1 : 0; }
+int cmlhost_ba_run_resident(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->runResident(updatePointsOnly != 0) ? 1 : 0; }
+int cmlhost_ba_begin_resident(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->beginResident(updatePointsOnly != 0) ? 1 : 0; }
+int cmlhost_ba_iterate_resident(void* h, int k, double lambda) { return static_cast<DSOBundleAdjustment*>(h)->iterateResident(k, lambda) ? 1 : 0; }
+int cmlhost_ba_end_resident(void* h, double* lastEnergy) { return static_cast<DSOBundleAdjustment*>(h)->endResident(lastEnergy) ? 1 : 0; }
 const char* cmlhost_ba_last_error(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastError().c_str(); }
 int cmlhost_ba_counts(void* h, int* nframes, int* npoints, int* nresiduals, int* noutliers, int* iterations) {
     DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);

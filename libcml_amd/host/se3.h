@@ -6,26 +6,33 @@
 #include <cmath>
 #include <cstring>
 
+// the device layer steps the frame states with the same code (csrc/ba_frames.hip): one definition, host and gfx950
+#ifdef __HIPCC__
+#define CML_HD __host__ __device__
+#else
+#define CML_HD
+#endif
+
 namespace cml_amd {
 
 struct SE3 {
     double q[4] = {1, 0, 0, 0};   // w x y z
     double t[3] = {0, 0, 0};
 
-    static void hat(const double w[3], double O[9]) {
+    CML_HD static void hat(const double w[3], double O[9]) {
         O[0] = 0; O[1] = -w[2]; O[2] = w[1]; O[3] = w[2]; O[4] = 0; O[5] = -w[0]; O[6] = -w[1]; O[7] = w[0]; O[8] = 0;
     }
-    static void mm(const double A[9], const double B[9], double C[9]) {
+    CML_HD static void mm(const double A[9], const double B[9], double C[9]) {
         double r[9];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
-        std::memcpy(C, r, sizeof r);
+        for (int i = 0; i < 9; i++) C[i] = r[i];
     }
-    static void mv(const double A[9], const double v[3], double o[3]) {
+    CML_HD static void mv(const double A[9], const double v[3], double o[3]) {
         double r[3];
         for (int i = 0; i < 3; i++) r[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
         o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
     }
-    void matrix(double R[9]) const {
+    CML_HD void matrix(double R[9]) const {
         const double w = q[0], x = q[1], y = q[2], z = q[3];
         const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
         const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
@@ -33,7 +40,7 @@ struct SE3 {
         R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
         R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
     }
-    static SE3 fromRt(const double R[9], const double tt[3]) {
+    CML_HD static SE3 fromRt(const double R[9], const double tt[3]) {
         SE3 T;
         double tr = R[0] + R[4] + R[8];
         if (tr > 0) {
@@ -53,10 +60,10 @@ struct SE3 {
         }
         const double n = std::sqrt(T.q[0] * T.q[0] + T.q[1] * T.q[1] + T.q[2] * T.q[2] + T.q[3] * T.q[3]);
         for (int i = 0; i < 4; i++) T.q[i] /= n;
-        std::memcpy(T.t, tt, sizeof T.t);
+        for (int i = 0; i < 3; i++) T.t[i] = tt[i];
         return T;
     }
-    static SE3 exp(const double xi[6]) {
+    CML_HD static SE3 exp(const double xi[6]) {
         const double eps = 1e-10;
         const double* om = xi + 3;
         const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
@@ -84,7 +91,7 @@ struct SE3 {
         mv(V, xi, T.t);
         return T;
     }
-    void log(double xi[6]) const {
+    CML_HD void log(double xi[6]) const {
         const double eps = 1e-10;
         const double sq = q[1] * q[1] + q[2] * q[2] + q[3] * q[3], w = q[0];
         double f, theta;
@@ -108,7 +115,7 @@ struct SE3 {
         mv(Vi, t, xi);
         xi[3] = om[0]; xi[4] = om[1]; xi[5] = om[2];
     }
-    SE3 operator*(const SE3& B) const {
+    CML_HD SE3 operator*(const SE3& B) const {
         SE3 r;
         const double* a = q; const double* b = B.q;
         r.q[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
@@ -123,7 +130,7 @@ struct SE3 {
         for (int i = 0; i < 3; i++) r.t[i] = t[i] + v[i];
         return r;
     }
-    SE3 inverse() const {
+    CML_HD SE3 inverse() const {
         SE3 r;
         r.q[0] = q[0]; r.q[1] = -q[1]; r.q[2] = -q[2]; r.q[3] = -q[3];
         double R[9], v[3];
@@ -132,12 +139,12 @@ struct SE3 {
         r.t[0] = -v[0]; r.t[1] = -v[1]; r.t[2] = -v[2];
         return r;
     }
-    void Adj(double A[36]) const {
+    CML_HD void Adj(double A[36]) const {
         double R[9], H[9], HR[9];
         matrix(R);
         hat(t, H);
         mm(H, R, HR);
-        std::memset(A, 0, 36 * sizeof(double));
+        for (int i = 0; i < 36; i++) A[i] = 0.0;
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) { A[i * 6 + j] = R[i * 3 + j]; A[(i + 3) * 6 + j + 3] = R[i * 3 + j]; A[i * 6 + j + 3] = HR[i * 3 + j]; }
     }
@@ -146,9 +153,9 @@ struct SE3 {
 // src/cml/map/Exposure.h:119-123
 struct Exposure {
     double a = 0, b = 0, t = 1;
-    Exposure() {}
-    Exposure(double t_, double a_, double b_) : a(a_), b(b_), t(t_) {}
-    void to(const Exposure& o, double& A, double& B) const { A = std::exp(o.a - a) * o.t / t; B = o.b - A * b; }
+    CML_HD Exposure() {}
+    CML_HD Exposure(double t_, double a_, double b_) : a(a_), b(b_), t(t_) {}
+    CML_HD void to(const Exposure& o, double& A, double& B) const { A = std::exp(o.a - a) * o.t / t; B = o.b - A * b; }
 };
 
 }  // namespace cml_amd

@@ -89,3 +89,33 @@ def test_run_is_deterministic():
         assert np.array_equal(o[1], outs[0][1])
         assert np.array_equal(o[0].view(np.uint64), outs[0][0].view(np.uint64))
         assert np.array_equal(o[2].view(np.uint64), outs[0][2].view(np.uint64))
+
+
+@pytest.mark.parametrize("config", ["small", "medium"])
+def test_resident_iterations_match_host_loop(config):
+    """run() steps the frames on the host between device calls; runResident() keeps the whole loop on the device (frame
+    step, pair precomputation, computeDelta, orthogonalize in kernels).  Same arithmetic, different place: the results
+    must agree far below the fp32 accumulation noise of the Hessians."""
+    res = []
+    for mode in ("host", "resident"):
+        I = S.make_inputs(config)
+        ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R)
+        ba = host.window_to_host_ba(ctx, I.W)
+        ba.set_param("iterations", 5)
+        ba.set_param("ThOptIterations", 0.0)          # no early break (BA.cpp:879)
+        ok = ba.run() if mode == "host" else ba.run_resident()
+        assert ok, ba.last_error()
+        assert ba.counts()["iterations"] == 5
+        idp, alive, ng = ba.points()
+        st, ralive, good = ba.residual_states()
+        frames = [ba.frame(k) for k in range(I.N)]
+        res.append((idp.copy(), good.copy(), frames, ba.energies(8)))
+        ba.close(); ctx.close()
+    (idp_h, good_h, fr_h, e_h), (idp_r, good_r, fr_r, e_r) = res
+    assert int((good_h != good_r).sum()) <= max(1, len(good_h) // 2000)
+    for a, b in zip(fr_h, fr_r):
+        assert np.abs(a["state"] - b["state"]).max() < 1e-7 * max(1.0, np.abs(a["state"]).max())
+        assert np.abs(a["R"] - b["R"]).max() < 1e-8 and np.abs(a["t"] - b["t"]).max() < 1e-7
+        assert abs(a["th"] - b["th"]) <= 1e-5 * abs(a["th"])
+    assert np.abs(idp_h / idp_r - 1).max() < 1e-5
+    assert abs(e_h[-1] / e_r[-1] - 1) < 1e-6, (e_h, e_r)

@@ -5,7 +5,7 @@ from libcml_amd import device, host, synth
 cfg = sys.argv[1] if len(sys.argv) > 1 else "B"
 W = synth.make_window(cfg)
 ctx = device.Ctx(max_frames=W.N, max_points=W.P, max_residuals=W.P * W.N)
-ba = host.window_to_host_ba(ctx, W, levels=1); ba.set_param("iterations", 1); assert ba.run()
+ba = host.window_to_host_ba(ctx, W, levels=1); ba.set_param("iterations", 1); assert ba.run(); assert ba.begin_resident()
 for _ in range(10): ctx.ba_iteration_async(1e-5)
 ctx.sync()
 NS = 128 + 5 * 1024 * 2
