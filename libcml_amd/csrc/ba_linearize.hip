@@ -43,24 +43,30 @@ __device__ __forceinline__ void tap3(const void* img, int w, float x, float y, f
 __constant__ int c_star8[16] = {0, -2, -1, -1, 1, -1, -2, 0, 0, 0, 2, 0, -1, 1, 0, 2};   // types.h:1381-1393
 
 #define RES_PER_BLOCK 32
-#define NSHARE 8          // floats exchanged per pattern pixel
+#define NSHARE 9          // floats exchanged per pattern pixel (+ a row of ones for the product forms)
 
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     __shared__ __attribute__((aligned(16))) float s_share[RES_PER_BLOCK][NSHARE][8];   // [residual][quantity][pixel]
     __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE];
-    __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK], s_app[RES_PER_BLOCK];
+    __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK], s_app[RES_PER_BLOCK], s_sel[RES_PER_BLOCK], s_pos[RES_PER_BLOCK];
     __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
     DBG_BLK(A.dbg, 0, 0);
     const int r = blockIdx.x * RES_PER_BLOCK + g;
-    const bool live = (r < A.R) && !A.r_lin[r];
-    const int st = live ? A.r_state[r] : CMLHIP_RES_OOB;
+    // ---- per-residual inputs (all 8 lanes of the group read the same addresses: broadcast).  Every load is unconditional
+    //      on a clamped index — a `cond ? load : 0` costs its own branch and memory round trip — and what the tail of the
+    //      kernel needs (energy, new state, Jacobian-buffer selector, pair-list slot) is fetched in this first round trip.
+    const int rc = min(r, A.R - 1);
+    const int lin_ = A.r_lin[rc], st_ = A.r_state[rc], p_ = A.r_point[rc], tg_ = A.r_target[rc];
+    const float pre_energy = A.r_energy[rc];
+    const int pre_new_state = A.r_new_state[rc], pre_pos = A.pair_pos[rc];
+    const unsigned char pre_sel = A.r_sel[rc];
+    const bool live = (r < A.R) && !lin_;
+    const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
-
-    // ---- per-residual inputs (all 8 lanes of the group read the same addresses: broadcast)
-    const int p = live ? A.r_point[r] : 0;
-    const int host = A.pt_host[p], target = live ? A.r_target[r] : 0;
+    const int p = live ? p_ : 0;
+    const int host = A.pt_host[p], target = live ? tg_ : 0;
     const cmlhip_ba_pair* pc = &A.pairs[host * A.N + target];
     const FrameDev fh = A.frames[host], ft = A.frames[target];
     const double cxd = (double)A.pt_x[p], cyd = (double)A.pt_y[p];
@@ -119,36 +125,33 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const float rF = residual * hw;
 
     s_share[g][0][k] = f1; s_share[g][1][k] = f2; s_share[g][2][k] = a_; s_share[g][3][k] = hw;
-    s_share[g][4][k] = drdA; s_share[g][5][k] = pf; s_share[g][6][k] = hw0; s_share[g][7][k] = rF;
+    s_share[g][4][k] = drdA; s_share[g][5][k] = pf; s_share[g][6][k] = hw0; s_share[g][7][k] = rF; s_share[g][8][k] = 1.f;
     __syncthreads();
 
-    // ---- pattern-order sums, BA.cpp:237,257-271 and the ACTIVE-mode inner products of BA.cpp:1719-1729
-    float J00 = 0, J11 = 0, J10 = 0, Q00 = 0, Q01 = 0, Q10 = 0, Q11 = 0, B00 = 0, B01 = 0, B11 = 0, wJI2 = 0, E = 0;
-    double JIr0 = 0, JIr1 = 0, Jabr0 = 0, Jabr1 = 0;
-    float rr = 0;
+    // ---- pattern-order sums, BA.cpp:237,257-271 and the ACTIVE-mode inner products of BA.cpp:1719-1729.
+    // The 17 sums over the 8 pattern pixels have three arithmetic forms; lane k evaluates ONE sum of each form (same
+    // instructions in every lane, per-lane operand rows), so a wave issues 5 sums per pixel instead of 17:
+    //   A  acc = (float)((double)acc + (double)X*(double)Y)   k: J00 J10 J11 Q00 Q10 Q01 Q11 r^T r
+    //   B  acc += (double)rF*(double)Y (fp64)                 k: JI^T r (2), Jab^T r (2)
+    //   C  acc += ((p*q)*r)*s (fp32)                          k: B00 B01 B11        (multiplications by the ones row are exact)
+    // plus the energy and wJI2_sum, which every lane needs for the classification.  Statement order per sum is the reference's.
+    const float* SH = &s_share[g][0][0];
+    const int ax = (0x73232100 >> (4 * k)) & 15, ay = (0x71100110 >> (4 * k)) & 15;     // rows: 0 F1, 1 F2, 2 a, 3 hw, 4 drdA, 7 rF, 8 ones
+    const int by = (0x00003210 >> (4 * k)) & 15;
+    const float bmask = (k == 2 && !A.opt_a) || (k == 3 && !A.opt_b) ? 0.f : 1.f;          // BA.cpp:273-278
+    const int cp = k == 0 ? 4 : (k == 1 ? 4 : (k == 2 ? 3 : 8)), cq = k == 0 ? 4 : (k < 3 ? 3 : 8);
+    const int cr = k < 2 ? 3 : 8, cs = k == 0 ? 3 : 8;
+    float sumA = 0, sumC = 0, wJI2 = 0, E = 0;
+    double sumB = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const float F1 = s_share[g][0][j], F2 = s_share[g][1][j], AA = s_share[g][2][j], HW = s_share[g][3][j];
-        const float DA = s_share[g][4][j], PF = s_share[g][5][j], HW0 = s_share[g][6][j], RF = s_share[g][7][j];
+        const float F1 = SH[0 * 8 + j], F2 = SH[1 * 8 + j], HW = SH[3 * 8 + j], PF = SH[5 * 8 + j], HW0 = SH[6 * 8 + j], RF = SH[7 * 8 + j];
         const double h1 = (double)F1, h2 = (double)F2;
         E = (float)((double)E + (double)PF * (2.0 - (double)HW0));
-        J00 = (float)(J00 + h1 * h1);
-        J11 = (float)(J11 + h2 * h2);
-        J10 = (float)(J10 + h1 * h2);
-        Q00 = (float)(Q00 + (double)AA * h1);
-        Q01 = (float)(Q01 + (double)AA * h2);
-        Q10 = (float)(Q10 + (double)HW * h1);
-        Q11 = (float)(Q11 + (double)HW * h2);
-        B00 += DA * DA * HW * HW;
-        B01 += DA * HW * HW;
-        B11 += HW * HW;
         wJI2 = (float)(wJI2 + (double)(HW * HW) * (h1 * h1 + h2 * h2));
-        const float ja = A.opt_a ? AA : 0.f, jb = A.opt_b ? HW : 0.f;       // BA.cpp:273-278
-        JIr0 += (double)RF * h1;
-        JIr1 += (double)RF * h2;
-        Jabr0 += (double)RF * (double)ja;
-        Jabr1 += (double)RF * (double)jb;
-        rr = (float)((double)rr + (double)RF * (double)RF);
+        sumA = (float)(sumA + (double)SH[ax * 8 + j] * (double)SH[ay * 8 + j]);
+        sumB += (double)RF * (double)(SH[by * 8 + j] * bmask);
+        sumC += SH[cp * 8 + j] * SH[cq * 8 + j] * SH[cr * 8 + j] * SH[cs * 8 + j];
     }
 
     // ---- geometric Jacobians, BA.cpp:120-188 (computed by every lane, each stores its share)
@@ -178,15 +181,14 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         double d0 = rx * d2, d1 = ry * d3;
         rec[O_C1 + 0] = (float)(d0 * A.scale_f); rec[O_C1 + 1] = (float)((d1 + v) * A.scale_f);
         rec[O_C1 + 2] = (float)(d2 * A.scale_c); rec[O_C1 + 3] = (float)((d3 + 1) * A.scale_c);
-    } else if (k == 4) {
-        rec[O_JI2 + 0] = J00; rec[O_JI2 + 1] = J10; rec[O_JI2 + 2] = J10; rec[O_JI2 + 3] = J11;
-        rec[O_JABJI + 0] = Q00; rec[O_JABJI + 1] = Q10; rec[O_JABJI + 2] = Q01; rec[O_JABJI + 3] = Q11;
-    } else if (k == 5) {
-        rec[O_JAB2 + 0] = B00; rec[O_JAB2 + 1] = B01; rec[O_JAB2 + 2] = B01; rec[O_JAB2 + 3] = B11;
-        rec[O_X_JIR + 0] = (float)JIr0; rec[O_X_JIR + 1] = (float)JIr1;
-        rec[O_X_JABR + 0] = (float)Jabr0; rec[O_X_JABR + 1] = (float)Jabr1;
-        rec[O_X_RR] = rr; rec[O_X_RR + 1] = 0.f;
     }
+    // the sums of this lane: form A -> JIdx2 (J00 J10 J10 J11), JabJIdx (Q00 Q10 Q01 Q11), r^T r; B -> JI^T r, Jab^T r; C -> Jab2
+    rec[k < 1 ? O_JI2 : (k < 2 ? O_JI2 + 1 : (k < 3 ? O_JI2 + 3 : (k < 7 ? O_JABJI + (k - 3) : O_X_RR)))] = sumA;
+    if (k == 1) rec[O_JI2 + 2] = sumA;
+    if (k < 4) rec[O_X_JIR + k] = (float)sumB;               // O_X_JIR, O_X_JIR+1, O_X_JABR, O_X_JABR+1 are contiguous
+    if (k < 3) rec[k == 0 ? O_JAB2 : (k == 1 ? O_JAB2 + 1 : O_JAB2 + 3)] = sumC;
+    if (k == 1) rec[O_JAB2 + 2] = sumC;
+    if (k == 7) rec[O_X_RR + 1] = 0.f;
     rec[O_RES + k] = rF;
     rec[O_JI0 + k] = f1;
     rec[O_JI1 + k] = f2;
@@ -194,11 +196,11 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     rec[O_JAB1 + k] = A.opt_b ? hw : 0.f;
 
     // ---- classification, BA.cpp:66-72,115-118,297-314
-    if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; s_app[g] = 0; }
+    if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; s_app[g] = 0; s_sel[g] = pre_sel; s_pos[g] = pre_pos; }
     if (live && k == 0) {
-        float ret = A.r_energy[r];
+        float ret = pre_energy;
         float nwo = -1.f;
-        int ns_final = A.r_new_state[r];
+        int ns_final = pre_new_state;
         bool state_now_oob = (st == CMLHIP_RES_OOB), wrote_e = false;
         if (run) {
             if (centre_in) {                                        // setCenterProjectedTo, :131
@@ -256,25 +258,26 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         const int rr_ = r0 + gg;
         if (rr_ >= A.R) break;
         if (!s_write[gg]) continue;
-        float* dst = (A.r_sel[rr_] ? A.rj0 : A.rj1) + (size_t)rr_ * RJ_STRIDE;
+        float* dst = (s_sel[gg] ? A.rj0 : A.rj1) + (size_t)rr_ * RJ_STRIDE;
         reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(s_rec[gg])[q];
     }
-    __syncthreads();                                                // every lane has read r_sel before it is flipped
     if (tid < RES_PER_BLOCK && s_app[tid]) {                        // efsJ code of the pair list (read by the accumulate kernel)
         const int rr_ = r0 + tid;
         int code = -1;
-        if (s_flip[tid]) { const unsigned char sl = A.r_sel[rr_] ^ 1; A.r_sel[rr_] = sl; code = 2 * rr_ + sl; }
-        A.pair_code[A.pair_pos[rr_]] = code;
+        if (s_flip[tid]) { const unsigned char sl = (unsigned char)(s_sel[tid] ^ 1); A.r_sel[rr_] = sl; code = 2 * rr_ + sl; }
+        A.pair_code[s_pos[tid]] = code;
     }
-    // ---- per-block partials {energy, n_in, n_oob, n_outlier} in residual order (BA.cpp:1565)
-    if (tid == 0 && A.lin_partial) {
-        double e = 0, c0 = 0, c1 = 0, c2 = 0;
-        for (int gg = 0; gg < RES_PER_BLOCK; gg++) {
-            e += s_ret[gg];
-            c0 += s_ns[gg] == CMLHIP_RES_IN; c1 += s_ns[gg] == CMLHIP_RES_OOB; c2 += s_ns[gg] == CMLHIP_RES_OUTLIER;
+    // ---- per-block partials {energy, n_in, n_oob, n_outlier} (BA.cpp:1565): fixed butterfly order over the 32 residuals
+    if (tid < 64 && A.lin_partial) {
+        double e = tid < RES_PER_BLOCK ? s_ret[tid & (RES_PER_BLOCK - 1)] : 0.0;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        const int ns = tid < RES_PER_BLOCK ? s_ns[tid & (RES_PER_BLOCK - 1)] : -1;
+        const int c0 = __popcll(__ballot(ns == CMLHIP_RES_IN)), c1 = __popcll(__ballot(ns == CMLHIP_RES_OOB)), c2 = __popcll(__ballot(ns == CMLHIP_RES_OUTLIER));
+        if (tid == 0) {
+            double* o = A.lin_partial + 4 * (size_t)blockIdx.x;
+            o[0] = e; o[1] = (double)c0; o[2] = (double)c1; o[3] = (double)c2;
         }
-        double* o = A.lin_partial + 4 * (size_t)blockIdx.x;
-        o[0] = e; o[1] = c0; o[2] = c1; o[3] = c2;
     }
     (void)ok;
     DBG_BLK_END(A.dbg, 0);

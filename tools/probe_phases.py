@@ -34,3 +34,6 @@ for k in (1, 2, 3, 4, 0):
 b = blk[2]; nb_ = int((b[:, 0] > 0).sum()); d = (b[:nb_, 1] - b[:nb_, 0]) * 0.01
 nrow = W.N + 1
 print("system: SYRK blocks %d dur med %.2f max %.2f ; row blocks dur med %.2f max %.2f" % (nb_ - nrow, np.median(d[:-nrow]), d[:-nrow].max(), np.median(d[-nrow:]), d[-nrow:].max()))
+
+names_l = ["inputs (r, point, pair, frames)", "projection math (fp64)", "image taps", "photometrics + LDS share", "sums + geometric J", "classification", "fused apply", "copy-out + partials"]
+for k in range(8): seg("lin blk200: " + names_l[k], k, k + 1)
