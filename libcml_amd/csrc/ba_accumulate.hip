@@ -400,10 +400,21 @@ __device__ __forceinline__ double frame_sum(const double* pb, int N, int a, int 
     const int offH = v < 64 ? PB_HH + v : (v < 96 ? PB_HC + (v - 64) : PB_BH + (v - 96));
     const int offT = v < 64 ? PB_TT + v : (v < 96 ? PB_TC + (v - 64) : PB_BT + (v - 96));
     double s = 0;
-#pragma unroll 4
-    for (int t = 0; t < N; t++) s += pb[(size_t)(a + t * N) * PB_STRIDE + offH];
-#pragma unroll 4
-    for (int h = 0; h < N; h++) s += pb[(size_t)(h + a * N) * PB_STRIDE + offT];
+    for (int base = 0; base < N; base += 8) {                // 16 loads in flight per trip (clamped, masked), added in pair order
+        double h[8], t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = min(base + u, N - 1);
+            h[u] = pb[(size_t)(a + k * N) * PB_STRIDE + offH];
+            t[u] = pb[(size_t)(k + a * N) * PB_STRIDE + offT];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const double mk = base + u < N ? 1.0 : 0.0; h[u] *= mk; t[u] *= mk; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += h[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += t[u];
+    }
     return s;
 }
 
@@ -437,16 +448,23 @@ __global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
         const int p_beg = s_beg + wv * per, p_end = min(s_end, p_beg + per);
         double4_ acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
         for (int sp = p_beg; sp < p_end; sp += 64) {               // 16 MFMAs per trip on two independent accumulators
-            double a[16], b[16];
+            // all 48 loads of the trip are issued before the first use (clamped rows, masks multiplied in afterwards)
+            double a[16], b[16], w[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
-                const int p = sp + 4 * u + kk;
-                a[u] = 0.0; b[u] = 0.0;
-                if (p < p_end) {
-                    const double* row = S.G + (size_t)p * S.ldg;
-                    a[u] = row[16 * ti + c];
-                    b[u] = S.Wt[p] * row[16 * tj + c];
-                }
+                const int p = min(sp + 4 * u + kk, p_end - 1);
+                const double* row = S.G + (size_t)p * S.ldg;
+                a[u] = row[16 * ti + c];
+                b[u] = row[16 * tj + c];
+                w[u] = S.Wt[p];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one wait for the whole batch (measured: a staggered wait chain is ~1 us slower)
+            if (S.dbg && tid == 0 && blockIdx.x == 33) S.dbg[32] = wall_clock64();
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const double mk = (sp + 4 * u + kk < p_end) ? 1.0 : 0.0;
+                a[u] *= mk;
+                b[u] = (w[u] * b[u]) * mk;
             }
 #pragma unroll
             for (int u = 0; u < 16; u += 2) {
@@ -458,7 +476,9 @@ __global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
         for (int rg = 0; rg < 4; rg++) acc[rg] += acc2[rg];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) s_part[wv][(kk + 4 * rg) * 16 + c] = acc[rg];
+        if (S.dbg && tid == 0 && blockIdx.x == 33) S.dbg[33] = wall_clock64();
         __syncthreads();
+        if (S.dbg && tid == 0 && blockIdx.x == 33) S.dbg[34] = wall_clock64();
         if (tid < 256) {
             double sum = s_part[0][tid];
 #pragma unroll
@@ -471,13 +491,30 @@ __global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
     const int a = (int)blockIdx.x - S.nsyrk - 1;                             // -1: calibration rows
     const int nmat = S.use_lin_blocks ? 2 : 1;
     if (a < 0) {
-        for (int task = tid; task < nmat * 20; task += NT) {
-            const int v = task % 20, mat = task / 20;
+        // CC (16) + bC (4) sums over the N^2 pairs: 8 groups of pairs per entry, 8 loads in flight per trip, then a fixed-order add
+        __shared__ double s_cpart[2][8][20];
+        const int NN = N * N, per = (NN + 7) / 8;
+        for (int task = tid; task < nmat * 160; task += NT) {
+            const int v = task % 20, grp = (task / 20) % 8, mat = task / 160;
             const double* pb = mat == 0 ? S.pbA : S.pbL;
             const int off = v < 16 ? PB_CC + v : PB_BC + (v - 16);
+            const int q0 = grp * per, q1 = min(NN, q0 + per);
             double sum = 0;
-#pragma unroll 8
-            for (int q = 0; q < N * N; q++) sum += pb[(size_t)q * PB_STRIDE + off];
+            for (int base = q0; base < q1; base += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = pb[(size_t)min(base + u, q1 - 1) * PB_STRIDE + off];
+#pragma unroll
+                for (int u = 0; u < 8; u++) sum += t[u] * (base + u < q1 ? 1.0 : 0.0);
+            }
+            s_cpart[mat][grp][v] = sum;
+        }
+        __syncthreads();
+        for (int task = tid; task < nmat * 20; task += NT) {
+            const int v = task % 20, mat = task / 20;
+            double sum = 0;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; g8++) sum += s_cpart[mat][g8][v];
             s_f[mat][v] = sum;
         }
         __syncthreads();
@@ -582,14 +619,15 @@ struct SolveSys {            // the final LM system, assembled while it is loade
     const double* Hb; const double* bb; const double* part; int nsl, ntile; double lambda;
 };
 // H_sc(gi, gj), gj <= gi or the rhs column gi == n: slices added in slice order
+template <int NSL>
 __device__ __forceinline__ double schur_entry(const SolveSys& Y, int grow, int gcol) {     // grow <= gcol (upper tile storage)
     const int ti = grow >> 4, tj = gcol >> 4;
     const double* q = Y.part + ((size_t)sys_tile_index(ti, tj, Y.ntile) * Y.nsl) * 256 + (grow & 15) * 16 + (gcol & 15);
-    double ps[8], sum = 0;
+    double ps[NSL], sum = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) ps[k] = q[(size_t)min(k, Y.nsl - 1) * 256] * (k < Y.nsl ? 1.0 : 0.0);   // cml_sys_slices() <= 8: all loads in flight
+    for (int k = 0; k < NSL; k++) ps[k] = q[(size_t)k * 256];        // all loads in flight
 #pragma unroll
-    for (int k = 0; k < 8; k++) sum += ps[k];
+    for (int k = 0; k < NSL; k++) sum += ps[k];
     return sum;
 }
 
@@ -598,10 +636,11 @@ __device__ __forceinline__ double schur_entry(const SolveSys& Y, int grow, int g
 // Every load is unconditional (clamped address, mask multiplied in): a select would let the compiler sink each load
 // behind its own branch + s_waitcnt, i.e. one memory round trip per load instead of one per thread.
 #define SOLVE_IPT 8
+template <int NSL>
 __device__ __forceinline__ void solve_load_items(const SolveSys& Y, int n, int off, int m, int items, int it0,
                                                  double (&val)[SOLVE_IPT], int (&dst)[SOLVE_IPT], int (&ij)[SOLVE_IPT]) {
     const double il = 1.0 / (1 + Y.lambda);
-    double hb[SOLVE_IPT], ps[SOLVE_IPT][8];
+    double hb[SOLVE_IPT], ps[SOLVE_IPT][NSL];
     bool diag[SOLVE_IPT];
 #pragma unroll
     for (int u = 0; u < SOLVE_IPT; u++) {
@@ -619,19 +658,20 @@ __device__ __forceinline__ void solve_load_items(const SolveSys& Y, int n, int o
         const double hv = Y.Hb[real ? (size_t)gc * n + gr : 0];
         hb[u] = real ? hv : (i == j ? 1.0 : 0.0);
 #pragma unroll
-        for (int k = 0; k < 8; k++) ps[u][k] = q[(size_t)min(k, Y.nsl - 1) * 256] * ((real && k < Y.nsl) ? 1.0 : 0.0);
+        for (int k = 0; k < NSL; k++) ps[u][k] = q[(size_t)k * 256] * (real ? 1.0 : 0.0);
     }
 #pragma unroll
     for (int u = 0; u < SOLVE_IPT; u++) {
         double hsc = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) hsc += ps[u][k];
+        for (int k = 0; k < NSL; k++) hsc += ps[u][k];
         double v = hb[u];
         if (diag[u]) v *= (1 + Y.lambda);
         val[u] = v - hsc * il;
     }
 }
 
+template <int NSL>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
                                                             const int* newframe_res, int n_newframe, const double* lin_partial,
                                                             int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
@@ -671,8 +711,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     if (items <= SOLVE_IPT * SOLVE_THREADS) {                    // usual window sizes: values stay in registers across the scaling
         double val[SOLVE_IPT]; int dst[SOLVE_IPT], ij[SOLVE_IPT];
         const int yi = SOLVE_THREADS - 1 - tid;                  // rhs on the last waves (fewest live matrix items), issued first
-        const double yraw = (Y.bb[off + min(yi, m - 1)] - schur_entry(Y, off + min(yi, m - 1), n)) * (yi < m ? 1.0 : 0.0);
-        solve_load_items(Y, n, off, m, items, tid, val, dst, ij);
+        const double yraw = (Y.bb[off + min(yi, m - 1)] - schur_entry<NSL>(Y, off + min(yi, m - 1), n)) * (yi < m ? 1.0 : 0.0);
+        solve_load_items<NSL>(Y, n, off, m, items, tid, val, dst, ij);
         if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(A, 54); }
 #pragma unroll
         for (int u = 0; u < SOLVE_IPT; u++) {
@@ -690,11 +730,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     } else {
         for (int it0 = tid; it0 < items; it0 += SOLVE_IPT * SOLVE_THREADS) {
             double val[SOLVE_IPT]; int dst[SOLVE_IPT], ij[SOLVE_IPT];
-            solve_load_items(Y, n, off, m, items, it0, val, dst, ij);
+            solve_load_items<NSL>(Y, n, off, m, items, it0, val, dst, ij);
 #pragma unroll
             for (int u = 0; u < SOLVE_IPT; u++) if (dst[u] >= 0) L[dst[u]] = val[u];
         }
-        for (int i = tid; i < mp; i += SOLVE_THREADS) y[i] = (i < m) ? Y.bb[off + i] - schur_entry(Y, off + i, n) : 0.0;
+        for (int i = tid; i < mp; i += SOLVE_THREADS) y[i] = (i < m) ? Y.bb[off + i] - schur_entry<NSL>(Y, off + i, n) : 0.0;
         __syncthreads();
         for (int i = tid; i < mp; i += SOLVE_THREADS) Sv[i] = (i < m) ? 1.0 / sqrt(L[blk_off(i >> 4, i >> 4) + (i & 15) * (BLD + 1)] + 10.0) : 0.0;
         __syncthreads();
@@ -1021,18 +1061,26 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
     const int n = A.n, off = optcal ? 0 : 4, m = n - off;
     const size_t sh = solve_lds_bytes(m);
     int* flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
-    static bool attr_set = false;
-    if (!attr_set || sh > 64 * 1024) {
-        hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    if (sh > 160 * 1024) {                                   // the factorisation is LDS-resident: 8N+4 <= 160 (+4 with the calibration block)
+        c->err = "window too wide for the LDS-resident solver";
+        return CMLHIP_ERR_INVALID;
     }
     SolveSys Y;
     Y.Hb = c->Hf.as<double>(); Y.bb = c->bf.as<double>(); Y.part = c->syrk_part.as<double>();
     Y.nsl = cml_sys_slices(A.P); Y.ntile = ldg_of(n) / 16; Y.lambda = c->sys_lambda;
-    k_ba_solve<<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag,
-                                                                          c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(),
-                                                                          c->n_lin_partial, c->scal.as<LinSummary>(), c->frames.as<FrameDev>(),
-                                                                          with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr);
+#define LAUNCH_SOLVE(NSL) do { \
+        static bool attr_set = false; \
+        if (!attr_set) { hipFuncSetAttribute((const void*)k_ba_solve<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        k_ba_solve<NSL><<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag, \
+            c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->n_lin_partial, c->scal.as<LinSummary>(), \
+            c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr); } while (0)
+    switch (Y.nsl) {
+        case 1: LAUNCH_SOLVE(1); break;
+        case 2: LAUNCH_SOLVE(2); break;
+        case 4: LAUNCH_SOLVE(4); break;
+        default: LAUNCH_SOLVE(8); break;
+    }
+#undef LAUNCH_SOLVE
     return CMLHIP_OK;
 }
 

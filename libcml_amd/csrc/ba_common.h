@@ -49,10 +49,8 @@ struct BAArgs {
 };
 
 // point slices of the Schur SYRK (k_ba_system): more slices = more CUs pulling rows, but more partials for the consumer to add
-static inline int cml_sys_slices(int P) {
-    int want = (P + 511) / 512;
-    return want < 1 ? 1 : (want > 8 ? 8 : want);
-}
+// (a power of two <= 8: the solve kernel is instantiated per slice count so that it issues exactly the loads it needs)
+static inline int cml_sys_slices(int P) { return P <= 512 ? 1 : (P <= 1024 ? 2 : (P <= 2048 ? 4 : 8)); }
 int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A);
 int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A);
