@@ -267,21 +267,21 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
     double* srow = s_row[wv];
     for (int c = l; c < X.ldg; c += 64) srow[c] = 0.0;
     const int host = A.pt_host[p];
-    const int beg = A.by_point_off[p], end = A.by_point_off[p + 1];
     // component a of a slot computes one of the per-residual scalars: a<4 Hcd[a], a=4 Hdd, a=5 bd, a=6 good count
     float accA = 0.f, accL = 0.f;
     double hostacc = 0.0;
-    for (int base = beg; base < end; base += 8) {            // one pass for N <= 9
-        const int kk = base + s;
-        const bool have = kk < end;
-        const int r = have ? A.by_point[kk] : 0;
-        const bool good = have && A.r_good[r];
-        const bool lin = good && A.r_lin[r];
+    for (int base = 0; base < A.pt_stride; base += 8) {      // one pass for N <= 9
+        // two memory round trips per pass: {efsJ code kept by applyRes, static target} of the slot, then the record fields
+        const int slot = p * A.pt_stride + base + s;
+        const int code = A.point_code[slot], tgl = A.point_tgt[slot];
+        const bool good = code >= 0;
+        const bool lin = good && (tgl & 256);
         double sh = 0.0;
         float val = 0.f;
         if (good) {
-            const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
-            const int t = A.r_target[r];
+            const int r = code >> 1;
+            const float* J = ((code & 1) ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
+            const int t = tgl & 255;
             const int q = host + t * A.N;
             const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r + 4);
             const double4_* AH = reinterpret_cast<const double4_*>(X.adH + 64 * (size_t)q + 8 * a);
@@ -817,35 +817,37 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     }
     DBG_T(A, 50);
     DBG_T(A, 51);
-    for (int i = tid; i < mp; i += SOLVE_THREADS) {
-        const double d = dvec[i];
-        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] * dinv[i] : 0.0;
-    }
-    __syncthreads();
-    for (int K = nb - 1; K >= 0; K--) {
-        if (wv == 0) {                                       // L_KK^T x = z: COLUMN per lane in registers
-            const double* D = L + blk_off(K, K);
-            double col[16];
+    {
+        for (int i = tid; i < mp; i += SOLVE_THREADS) {
+            const double d = dvec[i];
+            y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] * dinv[i] : 0.0;
+        }
+        __syncthreads();
+        for (int K = nb - 1; K >= 0; K--) {
+            if (wv == 0) {                                       // L_KK^T x = z: COLUMN per lane in registers
+                const double* D = L + blk_off(K, K);
+                double col[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) col[k] = (l < 16) ? D[k * BLD + l] : 0.0;
-            double yv = (l < 16) ? y[16 * K + l] : 0.0;
+                for (int k = 0; k < 16; k++) col[k] = (l < 16) ? D[k * BLD + l] : 0.0;
+                double yv = (l < 16) ? y[16 * K + l] : 0.0;
 #pragma unroll
-            for (int k = 15; k >= 0; k--) {
-                const double xk = rl(yv, k);
-                if (l < k) yv -= col[k] * xk;
+                for (int k = 15; k >= 0; k--) {
+                    const double xk = rl(yv, k);
+                    if (l < k) yv -= col[k] * xk;
+                }
+                if (l < 16) y[16 * K + l] = yv;
             }
-            if (l < 16) y[16 * K + l] = yv;
-        }
-        __syncthreads();
-        for (int rr = tid; rr < K * 16; rr += SOLVE_THREADS) {      // rows of blocks J < K: y_J -= L_KJ^T x_K
-            const int J = rr >> 4, j = rr & 15;
-            const double* Lb = L + blk_off(K, J);
-            double s = 0;
+            __syncthreads();
+            for (int rr = tid; rr < K * 16; rr += SOLVE_THREADS) {      // rows of blocks J < K: y_J -= L_KJ^T x_K
+                const int J = rr >> 4, j = rr & 15;
+                const double* Lb = L + blk_off(K, J);
+                double s = 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) s += Lb[i * BLD + j] * y[16 * K + i];
-            y[16 * J + j] -= s;
+                for (int i = 0; i < 16; i++) s += Lb[i * BLD + j] * y[16 * K + i];
+                y[16 * J + j] -= s;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     DBG_T(A, 52);
     int bad = 0;
@@ -924,19 +926,18 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
     float sumID = 0, sumNID = 0, numID = 0;
     {
         const float* pa = A.pt_acc + (size_t)pp * PT_ACC_STRIDE;
-        const int beg = A.by_point_off[pp], end = pv ? A.by_point_off[pp + 1] : beg;
         const int host = A.pt_host[pp];
         const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
         const double xc = x[i & 3];
         int ngood = 0;
         double dsum = 0.0;
-        for (int base = beg; base < end; base += 8) {
-            const int kk = base + i;
-            const bool have = kk < end;
-            const int r = A.by_point[have ? kk : beg];
+        for (int base = 0; base < A.pt_stride; base += 8) {
+            const int slot = pp * A.pt_stride + base + i;
+            const int code = A.point_code[slot], tgl = A.point_tgt[slot];         // efsJ code kept by applyRes, static target
+            const bool good = pv && code >= 0;
+            const int r = max(code, 0) >> 1;
             const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r + 4);
-            const bool good = have && A.r_good[r];
-            const double* xa = s_xAd + 8 * (host * N + A.r_target[r]);
+            const double* xa = s_xAd + 8 * (host * N + (max(tgl, 0) & 255));
             double d = ((xa[0] * (double)v0.x + xa[1] * (double)v0.y) + (xa[2] * (double)v0.z + xa[3] * (double)v0.w))
                      + ((xa[4] * (double)v1.x + xa[5] * (double)v1.y) + (xa[6] * (double)v1.z + xa[7] * (double)v1.w));
             d = good ? d : 0.0;

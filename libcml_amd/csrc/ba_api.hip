@@ -30,6 +30,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.rj0 = c->rj[0].as<float>(); A.rj1 = c->rj[1].as<float>();
     A.by_point_off = c->by_point_off.as<int>(); A.by_point = c->by_point.as<int>();
     A.by_pair_off = c->by_pair_off.as<int>(); A.by_pair = c->by_pair.as<int>();
+    A.point_code = c->point_code.as<int>(); A.point_tgt = c->point_tgt.as<int>(); A.point_pos = c->point_pos.as<int>(); A.pt_stride = c->pt_stride;
     A.pair_code = c->pair_code.as<int>(); A.pair_pos = c->pair_pos.as<int>(); A.pair_stride = c->pair_stride;
     A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0;
     A.dbg = c->dbg_on ? c->dbg.as<long long>() : nullptr;
@@ -146,6 +147,23 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         if ((rc = cml_ensure(c, c->pair_code, 4 * code.size()))) return rc;
         if ((rc = cml_ensure(c, c->pair_pos, 4 * pos.size()))) return rc;
         UP(c->pair_code, code); UP(c->pair_pos, pos);
+    }
+    {
+        int mx = 1;
+        for (int p = 0; p < P; p++) mx = std::max(mx, c->h_by_point_off[p + 1] - c->h_by_point_off[p]);
+        c->pt_stride = (mx + 7) & ~7;
+        const size_t tot = (size_t)std::max(P, 1) * c->pt_stride;
+        std::vector<int> code(tot, -1), tgt(tot, -1), pos(std::max(R, 1), 0);
+        for (int p = 0; p < P; p++)
+            for (int i = c->h_by_point_off[p]; i < c->h_by_point_off[p + 1]; i++) {
+                const int r = c->h_by_point[i], slot = p * c->pt_stride + (i - c->h_by_point_off[p]);
+                pos[r] = slot;
+                tgt[slot] = res[r].target | (res[r].is_linearized ? 256 : 0);
+            }
+        if ((rc = cml_ensure(c, c->point_code, 4 * code.size()))) return rc;
+        if ((rc = cml_ensure(c, c->point_tgt, 4 * tgt.size()))) return rc;
+        if ((rc = cml_ensure(c, c->point_pos, 4 * pos.size()))) return rc;
+        UP(c->point_code, code); UP(c->point_tgt, tgt); UP(c->point_pos, pos);
     }
     UP(c->newframe_res, newframe);
 #undef UP

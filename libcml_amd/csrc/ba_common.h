@@ -42,6 +42,7 @@ struct BAArgs {
     unsigned char* r_good; const unsigned char* r_lin; unsigned char* r_sel;
     float* r_center; float* r_jpjdf; float* r_rtz; float* rj0; float* rj1;
     const int* by_point_off; const int* by_point; const int* by_pair_off; const int* by_pair;
+    int* point_code; const int* point_tgt; const int* point_pos; int pt_stride;   // [P][pt_stride]: 2r+sel of the point's good residuals else -1; target | lin << 8 (-1 = empty slot); slot of r
     int* pair_code; const int* pair_pos; int pair_stride;     // [N*N][pair_stride]: 2r+sel of the ACTIVE good residuals of the pair, else -1 (written by applyRes); slot of r
     double* lin_partial;          // per-block {energy, n_in, n_oob, n_outlier} of the residual kernel (may be null)
     long long* dbg;               // optional phase timestamps (wall_clock64, 100 MHz): 16 slots per kernel, see cmlhip_debug_read

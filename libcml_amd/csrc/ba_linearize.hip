@@ -49,7 +49,7 @@ template <bool HALF>
 __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     __shared__ __attribute__((aligned(16))) float s_share[RES_PER_BLOCK][NSHARE][8];   // [residual][quantity][pixel]
     __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE];
-    __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK], s_app[RES_PER_BLOCK], s_sel[RES_PER_BLOCK], s_pos[RES_PER_BLOCK];
+    __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK], s_app[RES_PER_BLOCK], s_sel[RES_PER_BLOCK], s_pos[RES_PER_BLOCK], s_ppos[RES_PER_BLOCK];
     __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
     DBG_BLK(A.dbg, 0, 0);
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const int rc = min(r, A.R - 1);
     const int lin_ = A.r_lin[rc], st_ = A.r_state[rc], p_ = A.r_point[rc], tg_ = A.r_target[rc];
     const float pre_energy = A.r_energy[rc];
-    const int pre_new_state = A.r_new_state[rc], pre_pos = A.pair_pos[rc];
+    const int pre_new_state = A.r_new_state[rc], pre_pos = A.pair_pos[rc], pre_ppos = A.point_pos[rc];
     const unsigned char pre_sel = A.r_sel[rc];
     const bool live = (r < A.R) && !lin_;
     const int st = live ? st_ : CMLHIP_RES_OOB;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     rec[O_JAB1 + k] = A.opt_b ? hw : 0.f;
 
     // ---- classification, BA.cpp:66-72,115-118,297-314
-    if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; s_app[g] = 0; s_sel[g] = pre_sel; s_pos[g] = pre_pos; }
+    if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; s_app[g] = 0; s_sel[g] = pre_sel; s_pos[g] = pre_pos; s_ppos[g] = pre_ppos; }
     if (live && k == 0) {
         float ret = pre_energy;
         float nwo = -1.f;
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         int code = -1;
         if (s_flip[tid]) { const unsigned char sl = (unsigned char)(s_sel[tid] ^ 1); A.r_sel[rr_] = sl; code = 2 * rr_ + sl; }
         A.pair_code[s_pos[tid]] = code;
+        A.point_code[s_ppos[tid]] = code;
     }
     // ---- per-block partials {energy, n_in, n_oob, n_outlier} (BA.cpp:1565): fixed butterfly order over the 32 residuals
     if (tid < 64 && A.lin_partial) {
@@ -305,6 +306,7 @@ __global__ void k_ba_apply(BAArgs A, int copy) {
             const unsigned char sel = A.r_sel[r] ^ 1;
             A.r_sel[r] = sel;
             A.pair_code[A.pair_pos[r]] = 2 * r + sel;
+            A.point_code[A.point_pos[r]] = 2 * r + sel;
             const float* J = (sel ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
             const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
             const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
@@ -316,6 +318,7 @@ __global__ void k_ba_apply(BAArgs A, int copy) {
         } else {
             A.r_good[r] = 0;
             A.pair_code[A.pair_pos[r]] = -1;
+            A.point_code[A.point_pos[r]] = -1;
         }
     }
     A.r_state[r] = A.r_new_state[r];

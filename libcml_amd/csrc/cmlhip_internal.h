@@ -60,6 +60,7 @@ struct cmlhip_ctx {
     DevBuf r_point, r_target, r_state, r_new_state, r_energy, r_new_energy, r_new_energy_wo, r_ret_energy;
     DevBuf r_good, r_lin, r_sel, r_center, r_jpjdf, r_rtz, rj[2];
     DevBuf by_point_off, by_point, by_pair_off, by_pair, newframe_res;
+    DevBuf point_code, point_tgt, point_pos; int pt_stride = 0; // [P][pt_stride]: efsJ code per point slot (kept by applyRes), static target | lin << 8, slot of r
     DevBuf pair_code, pair_pos; int pair_stride = 0;          // [N*N][pair_stride] efsJ code (2r+sel, -1 = not in the ACTIVE sum) kept by applyRes; position of r
     DevBuf acc_pair[2];                                       // N*N x 96 floats (91 used) ACTIVE / LINEARIZED
     DevBuf acc_num[2];                                        // N*N ints
