@@ -132,8 +132,10 @@ def main():
     _dbg('profile enabled')
     dt = shard.timed_region(group, sync, run_steps)
     _dbg('timed region done')
-    lin_v, ss_v, _n = ctx.profile_read()
-    lin_ms, ss_ms = C.c_float(lin_v), C.c_float(ss_v)
+    lin_v, ss_v, empty_v, _n = ctx.profile_read()
+    # raw brackets contain the cost of the two event records themselves (measured by the empty bracket recorded next to
+    # them, ~5 us, i.e. comparable to the kernel): the kernel time is the difference
+    lin_ms, ss_ms = C.c_float(max(lin_v - empty_v, 0.0)), C.c_float(max(ss_v - empty_v, 0.0))
     _dbg('profile read')
     st = ctx.ba_states()
     n_good = int(st["good"].sum())
@@ -144,6 +146,19 @@ def main():
     _dbg('reductions done')
     if rank == 0:
         achieved = R * READ_BYTES_PER_RESIDUAL / (lin_ms.value * 1e-3) / 1e9 if lin_ms.value > 0 else 0.0
+        # memory-side bytes per launch of the residual kernel come from separate `rocprofv3 --pmc` passes of this same command
+        # (tools/profile_bench.py; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide) and are only
+        # quoted for the workload they were collected on
+        traffic, traffic_src, rocprof_us = None, None, None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_f_pmc_linearize.json")
+        if args.config == "B" and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("traffic_bytes_per_launch")
+                rocprof_us = pmc.get("linearize_avg_us")   # kernel-trace average of the same command (dispatches serialised by the profiler)
+                traffic_src = "profiles/round1_f_pmc_linearize.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            except Exception:
+                traffic = None
         out = {
             "metric": "point-residuals/sec + Schur-reduce+solve ms, 8 KF x 2000 pts window",
             "value": total_units / dt, "unit": "point-residuals/s",
@@ -154,8 +169,11 @@ def main():
                        "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
             "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
             "roofline": {"bound": "hbm", "kernel": "k_ba_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": R * READ_BYTES_PER_RESIDUAL, "launch_us": 1e3 * lin_ms.value},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": R * READ_BYTES_PER_RESIDUAL, "launch_us": 1e3 * lin_ms.value,
+                         "launch_us_note": "HIP-event bracket on the context stream, sampled every 8th step inside the timed region, "
+                                           "minus the empty bracket recorded next to it (raw %.2f us, empty %.2f us)" % (1e3 * lin_v, 1e3 * empty_v),
+                         "rocprof_avg_us": rocprof_us},
         }
         if not args.no_cpu_baseline:
             try:

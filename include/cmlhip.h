@@ -329,7 +329,9 @@ int cmlhip_profile_stride(cmlhip_ctx* ctx, int stride);
  * Reads the previous values, then (re)arms. */
 #define CMLHIP_DEBUG_SLOTS (128 + 5 * 1024 * 2)
 int cmlhip_debug_timestamps(cmlhip_ctx* ctx, int enable, long long* out);
-int cmlhip_profile_read(cmlhip_ctx* ctx, float* linearize_ms, float* schur_solve_ms, int* n_recorded);
+/* mean RAW bracket durations (event record -> kernel(s) -> event record) and the mean duration of an empty bracket
+ * recorded next to them (the event overhead contained in each raw figure) */
+int cmlhip_profile_read(cmlhip_ctx* ctx, float* linearize_ms, float* schur_solve_ms, float* empty_bracket_ms, int* n_recorded);
 
 #ifdef __cplusplus
 }

@@ -479,20 +479,21 @@ int cmlhip_profile_stride(cmlhip_ctx* c, int stride) {
     return CMLHIP_OK;
 }
 
-int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, int* n) {
+int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, float* empty_ms, int* n) {
     if (!c) return CMLHIP_ERR_INVALID;
     CML_CHECK(c, hipStreamSynchronize(c->stream));
-    double a = 0, b = 0;
+    double a = 0, b = 0, e = 0;
     for (int i = 0; i < c->prof_n; i++) {
         float m0 = 0, m1 = 0, m2 = 0;
         CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[6 * (size_t)i + 0], c->prof_ev[6 * (size_t)i + 1]));
         CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[6 * (size_t)i + 2], c->prof_ev[6 * (size_t)i + 3]));
         CML_CHECK(c, hipEventElapsedTime(&m2, c->prof_ev[6 * (size_t)i + 4], c->prof_ev[6 * (size_t)i + 5]));   // empty bracket = event overhead
-        b += m0 - m2; a += m1 - m2;
+        b += m0; a += m1; e += m2;
     }
     if (n) *n = c->prof_n;
     if (lin_ms) *lin_ms = c->prof_n ? (float)(a / c->prof_n) : 0.f;
     if (ss_ms) *ss_ms = c->prof_n ? (float)(b / c->prof_n) : 0.f;
+    if (empty_ms) *empty_ms = c->prof_n ? (float)(e / c->prof_n) : 0.f;
     c->prof_n = 0;
     return CMLHIP_OK;
 }

@@ -48,7 +48,7 @@ PROTOTYPES = {
     "cmlhip_profile_stride": (C.c_int, [_ctx, _i]),
     "cmlhip_ba_set_resident_state": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(abi.BAFrameState), _P(C.c_double), _P(C.c_double)]),
     "cmlhip_ba_get_resident_state": (C.c_int, [_ctx, _P(abi.BAFrameState), _P(C.c_double), _P(abi.BALinResult)]),
-    "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_i)]),
+    "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
     "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
@@ -146,9 +146,9 @@ class Ctx:
         self.ck(self.L.cmlhip_profile_enable(self.h, max_iterations))
 
     def profile_read(self):
-        a, b, n = _f(), _f(), _i()
-        self.ck(self.L.cmlhip_profile_read(self.h, C.byref(a), C.byref(b), C.byref(n)))
-        return a.value, b.value, n.value
+        a, b, e, n = _f(), _f(), _f(), _i()
+        self.ck(self.L.cmlhip_profile_read(self.h, C.byref(a), C.byref(b), C.byref(e), C.byref(n)))
+        return a.value, b.value, e.value, n.value
 
     # ------------------------------------------------------------------ pyramids
     def pyramid_put(self, image_id, level, aos3):
