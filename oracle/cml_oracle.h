@@ -119,6 +119,14 @@ int  orc_ba_solve(const orc_ba_window* w, double lambda, const double* HA, const
 int  orc_ba_backsub(orc_ba_window* w, const cmlhip_ba_accum_in* in, const double* x);
 void orc_ba_backup_points(orc_ba_window* w);
 void orc_ba_step_points(orc_ba_window* w, float sums[3]);      /* BA.cpp:976-994 */
+/* marginalisation, SURVEY §8 a15 */
+void orc_ba_fix_linearization(orc_ba_window* w, int r, const cmlhip_ba_accum_in* in);              /* BA.cpp:2210-2238 */
+int  orc_ba_relinearize_points(orc_ba_window* w, int n, const int* pts, const cmlhip_ba_accum_in* in);   /* BA.cpp:2291-2304 */
+void orc_ba_marginalize_points(orc_ba_window* w, int n, const int* pts, const cmlhip_ba_accum_in* in,
+                               double* M, double* Mb, double* Msc, double* Mbsc);                      /* BA.cpp:2466-2513 */
+void orc_ba_marginalize_frame(double* HM, double* bM, int N, int frame, const double prior[8], const double delta_prior[8]);   /* BA.cpp:483-558 */
+double orc_ba_calc_m_energy(const double* HM, const double* bM, int n, const double* delta);          /* BA.cpp:2095-2117 */
+double orc_ba_calc_l_energy(const orc_ba_window* w, const cmlhip_ba_accum_in* in, int* num_out);      /* BA.cpp:2119-2208 */
 
 /* host-side frame algebra used by the tests to build inputs the way the reference does */
 typedef struct {

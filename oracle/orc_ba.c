@@ -275,11 +275,10 @@ void orc_ba_linearize_all(orc_ba_window* w, cmlhip_ba_lin_result* out) {
 }
 
 /* BA.cpp:2051-2093 */
-void orc_ba_apply(orc_ba_window* w, int copy) {
-    for (int r = 0; r < w->R; r++) {
-        if (w->r_lin[r]) continue;
+static void apply_one(orc_ba_window* w, int r, int copy) {
+    {
         if (copy) {
-            if (w->r_state[r] == CMLHIP_RES_OOB) continue;       /* return: can never go back from OOB */
+            if (w->r_state[r] == CMLHIP_RES_OOB) return;         /* return: can never go back from OOB */
             if (w->r_new_state[r] == CMLHIP_RES_IN) {
                 w->r_good[r] = 1;
                 float* a = w->rJ + 74 * (size_t)r; float* b = w->efsJ + 74 * (size_t)r;
@@ -298,6 +297,12 @@ void orc_ba_apply(orc_ba_window* w, int copy) {
         }
         w->r_state[r] = w->r_new_state[r];
         w->r_energy[r] = w->r_new_energy[r];
+    }
+}
+void orc_ba_apply(orc_ba_window* w, int copy) {
+    for (int r = 0; r < w->R; r++) {
+        if (w->r_lin[r]) continue;
+        apply_one(w, r, copy);
     }
 }
 
@@ -399,12 +404,15 @@ static void add_to_hessian_top(orc_ba_window* w, int p, int mode, approx_acc* ac
         int r = w->by_point[k];
         if (mode == CMLHIP_MODE_ACTIVE) { if (w->r_lin[r] || !w->r_good[r]) continue; }
         if (mode == CMLHIP_MODE_LINEARIZED) { if (!w->r_lin[r] || !w->r_good[r]) continue; }
+        if (mode == CMLHIP_MODE_MARGINALIZED) { if (!w->r_good[r]) continue; }   /* :1670-1674 (asserts isLinearized) */
         const float* J = w->efsJ + 74 * (size_t)r;
         int ht = w->pair_of[r];
         const float* dp = in->adHTdeltaF + 8 * ht;
         double resApprox[8];
         if (mode == CMLHIP_MODE_ACTIVE) {
             for (int i = 0; i < 8; i++) resApprox[i] = (double)J[O_RES + i];
+        } else if (mode == CMLHIP_MODE_MARGINALIZED) {
+            for (int i = 0; i < 8; i++) resApprox[i] = (double)w->res_toZeroF[8 * r + i];   /* :1689-1692 */
         } else {
             /* BA.cpp:1699-1713.  The reference stores the 8 float results through a float* into a
              * double[8] (:1712) — undefined contents; this restates the evident intent (float rtz
@@ -452,6 +460,9 @@ static void add_to_hessian_top(orc_ba_window* w, int p, int mode, approx_acc* ac
         w->Hdd_accAF[p] = Hdd_acc; w->bd_accAF[p] = bd_acc; memcpy(w->Hcd_accAF + 4 * p, Hcd_acc, 16);
     } else {
         w->Hdd_accLF[p] = Hdd_acc; w->bd_accLF[p] = bd_acc; memcpy(w->Hcd_accLF + 4 * p, Hcd_acc, 16);
+    }
+    if (mode == CMLHIP_MODE_MARGINALIZED) {                  /* :1769-1775 */
+        w->Hdd_accAF[p] = 0; w->bd_accAF[p] = 0; memset(w->Hcd_accAF + 4 * p, 0, 16);
     }
 }
 
@@ -528,27 +539,9 @@ static void stitch_top(const orc_ba_window* w, const float* accH, const int* acc
 #undef FH
 }
 
-void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* HA, double* bA, double* HL,
-                       double* bL, double* Hsc, double* bsc) {
+/* addToHessianSC over the points with sel[p] != 0 (NULL: all) + stitchDoubleSC, BA.cpp:1880-2043 */
+static void schur_points(orc_ba_window* w, const cmlhip_ba_accum_in* in, const unsigned char* sel, int shift_prior, double* tH, double* tb) {
     const int N = w->N, n = 8 * N + 4, NN = N * N;
-    approx_acc* acc = (approx_acc*)zalloc(sizeof(approx_acc) * NN);
-    double* tH = (double*)zalloc(sizeof(double) * n * n); double* tb = (double*)zalloc(sizeof(double) * n);
-    /* ACTIVE, BA.cpp:1368-1371 */
-    for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_ACTIVE, acc, in);
-    for (int q = 0; q < NN; q++) { approx_finish(&acc[q], w->accA + 169 * q); w->accA_num[q] = acc[q].num; }
-    stitch_top(w, w->accA, w->accA_num, in, 0, tH, tb);
-    if (HA) memcpy(HA, tH, sizeof(double) * n * n);
-    if (bA) memcpy(bA, tb, sizeof(double) * n);
-    /* LINEARIZED, BA.cpp:1375-1378 */
-    memset(acc, 0, sizeof(approx_acc) * NN);
-    for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_LINEARIZED, acc, in);
-    for (int q = 0; q < NN; q++) { approx_finish(&acc[q], w->accL + 169 * q); w->accL_num[q] = acc[q].num; }
-    stitch_top(w, w->accL, w->accL_num, in, 1, tH, tb);
-    if (HL) memcpy(HL, tH, sizeof(double) * n * n);
-    if (bL) memcpy(bL, tb, sizeof(double) * n);
-    free(acc);
-
-    /* addToHessianSC, BA.cpp:1880-1937 */
     tier_acc* accD = (tier_acc*)zalloc(sizeof(tier_acc) * NN * N);
     tier_acc* accE = (tier_acc*)zalloc(sizeof(tier_acc) * NN);
     tier_acc* accEB = (tier_acc*)zalloc(sizeof(tier_acc) * NN);
@@ -557,6 +550,7 @@ void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* H
     for (int i = 0; i < NN; i++) { tier_init(&accE[i], 32); tier_init(&accEB[i], 8); }
     tier_init(&accHcc, 16); tier_init(&accbc, 4);
     for (int p = 0; p < w->P; p++) {
+        if (sel && !sel[p]) continue;
         const cmlhip_ba_point* pt = &w->points[p];
         int ngood = 0;
         for (int k = w->by_point_off[p]; k < w->by_point_off[p + 1]; k++) if (w->r_good[w->by_point[k]]) ngood++;
@@ -566,7 +560,7 @@ void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* H
         w->HdiF[p] = (float)(1.0 / H);
         w->bdSumF[p] = w->bd_accAF[p] + w->bd_accLF[p];
         float deltaF = (float)(pt->idepth - (double)pt->idepth_zero);
-        w->bdSumF[p] += pt->prior * deltaF;                      /* shiftPriorToZero = true, :1904 */
+        if (shift_prior) w->bdSumF[p] += pt->prior * deltaF;     /* shiftPriorToZero, :1904 */
         float Hcd[4];
         for (int i = 0; i < 4; i++) Hcd[i] = w->Hcd_accAF[4 * p + i] + w->Hcd_accLF[4 * p + i];
         tier_update_outer(&accHcc, Hcd, 4, Hcd, 4, w->HdiF[p]);
@@ -623,9 +617,34 @@ void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* H
     for (int h = 0; h < N; h++)
         for (int a = 0; a < 4; a++) for (int b = 0; b < 8; b++) TH(a, 4 + 8 * h + b) = TH(4 + 8 * h + b, a);
 #undef TH
+    free(accD); free(accE); free(accEB);
+}
+
+
+void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* HA, double* bA, double* HL,
+                       double* bL, double* Hsc, double* bsc) {
+    const int N = w->N, n = 8 * N + 4, NN = N * N;
+    approx_acc* acc = (approx_acc*)zalloc(sizeof(approx_acc) * NN);
+    double* tH = (double*)zalloc(sizeof(double) * n * n); double* tb = (double*)zalloc(sizeof(double) * n);
+    /* ACTIVE, BA.cpp:1368-1371 */
+    for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_ACTIVE, acc, in);
+    for (int q = 0; q < NN; q++) { approx_finish(&acc[q], w->accA + 169 * q); w->accA_num[q] = acc[q].num; }
+    stitch_top(w, w->accA, w->accA_num, in, 0, tH, tb);
+    if (HA) memcpy(HA, tH, sizeof(double) * n * n);
+    if (bA) memcpy(bA, tb, sizeof(double) * n);
+    /* LINEARIZED, BA.cpp:1375-1378 */
+    memset(acc, 0, sizeof(approx_acc) * NN);
+    for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_LINEARIZED, acc, in);
+    for (int q = 0; q < NN; q++) { approx_finish(&acc[q], w->accL + 169 * q); w->accL_num[q] = acc[q].num; }
+    stitch_top(w, w->accL, w->accL_num, in, 1, tH, tb);
+    if (HL) memcpy(HL, tH, sizeof(double) * n * n);
+    if (bL) memcpy(bL, tb, sizeof(double) * n);
+    free(acc);
+
+    schur_points(w, in, NULL, 1, tH, tb);
     if (Hsc) memcpy(Hsc, tH, sizeof(double) * n * n);
     if (bsc) memcpy(bsc, tb, sizeof(double) * n);
-    free(accD); free(accE); free(accEB); free(tH); free(tb);
+    free(tH); free(tb);
 }
 
 /* solveLevenbergMarquardt, BA.cpp:1284-1320 */
@@ -863,4 +882,172 @@ void orc_ba_nullspaces(const orc_frame* fr, int N, const orc_scales* s, double* 
             v *= (k < 3) ? 1.0 / s->trans : 1.0 / s->rot;
             out[6 * n + 4 + 8 * f + k] = v;
         }
+}
+
+/* ------------------------------------------------------------------ marginalisation */
+/* fixLinearization, BA.cpp:2210-2238: res_toZeroF = resF - [JI*Jp Ja]*delta (float, statement order of the SSE code) */
+void orc_ba_fix_linearization(orc_ba_window* w, int r, const cmlhip_ba_accum_in* in) {
+    const cmlhip_ba_point* pt = &w->points[w->r_point[r]];
+    const float* J = w->efsJ + 74 * (size_t)r;
+    const float* dp = in->adHTdeltaF + 8 * w->pair_of[r];
+    const float deltaF = (float)(pt->idepth - (double)pt->idepth_zero);
+    float jx = 0, jy = 0, cx = 0, cy = 0;
+    for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
+    for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)in->cdelta[i]; cy += J[O_C1 + i] * (float)in->cdelta[i]; }
+    const float Jp_delta_x = jx + cx + J[O_DD] * deltaF, Jp_delta_y = jy + cy + J[O_DD + 1] * deltaF;
+    for (int i = 0; i < 8; i++) {
+        float rtz = J[O_RES + i];
+        rtz = rtz - J[O_JI0 + i] * Jp_delta_x;
+        rtz = rtz - J[O_JI1 + i] * Jp_delta_y;
+        rtz = rtz - J[O_JAB0 + i] * dp[6];
+        rtz = rtz - J[O_JAB1 + i] * dp[7];
+        w->res_toZeroF[8 * r + i] = rtz;
+    }
+    w->r_lin[r] = 1;
+}
+
+/* the residual loop of tryMarginalize for the points that will be marginalised, BA.cpp:2291-2304:
+ * resetOOB, linearize, isLinearized = false, applyRes(true), fixLinearization of the good ones.  Returns #good. */
+int orc_ba_relinearize_points(orc_ba_window* w, int n, const int* pts, const cmlhip_ba_accum_in* in) {
+    int ngood = 0;
+    for (int k = 0; k < n; k++) {
+        const int p = pts[k];
+        for (int q = w->by_point_off[p]; q < w->by_point_off[p + 1]; q++) {
+            const int r = w->by_point[q];
+            w->r_new_energy[r] = w->r_energy[r] = 0;                /* resetOOB, DSOResidual.h:81-86 */
+            w->r_new_state[r] = CMLHIP_RES_OUTLIER;
+            w->r_state[r] = CMLHIP_RES_IN;
+            orc_ba_linearize_one(w, r);
+            w->r_lin[r] = 0;
+            apply_one(w, r, 1);
+            if (w->r_good[r]) { orc_ba_fix_linearization(w, r, in); ngood++; }
+        }
+    }
+    return ngood;
+}
+
+/* marginalizePointsF without the bookkeeping, BA.cpp:2466-2513: M, Mb = stitchDoubleTop of the MARGINALIZED-mode
+ * accumulation of the listed points (usePrior = false), Msc, Mbsc = their Schur complement (shiftPriorToZero = false).
+ * The caller adds 0.25 * (M - Msc), 0.25 * (Mb - Mbsc) to the prior (:2502-2507). */
+void orc_ba_marginalize_points(orc_ba_window* w, int n, const int* pts, const cmlhip_ba_accum_in* in,
+                               double* M, double* Mb, double* Msc, double* Mbsc) {
+    const int N = w->N, nn = 8 * N + 4, NN = N * N;
+    approx_acc* acc = (approx_acc*)zalloc(sizeof(approx_acc) * NN);
+    unsigned char* sel = (unsigned char*)zalloc(w->P > 0 ? w->P : 1);
+    for (int k = 0; k < n; k++) {
+        sel[pts[k]] = 1;
+        add_to_hessian_top(w, pts[k], CMLHIP_MODE_MARGINALIZED, acc, in);
+    }
+    for (int q = 0; q < NN; q++) { approx_finish(&acc[q], w->accA + 169 * q); w->accA_num[q] = acc[q].num; }
+    stitch_top(w, w->accA, w->accA_num, in, 0, M, Mb);
+    schur_points(w, in, sel, 0, Msc, Mbsc);
+    free(acc); free(sel);
+}
+
+/* marginalizeFrame, the algebra of BA.cpp:483-558: HM, bM are (8N+4)^2 / (8N+4) row-major on entry, (8N-4)^2 / (8N-4) on exit */
+void orc_ba_marginalize_frame(double* HM, double* bM, int N, int frame, const double prior[8], const double delta_prior[8]) {
+    const int odim = 8 * N + 4, ndim = odim - 8;
+    double* H = (double*)zalloc(sizeof(double) * odim * odim);
+    double* b = (double*)zalloc(sizeof(double) * odim);
+    int* perm = (int*)zalloc(sizeof(int) * odim);
+    /* move the frame's 8 rows/cols to the end, order of the rest unchanged (:489-508) */
+    const int io = 8 * frame + 4;
+    int k = 0;
+    for (int i = 0; i < odim; i++) if (i < io || i >= io + 8) perm[k++] = i;
+    for (int i = 0; i < 8; i++) perm[k++] = io + i;
+    for (int i = 0; i < odim; i++) {
+        b[i] = bM[perm[i]];
+        for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = HM[(size_t)perm[i] * odim + perm[j]];
+    }
+    for (int i = 0; i < 8; i++) {                                      /* :511-513 */
+        H[(size_t)(ndim + i) * odim + ndim + i] += prior[i];
+        b[ndim + i] += prior[i] * delta_prior[i];
+    }
+    double* SVec = (double*)zalloc(sizeof(double) * odim);
+    for (int i = 0; i < odim; i++) SVec[i] = sqrt(fabs(H[(size_t)i * odim + i]) + 10.0);     /* :520-521 */
+    for (int i = 0; i < odim; i++) {
+        for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = (1.0 / SVec[i]) * H[(size_t)i * odim + j] * (1.0 / SVec[j]);
+        b[i] = (1.0 / SVec[i]) * b[i];
+    }
+    double hpi[64], hinv[64];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) hpi[i * 8 + j] = H[(size_t)(ndim + i) * odim + ndim + j];
+    for (int i = 0; i < 64; i++) hpi[i] = 0.5f * (hpi[i] + hpi[i]);                          /* :533 (sic: hpi + hpi) */
+    orc_inverse(hpi, 8, hinv);
+    for (int i = 0; i < 64; i++) hinv[i] = 0.5f * (hinv[i] + hinv[i]);
+    /* bli = bottomLeft^T * hpi (ndim x 8); top-left -= bli * bottomLeft; b.head -= bli * b.tail (:538-541) */
+    double* bli = (double*)zalloc(sizeof(double) * ndim * 8);
+    for (int i = 0; i < ndim; i++)
+        for (int j = 0; j < 8; j++) {
+            double s = 0;
+            for (int q = 0; q < 8; q++) s += H[(size_t)(ndim + q) * odim + i] * hinv[q * 8 + j];
+            bli[i * 8 + j] = s;
+        }
+    for (int i = 0; i < ndim; i++) {
+        for (int j = 0; j < ndim; j++) {
+            double s = 0;
+            for (int q = 0; q < 8; q++) s += bli[i * 8 + q] * H[(size_t)(ndim + q) * odim + j];
+            H[(size_t)i * odim + j] -= s;
+        }
+        double s = 0;
+        for (int q = 0; q < 8; q++) s += bli[i * 8 + q] * b[ndim + q];
+        b[i] -= s;
+    }
+    for (int i = 0; i < odim; i++) {                                   /* unscale, :544-545 */
+        for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = SVec[i] * H[(size_t)i * odim + j] * SVec[j];
+        b[i] = SVec[i] * b[i];
+    }
+    for (int i = 0; i < ndim; i++) {                                   /* :548-549 */
+        for (int j = 0; j < ndim; j++) HM[(size_t)i * ndim + j] = 0.5 * (H[(size_t)i * odim + j] + H[(size_t)j * odim + i]);
+        bM[i] = b[i];
+    }
+    free(H); free(b); free(perm); free(SVec); free(bli);
+}
+
+/* calcMEnergy, BA.cpp:2095-2117 (the forceAccept early-out is the caller's) */
+double orc_ba_calc_m_energy(const double* HM, const double* bM, int n, const double* delta) {
+    double e = 0;
+    for (int i = 0; i < n; i++) {
+        double s = 2 * bM[i];
+        for (int j = 0; j < n; j++) s += HM[(size_t)i * n + j] * delta[j];
+        e += delta[i] * s;
+    }
+    return fabs(e);
+}
+
+/* calcLEnergy, BA.cpp:2119-2208: prior terms + sum over the LINEARIZED good residuals of (2 res_toZero + J delta) . J delta
+ * (fp32, accumulated here in double: Accumulator11 is a tiered float sum) + per-point prior term */
+double orc_ba_calc_l_energy(const orc_ba_window* w, const cmlhip_ba_accum_in* in, int* num_out) {
+    double F = 0;
+    for (int i = 0; i < 8 * w->N; i++) F += in->delta_prior[i] * in->prior[i] * in->delta_prior[i];
+    for (int i = 0; i < 4; i++) F += in->cdelta[i] * 5e9 * in->cdelta[i];
+    double E = 0;
+    int num = 0;
+    for (int p = 0; p < w->P; p++) {
+        const cmlhip_ba_point* pt = &w->points[p];
+        const float dd = (float)(pt->idepth - (double)pt->idepth_zero);
+        for (int q = w->by_point_off[p]; q < w->by_point_off[p + 1]; q++) {
+            const int r = w->by_point[q];
+            if (!w->r_lin[r] || !w->r_good[r]) continue;
+            num++;
+            const float* J = w->efsJ + 74 * (size_t)r;
+            const float* dp = in->adHTdeltaF + 8 * w->pair_of[r];
+            float jx = 0, jy = 0, cx = 0, cy = 0;
+            for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
+            for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)in->cdelta[i]; cy += J[O_C1 + i] * (float)in->cdelta[i]; }
+            const float Jpx = jx + cx + J[O_DD] * dd, Jpy = jy + cy + J[O_DD + 1] * dd;
+            for (int i = 0; i < 8; i++) {
+                float Jdelta = J[O_JI0 + i] * Jpx;
+                Jdelta = Jdelta + J[O_JI1 + i] * Jpy;
+                Jdelta = Jdelta + J[O_JAB0 + i] * dp[6];
+                Jdelta = Jdelta + J[O_JAB1 + i] * dp[7];
+                float r0 = w->res_toZeroF[8 * r + i];
+                r0 = r0 + r0;
+                r0 = r0 + Jdelta;
+                E += (double)(Jdelta * r0);
+            }
+        }
+        E += (double)(dd * dd * pt->prior);
+    }
+    if (num_out) *num_out = num;
+    return E + F;
 }

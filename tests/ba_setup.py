@@ -160,6 +160,28 @@ class OracleBA:
         rc = O.lib().orc_ba_backsub(self.w, C.byref(self._ain), O.ptr(x, C.c_double))
         return self.view("step", self.I.P, np.float64).copy(), rc
 
+    # ---- marginalisation
+    def relinearize_points(self, pts):
+        self._ain = accum_in(self.I)
+        pts = np.ascontiguousarray(pts, np.int32)
+        return O.lib().orc_ba_relinearize_points(self.w, len(pts), O.ptr(pts, C.c_int), C.byref(self._ain))
+
+    def marginalize_points(self, pts):
+        n = 8 * self.I.N + 4
+        self._ain = accum_in(self.I)
+        pts = np.ascontiguousarray(pts, np.int32)
+        M = np.zeros((n, n)); Mb = np.zeros(n); Msc = np.zeros((n, n)); Mbsc = np.zeros(n)
+        d = C.c_double
+        O.lib().orc_ba_marginalize_points(self.w, len(pts), O.ptr(pts, C.c_int), C.byref(self._ain), O.ptr(M, d), O.ptr(Mb, d),
+                                          O.ptr(Msc, d), O.ptr(Mbsc, d))
+        return M, Mb, Msc, Mbsc
+
+    def l_energy(self):
+        self._ain = accum_in(self.I)
+        num = C.c_int()
+        O.lib().orc_ba_calc_l_energy.restype = C.c_double
+        return O.lib().orc_ba_calc_l_energy(self.w, C.byref(self._ain), C.byref(num)), num.value
+
     def rJ(self, which=0):
         return self.view("efsJ" if which else "rJ", self.I.R * 74, np.float32).reshape(-1, 74).copy()
 

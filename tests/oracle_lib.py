@@ -91,6 +91,8 @@ def lib():
         L = C.CDLL(_ensure_built())
         L.orc_ba_create.restype = C.POINTER(OrcBAWindow)
         L.orc_ba_linearize_one.restype = C.c_double
+        L.orc_ba_calc_l_energy.restype = C.c_double
+        L.orc_ba_calc_m_energy.restype = C.c_double
         _lib = L
     return _lib
 
@@ -206,3 +208,17 @@ def interpolate3(aos3, x, y):
     out = np.zeros(3, np.float32)
     lib().orc_interpolate3(ptr(aos3, C.c_float), aos3.shape[1], C.c_float(x), C.c_float(y), ptr(out, C.c_float))
     return out
+
+
+def marginalize_frame(HM, bM, N, frame, prior, delta_prior):
+    """orc_ba_marginalize_frame (BA.cpp:483-558): returns the (8N-4)^2 prior and its rhs."""
+    n = 8 * N + 4
+    H = f64(np.array(HM, np.float64).reshape(n, n).copy()); b = f64(np.array(bM, np.float64).copy())
+    lib().orc_ba_marginalize_frame(ptr(H, C.c_double), ptr(b, C.c_double), N, frame, ptr(f64(prior), C.c_double), ptr(f64(delta_prior), C.c_double))
+    nd = n - 8
+    return H.ravel()[:nd * nd].reshape(nd, nd).copy(), b[:nd].copy()
+
+
+def m_energy(HM, bM, delta):
+    n = len(delta)
+    return lib().orc_ba_calc_m_energy(ptr(f64(HM), C.c_double), ptr(f64(bM), C.c_double), n, ptr(f64(delta), C.c_double))

@@ -200,3 +200,81 @@ def test_linearize_edge_cases():
     assert w.r_new_state[5] == 1
     # empty window
     ob.linearize()
+
+
+def test_marginalisation_restatement():
+    """SURVEY §8 a15, pinned against the textbook forms: marginalizeFrame = Schur complement of the frame's 8 variables
+    (with its prior folded in first); fixLinearization + MARGINALIZED-mode accumulation = normal equations of the selected
+    points' residuals with res_toZero as the residual vector, Schur-reduced over their inverse depths."""
+    # ---- marginalizeFrame
+    rng = np.random.default_rng(5)
+    N = 5; n = 8 * N + 4
+    Q = rng.standard_normal((n, n + 6)) * rng.uniform(1, 1e3, (n, 1))
+    HM = Q @ Q.T; bM = rng.standard_normal(n) * 1e3
+    prior = rng.uniform(1e3, 1e6, 8); dprior = rng.standard_normal(8) * 1e-3
+    for frame in (1, N - 1, 0):
+        Hn, bn = O.marginalize_frame(HM, bM, N, frame, prior, dprior)
+        io = 4 + 8 * frame
+        keep = [i for i in range(n) if not (io <= i < io + 8)]
+        drop = list(range(io, io + 8))
+        A = HM[np.ix_(keep, keep)]; B = HM[np.ix_(keep, drop)]; D = HM[np.ix_(drop, drop)] + np.diag(prior)
+        bd = bM[drop] + prior * dprior
+        Di = np.linalg.inv(D)
+        He = A - B @ Di @ B.T; be = bM[keep] - B @ Di @ bd
+        assert np.abs(Hn - 0.5 * (He + He.T)).max() <= 1e-9 * np.abs(He).max()
+        assert np.abs(bn - be).max() <= 1e-9 * np.abs(be).max()
+        assert np.array_equal(Hn, Hn.T)
+    d = rng.standard_normal(n)
+    assert abs(O.m_energy(HM, bM, d) - abs(d @ (2 * bM + HM @ d))) <= 1e-12 * abs(d @ HM @ d)
+    # ---- points
+    I = S.make_inputs("small", state_noise=0.3)            # non-zero state - state_zero, so that J*delta is exercised
+    ob = S.OracleBA(I)
+    ob.linearize(); ob.apply(1)
+    sel = np.arange(0, I.P, 3, dtype=np.int32)
+    ngood = ob.relinearize_points(sel)
+    st = ob.states()
+    lin = ob.view("r_lin", I.R, np.uint8).copy()
+    in_sel = np.isin(I.residuals["point"], sel)
+    assert ngood == int(st["good"][in_sel].sum()) and ngood > 30
+    assert np.array_equal(lin.astype(bool), in_sel & (st["good"] == 1))
+    # res_toZero = resF - J * delta (BA.cpp:2224-2233)
+    J = ob.rJ(1); rtz = ob.view("res_toZeroF", 8 * I.R, np.float32).reshape(-1, 8)
+    for r in np.flatnonzero(lin)[:40]:
+        p = I.residuals["point"][r]; t = I.residuals["target"][r]; h = I.points["host"][p]
+        dp = I.adHTd.reshape(-1, 8)[h + t * I.N].astype(np.float64)
+        dd = np.float32(I.points["idepth"][p] - np.float64(I.points["idepth_zero"][p]))
+        j = J[r].astype(np.float64)
+        jpx = j[8:14] @ dp[:6] + j[20:24] @ I.cdelta + j[28] * dd
+        jpy = j[14:20] @ dp[:6] + j[24:28] @ I.cdelta + j[29] * dd
+        expect = j[0:8] - j[30:38] * jpx - j[38:46] * jpy - j[46:54] * dp[6] - j[54:62] * dp[7]
+        assert np.abs(rtz[r] - expect).max() <= 2e-5 * max(1.0, np.abs(expect).max())
+    M, Mb, Msc, Mbsc = ob.marginalize_points(sel)
+    # dense check: rows of the selected points' good residuals, residual vector = res_toZero
+    N_, P = I.N, I.P
+    nn = 8 * N_
+    AH = I.adH.reshape(N_ * N_, 8, 8); AT = I.adT.reshape(N_ * N_, 8, 8)
+    rows, rhs = [], []
+    for r in np.flatnonzero(in_sel & (st["good"] == 1)):
+        p = I.residuals["point"][r]; t = I.residuals["target"][r]; h = I.points["host"][p]
+        j = J[r]
+        for k in range(8):
+            jp = np.zeros(8)
+            jp[:6] = j[30 + k] * j[8:14] + j[38 + k] * j[14:20]
+            jp[6] = j[46 + k]; jp[7] = j[54 + k]
+            row = np.zeros(nn + P)
+            row[8 * h:8 * h + 8] += AH[h + t * N_] @ jp
+            row[8 * t:8 * t + 8] += AT[h + t * N_] @ jp
+            row[nn + p] = j[30 + k] * j[28] + j[38 + k] * j[29]
+            rows.append(row); rhs.append(rtz[r][k])
+    Jm = np.array(rows); rv = np.array(rhs, np.float64)
+    H = Jm.T @ Jm; b = Jm.T @ rv
+    assert np.abs(M[4:, 4:] - H[:nn, :nn]).max() <= 2e-6 * np.abs(H[:nn, :nn]).max()
+    assert np.abs(Mb[4:] - b[:nn]).max() <= 5e-6 * np.abs(b[:nn]).max()
+    Hdd = np.diag(H[nn:, nn:]).copy()
+    Hdi = np.where(Hdd > 0, 1 / np.maximum(Hdd, 1e-10), 0)
+    Hpd = H[:nn, nn:]
+    assert np.abs(Msc[4:, 4:] - (Hpd * Hdi) @ Hpd.T).max() <= 5e-6 * np.abs(Msc).max()
+    assert np.abs(Mbsc[4:] - (Hpd * Hdi) @ b[nn:]).max() <= 2e-5 * np.abs(Mbsc).max()
+    # linearized energy: sum over the LINEARIZED good residuals of (2 res_toZero + J delta) . J delta + priors (BA.cpp:2119-2208)
+    e, num = ob.l_energy()
+    assert num == int(lin.sum())
