@@ -284,6 +284,22 @@ int cmlhip_reproj_accumulate(cmlhip_ctx* ctx, int N, const double* poses /* N*12
 /* indirectX = ldlt(M6 with diag*(1+lambda)).solve(-b6) (BA.cpp:2695-2700) on the device */
 int cmlhip_reproj_solve(cmlhip_ctx* ctx, int N, double lambda, double* x6 /* 6N */);
 
+/* ---------------------------------------------------------------- marginalisation (once per keyframe), SURVEY §8 a15
+ * tryMarginalize's residual loop (BA.cpp:2291-2304) for the points that are about to be marginalised: every residual of the
+ * listed points is reset (resetOOB), re-linearised at the current state, committed (applyRes(true)) and, when good,
+ * fixed (fixLinearization, BA.cpp:2210-2238: res_toZero = resF - J*delta, isLinearized = true).  `in` supplies adHTdeltaF /
+ * cdelta; pairs must be current (cmlhip_ba_set_pairs). */
+int cmlhip_ba_relinearize_points(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good);
+/* marginalizePointsF (BA.cpp:2466-2500): MARGINALIZED-mode accumulation of the listed points only.
+ * M, Mb = stitchDoubleTop(usePrior = false); Msc, Mbsc = stitchDoubleSC with shiftPriorToZero = false.  The caller adds
+ * 0.25 * (M - Msc) and 0.25 * (Mb - Mbsc) to the prior (BA.cpp:2502-2507).  (8N+4)^2 / (8N+4) doubles each. */
+int cmlhip_ba_marginalize_points(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, int n, const int* point_idx,
+                                 double* M, double* Mb, double* Msc, double* Mbsc);
+/* calcLEnergy (BA.cpp:2119-2208) without its forceAccept early-out: prior terms + the sum over the LINEARIZED good residuals */
+int cmlhip_ba_lin_energy(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, double* energy, int* num_linearized);
+/* res_toZeroF (R x 8) and isLinearized (R) as the device holds them */
+int cmlhip_ba_get_res_to_zero(cmlhip_ctx* ctx, float* res_to_zero, unsigned char* is_linearized);
+
 /* ---------------------------------------------------------------- device-resident Gauss-Newton iterations
  * The loop body of BA::run (BA.cpp:804-880) under forceAccept / fixLambda without a host round trip per iteration:
  *   accumulate -> Schur + system -> solve (+ orthogonalize) -> back-substitution + doStepFromBackup of the points AND of the

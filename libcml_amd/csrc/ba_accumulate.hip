@@ -75,7 +75,8 @@ typedef float float4_ __attribute__((ext_vector_type(4)));
 // (10 per record), PAIR_TRIP residuals per trip; wave w takes residuals w, w+16, ... of the trip and every lane reads its
 // operand elements from the staged record (distinct banks or broadcast).  The 16 wave tiles are added in wave order.
 // LINEARIZED mode (rare) computes res_toZero + J*delta per residual (BA.cpp:1699-1729) and stages the same 38 floats.
-__device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const bool LIN) {
+__device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const int mode) {
+    const bool LIN = mode != CMLHIP_MODE_ACTIVE;          // LINEARIZED and MARGINALIZED walk the plain pair list
     __shared__ float s_rec[PAIR_TRIP][PAIR_REC];
     __shared__ float s_tile[16][256];
     __shared__ int s_cnt;
@@ -130,7 +131,9 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
             }
         } else if (tid < ntrip) {
             const int r = A.by_pair[trip + tid];
-            const bool ok = A.r_lin[r] && A.r_good[r];
+            // LINEARIZED: the window's linearized good residuals (BA.cpp:1666-1669).  MARGINALIZED: every good residual of
+            // the points being marginalised (:1670-1674), residual vector = res_toZero as it is (:1689-1692)
+            const bool ok = mode == CMLHIP_MODE_MARGINALIZED ? (A.r_good[r] && A.pt_mask[A.r_point[r]]) : (A.r_lin[r] && A.r_good[r]);
             if (!ok) { for (int j = 0; j < 40; j++) s_rec[tid][j] = 0.f; }
             if (ok) {
                 atomicAdd(&s_cnt, 1);
@@ -149,8 +152,10 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
                 double s0 = 0, s1 = 0, s2 = 0, s3 = 0; float srr = 0;
                 for (int j = 0; j < 8; j++) {
                     float rtz = A.r_rtz[8 * (size_t)r + j];
-                    rtz = rtz + J[O_JI0 + j] * Jpx; rtz = rtz + J[O_JI1 + j] * Jpy;
-                    rtz = rtz + J[O_JAB0 + j] * dp[6]; rtz = rtz + J[O_JAB1 + j] * dp[7];
+                    if (mode == CMLHIP_MODE_LINEARIZED) {
+                        rtz = rtz + J[O_JI0 + j] * Jpx; rtz = rtz + J[O_JI1 + j] * Jpy;
+                        rtz = rtz + J[O_JAB0 + j] * dp[6]; rtz = rtz + J[O_JAB1 + j] * dp[7];
+                    }
                     const double ra = (double)rtz;
                     s0 += ra * (double)J[O_JI0 + j]; s1 += ra * (double)J[O_JI1 + j];
                     s2 += ra * (double)J[O_JAB0 + j]; s3 += ra * (double)J[O_JAB1 + j];
@@ -340,11 +345,11 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
     for (int c = l; c < X.ldg; c += 64) row[c] = srow[c];
 }
 
-// mode: 0 = ACTIVE pair blocks + point rows, 1 = LINEARIZED pair blocks only (rare path)
+// mode: ACTIVE = pair blocks + point rows; LINEARIZED / MARGINALIZED = pair blocks only (rare paths, own point kernels)
 __global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
     const int NN = A.N * A.N;
     DBG_BLK(A.dbg, 1, 0);
-    if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode == 1);
+    if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode);
     else point_rows_block(A, X, blockIdx.x - NN);      // 16 points per 1024-thread block
     DBG_BLK_END(A.dbg, 1);
 }
@@ -375,6 +380,58 @@ __global__ void k_ba_point_bdL(BAArgs A, const float* __restrict__ adHTd, const 
         bd = (float)((double)bd + (s0 * (double)J[O_DD] + s1 * (double)J[O_DD + 1]));
     }
     A.pt_acc[(size_t)p * PT_ACC_STRIDE + 7] = bd;
+}
+
+// marginalizePointsF, point side (BA.cpp:2490-2493): for the points being marginalised, addToHessianTop(MARGINALIZED)'s
+// Hdd/bd/Hcd (stored as the L sums, the A sums zeroed, :1763-1775) with res_toZero as the residual vector, addToHessianSC's
+// HdiF and bdSum WITHOUT the prior shift (shiftPriorToZero = false), and the coupling row in frame coordinates.  Every
+// other point gets weight 0.  Once per keyframe: one thread per point.
+__global__ void k_ba_point_rows_marg(BAArgs A, AccArgs X) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.P) return;
+    double* row = X.G + (size_t)p * X.ldg;
+    for (int c = 0; c < X.ldg; c++) row[c] = 0.0;
+    float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
+    for (int k = 0; k < 14; k++) pa[k] = 0.f;
+    X.Wt[p] = 0.0;
+    if (!A.pt_mask[p]) return;
+    const int host = A.pt_host[p];
+    float Hdd = 0, bd = 0, Hcd[4] = {0, 0, 0, 0};
+    int ngood = 0;
+    for (int kk = A.by_point_off[p]; kk < A.by_point_off[p + 1]; kk++) {
+        const int r = A.by_point[kk];
+        if (!A.r_good[r]) continue;
+        ngood++;
+        const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
+        double s0 = 0, s1 = 0;
+        for (int j = 0; j < 8; j++) {
+            const double ra = (double)A.r_rtz[8 * (size_t)r + j];
+            s0 += ra * (double)J[O_JI0 + j]; s1 += ra * (double)J[O_JI1 + j];
+        }
+        const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
+        const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
+        bd = (float)((double)bd + (s0 * (double)J[O_DD] + s1 * (double)J[O_DD + 1]));
+        Hdd += g0 * J[O_DD] + g1 * J[O_DD + 1];
+        for (int j = 0; j < 4; j++) Hcd[j] += J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
+        const int t = A.r_target[r], q = host + t * A.N;
+        const float* v = A.r_jpjdf + 8 * (size_t)r;
+        const double* AH = X.adH + 64 * (size_t)q; const double* AT = X.adT + 64 * (size_t)q;
+        for (int a = 0; a < 8; a++) {
+            double sh = 0, st = 0;
+            for (int j = 0; j < 8; j++) { sh += AH[a * 8 + j] * (double)v[j]; st += AT[a * 8 + j] * (double)v[j]; }
+            row[4 + 8 * host + a] += sh;
+            row[4 + 8 * t + a] = st;
+        }
+    }
+    pa[6] = Hdd; pa[7] = bd; pa[8] = Hcd[0]; pa[9] = Hcd[1]; pa[10] = Hcd[2]; pa[11] = Hcd[3];
+    if (ngood == 0) return;
+    float H = Hdd + A.pt_prior[p];
+    if (H < 1e-10) H = 1e-10;
+    const float HdiF = (float)(1.0 / H);
+    pa[12] = HdiF; pa[13] = bd;
+    for (int j = 0; j < 4; j++) row[j] = (double)Hcd[j];
+    row[A.n] = (double)bd;
+    X.Wt[p] = (double)HdiF;
 }
 
 // ------------------------------------------------------------------------------------------------ K4
@@ -1016,7 +1073,7 @@ static size_t solve_lds_bytes(int m) {
     return d * sizeof(double);
 }
 
-int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only) {
+int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only, bool marg) {
     const int N = A.N, n = A.n, NN = N * N;
     const double* vs = c->vec_small.as<double>();        // cdelta[4] cprior[4] prior[8N] dprior[8N]
     AccArgs X;
@@ -1024,7 +1081,10 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     X.acc_out = c->acc_pair[0].as<float>(); X.num_out = c->acc_num[0].as<int>(); X.pair_blocks = c->pair_blocks.as<double>();
     X.ldg = ldg_of(n); X.G = c->G.as<double>(); X.Wt = X.G + (size_t)A.P * X.ldg; X.do_backup = do_backup ? 1 : 0;
     double* pbL = c->pair_blocks.as<double>() + (size_t)PB_STRIDE * NN;
-    if (!system_only) {
+    if (marg) {                                          // marginalizePointsF: MARGINALIZED-mode blocks of the selected points only
+        k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, X, CMLHIP_MODE_MARGINALIZED);
+        k_ba_point_rows_marg<<<cml_div_up(A.P, 64), 64, 0, c->stream>>>(A, X);
+    } else if (!system_only) {
         if (c->n_lin > 0) {                              // rare path: LINEARIZED residuals present
             AccArgs XL = X;
             XL.acc_out = c->acc_pair[1].as<float>(); XL.num_out = c->acc_num[1].as<int>(); XL.pair_blocks = pbL;
@@ -1034,7 +1094,7 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
         k_ba_acc<<<NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, c->stream>>>(A, X, 0);
     }
     SysArgs S;
-    S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = c->n_lin > 0 ? 1 : 0;
+    S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = (c->n_lin > 0 && !marg) ? 1 : 0;
     S.G = X.G; S.Wt = X.Wt; S.pbA = c->pair_blocks.as<double>(); S.pbL = pbL; S.dbg = A.dbg;
     S.cdelta = vs; S.cprior = vs + 4; S.prior = vs + 8; S.dprior = vs + 8 + 8 * N;
     S.HM = have_hm ? c->HM.as<double>() : nullptr; S.bM = have_hm ? c->bM.as<double>() : nullptr;

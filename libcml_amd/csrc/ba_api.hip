@@ -26,6 +26,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.r_new_state = c->r_new_state.as<int>(); A.r_energy = c->r_energy.as<float>(); A.r_new_energy = c->r_new_energy.as<float>();
     A.r_new_energy_wo = c->r_new_energy_wo.as<float>(); A.r_ret_energy = c->r_ret_energy.as<float>();
     A.r_good = c->r_good.as<unsigned char>(); A.r_lin = c->r_lin.as<unsigned char>(); A.r_sel = c->r_sel.as<unsigned char>();
+    A.r_lin_rw = c->r_lin.as<unsigned char>(); A.point_tgt_rw = c->point_tgt.as<int>(); A.pt_mask = nullptr;
     A.r_center = c->r_center.as<float>(); A.r_jpjdf = c->r_jpjdf.as<float>(); A.r_rtz = c->r_rtz.as<float>();
     A.rj0 = c->rj[0].as<float>(); A.rj1 = c->rj[1].as<float>();
     A.by_point_off = c->by_point_off.as<int>(); A.by_point = c->by_point.as<int>();
@@ -404,6 +405,101 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     c->lin_finish_pending = true;
     if (prof) { hipEventRecord(ev[3], c->stream); hipEventRecord(ev[4], c->stream); hipEventRecord(ev[5], c->stream); c->prof_n++; }
     CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- marginalisation
+static int upload_point_mask(cmlhip_ctx* c, int n, const int* idx) {
+    std::vector<unsigned char> m((size_t)std::max(c->P, 1), 0);
+    for (int i = 0; i < n; i++) {
+        if (idx[i] < 0 || idx[i] >= c->P) { c->err = "point index out of range"; return CMLHIP_ERR_INVALID; }
+        m[idx[i]] = 1;
+    }
+    int rc = cml_ensure(c, c->pt_mask, m.size());
+    if (rc) return rc;
+    return cml_h2d(c, c->pt_mask.p, m.data(), m.size());
+}
+
+int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good) {
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
+        return CMLHIP_ERR_INVALID;
+    if ((rc = upload_accum_in(c, in))) return rc;
+    if ((rc = upload_point_mask(c, n, point_idx))) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    A.pt_mask = c->pt_mask.as<unsigned char>();
+    A.lin_partial = nullptr;                                 // a subset pass: no window energy
+    A.fuse_apply = 1;                                        // applyRes(r, true), BA.cpp:2299
+    int* counter = reinterpret_cast<int*>(c->scal.as<char>() + 512);
+    CML_CHECK(c, hipMemsetAsync(counter, 0, sizeof(int), c->stream));
+    cml_launch_marg_reset(c, A);
+    cml_launch_linearize(c, A);
+    cml_launch_marg_fix(c, A, c->adHTd.as<float>(), c->vec_small.as<double>(), counter);
+    CML_CHECK(c, hipGetLastError());
+    int ng = 0;
+    if ((rc = cml_d2h(c, &ng, counter, sizeof(int)))) return rc;
+    if (ng > 0) c->n_lin = std::max(c->n_lin, 1);            // the LINEARIZED blocks of the regular accumulation are live from now on
+    if (n_good) *n_good = ng;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_marginalize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, double* M, double* Mb,
+                                 double* Msc, double* Mbsc) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
+        return CMLHIP_ERR_INVALID;
+    if ((rc = upload_accum_in(c, in))) return rc;
+    if ((rc = upload_point_mask(c, n, point_idx))) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    A.pt_mask = c->pt_mask.as<unsigned char>();
+    cml_launch_accumulate(c, A, 0.0, false, false, false, true);
+    cml_launch_schur_out(c, A);
+    CML_CHECK(c, hipGetLastError());
+    const size_t nn = 8 * (size_t)c->N + 4;
+    if (M && (rc = cml_d2h(c, M, c->HA.p, 8 * nn * nn))) return rc;
+    if (Mb && (rc = cml_d2h(c, Mb, c->bA.p, 8 * nn))) return rc;
+    if (Msc && (rc = cml_d2h(c, Msc, c->Hsc.p, 8 * nn * nn))) return rc;
+    if (Mbsc && (rc = cml_d2h(c, Mbsc, c->bsc.p, 8 * nn))) return rc;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* energy, int* num) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!in || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->adHost || !in->adTarget || !in->cprior) return CMLHIP_ERR_INVALID;
+    if ((rc = upload_accum_in(c, in))) return rc;
+    const int nb = (c->P + 255) / 256;
+    if ((rc = cml_ensure(c, c->marg_scratch, 16 * (size_t)std::max(nb, 1)))) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    double* part = c->marg_scratch.as<double>();
+    int* nums = reinterpret_cast<int*>(part + std::max(nb, 1));
+    cml_launch_lin_energy(c, A, c->adHTd.as<float>(), c->vec_small.as<double>(), part, nums);
+    CML_CHECK(c, hipGetLastError());
+    std::vector<double> hp(std::max(nb, 1)); std::vector<int> hn(std::max(nb, 1));
+    if (nb > 0) {
+        if ((rc = cml_d2h(c, hp.data(), part, 8 * (size_t)nb))) return rc;
+        if ((rc = cml_d2h(c, hn.data(), nums, 4 * (size_t)nb))) return rc;
+    }
+    double F = 0;                                            // BA.cpp:2131-2142
+    for (int i = 0; i < 8 * c->N; i++) F += in->delta_prior[i] * in->prior[i] * in->delta_prior[i];
+    for (int i = 0; i < 4; i++) F += in->cdelta[i] * 5e9 * in->cdelta[i];
+    double E = 0; int k = 0;
+    for (int i = 0; i < nb; i++) { E += hp[i]; k += hn[i]; }
+    if (energy) *energy = E + F;
+    if (num) *num = k;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_get_res_to_zero(cmlhip_ctx* c, float* rtz, unsigned char* is_lin) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (rtz && (rc = cml_d2h(c, rtz, c->r_rtz.p, 32 * (size_t)c->R))) return rc;
+    if (is_lin && (rc = cml_d2h(c, is_lin, c->r_lin.p, (size_t)c->R))) return rc;
     return CMLHIP_OK;
 }
 

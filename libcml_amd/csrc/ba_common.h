@@ -40,12 +40,14 @@ struct BAArgs {
     const int* r_point; const int* r_target; int* r_state; int* r_new_state;
     float* r_energy; float* r_new_energy; float* r_new_energy_wo; float* r_ret_energy;
     unsigned char* r_good; const unsigned char* r_lin; unsigned char* r_sel;
+    unsigned char* r_lin_rw; int* point_tgt_rw;    // writable views for the marginalisation kernels (isLinearized changes there)
     float* r_center; float* r_jpjdf; float* r_rtz; float* rj0; float* rj1;
     const int* by_point_off; const int* by_point; const int* by_pair_off; const int* by_pair;
     int* point_code; const int* point_tgt; const int* point_pos; int pt_stride;   // [P][pt_stride]: 2r+sel of the point's good residuals else -1; target | lin << 8 (-1 = empty slot); slot of r
     int* pair_code; const int* pair_pos; int pair_stride;     // [N*N][pair_stride]: 2r+sel of the ACTIVE good residuals of the pair, else -1 (written by applyRes); slot of r
     double* lin_partial;          // per-block {energy, n_in, n_oob, n_outlier} of the residual kernel (may be null)
     long long* dbg;               // optional phase timestamps (wall_clock64, 100 MHz): 16 slots per kernel, see cmlhip_debug_read
+    const unsigned char* pt_mask; // optional per-point selection (marginalisation passes); null = every point
     int fuse_apply;               // residual kernel also performs applyRes(copyJacobians=true) (valid when the step is always accepted)
 };
 
@@ -57,9 +59,12 @@ int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy);
 // K3 (pair blocks + point rows) and K4 (system tiles: H_A, H_L, H_sc and the final LM system for `lambda` / optional HM)
-int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only = false);
+int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only = false, bool marg = false);
 int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho = false);
-int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A);     // H_sc / b_sc for host readback
+int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_marg_reset(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_marg_fix(cmlhip_ctx* c, const BAArgs& A, const float* adHTd, const double* cdelta, int* counter);
+int cml_launch_lin_energy(cmlhip_ctx* c, const BAArgs& A, const float* adHTd, const double* cdelta, double* partial, int* num);     // H_sc / b_sc for host readback
 int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step);
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A);

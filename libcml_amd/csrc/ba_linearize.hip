@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const float pre_energy = A.r_energy[rc];
     const int pre_new_state = A.r_new_state[rc], pre_pos = A.pair_pos[rc], pre_ppos = A.point_pos[rc];
     const unsigned char pre_sel = A.r_sel[rc];
-    const bool live = (r < A.R) && !lin_;
+    const bool live = (r < A.R) && !lin_ && (!A.pt_mask || A.pt_mask[p_]);      // pt_mask: tryMarginalize's point subset
     const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
     const int p = live ? p_ : 0;
@@ -323,6 +323,100 @@ __global__ void k_ba_apply(BAArgs A, int copy) {
     }
     A.r_state[r] = A.r_new_state[r];
     A.r_energy[r] = A.r_new_energy[r];
+}
+
+// ------------------------------------------------------------------------------------------------ marginalisation, residual side
+// tryMarginalize's residual loop for the selected points (BA.cpp:2291-2304) = k_ba_marg_reset -> k_ba_linearize with the
+// point mask and fused applyRes(true) -> k_ba_marg_fix.
+__global__ void k_ba_marg_reset(BAArgs A) {                      // resetOOB (DSOResidual.h:81-86) + isLinearized = false
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.R || !A.pt_mask[A.r_point[r]]) return;
+    A.r_new_energy[r] = 0.f; A.r_energy[r] = 0.f;
+    A.r_new_state[r] = CMLHIP_RES_OUTLIER; A.r_state[r] = CMLHIP_RES_IN;
+    A.r_lin_rw[r] = 0;
+    A.point_tgt_rw[A.point_pos[r]] &= 255;
+}
+// fixLinearization (BA.cpp:2210-2238) of the selected points' good residuals: res_toZero = resF - [JI*Jp Ja]*delta in the
+// statement order of the reference's SSE code (fp contraction is off in this file), isLinearized = true
+__global__ void k_ba_marg_fix(BAArgs A, const float* __restrict__ adHTd, const double* __restrict__ cdelta, int* counter) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.R) return;
+    const int p = A.r_point[r];
+    if (!A.pt_mask[p] || !A.r_good[r]) return;
+    const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;      // efsJ
+    const float* dp = adHTd + 8 * (A.pt_host[p] + A.r_target[r] * A.N);
+    const float deltaF = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
+    float jx = 0, jy = 0, cx = 0, cy = 0;
+    for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
+    for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)cdelta[i]; cy += J[O_C1 + i] * (float)cdelta[i]; }
+    const float Jpx = jx + cx + J[O_DD] * deltaF, Jpy = jy + cy + J[O_DD + 1] * deltaF;
+    for (int i = 0; i < 8; i++) {
+        float rtz = J[O_RES + i];
+        rtz = rtz - J[O_JI0 + i] * Jpx;
+        rtz = rtz - J[O_JI1 + i] * Jpy;
+        rtz = rtz - J[O_JAB0 + i] * dp[6];
+        rtz = rtz - J[O_JAB1 + i] * dp[7];
+        A.r_rtz[8 * (size_t)r + i] = rtz;
+    }
+    A.r_lin_rw[r] = 1;
+    A.pair_code[A.pair_pos[r]] = -1;                             // no longer in the ACTIVE sums
+    A.point_tgt_rw[A.point_pos[r]] |= 256;
+    atomicAdd(counter, 1);
+}
+// calcLEnergy's residual sum (BA.cpp:2149-2203): per point, over its LINEARIZED good residuals, (2 res_toZero + J delta).J delta,
+// plus deltaF^2 priorF; one thread per point, fixed-order block partials (fp64; the reference's Accumulator11 is a tiered fp32 sum)
+__global__ __launch_bounds__(256) void k_ba_lin_energy(BAArgs A, const float* __restrict__ adHTd, const double* __restrict__ cdelta,
+                                                      double* __restrict__ partial, int* __restrict__ num) {
+    __shared__ double s_e[256];
+    __shared__ int s_n[256];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double E = 0;
+    int n = 0;
+    if (p < A.P) {
+        const float dd = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
+        for (int kk = A.by_point_off[p]; kk < A.by_point_off[p + 1]; kk++) {
+            const int r = A.by_point[kk];
+            if (!A.r_lin[r] || !A.r_good[r]) continue;
+            n++;
+            const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
+            const float* dp = adHTd + 8 * (A.pt_host[p] + A.r_target[r] * A.N);
+            float jx = 0, jy = 0, cx = 0, cy = 0;
+            for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
+            for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)cdelta[i]; cy += J[O_C1 + i] * (float)cdelta[i]; }
+            const float Jpx = jx + cx + J[O_DD] * dd, Jpy = jy + cy + J[O_DD + 1] * dd;
+            for (int i = 0; i < 8; i++) {
+                float Jdelta = J[O_JI0 + i] * Jpx;
+                Jdelta = Jdelta + J[O_JI1 + i] * Jpy;
+                Jdelta = Jdelta + J[O_JAB0 + i] * dp[6];
+                Jdelta = Jdelta + J[O_JAB1 + i] * dp[7];
+                float r0 = A.r_rtz[8 * (size_t)r + i];
+                r0 = r0 + r0;
+                r0 = r0 + Jdelta;
+                E += (double)(Jdelta * r0);
+            }
+        }
+        E += (double)(dd * dd * A.pt_prior[p]);
+    }
+    s_e[threadIdx.x] = E; s_n[threadIdx.x] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double e = 0; int c = 0;
+        for (int i = 0; i < 256; i++) { e += s_e[i]; c += s_n[i]; }
+        partial[blockIdx.x] = e; num[blockIdx.x] = c;
+    }
+}
+
+int cml_launch_marg_reset(cmlhip_ctx* c, const BAArgs& A) {
+    if (A.R > 0) k_ba_marg_reset<<<cml_div_up(A.R, 256), 256, 0, c->stream>>>(A);
+    return CMLHIP_OK;
+}
+int cml_launch_marg_fix(cmlhip_ctx* c, const BAArgs& A, const float* adHTd, const double* cdelta, int* counter) {
+    if (A.R > 0) k_ba_marg_fix<<<cml_div_up(A.R, 256), 256, 0, c->stream>>>(A, adHTd, cdelta, counter);
+    return CMLHIP_OK;
+}
+int cml_launch_lin_energy(cmlhip_ctx* c, const BAArgs& A, const float* adHTd, const double* cdelta, double* partial, int* num) {
+    if (A.P > 0) k_ba_lin_energy<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, adHTd, cdelta, partial, num);
+    return CMLHIP_OK;
 }
 
 int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A) {

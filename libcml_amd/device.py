@@ -46,6 +46,10 @@ PROTOTYPES = {
     "cmlhip_profile_enable": (C.c_int, [_ctx, _i]),
     "cmlhip_debug_timestamps": (C.c_int, [_ctx, _i, _P(C.c_longlong)]),
     "cmlhip_profile_stride": (C.c_int, [_ctx, _i]),
+    "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
+    "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    "cmlhip_ba_lin_energy": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(C.c_double), _P(C.c_int)]),
+    "cmlhip_ba_get_res_to_zero": (C.c_int, [_ctx, _P(C.c_float), _P(C.c_ubyte)]),
     "cmlhip_ba_set_resident_state": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(abi.BAFrameState), _P(C.c_double), _P(C.c_double)]),
     "cmlhip_ba_get_resident_state": (C.c_int, [_ctx, _P(abi.BAFrameState), _P(C.c_double), _P(abi.BALinResult)]),
     "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_f), _P(_i)]),
@@ -217,6 +221,41 @@ class Ctx:
         HA = np.zeros((n, n)); bA = np.zeros(n); HL = np.zeros((n, n)); bL = np.zeros(n); Hsc = np.zeros((n, n)); bsc = np.zeros(n)
         self.ck(self.L.cmlhip_ba_accumulate(self.h, C.byref(ain), _p(HA, _d), _p(bA, _d), _p(HL, _d), _p(bL, _d), _p(Hsc, _d), _p(bsc, _d)))
         return HA, bA, HL, bL, Hsc, bsc
+
+    def _accum_in(self, adH, adT, adHTd, cdelta, prior, dprior, cprior):
+        self._keep = [np.ascontiguousarray(adH, np.float64), np.ascontiguousarray(adT, np.float64),
+                      np.ascontiguousarray(adHTd, np.float32), np.ascontiguousarray(cdelta, np.float64),
+                      np.ascontiguousarray(prior, np.float64), np.ascontiguousarray(dprior, np.float64),
+                      np.ascontiguousarray(cprior, np.float64)]
+        k = self._keep
+        return abi.BAAccumIn(_p(k[0], _d), _p(k[1], _d), _p(k[2], _f), _p(k[3], _d), _p(k[4], _d), _p(k[5], _d), _p(k[6], _d))
+
+    # ---- marginalisation
+    def ba_relinearize_points(self, pts, *accum_in):
+        ain = self._accum_in(*accum_in)
+        pts = np.ascontiguousarray(pts, np.int32)
+        ng = _i()
+        self.ck(self.L.cmlhip_ba_relinearize_points(self.h, C.byref(ain), len(pts), _p(pts, C.c_int), C.byref(ng)))
+        return ng.value
+
+    def ba_marginalize_points(self, pts, *accum_in):
+        ain = self._accum_in(*accum_in)
+        pts = np.ascontiguousarray(pts, np.int32)
+        n = 8 * self.N + 4
+        M = np.zeros((n, n)); Mb = np.zeros(n); Msc = np.zeros((n, n)); Mbsc = np.zeros(n)
+        self.ck(self.L.cmlhip_ba_marginalize_points(self.h, C.byref(ain), len(pts), _p(pts, C.c_int), _p(M, _d), _p(Mb, _d), _p(Msc, _d), _p(Mbsc, _d)))
+        return M, Mb, Msc, Mbsc
+
+    def ba_lin_energy(self, *accum_in):
+        ain = self._accum_in(*accum_in)
+        e = _d(); k = _i()
+        self.ck(self.L.cmlhip_ba_lin_energy(self.h, C.byref(ain), C.byref(e), C.byref(k)))
+        return e.value, k.value
+
+    def ba_res_to_zero(self):
+        rtz = np.zeros((self.R, 8), np.float32); lin = np.zeros(self.R, np.uint8)
+        self.ck(self.L.cmlhip_ba_get_res_to_zero(self.h, _p(rtz, _f), _p(lin, C.c_ubyte)))
+        return rtz, lin
 
     def ba_solve(self, lam, HM=None, bM=None, optcal=0):
         n = 8 * self.N + 4
