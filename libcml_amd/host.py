@@ -34,6 +34,15 @@ def lib():
         L.cmlhost_ba_begin_resident.argtypes = [_vp, _i]
         L.cmlhost_ba_iterate_resident.argtypes = [_vp, _i, _d]
         L.cmlhost_ba_end_resident.argtypes = [_vp, _P(_d)]
+        L.cmlhost_ba_flag_frame.argtypes = [_vp, _i, _i]
+        L.cmlhost_ba_flag_frames_for_marginalization.argtypes = [_vp, _i]
+        L.cmlhost_ba_try_marginalize.argtypes = [_vp]
+        L.cmlhost_ba_marginalize_points.argtypes = [_vp]
+        L.cmlhost_ba_marginalize_frames.argtypes = [_vp, _P(_i), _i]
+        L.cmlhost_ba_get_prior.argtypes = [_vp, _P(_d), _P(_d)]
+        L.cmlhost_ba_get_point_flags.argtypes = [_vp, _P(_u8), _P(_u8), _P(_f)]
+        L.cmlhost_ba_calc_m_energy.restype = _d; L.cmlhost_ba_calc_m_energy.argtypes = [_vp]
+        L.cmlhost_ba_calc_l_energy.restype = _d; L.cmlhost_ba_calc_l_energy.argtypes = [_vp]
         L.cmlhost_ba_last_error.restype = C.c_char_p; L.cmlhost_ba_last_error.argtypes = [_vp]
         L.cmlhost_ba_counts.argtypes = [_vp] + [_P(_i)] * 5
         L.cmlhost_ba_get_frame.argtypes = [_vp, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d)]
@@ -114,6 +123,42 @@ class HostBA:
         e = _d()
         ok = bool(self.L.cmlhost_ba_end_resident(self.h, C.byref(e)))
         return ok, e.value
+
+    # ---- marginalisation (reference BA.h:34-46)
+    def flag_frame(self, f, flag=True):
+        self.L.cmlhost_ba_flag_frame(self.h, int(f), int(flag))
+
+    def flag_frames_for_marginalization(self, immature=0):
+        self.L.cmlhost_ba_flag_frames_for_marginalization(self.h, int(immature))
+
+    def try_marginalize(self):
+        return bool(self.L.cmlhost_ba_try_marginalize(self.h))
+
+    def marginalize_points(self):
+        return bool(self.L.cmlhost_ba_marginalize_points(self.h))
+
+    def marginalize_frames(self):
+        out = np.zeros(64, np.int32)
+        n = self.L.cmlhost_ba_marginalize_frames(self.h, _p(out, _i), 64)
+        return out[:n].copy()
+
+    def prior(self):
+        n = self.L.cmlhost_ba_get_prior(self.h, None, None)
+        H = np.zeros((n, n)); b = np.zeros(n)
+        self.L.cmlhost_ba_get_prior(self.h, _p(H, _d), _p(b, _d))
+        return H, b
+
+    def point_flags(self):
+        n = self.counts()["points"]
+        tm = np.zeros(n, np.uint8); mg = np.zeros(n, np.uint8); ih = np.zeros(n, np.float32)
+        self.L.cmlhost_ba_get_point_flags(self.h, _p(tm, _u8), _p(mg, _u8), _p(ih, _f))
+        return tm, mg, ih
+
+    def m_energy(self):
+        return self.L.cmlhost_ba_calc_m_energy(self.h)
+
+    def l_energy(self):
+        return self.L.cmlhost_ba_calc_l_energy(self.h)
 
     def last_error(self):
         return (self.L.cmlhost_ba_last_error(self.h) or b"").decode()

@@ -131,6 +131,8 @@ int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, c
         r.state_state = inside ? DSORES_IN : DSORES_OOB;
         r.state_NewState = DSORES_OUTLIER;
         mResiduals.push_back(r);
+        mPoints[p].lastResidual[0] = (int)mResiduals.size() - 1;            // target is getFrames().back(), BA.cpp:374-375
+        mPoints[p].lastResidualState[0] = r.state_state;
     }
     return f.id;
 }
@@ -160,6 +162,9 @@ int DSOBundleAdjustment::addPoint(float x, float y, double idepth, int host, con
         const bool inside = Ku >= 0 && Kv >= 0 && Ku < mPrm.w && Kv < mPrm.h;
         r.state_state = inside ? DSORES_IN : DSORES_OOB;
         mResiduals.push_back(r);
+        const int nf = (int)mFrames.size();
+        if (t == nf - 1) { mPoints[p].lastResidual[0] = (int)mResiduals.size() - 1; mPoints[p].lastResidualState[0] = r.state_state; }        // BA.cpp:374-378
+        else if (nf >= 2 && t == nf - 2) { mPoints[p].lastResidual[1] = (int)mResiduals.size() - 1; mPoints[p].lastResidualState[1] = r.state_state; }
     }
     return p;
 }
@@ -271,6 +276,28 @@ static void jacobiEig(double* A, int m, double* V) {
                 for (int k = 0; k < m; k++) { const double a = A[p * m + k], b = A[q * m + k]; A[p * m + k] = c * a - s * b; A[q * m + k] = s * a + c * b; }
                 for (int k = 0; k < m; k++) { const double a = V[k * m + p], b = V[k * m + q]; V[k * m + p] = c * a - s * b; V[k * m + q] = s * a + c * b; }
             }
+    }
+}
+
+// inverse of a fixed 8x8 the way Eigen computes Matrix<8,8>::inverse(): partial-pivot LU, then solve against the identity
+static void inverse8(const double* A, double* Ainv) {
+    double LU[64];
+    int piv[8];
+    std::memcpy(LU, A, sizeof LU);
+    for (int i = 0; i < 8; i++) piv[i] = i;
+    for (int k = 0; k < 8; k++) {
+        int best = k; double bv = std::fabs(LU[k * 8 + k]);
+        for (int i = k + 1; i < 8; i++) if (std::fabs(LU[i * 8 + k]) > bv) { bv = std::fabs(LU[i * 8 + k]); best = i; }
+        if (best != k) { for (int j = 0; j < 8; j++) std::swap(LU[k * 8 + j], LU[best * 8 + j]); std::swap(piv[k], piv[best]); }
+        for (int i = k + 1; i < 8; i++) {
+            LU[i * 8 + k] /= LU[k * 8 + k];
+            for (int j = k + 1; j < 8; j++) LU[i * 8 + j] -= LU[i * 8 + k] * LU[k * 8 + j];
+        }
+    }
+    for (int c = 0; c < 8; c++) {
+        double y[8];
+        for (int i = 0; i < 8; i++) { double s = (piv[i] == c) ? 1.0 : 0.0; for (int j = 0; j < i; j++) s -= LU[i * 8 + j] * y[j]; y[i] = s; }
+        for (int i = 7; i >= 0; i--) { double s = y[i]; for (int j = i + 1; j < 8; j++) s -= LU[i * 8 + j] * Ainv[j * 8 + c]; Ainv[i * 8 + c] = s / LU[i * 8 + i]; }
     }
 }
 
@@ -393,9 +420,15 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3]) 
             DSOResidual& Rr = mResiduals[mActive[k]];
             Rr.state_state = st[k]; Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k];
             Rr.state_NewEnergyWithOutlier = nw[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
+            DSOPoint& Pp = mPoints[Rr.point];
+            for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidualState[q] = Rr.state_state;   // setResidualState, :1618-1622
             if (Rr.isLinearized) continue;
-            if (Rr.isActiveAndIsGoodNEW) mPoints[Rr.point].numGoodResiduals++;      // :1592
-            else Rr.alive = false;                                                  // toRemove, :1595-1598,1638
+            if (Rr.isActiveAndIsGoodNEW) Pp.numGoodResiduals++;                     // :1592
+            else {                                                                  // toRemove, :1595-1598,1624-1638
+                Rr.alive = false;
+                mFrames[Rr.target].numResidualsOut++;                               // removeResiduals, DSOContext.h:210
+                for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidual[q] = -1;
+            }
         }
         for (const auto& Rr : mResiduals) if (Rr.alive) nres[Rr.point]++;
         for (int p = 0; p < (int)mPoints.size(); p++)                               // points left without residual, :1638-1640
@@ -514,10 +547,15 @@ bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // 
     std::vector<double> idp(mActivePoints.size());
     int rc = cmlhip_ba_get_idepth(mCtx, idp.data());
     if (rc) return fail("cmlhip_ba_get_idepth", rc);
+    std::vector<float> pacc(14 * mActivePoints.size() + 14);
+    rc = cmlhip_ba_get_point_acc(mCtx, pacc.data());
+    if (rc) return fail("cmlhip_ba_get_point_acc", rc);
     for (size_t k = 0; k < mActivePoints.size(); k++) {
         DSOPoint& P = mPoints[mActivePoints[k]];
         P.idepth = idp[k];
         P.idepth_zero = (float)idp[k];
+        const float hdi = pacc[14 * k + 12];                                      // setInverseDepthHessian(H), HdiF = 1/H, BA.cpp:1889-1901
+        P.idepth_hessian = hdi > 0 ? 1.0f / hdi : 0.f;
     }
     return true;
 }
@@ -555,6 +593,280 @@ bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        //
         if (canbreak && it >= 1) break;                                       // :879
     }
     return runEpilogue(lastEnergy);
+}
+
+// ------------------------------------------------------------------------------------------------ marginalisation
+void DSOBundleAdjustment::fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double>& prior, std::vector<double>& dprior, double cdelta[4], double cprior[4]) {
+    const int N = (int)mFrames.size();
+    prior.assign(8 * (size_t)N, 0.0); dprior.assign(8 * (size_t)N, 0.0);
+    for (int i = 0; i < N; i++) for (int k = 0; k < 8; k++) { prior[8 * i + k] = mFrames[i].prior[k]; dprior[8 * i + k] = mFrames[i].delta_prior[k]; }
+    for (int i = 0; i < 4; i++) { cdelta[i] = mCDeltaF[i]; cprior[i] = mCPriorValue; }
+    in = cmlhip_ba_accum_in{mAdHost.data(), mAdTarget.data(), mAdHTdeltaF.data(), cdelta, prior.data(), dprior.data(), cprior};
+}
+
+void DSOBundleAdjustment::removePointsWithoutResidual() {                     // DSOContext.h:218-229
+    std::vector<int> nres(mPoints.size(), 0);
+    for (const auto& r : mResiduals) if (r.alive) nres[r.point]++;
+    for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && nres[p] == 0) mPoints[p].alive = false;
+}
+
+void DSOBundleAdjustment::removePoint(int p, bool marginalize) {              // DSOContext.h:94-111,204-215
+    if (!mPoints[p].alive) return;
+    std::vector<char> seen(mFrames.size(), 0);
+    for (auto& r : mResiduals) {
+        if (!r.alive || r.point != p) continue;
+        if (marginalize && !seen[r.target]) { seen[r.target] = 1; mFrames[r.target].numMarginalized++; }
+        r.alive = false;
+        mFrames[r.target].numResidualsOut++;
+    }
+    mPoints[p].alive = false;
+    removePointsWithoutResidual();
+}
+
+void DSOBundleAdjustment::removeFrame(int f) {                                // DSOContext.h:154-174
+    for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && mPoints[p].host == f) removePoint(p, false);
+    for (auto& r : mResiduals) if (r.alive && r.target == f) { r.alive = false; mFrames[f].numResidualsOut++; }
+    removePointsWithoutResidual();
+    mFrames.erase(mFrames.begin() + f);
+    for (int i = 0; i < (int)mFrames.size(); i++) mFrames[i].id = i;          // makeFrameId
+    for (auto& P : mPoints) { if (P.host == f) P.host = -1; else if (P.host > f) P.host--; }
+    for (auto& r : mResiduals) { if (r.target == f) r.target = -1; else if (r.target > f) r.target--; }
+}
+
+bool DSOBundleAdjustment::isOOB(int p, const std::vector<int>& toMarg) const {   // BA.cpp:2515-2554 (toKeep is never filled, :2253-2258)
+    const int setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4;
+    const DSOPoint& P = mPoints[p];
+    int visInToMarg = 0, numIn = 0;
+    for (const auto& r : mResiduals) {
+        if (!r.alive || r.point != p || r.state_state != DSORES_IN) continue;
+        numIn++;
+        for (int k : toMarg) if (r.target == k) visInToMarg++;
+    }
+    if (numIn >= setting_minGoodActiveResForMarg && P.numGoodResiduals > setting_minGoodResForMarg + 10 &&
+        numIn - visInToMarg < setting_minGoodActiveResForMarg) return true;
+    if (P.lastResidualState[0] == DSORES_OOB) return true;
+    if (numIn < 2) return false;
+    if (P.lastResidualState[0] == DSORES_OUTLIER && P.lastResidualState[1] == DSORES_OUTLIER) return true;
+    return false;
+}
+
+void DSOBundleAdjustment::flagFramesForMarginalization(int numImmaturePerFrame) {   // BA.cpp:603-716
+    const int N = (int)mFrames.size();
+    int flagged = 0;
+    double sc[4];
+    scales(sc);
+    std::vector<int> nresOfFrame(N, 0);
+    for (const auto& r : mResiduals) if (r.alive) nresOfFrame[r.target]++;
+    for (int i = 0; i < N; i++) {
+        DSOFrame& f = mFrames[i];
+        const double in = nresOfFrame[i] + numImmaturePerFrame;
+        const double out = f.numMarginalized + f.numResidualsOut;
+        double a, b;
+        mFrames.back().aff_g2l().to(f.aff_g2l(), a, b);                         // frameBack exposure -> frame exposure
+        const double setting_minPointsRemaining = 0.05, setting_maxLogAffFacInWindow = 0.7;
+        const int setting_minFrames = mMaxFrames - 2;
+        const bool notEnough = in < setting_minPointsRemaining * (in + out);
+        const bool tooBig = std::fabs(std::log(a)) > setting_maxLogAffFacInWindow && N - flagged > setting_minFrames;
+        if (notEnough || tooBig) { f.flaggedForMarginalization = true; flagged++; }
+    }
+    if (N - flagged >= mMaxFrames) {                                           // marginalize one, :648-708
+        double smallestScore = 1;
+        int toMarginalize = -1;
+        const DSOFrame& latest = mFrames.back();
+        for (int ri = 0; ri < N; ri++) {
+            const DSOFrame& ref = mFrames[ri];
+            if (ref.keyid > latest.keyid - mMinFrameAge || ref.keyid == 0) continue;
+            double distScore = 0;
+            for (int ti = 0; ti < N; ti++) {
+                if (ti == ri) continue;
+                const DSOFrame& tg = mFrames[ti];
+                if (tg.keyid > latest.keyid - mMinFrameAge + 1) continue;
+                const SE3 rt = tg.PRE_worldToCam * ref.PRE_camToWorld;            // reference camera -> target camera
+                const double d = std::sqrt(rt.t[0] * rt.t[0] + rt.t[1] * rt.t[1] + rt.t[2] * rt.t[2]);
+                distScore += 1.0 / (1e-5 + d);
+            }
+            const SE3 rb = latest.PRE_worldToCam * ref.PRE_camToWorld;
+            distScore *= -std::sqrt(std::sqrt(rb.t[0] * rb.t[0] + rb.t[1] * rb.t[1] + rb.t[2] * rb.t[2]));
+            if (distScore < smallestScore) { smallestScore = distScore; toMarginalize = ri; }
+        }
+        if (toMarginalize >= 0) { mFrames[toMarginalize].flaggedForMarginalization = true; flagged++; }
+    }
+}
+
+bool DSOBundleAdjustment::tryMarginalize() {                                  // BA.cpp:2240-2363
+    const int setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4;
+    std::vector<int> toMarg;
+    for (int i = 0; i < (int)mFrames.size(); i++) if (mFrames[i].flaggedForMarginalization) toMarg.push_back(i);
+    std::vector<int> nres(mPoints.size(), 0);
+    for (const auto& r : mResiduals) if (r.alive) nres[r.point]++;
+    std::vector<int> toDrop, candidates;
+    for (int p = 0; p < (int)mPoints.size(); p++) {
+        const DSOPoint& P = mPoints[p];
+        if (!P.alive) continue;
+        if (P.idepth < 0 || nres[p] == 0) toDrop.push_back(p);
+        else if (isOOB(p, toMarg) || mFrames[P.host].flaggedForMarginalization) {
+            if (nres[p] >= setting_minGoodActiveResForMarg && P.numGoodResiduals >= setting_minGoodResForMarg) candidates.push_back(p);
+            else toDrop.push_back(p);
+        }
+    }
+    // residual loop of the candidates on the device (:2291-2304): resetOOB, linearize, applyRes(true), fixLinearization
+    if (!candidates.empty()) {
+        std::vector<int> slots;
+        for (int p : candidates) {
+            if (mPointSlot[p] < 0) { mError = "tryMarginalize: point is not in the uploaded window"; return false; }
+            slots.push_back(mPointSlot[p]);
+        }
+        computeDelta();
+        std::vector<cmlhip_ba_pair> pairs;
+        framePairs(pairs);
+        int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+        if (rc) return fail("cmlhip_ba_set_pairs", rc);
+        cmlhip_ba_accum_in in; std::vector<double> prior, dprior; double cdelta[4], cprior[4];
+        fillAccumIn(in, prior, dprior, cdelta, cprior);
+        int ngood = 0;
+        rc = cmlhip_ba_relinearize_points(mCtx, &in, (int)slots.size(), slots.data(), &ngood);
+        if (rc) return fail("cmlhip_ba_relinearize_points", rc);
+        const int R = (int)mActive.size();
+        std::vector<int> st(R), ns(R);
+        std::vector<float> e(R), ne(R), nw(R);
+        std::vector<unsigned char> good(R), lin(R);
+        rc = cmlhip_ba_get_states(mCtx, st.data(), ns.data(), e.data(), ne.data(), nw.data(), good.data());
+        if (rc) return fail("cmlhip_ba_get_states", rc);
+        rc = cmlhip_ba_get_res_to_zero(mCtx, nullptr, lin.data());
+        if (rc) return fail("cmlhip_ba_get_res_to_zero", rc);
+        std::vector<char> isCand(mPoints.size(), 0);
+        for (int p : candidates) isCand[p] = 1;
+        for (int k = 0; k < R; k++) {
+            DSOResidual& Rr = mResiduals[mActive[k]];
+            if (!isCand[Rr.point]) continue;
+            Rr.state_state = st[k]; Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k];
+            Rr.state_NewEnergyWithOutlier = nw[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0; Rr.isLinearized = lin[k] != 0;
+        }
+    }
+    for (int p : candidates) {
+        if (mPoints[p].idepth_hessian > mMinIdepthHMarg) mPoints[p].toMarginalize = true;       // :2316-2325
+        else toDrop.push_back(p);
+    }
+    for (int p : toDrop) { removePoint(p, false); mOutliers.push_back(p); }    // :2344-2348
+    return true;
+}
+
+bool DSOBundleAdjustment::marginalizePointsF() {                              // BA.cpp:2466-2513
+    computeDelta();
+    computeAdjoints();
+    std::vector<int> pts, slots;
+    for (int p = 0; p < (int)mPoints.size(); p++)
+        if (mPoints[p].toMarginalize) { pts.push_back(p); slots.push_back(mPointSlot[p]); }
+    const int n = 8 * (int)mFrames.size() + CMLHIP_CPARS;
+    std::vector<double> M((size_t)n * n, 0.0), Mb(n, 0.0), Msc((size_t)n * n, 0.0), Mbsc(n, 0.0);
+    if (!pts.empty()) {
+        cmlhip_ba_accum_in in; std::vector<double> prior, dprior; double cdelta[4], cprior[4];
+        fillAccumIn(in, prior, dprior, cdelta, cprior);
+        const int rc = cmlhip_ba_marginalize_points(mCtx, &in, (int)slots.size(), slots.data(), M.data(), Mb.data(), Msc.data(), Mbsc.data());
+        if (rc) return fail("cmlhip_ba_marginalize_points", rc);
+    }
+    for (int p : pts) {                                                        // :2490-2497
+        mPoints[p].marginalized = true; mPoints[p].toMarginalize = false;
+        removePoint(p, true);
+    }
+    const double setting_margWeightFac = 0.5 * 0.5;                            // :2502
+    for (size_t i = 0; i < M.size(); i++) mMarginalizedHessian[i] += setting_margWeightFac * (M[i] - Msc[i]);
+    for (int i = 0; i < n; i++) mMarginalizedB[i] += setting_margWeightFac * (Mb[i] - Mbsc[i]);
+    return true;
+}
+
+void DSOBundleAdjustment::marginalizeFrame(int frame) {                       // BA.cpp:464-601
+    const int N = (int)mFrames.size(), odim = 8 * N + CMLHIP_CPARS, ndim = odim - 8;
+    std::vector<double> H((size_t)odim * odim), b(odim);
+    std::vector<int> perm;
+    const int io = 8 * frame + CMLHIP_CPARS;
+    for (int i = 0; i < odim; i++) if (i < io || i >= io + 8) perm.push_back(i);   // frame block to the end, order of the rest kept (:489-508)
+    for (int i = 0; i < 8; i++) perm.push_back(io + i);
+    for (int i = 0; i < odim; i++) {
+        b[i] = mMarginalizedB[perm[i]];
+        for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = mMarginalizedHessian[(size_t)perm[i] * odim + perm[j]];
+    }
+    const DSOFrame& F = mFrames[frame];
+    for (int i = 0; i < 8; i++) {                                              // :511-513
+        H[(size_t)(ndim + i) * odim + ndim + i] += F.prior[i];
+        b[ndim + i] += F.prior[i] * F.delta_prior[i];
+    }
+    std::vector<double> SVec(odim);
+    for (int i = 0; i < odim; i++) SVec[i] = std::sqrt(std::fabs(H[(size_t)i * odim + i]) + 10.0);
+    for (int i = 0; i < odim; i++) {
+        for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = (1.0 / SVec[i]) * H[(size_t)i * odim + j] * (1.0 / SVec[j]);
+        b[i] = (1.0 / SVec[i]) * b[i];
+    }
+    double hpi[64], hinv[64];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) hpi[i * 8 + j] = H[(size_t)(ndim + i) * odim + ndim + j];
+    inverse8(hpi, hinv);                                                       // Matrix<8,8>::inverse(): partial-pivot LU (:532-535)
+    std::vector<double> bli((size_t)ndim * 8);
+    for (int i = 0; i < ndim; i++)
+        for (int j = 0; j < 8; j++) {
+            double s = 0;
+            for (int q = 0; q < 8; q++) s += H[(size_t)(ndim + q) * odim + i] * hinv[q * 8 + j];
+            bli[(size_t)i * 8 + j] = s;
+        }
+    for (int i = 0; i < ndim; i++) {                                           // Schur complement, :538-541
+        for (int j = 0; j < ndim; j++) {
+            double s = 0;
+            for (int q = 0; q < 8; q++) s += bli[(size_t)i * 8 + q] * H[(size_t)(ndim + q) * odim + j];
+            H[(size_t)i * odim + j] -= s;
+        }
+        double s = 0;
+        for (int q = 0; q < 8; q++) s += bli[(size_t)i * 8 + q] * b[ndim + q];
+        b[i] -= s;
+    }
+    for (int i = 0; i < odim; i++) {                                           // unscale, :544-545
+        for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = SVec[i] * H[(size_t)i * odim + j] * SVec[j];
+        b[i] = SVec[i] * b[i];
+    }
+    std::vector<double> Hn((size_t)ndim * ndim), bn(ndim);
+    for (int i = 0; i < ndim; i++) {                                           // :548-549
+        for (int j = 0; j < ndim; j++) Hn[(size_t)i * ndim + j] = 0.5 * (H[(size_t)i * odim + j] + H[(size_t)j * odim + i]);
+        bn[i] = b[i];
+    }
+    mMarginalizedHessian.swap(Hn);
+    mMarginalizedB.swap(bn);
+    removeFrame(frame);                                                        // :552
+    computeDelta();                                                            // :598-599
+    computeAdjoints();
+}
+
+std::vector<int> DSOBundleAdjustment::marginalizeFrames() {                   // BA.cpp:718-742
+    std::vector<int> removed;
+    for (;;) {
+        int f = -1;
+        for (int i = 0; i < (int)mFrames.size(); i++) if (mFrames[i].flaggedForMarginalization) { f = i; break; }
+        if (f < 0) break;
+        removed.push_back(f + (int)removed.size());                             // id at call time of the first removal
+        marginalizeFrame(f);
+    }
+    return removed;
+}
+
+double DSOBundleAdjustment::calcMEnergy() const {                             // BA.cpp:2095-2117
+    if (mForceAccept) return 0;
+    const int N = (int)mFrames.size(), n = 8 * N + CMLHIP_CPARS;
+    std::vector<double> d(n, 0.0);
+    for (int i = 0; i < 4; i++) d[i] = mCDeltaF[i];
+    for (int h = 0; h < N; h++) for (int k = 0; k < 8; k++) d[4 + 8 * h + k] = mFrames[h].delta[k];
+    double e = 0;
+    for (int i = 0; i < n; i++) {
+        double s = 2 * mMarginalizedB[i];
+        for (int j = 0; j < n; j++) s += mMarginalizedHessian[(size_t)i * n + j] * d[j];
+        e += d[i] * s;
+    }
+    return std::fabs(e);
+}
+
+double DSOBundleAdjustment::calcLEnergy() {                                   // BA.cpp:2119-2208
+    if (mForceAccept) return 0;
+    cmlhip_ba_accum_in in; std::vector<double> prior, dprior; double cdelta[4], cprior[4];
+    fillAccumIn(in, prior, dprior, cdelta, cprior);
+    double e = 0; int num = 0;
+    if (cmlhip_ba_lin_energy(mCtx, &in, &e, &num)) return 0;
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------ device-resident loop

@@ -27,6 +27,7 @@ struct DSOFrame {                                                              /
     SE3 PRE_worldToCam, PRE_camToWorld;
     double ab_exposure = 1;
     bool flaggedForMarginalization = false;
+    int numMarginalized = 0, numResidualsOut = 0;                    // DSOFrame.h:229-244
     double state[10] = {0}, state_zero[10] = {0}, state_backup[10] = {0}, state_scaled[10] = {0}, step[10] = {0};
     SE3 worldToCam_evalPT;
 
@@ -55,6 +56,9 @@ struct DSOPoint {                                                              /
     bool hasDepthPrior = false;
     int numGoodResiduals = 0;
     float idepth_hessian = 0, maxRelBaseline = 0;
+    int lastResidual[2] = {-1, -1};                                  // residual index / state of the newest two frames (DSOPoint.h:120-140)
+    int lastResidualState[2] = {DSORES_OOB, DSORES_OOB};
+    bool toMarginalize = false, marginalized = false;                // groups DSOTOMARGINALIZE / DSOMARGINALIZED
     double uncertainty = 0;
     bool alive = true;
 };
@@ -82,6 +86,8 @@ public:
     double mSolverModeDelta = 0.00001;
     bool   mOptimizeA = true, mOptimizeB = true, mMixedBundleAdjustment = false, mAddLinearizedPoints = false;
     bool   mDisableMarginalization = true, mOptimizeCalibration = false, mAbortBAOnFailture = false;
+    double mMinIdepthHMarg = 50.0;                           // BA.h:263
+    int    mMaxFrames = 6, mMinFrameAge = 1;                 // BA.h:271-272
     double mCPriorValue = 5e9;                               // BA.cpp:2136-2137 (mCPrior is only assigned inside calcLEnergy)
 
     // ---- reference interface (BA.h:28-85), flat arguments
@@ -97,6 +103,16 @@ public:
     bool iterateResident(int k, double lambda);
     bool endResident(double* lastEnergy = nullptr);
     void nullspaceBasis(std::vector<double>& U7n) const;                                         // orthonormal basis used by orthogonalize
+    // ---- marginalisation (BA.h:34-46), once per keyframe after run()
+    void flagFramesForMarginalization(int numImmaturePerFrame = 0);                              // BA.cpp:603-716
+    bool tryMarginalize();                                                                       // BA.cpp:2240-2363 (device: relinearize + fixLinearization)
+    bool marginalizePointsF();                                                                   // BA.cpp:2466-2513 (device: MARGINALIZED accumulation)
+    std::vector<int> marginalizeFrames();                                                        // BA.cpp:718-742; returns the removed DSOFrame ids (before renumbering)
+    void marginalizeFrame(int frameId);                                                          // BA.cpp:464-601
+    double calcMEnergy() const;                                                                  // BA.cpp:2095-2117
+    double calcLEnergy();                                                                        // BA.cpp:2119-2208
+    const std::vector<double>& marginalizedHessian() const { return mMarginalizedHessian; }
+    const std::vector<double>& marginalizedB() const { return mMarginalizedB; }
     const std::vector<int>& getOutliers() const { return mOutliers; }                            // point indices dropped by the last run
     void computeNullspaces(std::vector<double>& out7) const;                                     // BA.cpp:2365-2417
 
@@ -121,6 +137,11 @@ public:
 
 private:
     bool uploadWindow();
+    bool isOOB(int p, const std::vector<int>& toMarg) const;                  // BA.cpp:2515-2554
+    void removePoint(int p, bool marginalize);                                // DSOContext.h:94-111
+    void removeFrame(int f);                                                  // DSOContext.h:154-174
+    void removePointsWithoutResidual();
+    void fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double>& prior, std::vector<double>& dprior, double cdelta[4], double cprior[4]);
     bool runPreamble(double lastEnergy[3]);
     bool runEpilogue(double lastEnergy[3]);
     bool linearizeAll(bool fixLinearization, double energy[3]);

@@ -30,6 +30,9 @@ int cmlhost_ba_set_param(void* h, const char* name, double v) {
     else if (n == "ThOptIterations") b->mThOptIterations = v;
     else if (n == "iDepth Fix Prior") b->mIdepthFixPrior = (int)v;
     else if (n == "Solver mode delta") b->mSolverModeDelta = v;
+    else if (n == "Minimum iDepth Hessian Marginlaization") b->mMinIdepthHMarg = v;
+    else if (n == "maxFrames") b->mMaxFrames = (int)v;
+    else if (n == "frameMinAge") b->mMinFrameAge = (int)v;
     else return 1;      // unknown keys are an error, like the reference's YAML loader (AbstractSlam.h:70-83)
     return 0;
 }
@@ -51,6 +54,29 @@ int cmlhost_ba_run_resident(void* h, int updatePointsOnly) { return static_cast<
 int cmlhost_ba_begin_resident(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->beginResident(updatePointsOnly != 0) ? 1 : 0; }
 int cmlhost_ba_iterate_resident(void* h, int k, double lambda) { return static_cast<DSOBundleAdjustment*>(h)->iterateResident(k, lambda) ? 1 : 0; }
 int cmlhost_ba_end_resident(void* h, double* lastEnergy) { return static_cast<DSOBundleAdjustment*>(h)->endResident(lastEnergy) ? 1 : 0; }
+// ---- marginalisation (BA.h:34-46)
+void cmlhost_ba_flag_frame(void* h, int f, int flag) { static_cast<DSOBundleAdjustment*>(h)->getFrames()[f].flaggedForMarginalization = flag != 0; }
+void cmlhost_ba_flag_frames_for_marginalization(void* h, int immature) { static_cast<DSOBundleAdjustment*>(h)->flagFramesForMarginalization(immature); }
+int cmlhost_ba_try_marginalize(void* h) { return static_cast<DSOBundleAdjustment*>(h)->tryMarginalize() ? 1 : 0; }
+int cmlhost_ba_marginalize_points(void* h) { return static_cast<DSOBundleAdjustment*>(h)->marginalizePointsF() ? 1 : 0; }
+int cmlhost_ba_marginalize_frames(void* h, int* removed, int cap) {
+    const std::vector<int> r = static_cast<DSOBundleAdjustment*>(h)->marginalizeFrames();
+    for (int i = 0; i < (int)r.size() && i < cap; i++) removed[i] = r[i];
+    return (int)r.size();
+}
+int cmlhost_ba_get_prior(void* h, double* HM, double* bM) {          // returns n = 8N+4
+    DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);
+    const int n = (int)b->marginalizedB().size();
+    if (HM) std::memcpy(HM, b->marginalizedHessian().data(), sizeof(double) * n * n);
+    if (bM) std::memcpy(bM, b->marginalizedB().data(), sizeof(double) * n);
+    return n;
+}
+void cmlhost_ba_get_point_flags(void* h, unsigned char* toMarg, unsigned char* marginalized, float* idepthHessian) {
+    const auto& P = static_cast<DSOBundleAdjustment*>(h)->getPoints();
+    for (size_t i = 0; i < P.size(); i++) { if (toMarg) toMarg[i] = P[i].toMarginalize; if (marginalized) marginalized[i] = P[i].marginalized; if (idepthHessian) idepthHessian[i] = P[i].idepth_hessian; }
+}
+double cmlhost_ba_calc_m_energy(void* h) { return static_cast<DSOBundleAdjustment*>(h)->calcMEnergy(); }
+double cmlhost_ba_calc_l_energy(void* h) { return static_cast<DSOBundleAdjustment*>(h)->calcLEnergy(); }
 const char* cmlhost_ba_last_error(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastError().c_str(); }
 int cmlhost_ba_counts(void* h, int* nframes, int* npoints, int* nresiduals, int* noutliers, int* iterations) {
     DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);

@@ -59,3 +59,63 @@ def test_marginalize_points_path(config):
         assert all(np.abs(z).max() == 0 for z in Z)
     finally:
         ctx.close()
+
+
+def test_host_marginalisation_flow():
+    """The keyframe epilogue of direct/Mapping.cpp:89-100 through the host mirror: run -> flag -> tryMarginalize ->
+    marginalizePointsF -> marginalizeFrames -> run again with the prior.  The device pieces are pinned above; here the host
+    plumbing (slot mapping, prior growth/permutation, frame renumbering) is checked against the oracle's dense algebra."""
+    from libcml_amd import device, host
+    from tests import oracle_lib as O
+    I = S.make_inputs("medium")
+    ctx = device.Ctx(max_frames=I.N + 1, max_points=I.P, max_residuals=I.P * (I.N + 1))
+    ba = host.window_to_host_ba(ctx, I.W)
+    try:
+        ba.set_param("Minimum iDepth Hessian Marginlaization", 1.0)
+        assert ba.run(), ba.last_error()
+        N = I.N
+        ba.flag_frame(1)
+        idp, alive0, ng = ba.points()
+        assert ba.try_marginalize(), ba.last_error()
+        tm, mg, ih = ba.point_flags()
+        idp, alive1, ng = ba.points()
+        hosted = (I.W.pts["host"] == 1) & (alive0 == 1)
+        assert tm.sum() > 10, tm.sum()
+        # every surviving point hosted by the flagged frame is going to be marginalised; dropped ones are dead
+        assert np.all((tm[hosted] == 1) | (alive1[hosted] == 0))
+        assert np.all(ih[tm == 1] > 1.0)
+        st, ralive, good = ba.residual_states()
+        # ---- marginalizePointsF: prior += 0.25 (M - Msc) of exactly those points
+        H0, b0 = ba.prior()
+        assert np.all(H0 == 0) and H0.shape == (8 * N + 4, 8 * N + 4)
+        A = ba.algebra()
+        assert ba.marginalize_points(), ba.last_error()
+        H1, b1 = ba.prior()
+        assert np.abs(H1 - H1.T).max() <= 1e-9 * np.abs(H1).max() and np.abs(H1).max() > 0
+        ev = np.linalg.eigvalsh(0.5 * (H1 + H1.T)[4:, 4:])
+        assert ev.min() > -1e-6 * ev.max()                       # Schur complement of a Gram matrix
+        tm2, mg2, _ = ba.point_flags()
+        assert np.array_equal(mg2, tm) and tm2.sum() == 0
+        _, alive2, _ = ba.points()
+        assert np.all(alive2[mg2 == 1] == 0)
+        # ---- marginalizeFrames: dense algebra against the oracle
+        Aa = ba.algebra()
+        removed = ba.marginalize_frames()
+        assert list(removed) == [1]
+        H2, b2 = ba.prior()
+        Ho, bo = O.marginalize_frame(H1, b1, N, 1, Aa["prior"][8:16], Aa["dprior"][8:16])
+        assert H2.shape == (8 * N - 4, 8 * N - 4)
+        assert np.abs(H2 - Ho).max() <= 1e-10 * np.abs(Ho).max() and np.abs(b2 - bo).max() <= 1e-10 * np.abs(bo).max()
+        c = ba.counts()
+        assert c["frames"] == N - 1
+        _, alive3, _ = ba.points()
+        assert np.all(alive3[I.W.pts["host"] == 1] == 0)          # the removed frame takes its points with it
+        # ---- next keyframe cycle with the prior active
+        ba.set_param("disableMarginalization", 0)
+        assert ba.run(), ba.last_error()
+        e = ba.energies(32)
+        assert np.all(np.isfinite(e))
+        H3, b3 = ba.prior()
+        assert np.array_equal(H3, H2)                             # run() reads the prior, it does not change it
+    finally:
+        ba.close(); ctx.close()
