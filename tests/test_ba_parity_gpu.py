@@ -138,3 +138,32 @@ def test_system_and_solver_wide_window(N, P):
                     assert np.all(xd[:4] == 0)
     finally:
         ctx.close()
+
+
+def test_linearize_fp16_texels_bit_exact():
+    """Config E stores the pyramids as four halves per texel (CMLHIP_TEXEL_F16) and computes in fp32.  With the oracle fed
+    the same images rounded to half precision, records, states and energies must again be bit-exact: the only difference
+    of the mode is the storage format of the texel."""
+    from libcml_amd import abi
+    I = S.make_inputs("small")
+    for k in range(I.N):
+        for lvl in range(len(I.grads[k])):
+            I.grads[k][lvl] = I.grads[k][lvl].astype(np.float16).astype(np.float32)
+    ob = S.OracleBA(I)
+    ctx = D.make_ctx(I, texel_format=abi.TEXEL_F16)
+    try:
+        ro = ob.linearize()
+        rd = ctx.ba_linearize()
+        so, sd = ob.states(), ctx.ba_states()
+        assert np.array_equal(so["new_state"], sd["new_state"])
+        assert np.array_equal(so["new_energy_wo"].view(np.uint32), sd["new_energy_wo"].view(np.uint32))
+        IN = so["new_state"] == 0
+        assert IN.sum() > 10
+        assert np.array_equal(ob.rJ(0)[IN].view(np.uint32), ctx.ba_rj(0)[IN].view(np.uint32)), "raw Jacobian records differ"
+        assert (ro.n_in, ro.n_oob, ro.n_outlier) == (rd.n_in, rd.n_oob, rd.n_outlier)
+        assert np.float32(ro.new_frame_energy_th).view(np.uint32) == np.float32(rd.new_frame_energy_th).view(np.uint32)
+        ob.apply(1); ctx.ba_apply(1)
+        Ho = ob.accumulate(); Hd = D.accumulate(ctx, I)
+        assert D.rel(Hd[0], Ho[0]) < 2e-5 and D.rel(Hd[4], Ho[4]) < 5e-5
+    finally:
+        ctx.close()

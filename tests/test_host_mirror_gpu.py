@@ -119,3 +119,42 @@ def test_resident_iterations_match_host_loop(config):
         assert abs(a["th"] - b["th"]) <= 1e-5 * abs(a["th"])
     assert np.abs(idp_h / idp_r - 1).max() < 1e-5
     assert abs(e_h[-1] / e_r[-1] - 1) < 1e-6, (e_h, e_r)
+
+
+def test_host_tracker_recovers_known_motion():
+    """DSOTracker::optimize (TR.cpp:15-246) through the host mirror: coarse-to-fine LM on the device residual/Hessian
+    kernel.  The synthetic scene has a known relative pose and affine brightness between the reference keyframe and the
+    new frame; started from a perturbed pose the loop must come back to it, level by level, deterministically."""
+    from tests import trk_setup as T
+    from libcml_amd import synth
+    s = T.make_scene("medium", eval_noise=0.0, idepth_noise=0.0, state_noise=0.0)    # exact geometry: the optimum is the true motion
+    W = s.W
+    fx, fy, cx, cy = W.K
+    outs = []
+    for rep in range(2):
+        ctx = device.Ctx(max_frames=8)
+        trk = host.HostTracker(ctx)
+        trk.set_calibration(fx, fy, cx, cy)
+        L = s.levels
+        ctx.pyramid_build(500, W.gray[s.ref], L)
+        ctx.pyramid_build(501, W.gray[s.new], L)
+        nout = trk.make_coarse_depth(500, L, s.cd_pts)
+        assert nout[0] > 100
+        Rt = W.R_true[s.new] @ W.R_true[s.ref].T
+        tt = W.t_true[s.new] - Rt @ W.t_true[s.ref]
+        R0 = synth.so3_exp(np.array([0.004, -0.003, 0.002])) @ Rt
+        t0 = tt + np.array([0.03, -0.02, 0.025])
+        a_r, b_r = W.aff_true[s.ref]; a_n, b_n = W.aff_true[s.new]
+        r = trk.optimize(501, L, R0, t0, [a_r, b_r, float(W.ab_exposure[s.ref])], [a_r, b_r, float(W.ab_exposure[s.new])])
+        assert r["isCorrect"]            # (tooManySaturated mirrors the reference literally: it is set to haveGoodPoints, TR.cpp:138)
+        assert r["numTerms"][0] > 100 and np.all(r["iterations"][:L] >= 1)
+        err_R0 = np.linalg.norm(synth.so3_log(R0 @ Rt.T)) if hasattr(synth, "so3_log") else np.arccos(np.clip((np.trace(R0 @ Rt.T) - 1) / 2, -1, 1))
+        err_R = np.arccos(np.clip((np.trace(r["R"] @ Rt.T) - 1) / 2, -1, 1))
+        err_t0 = np.linalg.norm(t0 - tt); err_t = np.linalg.norm(r["t"] - tt)
+        assert err_R < 0.25 * err_R0 and err_t < 0.25 * err_t0, (err_R, err_R0, err_t, err_t0)
+        # photometric rmse at level 0 must be small compared with the image contrast
+        assert r["E"][0] / r["numTerms"][0] < 40.0
+        outs.append((r["R"].copy(), r["t"].copy(), r["E"].copy(), r["exposure"].copy()))
+        trk.close(); ctx.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))

@@ -11,8 +11,8 @@ class Scene:
     pass
 
 
-def make_scene(config="small", seed=0xC0FFEE):
-    W = synth.make_window(config, seed=seed)
+def make_scene(config="small", seed=0xC0FFEE, **kw):
+    W = synth.make_window(config, seed=seed, **kw)
     s = Scene()
     s.W = W
     s.levels = min(len(O.pyramid_sizes(W.w, W.h)[0]), 5)
