@@ -22,7 +22,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.pt_idepth_zero = c->pt_idepth_zero.as<float>(); A.pt_prior = c->pt_prior.as<float>(); A.pt_host = c->pt_host.as<int>();
     A.pt_colors = c->pt_colors.as<float>(); A.pt_weights = c->pt_weights.as<float>(); A.pt_backup = c->pt_backup.as<float>();
     A.pt_acc = c->pt_acc.as<float>(); A.pt_step = c->pt_step.as<double>();
-    A.r_point = c->r_point.as<int>(); A.r_target = c->r_target.as<int>(); A.r_state = c->r_state.as<int>();
+    A.r_point = c->r_point.as<int>(); A.r_host = c->r_host.as<int>(); A.r_target = c->r_target.as<int>(); A.r_state = c->r_state.as<int>();
     A.r_new_state = c->r_new_state.as<int>(); A.r_energy = c->r_energy.as<float>(); A.r_new_energy = c->r_new_energy.as<float>();
     A.r_new_energy_wo = c->r_new_energy_wo.as<float>(); A.r_ret_energy = c->r_ret_energy.as<float>();
     A.r_good = c->r_good.as<unsigned char>(); A.r_lin = c->r_lin.as<unsigned char>(); A.r_sel = c->r_sel.as<unsigned char>();
@@ -101,7 +101,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->pt_x, 4 * P); ENS(c->pt_y, 4 * P); ENS(c->pt_idepth, 8 * P); ENS(c->pt_idepth_zero, 4 * P); ENS(c->pt_prior, 4 * P);
     ENS(c->pt_host, 4 * P); ENS(c->pt_colors, 32 * P); ENS(c->pt_weights, 32 * P); ENS(c->pt_backup, 4 * P);
     ENS(c->pt_acc, 4 * PT_ACC_STRIDE * P); ENS(c->pt_step, 8 * P);
-    ENS(c->r_point, 4 * R); ENS(c->r_target, 4 * R); ENS(c->r_state, 4 * R); ENS(c->r_new_state, 4 * R);
+    ENS(c->r_point, 4 * R); ENS(c->r_host, 4 * R); ENS(c->r_target, 4 * R); ENS(c->r_state, 4 * R); ENS(c->r_new_state, 4 * R);
     ENS(c->r_energy, 4 * R); ENS(c->r_new_energy, 4 * R); ENS(c->r_new_energy_wo, 4 * R); ENS(c->r_ret_energy, 4 * R);
     ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 32 * R); ENS(c->r_rtz, 32 * R);
     ENS(c->rj[0], 4 * (size_t)RJ_STRIDE * R); ENS(c->rj[1], 4 * (size_t)RJ_STRIDE * R);
@@ -135,6 +135,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     UP(c->frames, fd);
     UP(c->pt_x, fx); UP(c->pt_y, fy); UP(c->pt_idepth, idp); UP(c->pt_idepth_zero, fz); UP(c->pt_prior, fp); UP(c->pt_host, hst);
     UP(c->pt_colors, col); UP(c->pt_weights, wgt);
+    { std::vector<int> rh(R); for (int r = 0; r < R; r++) rh[r] = points[res[r].point].host; UP(c->r_host, rh); }
     UP(c->r_point, rp); UP(c->r_target, rt); UP(c->r_state, rs); UP(c->r_new_state, rns); UP(c->r_lin, rl);
     UP(c->by_point_off, c->h_by_point_off); UP(c->by_point, c->h_by_point);
     UP(c->by_pair_off, c->h_by_pair_off); UP(c->by_pair, c->h_by_pair);

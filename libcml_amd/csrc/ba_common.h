@@ -37,7 +37,7 @@ struct BAArgs {
     const cmlhip_ba_pair* pairs;
     const float* pt_x; const float* pt_y; double* pt_idepth; float* pt_idepth_zero; const float* pt_prior;
     const int* pt_host; const float* pt_colors; const float* pt_weights; float* pt_backup; float* pt_acc; double* pt_step;
-    const int* r_point; const int* r_target; int* r_state; int* r_new_state;
+    const int* r_point; const int* r_host; const int* r_target; int* r_state; int* r_new_state;
     float* r_energy; float* r_new_energy; float* r_new_energy_wo; float* r_ret_energy;
     unsigned char* r_good; const unsigned char* r_lin; unsigned char* r_sel;
     unsigned char* r_lin_rw; int* point_tgt_rw;    // writable views for the marginalisation kernels (isLinearized changes there)

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     //      on a clamped index — a `cond ? load : 0` costs its own branch and memory round trip — and what the tail of the
     //      kernel needs (energy, new state, Jacobian-buffer selector, pair-list slot) is fetched in this first round trip.
     const int rc = min(r, A.R - 1);
-    const int lin_ = A.r_lin[rc], st_ = A.r_state[rc], p_ = A.r_point[rc], tg_ = A.r_target[rc];
+    const int lin_ = A.r_lin[rc], st_ = A.r_state[rc], p_ = A.r_point[rc], tg_ = A.r_target[rc], hs_ = A.r_host[rc];
     const float pre_energy = A.r_energy[rc];
     const int pre_new_state = A.r_new_state[rc], pre_pos = A.pair_pos[rc], pre_ppos = A.point_pos[rc];
     const unsigned char pre_sel = A.r_sel[rc];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
     const int p = live ? p_ : 0;
-    const int host = A.pt_host[p], target = live ? tg_ : 0;
+    const int host = hs_, target = tg_;                       // (static per residual: pair / frame data load with the point data)
     const cmlhip_ba_pair* pc = &A.pairs[host * A.N + target];
     const FrameDev fh = A.frames[host], ft = A.frames[target];
     const double cxd = (double)A.pt_x[p], cyd = (double)A.pt_y[p];
@@ -74,6 +74,9 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const double R0_ = pc->R[0], R1_ = pc->R[1], R2_ = pc->R[2], R3_ = pc->R[3], R4_ = pc->R[4], R5_ = pc->R[5],
                  R6_ = pc->R[6], R7_ = pc->R[7], R8_ = pc->R[8];
     const double t0_ = pc->t[0], t1_ = pc->t[1], t2_ = pc->t[2];
+    // evaluation-point pair (PRE_RTll_0 / PRE_tTll_0) for the calibration / depth Jacobians: fetched with the rest, not inside the lane branches
+    const double E0 = pc->R0[0], E1 = pc->R0[1], E3 = pc->R0[3], E4 = pc->R0[4], E6 = pc->R0[6], E7 = pc->R0[7];
+    const double et0 = pc->t0[0], et1 = pc->t0[1], et2 = pc->t0[2];
 
     // ---- centre projection, BA.cpp:102-131 (identical on the 8 lanes)
     const double rx = (cxd - A.cx) * A.fxi, ry = (cyd - A.cy) * A.fyi;
@@ -166,18 +169,16 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         rec[O_XI1 + 0] = 0; rec[O_XI1 + 1] = new_idepth * fyf; rec[O_XI1 + 2] = -new_idepth * v * fyf;
         rec[O_XI1 + 3] = -(1 + v * v) * fyf; rec[O_XI1 + 4] = u * v * fyf; rec[O_XI1 + 5] = u * fyf;
     } else if (k == 2) {
-        const double* R0 = pc->R0; const double* t0 = pc->t0;
-        double c2 = drescale * (R0[6] * u - R0[0]);
-        double c3 = (fxf * drescale) * (R0[7] * u - R0[1]) / fyf;
+        double c2 = drescale * (E6 * u - E0);
+        double c3 = (fxf * drescale) * (E7 * u - E1) / fyf;
         double c0 = rx * c2, c1 = ry * c3;
         rec[O_C0 + 0] = (float)((c0 + u) * A.scale_f); rec[O_C0 + 1] = (float)(c1 * A.scale_f);
         rec[O_C0 + 2] = (float)((c2 + 1) * A.scale_c); rec[O_C0 + 3] = (float)(c3 * A.scale_c);
-        rec[O_DD + 0] = (float)(drescale * (t0[0] - t0[2] * u) * fxf);
-        rec[O_DD + 1] = (float)(drescale * (t0[1] - t0[2] * v) * fyf);
+        rec[O_DD + 0] = (float)(drescale * (et0 - et2 * u) * fxf);
+        rec[O_DD + 1] = (float)(drescale * (et1 - et2 * v) * fyf);
     } else if (k == 3) {
-        const double* R0 = pc->R0;
-        double d2 = (fyf * drescale) * (R0[6] * v - R0[3]) / fxf;
-        double d3 = drescale * (R0[7] * v - R0[4]);
+        double d2 = (fyf * drescale) * (E6 * v - E3) / fxf;
+        double d3 = drescale * (E7 * v - E4);
         double d0 = rx * d2, d1 = ry * d3;
         rec[O_C1 + 0] = (float)(d0 * A.scale_f); rec[O_C1 + 1] = (float)((d1 + v) * A.scale_f);
         rec[O_C1 + 2] = (float)(d2 * A.scale_c); rec[O_C1 + 3] = (float)((d3 + 1) * A.scale_c);

@@ -86,7 +86,7 @@ void cmlhip_destroy(cmlhip_ctx* c) {
     for (auto& kv : c->pyr)
         for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) hipFree(kv.second.lv[l].gray); }
     DevBuf* all[] = {&c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
-                     &c->pt_colors, &c->pt_weights, &c->pt_backup, &c->pt_acc, &c->pt_step, &c->r_point, &c->r_target,
+                     &c->pt_colors, &c->pt_weights, &c->pt_backup, &c->pt_acc, &c->pt_step, &c->r_point, &c->r_host, &c->r_target,
                      &c->r_state, &c->r_new_state, &c->r_energy, &c->r_new_energy, &c->r_new_energy_wo, &c->r_ret_energy,
                      &c->r_good, &c->r_lin, &c->r_sel, &c->r_center, &c->r_jpjdf, &c->r_rtz, &c->rj[0], &c->rj[1],
                      &c->by_point_off, &c->by_point, &c->by_pair_off, &c->by_pair, &c->pair_code, &c->pair_pos, &c->point_code, &c->point_tgt, &c->point_pos, &c->frame_state, &c->pre_w2c, &c->null_basis, &c->pt_mask, &c->marg_scratch, &c->newframe_res, &c->acc_pair[0],

@@ -35,8 +35,3 @@ b = blk[2]; nb_ = int((b[:, 0] > 0).sum()); d = (b[:nb_, 1] - b[:nb_, 0]) * 0.01
 nrow = W.N + 1
 print("system: SYRK blocks %d dur med %.2f max %.2f ; row blocks dur med %.2f max %.2f" % (nb_ - nrow, np.median(d[:-nrow]), d[:-nrow].max(), np.median(d[-nrow:]), d[-nrow:].max()))
 
-names_l = ["inputs (r, point, pair, frames)", "projection math (fp64)", "image taps", "photometrics + LDS share", "sums + geometric J", "classification", "fused apply", "copy-out + partials"]
-for k in range(8): seg("lin blk200: " + names_l[k], k, k + 1)
-
-b33 = blk[2][33]
-print("syrk blk33: start->loads landed %.2f  mfma+lds write %.2f  barrier %.2f  tail %.2f" % ((out[32] - b33[0]) * .01, (out[33] - out[32]) * .01, (out[34] - out[33]) * .01, (b33[1] - out[34]) * .01))
