@@ -21,8 +21,7 @@ struct TrkArgs {
     float* warped;                           // n x 8 floats {idepth,u,v,dx,dy,residual,weight,refcolor}
     unsigned char* flag;                     // n: 1 = written to the warped buffer
     float* partial;                          // gridDim x TRK_NRED
-    unsigned* counter;
-    float* out;                              // TRK_NRED floats (final sums)
+    int trips;                               // 256-point trips per workgroup (1 for the usual list sizes: more workgroups, one round trip each)
 };
 #define TRK_NRED 56   // 45 (H upper) + E + sT + sRT + sN + numTerms + numSat + numRobust + numWarped + pad(3)
 
@@ -36,115 +35,127 @@ __device__ __forceinline__ float4 trk_texel(const void* img, size_t i) {
     return reinterpret_cast<const float4*>(img)[i];
 }
 
+// Reduction layout.  Everything the host needs is a sum over the points of an outer product a_k b_k^T with
+//   a = [hw*J (9) | 1 | numRobust numWarped 0 0 0 0]      b = [J (9) | 1 | E sT sRT sN numTerms numSat]
+// so D = sum_k a_k b_k^T holds the 9x9 system in D[0..8][0..8] (entry (r,c) = sum (J_r hw) J_c, TR.cpp:443-470 /
+// Accumulator9), the b-side scalars in row 9 (a_9 = 1) and the a-side scalars in column 9 (b_9 = 1).  D accumulates on the
+// matrix cores (v_mfma_f32_16x16x4_f32, IEEE fp32, 4 points per instruction): no per-lane accumulators, no shuffles.
+// Each lane computes one point, the a/b vectors cross to the MFMA operand layout through a per-wave LDS tile, a
+// workgroup covers 256 x trips points, writes the 56 sums it owns, and the (synchronous) caller adds the few
+// workgroup rows in block order on the host — no atomics, no inter-workgroup fences.
+typedef float trk_float4 __attribute__((ext_vector_type(4)));
+#define TRK_LD 17
+
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
-    __shared__ float s_red[4][TRK_NRED];
-    __shared__ int s_last;
-    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
-    float v[TRK_NRED];
+    __shared__ float s_a[4][64][TRK_LD], s_b[4][64][TRK_LD];
+    __shared__ float s_tile[4][256];
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    trk_float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int trip = 0; trip < A.trips; trip++) {
+        const int i = (blockIdx.x * A.trips + trip) * 256 + tid;
+        if ((blockIdx.x * A.trips + trip) * 256 >= A.n) break;               // workgroup-uniform
+        float va[16], vb[16];
 #pragma unroll
-    for (int k = 0; k < TRK_NRED; k++) v[k] = 0.f;
-    if (i < A.n) {
-        const float x = A.uvic[4 * (size_t)i], y = A.uvic[4 * (size_t)i + 1], id = A.uvic[4 * (size_t)i + 2], refColor = A.uvic[4 * (size_t)i + 3];
-        bool wrote = false;
-        if (isfinite(refColor)) {                                           // TR.cpp:301-303
-            float pt[3];
+        for (int k = 0; k < 16; k++) { va[k] = 0.f; vb[k] = 0.f; }
+        if (i < A.n) {
+            va[9] = 1.f; vb[9] = 1.f;
+            const float4 q = reinterpret_cast<const float4*>(A.uvic)[i];
+            const float x = q.x, y = q.y, id = q.z, refColor = q.w;
+            bool wrote = false;
+            if (isfinite(refColor)) {                                           // TR.cpp:301-303
+                float pt[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) pt[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) + A.t[k] * id;
-            const float u = pt[0] / pt[2], vv = pt[1] / pt[2];
-            const float Ku = A.fxl * u + A.cxl, Kv = A.fyl * vv + A.cyl;
-            const float new_idepth = id / pt[2];
-            if (A.level == 0 && (i % 32) == 0) {                           // flow statistic, TR.cpp:313-344
-                float a[3], b[3], c[3];
+                for (int k = 0; k < 3; k++) pt[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) + A.t[k] * id;
+                const float u = pt[0] / pt[2], vv = pt[1] / pt[2];
+                const float Ku = A.fxl * u + A.cxl, Kv = A.fyl * vv + A.cyl;
+                const float new_idepth = id / pt[2];
+                if (A.level == 0 && (i % 32) == 0) {                           // flow statistic, TR.cpp:313-344
+                    float a[3], b[3], c[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float kp = (A.Ki[k * 3] * x + A.Ki[k * 3 + 1] * y) + A.Ki[k * 3 + 2] * 1.0f;
-                    a[k] = kp + A.t[k] * id; b[k] = kp - A.t[k] * id;
-                    c[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) - A.t[k] * id;
+                    for (int k = 0; k < 3; k++) {
+                        const float kp = (A.Ki[k * 3] * x + A.Ki[k * 3 + 1] * y) + A.Ki[k * 3 + 2] * 1.0f;
+                        a[k] = kp + A.t[k] * id; b[k] = kp - A.t[k] * id;
+                        c[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) - A.t[k] * id;
+                    }
+                    const float KuT = A.fxl * (a[0] / a[2]) + A.cxl, KvT = A.fyl * (a[1] / a[2]) + A.cyl;
+                    const float KuT2 = A.fxl * (b[0] / b[2]) + A.cxl, KvT2 = A.fyl * (b[1] / b[2]) + A.cyl;
+                    const float Ku3 = A.fxl * (c[0] / c[2]) + A.cxl, Kv3 = A.fyl * (c[1] / c[2]) + A.cyl;
+                    float sT = 0, sRT = 0;
+                    sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+                    sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+                    sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+                    sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+                    vb[11] = sT; vb[12] = sRT; vb[13] = 2.f;
                 }
-                const float KuT = A.fxl * (a[0] / a[2]) + A.cxl, KvT = A.fyl * (a[1] / a[2]) + A.cyl;
-                const float KuT2 = A.fxl * (b[0] / b[2]) + A.cxl, KvT2 = A.fyl * (b[1] / b[2]) + A.cyl;
-                const float Ku3 = A.fxl * (c[0] / c[2]) + A.cxl, Kv3 = A.fyl * (c[1] / c[2]) + A.cyl;
-                float sT = 0, sRT = 0;
-                sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-                sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-                sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-                sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-                v[46] = sT; v[47] = sRT; v[48] = 2.f;
-            }
-            if (Ku > 2 && Kv > 2 && Ku < A.w - 3 && Kv < A.h - 3 && new_idepth > 0) {     // TR.cpp:346
-                const int ix = (int)Ku, iy = (int)Kv;
-                const float dx = Ku - (float)ix, dy = Kv - (float)iy, dxdy = dx * dy;
-                const float w00 = 1 - dx - dy + dxdy, w01 = dx - dxdy, w10 = dy - dxdy, w11 = dxdy;
-                const size_t i1 = (size_t)iy * A.w + ix;
-                const float4 ta = trk_texel<HALF>(A.img, i1), tb = trk_texel<HALF>(A.img, i1 + 1);
-                const float4 tc = trk_texel<HALF>(A.img, i1 + A.w), td = trk_texel<HALF>(A.img, i1 + A.w + 1);
-                const float h0 = ta.x * w00 + tb.x * w01 + tc.x * w10 + td.x * w11;
-                const float h1 = ta.y * w00 + tb.y * w01 + tc.y * w10 + td.y * w11;
-                const float h2 = ta.z * w00 + tb.z * w01 + tc.z * w10 + td.z * w11;
-                if (isfinite(h0) && isfinite(h1) && isfinite(h2)) {
-                    const float residual = h0 - (float)(A.a0 * refColor + A.a1);
-                    const float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / fabs((double)residual));
-                    if (fabs((double)residual) > A.cutoff_d) {
-                        v[45] = A.maxEnergy; v[49] = 1.f; v[50] = 1.f;
-                    } else {
-                        v[45] = hw * residual * residual * (2 - hw); v[49] = 1.f; v[52] = 1.f;
-                        wrote = true;
-                        float* W = A.warped + 8 * (size_t)i;
-                        W[0] = new_idepth; W[1] = u; W[2] = vv; W[3] = h1; W[4] = h2; W[5] = residual; W[6] = hw; W[7] = refColor;
-                        if (A.want_h) {                                       // computeHessian lanes, TR.cpp:443-470
-                            const float ddx = h1 * A.fxh, ddy = h2 * A.fyh;
-                            float J[9];
-                            J[0] = new_idepth * ddx;
-                            J[1] = new_idepth * ddy;
-                            J[2] = 0.0f - (new_idepth * (u * ddx + vv * ddy));
-                            J[3] = 0.0f - ((u * vv * ddx) + ddy * (1.0f + vv * vv));
-                            J[4] = (u * vv * ddy) + (ddx * (1.0f + u * u));
-                            J[5] = u * ddy - vv * ddx;
-                            J[6] = A.a_h * (A.b0 - refColor);
-                            J[7] = -1.0f;
-                            J[8] = residual;
-                            int idx = 0;
+                if (Ku > 2 && Kv > 2 && Ku < A.w - 3 && Kv < A.h - 3 && new_idepth > 0) {     // TR.cpp:346
+                    const int ix = (int)Ku, iy = (int)Kv;
+                    const float dx = Ku - (float)ix, dy = Kv - (float)iy, dxdy = dx * dy;
+                    const float w00 = 1 - dx - dy + dxdy, w01 = dx - dxdy, w10 = dy - dxdy, w11 = dxdy;
+                    const size_t i1 = (size_t)iy * A.w + ix;
+                    const float4 ta = trk_texel<HALF>(A.img, i1), tb = trk_texel<HALF>(A.img, i1 + 1);
+                    const float4 tc = trk_texel<HALF>(A.img, i1 + A.w), td = trk_texel<HALF>(A.img, i1 + A.w + 1);
+                    const float h0 = ta.x * w00 + tb.x * w01 + tc.x * w10 + td.x * w11;
+                    const float h1 = ta.y * w00 + tb.y * w01 + tc.y * w10 + td.y * w11;
+                    const float h2 = ta.z * w00 + tb.z * w01 + tc.z * w10 + td.z * w11;
+                    if (isfinite(h0) && isfinite(h1) && isfinite(h2)) {
+                        const float residual = h0 - (float)(A.a0 * refColor + A.a1);
+                        const float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / fabs((double)residual));
+                        if (fabs((double)residual) > A.cutoff_d) {
+                            vb[10] = A.maxEnergy; vb[14] = 1.f; vb[15] = 1.f;                  // E, numTerms, numSaturated
+                        } else {
+                            vb[10] = hw * residual * residual * (2 - hw); vb[14] = 1.f; va[11] = 1.f;   // E, numTerms, numWarped
+                            wrote = true;
+                            float* W = A.warped + 8 * (size_t)i;
+                            W[0] = new_idepth; W[1] = u; W[2] = vv; W[3] = h1; W[4] = h2; W[5] = residual; W[6] = hw; W[7] = refColor;
+                            if (A.want_h) {                                       // computeHessian lanes, TR.cpp:443-470
+                                const float ddx = h1 * A.fxh, ddy = h2 * A.fyh;
+                                vb[0] = new_idepth * ddx;
+                                vb[1] = new_idepth * ddy;
+                                vb[2] = 0.0f - (new_idepth * (u * ddx + vv * ddy));
+                                vb[3] = 0.0f - ((u * vv * ddx) + ddy * (1.0f + vv * vv));
+                                vb[4] = (u * vv * ddy) + (ddx * (1.0f + u * u));
+                                vb[5] = u * ddy - vv * ddx;
+                                vb[6] = A.a_h * (A.b0 - refColor);
+                                vb[7] = -1.0f;
+                                vb[8] = residual;
 #pragma unroll
-                            for (int r = 0; r < 9; r++) {
-                                const float Jw = J[r] * hw;
-#pragma unroll
-                                for (int c = r; c < 9; c++) { v[idx] = Jw * J[c]; idx++; }
+                                for (int r = 0; r < 9; r++) va[r] = vb[r] * hw;
                             }
                         }
+                        if (fabs((double)residual) <= A.cutoff_base_d) va[10] = 1.f;           // numRobust
                     }
-                    if (fabs((double)residual) <= A.cutoff_base_d) v[51] = 1.f;
                 }
             }
+            A.flag[i] = wrote ? 1 : 0;
         }
-        A.flag[i] = wrote ? 1 : 0;
-    }
-    // ---- block reduction: wave shuffles, then one LDS hop
-    const int wv = tid >> 6, ln = tid & 63;
+        // ---- this wave's 64 points to the MFMA operand layout (A[i][k] = a_k[i], B[k][j] = b_k[j], 4 points per step)
 #pragma unroll
-    for (int k = 0; k < TRK_NRED; k++) {
-        float s = v[k];
+        for (int k = 0; k < 16; k++) { s_a[wv][l][k] = va[k]; s_b[wv][l][k] = vb[k]; }
+        // (LDS accesses of one wave are ordered: no barrier between the stores above and the loads below)
+        const int e = l & 15, kq = l >> 4;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (ln == 0) s_red[wv][k] = s;
+        for (int m = 0; m < 16; m++) {
+            const float av = s_a[wv][4 * m + kq][e], bv = s_b[wv][4 * m + kq][e];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
     }
+    // D: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) s_tile[wv][(4 * (l >> 4) + rg) * 16 + (l & 15)] = acc[rg];
     __syncthreads();
-    if (tid < TRK_NRED) A.partial[(size_t)blockIdx.x * TRK_NRED + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
-    // ---- last-block finish (agent-scope publish: per-XCD L2s are not coherent)
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1);
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (s_last && tid < TRK_NRED) {
-        double s = 0;                                     // fixed block order, fp64 combine of the fp32 block sums
-        for (unsigned b = 0; b < gridDim.x; b++) s += (double)A.partial[(size_t)b * TRK_NRED + tid];
-        A.out[tid] = (float)s;
-        if (tid == 0) *A.counter = 0;
+    if (tid < TRK_NRED) {
+        int src = -1;
+        if (tid < 45) {
+            int k = tid, r = 0;
+            while (k >= 9 - r) { k -= 9 - r; r++; }
+            src = r * 16 + (r + k);
+        } else if (tid <= 50) src = 9 * 16 + 10 + (tid - 45);          // E sT sRT sN numTerms numSaturated
+        else if (tid == 51) src = 10 * 16 + 9;                          // numRobust
+        else if (tid == 52) src = 11 * 16 + 9;                          // numWarped
+        float v = 0.f;
+        if (src >= 0) v = ((s_tile[0][src] + s_tile[1][src]) + s_tile[2][src]) + s_tile[3][src];
+        A.partial[(size_t)blockIdx.x * TRK_NRED + tid] = v;
     }
 }
 
@@ -285,7 +296,8 @@ int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const doubl
     A.fxh = (float)K[0]; A.fyh = (float)K[1]; A.b0 = (float)b0; A.a_h = (float)aff[0];
     A.huber_d = (double)prm->huber; A.cutoff_d = (double)prm->cutoff; A.cutoff_base_d = (double)prm->cutoff_base;
     A.maxEnergy = (float)(2.0f * A.huber_d * A.cutoff_d - A.huber_d * A.huber_d);
-    const int blocks = cml_div_up(n > 0 ? n : 1, 256);
+    A.trips = n <= 65536 ? 1 : 4;
+    const int blocks = cml_div_up(n > 0 ? n : 1, 256 * A.trips);
     int rc;
     if ((rc = cml_ensure(c, c->trk_warped, (size_t)(n ? n : 1) * 36))) return rc;
     if ((rc = cml_ensure(c, c->trk_partial, (size_t)blocks * TRK_NRED * 4))) return rc;
@@ -293,16 +305,19 @@ int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const doubl
     A.warped = c->trk_warped.as<float>();
     A.flag = reinterpret_cast<unsigned char*>(c->trk_warped.as<float>() + 8 * (size_t)(n ? n : 1));
     A.partial = c->trk_partial.as<float>();
-    A.out = c->trk_out.as<float>();
-    A.counter = reinterpret_cast<unsigned*>(c->trk_out.as<float>() + 64);
-    if (!c->trk_out.bytes) return CMLHIP_ERR_HIP;
     c->trk_last_n = n;
-    CML_CHECK(c, hipMemsetAsync(A.counter, 0, sizeof(unsigned), c->stream));
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_tracker_eval<true><<<blocks, 256, 0, c->stream>>>(A);
     else k_tracker_eval<false><<<blocks, 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
+    // the workgroup rows are added here, in block order, fp64 (what the last-block pass of a fused finish would do)
+    std::vector<float> part((size_t)blocks * TRK_NRED);
+    if ((rc = cml_d2h(c, part.data(), c->trk_partial.p, part.size() * sizeof(float)))) return rc;
     float s[TRK_NRED];
-    if ((rc = cml_d2h(c, s, c->trk_out.p, sizeof s))) return rc;
+    for (int k = 0; k < TRK_NRED; k++) {
+        double acc = 0;
+        for (int b = 0; b < blocks; b++) acc += (double)part[(size_t)b * TRK_NRED + k];
+        s[k] = (float)acc;
+    }
     memset(out, 0, sizeof *out);
     out->E = s[45]; out->numTermsInE = (int)s[49]; out->numSaturated = (int)s[50]; out->numRobust = (int)s[51]; out->numWarped = (int)s[52];
     out->flow[0] = s[46] / (s[48] + 0.1f); out->flow[1] = 0; out->flow[2] = s[47] / (s[48] + 0.1f);       // TR.cpp:412-414
