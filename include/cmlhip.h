@@ -284,6 +284,45 @@ int cmlhip_reproj_accumulate(cmlhip_ctx* ctx, int N, const double* poses /* N*12
 /* indirectX = ldlt(M6 with diag*(1+lambda)).solve(-b6) (BA.cpp:2695-2700) on the device */
 int cmlhip_reproj_solve(cmlhip_ctx* ctx, int N, double lambda, double* x6 /* 6N */);
 
+/* ---------------------------------------------------------------- immature points: DSOTracer
+ * trace(): epipolar search of every immature point in a new frame (DSOTracer.cpp:585-823); optimizeImmaturePoint():
+ * the per-point Gauss-Newton on activation (DSOTracer.cpp:280-404, linearizeResidual :406-494).  The pattern is star8. */
+enum { CMLHIP_IPS_GOOD = 0, CMLHIP_IPS_OOB = 1, CMLHIP_IPS_OUTLIER = 2, CMLHIP_IPS_SKIPPED = 3, CMLHIP_IPS_BADCONDITION = 4,
+       CMLHIP_IPS_UNINITIALIZED = 5 };                              /* DSOTracerStatus, DSOPoint.h:12-19 */
+typedef struct {            /* DSOTracerPointPrivate (DSOTracer.h:17-33) + the MapPoint fields the tracer reads */
+    float  x, y;            /* reference corner, level 0 */
+    int    host;            /* index of the reference frame in the per-call frame list */
+    int    last_status;     /* lastTraceStatus (in/out) */
+    double idepth_min, idepth_max;                                   /* iDepthMin / iDepthMax (in/out; max may be NaN) */
+    double gradH[4];        /* row-major 2x2 */
+    double energy_th, quality;
+    double last_uv[2], last_pixel_interval;                          /* lastTraceUV, lastTracePixelInterval (out) */
+    float  gray[8];         /* MapPoint::getGrayPatch at the pattern pixels (MapObject.h:392-401) */
+    float  dpatch[24];      /* MapPoint::getDerivativePatch (I, dI/dx, dI/dy) at the pattern pixels (:403-412) */
+} cmlhip_immature_point;
+typedef struct {            /* reference frame -> traced frame, formed as DSOTracer.cpp:608-610 */
+    double KRKi[9], Kt[3];  /* K R K^-1 and K t of host -> frame (level 0) */
+    double aff_a, aff_b;    /* referenceFrame.getExposure().to(frame.getExposure()) */
+} cmlhip_trace_pair;
+typedef struct {            /* DSOTracer.h:188-206 (values as Parameter stores them: float literals widened to double) */
+    double max_pix_search, max_slack_interval, trace_step_size, min_improvement_factor, min_trace_test_radius,
+           extra_slack_on_th, huber_th, outlier_th_sum_component, min_idepth_h_act;
+    int    gn_its_on_activation, pad;
+} cmlhip_tracer_params;
+/* traceNewCoarse's per-point work: points[i] is traced in `image_id` with pairs[points[i].host]; every field trace() writes
+ * is updated in place.  A point whose host IS the traced frame must not be passed (trace() returns early for it). */
+int cmlhip_trace_points(cmlhip_ctx* ctx, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
+                        const cmlhip_trace_pair* pairs, int n, cmlhip_immature_point* points);
+typedef struct {            /* host -> target of the activation window: Camera::to and Exposure::to (DSOTracer.cpp:418-420) */
+    double R[9], t[3], aff_a, aff_b;
+} cmlhip_activation_pair;
+/* optimizeImmaturePoint for n points over the N frames `image_ids` (level-0 pinhole K = fx,fy,cx,cy): pairs[h*N+t].
+ * result[i] = 1 activate / 0 keep immature / -1 remove (the return value of the reference); idepth[i] is the optimised
+ * inverse depth when result is 1; res_state[i*N + t] = final state_state of the residual into frame t (-1 for t == host). */
+int cmlhip_optimize_immature_points(cmlhip_ctx* ctx, int N, const uint64_t* image_ids, const double K[4],
+                                    const cmlhip_activation_pair* pairs, const cmlhip_tracer_params* prm, int min_obs,
+                                    int n, const cmlhip_immature_point* points, int* result, float* idepth, int* res_state);
+
 /* ---------------------------------------------------------------- marginalisation (once per keyframe), SURVEY §8 a15
  * tryMarginalize's residual loop (BA.cpp:2291-2304) for the points that are about to be marginalised: every residual of the
  * listed points is reset (resetOOB), re-linearised at the current state, committed (applyRes(true)) and, when good,

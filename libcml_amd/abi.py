@@ -117,3 +117,25 @@ class BAFrameState(C.Structure):
     """cmlhip_ba_frame_state (device-resident iterations)."""
     _fields_ = [("eval_q", C.c_double * 4), ("eval_t", C.c_double * 3), ("state", C.c_double * 10), ("state_zero", C.c_double * 10),
                 ("prior_zero", C.c_double * 8), ("ab_exposure", C.c_double), ("fix_pose", C.c_int), ("pad", C.c_int)]
+
+
+# ---- immature points (DSOTracer, SURVEY §8 f1)
+IPS_GOOD, IPS_OOB, IPS_OUTLIER, IPS_SKIPPED, IPS_BADCONDITION, IPS_UNINITIALIZED = range(6)
+IMMATURE_POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("host", "<i4"), ("last_status", "<i4"), ("idepth_min", "<f8"), ("idepth_max", "<f8"),
+                                 ("gradH", "<f8", (4,)), ("energy_th", "<f8"), ("quality", "<f8"), ("last_uv", "<f8", (2,)),
+                                 ("last_pixel_interval", "<f8"), ("gray", "<f4", (8,)), ("dpatch", "<f4", (24,))])
+TRACE_PAIR_DTYPE = np.dtype([("KRKi", "<f8", (9,)), ("Kt", "<f8", (3,)), ("aff_a", "<f8"), ("aff_b", "<f8")])
+ACTIVATION_PAIR_DTYPE = np.dtype([("R", "<f8", (9,)), ("t", "<f8", (3,)), ("aff_a", "<f8"), ("aff_b", "<f8")])
+
+
+class TracerParams(C.Structure):
+    _fields_ = [("max_pix_search", C.c_double), ("max_slack_interval", C.c_double), ("trace_step_size", C.c_double),
+                ("min_improvement_factor", C.c_double), ("min_trace_test_radius", C.c_double), ("extra_slack_on_th", C.c_double),
+                ("huber_th", C.c_double), ("outlier_th_sum_component", C.c_double), ("min_idepth_h_act", C.c_double),
+                ("gn_its_on_activation", C.c_int), ("pad", C.c_int)]
+
+
+def default_tracer_params():
+    """DSOTracer.h:188-206: Parameters hold doubles initialised from float literals."""
+    f = lambda v: float(np.float32(v))
+    return TracerParams(f(0.027), f(1.5), f(1.0), f(2.0), f(2.0), f(1.2), f(9.0), f(50.0 * 50.0), f(100.0), 3, 0)

@@ -46,6 +46,8 @@ PROTOTYPES = {
     "cmlhip_profile_enable": (C.c_int, [_ctx, _i]),
     "cmlhip_debug_timestamps": (C.c_int, [_ctx, _i, _P(C.c_longlong)]),
     "cmlhip_profile_stride": (C.c_int, [_ctx, _i]),
+    "cmlhip_trace_points": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, C.c_void_p]),
+    "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
     "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "cmlhip_ba_lin_energy": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(C.c_double), _P(C.c_int)]),
@@ -356,6 +358,23 @@ class Ctx:
         n = _i()
         self.ck(self.L.cmlhip_tracker_get_warped(self.h, _p(out, _f), capacity, C.byref(n)))
         return out[:, :min(n.value, capacity)], n.value
+
+    # ------------------------------------------------------------------ immature points (DSOTracer)
+    def trace_points(self, image_id, prm, pairs, points):
+        """points: IMMATURE_POINT_DTYPE array, updated in place and returned."""
+        pairs = np.ascontiguousarray(pairs, abi.TRACE_PAIR_DTYPE); points = np.ascontiguousarray(points, abi.IMMATURE_POINT_DTYPE)
+        self.ck(self.L.cmlhip_trace_points(self.h, int(image_id), C.byref(prm), len(pairs), pairs.ctypes.data, len(points), points.ctypes.data))
+        return points
+
+    def optimize_immature_points(self, image_ids, K, pairs, prm, min_obs, points):
+        N = len(image_ids)
+        ids = np.ascontiguousarray(image_ids, np.uint64); K = np.ascontiguousarray(K, np.float64)
+        pairs = np.ascontiguousarray(pairs, abi.ACTIVATION_PAIR_DTYPE); points = np.ascontiguousarray(points, abi.IMMATURE_POINT_DTYPE)
+        n = len(points)
+        res = np.zeros(n, np.int32); idp = np.zeros(n, np.float32); st = np.zeros((n, N), np.int32)
+        self.ck(self.L.cmlhip_optimize_immature_points(self.h, N, _p(ids, C.c_uint64), _p(K, _d), pairs.ctypes.data, C.byref(prm), int(min_obs), n,
+                                                        points.ctypes.data, _p(res, C.c_int), _p(idp, _f), _p(st, C.c_int)))
+        return res, idp, st
 
     # ------------------------------------------------------------------ reproj
     def reproj_accumulate(self, poses, points, obs, fx, fy):

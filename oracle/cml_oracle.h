@@ -178,4 +178,14 @@ void orc_reproj_accumulate(int N, const double* poses, int M, const double* poin
 #ifdef __cplusplus
 }
 #endif
+
+/* ------------------------------------------------------------------ immature points: DSOTracer */
+/* DSOTracer::trace, DSOTracer.cpp:585-823: aos3 = level-0 gradient image of the traced frame (channel 0 = gray) */
+int orc_trace_point(const float* aos3, int w, int h, const cmlhip_trace_pair* pair, const cmlhip_tracer_params* prm,
+                    cmlhip_immature_point* point);
+/* DSOTracer::optimizeImmaturePoint + linearizeResidual, DSOTracer.cpp:280-494 */
+int orc_optimize_immature_point(int N, const float* const* images, int w, int h, const double K[4], const cmlhip_activation_pair* pairs,
+                                const cmlhip_tracer_params* prm, int min_obs, const cmlhip_immature_point* point, float* idepth_out,
+                                int* res_state);
+
 #endif

@@ -278,3 +278,39 @@ def test_marginalisation_restatement():
     # linearized energy: sum over the LINEARIZED good residuals of (2 res_toZero + J delta) . J delta + priors (BA.cpp:2119-2208)
     e, num = ob.l_energy()
     assert num == int(lin.sum())
+
+
+def test_tracer_restatement_recovers_depth():
+    """SURVEY §8 f1 (DSOTracer).  The restatement is pinned functionally: on exact synthetic geometry the epipolar search
+    must bracket the true inverse depth, a second trace from another frame must shrink the interval, and the activation
+    Gauss-Newton must land on the true inverse depth."""
+    from libcml_amd import abi, synth
+    from tests import tracer_setup as TS
+    W = synth.make_window("small", eval_noise=0.0, idepth_noise=0.0, state_noise=0.0)
+    grads0 = [O.build_pyramid(W.gray[k], 1)[1][0] for k in range(W.N)]
+    prm = abi.default_tracer_params()
+    pts = TS.make_immature(W, grads0)
+    f1, f2 = 1, 2                      # a fresh point is first traced in the frames right after its host (small baseline:
+    sel = pts["host"] == 0             # the search is limited to maxPixSearch = 2.7 % of (w+h) pixels, DSOTracer.cpp:611)
+    p0 = pts[sel]
+    truth = W.pts["idepth_true"][sel]
+    p1 = TS.oracle_trace(grads0[f1], TS.trace_pairs(W, f1), prm, p0)
+    good1 = p1["last_status"] == abi.IPS_GOOD
+    assert good1.sum() > 0.5 * len(p1), np.bincount(p1["last_status"], minlength=6)
+    inside1 = (p1["idepth_min"] <= truth * 1.02) & (p1["idepth_max"] >= truth * 0.98)
+    assert inside1[good1].mean() > 0.8            # the error bound of the search is a heuristic (DSOTracer.cpp:690-697)
+    assert np.all(p1["idepth_max"][good1] >= p1["idepth_min"][good1])
+    assert np.all((p1["last_status"] != abi.IPS_GOOD) | (p1["last_pixel_interval"] > 0))
+    p2 = TS.oracle_trace(grads0[f2], TS.trace_pairs(W, f2), prm, p1)
+    both = good1 & (p2["last_status"] == abi.IPS_GOOD)
+    assert both.sum() > 20
+    w1 = p1["idepth_max"][both] - p1["idepth_min"][both]; w2 = p2["idepth_max"][both] - p2["idepth_min"][both]
+    assert np.median(w2 / w1) < 1.0
+    # activation: per-point Gauss-Newton over the window
+    cand = p2[np.isfinite(p2["idepth_max"]) & (p2["last_status"] != abi.IPS_OOB)]
+    tr = W.pts["idepth_true"][sel][np.isfinite(p2["idepth_max"]) & (p2["last_status"] != abi.IPS_OOB)]
+    res, idp, st = TS.oracle_optimize(grads0, W.K, TS.activation_pairs(W), prm, 1, cand)
+    ok = res == 1
+    assert ok.sum() > 20, np.bincount(res + 1, minlength=3)
+    assert np.median(np.abs(idp[ok] / tr[ok] - 1)) < 0.02
+    assert np.all(st[ok][np.arange(ok.sum()), cand["host"][ok]] == -1)

@@ -1,0 +1,62 @@
+"""SURVEY §8 f1 on the device: DSOTracer::trace and optimizeImmaturePoint through the C ABI against the oracle.
+Bar: BIT-EXACT (statuses, inverse-depth intervals, quality, traced position; activation result, inverse depth, residual
+states) — scalar_t double with the reference's float places kept float, fp contraction off."""
+import numpy as np
+import pytest
+
+from libcml_amd import abi, device, synth
+from tests import oracle_lib as O
+from tests import tracer_setup as TS
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("last_status", "idepth_min", "idepth_max", "quality", "last_uv", "last_pixel_interval")
+
+
+def _same(a, b, name):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.dtype.kind == "f":
+        u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+        bad = a.view(u) != b.view(u)
+        bad &= ~(np.isnan(a) & np.isnan(b))
+        assert not bad.any(), (name, int(bad.sum()), a[bad][:4], b[bad][:4])
+    else:
+        assert np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize("config,kw", [("small", {}), ("medium", dict(eval_noise=0.0, idepth_noise=0.0, state_noise=0.0))])
+def test_trace_and_activation_bit_exact(config, kw):
+    W = synth.make_window(config, **kw)
+    grads0 = [O.build_pyramid(W.gray[k], 1)[1][0] for k in range(W.N)]
+    ctx = device.Ctx(max_frames=W.N)
+    try:
+        ids = [900 + k for k in range(W.N)]
+        for k in range(W.N):
+            ctx.pyramid_put(ids[k], 0, grads0[k])
+        prm = abi.default_tracer_params()
+        pts = TS.make_immature(W, grads0)
+        cur_o = pts.copy(); cur_d = pts.copy()
+        hist = np.zeros(6, int)
+        # every point is traced in the frames after its host, nearest first (traceNewCoarse per new frame)
+        for f in range(1, W.N):
+            sel = np.flatnonzero(pts["host"] < f)
+            pr = TS.trace_pairs(W, f)
+            o = TS.oracle_trace(grads0[f], pr, prm, cur_o[sel])
+            d = ctx.trace_points(ids[f], prm, pr, cur_d[sel])
+            for name in FIELDS:
+                _same(o[name], d[name], "%s @ frame %d" % (name, f))
+            cur_o[sel] = o; cur_d[sel] = d
+            hist += np.bincount(o["last_status"], minlength=6)
+        assert hist[abi.IPS_GOOD] > 50 and hist[abi.IPS_OOB] > 0 and (hist[abi.IPS_SKIPPED] + hist[abi.IPS_BADCONDITION] + hist[abi.IPS_OUTLIER]) > 0, hist
+        # activation candidates: what activatePoints lets through (finite interval, not OOB)
+        cand = cur_o[np.isfinite(cur_o["idepth_max"]) & (cur_o["last_status"] != abi.IPS_OOB)]
+        assert len(cand) > 30
+        apr = TS.activation_pairs(W)
+        ro, io, so = TS.oracle_optimize(grads0, W.K, apr, prm, 1, cand)
+        rd, idd, sd = ctx.optimize_immature_points(ids, W.K, apr, prm, 1, cand)
+        assert np.array_equal(ro, rd), (np.bincount(ro + 1, minlength=3), np.bincount(rd + 1, minlength=3))
+        _same(io, idd, "activated idepth")
+        assert np.array_equal(so[ro == 1], sd[rd == 1])
+        assert (ro == 1).sum() > 10 and (ro != 1).sum() > 0
+    finally:
+        ctx.close()
