@@ -60,6 +60,14 @@ def lib():
         L.cmlhost_tracker_optimize.argtypes = [_vp, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_i), _P(_i), _P(_d),
                                                _P(_d), _P(_d), _P(_i), _P(_i), _P(_i)]
         L.cmlhost_tracker_last_error.restype = C.c_char_p; L.cmlhost_tracker_last_error.argtypes = [_vp]
+        L.cmlhost_tracer_create.restype = _vp; L.cmlhost_tracer_create.argtypes = [_vp]
+        L.cmlhost_tracer_destroy.argtypes = [_vp]
+        L.cmlhost_tracer_add_point.argtypes = [_vp, _f, _f, _i, _P(_f), _P(_f), _P(_d), _f]
+        L.cmlhost_tracer_trace.argtypes = [_vp, C.c_uint64, _i, _i, _P(_i), _vp, _P(_i)]
+        L.cmlhost_tracer_activate.argtypes = [_vp, _i, _P(_i), _P(C.c_uint64), _P(_d), _i, _i, _vp, _P(_i), _i]
+        L.cmlhost_tracer_count.argtypes = [_vp]
+        L.cmlhost_tracer_get_points.argtypes = [_vp, _vp, _P(_u8), _P(_u8), _P(_f)]
+        L.cmlhost_tracer_last_error.restype = C.c_char_p; L.cmlhost_tracer_last_error.argtypes = [_vp]
         _lib = L
     return _lib
 
@@ -252,6 +260,53 @@ class HostTracker:
                                         _p(nsat, _i), _p(flow, _d), _p(rel, _d), _p(cov, _d), C.byref(ok), C.byref(sat), _p(its, _i))
         return dict(R=R.reshape(3, 3), t=t, exposure=ce, E=E, numTerms=nt, numSat=nsat, flow=flow, relAff=rel, covariance=cov,
                     isCorrect=bool(ok.value), tooManySaturated=bool(sat.value), iterations=its)
+
+
+class HostTracer:
+    """cml_amd::DSOTracer (flat mirror of the reference's immature-point tracer)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = lib()
+        self.h = self.L.cmlhost_tracer_create(ctx.h)
+
+    def close(self):
+        if self.h:
+            self.L.cmlhost_tracer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_point(self, x, y, host_frame_id, gray, dpatch, gradH, type=1.0):
+        g = np.ascontiguousarray(gray, np.float32); d = np.ascontiguousarray(dpatch, np.float32); G = np.ascontiguousarray(gradH, np.float64)
+        return self.L.cmlhost_tracer_add_point(self.h, float(x), float(y), int(host_frame_id), _p(g, _f), _p(d, _f), _p(G, _d), float(type))
+
+    def trace_new_coarse(self, image_id, traced_frame_id, frame_ids, pairs):
+        ids = np.ascontiguousarray(frame_ids, np.int32); pr = np.ascontiguousarray(pairs, abi.TRACE_PAIR_DTYPE)
+        counts = np.zeros(6, np.int32)
+        ok = self.L.cmlhost_tracer_trace(self.h, int(image_id), int(traced_frame_id), len(ids), _p(ids, _i), pr.ctypes.data, _p(counts, _i))
+        if not ok:
+            raise RuntimeError(self.L.cmlhost_tracer_last_error(self.h).decode())
+        return counts
+
+    def activate_points(self, frame_ids, image_ids, K, w, h, pairs):
+        ids = np.ascontiguousarray(frame_ids, np.int32); im = np.ascontiguousarray(image_ids, np.uint64)
+        Kd = np.ascontiguousarray(K, np.float64); pr = np.ascontiguousarray(pairs, abi.ACTIVATION_PAIR_DTYPE)
+        out = np.zeros(self.L.cmlhost_tracer_count(self.h) + 1, np.int32)
+        n = self.L.cmlhost_tracer_activate(self.h, len(ids), _p(ids, _i), _p(im, C.c_uint64), _p(Kd, _d), int(w), int(h), pr.ctypes.data, _p(out, _i), len(out))
+        if n < 0:
+            raise RuntimeError(self.L.cmlhost_tracer_last_error(self.h).decode())
+        return out[:n].copy()
+
+    def points(self):
+        n = self.L.cmlhost_tracer_count(self.h)
+        pts = np.zeros(n, abi.IMMATURE_POINT_DTYPE); alive = np.zeros(n, np.uint8); act = np.zeros(n, np.uint8); idp = np.zeros(n, np.float32)
+        self.L.cmlhost_tracer_get_points(self.h, pts.ctypes.data, _p(alive, _u8), _p(act, _u8), _p(idp, _f))
+        return pts, alive, act, idp
 
 
 def window_to_host_ba(ctx, W, image_id_base=1000, levels=1):

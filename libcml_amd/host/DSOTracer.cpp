@@ -1,0 +1,122 @@
+// DSOTracer.cpp — host mirror of CML::Optimization::DSOTracer over the C ABI (TRC.cpp = src/cml/optimization/dso/DSOTracer.cpp).
+#include "DSOTracer.h"
+#include <cmath>
+#include <cstring>
+
+namespace cml_amd {
+
+DSOTracer::DSOTracer(cmlhip_ctx* ctx) : mCtx(ctx) {
+    prm.max_pix_search = (double)0.027f; prm.max_slack_interval = (double)1.5f; prm.trace_step_size = (double)1.0f;
+    prm.min_improvement_factor = (double)2.0f; prm.min_trace_test_radius = (double)2.0f; prm.extra_slack_on_th = (double)1.2f;
+    prm.huber_th = (double)9.0f; prm.outlier_th_sum_component = (double)(50.0f * 50.0f); prm.min_idepth_h_act = (double)100.0f;
+    prm.gn_its_on_activation = 3; prm.pad = 0;
+}
+
+int DSOTracer::addImmaturePoint(float x, float y, int host_frame_id, const float gray[8], const float dpatch[24], const double gradH[4], float type) {
+    ImmaturePoint P;
+    std::memset(&P.d, 0, sizeof P.d);
+    P.d.x = x; P.d.y = y; P.d.host = -1; P.frame_id = host_frame_id;
+    P.d.last_status = CMLHIP_IPS_UNINITIALIZED;                                 // DSOTracer.h:21-28
+    P.d.idepth_min = 1.0 / 1000.0; P.d.idepth_max = NAN;
+    P.d.last_uv[0] = P.d.last_uv[1] = -1; P.d.last_pixel_interval = -1;
+    P.d.quality = 10000;
+    std::memcpy(P.d.gradH, gradH, sizeof P.d.gradH);
+    std::memcpy(P.d.gray, gray, sizeof P.d.gray);
+    std::memcpy(P.d.dpatch, dpatch, sizeof P.d.dpatch);
+    P.d.energy_th = 8 * mSettingOutlierTH;                                      // TRC.cpp:527
+    P.my_type = type;
+    if (!std::isfinite(P.d.energy_th)) return -1;                               // :531-534
+    mPoints.push_back(P);
+    return (int)mPoints.size() - 1;
+}
+
+static int indexOf(const std::vector<int>& ids, int id) {
+    for (size_t i = 0; i < ids.size(); i++) if (ids[i] == id) return (int)i;
+    return -1;
+}
+
+bool DSOTracer::traceNewCoarse(uint64_t traced_image_id, int traced_frame_id, const std::vector<int>& frame_ids,
+                               const std::vector<cmlhip_trace_pair>& pairs, int counts[6]) {
+    std::vector<cmlhip_immature_point> batch;
+    std::vector<int> who;
+    for (int c = 0; c < 6; c++) counts[c] = 0;
+    for (int i = 0; i < (int)mPoints.size(); i++) {
+        ImmaturePoint& P = mPoints[i];
+        if (!P.alive || P.activated) continue;
+        const int h = indexOf(frame_ids, P.frame_id);
+        if (h < 0) { P.alive = false; continue; }                               // reference frame left the group, TRC.cpp:20-26
+        if (P.frame_id == traced_frame_id) { counts[P.d.last_status]++; continue; }   // trace() returns the old status, :597-599
+        P.d.host = h;
+        batch.push_back(P.d); who.push_back(i);
+    }
+    if (!batch.empty()) {
+        const int rc = cmlhip_trace_points(mCtx, traced_image_id, &prm, (int)pairs.size(), pairs.data(), (int)batch.size(), batch.data());
+        if (rc) { mError = std::string("cmlhip_trace_points: ") + cmlhip_last_error(mCtx); return false; }
+    }
+    for (size_t k = 0; k < who.size(); k++) {
+        mPoints[who[k]].d = batch[k];
+        counts[batch[k].last_status]++;
+    }
+    return true;
+}
+
+bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vector<uint64_t>& image_ids, const double K[4], int w, int h,
+                               const std::vector<cmlhip_activation_pair>& pairs, std::vector<int>& activated, const SpacingPolicy& spacing) {
+    const int N = (int)frame_ids.size(), last = N - 1;
+    activated.clear();
+    numSkippedBecauseStatus = numSkippedBecausePixelInterval = numSkippedBecauseQuality = numSkippedBecauseDepth = 0;
+    numDeletedBecauseOutlier = numDeletedBecauseOOB = numMapped = numNonMapped = numDropped = 0;
+    std::vector<cmlhip_immature_point> batch;
+    std::vector<int> who;
+    for (int i = 0; i < (int)mPoints.size(); i++) {
+        ImmaturePoint& P = mPoints[i];
+        if (!P.alive || P.activated) continue;
+        const int hst = indexOf(frame_ids, P.frame_id);
+        if (hst == last) continue;                                              // TRC.cpp:120-122
+        if (hst < 0) { P.alive = false; continue; }                             // :124-127
+        if (!std::isfinite(P.d.idepth_max) || P.d.last_status == CMLHIP_IPS_OUTLIER) { P.alive = false; numDeletedBecauseOutlier++; continue; }   // :129-134
+        const bool okStatus = P.d.last_status == CMLHIP_IPS_GOOD || P.d.last_status == CMLHIP_IPS_SKIPPED ||
+                              P.d.last_status == CMLHIP_IPS_BADCONDITION || P.d.last_status == CMLHIP_IPS_OOB;
+        const bool okInterval = P.d.last_pixel_interval < 8;
+        const bool okQuality = P.d.quality > mSettingsMinTraceQuality;
+        const bool okDepth = (P.d.idepth_max + P.d.idepth_min) > 0;
+        if (!okStatus) numSkippedBecauseStatus++;
+        if (!okInterval) numSkippedBecausePixelInterval++;
+        if (!okQuality) numSkippedBecauseQuality++;
+        if (!okDepth) numSkippedBecauseDepth++;
+        if (!(okStatus && okInterval && okQuality && okDepth)) {
+            if (P.d.last_status == CMLHIP_IPS_OOB) { P.alive = false; numDeletedBecauseOOB++; }    // :170-176
+            continue;
+        }
+        // projection into the last frame at the centre of the interval, TRC.cpp:181-183
+        const double idepth = (P.d.idepth_min + P.d.idepth_max) / 2.0;
+        const cmlhip_activation_pair& hl = pairs[(size_t)hst * N + last];
+        const double ux = ((double)P.d.x - K[2]) * (1.0 / K[0]), uy = ((double)P.d.y - K[3]) * (1.0 / K[1]);
+        const double p0 = hl.R[0] * ux + hl.R[1] * uy + hl.R[2] + hl.t[0] * idepth, p1 = hl.R[3] * ux + hl.R[4] * uy + hl.R[5] + hl.t[1] * idepth,
+                     p2 = hl.R[6] * ux + hl.R[7] * uy + hl.R[8] + hl.t[2] * idepth;
+        const double u = (p0 / p2) * K[0] + K[2], v = (p1 / p2) * K[1] + K[3];
+        if (!(u >= 0 && v >= 0 && u < w && v < h)) { P.alive = false; continue; }                 // :185,193-197
+        if (spacing && !spacing(u, v, P.my_type)) continue;                                        // DistanceMap test, :186-191
+        P.d.host = hst;
+        batch.push_back(P.d); who.push_back(i);
+    }
+    if (batch.empty()) return true;
+    std::vector<int> result(batch.size()), states(batch.size() * (size_t)N);
+    std::vector<float> idp(batch.size());
+    const int rc = cmlhip_optimize_immature_points(mCtx, N, image_ids.data(), K, pairs.data(), &prm, 1, (int)batch.size(), batch.data(), result.data(),
+                                                   idp.data(), states.data());
+    if (rc) { mError = std::string("cmlhip_optimize_immature_points: ") + cmlhip_last_error(mCtx); return false; }
+    for (size_t k = 0; k < who.size(); k++) {                                   // TRC.cpp:216-247
+        ImmaturePoint& P = mPoints[who[k]];
+        if (result[k] == 1) {
+            P.activated = true; P.idepth = idp[k];
+            P.res_state.assign(states.begin() + k * N, states.begin() + (k + 1) * N);
+            activated.push_back(who[k]);
+            numMapped++;
+        } else if (result[k] == -1 || P.d.last_status == CMLHIP_IPS_OOB) { P.alive = false; numDropped++; }
+        else numNonMapped++;
+    }
+    return true;
+}
+
+}  // namespace cml_amd

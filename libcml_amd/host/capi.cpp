@@ -4,6 +4,7 @@
 #include <string>
 #include "DSOBundleAdjustment.h"
 #include "DSOTracker.h"
+#include "DSOTracer.h"
 
 using namespace cml_amd;
 
@@ -173,5 +174,33 @@ int cmlhost_tracker_optimize(void* h, uint64_t new_image, int levels, double R[9
     return res.isCorrect ? 1 : 0;
 }
 const char* cmlhost_tracker_last_error(void* h) { return static_cast<DSOTracker*>(h)->lastError().c_str(); }
+
+// ---- DSOTracer mirror
+void* cmlhost_tracer_create(cmlhip_ctx* ctx) { return new cml_amd::DSOTracer(ctx); }
+void cmlhost_tracer_destroy(void* h) { delete static_cast<cml_amd::DSOTracer*>(h); }
+int cmlhost_tracer_add_point(void* h, float x, float y, int host_frame_id, const float gray[8], const float dpatch[24], const double gradH[4], float type) {
+    return static_cast<cml_amd::DSOTracer*>(h)->addImmaturePoint(x, y, host_frame_id, gray, dpatch, gradH, type);
+}
+int cmlhost_tracer_trace(void* h, uint64_t image_id, int traced_frame_id, int n_frames, const int* frame_ids, const cmlhip_trace_pair* pairs, int counts[6]) {
+    std::vector<int> ids(frame_ids, frame_ids + n_frames);
+    std::vector<cmlhip_trace_pair> pr(pairs, pairs + n_frames);
+    return static_cast<cml_amd::DSOTracer*>(h)->traceNewCoarse(image_id, traced_frame_id, ids, pr, counts) ? 1 : 0;
+}
+int cmlhost_tracer_activate(void* h, int n_frames, const int* frame_ids, const uint64_t* image_ids, const double K[4], int w, int hgt,
+                            const cmlhip_activation_pair* pairs, int* activated, int cap) {
+    std::vector<int> ids(frame_ids, frame_ids + n_frames);
+    std::vector<uint64_t> im(image_ids, image_ids + n_frames);
+    std::vector<cmlhip_activation_pair> pr(pairs, pairs + (size_t)n_frames * n_frames);
+    std::vector<int> act;
+    if (!static_cast<cml_amd::DSOTracer*>(h)->activatePoints(ids, im, K, w, hgt, pr, act)) return -1;
+    for (size_t i = 0; i < act.size() && (int)i < cap; i++) activated[i] = act[i];
+    return (int)act.size();
+}
+int cmlhost_tracer_count(void* h) { return (int)static_cast<cml_amd::DSOTracer*>(h)->points().size(); }
+void cmlhost_tracer_get_points(void* h, cmlhip_immature_point* out, unsigned char* alive, unsigned char* activated, float* idepth) {
+    auto& P = static_cast<cml_amd::DSOTracer*>(h)->points();
+    for (size_t i = 0; i < P.size(); i++) { out[i] = P[i].d; alive[i] = P[i].alive; activated[i] = P[i].activated; idepth[i] = P[i].idepth; }
+}
+const char* cmlhost_tracer_last_error(void* h) { return static_cast<cml_amd::DSOTracer*>(h)->lastError().c_str(); }
 
 }  // extern "C"

