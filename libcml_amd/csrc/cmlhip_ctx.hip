@@ -97,6 +97,7 @@ void cmlhip_destroy(cmlhip_ctx* c) {
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->trk_host) hipHostFree(c->trk_host);
     for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
     hipEventDestroy(c->ev[0]);
     hipEventDestroy(c->ev[1]);

@@ -83,6 +83,8 @@ struct cmlhip_ctx {
     DevBuf trk_ref[8]; int trk_n[8] = {0}; int trk_last_n = 0;                    // per-level uvic lists
     DevBuf trk_warped;                                        // n x 8 floats + flag
     DevBuf trk_partial, trk_out;
+    float* trk_host = nullptr; unsigned trk_seq = 0;           // mapped, coherent host buffer: the tracker kernel writes its rows + a per-workgroup
+                                                              // sequence flag straight to host memory, the caller polls (no memcpy, no stream sync)
     DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt;      // makeCoarseDepth scratch
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x;

@@ -9,6 +9,9 @@
 // here (the Hessian is accumulated where the residual is computed); the per-point warped record is still
 // written, uncompacted, for parity tests and for callers that want it.
 #include "cmlhip_internal.h"
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -20,7 +23,8 @@ struct TrkArgs {
     float maxEnergy; double huber_d, cutoff_d, cutoff_base_d;
     float* warped;                           // n x 8 floats {idepth,u,v,dx,dy,residual,weight,refcolor}
     unsigned char* flag;                     // n: 1 = written to the warped buffer
-    float* partial;                          // gridDim x TRK_NRED
+    float* partial;                          // gridDim x TRK_NRED (device buffer, or the mapped host buffer)
+    unsigned* done; unsigned seq;            // host-visible per-workgroup flags (null: the caller copies `partial` back)
     int trips;                               // 256-point trips per workgroup (1 for the usual list sizes: more workgroups, one round trip each)
 };
 #define TRK_NRED 56   // 45 (H upper) + E + sT + sRT + sN + numTerms + numSat + numRobust + numWarped + pad(3)
@@ -45,6 +49,7 @@ __device__ __forceinline__ float4 trk_texel(const void* img, size_t i) {
 // workgroup rows in block order on the host — no atomics, no inter-workgroup fences.
 typedef float trk_float4 __attribute__((ext_vector_type(4)));
 #define TRK_LD 17
+#define TRK_HOST_BLOCKS 256
 
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
@@ -156,6 +161,11 @@ __global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
         float v = 0.f;
         if (src >= 0) v = ((s_tile[0][src] + s_tile[1][src]) + s_tile[2][src]) + s_tile[3][src];
         A.partial[(size_t)blockIdx.x * TRK_NRED + tid] = v;
+    }
+    if (A.done) {                                          // publish to the polling host: rows first, then the flag (system scope)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) { __hip_atomic_store(A.done + blockIdx.x, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
 }
 
@@ -306,12 +316,39 @@ int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const doubl
     A.flag = reinterpret_cast<unsigned char*>(c->trk_warped.as<float>() + 8 * (size_t)(n ? n : 1));
     A.partial = c->trk_partial.as<float>();
     c->trk_last_n = n;
+    // result path: up to TRK_HOST_BLOCKS workgroups write straight into a mapped host buffer that the caller polls
+    const bool direct = blocks <= TRK_HOST_BLOCKS && !getenv("CMLHIP_TRACKER_NO_HOST_POLL");
+    if (direct && !c->trk_host) {
+        CML_CHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->trk_host), TRK_HOST_BLOCKS * (TRK_NRED + 1) * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->trk_host, 0, TRK_HOST_BLOCKS * (TRK_NRED + 1) * sizeof(float));
+    }
+    if (direct) {
+        void* dptr = nullptr;
+        CML_CHECK(c, hipHostGetDevicePointer(&dptr, c->trk_host, 0));
+        A.partial = static_cast<float*>(dptr);
+        A.done = reinterpret_cast<unsigned*>(static_cast<float*>(dptr) + TRK_HOST_BLOCKS * TRK_NRED);
+        A.seq = ++c->trk_seq;
+        if (A.seq == 0) A.seq = ++c->trk_seq;
+    }
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_tracker_eval<true><<<blocks, 256, 0, c->stream>>>(A);
     else k_tracker_eval<false><<<blocks, 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
     // the workgroup rows are added here, in block order, fp64 (what the last-block pass of a fused finish would do)
     std::vector<float> part((size_t)blocks * TRK_NRED);
-    if ((rc = cml_d2h(c, part.data(), c->trk_partial.p, part.size() * sizeof(float)))) return rc;
+    if (direct) {
+        volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(c->trk_host + TRK_HOST_BLOCKS * TRK_NRED);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok = true;
+        for (int b = 0; b < blocks && ok; b++) {
+            unsigned spins = 0;
+            while (flags[b] != A.seq) {
+                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { ok = false; break; }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!ok) CML_CHECK(c, hipStreamSynchronize(c->stream));      // never spin forever: fall back to the stream
+        memcpy(part.data(), c->trk_host, part.size() * sizeof(float));
+    } else if ((rc = cml_d2h(c, part.data(), c->trk_partial.p, part.size() * sizeof(float)))) return rc;
     float s[TRK_NRED];
     for (int k = 0; k < TRK_NRED; k++) {
         double acc = 0;
