@@ -102,7 +102,10 @@ def main():
     W = synth.make_window(args.config, seed=seed, shard=rank)             # one independent sequence shard per rank
     N, P = W.N, W.P
     _dbg('window made')
-    ctx = device.Ctx(device_id=local_rank, max_frames=max(N, 2), max_points=P, max_residuals=P * N)
+    from libcml_amd import abi
+    half = args.config == "E"                                            # config E stores fp16 pyramids (fp32 arithmetic)
+    ctx = device.Ctx(device_id=local_rank, max_frames=max(N, 2), max_points=P, max_residuals=P * N,
+                     texel_format=abi.TEXEL_F16 if half else abi.TEXEL_F32)
     ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (rank + 1), levels=1)
     _dbg('ba built')
     ba.set_param("iterations", 1)
@@ -168,7 +171,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "
-                                   "gradient images, fp32; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (args.config, N, P, R, W.w, W.h),
+                                   "gradient images, %s texels / fp32 arithmetic; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (args.config, N, P, R, W.w, W.h, "fp16" if half else "fp32"),
                        "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
             "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
             "roofline": {"bound": "hbm", "kernel": "k_ba_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
