@@ -181,7 +181,7 @@ def main():
                                            "minus the empty bracket recorded next to it (raw %.2f us, empty %.2f us)" % (1e3 * lin_v, 1e3 * empty_v),
                          "rocprof_avg_us": rocprof_us},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, seed)
             except Exception as e:      # the checker must never take the measurement down
