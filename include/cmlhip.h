@@ -313,6 +313,13 @@ typedef struct {            /* DSOTracer.h:188-206 (values as Parameter stores t
  * is updated in place.  A point whose host IS the traced frame must not be passed (trace() returns early for it). */
 int cmlhip_trace_points(cmlhip_ctx* ctx, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
                         const cmlhip_trace_pair* pairs, int n, cmlhip_immature_point* points);
+/* The same with the immature set resident on the device (one launch + a 24-byte readback per traced frame): upload once,
+ * trace every point whose host is neither `skip_host` (the traced frame itself, DSOTracer.cpp:597-599: counted with its old
+ * status) nor negative (not in the window: untouched, not counted); counts[s] = number of points with status s afterwards. */
+int cmlhip_tracer_set_points(cmlhip_ctx* ctx, int n, const cmlhip_immature_point* points);
+int cmlhip_tracer_trace_resident(cmlhip_ctx* ctx, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
+                                 const cmlhip_trace_pair* pairs, int skip_host, int counts[6]);
+int cmlhip_tracer_get_points(cmlhip_ctx* ctx, int n, cmlhip_immature_point* points);
 typedef struct {            /* host -> target of the activation window: Camera::to and Exposure::to (DSOTracer.cpp:418-420) */
     double R[9], t[3], aff_a, aff_b;
 } cmlhip_activation_pair;

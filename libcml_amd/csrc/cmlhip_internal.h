@@ -68,7 +68,8 @@ struct cmlhip_ctx {
     DevBuf pair_blocks;                                       // N*N x PAIR_BLK doubles (stitched per-pair blocks)
     DevBuf adH, adT, adHTd, vec_small;                        // adjoints, adHTdeltaF, {cdelta,cprior,prior,delta_prior}
     DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec, Hf, bf;    // (8N+4)^2 / (8N+4) doubles; Hf/bf = final LM system
-    DevBuf tr_points, tr_pairs, tr_out;                       // immature-point tracer staging
+    DevBuf tr_points, tr_pairs, tr_out;
+    DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)
     bool resident_on = false, have_null = false, lin_finish_pending = false; int resident_iter = 0; double res_scales[4] = {1, 1, 1, 1};

@@ -53,14 +53,34 @@ struct TraceArgs {
     const cmlhip_trace_pair* pairs;
     cmlhip_tracer_params P;
     cmlhip_immature_point* pts;
+    int skip_host; int* counts;                // resident mode: host index of the traced frame, status histogram (null otherwise)
 };
 
 template <bool HALF>
+__global__ __launch_bounds__(256) void k_trace_points(TraceArgs A);
+
+// resident mode wrapper: one more wave-uniform test in front, the histogram behind
+template <bool HALF>
+__device__ __forceinline__ void trace_one(const TraceArgs& A, int pi);
+
+template <bool HALF>
 __global__ __launch_bounds__(256) void k_trace_points(TraceArgs A) {
-    __shared__ double s_err[4][128];
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int pi = blockIdx.x * 4 + wv;
     if (pi >= A.n) return;                                                         // wave-uniform
+    const int host = A.pts[pi].host;
+    if (host < 0) return;                                                          // not in the window
+    if (host != A.skip_host) trace_one<HALF>(A, pi);
+    if (A.counts && l == 0) {
+        __threadfence_block();
+        atomicAdd(A.counts + A.pts[pi].last_status, 1);
+    }
+}
+
+template <bool HALF>
+__device__ __forceinline__ void trace_one(const TraceArgs& A, const int pi) {
+    __shared__ double s_err[4][128];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     cmlhip_immature_point* s = A.pts + pi;
     const cmlhip_trace_pair* pr_ = A.pairs + s->host;
     const cmlhip_tracer_params& P = A.P;
@@ -353,10 +373,48 @@ int cmlhip_trace_points(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_pa
     TraceArgs A;
     A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
     A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_points.as<cmlhip_immature_point>();
+    A.skip_host = -2; A.counts = nullptr;
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_trace_points<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     else k_trace_points<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
     return cml_d2h(c, points, c->tr_points.p, sizeof(cmlhip_immature_point) * (size_t)n);
+}
+
+int cmlhip_tracer_set_points(cmlhip_ctx* c, int n, const cmlhip_immature_point* points) {
+    if (!c || n < 0 || (n > 0 && !points)) return CMLHIP_ERR_INVALID;
+    int rc;
+    if ((rc = cml_ensure(c, c->tr_resident, sizeof(cmlhip_immature_point) * (size_t)std::max(n, 1)))) return rc;
+    if (n > 0 && (rc = cml_h2d(c, c->tr_resident.p, points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
+    c->tr_resident_n = n;
+    return CMLHIP_OK;
+}
+
+int cmlhip_tracer_get_points(cmlhip_ctx* c, int n, cmlhip_immature_point* points) {
+    if (!c || n < 0 || n > c->tr_resident_n || (n > 0 && !points)) return CMLHIP_ERR_INVALID;
+    return n ? cml_d2h(c, points, c->tr_resident.p, sizeof(cmlhip_immature_point) * (size_t)n) : CMLHIP_OK;
+}
+
+int cmlhip_tracer_trace_resident(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts, const cmlhip_trace_pair* pairs,
+                                 int skip_host, int counts[6]) {
+    if (!c || !prm || n_hosts < 1 || !pairs || !counts) return CMLHIP_ERR_INVALID;
+    const Pyramid* py = cml_find_pyr(c, image_id);
+    CML_REQUIRE(c, py && py->lv[0].grad, CMLHIP_ERR_NOT_FOUND, "traced image not in the pyramid cache");
+    const int n = c->tr_resident_n;
+    for (int k = 0; k < 6; k++) counts[k] = 0;
+    if (n == 0) return CMLHIP_OK;
+    int rc;
+    if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_trace_pair) * (size_t)n_hosts))) return rc;
+    if ((rc = cml_ensure(c, c->tr_out, 64))) return rc;
+    if ((rc = cml_h2d(c, c->tr_pairs.p, pairs, sizeof(cmlhip_trace_pair) * (size_t)n_hosts))) return rc;
+    CML_CHECK(c, hipMemsetAsync(c->tr_out.p, 0, 24, c->stream));
+    TraceArgs A;
+    A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
+    A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_resident.as<cmlhip_immature_point>();
+    A.skip_host = skip_host; A.counts = c->tr_out.as<int>();
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_trace_points<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
+    else k_trace_points<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
+    CML_CHECK(c, hipGetLastError());
+    return cml_d2h(c, counts, c->tr_out.p, 24);
 }
 
 int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_ids, const double K[4], const cmlhip_activation_pair* pairs,

@@ -47,6 +47,9 @@ PROTOTYPES = {
     "cmlhip_debug_timestamps": (C.c_int, [_ctx, _i, _P(C.c_longlong)]),
     "cmlhip_profile_stride": (C.c_int, [_ctx, _i]),
     "cmlhip_trace_points": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, C.c_void_p]),
+    "cmlhip_tracer_set_points": (C.c_int, [_ctx, _i, C.c_void_p]),
+    "cmlhip_tracer_trace_resident": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, _P(C.c_int)]),
+    "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
     "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
@@ -365,6 +368,22 @@ class Ctx:
         pairs = np.ascontiguousarray(pairs, abi.TRACE_PAIR_DTYPE); points = np.ascontiguousarray(points, abi.IMMATURE_POINT_DTYPE)
         self.ck(self.L.cmlhip_trace_points(self.h, int(image_id), C.byref(prm), len(pairs), pairs.ctypes.data, len(points), points.ctypes.data))
         return points
+
+    def tracer_set_points(self, points):
+        points = np.ascontiguousarray(points, abi.IMMATURE_POINT_DTYPE)
+        self._tr_n = len(points)
+        self.ck(self.L.cmlhip_tracer_set_points(self.h, len(points), points.ctypes.data))
+
+    def tracer_trace_resident(self, image_id, prm, pairs, skip_host):
+        pairs = np.ascontiguousarray(pairs, abi.TRACE_PAIR_DTYPE)
+        counts = np.zeros(6, np.int32)
+        self.ck(self.L.cmlhip_tracer_trace_resident(self.h, int(image_id), C.byref(prm), len(pairs), pairs.ctypes.data, int(skip_host), _p(counts, C.c_int)))
+        return counts
+
+    def tracer_get_points(self):
+        out = np.zeros(self._tr_n, abi.IMMATURE_POINT_DTYPE)
+        self.ck(self.L.cmlhip_tracer_get_points(self.h, self._tr_n, out.ctypes.data))
+        return out
 
     def optimize_immature_points(self, image_ids, K, pairs, prm, min_obs, points):
         N = len(image_ids)

@@ -103,3 +103,32 @@ def test_host_tracer_flow():
         assert np.all(~np.isfinite(manual["idepth_max"][(alive == 0)]) | (manual["last_status"][(alive == 0)] != abi.IPS_GOOD) | True)
     finally:
         trc.close(); ctx.close()
+
+
+def test_resident_immature_set_equals_copy_path():
+    """cmlhip_tracer_set_points / _trace_resident / _get_points: the set stays on the device between frames; same results as
+    the per-call copy path, and the status histogram is the census of the whole set."""
+    W = synth.make_window("small")
+    grads0 = [O.build_pyramid(W.gray[k], 1)[1][0] for k in range(W.N)]
+    ctx = device.Ctx(max_frames=W.N)
+    try:
+        ids = [800 + k for k in range(W.N)]
+        for k in range(W.N):
+            ctx.pyramid_put(ids[k], 0, grads0[k])
+        prm = abi.default_tracer_params()
+        pts = TS.make_immature(W, grads0)
+        pts["host"][::17] = -1                                   # a few points whose host left the window: untouched, not counted
+        manual = pts.copy()
+        ctx.tracer_set_points(pts)
+        for f in range(1, W.N):
+            pr = TS.trace_pairs(W, f)
+            counts = ctx.tracer_trace_resident(ids[f], prm, pr, f)
+            sel = np.flatnonzero((manual["host"] >= 0) & (manual["host"] != f))
+            manual[sel] = ctx.trace_points(ids[f], prm, pr, manual[sel])
+            live = manual["host"] >= 0
+            assert np.array_equal(counts, np.bincount(manual["last_status"][live], minlength=6))
+        got = ctx.tracer_get_points()
+        for name in FIELDS:
+            _same(manual[name], got[name], name)
+    finally:
+        ctx.close()

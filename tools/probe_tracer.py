@@ -26,6 +26,12 @@ for f in range(1, W.N):
     cur[sel] = out
     print("trace into frame %d: %5d points  %.1f us per synchronous call (H2D %d KB + kernel + D2H)  status histogram %s" %
           (f, len(sel), dt * 1e6, len(sel) * pts.itemsize // 1024, np.bincount(out["last_status"], minlength=6)))
+ctx.tracer_set_points(pts)
+for f in range(1, W.N):
+    pr = TS.trace_pairs(W, f)
+    t0 = time.perf_counter()
+    counts = ctx.tracer_trace_resident(ids[f], prm, pr, f)
+    print("resident trace into frame %d: %5d points  %.1f us per call (pairs H2D + kernel + 24-byte readback)  %s" % (f, len(pts), (time.perf_counter() - t0) * 1e6, counts))
 cand = cur[np.isfinite(cur["idepth_max"]) & (cur["last_status"] != abi.IPS_OOB)]
 apr = TS.activation_pairs(W)
 for _ in range(3): ctx.optimize_immature_points(ids, W.K, apr, prm, 1, cand)
