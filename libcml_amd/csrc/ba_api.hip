@@ -56,7 +56,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     CML_REQUIRE(c, c->ba_prm_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_params not called");
     CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P >= 0 && P <= c->lim.max_points && R >= 0 && R <= c->lim.max_residuals,
                 CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     // ---- frames: resolve pyramids
     std::vector<FrameDev> fd(N);
     for (int i = 0; i < N; i++) {
@@ -396,15 +396,15 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     A.fuse_apply = 1;                                        // the step is always accepted here (forceAccept, BA.h:265)
     const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap && (c->prof_tick++ % c->prof_stride) == 0;
     hipEvent_t* ev = prof ? &c->prof_ev[6 * (size_t)c->prof_n] : nullptr;
-    if (prof) hipEventRecord(ev[0], c->stream);
+    if (prof) (void)hipEventRecord(ev[0], c->stream);
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
     cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2);   // K5: solve (+ orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
     c->resident_iter++;
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
-    if (prof) { hipEventRecord(ev[1], c->stream); hipEventRecord(ev[2], c->stream); }
+    if (prof) { (void)hipEventRecord(ev[1], c->stream); (void)hipEventRecord(ev[2], c->stream); }
     cml_launch_linearize(c, A);                              // K1: residuals + Jacobians (+ applyRes)
     c->lin_finish_pending = true;
-    if (prof) { hipEventRecord(ev[3], c->stream); hipEventRecord(ev[4], c->stream); hipEventRecord(ev[5], c->stream); c->prof_n++; }
+    if (prof) { (void)hipEventRecord(ev[3], c->stream); (void)hipEventRecord(ev[4], c->stream); (void)hipEventRecord(ev[5], c->stream); c->prof_n++; }
     CML_CHECK(c, hipGetLastError());
     return CMLHIP_OK;
 }
@@ -561,8 +561,8 @@ int cmlhip_debug_timestamps(cmlhip_ctx* c, int enable, long long* out128) {
 
 int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) {
     if (!c || max_iterations < 0) return CMLHIP_ERR_INVALID;
-    hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     c->prof_ev.clear();
     c->prof_cap = max_iterations; c->prof_n = 0; c->prof_tick = 0;
     c->prof_ev.resize(6 * (size_t)max_iterations);

@@ -6,14 +6,14 @@
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.bytes >= bytes) return CMLHIP_OK;
-    if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (b.p) { hipStreamSynchronize(c->stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     size_t cap = (bytes + 255) & ~size_t(255);
     CML_CHECK(c, hipMalloc(&b.p, cap));
     b.bytes = cap;
     return CMLHIP_OK;
 }
 void cml_free(DevBuf& b) {
-    if (b.p) hipFree(b.p);
+    if (b.p) (void)hipFree(b.p);
     b.p = nullptr; b.bytes = 0;
 }
 int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -73,18 +73,18 @@ int cmlhip_create(cmlhip_ctx** out, const cmlhip_limits* lim) {
     c->lim = *lim;
     c->device = lim->device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CMLHIP_ERR_HIP; }
-    hipEventCreate(&c->ev[0]);
-    hipEventCreate(&c->ev[1]);
+    (void)hipEventCreate(&c->ev[0]);
+    (void)hipEventCreate(&c->ev[1]);
     *out = c;
     return CMLHIP_OK;
 }
 
 void cmlhip_destroy(cmlhip_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pyr)
-        for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) hipFree(kv.second.lv[l].gray); }
+        for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) (void)hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) (void)hipFree(kv.second.lv[l].gray); }
     DevBuf* all[] = {&c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
                      &c->pt_colors, &c->pt_weights, &c->pt_backup, &c->pt_acc, &c->pt_step, &c->r_point, &c->r_host, &c->r_target,
                      &c->r_state, &c->r_new_state, &c->r_energy, &c->r_new_energy, &c->r_new_energy_wo, &c->r_ret_energy,
@@ -96,12 +96,12 @@ void cmlhip_destroy(cmlhip_ctx* c) {
                      &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
-    if (c->pinned) hipHostFree(c->pinned);
-    if (c->trk_host) hipHostFree(c->trk_host);
-    for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
-    hipEventDestroy(c->ev[0]);
-    hipEventDestroy(c->ev[1]);
-    hipStreamDestroy(c->stream);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->trk_host) (void)hipHostFree(c->trk_host);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->ev[0]);
+    (void)hipEventDestroy(c->ev[1]);
+    (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -189,8 +189,8 @@ __global__ void k_collapse_aos3(const void* __restrict__ img, float* __restrict_
 static size_t texel_bytes(const cmlhip_ctx* c) { return c->lim.texel_format == CMLHIP_TEXEL_F16 ? 8 : 16; }
 
 static void free_level(PyrLevel& L) {
-    if (L.grad) hipFree(L.grad);
-    if (L.gray) hipFree(L.gray);
+    if (L.grad) (void)hipFree(L.grad);
+    if (L.gray) (void)hipFree(L.gray);
     L = PyrLevel();
 }
 
@@ -200,7 +200,7 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
     if (!c || !aos3 || level < 0 || level >= 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
     PyrLevel& L = P.lv[level];
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     if (L.w != w || L.h != h) free_level(L);
     size_t n = (size_t)w * h;
     if (!L.grad) CML_CHECK(c, hipMalloc(&L.grad, n * texel_bytes(c)));
@@ -209,12 +209,12 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
     float* tmp = nullptr;
     CML_CHECK(c, hipMalloc((void**)&tmp, n * 3 * sizeof(float)));
     int rc = cml_h2d(c, tmp, aos3, n * 3 * sizeof(float));
-    if (rc) { hipFree(tmp); return rc; }
+    if (rc) { (void)hipFree(tmp); return rc; }
     int blocks = cml_div_up((int)n, 256);
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_expand_aos3<true><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
     else k_expand_aos3<false><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
-    hipStreamSynchronize(c->stream);
-    hipFree(tmp);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
     CML_CHECK(c, hipGetLastError());
     return CMLHIP_OK;
 }
@@ -222,7 +222,7 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
 int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, int h, int levels) {
     if (!c || !gray || levels < 1 || levels > 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < 8; l++) free_level(P.lv[l]);
     P.levels = levels;
     int cw = w, ch = h;
@@ -254,7 +254,7 @@ int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) {
     if (!c) return CMLHIP_ERR_INVALID;
     auto it = c->pyr.find(id);
     if (it == c->pyr.end()) return CMLHIP_ERR_NOT_FOUND;
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < 8; l++) free_level(it->second.lv[l]);
     c->pyr.erase(it);
     return CMLHIP_OK;
@@ -281,7 +281,7 @@ int cmlhip_pyramid_get(cmlhip_ctx* c, uint64_t id, int level, float* out) {
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_collapse_aos3<true><<<blocks, 256, 0, c->stream>>>(L.grad, tmp, (int)n);
     else k_collapse_aos3<false><<<blocks, 256, 0, c->stream>>>(L.grad, tmp, (int)n);
     int rc = cml_d2h(c, out, tmp, n * 3 * sizeof(float));
-    hipFree(tmp);
+    (void)hipFree(tmp);
     return rc;
 }
 
