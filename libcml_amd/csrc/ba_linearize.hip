@@ -162,26 +162,26 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const float u = (float)px, v = (float)py;            // BA.cpp:121-122: un-normalised x,y, literal
     const float fxf = (float)A.fx, fyf = (float)A.fy;
     float* rec = s_rec[g];
-    if (k == 0) {
-        rec[O_XI0 + 0] = new_idepth * fxf; rec[O_XI0 + 1] = 0; rec[O_XI0 + 2] = -new_idepth * u * fxf;
-        rec[O_XI0 + 3] = -u * v * fxf; rec[O_XI0 + 4] = (1 + u * u) * fxf; rec[O_XI0 + 5] = -v * fxf;
-    } else if (k == 1) {
-        rec[O_XI1 + 0] = 0; rec[O_XI1 + 1] = new_idepth * fyf; rec[O_XI1 + 2] = -new_idepth * v * fyf;
-        rec[O_XI1 + 3] = -(1 + v * v) * fyf; rec[O_XI1 + 4] = u * v * fyf; rec[O_XI1 + 5] = u * fyf;
-    } else if (k == 2) {
-        double c2 = drescale * (E6 * u - E0);
-        double c3 = (fxf * drescale) * (E7 * u - E1) / fyf;
-        double c0 = rx * c2, c1 = ry * c3;
-        rec[O_C0 + 0] = (float)((c0 + u) * A.scale_f); rec[O_C0 + 1] = (float)(c1 * A.scale_f);
-        rec[O_C0 + 2] = (float)((c2 + 1) * A.scale_c); rec[O_C0 + 3] = (float)(c3 * A.scale_c);
-        rec[O_DD + 0] = (float)(drescale * (et0 - et2 * u) * fxf);
-        rec[O_DD + 1] = (float)(drescale * (et1 - et2 * v) * fyf);
-    } else if (k == 3) {
-        double d2 = (fyf * drescale) * (E6 * v - E3) / fxf;
-        double d3 = drescale * (E7 * v - E4);
-        double d0 = rx * d2, d1 = ry * d3;
-        rec[O_C1 + 0] = (float)(d0 * A.scale_f); rec[O_C1 + 1] = (float)((d1 + v) * A.scale_f);
-        rec[O_C1 + 2] = (float)(d2 * A.scale_c); rec[O_C1 + 3] = (float)((d3 + 1) * A.scale_c);
+    // Same instructions in every lane, per-lane operands (four lane-divergent branches with two fp64 divisions cost ~1 us):
+    //   lane k < 6   Jpdxi[0][k], Jpdxi[1][k]                                       (fp32, BA.cpp:133-147)
+    //   lane k       one entry of Jpdc: ((m * q) + add) * scale with q = (sfac * drescale) * (Ea * w - Eb) / s2   (:150-176)
+    //                lanes 0-3 -> Jpdc[0][k], lanes 4-7 -> Jpdc[1][k-4]; multiplications by 1 and the addition of -0.0 are exact
+    //   lane k < 2   Jpdd[k] = drescale * (t0[k] - t0[2] * {u,v}) * {fx,fy}                                        (:178-182)
+    {
+        const float xi0 = k == 0 ? new_idepth * fxf : (k == 1 ? 0.f : (k == 2 ? -new_idepth * u * fxf : (k == 3 ? -u * v * fxf : (k == 4 ? (1 + u * u) * fxf : -v * fxf))));
+        const float xi1 = k == 0 ? 0.f : (k == 1 ? new_idepth * fyf : (k == 2 ? -new_idepth * v * fyf : (k == 3 ? -(1 + v * v) * fyf : (k == 4 ? u * v * fyf : u * fyf))));
+        if (k < 6) { rec[O_XI0 + k] = xi0; rec[O_XI1 + k] = xi1; }
+        const bool odd = k & 1, lo = k < 4;
+        const double Ea = odd ? E7 : E6, Eb = lo ? (odd ? E1 : E0) : (odd ? E4 : E3);
+        const float wq = lo ? u : v;
+        const float sfac = lo ? (odd ? fxf : 1.f) : (odd ? 1.f : fyf), s2 = lo ? (odd ? fyf : 1.f) : (odd ? 1.f : fxf);
+        const double q = (sfac * drescale) * (Ea * wq - Eb) / s2;
+        const double m = (k & 2) ? 1.0 : (odd ? ry : rx);
+        const double add = k == 0 ? (double)u : (k == 5 ? (double)v : ((k == 2 || k == 7) ? 1.0 : -0.0));
+        const double scl = (k & 2) ? A.scale_c : A.scale_f;
+        rec[lo ? O_C0 + k : O_C1 + (k - 4)] = (float)(((m * q) + add) * scl);
+        const double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
+        if (k < 2) rec[O_DD + k] = (float)dd;
     }
     // the sums of this lane: form A -> JIdx2 (J00 J10 J10 J11), JabJIdx (Q00 Q10 Q01 Q11), r^T r; B -> JI^T r, Jab^T r; C -> Jab2
     rec[k < 1 ? O_JI2 : (k < 2 ? O_JI2 + 1 : (k < 3 ? O_JI2 + 3 : (k < 7 ? O_JABJI + (k - 3) : O_X_RR)))] = sumA;
