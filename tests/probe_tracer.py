@@ -1,4 +1,5 @@
-"""Timing of the immature-point kernels (DSOTracer::trace / optimizeImmaturePoint) at the BA benchmark's scene size."""
+"""(kept under tests/: it builds its inputs with the oracle-side helpers, which only tests may use)
+Timing of the immature-point kernels (DSOTracer::trace / optimizeImmaturePoint) at the BA benchmark's scene size."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
