@@ -367,6 +367,12 @@ typedef struct {
  * row-major, zero rows allowed) of the gauge nullspace: from the third iteration on x -= U^T (U x) (BA.cpp:1196-1261,1404). */
 int cmlhip_ba_set_resident_state(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, const cmlhip_ba_frame_state* frames,
                                  const double scales[4], const double* nullspace_basis /* 7*(8N+4) or NULL */);
+/* Mirror of BA::run's early exit (`if (canbreak && it >= 1) break`, BA.cpp:879, canbreak from doStepFromBackup :996-1027 with
+ * thOptIterations): after the call, the iteration whose step passes the test is the last one that runs — the kernels of the
+ * iterations enqueued behind it return at once.  th <= 0 switches the test off (every enqueued iteration runs). */
+int cmlhip_ba_resident_convergence(cmlhip_ctx* ctx, double th_opt_iterations);
+/* number of iterations that ran and the photometric energy after each of them (statEnergyP); synchronises */
+int cmlhip_ba_get_resident_log(cmlhip_ctx* ctx, int* iterations, double* energies, int capacity);
 /* frame states after the iterations enqueued so far (synchronises); pre_w2c: N x 7 (q, t) of PRE_worldToCam, may be NULL;
  * last_pass: energy / census / setNewFrameEnergyTH of the last residual pass (what cmlhip_ba_linearize returns), may be NULL */
 int cmlhip_ba_get_resident_state(cmlhip_ctx* ctx, cmlhip_ba_frame_state* frames, double* pre_w2c, cmlhip_ba_lin_result* last_pass);

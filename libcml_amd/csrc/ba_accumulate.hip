@@ -349,6 +349,7 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
 __global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
     const int NN = A.N * A.N;
     DBG_BLK(A.dbg, 1, 0);
+    if (A.ctl && A.ctl->stop) return;                      // converged: the loop of BA::run has left (BA.cpp:879)
     if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode);
     else point_rows_block(A, X, blockIdx.x - NN);      // 16 points per 1024-thread block
     DBG_BLK_END(A.dbg, 1);
@@ -436,6 +437,7 @@ __global__ void k_ba_point_rows_marg(BAArgs A, AccArgs X) {
 
 // ------------------------------------------------------------------------------------------------ K4
 struct SysArgs {
+    const int* stop;                                        // early-exit flag of the resident loop (may be null)
     int N, n, ldg, ntile, P, use_lin_blocks, nsl, nsyrk;    // nsl point slices per tile, nsyrk = ntiles*nsl SYRK workgroups (0: row blocks only)
     double* part;                                           // SYRK partial tiles [tile][slice][256]
     const double* G; const double* Wt;
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
     __shared__ double s_part[SYS_NW][256];
     __shared__ double s_f[2][FS_STRIDE];          // [ACTIVE | LINEARIZED] D (64) C (32) B (8) of this frame, or CC (16) bC (4)
     DBG_BLK(S.dbg, 2, 0);
+    if (S.stop && *S.stop) return;
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, NT = 64 * SYS_NW;
     const int N = S.N, n = S.n;
     if ((int)blockIdx.x < S.nsyrk) {
@@ -736,6 +739,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
     DBG_BLK(A.dbg, 3, 0);
+    if (A.ctl && A.ctl->stop) return;
     if (blockIdx.x == 1) {
         if (do_finish) lin_finish_block(A, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw,
                                         reinterpret_cast<unsigned*>(sm), sm + 2048);
@@ -959,6 +963,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
     __shared__ float s_red[3][4];
     const int N = A.N;
     DBG_BLK(A.dbg, 4, 0);
+    if (A.ctl && A.ctl->stop) return;
     if (F.on && blockIdx.x == gridDim.x - 1) {               // last workgroup: the frames' half of doStepFromBackup
         frame_step_block(F, x);
         DBG_BLK_END(A.dbg, 4);
@@ -1095,7 +1100,7 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     }
     SysArgs S;
     S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = (c->n_lin > 0 && !marg) ? 1 : 0;
-    S.G = X.G; S.Wt = X.Wt; S.pbA = c->pair_blocks.as<double>(); S.pbL = pbL; S.dbg = A.dbg;
+    S.G = X.G; S.Wt = X.Wt; S.pbA = c->pair_blocks.as<double>(); S.pbL = pbL; S.dbg = A.dbg; S.stop = A.ctl ? &A.ctl->stop : nullptr;
     S.cdelta = vs; S.cprior = vs + 4; S.prior = vs + 8; S.dprior = vs + 8 + 8 * N;
     S.HM = have_hm ? c->HM.as<double>() : nullptr; S.bM = have_hm ? c->bM.as<double>() : nullptr;
     S.lambda = lambda;
@@ -1154,7 +1159,7 @@ int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
         F.adH = c->adH.as<double>(); F.adT = c->adT.as<double>(); F.adHTd = c->adHTd.as<float>();
         F.dprior = c->vec_small.as<double>() + 8 + 8 * A.N;
         for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
-        F.N = A.N;
+        F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
     }
     k_ba_backsub<<<cml_div_up(A.P * 8, 256) + F.on, 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
                                                                       c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0, F);

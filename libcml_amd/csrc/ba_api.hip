@@ -26,6 +26,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.r_new_state = c->r_new_state.as<int>(); A.r_energy = c->r_energy.as<float>(); A.r_new_energy = c->r_new_energy.as<float>();
     A.r_new_energy_wo = c->r_new_energy_wo.as<float>(); A.r_ret_energy = c->r_ret_energy.as<float>();
     A.r_good = c->r_good.as<unsigned char>(); A.r_lin = c->r_lin.as<unsigned char>(); A.r_sel = c->r_sel.as<unsigned char>();
+    A.ctl = nullptr; A.it_index = 0; A.n_step_blocks = (c->P * 8 + 255) / 256; A.th_opt = 0; A.step_partial_ro = c->step_partial.as<float>();
     A.r_lin_rw = c->r_lin.as<unsigned char>(); A.point_tgt_rw = c->point_tgt.as<int>(); A.pt_mask = nullptr;
     A.r_center = c->r_center.as<float>(); A.r_jpjdf = c->r_jpjdf.as<float>(); A.r_rtz = c->r_rtz.as<float>();
     A.rj0 = c->rj[0].as<float>(); A.rj1 = c->rj[1].as<float>();
@@ -394,6 +395,10 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     BAArgs A;
     cml_make_ba_args(c, A);
     A.fuse_apply = 1;                                        // the step is always accepted here (forceAccept, BA.h:265)
+    if (c->resident_on && c->conv_on) {                  // mirror of run()'s early exit: see ResidentCtl
+        A.ctl = reinterpret_cast<ResidentCtl*>(c->scal.as<char>() + CML_CTL_OFFSET);
+        A.it_index = c->resident_iter; A.th_opt = c->conv_th;
+    }
     const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap && (c->prof_tick++ % c->prof_stride) == 0;
     hipEvent_t* ev = prof ? &c->prof_ev[6 * (size_t)c->prof_n] : nullptr;
     if (prof) (void)hipEventRecord(ev[0], c->stream);
@@ -522,7 +527,37 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, co
         if ((rc = cml_ensure(c, c->null_basis, 8 * 7 * (size_t)n))) return rc;
         if ((rc = cml_h2d(c, c->null_basis.p, nullspace_basis, 8 * 7 * (size_t)n))) return rc;
     }
-    c->resident_on = true; c->resident_iter = 0;
+    c->resident_on = true; c->resident_iter = 0; c->conv_th = 0; c->conv_on = false;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_resident_convergence(cmlhip_ctx* c, double th_opt_iterations) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
+    c->conv_th = th_opt_iterations > 0 ? th_opt_iterations : 0.0;     // 0: the test can never pass, the log is still kept
+    c->conv_on = true;
+    CML_CHECK(c, hipMemsetAsync(c->scal.as<char>() + CML_CTL_OFFSET, 0, sizeof(ResidentCtl), c->stream));
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_get_resident_log(cmlhip_ctx* c, int* iterations, double* energies, int capacity) {
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
+    if (c->lin_finish_pending) {
+        BAArgs A;
+        cml_make_ba_args(c, A);
+        if (c->conv_on) A.ctl = reinterpret_cast<ResidentCtl*>(c->scal.as<char>() + CML_CTL_OFFSET);
+        cml_launch_lin_finish(c, A);
+        CML_CHECK(c, hipGetLastError());
+        c->lin_finish_pending = false;
+    }
+    ResidentCtl h;
+    if ((rc = cml_d2h(c, &h, c->scal.as<char>() + CML_CTL_OFFSET, sizeof h))) return rc;
+    const int n = c->conv_on ? h.iters_done : c->resident_iter;
+    if (iterations) *iterations = n;
+    if (energies) for (int i = 0; i < capacity && i < n && i < 40; i++) energies[i] = h.energy[i];
     return CMLHIP_OK;
 }
 
@@ -533,6 +568,7 @@ int cmlhip_ba_get_resident_state(cmlhip_ctx* c, cmlhip_ba_frame_state* frames, d
     if (c->lin_finish_pending) {                             // the tail of the last residual pass normally rides in the NEXT solve launch
         BAArgs A;
         cml_make_ba_args(c, A);
+        if (c->conv_on) A.ctl = reinterpret_cast<ResidentCtl*>(c->scal.as<char>() + CML_CTL_OFFSET);
         cml_launch_lin_finish(c, A);
         CML_CHECK(c, hipGetLastError());
         c->lin_finish_pending = false;

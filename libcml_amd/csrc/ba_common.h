@@ -30,6 +30,17 @@ struct LinSummary {
     int pad;
 };
 
+// control block of the device-resident loop when it mirrors BA::run's early exit (BA.cpp:879 `if (canbreak && it >= 1) break`):
+// lives in the context's scalar scratch; every kernel of an iteration returns at once when `stop` is set
+struct ResidentCtl {
+    int stop;                 // sticky
+    int iters_done;           // iterations that really ran
+    float frame_sums[4];      // sumA sumB sumT sumR of the last frame step (doStepFromBackup, BA.cpp:957-972)
+    int pad[2];
+    double energy[40];        // photometric energy after iteration i (statEnergyP)
+};
+#define CML_CTL_OFFSET 640
+
 struct BAArgs {
     int N, P, R, w, h, opt_a, opt_b, n;            // n = 8N+4
     double fx, fy, cx, cy, fxi, fyi, huber_d, oth_d, scale_f, scale_c;
@@ -47,6 +58,9 @@ struct BAArgs {
     int* pair_code; const int* pair_pos; int pair_stride;     // [N*N][pair_stride]: 2r+sel of the ACTIVE good residuals of the pair, else -1 (written by applyRes); slot of r
     double* lin_partial;          // per-block {energy, n_in, n_oob, n_outlier} of the residual kernel (may be null)
     long long* dbg;               // optional phase timestamps (wall_clock64, 100 MHz): 16 slots per kernel, see cmlhip_debug_read
+    ResidentCtl* ctl;             // null: no convergence test / early exit (bench, tests of single iterations)
+    int it_index; int n_step_blocks; double th_opt;   // iteration number, #blocks of step_partial, thOptIterations (BA.h:244)
+    const float* step_partial_ro;
     const unsigned char* pt_mask; // optional per-point selection (marginalisation passes); null = every point
     int fuse_apply;               // residual kernel also performs applyRes(copyJacobians=true) (valid when the step is always accepted)
 };

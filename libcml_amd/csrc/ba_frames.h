@@ -16,12 +16,13 @@ struct FrameStepArgs {
     double* dprior;                // 8N: state - prior_zero
     double sc[4];                  // scale translation / rotation / a / b
     int N, on;
+    float* frame_sums;             // optional: sumA sumB sumT sumR of doStepFromBackup (BA.cpp:957-972) for the convergence test
 };
 
 __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const double* __restrict__ x) {
     using cml_amd::SE3;
     using cml_amd::Exposure;
-    __shared__ double s_w2c[CMLHIP_MAX_FRAMES][7], s_c2w[CMLHIP_MAX_FRAMES][7], s_aff[CMLHIP_MAX_FRAMES][3], s_delta[CMLHIP_MAX_FRAMES][8];
+    __shared__ double s_w2c[CMLHIP_MAX_FRAMES][7], s_c2w[CMLHIP_MAX_FRAMES][7], s_aff[CMLHIP_MAX_FRAMES][3], s_delta[CMLHIP_MAX_FRAMES][8], s_step[CMLHIP_MAX_FRAMES][8];
     const int tid = threadIdx.x, N = F.N;
     if (tid < N) {
         cmlhip_ba_frame_state& S = F.fs[tid];
@@ -33,6 +34,7 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
         for (int k = 0; k < 8; k++) {
             if (!fin) step[k] = 0.0;                                   // setStep, DSOFrame.h:205-214
             if (S.fix_pose && k < 6) step[k] = 0.0;                    // BA.cpp:957-960
+            s_step[tid][k] = step[k];
             st[k] = S.state[k] + step[k];                              // state_backup == state: every step is accepted here
             S.state[k] = st[k];
             s_delta[tid][k] = st[k] - S.state_zero[k];
@@ -53,6 +55,17 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
         s_aff[tid][0] = S.ab_exposure; s_aff[tid][1] = F.sc[2] * st[6]; s_aff[tid][2] = F.sc[3] * st[7];    // aff_g2l
     }
     __syncthreads();
+    if (F.frame_sums && tid == 0) {                                    // fp32 sums in frame order, as the host loop forms them
+        float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+        for (int f = 0; f < N; f++) {
+            const double* st = s_step[f];
+            sumA += (float)(st[6] * st[6]);
+            sumB += (float)(st[7] * st[7]);
+            sumT += (float)(st[0] * st[0] + st[1] * st[1] + st[2] * st[2]);
+            sumR += (float)(st[3] * st[3] + st[4] * st[4] + st[5] * st[5]);
+        }
+        F.frame_sums[0] = sumA; F.frame_sums[1] = sumB; F.frame_sums[2] = sumT; F.frame_sums[3] = sumR;
+    }
     for (int q = tid; q < N * N; q += blockDim.x) {
         const int h = q / N, t = q % N;
         SE3 Wt, Ch;

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
     DBG_BLK(A.dbg, 0, 0);
+    if (A.ctl && A.ctl->stop) return;                      // converged: the loop of BA::run has left (BA.cpp:879)
     const int r = blockIdx.x * RES_PER_BLOCK + g;
     // ---- per-residual inputs (all 8 lanes of the group read the same addresses: broadcast).  Every load is unconditional
     //      on a clamped index — a `cond ? load : 0` costs its own branch and memory round trip — and what the tail of the
@@ -280,6 +281,19 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
             double* o = A.lin_partial + 4 * (size_t)blockIdx.x;
             o[0] = e; o[1] = (double)c0; o[2] = (double)c1; o[3] = (double)c2;
         }
+    }
+    // ---- resident loop: the convergence test of doStepFromBackup (BA.cpp:996-1027) on the sums of the step that preceded this
+    //      pass; `if (canbreak && it >= 1) break` (BA.cpp:879) becomes a sticky flag that every later kernel checks first
+    if (A.ctl && blockIdx.x == 0 && tid == 0) {
+        float sumID = 0, sumNID = 0, numID = 0;
+        for (int b = 0; b < A.n_step_blocks; b++) { sumID += A.step_partial_ro[4 * b]; sumNID += A.step_partial_ro[4 * b + 1]; numID += A.step_partial_ro[4 * b + 2]; }
+        float sumA = A.ctl->frame_sums[0], sumB = A.ctl->frame_sums[1], sumT = A.ctl->frame_sums[2], sumR = A.ctl->frame_sums[3];
+        const float nf = (float)A.N;
+        sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf; sumID /= numID; sumNID /= numID;
+        const bool canbreak = sqrtf(sumA) < 0.0005 * A.th_opt && sqrtf(sumB) < 0.00005 * A.th_opt && sqrtf(sumR) < 0.00005 * A.th_opt &&
+                              sqrtf(sumT) * sumNID < 0.00005 * A.th_opt;
+        A.ctl->iters_done = A.it_index + 1;
+        if (canbreak && A.it_index >= 1) A.ctl->stop = 1;
     }
     (void)ok;
     DBG_BLK_END(A.dbg, 0);

@@ -72,7 +72,7 @@ struct cmlhip_ctx {
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)
-    bool resident_on = false, have_null = false, lin_finish_pending = false; int resident_iter = 0; double res_scales[4] = {1, 1, 1, 1};
+    bool resident_on = false, have_null = false, lin_finish_pending = false; int resident_iter = 0; double res_scales[4] = {1, 1, 1, 1}; double conv_th = 0; bool conv_on = false;
     DevBuf dbg; bool dbg_on = false;                          // phase timestamps (tools)
     DevBuf step_partial;                                      // per-block {sumID, sumNID, numID, pad} of the point update
     int n_lin_partial = 0; double last_lambda = 1e-5; bool last_have_hm = false; double sys_lambda = 1e-5;

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "cmlhip_ba_lin_energy": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(C.c_double), _P(C.c_int)]),
     "cmlhip_ba_get_res_to_zero": (C.c_int, [_ctx, _P(C.c_float), _P(C.c_ubyte)]),
     "cmlhip_ba_set_resident_state": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(abi.BAFrameState), _P(C.c_double), _P(C.c_double)]),
+    "cmlhip_ba_resident_convergence": (C.c_int, [_ctx, C.c_double]),
+    "cmlhip_ba_get_resident_log": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_double), _i]),
     "cmlhip_ba_get_resident_state": (C.c_int, [_ctx, _P(abi.BAFrameState), _P(C.c_double), _P(abi.BALinResult)]),
     "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),

@@ -31,6 +31,7 @@ def lib():
         L.cmlhost_ba_add_point.argtypes = [_vp, _f, _f, _d, _i, _P(_f), _P(_f), _i]
         L.cmlhost_ba_run.argtypes = [_vp, _i]
         L.cmlhost_ba_run_resident.argtypes = [_vp, _i]
+        L.cmlhost_ba_run_host_loop.argtypes = [_vp, _i]
         L.cmlhost_ba_begin_resident.argtypes = [_vp, _i]
         L.cmlhost_ba_iterate_resident.argtypes = [_vp, _i, _d]
         L.cmlhost_ba_end_resident.argtypes = [_vp, _P(_d)]
@@ -116,6 +117,10 @@ class HostBA:
 
     def run(self, update_points_only=False):
         return bool(self.L.cmlhost_ba_run(self.h, int(update_points_only)))
+
+    def run_host_loop(self, update_points_only=False):
+        """The literal loop of BA::run: one synchronous device call per reference statement."""
+        return bool(self.L.cmlhost_ba_run_host_loop(self.h, int(update_points_only)))
 
     def run_resident(self, update_points_only=False):
         """run() with the iteration loop resident on the device (forceAccept + fixLambda, no early break)."""

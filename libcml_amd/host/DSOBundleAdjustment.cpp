@@ -561,6 +561,13 @@ bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // 
 }
 
 bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        // BA.cpp:744-910
+    // forceAccept + fixLambda + no marginalisation prior (the reference's defaults, BA.h:265-270): every step is accepted and
+    // lambda never changes, so the loop body has no host decision left except the early exit, which the device mirrors
+    if (mResidentLoop && mForceAccept && mFixLambda && mDisableMarginalization && mNumIterations <= 40) return runResident(updatePointsOnly);
+    return runHostLoop(updatePointsOnly);
+}
+
+bool DSOBundleAdjustment::runHostLoop(bool updatePointsOnly) {
     double sc[4];
     scales(sc);
     double lastEnergy[3], newEnergy[3];
@@ -935,12 +942,18 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     double lastEnergy[3];
     if (!runPreamble(lastEnergy)) return false;
     if (!beginResident(updatePointsOnly)) return false;
+    int rc = cmlhip_ba_resident_convergence(mCtx, mThOptIterations);         // `if (canbreak && it >= 1) break`, BA.cpp:879
+    if (rc) return fail("cmlhip_ba_resident_convergence", rc);
     if (!iterateResident(mNumIterations, mFixedLambda)) return false;
-    lastIterations = mNumIterations;
     lastLambda = mFixedLambda;
     double e = 0;
     if (!endResident(&e)) { mError = "non finite energy"; return false; }
-    statEnergyP.push_back(e);
+    std::vector<double> en(mNumIterations > 0 ? mNumIterations : 1, 0.0);
+    int its = 0;
+    rc = cmlhip_ba_get_resident_log(mCtx, &its, en.data(), (int)en.size());
+    if (rc) return fail("cmlhip_ba_get_resident_log", rc);
+    lastIterations = its;
+    for (int i = 0; i < its && i < (int)en.size(); i++) statEnergyP.push_back(en[i]);
     lastEnergy[0] = e;
     return runEpilogue(lastEnergy);
 }

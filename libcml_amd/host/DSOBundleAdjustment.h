@@ -88,6 +88,7 @@ public:
     bool   mDisableMarginalization = true, mOptimizeCalibration = false, mAbortBAOnFailture = false;
     double mMinIdepthHMarg = 50.0;                           // BA.h:263
     int    mMaxFrames = 6, mMinFrameAge = 1;                 // BA.h:271-272
+    bool   mResidentLoop = true;                             // run(): keep the iteration loop on the device when the parameters allow it
     double mCPriorValue = 5e9;                               // BA.cpp:2136-2137 (mCPrior is only assigned inside calcLEnergy)
 
     // ---- reference interface (BA.h:28-85), flat arguments
@@ -98,6 +99,7 @@ public:
     // The same run with the iteration loop resident on the device (forceAccept + fixLambda, no early break):
     // preamble and epilogue as run(), mNumIterations x cmlhip_ba_iteration_async in between, no host round trip per iteration.
     bool runResident(bool updatePointsOnly = false);
+    bool runHostLoop(bool updatePointsOnly = false);                                             // the literal loop: one device call per reference statement
     // pieces of runResident, for callers that keep iterating (bench): states to the device / k iterations / states back
     bool beginResident(bool updatePointsOnly = false);
     bool iterateResident(int k, double lambda);

@@ -31,6 +31,7 @@ int cmlhost_ba_set_param(void* h, const char* name, double v) {
     else if (n == "ThOptIterations") b->mThOptIterations = v;
     else if (n == "iDepth Fix Prior") b->mIdepthFixPrior = (int)v;
     else if (n == "Solver mode delta") b->mSolverModeDelta = v;
+    else if (n == "residentLoop") b->mResidentLoop = v != 0;
     else if (n == "Minimum iDepth Hessian Marginlaization") b->mMinIdepthHMarg = v;
     else if (n == "maxFrames") b->mMaxFrames = (int)v;
     else if (n == "frameMinAge") b->mMinFrameAge = (int)v;
@@ -51,6 +52,7 @@ int cmlhost_ba_add_point(void* h, float x, float y, double idepth, int host, con
     return static_cast<DSOBundleAdjustment*>(h)->addPoint(x, y, idepth, host, colors, weights, prior != 0);
 }
 int cmlhost_ba_run(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->run(updatePointsOnly != 0) ? 1 : 0; }
+int cmlhost_ba_run_host_loop(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->runHostLoop(updatePointsOnly != 0) ? 1 : 0; }
 int cmlhost_ba_run_resident(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->runResident(updatePointsOnly != 0) ? 1 : 0; }
 int cmlhost_ba_begin_resident(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->beginResident(updatePointsOnly != 0) ? 1 : 0; }
 int cmlhost_ba_iterate_resident(void* h, int k, double lambda) { return static_cast<DSOBundleAdjustment*>(h)->iterateResident(k, lambda) ? 1 : 0; }

@@ -103,7 +103,7 @@ def test_resident_iterations_match_host_loop(config):
         ba = host.window_to_host_ba(ctx, I.W)
         ba.set_param("iterations", 5)
         ba.set_param("ThOptIterations", 0.0)          # no early break (BA.cpp:879)
-        ok = ba.run() if mode == "host" else ba.run_resident()
+        ok = ba.run_host_loop() if mode == "host" else ba.run_resident()
         assert ok, ba.last_error()
         assert ba.counts()["iterations"] == 5
         idp, alive, ng = ba.points()
@@ -118,7 +118,7 @@ def test_resident_iterations_match_host_loop(config):
         assert np.abs(a["R"] - b["R"]).max() < 1e-8 and np.abs(a["t"] - b["t"]).max() < 1e-7
         assert abs(a["th"] - b["th"]) <= 1e-5 * abs(a["th"])
     assert np.abs(idp_h / idp_r - 1).max() < 1e-5
-    assert abs(e_h[-1] / e_r[-1] - 1) < 1e-6, (e_h, e_r)
+    assert len(e_h) == len(e_r) and np.abs(e_h / e_r - 1).max() < 1e-6, (e_h, e_r)
 
 
 def test_host_tracker_recovers_known_motion():
@@ -158,3 +158,28 @@ def test_host_tracker_recovers_known_motion():
         trk.close(); ctx.close()
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+@pytest.mark.parametrize("config", ["small", "medium"])
+def test_run_delegates_to_resident_loop_with_the_same_early_exit(config):
+    """run() keeps the loop on the device under the default parameters (forceAccept, fixLambda).  The reference's early exit
+    `if (canbreak && it >= 1) break` (BA.cpp:879) is mirrored by a sticky device flag: same number of iterations, same
+    per-iteration energies and same final state as the literal host loop."""
+    res = []
+    for mode in ("host", "auto"):
+        I = S.make_inputs(config)
+        ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R)
+        ba = host.window_to_host_ba(ctx, I.W)
+        ba.set_param("iterations", 12)
+        ba.set_param("ThOptIterations", 400.0)        # loose enough that the loop leaves before the 12th iteration
+        ok = ba.run_host_loop() if mode == "host" else ba.run()
+        assert ok, ba.last_error()
+        idp, alive, ng = ba.points()
+        res.append((ba.counts()["iterations"], ba.energies(16).copy(), idp.copy(), [ba.frame(k)["state"].copy() for k in range(I.N)]))
+        ba.close(); ctx.close()
+    (it_h, e_h, idp_h, st_h), (it_r, e_r, idp_r, st_r) = res
+    assert it_h == it_r and 2 <= it_h < 12, (it_h, it_r)
+    assert len(e_h) == len(e_r) and np.abs(e_h / e_r - 1).max() < 1e-6
+    for a, b in zip(st_h, st_r):
+        assert np.abs(a - b).max() < 1e-7 * max(1.0, np.abs(a).max())
+    assert np.abs(idp_h / idp_r - 1).max() < 1e-5

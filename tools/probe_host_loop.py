@@ -1,5 +1,5 @@
-"""Host-driven loop (DSOBundleAdjustment::run: one synchronous device call per reference statement) vs the device-resident
-loop (runResident), per Gauss-Newton iteration, config B."""
+"""Host-driven loop (DSOBundleAdjustment::run: one synchronous device call per reference statement) vs run() itself,
+which keeps the loop on the device under the default parameters (runResident with the early-exit mirror), per Gauss-Newton iteration, config B."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from libcml_amd import device, host, synth
@@ -11,7 +11,7 @@ for mode in ("host", "resident"):
         ba = host.window_to_host_ba(ctx, W, levels=1)
         ba.set_param("iterations", its); ba.set_param("ThOptIterations", 0.0)
         t0 = time.perf_counter()
-        ok = ba.run() if mode == "host" else ba.run_resident()
+        ok = ba.run_host_loop() if mode == "host" else ba.run()
         ts[its] = min(ts[its], time.perf_counter() - t0)
         assert ok and ba.counts()["iterations"] == its
         ba.close(); ctx.close()
