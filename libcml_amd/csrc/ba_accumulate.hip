@@ -830,7 +830,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const double dk = rl(row[k], k);
-                const double di = fast_rcp(dk);
+                // a zero pivot of a positive SEMI-definite system (frames without any good residual and without a pose prior)
+                // has a zero column below it: it is skipped, and D^-1 below maps it to x = 0 — what Eigen's pivoted LDLT
+                // returns for it (LDLT.h:300-396 stops at a zero corner, :580-587 pseudo-inverts D)
+                const double di = fabs(dk) > 2.2250738585072014e-308 ? fast_rcp(dk) : 0.0;
                 const double cid = row[k] * di;                 // l_ik (meaningful for rows below row k)
                 const double zk = rl(yv, k);
                 w[k] = row[k];

@@ -320,7 +320,7 @@ int cmlhip_ba_solve(cmlhip_ctx* c, double lambda, const double* HM, const double
     cml_make_ba_args(c, A);
     c->last_lambda = lambda; c->last_have_hm = have;
     cml_launch_accumulate(c, A, lambda, have, false, true); // pair blocks / Schur rows are current; rebuilds the final system for this lambda / HM
-    cml_launch_solve(c, A, optcal, false);
+    if ((rc = cml_launch_solve(c, A, optcal, false))) return rc;   // (a window too wide for the LDS-resident factorisation is refused here)
     CML_CHECK(c, hipGetLastError());
     int flag = 0;
     if ((rc = cml_d2h(c, &flag, c->scal.as<char>() + 256, sizeof(int)))) return rc;
@@ -403,7 +403,7 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
     hipEvent_t* ev = prof ? &c->prof_ev[6 * (size_t)c->prof_n] : nullptr;
     if (prof) (void)hipEventRecord(ev[0], c->stream);
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
-    cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2);   // K5: solve (+ orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
+    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2))) return rc;   // K5: solve (+ orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
     c->resident_iter++;
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
     if (prof) { (void)hipEventRecord(ev[1], c->stream); (void)hipEventRecord(ev[2], c->stream); }

@@ -1,0 +1,131 @@
+"""Edge cases of the BA path on the device against the oracle: the smallest window, a window without residuals, residuals
+that all leave the image, ragged points (some without any residual), non-finite inputs, and the limits of the layer."""
+import numpy as np
+import pytest
+
+from libcml_amd import abi, device
+from tests import ba_setup as S
+from tests import dev_setup as D
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipeline(I):
+    """linearize -> apply -> accumulate -> solve -> backsub on both sides; returns what to compare."""
+    ob = S.OracleBA(I)
+    ctx = D.make_ctx(I)
+    try:
+        ro, rd = ob.linearize(), ctx.ba_linearize()
+        so, sd = ob.states(), ctx.ba_states()
+        assert np.array_equal(so["new_state"], sd["new_state"]) and np.array_equal(so["state"], sd["state"])
+        assert (ro.n_in, ro.n_oob, ro.n_outlier) == (rd.n_in, rd.n_oob, rd.n_outlier)
+        assert np.float32(ro.new_frame_energy_th).view(np.uint32) == np.float32(rd.new_frame_energy_th).view(np.uint32)
+        IN = so["new_state"] == 0
+        if IN.any():
+            assert np.array_equal(ob.rJ(0)[IN].view(np.uint32), ctx.ba_rj(0)[IN].view(np.uint32))
+        ob.apply(1); ctx.ba_apply(1)
+        Ho = ob.accumulate(); Hd = D.accumulate(ctx, I)
+        for a, b in zip(Ho, Hd):
+            assert np.all(np.isfinite(b))
+            assert np.abs(a - b).max() <= 5e-5 * max(np.abs(a).max(), 1e-30)
+        xd, rc = ctx.ba_solve(1e-5)
+        xo, rco = ob.solve(1e-5, *Hd)
+        assert rc == 0 and rco == 0 and np.all(np.isfinite(xd))
+        assert np.abs(xd - xo).max() <= 1e-7 * max(np.abs(xo).max(), 1e-30)
+        sto, _ = ob.backsub(xd)
+        std, rcb = ctx.ba_backsub(xd)
+        assert rcb == 0 and np.abs(sto - std).max() <= 5e-5 * max(np.abs(sto).max(), 1e-30)
+        return ro, rd, so
+    finally:
+        ctx.close()
+
+
+def test_smallest_window():
+    ro, rd, so = _pipeline(S.make_inputs((2, 3, 160, 120, 2, 140.0, 140.0, 79.5, 59.5)))
+    assert ro.n_in + ro.n_oob + ro.n_outlier == 3
+
+
+def test_all_residuals_out_of_bounds():
+    I = S.make_inputs("tiny")
+    I.residuals["state"][:] = abi.RES_OOB if hasattr(abi, "RES_OOB") else 1          # DSOResidualState::DSORES_OOB
+    ro, rd, so = _pipeline(I)
+    assert rd.n_in == 0 and rd.energy == 0
+    assert rd.new_frame_energy_th == np.float32(12 * 12 * 8)                        # BA.cpp:2432-2436
+
+
+def test_ragged_points_and_empty_pairs():
+    """Half of the points keep a single residual, a quarter none at all; several (host,target) pairs end up empty."""
+    I = S.make_inputs("small")
+    keep = np.ones(I.R, bool)
+    pt = I.residuals["point"]
+    first_of_point = np.r_[True, pt[1:] != pt[:-1]]
+    keep[(pt % 4 == 1) & ~first_of_point] = False        # a single residual
+    keep[pt % 4 == 2] = False                            # none
+    I.residuals = I.residuals[keep].copy(); I.R = int(keep.sum())
+    ro, rd, so = _pipeline(I)
+    assert rd.n_in > 10
+
+
+def test_window_without_residuals():
+    I = S.make_inputs("tiny")
+    I.residuals = I.residuals[:0].copy(); I.R = 0
+    ctx = D.make_ctx(I)
+    try:
+        r = ctx.ba_linearize()
+        assert (r.n_in, r.n_oob, r.n_outlier) == (0, 0, 0) and r.energy == 0
+        ctx.ba_apply(1)
+        HA, bA, HL, bL, Hsc, bsc = D.accumulate(ctx, I)
+        assert not HA.any() and not Hsc.any() and not bA.any() and not bsc.any()
+        assert np.allclose(np.diag(HL)[4:], I.prior)
+        x, rc = ctx.ba_solve(1e-5)
+        assert rc == 0 and np.all(np.isfinite(x))
+    finally:
+        ctx.close()
+
+
+def test_non_finite_point_is_contained():
+    """A NaN inverse depth poisons exactly its own residuals (BA.cpp:115-118,297-300: new state OOB), nothing else, on both sides."""
+    I = S.make_inputs("small")
+    I.points["idepth"][5] = np.nan
+    ob = S.OracleBA(I)
+    ctx = D.make_ctx(I)
+    try:
+        ro, rd = ob.linearize(), ctx.ba_linearize()
+        so, sd = ob.states(), ctx.ba_states()
+        assert np.array_equal(so["new_state"], sd["new_state"]) and np.array_equal(so["state"], sd["state"])
+        mine = I.residuals["point"] == 5
+        assert np.all(sd["new_state"][mine] != 0) and (sd["new_state"][~mine] == 0).sum() > 50
+        assert (ro.n_in, ro.n_oob, ro.n_outlier) == (rd.n_in, rd.n_oob, rd.n_outlier)
+        assert np.isfinite(rd.energy) and abs(ro.energy - rd.energy) <= 1e-12 * abs(ro.energy)
+    finally:
+        ctx.close()
+
+
+def test_limits_are_errors_not_crashes():
+    L = device.lib()
+    with pytest.raises(device.CmlHipError):
+        device.Ctx(max_frames=abi.MAX_FRAMES + 1 if hasattr(abi, "MAX_FRAMES") else 33)
+    I = S.make_inputs("tiny")
+    ctx = device.Ctx(max_frames=2, max_points=I.P, max_residuals=I.R)          # the window has 3 frames
+    try:
+        for k in range(I.N):
+            ctx.pyramid_put(int(I.frames_dev["image_id"][k]), 0, I.grads[k][0])
+        ctx.ba_set_params(I.prm)
+        with pytest.raises(device.CmlHipError):
+            ctx.ba_upload_window(I.frames_dev, I.points, I.residuals)
+        with pytest.raises(device.CmlHipError):
+            ctx.ba_linearize()                                                  # nothing uploaded: call-order error
+    finally:
+        ctx.close()
+    # a window wider than the LDS-resident solver supports is refused by the solve, everything before it works
+    N = 22
+    I = S.make_inputs((N, 60, 160, 120, 2, 140.0, 140.0, 79.5, 59.5))
+    ctx = D.make_ctx(I)
+    try:
+        ctx.ba_linearize(); ctx.ba_apply(1)
+        Hd = D.accumulate(ctx, I)
+        assert all(np.all(np.isfinite(h)) for h in Hd)
+        with pytest.raises(device.CmlHipError):
+            ctx.ba_solve(1e-5)
+    finally:
+        ctx.close()
