@@ -129,3 +129,71 @@ def test_limits_are_errors_not_crashes():
             ctx.ba_solve(1e-5)
     finally:
         ctx.close()
+
+
+def test_tracer_edge_cases():
+    """Empty immature set, a set that is entirely out of bounds, and a NaN interval: device == oracle, no hang."""
+    from libcml_amd import synth
+    from tests import oracle_lib as O
+    from tests import tracer_setup as TS
+    W = synth.make_window("tiny")
+    grads0 = [O.build_pyramid(W.gray[k], 1)[1][0] for k in range(W.N)]
+    ctx = device.Ctx(max_frames=W.N)
+    try:
+        ids = [300 + k for k in range(W.N)]
+        for k in range(W.N):
+            ctx.pyramid_put(ids[k], 0, grads0[k])
+        prm = abi.default_tracer_params()
+        pr = TS.trace_pairs(W, 1)
+        pts = TS.make_immature(W, grads0)
+        assert len(ctx.trace_points(ids[1], prm, pr, pts[:0])) == 0
+        ctx.tracer_set_points(pts[:0])
+        assert ctx.tracer_trace_resident(ids[1], prm, pr, 1).sum() == 0
+        sel = pts[pts["host"] == 0].copy()
+        far = sel.copy(); far["x"] += 10000                          # projects far outside: OOB at the first test (DSOTracer.cpp:620-626)
+        o = TS.oracle_trace(grads0[1], pr, prm, far); d = ctx.trace_points(ids[1], prm, pr, far)
+        assert np.all(o["last_status"] == abi.IPS_OOB) and np.array_equal(o["last_status"], d["last_status"])
+        bad = sel.copy(); bad["idepth_min"][::2] = np.nan
+        o = TS.oracle_trace(grads0[1], pr, prm, bad); d = ctx.trace_points(ids[1], prm, pr, bad)
+        assert np.array_equal(o["last_status"], d["last_status"])
+        ok = np.isfinite(o["idepth_min"])
+        assert np.array_equal(o["idepth_min"][ok].view(np.uint64), d["idepth_min"][ok].view(np.uint64))
+        # activation with a single other frame and with every residual out of bounds
+        apr = TS.activation_pairs(W)
+        cand = sel.copy(); cand["idepth_min"] = 0.05; cand["idepth_max"] = 0.2
+        ro, io, so = TS.oracle_optimize(grads0, W.K, apr, prm, 1, cand)
+        rd, idd, sd = ctx.optimize_immature_points(ids, W.K, apr, prm, 1, cand)
+        assert np.array_equal(ro, rd) and np.array_equal(io.view(np.uint32), idd.view(np.uint32))
+        cand["x"] += 10000
+        ro, io, so = TS.oracle_optimize(grads0, W.K, apr, prm, 1, cand)
+        rd, idd, sd = ctx.optimize_immature_points(ids, W.K, apr, prm, 1, cand)
+        assert np.array_equal(ro, rd) and np.all(rd != 1)
+    finally:
+        ctx.close()
+
+
+def test_host_mirror_error_returns():
+    """The reference's `return false` paths: no points (BA.cpp:759-762) and a missing calibration."""
+    from libcml_amd import host
+    ctx = device.Ctx(max_frames=4)
+    ba = host.HostBA(ctx)
+    try:
+        ba.set_calibration(140.0, 140.0, 79.5, 59.5, 160, 120)
+        assert not ba.run() and "No points" in ba.last_error()
+        assert not ba.run_host_loop()
+        with pytest.raises(KeyError):
+            ba.set_param("no such parameter", 1.0)
+    finally:
+        ba.close(); ctx.close()
+
+
+def test_reproj_without_observations():
+    ctx = device.Ctx(max_frames=4)
+    try:
+        poses = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (3, 1))
+        pts = np.zeros((5, 3)); pts[:, 2] = 4.0
+        obs = np.zeros(0, abi.REPROJ_OBS_DTYPE) if hasattr(abi, "REPROJ_OBS_DTYPE") else np.zeros(0, np.dtype([("frame", "i4"), ("point", "i4"), ("u", "f8"), ("v", "f8")]))
+        M6, b6, Jp, used = ctx.reproj_accumulate(poses, pts, obs, 500.0, 500.0)
+        assert not M6.any() and not b6.any() and len(used) == 0
+    finally:
+        ctx.close()
