@@ -42,6 +42,8 @@ def lib():
         L.cmlhost_ba_marginalize_frames.argtypes = [_vp, _P(_i), _i]
         L.cmlhost_ba_get_prior.argtypes = [_vp, _P(_d), _P(_d)]
         L.cmlhost_ba_get_point_flags.argtypes = [_vp, _P(_u8), _P(_u8), _P(_f)]
+        L.cmlhost_ba_rejected.argtypes = [_vp]
+        L.cmlhost_ba_last_lambda.restype = _d; L.cmlhost_ba_last_lambda.argtypes = [_vp]
         L.cmlhost_ba_calc_m_energy.restype = _d; L.cmlhost_ba_calc_m_energy.argtypes = [_vp]
         L.cmlhost_ba_calc_l_energy.restype = _d; L.cmlhost_ba_calc_l_energy.argtypes = [_vp]
         L.cmlhost_ba_last_error.restype = C.c_char_p; L.cmlhost_ba_last_error.argtypes = [_vp]
@@ -166,6 +168,12 @@ class HostBA:
         tm = np.zeros(n, np.uint8); mg = np.zeros(n, np.uint8); ih = np.zeros(n, np.float32)
         self.L.cmlhost_ba_get_point_flags(self.h, _p(tm, _u8), _p(mg, _u8), _p(ih, _f))
         return tm, mg, ih
+
+    def rejected(self):
+        return self.L.cmlhost_ba_rejected(self.h)
+
+    def last_lambda(self):
+        return self.L.cmlhost_ba_last_lambda(self.h)
 
     def m_energy(self):
         return self.L.cmlhost_ba_calc_m_energy(self.h)

@@ -572,6 +572,7 @@ bool DSOBundleAdjustment::runHostLoop(bool updatePointsOnly) {
     scales(sc);
     double lastEnergy[3], newEnergy[3];
     if (!runPreamble(lastEnergy)) return false;
+    double lastEnergyL = calcLEnergy(), lastEnergyM = calcMEnergy();          // BA.cpp:783-784 (0 under forceAccept, :2100-2102,2123-2125)
     int rc;
     double lambda = mFixedLambda;
     for (int it = 0; it < mNumIterations; it++) {
@@ -580,13 +581,16 @@ bool DSOBundleAdjustment::runHostLoop(bool updatePointsOnly) {
         if (!solveSystem(it, lambda)) return false;                           // :813-816
         const bool canbreak = doStepFromBackup(updatePointsOnly);
         if (!linearizeAll(false, newEnergy)) return false;
-        const double newTotal = newEnergy[0] + newEnergy[1], lastTotal = lastEnergy[0] + lastEnergy[1];   // L and M energies are 0 under forceAccept (:2100-2102,2123-2125)
+        const double newEnergyL = calcLEnergy(), newEnergyM = calcMEnergy();
+        const double newTotal = newEnergy[0] + newEnergy[1] + newEnergyL + newEnergyM;       // :830-831
+        const double lastTotal = lastEnergy[0] + lastEnergy[1] + lastEnergyL + lastEnergyM;
         if (!std::isfinite(newTotal)) { mError = "non finite energy"; return false; }     // :836-841
         if (newTotal < lastTotal || mForceAccept) {
             statEnergyP.push_back(newEnergy[0]);
             rc = cmlhip_ba_apply(mCtx, 1);
             if (rc) return fail("cmlhip_ba_apply", rc);
             for (int k = 0; k < 3; k++) lastEnergy[k] = newEnergy[k];
+            lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
             lambda *= 0.25;
         } else {                                                              // loadSateBackup, :871-875
             for (auto& f : mFrames) f.loadSateBackup(sc);
@@ -594,7 +598,9 @@ bool DSOBundleAdjustment::runHostLoop(bool updatePointsOnly) {
             if (rc) return fail("cmlhip_ba_restore_points", rc);
             computeDelta();
             if (!linearizeAll(false, lastEnergy)) return false;
+            lastEnergyL = calcLEnergy(); lastEnergyM = calcMEnergy();
             lambda *= 1e2;
+            statRejected++;
         }
         lastLambda = lambda;
         if (canbreak && it >= 1) break;                                       // :879

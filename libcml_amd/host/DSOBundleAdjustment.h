@@ -126,7 +126,7 @@ public:
 
     // ---- statistics of the last run (BA.h:215-233)
     std::vector<double> statEnergyP, statXNorm, statHessianP, statHessianSC, statBP, statBSC;
-    int lastIterations = 0;
+    int lastIterations = 0, statRejected = 0;                // iterations of the last run / rejected steps since construction
     double lastLambda = 0;
     // exposed for tests
     void computeAdjoints();

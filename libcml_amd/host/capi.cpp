@@ -78,6 +78,8 @@ void cmlhost_ba_get_point_flags(void* h, unsigned char* toMarg, unsigned char* m
     const auto& P = static_cast<DSOBundleAdjustment*>(h)->getPoints();
     for (size_t i = 0; i < P.size(); i++) { if (toMarg) toMarg[i] = P[i].toMarginalize; if (marginalized) marginalized[i] = P[i].marginalized; if (idepthHessian) idepthHessian[i] = P[i].idepth_hessian; }
 }
+int cmlhost_ba_rejected(void* h) { return static_cast<DSOBundleAdjustment*>(h)->statRejected; }
+double cmlhost_ba_last_lambda(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastLambda; }
 double cmlhost_ba_calc_m_energy(void* h) { return static_cast<DSOBundleAdjustment*>(h)->calcMEnergy(); }
 double cmlhost_ba_calc_l_energy(void* h) { return static_cast<DSOBundleAdjustment*>(h)->calcLEnergy(); }
 const char* cmlhost_ba_last_error(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastError().c_str(); }

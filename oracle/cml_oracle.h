@@ -118,6 +118,7 @@ int  orc_ba_solve(const orc_ba_window* w, double lambda, const double* HA, const
 /* resubstitution: BA.cpp:1427-1487 */
 int  orc_ba_backsub(orc_ba_window* w, const cmlhip_ba_accum_in* in, const double* x);
 void orc_ba_backup_points(orc_ba_window* w);
+void orc_ba_restore_points(orc_ba_window* w);                  /* BA.cpp:938-942 */
 void orc_ba_step_points(orc_ba_window* w, float sums[3]);      /* BA.cpp:976-994 */
 /* marginalisation, SURVEY §8 a15 */
 void orc_ba_fix_linearization(orc_ba_window* w, int r, const cmlhip_ba_accum_in* in);              /* BA.cpp:2210-2238 */

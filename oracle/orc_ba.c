@@ -720,6 +720,10 @@ void orc_ba_backup_points(orc_ba_window* w) {           /* BA.cpp:919-922 */
     for (int p = 0; p < w->P; p++) w->idepth_backup[p] = (float)w->points[p].idepth;
 }
 
+void orc_ba_restore_points(orc_ba_window* w) {          /* loadSateBackup, BA.cpp:938-942 */
+    for (int p = 0; p < w->P; p++) { w->points[p].idepth = (double)w->idepth_backup[p]; w->points[p].idepth_zero = w->idepth_backup[p]; }
+}
+
 void orc_ba_step_points(orc_ba_window* w, float sums[3]) {   /* BA.cpp:976-994 */
     float sumID = 0, sumNID = 0, numID = 0;
     for (int p = 0; p < w->P; p++) {

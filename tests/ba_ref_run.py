@@ -7,20 +7,24 @@ from tests import ba_setup as S
 from tests import oracle_lib as O
 
 
-def oracle_run(I, iterations=4, fixed_lambda=1e-5, th_opt=1.2):
+def oracle_run(I, iterations=4, fixed_lambda=1e-5, th_opt=1.2, force_accept=True, fix_lambda=True):
     ob = S.OracleBA(I)
     N, P = I.N, I.P
     n = 8 * N + 4
     lib = O.lib()
-    log = dict(energy=[], x=[])
-    r = ob.linearize(); ob.apply(1)
+    log = dict(energy=[], x=[], accepted=[], lam=[])
+    r = ob.linearize()
+    last_e = r.energy
+    last_l = 0.0 if force_accept else ob.l_energy()[0]        # calcLEnergy (+ calcMEnergy = 0: no prior), BA.cpp:783-784
+    ob.apply(1)
     log["energy"].append(r.energy)
+    lam = fixed_lambda
     I.frames[N - 1].frame_energy_th = 0  # placeholder (oracle window keeps its own thresholds)
     for it in range(iterations):
         backup = [np.array(I.frames[k].state[:]) for k in range(N)]
         lib.orc_ba_backup_points(ob.w)
         HA, bA, HL, bL, Hsc, bsc = ob.accumulate()
-        x, rc = ob.solve(fixed_lambda, HA, bA, HL, bL, Hsc, bsc)
+        x, rc = ob.solve(fixed_lambda if fix_lambda else lam, HA, bA, HL, bL, Hsc, bsc)
         if it >= 2:
             ns = np.zeros(7 * n)
             lib.orc_ba_nullspaces(I.frames, N, C.byref(I.scales), O.ptr(ns, C.c_double))
@@ -42,8 +46,24 @@ def oracle_run(I, iterations=4, fixed_lambda=1e-5, th_opt=1.2):
                     np.sqrt(sums["R"] / N) < 0.00005 * th_opt and np.sqrt(sums["T"] / N) * sumNID < 0.00005 * th_opt)
         I.pairs = S.frame_pairs(I.frames, N); ob.set_pairs(I.pairs)
         I.adH, I.adT, I.adHTd, I.prior, I.dprior = S.adjoints_and_delta(I.frames, N, I.scales)
-        r = ob.linearize(); ob.apply(1)
-        log["energy"].append(r.energy)
+        r = ob.linearize()
+        new_l = 0.0 if force_accept else ob.l_energy()[0]
+        if r.energy + new_l < last_e + last_l or force_accept:                 # BA.cpp:830-853
+            ob.apply(1)
+            log["energy"].append(r.energy); log["accepted"].append(True)
+            last_e, last_l = r.energy, new_l
+            lam *= 0.25
+        else:                                                                   # loadSateBackup, BA.cpp:871-875
+            for k in range(N):
+                lib.orc_frame_set_state(C.byref(I.frames[k]), O.ptr(backup[k].copy(), C.c_double), C.byref(I.scales))
+            lib.orc_ba_restore_points(ob.w)
+            I.pairs = S.frame_pairs(I.frames, N); ob.set_pairs(I.pairs)
+            I.adH, I.adT, I.adHTd, I.prior, I.dprior = S.adjoints_and_delta(I.frames, N, I.scales)
+            r = ob.linearize()
+            last_e = r.energy; last_l = ob.l_energy()[0]
+            log["accepted"].append(False)
+            lam *= 1e2
+        log["lam"].append(lam)
         if canbreak and it >= 1:
             break
     # re-anchor the newest frame (BA.cpp:885-894): setEvalPT(PRE_worldToCam, [0.., a, b])

@@ -183,3 +183,28 @@ def test_run_delegates_to_resident_loop_with_the_same_early_exit(config):
     for a, b in zip(st_h, st_r):
         assert np.abs(a - b).max() < 1e-7 * max(1.0, np.abs(a).max())
     assert np.abs(idp_h / idp_r - 1).max() < 1e-5
+
+
+def test_host_loop_with_step_rejection():
+    """forceAccept = false, fixLambda = false: the Levenberg-Marquardt accept/reject branch of BA::run (BA.cpp:830-876) —
+    total energy with the linearised/prior term (calcLEnergy), loadSateBackup + restore of the points on rejection, lambda
+    x 0.25 / x 100.  An over-long first step (large lambda scale-down is not available at iteration 0) makes at least one
+    rejection likely; the accept/reject sequence and lambda must match the oracle-composed run."""
+    I = S.make_inputs("small", idepth_noise=0.25)           # poor depths: the first Gauss-Newton steps overshoot
+    ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R)
+    ba = host.window_to_host_ba(ctx, I.W)
+    try:
+        for k, v in (("forceAccept", 0), ("fixLambda", 0), ("iterations", 6), ("ThOptIterations", 0.0), ("fixedLambda", 1e-1)):
+            ba.set_param(k, v)
+        assert ba.run(), ba.last_error()                     # not the resident loop: the host decides every iteration
+        ref = ba_ref_run.oracle_run(I, iterations=6, fixed_lambda=1e-1, th_opt=0.0, force_accept=False, fix_lambda=False)
+        acc = ref["log"]["accepted"]
+        assert ba.counts()["iterations"] == len(acc) == 6
+        assert ba.rejected() == acc.count(False)
+        assert abs(ba.last_lambda() / ref["log"]["lam"][-1] - 1) < 1e-12
+        e_dev = ba.energies(16); e_ref = np.array(ref["log"]["energy"])
+        assert len(e_dev) >= 2                               # energy/#residuals of the preamble + one entry per accepted step
+        k = min(len(e_dev), len(e_ref) - 1) - 1
+        assert np.abs(e_dev[1:1 + k] / e_ref[1:1 + k] - 1).max() < 5e-3
+    finally:
+        ba.close(); ctx.close()
