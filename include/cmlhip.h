@@ -330,6 +330,36 @@ int cmlhip_optimize_immature_points(cmlhip_ctx* ctx, int N, const uint64_t* imag
                                     const cmlhip_activation_pair* pairs, const cmlhip_tracer_params* prm, int min_obs,
                                     int n, const cmlhip_immature_point* points, int* result, float* idepth, int* res_state);
 
+/* ---------------------------------------------------------------- coarse initializer: DSOInitializer
+ * calcResAndGS (DSOInitializer.cpp:451-750): the photometric residuals/Jacobians of every initializer point of one pyramid
+ * level against the frame being tracked, the 9x9 Gauss-Newton system (Accumulator9), its Schur complement on the inverse
+ * depths and the per-point JbBuffer the idepth step (doStep, :869-909) is formed from.  One launch per LM evaluation. */
+typedef struct {            /* the fields of DSOInitializerPoint (DSOInitializer.h:11-58) calcResAndGS reads and writes */
+    float p_pattern[8][3];  /* pPattern: homogeneous pixel of each pattern position in the reference (setFirst, :66) */
+    float color[8];         /* reference gray at the pattern positions (:67) */
+    float idepth_new, iR, outlier_th;
+    float energy[2];
+    int   is_good;          /* in/out: cleared for good when a pattern pixel leaves the image (:508) */
+    /* written by the call */
+    int   is_good_new;
+    float energy_new[2], maxstep, last_hessian_new;
+    float jb[10];           /* mJbBuffer_new[i]: only touched for points that were good on entry, as in the reference */
+    float pad[3];
+} cmlhip_init_point;       /* 224 bytes */
+typedef struct {
+    float RKi[9], t[3];     /* (refToNew.R * K^-1).cast<float>(), refToNew.t.cast<float>() at this level (:473-474) */
+    float fx, fy, cx, cy;   /* K(lvl) as float (:457-460) */
+    float aff_a, aff_b;     /* r2new_aff: exposure ratio, 0 (:476-479) */
+    float huber, alpha_w, alpha_k, coupling_weight;                  /* mHuberThreshold, mAlphaW, mAlphaK, mCouplingWeight */
+    float tlog[3];          /* SE3(camera).log().head<3>() as float (:738) */
+    float pad;
+    double t_sqnorm;        /* refToNew.getTranslation().squaredNorm() in scalar_t (:674) */
+} cmlhip_init_params;
+/* H_out / H_out_sc 8x8 row-major, b_out / b_out_sc 8, res = (E.A, alphaEnergy, E.num) as the reference returns them. */
+int cmlhip_initializer_calc_res_and_gs(cmlhip_ctx* ctx, uint64_t image_id, int level, const cmlhip_init_params* prm,
+                                       int n, cmlhip_init_point* points, float* H_out, float* b_out,
+                                       float* H_out_sc, float* b_out_sc, float res[3]);
+
 /* ---------------------------------------------------------------- marginalisation (once per keyframe), SURVEY §8 a15
  * tryMarginalize's residual loop (BA.cpp:2291-2304) for the points that are about to be marginalised: every residual of the
  * listed points is reset (resetOOB), re-linearised at the current state, committed (applyRes(true)) and, when good,

@@ -128,6 +128,19 @@ TRACE_PAIR_DTYPE = np.dtype([("KRKi", "<f8", (9,)), ("Kt", "<f8", (3,)), ("aff_a
 ACTIVATION_PAIR_DTYPE = np.dtype([("R", "<f8", (9,)), ("t", "<f8", (3,)), ("aff_a", "<f8"), ("aff_b", "<f8")])
 
 
+INIT_POINT_DTYPE = np.dtype([("p_pattern", "<f4", (8, 3)), ("color", "<f4", (8,)), ("idepth_new", "<f4"), ("iR", "<f4"), ("outlier_th", "<f4"),
+                             ("energy", "<f4", (2,)), ("is_good", "<i4"), ("is_good_new", "<i4"), ("energy_new", "<f4", (2,)),
+                             ("maxstep", "<f4"), ("last_hessian_new", "<f4"), ("jb", "<f4", (10,)), ("pad", "<f4", (3,))])
+assert INIT_POINT_DTYPE.itemsize == 224
+
+
+class InitParams(C.Structure):
+    """cmlhip_init_params: the per-evaluation constants of DSOInitializer::calcResAndGS (DSOInitializer.cpp:451-480)."""
+    _fields_ = [("RKi", C.c_float * 9), ("t", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("aff_a", C.c_float), ("aff_b", C.c_float), ("huber", C.c_float), ("alpha_w", C.c_float), ("alpha_k", C.c_float),
+                ("coupling_weight", C.c_float), ("tlog", C.c_float * 3), ("pad", C.c_float), ("t_sqnorm", C.c_double)]
+
+
 class TracerParams(C.Structure):
     _fields_ = [("max_pix_search", C.c_double), ("max_slack_interval", C.c_double), ("trace_step_size", C.c_double),
                 ("min_improvement_factor", C.c_double), ("min_trace_test_radius", C.c_double), ("extra_slack_on_th", C.c_double),

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "cmlhip_tracer_set_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_tracer_trace_resident": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, _P(C.c_int)]),
     "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
+    "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
     "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
@@ -396,6 +397,16 @@ class Ctx:
         self.ck(self.L.cmlhip_optimize_immature_points(self.h, N, _p(ids, C.c_uint64), _p(K, _d), pairs.ctypes.data, C.byref(prm), int(min_obs), n,
                                                         points.ctypes.data, _p(res, C.c_int), _p(idp, _f), _p(st, C.c_int)))
         return res, idp, st
+
+    # ------------------------------------------------------------------ coarse initializer (DSOInitializer::calcResAndGS)
+    def initializer_calc_res_and_gs(self, image_id, level, prm, points):
+        """points: INIT_POINT_DTYPE array, updated in place.  Returns (H 8x8, b 8, Hsc 8x8, bsc 8, res 3) as float32."""
+        assert points.dtype == abi.INIT_POINT_DTYPE and points.flags.c_contiguous
+        H = np.zeros((8, 8), np.float32); b = np.zeros(8, np.float32); Hsc = np.zeros((8, 8), np.float32); bsc = np.zeros(8, np.float32)
+        res = np.zeros(3, np.float32)
+        self.ck(self.L.cmlhip_initializer_calc_res_and_gs(self.h, int(image_id), int(level), C.byref(prm), len(points), points.ctypes.data,
+                                                           _p(H, _f), _p(b, _f), _p(Hsc, _f), _p(bsc, _f), _p(res, _f)))
+        return H, b, Hsc, bsc, res
 
     # ------------------------------------------------------------------ reproj
     def reproj_accumulate(self, poses, points, obs, fx, fy):

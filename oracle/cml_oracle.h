@@ -189,4 +189,9 @@ int orc_optimize_immature_point(int N, const float* const* images, int w, int h,
                                 const cmlhip_tracer_params* prm, int min_obs, const cmlhip_immature_point* point, float* idepth_out,
                                 int* res_state);
 
+/* ------------------------------------------------------------------ coarse initializer */
+/* DSOInitializer::calcResAndGS, DSOInitializer.cpp:451-750: aos3 = gradient image of the tracked frame at the level */
+void orc_init_calc_res_and_gs(const float* aos3, int w, int h, const cmlhip_init_params* prm, int n, cmlhip_init_point* points,
+                              float* H_out, float* b_out, float* H_out_sc, float* b_out_sc, float res[3]);
+
 #endif

@@ -314,3 +314,68 @@ def test_tracer_restatement_recovers_depth():
     assert ok.sum() > 20, np.bincount(res + 1, minlength=3)
     assert np.median(np.abs(idp[ok] / tr[ok] - 1)) < 0.02
     assert np.all(st[ok][np.arange(ok.sum()), cand["host"][ok]] == -1)
+
+
+def test_initializer_restatement_dense_form_and_derivative():
+    """SURVEY §8 f3 (DSOInitializer::calcResAndGS).  The restatement against an independent float64 numpy form of the same
+    sums (H = sum J^T J over the inlier residuals, Hsc = sum_p w_p jb_p jb_p^T), and its idepth Jacobian against a finite
+    difference of the per-point energy (dE/didepth = 2 sum r dd)."""
+    from tests import initializer_setup as IS
+    level = 1
+    W, g0, g1, R, t, ratio, tlog = IS.scene(level=level)
+    pts = IS.make_points(g0, step=3)
+    prm = IS.make_params(W.K, level, R, t, ratio, tlog)
+    o, H, b, Hsc, bsc, res = IS.oracle_calc(g1, prm, pts)
+    n = len(pts)
+    inl = o["is_good_new"] == 1
+    assert 0.3 * n < inl.sum() < n
+    assert res[2] == 2 * n
+    assert res[1] == np.float32(prm.alpha_k * n)                          # |t|^2 * alphaW > alphaK here: alphaOpt = 0 (coupling branch)
+    # --- independent dense form, float64
+    RKi = np.array(list(prm.RKi), np.float64).reshape(3, 3); tt = np.array(list(prm.t), np.float64)
+    Hn = np.zeros((9, 9)); Hs = np.zeros((9, 9)); E = 0.0
+    for i in range(n):
+        if not inl[i]:
+            E += float(pts["energy"][i, 0]); continue
+        q = pts["p_pattern"][i].astype(np.float64) @ RKi.T + tt * float(pts["idepth_new"][i])
+        u = q[:, 0] / q[:, 2]; v = q[:, 1] / q[:, 2]; nid = float(pts["idepth_new"][i]) / q[:, 2]
+        J = np.zeros((8, 9)); dd = np.zeros(8); e = 0.0
+        for k in range(8):
+            hit = O.interpolate3(g1, float(np.float32(prm.fx * u[k] + prm.cx)), float(np.float32(prm.fy * v[k] + prm.cy))).astype(np.float64)
+            r = hit[0] - prm.aff_a * float(pts["color"][i, k]) - prm.aff_b
+            hw = 1.0 if abs(r) < prm.huber else prm.huber / abs(r)
+            e += hw * r * r * (2 - hw)
+            s = np.sqrt(hw) if hw < 1 else 1.0
+            dx = s * hit[1] * prm.fx; dy = s * hit[2] * prm.fy
+            J[k, :8] = [nid[k] * dx, nid[k] * dy, -nid[k] * (u[k] * dx + v[k] * dy), -u[k] * v[k] * dx - (1 + v[k] ** 2) * dy,
+                        (1 + u[k] ** 2) * dx + u[k] * v[k] * dy, -v[k] * dx + u[k] * dy, -s * prm.aff_a * float(pts["color"][i, k]), -s]
+            J[k, 8] = s * r
+            dd[k] = dx * (tt[0] - tt[2] * u[k]) / q[k, 2] + dy * (tt[1] - tt[2] * v[k]) / q[k, 2]
+        E += e
+        Hn += J.T @ J
+        jb = J.T @ dd
+        jb[8] += prm.coupling_weight * (float(pts["idepth_new"][i]) - float(pts["iR"][i]))
+        w = 1.0 / (1.0 + dd @ dd + prm.coupling_weight)
+        Hs += w * np.outer(jb, jb)
+        assert abs(o["energy_new"][i, 0] - e) <= 1e-4 * max(e, 1.0)
+        assert abs(o["jb"][i, 9] - w) <= 1e-4 * w and abs(o["last_hessian_new"][i] - dd @ dd) <= 1e-3 * max(dd @ dd, 1e-4)
+    for got, want, name in ((H, Hn[:8, :8], "H"), (b, Hn[:8, 8], "b"), (Hsc, Hs[:8, :8], "Hsc"), (bsc, Hs[:8, 8], "bsc")):
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), name
+    assert abs(res[0] - E) <= 1e-4 * E
+    # --- dE/didepth by central differences (holds in the Huber band too: d(2k|r| - k^2) = 2 hw r dr = 2 (sqrt(hw) r)(sqrt(hw) dr))
+    eps = 1e-3
+    hi = pts.copy(); hi["idepth_new"] += np.float32(eps)
+    lo = pts.copy(); lo["idepth_new"] -= np.float32(eps)
+    oh = IS.oracle_calc(g1, prm, hi)[0]; ol = IS.oracle_calc(g1, prm, lo)[0]
+    step = (hi["idepth_new"].astype(np.float64) - lo["idepth_new"].astype(np.float64))
+    num = (oh["energy_new"][:, 0].astype(np.float64) - ol["energy_new"][:, 0]) / step
+    # jb[8] after the Schur loop = sum r dd + coupling * (idepth - iR)
+    rdd = o["jb"][:, 8].astype(np.float64) - prm.coupling_weight * (pts["idepth_new"].astype(np.float64) - pts["iR"])
+    ana = 2 * rdd
+    sel = inl & (oh["is_good_new"] == 1) & (ol["is_good_new"] == 1)
+    assert sel.sum() > 50
+    # the analytic form uses the interpolated central-difference gradient, the finite difference sees the bilinear facet the
+    # sample sits on: they agree as a population (slope and correlation), not per point
+    slope = float(np.dot(num[sel], ana[sel]) / np.dot(ana[sel], ana[sel]))
+    corr = float(np.corrcoef(num[sel], ana[sel])[0, 1])
+    assert 0.9 < slope < 1.1 and corr > 0.9, (slope, corr)
