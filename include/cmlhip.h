@@ -360,6 +360,34 @@ int cmlhip_initializer_calc_res_and_gs(cmlhip_ctx* ctx, uint64_t image_id, int l
                                        int n, cmlhip_init_point* points, float* H_out, float* b_out,
                                        float* H_out_sc, float* b_out_sc, float res[3]);
 
+/* ---------------------------------------------------------------- ORB side: pose-only optimisation
+ * IndirectCameraOptimizer::optimize (src/cml/optimization/g2o/IndirectCameraOptimizer.cpp:4-195 with g2o's Levenberg,
+ * :197-382 with Gauss-Newton) and evaluateOutliers (:384-427): one free VertexSE3Expmap, fixed points,
+ * EdgeSE3ProjectXYZ with a Huber kernel of delta sqrt(5.991), 4 rounds of 10 iterations with the observations re-classified
+ * after each round and the kernel removed for the last one.  The whole optimisation is ONE launch of one workgroup. */
+typedef struct {
+    double X[3];            /* pMP->getWorldCoordinate().absolute() (:71) */
+    double obs[2];          /* feature point of the frame (:66) */
+    double inv_sigma2;      /* edge information (:87-88: 1 / descriptor distance; :281: 1 / scaleFactor^2) */
+    double info;            /* vnInfo: the information evaluateOutliers tests with (:89, :285) */
+} cmlhip_pnp_match;        /* 56 bytes */
+enum { CMLHIP_PNP_LEVENBERG = 0, CMLHIP_PNP_GAUSS_NEWTON = 1 };
+typedef struct {
+    int    is_ok;           /* IndirectCameraOptimizerResult::isOk */
+    int    rounds;          /* rounds completed before returning */
+    int    n_bad;           /* outliers after the last evaluateOutliers */
+    int    lm_iterations[4];/* solve() calls of each round */
+    int    pad;
+    double R[9], t[3];      /* result.camera (world -> camera); the pose reached when is_ok == 0 */
+    double covariance[6];   /* diagonal of Hpp^-1 (:177-190) when asked for */
+    double chi2[4];         /* active robust chi2 at the last linearisation of each round */
+} cmlhip_pnp_result;
+/* R, t: the pose every round starts from (`camera` when given, else frame->getCamera(), :132-135); K = fx, fy, cx, cy
+ * of level 0; outliers (n bytes, in/out) as the reference's List<bool>; check_outliers = mCheckOutliers. */
+int cmlhip_pnp_optimize(cmlhip_ctx* ctx, const double R[9], const double t[3], const double K[4], int n,
+                        const cmlhip_pnp_match* matches, unsigned char* outliers, int algorithm, int check_outliers,
+                        int compute_covariance, cmlhip_pnp_result* out);
+
 /* ---------------------------------------------------------------- marginalisation (once per keyframe), SURVEY §8 a15
  * tryMarginalize's residual loop (BA.cpp:2291-2304) for the points that are about to be marginalised: every residual of the
  * listed points is reset (resetOOB), re-linearised at the current state, committed (applyRes(true)) and, when good,

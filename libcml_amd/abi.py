@@ -141,6 +141,17 @@ class InitParams(C.Structure):
                 ("coupling_weight", C.c_float), ("tlog", C.c_float * 3), ("pad", C.c_float), ("t_sqnorm", C.c_double)]
 
 
+PNP_MATCH_DTYPE = np.dtype([("X", "<f8", (3,)), ("obs", "<f8", (2,)), ("inv_sigma2", "<f8"), ("info", "<f8")])
+assert PNP_MATCH_DTYPE.itemsize == 56
+PNP_LEVENBERG, PNP_GAUSS_NEWTON = 0, 1
+
+
+class PnpResult(C.Structure):
+    """cmlhip_pnp_result: IndirectCameraOptimizerResult (IndirectCameraOptimizer.h) + per-round diagnostics."""
+    _fields_ = [("is_ok", C.c_int), ("rounds", C.c_int), ("n_bad", C.c_int), ("lm_iterations", C.c_int * 4), ("pad", C.c_int),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("covariance", C.c_double * 6), ("chi2", C.c_double * 4)]
+
+
 class TracerParams(C.Structure):
     _fields_ = [("max_pix_search", C.c_double), ("max_slack_interval", C.c_double), ("trace_step_size", C.c_double),
                 ("min_improvement_factor", C.c_double), ("min_trace_test_radius", C.c_double), ("extra_slack_on_th", C.c_double),

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "cmlhip_tracer_trace_resident": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, _P(C.c_int)]),
     "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
+    "cmlhip_pnp_optimize": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_double), _P(C.c_double), _i, C.c_void_p, _P(C.c_ubyte), _i, _i, _i, _P(abi.PnpResult)]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
     "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
@@ -407,6 +408,17 @@ class Ctx:
         self.ck(self.L.cmlhip_initializer_calc_res_and_gs(self.h, int(image_id), int(level), C.byref(prm), len(points), points.ctypes.data,
                                                            _p(H, _f), _p(b, _f), _p(Hsc, _f), _p(bsc, _f), _p(res, _f)))
         return H, b, Hsc, bsc, res
+
+    # ------------------------------------------------------------------ ORB side: pose-only optimisation (IndirectCameraOptimizer)
+    def pnp_optimize(self, R, t, K, matches, outliers, algorithm=abi.PNP_LEVENBERG, check_outliers=True, compute_covariance=False):
+        """matches: PNP_MATCH_DTYPE array; outliers: uint8 array, updated in place.  Returns abi.PnpResult."""
+        assert matches.dtype == abi.PNP_MATCH_DTYPE and matches.flags.c_contiguous
+        assert outliers.dtype == np.uint8 and len(outliers) == len(matches) and outliers.flags.c_contiguous
+        R = np.ascontiguousarray(R, np.float64); t = np.ascontiguousarray(t, np.float64); K = np.ascontiguousarray(K, np.float64)
+        out = abi.PnpResult()
+        self.ck(self.L.cmlhip_pnp_optimize(self.h, _p(R, _d), _p(t, _d), _p(K, _d), len(matches), matches.ctypes.data, _p(outliers, C.c_ubyte),
+                                            int(algorithm), int(bool(check_outliers)), int(bool(compute_covariance)), C.byref(out)))
+        return out
 
     # ------------------------------------------------------------------ reproj
     def reproj_accumulate(self, poses, points, obs, fx, fy):

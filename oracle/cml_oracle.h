@@ -29,6 +29,11 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* ------------------------------------------------------------------ ORB side: pose-only optimisation */
+/* IndirectCameraOptimizer::optimize + evaluateOutliers over the vendored g2o, IndirectCameraOptimizer.cpp:4-427 */
+void orc_pnp_optimize(const double R0[9], const double t0[3], const double K[4], int n, const cmlhip_pnp_match* m,
+                      unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out);
+
 #endif
 
 /* ------------------------------------------------------------------ images */
@@ -178,6 +183,11 @@ void orc_reproj_accumulate(int N, const double* poses, int M, const double* poin
 
 #ifdef __cplusplus
 }
+/* ------------------------------------------------------------------ ORB side: pose-only optimisation */
+/* IndirectCameraOptimizer::optimize + evaluateOutliers over the vendored g2o, IndirectCameraOptimizer.cpp:4-427 */
+void orc_pnp_optimize(const double R0[9], const double t0[3], const double K[4], int n, const cmlhip_pnp_match* m,
+                      unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out);
+
 #endif
 
 /* ------------------------------------------------------------------ immature points: DSOTracer */
@@ -193,5 +203,10 @@ int orc_optimize_immature_point(int N, const float* const* images, int w, int h,
 /* DSOInitializer::calcResAndGS, DSOInitializer.cpp:451-750: aos3 = gradient image of the tracked frame at the level */
 void orc_init_calc_res_and_gs(const float* aos3, int w, int h, const cmlhip_init_params* prm, int n, cmlhip_init_point* points,
                               float* H_out, float* b_out, float* H_out_sc, float* b_out_sc, float res[3]);
+
+/* ------------------------------------------------------------------ ORB side: pose-only optimisation */
+/* IndirectCameraOptimizer::optimize + evaluateOutliers over the vendored g2o, IndirectCameraOptimizer.cpp:4-427 */
+void orc_pnp_optimize(const double R0[9], const double t0[3], const double K[4], int n, const cmlhip_pnp_match* m,
+                      unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out);
 
 #endif

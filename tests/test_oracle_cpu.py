@@ -379,3 +379,31 @@ def test_initializer_restatement_dense_form_and_derivative():
     slope = float(np.dot(num[sel], ana[sel]) / np.dot(ana[sel], ana[sel]))
     corr = float(np.corrcoef(num[sel], ana[sel])[0, 1])
     assert 0.9 < slope < 1.1 and corr > 0.9, (slope, corr)
+
+
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_pnp_restatement_recovers_pose_and_flags_outliers(algorithm):
+    """SURVEY §8 f4 (IndirectCameraOptimizer over g2o).  Functional pin of the restatement: from a perturbed start the 4
+    rounds land on the true pose, the planted gross outliers are flagged, the covariance is the diagonal of (J^T W J)^-1."""
+    from tests import pnp_setup as PS
+    S = PS.scene()
+    m = S["matches"]
+    if algorithm == 1:
+        m = m.copy(); m["inv_sigma2"] = m["info"]                 # the Gauss-Newton overload uses 1/scaleFactor^2 for both
+    out = np.zeros(len(m), np.uint8)
+    r = PS.oracle_pnp(S["R0"], S["t0"], S["K"], m, out, algorithm=algorithm, compute_covariance=True)
+    assert r.is_ok == 1 and r.rounds == 4
+    R = np.array(list(r.R)).reshape(3, 3); t = np.array(list(r.t))
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+    ang = np.arccos(np.clip((np.trace(R @ S["R_true"].T) - 1) / 2, -1, 1))
+    assert ang < 2e-3 and np.linalg.norm(t - S["t_true"]) < 2e-2, (ang, t - S["t_true"])
+    planted = S["planted"]
+    assert out[planted].mean() > 0.98 and out[~planted].mean() < 0.15
+    assert r.n_bad == int(out.sum())
+    # start pose error was ~10x larger
+    ang0 = np.arccos(np.clip((np.trace(S["R0"] @ S["R_true"].T) - 1) / 2, -1, 1))
+    assert ang0 > 5 * ang
+    cov = np.array(list(r.covariance))
+    assert np.all(cov > 0) and np.all(cov < 1e-2)
+    # chi2 decreases over the robust rounds as outliers are excluded
+    assert r.chi2[1] <= r.chi2[0] * 1.0001
