@@ -19,6 +19,7 @@
 #pragma clang fp contract(off)
 
 #define PNP_THREADS 256
+#define PNP_WAVES (PNP_THREADS / 64)
 #define PNP_MAX_MATCHES 2560             // 48 B of LDS per match (120 KB) + tiles: under the 160 KB of a CU
 typedef double pnp_double4 __attribute__((ext_vector_type(4)));
 
@@ -31,12 +32,28 @@ struct PnpArgs {
     cmlhip_pnp_result* out;
 };
 
+// v_rcp_f64 / v_rsq_f64 seeds + two Newton steps with explicit fmas: <= 1 ulp, a third of the instructions of the IEEE
+// division / square root sequences.  The parity bar of this path is 1e-9 (the reduction order differs from g2o's anyway).
+__device__ __forceinline__ double pnp_rcp(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
+    x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
+    return x;
+}
+__device__ __forceinline__ double pnp_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
+    return y;
+}
+
 // ---------------------------------------------------------------------------------------------- SE3Quat on one lane
 __device__ static void pq_from_matrix(const double m[9], PnpPose& q) {     // Eigen Quaternion(Matrix3)
     const double tr = m[0] + m[4] + m[8];
     if (tr > 0) {
-        double t = sqrt(tr + 1.0);
-        q.w = 0.5 * t; t = 0.5 / t;
+        const double r = pnp_rsqrt(tr + 1.0);
+        double t = (tr + 1.0) * r;
+        q.w = 0.5 * t; t = 0.5 * r;
         q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
     } else {
         int i = 0;
@@ -54,8 +71,8 @@ __device__ static void pq_from_matrix(const double m[9], PnpPose& q) {     // Ei
 }
 __device__ static void pq_normalize(PnpPose& q) {                          // se3quat.h normalizeRotation
     if (q.w < 0) { q.x *= -1; q.y *= -1; q.z *= -1; q.w *= -1; }
-    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    const double n = pnp_rsqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x *= n; q.y *= n; q.z *= n; q.w *= n;
 }
 __device__ __forceinline__ void pq_rotate(const PnpPose& q, const double v[3], double o[3]) {
     double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
@@ -74,15 +91,19 @@ __device__ static void pq_to_matrix(const PnpPose& q, double R[9]) {
 }
 __device__ static void pq_exp(const double u[6], PnpPose& T) {             // se3quat.h:201-229
     const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
-    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    const double theta = sqrt(th2);
     const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
     double O2[9], R[9], V[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
     double a, b, c, d;
     if (theta < 0.00001) { a = 1; b = 0.5; c = 0.5; d = 1. / 6.; }
     else {
-        a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta);
-        c = b; d = (theta - sin(theta)) / pow(theta, 3.0);
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        const double it = pnp_rcp(theta), it2 = it * it;
+        a = sn * it; b = (1 - cs) * it2;
+        c = b; d = (theta - sn) * (it2 * it);
     }
     for (int i = 0; i < 9; i++) {
         const double I = (i % 4 == 0) ? 1.0 : 0.0;
@@ -109,46 +130,59 @@ __device__ static bool pnp_llt_solve(const double* Hin, double lambda, const dou
     double L[36];
     for (int i = 0; i < 36; i++) L[i] = Hin[i];
     for (int i = 0; i < 6; i++) L[i * 6 + i] += lambda;
+    double inv[6];
+#pragma unroll
     for (int j = 0; j < 6; j++) {
         double d = L[j * 6 + j];
+#pragma unroll
         for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
         if (!(d > 0)) return false;
-        d = sqrt(d); L[j * 6 + j] = d;
+        inv[j] = pnp_rsqrt(d); L[j * 6 + j] = d * inv[j];
+#pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double s = L[i * 6 + j];
+#pragma unroll
             for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = s / d;
+            L[i * 6 + j] = s * inv[j];
         }
     }
     double y[6];
-    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
-    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s * inv[i]; }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) { double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s * inv[i]; }
     return true;
 }
 
 // ---------------------------------------------------------------------------------------------- one pass over the edges
 struct PnpShared {
-    double tile[4][64][9];       // per wave: one Jacobian row of each lane's edge, [6] = -e, [7] = rho' * omega
-    double part[4][44];          // per wave: 6x7 sums + chi
+    double tile[PNP_WAVES][64][9];   // per wave: one Jacobian row of each lane's edge, [6] = -e, [7] = rho' * omega
+    double part[2 * PNP_WAVES][44];  // per wave and 8 x 8 block: 6x7 sums + chi
     double sys[2][44];           // [0] the system the solver works on, [1] the system at the trial pose (H 36 | b 6 | chi)
     PnpPose T, Ttrial, T0;
     int ctl[4];                  // [0] loop-again flag, [1] stop flag, [2] nBad
     unsigned char lvl[PNP_MAX_MATCHES];
 };
 
+// computeError, edge_project_xyz.cpp:44-50: p = (x/z, y/z, 1/z) of the mapped point
 __device__ __forceinline__ void pnp_edge(const double* sm, int i, const PnpPose& T, const double K[4], double e[2], double p[3], double& om) {
     const double X[3] = {sm[6 * i], sm[6 * i + 1], sm[6 * i + 2]};
     double r[3];
-    pq_rotate(T, X, r);                                                        // computeError, edge_project_xyz.cpp:44-50
-    p[0] = r[0] + T.t[0]; p[1] = r[1] + T.t[1]; p[2] = r[2] + T.t[2];
-    e[0] = sm[6 * i + 3] - (p[0] / p[2] * K[0] + K[2]);
-    e[1] = sm[6 * i + 4] - (p[1] / p[2] * K[1] + K[3]);
+    pq_rotate(T, X, r);
+    const double iz = pnp_rcp(r[2] + T.t[2]);
+    p[0] = (r[0] + T.t[0]) * iz; p[1] = (r[1] + T.t[1]) * iz; p[2] = iz;
+    e[0] = sm[6 * i + 3] - (p[0] * K[0] + K[2]);
+    e[1] = sm[6 * i + 4] - (p[1] * K[1] + K[3]);
     om = sm[6 * i + 5];
 }
 
 // computeActiveErrors + activeRobustChi2 + buildSystem at pose `T` into S.sys[dst]
 __device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const PnpPose& T, const double K[4], bool robust, double delta, int dst) {
-    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, col = l & 15, kq = l >> 4;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, col = l & 15, kq = l >> 4, pk = col >> 3, c7 = col & 7;
     pnp_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
     double chi = 0.0;
     for (int base = 0; base < n; base += PNP_THREADS) {
@@ -164,36 +198,38 @@ __device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const
             double rho0 = chi2, rho1 = 1.0;
             if (robust) {                                                      // robust_kernel_impl.cpp:60-74
                 const double dsqr = delta * delta;
-                if (!(chi2 <= dsqr)) { const double sq = sqrt(chi2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+                if (!(chi2 <= dsqr)) { const double rs = pnp_rsqrt(chi2), sq = chi2 * rs; rho0 = 2 * sq * delta - dsqr; rho1 = delta * rs; }
             }
             chi += rho0;
-            const double x = p[0], y = p[1], z = p[2], z_2 = z * z, fx = K[0], fy = K[1];
-            J0[0] = x * y / z_2 * fx; J0[1] = -(1 + (x * x / z_2)) * fx; J0[2] = y / z * fx;        // edge_project_xyz.cpp:80-94
-            J0[3] = -1. / z * fx; J0[4] = 0; J0[5] = x / z_2 * fx;
-            J1[0] = (1 + y * y / z_2) * fy; J1[1] = -x * y / z_2 * fy; J1[2] = -x / z * fy;
-            J1[3] = 0; J1[4] = -1. / z * fy; J1[5] = y / z_2 * fy;
+            const double u = p[0], v = p[1], iz = p[2], fx = K[0], fy = K[1];                       // u = x/z, v = y/z
+            J0[0] = u * v * fx; J0[1] = -(1 + u * u) * fx; J0[2] = v * fx;                          // edge_project_xyz.cpp:80-94
+            J0[3] = -iz * fx; J0[4] = 0; J0[5] = u * iz * fx;
+            J1[0] = (1 + v * v) * fy; J1[1] = -u * v * fy; J1[2] = -u * fy;
+            J1[3] = 0; J1[4] = -iz * fy; J1[5] = v * iz * fy;
             J0[6] = -e[0]; J1[6] = -e[1];
             w = rho1 * om;
         }
-        // row 0 of every edge of this wave, then row 1: D += sum_k (w_k J_k) [J_k | -e_k]^T, 4 rows per instruction
+        // row 0 of every edge of this wave, then row 1: D += sum_k (w_k J_k) [J_k | -e_k]^T.  Only 6 x 7 of the 16 x 16 tile is
+        // wanted, so two edges ride in one K step: A rows / B columns 0..7 carry edge 2k, 8..15 carry edge 2k+1 (the two
+        // off-diagonal 8 x 8 blocks hold cross terms nobody reads): 8 edge rows per instruction
 #pragma unroll
         for (int k = 0; k < 7; k++) S.tile[wv][l][k] = J0[k];
         S.tile[wv][l][7] = w;
         // (LDS accesses of one wave are ordered: no barrier between the stores above and the loads below)
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const double* row = S.tile[wv][4 * m + kq];
-            const double v = col < 7 ? row[col] : 0.0;
-            const double av = col < 6 ? v * row[7] : 0.0;
+        for (int m = 0; m < 8; m++) {
+            const double* row = S.tile[wv][8 * m + 2 * kq + pk];
+            const double v = c7 < 7 ? row[c7] : 0.0;
+            const double av = c7 < 6 ? v * row[7] : 0.0;
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, v, acc0, 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < 7; k++) S.tile[wv][l][k] = J1[k];
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const double* row = S.tile[wv][4 * m + kq];
-            const double v = col < 7 ? row[col] : 0.0;
-            const double av = col < 6 ? v * row[7] : 0.0;
+        for (int m = 0; m < 8; m++) {
+            const double* row = S.tile[wv][8 * m + 2 * kq + pk];
+            const double v = c7 < 7 ? row[c7] : 0.0;
+            const double av = c7 < 6 ? v * row[7] : 0.0;
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, v, acc1, 0, 0, 0);
         }
     }
@@ -201,14 +237,16 @@ __device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
         const int row = kq + 4 * rg;
-        if (row < 6 && col < 7) S.part[wv][row * 7 + col] = acc0[rg] + acc1[rg];
+        if ((row >> 3) == pk && (row & 7) < 6 && c7 < 7) S.part[2 * wv + pk][(row & 7) * 7 + c7] = acc0[rg] + acc1[rg];
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) chi += __shfl_xor(chi, off, 64);
-    if (l == 0) S.part[wv][42] = chi;
+    if (l == 0) { S.part[2 * wv][42] = chi; S.part[2 * wv + 1][42] = 0.0; }
     __syncthreads();
     if (tid < 43) {
-        const double v = ((S.part[0][tid] + S.part[1][tid]) + S.part[2][tid]) + S.part[3][tid];
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2 * PNP_WAVES; k++) v += S.part[k][tid];
         int at = 42;                                                           // chi
         if (tid < 42) { const int r = tid / 7, c = tid % 7; at = c < 6 ? r * 6 + c : 36 + r; }
         S.sys[dst][at] = v;
@@ -280,7 +318,8 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                         rho /= scale;
                         bool brk = false;
                         if (rho > 0 && isfinite(tempChi)) {
-                            double alpha = 1. - pow(2 * rho - 1, 3.0);
+                            const double r21 = 2 * rho - 1;
+                            double alpha = 1. - r21 * r21 * r21;
                             alpha = fmin(alpha, 2. / 3.);
                             const double sf = fmax(1. / 3., alpha);
                             lambda *= sf; ni = 2.0; currentChi = tempChi;
