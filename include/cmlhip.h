@@ -388,6 +388,36 @@ int cmlhip_pnp_optimize(cmlhip_ctx* ctx, const double R[9], const double t[3], c
                         const cmlhip_pnp_match* matches, unsigned char* outliers, int algorithm, int check_outliers,
                         int compute_covariance, cmlhip_pnp_result* out);
 
+/* ---------------------------------------------------------------- ORB side: local bundle adjustment
+ * IndirectBundleAdjustment::localOptimize / startOptimization / the removal test of apply()
+ * (src/cml/optimization/g2o/IndirectBundleAdjustment.cpp:7-236,:322-334) with the graph handed over as arrays.
+ * The host keeps the covisibility search that selects local keyframes, fixed keyframes and local points (:9-35). */
+typedef struct {
+    double R[9], t[3];      /* frame->getCamera(): world -> camera (:72, :86) */
+    double K[4];            /* fx, fy, cx, cy of frame->getK(0) (:150-154) */
+    int    fixed;           /* 1: lFixedCameras (or every frame when fixFrames) */
+    int    pad;
+} cmlhip_lba_frame;        /* 136 bytes */
+typedef struct {
+    int    frame;           /* index into the frame array */
+    int    pad;
+    double obs[2];          /* corner.point0() (:139) */
+    double inv_sigma2;      /* 1 / scaleFactor^2 (:141-143) */
+} cmlhip_lba_edge;         /* 32 bytes */
+typedef struct {
+    int    ok;
+    int    n_bad;           /* edges that fail apply()'s test chi2 > 5.991 || !isDepthPositive (:327) */
+    int    iterations_done[2];   /* optimize() iterations of the first pass and of the refinement pass */
+    double chi2[2];         /* active robust chi2 after each pass (Levenberg mode) */
+} cmlhip_lba_result;
+/* Edges are point-major, in the order :120-165 creates them: point p owns edges [point_offsets[p], point_offsets[p+1]).
+ * fix_frames != 0 (mBaMode != BAINDIRECT, indirect/Mapping.cpp:89): g2o's StructureOnlySolver<3> — poses stay, every point is
+ * refined on its own (one launch, a lane per point).  points (n_points x 3) and frames are updated in place;
+ * edge_bad (one byte per edge) receives apply()'s removal test. */
+int cmlhip_lba_optimize(cmlhip_ctx* ctx, int n_frames, cmlhip_lba_frame* frames, int n_points, double* points,
+                        const int* point_offsets, const cmlhip_lba_edge* edges, int fix_frames, int num_iterations,
+                        int refine_iterations, unsigned char* edge_bad, cmlhip_lba_result* out);
+
 /* ---------------------------------------------------------------- marginalisation (once per keyframe), SURVEY §8 a15
  * tryMarginalize's residual loop (BA.cpp:2291-2304) for the points that are about to be marginalised: every residual of the
  * listed points is reset (resetOOB), re-linearised at the current state, committed (applyRes(true)) and, when good,

@@ -152,6 +152,16 @@ class PnpResult(C.Structure):
                 ("R", C.c_double * 9), ("t", C.c_double * 3), ("covariance", C.c_double * 6), ("chi2", C.c_double * 4)]
 
 
+LBA_FRAME_DTYPE = np.dtype([("R", "<f8", (9,)), ("t", "<f8", (3,)), ("K", "<f8", (4,)), ("fixed", "<i4"), ("pad", "<i4")])
+LBA_EDGE_DTYPE = np.dtype([("frame", "<i4"), ("pad", "<i4"), ("obs", "<f8", (2,)), ("inv_sigma2", "<f8")])
+assert LBA_FRAME_DTYPE.itemsize == 136 and LBA_EDGE_DTYPE.itemsize == 32
+
+
+class LbaResult(C.Structure):
+    """cmlhip_lba_result"""
+    _fields_ = [("ok", C.c_int), ("n_bad", C.c_int), ("iterations_done", C.c_int * 2), ("chi2", C.c_double * 2)]
+
+
 class TracerParams(C.Structure):
     _fields_ = [("max_pix_search", C.c_double), ("max_slack_interval", C.c_double), ("trace_step_size", C.c_double),
                 ("min_improvement_factor", C.c_double), ("min_trace_test_radius", C.c_double), ("extra_slack_on_th", C.c_double),

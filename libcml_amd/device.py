@@ -52,6 +52,7 @@ PROTOTYPES = {
     "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "cmlhip_pnp_optimize": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_double), _P(C.c_double), _i, C.c_void_p, _P(C.c_ubyte), _i, _i, _i, _P(abi.PnpResult)]),
+    "cmlhip_lba_optimize": (C.c_int, [_ctx, _i, C.c_void_p, _i, _P(C.c_double), _P(C.c_int), C.c_void_p, _i, _i, _i, _P(C.c_ubyte), _P(abi.LbaResult)]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
     "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
@@ -419,6 +420,19 @@ class Ctx:
         self.ck(self.L.cmlhip_pnp_optimize(self.h, _p(R, _d), _p(t, _d), _p(K, _d), len(matches), matches.ctypes.data, _p(outliers, C.c_ubyte),
                                             int(algorithm), int(bool(check_outliers)), int(bool(compute_covariance)), C.byref(out)))
         return out
+
+    # ------------------------------------------------------------------ ORB side: local bundle adjustment (IndirectBundleAdjustment)
+    def lba_optimize(self, frames, points, point_offsets, edges, fix_frames=True, num_iterations=5, refine_iterations=0):
+        """frames (LBA_FRAME_DTYPE) and points (n x 3 float64) are updated in place.  Returns (edge_bad uint8, abi.LbaResult)."""
+        assert frames.dtype == abi.LBA_FRAME_DTYPE and edges.dtype == abi.LBA_EDGE_DTYPE and frames.flags.c_contiguous and edges.flags.c_contiguous
+        assert points.dtype == np.float64 and points.flags.c_contiguous and points.shape == (len(point_offsets) - 1, 3)
+        off = np.ascontiguousarray(point_offsets, np.int32)
+        assert off[-1] == len(edges)
+        bad = np.zeros(len(edges), np.uint8)
+        out = abi.LbaResult()
+        self.ck(self.L.cmlhip_lba_optimize(self.h, len(frames), frames.ctypes.data, len(points), _p(points, _d), _p(off, C.c_int), edges.ctypes.data,
+                                            int(bool(fix_frames)), int(num_iterations), int(refine_iterations), _p(bad, C.c_ubyte), C.byref(out)))
+        return bad, out
 
     # ------------------------------------------------------------------ reproj
     def reproj_accumulate(self, poses, points, obs, fx, fy):

@@ -34,6 +34,13 @@ extern "C" {
 void orc_pnp_optimize(const double R0[9], const double t0[3], const double K[4], int n, const cmlhip_pnp_match* m,
                       unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out);
 
+/* ------------------------------------------------------------------ ORB side: local bundle adjustment */
+/* IndirectBundleAdjustment::localOptimize + startOptimization + apply's edge test, IndirectBundleAdjustment.cpp:7-334 */
+int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, double* points, const int* point_offsets,
+                     const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations,
+                     unsigned char* edge_bad, cmlhip_lba_result* out);
+int orc_ldlt3(const double A[9], const double b[3], double x[3]);   /* Eigen::LDLT<Matrix3d>: returns isPositive() */
+
 #endif
 
 /* ------------------------------------------------------------------ images */
@@ -188,6 +195,13 @@ void orc_reproj_accumulate(int N, const double* poses, int M, const double* poin
 void orc_pnp_optimize(const double R0[9], const double t0[3], const double K[4], int n, const cmlhip_pnp_match* m,
                       unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out);
 
+/* ------------------------------------------------------------------ ORB side: local bundle adjustment */
+/* IndirectBundleAdjustment::localOptimize + startOptimization + apply's edge test, IndirectBundleAdjustment.cpp:7-334 */
+int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, double* points, const int* point_offsets,
+                     const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations,
+                     unsigned char* edge_bad, cmlhip_lba_result* out);
+int orc_ldlt3(const double A[9], const double b[3], double x[3]);   /* Eigen::LDLT<Matrix3d>: returns isPositive() */
+
 #endif
 
 /* ------------------------------------------------------------------ immature points: DSOTracer */
@@ -208,5 +222,12 @@ void orc_init_calc_res_and_gs(const float* aos3, int w, int h, const cmlhip_init
 /* IndirectCameraOptimizer::optimize + evaluateOutliers over the vendored g2o, IndirectCameraOptimizer.cpp:4-427 */
 void orc_pnp_optimize(const double R0[9], const double t0[3], const double K[4], int n, const cmlhip_pnp_match* m,
                       unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out);
+
+/* ------------------------------------------------------------------ ORB side: local bundle adjustment */
+/* IndirectBundleAdjustment::localOptimize + startOptimization + apply's edge test, IndirectBundleAdjustment.cpp:7-334 */
+int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, double* points, const int* point_offsets,
+                     const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations,
+                     unsigned char* edge_bad, cmlhip_lba_result* out);
+int orc_ldlt3(const double A[9], const double b[3], double x[3]);   /* Eigen::LDLT<Matrix3d>: returns isPositive() */
 
 #endif

@@ -1,0 +1,55 @@
+"""SURVEY §8 f4 on the device: IndirectBundleAdjustment::localOptimize with fixFrames (g2o StructureOnlySolver<3>: every
+point refined on its own over its track, Huber sqrt(5.991), damped Gauss-Newton with up to 10 trials, Eigen LDLT 3x3) and
+apply()'s edge removal test, through the C ABI against the oracle.
+Bar: BIT-EXACT points and edge flags — each point's arithmetic is sequential fp64 in the same order on both sides."""
+import numpy as np
+import pytest
+
+from libcml_amd import abi, device
+from tests import lba_setup as LS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw,iters,refine", [(dict(), 5, 0), (dict(n_points=3000, seed=4, point_noise=0.15), 5, 3),
+                                             (dict(n_points=200, seed=6, outlier_fraction=0.2), 1, 1), (dict(n_points=64, seed=8, noise_px=0.0, point_noise=0.0), 5, 0)])
+def test_structure_only_bit_exact(kw, iters, refine):
+    S = LS.scene(**kw)
+    fr_o, pts_o, bad_o, r_o = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], True, iters, refine)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        fr = S["frames"].copy(); pts = S["points"].copy()
+        bad, r = ctx.lba_optimize(fr, pts, S["off"], S["edges"], True, iters, refine)
+    finally:
+        ctx.close()
+    assert np.array_equal(fr, S["frames"])
+    assert np.array_equal(pts.view(np.uint64), pts_o.view(np.uint64)), float(np.abs(pts - pts_o).max())
+    assert np.array_equal(bad, bad_o)
+    assert r.ok == 1 and r.n_bad == r_o.n_bad and list(r.iterations_done) == list(r_o.iterations_done)
+    moved = np.abs(pts - S["points"]).max(axis=1) > 0
+    assert moved.mean() > 0.5 or kw.get("point_noise", 1) == 0.0
+
+
+def test_lba_edge_cases():
+    S = LS.scene(n_points=50, seed=1)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        # no points / no iterations: nothing moves, flags from zero errors (all good unless behind the camera)
+        bad, r = ctx.lba_optimize(S["frames"].copy(), np.zeros((0, 3)), np.zeros(1, np.int32), S["edges"][:0].copy())
+        assert r.ok == 1 and len(bad) == 0
+        pts = S["points"].copy()
+        bad, r = ctx.lba_optimize(S["frames"].copy(), pts, S["off"], S["edges"], True, 0, 0)
+        assert np.array_equal(pts, S["points"]) and not bad.any()
+        # a point behind a camera is flagged by isDepthPositive
+        pts = S["points"].copy(); pts[0] = [0.0, 0.0, -50.0]
+        _, pts_o, bad_o, _ = LS.oracle_lba(S["frames"], pts, S["off"], S["edges"], True, 2, 0)
+        bad, r = ctx.lba_optimize(S["frames"].copy(), pts, S["off"], S["edges"], True, 2, 0)
+        assert np.array_equal(bad, bad_o) and np.array_equal(pts.view(np.uint64), pts_o.view(np.uint64))
+        # bad frame index / free poses: refused
+        e = S["edges"].copy(); e["frame"][3] = 99
+        with pytest.raises(device.CmlHipError):
+            ctx.lba_optimize(S["frames"].copy(), S["points"].copy(), S["off"], e)
+        with pytest.raises(device.CmlHipError):
+            ctx.lba_optimize(S["frames"].copy(), S["points"].copy(), S["off"], S["edges"], fix_frames=False)
+    finally:
+        ctx.close()

@@ -407,3 +407,32 @@ def test_pnp_restatement_recovers_pose_and_flags_outliers(algorithm):
     assert np.all(cov > 0) and np.all(cov < 1e-2)
     # chi2 decreases over the robust rounds as outliers are excluded
     assert r.chi2[1] <= r.chi2[0] * 1.0001
+
+
+def test_local_ba_structure_only_restatement():
+    """SURVEY §8 f4 (IndirectBundleAdjustment, fixFrames: g2o StructureOnlySolver).  Functional pin: the points move towards
+    the truth, the robust cost of every track does not increase, the planted gross outliers fail apply()'s chi2 test; the
+    3x3 LDLT equals the restatement that is pinned on the vendored Eigen."""
+    from tests import lba_setup as LS
+    rng = np.random.default_rng(0)
+    L = O.lib()
+    for _ in range(50):
+        A = rng.normal(size=(3, 3)); A = A @ A.T + 1e-3 * np.eye(3); b = rng.normal(size=3)
+        x = np.zeros(3)
+        pos = L.orc_ldlt3(O.ptr(np.ascontiguousarray(A), C.c_double), O.ptr(b, C.c_double), O.ptr(x, C.c_double))
+        assert pos == 1 and np.array_equal(x, O.ldlt_solve(A, b)[0])
+    ind = np.diag([1.0, -2.0, 3.0]); x = np.zeros(3)
+    assert L.orc_ldlt3(O.ptr(ind, C.c_double), O.ptr(np.ones(3), C.c_double), O.ptr(x, C.c_double)) == 0
+    S = LS.scene()
+    fr, pts, bad, r = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], fix_frames=True, num_iterations=5)
+    assert r.ok == 1 and r.iterations_done[0] == 5 and r.iterations_done[1] == 0
+    assert np.array_equal(fr, S["frames"])                                   # poses untouched
+    e0 = np.linalg.norm(S["points"] - S["truth"], axis=1); e1 = np.linalg.norm(pts - S["truth"], axis=1)
+    clean = np.array([not S["planted"][S["off"][p]:S["off"][p + 1]].any() for p in range(len(pts))])
+    assert np.median(e1[clean]) < 0.5 * np.median(e0[clean]), (np.median(e0[clean]), np.median(e1[clean]))
+    assert bad[S["planted"]].mean() > 0.9 and bad[~S["planted"]].mean() < 0.1
+    assert r.n_bad == int(bad.sum())
+    # the refinement pass (kernel off, bad edges at level 1) keeps converging
+    fr2, pts2, bad2, r2 = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], fix_frames=True, num_iterations=5, refine_iterations=3)
+    assert r2.iterations_done[1] == 3
+    assert np.isfinite(pts2).all()
