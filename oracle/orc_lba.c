@@ -147,6 +147,229 @@ static void structure_only_point(const lba_cam* cams, const cmlhip_lba_edge* E, 
     }
 }
 
+
+/* ================================================================== free poses: g2o Levenberg + Schur (fixFrames == false)
+ * OptimizationAlgorithmLevenberg::solve (g2o/core/optimization_algorithm_levenberg.cpp:58-175) over BlockSolver_6_3 with the
+ * points marginalised (buildSystem / setLambda / solve, g2o/core/block_solver.hpp:329-479,495-587) and LinearSolverEigen
+ * (SimplicialLLT) on the reduced pose system — restated densely: the sparse block structure only skips zero blocks. */
+
+/* _jacobianOplusXj, edge_project_xyz.cpp:80-94 */
+static void edge_jacobian_pose(const lba_cam* C, const double p[3], double J[2][6]) {
+    const double x = p[0], y = p[1], z = p[2], z_2 = z * z, fx = C->K[0], fy = C->K[1];
+    J[0][0] = x * y / z_2 * fx; J[0][1] = -(1 + (x * x / z_2)) * fx; J[0][2] = y / z * fx;
+    J[0][3] = -1. / z * fx; J[0][4] = 0; J[0][5] = x / z_2 * fx;
+    J[1][0] = (1 + y * y / z_2) * fy; J[1][1] = -x * y / z_2 * fy; J[1][2] = -x / z * fy;
+    J[1][3] = 0; J[1][4] = -1. / z * fy; J[1][5] = y / z_2 * fy;
+}
+
+typedef struct {
+    int n_frames, n_points, n_edges, nfree;
+    const int* off; const cmlhip_lba_edge* edges;
+    int* pidx;                    /* frame -> pose block, -1: fixed or without an active edge */
+    unsigned char* pt_active;     /* point has a level-0 edge */
+    unsigned char* level1;
+    int robust; double delta;
+    double *Hpp, *bp, *Hll, *bl, *Hpl, *err;
+} lba_graph;
+
+static void inv3(const double* A, double* o) {                          /* Matrix3d::inverse(): adjugate / determinant */
+    const double c00 = A[4] * A[8] - A[5] * A[7], c10 = A[5] * A[6] - A[3] * A[8], c20 = A[3] * A[7] - A[4] * A[6];
+    const double det = c00 * A[0] + c10 * A[1] + c20 * A[2];
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[3] = c10 * id; o[6] = c20 * id;
+    o[1] = (A[2] * A[7] - A[1] * A[8]) * id; o[4] = (A[0] * A[8] - A[2] * A[6]) * id; o[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+    o[2] = (A[1] * A[5] - A[2] * A[4]) * id; o[5] = (A[2] * A[3] - A[0] * A[5]) * id; o[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+/* computeActiveErrors + activeRobustChi2 (+ buildSystem when build != 0) at (cams, points) */
+static double lba_evaluate(lba_graph* G, const lba_cam* cams, const double* points, int build) {
+    double chi = 0;
+    if (build) {
+        memset(G->Hpp, 0, sizeof(double) * 36 * (size_t)G->nfree); memset(G->bp, 0, sizeof(double) * 6 * (size_t)G->nfree);
+        memset(G->Hll, 0, sizeof(double) * 9 * (size_t)G->n_points); memset(G->bl, 0, sizeof(double) * 3 * (size_t)G->n_points);
+        memset(G->Hpl, 0, sizeof(double) * 18 * (size_t)G->n_edges);
+    }
+    for (int pt = 0; pt < G->n_points; pt++)
+        for (int k = G->off[pt]; k < G->off[pt + 1]; k++) {
+            if (G->level1[k]) continue;
+            const cmlhip_lba_edge* E = &G->edges[k];
+            const lba_cam* C = &cams[E->frame];
+            double p[3], *e = &G->err[2 * (size_t)k];
+            edge_compute_error(C, &points[3 * pt], E, e, p);
+            const double om = E->inv_sigma2;
+            double rho[3] = {edge_chi2(e, om), 1., 0};
+            if (G->robust) orc_huber(rho[0], G->delta, rho);
+            chi += rho[0];
+            if (!build) continue;
+            double Jl[2][3], Jp[2][6];
+            edge_jacobian_point(C, p, Jl);
+            const double w = rho[1] * om;
+            const double we[2] = {(-om * e[0]) * rho[1], (-om * e[1]) * rho[1]};
+            double* Hll = &G->Hll[9 * (size_t)pt]; double* bl = &G->bl[3 * (size_t)pt];
+            for (int j = 0; j < 3; j++) {
+                bl[j] += Jl[0][j] * we[0] + Jl[1][j] * we[1];
+                for (int c = 0; c < 3; c++) Hll[j * 3 + c] += (Jl[0][j] * w) * Jl[0][c] + (Jl[1][j] * w) * Jl[1][c];
+            }
+            const int pi = G->pidx[E->frame];
+            if (pi < 0) continue;
+            edge_jacobian_pose(C, p, Jp);
+            double* Hpp = &G->Hpp[36 * (size_t)pi]; double* bp = &G->bp[6 * (size_t)pi]; double* Hpl = &G->Hpl[18 * (size_t)k];
+            for (int j = 0; j < 6; j++) {
+                bp[j] += Jp[0][j] * we[0] + Jp[1][j] * we[1];
+                for (int c = 0; c < 6; c++) Hpp[j * 6 + c] += (Jp[0][j] * w) * Jp[0][c] + (Jp[1][j] * w) * Jp[1][c];
+                for (int c = 0; c < 3; c++) Hpl[j * 3 + c] += (Jp[0][j] * w) * Jl[0][c] + (Jp[1][j] * w) * Jl[1][c];
+            }
+        }
+    return chi;
+}
+
+static int chol_solve_dense(double* A, int n, const double* b, double* x) {     /* LLT, fails on a pivot <= 0 */
+    for (int j = 0; j < n; j++) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0)) return 0;
+        d = sqrt(d); A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
+    return 1;
+}
+
+/* BlockSolver::solve with Schur (block_solver.hpp:343-478) at damping lambda: xp (6 nfree), xl (3 n_points) */
+static int lba_schur_solve(const lba_graph* G, double lambda, double* xp, double* xl) {
+    const int n = 6 * G->nfree;
+    double* S = (double*)calloc((size_t)n * n, sizeof(double));
+    double* bs = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double* Dinv = (double*)malloc(sizeof(double) * 9 * (size_t)G->n_points);
+    for (int f = 0; f < G->nfree; f++) {
+        for (int r = 0; r < 6; r++) {
+            for (int c = 0; c < 6; c++) S[(size_t)(6 * f + r) * n + 6 * f + c] = G->Hpp[36 * (size_t)f + r * 6 + c];
+            S[(size_t)(6 * f + r) * n + 6 * f + r] += lambda;
+            bs[6 * f + r] = G->bp[6 * (size_t)f + r];
+        }
+    }
+    for (int pt = 0; pt < G->n_points; pt++) {
+        if (!G->pt_active[pt]) continue;
+        double D[9], db[3];
+        memcpy(D, &G->Hll[9 * (size_t)pt], sizeof D);
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        double* Di = &Dinv[9 * (size_t)pt];
+        inv3(D, Di);
+        const double* bl = &G->bl[3 * (size_t)pt];
+        for (int r = 0; r < 3; r++) db[r] = Di[r * 3] * bl[0] + Di[r * 3 + 1] * bl[1] + Di[r * 3 + 2] * bl[2];
+        for (int k1 = G->off[pt]; k1 < G->off[pt + 1]; k1++) {
+            const int i1 = G->pidx[G->edges[k1].frame];
+            if (i1 < 0 || G->level1[k1]) continue;
+            const double* Bi = &G->Hpl[18 * (size_t)k1];
+            double BD[18];
+            for (int r = 0; r < 6; r++) {
+                for (int c = 0; c < 3; c++) BD[r * 3 + c] = Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c];
+                bs[6 * i1 + r] -= Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+            }
+            for (int k2 = G->off[pt]; k2 < G->off[pt + 1]; k2++) {
+                const int i2 = G->pidx[G->edges[k2].frame];
+                if (i2 < 0 || G->level1[k2]) continue;
+                const double* Bj = &G->Hpl[18 * (size_t)k2];
+                for (int r = 0; r < 6; r++)
+                    for (int c = 0; c < 6; c++)
+                        S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] -= BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
+            }
+        }
+    }
+    const int ok = n == 0 ? 1 : chol_solve_dense(S, n, bs, xp);
+    if (ok)
+        for (int pt = 0; pt < G->n_points; pt++) {
+            double* x = &xl[3 * (size_t)pt];
+            x[0] = x[1] = x[2] = 0;
+            if (!G->pt_active[pt]) continue;
+            double cl[3] = {G->bl[3 * (size_t)pt], G->bl[3 * (size_t)pt + 1], G->bl[3 * (size_t)pt + 2]};
+            for (int k = G->off[pt]; k < G->off[pt + 1]; k++) {
+                const int i1 = G->pidx[G->edges[k].frame];
+                if (i1 < 0 || G->level1[k]) continue;
+                const double* B = &G->Hpl[18 * (size_t)k];
+                for (int c = 0; c < 3; c++)
+                    for (int r = 0; r < 6; r++) cl[c] += B[r * 3 + c] * (-xp[6 * i1 + r]);
+            }
+            const double* Di = &Dinv[9 * (size_t)pt];
+            for (int r = 0; r < 3; r++) x[r] = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+        }
+    free(S); free(bs); free(Dinv);
+    return ok;
+}
+
+/* SparseOptimizer::optimize(iterations) with Levenberg over the graph; returns the number of solve() calls */
+static int lba_lm_optimize(lba_graph* G, lba_cam* cams, double* points, int iterations, double* last_chi) {
+    const int np3 = 3 * G->n_points, n6 = 6 * G->nfree;
+    double* xp = (double*)calloc((size_t)(n6 > 0 ? n6 : 1), sizeof(double));
+    double* xl = (double*)calloc((size_t)(np3 > 0 ? np3 : 1), sizeof(double));
+    lba_cam* cam_bak = (lba_cam*)malloc(sizeof(lba_cam) * (size_t)G->n_frames);
+    double* pts_bak = (double*)malloc(sizeof(double) * (size_t)(np3 > 0 ? np3 : 1));
+    double lambda = 0, ni = 2;
+    int done = 0, ok = 1;
+    for (int it = 0; it < iterations && ok; it++) {
+        double currentChi = lba_evaluate(G, cams, points, 1);
+        if (it == 0) {                                                  /* computeLambdaInit over every active vertex */
+            double mx = 0;
+            for (int f = 0; f < G->nfree; f++) for (int j = 0; j < 6; j++) mx = fmax(fabs(G->Hpp[36 * (size_t)f + j * 7]), mx);
+            for (int pt = 0; pt < G->n_points; pt++) if (G->pt_active[pt]) for (int j = 0; j < 3; j++) mx = fmax(fabs(G->Hll[9 * (size_t)pt + j * 4]), mx);
+            lambda = 1e-5 * mx; ni = 2;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            memcpy(cam_bak, cams, sizeof(lba_cam) * (size_t)G->n_frames); memcpy(pts_bak, points, sizeof(double) * (size_t)np3);   /* push */
+            const int ok2 = lba_schur_solve(G, lambda, xp, xl);
+            for (int f = 0; f < G->n_frames; f++) {                     /* update: oplus on every active vertex */
+                const int pi = G->pidx[f];
+                if (pi < 0) continue;
+                se3q E, Tn;
+                se3q_exp(&xp[6 * pi], &E); se3q_mul(&E, &cams[f].T, &Tn);
+                cams[f].T = Tn; q_to_matrix(&Tn, cams[f].R);
+            }
+            for (int pt = 0; pt < G->n_points; pt++) if (G->pt_active[pt]) for (int c = 0; c < 3; c++) points[3 * pt + c] += xl[3 * pt + c];
+            double tempChi = lba_evaluate(G, cams, points, 0);
+            if (!ok2) tempChi = 1.7976931348623157e308;
+            rho = currentChi - tempChi;
+            double scale = 0;                                           /* computeScale: poses, then points */
+            for (int j = 0; j < n6; j++) scale += xp[j] * (lambda * xp[j] + G->bp[j]);
+            for (int pt = 0; pt < G->n_points; pt++) if (G->pt_active[pt]) for (int c = 0; c < 3; c++) scale += xl[3 * pt + c] * (lambda * xl[3 * pt + c] + G->bl[3 * pt + c]);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow(2 * rho - 1, 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                memcpy(cams, cam_bak, sizeof(lba_cam) * (size_t)G->n_frames); memcpy(points, pts_bak, sizeof(double) * (size_t)np3);   /* pop */
+                if (!isfinite(lambda)) break;
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        done++;
+        *last_chi = currentChi;
+        if (qmax == 10 || rho == 0 || !isfinite(lambda)) ok = 0;
+    }
+    free(xp); free(xl); free(cam_bak); free(pts_bak);
+    return done;
+}
+
+static void lba_activate(lba_graph* G, const cmlhip_lba_frame* frames) {  /* initializeOptimization(0): vertices with a level-0 edge */
+    unsigned char* fa = (unsigned char*)calloc((size_t)G->n_frames, 1);
+    for (int pt = 0; pt < G->n_points; pt++) {
+        G->pt_active[pt] = 0;
+        for (int k = G->off[pt]; k < G->off[pt + 1]; k++) if (!G->level1[k]) { G->pt_active[pt] = 1; fa[G->edges[k].frame] = 1; }
+    }
+    G->nfree = 0;
+    for (int f = 0; f < G->n_frames; f++) G->pidx[f] = (!frames[f].fixed && fa[f]) ? G->nfree++ : -1;
+    free(fa);
+}
+
 /* IndirectBundleAdjustment::localOptimize with the graph given as arrays: edges are point-major (the order :120-165 creates
  * them in), point p owns edges [off[p], off[p+1]).  fix_frames != 0: StructureOnlySolver (poses untouched).
  * edge_bad[e] = the removal test of apply() (:327). */
@@ -154,7 +377,6 @@ int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, doubl
                      const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations,
                      unsigned char* edge_bad, cmlhip_lba_result* out) {
     memset(out, 0, sizeof *out);
-    if (!fix_frames) return CMLHIP_ERR_INVALID;
     const int n_edges = off[n_points];
     const double delta = (double)(float)sqrt(5.991);                    /* const float thHuberIndirect, :111 */
     lba_cam* cams = (lba_cam*)malloc(sizeof(lba_cam) * (size_t)(n_frames > 0 ? n_frames : 1));
@@ -177,6 +399,21 @@ int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, doubl
                     level1[k] = (edge_chi2(&err[2 * k], edges[k].inv_sigma2) > 5.991 || !depth_pos) ? 1 : 0;
                 }
         }
+        if (!fix_frames) {                                              /* OptimizationAlgorithmLevenberg over BlockSolver_6_3 */
+            lba_graph G;
+            memset(&G, 0, sizeof G);
+            G.n_frames = n_frames; G.n_points = n_points; G.n_edges = n_edges; G.off = off; G.edges = edges;
+            G.level1 = level1; G.robust = phase == 0; G.delta = delta; G.err = err;
+            G.pidx = (int*)malloc(sizeof(int) * (size_t)n_frames);
+            G.pt_active = (unsigned char*)malloc((size_t)(n_points > 0 ? n_points : 1));
+            lba_activate(&G, frames);
+            G.Hpp = (double*)malloc(sizeof(double) * 36 * (size_t)(G.nfree > 0 ? G.nfree : 1)); G.bp = (double*)malloc(sizeof(double) * 6 * (size_t)(G.nfree > 0 ? G.nfree : 1));
+            G.Hll = (double*)malloc(sizeof(double) * 9 * (size_t)(n_points > 0 ? n_points : 1)); G.bl = (double*)malloc(sizeof(double) * 3 * (size_t)(n_points > 0 ? n_points : 1));
+            G.Hpl = (double*)malloc(sizeof(double) * 18 * (size_t)(n_edges > 0 ? n_edges : 1));
+            out->iterations_done[phase] = lba_lm_optimize(&G, cams, points, iters, &out->chi2[phase]);
+            free(G.pidx); free(G.pt_active); free(G.Hpp); free(G.bp); free(G.Hll); free(G.bl); free(G.Hpl);
+            continue;
+        }
         for (int it = 0; it < iters; it++) {                            /* optimize(num): one calc(points, 1) per iteration */
             for (int p = 0; p < n_points; p++) {
                 const int n = off[p + 1] - off[p];
@@ -198,6 +435,12 @@ int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, doubl
             nbad += edge_bad[k];
         }
     out->n_bad = nbad; out->ok = 1;
+    if (!fix_frames)                                                    /* apply(): pKF->setCamera of the local keyframes, :301-305 */
+        for (int f = 0; f < n_frames; f++) {
+            if (frames[f].fixed) continue;
+            memcpy(frames[f].R, cams[f].R, sizeof frames[f].R);
+            memcpy(frames[f].t, cams[f].T.t, sizeof frames[f].t);
+        }
     free(cams); free(err); free(level1);
     return 0;
 }

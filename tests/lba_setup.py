@@ -8,7 +8,7 @@ from tests import oracle_lib as O
 
 
 def scene(n_local=6, n_fixed=4, n_points=800, seed=2, noise_px=0.5, point_noise=0.05, outlier_fraction=0.03,
-          K=(718.856, 718.856, 607.19, 185.22), wh=(1241, 376)):
+          K=(718.856, 718.856, 607.19, 185.22), wh=(1241, 376), pose_noise=0.0):
     """A forward-moving rig: n_local + n_fixed keyframes, points in front of the middle of the trajectory; a point is observed
     by the frames it projects into (at least 2).  Point estimates start `point_noise` (relative depth) off the truth; a few
     observations are gross outliers.  Frames [0, n_local) are the local keyframes, the rest are fixed."""
@@ -50,7 +50,13 @@ def scene(n_local=6, n_fixed=4, n_points=800, seed=2, noise_px=0.5, point_noise=
     truth = np.array(pts)
     cen = np.array([0, 0, mid])
     start = cen + (truth - cen) * (1 + rng.normal(0, point_noise, (len(pts), 1)))      # depth error along the viewing ray
-    return dict(frames=frames, truth=truth, points=np.ascontiguousarray(start), off=np.array(offs, np.int32), edges=E,
+    frames_true = frames.copy()
+    if pose_noise > 0:                                  # the local keyframes start away from where the observations were made
+        for f in range(n_local):
+            dR = synth.so3_exp(rng.normal(0, pose_noise * 0.2, 3))
+            R = dR @ Rs[f]
+            frames["R"][f] = R.ravel(); frames["t"][f] = ts[f] + rng.normal(0, pose_noise, 3)
+    return dict(frames=frames, frames_true=frames_true, truth=truth, points=np.ascontiguousarray(start), off=np.array(offs, np.int32), edges=E,
                 planted=np.array(planted), K=np.array(K))
 
 

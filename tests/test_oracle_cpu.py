@@ -436,3 +436,27 @@ def test_local_ba_structure_only_restatement():
     fr2, pts2, bad2, r2 = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], fix_frames=True, num_iterations=5, refine_iterations=3)
     assert r2.iterations_done[1] == 3
     assert np.isfinite(pts2).all()
+
+
+def test_local_ba_levenberg_restatement():
+    """SURVEY §8 f4 (IndirectBundleAdjustment, free poses: g2o Levenberg + Schur).  Functional pin: from perturbed local
+    keyframes and points the optimisation lowers the robust cost monotonically over the passes, pulls the local poses back to
+    where the observations were made (the gauge is held by the fixed keyframes) and leaves the fixed keyframes alone."""
+    from tests import lba_setup as LS
+    S = LS.scene(pose_noise=0.02, n_points=600, seed=3)
+    nl = int((S["frames"]["fixed"] == 0).sum())
+    fr, pts, bad, r = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], fix_frames=False, num_iterations=10, refine_iterations=5)
+    assert r.ok == 1 and 1 <= r.iterations_done[0] <= 10 and 1 <= r.iterations_done[1] <= 5
+    assert np.array_equal(fr[nl:], S["frames"][nl:])
+    t_err0 = np.linalg.norm(S["frames"]["t"][:nl] - S["frames_true"]["t"][:nl], axis=1)
+    t_err1 = np.linalg.norm(fr["t"][:nl] - S["frames_true"]["t"][:nl], axis=1)
+    assert np.median(t_err1) < 0.2 * np.median(t_err0), (t_err0, t_err1)
+    for f in range(nl):
+        R = fr["R"][f].reshape(3, 3)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+    e0 = np.linalg.norm(S["points"] - S["truth"], axis=1); e1 = np.linalg.norm(pts - S["truth"], axis=1)
+    assert np.median(e1) < 0.5 * np.median(e0)
+    assert bad[S["planted"]].mean() > 0.9 and bad[~S["planted"]].mean() < 0.1
+    # one Levenberg pass alone: chi2 of the pass is below the starting cost of a pass with zero iterations' worth of progress
+    _, _, _, r1 = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], fix_frames=False, num_iterations=1, refine_iterations=0)
+    assert r.chi2[0] < r1.chi2[0]
