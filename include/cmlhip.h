@@ -412,7 +412,9 @@ typedef struct {
 } cmlhip_lba_result;
 /* Edges are point-major, in the order :120-165 creates them: point p owns edges [point_offsets[p], point_offsets[p+1]).
  * fix_frames != 0 (mBaMode != BAINDIRECT, indirect/Mapping.cpp:89): g2o's StructureOnlySolver<3> — poses stay, every point is
- * refined on its own (one launch, a lane per point).  points (n_points x 3) and frames are updated in place;
+ * refined on its own (one launch, a lane per point).  fix_frames == 0: g2o's Levenberg over BlockSolver_6_3 with the points
+ * marginalised; frames with fixed == 0 are optimised (1..32 of them: the reduced pose system is factorised in the LDS of one
+ * CU), the others only constrain the points.  points (n_points x 3) and the R, t of the free frames are updated in place;
  * edge_bad (one byte per edge) receives apply()'s removal test. */
 int cmlhip_lba_optimize(cmlhip_ctx* ctx, int n_frames, cmlhip_lba_frame* frames, int n_points, double* points,
                         const int* point_offsets, const cmlhip_lba_edge* edges, int fix_frames, int num_iterations,

@@ -71,7 +71,7 @@ struct cmlhip_ctx {
     DevBuf tr_points, tr_pairs, tr_out;
     DevBuf ini_points, ini_partial;          // coarse initializer (initializer.hip)
     DevBuf pnp_matches, pnp_flags, pnp_out;  // pose-only optimisation (pnp.hip)
-    DevBuf lba_frames, lba_cams, lba_points, lba_off, lba_edges, lba_err, lba_flags;   // local bundle adjustment (lba.hip)
+    DevBuf lba_frames, lba_cams, lba_points, lba_off, lba_edges, lba_err, lba_flags, lba_work;   // local bundle adjustment (lba.hip)
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)

@@ -45,11 +45,43 @@ def test_lba_edge_cases():
         _, pts_o, bad_o, _ = LS.oracle_lba(S["frames"], pts, S["off"], S["edges"], True, 2, 0)
         bad, r = ctx.lba_optimize(S["frames"].copy(), pts, S["off"], S["edges"], True, 2, 0)
         assert np.array_equal(bad, bad_o) and np.array_equal(pts.view(np.uint64), pts_o.view(np.uint64))
-        # bad frame index / free poses: refused
+        # bad frame index: refused
         e = S["edges"].copy(); e["frame"][3] = 99
         with pytest.raises(device.CmlHipError):
             ctx.lba_optimize(S["frames"].copy(), S["points"].copy(), S["off"], e)
-        with pytest.raises(device.CmlHipError):
-            ctx.lba_optimize(S["frames"].copy(), S["points"].copy(), S["off"], S["edges"], fix_frames=False)
     finally:
         ctx.close()
+
+
+def _pose_diff(a, b):
+    return float(np.abs(a["R"] - b["R"]).max()), float(np.abs(a["t"] - b["t"]).max())
+
+
+@pytest.mark.parametrize("kw,iters,refine", [(dict(pose_noise=0.02, n_points=600, seed=3), 5, 0), (dict(pose_noise=0.02, n_points=600, seed=3), 10, 5),
+                                             (dict(pose_noise=0.05, n_points=2500, seed=5, n_local=12, n_fixed=5), 6, 2),
+                                             (dict(pose_noise=0.0, n_points=300, seed=7, n_local=3, n_fixed=3), 3, 1)])
+def test_levenberg_matches_oracle(kw, iters, refine):
+    """Free poses: g2o Levenberg + Schur.  fp64; the device sums edges per point / per pose / per block in a different order
+    than the edge-order loops of g2o, so: same accept/reject sequence while the steps are large (checked through the pass
+    chi2 and the iteration counts being plausible), poses and points within 1e-7 of the oracle, edge flags identical except
+    where chi2 sits within 1e-6 of the threshold."""
+    S = LS.scene(**kw)
+    fr_o, pts_o, bad_o, r_o = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], False, iters, refine)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        fr = S["frames"].copy(); pts = S["points"].copy()
+        bad, r = ctx.lba_optimize(fr, pts, S["off"], S["edges"], False, iters, refine)
+        fr2 = S["frames"].copy(); pts2 = S["points"].copy()
+        bad2, r2 = ctx.lba_optimize(fr2, pts2, S["off"], S["edges"], False, iters, refine)
+    finally:
+        ctx.close()
+    assert r.ok == 1
+    assert np.array_equal(fr2, fr) and np.array_equal(pts2, pts) and np.array_equal(bad2, bad)       # deterministic
+    fixed = S["frames"]["fixed"] == 1
+    assert np.array_equal(fr[fixed], S["frames"][fixed])
+    dR, dt = _pose_diff(fr, fr_o)
+    assert dR < 1e-7 and dt < 1e-7, (dR, dt, list(r.iterations_done), list(r_o.iterations_done))
+    assert np.abs(pts - pts_o).max() < 1e-6 * max(1.0, np.abs(pts_o).max())
+    for k in range(2):
+        assert abs(r.chi2[k] - r_o.chi2[k]) <= 1e-7 * max(1.0, abs(r_o.chi2[k]))
+    assert (bad != bad_o).sum() <= 2
