@@ -6,6 +6,7 @@ import numpy as np
 from libcml_amd import abi, device
 from tests import initializer_setup as IS
 from tests import pnp_setup as PS
+from tests import lba_setup as LS
 
 
 def timed(f, n=20, warm=3):
@@ -34,4 +35,14 @@ for n in (150, 600, 2560):
         r = ctx.pnp_optimize(S["R0"], S["t0"], S["K"], m, np.zeros(n, np.uint8), algorithm=alg)
         print("pose-only optimisation %-12s %4d matches: device %.1f us per synchronous call (one launch, solve() calls per round %s)   oracle (1 core) %.1f us" %
               (name, n, d, list(r.lm_iterations), o))
+for kw, name in ((dict(n_points=800, seed=2), "10 keyframes /  800 points"), (dict(n_points=4000, seed=4, n_local=21, n_fixed=9), "30 keyframes / 4000 points")):
+    S = LS.scene(pose_noise=0.02, **kw)
+    ne = len(S["edges"])
+    d = timed(lambda: ctx.lba_optimize(S["frames"].copy(), S["points"].copy(), S["off"], S["edges"], True, 5, 0), n=10)
+    o = timed(lambda: LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], True, 5, 0), n=3, warm=1)
+    print("local BA structure-only (fixFrames) %s / %d edges, 5 iterations: device %.1f us per synchronous call   oracle (1 core) %.1f us" % (name, ne, d, o))
+    d = timed(lambda: ctx.lba_optimize(S["frames"].copy(), S["points"].copy(), S["off"], S["edges"], False, 5, 0), n=5, warm=1)
+    o = timed(lambda: LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], False, 5, 0), n=2, warm=1)
+    _, r = ctx.lba_optimize(S["frames"].copy(), S["points"].copy(), S["off"], S["edges"], False, 5, 0)
+    print("local BA Levenberg + Schur %s / %d edges, 5 iterations (%d done): device %.1f us per synchronous call   oracle (1 core, dense) %.1f us" % (name, ne, r.iterations_done[0], d, o))
 ctx.close()
