@@ -223,8 +223,9 @@ __global__ void k_lba_edge_test(const LbaCam* __restrict__ cams, const cmlhip_lb
 // fixFrames == false: g2o's OptimizationAlgorithmLevenberg over BlockSolver_6_3 with the points marginalised
 // (g2o/core/optimization_algorithm_levenberg.cpp:58-175, g2o/core/block_solver.hpp:329-479,495-587).  One Levenberg trial is
 //   k_lba_dinv   lane per point      D = Hll + lambda I, D^-1, D^-1 bl
-//   k_lba_schur  wave per 6x6 block  S(i1,i2) = [Hpp + lambda I] - sum_p Hpl D^-1 Hpl^T over a host-built list of edge pairs,
-//                                    bs(i1) = bp - sum Hpl D^-1 bl            (fixed order: deterministic, no atomics)
+//   k_lba_schur  wave per 6x6 block  S(i1,i2) = [Hpp + lambda I] - sum_p Hpl D^-1 Hpl^T over the edges of pose i1, each paired
+//                                    through a point x pose -> edge table; bs(i1) = bp - sum Hpl D^-1 bl
+//                                    (fixed order: deterministic, no atomics)
 //   k_lba_chol   one workgroup       dense LL^T of the reduced pose system in LDS (packed lower), forward/backward substitution
 //   k_lba_update lane per point / per pose   xl = D^-1 (bl - Hpl^T xp), X + xl, exp(xp) T, the terms of computeScale
 //   k_lba_eval_points / k_lba_eval_frames    errors, Huber, chi2 and the next system AT THE TRIAL STATE (if the trial is
@@ -366,17 +367,20 @@ __global__ void k_lba_dinv(const double* __restrict__ Hll, const double* __restr
     for (int r = 0; r < 3; r++) db[3 * (size_t)pt + r] = o[r * 3] * b[0] + o[r * 3 + 1] * b[1] + o[r * 3 + 2] * b[2];
 }
 
-// one wave per upper block (i1 <= i2) of the reduced system: block_solver.hpp:357-432
+// one wave per upper block (i1 <= i2) of the reduced system, block_solver.hpp:357-432: the edges of pose i1 in list order, each
+// paired with the edge of the same point into pose i2 (edge_of: n_points x nfree table, -1 = not observed)
 __global__ __launch_bounds__(64) void k_lba_schur(LbaSys sys, const double* __restrict__ Dinv, const double* __restrict__ db,
-                                                  const int* __restrict__ blk_i1, const int* __restrict__ blk_i2, const int* __restrict__ pr_off,
-                                                  const int* __restrict__ pr_e1, const int* __restrict__ pr_e2, const int* __restrict__ edge_point,
-                                                  double lambda, int n, double* __restrict__ S, double* __restrict__ bs) {
+                                                  const int* __restrict__ blk_i1, const int* __restrict__ blk_i2, const int* __restrict__ fe_off,
+                                                  const int* __restrict__ fe_edge, const int* __restrict__ edge_point, const int* __restrict__ edge_of,
+                                                  int nfree, double lambda, int n, double* __restrict__ S, double* __restrict__ bs) {
     const int b = blockIdx.x, l = threadIdx.x, i1 = blk_i1[b], i2 = blk_i2[b];
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; i++) acc[i] = 0.0;
-    for (int q = pr_off[b] + l; q < pr_off[b + 1]; q += 64) {
-        const int k1 = pr_e1[q], k2 = pr_e2[q], pt = edge_point[k1];
+    for (int q = fe_off[i1] + l; q < fe_off[i1 + 1]; q += 64) {
+        const int k1 = fe_edge[q], pt = edge_point[k1];
+        const int k2 = i1 == i2 ? k1 : edge_of[(size_t)pt * nfree + i2];
+        if (k2 < 0) continue;
         const double* Bi = sys.Hpl + 18 * (size_t)k1; const double* Bj = sys.Hpl + 18 * (size_t)k2;
         const double* Di = Dinv + 9 * (size_t)pt;
         double BD[18];
@@ -414,51 +418,42 @@ __global__ __launch_bounds__(64) void k_lba_schur(LbaSys sys, const double* __re
     }
 }
 
-// dense LL^T of S (n x n, symmetric, row-major in global) in LDS (packed lower) and the solve S xp = bs; flag[0] = 1 on success
+// Factorisation of S (n x n, symmetric positive definite, row-major in global) in LDS (packed lower) and the solve S xp = bs;
+// flag[0] = 1 on success.  Same pivots as the LL^T of SimplicialLLT (it fails on the same non-positive pivot), carried in the
+// square-root-free form S = L D L^T: column j is left unscaled while it updates the trailing matrix (a_ik -= a_ij a_kj / d_j),
+// so a column costs ONE barrier, and both substitutions run on the unit-lower factor with one barrier per column as well.
 #define LBA_CHOL_THREADS 512
 __global__ __launch_bounds__(LBA_CHOL_THREADS) void k_lba_chol(const double* __restrict__ S, const double* __restrict__ bs, int n, double* __restrict__ xp, int* __restrict__ flag) {
-    extern __shared__ double s_L[];                 // n (n + 1) / 2 packed lower, then n of the right-hand side
-    __shared__ int s_fail;
-    const int tid = threadIdx.x;
+    extern __shared__ double s_L[];                 // n (n + 1) / 2 packed lower, then n of the right-hand side, then n inverse pivots
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, NW = LBA_CHOL_THREADS / 64;
     double* rhs = s_L + (size_t)n * (n + 1) / 2;
+    double* idg = rhs + n;
 #define LI(i, j) s_L[(size_t)(i) * ((i) + 1) / 2 + (j)]
     for (int q = tid; q < n * n; q += LBA_CHOL_THREADS) { const int i = q / n, j = q % n; if (j <= i) LI(i, j) = S[q]; }
     for (int i = tid; i < n; i += LBA_CHOL_THREADS) rhs[i] = bs[i];
-    if (tid == 0) s_fail = 0;
     __syncthreads();
+    bool fail = false;
     for (int j = 0; j < n; j++) {
-        const double d = LI(j, j);
-        if (!(d > 0)) { if (tid == 0) s_fail = 1; break; }       // uniform: every thread reads the same LDS word
-        const double sd = sqrt(d);
-        __syncthreads();
-        for (int i = j + tid; i < n; i += LBA_CHOL_THREADS) LI(i, j) = (i == j) ? sd : LI(i, j) / sd;
-        __syncthreads();
-        const int m = n - j - 1;                                  // trailing update: rows j+1.., columns j+1..row
-        for (int q = tid; q < m * (m + 1) / 2; q += LBA_CHOL_THREADS) {
-            int r = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
-            while ((r + 1) * (r + 2) / 2 <= q) r++;
-            while (r * (r + 1) / 2 > q) r--;
-            const int c = q - r * (r + 1) / 2;
-            const int i = j + 1 + r, k = j + 1 + c;
-            LI(i, k) -= LI(i, j) * LI(k, j);
+        const double d = LI(j, j);                                // final: every update of column j happened before the last barrier
+        if (!(d > 0)) { fail = true; break; }                     // uniform: every thread reads the same LDS word
+        const double id = 1.0 / d;
+        for (int i = j + 1 + wv; i < n; i += NW) {                // a wave per row of the trailing matrix, lanes along the row
+            const double aij = LI(i, j) * id;
+            for (int k = j + 1 + l; k <= i; k += 64) LI(i, k) -= aij * LI(k, j);
         }
         __syncthreads();
     }
-    __syncthreads();
-    const bool fail = s_fail != 0;
     if (!fail) {
-        for (int j = 0; j < n; j++) {                             // L y = b
-            if (tid == 0) rhs[j] = rhs[j] / LI(j, j);
-            __syncthreads();
-            const double yj = rhs[j];
+        for (int j = 0; j < n; j++) {                             // L y = b with L = unit lower: L(i,j) = a_ij / d_j
+            const double yj = rhs[j] / LI(j, j);                  // rhs[j] is final here; every thread forms the same value
             for (int i = j + 1 + tid; i < n; i += LBA_CHOL_THREADS) rhs[i] -= LI(i, j) * yj;
             __syncthreads();
         }
-        for (int j = n - 1; j >= 0; j--) {                        // L^T x = y
-            if (tid == 0) rhs[j] = rhs[j] / LI(j, j);
-            __syncthreads();
+        for (int i = tid; i < n; i += LBA_CHOL_THREADS) { const double di = 1.0 / LI(i, i); idg[i] = di; rhs[i] = rhs[i] * di; }   // z = D^-1 y
+        __syncthreads();
+        for (int j = n - 1; j >= 0; j--) {                        // L^T x = z, L(j,i) = a_ji / d_i
             const double xj = rhs[j];
-            for (int i = tid; i < j; i += LBA_CHOL_THREADS) rhs[i] -= LI(j, i) * xj;
+            for (int i = tid; i < j; i += LBA_CHOL_THREADS) rhs[i] -= (LI(j, i) * idg[i]) * xj;
             __syncthreads();
         }
         for (int i = tid; i < n; i += LBA_CHOL_THREADS) xp[i] = rhs[i];
@@ -559,12 +554,12 @@ __global__ __launch_bounds__(64) void k_lba_update_points(LbaSys sys, const doub
 
 // fixed-order sums of the partials: out = {chi2, scale, max |diag|}
 __global__ __launch_bounds__(64) void k_lba_reduce(const double* part_chi, const double* part_max, const double* part_scale, int nb,
-                                                   const double* pose_scale, const double* pose_max, int nfree, double* out) {
+                                                   const double* pose_scale, const double* pose_max, int nfree, const int* flag, double* out) {
     if (threadIdx.x != 0) return;
     double chi = 0.0, sc = 0.0, mx = 0.0;
     for (int i = 0; i < nfree; i++) { sc += pose_scale[i]; mx = fmax(mx, pose_max[i]); }
     for (int i = 0; i < nb; i++) { chi += part_chi[i]; sc += part_scale[i]; mx = fmax(mx, part_max[i]); }
-    out[0] = chi; out[1] = sc; out[2] = mx;
+    out[0] = chi; out[1] = sc; out[2] = mx; out[3] = flag ? (double)flag[0] : 1.0;      // [3]: the factorisation succeeded
 }
 
 // ---- host driver of the Levenberg mode: graph index lists, buffers, g2o's accept / reject loop
@@ -595,45 +590,17 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
     fe_edge.resize(std::max(fe_off[nfree], 1));
     { std::vector<int> at(fe_off.begin(), fe_off.end() - 1);
       for (int k = 0; k < n_edges; k++) { const int pi = pose_of_frame[edges[k].frame]; if (pi >= 0) fe_edge[at[pi]++] = k; } }
-    // edge pairs of every upper block (i1 <= i2) of the reduced system, points in order inside a block
-    std::vector<int> cnt((size_t)nfree * nfree, 0);
-    for (int p = 0; p < n_points; p++)
-        for (int k1 = off[p]; k1 < off[p + 1]; k1++) {
-            const int a = pose_of_frame[edges[k1].frame];
-            if (a < 0) continue;
-            for (int k2 = off[p]; k2 < off[p + 1]; k2++) {
-                const int b = pose_of_frame[edges[k2].frame];
-                if (b < a || (b == a && k2 != k1)) continue;
-                cnt[(size_t)a * nfree + b]++;
-            }
-        }
-    std::vector<int> blk_i1, blk_i2, blk_of((size_t)nfree * nfree, -1), pr_off(1, 0);
-    for (int a = 0; a < nfree; a++)
-        for (int b = a; b < nfree; b++)
-            if (a == b || cnt[(size_t)a * nfree + b] > 0) {
-                blk_of[(size_t)a * nfree + b] = (int)blk_i1.size();
-                blk_i1.push_back(a); blk_i2.push_back(b);
-                pr_off.push_back(pr_off.back() + cnt[(size_t)a * nfree + b]);
-            }
-    const int nblk = (int)blk_i1.size(), npairs = pr_off.back();
-    std::vector<int> pr_e1(std::max(npairs, 1)), pr_e2(std::max(npairs, 1)), at(pr_off.begin(), pr_off.end() - 1);
-    for (int p = 0; p < n_points; p++)
-        for (int k1 = off[p]; k1 < off[p + 1]; k1++) {
-            const int a = pose_of_frame[edges[k1].frame];
-            if (a < 0) continue;
-            for (int k2 = off[p]; k2 < off[p + 1]; k2++) {
-                const int b = pose_of_frame[edges[k2].frame];
-                if (b < a || (b == a && k2 != k1)) continue;
-                const int q = at[blk_of[(size_t)a * nfree + b]]++;
-                pr_e1[q] = k1; pr_e2[q] = k2;
-            }
-        }
+    // every upper block (i1 <= i2) of the reduced system, and the point x pose -> edge table the Schur kernel pairs edges with
+    std::vector<int> blk_i1, blk_i2, edge_of((size_t)std::max(n_points, 1) * nfree, -1);
+    for (int a = 0; a < nfree; a++) for (int b = a; b < nfree; b++) { blk_i1.push_back(a); blk_i2.push_back(b); }
+    for (int k = 0; k < n_edges; k++) { const int pi = pose_of_frame[edges[k].frame]; if (pi >= 0) edge_of[(size_t)edge_point[k] * nfree + pi] = k; }
+    const int nblk = (int)blk_i1.size();
     // ---- device memory
     const int nb = cml_div_up(n_points, 64);
     // (one work buffer: sized by a dry run of the carving with a null base, then carved for real)
     auto carve = [&](Carver& Q, LbaSys sys[2], LbaCam* cams[2], double* pts[2], double*& Dinv, double*& db, double*& S, double*& bs, double*& xp,
                      double*& part_chi, double*& part_max, double*& part_scale, double*& pose_scale, double*& pose_max, double*& out4, int*& flag,
-                     int*& d_pof, int*& d_fop, int*& d_ep, int*& d_feoff, int*& d_feedge, int*& d_b1, int*& d_b2, int*& d_proff, int*& d_pe1, int*& d_pe2) {
+                     int*& d_pof, int*& d_fop, int*& d_ep, int*& d_feoff, int*& d_feedge, int*& d_b1, int*& d_b2, int*& d_eof) {
         for (int i = 0; i < 2; i++) {
             sys[i].Hpp = Q.take<double>(36 * (size_t)nfree); sys[i].bp = Q.take<double>(6 * (size_t)nfree);
             sys[i].Hll = Q.take<double>(9 * (size_t)n_points); sys[i].bl = Q.take<double>(3 * (size_t)n_points);
@@ -646,29 +613,28 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
         pose_scale = Q.take<double>(nfree); pose_max = Q.take<double>(nfree); out4 = Q.take<double>(4); flag = Q.take<int>(4);
         d_pof = Q.take<int>(n_frames); d_fop = Q.take<int>(nfree); d_ep = Q.take<int>(n_edges);
         d_feoff = Q.take<int>(nfree + 1); d_feedge = Q.take<int>(fe_edge.size());
-        d_b1 = Q.take<int>(nblk); d_b2 = Q.take<int>(nblk); d_proff = Q.take<int>(nblk + 1); d_pe1 = Q.take<int>(pr_e1.size()); d_pe2 = Q.take<int>(pr_e2.size());
+        d_b1 = Q.take<int>(nblk); d_b2 = Q.take<int>(nblk); d_eof = Q.take<int>(edge_of.size());
     };
     LbaSys sys[2]; LbaCam* cams[2]; double* pts[2];
     double *Dinv, *db, *S, *bs, *xp, *part_chi, *part_max, *part_scale, *pose_scale, *pose_max, *out4;
-    int *flag, *d_pof, *d_fop, *d_ep, *d_feoff, *d_feedge, *d_b1, *d_b2, *d_proff, *d_pe1, *d_pe2;
+    int *flag, *d_pof, *d_fop, *d_ep, *d_feoff, *d_feedge, *d_b1, *d_b2, *d_eof;
     Carver dry{nullptr};
-    carve(dry, sys, cams, pts, Dinv, db, S, bs, xp, part_chi, part_max, part_scale, pose_scale, pose_max, out4, flag, d_pof, d_fop, d_ep, d_feoff, d_feedge, d_b1, d_b2, d_proff, d_pe1, d_pe2);
+    carve(dry, sys, cams, pts, Dinv, db, S, bs, xp, part_chi, part_max, part_scale, pose_scale, pose_max, out4, flag, d_pof, d_fop, d_ep, d_feoff, d_feedge, d_b1, d_b2, d_eof);
     int rc;
     if ((rc = cml_ensure(c, c->lba_work, dry.at + 512))) return rc;
     Carver real{c->lba_work.as<char>()};
-    carve(real, sys, cams, pts, Dinv, db, S, bs, xp, part_chi, part_max, part_scale, pose_scale, pose_max, out4, flag, d_pof, d_fop, d_ep, d_feoff, d_feedge, d_b1, d_b2, d_proff, d_pe1, d_pe2);
+    carve(real, sys, cams, pts, Dinv, db, S, bs, xp, part_chi, part_max, part_scale, pose_scale, pose_max, out4, flag, d_pof, d_fop, d_ep, d_feoff, d_feedge, d_b1, d_b2, d_eof);
 #define LBA_UP(dst, vec) if ((rc = cml_h2d(c, dst, (vec).data(), sizeof((vec)[0]) * (vec).size()))) return rc
     LBA_UP(d_pof, pose_of_frame); LBA_UP(d_fop, frame_of_pose); LBA_UP(d_ep, edge_point); LBA_UP(d_feoff, fe_off); LBA_UP(d_feedge, fe_edge);
-    LBA_UP(d_b1, blk_i1); LBA_UP(d_b2, blk_i2); LBA_UP(d_proff, pr_off); LBA_UP(d_pe1, pr_e1); LBA_UP(d_pe2, pr_e2);
+    LBA_UP(d_b1, blk_i1); LBA_UP(d_b2, blk_i2); LBA_UP(d_eof, edge_of);
 #undef LBA_UP
     unsigned char* level1 = c->lba_flags.as<unsigned char>();
     unsigned char* bad = level1 + n_edges;
     CML_CHECK(c, hipMemcpyAsync(cams[0], c->lba_cams.p, sizeof(LbaCam) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
     CML_CHECK(c, hipMemcpyAsync(pts[0], c->lba_points.p, sizeof(double) * 3 * (size_t)n_points, hipMemcpyDeviceToDevice, c->stream));
-    CML_CHECK(c, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n * n, c->stream));
     CML_CHECK(c, hipMemsetAsync(xp, 0, sizeof(double) * (size_t)n, c->stream));
-    CML_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_lba_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * ((size_t)192 * 193 / 2 + 192))));
-    const size_t chol_lds = sizeof(double) * ((size_t)n * (n + 1) / 2 + n);
+    CML_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_lba_chol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * ((size_t)192 * 193 / 2 + 2 * 192))));
+    const size_t chol_lds = sizeof(double) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n);
     const double delta = (double)sqrtf(5.991f);
     int cur = 0;                                                            // state (cams, points) and its system live in slot `cur`
     auto evaluate = [&](int slot, bool robust) {
@@ -680,7 +646,6 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
         k_lba_eval_frames<<<nfree, 256, 0, c->stream>>>(A, d_feoff, d_feedge, d_ep, d_fop, pose_max);
     };
     double h4[4];
-    int hflag[4];
     for (int phase = 0; phase < 2; phase++) {
         const int iters = phase == 0 ? num_iterations : refine_iterations;
         const bool robust = phase == 0;
@@ -692,7 +657,7 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
         CML_CHECK(c, hipMemsetAsync(part_scale, 0, sizeof(double) * (size_t)nb, c->stream));
         CML_CHECK(c, hipMemsetAsync(pose_scale, 0, sizeof(double) * (size_t)nfree, c->stream));
         evaluate(cur, robust);
-        k_lba_reduce<<<1, 64, 0, c->stream>>>(part_chi, part_max, part_scale, nb, pose_scale, pose_max, nfree, out4);
+        k_lba_reduce<<<1, 64, 0, c->stream>>>(part_chi, part_max, part_scale, nb, pose_scale, pose_max, nfree, nullptr, out4);
         if ((rc = cml_d2h(c, h4, out4, sizeof(double) * 4))) return rc;
         double currentChi = h4[0], maxdiag = h4[2], lambda = 0.0, ni = 2.0;
         int done = 0;
@@ -704,19 +669,18 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
             do {
                 const int tr = cur ^ 1;
                 k_lba_dinv<<<cml_div_up(n_points, 64), 64, 0, c->stream>>>(sys[cur].Hll, sys[cur].bl, n_points, lambda, Dinv, db);
-                k_lba_schur<<<nblk, 64, 0, c->stream>>>(sys[cur], Dinv, db, d_b1, d_b2, d_proff, d_pe1, d_pe2, d_ep, lambda, n, S, bs);
+                k_lba_schur<<<nblk, 64, 0, c->stream>>>(sys[cur], Dinv, db, d_b1, d_b2, d_feoff, d_feedge, d_ep, d_eof, nfree, lambda, n, S, bs);
                 k_lba_chol<<<1, LBA_CHOL_THREADS, chol_lds, c->stream>>>(S, bs, n, xp, flag);
                 // (after a failed factorisation g2o applies the stale x of the previous solve and pops it again; here xp is
                 //  stale too, the point part is recomputed from it: the state is restored either way)
                 k_lba_update_poses<<<cml_div_up(n_frames, 64), 64, 0, c->stream>>>(cams[cur], cams[tr], n_frames, d_pof, xp, sys[cur].bp, lambda, pose_scale);
                 k_lba_update_points<<<nb, 64, 0, c->stream>>>(sys[cur], Dinv, c->lba_off.as<int>(), c->lba_edges.as<cmlhip_lba_edge>(), d_pof, xp, pts[cur], pts[tr], n_points, lambda, part_scale);
                 evaluate(tr, robust);
-                k_lba_reduce<<<1, 64, 0, c->stream>>>(part_chi, part_max, part_scale, nb, pose_scale, pose_max, nfree, out4);
+                k_lba_reduce<<<1, 64, 0, c->stream>>>(part_chi, part_max, part_scale, nb, pose_scale, pose_max, nfree, flag, out4);
                 CML_CHECK(c, hipGetLastError());
                 if ((rc = cml_d2h(c, h4, out4, sizeof(double) * 4))) return rc;
-                if ((rc = cml_d2h(c, hflag, flag, sizeof(int) * 4))) return rc;
                 double tempChi = h4[0];
-                if (!hflag[0]) tempChi = DBL_MAX;
+                if (h4[3] == 0.0) tempChi = DBL_MAX;
                 rho = currentChi - tempChi;
                 const double scale = h4[1] + 1e-3;
                 rho /= scale;
