@@ -40,6 +40,14 @@ int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, doubl
                      const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations,
                      unsigned char* edge_bad, cmlhip_lba_result* out);
 int orc_ldlt3(const double A[9], const double b[3], double x[3]);   /* Eigen::LDLT<Matrix3d>: returns isPositive() */
+/* the SE3Quat / Eigen arithmetic shared by orc_pnp.c and orc_lba.c (orc_g2o.h), exported for pinning; quaternions x, y, z, w */
+void orc_g2o_from_Rt(const double R[9], const double t[3], double q[4], double tt[3]);
+void orc_g2o_exp(const double u[6], double q[4], double tt[3]);
+void orc_g2o_mul(const double qa[4], const double ta[3], const double qb[4], const double tb[3], double q[4], double tt[3]);
+void orc_g2o_map(const double q[4], const double t[3], const double X[3], double out[3]);
+void orc_g2o_to_matrix(const double q[4], double R[9]);
+void orc_g2o_inv3(const double A[9], double Ai[9]);
+int  orc_g2o_llt_solve(const double* A, int n, const double* b, double* x);
 
 #endif
 
@@ -201,6 +209,14 @@ int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, doubl
                      const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations,
                      unsigned char* edge_bad, cmlhip_lba_result* out);
 int orc_ldlt3(const double A[9], const double b[3], double x[3]);   /* Eigen::LDLT<Matrix3d>: returns isPositive() */
+/* the SE3Quat / Eigen arithmetic shared by orc_pnp.c and orc_lba.c (orc_g2o.h), exported for pinning; quaternions x, y, z, w */
+void orc_g2o_from_Rt(const double R[9], const double t[3], double q[4], double tt[3]);
+void orc_g2o_exp(const double u[6], double q[4], double tt[3]);
+void orc_g2o_mul(const double qa[4], const double ta[3], const double qb[4], const double tb[3], double q[4], double tt[3]);
+void orc_g2o_map(const double q[4], const double t[3], const double X[3], double out[3]);
+void orc_g2o_to_matrix(const double q[4], double R[9]);
+void orc_g2o_inv3(const double A[9], double Ai[9]);
+int  orc_g2o_llt_solve(const double* A, int n, const double* b, double* x);
 
 #endif
 
@@ -229,5 +245,13 @@ int orc_lba_optimize(int n_frames, cmlhip_lba_frame* frames, int n_points, doubl
                      const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations,
                      unsigned char* edge_bad, cmlhip_lba_result* out);
 int orc_ldlt3(const double A[9], const double b[3], double x[3]);   /* Eigen::LDLT<Matrix3d>: returns isPositive() */
+/* the SE3Quat / Eigen arithmetic shared by orc_pnp.c and orc_lba.c (orc_g2o.h), exported for pinning; quaternions x, y, z, w */
+void orc_g2o_from_Rt(const double R[9], const double t[3], double q[4], double tt[3]);
+void orc_g2o_exp(const double u[6], double q[4], double tt[3]);
+void orc_g2o_mul(const double qa[4], const double ta[3], const double qb[4], const double tb[3], double q[4], double tt[3]);
+void orc_g2o_map(const double q[4], const double t[3], const double X[3], double out[3]);
+void orc_g2o_to_matrix(const double q[4], double R[9]);
+void orc_g2o_inv3(const double A[9], double Ai[9]);
+int  orc_g2o_llt_solve(const double* A, int n, const double* b, double* x);
 
 #endif

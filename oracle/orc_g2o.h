@@ -90,4 +90,30 @@ static inline void orc_huber(double e, double delta, double rho[3]) {     /* g2o
     if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
     else { const double sq = sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
 }
+static inline void inv3(const double* A, double* o) {                          /* Matrix3d::inverse(): adjugate / determinant */
+    const double c00 = A[4] * A[8] - A[5] * A[7], c10 = A[5] * A[6] - A[3] * A[8], c20 = A[3] * A[7] - A[4] * A[6];
+    const double det = c00 * A[0] + c10 * A[1] + c20 * A[2];
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[3] = c10 * id; o[6] = c20 * id;
+    o[1] = (A[2] * A[7] - A[1] * A[8]) * id; o[4] = (A[0] * A[8] - A[2] * A[6]) * id; o[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+    o[2] = (A[1] * A[5] - A[2] * A[4]) * id; o[5] = (A[2] * A[3] - A[0] * A[5]) * id; o[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+static inline int chol_solve_dense(double* A, int n, const double* b, double* x) {     /* LLT, fails on a pivot <= 0 */
+    for (int j = 0; j < n; j++) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0)) return 0;
+        d = sqrt(d); A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
+    return 1;
+}
+
 #endif

@@ -7,9 +7,10 @@
  *                      Gauss-Newton iteration per optimize() iteration with up to 10 trials, Eigen::LDLT 3x3;
  *   EdgeSE3ProjectXYZ  g2o/types/sba/edge_project_xyz.cpp:44-95;  RobustKernelHuber  g2o/core/robust_kernel_impl.cpp:60-74;
  *   constructQuadraticForm  g2o/core/base_fixed_sized_edge.hpp:49-133;  Eigen LDLT  Eigen/src/Cholesky/LDLT.h:300-396,560-600.
- * TEST INFRASTRUCTURE ONLY (see cml_oracle.h).  Parity unpinned: the reference has no test or fixture for this path; checked
- * functionally (tests/test_oracle_cpu.py) and, for the 3x3 LDLT, against the restatement that IS pinned on the vendored Eigen
- * (orc_ldlt_solve).  Literal behaviour kept: an edge's chi2() is whatever its last computeError() left — after a rejected
+ * TEST INFRASTRUCTURE ONLY (see cml_oracle.h).  Pinning: the Eigen pieces (LDLT<Matrix3d> incl. isPositive(), Matrix3d::inverse,
+ * LL^T, the SE3Quat arithmetic of orc_g2o.h) are pinned on the reference's vendored Eigen 3.4.0 (oracle/_ref, tests/golden/
+ * thirdparty_vectors.npz).  The g2o control flow (structure-only calc, Levenberg, Schur solve) is PARITY UNPINNED: the reference
+ * has no test or fixture for this path; checked functionally (tests/test_oracle_cpu.py).  Literal behaviour kept: an edge's chi2() is whatever its last computeError() left — after a rejected
  * trial that is the error at the rejected point position — and that is what the level test of the refinement pass (:214) and
  * apply()'s removal test (:327) read. */
 #include <math.h>
@@ -172,15 +173,6 @@ typedef struct {
     double *Hpp, *bp, *Hll, *bl, *Hpl, *err;
 } lba_graph;
 
-static void inv3(const double* A, double* o) {                          /* Matrix3d::inverse(): adjugate / determinant */
-    const double c00 = A[4] * A[8] - A[5] * A[7], c10 = A[5] * A[6] - A[3] * A[8], c20 = A[3] * A[7] - A[4] * A[6];
-    const double det = c00 * A[0] + c10 * A[1] + c20 * A[2];
-    const double id = 1.0 / det;
-    o[0] = c00 * id; o[3] = c10 * id; o[6] = c20 * id;
-    o[1] = (A[2] * A[7] - A[1] * A[8]) * id; o[4] = (A[0] * A[8] - A[2] * A[6]) * id; o[7] = (A[1] * A[6] - A[0] * A[7]) * id;
-    o[2] = (A[1] * A[5] - A[2] * A[4]) * id; o[5] = (A[2] * A[3] - A[0] * A[5]) * id; o[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-}
-
 /* computeActiveErrors + activeRobustChi2 (+ buildSystem when build != 0) at (cams, points) */
 static double lba_evaluate(lba_graph* G, const lba_cam* cams, const double* points, int build) {
     double chi = 0;
@@ -221,23 +213,6 @@ static double lba_evaluate(lba_graph* G, const lba_cam* cams, const double* poin
             }
         }
     return chi;
-}
-
-static int chol_solve_dense(double* A, int n, const double* b, double* x) {     /* LLT, fails on a pivot <= 0 */
-    for (int j = 0; j < n; j++) {
-        double d = A[(size_t)j * n + j];
-        for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-        if (!(d > 0)) return 0;
-        d = sqrt(d); A[(size_t)j * n + j] = d;
-        for (int i = j + 1; i < n; i++) {
-            double s = A[(size_t)i * n + j];
-            for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-            A[(size_t)i * n + j] = s / d;
-        }
-    }
-    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
-    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * x[k]; x[i] = s / A[(size_t)i * n + i]; }
-    return 1;
 }
 
 /* BlockSolver::solve with Schur (block_solver.hpp:343-478) at damping lambda: xp (6 nfree), xl (3 n_points) */

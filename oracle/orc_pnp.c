@@ -11,9 +11,11 @@
  *   SparseOptimizer::optimize                             g2o/core/sparse_optimizer.cpp:392-455
  *   LinearSolverEigen (SimplicialLLT, upper) on the one 6x6 pose block   g2o/solvers/eigen/linear_solver_eigen.h:57-130
  * and Eigen 3.4.0's Quaternion <-> matrix conversions (Eigen/src/Geometry/Quaternion.h).
- * TEST INFRASTRUCTURE ONLY (see cml_oracle.h).  Parity unpinned: the reference has no test or fixture for this path; the
- * restatement follows the statements in order (sums over the edges in edge order) and is checked functionally
- * (tests/test_oracle_cpu.py: recovers the true pose, flags the planted outliers). */
+ * TEST INFRASTRUCTURE ONLY (see cml_oracle.h).  Pinning: the SE3Quat / Eigen arithmetic (orc_g2o.h: exp, product, map,
+ * quaternion <-> matrix, LL^T) is pinned on the reference's vendored Eigen 3.4.0 (oracle/_ref, tests/golden/
+ * thirdparty_vectors.npz, 1e-14).  The g2o control flow (edge, Huber, Levenberg, the 4 rounds) is PARITY UNPINNED: the
+ * reference has no test or fixture for this path; it follows the statements in order (sums over the edges in edge order)
+ * and is checked functionally (tests/test_oracle_cpu.py: recovers the true pose, flags the planted outliers). */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

@@ -97,4 +97,80 @@ void ref_orthogonalize(double* b, int n, const double* Ncols, int m, double delt
     for (int i = 0; i < n; i++) b[i] = bv[i];
 }
 
+/* ---- the Eigen arithmetic behind g2o's SE3Quat (thirdparty/g2o/g2o/types/slam3d/se3quat.h cannot be compiled here: it pulls in
+ * the cmake-generated g2o/config.h).  The functions below make the SAME Eigen calls its statements make, so that the oracle's
+ * plain-C versions (orc_g2o.h) are pinned on Eigen's Quaternion(Matrix3), quaternion product, operator*(Vector3),
+ * normalize(), toRotationMatrix(), Matrix3d::inverse(), LDLT<Matrix3d> and LLT.  Quaternions are passed as x, y, z, w. */
+static void put(const Eigen::Quaterniond& r, const Eigen::Vector3d& t, double q[4], double tt[3]) {
+    q[0] = r.x(); q[1] = r.y(); q[2] = r.z(); q[3] = r.w();
+    for (int i = 0; i < 3; i++) tt[i] = t[i];
+}
+static void normalize_rotation(Eigen::Quaterniond& r) {              /* se3quat.h normalizeRotation */
+    if (r.w() < 0) r.coeffs() *= -1;
+    r.normalize();
+}
+void ref_g2o_from_Rt(const double R[9], const double t[3], double q[4], double tt[3]) {      /* SE3Quat(R, t), :52-54 */
+    Eigen::Matrix3d M;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M(i, j) = R[i * 3 + j];
+    Eigen::Quaterniond r(M);
+    normalize_rotation(r);
+    put(r, Eigen::Vector3d(t[0], t[1], t[2]), q, tt);
+}
+void ref_g2o_exp(const double u[6], double q[4], double tt[3]) {                              /* SE3Quat::exp, :201-229 */
+    Eigen::Vector3d omega(u[0], u[1], u[2]), upsilon(u[3], u[4], u[5]);
+    double theta = omega.norm();
+    Eigen::Matrix3d Omega;
+    Omega << 0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0;
+    Eigen::Matrix3d R, V, Omega2 = Omega * Omega;
+    if (theta < 0.00001) {
+        R = (Eigen::Matrix3d::Identity() + Omega + 0.5 * Omega2);
+        V = (Eigen::Matrix3d::Identity() + 0.5 * Omega + 1. / 6. * Omega2);
+    } else {
+        R = (Eigen::Matrix3d::Identity() + std::sin(theta) / theta * Omega + (1 - std::cos(theta)) / (theta * theta) * Omega2);
+        V = (Eigen::Matrix3d::Identity() + (1 - std::cos(theta)) / (theta * theta) * Omega + (theta - std::sin(theta)) / (std::pow(theta, 3)) * Omega2);
+    }
+    Eigen::Quaterniond r(R);
+    normalize_rotation(r);
+    put(r, V * upsilon, q, tt);
+}
+void ref_g2o_mul(const double qa[4], const double ta[3], const double qb[4], const double tb[3], double q[4], double tt[3]) {   /* operator*, :96-102 */
+    Eigen::Quaterniond ra(qa[3], qa[0], qa[1], qa[2]), rb(qb[3], qb[0], qb[1], qb[2]);
+    Eigen::Vector3d t(ta[0], ta[1], ta[2]);
+    t += ra * Eigen::Vector3d(tb[0], tb[1], tb[2]);
+    ra *= rb;
+    normalize_rotation(ra);
+    put(ra, t, q, tt);
+}
+void ref_g2o_map(const double q[4], const double t[3], const double X[3], double out[3]) {   /* map, :199 */
+    Eigen::Quaterniond r(q[3], q[0], q[1], q[2]);
+    Eigen::Vector3d p = r * Eigen::Vector3d(X[0], X[1], X[2]) + Eigen::Vector3d(t[0], t[1], t[2]);
+    for (int i = 0; i < 3; i++) out[i] = p[i];
+}
+void ref_quat_to_matrix(const double q[4], double R[9]) {
+    Eigen::Matrix3d M = Eigen::Quaterniond(q[3], q[0], q[1], q[2]).toRotationMatrix();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = M(i, j);
+}
+void ref_mat3_inverse(const double A[9], double Ai[9]) {                                     /* D->inverse(), block_solver.hpp:369 */
+    Eigen::Matrix3d M;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M(i, j) = A[i * 3 + j];
+    Eigen::Matrix3d I = M.inverse();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ai[i * 3 + j] = I(i, j);
+}
+int ref_ldlt3(const double A[9], const double b[3], double x[3]) {                           /* structure_only_solver.h:166-173 */
+    Eigen::Matrix3d M;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M(i, j) = A[i * 3 + j];
+    Eigen::LDLT<Eigen::Matrix3d> chol(M);
+    Eigen::Vector3d s = chol.solve(Eigen::Vector3d(b[0], b[1], b[2]));
+    for (int i = 0; i < 3; i++) x[i] = s[i];
+    return chol.isPositive() ? 1 : 0;
+}
+int ref_llt_solve(const double* A, int n, const double* b, double* x) {                      /* the dense equivalent of SimplicialLLT */
+    ColMat M = Eigen::Map<const RowMat>(A, n, n);
+    Eigen::LLT<ColMat> llt(M);
+    if (llt.info() != Eigen::Success) return 0;
+    Vec s = llt.solve(Eigen::Map<const Vec>(b, n));
+    for (int i = 0; i < n; i++) x[i] = s[i];
+    return 1;
+}
+
 }  /* extern "C" */

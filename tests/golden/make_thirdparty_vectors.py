@@ -65,5 +65,35 @@ for name, n, dup in (("orth68", 68, False), ("orth164", 164, False), ("orth_rank
     b = rng.normal(size=n); b2 = b.copy()
     R.ref_orthogonalize(P(b2, d), n, P(Nc.ravel(), d), 7, d(1e-5))
     out[name + "_N"] = Nc; out[name + "_b"] = b; out[name + "_out"] = b2
+# ---- the Eigen arithmetic behind g2o's SE3Quat, Matrix3d::inverse, LDLT<Matrix3d>, LLT (pose-only optimisation, local BA)
+u = rng.normal(size=(40, 6)) * np.array([.5, .5, .5, 1, 1, 1])
+u[:6, :3] *= 1e-7; u[6:9, :3] = 0; u[9:14, :3] *= 5.5
+gq = np.zeros((40, 4)); gt = np.zeros((40, 3)); gR = np.zeros((40, 9)); gq2 = np.zeros((40, 4)); gt2 = np.zeros((40, 3))
+gqm = np.zeros((40, 4)); gtm = np.zeros((40, 3)); gX = rng.normal(size=(40, 3)) * 5; gmap = np.zeros((40, 3))
+for i in range(40):
+    R.ref_g2o_exp(P(u[i], d), P(gq[i], d), P(gt[i], d))
+    R.ref_quat_to_matrix(P(gq[i], d), P(gR[i], d))
+    R.ref_g2o_from_Rt(P(gR[i], d), P(gt[i], d), P(gq2[i], d), P(gt2[i], d))
+    R.ref_g2o_map(P(gq[i], d), P(gt[i], d), P(gX[i], d), P(gmap[i], d))
+for i in range(40):
+    j = (i + 11) % 40
+    R.ref_g2o_mul(P(gq[i], d), P(gt[i], d), P(gq[j], d), P(gt[j], d), P(gqm[i], d), P(gtm[i], d))
+out.update(g2o_u=u, g2o_q=gq, g2o_t=gt, g2o_R=gR, g2o_q_from_R=gq2, g2o_X=gX, g2o_map=gmap, g2o_q_mul=gqm, g2o_t_mul=gtm)
+A3 = np.zeros((24, 9)); b3 = rng.normal(size=(24, 3)); x3 = np.zeros((24, 3)); pos3 = np.zeros(24, np.int32); inv3 = np.zeros((24, 9))
+for i in range(24):
+    M = rng.normal(size=(3, 3))
+    A = M @ M.T + 1e-3 * np.eye(3) if i < 16 else (M + M.T)                  # SPD, then indefinite
+    if i in (14, 15):
+        A = A * np.array([1e4, 1.0, 1e-4])[:, None] * np.array([1e4, 1.0, 1e-4])[None, :]
+    A3[i] = A.ravel()
+    pos3[i] = R.ref_ldlt3(P(A3[i], d), P(b3[i], d), P(x3[i], d))
+    R.ref_mat3_inverse(P(A3[i], d), P(inv3[i], d))
+out.update(ldlt3_A=A3, ldlt3_b=b3, ldlt3_x=x3, ldlt3_pos=pos3, inv3=inv3)
+for n in (6, 36, 126):
+    M = rng.normal(size=(n, n + 4)); A = M @ M.T; b = rng.normal(size=n); x = np.zeros(n)
+    ok = R.ref_llt_solve(P(A.ravel(), d), n, P(b, d), P(x, d))
+    out[f"llt_A{n}"] = A; out[f"llt_b{n}"] = b; out[f"llt_x{n}"] = x; out[f"llt_ok{n}"] = np.int32(ok)
+A = rng.normal(size=(6, 6)); A = A + A.T; x = np.zeros(6)
+out["llt_indef_A"] = A; out["llt_indef_ok"] = np.int32(R.ref_llt_solve(P(A.ravel(), d), 6, P(np.ones(6), d), P(x, d)))
 np.savez_compressed(os.path.join(os.path.dirname(__file__), "thirdparty_vectors.npz"), **out)
 print("wrote", len(out), "arrays")

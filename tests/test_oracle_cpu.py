@@ -34,6 +34,52 @@ def test_se3_against_golden_sophus():
         assert np.abs(D.ravel() - G["dx_exp_x"][i]).max() < 1e-9 * max(1.0, np.abs(G["dx_exp_x"][i]).max())
 
 
+def test_g2o_arithmetic_against_golden_eigen():
+    """The SE3Quat / Eigen arithmetic of the g2o-based restatements (oracle/orc_g2o.h: pose-only optimisation, local BA) against
+    the outputs of the same Eigen calls made by the reference's vendored Eigen 3.4.0 (oracle/ref_thirdparty.cpp)."""
+    L = O.lib()
+    d = C.c_double
+    P = O.ptr
+    n = len(G["g2o_u"])
+    q = np.zeros((n, 4)); t = np.zeros((n, 3))
+    for i in range(n):
+        L.orc_g2o_exp(P(G["g2o_u"][i].copy(), d), P(q[i], d), P(t[i], d))
+        assert np.abs(q[i] - G["g2o_q"][i]).max() < 1e-14 and np.abs(t[i] - G["g2o_t"][i]).max() < 1e-13, i
+        R = np.zeros(9); L.orc_g2o_to_matrix(P(G["g2o_q"][i].copy(), d), P(R, d))
+        assert np.abs(R - G["g2o_R"][i]).max() < 1e-15
+        q2 = np.zeros(4); t2 = np.zeros(3)
+        L.orc_g2o_from_Rt(P(G["g2o_R"][i].copy(), d), P(G["g2o_t"][i].copy(), d), P(q2, d), P(t2, d))
+        assert np.abs(q2 - G["g2o_q_from_R"][i]).max() < 1e-14
+        m = np.zeros(3); L.orc_g2o_map(P(G["g2o_q"][i].copy(), d), P(G["g2o_t"][i].copy(), d), P(G["g2o_X"][i].copy(), d), P(m, d))
+        assert np.abs(m - G["g2o_map"][i]).max() < 1e-13
+        j = (i + 11) % n
+        qm = np.zeros(4); tm = np.zeros(3)
+        L.orc_g2o_mul(P(G["g2o_q"][i].copy(), d), P(G["g2o_t"][i].copy(), d), P(G["g2o_q"][j].copy(), d), P(G["g2o_t"][j].copy(), d), P(qm, d), P(tm, d))
+        assert np.abs(qm - G["g2o_q_mul"][i]).max() < 1e-14 and np.abs(tm - G["g2o_t_mul"][i]).max() < 1e-13
+    for i in range(len(G["ldlt3_A"])):
+        A = G["ldlt3_A"][i].copy(); x = np.zeros(3)
+        pos = L.orc_ldlt3(P(A, d), P(G["ldlt3_b"][i].copy(), d), P(x, d))
+        assert pos == int(G["ldlt3_pos"][i]), i
+        assert np.abs(x - G["ldlt3_x"][i]).max() <= 1e-9 * max(1e-300, np.abs(G["ldlt3_x"][i]).max()), i
+        Ai = np.zeros(9); L.orc_g2o_inv3(P(A, d), P(Ai, d))
+        assert np.abs(Ai - G["inv3"][i]).max() <= 1e-10 * np.abs(G["inv3"][i]).max()
+    assert int(G["ldlt3_pos"][:16].sum()) == 16 and int(G["ldlt3_pos"][16:].sum()) < 8
+    for nn in (6, 36, 126):
+        A = np.ascontiguousarray(G[f"llt_A{nn}"]); x = np.zeros(nn)
+        ok = L.orc_g2o_llt_solve(P(A, d), nn, P(G[f"llt_b{nn}"].copy(), d), P(x, d))
+        assert ok == int(G[f"llt_ok{nn}"]) == 1
+        assert np.abs(x - G[f"llt_x{nn}"]).max() <= 1e-9 * np.abs(G[f"llt_x{nn}"]).max()
+    x = np.zeros(6)
+    assert L.orc_g2o_llt_solve(P(np.ascontiguousarray(G["llt_indef_A"]), d), 6, P(np.ones(6), d), P(x, d)) == int(G["llt_indef_ok"]) == 0
+    if O.ref():                                             # where oracle/_ref is built: fresh random cases straight against it
+        Rf = O.ref(); rng = np.random.default_rng(1)
+        for _ in range(200):
+            u = rng.normal(size=6) * rng.choice([1e-8, 0.3, 3.0])
+            a = np.zeros(4); b = np.zeros(3); c2 = np.zeros(4); d2 = np.zeros(3)
+            L.orc_g2o_exp(P(u, d), P(a, d), P(b, d)); Rf.ref_g2o_exp(P(u, d), P(c2, d), P(d2, d))
+            assert np.abs(a - c2).max() < 1e-14 and np.abs(b - d2).max() < 1e-13
+
+
 def test_ldlt_inverse_orthogonalize_against_golden_eigen():
     for n in (6, 7, 8, 64, 160):
         A, b, x = G[f"ldlt_A{n}"], G[f"ldlt_b{n}"], G[f"ldlt_x{n}"]
