@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_init_calc_res_and_gs(InitArgs A) {
             float q[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const float v = 0.0f + ((P.RKi[3 * k] * p0 + P.RKi[3 * k + 1] * p1) + P.RKi[3 * k + 2] * p2);
+                const float v = 0.0f + (P.RKi[3 * k] * p0 + (P.RKi[3 * k + 1] * p1 + P.RKi[3 * k + 2] * p2));   // Eigen's order: e0 + (e1 + e2)
                 q[k] = v + P.t[k] * idn;
             }
             tz[idx] = q[2];

@@ -95,7 +95,8 @@ __device__ __forceinline__ void trace_one(const TraceArgs& A, const int pi) {
     const double aff_a = pr_->aff_a, aff_b = pr_->aff_b;
     const double idmin = s->idepth_min, idmax = s->idepth_max;
     const double cx = (double)s->x, cy = (double)s->y;
-    const double pr0 = M[0] * cx + M[1] * cy + M[2] * 1.0, pr1 = M[3] * cx + M[4] * cy + M[5] * 1.0, pr2 = M[6] * cx + M[7] * cy + M[8] * 1.0;
+    // Eigen's order for a double 3x3 * 3-vector: packet rows 0-1 (e0 + e1) + e2, scalar row 2 e0 + (e1 + e2)
+    const double pr0 = (M[0] * cx + M[1] * cy) + M[2] * 1.0, pr1 = (M[3] * cx + M[4] * cy) + M[5] * 1.0, pr2 = M[6] * cx + (M[7] * cy + M[8] * 1.0);
     const double maxPixSearch = (double)(w + h) * P.max_pix_search;                 // :611
     const double pm0 = pr0 + Kt[0] * idmin, pm1 = pr1 + Kt[1] * idmin, pm2 = pr2 + Kt[2] * idmin;
     const double minx = pm0 / pm2, miny = pm1 / pm2;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
             if (isfinite(refColor)) {                                           // TR.cpp:301-303
                 float pt[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) pt[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) + A.t[k] * id;
+                for (int k = 0; k < 3; k++) pt[k] = (A.RKi[k * 3] * x + (A.RKi[k * 3 + 1] * y + A.RKi[k * 3 + 2] * 1.0f)) + A.t[k] * id;   // Eigen's order for a float 3x3 * 3-vector: e0 + (e1 + e2)
                 const float u = pt[0] / pt[2], vv = pt[1] / pt[2];
                 const float Ku = A.fxl * u + A.cxl, Kv = A.fyl * vv + A.cyl;
                 const float new_idepth = id / pt[2];
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
                     float a[3], b[3], c[3];
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
-                        const float kp = (A.Ki[k * 3] * x + A.Ki[k * 3 + 1] * y) + A.Ki[k * 3 + 2] * 1.0f;
+                        const float kp = A.Ki[k * 3] * x + (A.Ki[k * 3 + 1] * y + A.Ki[k * 3 + 2] * 1.0f);
                         a[k] = kp + A.t[k] * id; b[k] = kp - A.t[k] * id;
-                        c[k] = ((A.RKi[k * 3] * x + A.RKi[k * 3 + 1] * y) + A.RKi[k * 3 + 2] * 1.0f) - A.t[k] * id;
+                        c[k] = (A.RKi[k * 3] * x + (A.RKi[k * 3 + 1] * y + A.RKi[k * 3 + 2] * 1.0f)) - A.t[k] * id;
                     }
                     const float KuT = A.fxl * (a[0] / a[2]) + A.cxl, KvT = A.fyl * (a[1] / a[2]) + A.cyl;
                     const float KuT2 = A.fxl * (b[0] / b[2]) + A.cxl, KvT2 = A.fyl * (b[1] / b[2]) + A.cyl;
@@ -255,7 +255,7 @@ static void inv3f(const float m[9], float o[9]) {
 #define MM(i, j) m[(i) * 3 + (j)]
 #define COF(i, j) (MM(((i) + 1) % 3, ((j) + 1) % 3) * MM(((i) + 2) % 3, ((j) + 2) % 3) - MM(((i) + 1) % 3, ((j) + 2) % 3) * MM(((i) + 2) % 3, ((j) + 1) % 3))
     const float c0 = COF(0, 0), c1 = COF(1, 0), c2 = COF(2, 0);
-    const float det = (c0 * MM(0, 0) + c1 * MM(1, 0)) + c2 * MM(2, 0);
+    const float det = c0 * MM(0, 0) + (c1 * MM(1, 0) + c2 * MM(2, 0));     // Eigen's redux of three terms: e0 + (e1 + e2)
     const float invdet = 1.0f / det;
     o[0] = c0 * invdet; o[1] = c1 * invdet; o[2] = c2 * invdet;
     o[3] = COF(0, 1) * invdet; o[4] = COF(1, 1) * invdet; o[5] = COF(2, 1) * invdet;
@@ -299,7 +299,7 @@ int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const doubl
     inv3f(Kf, A.Ki);
     for (int i = 0; i < 9; i++) Rf[i] = (float)R[i];
     for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) A.RKi[i * 3 + j] = (Rf[i * 3] * A.Ki[j] + Rf[i * 3 + 1] * A.Ki[3 + j]) + Rf[i * 3 + 2] * A.Ki[6 + j];
+        for (int j = 0; j < 3; j++) A.RKi[i * 3 + j] = Rf[i * 3] * A.Ki[j] + (Rf[i * 3 + 1] * A.Ki[3 + j] + Rf[i * 3 + 2] * A.Ki[6 + j]);   // Matrix33f product, Eigen order
     for (int i = 0; i < 3; i++) A.t[i] = (float)t[i];
     A.fxl = Kf[0]; A.fyl = Kf[4]; A.cxl = Kf[2]; A.cyl = Kf[5];
     A.a0 = (float)aff[0]; A.a1 = (float)aff[1];

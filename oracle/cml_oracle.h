@@ -220,6 +220,16 @@ int  orc_g2o_llt_solve(const double* A, int n, const double* b, double* x);
 
 #endif
 
+/* Eigen expression shapes of the projection arithmetic (pinned on the vendored Eigen, see orc_base.c) */
+void orc_eig_matvec3f_affine(const float M[9], const float v[3], const float t[3], float s, int sign, float out[3]);
+void orc_eig_matvec3f_noalias(const float M[9], const float v[3], const float t[3], float s, float out[3]);
+void orc_eig_homog3d(const double R[9], const double v[2], const double t[3], double s, double out[3]);
+void orc_eig_matvec3d(const double M[9], const double v[3], double out[3]);
+void orc_eig_matmul3f(const float A[9], const float B[9], float out[9]);
+void orc_eig_matmul3d(const double A[9], const double B[9], double out[9]);
+void orc_eig_inverse3f(const float m[9], float o[9]);
+void orc_eig_inverse3d(const double m[9], double o[9]);
+
 /* ------------------------------------------------------------------ immature points: DSOTracer */
 /* DSOTracer::trace, DSOTracer.cpp:585-823: aos3 = level-0 gradient image of the traced frame (channel 0 = gray) */
 int orc_trace_point(const float* aos3, int w, int h, const cmlhip_trace_pair* pair, const cmlhip_tracer_params* prm,

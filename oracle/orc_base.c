@@ -64,6 +64,62 @@ void orc_interpolate3(const float* d, int w, float x, float y, float out[3]) {
         out[c] = p1[c] * w00 + p1[3 + c] * w01 + p2[c] * w10 + p2[3 + c] * w11;
 }
 
+
+/* ============================================================ Eigen expression shapes (pinned: tests/golden, oracle/_ref)
+ * How the vendored Eigen 3.4.0 (non-FMA build) evaluates the small fixed-size products the path is written with.  The inner
+ * sum of three products is NOT left-to-right everywhere: scalar (non-vectorisable) evaluation reduces as e0 + (e1 + e2)
+ * (redux unroller splits 3 into 1 + 2), SSE2 double packets (rows 0-1 of a column-major 3-vector) accumulate column by column,
+ * (e0 + e1) + e2; the homogeneous product adds the last column after the 2-column product. */
+void orc_eig_matvec3f_affine(const float M[9], const float v[3], const float t[3], float s, int sign, float out[3]) {
+    for (int i = 0; i < 3; i++) {                                   /* Vector3f pt = RKi * Vector3f(x, y, 1) +/- t*id, TR.cpp:306-330 */
+        const float r = M[3 * i] * v[0] + (M[3 * i + 1] * v[1] + M[3 * i + 2] * v[2]);
+        out[i] = sign >= 0 ? r + t[i] * s : r - t[i] * s;
+    }
+}
+void orc_eig_matvec3f_noalias(const float M[9], const float v[3], const float t[3], float s, float out[3]) {
+    for (int i = 0; i < 3; i++) {                                   /* setZero; noalias() += RKi * p; noalias() += t * id, DSOInitializer.cpp:490-493 */
+        const float r = 0.0f + (M[3 * i] * v[0] + (M[3 * i + 1] * v[1] + M[3 * i + 2] * v[2]));
+        out[i] = r + t[i] * s;
+    }
+}
+void orc_eig_homog3d(const double R[9], const double v[2], const double t[3], double s, double out[3]) {
+    for (int i = 0; i < 3; i++)                                     /* R * refcorner.homogeneous() + t * idepth, BA.cpp:109 */
+        out[i] = ((R[3 * i] * v[0] + R[3 * i + 1] * v[1]) + R[3 * i + 2]) + t[i] * s;
+}
+void orc_eig_matvec3d(const double M[9], const double v[3], double out[3]) {
+    for (int i = 0; i < 2; i++) out[i] = (M[3 * i] * v[0] + M[3 * i + 1] * v[1]) + M[3 * i + 2] * v[2];   /* packet rows */
+    out[2] = M[6] * v[0] + (M[7] * v[1] + M[8] * v[2]);                                                    /* scalar row */
+}
+void orc_eig_matmul3f(const float A[9], const float B[9], float out[9]) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[3 * i + j] = A[3 * i] * B[j] + (A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j]);
+}
+void orc_eig_matmul3d(const double A[9], const double B[9], double out[9]) {
+    for (int j = 0; j < 3; j++) {
+        for (int i = 0; i < 2; i++) out[3 * i + j] = (A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j];
+        out[6 + j] = A[6] * B[j] + (A[7] * B[3 + j] + A[8] * B[6 + j]);
+    }
+}
+
+/* Matrix3f / Matrix3d::inverse(), Eigen/src/LU/InverseImpl.h:139-176: cofactors, det = sum of cofactors_col0 .* col(0)
+ * (float: e0 + (e1 + e2); double: the 2-packet first, (e0 + e1) + e2), result(j,i) = cofactor<i,j> * invdet */
+#define EIG_COF(m, i, j) (m[(((i) + 1) % 3) * 3 + (((j) + 1) % 3)] * m[(((i) + 2) % 3) * 3 + (((j) + 2) % 3)] - m[(((i) + 1) % 3) * 3 + (((j) + 2) % 3)] * m[(((i) + 2) % 3) * 3 + (((j) + 1) % 3)])
+void orc_eig_inverse3f(const float m[9], float o[9]) {
+    const float c0 = EIG_COF(m, 0, 0), c1 = EIG_COF(m, 1, 0), c2 = EIG_COF(m, 2, 0);
+    const float det = c0 * m[0] + (c1 * m[3] + c2 * m[6]);
+    const float invdet = 1.0f / det;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) if (j != 0) o[j * 3 + i] = EIG_COF(m, i, j) * invdet;
+    o[0] = c0 * invdet; o[1] = c1 * invdet; o[2] = c2 * invdet;
+}
+void orc_eig_inverse3d(const double m[9], double o[9]) {
+    const double c0 = EIG_COF(m, 0, 0), c1 = EIG_COF(m, 1, 0), c2 = EIG_COF(m, 2, 0);
+    const double det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+    const double invdet = 1.0 / det;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) if (j != 0) o[j * 3 + i] = EIG_COF(m, i, j) * invdet;
+    o[0] = c0 * invdet; o[1] = c1 * invdet; o[2] = c2 * invdet;
+}
+#undef EIG_COF
+
 /* ============================================================ SE3 */
 
 static void q_normalize_approx(double q[4]) {

@@ -76,7 +76,7 @@ void orc_init_calc_res_and_gs(const float* aos3, int wl, int hl, const cmlhip_in
         for (int idx = 0; idx < 8; idx++) {                                               /* :484-513 */
             const float* pp = pt->p_pattern[idx];
             for (int k = 0; k < 3; k++) {
-                float v = 0.0f + ((RKi[3 * k] * pp[0] + RKi[3 * k + 1] * pp[1]) + RKi[3 * k + 2] * pp[2]);
+                float v = 0.0f + (RKi[3 * k] * pp[0] + (RKi[3 * k + 1] * pp[1] + RKi[3 * k + 2] * pp[2]));   /* Eigen: e0 + (e1 + e2), pinned: orc_eig_matvec3f_noalias */
                 tempPt[idx][k] = v + t[k] * pt->idepth_new;
             }
             tempU[idx] = tempPt[idx][0] / tempPt[idx][2];

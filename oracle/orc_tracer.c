@@ -28,7 +28,9 @@ int orc_trace_point(const float* aos3, int w, int h, const cmlhip_trace_pair* pr
     const double* M = pr_->KRKi; const double* Kt = pr_->Kt;
     if (s->last_status == CMLHIP_IPS_OOB) return CMLHIP_IPS_OOB;                           /* :601-604 */
     const double cx = (double)s->x, cy = (double)s->y;
-    const double pr[3] = {M[0] * cx + M[1] * cy + M[2] * 1.0, M[3] * cx + M[4] * cy + M[5] * 1.0, M[6] * cx + M[7] * cy + M[8] * 1.0};
+    /* Vector3 pr = KRKi * Vector3(x, y, 1), :608 — Eigen's order for a double 3x3 * 3-vector: the SSE2 packet rows 0-1
+     * accumulate column by column, the scalar row 2 reduces as e0 + (e1 + e2) (pinned: orc_eig_matvec3d) */
+    const double pr[3] = {(M[0] * cx + M[1] * cy) + M[2] * 1.0, (M[3] * cx + M[4] * cy) + M[5] * 1.0, M[6] * cx + (M[7] * cy + M[8] * 1.0)};
     const double maxPixSearch = (double)(w + h) * P->max_pix_search;                       /* :611 */
     const double ptpMin[3] = {pr[0] + Kt[0] * s->idepth_min, pr[1] + Kt[1] * s->idepth_min, pr[2] + Kt[2] * s->idepth_min};
     double minx = ptpMin[0] / ptpMin[2], miny = ptpMin[1] / ptpMin[2];

@@ -9,19 +9,6 @@
 #include <string.h>
 
 /* Eigen compute_inverse_size3 (cofactors * 1/det), float */
-static void inv3f(const float m[9], float o[9]) {
-#define MM(i, j) m[(i) * 3 + (j)]
-#define COF(i, j) (MM(((i) + 1) % 3, ((j) + 1) % 3) * MM(((i) + 2) % 3, ((j) + 2) % 3) - MM(((i) + 1) % 3, ((j) + 2) % 3) * MM(((i) + 2) % 3, ((j) + 1) % 3))
-    float c0 = COF(0, 0), c1 = COF(1, 0), c2 = COF(2, 0);
-    float det = (c0 * MM(0, 0) + c1 * MM(1, 0)) + c2 * MM(2, 0);
-    float invdet = 1.0f / det;
-    o[0] = c0 * invdet; o[1] = c1 * invdet; o[2] = c2 * invdet;
-    o[3] = COF(0, 1) * invdet; o[4] = COF(1, 1) * invdet; o[5] = COF(2, 1) * invdet;
-    o[6] = COF(0, 2) * invdet; o[7] = COF(1, 2) * invdet; o[8] = COF(2, 2) * invdet;
-#undef COF
-#undef MM
-}
-
 /* TR.cpp:248-492 */
 void orc_tracker_eval(const float* aos3, int wl, int hl, const float* uvic, int n, int level,
                       const double Rd[9], const double td[3], const double Kd[4], const double aff[2], double b0d,
@@ -30,12 +17,11 @@ void orc_tracker_eval(const float* aos3, int wl, int hl, const float* uvic, int 
     float E = 0;
     int numTermsInE = 0, numWarped = 0, numSaturated = 0, numRobust = 0;
     float K[9] = {(float)Kd[0], 0, (float)Kd[2], 0, (float)Kd[1], (float)Kd[3], 0, 0, 1}, Ki[9];
-    inv3f(K, Ki);                                   /* :260-261 */
+    orc_eig_inverse3f(K, Ki);                       /* Matrix33f Ki = K.inverse(), :260-261 */
     float fxl = K[0], fyl = K[4], cxl = K[2], cyl = K[5];
     float R[9], RKi[9], t[3];
     for (int i = 0; i < 9; i++) R[i] = (float)Rd[i];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) RKi[i * 3 + j] = (R[i * 3] * Ki[j] + R[i * 3 + 1] * Ki[3 + j]) + R[i * 3 + 2] * Ki[6 + j];
+    orc_eig_matmul3f(R, Ki, RKi);                   /* Matrix33f RKi = R.cast<float>() * Ki, :270 (Eigen order: e0 + (e1 + e2)) */
     for (int i = 0; i < 3; i++) t[i] = (float)td[i];
     float a0 = (float)aff[0], a1 = (float)aff[1];   /* affLL, :272 */
     float sT = 0, sRT = 0, sN = 0;
@@ -47,17 +33,17 @@ void orc_tracker_eval(const float* aos3, int wl, int hl, const float* uvic, int 
         float x = uvic[4 * i], y = uvic[4 * i + 1], id = uvic[4 * i + 2], refColor = uvic[4 * i + 3];
         if (!isfinite(refColor)) continue;
         float pt[3];
-        for (int k = 0; k < 3; k++) pt[k] = ((RKi[k * 3] * x + RKi[k * 3 + 1] * y) + RKi[k * 3 + 2] * 1.0f) + t[k] * id;
+        for (int k = 0; k < 3; k++) pt[k] = (RKi[k * 3] * x + (RKi[k * 3 + 1] * y + RKi[k * 3 + 2] * 1.0f)) + t[k] * id;   /* :306, Eigen: e0 + (e1 + e2) */
         float u = pt[0] / pt[2], v = pt[1] / pt[2];
         float Ku = fxl * u + cxl, Kv = fyl * v + cyl;
         float new_idepth = id / pt[2];
         if (level == 0 && i % 32 == 0) {                /* :313-344 */
             float a[3], b[3], c[3];
             for (int k = 0; k < 3; k++) {
-                float kp = (Ki[k * 3] * x + Ki[k * 3 + 1] * y) + Ki[k * 3 + 2] * 1.0f;
+                float kp = Ki[k * 3] * x + (Ki[k * 3 + 1] * y + Ki[k * 3 + 2] * 1.0f);     /* Eigen: e0 + (e1 + e2) */
                 a[k] = kp + t[k] * id;
                 b[k] = kp - t[k] * id;
-                c[k] = ((RKi[k * 3] * x + RKi[k * 3 + 1] * y) + RKi[k * 3 + 2] * 1.0f) - t[k] * id;
+                c[k] = (RKi[k * 3] * x + (RKi[k * 3 + 1] * y + RKi[k * 3 + 2] * 1.0f)) - t[k] * id;
             }
             float KuT = fxl * (a[0] / a[2]) + cxl, KvT = fyl * (a[1] / a[2]) + cyl;
             float KuT2 = fxl * (b[0] / b[2]) + cxl, KvT2 = fyl * (b[1] / b[2]) + cyl;

@@ -173,4 +173,68 @@ int ref_llt_solve(const double* A, int n, const double* b, double* x) {         
     return 1;
 }
 
+/* ---- the Eigen expression SHAPES of the projection arithmetic on the path, evaluated by the vendored Eigen exactly as the
+ * reference's statements are typed (same scalar types, same operand expressions), non-FMA build.  Eigen's evaluation order is
+ * not the textbook left-to-right sum: e.g. a float 3x3 * 3-vector is e0 + (e1 + e2) per row, a double one is (e0 + e1) + e2 in
+ * the SSE2 packet rows 0-1 and e0 + (e1 + e2) in the scalar row 2.  The oracle's orc_eig_* helpers are pinned on these. */
+typedef Eigen::Matrix<float, 3, 3> M3f;
+typedef Eigen::Matrix<double, 3, 3> M3d;
+static M3f ldf(const float* a) { M3f m; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m(i, j) = a[i * 3 + j]; return m; }
+static M3d ldd(const double* a) { M3d m; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m(i, j) = a[i * 3 + j]; return m; }
+/* Vector3f pt = RKi * Vector3f(x, y, 1) + t*id;  (TR.cpp:306,316)   sign < 0: ... - t*id (TR.cpp:323,330) */
+void ref_eig_matvec3f_affine(const float M[9], const float v[3], const float t[3], float s, int sign, float out[3]) {
+    M3f RKi = ldf(M); Eigen::Vector3f tt(t[0], t[1], t[2]);
+    Eigen::Vector3f pt;
+    if (sign >= 0) pt = RKi * Eigen::Vector3f(v[0], v[1], v[2]) + tt * s;
+    else pt = RKi * Eigen::Vector3f(v[0], v[1], v[2]) - tt * s;
+    for (int i = 0; i < 3; i++) out[i] = pt[i];
+}
+/* tempPt.setZero(); tempPt.noalias() += RKi * pPattern; tempPt.noalias() += t * idepth_new;  (DSOInitializer.cpp:490-493) */
+void ref_eig_matvec3f_noalias(const float M[9], const float v[3], const float t[3], float s, float out[3]) {
+    M3f RKi = ldf(M); Eigen::Vector3f tt(t[0], t[1], t[2]), p(v[0], v[1], v[2]), tempPt;
+    tempPt.setZero();
+    tempPt.noalias() += RKi * p;
+    tempPt.noalias() += tt * s;
+    for (int i = 0; i < 3; i++) out[i] = tempPt[i];
+}
+/* projectedcurp.noalias() = R * refcorner.homogeneous() + t * pointIdepth;  (BA.cpp:109, DSOTracer.cpp:436) */
+void ref_eig_homog3d(const double R[9], const double v[2], const double t[3], double s, double out[3]) {
+    M3d Rm = ldd(R); Eigen::Vector2d refcorner(v[0], v[1]); Eigen::Vector3d tt(t[0], t[1], t[2]), projectedcurp;
+    projectedcurp.noalias() = Rm * refcorner.homogeneous() + tt * s;
+    for (int i = 0; i < 3; i++) out[i] = projectedcurp[i];
+}
+/* Vector3 pr = hostToFrame_KRKi * Vector3(x, y, 1);  (DSOTracer.cpp:608) */
+void ref_eig_matvec3d(const double M[9], const double v[3], double out[3]) {
+    M3d A = ldd(M);
+    Eigen::Vector3d pr = A * Eigen::Vector3d(v[0], v[1], v[2]);
+    for (int i = 0; i < 3; i++) out[i] = pr[i];
+}
+/* Matrix33f RKi = (R.cast<float>() * Ki);  (TR.cpp:270) */
+void ref_eig_matmul3f(const float A[9], const float B[9], float out[9]) {
+    M3f C = ldf(A) * ldf(B);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[i * 3 + j] = C(i, j);
+}
+/* Matrix33f RKi = (R * Ki).cast<float>();  (DSOInitializer.cpp:471) and the plain double product */
+void ref_eig_matmul3d(const double A[9], const double B[9], double out[9], float outf[9]) {
+    M3d C = ldd(A) * ldd(B);
+    M3f Cf = (ldd(A) * ldd(B)).cast<float>();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { out[i * 3 + j] = C(i, j); outf[i * 3 + j] = Cf(i, j); }
+}
+/* Matrix33f Ki = K.inverse() (TR.cpp:260-261) / Matrix33 Ki = K.inverse() (DSOInitializer.cpp:456) */
+void ref_eig_inverse3f(const float A[9], float out[9]) {
+    M3f I = ldf(A).inverse();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[i * 3 + j] = I(i, j);
+}
+void ref_eig_inverse3d(const double A[9], double out[9]) {
+    M3d I = ldd(A).inverse();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[i * 3 + j] = I(i, j);
+}
+/* Matrix33 hostToFrame_KRKi = K * R * K.inverse();  Vector3 hostToFrame_Kt = K * t;  (DSOTracer.cpp:606-607) */
+void ref_eig_krki(const double K[9], const double R[9], const double t[3], double out[9], double kt[3]) {
+    M3d Km = ldd(K), Rm = ldd(R);
+    M3d hostToFrame_KRKi = Km * Rm * Km.inverse();
+    Eigen::Vector3d hostToFrame_Kt = Km * Eigen::Vector3d(t[0], t[1], t[2]);
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) out[i * 3 + j] = hostToFrame_KRKi(i, j); kt[i] = hostToFrame_Kt[i]; }
+}
+
 }  /* extern "C" */

@@ -95,5 +95,32 @@ for n in (6, 36, 126):
     out[f"llt_A{n}"] = A; out[f"llt_b{n}"] = b; out[f"llt_x{n}"] = x; out[f"llt_ok{n}"] = np.int32(ok)
 A = rng.normal(size=(6, 6)); A = A + A.T; x = np.zeros(6)
 out["llt_indef_A"] = A; out["llt_indef_ok"] = np.int32(R.ref_llt_solve(P(A.ravel(), d), 6, P(np.ones(6), d), P(x, d)))
+# ---- Eigen expression shapes of the projection arithmetic (float / double 3x3 products, homogeneous product, 3x3 inverse)
+f = C.c_float
+ne = 400
+eM = rng.normal(size=(ne, 9)).astype(np.float32); ev = (rng.normal(size=(ne, 3)) * 100).astype(np.float32); ev[::2, 2] = 1
+et = rng.normal(size=(ne, 3)).astype(np.float32); es = rng.normal(size=ne).astype(np.float32)
+e_aff_p = np.zeros((ne, 3), np.float32); e_aff_m = np.zeros((ne, 3), np.float32); e_noal = np.zeros((ne, 3), np.float32)
+eB = rng.normal(size=(ne, 9)).astype(np.float32); e_mm3f = np.zeros((ne, 9), np.float32); e_inv3f = np.zeros((ne, 9), np.float32)
+eK = np.zeros((ne, 9), np.float32); e_invK = np.zeros((ne, 9), np.float32)
+dM = rng.normal(size=(ne, 9)); dv = rng.normal(size=(ne, 3)) * 100; dt = rng.normal(size=(ne, 3)); ds = rng.normal(size=ne)
+d_hom = np.zeros((ne, 3)); d_mv = np.zeros((ne, 3)); dB = rng.normal(size=(ne, 9)); d_mm = np.zeros((ne, 9)); d_mmf = np.zeros((ne, 9), np.float32)
+d_inv = np.zeros((ne, 9)); d_krki = np.zeros((ne, 9)); d_kt = np.zeros((ne, 3))
+for i in range(ne):
+    eK[i] = [300 + 100 * rng.normal(), 0, 300 + 50 * rng.normal(), 0, 300 + 100 * rng.normal(), 200 + 50 * rng.normal(), 0, 0, 1]
+    R.ref_eig_matvec3f_affine(P(eM[i], f), P(ev[i], f), P(et[i], f), f(es[i]), 1, P(e_aff_p[i], f))
+    R.ref_eig_matvec3f_affine(P(eM[i], f), P(ev[i], f), P(et[i], f), f(es[i]), -1, P(e_aff_m[i], f))
+    R.ref_eig_matvec3f_noalias(P(eM[i], f), P(ev[i], f), P(et[i], f), f(es[i]), P(e_noal[i], f))
+    R.ref_eig_matmul3f(P(eM[i], f), P(eB[i], f), P(e_mm3f[i], f))
+    R.ref_eig_inverse3f(P(eM[i], f), P(e_inv3f[i], f)); R.ref_eig_inverse3f(P(eK[i], f), P(e_invK[i], f))
+    R.ref_eig_homog3d(P(dM[i], d), P(dv[i, :2].copy(), d), P(dt[i], d), d(ds[i]), P(d_hom[i], d))
+    R.ref_eig_matvec3d(P(dM[i], d), P(dv[i], d), P(d_mv[i], d))
+    R.ref_eig_matmul3d(P(dM[i], d), P(dB[i], d), P(d_mm[i], d), P(d_mmf[i], f))
+    R.ref_eig_inverse3d(P(dM[i], d), P(d_inv[i], d))
+    R.ref_eig_krki(P(eK[i].astype(np.float64), d), P(dM[i], d), P(dt[i], d), P(d_krki[i], d), P(d_kt[i], d))
+out.update(eig_M3f=eM, eig_v3f=ev, eig_t3f=et, eig_s3f=es, eig_affine_plus=e_aff_p, eig_affine_minus=e_aff_m, eig_noalias=e_noal,
+           eig_B3f=eB, eig_matmul3f=e_mm3f, eig_inverse3f=e_inv3f, eig_K3f=eK, eig_inverseK3f=e_invK,
+           eig_M3d=dM, eig_v3d=dv, eig_t3d=dt, eig_s3d=ds, eig_homog3d=d_hom, eig_matvec3d=d_mv, eig_B3d=dB, eig_matmul3d=d_mm,
+           eig_matmul3d_cast=d_mmf, eig_inverse3d=d_inv, eig_krki=d_krki, eig_kt=d_kt)
 np.savez_compressed(os.path.join(os.path.dirname(__file__), "thirdparty_vectors.npz"), **out)
 print("wrote", len(out), "arrays")

@@ -34,6 +34,44 @@ def test_se3_against_golden_sophus():
         assert np.abs(D.ravel() - G["dx_exp_x"][i]).max() < 1e-9 * max(1.0, np.abs(G["dx_exp_x"][i]).max())
 
 
+def test_eigen_expression_shapes_bitwise_against_golden():
+    """The projection arithmetic of the path is written with small fixed-size Eigen products whose evaluation order is Eigen's,
+    not left-to-right (float 3x3 * 3-vector: e0 + (e1 + e2); double: packet rows (e0 + e1) + e2, scalar row e0 + (e1 + e2);
+    homogeneous product; cofactor inverse).  The oracle's orc_eig_* helpers — the formulas the tracker, tracer and initializer
+    restatements and the device kernels use — must reproduce the vendored Eigen 3.4.0 BIT FOR BIT."""
+    L = O.lib()
+    f = C.c_float; d = C.c_double; P = O.ptr
+    def same32(a, b): return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    def same64(a, b): return np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    n = len(G["eig_M3f"])
+    for i in range(n):
+        M = G["eig_M3f"][i].copy(); v = G["eig_v3f"][i].copy(); t = G["eig_t3f"][i].copy(); s = float(G["eig_s3f"][i])
+        o = np.zeros(3, np.float32)
+        L.orc_eig_matvec3f_affine(P(M, f), P(v, f), P(t, f), f(s), 1, P(o, f)); assert same32(o, G["eig_affine_plus"][i]), i
+        L.orc_eig_matvec3f_affine(P(M, f), P(v, f), P(t, f), f(s), -1, P(o, f)); assert same32(o, G["eig_affine_minus"][i]), i
+        L.orc_eig_matvec3f_noalias(P(M, f), P(v, f), P(t, f), f(s), P(o, f)); assert same32(o, G["eig_noalias"][i]), i
+        o9 = np.zeros(9, np.float32)
+        L.orc_eig_matmul3f(P(M, f), P(G["eig_B3f"][i].copy(), f), P(o9, f)); assert same32(o9, G["eig_matmul3f"][i]), i
+        L.orc_eig_inverse3f(P(M, f), P(o9, f)); assert same32(o9, G["eig_inverse3f"][i]), i
+        L.orc_eig_inverse3f(P(G["eig_K3f"][i].copy(), f), P(o9, f)); assert same32(o9, G["eig_inverseK3f"][i]), i
+        Md = G["eig_M3d"][i].copy(); vd = G["eig_v3d"][i].copy(); td = G["eig_t3d"][i].copy(); sd = float(G["eig_s3d"][i])
+        od = np.zeros(3)
+        L.orc_eig_homog3d(P(Md, d), P(vd[:2].copy(), d), P(td, d), d(sd), P(od, d)); assert same64(od, G["eig_homog3d"][i]), i
+        L.orc_eig_matvec3d(P(Md, d), P(vd, d), P(od, d)); assert same64(od, G["eig_matvec3d"][i]), i
+        o9d = np.zeros(9)
+        L.orc_eig_matmul3d(P(Md, d), P(G["eig_B3d"][i].copy(), d), P(o9d, d)); assert same64(o9d, G["eig_matmul3d"][i]), i
+        assert same32(o9d.astype(np.float32), G["eig_matmul3d_cast"][i])
+        L.orc_eig_inverse3d(P(Md, d), P(o9d, d)); assert same64(o9d, G["eig_inverse3d"][i]), i
+        Kd = G["eig_K3f"][i].astype(np.float64); KR = np.zeros(9); Ki = np.zeros(9); out = np.zeros(9); kt = np.zeros(3)
+        L.orc_eig_matmul3d(P(Kd, d), P(Md, d), P(KR, d)); L.orc_eig_inverse3d(P(Kd, d), P(Ki, d)); L.orc_eig_matmul3d(P(KR, d), P(Ki, d), P(out, d))
+        L.orc_eig_matvec3d(P(Kd, d), P(td, d), P(kt, d))
+        assert same64(out, G["eig_krki"][i]) and same64(kt, G["eig_kt"][i]), i            # K * R * K.inverse(), K * t (DSOTracer.cpp:606-607)
+    # the naive left-to-right sum is NOT what Eigen computes: the pin has teeth
+    M = G["eig_M3f"]; v = G["eig_v3f"]; t = G["eig_t3f"]; s = G["eig_s3f"]
+    naive = ((M[:, 0::3] * v[:, :1] + M[:, 1::3] * v[:, 1:2]) + M[:, 2::3] * v[:, 2:3]) + t * s[:, None]
+    assert (naive.astype(np.float32) != G["eig_affine_plus"]).any()
+
+
 def test_g2o_arithmetic_against_golden_eigen():
     """The SE3Quat / Eigen arithmetic of the g2o-based restatements (oracle/orc_g2o.h: pose-only optimisation, local BA) against
     the outputs of the same Eigen calls made by the reference's vendored Eigen 3.4.0 (oracle/ref_thirdparty.cpp)."""
