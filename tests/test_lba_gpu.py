@@ -85,3 +85,24 @@ def test_levenberg_matches_oracle(kw, iters, refine):
     for k in range(2):
         assert abs(r.chi2[k] - r_o.chi2[k]) <= 1e-7 * max(1.0, abs(r_o.chi2[k]))
     assert (bad != bad_o).sum() <= 2
+
+
+@pytest.mark.parametrize("n_local,n_fixed", [(32, 3), (1, 3)])
+def test_levenberg_size_limits(n_local, n_fixed):
+    """32 free keyframes = 192 unknowns = the largest reduced system the LDS factorisation holds (148 KB); 1 free keyframe."""
+    S = LS.scene(pose_noise=0.02, n_points=1500, seed=9, n_local=n_local, n_fixed=n_fixed)
+    fr_o, pts_o, bad_o, r_o = LS.oracle_lba(S["frames"], S["points"], S["off"], S["edges"], False, 4, 0)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        fr = S["frames"].copy(); pts = S["points"].copy()
+        bad, r = ctx.lba_optimize(fr, pts, S["off"], S["edges"], False, 4, 0)
+        if n_local == 32:                                   # 33 free keyframes: refused
+            S2 = LS.scene(pose_noise=0.0, n_points=100, seed=9, n_local=33, n_fixed=3)
+            with pytest.raises(device.CmlHipError):
+                ctx.lba_optimize(S2["frames"].copy(), S2["points"].copy(), S2["off"], S2["edges"], False, 1, 0)
+    finally:
+        ctx.close()
+    dR, dt = _pose_diff(fr, fr_o)
+    assert dR < 1e-7 and dt < 1e-7, (dR, dt)
+    assert np.abs(pts - pts_o).max() < 1e-6 * max(1.0, np.abs(pts_o).max())
+    assert abs(r.chi2[0] - r_o.chi2[0]) <= 1e-7 * max(1.0, abs(r_o.chi2[0]))
