@@ -59,7 +59,8 @@ def _pose_diff(a, b):
 
 @pytest.mark.parametrize("kw,iters,refine", [(dict(pose_noise=0.02, n_points=600, seed=3), 5, 0), (dict(pose_noise=0.02, n_points=600, seed=3), 10, 5),
                                              (dict(pose_noise=0.05, n_points=2500, seed=5, n_local=12, n_fixed=5), 6, 2),
-                                             (dict(pose_noise=0.0, n_points=300, seed=7, n_local=3, n_fixed=3), 3, 1)])
+                                             (dict(pose_noise=0.0, n_points=300, seed=7, n_local=3, n_fixed=3), 3, 1),
+                                             (dict(pose_noise=0.02, n_points=4000, seed=4, n_local=21, n_fixed=9), 5, 0)])
 def test_levenberg_matches_oracle(kw, iters, refine):
     """Free poses: g2o Levenberg + Schur.  fp64; the device sums edges per point / per pose / per block in a different order
     than the edge-order loops of g2o, so: same accept/reject sequence while the steps are large (checked through the pass
