@@ -145,10 +145,8 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
                 const float* dp = X.adHTd + 8 * q;
                 const int p = A.r_point[r];
                 const float dd = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
-                float jdx = 0, jdy = 0, cx = 0, cy = 0;
-                for (int j = 0; j < 6; j++) { jdx += J[O_XI0 + j] * dp[j]; jdy += J[O_XI1 + j] * dp[j]; }
-                for (int j = 0; j < 4; j++) { cx += J[O_C0 + j] * (float)X.cdelta[j]; cy += J[O_C1 + j] * (float)X.cdelta[j]; }
-                const float Jpx = jdx + cx + J[O_DD] * dd, Jpy = jdy + cy + J[O_DD + 1] * dd;
+                const float Jpx = cml_jp_delta(J + O_XI0, dp, J + O_C0, X.cdelta, J[O_DD], dd, false);
+                const float Jpy = cml_jp_delta(J + O_XI1, dp, J + O_C1, X.cdelta, J[O_DD + 1], dd, false);
                 double s0 = 0, s1 = 0, s2 = 0, s3 = 0; float srr = 0;
                 for (int j = 0; j < 8; j++) {
                     float rtz = A.r_rtz[8 * (size_t)r + j];
@@ -367,10 +365,8 @@ __global__ void k_ba_point_bdL(BAArgs A, const float* __restrict__ adHTd, const 
         if (!A.r_lin[r] || !A.r_good[r]) continue;
         const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
         const float* dp = adHTd + 8 * (host + A.r_target[r] * A.N);
-        float jdx = 0, jdy = 0, cx = 0, cy = 0;
-        for (int j = 0; j < 6; j++) { jdx += J[O_XI0 + j] * dp[j]; jdy += J[O_XI1 + j] * dp[j]; }
-        for (int j = 0; j < 4; j++) { cx += J[O_C0 + j] * (float)cdelta[j]; cy += J[O_C1 + j] * (float)cdelta[j]; }
-        const float Jpx = jdx + cx + J[O_DD] * dd, Jpy = jdy + cy + J[O_DD + 1] * dd;
+        const float Jpx = cml_jp_delta(J + O_XI0, dp, J + O_C0, cdelta, J[O_DD], dd, false);
+        const float Jpy = cml_jp_delta(J + O_XI1, dp, J + O_C1, cdelta, J[O_DD + 1], dd, false);
         double s0 = 0, s1 = 0;
         for (int j = 0; j < 8; j++) {
             float rtz = A.r_rtz[8 * (size_t)r + j];
@@ -995,7 +991,11 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
         const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
         const double xc = x[i & 3];
         int ngood = 0;
-        double dsum = 0.0;
+        // scalar_t b = bdSumF; b -= mCalibStep.dot(Hcd_A + Hcd_L); then b -= xAd * JpJdF for every good residual IN LIST ORDER
+        // (BA.cpp:1469-1479).  Both dots reduce by halves in Eigen (pinned on the reference's vendored Eigen, tests/golden) — the
+        // 8-lane butterfly below and the bracketing of `d` are exactly that order — and the subtractions are replayed one
+        // residual at a time, so the point step is the reference's bit for bit.
+        double bb = (double)pa13 - sum8d(i < 4 ? (-xc) * ((double)hcd + (double)hcl) : 0.0);
         for (int base = 0; base < A.pt_stride; base += 8) {
             const int slot = pp * A.pt_stride + base + i;
             const int code = A.point_code[slot], tgl = A.point_tgt[slot];         // efsJ code kept by applyRes, static target
@@ -1007,13 +1007,11 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
                      + ((xa[4] * (double)v1.x + xa[5] * (double)v1.y) + (xa[6] * (double)v1.z + xa[7] * (double)v1.w));
             d = good ? d : 0.0;
             ngood += (int)sum8(good ? 1.f : 0.f);
-            dsum += sum8d(d);
+#pragma unroll
+            for (int k = 0; k < 8; k++) bb -= __shfl(d, (threadIdx.x & 56) + k);      // b - 0.0 is exact for the slots that are not good
         }
-        // mCalibStep . (Hcd_accAF + Hcd_accLF), BA.cpp:1455-1487
-        const double cs = sum8d(i < 4 ? (-xc) * ((double)hcd + (double)hcl) : 0.0);
         double st = 0.0;
         if (ngood > 0) {
-            const double bb = ((double)pa13 - cs) - dsum;
             st = -bb * (double)pa12;
             if (pv && i == 0 && !isfinite(st)) atomicAdd(&sum->nonfinite, 1);
         }

@@ -83,3 +83,15 @@ int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step);
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_restore_points(cmlhip_ctx* c, const BAArgs& A);
+
+// Jp*delta of a linearised residual, in Eigen's evaluation order (pinned on the reference's vendored Eigen, tests/golden):
+// Vector6f.dot(Vector8f.head<6>()) is ((x0 + x2) + (x1 + x3)) + (x4 + x5); the 4-dot is (c0 + c2) + (c1 + c3) against an
+// evaluated Vector4f (BA.cpp:1699, 2166) and (c0 + c1) + (c2 + c3) when the cast expression stays inside the dot (BA.cpp:2219).
+__device__ __forceinline__ float cml_jp_delta(const float* Jxi, const float* dp, const float* Jc, const double* cdelta, float jpdd, float dd, bool cast_in_dot) {
+#pragma clang fp contract(off)
+    const float x0 = Jxi[0] * dp[0], x1 = Jxi[1] * dp[1], x2 = Jxi[2] * dp[2], x3 = Jxi[3] * dp[3], x4 = Jxi[4] * dp[4], x5 = Jxi[5] * dp[5];
+    const float c0 = Jc[0] * (float)cdelta[0], c1 = Jc[1] * (float)cdelta[1], c2 = Jc[2] * (float)cdelta[2], c3 = Jc[3] * (float)cdelta[3];
+    const float d6 = ((x0 + x2) + (x1 + x3)) + (x4 + x5);
+    const float d4 = cast_in_dot ? (c0 + c1) + (c2 + c3) : (c0 + c2) + (c1 + c3);
+    return (d6 + d4) + jpdd * dd;
+}

@@ -361,10 +361,8 @@ __global__ void k_ba_marg_fix(BAArgs A, const float* __restrict__ adHTd, const d
     const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;      // efsJ
     const float* dp = adHTd + 8 * (A.pt_host[p] + A.r_target[r] * A.N);
     const float deltaF = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
-    float jx = 0, jy = 0, cx = 0, cy = 0;
-    for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
-    for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)cdelta[i]; cy += J[O_C1 + i] * (float)cdelta[i]; }
-    const float Jpx = jx + cx + J[O_DD] * deltaF, Jpy = jy + cy + J[O_DD + 1] * deltaF;
+    const float Jpx = cml_jp_delta(J + O_XI0, dp, J + O_C0, cdelta, J[O_DD], deltaF, true);       // fixLinearization: the cast stays inside the dot
+    const float Jpy = cml_jp_delta(J + O_XI1, dp, J + O_C1, cdelta, J[O_DD + 1], deltaF, true);
     for (int i = 0; i < 8; i++) {
         float rtz = J[O_RES + i];
         rtz = rtz - J[O_JI0 + i] * Jpx;
@@ -395,10 +393,8 @@ __global__ __launch_bounds__(256) void k_ba_lin_energy(BAArgs A, const float* __
             n++;
             const float* J = (A.r_sel[r] ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
             const float* dp = adHTd + 8 * (A.pt_host[p] + A.r_target[r] * A.N);
-            float jx = 0, jy = 0, cx = 0, cy = 0;
-            for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
-            for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)cdelta[i]; cy += J[O_C1 + i] * (float)cdelta[i]; }
-            const float Jpx = jx + cx + J[O_DD] * dd, Jpy = jy + cy + J[O_DD + 1] * dd;
+            const float Jpx = cml_jp_delta(J + O_XI0, dp, J + O_C0, cdelta, J[O_DD], dd, false);
+            const float Jpy = cml_jp_delta(J + O_XI1, dp, J + O_C1, cdelta, J[O_DD + 1], dd, false);
             for (int i = 0; i < 8; i++) {
                 float Jdelta = J[O_JI0 + i] * Jpx;
                 Jdelta = Jdelta + J[O_JI1 + i] * Jpy;

@@ -229,6 +229,9 @@ void orc_eig_matmul3f(const float A[9], const float B[9], float out[9]);
 void orc_eig_matmul3d(const double A[9], const double B[9], double out[9]);
 void orc_eig_inverse3f(const float m[9], float o[9]);
 void orc_eig_inverse3d(const double m[9], double o[9]);
+float orc_eig_jp_delta(const float Jxi[6], const float dp[8], const float Jc[4], const double cdelta[4], float Jpdd, float dd, int cast_in_dot);
+double orc_eig_calib_dot(const double step[4], const float a[4], const float l[4]);
+double orc_eig_row8_dot_cast(const double xa[8], const float J[8]);
 
 /* ------------------------------------------------------------------ immature points: DSOTracer */
 /* DSOTracer::trace, DSOTracer.cpp:585-823: aos3 = level-0 gradient image of the traced frame (channel 0 = gray) */

@@ -418,12 +418,9 @@ static void add_to_hessian_top(orc_ba_window* w, int p, int mode, approx_acc* ac
              * double[8] (:1712) — undefined contents; this restates the evident intent (float rtz
              * widened to double).  Unreachable in the default flow: linearized residuals only exist
              * between tryMarginalize and marginalizePointsF, never inside solveSystem. */
-            float jdx = 0, jdy = 0;
-            for (int i = 0; i < 6; i++) { jdx += J[O_XI0 + i] * dp[i]; jdy += J[O_XI1 + i] * dp[i]; }
-            float cx = 0, cy = 0;
-            for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * dc[i]; cy += J[O_C1 + i] * dc[i]; }
-            float Jp_delta_x = jdx + cx + J[O_DD] * dd;
-            float Jp_delta_y = jdy + cy + J[O_DD + 1] * dd;
+            /* rJ.Jpdxi[k].dot(dp.head<6>()) + rJ.Jpdc[k].dot(dc) + rJ.Jpdd[k]*dd, Eigen's evaluation order (orc_eig_jp_delta) */
+            float Jp_delta_x = orc_eig_jp_delta(J + O_XI0, dp, J + O_C0, in->cdelta, J[O_DD], dd, 0);
+            float Jp_delta_y = orc_eig_jp_delta(J + O_XI1, dp, J + O_C1, in->cdelta, J[O_DD + 1], dd, 0);
             for (int i = 0; i < 8; i++) {
                 float rtz = w->res_toZeroF[8 * r + i];
                 rtz = rtz + J[O_JI0 + i] * Jp_delta_x;
@@ -697,17 +694,13 @@ int orc_ba_backsub(orc_ba_window* w, const cmlhip_ba_accum_in* in, const double*
         for (int k = w->by_point_off[p]; k < w->by_point_off[p + 1]; k++) if (w->r_good[w->by_point[k]]) ngood++;
         if (ngood == 0) { w->step[p] = 0; continue; }
         double b = (double)w->bdSumF[p];
-        double s = 0;
-        for (int i = 0; i < 4; i++) s += cstep[i] * ((double)w->Hcd_accAF[4 * p + i] + (double)w->Hcd_accLF[4 * p + i]);
-        b -= s;
+        b -= orc_eig_calib_dot(cstep, w->Hcd_accAF + 4 * p, w->Hcd_accLF + 4 * p);     /* :1470, Eigen's order */
         int host = w->points[p].host;
         for (int k = w->by_point_off[p]; k < w->by_point_off[p + 1]; k++) {
             int r = w->by_point[k];
             if (!w->r_good[r]) continue;
             const double* xa = xAd + 8 * (host * N + w->r_target[r]);
-            double d = 0;
-            for (int i = 0; i < 8; i++) d += xa[i] * (double)w->JpJdF[8 * r + i];
-            b -= d;
+            b -= orc_eig_row8_dot_cast(xa, w->JpJdF + 8 * r);                            /* :1478, Eigen's order */
         }
         w->step[p] = -b * (double)w->HdiF[p];
         if (!isfinite(w->step[p])) bad++;
@@ -895,10 +888,9 @@ void orc_ba_fix_linearization(orc_ba_window* w, int r, const cmlhip_ba_accum_in*
     const float* J = w->efsJ + 74 * (size_t)r;
     const float* dp = in->adHTdeltaF + 8 * w->pair_of[r];
     const float deltaF = (float)(pt->idepth - (double)pt->idepth_zero);
-    float jx = 0, jy = 0, cx = 0, cy = 0;
-    for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
-    for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)in->cdelta[i]; cy += J[O_C1 + i] * (float)in->cdelta[i]; }
-    const float Jp_delta_x = jx + cx + J[O_DD] * deltaF, Jp_delta_y = jy + cy + J[O_DD + 1] * deltaF;
+    /* J.Jpdxi[k].dot(dp.head<6>()) + J.Jpdc[k].dot(mCDeltaF.cast<float>()) + J.Jpdd[k] * deltaF: the cast stays inside the dot */
+    const float Jp_delta_x = orc_eig_jp_delta(J + O_XI0, dp, J + O_C0, in->cdelta, J[O_DD], deltaF, 1);
+    const float Jp_delta_y = orc_eig_jp_delta(J + O_XI1, dp, J + O_C1, in->cdelta, J[O_DD + 1], deltaF, 1);
     for (int i = 0; i < 8; i++) {
         float rtz = J[O_RES + i];
         rtz = rtz - J[O_JI0 + i] * Jp_delta_x;
@@ -1035,10 +1027,8 @@ double orc_ba_calc_l_energy(const orc_ba_window* w, const cmlhip_ba_accum_in* in
             num++;
             const float* J = w->efsJ + 74 * (size_t)r;
             const float* dp = in->adHTdeltaF + 8 * w->pair_of[r];
-            float jx = 0, jy = 0, cx = 0, cy = 0;
-            for (int i = 0; i < 6; i++) { jx += J[O_XI0 + i] * dp[i]; jy += J[O_XI1 + i] * dp[i]; }
-            for (int i = 0; i < 4; i++) { cx += J[O_C0 + i] * (float)in->cdelta[i]; cy += J[O_C1 + i] * (float)in->cdelta[i]; }
-            const float Jpx = jx + cx + J[O_DD] * dd, Jpy = jy + cy + J[O_DD + 1] * dd;
+            const float Jpx = orc_eig_jp_delta(J + O_XI0, dp, J + O_C0, in->cdelta, J[O_DD], dd, 0);      /* :2166-2172, Vector4f dc */
+            const float Jpy = orc_eig_jp_delta(J + O_XI1, dp, J + O_C1, in->cdelta, J[O_DD + 1], dd, 0);
             for (int i = 0; i < 8; i++) {
                 float Jdelta = J[O_JI0 + i] * Jpx;
                 Jdelta = Jdelta + J[O_JI1 + i] * Jpy;

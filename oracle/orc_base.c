@@ -120,6 +120,32 @@ void orc_eig_inverse3d(const double m[9], double o[9]) {
 }
 #undef EIG_COF
 
+/* Jp*delta of the linearised residuals: Vector6f.dot(Vector8f.head<6>()) + Vector4f.dot(.) + Jpdd * dd.  Eigen's SSE
+ * evaluation: the 6-dot is one packet product-sum plus a scalar tail, ((x0 + x2) + (x1 + x3)) + (x4 + x5); the 4-dot against a
+ * Vector4f is (c0 + c2) + (c1 + c3) (BA.cpp:1699-1700, 2166-2172: Vector4f dc = mCDeltaF.cast<float>()), against the
+ * un-evaluated cast expression it is not vectorised and reduces by halves, (c0 + c1) + (c2 + c3) (fixLinearization,
+ * BA.cpp:2219-2220: J.Jpdc[0].dot(mCDeltaF.cast<float>())). */
+float orc_eig_jp_delta(const float Jxi[6], const float dp[8], const float Jc[4], const double cdelta[4], float Jpdd, float dd, int cast_in_dot) {
+    float x[6], c[4];
+    for (int i = 0; i < 6; i++) x[i] = Jxi[i] * dp[i];
+    for (int i = 0; i < 4; i++) c[i] = Jc[i] * (float)cdelta[i];
+    const float d6 = ((x[0] + x[2]) + (x[1] + x[3])) + (x[4] + x[5]);
+    const float d4 = cast_in_dot ? (c[0] + c[1]) + (c[2] + c[3]) : (c[0] + c[2]) + (c[1] + c[3]);
+    return (d6 + d4) + Jpdd * dd;
+}
+/* mCalibStep.dot(Hcd_accAF.cast<double>() + Hcd_accLF.cast<double>()), BA.cpp:1470: cast expression, reduced by halves */
+double orc_eig_calib_dot(const double step[4], const float a[4], const float l[4]) {
+    double z[4];
+    for (int i = 0; i < 4; i++) z[i] = step[i] * ((double)a[i] + (double)l[i]);
+    return (z[0] + z[1]) + (z[2] + z[3]);
+}
+/* Matrix<double,1,8> * Vector8f.cast<double>(), BA.cpp:1478: reduced by halves */
+double orc_eig_row8_dot_cast(const double xa[8], const float J[8]) {
+    double z[8];
+    for (int i = 0; i < 8; i++) z[i] = xa[i] * (double)J[i];
+    return ((z[0] + z[1]) + (z[2] + z[3])) + ((z[4] + z[5]) + (z[6] + z[7]));
+}
+
 /* ============================================================ SE3 */
 
 static void q_normalize_approx(double q[4]) {

@@ -237,4 +237,23 @@ void ref_eig_krki(const double K[9], const double R[9], const double t[3], doubl
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) out[i * 3 + j] = hostToFrame_KRKi(i, j); kt[i] = hostToFrame_Kt[i]; }
 }
 
+/* Jp*delta of fixLinearization (BA.cpp:2219-2220) and of the LINEARIZED accumulation (BA.cpp:1699-1700):
+ *   J.Jpdxi[0].dot(dp.head<6>()) + J.Jpdc[0].dot(mCDeltaF.cast<float>()) + J.Jpdd[0] * deltaF      (cast_in_dot != 0)
+ *   rJ.Jpdxi[0].dot(dp.head<6>()) + rJ.Jpdc[0].dot(dc) + rJ.Jpdd[0] * dd,  Vector4f dc = mCDeltaF.cast<float>()  (cast_in_dot == 0) */
+float ref_eig_jp_delta(const float Jpdxi[6], const float dp8[8], const float Jpdc[4], const double cdelta[4], float Jpdd, float deltaF, int cast_in_dot) {
+    Eigen::Matrix<float, 6, 1> Jx; Eigen::Matrix<float, 8, 1> dp; Eigen::Matrix<float, 4, 1> Jc; Eigen::Matrix<double, 4, 1> mCDeltaF;
+    for (int i = 0; i < 6; i++) Jx[i] = Jpdxi[i];
+    for (int i = 0; i < 8; i++) dp[i] = dp8[i];
+    for (int i = 0; i < 4; i++) { Jc[i] = Jpdc[i]; mCDeltaF[i] = cdelta[i]; }
+    if (cast_in_dot) return Jx.dot(dp.head<6>()) + Jc.dot(mCDeltaF.cast<float>()) + Jpdd * deltaF;
+    Eigen::Matrix<float, 4, 1> dc = mCDeltaF.cast<float>();
+    return Jx.dot(dp.head<6>()) + Jc.dot(dc) + Jpdd * deltaF;
+}
+/* b -= mCalibStep.dot(Hcd_accAF.cast<scalar_t>() + Hcd_accLF.cast<scalar_t>())  (BA.cpp:1470) */
+double ref_eig_calib_dot(const double step[4], const float a[4], const float l[4]) {
+    Eigen::Matrix<double, 4, 1> mCalibStep; Eigen::Matrix<float, 4, 1> A, L;
+    for (int i = 0; i < 4; i++) { mCalibStep[i] = step[i]; A[i] = a[i]; L[i] = l[i]; }
+    return mCalibStep.dot(A.cast<double>() + L.cast<double>());
+}
+
 }  /* extern "C" */

@@ -122,5 +122,18 @@ out.update(eig_M3f=eM, eig_v3f=ev, eig_t3f=et, eig_s3f=es, eig_affine_plus=e_aff
            eig_B3f=eB, eig_matmul3f=e_mm3f, eig_inverse3f=e_inv3f, eig_K3f=eK, eig_inverseK3f=e_invK,
            eig_M3d=dM, eig_v3d=dv, eig_t3d=dt, eig_s3d=ds, eig_homog3d=d_hom, eig_matvec3d=d_mv, eig_B3d=dB, eig_matmul3d=d_mm,
            eig_matmul3d_cast=d_mmf, eig_inverse3d=d_inv, eig_krki=d_krki, eig_kt=d_kt)
+# ---- dot-product shapes of the linearised-residual algebra and of the back-substitution (BA.cpp:1470,1478,1699,2166,2219)
+R.ref_eig_jp_delta.restype = C.c_float; R.ref_eig_calib_dot.restype = C.c_double
+nd = 400
+jx = rng.normal(size=(nd, 6)).astype(np.float32); jdp = rng.normal(size=(nd, 8)).astype(np.float32); jc = rng.normal(size=(nd, 4)).astype(np.float32)
+jcd = rng.normal(size=(nd, 4)); jdd = rng.normal(size=nd).astype(np.float32); jde = rng.normal(size=nd).astype(np.float32)
+jp0 = np.zeros(nd, np.float32); jp1 = np.zeros(nd, np.float32)
+cst = rng.normal(size=(nd, 4)); ca = rng.normal(size=(nd, 4)).astype(np.float32); cl = rng.normal(size=(nd, 4)).astype(np.float32); cdot = np.zeros(nd)
+for i in range(nd):
+    jp0[i] = R.ref_eig_jp_delta(P(jx[i], f), P(jdp[i], f), P(jc[i], f), P(jcd[i], d), f(jdd[i]), f(jde[i]), 0)
+    jp1[i] = R.ref_eig_jp_delta(P(jx[i], f), P(jdp[i], f), P(jc[i], f), P(jcd[i], d), f(jdd[i]), f(jde[i]), 1)
+    cdot[i] = R.ref_eig_calib_dot(P(cst[i], d), P(ca[i], f), P(cl[i], f))
+out.update(jp_Jxi=jx, jp_dp=jdp, jp_Jc=jc, jp_cdelta=jcd, jp_Jpdd=jdd, jp_dd=jde, jp_delta_vec4f=jp0, jp_delta_cast=jp1,
+           calib_step=cst, calib_A=ca, calib_L=cl, calib_dot=cdot)
 np.savez_compressed(os.path.join(os.path.dirname(__file__), "thirdparty_vectors.npz"), **out)
 print("wrote", len(out), "arrays")

@@ -66,6 +66,15 @@ def test_eigen_expression_shapes_bitwise_against_golden():
         L.orc_eig_matmul3d(P(Kd, d), P(Md, d), P(KR, d)); L.orc_eig_inverse3d(P(Kd, d), P(Ki, d)); L.orc_eig_matmul3d(P(KR, d), P(Ki, d), P(out, d))
         L.orc_eig_matvec3d(P(Kd, d), P(td, d), P(kt, d))
         assert same64(out, G["eig_krki"][i]) and same64(kt, G["eig_kt"][i]), i            # K * R * K.inverse(), K * t (DSOTracer.cpp:606-607)
+    # dot-product shapes of the linearised-residual algebra and of the back-substitution (BA.cpp:1470, 1699, 2166, 2219)
+    L.orc_eig_jp_delta.restype = C.c_float; L.orc_eig_calib_dot.restype = C.c_double; L.orc_eig_row8_dot_cast.restype = C.c_double
+    for i in range(len(G["jp_Jxi"])):
+        a = (P(G["jp_Jxi"][i].copy(), f), P(G["jp_dp"][i].copy(), f), P(G["jp_Jc"][i].copy(), f), P(G["jp_cdelta"][i].copy(), d),
+             f(float(G["jp_Jpdd"][i])), f(float(G["jp_dd"][i])))
+        assert np.float32(L.orc_eig_jp_delta(*a, 0)) == G["jp_delta_vec4f"][i], i
+        assert np.float32(L.orc_eig_jp_delta(*a, 1)) == G["jp_delta_cast"][i], i
+        assert L.orc_eig_calib_dot(P(G["calib_step"][i].copy(), d), P(G["calib_A"][i].copy(), f), P(G["calib_L"][i].copy(), f)) == G["calib_dot"][i], i
+    assert (G["jp_delta_vec4f"] != G["jp_delta_cast"]).any()          # the two forms of the same formula really differ
     # the naive left-to-right sum is NOT what Eigen computes: the pin has teeth
     M = G["eig_M3f"]; v = G["eig_v3f"]; t = G["eig_t3f"]; s = G["eig_s3f"]
     naive = ((M[:, 0::3] * v[:, :1] + M[:, 1::3] * v[:, 1:2]) + M[:, 2::3] * v[:, 2:3]) + t * s[:, None]
