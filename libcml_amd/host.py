@@ -71,6 +71,14 @@ def lib():
         L.cmlhost_tracer_count.argtypes = [_vp]
         L.cmlhost_tracer_get_points.argtypes = [_vp, _vp, _P(_u8), _P(_u8), _P(_f)]
         L.cmlhost_tracer_last_error.restype = C.c_char_p; L.cmlhost_tracer_last_error.argtypes = [_vp]
+        L.cmlhost_pnp_optimize.argtypes = [_vp, _i, _P(_d), _P(_d), _vp, _vp, _P(_d), _i, _vp, _P(_u8), _i, _i, _P(_i), _P(_d), _P(_d), _P(_d)]
+        L.cmlhost_pnp_optimize_points.argtypes = [_vp, _i, _P(_d), _P(_d), _P(_d), _i, _vp, _P(_i), _P(_i), _i, _P(_i), _P(_d), _P(_d), _P(_d)]
+        L.cmlhost_lba_create.restype = _vp; L.cmlhost_lba_create.argtypes = [_vp]
+        L.cmlhost_lba_destroy.argtypes = [_vp]
+        L.cmlhost_lba_set_params.argtypes = [_vp, _i, _i, _i]
+        L.cmlhost_lba_local_optimize.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i]
+        L.cmlhost_lba_apply.argtypes = [_vp, _i, _vp, _i, _P(_d), _P(_i), _i, _P(abi.LbaResult)]
+        L.cmlhost_lba_last_error.restype = C.c_char_p; L.cmlhost_lba_last_error.argtypes = [_vp]
         _lib = L
     return _lib
 
@@ -342,3 +350,73 @@ def window_to_host_ba(ctx, W, image_id_base=1000, levels=1):
     for i in range(W.P):
         ba.add_point(W.pts["x"][i], W.pts["y"][i], W.pts["idepth"][i], W.pts["host"][i], colors[i], weights[i])
     return ba
+
+
+# ---- flat records of the IndirectCameraOptimizer / IndirectBundleAdjustment mirrors (libcml_amd/host/capi.cpp)
+HOST_MATCHING_DTYPE = np.dtype([("has_map_point", "<i4"), ("level", "<i4"), ("X", "<f8", (3,)), ("obs", "<f8", (2,)), ("scale_factor_base", "<f8"),
+                                ("descriptor_distance", "<f8")])
+HOST_LBA_FRAME_DTYPE = np.dtype([("id", "<i4"), ("pad", "<i4"), ("R", "<f8", (9,)), ("t", "<f8", (3,)), ("K", "<f8", (4,))])
+HOST_LBA_POINT_DTYPE = np.dtype([("id", "<i4"), ("reference_frame_id", "<i4"), ("X", "<f8", (3,))])
+HOST_LBA_APPARITION_DTYPE = np.dtype([("point", "<i4"), ("frame_id", "<i4"), ("obs", "<f8", (2,)), ("level", "<i4"), ("pad", "<i4"), ("scale_factor_base", "<f8")])
+
+
+class HostCameraOptimizer:
+    """cml_amd::IndirectCameraOptimizer (flat mirror of the reference's g2o pose optimiser)."""
+
+    def __init__(self, ctx, check_outliers=True):
+        self.ctx = ctx; self.L = lib(); self.check = bool(check_outliers)
+
+    def optimize(self, frameR, frameT, K, matchings, outliers, camera=None, compute_covariance=False):
+        """The Levenberg overload.  outliers: uint8 array (len(matchings) or any other length = "reset"), returns (isOk, R, t, cov, outliers)."""
+        m = np.ascontiguousarray(matchings, HOST_MATCHING_DTYPE); n = len(m)
+        fr = np.ascontiguousarray(frameR, np.float64); ft = np.ascontiguousarray(frameT, np.float64); Kd = np.ascontiguousarray(K, np.float64)
+        out = np.zeros(max(n, len(outliers), 1), np.uint8); out[:len(outliers)] = outliers
+        cr = ct = None
+        if camera is not None:
+            cr = np.ascontiguousarray(camera[0], np.float64); ct = np.ascontiguousarray(camera[1], np.float64)
+        ok = _i(0); R = np.zeros(9); t = np.zeros(3); cov = np.zeros(6)
+        rc = self.L.cmlhost_pnp_optimize(self.ctx.h, int(self.check), _p(fr, _d), _p(ft, _d), cr.ctypes.data if cr is not None else None,
+                                         ct.ctypes.data if ct is not None else None, _p(Kd, _d), n, m.ctypes.data, _p(out, _u8), len(outliers),
+                                         int(bool(compute_covariance)), C.byref(ok), _p(R, _d), _p(t, _d), _p(cov, _d))
+        if rc:
+            raise RuntimeError("cmlhost_pnp_optimize failed")
+        return bool(ok.value), R.reshape(3, 3), t, cov, out[:n].copy()
+
+    def optimize_points(self, frameR, frameT, K, points, compute_covariance=False):
+        """The Gauss-Newton overload; returns (isOk, R, t, cov, indices of the outlier points)."""
+        m = np.ascontiguousarray(points, HOST_MATCHING_DTYPE); n = len(m)
+        fr = np.ascontiguousarray(frameR, np.float64); ft = np.ascontiguousarray(frameT, np.float64); Kd = np.ascontiguousarray(K, np.float64)
+        idx = np.zeros(max(n, 1), np.int32); nidx = _i(0); ok = _i(0); R = np.zeros(9); t = np.zeros(3); cov = np.zeros(6)
+        rc = self.L.cmlhost_pnp_optimize_points(self.ctx.h, int(self.check), _p(fr, _d), _p(ft, _d), _p(Kd, _d), n, m.ctypes.data, _p(idx, _i), C.byref(nidx),
+                                                int(bool(compute_covariance)), C.byref(ok), _p(R, _d), _p(t, _d), _p(cov, _d))
+        if rc:
+            raise RuntimeError("cmlhost_pnp_optimize_points failed")
+        return bool(ok.value), R.reshape(3, 3), t, cov, idx[:nidx.value].copy()
+
+
+class HostLocalBA:
+    """cml_amd::IndirectBundleAdjustment (flat mirror of the reference's g2o local bundle adjustment)."""
+
+    def __init__(self, ctx, num_iteration=5, refine_iteration=0, remove_edge=True):
+        self.ctx = ctx; self.L = lib()
+        self.h = self.L.cmlhost_lba_create(ctx.h)
+        self.L.cmlhost_lba_set_params(self.h, int(num_iteration), int(refine_iteration), int(bool(remove_edge)))
+
+    def close(self):
+        if self.h:
+            self.L.cmlhost_lba_destroy(self.h); self.h = None
+
+    def local_optimize(self, local, fixed, points, apparitions, fix_frames):
+        self._nl, self._np = len(local), len(points)
+        lo = np.ascontiguousarray(local, HOST_LBA_FRAME_DTYPE); fx = np.ascontiguousarray(fixed, HOST_LBA_FRAME_DTYPE)
+        pt = np.ascontiguousarray(points, HOST_LBA_POINT_DTYPE); ap = np.ascontiguousarray(apparitions, HOST_LBA_APPARITION_DTYPE)
+        return bool(self.L.cmlhost_lba_local_optimize(self.h, len(lo), lo.ctypes.data, len(fx), fx.ctypes.data, len(pt), pt.ctypes.data, len(ap), ap.ctypes.data,
+                                                       int(bool(fix_frames))))
+
+    def last_error(self):
+        return self.L.cmlhost_lba_last_error(self.h).decode()
+
+    def apply(self, cap=1 << 20):
+        lo = np.zeros(self._nl, HOST_LBA_FRAME_DTYPE); X = np.zeros((self._np, 3)); rem = np.zeros(2 * cap, np.int32); res = abi.LbaResult()
+        n = self.L.cmlhost_lba_apply(self.h, self._nl, lo.ctypes.data, self._np, _p(X, _d), _p(rem, _i), cap, C.byref(res))
+        return lo, X, rem[:2 * min(n, cap)].reshape(-1, 2).copy(), res

@@ -5,6 +5,7 @@
 #include "DSOBundleAdjustment.h"
 #include "DSOTracker.h"
 #include "DSOTracer.h"
+#include "IndirectG2O.h"
 
 using namespace cml_amd;
 
@@ -206,5 +207,96 @@ void cmlhost_tracer_get_points(void* h, cmlhip_immature_point* out, unsigned cha
     for (size_t i = 0; i < P.size(); i++) { out[i] = P[i].d; alive[i] = P[i].alive; activated[i] = P[i].activated; idepth[i] = P[i].idepth; }
 }
 const char* cmlhost_tracer_last_error(void* h) { return static_cast<cml_amd::DSOTracer*>(h)->lastError().c_str(); }
+
+
+// ---- IndirectCameraOptimizer / IndirectBundleAdjustment mirrors (flat records for ctypes)
+struct cmlhost_matching { int has_map_point; int level; double X[3]; double obs[2]; double scale_factor_base; double descriptor_distance; };
+struct cmlhost_lba_frame { int id; int pad; double R[9], t[3], K[4]; };
+struct cmlhost_lba_point { int id; int reference_frame_id; double X[3]; };
+struct cmlhost_lba_apparition { int point; int frame_id; double obs[2]; int level; int pad; double scale_factor_base; };
+
+static std::vector<cml_amd::IndirectCameraOptimizer::Matching> to_matchings(int n, const cmlhost_matching* m) {
+    std::vector<cml_amd::IndirectCameraOptimizer::Matching> v((size_t)n);
+    for (int i = 0; i < n; i++) {
+        v[i].hasMapPoint = m[i].has_map_point != 0; v[i].level = m[i].level; v[i].scaleFactorBase = m[i].scale_factor_base;
+        v[i].descriptorDistance = m[i].descriptor_distance;
+        for (int k = 0; k < 3; k++) v[i].X[k] = m[i].X[k];
+        v[i].obs[0] = m[i].obs[0]; v[i].obs[1] = m[i].obs[1];
+    }
+    return v;
+}
+static void put_result(const cml_amd::IndirectCameraOptimizerResult& r, int* is_ok, double R[9], double t[3], double cov[6]) {
+    *is_ok = r.isOk ? 1 : 0;
+    for (int k = 0; k < 9; k++) R[k] = r.R[k];
+    for (int k = 0; k < 3; k++) t[k] = r.t[k];
+    for (int k = 0; k < 6; k++) cov[k] = r.covariance[k];
+}
+int cmlhost_pnp_optimize(cmlhip_ctx* ctx, int check_outliers, const double frameR[9], const double frameT[3], const double* cameraR, const double* cameraT,
+                         const double K[4], int n, const cmlhost_matching* m, unsigned char* outliers, int n_outliers_in, int compute_cov,
+                         int* is_ok, double R[9], double t[3], double cov[6]) {
+    cml_amd::IndirectCameraOptimizer opt(ctx);
+    opt.mCheckOutliers = check_outliers != 0;
+    std::vector<bool> out((size_t)n_outliers_in);
+    for (int i = 0; i < n_outliers_in; i++) out[i] = outliers[i] != 0;
+    const auto r = opt.optimize(frameR, frameT, cameraR, cameraT, K, to_matchings(n, m), out, compute_cov != 0);
+    for (int i = 0; i < n; i++) outliers[i] = out[i] ? 1 : 0;
+    put_result(r, is_ok, R, t, cov);
+    return opt.lastError().empty() ? 0 : 1;
+}
+int cmlhost_pnp_optimize_points(cmlhip_ctx* ctx, int check_outliers, const double frameR[9], const double frameT[3], const double K[4], int n,
+                                const cmlhost_matching* m, int* outlier_idx, int* n_outlier_idx, int compute_cov, int* is_ok, double R[9], double t[3], double cov[6]) {
+    cml_amd::IndirectCameraOptimizer opt(ctx);
+    opt.mCheckOutliers = check_outliers != 0;
+    std::vector<int> idx;
+    const auto r = opt.optimize(frameR, frameT, K, to_matchings(n, m), idx, compute_cov != 0);
+    for (size_t i = 0; i < idx.size(); i++) outlier_idx[i] = idx[i];
+    *n_outlier_idx = (int)idx.size();
+    put_result(r, is_ok, R, t, cov);
+    return opt.lastError().empty() ? 0 : 1;
+}
+void* cmlhost_lba_create(cmlhip_ctx* ctx) { return new cml_amd::IndirectBundleAdjustment(ctx); }
+void cmlhost_lba_destroy(void* h) { delete static_cast<cml_amd::IndirectBundleAdjustment*>(h); }
+void cmlhost_lba_set_params(void* h, int num_iteration, int refine_iteration, int remove_edge) {
+    auto* b = static_cast<cml_amd::IndirectBundleAdjustment*>(h);
+    b->mNumIteration = num_iteration; b->mRefineIteration = refine_iteration; b->mRemoveEdge = remove_edge != 0;
+}
+static std::vector<cml_amd::IndirectBundleAdjustment::Frame> to_frames(int n, const cmlhost_lba_frame* f) {
+    std::vector<cml_amd::IndirectBundleAdjustment::Frame> v((size_t)n);
+    for (int i = 0; i < n; i++) {
+        v[i].id = f[i].id;
+        for (int k = 0; k < 9; k++) v[i].R[k] = f[i].R[k];
+        for (int k = 0; k < 3; k++) v[i].t[k] = f[i].t[k];
+        for (int k = 0; k < 4; k++) v[i].K[k] = f[i].K[k];
+    }
+    return v;
+}
+int cmlhost_lba_local_optimize(void* h, int n_local, const cmlhost_lba_frame* local, int n_fixed, const cmlhost_lba_frame* fixed, int n_points,
+                               const cmlhost_lba_point* points, int n_app, const cmlhost_lba_apparition* app, int fix_frames) {
+    std::vector<cml_amd::IndirectBundleAdjustment::Point> P((size_t)n_points);
+    for (int i = 0; i < n_points; i++) { P[i].id = points[i].id; P[i].referenceFrameId = points[i].reference_frame_id; for (int k = 0; k < 3; k++) P[i].X[k] = points[i].X[k]; }
+    for (int a = 0; a < n_app; a++) {
+        cml_amd::IndirectBundleAdjustment::Apparition A;
+        A.frameId = app[a].frame_id; A.obs[0] = app[a].obs[0]; A.obs[1] = app[a].obs[1]; A.level = app[a].level; A.scaleFactorBase = app[a].scale_factor_base;
+        P[(size_t)app[a].point].apparitions.push_back(A);
+    }
+    return static_cast<cml_amd::IndirectBundleAdjustment*>(h)->localOptimize(to_frames(n_local, local), to_frames(n_fixed, fixed), P, fix_frames != 0) ? 1 : 0;
+}
+int cmlhost_lba_apply(void* h, int n_local, cmlhost_lba_frame* local_out, int n_points, double* X_out, int* removals, int cap, cmlhip_lba_result* res) {
+    std::vector<cml_amd::IndirectBundleAdjustment::Frame> F; std::vector<cml_amd::IndirectBundleAdjustment::Point> P;
+    std::vector<cml_amd::IndirectBundleAdjustment::Removal> Rm;
+    auto* b = static_cast<cml_amd::IndirectBundleAdjustment*>(h);
+    b->apply(F, P, Rm);
+    for (int i = 0; i < n_local && i < (int)F.size(); i++) {
+        local_out[i].id = F[i].id;
+        for (int k = 0; k < 9; k++) local_out[i].R[k] = F[i].R[k];
+        for (int k = 0; k < 3; k++) local_out[i].t[k] = F[i].t[k];
+        for (int k = 0; k < 4; k++) local_out[i].K[k] = F[i].K[k];
+    }
+    for (int i = 0; i < n_points && i < (int)P.size(); i++) for (int k = 0; k < 3; k++) X_out[3 * i + k] = P[i].X[k];
+    for (size_t i = 0; i < Rm.size() && (int)i < cap; i++) { removals[2 * i] = Rm[i].frameId; removals[2 * i + 1] = Rm[i].pointId; }
+    if (res) *res = b->result();
+    return (int)Rm.size();
+}
+const char* cmlhost_lba_last_error(void* h) { return static_cast<cml_amd::IndirectBundleAdjustment*>(h)->lastError().c_str(); }
 
 }  // extern "C"
