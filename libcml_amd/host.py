@@ -79,6 +79,14 @@ def lib():
         L.cmlhost_lba_local_optimize.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i]
         L.cmlhost_lba_apply.argtypes = [_vp, _i, _vp, _i, _P(_d), _P(_i), _i, _P(abi.LbaResult)]
         L.cmlhost_lba_last_error.restype = C.c_char_p; L.cmlhost_lba_last_error.argtypes = [_vp]
+        L.cmlhost_init_create.restype = _vp; L.cmlhost_init_create.argtypes = [_vp]
+        L.cmlhost_init_destroy.argtypes = [_vp]
+        L.cmlhost_init_set_first.argtypes = [_vp, _i, _P(_i), _P(_i), _P(_d), _P(_vp), _P(_i), _P(_i), _P(_i), _P(_d), _d]
+        L.cmlhost_init_try.argtypes = [_vp, C.c_uint64, _P(_d), _d]
+        L.cmlhost_init_state.argtypes = [_vp, _P(_d), _P(_i), _P(_i), _P(_i), _P(_f)]
+        L.cmlhost_init_level_size.argtypes = [_vp, _i]
+        L.cmlhost_init_get_points.argtypes = [_vp, _i, _P(_f), _P(_f), _P(_f), _P(_u8), _P(_f), _P(_i), _P(_i)]
+        L.cmlhost_init_last_error.restype = C.c_char_p; L.cmlhost_init_last_error.argtypes = [_vp]
         _lib = L
     return _lib
 
@@ -420,3 +428,48 @@ class HostLocalBA:
         lo = np.zeros(self._nl, HOST_LBA_FRAME_DTYPE); X = np.zeros((self._np, 3)); rem = np.zeros(2 * cap, np.int32); res = abi.LbaResult()
         n = self.L.cmlhost_lba_apply(self.h, self._nl, lo.ctypes.data, self._np, _p(X, _d), _p(rem, _i), cap, C.byref(res))
         return lo, X, rem[:2 * min(n, cap)].reshape(-1, 2).copy(), res
+
+
+class HostInitializer:
+    """cml_amd::DSOInitializer (flat mirror of the reference's coarse initializer; calcResAndGS runs on the device)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx; self.L = lib()
+        self.h = self.L.cmlhost_init_create(ctx.h)
+
+    def close(self):
+        if self.h:
+            self.L.cmlhost_init_destroy(self.h); self.h = None
+
+    def set_first(self, grays, Ks, pixels, ref_qt, ref_exposure=1.0):
+        """grays: per level float32 (h, w); Ks: per level (fx, fy, cx, cy); pixels: per level (x int array, y int array) in raster order."""
+        n = len(grays)
+        self._keep = [np.ascontiguousarray(g, np.float32) for g in grays]
+        w = np.array([g.shape[1] for g in self._keep], np.int32); h = np.array([g.shape[0] for g in self._keep], np.int32)
+        K4 = np.ascontiguousarray(np.array(Ks, np.float64).reshape(n, 4))
+        ptrs = (_vp * n)(*[g.ctypes.data for g in self._keep])
+        npx = np.array([len(p[0]) for p in pixels], np.int32)
+        px = np.ascontiguousarray(np.concatenate([np.asarray(p[0], np.int32) for p in pixels])); py = np.ascontiguousarray(np.concatenate([np.asarray(p[1], np.int32) for p in pixels]))
+        qt = np.ascontiguousarray(ref_qt, np.float64)
+        ok = self.L.cmlhost_init_set_first(self.h, n, _p(w, _i), _p(h, _i), _p(K4, _d), ptrs, _p(npx, _i), _p(px, _i), _p(py, _i), _p(qt, _d), float(ref_exposure))
+        self.n_levels = n
+        return bool(ok)
+
+    def try_initialize(self, image_id, frame_qt, exposure=1.0):
+        qt = np.ascontiguousarray(frame_qt, np.float64)
+        return self.L.cmlhost_init_try(self.h, int(image_id), _p(qt, _d), float(exposure))
+
+    def state(self):
+        qt = np.zeros(7); sn = _i(0); fid = _i(0); cnt = np.zeros(3, np.int32); rs = _f(0)
+        self.L.cmlhost_init_state(self.h, _p(qt, _d), C.byref(sn), C.byref(fid), _p(cnt, _i), C.byref(rs))
+        return dict(qt=qt, snapped=bool(sn.value), frame_id=fid.value, calc_calls=int(cnt[0]), accepted=int(cnt[1]), rejected=int(cnt[2]), rescale=rs.value)
+
+    def points(self, lvl):
+        n = self.L.cmlhost_init_level_size(self.h, lvl)
+        xy = np.zeros((n, 2), np.float32); iR = np.zeros(n, np.float32); idp = np.zeros(n, np.float32); good = np.zeros(n, np.uint8)
+        lh = np.zeros(n, np.float32); par = np.zeros(n, np.int32); nb = np.zeros((n, 10), np.int32)
+        self.L.cmlhost_init_get_points(self.h, lvl, _p(xy, _f), _p(iR, _f), _p(idp, _f), _p(good, _u8), _p(lh, _f), _p(par, _i), _p(nb, _i))
+        return dict(xy=xy, iR=iR, idepth=idp, good=good, last_hessian=lh, parent=par, neighbours=nb)
+
+    def last_error(self):
+        return self.L.cmlhost_init_last_error(self.h).decode()

@@ -6,6 +6,7 @@
 #include "DSOTracker.h"
 #include "DSOTracer.h"
 #include "IndirectG2O.h"
+#include "DSOInitializer.h"
 
 using namespace cml_amd;
 
@@ -298,5 +299,45 @@ int cmlhost_lba_apply(void* h, int n_local, cmlhost_lba_frame* local_out, int n_
     return (int)Rm.size();
 }
 const char* cmlhost_lba_last_error(void* h) { return static_cast<cml_amd::IndirectBundleAdjustment*>(h)->lastError().c_str(); }
+
+
+// ---- DSOInitializer mirror
+static cml_amd::SE3 se3_from_qt(const double qt[7]) { cml_amd::SE3 T; for (int k = 0; k < 4; k++) T.q[k] = qt[k]; for (int k = 0; k < 3; k++) T.t[k] = qt[4 + k]; return T; }
+void* cmlhost_init_create(cmlhip_ctx* ctx) { return new cml_amd::DSOInitializer(ctx); }
+void cmlhost_init_destroy(void* h) { delete static_cast<cml_amd::DSOInitializer*>(h); }
+int cmlhost_init_set_first(void* h, int n_levels, const int* w, const int* hgt, const double* K4, const float* const* gray, const int* n_px,
+                           const int* px, const int* py, const double ref_qt[7], double ref_exposure) {
+    std::vector<cml_amd::DSOInitializer::LevelInput> L((size_t)n_levels);
+    size_t at = 0;
+    for (int l = 0; l < n_levels; l++) {
+        L[l].w = w[l]; L[l].h = hgt[l]; for (int k = 0; k < 4; k++) L[l].K[k] = K4[4 * l + k];
+        L[l].gray = gray[l];
+        L[l].px.assign(px + at, px + at + n_px[l]); L[l].py.assign(py + at, py + at + n_px[l]);
+        at += (size_t)n_px[l];
+    }
+    return static_cast<cml_amd::DSOInitializer*>(h)->setFirst(L, se3_from_qt(ref_qt), ref_exposure) ? 1 : 0;
+}
+int cmlhost_init_try(void* h, uint64_t image_id, const double frame_qt[7], double exposure) {
+    return static_cast<cml_amd::DSOInitializer*>(h)->tryInitialize(image_id, se3_from_qt(frame_qt), exposure);
+}
+void cmlhost_init_state(void* h, double cur_qt[7], int* snapped, int* frame_id, int counts[3], float* rescale) {
+    auto* I = static_cast<cml_amd::DSOInitializer*>(h);
+    const cml_amd::SE3& T = I->currentCamera();
+    for (int k = 0; k < 4; k++) cur_qt[k] = T.q[k];
+    for (int k = 0; k < 3; k++) cur_qt[4 + k] = T.t[k];
+    *snapped = I->snapped() ? 1 : 0; *frame_id = I->frameID();
+    counts[0] = I->numCalcCalls; counts[1] = I->numAccepted; counts[2] = I->numRejected;
+    *rescale = I->rescaleFactor();
+}
+int cmlhost_init_level_size(void* h, int lvl) { return (int)static_cast<cml_amd::DSOInitializer*>(h)->points(lvl).size(); }
+void cmlhost_init_get_points(void* h, int lvl, float* xy, float* iR, float* idepth, unsigned char* good, float* last_hessian, int* parent, int* neighbours) {
+    const auto& P = static_cast<cml_amd::DSOInitializer*>(h)->points(lvl);
+    for (size_t i = 0; i < P.size(); i++) {
+        xy[2 * i] = P[i].px; xy[2 * i + 1] = P[i].py; iR[i] = P[i].d.iR; idepth[i] = P[i].idepth; good[i] = P[i].d.is_good ? 1 : 0;
+        last_hessian[i] = P[i].lastHessian; parent[i] = P[i].parent;
+        for (int k = 0; k < 10; k++) neighbours[10 * i + k] = P[i].neighbours[k];
+    }
+}
+const char* cmlhost_init_last_error(void* h) { return static_cast<cml_amd::DSOInitializer*>(h)->lastError().c_str(); }
 
 }  // extern "C"
