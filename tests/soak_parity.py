@@ -1,0 +1,120 @@
+"""(kept under tests/: it runs the oracle beside the device)
+Seed sweep of the bit-exact parity claims: BA residual records / states / energies, tracker warped buffer, immature-point
+trace + activation, initializer per-point outputs, structure-only local BA — each over many synthetic scenes.
+Usage: python tests/soak_parity.py [n_seeds]   (prints one line per family; exits non-zero on the first mismatch)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from libcml_amd import abi, device, synth
+from tests import ba_setup as S
+from tests import dev_setup as D
+from tests import initializer_setup as IS
+from tests import lba_setup as LS
+from tests import oracle_lib as O
+from tests import tracer_setup as TS
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+
+
+def same(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.dtype.kind == "f":
+        u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+        bad = a.view(u) != b.view(u)
+        bad &= ~(np.isnan(a) & np.isnan(b))
+        return not bad.any()
+    return np.array_equal(a, b)
+
+
+def ba(seed):
+    I = S.make_inputs("small", seed=seed)
+    ob = S.OracleBA(I); ctx = D.make_ctx(I)
+    try:
+        for it in range(2):                                   # two passes: the second one runs on states written by applyRes
+            ro = ob.linearize(); rd = ctx.ba_linearize()
+            so, sd = ob.states(), ctx.ba_states()
+            IN = so["new_state"] == 0
+            ok = same(so["new_state"], sd["new_state"]) and same(so["state"], sd["state"]) and same(so["new_energy_wo"], sd["new_energy_wo"])
+            ok = ok and same(so["new_energy"][IN], sd["new_energy"][IN]) and same(ob.rJ(0)[IN], ctx.ba_rj(0)[IN])
+            ok = ok and (ro.n_in, ro.n_oob, ro.n_outlier) == (rd.n_in, rd.n_oob, rd.n_outlier)
+            ok = ok and np.float32(ro.new_frame_energy_th).view(np.uint32) == np.float32(rd.new_frame_energy_th).view(np.uint32)
+            if not ok:
+                return False, int(IN.sum())
+            ob.apply(True); ctx.ba_apply(True)
+        return True, int(IN.sum())
+    finally:
+        ctx.close()
+
+
+def tracer(seed):
+    W = synth.make_window("small", seed=seed, eval_noise=0.0, idepth_noise=0.0, state_noise=0.0)
+    grads0 = [O.build_pyramid(W.gray[k], 1)[1][0] for k in range(W.N)]
+    ctx = device.Ctx(max_frames=W.N)
+    try:
+        ids = [900 + k for k in range(W.N)]
+        for k in range(W.N):
+            ctx.pyramid_put(ids[k], 0, grads0[k])
+        prm = abi.default_tracer_params()
+        pts = TS.make_immature(W, grads0)
+        cur_o = pts.copy(); cur_d = pts.copy()
+        for f in range(1, W.N):
+            sel = np.flatnonzero(pts["host"] < f)
+            pr = TS.trace_pairs(W, f)
+            o = TS.oracle_trace(grads0[f], pr, prm, cur_o[sel]); d = ctx.trace_points(ids[f], prm, pr, cur_d[sel])
+            for name in ("last_status", "idepth_min", "idepth_max", "quality", "last_uv", "last_pixel_interval"):
+                if not same(o[name], d[name]):
+                    return False, f
+            cur_o[sel] = o; cur_d[sel] = d
+        cand = cur_o[np.isfinite(cur_o["idepth_max"]) & (cur_o["last_status"] != abi.IPS_OOB)]
+        apr = TS.activation_pairs(W)
+        ro, io, so = TS.oracle_optimize(grads0, W.K, apr, prm, 1, cand)
+        rd, idd, sd = ctx.optimize_immature_points(ids, W.K, apr, prm, 1, cand)
+        return bool(np.array_equal(ro, rd) and same(io, idd) and np.array_equal(so[ro == 1], sd[rd == 1])), len(cand)
+    finally:
+        ctx.close()
+
+
+def initializer(seed):
+    rng = np.random.default_rng(seed)
+    level = int(rng.integers(0, 3))
+    W, g0, g1, R, t, ratio, tlog = IS.scene(level=level, trans_scale=float(rng.choice([1.0, 1e-3, 0.3])))
+    pts = IS.make_points(g0, step=int(rng.integers(2, 6)), seed=seed)
+    prm = IS.make_params(W.K, level, R, t, ratio, tlog)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        ctx.pyramid_put(77, level, g1)
+        d = pts.copy()
+        ctx.initializer_calc_res_and_gs(77, level, prm, d)
+    finally:
+        ctx.close()
+    o = IS.oracle_calc(g1, prm, pts)[0]
+    return all(same(o[f], d[f]) for f in ("is_good", "is_good_new", "energy_new", "maxstep", "last_hessian_new", "jb")), len(pts)
+
+
+def lba(seed):
+    rng = np.random.default_rng(seed)
+    Sx = LS.scene(n_points=int(rng.integers(100, 1500)), seed=seed, point_noise=float(rng.uniform(0, 0.2)), outlier_fraction=float(rng.uniform(0, 0.2)))
+    it, rf = int(rng.integers(1, 7)), int(rng.integers(0, 4))
+    _, pts_o, bad_o, _ = LS.oracle_lba(Sx["frames"], Sx["points"], Sx["off"], Sx["edges"], True, it, rf)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        pts = Sx["points"].copy()
+        bad, _ = ctx.lba_optimize(Sx["frames"].copy(), pts, Sx["off"], Sx["edges"], True, it, rf)
+    finally:
+        ctx.close()
+    return same(pts, pts_o) and np.array_equal(bad, bad_o), len(pts)
+
+
+fail = 0
+for name, fn in (("BA linearize/apply records", ba), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba)):
+    n_ok, units = 0, 0
+    for s in range(n_seeds):
+        ok, u = fn(1000 + 17 * s)
+        n_ok += bool(ok); units += u
+        if not ok:
+            print("MISMATCH %s seed %d" % (name, 1000 + 17 * s)); fail = 1
+    print("%-30s %d / %d seeds bit-exact (%d units compared)" % (name, n_ok, n_seeds, units))
+sys.exit(fail)
