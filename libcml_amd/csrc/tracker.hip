@@ -170,15 +170,40 @@ __global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ makeCoarseDepthL0
-__global__ void k_cd_splat(const double* __restrict__ pts, int n, int w0, int h0, float* idepth, float* wsum) {   // TR.cpp:538-551
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double Ku = pts[4 * (size_t)i], Kv = pts[4 * (size_t)i + 1], nid = pts[4 * (size_t)i + 2];
-    const float weight = (float)pts[4 * (size_t)i + 3];
-    const int u = (int)(Ku + 0.5), v = (int)(Kv + 0.5);
-    if (u < 0 || u >= w0 || v < 0 || v >= h0) return;
-    atomicAdd(&idepth[u + w0 * v], (float)(nid * (double)weight));
-    atomicAdd(&wsum[u + w0 * v], weight);
+// One wave, points in list order: `idepth(u + w0 v) += new_idepth * weight; weightSum += weight` is a sequential float
+// accumulation in the reference, and two points do land on one pixel now and then, so float atomics in arrival order would
+// differ from it in the last bit (and from run to run).  Per chunk of 64 points the first lane of every pixel folds the later
+// lanes of the same pixel in lane order and writes once; chunks follow each other in the same wave.  Once per keyframe.
+__global__ __launch_bounds__(64) void k_cd_splat(const double* __restrict__ pts, int n, int w0, int h0, float* idepth, float* wsum) {   // TR.cpp:538-551
+    const int l = threadIdx.x;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + l;
+        const bool in = i < n;
+        const size_t ii = in ? (size_t)i : 0;
+        const double Ku = pts[4 * ii], Kv = pts[4 * ii + 1], nid = pts[4 * ii + 2];
+        const float weight = (float)pts[4 * ii + 3];
+        const int u = (int)(Ku + 0.5), v = (int)(Kv + 0.5);
+        const bool valid = in && !(u < 0 || u >= w0 || v < 0 || v >= h0);
+        const int pix = valid ? u + w0 * v : -1 - l;                 // unique negative = takes part in nothing
+        const double x = nid * (double)weight;
+        bool first = true;
+        for (int k = 0; k < 64; k++) { const int pk = __shfl(pix, k); if (k < l && pk == pix) first = false; }
+        float acc_id = 0.f, acc_w = 0.f;
+        if (valid && first) {
+            acc_id = __hip_atomic_load(&idepth[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc_w = __hip_atomic_load(&wsum[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc_id = (float)((double)acc_id + x); acc_w += weight;   // this lane's own contribution
+        }
+        for (int k = 1; k < 64; k++) {                               // later lanes of the same pixel, in order
+            const int pk = __shfl(pix, k); const double xk = __shfl(x, k); const float wk = __shfl(weight, k);
+            if (valid && first && k > l && pk == pix) { acc_id = (float)((double)acc_id + xk); acc_w += wk; }
+        }
+        if (valid && first) {
+            __hip_atomic_store(&idepth[pix], acc_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&wsum[pix], acc_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+    }
 }
 __global__ void k_cd_down(const float* __restrict__ idm, const float* __restrict__ wm, int wm1, int wl, int hl,
                           float* __restrict__ idl, float* __restrict__ wsl) {                                      // TR.cpp:571-584
@@ -416,7 +441,7 @@ int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int l
     if (n > 0) {
         if ((rc = cml_ensure(c, dpts, 32 * (size_t)n))) return rc;
         if ((rc = cml_h2d(c, dpts.p, pts, 32 * (size_t)n))) { cml_free(dpts); return rc; }
-        k_cd_splat<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, c->cd_idepth[0].as<float>(),
+        k_cd_splat<<<1, 64, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, c->cd_idepth[0].as<float>(),
                                                               c->cd_wsum[0].as<float>());
     }
     for (int l = 1; l < levels; l++) {

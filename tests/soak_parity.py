@@ -15,6 +15,7 @@ from tests import initializer_setup as IS
 from tests import lba_setup as LS
 from tests import oracle_lib as O
 from tests import tracer_setup as TS
+from tests import trk_setup as T
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 
@@ -45,6 +46,40 @@ def ba(seed):
                 return False, int(IN.sum())
             ob.apply(True); ctx.ba_apply(True)
         return True, int(IN.sum())
+    finally:
+        ctx.close()
+
+
+def tracker(seed):
+    """warped buffer of computeResidual (bit-exact) + pyramid texels + coarse-depth lists at every level"""
+    sc = T.make_scene("small", seed=seed)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        ctx.pyramid_build(1, sc.W.gray[sc.ref], sc.levels); ctx.pyramid_build(2, sc.W.gray[sc.new], sc.levels)
+        for l in range(sc.levels):
+            if not same(ctx.pyramid_get(2, l), sc.grads[sc.new][l]):
+                return False, l
+        lists, n_orc = T.oracle_coarse_depth(sc)
+        n_dev = ctx.tracker_make_coarse_depth(1, sc.levels, sc.cd_pts)
+        if list(n_dev) != list(n_orc):
+            return False, -1
+        prm = abi.default_tracker_params()
+        units = 0
+        for level in range(sc.levels):
+            uvic = lists[level][:n_orc[level]]
+            ud = ctx.tracker_get_reference(level)
+            if not same(ud, uvic):
+                return False, level
+            R, t, K, aff, b0 = T.tracker_inputs(sc, level)
+            out_d, rc = ctx.tracker_eval(2, level, R, t, K, aff, b0, prm, 1)
+            out_o, warped_o = T.oracle_tracker_eval(sc, level, uvic, R, t, K, aff, b0, prm)
+            wd, n = ctx.tracker_get_warped(len(uvic) + 4)
+            if n != out_o.numWarped or not same(wd, warped_o[:, :n]):
+                return False, level
+            if (out_d.numTermsInE, out_d.numSaturated, out_d.numRobust) != (out_o.numTermsInE, out_o.numSaturated, out_o.numRobust):
+                return False, level
+            units += n
+        return True, units
     finally:
         ctx.close()
 
@@ -109,7 +144,7 @@ def lba(seed):
 
 
 fail = 0
-for name, fn in (("BA linearize/apply records", ba), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba)):
+for name, fn in (("BA linearize/apply records", ba), ("tracker pyramid/lists/warped", tracker), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba)):
     n_ok, units = 0, 0
     for s in range(n_seeds):
         ok, u = fn(1000 + 17 * s)
