@@ -50,6 +50,29 @@ def ba(seed):
         ctx.close()
 
 
+def marginalisation(seed):
+    """tryMarginalize's residual loop: states, energies, the fixed linearisation res_toZero (bit-exact)"""
+    rng = np.random.default_rng(seed)
+    I = S.make_inputs("small", seed=seed, state_noise=float(rng.uniform(0.05, 0.5)))
+    ob = S.OracleBA(I); ctx = D.make_ctx(I)
+    try:
+        ob.linearize(); ctx.ba_linearize(); ob.apply(1); ctx.ba_apply(1)
+        ain = (I.adH, I.adT, I.adHTd, I.cdelta, I.prior, I.dprior, I.cprior)
+        sel = np.arange(int(rng.integers(0, 3)), I.P, int(rng.integers(2, 5)), dtype=np.int32)
+        ngo = ob.relinearize_points(sel); ngd = ctx.ba_relinearize_points(sel, *ain)
+        so, sd = ob.states(), ctx.ba_states()
+        ok = ngo == ngd and all(np.array_equal(so[k], sd[k]) for k in ("state", "new_state", "good")) and same(so["energy"], sd["energy"])
+        rtz_o = ob.view("res_toZeroF", 8 * I.R, np.float32).reshape(-1, 8).copy(); lin_o = ob.view("r_lin", I.R, np.uint8).copy()
+        rtz_d, lin_d = ctx.ba_res_to_zero()
+        L = lin_o == 1
+        ok = ok and np.array_equal(lin_o, lin_d) and same(rtz_o[L], rtz_d[L])
+        g = so["good"] == 1
+        ok = ok and same(ob.rJ(1)[g], ctx.ba_rj(1)[g])
+        return bool(ok), int(L.sum())
+    finally:
+        ctx.close()
+
+
 def tracker(seed):
     """warped buffer of computeResidual (bit-exact) + pyramid texels + coarse-depth lists at every level"""
     sc = T.make_scene("small", seed=seed)
@@ -144,7 +167,7 @@ def lba(seed):
 
 
 fail = 0
-for name, fn in (("BA linearize/apply records", ba), ("tracker pyramid/lists/warped", tracker), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba)):
+for name, fn in (("BA linearize/apply records", ba), ("marginalisation res_toZero", marginalisation), ("tracker pyramid/lists/warped", tracker), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba)):
     n_ok, units = 0, 0
     for s in range(n_seeds):
         ok, u = fn(1000 + 17 * s)
