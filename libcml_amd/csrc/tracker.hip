@@ -170,39 +170,51 @@ __global__ __launch_bounds__(256) void k_tracker_eval(TrkArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ makeCoarseDepthL0
-// One wave, points in list order: `idepth(u + w0 v) += new_idepth * weight; weightSum += weight` is a sequential float
-// accumulation in the reference, and two points do land on one pixel now and then, so float atomics in arrival order would
-// differ from it in the last bit (and from run to run).  Per chunk of 64 points the first lane of every pixel folds the later
-// lanes of the same pixel in lane order and writes once; chunks follow each other in the same wave.  Once per keyframe.
-__global__ __launch_bounds__(64) void k_cd_splat(const double* __restrict__ pts, int n, int w0, int h0, float* idepth, float* wsum) {   // TR.cpp:538-551
-    const int l = threadIdx.x;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + l;
-        const bool in = i < n;
-        const size_t ii = in ? (size_t)i : 0;
-        const double Ku = pts[4 * ii], Kv = pts[4 * ii + 1], nid = pts[4 * ii + 2];
-        const float weight = (float)pts[4 * ii + 3];
-        const int u = (int)(Ku + 0.5), v = (int)(Kv + 0.5);
-        const bool valid = in && !(u < 0 || u >= w0 || v < 0 || v >= h0);
-        const int pix = valid ? u + w0 * v : -1 - l;                 // unique negative = takes part in nothing
-        const double x = nid * (double)weight;
-        bool first = true;
-        for (int k = 0; k < 64; k++) { const int pk = __shfl(pix, k); if (k < l && pk == pix) first = false; }
-        float acc_id = 0.f, acc_w = 0.f;
-        if (valid && first) {
-            acc_id = __hip_atomic_load(&idepth[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc_w = __hip_atomic_load(&wsum[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc_id = (float)((double)acc_id + x); acc_w += weight;   // this lane's own contribution
-        }
-        for (int k = 1; k < 64; k++) {                               // later lanes of the same pixel, in order
-            const int pk = __shfl(pix, k); const double xk = __shfl(x, k); const float wk = __shfl(weight, k);
-            if (valid && first && k > l && pk == pix) { acc_id = (float)((double)acc_id + xk); acc_w += wk; }
-        }
-        if (valid && first) {
-            __hip_atomic_store(&idepth[pix], acc_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&wsum[pix], acc_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __threadfence();
+// `idepth(u + w0 v) += new_idepth * weight; weightSum += weight` is a sequential float accumulation over the points in the
+// reference, and two points do land on one pixel now and then: float atomics in arrival order would differ from it in the last
+// bit (and from run to run).  Three small launches keep the list order exactly: the lowest point index of every pixel
+// (atomicMin on an int map), the plain store of those first points, and one thread that applies the few later points of
+// shared pixels in index order.
+struct CdPoint { int u, v; double x; float weight; bool valid; };
+__device__ __forceinline__ CdPoint cd_point(const double* __restrict__ pts, int i, int w0, int h0) {     // TR.cpp:538-548
+    CdPoint p;
+    const double Ku = pts[4 * (size_t)i], Kv = pts[4 * (size_t)i + 1], nid = pts[4 * (size_t)i + 2];
+    p.weight = (float)pts[4 * (size_t)i + 3];
+    p.u = (int)(Ku + 0.5); p.v = (int)(Kv + 0.5);
+    p.valid = !(p.u < 0 || p.u >= w0 || p.v < 0 || p.v >= h0);
+    p.x = nid * (double)p.weight;
+    return p;
+}
+__global__ void k_cd_owner(const double* __restrict__ pts, int n, int w0, int h0, int* owner) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CdPoint p = cd_point(pts, i, w0, h0);
+    if (p.valid) atomicMin(&owner[p.u + w0 * p.v], i);
+}
+__global__ void k_cd_splat(const double* __restrict__ pts, int n, int w0, int h0, const int* __restrict__ owner, float* idepth, float* wsum,
+                           int* late, int* n_late) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CdPoint p = cd_point(pts, i, w0, h0);
+    if (!p.valid) return;
+    const int pix = p.u + w0 * p.v;
+    if (owner[pix] == i) { idepth[pix] = (float)((double)0.0f + p.x); wsum[pix] = 0.0f + p.weight; }     // the maps start at zero
+    else late[atomicAdd(n_late, 1)] = i;
+}
+__global__ void k_cd_late(const double* __restrict__ pts, int w0, int h0, float* idepth, float* wsum, int* late, const int* n_late) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int m = *n_late;
+    for (int a = 1; a < m; a++) {                                     // insertion sort: a handful of entries
+        const int key = late[a];
+        int b = a - 1;
+        while (b >= 0 && late[b] > key) { late[b + 1] = late[b]; b--; }
+        late[b + 1] = key;
+    }
+    for (int a = 0; a < m; a++) {
+        const CdPoint p = cd_point(pts, late[a], w0, h0);
+        const int pix = p.u + w0 * p.v;
+        idepth[pix] = (float)((double)idepth[pix] + p.x);
+        wsum[pix] += p.weight;
     }
 }
 __global__ void k_cd_down(const float* __restrict__ idm, const float* __restrict__ wm, int wm1, int wl, int hl,
@@ -439,10 +451,18 @@ int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int l
     if ((rc = cml_ensure(c, c->cd_cnt, 4 * (size_t)(maxblocks + 16)))) return rc;
     DevBuf dpts;
     if (n > 0) {
-        if ((rc = cml_ensure(c, dpts, 32 * (size_t)n))) return rc;
+        if ((rc = cml_ensure(c, dpts, 32 * (size_t)n + 4 * ((size_t)n + 4)))) return rc;
         if ((rc = cml_h2d(c, dpts.p, pts, 32 * (size_t)n))) { cml_free(dpts); return rc; }
-        k_cd_splat<<<1, 64, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, c->cd_idepth[0].as<float>(),
-                                                              c->cd_wsum[0].as<float>());
+        int* late = reinterpret_cast<int*>(dpts.as<char>() + 32 * (size_t)n);
+        int* n_late = late + n;
+        int* owner = c->cd_wbak[0].as<int>();                           // free until the dilation backs the weights up into it
+        const size_t sz0 = (size_t)py->lv[0].w * py->lv[0].h;
+        CML_CHECK(c, hipMemsetAsync(owner, 0x7f, 4 * sz0, c->stream));
+        CML_CHECK(c, hipMemsetAsync(n_late, 0, 4, c->stream));
+        k_cd_owner<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner);
+        k_cd_splat<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner, c->cd_idepth[0].as<float>(),
+                                                              c->cd_wsum[0].as<float>(), late, n_late);
+        k_cd_late<<<1, 64, 0, c->stream>>>(dpts.as<double>(), py->lv[0].w, py->lv[0].h, c->cd_idepth[0].as<float>(), c->cd_wsum[0].as<float>(), late, n_late);
     }
     for (int l = 1; l < levels; l++) {
         dim3 g(cml_div_up(py->lv[l].w, 256), py->lv[l].h);

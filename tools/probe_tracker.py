@@ -16,8 +16,11 @@ for i in range(W.P):
     Rht = W.R_eval[ref] @ W.R_eval[h].T; tht = W.t_eval[ref] - Rht @ W.t_eval[h]
     p = Rht @ np.array([(x - cx) / fx, (y - cy) / fy, 1.0]) + tht * idp
     pts.append(((p[0] / p[2]) * fx + cx, (p[1] / p[2]) * fy + cy, idp / p[2], 1.0))
+import time as _t
 nout = ctx.tracker_make_coarse_depth(1, L, np.array(pts))
-print("reference list sizes per level:", nout)
+_t0 = _t.perf_counter()
+for _ in range(10): nout = ctx.tracker_make_coarse_depth(1, L, np.array(pts))
+print("makeCoarseDepthL0 on the device: %d points -> lists %s, %.0f us per synchronous call (ordered splat, %d levels)" % (len(pts), nout, (_t.perf_counter() - _t0) / 10 * 1e6, L))
 Rrn = W.R_true[new] @ W.R_true[ref].T; trn = W.t_true[new] - Rrn @ W.t_true[ref]
 prm = abi.default_tracker_params()
 for lvl in range(L):
