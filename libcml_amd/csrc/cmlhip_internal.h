@@ -89,7 +89,7 @@ struct cmlhip_ctx {
     DevBuf trk_partial, trk_out;
     float* trk_host = nullptr; unsigned trk_seq = 0;           // mapped, coherent host buffer: the tracker kernel writes its rows + a per-workgroup
                                                               // sequence flag straight to host memory, the caller polls (no memcpy, no stream sync)
-    DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt;      // makeCoarseDepth scratch
+    DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt, cd_pts;      // makeCoarseDepth scratch
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x;
 };

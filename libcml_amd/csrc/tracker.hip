@@ -218,15 +218,24 @@ __global__ void k_cd_late(const double* __restrict__ pts, int w0, int h0, float*
     }
 }
 __global__ void k_cd_down(const float* __restrict__ idm, const float* __restrict__ wm, int wm1, int wl, int hl,
-                          float* __restrict__ idl, float* __restrict__ wsl) {                                      // TR.cpp:571-584
+                          float* __restrict__ idl, float* __restrict__ wsl, float* __restrict__ wbak) {             // TR.cpp:571-584
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= wl || y >= hl) return;
     const int b = 2 * x + 2 * y * wm1;
     idl[x + y * wl] = ((idm[b] + idm[b + 1]) + idm[b + wm1]) + idm[b + wm1 + 1];
-    wsl[x + y * wl] = ((wm[b] + wm[b + 1]) + wm[b + wm1]) + wm[b + wm1 + 1];
+    const float ws = ((wm[b] + wm[b + 1]) + wm[b + wm1]) + wm[b + wm1 + 1];
+    wsl[x + y * wl] = ws; wbak[x + y * wl] = ws;                       // backupWeightSum of this level rides along
 }
+// per-level pointers of the passes that run over all levels in one launch (blockIdx.y = level)
+struct CdLevels {
+    float* idepth[8]; float* wsum[8]; float* wbak[8]; const float* gray[8]; float* uvic[8];
+    int w[8], h[8], cnt_off[8], nb[8];
+    int* counts; int* totals;
+};
 // dilation, TR.cpp:589-665: reads only cells with weightSumBak > 0, writes only cells with weightSumBak <= 0
-__global__ void k_cd_dilate(float* idepth, float* wsum, const float* __restrict__ wbak, int wl, int hl, int diag) {
+__global__ void k_cd_dilate(CdLevels L) {
+    const int lv = blockIdx.y, wl = L.w[lv], hl = L.h[lv], diag = lv < 2 ? 1 : 0;
+    float* idepth = L.idepth[lv]; float* wsum = L.wsum[lv]; const float* __restrict__ wbak = L.wbak[lv];
     const int i = blockIdx.x * blockDim.x + threadIdx.x + wl;
     const int wh = wl * hl - wl, size = wl * hl;
     if (i >= wh) return;
@@ -251,8 +260,13 @@ __device__ __forceinline__ bool cd_valid(const float* idepth, const float* wsum,
     col = gray[i];
     return isfinite(col) && (id > 0);
 }
-__global__ __launch_bounds__(1024) void k_cd_count(const float* idepth, const float* wsum, const float* gray, int wl, int hl, int* counts) {
+__global__ __launch_bounds__(1024) void k_cd_count(CdLevels L) {
     __shared__ int s[16];
+    const int lv = blockIdx.y;
+    if ((int)blockIdx.x >= L.nb[lv]) return;
+    const float* idepth = L.idepth[lv]; const float* wsum = L.wsum[lv]; const float* gray = L.gray[lv];
+    const int wl = L.w[lv], hl = L.h[lv];
+    int* counts = L.counts + L.cnt_off[lv];
     const int i = blockIdx.x * 1024 + threadIdx.x;
     float id, col;
     const bool ok = (i < wl * hl) && cd_valid(idepth, wsum, gray, wl, hl, i, id, col);
@@ -261,16 +275,38 @@ __global__ __launch_bounds__(1024) void k_cd_count(const float* idepth, const fl
     __syncthreads();
     if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; k++) t += s[k]; counts[blockIdx.x] = t; }
 }
-__global__ void k_cd_scan(int* counts, int nb, int* total) {      // single thread: nb <= a few thousand
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < nb; b++) { const int c = counts[b]; counts[b] = acc; acc += c; }
-        *total = acc;
+__global__ __launch_bounds__(1024) void k_cd_scan(CdLevels L) {      // exclusive scan of the per-block counts, one workgroup per level
+    int* counts = L.counts + L.cnt_off[blockIdx.x]; const int nb = L.nb[blockIdx.x]; int* total = L.totals + blockIdx.x;
+    __shared__ int s[1024];
+    __shared__ int carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + t;
+        const int v = i < nb ? counts[i] : 0;
+        s[t] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {                         // Hillis-Steele inclusive scan
+            const int a = t >= o ? s[t - o] : 0;
+            __syncthreads();
+            s[t] += a;
+            __syncthreads();
+        }
+        if (i < nb) counts[i] = carry + s[t] - v;
+        __syncthreads();
+        if (t == 1023) carry += s[1023];
+        __syncthreads();
     }
+    if (t == 0) *total = carry;
 }
-__global__ __launch_bounds__(1024) void k_cd_scatter(const float* idepth, const float* wsum, const float* gray, int wl, int hl,
-                                                     const int* offs, float* uvic) {
+__global__ __launch_bounds__(1024) void k_cd_scatter(CdLevels L) {
     __shared__ int s[16];
+    const int lv = blockIdx.y;
+    if ((int)blockIdx.x >= L.nb[lv]) return;
+    const float* idepth = L.idepth[lv]; const float* wsum = L.wsum[lv]; const float* gray = L.gray[lv];
+    const int wl = L.w[lv], hl = L.h[lv];
+    const int* offs = L.counts + L.cnt_off[lv]; float* uvic = L.uvic[lv];
     const int i = blockIdx.x * 1024 + threadIdx.x;
     float id = 0, col = 0;
     const bool ok = (i < wl * hl) && cd_valid(idepth, wsum, gray, wl, hl, i, id, col);
@@ -436,64 +472,55 @@ int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int l
     const Pyramid* py = cml_find_pyr(c, ref_image_id);
     CML_REQUIRE(c, py && py->levels >= levels && py->lv[0].gray, CMLHIP_ERR_NOT_FOUND, "reference pyramid (with gray levels) not cached");
     int rc;
-    int maxblocks = 1;
+    CdLevels L{};
+    int maxblocks = 1, cnt_total_off = 0, maxdil = 1;
     for (int l = 0; l < levels; l++) {
         const size_t sz = (size_t)py->lv[l].w * py->lv[l].h;
         if ((rc = cml_ensure(c, c->cd_idepth[l], 4 * sz))) return rc;
         if ((rc = cml_ensure(c, c->cd_wsum[l], 4 * sz))) return rc;
         if ((rc = cml_ensure(c, c->cd_wbak[l], 4 * sz))) return rc;
         if ((rc = cml_ensure(c, c->trk_ref[l], 16 * sz))) return rc;
-        CML_CHECK(c, hipMemsetAsync(c->cd_idepth[l].p, 0, 4 * sz, c->stream));
-        CML_CHECK(c, hipMemsetAsync(c->cd_wsum[l].p, 0, 4 * sz, c->stream));
         const int nb = cml_div_up((int)sz, 1024);
+        L.idepth[l] = c->cd_idepth[l].as<float>(); L.wsum[l] = c->cd_wsum[l].as<float>(); L.wbak[l] = c->cd_wbak[l].as<float>();
+        L.gray[l] = py->lv[l].gray; L.uvic[l] = c->trk_ref[l].as<float>();
+        L.w[l] = py->lv[l].w; L.h[l] = py->lv[l].h; L.cnt_off[l] = cnt_total_off; L.nb[l] = nb;
         if (nb > maxblocks) maxblocks = nb;
+        cnt_total_off += nb;
+        maxdil = std::max(maxdil, cml_div_up(std::max((int)sz - 2 * py->lv[l].w, 1), 256));
     }
-    if ((rc = cml_ensure(c, c->cd_cnt, 4 * (size_t)(maxblocks + 16)))) return rc;
-    DevBuf dpts;
+    if ((rc = cml_ensure(c, c->cd_cnt, 4 * (size_t)(cnt_total_off + 16)))) return rc;
+    L.counts = c->cd_cnt.as<int>(); L.totals = L.counts + cnt_total_off;
+    const size_t sz0 = (size_t)py->lv[0].w * py->lv[0].h;
+    CML_CHECK(c, hipMemsetAsync(L.idepth[0], 0, 4 * sz0, c->stream));        // only level 0 is splatted into; the others are written whole
+    CML_CHECK(c, hipMemsetAsync(L.wsum[0], 0, 4 * sz0, c->stream));
+    DevBuf& dpts = c->cd_pts;                                        // grow-only, kept across calls
     if (n > 0) {
         if ((rc = cml_ensure(c, dpts, 32 * (size_t)n + 4 * ((size_t)n + 4)))) return rc;
-        if ((rc = cml_h2d(c, dpts.p, pts, 32 * (size_t)n))) { cml_free(dpts); return rc; }
+        if ((rc = cml_h2d(c, dpts.p, pts, 32 * (size_t)n))) return rc;
         int* late = reinterpret_cast<int*>(dpts.as<char>() + 32 * (size_t)n);
         int* n_late = late + n;
-        int* owner = c->cd_wbak[0].as<int>();                           // free until the dilation backs the weights up into it
-        const size_t sz0 = (size_t)py->lv[0].w * py->lv[0].h;
+        int* owner = c->cd_wbak[0].as<int>();                           // free until the weights are backed up into it
         CML_CHECK(c, hipMemsetAsync(owner, 0x7f, 4 * sz0, c->stream));
         CML_CHECK(c, hipMemsetAsync(n_late, 0, 4, c->stream));
         k_cd_owner<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner);
-        k_cd_splat<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner, c->cd_idepth[0].as<float>(),
-                                                              c->cd_wsum[0].as<float>(), late, n_late);
-        k_cd_late<<<1, 64, 0, c->stream>>>(dpts.as<double>(), py->lv[0].w, py->lv[0].h, c->cd_idepth[0].as<float>(), c->cd_wsum[0].as<float>(), late, n_late);
+        k_cd_splat<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner, L.idepth[0], L.wsum[0], late, n_late);
+        k_cd_late<<<1, 64, 0, c->stream>>>(dpts.as<double>(), py->lv[0].w, py->lv[0].h, L.idepth[0], L.wsum[0], late, n_late);
     }
+    CML_CHECK(c, hipMemcpyAsync(L.wbak[0], L.wsum[0], 4 * sz0, hipMemcpyDeviceToDevice, c->stream));   // backupWeightSum, level 0
     for (int l = 1; l < levels; l++) {
         dim3 g(cml_div_up(py->lv[l].w, 256), py->lv[l].h);
-        k_cd_down<<<g, 256, 0, c->stream>>>(c->cd_idepth[l - 1].as<float>(), c->cd_wsum[l - 1].as<float>(), py->lv[l - 1].w, py->lv[l].w,
-                                            py->lv[l].h, c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>());
+        k_cd_down<<<g, 256, 0, c->stream>>>(L.idepth[l - 1], L.wsum[l - 1], py->lv[l - 1].w, py->lv[l].w, py->lv[l].h, L.idepth[l], L.wsum[l], L.wbak[l]);
     }
-    for (int l = 0; l < levels; l++) {
-        const int wl = py->lv[l].w, hl = py->lv[l].h;
-        const size_t sz = (size_t)wl * hl;
-        CML_CHECK(c, hipMemcpyAsync(c->cd_wbak[l].p, c->cd_wsum[l].p, 4 * sz, hipMemcpyDeviceToDevice, c->stream));   // backupWeightSum
-        const int cnt = wl * hl - 2 * wl;
-        if (cnt > 0)
-            k_cd_dilate<<<cml_div_up(cnt, 256), 256, 0, c->stream>>>(c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>(),
-                                                                     c->cd_wbak[l].as<float>(), wl, hl, l < 2 ? 1 : 0);
-    }
-    for (int l = 0; l < levels; l++) {
-        const int wl = py->lv[l].w, hl = py->lv[l].h;
-        const int nb = cml_div_up(wl * hl, 1024);
-        int* counts = c->cd_cnt.as<int>();
-        int* total = counts + nb;
-        k_cd_count<<<nb, 1024, 0, c->stream>>>(c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>(), py->lv[l].gray, wl, hl, counts);
-        k_cd_scan<<<1, 64, 0, c->stream>>>(counts, nb, total);
-        k_cd_scatter<<<nb, 1024, 0, c->stream>>>(c->cd_idepth[l].as<float>(), c->cd_wsum[l].as<float>(), py->lv[l].gray, wl, hl, counts,
-                                                 c->trk_ref[l].as<float>());
-        int tot = 0;
-        if ((rc = cml_d2h(c, &tot, total, sizeof(int)))) { cml_free(dpts); return rc; }
-        c->trk_n[l] = tot;
-        n_out[l] = tot;
-    }
+    // (the down-sampling reads the UN-dilated maps of the level above, TR.cpp:571-584 runs before :589-665, so every level is
+    //  complete before any is dilated and the dilation, like the compaction, is one launch over all levels)
+    k_cd_dilate<<<dim3(maxdil, levels), 256, 0, c->stream>>>(L);
+    k_cd_count<<<dim3(maxblocks, levels), 1024, 0, c->stream>>>(L);
+    k_cd_scan<<<levels, 1024, 0, c->stream>>>(L);
+    k_cd_scatter<<<dim3(maxblocks, levels), 1024, 0, c->stream>>>(L);
+    int tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((rc = cml_d2h(c, tot, L.totals, sizeof(int) * levels))) return rc;      // one readback for all levels
+    for (int l = 0; l < levels; l++) { c->trk_n[l] = tot[l]; n_out[l] = tot[l]; }
     CML_CHECK(c, hipGetLastError());
-    cml_free(dpts);
     return CMLHIP_OK;
 }
 

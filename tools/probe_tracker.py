@@ -17,9 +17,10 @@ for i in range(W.P):
     p = Rht @ np.array([(x - cx) / fx, (y - cy) / fy, 1.0]) + tht * idp
     pts.append(((p[0] / p[2]) * fx + cx, (p[1] / p[2]) * fy + cy, idp / p[2], 1.0))
 import time as _t
-nout = ctx.tracker_make_coarse_depth(1, L, np.array(pts))
+_pts = np.array(pts)
+nout = ctx.tracker_make_coarse_depth(1, L, _pts)
 _t0 = _t.perf_counter()
-for _ in range(10): nout = ctx.tracker_make_coarse_depth(1, L, np.array(pts))
+for _ in range(10): nout = ctx.tracker_make_coarse_depth(1, L, _pts)
 print("makeCoarseDepthL0 on the device: %d points -> lists %s, %.0f us per synchronous call (ordered splat, %d levels)" % (len(pts), nout, (_t.perf_counter() - _t0) / 10 * 1e6, L))
 Rrn = W.R_true[new] @ W.R_true[ref].T; trn = W.t_true[new] - Rrn @ W.t_true[ref]
 prm = abi.default_tracker_params()
