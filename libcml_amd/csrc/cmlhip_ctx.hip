@@ -2,6 +2,7 @@
 // Reference: GradientImage layout/ownership src/cml/types.h:915, src/cml/capture/CaptureImage.cpp:209-403;
 // image ops src/cml/image/Array2D.h:288-327 (gradient), :388-401 (reduceByTwo).
 #include "cmlhip_internal.h"
+#include <cstdlib>
 
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -85,7 +86,9 @@ void cmlhip_destroy(cmlhip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pyr)
         for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) (void)hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) (void)hipFree(kv.second.lv[l].gray); }
-    DevBuf* all[] = {&c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
+    for (auto& kv : c->img_pool) (void)hipFree(kv.second);
+    c->img_pool.clear();
+    DevBuf* all[] = {&c->img_tmp, &c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
                      &c->pt_colors, &c->pt_weights, &c->pt_backup, &c->pt_acc, &c->pt_step, &c->r_point, &c->r_host, &c->r_target,
                      &c->r_state, &c->r_new_state, &c->r_energy, &c->r_new_energy, &c->r_new_energy_wo, &c->r_ret_energy,
                      &c->r_good, &c->r_lin, &c->r_sel, &c->r_center, &c->r_jpjdf, &c->r_rtz, &c->rj[0], &c->rj[1],
@@ -188,9 +191,25 @@ __global__ void k_collapse_aos3(const void* __restrict__ img, float* __restrict_
 
 static size_t texel_bytes(const cmlhip_ctx* c) { return c->lim.texel_format == CMLHIP_TEXEL_F16 ? 8 : 16; }
 
-static void free_level(PyrLevel& L) {
-    if (L.grad) (void)hipFree(L.grad);
-    if (L.gray) (void)hipFree(L.gray);
+// Image levels come from and go back to a per-context pool keyed by byte size: a sequence allocates its pyramid levels once and
+// every later frame (same sizes) reuses them.  The pool is capped; beyond the cap a released level really is freed.
+static const size_t IMG_POOL_CAP = (size_t)8 << 30;
+static int pool_alloc(cmlhip_ctx* c, size_t bytes, void** out) {
+    auto it = c->img_pool.find(bytes);
+    if (it != c->img_pool.end()) { *out = it->second; c->img_pool.erase(it); c->img_pool_bytes -= bytes; return CMLHIP_OK; }
+    CML_CHECK(c, hipMalloc(out, bytes));
+    return CMLHIP_OK;
+}
+static void pool_release(cmlhip_ctx* c, void* p, size_t bytes) {
+    if (!p) return;
+    static const bool off = getenv("CMLHIP_NO_IMAGE_POOL") != nullptr;      // measurement switch: free and allocate per frame
+    if (off || c->img_pool_bytes + bytes > IMG_POOL_CAP) { (void)hipFree(p); return; }
+    c->img_pool.emplace(bytes, p); c->img_pool_bytes += bytes;
+}
+static void free_level(cmlhip_ctx* c, PyrLevel& L) {
+    const size_t n = (size_t)L.w * L.h;
+    pool_release(c, L.grad, n * texel_bytes(c));
+    pool_release(c, L.gray, n * sizeof(float));
     L = PyrLevel();
 }
 
@@ -201,40 +220,38 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
     Pyramid& P = c->pyr[id];
     PyrLevel& L = P.lv[level];
     (void)hipStreamSynchronize(c->stream);
-    if (L.w != w || L.h != h) free_level(L);
+    if (L.w != w || L.h != h) free_level(c, L);
     size_t n = (size_t)w * h;
-    if (!L.grad) CML_CHECK(c, hipMalloc(&L.grad, n * texel_bytes(c)));
+    int rc;
+    if (!L.grad && (rc = pool_alloc(c, n * texel_bytes(c), &L.grad))) return rc;
     L.w = w; L.h = h;
     if (level + 1 > P.levels) P.levels = level + 1;
-    float* tmp = nullptr;
-    CML_CHECK(c, hipMalloc((void**)&tmp, n * 3 * sizeof(float)));
-    int rc = cml_h2d(c, tmp, aos3, n * 3 * sizeof(float));
-    if (rc) { (void)hipFree(tmp); return rc; }
+    if ((rc = cml_ensure(c, c->img_tmp, n * 3 * sizeof(float)))) return rc;
+    float* tmp = c->img_tmp.as<float>();
+    if ((rc = cml_h2d(c, tmp, aos3, n * 3 * sizeof(float)))) return rc;
     int blocks = cml_div_up((int)n, 256);
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_expand_aos3<true><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
     else k_expand_aos3<false><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
     CML_CHECK(c, hipGetLastError());
-    return CMLHIP_OK;
+    return CMLHIP_OK;                                                   // (the staging buffer is reused in stream order)
 }
 
 int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, int h, int levels) {
     if (!c || !gray || levels < 1 || levels > 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
     (void)hipStreamSynchronize(c->stream);
-    for (int l = 0; l < 8; l++) free_level(P.lv[l]);
+    for (int l = 0; l < 8; l++) free_level(c, P.lv[l]);
     P.levels = levels;
     int cw = w, ch = h;
     for (int l = 0; l < levels; l++) {
         PyrLevel& L = P.lv[l];
         L.w = cw; L.h = ch;
         size_t n = (size_t)cw * ch;
-        CML_CHECK(c, hipMalloc((void**)&L.gray, n * sizeof(float)));
-        CML_CHECK(c, hipMalloc(&L.grad, n * texel_bytes(c)));
+        int rc;
+        if ((rc = pool_alloc(c, n * sizeof(float), (void**)&L.gray))) return rc;
+        if ((rc = pool_alloc(c, n * texel_bytes(c), &L.grad))) return rc;
         if (l == 0) {
-            int rc = cml_h2d(c, L.gray, gray, n * sizeof(float));
-            if (rc) return rc;
+            if ((rc = cml_h2d(c, L.gray, gray, n * sizeof(float)))) return rc;
         } else {
             const PyrLevel& U = P.lv[l - 1];
             dim3 g(cml_div_up(cw, 256), ch);
@@ -255,7 +272,7 @@ int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) {
     auto it = c->pyr.find(id);
     if (it == c->pyr.end()) return CMLHIP_ERR_NOT_FOUND;
     (void)hipStreamSynchronize(c->stream);
-    for (int l = 0; l < 8; l++) free_level(it->second.lv[l]);
+    for (int l = 0; l < 8; l++) free_level(c, it->second.lv[l]);
     c->pyr.erase(it);
     return CMLHIP_OK;
 }
@@ -275,14 +292,13 @@ int cmlhip_pyramid_get(cmlhip_ctx* c, uint64_t id, int level, float* out) {
     if (!P || level < 0 || level >= P->levels || !P->lv[level].grad) return CMLHIP_ERR_NOT_FOUND;
     const PyrLevel& L = P->lv[level];
     size_t n = (size_t)L.w * L.h;
-    float* tmp = nullptr;
-    CML_CHECK(c, hipMalloc((void**)&tmp, n * 3 * sizeof(float)));
+    int rc;
+    if ((rc = cml_ensure(c, c->img_tmp, n * 3 * sizeof(float)))) return rc;
+    float* tmp = c->img_tmp.as<float>();
     int blocks = cml_div_up((int)n, 256);
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_collapse_aos3<true><<<blocks, 256, 0, c->stream>>>(L.grad, tmp, (int)n);
     else k_collapse_aos3<false><<<blocks, 256, 0, c->stream>>>(L.grad, tmp, (int)n);
-    int rc = cml_d2h(c, out, tmp, n * 3 * sizeof(float));
-    (void)hipFree(tmp);
-    return rc;
+    return cml_d2h(c, out, tmp, n * 3 * sizeof(float));
 }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
 #include <unordered_map>
 #include <vector>
 #include "../../include/cmlhip.h"
@@ -43,6 +44,9 @@ struct cmlhip_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::string err;
     std::unordered_map<uint64_t, Pyramid> pyr;
+    std::multimap<size_t, void*> img_pool;                    // released pyramid levels by byte size: a new frame reuses them (no hipMalloc / hipFree per frame)
+    size_t img_pool_bytes = 0;
+    DevBuf img_tmp;                                           // AoS3 staging of pyramid_put / pyramid_get
     void* pinned = nullptr;       // pinned host staging (readbacks / small uploads)
     size_t pinned_bytes = 0, pinned_off = 0;
     std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration (cmlhip_profile_enable)
