@@ -120,7 +120,9 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->syrk_part, 8 * 256 * (size_t)(ntile * (ntile + 1) / 2) * cml_sys_slices(P));
     ENS(c->scal, 1024);
 #undef ENS
-    // ---- SoA staging + upload
+    // ---- SoA staging + upload: everything below is staged and leaves in ONE copy + one scatter / fill kernel (cml_h2d_batch_flush)
+    cml_h2d_batch_begin(c);
+    struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};   // error returns close the batch
     std::vector<float> fx(P), fy(P), fz(P), fp(P), col(8 * (size_t)P), wgt(8 * (size_t)P);
     std::vector<double> idp(P);
     std::vector<int> hst(P);
@@ -171,25 +173,25 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     UP(c->newframe_res, newframe);
 #undef UP
     // resetOOB (DSOResidual.h:83-88): energies 0, flags cleared
-    CML_CHECK(c, hipMemsetAsync(c->r_energy.p, 0, c->r_energy.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_new_energy.p, 0, c->r_new_energy.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_new_energy_wo.p, 0, c->r_new_energy_wo.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_ret_energy.p, 0, c->r_ret_energy.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_good.p, 0, c->r_good.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_sel.p, 0, c->r_sel.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_center.p, 0, c->r_center.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_jpjdf.p, 0, c->r_jpjdf.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->r_rtz.p, 0, c->r_rtz.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->rj[0].p, 0, c->rj[0].bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->rj[1].p, 0, c->rj[1].bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->pt_acc.p, 0, c->pt_acc.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->pt_step.p, 0, c->pt_step.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->pt_backup.p, 0, c->pt_backup.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->scal.p, 0, c->scal.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->pair_blocks.p, 0, c->pair_blocks.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->lin_partial.p, 0, c->lin_partial.bytes, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->step_partial.p, 0, c->step_partial.bytes, c->stream));
-    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    if ((rc = cml_zero(c, c->r_energy.p, c->r_energy.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_new_energy.p, c->r_new_energy.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_new_energy_wo.p, c->r_new_energy_wo.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_ret_energy.p, c->r_ret_energy.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_good.p, c->r_good.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_sel.p, c->r_sel.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_center.p, c->r_center.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_jpjdf.p, c->r_jpjdf.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_rtz.p, c->r_rtz.bytes))) return rc;
+    if ((rc = cml_zero(c, c->rj[0].p, c->rj[0].bytes))) return rc;
+    if ((rc = cml_zero(c, c->rj[1].p, c->rj[1].bytes))) return rc;
+    if ((rc = cml_zero(c, c->pt_acc.p, c->pt_acc.bytes))) return rc;
+    if ((rc = cml_zero(c, c->pt_step.p, c->pt_step.bytes))) return rc;
+    if ((rc = cml_zero(c, c->pt_backup.p, c->pt_backup.bytes))) return rc;
+    if ((rc = cml_zero(c, c->scal.p, c->scal.bytes))) return rc;
+    if ((rc = cml_zero(c, c->pair_blocks.p, c->pair_blocks.bytes))) return rc;
+    if ((rc = cml_zero(c, c->lin_partial.p, c->lin_partial.bytes))) return rc;
+    if ((rc = cml_zero(c, c->step_partial.p, c->step_partial.bytes))) return rc;
+    if ((rc = cml_h2d_batch_flush(c))) return rc;
     c->ba_uploaded = true;
     c->ba_pairs_set = false;
     c->resident_on = false; c->resident_iter = 0;
@@ -637,13 +639,14 @@ int cmlhip_ba_get_states(cmlhip_ctx* c, int* state, int* new_state, float* energ
     int rc = ba_check(c, false);
     if (rc) return rc;
     const size_t R = c->R;
-    if (state && (rc = cml_d2h(c, state, c->r_state.p, 4 * R))) return rc;
-    if (new_state && (rc = cml_d2h(c, new_state, c->r_new_state.p, 4 * R))) return rc;
-    if (energy && (rc = cml_d2h(c, energy, c->r_energy.p, 4 * R))) return rc;
-    if (new_energy && (rc = cml_d2h(c, new_energy, c->r_new_energy.p, 4 * R))) return rc;
-    if (new_energy_wo && (rc = cml_d2h(c, new_energy_wo, c->r_new_energy_wo.p, 4 * R))) return rc;
-    if (is_good && (rc = cml_d2h(c, is_good, c->r_good.p, R))) return rc;
-    return CMLHIP_OK;
+    cml_d2h_batch_begin(c);                                             // six arrays, one round trip
+    if (state) cml_d2h(c, state, c->r_state.p, 4 * R);
+    if (new_state) cml_d2h(c, new_state, c->r_new_state.p, 4 * R);
+    if (energy) cml_d2h(c, energy, c->r_energy.p, 4 * R);
+    if (new_energy) cml_d2h(c, new_energy, c->r_new_energy.p, 4 * R);
+    if (new_energy_wo) cml_d2h(c, new_energy_wo, c->r_new_energy_wo.p, 4 * R);
+    if (is_good) cml_d2h(c, is_good, c->r_good.p, R);
+    return cml_d2h_batch_flush(c);
 }
 
 int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) {

@@ -3,6 +3,7 @@
 // image ops src/cml/image/Array2D.h:288-327 (gradient), :388-401 (reduceByTwo).
 #include "cmlhip_internal.h"
 #include <cstdlib>
+#include <algorithm>
 
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -33,19 +34,132 @@ int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
         return CMLHIP_OK;
     }
     if (c->pinned_off + bytes > cap) {              // ring wrap: everything staged so far must have been consumed
+        if (c->h2d_batching) { const int rc = cml_h2d_batch_flush(c); if (rc) return rc; c->h2d_batching = true; }
         CML_CHECK(c, hipStreamSynchronize(c->stream));
         c->pinned_off = 0;
+        c->h2d_batch_start = 0;
     }
     char* stage = static_cast<char*>(c->pinned) + c->pinned_off;
     memcpy(stage, src, bytes);
+    if (c->h2d_batching) {                          // staged only: the flush copies the packed block once
+        c->h2d_segs.push_back((unsigned long long)(uintptr_t)dst);
+        c->h2d_segs.push_back((unsigned long long)(c->pinned_off - c->h2d_batch_start));
+        c->h2d_segs.push_back((unsigned long long)bytes);
+        c->pinned_off += (bytes + 255) & ~size_t(255);
+        return CMLHIP_OK;
+    }
     c->pinned_off += (bytes + 255) & ~size_t(255);
     CML_CHECK(c, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, c->stream));
     return CMLHIP_OK;
 }
+// one workgroup row per segment: 16-byte words, then the byte tail (block offsets and DevBuf bases are 256-byte aligned)
+__global__ void k_h2d_scatter(const unsigned long long* __restrict__ segs, const char* __restrict__ blob) {
+    const unsigned long long* S = segs + 3 * (size_t)blockIdx.y;
+    char* dst = reinterpret_cast<char*>((uintptr_t)S[0]);
+    const bool zero = S[1] == ~0ull;                  // a fill segment
+    const char* src = zero ? blob : blob + S[1];
+    const size_t bytes = (size_t)S[2], words = bytes / 16;
+    const bool aligned = (((uintptr_t)dst) & 15) == 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero) {
+        if (aligned) {
+            for (size_t i = t0; i < words; i += stride) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
+            for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = 0;
+        } else for (size_t i = t0; i < bytes; i += stride) dst[i] = 0;
+    } else if (aligned) {
+        for (size_t i = t0; i < words; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = t0; i < bytes; i += stride) dst[i] = src[i];
+    }
+}
+int cml_zero(cmlhip_ctx* c, void* dst, size_t bytes) {
+    if (bytes == 0) return CMLHIP_OK;
+    if (c->h2d_batching) {
+        c->h2d_segs.push_back((unsigned long long)(uintptr_t)dst); c->h2d_segs.push_back(~0ull); c->h2d_segs.push_back((unsigned long long)bytes);
+        return CMLHIP_OK;
+    }
+    CML_CHECK(c, hipMemsetAsync(dst, 0, bytes, c->stream));
+    return CMLHIP_OK;
+}
+void cml_h2d_batch_begin(cmlhip_ctx* c) {
+    c->h2d_batching = true; c->h2d_segs.clear(); c->h2d_batch_start = c->pinned ? c->pinned_off : 0;
+}
+int cml_h2d_batch_flush(cmlhip_ctx* c) {
+    c->h2d_batching = false;
+    const size_t nseg = c->h2d_segs.size() / 3;
+    if (nseg == 0) return CMLHIP_OK;
+    const size_t blob = c->pinned_off - c->h2d_batch_start;
+    int rc;
+    if ((rc = cml_ensure(c, c->h2d_blob, blob + 16))) return rc;
+    if ((rc = cml_ensure(c, c->h2d_desc, sizeof(unsigned long long) * 3 * nseg))) return rc;
+    // the table rides at the end of the pinned block
+    const size_t tbytes = sizeof(unsigned long long) * 3 * nseg;
+    const size_t cap = c->pinned_bytes;
+    if (c->pinned_off + tbytes > cap) { CML_CHECK(c, hipStreamSynchronize(c->stream)); }
+    char* tstage = static_cast<char*>(c->pinned) + (c->pinned_off + tbytes <= cap ? c->pinned_off : 0);
+    if (c->pinned_off + tbytes > cap) {             // no room behind the block: the table goes through a plain synchronous copy
+        CML_CHECK(c, hipMemcpyAsync(c->h2d_blob.p, static_cast<char*>(c->pinned) + c->h2d_batch_start, blob, hipMemcpyHostToDevice, c->stream));
+        CML_CHECK(c, hipMemcpyAsync(c->h2d_desc.p, c->h2d_segs.data(), tbytes, hipMemcpyHostToDevice, c->stream));
+        CML_CHECK(c, hipStreamSynchronize(c->stream));
+    } else {
+        memcpy(tstage, c->h2d_segs.data(), tbytes);
+        c->pinned_off += (tbytes + 255) & ~size_t(255);
+        CML_CHECK(c, hipMemcpyAsync(c->h2d_blob.p, static_cast<char*>(c->pinned) + c->h2d_batch_start, blob, hipMemcpyHostToDevice, c->stream));
+        CML_CHECK(c, hipMemcpyAsync(c->h2d_desc.p, tstage, tbytes, hipMemcpyHostToDevice, c->stream));
+    }
+    k_h2d_scatter<<<dim3(32, (unsigned)nseg), 256, 0, c->stream>>>(c->h2d_desc.as<unsigned long long>(), c->h2d_blob.as<char>());
+    CML_CHECK(c, hipGetLastError());
+    c->h2d_segs.clear();
+    return CMLHIP_OK;
+}
 int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return CMLHIP_OK;
+    if (c->d2h_batching) {
+        const size_t ns = c->d2h_segs.size();                        // the next piece starts behind the last one, 256-byte aligned
+        const size_t off = ns ? (size_t)c->d2h_segs[ns - 2] + (((size_t)c->d2h_segs[ns - 1] + 255) & ~size_t(255)) : 0;
+        c->d2h_segs.push_back((unsigned long long)(uintptr_t)src); c->d2h_segs.push_back((unsigned long long)off); c->d2h_segs.push_back((unsigned long long)bytes);
+        c->d2h_dst.push_back(dst);
+        return CMLHIP_OK;
+    }
     CML_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     CML_CHECK(c, hipStreamSynchronize(c->stream));
+    return CMLHIP_OK;
+}
+__global__ void k_d2h_gather(const unsigned long long* __restrict__ segs, char* __restrict__ blob) {
+    const unsigned long long* S = segs + 3 * (size_t)blockIdx.y;
+    const char* src = reinterpret_cast<const char*>((uintptr_t)S[0]);
+    char* dst = blob + S[1];
+    const size_t bytes = (size_t)S[2], words = bytes / 16;
+    const bool aligned = (((uintptr_t)src) & 15) == 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (aligned) {
+        for (size_t i = t0; i < words; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = src[i];
+    } else for (size_t i = t0; i < bytes; i += stride) dst[i] = src[i];
+}
+void cml_d2h_batch_begin(cmlhip_ctx* c) { c->d2h_batching = true; c->d2h_segs.clear(); c->d2h_dst.clear(); }
+int cml_d2h_batch_flush(cmlhip_ctx* c) {
+    c->d2h_batching = false;
+    const size_t nseg = c->d2h_dst.size();
+    if (nseg == 0) return CMLHIP_OK;
+    const size_t total = (size_t)c->d2h_segs[3 * (nseg - 1) + 1] + (((size_t)c->d2h_segs[3 * (nseg - 1) + 2] + 255) & ~size_t(255));
+    int rc;
+    if ((rc = cml_ensure(c, c->d2h_blob, total))) return rc;
+    if ((rc = cml_ensure(c, c->h2d_desc, sizeof(unsigned long long) * 3 * nseg))) return rc;
+    if (c->pinned_d2h_bytes < total) {
+        if (c->pinned_d2h) (void)hipHostFree(c->pinned_d2h);
+        c->pinned_d2h = nullptr; c->pinned_d2h_bytes = 0;
+        const size_t cap = std::max(total, (size_t)1 << 20);
+        CML_CHECK(c, hipHostMalloc(&c->pinned_d2h, cap, hipHostMallocDefault));
+        c->pinned_d2h_bytes = cap;
+    }
+    if ((rc = cml_h2d(c, c->h2d_desc.p, c->d2h_segs.data(), sizeof(unsigned long long) * 3 * nseg))) return rc;
+    k_d2h_gather<<<dim3(16, (unsigned)nseg), 256, 0, c->stream>>>(c->h2d_desc.as<unsigned long long>(), c->d2h_blob.as<char>());
+    CML_CHECK(c, hipMemcpyAsync(c->pinned_d2h, c->d2h_blob.p, total, hipMemcpyDeviceToHost, c->stream));
+    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < nseg; k++) memcpy(c->d2h_dst[k], static_cast<char*>(c->pinned_d2h) + c->d2h_segs[3 * k + 1], (size_t)c->d2h_segs[3 * k + 2]);
+    c->d2h_segs.clear(); c->d2h_dst.clear();
     return CMLHIP_OK;
 }
 const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id) {
@@ -88,7 +202,7 @@ void cmlhip_destroy(cmlhip_ctx* c) {
         for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) (void)hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) (void)hipFree(kv.second.lv[l].gray); }
     for (auto& kv : c->img_pool) (void)hipFree(kv.second);
     c->img_pool.clear();
-    DevBuf* all[] = {&c->img_tmp, &c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
+    DevBuf* all[] = {&c->img_tmp, &c->h2d_blob, &c->h2d_desc, &c->d2h_blob, &c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
                      &c->pt_colors, &c->pt_weights, &c->pt_backup, &c->pt_acc, &c->pt_step, &c->r_point, &c->r_host, &c->r_target,
                      &c->r_state, &c->r_new_state, &c->r_energy, &c->r_new_energy, &c->r_new_energy_wo, &c->r_ret_energy,
                      &c->r_good, &c->r_lin, &c->r_sel, &c->r_center, &c->r_jpjdf, &c->r_rtz, &c->rj[0], &c->rj[1],
@@ -100,6 +214,7 @@ void cmlhip_destroy(cmlhip_ctx* c) {
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_d2h) (void)hipHostFree(c->pinned_d2h);
     if (c->trk_host) (void)hipHostFree(c->trk_host);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev[0]);

@@ -46,7 +46,12 @@ struct cmlhip_ctx {
     std::unordered_map<uint64_t, Pyramid> pyr;
     std::multimap<size_t, void*> img_pool;                    // released pyramid levels by byte size: a new frame reuses them (no hipMalloc / hipFree per frame)
     size_t img_pool_bytes = 0;
-    DevBuf img_tmp;                                           // AoS3 staging of pyramid_put / pyramid_get
+    DevBuf img_tmp;
+    DevBuf h2d_blob, h2d_desc;                                // packed upload block and its segment table (batched cml_h2d)
+    bool h2d_batching = false; size_t h2d_batch_start = 0;
+    bool d2h_batching = false; std::vector<unsigned long long> d2h_segs; std::vector<void*> d2h_dst;
+    DevBuf d2h_blob; void* pinned_d2h = nullptr; size_t pinned_d2h_bytes = 0;
+    std::vector<unsigned long long> h2d_segs;                 // (dst pointer, offset in the block, bytes) triples                                           // AoS3 staging of pyramid_put / pyramid_get
     void* pinned = nullptr;       // pinned host staging (readbacks / small uploads)
     size_t pinned_bytes = 0, pinned_off = 0;
     std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration (cmlhip_profile_enable)
@@ -114,8 +119,17 @@ struct cmlhip_ctx {
 
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes);          // grow-only device allocation
 void cml_free(DevBuf& b);
-int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // async on ctx stream via pinned staging
-int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // sync readback
+int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);
+// Batched form for the many small arrays of a window upload: between begin and flush every cml_h2d only stages its bytes;
+// flush moves the packed block with ONE copy and scatters it to the destinations with one small kernel.
+void cml_h2d_batch_begin(cmlhip_ctx* c);
+int cml_zero(cmlhip_ctx* c, void* dst, size_t bytes);        // hipMemsetAsync(0), or a zero segment of the open batch
+int cml_h2d_batch_flush(cmlhip_ctx* c);   // async on ctx stream via pinned staging
+int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // sync readback (inside a batch: recorded, delivered by the flush)
+// Several arrays, one round trip: between begin and flush cml_d2h only records; flush gathers the pieces into one device block,
+// copies it once into pinned memory, waits once and hands the pieces out.
+void cml_d2h_batch_begin(cmlhip_ctx* c);
+int cml_d2h_batch_flush(cmlhip_ctx* c);
 const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id);
 
 static inline int cml_div_up(int a, int b) { return (a + b - 1) / b; }

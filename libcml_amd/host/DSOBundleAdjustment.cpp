@@ -1,6 +1,9 @@
 // DSOBundleAdjustment.cpp — host mirror of CML::Optimization::DSOBundleAdjustment over the C ABI.
 // BA.cpp = src/cml/optimization/dso/DSOBundleAdjustment.cpp in the reference tree.
 #include "DSOBundleAdjustment.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -515,6 +518,8 @@ bool DSOBundleAdjustment::doStepFromBackup(bool fixCamera) {                  //
 }
 
 bool DSOBundleAdjustment::runPreamble(double lastEnergy[3]) {                // BA.cpp:744-802
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "    [preamble] %-22s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
     mOutliers.clear();
     mError.clear();
     lastIterations = 0;
@@ -523,8 +528,11 @@ bool DSOBundleAdjustment::runPreamble(double lastEnergy[3]) {                // 
     if (alivePts == 0) { mError = "No points..."; return false; }             // :759-762
     computeAdjoints();
     computeDelta();
+    lap("adjoints+delta");
     if (!uploadWindow()) return false;
+    lap("uploadWindow");
     if (!linearizeAll(false, lastEnergy)) return false;
+    lap("linearizeAll");
     int rc = cmlhip_ba_apply(mCtx, 1);                                        // applyActiveRes(true), :790
     if (rc) return fail("cmlhip_ba_apply", rc);
     statEnergyP.push_back(lastEnergy[0] / std::max<size_t>(1, mActive.size()));
@@ -946,14 +954,20 @@ bool DSOBundleAdjustment::endResident(double* lastEnergy) {
 
 bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     double lastEnergy[3];
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "  [run] %-28s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
     if (!runPreamble(lastEnergy)) return false;
+    lap("preamble done");
     if (!beginResident(updatePointsOnly)) return false;
+    lap("beginResident done");
     int rc = cmlhip_ba_resident_convergence(mCtx, mThOptIterations);         // `if (canbreak && it >= 1) break`, BA.cpp:879
     if (rc) return fail("cmlhip_ba_resident_convergence", rc);
     if (!iterateResident(mNumIterations, mFixedLambda)) return false;
     lastLambda = mFixedLambda;
     double e = 0;
+    lap("iterations enqueued");
     if (!endResident(&e)) { mError = "non finite energy"; return false; }
+    lap("endResident done");
     std::vector<double> en(mNumIterations > 0 ? mNumIterations : 1, 0.0);
     int its = 0;
     rc = cmlhip_ba_get_resident_log(mCtx, &its, en.data(), (int)en.size());
@@ -961,7 +975,9 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     lastIterations = its;
     for (int i = 0; i < its && i < (int)en.size(); i++) statEnergyP.push_back(en[i]);
     lastEnergy[0] = e;
-    return runEpilogue(lastEnergy);
+    const bool ok = runEpilogue(lastEnergy);
+    lap("epilogue done");
+    return ok;
 }
 
 }  // namespace cml_amd
