@@ -215,6 +215,13 @@ int cmlhip_ba_get_idepth(cmlhip_ctx* ctx, double* idepth /* P */);
 int cmlhip_ba_linearize(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);
 /* applyActiveRes(copyJacobians) (BA.cpp:2045-2093) */
 int cmlhip_ba_apply(cmlhip_ctx* ctx, int copy_jacobians);
+/* The tail of DSOBundleAdjustment::run in one call and ONE readback: linearizeAll(true) (BA.cpp:896 = linearize + applyRes(true),
+ * :1551-1569) followed by everything the host writes back afterwards — residual states / energies (:1571-1640), the points'
+ * inverse depths and the per-point accumulators (HdiF -> setInverseDepthHessian, :1889-1901).  pairs must be current.
+ * Any output pointer may be NULL; point_acc is P x 14 as cmlhip_ba_get_point_acc returns it. */
+int cmlhip_ba_finish_keyframe(cmlhip_ctx* ctx, cmlhip_ba_lin_result* lin, int* state, int* new_state, float* energy,
+                              float* new_energy, float* new_energy_without_outlier, unsigned char* is_good,
+                              double* idepth, float* point_acc);
 
 /* solveSystem accumulation (BA.cpp:1354-1385): addToHessianTop (ACTIVE and LINEARIZED),
  * stitchDoubleTop, addToHessianSC, stitchDoubleSC.

@@ -275,6 +275,33 @@ int cmlhip_ba_apply(cmlhip_ctx* c, int copy) {
     return CMLHIP_OK;
 }
 
+int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* state, int* new_state, float* energy, float* new_energy,
+                              float* new_energy_wo, unsigned char* is_good, double* idepth, float* point_acc) {
+    int rc = cmlhip_ba_linearize_async(c);
+    if (rc) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    cml_launch_apply(c, A, 1);
+    CML_CHECK(c, hipGetLastError());
+    const size_t R = c->R, P = c->P;
+    LinSummary S;
+    std::vector<float> pacc(point_acc ? PT_ACC_STRIDE * P : 0);
+    cml_d2h_batch_begin(c);
+    cml_d2h(c, &S, c->scal.p, sizeof S);
+    if (state) cml_d2h(c, state, c->r_state.p, 4 * R);
+    if (new_state) cml_d2h(c, new_state, c->r_new_state.p, 4 * R);
+    if (energy) cml_d2h(c, energy, c->r_energy.p, 4 * R);
+    if (new_energy) cml_d2h(c, new_energy, c->r_new_energy.p, 4 * R);
+    if (new_energy_wo) cml_d2h(c, new_energy_wo, c->r_new_energy_wo.p, 4 * R);
+    if (is_good) cml_d2h(c, is_good, c->r_good.p, R);
+    if (idepth) cml_d2h(c, idepth, c->pt_idepth.p, 8 * P);
+    if (point_acc && P) cml_d2h(c, pacc.data(), c->pt_acc.p, 4 * pacc.size());
+    if ((rc = cml_d2h_batch_flush(c))) return rc;
+    if (point_acc) for (size_t p = 0; p < P; p++) memcpy(point_acc + 14 * p, &pacc[PT_ACC_STRIDE * p], 14 * 4);
+    if (lin) { lin->energy = S.energy; lin->n_in = S.n_in; lin->n_oob = S.n_oob; lin->n_outlier = S.n_outlier; lin->new_frame_energy_th = S.new_frame_energy_th; }
+    return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
+}
+
 static int upload_accum_in(cmlhip_ctx* c, const cmlhip_ba_accum_in* in) {
     const int N = c->N;
     int rc;

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "cmlhip_tracer_trace_resident": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, _P(C.c_int)]),
     "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
+    "cmlhip_ba_finish_keyframe": (C.c_int, [_ctx, C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_ubyte), _P(C.c_double), _P(C.c_float)]),
     "cmlhip_pnp_optimize": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_double), _P(C.c_double), _i, C.c_void_p, _P(C.c_ubyte), _i, _i, _i, _P(abi.PnpResult)]),
     "cmlhip_lba_optimize": (C.c_int, [_ctx, _i, C.c_void_p, _i, _P(C.c_double), _P(C.c_int), C.c_void_p, _i, _i, _i, _P(C.c_ubyte), _P(abi.LbaResult)]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),

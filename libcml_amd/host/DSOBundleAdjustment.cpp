@@ -399,25 +399,31 @@ bool DSOBundleAdjustment::uploadWindow() {
     return true;
 }
 
-bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3]) {   // BA.cpp:1497-1646
+bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut) {   // BA.cpp:1497-1646
     std::vector<cmlhip_ba_pair> pairs;
     framePairs(pairs);
     int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
     if (rc) return fail("cmlhip_ba_set_pairs", rc);
     cmlhip_ba_lin_result lr;
-    rc = cmlhip_ba_linearize(mCtx, &lr);
-    if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_linearize", rc);
+    const int R = (int)mActive.size();
+    std::vector<int> st, ns;
+    std::vector<float> e, ne, nw;
+    std::vector<unsigned char> good;
+    if (fixLinearization) {
+        // linearize + applyRes(r, true) (:1568-1569) + every array the host writes back afterwards: one device call, one readback
+        st.resize(R); ns.resize(R); e.resize(R); ne.resize(R); nw.resize(R); good.resize(R);
+        if (idepthOut) idepthOut->resize(mActivePoints.size());
+        if (pointAccOut) pointAccOut->resize(14 * mActivePoints.size() + 14);
+        rc = cmlhip_ba_finish_keyframe(mCtx, &lr, st.data(), ns.data(), e.data(), ne.data(), nw.data(), good.data(),
+                                       idepthOut ? idepthOut->data() : nullptr, pointAccOut ? pointAccOut->data() : nullptr);
+        if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_finish_keyframe", rc);
+    } else {
+        rc = cmlhip_ba_linearize(mCtx, &lr);
+        if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_linearize", rc);
+    }
     energy[0] = lr.energy; energy[1] = 0; energy[2] = 0;
     mFrames.back().frameEnergyTH = lr.new_frame_energy_th;                // setNewFrameEnergyTH, :1610
     if (fixLinearization) {
-        rc = cmlhip_ba_apply(mCtx, 1);                                    // applyRes(r, true) per residual, :1568-1569
-        if (rc) return fail("cmlhip_ba_apply", rc);
-        const int R = (int)mActive.size();
-        std::vector<int> st(R), ns(R);
-        std::vector<float> e(R), ne(R), nw(R);
-        std::vector<unsigned char> good(R);
-        rc = cmlhip_ba_get_states(mCtx, st.data(), ns.data(), e.data(), ne.data(), nw.data(), good.data());
-        if (rc) return fail("cmlhip_ba_get_states", rc);
         std::vector<int> nres(mPoints.size(), 0);
         for (int k = 0; k < R; k++) {
             DSOResidual& Rr = mResiduals[mActive[k]];
@@ -549,15 +555,11 @@ bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // 
     fb.setEvalPT(fb.PRE_worldToCam, nz, sc);
     computeAdjoints();
     computeDelta();
-    if (!linearizeAll(true, lastEnergy)) return false;                        // :896
+    std::vector<double> idp;
+    std::vector<float> pacc;
+    if (!linearizeAll(true, lastEnergy, &idp, &pacc)) return false;           // :896 (+ the inverse depths and point accumulators, same readback)
     if (!std::isfinite(lastEnergy[0])) { mError = "Not finite energy"; return false; }
     // write the optimised inverse depths back (MapPoint::setReferenceInverseDepth in the reference)
-    std::vector<double> idp(mActivePoints.size());
-    int rc = cmlhip_ba_get_idepth(mCtx, idp.data());
-    if (rc) return fail("cmlhip_ba_get_idepth", rc);
-    std::vector<float> pacc(14 * mActivePoints.size() + 14);
-    rc = cmlhip_ba_get_point_acc(mCtx, pacc.data());
-    if (rc) return fail("cmlhip_ba_get_point_acc", rc);
     for (size_t k = 0; k < mActivePoints.size(); k++) {
         DSOPoint& P = mPoints[mActivePoints[k]];
         P.idepth = idp[k];
