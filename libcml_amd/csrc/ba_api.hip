@@ -545,17 +545,18 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, co
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || !frames || !scales)
         return CMLHIP_ERR_INVALID;
     const int N = c->N, n = 8 * N + 4;
-    if ((rc = upload_accum_in(c, in))) return rc;
     if ((rc = cml_ensure(c, c->frame_state, sizeof(cmlhip_ba_frame_state) * (size_t)N))) return rc;
     if ((rc = cml_ensure(c, c->pre_w2c, 8 * 7 * (size_t)N))) return rc;
+    if (nullspace_basis && (rc = cml_ensure(c, c->null_basis, 8 * 7 * (size_t)n))) return rc;
+    cml_h2d_batch_begin(c);                                              // adjoints, deltas, priors, frame states, gauge basis: one copy
+    struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};
+    if ((rc = upload_accum_in(c, in))) return rc;
     if ((rc = cml_h2d(c, c->frame_state.p, frames, sizeof(cmlhip_ba_frame_state) * (size_t)N))) return rc;
-    CML_CHECK(c, hipMemsetAsync(c->pre_w2c.p, 0, 8 * 7 * (size_t)N, c->stream));
+    if ((rc = cml_zero(c, c->pre_w2c.p, 8 * 7 * (size_t)N))) return rc;
     for (int i = 0; i < 4; i++) c->res_scales[i] = scales[i];
     c->have_null = nullspace_basis != nullptr;
-    if (c->have_null) {
-        if ((rc = cml_ensure(c, c->null_basis, 8 * 7 * (size_t)n))) return rc;
-        if ((rc = cml_h2d(c, c->null_basis.p, nullspace_basis, 8 * 7 * (size_t)n))) return rc;
-    }
+    if (c->have_null && (rc = cml_h2d(c, c->null_basis.p, nullspace_basis, 8 * 7 * (size_t)n))) return rc;
+    if ((rc = cml_h2d_batch_flush(c))) return rc;
     c->resident_on = true; c->resident_iter = 0; c->conv_th = 0; c->conv_on = false;
     return CMLHIP_OK;
 }
