@@ -1,6 +1,9 @@
 // ba_api.hip — extern "C" entry points of the bundle-adjustment part of include/cmlhip.h.
 // Host side: index bookkeeping (bit-exact maps), uploads, launches, readbacks.  No CPU compute fallback.
 #include "cmlhip_internal.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "ba_common.h"
 #include <cmath>
 
@@ -58,6 +61,8 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P >= 0 && P <= c->lim.max_points && R >= 0 && R <= c->lim.max_residuals,
                 CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
     (void)hipSetDevice(c->device);
+    const auto T0_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char* w) { if (getenv("CMLHIP_TIMING")) fprintf(stderr, "      [upload] %-18s %.0f us\n", w, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0_).count()); };
     // ---- frames: resolve pyramids
     std::vector<FrameDev> fd(N);
     for (int i = 0; i < N; i++) {
@@ -120,6 +125,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->syrk_part, 8 * 256 * (size_t)(ntile * (ntile + 1) / 2) * cml_sys_slices(P));
     ENS(c->scal, 1024);
 #undef ENS
+    lap_("index lists+ensure");
     // ---- SoA staging + upload: everything below is staged and leaves in ONE copy + one scatter / fill kernel (cml_h2d_batch_flush)
     cml_h2d_batch_begin(c);
     struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};   // error returns close the batch
@@ -191,7 +197,9 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     if ((rc = cml_zero(c, c->pair_blocks.p, c->pair_blocks.bytes))) return rc;
     if ((rc = cml_zero(c, c->lin_partial.p, c->lin_partial.bytes))) return rc;
     if ((rc = cml_zero(c, c->step_partial.p, c->step_partial.bytes))) return rc;
+    lap_("staged");
     if ((rc = cml_h2d_batch_flush(c))) return rc;
+    lap_("flushed");
     c->ba_uploaded = true;
     c->ba_pairs_set = false;
     c->resident_on = false; c->resident_iter = 0;
