@@ -247,8 +247,10 @@ int cmlhip_initializer_calc_res_and_gs(cmlhip_ctx* c, uint64_t image_id, int lev
         else k_init_calc_res_and_gs<false><<<nb, 256, 0, c->stream>>>(A);
         CML_CHECK(c, hipGetLastError());
         std::vector<float> part((size_t)nb * INI_NRED);
-        if ((rc = cml_d2h(c, part.data(), c->ini_partial.p, sizeof(float) * part.size()))) return rc;
-        if ((rc = cml_d2h(c, points, c->ini_points.p, sizeof(cmlhip_init_point) * (size_t)n))) return rc;
+        cml_d2h_batch_begin(c);
+        cml_d2h(c, part.data(), c->ini_partial.p, sizeof(float) * part.size());
+        cml_d2h(c, points, c->ini_points.p, sizeof(cmlhip_init_point) * (size_t)n);
+        if ((rc = cml_d2h_batch_flush(c))) return rc;
         for (int b = 0; b < nb; b++)
             for (int k = 0; k < INI_NRED; k++) sums[k] += (double)part[(size_t)b * INI_NRED + k];
     }

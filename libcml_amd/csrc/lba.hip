@@ -703,10 +703,12 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
     }
     k_lba_edge_test<<<nb, 64, 0, c->stream>>>(cams[cur], c->lba_edges.as<cmlhip_lba_edge>(), c->lba_off.as<int>(), pts[cur], c->lba_err.as<double>(), n_points, bad);
     CML_CHECK(c, hipGetLastError());
-    if ((rc = cml_d2h(c, points, pts[cur], sizeof(double) * 3 * (size_t)n_points))) return rc;
-    if ((rc = cml_d2h(c, edge_bad, bad, (size_t)n_edges))) return rc;
     std::vector<LbaCam> hc(n_frames);
-    if ((rc = cml_d2h(c, hc.data(), cams[cur], sizeof(LbaCam) * (size_t)n_frames))) return rc;
+    cml_d2h_batch_begin(c);                                             // points, edge flags, cameras: one round trip
+    cml_d2h(c, points, pts[cur], sizeof(double) * 3 * (size_t)n_points);
+    cml_d2h(c, edge_bad, bad, (size_t)n_edges);
+    cml_d2h(c, hc.data(), cams[cur], sizeof(LbaCam) * (size_t)n_frames);
+    if ((rc = cml_d2h_batch_flush(c))) return rc;
     for (int f = 0; f < n_frames; f++) {                                    // apply(): pKF->setCamera of the local keyframes, :301-305
         if (frames[f].fixed) continue;
         for (int k = 0; k < 9; k++) frames[f].R[k] = hc[f].R[k];
@@ -764,8 +766,10 @@ int cmlhip_lba_optimize(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, i
     }
     k_lba_edge_test<<<nb, 64, 0, c->stream>>>(A.cams, A.edges, A.off, A.points, A.err, n_points, bad);
     CML_CHECK(c, hipGetLastError());
-    if ((rc = cml_d2h(c, points, c->lba_points.p, sizeof(double) * 3 * (size_t)n_points))) return rc;
-    if ((rc = cml_d2h(c, edge_bad, bad, (size_t)n_edges))) return rc;
+    cml_d2h_batch_begin(c);
+    cml_d2h(c, points, c->lba_points.p, sizeof(double) * 3 * (size_t)n_points);
+    cml_d2h(c, edge_bad, bad, (size_t)n_edges);
+    if ((rc = cml_d2h_batch_flush(c))) return rc;
     int nbad = 0;
     for (int e = 0; e < n_edges; e++) nbad += edge_bad[e];
     out->n_bad = nbad; out->ok = 1;

@@ -449,8 +449,10 @@ int cmlhip_pnp_optimize(cmlhip_ctx* c, const double R[9], const double t[3], con
     }
     k_pnp_optimize<<<1, PNP_THREADS, dyn, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
-    if ((rc = cml_d2h(c, out, c->pnp_out.p, sizeof(cmlhip_pnp_result)))) return rc;
-    return cml_d2h(c, outliers, c->pnp_flags.p, (size_t)n);
+    cml_d2h_batch_begin(c);                                             // result + flags: one round trip
+    cml_d2h(c, out, c->pnp_out.p, sizeof(cmlhip_pnp_result));
+    cml_d2h(c, outliers, c->pnp_flags.p, (size_t)n);
+    return cml_d2h_batch_flush(c);
 }
 
 }  // extern "C"

@@ -448,9 +448,11 @@ int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_optimize_immature<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     else k_optimize_immature<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
-    if ((rc = cml_d2h(c, result, A.result, 4 * (size_t)n))) return rc;
-    if ((rc = cml_d2h(c, idepth, A.idepth, 4 * (size_t)n))) return rc;
-    return cml_d2h(c, res_state, A.res_state, 4 * (size_t)n * N);
+    cml_d2h_batch_begin(c);
+    cml_d2h(c, result, A.result, 4 * (size_t)n);
+    cml_d2h(c, idepth, A.idepth, 4 * (size_t)n);
+    cml_d2h(c, res_state, A.res_state, 4 * (size_t)n * N);
+    return cml_d2h_batch_flush(c);
 }
 
 }  // extern "C"
