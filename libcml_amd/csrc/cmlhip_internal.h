@@ -31,6 +31,13 @@ struct Pyramid {
 };
 
 // per-frame device descriptor used by the BA kernels
+// the flat records cross the ABI by value from other languages (ctypes / numpy dtypes in libcml_amd/abi.py): pin their sizes
+static_assert(sizeof(cmlhip_immature_point) == 232, "cmlhip_immature_point layout");
+static_assert(sizeof(cmlhip_init_point) == 224, "cmlhip_init_point layout");
+static_assert(sizeof(cmlhip_pnp_match) == 56, "cmlhip_pnp_match layout");
+static_assert(sizeof(cmlhip_lba_frame) == 136 && sizeof(cmlhip_lba_edge) == 32, "cmlhip_lba_* layout");
+static_assert(sizeof(cmlhip_ba_pair) == 26 * sizeof(double), "cmlhip_ba_pair layout");
+
 struct FrameDev {
     const void* grad0;      // level-0 gradient image of the frame
     float frame_energy_th;
