@@ -164,7 +164,7 @@ struct PnpShared {
     double part[2 * PNP_WAVES][44];  // per wave and 8 x 8 block: 6x7 sums + chi
     double sys[2][44];           // [0] the system the solver works on, [1] the system at the trial pose (H 36 | b 6 | chi)
     PnpPose T, Ttrial, T0;
-    int ctl[4];                  // [0] loop-again flag, [1] stop flag, [2] nBad
+    int ctl[8];                  // [0] loop again, [1] stop, [2] nBad, [3] adopt the trial system, [4] next trial chi2 only, [5] rebuild at the accepted pose
     unsigned char lvl[PNP_MAX_MATCHES];
 };
 
@@ -181,7 +181,9 @@ __device__ __forceinline__ void pnp_edge(const double* sm, int i, const PnpPose&
 }
 
 // computeActiveErrors + activeRobustChi2 + buildSystem at pose `T` into S.sys[dst]
-__device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const PnpPose& T, const double K[4], bool robust, double delta, int dst) {
+// want_H == false: computeActiveErrors + activeRobustChi2 only (what a REJECTED Levenberg trial needs); the chi2 sum is the same
+// code either way, so a trial evaluated light and then accepted is rebuilt in full at the same pose with an identical chi2
+__device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const PnpPose& T, const double K[4], bool robust, double delta, int dst, bool want_H = true) {
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, col = l & 15, kq = l >> 4, pk = col >> 3, c7 = col & 7;
     pnp_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
     double chi = 0.0;
@@ -201,6 +203,7 @@ __device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const
                 if (!(chi2 <= dsqr)) { const double rs = pnp_rsqrt(chi2), sq = chi2 * rs; rho0 = 2 * sq * delta - dsqr; rho1 = delta * rs; }
             }
             chi += rho0;
+            if (want_H) {
             const double u = p[0], v = p[1], iz = p[2], fx = K[0], fy = K[1];                       // u = x/z, v = y/z
             J0[0] = u * v * fx; J0[1] = -(1 + u * u) * fx; J0[2] = v * fx;                          // edge_project_xyz.cpp:80-94
             J0[3] = -iz * fx; J0[4] = 0; J0[5] = u * iz * fx;
@@ -208,7 +211,9 @@ __device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const
             J1[3] = 0; J1[4] = -iz * fy; J1[5] = v * iz * fy;
             J0[6] = -e[0]; J1[6] = -e[1];
             w = rho1 * om;
+            }
         }
+        if (!want_H) continue;                                                 // (workgroup-uniform)
         // row 0 of every edge of this wave, then row 1: D += sum_k (w_k J_k) [J_k | -e_k]^T.  Only 6 x 7 of the 16 x 16 tile is
         // wanted, so two edges ride in one K step: A rows / B columns 0..7 carry edge 2k, 8..15 carry edge 2k+1 (the two
         // off-diagonal 8 x 8 blocks hold cross terms nobody reads): 8 edge rows per instruction
@@ -296,9 +301,12 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                         lambda = 1e-5 * mx; ni = 2.0;
                     }
                 }
-                bool again;
+                bool again, accepted_light = false;
+                if (tid == 0) S.ctl[4] = 0;                                    // the first trial of a solve() is evaluated in full
+                __syncthreads();
                 do {
                     bool ok2 = false;
+                    const bool light = S.ctl[4] != 0;
                     if (tid == 0) {
                         for (int j = 0; j < 6; j++) x[j] = 0.0;
                         ok2 = pnp_llt_solve(S.sys[0], lambda, S.sys[0] + 36, x);
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                         S.Ttrial = Tn;
                     }
                     __syncthreads();
-                    pnp_evaluate(S, s_m, n, S.Ttrial, A.K, robust, delta, 1);
+                    pnp_evaluate(S, s_m, n, S.Ttrial, A.K, robust, delta, 1, !light);
                     if (tid == 0) {
                         double tempChi = S.sys[1][42];
                         if (!ok2) tempChi = DBL_MAX;
@@ -323,11 +331,12 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                             alpha = fmin(alpha, 2. / 3.);
                             const double sf = fmax(1. / 3., alpha);
                             lambda *= sf; ni = 2.0; currentChi = tempChi;
-                            S.T = S.Ttrial; accepted = true;
+                            S.T = S.Ttrial; accepted = true; accepted_light = light;
                         } else {
                             lambda *= ni; ni *= 2.0;                           // pop: S.T stays
                             if (!isfinite(lambda)) brk = true;
-                        }
+                            S.ctl[4] = 1;                                      // a rejection is usually followed by more (the cascade at
+                        }                                                      // convergence): those trials only need their chi2
                         if (!brk) qmax++;
                         S.ctl[0] = (!brk && rho < 0 && qmax < 10) ? 1 : 0;
                     }
@@ -341,8 +350,10 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                     // the accepted trial system is the next iteration's buildSystem; keep the solver's system otherwise
                     S.ctl[1] = terminate ? 1 : 0;
                     S.ctl[3] = (accepted && !terminate && it < 9) ? 1 : 0;
+                    S.ctl[5] = (S.ctl[3] && accepted_light) ? 1 : 0;          // accepted on a chi2-only evaluation: build its system now
                 }
                 __syncthreads();
+                if (S.ctl[5]) pnp_evaluate(S, s_m, n, S.T, A.K, robust, delta, 1, true);
                 if (S.ctl[3] && tid < 43) S.sys[0][tid] = S.sys[1][tid];
                 const bool stop = S.ctl[1] != 0;
                 __syncthreads();
