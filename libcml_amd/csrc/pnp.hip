@@ -164,6 +164,8 @@ struct PnpShared {
     double part[2 * PNP_WAVES][44];  // per wave and 8 x 8 block: 6x7 sums + chi
     double sys[2][44];           // [0] the system the solver works on, [1] the system at the trial pose (H 36 | b 6 | chi)
     PnpPose T, Ttrial, T0;
+    // the rejection cascade: the trials that would follow a rejection, prepared side by side (PNP_SPEC = at most 9 of them)
+    PnpPose specT[9]; double specLambda[9], specNi[9], specScale[9], specChi[9], specPart[PNP_WAVES][9]; int specOk[9];
     int ctl[8];                  // [0] loop again, [1] stop, [2] nBad, [3] adopt the trial system, [4] next trial chi2 only, [5] rebuild at the accepted pose
     unsigned char lvl[PNP_MAX_MATCHES];
 };
@@ -259,6 +261,49 @@ __device__ static void pnp_evaluate(PnpShared& S, const double* sm, int n, const
     __syncthreads();
 }
 
+// activeRobustChi2 of the active set at m candidate poses in ONE pass over the edges (the poses of the trials a rejection cascade
+// would try one after the other); the per-pose sums use the reduction of pnp_evaluate, so each equals what that trial would get
+__device__ static void pnp_chi2_multi(PnpShared& S, const double* sm, int n, int m, const double K[4], bool robust, double delta) {
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    double chi[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) chi[j] = 0.0;
+    for (int base = 0; base < n; base += PNP_THREADS) {
+        const int i = base + tid;
+        const bool valid = i < n && !S.lvl[i < n ? i : 0];
+        if (!valid) continue;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            if (j < m) {                                                       // (uniform; no break, so that chi[] stays in registers)
+                double e[2], p[3], om;
+                pnp_edge(sm, i, S.specT[j], K, e, p, om);
+                const double chi2 = e[0] * (om * e[0]) + e[1] * (om * e[1]);
+                double rho0 = chi2;
+                if (robust) {
+                    const double dsqr = delta * delta;
+                    if (!(chi2 <= dsqr)) { const double rs = pnp_rsqrt(chi2), sq = chi2 * rs; rho0 = 2 * sq * delta - dsqr; }
+                }
+                chi[j] += rho0;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        double v = chi[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (l == 0) S.specPart[wv][j] = v;
+    }
+    __syncthreads();
+    if (tid < 9) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < PNP_WAVES; k++) { v += S.specPart[k][tid]; v += 0.0; }     // (+ 0.0: the empty second block of pnp_evaluate's sum)
+        S.specChi[tid] = v;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
     extern __shared__ double s_m[];                   // n x {X(3), obs(2), inv_sigma2}
     __shared__ PnpShared S;
@@ -302,11 +347,8 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                     }
                 }
                 bool again, accepted_light = false;
-                if (tid == 0) S.ctl[4] = 0;                                    // the first trial of a solve() is evaluated in full
-                __syncthreads();
                 do {
                     bool ok2 = false;
-                    const bool light = S.ctl[4] != 0;
                     if (tid == 0) {
                         for (int j = 0; j < 6; j++) x[j] = 0.0;
                         ok2 = pnp_llt_solve(S.sys[0], lambda, S.sys[0] + 36, x);
@@ -315,7 +357,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                         S.Ttrial = Tn;
                     }
                     __syncthreads();
-                    pnp_evaluate(S, s_m, n, S.Ttrial, A.K, robust, delta, 1, !light);
+                    pnp_evaluate(S, s_m, n, S.Ttrial, A.K, robust, delta, 1);
                     if (tid == 0) {
                         double tempChi = S.sys[1][42];
                         if (!ok2) tempChi = DBL_MAX;
@@ -331,16 +373,61 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
                             alpha = fmin(alpha, 2. / 3.);
                             const double sf = fmax(1. / 3., alpha);
                             lambda *= sf; ni = 2.0; currentChi = tempChi;
-                            S.T = S.Ttrial; accepted = true; accepted_light = light;
+                            S.T = S.Ttrial; accepted = true;
                         } else {
                             lambda *= ni; ni *= 2.0;                           // pop: S.T stays
                             if (!isfinite(lambda)) brk = true;
-                            S.ctl[4] = 1;                                      // a rejection is usually followed by more (the cascade at
-                        }                                                      // convergence): those trials only need their chi2
+                        }
                         if (!brk) qmax++;
-                        S.ctl[0] = (!brk && rho < 0 && qmax < 10) ? 1 : 0;
+                        const bool more = !brk && rho < 0 && qmax < 10;
+                        // A rejection is usually followed by more (g2o's cascade of up to ten at convergence is most of the
+                        // evaluations of a call).  The trials that would follow only differ by lambda, so they are prepared side by
+                        // side — one lane each for the solve and the exponential — their chi2 come from ONE pass over the edges, and
+                        // the loop below replays g2o's decisions on them in order: same trials, same outcome, a fifth of the time.
+                        S.ctl[6] = more ? 10 - qmax : 0;
+                        S.specLambda[0] = lambda; S.specNi[0] = ni;
+                        S.ctl[0] = 0;
                     }
                     __syncthreads();
+                    const int m = S.ctl[6];
+                    if (m > 0) {
+                        if (tid < m) {
+                            double lj = S.specLambda[0], nj = S.specNi[0];
+                            for (int k = 0; k < tid; k++) { lj *= nj; nj *= 2.0; }
+                            double xj[6] = {0, 0, 0, 0, 0, 0};
+                            const bool okj = pnp_llt_solve(S.sys[0], lj, S.sys[0] + 36, xj);
+                            PnpPose E, Tn;
+                            pq_exp(xj, E); pq_mul(E, S.T, Tn);
+                            double sc = 0.0;
+                            for (int j = 0; j < 6; j++) sc += xj[j] * (lj * xj[j] + S.sys[0][36 + j]);
+                            sc += 1e-3;
+                            S.specT[tid] = Tn; S.specScale[tid] = sc; S.specOk[tid] = okj ? 1 : 0;
+                            if (tid > 0) { S.specLambda[tid] = lj; S.specNi[tid] = nj; }
+                        }
+                        __syncthreads();
+                        pnp_chi2_multi(S, s_m, n, m, A.K, robust, delta);
+                        if (tid == 0) {
+                            for (int j = 0; j < m; j++) {                      // the remaining trials, decided exactly as above
+                                double tempChi = S.specOk[j] ? S.specChi[j] : DBL_MAX;
+                                rho = (currentChi - tempChi) / S.specScale[j];
+                                bool brk = false;
+                                if (rho > 0 && isfinite(tempChi)) {
+                                    const double r21 = 2 * rho - 1;
+                                    double alpha = 1. - r21 * r21 * r21;
+                                    alpha = fmin(alpha, 2. / 3.);
+                                    const double sf = fmax(1. / 3., alpha);
+                                    lambda *= sf; ni = 2.0; currentChi = tempChi;
+                                    S.T = S.specT[j]; accepted = true; accepted_light = true;
+                                } else {
+                                    lambda *= ni; ni *= 2.0;
+                                    if (!isfinite(lambda)) brk = true;
+                                }
+                                if (!brk) qmax++;
+                                if (!(!brk && rho < 0 && qmax < 10)) break;
+                            }
+                        }
+                        __syncthreads();
+                    }
                     again = S.ctl[0] != 0;
                 } while (again);
                 if (tid == 0) {
