@@ -40,14 +40,21 @@ __device__ __forceinline__ void tap3(const void* img, int w, float x, float y, f
     gy = a.z * w00 + b.z * w01 + c.z * w10 + d.z * w11;
 }
 
+// value held by the lane of pattern pixel 4 in this lane's group of 8 (ds_swizzle, bit-mask mode: lane' = (lane & 0x18) | 0x04)
+__device__ __forceinline__ double bcast_pix4(double v) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x98), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x98);
+    return __hiloint2double(hi, lo);
+}
+
 __constant__ int c_star8[16] = {0, -2, -1, -1, 1, -1, -2, 0, 0, 0, 2, 0, -1, 1, 0, 2};   // types.h:1381-1393
 
 #define RES_PER_BLOCK 32
-#define NSHARE 9          // floats exchanged per pattern pixel (+ a row of ones for the product forms)
+#define NROWD 10          // fp64 rows exchanged per pattern pixel: F1 F2 a hw rF | pf, 2-hw0 | hw*hw, F1^2+F2^2 | zeros
 
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
-    __shared__ __attribute__((aligned(16))) float s_share[RES_PER_BLOCK][NSHARE][8];   // [residual][quantity][pixel]
+    __shared__ double s_shd[RES_PER_BLOCK][NROWD][9];                                  // [residual][quantity][pixel], fp64 operands of the sums (row stride padded to 72 B)
+    __shared__ float s_shf[RES_PER_BLOCK][3][8];                                       // fp32 operands of the product form: drdA, hw, ones
     __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE];
     __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK], s_app[RES_PER_BLOCK], s_sel[RES_PER_BLOCK], s_pos[RES_PER_BLOCK], s_ppos[RES_PER_BLOCK];
     __shared__ double s_ret[RES_PER_BLOCK];
@@ -79,15 +86,6 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const double E0 = pc->R0[0], E1 = pc->R0[1], E3 = pc->R0[3], E4 = pc->R0[4], E6 = pc->R0[6], E7 = pc->R0[7];
     const double et0 = pc->t0[0], et1 = pc->t0[1], et2 = pc->t0[2];
 
-    // ---- centre projection, BA.cpp:102-131 (identical on the 8 lanes)
-    const double rx = (cxd - A.cx) * A.fxi, ry = (cyd - A.cy) * A.fyi;
-    const double px = (R0_ * rx + R1_ * ry + R2_ * 1.0) + t0_ * idepth;
-    const double py = (R3_ * rx + R4_ * ry + R5_ * 1.0) + t1_ * idepth;
-    const double pz = (R6_ * rx + R7_ * ry + R8_ * 1.0) + t2_ * idepth;
-    const double Kud = (px / pz) * A.fx + A.cx, Kvd = (py / pz) * A.fy + A.cy;
-    const float drescale = (float)(1.0 / pz);
-    const bool centre_in = (Kud >= 2 && Kvd >= 2 && Kud < A.w - 2 && Kvd < A.h - 2);
-
     // ---- this lane's pattern pixel, BA.cpp:193-212
     const double sx = cxd + c_star8[2 * k], sy = cyd + c_star8[2 * k + 1];
     const double qx = (sx - A.cx) * A.fxi, qy = (sy - A.cy) * A.fyi;
@@ -96,6 +94,14 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const double ppz = (R6_ * qx + R7_ * qy + R8_ * 1.0) + t2_ * idepth;
     const double kx = (ppx / ppz) * A.fx + A.cx, ky = (ppy / ppz) * A.fy + A.cy;
     const bool pix_in = (kx >= 2 && ky >= 2 && kx < A.w - 2 && ky < A.h - 2);
+
+    // ---- centre projection, BA.cpp:102-131: pattern pixel 4 is the offset (0,0), so its lane has already evaluated the very same
+    //      expressions on the very same operands; the group takes them from there instead of issuing them again
+    const double rx = bcast_pix4(qx), ry = bcast_pix4(qy);
+    const double px = bcast_pix4(ppx), py = bcast_pix4(ppy), pz = bcast_pix4(ppz);
+    const double Kud = bcast_pix4(kx), Kvd = bcast_pix4(ky);
+    const float drescale = (float)(1.0 / pz);
+    const bool centre_in = (Kud >= 2 && Kvd >= 2 && Kud < A.w - 2 && Kvd < A.h - 2);
 
     float I = 0.f, gx = 0.f, gy = 0.f;
     const bool sample = run && centre_in && pix_in;
@@ -128,35 +134,44 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const float a_ = drdA * hw;
     const float rF = residual * hw;
 
-    s_share[g][0][k] = f1; s_share[g][1][k] = f2; s_share[g][2][k] = a_; s_share[g][3][k] = hw;
-    s_share[g][4][k] = drdA; s_share[g][5][k] = pf; s_share[g][6][k] = hw0; s_share[g][7][k] = rF; s_share[g][8][k] = 1.f;
+    // Every operand of the pattern sums is converted ONCE by the lane that owns the pixel (the casts and the per-pixel factors of the
+    // energy and wJI2 terms are the reference's own sub-expressions, so the sums below see the same values bit for bit).
+    {
+        const double f1d = (double)f1, f2d = (double)f2;
+        double* D = &s_shd[g][0][0];
+        D[0 * 9 + k] = f1d; D[1 * 9 + k] = f2d; D[2 * 9 + k] = (double)a_; D[3 * 9 + k] = (double)hw; D[4 * 9 + k] = (double)rF;
+        D[5 * 9 + k] = (double)pf; D[6 * 9 + k] = 2.0 - (double)hw0;                          // energy term, BA.cpp:237
+        D[7 * 9 + k] = (double)(hw * hw); D[8 * 9 + k] = f1d * f1d + f2d * f2d;              // wJI2_sum, BA.cpp:257
+        D[9 * 9 + k] = 0.0;
+        s_shf[g][0][k] = drdA; s_shf[g][1][k] = hw; s_shf[g][2][k] = 1.f;
+    }
     __syncthreads();
 
     // ---- pattern-order sums, BA.cpp:237,257-271 and the ACTIVE-mode inner products of BA.cpp:1719-1729.
-    // The 17 sums over the 8 pattern pixels have three arithmetic forms; lane k evaluates ONE sum of each form (same
-    // instructions in every lane, per-lane operand rows), so a wave issues 5 sums per pixel instead of 17:
-    //   A  acc = (float)((double)acc + (double)X*(double)Y)   k: J00 J10 J11 Q00 Q10 Q01 Q11 r^T r
-    //   B  acc += (double)rF*(double)Y (fp64)                 k: JI^T r (2), Jab^T r (2)
-    //   C  acc += ((p*q)*r)*s (fp32)                          k: B00 B01 B11        (multiplications by the ones row are exact)
-    // plus the energy and wJI2_sum, which every lane needs for the classification.  Statement order per sum is the reference's.
-    const float* SH = &s_share[g][0][0];
-    const int ax = (0x73232100 >> (4 * k)) & 15, ay = (0x71100110 >> (4 * k)) & 15;     // rows: 0 F1, 1 F2, 2 a, 3 hw, 4 drdA, 7 rF, 8 ones
-    const int by = (0x00003210 >> (4 * k)) & 15;
-    const float bmask = (k == 2 && !A.opt_a) || (k == 3 && !A.opt_b) ? 0.f : 1.f;          // BA.cpp:273-278
-    const int cp = k == 0 ? 4 : (k == 1 ? 4 : (k == 2 ? 3 : 8)), cq = k == 0 ? 4 : (k < 3 ? 3 : 8);
-    const int cr = k < 2 ? 3 : 8, cs = k == 0 ? 3 : 8;
-    float sumA = 0, sumC = 0, wJI2 = 0, E = 0;
+    // The 19 sums over the 8 pattern pixels have three arithmetic forms; lane k evaluates TWO sums of form A and one of B and C
+    // (same instructions in every lane, per-lane operand rows), so a wave issues 4 sums per pixel instead of 19:
+    //   A  acc = (float)((double)acc + X*Y)     first:  k: J00 J10 J11 Q00 Q10 Q01 Q11 r^T r      second:  k=0 energy, k=1 wJI2_sum
+    //   B  acc += rF*Y (fp64)                   k: JI^T r (2), Jab^T r (2)   (a masked column reads the row of zeros: BA.cpp:273-278)
+    //   C  acc += ((p*q)*r)*s (fp32)            k: B00 B01 B11               (multiplications by the ones row are exact)
+    // Statement order per sum is the reference's.
+    const double* SD = &s_shd[g][0][0];
+    const float* SF = &s_shf[g][0][0];
+    const int ax = (0x43232100 >> (4 * k)) & 15, ay = (0x41100110 >> (4 * k)) & 15;     // fp64 rows: 0 F1, 1 F2, 2 a, 3 hw, 4 rF
+    const int ex = k == 0 ? 5 : (k == 1 ? 7 : 9), ey = k == 0 ? 6 : (k == 1 ? 8 : 9);
+    const int by = ((k == 2 && !A.opt_a) || (k == 3 && !A.opt_b) || k > 3) ? 9 : k;
+    const int cp = k < 2 ? 0 : (k == 2 ? 1 : 2), cq = k == 0 ? 0 : (k < 3 ? 1 : 2);     // fp32 rows: 0 drdA, 1 hw, 2 ones
+    const int cr = k < 2 ? 1 : 2, cs = k == 0 ? 1 : 2;
+    float sumA = 0, sumE = 0, sumC = 0;
     double sumB = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const float F1 = SH[0 * 8 + j], F2 = SH[1 * 8 + j], HW = SH[3 * 8 + j], PF = SH[5 * 8 + j], HW0 = SH[6 * 8 + j], RF = SH[7 * 8 + j];
-        const double h1 = (double)F1, h2 = (double)F2;
-        E = (float)((double)E + (double)PF * (2.0 - (double)HW0));
-        wJI2 = (float)(wJI2 + (double)(HW * HW) * (h1 * h1 + h2 * h2));
-        sumA = (float)(sumA + (double)SH[ax * 8 + j] * (double)SH[ay * 8 + j]);
-        sumB += (double)RF * (double)(SH[by * 8 + j] * bmask);
-        sumC += SH[cp * 8 + j] * SH[cq * 8 + j] * SH[cr * 8 + j] * SH[cs * 8 + j];
+        sumA = (float)((double)sumA + SD[ax * 9 + j] * SD[ay * 9 + j]);
+        sumE = (float)((double)sumE + SD[ex * 9 + j] * SD[ey * 9 + j]);
+        sumB += SD[4 * 9 + j] * SD[by * 9 + j];
+        sumC += SF[cp * 8 + j] * SF[cq * 8 + j] * SF[cr * 8 + j] * SF[cs * 8 + j];
     }
+    const float E = sumE;                                             // lane 0 of the group: the energy; its neighbour holds wJI2_sum
+    const float wJI2 = __shfl(sumE, ((tid & 63) & ~7) + 1);
 
     // ---- geometric Jacobians, BA.cpp:120-188 (computed by every lane, each stores its share)
     const float new_idepth = (float)(drescale * idepth);
