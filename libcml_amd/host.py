@@ -54,6 +54,8 @@ def lib():
         L.cmlhost_ba_get_outliers.argtypes = [_vp, _P(_i)]
         L.cmlhost_ba_get_algebra.argtypes = [_vp, _P(_d), _P(_d), _P(_f), _P(abi.BAPair), _P(_d), _P(_d), _P(_d)]
         L.cmlhost_ba_orthogonalize.argtypes = [_vp, _P(_d), _i]
+        L.cmlhost_ba_set_indirect_points.argtypes = [_vp, _i, _P(_d), _i, _P(abi.ReprojObs)]
+        L.cmlhost_ba_get_indirect.argtypes = [_vp, _P(_d), _P(_d), _P(_d)]
         L.cmlhost_ba_stats.argtypes = [_vp, _P(_d), _i]
         L.cmlhost_tracker_create.restype = _vp; L.cmlhost_tracker_create.argtypes = [_vp]
         L.cmlhost_tracker_destroy.argtypes = [_vp]
@@ -241,6 +243,19 @@ class HostBA:
         x = np.ascontiguousarray(x, np.float64).copy()
         self.L.cmlhost_ba_orthogonalize(self.h, _p(x, _d), len(x))
         return x
+
+    def set_indirect_points(self, xyz, obs):
+        """The INDIRECTGROUP map points of the window's frames and their observations (abi.REPROJ_OBS_DTYPE), addIndirectToProblem's inputs."""
+        xyz = np.ascontiguousarray(xyz, np.float64); obs = np.ascontiguousarray(obs, abi.REPROJ_OBS_DTYPE)
+        self._n_indirect = len(xyz)
+        self.L.cmlhost_ba_set_indirect_points(self.h, len(xyz), _p(xyz, _d), len(obs), obs.ctypes.data_as(_P(abi.ReprojObs)))
+
+    def indirect(self):
+        """(indirectX of the last solve [6N], point uncertainties [M], x of the last solve [8N+4])"""
+        N = self.counts()["frames"]
+        x6 = np.zeros(6 * N); unc = np.zeros(max(getattr(self, "_n_indirect", 0), 1)); x = np.zeros(8 * N + 4)
+        n = self.L.cmlhost_ba_get_indirect(self.h, _p(x6, _d), _p(unc, _d), _p(x, _d))
+        return (x6 if n else None), unc[:getattr(self, "_n_indirect", 0)], x
 
     def energies(self, cap=16):
         e = np.zeros(cap)

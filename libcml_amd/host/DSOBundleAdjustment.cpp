@@ -484,6 +484,7 @@ bool DSOBundleAdjustment::solveSystem(int iteration, double lambda) {         //
     rc = cmlhip_ba_solve(mCtx, lambda, HM, bM, mOptimizeCalibration ? 1 : 0, mX.data());
     if (rc == CMLHIP_ERR_NONFINITE) { mError = "non-finite solution"; /* the reference dumps the system and carries on, :1323-1325 */ }
     else if (rc) return fail("cmlhip_ba_solve", rc);
+    if (N > 4 && !addIndirectToProblem(mX)) return false;                     // :1327-1329
     if (iteration >= 2) orthogonalize(mX);                                    // :1404 mustOrthogonalize
     auto norm = [](const std::vector<double>& v) { double s = 0; for (double a : v) s += a * a; return std::sqrt(s); };
     if (wantStats) { statHessianP.push_back(norm(HA)); statHessianSC.push_back(norm(Hsc)); statBP.push_back(norm(bA)); statBSC.push_back(norm(bsc)); }
@@ -496,6 +497,51 @@ bool DSOBundleAdjustment::solveSystem(int iteration, double lambda) {         //
     rc = cmlhip_ba_backsub(mCtx, mX.data(), nullptr);                          // :1455-1487
     if (rc == CMLHIP_ERR_NONFINITE) { mError = "points without a finite step"; return false; }   // :1489-1492
     if (rc) return fail("cmlhip_ba_backsub", rc);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ hybrid ORB term
+void DSOBundleAdjustment::setIndirectPoints(const std::vector<double>& worldXYZ, const std::vector<cmlhip_reproj_obs>& observations) {
+    mIndirectPoints = worldXYZ;
+    mIndirectObs = observations;
+    mIndirectUncertainty.assign(worldXYZ.size() / 3, 0.0);
+}
+
+// addIndirectToProblem, BA.cpp:2574-2729.  Device: the per-observation Jacobians (ReprojectionError::jacobian through
+// Dx_exp_x), the pose block of J J^T, b and the per-point Jacobian sums (cmlhip_reproj_accumulate), then
+// ldlt(M with diag*(1+fixedLambda)).solve(-bM) (cmlhip_reproj_solve).  Host: the literal weighting of :2714-2727 —
+// numIndirectPoint = 1 and numDirectPoint = 0 are constants there, so the pose part of x is REPLACED by the indirect solution.
+bool DSOBundleAdjustment::addIndirectToProblem(std::vector<double>& X) {
+    if (!mMixedBundleAdjustment) return true;                                 // :2575-2577
+    const int N = (int)mFrames.size(), M = (int)(mIndirectPoints.size() / 3), n = (int)mIndirectObs.size();
+    if (M == 0) return true;                                                  // :2587-2589
+    std::vector<double> poses(12 * (size_t)N), Jp(3 * (size_t)M);
+    for (int i = 0; i < N; i++) {                                             // frame->getCamera() is cameraOf(PRE_worldToCam) (:934, :966)
+        mFrames[i].PRE_worldToCam.matrix(&poses[12 * i]);
+        for (int k = 0; k < 3; k++) poses[12 * i + 9 + k] = mFrames[i].PRE_worldToCam.t[k];
+    }
+    int rc = cmlhip_reproj_accumulate(mCtx, N, poses.data(), M, mIndirectPoints.data(), n, mIndirectObs.data(), mPrm.fx, mPrm.fy,
+                                      nullptr, nullptr, Jp.data(), nullptr);
+    if (rc) return fail("cmlhip_reproj_accumulate", rc);
+    for (int j = 0; j < M; j++) {                                             // (Jp Jp^T).inverse().diagonal().norm(), :2690-2692: the inverse of
+        const double* a = &Jp[3 * j];                                         // a rank-one 3x3 by cofactors / determinant, whatever that gives
+        double A[9], C[3];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[3 * r + c] = a[r] * a[c];
+        C[0] = A[4] * A[8] - A[5] * A[7]; C[1] = A[0] * A[8] - A[2] * A[6]; C[2] = A[0] * A[4] - A[1] * A[3];
+        const double det = A[0] * C[0] - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+        const double d0 = C[0] / det, d1 = C[1] / det, d2 = C[2] / det;
+        mIndirectUncertainty[j] = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+    mIndirectX.assign(6 * (size_t)N, 0.0);
+    rc = cmlhip_reproj_solve(mCtx, N, mFixedLambda, mIndirectX.data());       // :2695-2700
+    if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_reproj_solve", rc);
+    for (double v : mIndirectX) if (!std::isfinite(v)) return true;           // :2702-2704
+    for (int i = 0; i < N; i++) {                                             // :2714-2727
+        const int numIndirectPoint = 1, numDirectPoint = 0;
+        const double indirectRatio = (double)numIndirectPoint / (double)(numIndirectPoint + numDirectPoint);
+        const double directRatio = 1.0 - indirectRatio;
+        for (int k = 0; k < 6; k++) X[4 + 8 * i + k] = X[4 + 8 * i + k] * directRatio + mIndirectX[6 * i + k] * indirectRatio;
+    }
     return true;
 }
 
@@ -573,7 +619,9 @@ bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // 
 bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        // BA.cpp:744-910
     // forceAccept + fixLambda + no marginalisation prior (the reference's defaults, BA.h:265-270): every step is accepted and
     // lambda never changes, so the loop body has no host decision left except the early exit, which the device mirrors
-    if (mResidentLoop && mForceAccept && mFixLambda && mDisableMarginalization && mNumIterations <= 40) return runResident(updatePointsOnly);
+    // (the hybrid ORB term replaces part of x on the host between the solve and the step: host loop)
+    if (mResidentLoop && mForceAccept && mFixLambda && mDisableMarginalization && mNumIterations <= 40 &&
+        !(mMixedBundleAdjustment && !mIndirectObs.empty())) return runResident(updatePointsOnly);
     return runHostLoop(updatePointsOnly);
 }
 

@@ -117,6 +117,14 @@ public:
     const std::vector<double>& marginalizedB() const { return mMarginalizedB; }
     const std::vector<int>& getOutliers() const { return mOutliers; }                            // point indices dropped by the last run
     void computeNullspaces(std::vector<double>& out7) const;                                     // BA.cpp:2365-2417
+    // ---- hybrid ORB term (BA.cpp:2574-2729, "mixedBundleAdjustment"): the INDIRECTGROUP map points of the window's frames
+    // (world coordinates) and their feature observations {DSOFrame id, point index, undistorted position}, handed over flat;
+    // solveSystem mixes the indirect pose solution into x between the solve and the orthogonalisation (BA.cpp:1327-1329)
+    void setIndirectPoints(const std::vector<double>& worldXYZ, const std::vector<cmlhip_reproj_obs>& observations);
+    bool addIndirectToProblem(std::vector<double>& X);
+    const std::vector<double>& indirectUncertainty() const { return mIndirectUncertainty; }     // MapPoint::setUncertainty, BA.cpp:2690-2692
+    const std::vector<double>& lastIndirectX() const { return mIndirectX; }
+    const std::vector<double>& lastX() const { return mX; }
 
     // ---- state access for the caller (what the reference writes back through Frame/MapPoint setters)
     std::vector<DSOFrame>& getFrames() { return mFrames; }
@@ -165,6 +173,8 @@ private:
     std::vector<int> mOutliers;
     std::vector<double> mAdHost, mAdTarget, mMarginalizedHessian, mMarginalizedB, mX;
     std::vector<float> mAdHTdeltaF;
+    std::vector<double> mIndirectPoints, mIndirectUncertainty, mIndirectX;
+    std::vector<cmlhip_reproj_obs> mIndirectObs;
     double mCDeltaF[4] = {0, 0, 0, 0};
     std::string mError;
 };

@@ -33,6 +33,7 @@ int cmlhost_ba_set_param(void* h, const char* name, double v) {
     else if (n == "ThOptIterations") b->mThOptIterations = v;
     else if (n == "iDepth Fix Prior") b->mIdepthFixPrior = (int)v;
     else if (n == "Solver mode delta") b->mSolverModeDelta = v;
+    else if (n == "mixedBundleAdjustment") b->mMixedBundleAdjustment = v != 0;
     else if (n == "residentLoop") b->mResidentLoop = v != 0;
     else if (n == "Minimum iDepth Hessian Marginlaization") b->mMinIdepthHMarg = v;
     else if (n == "maxFrames") b->mMaxFrames = (int)v;
@@ -79,6 +80,16 @@ int cmlhost_ba_get_prior(void* h, double* HM, double* bM) {          // returns 
 void cmlhost_ba_get_point_flags(void* h, unsigned char* toMarg, unsigned char* marginalized, float* idepthHessian) {
     const auto& P = static_cast<DSOBundleAdjustment*>(h)->getPoints();
     for (size_t i = 0; i < P.size(); i++) { if (toMarg) toMarg[i] = P[i].toMarginalize; if (marginalized) marginalized[i] = P[i].marginalized; if (idepthHessian) idepthHessian[i] = P[i].idepth_hessian; }
+}
+void cmlhost_ba_set_indirect_points(void* h, int M, const double* xyz, int n, const cmlhip_reproj_obs* obs) {   // addIndirectToProblem's inputs
+    static_cast<DSOBundleAdjustment*>(h)->setIndirectPoints(std::vector<double>(xyz, xyz + 3 * (size_t)M), std::vector<cmlhip_reproj_obs>(obs, obs + n));
+}
+int cmlhost_ba_get_indirect(void* h, double* x6, double* uncertainty, double* x) {   // last indirectX (6N), point uncertainties (M), last x (8N+4); returns 6N or 0
+    DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);
+    if (x6) std::copy(b->lastIndirectX().begin(), b->lastIndirectX().end(), x6);
+    if (uncertainty) std::copy(b->indirectUncertainty().begin(), b->indirectUncertainty().end(), uncertainty);
+    if (x) std::copy(b->lastX().begin(), b->lastX().end(), x);
+    return (int)b->lastIndirectX().size();
 }
 int cmlhost_ba_rejected(void* h) { return static_cast<DSOBundleAdjustment*>(h)->statRejected; }
 double cmlhost_ba_last_lambda(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastLambda; }
