@@ -11,7 +11,7 @@ from tests import dev_setup as D
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["tiny", "small"])
+@pytest.fixture(scope="module", params=["tiny", "small", "A", "B"])     # A, B: BASELINE.json configs[0] and configs[1] at full size
 def pair(request):
     I = S.make_inputs(request.param)
     ob = S.OracleBA(I)

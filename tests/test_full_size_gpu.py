@@ -1,5 +1,5 @@
 """BASELINE.json's full-size window (config B: 8 keyframes x 2000 points, R = 14000) on the device, checked through
-size-independent properties (the oracle comparison lives in the small-window tests):
+size-independent properties (the oracle comparison at this size is tests/test_ba_parity_gpu.py[B]):
   * index maps are exact partitions of the residual set;
   * H_A, H_sc symmetric, H_sc positive semi-definite, the solve's x satisfies the assembled system (backward error);
   * backup -> step -> restore is a bitwise round trip of the inverse depths;
