@@ -53,9 +53,11 @@ __constant__ int c_star8[16] = {0, -2, -1, -1, 1, -1, -2, 0, 0, 0, 2, 0, -1, 1, 
 
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
-    __shared__ double s_shd[RES_PER_BLOCK][NROWD][9];                                  // [residual][quantity][pixel], fp64 operands of the sums (row stride padded to 72 B)
-    __shared__ float s_shf[RES_PER_BLOCK][3][8];                                       // fp32 operands of the product form: drdA, hw, ones
-    __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE];
+    // LDS strides chosen against the bank maps of MI355X_MICROARCH.md (b64 reads: 32 lanes = 4 residuals over 64 banks; b32: over 32 banks):
+    // residual stride = 16 dwords mod 64 for the fp64 rows (row stride 18 dwords), 25 dwords for the fp32 rows, 88 dwords for the records
+    __shared__ double s_shd[RES_PER_BLOCK][104];                                       // [residual][quantity * 9 + pixel], fp64 operands of the sums
+    __shared__ float s_shf[RES_PER_BLOCK][25];                                         // [residual][quantity * 8 + pixel], fp32 operands of the product form: drdA, hw, ones
+    __shared__ __attribute__((aligned(16))) float s_rec[RES_PER_BLOCK][RJ_STRIDE + 8];
     __shared__ int s_write[RES_PER_BLOCK], s_ns[RES_PER_BLOCK], s_flip[RES_PER_BLOCK], s_app[RES_PER_BLOCK], s_sel[RES_PER_BLOCK], s_pos[RES_PER_BLOCK], s_ppos[RES_PER_BLOCK];
     __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
@@ -138,12 +140,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     // energy and wJI2 terms are the reference's own sub-expressions, so the sums below see the same values bit for bit).
     {
         const double f1d = (double)f1, f2d = (double)f2;
-        double* D = &s_shd[g][0][0];
+        double* D = &s_shd[g][0];
         D[0 * 9 + k] = f1d; D[1 * 9 + k] = f2d; D[2 * 9 + k] = (double)a_; D[3 * 9 + k] = (double)hw; D[4 * 9 + k] = (double)rF;
         D[5 * 9 + k] = (double)pf; D[6 * 9 + k] = 2.0 - (double)hw0;                          // energy term, BA.cpp:237
         D[7 * 9 + k] = (double)(hw * hw); D[8 * 9 + k] = f1d * f1d + f2d * f2d;              // wJI2_sum, BA.cpp:257
         D[9 * 9 + k] = 0.0;
-        s_shf[g][0][k] = drdA; s_shf[g][1][k] = hw; s_shf[g][2][k] = 1.f;
+        s_shf[g][k] = drdA; s_shf[g][8 + k] = hw; s_shf[g][16 + k] = 1.f;
     }
     __syncthreads();
 
@@ -154,8 +156,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     //   B  acc += rF*Y (fp64)                   k: JI^T r (2), Jab^T r (2)   (a masked column reads the row of zeros: BA.cpp:273-278)
     //   C  acc += ((p*q)*r)*s (fp32)            k: B00 B01 B11               (multiplications by the ones row are exact)
     // Statement order per sum is the reference's.
-    const double* SD = &s_shd[g][0][0];
-    const float* SF = &s_shf[g][0][0];
+    const double* SD = &s_shd[g][0];
+    const float* SF = &s_shf[g][0];
     const int ax = (0x43232100 >> (4 * k)) & 15, ay = (0x41100110 >> (4 * k)) & 15;     // fp64 rows: 0 F1, 1 F2, 2 a, 3 hw, 4 rF
     const int ex = k == 0 ? 5 : (k == 1 ? 7 : 9), ey = k == 0 ? 6 : (k == 1 ? 8 : 9);
     const int by = ((k == 2 && !A.opt_a) || (k == 3 && !A.opt_b) || k > 3) ? 9 : k;
