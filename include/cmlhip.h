@@ -36,7 +36,15 @@ extern "C" {
 #define CMLHIP_ABI_VERSION 1
 #define CMLHIP_PATTERN 8        /* star8, src/cml/types.h:1381-1407; DSOMAXRESPERPOINT, DSOResidual.h:10 */
 #define CMLHIP_CPARS 4          /* calibration block size, ACC.h:26 */
-#define CMLHIP_MAX_FRAMES 32    /* window size limit of this layer (reference default maxFrames = 6, BA.h:271) */
+#define CMLHIP_MAX_FRAMES 32    /* window size limit of the upload / accumulate / Schur kernels (reference default maxFrames = 6, BA.h:271) */
+/* Hard caps that are REFUSALS (CMLHIP_ERR_INVALID with a message in cmlhip_last_error), not fallbacks:
+ *   - cmlhip_ba_solve / cmlhip_ba_iteration_async: the factorisation is LDS-resident, 8N (+4 with optimize_calibration) <= 160,
+ *     i.e. N <= 20 (19 with the calibration block).  Wider windows upload, linearize and accumulate, and are refused by the solve.
+ *   - cmlhip_pnp_optimize: at most CMLHIP_PNP_MAX_MATCHES matches (LDS-resident match list).
+ *   - the dense LDL^T is unpivoted (Eigen's ldlt() pivots): it relies on the Jacobi scaling 1/sqrt(diag + 10) of BA.cpp:1312-1316,
+ *     which bounds the scaled diagonal; a non-finite or non-positive pivot is reported as CMLHIP_ERR_NONFINITE. */
+#define CMLHIP_MAX_SOLVE_FRAMES 20
+#define CMLHIP_PNP_MAX_MATCHES 2560
 #define CMLHIP_RJ_FLOATS 74     /* sizeof(DSORawResidualJacobian)/4, DSOResidual.h:22-69 */
 
 typedef enum {

@@ -347,7 +347,12 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
 __global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
     const int NN = A.N * A.N;
     DBG_BLK(A.dbg, 1, 0);
-    if (A.ctl && A.ctl->stop) return;                      // converged: the loop of BA::run has left (BA.cpp:879)
+    if (A.ctl && A.ctl->stop) {                            // converged: the loop of BA::run has left (BA.cpp:879)
+        // the residual kernel must not test the flag its own launch publishes (blocks scheduled after the publishing one would
+        // skip residuals of the pass that must still complete): it tests `stop_lin`, which is raised HERE, one launch later
+        if (blockIdx.x == 0 && threadIdx.x == 0) A.ctl->stop_lin = 1;
+        return;
+    }
     if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode);
     else point_rows_block(A, X, blockIdx.x - NN);      // 16 points per 1024-thread block
     DBG_BLK_END(A.dbg, 1);
@@ -1089,13 +1094,13 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     double* pbL = c->pair_blocks.as<double>() + (size_t)PB_STRIDE * NN;
     if (marg) {                                          // marginalizePointsF: MARGINALIZED-mode blocks of the selected points only
         k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, X, CMLHIP_MODE_MARGINALIZED);
-        k_ba_point_rows_marg<<<cml_div_up(A.P, 64), 64, 0, c->stream>>>(A, X);
+        if (A.P > 0) k_ba_point_rows_marg<<<cml_div_up(A.P, 64), 64, 0, c->stream>>>(A, X);
     } else if (!system_only) {
         if (c->n_lin > 0) {                              // rare path: LINEARIZED residuals present
             AccArgs XL = X;
             XL.acc_out = c->acc_pair[1].as<float>(); XL.num_out = c->acc_num[1].as<int>(); XL.pair_blocks = pbL;
             k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
-            k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
+            if (A.P > 0) k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
         }
         k_ba_acc<<<NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, c->stream>>>(A, X, 0);
     }
@@ -1136,8 +1141,7 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
     Y.Hb = c->Hf.as<double>(); Y.bb = c->bf.as<double>(); Y.part = c->syrk_part.as<double>();
     Y.nsl = cml_sys_slices(A.P); Y.ntile = ldg_of(n) / 16; Y.lambda = c->sys_lambda;
 #define LAUNCH_SOLVE(NSL) do { \
-        static bool attr_set = false; \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        if (!(c->attr_done & (1u << NSL))) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c->attr_done |= 1u << NSL; } \
         k_ba_solve<NSL><<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag, \
             c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->n_lin_partial, c->scal.as<LinSummary>(), \
             c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr); } while (0)
@@ -1162,19 +1166,20 @@ int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
         for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
         F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
     }
+    if (cml_div_up(A.P * 8, 256) + F.on == 0) return CMLHIP_OK;     // no points and no frame step: nothing to launch (a zero grid is a HIP error)
     k_ba_backsub<<<cml_div_up(A.P * 8, 256) + F.on, 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
                                                                       c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0, F);
     return CMLHIP_OK;
 }
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A) {
-    k_ba_backup_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A);
+    if (A.P > 0) k_ba_backup_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A);
     return CMLHIP_OK;
 }
 int cml_launch_restore_points(cmlhip_ctx* c, const BAArgs& A) {
-    k_ba_restore_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A);
+    if (A.P > 0) k_ba_restore_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A);
     return CMLHIP_OK;
 }
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A) {
-    k_ba_step_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->step_partial.as<float>());
+    if (A.P > 0) k_ba_step_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->step_partial.as<float>());
     return CMLHIP_OK;
 }

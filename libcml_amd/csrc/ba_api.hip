@@ -46,7 +46,7 @@ static inline int ldg_of(int n) { return ((n + 1 + 15) / 16) * 16; }
 
 extern "C" {
 
-int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) {
+int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) { CML_DEV(c);
     if (!c || !prm) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, prm->w > 4 && prm->h > 4 && prm->fx != 0 && prm->fy != 0, CMLHIP_ERR_INVALID, "bad BA params");
     c->ba_prm = *prm;
@@ -55,7 +55,7 @@ int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) {
 }
 
 int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames, int P, const cmlhip_ba_point* points,
-                            int R, const cmlhip_ba_residual* res) {
+                            int R, const cmlhip_ba_residual* res) { CML_DEV(c);
     if (!c || !frames || (P > 0 && !points) || (R > 0 && !res)) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, c->ba_prm_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_params not called");
     CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P >= 0 && P <= c->lim.max_points && R >= 0 && R <= c->lim.max_residuals,
@@ -206,7 +206,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_window_size(cmlhip_ctx* c, int* N, int* P, int* R) {
+int cmlhip_ba_window_size(cmlhip_ctx* c, int* N, int* P, int* R) { CML_DEV(c);
     if (!c) return CMLHIP_ERR_INVALID;
     if (N) *N = c->ba_uploaded ? c->N : 0;
     if (P) *P = c->ba_uploaded ? c->P : 0;
@@ -214,7 +214,7 @@ int cmlhip_ba_window_size(cmlhip_ctx* c, int* N, int* P, int* R) {
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) {
+int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (!pairs) return CMLHIP_ERR_INVALID;
@@ -224,7 +224,7 @@ int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) {
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) {
+int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (!th) return CMLHIP_ERR_INVALID;
@@ -235,7 +235,7 @@ int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) {
     return cml_h2d(c, c->frames.p, fd.data(), sizeof(FrameDev) * c->N);
 }
 
-int cmlhip_ba_set_idepth(cmlhip_ctx* c, const double* idepth, const float* idepth_zero) {
+int cmlhip_ba_set_idepth(cmlhip_ctx* c, const double* idepth, const float* idepth_zero) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (!idepth) return CMLHIP_ERR_INVALID;
@@ -243,13 +243,13 @@ int cmlhip_ba_set_idepth(cmlhip_ctx* c, const double* idepth, const float* idept
     if (!rc && idepth_zero) rc = cml_h2d(c, c->pt_idepth_zero.p, idepth_zero, 4 * (size_t)c->P);
     return rc;
 }
-int cmlhip_ba_get_idepth(cmlhip_ctx* c, double* idepth) {
+int cmlhip_ba_get_idepth(cmlhip_ctx* c, double* idepth) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     return cml_d2h(c, idepth, c->pt_idepth.p, 8 * (size_t)c->P);
 }
 
-int cmlhip_ba_linearize_async(cmlhip_ctx* c) {
+int cmlhip_ba_linearize_async(cmlhip_ctx* c) { CML_DEV(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
     BAArgs A;
@@ -260,7 +260,7 @@ int cmlhip_ba_linearize_async(cmlhip_ctx* c) {
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_linearize(cmlhip_ctx* c, cmlhip_ba_lin_result* out) {
+int cmlhip_ba_linearize(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DEV(c);
     int rc = cmlhip_ba_linearize_async(c);
     if (rc) return rc;
     LinSummary S;
@@ -273,7 +273,7 @@ int cmlhip_ba_linearize(cmlhip_ctx* c, cmlhip_ba_lin_result* out) {
     return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
 }
 
-int cmlhip_ba_apply(cmlhip_ctx* c, int copy) {
+int cmlhip_ba_apply(cmlhip_ctx* c, int copy) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     BAArgs A;
@@ -284,7 +284,7 @@ int cmlhip_ba_apply(cmlhip_ctx* c, int copy) {
 }
 
 int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* state, int* new_state, float* energy, float* new_energy,
-                              float* new_energy_wo, unsigned char* is_good, double* idepth, float* point_acc) {
+                              float* new_energy_wo, unsigned char* is_good, double* idepth, float* point_acc) { CML_DEV(c);
     int rc = cmlhip_ba_linearize_async(c);
     if (rc) return rc;
     BAArgs A;
@@ -323,7 +323,7 @@ static int upload_accum_in(cmlhip_ctx* c, const cmlhip_ba_accum_in* in) {
 }
 
 int cmlhip_ba_accumulate(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* HA, double* bA, double* HL, double* bL,
-                         double* Hsc, double* bsc) {
+                         double* Hsc, double* bsc) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior)
@@ -344,7 +344,7 @@ int cmlhip_ba_accumulate(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* HA
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_solve(cmlhip_ctx* c, double lambda, const double* HM, const double* bM, int optcal, double* x) {
+int cmlhip_ba_solve(cmlhip_ctx* c, double lambda, const double* HM, const double* bM, int optcal, double* x) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     const size_t n = 8 * (size_t)c->N + 4;
@@ -365,7 +365,7 @@ int cmlhip_ba_solve(cmlhip_ctx* c, double lambda, const double* HM, const double
     return flag ? CMLHIP_ERR_NONFINITE : CMLHIP_OK;
 }
 
-int cmlhip_ba_backsub(cmlhip_ctx* c, const double* x, double* step) {
+int cmlhip_ba_backsub(cmlhip_ctx* c, const double* x, double* step) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     const size_t n = 8 * (size_t)c->N + 4;
@@ -381,7 +381,7 @@ int cmlhip_ba_backsub(cmlhip_ctx* c, const double* x, double* step) {
     return S.nonfinite ? CMLHIP_ERR_NONFINITE : CMLHIP_OK;
 }
 
-int cmlhip_ba_backup_points(cmlhip_ctx* c) {
+int cmlhip_ba_backup_points(cmlhip_ctx* c) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     BAArgs A;
@@ -391,7 +391,7 @@ int cmlhip_ba_backup_points(cmlhip_ctx* c) {
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_restore_points(cmlhip_ctx* c) {
+int cmlhip_ba_restore_points(cmlhip_ctx* c) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     BAArgs A;
@@ -403,7 +403,8 @@ int cmlhip_ba_restore_points(cmlhip_ctx* c) {
 
 static int read_step_sums(cmlhip_ctx* c, float sums[3]) {
     const int nb = (c->P + 255) / 256;
-    std::vector<float> part(4 * (size_t)(nb ? nb : 1));
+    if (nb == 0) { sums[0] = sums[1] = sums[2] = 0.f; return CMLHIP_OK; }      // a window without points: empty sums, no copy
+    std::vector<float> part(4 * (size_t)nb);
     int rc = cml_d2h(c, part.data(), c->step_partial.p, 16 * (size_t)nb);
     if (rc) return rc;
     float a = 0, b = 0, n = 0;
@@ -412,7 +413,7 @@ static int read_step_sums(cmlhip_ctx* c, float sums[3]) {
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) {
+int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     BAArgs A;
@@ -426,7 +427,7 @@ int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) {
 // one Gauss-Newton iteration enqueued back to back, no host round trip (iterations 0 and 1 of BA::run, which do
 // not orthogonalise: BA.cpp:1404 `iteration >= 2`): backup -> accumulate -> solve -> backsub -> step -> linearize -> apply.
 // The adjoints / priors of the last cmlhip_ba_accumulate call are reused.
-int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) {
+int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
     BAArgs A;
@@ -463,7 +464,7 @@ static int upload_point_mask(cmlhip_ctx* c, int n, const int* idx) {
     return cml_h2d(c, c->pt_mask.p, m.data(), m.size());
 }
 
-int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good) {
+int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good) { CML_DEV(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
@@ -489,7 +490,7 @@ int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
 }
 
 int cmlhip_ba_marginalize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, double* M, double* Mb,
-                                 double* Msc, double* Mbsc) {
+                                 double* Msc, double* Mbsc) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
@@ -510,7 +511,7 @@ int cmlhip_ba_marginalize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* energy, int* num) {
+int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* energy, int* num) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (!in || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->adHost || !in->adTarget || !in->cprior) return CMLHIP_ERR_INVALID;
@@ -538,7 +539,7 @@ int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* en
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_get_res_to_zero(cmlhip_ctx* c, float* rtz, unsigned char* is_lin) {
+int cmlhip_ba_get_res_to_zero(cmlhip_ctx* c, float* rtz, unsigned char* is_lin) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (rtz && (rc = cml_d2h(c, rtz, c->r_rtz.p, 32 * (size_t)c->R))) return rc;
@@ -547,7 +548,7 @@ int cmlhip_ba_get_res_to_zero(cmlhip_ctx* c, float* rtz, unsigned char* is_lin) 
 }
 
 int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, const cmlhip_ba_frame_state* frames, const double scales[4],
-                                 const double* nullspace_basis) {
+                                 const double* nullspace_basis) { CML_DEV(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || !frames || !scales)
@@ -569,7 +570,7 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, co
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_resident_convergence(cmlhip_ctx* c, double th_opt_iterations) {
+int cmlhip_ba_resident_convergence(cmlhip_ctx* c, double th_opt_iterations) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
@@ -579,7 +580,7 @@ int cmlhip_ba_resident_convergence(cmlhip_ctx* c, double th_opt_iterations) {
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_get_resident_log(cmlhip_ctx* c, int* iterations, double* energies, int capacity) {
+int cmlhip_ba_get_resident_log(cmlhip_ctx* c, int* iterations, double* energies, int capacity) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
@@ -599,7 +600,7 @@ int cmlhip_ba_get_resident_log(cmlhip_ctx* c, int* iterations, double* energies,
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_get_resident_state(cmlhip_ctx* c, cmlhip_ba_frame_state* frames, double* pre_w2c, cmlhip_ba_lin_result* last) {
+int cmlhip_ba_get_resident_state(cmlhip_ctx* c, cmlhip_ba_frame_state* frames, double* pre_w2c, cmlhip_ba_lin_result* last) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
@@ -622,7 +623,7 @@ int cmlhip_ba_get_resident_state(cmlhip_ctx* c, cmlhip_ba_frame_state* frames, d
     return CMLHIP_OK;
 }
 
-int cmlhip_debug_timestamps(cmlhip_ctx* c, int enable, long long* out128) {
+int cmlhip_debug_timestamps(cmlhip_ctx* c, int enable, long long* out128) { CML_DEV(c);
     const size_t NS = CMLHIP_DEBUG_SLOTS;
     if (!c) return CMLHIP_ERR_INVALID;
     int rc = cml_ensure(c, c->dbg, NS * sizeof(long long));
@@ -633,7 +634,7 @@ int cmlhip_debug_timestamps(cmlhip_ctx* c, int enable, long long* out128) {
     return CMLHIP_OK;
 }
 
-int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) {
+int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) { CML_DEV(c);
     if (!c || max_iterations < 0) return CMLHIP_ERR_INVALID;
     (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -644,13 +645,13 @@ int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) {
     return CMLHIP_OK;
 }
 
-int cmlhip_profile_stride(cmlhip_ctx* c, int stride) {
+int cmlhip_profile_stride(cmlhip_ctx* c, int stride) { CML_DEV(c);
     if (!c || stride < 1) return CMLHIP_ERR_INVALID;
     c->prof_stride = stride; c->prof_tick = 0;
     return CMLHIP_OK;
 }
 
-int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, float* empty_ms, int* n) {
+int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, float* empty_ms, int* n) { CML_DEV(c);
     if (!c) return CMLHIP_ERR_INVALID;
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     double a = 0, b = 0, e = 0;
@@ -671,7 +672,7 @@ int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, float* empty
 
 // ---------------------------------------------------------------------------------------------- readbacks
 int cmlhip_ba_get_states(cmlhip_ctx* c, int* state, int* new_state, float* energy, float* new_energy, float* new_energy_wo,
-                         unsigned char* is_good) {
+                         unsigned char* is_good) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     const size_t R = c->R;
@@ -685,7 +686,7 @@ int cmlhip_ba_get_states(cmlhip_ctx* c, int* state, int* new_state, float* energ
     return cml_d2h_batch_flush(c);
 }
 
-int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) {
+int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (!out) return CMLHIP_ERR_INVALID;
@@ -703,17 +704,17 @@ int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) {
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_get_jpjdf(cmlhip_ctx* c, float* out) {
+int cmlhip_ba_get_jpjdf(cmlhip_ctx* c, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     return cml_d2h(c, out, c->r_jpjdf.p, 32 * (size_t)c->R);
 }
-int cmlhip_ba_get_center_projected(cmlhip_ctx* c, float* out) {
+int cmlhip_ba_get_center_projected(cmlhip_ctx* c, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     return cml_d2h(c, out, c->r_center.p, 12 * (size_t)c->R);
 }
-int cmlhip_ba_get_point_acc(cmlhip_ctx* c, float* out) {
+int cmlhip_ba_get_point_acc(cmlhip_ctx* c, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     std::vector<float> t(PT_ACC_STRIDE * (size_t)c->P);
@@ -721,7 +722,7 @@ int cmlhip_ba_get_point_acc(cmlhip_ctx* c, float* out) {
     for (int p = 0; p < c->P; p++) memcpy(out + 14 * (size_t)p, &t[PT_ACC_STRIDE * (size_t)p], 14 * 4);
     return CMLHIP_OK;
 }
-int cmlhip_ba_get_pair_acc(cmlhip_ctx* c, int mode, float* out) {
+int cmlhip_ba_get_pair_acc(cmlhip_ctx* c, int mode, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (mode < 0 || mode > 1 || !out) return CMLHIP_ERR_INVALID;
@@ -741,7 +742,7 @@ int cmlhip_ba_get_pair_acc(cmlhip_ctx* c, int mode, float* out) {
     }
     return CMLHIP_OK;
 }
-int cmlhip_ba_get_index_maps(cmlhip_ctx* c, int* pair_of, int* bpo, int* bp, int* bqo, int* bq) {
+int cmlhip_ba_get_index_maps(cmlhip_ctx* c, int* pair_of, int* bpo, int* bp, int* bqo, int* bq) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     if (pair_of) memcpy(pair_of, c->h_pair_of.data(), 4 * (size_t)c->R);

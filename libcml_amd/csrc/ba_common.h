@@ -36,7 +36,9 @@ struct ResidentCtl {
     int stop;                 // sticky
     int iters_done;           // iterations that really ran
     float frame_sums[4];      // sumA sumB sumT sumR of the last frame step (doStepFromBackup, BA.cpp:957-972)
-    int pad[2];
+    int stop_lin;             // `stop` as the residual kernel sees it: raised by the first launch AFTER the one that set `stop`, so that
+                              // the residual pass which detects convergence still runs to completion in every workgroup
+    int pad;
     double energy[40];        // photometric energy after iteration i (statEnergyP)
 };
 #define CML_CTL_OFFSET 640

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     __shared__ double s_ret[RES_PER_BLOCK];
     const int tid = threadIdx.x, g = tid >> 3, k = tid & 7;
     DBG_BLK(A.dbg, 0, 0);
-    if (A.ctl && A.ctl->stop) return;                      // converged: the loop of BA::run has left (BA.cpp:879)
+    if (A.ctl && A.ctl->stop_lin) return;                  // converged in an EARLIER launch (raised by k_ba_acc): the loop of BA::run has left (BA.cpp:879)
     const int r = blockIdx.x * RES_PER_BLOCK + g;
     // ---- per-residual inputs (all 8 lanes of the group read the same addresses: broadcast).  Every load is unconditional
     //      on a clamped index — a `cond ? load : 0` costs its own branch and memory round trip — and what the tail of the

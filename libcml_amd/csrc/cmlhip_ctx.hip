@@ -194,7 +194,7 @@ int cmlhip_create(cmlhip_ctx** out, const cmlhip_limits* lim) {
     return CMLHIP_OK;
 }
 
-void cmlhip_destroy(cmlhip_ctx* c) {
+void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -225,19 +225,19 @@ void cmlhip_destroy(cmlhip_ctx* c) {
 
 const char* cmlhip_last_error(const cmlhip_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-int cmlhip_synchronize(cmlhip_ctx* c) {
+int cmlhip_synchronize(cmlhip_ctx* c) { CML_DEV(c);
     if (!c) return CMLHIP_ERR_INVALID;
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     return CMLHIP_OK;
 }
 void* cmlhip_stream(cmlhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-int cmlhip_event_mark(cmlhip_ctx* c, int which) {
+int cmlhip_event_mark(cmlhip_ctx* c, int which) { CML_DEV(c);
     if (!c || which < 0 || which > 1) return CMLHIP_ERR_INVALID;
     CML_CHECK(c, hipEventRecord(c->ev[which], c->stream));
     return CMLHIP_OK;
 }
-int cmlhip_event_elapsed_ms(cmlhip_ctx* c, float* ms) {
+int cmlhip_event_elapsed_ms(cmlhip_ctx* c, float* ms) { CML_DEV(c);
     if (!c || !ms) return CMLHIP_ERR_INVALID;
     CML_CHECK(c, hipEventSynchronize(c->ev[1]));
     CML_CHECK(c, hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
@@ -330,7 +330,7 @@ static void free_level(cmlhip_ctx* c, PyrLevel& L) {
 
 extern "C" {
 
-int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3, int w, int h) {
+int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3, int w, int h) { CML_DEV(c);
     if (!c || !aos3 || level < 0 || level >= 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
     PyrLevel& L = P.lv[level];
@@ -351,7 +351,7 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
     return CMLHIP_OK;                                                   // (the staging buffer is reused in stream order)
 }
 
-int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, int h, int levels) {
+int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, int h, int levels) { CML_DEV(c);
     if (!c || !gray || levels < 1 || levels > 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
     (void)hipStreamSynchronize(c->stream);
@@ -382,7 +382,7 @@ int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, i
     return CMLHIP_OK;
 }
 
-int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) {
+int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) { CML_DEV(c);
     if (!c) return CMLHIP_ERR_INVALID;
     auto it = c->pyr.find(id);
     if (it == c->pyr.end()) return CMLHIP_ERR_NOT_FOUND;
@@ -392,7 +392,7 @@ int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) {
     return CMLHIP_OK;
 }
 
-int cmlhip_pyramid_level_size(cmlhip_ctx* c, uint64_t id, int level, int* w, int* h) {
+int cmlhip_pyramid_level_size(cmlhip_ctx* c, uint64_t id, int level, int* w, int* h) { CML_DEV(c);
     if (!c) return CMLHIP_ERR_INVALID;
     const Pyramid* P = cml_find_pyr(c, id);
     if (!P || level < 0 || level >= P->levels || !P->lv[level].grad) return CMLHIP_ERR_NOT_FOUND;
@@ -401,7 +401,7 @@ int cmlhip_pyramid_level_size(cmlhip_ctx* c, uint64_t id, int level, int* w, int
     return CMLHIP_OK;
 }
 
-int cmlhip_pyramid_get(cmlhip_ctx* c, uint64_t id, int level, float* out) {
+int cmlhip_pyramid_get(cmlhip_ctx* c, uint64_t id, int level, float* out) { CML_DEV(c);
     if (!c || !out) return CMLHIP_ERR_INVALID;
     const Pyramid* P = cml_find_pyr(c, id);
     if (!P || level < 0 || level >= P->levels || !P->lv[level].grad) return CMLHIP_ERR_NOT_FOUND;

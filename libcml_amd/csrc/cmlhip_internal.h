@@ -47,6 +47,7 @@ struct FrameDev {
 struct cmlhip_ctx {
     cmlhip_limits lim{};
     int device = 0;
+    unsigned attr_done = 0;       // hipFuncSetAttribute(MaxDynamicSharedMemorySize) already applied on this context's device, one bit per kernel
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::string err;
@@ -109,6 +110,10 @@ struct cmlhip_ctx {
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x;
 };
+
+// every extern "C" entry selects its context's device first: the current device is per-thread state and a process may own
+// contexts on several GPUs
+#define CML_DEV(ctx) do { if (ctx) (void)hipSetDevice((ctx)->device); } while (0)
 
 #define CML_CHECK(ctx, call)                                                                      \
     do {                                                                                          \

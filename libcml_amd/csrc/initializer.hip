@@ -223,7 +223,7 @@ extern "C" {
 
 int cmlhip_initializer_calc_res_and_gs(cmlhip_ctx* c, uint64_t image_id, int level, const cmlhip_init_params* prm, int n,
                                        cmlhip_init_point* points, float* H_out, float* b_out, float* H_out_sc, float* b_out_sc,
-                                       float res[3]) {
+                                       float res[3]) { CML_DEV(c);
     if (!c || !prm || n < 0 || (n > 0 && !points) || !H_out || !b_out || !H_out_sc || !b_out_sc || !res) return CMLHIP_ERR_INVALID;
     const Pyramid* py = cml_find_pyr(c, image_id);
     CML_REQUIRE(c, py && level >= 0 && level < py->levels && py->lv[level].grad, CMLHIP_ERR_NOT_FOUND, "tracked image / level not in the pyramid cache");

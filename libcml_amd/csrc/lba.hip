@@ -724,7 +724,7 @@ extern "C" {
 
 int cmlhip_lba_optimize(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, int n_points, double* points, const int* point_offsets,
                         const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations, unsigned char* edge_bad,
-                        cmlhip_lba_result* out) {
+                        cmlhip_lba_result* out) { CML_DEV(c);
     if (!c || !out || n_frames < 1 || !frames || n_points < 0 || !point_offsets || num_iterations < 0) return CMLHIP_ERR_INVALID;
     *out = cmlhip_lba_result{};
     const int n_edges = point_offsets[n_points];

@@ -20,7 +20,7 @@
 
 #define PNP_THREADS 256
 #define PNP_WAVES (PNP_THREADS / 64)
-#define PNP_MAX_MATCHES 2560             // 48 B of LDS per match (120 KB) + tiles: under the 160 KB of a CU
+#define PNP_MAX_MATCHES CMLHIP_PNP_MAX_MATCHES             // 48 B of LDS per match (120 KB) + tiles: under the 160 KB of a CU
 typedef double pnp_double4 __attribute__((ext_vector_type(4)));
 
 struct PnpPose { double x, y, z, w, t[3]; };                 // Eigen coefficient order
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_optimize(PnpArgs A) {
 extern "C" {
 
 int cmlhip_pnp_optimize(cmlhip_ctx* c, const double R[9], const double t[3], const double K[4], int n, const cmlhip_pnp_match* matches,
-                        unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out) {
+                        unsigned char* outliers, int algorithm, int check_outliers, int compute_covariance, cmlhip_pnp_result* out) { CML_DEV(c);
     if (!c || !R || !t || !K || n < 0 || (n > 0 && (!matches || !outliers)) || !out) return CMLHIP_ERR_INVALID;
     if (algorithm != CMLHIP_PNP_LEVENBERG && algorithm != CMLHIP_PNP_GAUSS_NEWTON) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, n <= PNP_MAX_MATCHES, CMLHIP_ERR_INVALID, "more matches than the LDS-resident pose optimiser holds (2560)");
@@ -540,10 +540,9 @@ int cmlhip_pnp_optimize(cmlhip_ctx* c, const double R[9], const double t[3], con
     A.algorithm = algorithm; A.check = check_outliers ? 1 : 0; A.cov = compute_covariance ? 1 : 0;
     A.out = c->pnp_out.as<cmlhip_pnp_result>();
     const size_t dyn = sizeof(double) * 6 * (size_t)n;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(c->attr_done & (1u << 16))) {                              // per context (= per device), not a process-wide static
         CML_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 6 * PNP_MAX_MATCHES)));
-        attr_set = true;
+        c->attr_done |= 1u << 16;
     }
     k_pnp_optimize<<<1, PNP_THREADS, dyn, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());

@@ -265,7 +265,7 @@ extern "C" {
 
 int cmlhip_reproj_accumulate(cmlhip_ctx* c, int N, const double* poses, int M, const double* points, int n,
                              const cmlhip_reproj_obs* obs, double fx, double fy, double* M6, double* b6, double* Jpoints,
-                             unsigned char* used) {
+                             unsigned char* used) { CML_DEV(c);
     if (!c || N < 1 || N > CMLHIP_MAX_FRAMES || M < 0 || n < 0 || !poses || (M > 0 && !points) || (n > 0 && !obs)) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, n <= c->lim.max_reproj_obs, CMLHIP_ERR_INVALID, "observations exceed max_reproj_obs");
     for (int k = 0; k < n; k++)
@@ -298,7 +298,7 @@ int cmlhip_reproj_accumulate(cmlhip_ctx* c, int N, const double* poses, int M, c
     return CMLHIP_OK;
 }
 
-int cmlhip_reproj_solve(cmlhip_ctx* c, int N, double lambda, double* x6) {
+int cmlhip_reproj_solve(cmlhip_ctx* c, int N, double lambda, double* x6) { CML_DEV(c);
     if (!c || N < 1 || N > CMLHIP_MAX_FRAMES || !x6) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, c->rp_M.p && c->rp_x.p, CMLHIP_ERR_STATE, "cmlhip_reproj_accumulate not called");
     k_reproj_solve<<<1, 64, 0, c->stream>>>(N, lambda, c->rp_M.as<double>(), c->rp_b.as<double>(), c->rp_x.as<double>());

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_optimize_immature(OptArgs A) {
 extern "C" {
 
 int cmlhip_trace_points(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts, const cmlhip_trace_pair* pairs,
-                        int n, cmlhip_immature_point* points) {
+                        int n, cmlhip_immature_point* points) { CML_DEV(c);
     if (!c || !prm || n < 0 || n_hosts < 1 || !pairs || (n > 0 && !points)) return CMLHIP_ERR_INVALID;
     const Pyramid* py = cml_find_pyr(c, image_id);
     CML_REQUIRE(c, py && py->lv[0].grad, CMLHIP_ERR_NOT_FOUND, "traced image not in the pyramid cache");
@@ -381,7 +381,7 @@ int cmlhip_trace_points(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_pa
     return cml_d2h(c, points, c->tr_points.p, sizeof(cmlhip_immature_point) * (size_t)n);
 }
 
-int cmlhip_tracer_set_points(cmlhip_ctx* c, int n, const cmlhip_immature_point* points) {
+int cmlhip_tracer_set_points(cmlhip_ctx* c, int n, const cmlhip_immature_point* points) { CML_DEV(c);
     if (!c || n < 0 || (n > 0 && !points)) return CMLHIP_ERR_INVALID;
     int rc;
     if ((rc = cml_ensure(c, c->tr_resident, sizeof(cmlhip_immature_point) * (size_t)std::max(n, 1)))) return rc;
@@ -390,13 +390,13 @@ int cmlhip_tracer_set_points(cmlhip_ctx* c, int n, const cmlhip_immature_point* 
     return CMLHIP_OK;
 }
 
-int cmlhip_tracer_get_points(cmlhip_ctx* c, int n, cmlhip_immature_point* points) {
+int cmlhip_tracer_get_points(cmlhip_ctx* c, int n, cmlhip_immature_point* points) { CML_DEV(c);
     if (!c || n < 0 || n > c->tr_resident_n || (n > 0 && !points)) return CMLHIP_ERR_INVALID;
     return n ? cml_d2h(c, points, c->tr_resident.p, sizeof(cmlhip_immature_point) * (size_t)n) : CMLHIP_OK;
 }
 
 int cmlhip_tracer_trace_resident(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts, const cmlhip_trace_pair* pairs,
-                                 int skip_host, int counts[6]) {
+                                 int skip_host, int counts[6]) { CML_DEV(c);
     if (!c || !prm || n_hosts < 1 || !pairs || !counts) return CMLHIP_ERR_INVALID;
     const Pyramid* py = cml_find_pyr(c, image_id);
     CML_REQUIRE(c, py && py->lv[0].grad, CMLHIP_ERR_NOT_FOUND, "traced image not in the pyramid cache");
@@ -420,7 +420,7 @@ int cmlhip_tracer_trace_resident(cmlhip_ctx* c, uint64_t image_id, const cmlhip_
 
 int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_ids, const double K[4], const cmlhip_activation_pair* pairs,
                                     const cmlhip_tracer_params* prm, int min_obs, int n, const cmlhip_immature_point* points, int* result,
-                                    float* idepth, int* res_state) {
+                                    float* idepth, int* res_state) { CML_DEV(c);
     if (!c || N < 2 || N > CMLHIP_MAX_FRAMES || !image_ids || !K || !pairs || !prm || n < 0 || (n > 0 && (!points || !result || !idepth || !res_state)))
         return CMLHIP_ERR_INVALID;
     if (n == 0) return CMLHIP_OK;

@@ -339,7 +339,7 @@ static void inv3f(const float m[9], float o[9]) {
 
 extern "C" {
 
-int cmlhip_tracker_set_reference(cmlhip_ctx* c, int level, const float* uvic, int n) {
+int cmlhip_tracker_set_reference(cmlhip_ctx* c, int level, const float* uvic, int n) { CML_DEV(c);
     if (!c || level < 0 || level >= 8 || n < 0 || (n > 0 && !uvic)) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, n <= c->lim.max_tracker_points, CMLHIP_ERR_INVALID, "tracker list exceeds max_tracker_points");
     int rc = cml_ensure(c, c->trk_ref[level], 16 * (size_t)(n ? n : 1));
@@ -349,7 +349,7 @@ int cmlhip_tracker_set_reference(cmlhip_ctx* c, int level, const float* uvic, in
     return CMLHIP_OK;
 }
 
-int cmlhip_tracker_get_reference(cmlhip_ctx* c, int level, float* out, int* n_out) {
+int cmlhip_tracker_get_reference(cmlhip_ctx* c, int level, float* out, int* n_out) { CML_DEV(c);
     if (!c || level < 0 || level >= 8) return CMLHIP_ERR_INVALID;
     if (n_out) *n_out = c->trk_n[level];
     if (out && c->trk_n[level] > 0) return cml_d2h(c, out, c->trk_ref[level].p, 16 * (size_t)c->trk_n[level]);
@@ -358,7 +358,7 @@ int cmlhip_tracker_get_reference(cmlhip_ctx* c, int level, float* out, int* n_ou
 
 int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const double R[9], const double t[3], const double K[4],
                         const double aff[2], double b0, const cmlhip_tracker_params* prm, int want_hessian,
-                        cmlhip_tracker_result* out) {
+                        cmlhip_tracker_result* out) { CML_DEV(c);
     if (!c || !R || !t || !K || !aff || !prm || !out || level < 0 || level >= 8) return CMLHIP_ERR_INVALID;
     const Pyramid* py = cml_find_pyr(c, image_id);
     CML_REQUIRE(c, py && level < py->levels && py->lv[level].grad, CMLHIP_ERR_NOT_FOUND, "tracker image/level not in the pyramid cache");
@@ -447,7 +447,7 @@ int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const doubl
     return CMLHIP_OK;
 }
 
-int cmlhip_tracker_get_warped(cmlhip_ctx* c, float* out, int capacity, int* n_out) {
+int cmlhip_tracker_get_warped(cmlhip_ctx* c, float* out, int capacity, int* n_out) { CML_DEV(c);
     if (!c || !out || capacity < 0) return CMLHIP_ERR_INVALID;
     const int n = c->trk_last_n;
     if (n_out) *n_out = 0;
@@ -467,7 +467,7 @@ int cmlhip_tracker_get_warped(cmlhip_ctx* c, float* out, int capacity, int* n_ou
     return CMLHIP_OK;
 }
 
-int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int levels, const double* pts, int n, int* n_out) {
+int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int levels, const double* pts, int n, int* n_out) { CML_DEV(c);
     if (!c || levels < 1 || levels > 8 || n < 0 || (n > 0 && !pts) || !n_out) return CMLHIP_ERR_INVALID;
     const Pyramid* py = cml_find_pyr(c, ref_image_id);
     CML_REQUIRE(c, py && py->levels >= levels && py->lv[0].gray, CMLHIP_ERR_NOT_FOUND, "reference pyramid (with gray levels) not cached");
