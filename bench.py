@@ -21,43 +21,73 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-READ_BYTES_PER_RESIDUAL = 468          # 8 px x 4 taps x 12 B + colours 32 + weights 32 + (x,y,idepth) 12 + ids 8
+# 8 px x 4 taps x 12 B (fp32 texel: I, dI/dx, dI/dy) + colours 32 + weights 32 + (x,y,idepth) 12 + ids 8 = 468 B;
+# with fp16 pyramids (config E) the taps are 6 B each: 192 + 84 = 276 B
+READ_BYTES_PER_RESIDUAL = {"fp32": 468, "fp16": 276}
 HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(config, seed, budget_s=12.0):
-    """The oracle (plain-C port of the reference CPU path) timed on this box's host cores, 1 thread, bounded sample."""
-    from tests import ba_setup as S
-    from tests import oracle_lib as O
-    so = os.path.join(ROOT, "oracle", "libcml_oracle_fast.so")
-    try:            # -O3 -march=native build on the box it is timed on (falls back to the portable -O2 build)
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        O._lib = None
-        L = C.CDLL(so)
-        L.orc_ba_create.restype = C.POINTER(O.OrcBAWindow)
-        L.orc_ba_linearize_one.restype = C.c_double
-        O._lib = L
-        build = "-O3 -march=native"
+def _one_socket_cores():
+    """Logical CPU ids of the physical cores (one hardware thread each) of socket 0 that this process may run on."""
+    allowed = os.sched_getaffinity(0)
+    seen, cpus = set(), []
+    cur = {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif not line.strip() and cur:
+                cpu = int(cur.get("processor", -1)); key = (cur.get("physical id", "0"), cur.get("core id", str(cpu)))
+                if cpu in allowed and cur.get("physical id", "0") == "0" and key not in seen:
+                    seen.add(key); cpus.append(cpu)
+                cur = {}
     except Exception:
-        build = "-O2"
+        pass
+    return cpus or sorted(allowed)
+
+
+def _time_oracle(L, O, S, config, seed, runs=20, warm=3, iters_per_run=5):
+    """median over `runs` (after `warm` warm-ups) of one run = iters_per_run Gauss-Newton iterations of the window."""
     I = S.make_inputs(config, seed=seed)
     ob = S.OracleBA(I)
     ob.linearize(); ob.apply(1)
-    t_lin = t_rest = 0.0
-    iters = 0
-    t_start = time.perf_counter()
-    while time.perf_counter() - t_start < budget_s or iters < 3:
-        t0 = time.perf_counter()
-        O.lib().orc_ba_backup_points(ob.w)
-        H = ob.accumulate()
-        x, rc = ob.solve(1e-5, *H)
-        ob.backsub(x)
-        O.lib().orc_ba_step_points(ob.w, None)
-        t1 = time.perf_counter()
-        ob.linearize(); ob.apply(1)
-        t2 = time.perf_counter()
-        t_rest += t1 - t0; t_lin += t2 - t1
-        iters += 1
+    t_lin, t_rest = [], []
+    for k in range(warm + runs):
+        a = b = 0.0
+        for _ in range(iters_per_run):
+            t0 = time.perf_counter()
+            L.orc_ba_backup_points(ob.w)
+            H = ob.accumulate()
+            x, rc = ob.solve(1e-5, *H)
+            ob.backsub(x)
+            L.orc_ba_step_points(ob.w, None)
+            t1 = time.perf_counter()
+            ob.linearize(); ob.apply(1)
+            t2 = time.perf_counter()
+            b += t1 - t0; a += t2 - t1
+        if k >= warm:
+            t_lin.append(a / iters_per_run); t_rest.append(b / iters_per_run)
+    import statistics
+    return I.R, statistics.median(t_lin), statistics.median(t_rest), min(t_lin), max(t_lin)
+
+
+def _load_oracle(O, target, soname):
+    so = os.path.join(ROOT, "oracle", soname)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), target], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.orc_ba_create.restype = C.POINTER(O.OrcBAWindow)
+    L.orc_ba_linearize_one.restype = C.c_double
+    O._lib = L
+    return L
+
+
+def cpu_baseline(config, seed):
+    """The oracle (plain-C port of the reference CPU path, "kind": "port") timed on this box's host cores, SURVEY §8(d):
+    median of 20 runs after 3 warm-ups, (i) single thread — the reference's BA is serial (BA.cpp:1551-1565) — and
+    (ii) the residual loop spread with OpenMP over the physical cores of one socket (accumulate / Schur / solve stay serial)."""
+    from tests import ba_setup as S
+    from tests import oracle_lib as O
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -66,10 +96,34 @@ def cpu_baseline(config, seed, budget_s=12.0):
                 break
     except Exception:
         pass
-    return {"value": I.R * iters / (t_lin + t_rest), "unit": "point-residuals/s", "cores": 1, "kind": "port",
-            "sample": "%d Gauss-Newton iterations of the same window (R=%d), oracle C port %s, single thread" % (iters, I.R, build),
-            "linearize_residuals_per_s": I.R * iters / t_lin, "schur_solve_ms": 1e3 * t_rest / iters,
-            "host_cpu": model, "host_logical_cpus": os.cpu_count()}
+    try:            # -O3 -march=native build on the box it is timed on (falls back to the portable -O2 checker build)
+        L = _load_oracle(O, "fast", "libcml_oracle_fast.so")
+        build = "-O3 -march=native"
+    except Exception:
+        O._lib = None
+        L = O.lib()
+        build = "-O2"
+    R, lin1, rest1, lo1, hi1 = _time_oracle(L, O, S, config, seed)
+    out = {"value": R / (lin1 + rest1), "unit": "point-residuals/s", "cores": 1, "kind": "port",
+           "sample": "median of 20 runs (3 warm-ups) of 5 Gauss-Newton iterations of the same window (R=%d), oracle C port %s, single thread "
+                     "(the reference's BA loop is serial)" % (R, build),
+           "linearize_residuals_per_s": R / lin1, "linearize_residuals_per_s_minmax": [R / hi1, R / lo1], "schur_solve_ms": 1e3 * rest1,
+           "host_cpu": model, "host_logical_cpus": os.cpu_count()}
+    try:
+        cores = _one_socket_cores()
+        os.environ["OMP_NUM_THREADS"] = str(len(cores))
+        os.environ["GOMP_CPU_AFFINITY"] = " ".join(str(c) for c in cores)
+        L = _load_oracle(O, "fast_omp", "libcml_oracle_omp.so")
+        R, linN, restN, loN, hiN = _time_oracle(L, O, S, config, seed)
+        out["all_cores_one_socket"] = {"value": R / (linN + restN), "unit": "point-residuals/s", "cores": len(cores),
+                                       "linearize_residuals_per_s": R / linN, "schur_solve_ms": 1e3 * restN,
+                                       "sample": "same protocol, -fopenmp over the residual loop on the %d physical cores of socket 0; "
+                                                 "accumulate / Schur / solve serial as in the reference" % len(cores)}
+    except Exception as e:
+        out["all_cores_one_socket"] = {"value": None, "sample": "failed: %r" % (e,)}
+    finally:
+        O._lib = None
+    return out
 
 
 def _dbg(*a):
@@ -122,7 +176,7 @@ def main():
     for _ in range(args.warmup):
         ctx.ba_iteration_async(lam)
     _dbg('warmup queued')
-    stride = 8 if args.steps >= 16 else (2 if args.steps >= 4 else 1)     # sampled HIP-event brackets (each costs ~5 us of stream time)
+    stride = 4 if args.steps >= 16 else (2 if args.steps >= 4 else 1)     # every stride-th step carries the profile events on its dispatches
     ctx.profile_stride(stride)
     ctx.profile_enable((args.steps + stride - 1) // stride)
 
@@ -138,10 +192,9 @@ def main():
     _dbg('profile enabled')
     dt = shard.timed_region(group, sync, run_steps)
     _dbg('timed region done')
-    lin_v, ss_v, empty_v, _n = ctx.profile_read()
-    # raw brackets contain the cost of the two event records themselves (measured by the empty bracket recorded next to
-    # them, ~5 us, i.e. comparable to the kernel): the kernel time is the difference
-    lin_ms, ss_ms = C.c_float(max(lin_v - empty_v, 0.0)), C.c_float(max(ss_v - empty_v, 0.0))
+    lin_v, ss_v, _empty, n_samples = ctx.profile_read()
+    # the events are the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL): no bracket overhead to subtract
+    lin_ms, ss_ms = C.c_float(lin_v), C.c_float(ss_v)
     _dbg('profile read')
     st = ctx.ba_states()
     n_good = int(st["good"].sum())
@@ -151,18 +204,19 @@ def main():
 
     _dbg('reductions done')
     if rank == 0:
-        achieved = R * READ_BYTES_PER_RESIDUAL / (lin_ms.value * 1e-3) / 1e9 if lin_ms.value > 0 else 0.0
+        bytes_per_residual = READ_BYTES_PER_RESIDUAL["fp16" if half else "fp32"]
+        achieved = R * bytes_per_residual / (lin_ms.value * 1e-3) / 1e9 if lin_ms.value > 0 else 0.0
         # memory-side bytes per launch of the residual kernel come from separate `rocprofv3 --pmc` passes of this same command
         # (tools/profile_bench.py; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide) and are only
         # quoted for the workload they were collected on
         traffic, traffic_src, rocprof_us = None, None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_f_pmc_linearize.json")
-        if args.config == "B" and os.path.exists(pmc_path):
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_linearize_%s.json" % args.config)
+        if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
                 traffic = pmc.get("traffic_bytes_per_launch")
                 rocprof_us = pmc.get("linearize_avg_us")   # kernel-trace average of the same command (dispatches serialised by the profiler)
-                traffic_src = "profiles/round1_f_pmc_linearize.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % os.path.basename(pmc_path)
             except Exception:
                 traffic = None
         out = {
@@ -176,9 +230,11 @@ def main():
             "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
             "roofline": {"bound": "hbm", "kernel": "k_ba_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": R * READ_BYTES_PER_RESIDUAL, "launch_us": 1e3 * lin_ms.value,
-                         "launch_us_note": "HIP-event bracket on the context stream, sampled every 8th step inside the timed region, "
-                                           "minus the empty bracket recorded next to it (raw %.2f us, empty %.2f us)" % (1e3 * lin_v, 1e3 * empty_v),
+                         "algorithmic_bytes_per_launch": R * bytes_per_residual, "bytes_per_residual": bytes_per_residual,
+                         "launch_us": 1e3 * lin_ms.value, "launch_samples": n_samples,
+                         "launch_us_note": "mean over the sampled steps of the timed region of hipEventElapsedTime between the start and stop events "
+                                           "attached to the k_ba_linearize dispatch itself (hipExtLaunchKernelGGL): the kernel's begin / end "
+                                           "timestamps, the quantity rocprofv3 --kernel-trace reports",
                          "rocprof_avg_us": rocprof_us},
         }
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only

@@ -490,9 +490,11 @@ int cmlhip_event_elapsed_ms(cmlhip_ctx* ctx, float* ms);
 int cmlhip_ba_linearize_async(cmlhip_ctx* ctx);
 /* one resident iteration (see above); without cmlhip_ba_set_resident_state only the points are stepped */
 int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);
-/* Per-kernel HIP-event timing of the iteration pipeline: when enabled, cmlhip_ba_iteration_async brackets (a) the
- * residual/Jacobian kernel and (b) the accumulate+Schur+solve+back-substitution group with events on the context
- * stream.  read returns the mean durations in ms over the recorded iterations and resets the recorder. */
+/* Per-kernel HIP-event timing of the iteration pipeline: when enabled, cmlhip_ba_iteration_async attaches HIP events to the
+ * DISPATCHES themselves (hipExtLaunchKernelGGL start / stop events, i.e. the begin / end timestamps of the kernel, the same
+ * quantity rocprofv3 --kernel-trace reports): (a) begin and end of the residual/Jacobian kernel, (b) begin of the
+ * accumulate kernel and end of the back-substitution kernel (the Schur-reduce + solve group, launch gaps included).
+ * read returns the mean durations in ms over the recorded iterations and resets the recorder. */
 int cmlhip_profile_enable(cmlhip_ctx* ctx, int max_iterations);
 /* record only every stride-th iteration (default 1), so that the event records do not perturb a timed run */
 int cmlhip_profile_stride(cmlhip_ctx* ctx, int stride);
@@ -502,8 +504,8 @@ int cmlhip_profile_stride(cmlhip_ctx* ctx, int stride);
  * Reads the previous values, then (re)arms. */
 #define CMLHIP_DEBUG_SLOTS (128 + 5 * 1024 * 2)
 int cmlhip_debug_timestamps(cmlhip_ctx* ctx, int enable, long long* out);
-/* mean RAW bracket durations (event record -> kernel(s) -> event record) and the mean duration of an empty bracket
- * recorded next to them (the event overhead contained in each raw figure) */
+/* mean durations as defined above; empty_bracket_ms is kept for ABI stability and is always 0 (the events are the
+ * dispatches' own timestamps: there is no bracket overhead to subtract) */
 int cmlhip_profile_read(cmlhip_ctx* ctx, float* linearize_ms, float* schur_solve_ms, float* empty_bracket_ms, int* n_recorded);
 
 #ifdef __cplusplus

@@ -1102,7 +1102,7 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
             k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
             if (A.P > 0) k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
         }
-        k_ba_acc<<<NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, c->stream>>>(A, X, 0);
+        CML_LAUNCH_EV(c, k_ba_acc, NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, A, X, 0);
     }
     SysArgs S;
     S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = (c->n_lin > 0 && !marg) ? 1 : 0;
@@ -1167,8 +1167,8 @@ int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
         F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
     }
     if (cml_div_up(A.P * 8, 256) + F.on == 0) return CMLHIP_OK;     // no points and no frame step: nothing to launch (a zero grid is a HIP error)
-    k_ba_backsub<<<cml_div_up(A.P * 8, 256) + F.on, 256, sh, c->stream>>>(A, c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(),
-                                                                      c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0, F);
+    CML_LAUNCH_EV(c, k_ba_backsub, cml_div_up(A.P * 8, 256) + F.on, 256, sh, A, (const double*)c->adH.as<double>(), (const double*)c->adT.as<double>(),
+                  (const double*)c->xvec.as<double>(), c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0, F);
     return CMLHIP_OK;
 }
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A) {

@@ -438,16 +438,18 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
         A.it_index = c->resident_iter; A.th_opt = c->conv_th;
     }
     const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap && (c->prof_tick++ % c->prof_stride) == 0;
-    hipEvent_t* ev = prof ? &c->prof_ev[6 * (size_t)c->prof_n] : nullptr;
-    if (prof) (void)hipEventRecord(ev[0], c->stream);
+    hipEvent_t* ev = prof ? &c->prof_ev[4 * (size_t)c->prof_n] : nullptr;
+    if (prof) c->ext_start = ev[0];                          // begin timestamp of the K3 dispatch
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
     if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2))) return rc;   // K5: solve (+ orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
     c->resident_iter++;
+    if (prof) c->ext_stop = ev[1];                           // end timestamp of the K6 dispatch
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
-    if (prof) { (void)hipEventRecord(ev[1], c->stream); (void)hipEventRecord(ev[2], c->stream); }
+    if (prof) { c->ext_start = ev[2]; c->ext_stop = ev[3]; } // begin / end timestamps of the K1 dispatch itself
     cml_launch_linearize(c, A);                              // K1: residuals + Jacobians (+ applyRes)
+    c->ext_start = c->ext_stop = nullptr;
     c->lin_finish_pending = true;
-    if (prof) { (void)hipEventRecord(ev[3], c->stream); (void)hipEventRecord(ev[4], c->stream); (void)hipEventRecord(ev[5], c->stream); c->prof_n++; }
+    if (prof) c->prof_n++;
     CML_CHECK(c, hipGetLastError());
     return CMLHIP_OK;
 }
@@ -640,7 +642,7 @@ int cmlhip_profile_enable(cmlhip_ctx* c, int max_iterations) { CML_DEV(c);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     c->prof_ev.clear();
     c->prof_cap = max_iterations; c->prof_n = 0; c->prof_tick = 0;
-    c->prof_ev.resize(6 * (size_t)max_iterations);
+    c->prof_ev.resize(4 * (size_t)max_iterations);
     for (auto& e : c->prof_ev) CML_CHECK(c, hipEventCreate(&e));
     return CMLHIP_OK;
 }
@@ -656,11 +658,10 @@ int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, float* empty
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     double a = 0, b = 0, e = 0;
     for (int i = 0; i < c->prof_n; i++) {
-        float m0 = 0, m1 = 0, m2 = 0;
-        CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[6 * (size_t)i + 0], c->prof_ev[6 * (size_t)i + 1]));
-        CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[6 * (size_t)i + 2], c->prof_ev[6 * (size_t)i + 3]));
-        CML_CHECK(c, hipEventElapsedTime(&m2, c->prof_ev[6 * (size_t)i + 4], c->prof_ev[6 * (size_t)i + 5]));   // empty bracket = event overhead
-        b += m0; a += m1; e += m2;
+        float m0 = 0, m1 = 0;
+        CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[4 * (size_t)i + 0], c->prof_ev[4 * (size_t)i + 1]));   // K3 begin -> K6 end
+        CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[4 * (size_t)i + 2], c->prof_ev[4 * (size_t)i + 3]));   // K1 begin -> K1 end
+        b += m0; a += m1;
     }
     if (n) *n = c->prof_n;
     if (lin_ms) *lin_ms = c->prof_n ? (float)(a / c->prof_n) : 0.f;

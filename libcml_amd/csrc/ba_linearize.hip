@@ -450,8 +450,8 @@ int cml_launch_lin_energy(cmlhip_ctx* c, const BAArgs& A, const float* adHTd, co
 int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A) {
     const int blocks = cml_div_up(A.R, RES_PER_BLOCK);
     if (blocks == 0) return CMLHIP_OK;
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_ba_linearize<true><<<blocks, 256, 0, c->stream>>>(A);
-    else k_ba_linearize<false><<<blocks, 256, 0, c->stream>>>(A);
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_ba_linearize<true>, blocks, 256, 0, A);
+    else CML_LAUNCH_EV(c, k_ba_linearize<false>, blocks, 256, 0, A);
     return CMLHIP_OK;
 }
 int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -62,7 +63,10 @@ struct cmlhip_ctx {
     std::vector<unsigned long long> h2d_segs;                 // (dst pointer, offset in the block, bytes) triples                                           // AoS3 staging of pyramid_put / pyramid_get
     void* pinned = nullptr;       // pinned host staging (readbacks / small uploads)
     size_t pinned_bytes = 0, pinned_off = 0;
-    std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration (cmlhip_profile_enable)
+    // Kernel timing of the resident iteration (cmlhip_profile_enable): the events ride ON the dispatches (hipExtLaunchKernelGGL
+    // start / stop events = the dispatch's own begin / end timestamps, what rocprofv3 --kernel-trace reads), not around them
+    hipEvent_t ext_start = nullptr, ext_stop = nullptr;       // consumed by the next CML_LAUNCH_EV
+    std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration: K3 begin, K6 end, K1 begin, K1 end
     int prof_cap = 0, prof_n = 0, prof_stride = 1, prof_tick = 0;
 
     // ---------------- BA window
@@ -145,3 +149,15 @@ int cml_d2h_batch_flush(cmlhip_ctx* c);
 const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id);
 
 static inline int cml_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// launch `kern<<<grid, block, shmem, c->stream>>>(args...)`; when the context carries pending profile events they are attached to
+// this dispatch and cleared
+#define CML_LAUNCH_EV(c, kern, grid, block, shmem, ...)                                                              \
+    do {                                                                                                            \
+        if ((c)->ext_start || (c)->ext_stop) {                                                                      \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (std::uint32_t)(shmem), (c)->stream, (c)->ext_start, (c)->ext_stop, 0, __VA_ARGS__); \
+            (c)->ext_start = nullptr; (c)->ext_stop = nullptr;                                                      \
+        } else {                                                                                                    \
+            kern<<<grid, block, shmem, (c)->stream>>>(__VA_ARGS__);                                                 \
+        }                                                                                                           \
+    } while (0)

@@ -239,6 +239,11 @@ static int cmp_float(const void* a, const void* b) {
 /* BA.cpp:1551-1565 (loop), :1608-1610, :2419-2464 (setNewFrameEnergyTH) */
 void orc_ba_linearize_all(orc_ba_window* w, cmlhip_ba_lin_result* out) {
     double stats = 0;
+    /* The reference's loop is serial (BA.cpp:1551-1565).  Built with -fopenmp (make fast_omp: bench.py's all-cores CPU baseline,
+       SURVEY §8d) the residuals are spread over the host cores: each one touches only its own slots, the energy sum is a reduction. */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : stats)
+#endif
     for (int r = 0; r < w->R; r++) {
         if (w->r_lin[r]) continue;          /* mActiveResiduals holds the non-linearized residuals, BA.cpp:766-779 */
         stats += orc_ba_linearize_one(w, r);
@@ -300,6 +305,9 @@ static void apply_one(orc_ba_window* w, int r, int copy) {
     }
 }
 void orc_ba_apply(orc_ba_window* w, int copy) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int r = 0; r < w->R; r++) {
         if (w->r_lin[r]) continue;
         apply_one(w, r, copy);

@@ -11,9 +11,15 @@ from tests import trk_setup as T
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def scene():
-    s = T.make_scene("small")
+# "A" = BASELINE.json configs[0] as SURVEY §8 defines it (1 reference keyframe + 200 points, 640x480, 2 levels: the tracker path);
+# "B" = the config-B shape (1241x376, 4 levels, 2000 points) — both at full size
+LEVELS = {"small": [0, 1, 2], "A": [0, 1], "B": [0, 1, 2, 3]}
+
+
+@pytest.fixture(scope="module", params=["small", "A", "B"])
+def scene(request):
+    s = T.make_scene(request.param)
+    s.name = request.param
     ctx = device.Ctx(max_frames=8)
     yield s, ctx
     ctx.close()
@@ -48,9 +54,11 @@ def test_coarse_depth_lists_exact(scene):
         assert np.array_equal(d[:, 2].view(np.uint32), o[:, 2].view(np.uint32))      # the splat is ordered: collisions included
 
 
-@pytest.mark.parametrize("level", [0, 1, 2])
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
 def test_tracker_eval(scene, level):
     s, ctx = scene
+    if level not in LEVELS[s.name]:
+        pytest.skip("level not part of this configuration")
     ctx.pyramid_build(2, s.W.gray[s.new], s.levels)
     lists, n_orc = T.oracle_coarse_depth(s)
     uvic = lists[level][:n_orc[level]]
@@ -77,6 +85,18 @@ def test_tracker_eval(scene, level):
             assert abs(Hd[i, j] - Ho[i, j]) <= 3e-5 * np.sqrt(abs(Ho[i, i] * Ho[j, j])) + 1e-30
     bd = np.array(out_d.b[:]); bo = np.array(out_o.b[:])
     assert np.abs(bd - bo).max() <= 1e-4 * np.abs(bo).max()
+    # the Gauss-Newton step of the iteration (TR.cpp:97-101, 140-159): inc = -ldlt(H with diag * (1 + lambda)).solve(b), lambda = 0.01.
+    # Pivoted LDLT (Eigen semantics, pinned on the vendored Eigen) on the device's system against the oracle's system:
+    # the step inherits the fp32 accumulation tolerance of H and b, amplified by the conditioning of the 8x8 system
+    lam = 0.01
+    Hl_d = Hd.copy(); Hl_d[np.diag_indices(8)] *= (1 + lam)
+    Hl_o = Ho.copy(); Hl_o[np.diag_indices(8)] *= (1 + lam)
+    inc_d, rc_d = O.ldlt_solve(Hl_d, -bd)
+    inc_o, rc_o = O.ldlt_solve(Hl_o, -bo)
+    assert rc_d == 0 and rc_o == 0
+    Sv = 1.0 / np.sqrt(np.diag(Hl_o))
+    back = Sv * (Hl_o @ inc_d + bo)                     # backward error of the device step in the oracle's (Jacobi-scaled) system
+    assert np.linalg.norm(back) <= 1e-4 * np.linalg.norm(Sv * bo)
 
 
 def test_tracker_empty_and_saturated(scene):

@@ -27,7 +27,8 @@ env = dict(os.environ, TMPDIR="/tmp")
 def run(extra, sub):
     d = os.path.join(OUT, "prof_%s_%s" % (tag, sub))
     cmd = ["rocprofv3"] + extra + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
-    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=False, text=True)
+    run.last_stdout = r.stdout or ""
     return d
 
 
@@ -45,15 +46,24 @@ with open(os.path.join(OUT, tag + "_kernels.md"), "w") as f:
     for r in rows[:16]:
         f.write("| `%s` | %s | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
                                                              float(r["MaxNs"]) / 1e3, r["Percentage"]))
-lin = [r for r in rows if "k_ba_linearize" in r["Name"]]
-res = {"bench_args": bench_args, "linearize_avg_us": float(lin[0]["AverageNs"]) / 1e3 if lin else None}
+KERNEL = os.environ.get("CML_PROF_KERNEL", "k_ba_lin")          # the residual kernel (k_ba_linearize<..> / k_ba_lin_rs<..>)
+lin = [r for r in rows if KERNEL in r["Name"] and "finish" not in r["Name"]]
+res = {"bench_args": bench_args, "kernel": lin[0]["Name"][:60] if lin else None, "linearize_avg_us": float(lin[0]["AverageNs"]) / 1e3 if lin else None}
+for line in run.last_stdout.splitlines():          # the bench line of the SAME (profiled) command: its roofline.launch_us must agree with the average above
+    if line.startswith("{") and "roofline" in line:
+        try:
+            b = json.loads(line)
+            res["bench_line_under_profiler"] = {"launch_us": b["roofline"]["launch_us"], "frac": b["roofline"]["frac"], "ms_per_step": b["ms_per_step"],
+                                                "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"]}
+        except Exception:
+            pass
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = run(["--pmc", ctr], ctr.lower())
     f = find(d, "counter_collection.csv")
     vals = []
     if f:
         for r in csv.DictReader(open(f)):
-            if "k_ba_linearize" in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
+            if KERNEL in r.get("Kernel_Name", "") and "finish" not in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
                 vals.append(float(r["Counter_Value"]))
     res[ctr + "_raw_avg"] = sum(vals) / len(vals) if vals else None
     res[ctr + "_launches"] = len(vals)
