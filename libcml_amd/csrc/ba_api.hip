@@ -44,6 +44,35 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
 
 static inline int ldg_of(int n) { return ((n + 1 + 15) / 16) * 16; }
 
+// R-length readbacks: the device holds residuals in pair-sorted order r' (see cmlhip_ba_upload_window); the caller gets its own
+// numbering back.  add() records a device array (element size in bytes), the copies ride in the open d2h batch (or read_now()
+// issues them), deliver() scatters temp[r'] -> out[caller r].
+struct ResRead {
+    cmlhip_ctx* c;
+    struct Item { void* out; size_t esz; std::vector<unsigned char> tmp; };
+    std::vector<Item> items;
+    explicit ResRead(cmlhip_ctx* c_) : c(c_) { items.reserve(8); }
+    void add(void* out, const void* dev, size_t esz) {
+        if (!out || c->R == 0) return;
+        items.push_back(Item{out, esz, std::vector<unsigned char>(esz * (size_t)c->R)});
+        pending_dev.push_back(dev);
+        if (c->d2h_batching) { cml_d2h(c, items.back().tmp.data(), dev, esz * (size_t)c->R); pending_dev.back() = nullptr; }
+    }
+    int read_now() {
+        for (size_t i = 0; i < items.size(); i++)
+            if (pending_dev[i]) { int rc = cml_d2h(c, items[i].tmp.data(), pending_dev[i], items[i].esz * (size_t)c->R); if (rc) return rc; }
+        deliver();
+        return CMLHIP_OK;
+    }
+    void deliver() {
+        for (auto& it : items) {
+            unsigned char* o = static_cast<unsigned char*>(it.out);
+            for (size_t r = 0; r < (size_t)c->R; r++) memcpy(o + it.esz * r, it.tmp.data() + it.esz * (size_t)c->h_dev_of[r], it.esz);
+        }
+    }
+    std::vector<const void*> pending_dev;
+};
+
 extern "C" {
 
 int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) { CML_DEV(c);
@@ -98,6 +127,13 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
             c->h_by_pair[c->h_by_pair_off[q] + c2[q]++] = r;
         }
     }
+    // ---- DEVICE residual order = (host,target)-pair-sorted: r' = position in the by-pair list.  Every R-length device array, the
+    //      by-point lists and the new-frame list hold r'; the ABI keeps the caller's numbering (inputs are permuted here, readbacks
+    //      are permuted back, cmlhip_ba_get_index_maps reports the caller-order maps).  Residuals of one pair are contiguous on the
+    //      device, so the residual kernel of the resident loop reads the pair record through scalar loads.
+    c->h_dev_of.assign(R, 0); c->h_caller_of.assign(R, 0);
+    for (int k = 0; k < R; k++) { c->h_caller_of[k] = c->h_by_pair[k]; c->h_dev_of[c->h_by_pair[k]] = k; }
+    for (size_t i = 0; i < newframe.size(); i++) newframe[i] = c->h_dev_of[newframe[i]];
     c->N = N; c->P = P; c->R = R; c->n_lin = n_lin; c->n_newframe = (int)newframe.size();
     const int n = 8 * N + 4, ldg = ldg_of(n), ntile = ldg / 16;
     // ---- allocations
@@ -139,22 +175,26 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     }
     std::vector<int> rp(R), rt(R), rs(R), rns(R, CMLHIP_RES_OUTLIER);
     std::vector<unsigned char> rl(R);
-    for (int r = 0; r < R; r++) { rp[r] = res[r].point; rt[r] = res[r].target; rs[r] = res[r].state; rl[r] = res[r].is_linearized != 0; }
+    for (int k = 0; k < R; k++) { const int r = c->h_caller_of[k]; rp[k] = res[r].point; rt[k] = res[r].target; rs[k] = res[r].state; rl[k] = res[r].is_linearized != 0; }
 #define UP(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
     UP(c->frames, fd);
     UP(c->pt_x, fx); UP(c->pt_y, fy); UP(c->pt_idepth, idp); UP(c->pt_idepth_zero, fz); UP(c->pt_prior, fp); UP(c->pt_host, hst);
     UP(c->pt_colors, col); UP(c->pt_weights, wgt);
-    { std::vector<int> rh(R); for (int r = 0; r < R; r++) rh[r] = points[res[r].point].host; UP(c->r_host, rh); }
+    { std::vector<int> rh(R); for (int k = 0; k < R; k++) rh[k] = points[res[c->h_caller_of[k]].point].host; UP(c->r_host, rh); }
     UP(c->r_point, rp); UP(c->r_target, rt); UP(c->r_state, rs); UP(c->r_new_state, rns); UP(c->r_lin, rl);
-    UP(c->by_point_off, c->h_by_point_off); UP(c->by_point, c->h_by_point);
-    UP(c->by_pair_off, c->h_by_pair_off); UP(c->by_pair, c->h_by_pair);
+    {   // device lists hold r': a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
+        std::vector<int> bp(R), bq(R);
+        for (int i = 0; i < R; i++) { bp[i] = c->h_dev_of[c->h_by_point[i]]; bq[i] = i; }
+        UP(c->by_point_off, c->h_by_point_off); UP(c->by_point, bp);
+        UP(c->by_pair_off, c->h_by_pair_off); UP(c->by_pair, bq);
+    }
     {
         int mx = 1;
         for (int q = 0; q < N * N; q++) mx = std::max(mx, c->h_by_pair_off[q + 1] - c->h_by_pair_off[q]);
         c->pair_stride = (mx + 3) & ~3;
         std::vector<int> code((size_t)N * N * c->pair_stride, -1), pos(std::max(R, 1), 0);   // nothing is good before the first applyRes
         for (int q = 0; q < N * N; q++)
-            for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i++) pos[c->h_by_pair[i]] = q * c->pair_stride + (i - c->h_by_pair_off[q]);
+            for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i++) pos[i] = q * c->pair_stride + (i - c->h_by_pair_off[q]);      // r' = i
         if ((rc = cml_ensure(c, c->pair_code, 4 * code.size()))) return rc;
         if ((rc = cml_ensure(c, c->pair_pos, 4 * pos.size()))) return rc;
         UP(c->pair_code, code); UP(c->pair_pos, pos);
@@ -168,7 +208,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         for (int p = 0; p < P; p++)
             for (int i = c->h_by_point_off[p]; i < c->h_by_point_off[p + 1]; i++) {
                 const int r = c->h_by_point[i], slot = p * c->pt_stride + (i - c->h_by_point_off[p]);
-                pos[r] = slot;
+                pos[c->h_dev_of[r]] = slot;
                 tgt[slot] = res[r].target | (res[r].is_linearized ? 256 : 0);
             }
         if ((rc = cml_ensure(c, c->point_code, 4 * code.size()))) return rc;
@@ -294,17 +334,15 @@ int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* sta
     const size_t R = c->R, P = c->P;
     LinSummary S;
     std::vector<float> pacc(point_acc ? PT_ACC_STRIDE * P : 0);
+    ResRead rr(c);
     cml_d2h_batch_begin(c);
     cml_d2h(c, &S, c->scal.p, sizeof S);
-    if (state) cml_d2h(c, state, c->r_state.p, 4 * R);
-    if (new_state) cml_d2h(c, new_state, c->r_new_state.p, 4 * R);
-    if (energy) cml_d2h(c, energy, c->r_energy.p, 4 * R);
-    if (new_energy) cml_d2h(c, new_energy, c->r_new_energy.p, 4 * R);
-    if (new_energy_wo) cml_d2h(c, new_energy_wo, c->r_new_energy_wo.p, 4 * R);
-    if (is_good) cml_d2h(c, is_good, c->r_good.p, R);
+    rr.add(state, c->r_state.p, 4); rr.add(new_state, c->r_new_state.p, 4); rr.add(energy, c->r_energy.p, 4);
+    rr.add(new_energy, c->r_new_energy.p, 4); rr.add(new_energy_wo, c->r_new_energy_wo.p, 4); rr.add(is_good, c->r_good.p, 1);
     if (idepth) cml_d2h(c, idepth, c->pt_idepth.p, 8 * P);
     if (point_acc && P) cml_d2h(c, pacc.data(), c->pt_acc.p, 4 * pacc.size());
     if ((rc = cml_d2h_batch_flush(c))) return rc;
+    rr.deliver();
     if (point_acc) for (size_t p = 0; p < P; p++) memcpy(point_acc + 14 * p, &pacc[PT_ACC_STRIDE * p], 14 * 4);
     if (lin) { lin->energy = S.energy; lin->n_in = S.n_in; lin->n_oob = S.n_oob; lin->n_outlier = S.n_outlier; lin->new_frame_energy_th = S.new_frame_energy_th; }
     return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
@@ -544,9 +582,9 @@ int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* en
 int cmlhip_ba_get_res_to_zero(cmlhip_ctx* c, float* rtz, unsigned char* is_lin) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
-    if (rtz && (rc = cml_d2h(c, rtz, c->r_rtz.p, 32 * (size_t)c->R))) return rc;
-    if (is_lin && (rc = cml_d2h(c, is_lin, c->r_lin.p, (size_t)c->R))) return rc;
-    return CMLHIP_OK;
+    ResRead rr(c);
+    rr.add(rtz, c->r_rtz.p, 32); rr.add(is_lin, c->r_lin.p, 1);
+    return rr.read_now();
 }
 
 int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, const cmlhip_ba_frame_state* frames, const double scales[4],
@@ -676,15 +714,13 @@ int cmlhip_ba_get_states(cmlhip_ctx* c, int* state, int* new_state, float* energ
                          unsigned char* is_good) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
-    const size_t R = c->R;
+    ResRead rr(c);
     cml_d2h_batch_begin(c);                                             // six arrays, one round trip
-    if (state) cml_d2h(c, state, c->r_state.p, 4 * R);
-    if (new_state) cml_d2h(c, new_state, c->r_new_state.p, 4 * R);
-    if (energy) cml_d2h(c, energy, c->r_energy.p, 4 * R);
-    if (new_energy) cml_d2h(c, new_energy, c->r_new_energy.p, 4 * R);
-    if (new_energy_wo) cml_d2h(c, new_energy_wo, c->r_new_energy_wo.p, 4 * R);
-    if (is_good) cml_d2h(c, is_good, c->r_good.p, R);
-    return cml_d2h_batch_flush(c);
+    rr.add(state, c->r_state.p, 4); rr.add(new_state, c->r_new_state.p, 4); rr.add(energy, c->r_energy.p, 4);
+    rr.add(new_energy, c->r_new_energy.p, 4); rr.add(new_energy_wo, c->r_new_energy_wo.p, 4); rr.add(is_good, c->r_good.p, 1);
+    if ((rc = cml_d2h_batch_flush(c))) return rc;
+    rr.deliver();
+    return CMLHIP_OK;
 }
 
 int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) { CML_DEV(c);
@@ -698,8 +734,9 @@ int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) { CML_DEV(c);
     if ((rc = cml_d2h(c, b1.data(), c->rj[1].p, 4 * RJ_STRIDE * R))) return rc;
     if ((rc = cml_d2h(c, sel.data(), c->r_sel.p, R))) return rc;
     for (size_t r = 0; r < R; r++) {
-        const bool efs_in_1 = sel[r] != 0;
-        const float* src = ((which == 1) == efs_in_1 ? b1.data() : b0.data()) + RJ_STRIDE * r;
+        const size_t k = (size_t)c->h_dev_of[r];
+        const bool efs_in_1 = sel[k] != 0;
+        const float* src = ((which == 1) == efs_in_1 ? b1.data() : b0.data()) + RJ_STRIDE * k;
         memcpy(out + CMLHIP_RJ_FLOATS * r, src, 4 * CMLHIP_RJ_FLOATS);
     }
     return CMLHIP_OK;
@@ -708,12 +745,17 @@ int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) { CML_DEV(c);
 int cmlhip_ba_get_jpjdf(cmlhip_ctx* c, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
-    return cml_d2h(c, out, c->r_jpjdf.p, 32 * (size_t)c->R);
+    ResRead rr(c);
+    rr.add(out, c->r_jpjdf.p, 32);
+    if ((rc = rr.read_now())) return rc;
+    return CMLHIP_OK;
 }
 int cmlhip_ba_get_center_projected(cmlhip_ctx* c, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
-    return cml_d2h(c, out, c->r_center.p, 12 * (size_t)c->R);
+    ResRead rr(c);
+    rr.add(out, c->r_center.p, 12);
+    return rr.read_now();
 }
 int cmlhip_ba_get_point_acc(cmlhip_ctx* c, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);

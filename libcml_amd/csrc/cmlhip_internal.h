@@ -73,7 +73,8 @@ struct cmlhip_ctx {
     cmlhip_ba_params ba_prm{};
     bool ba_prm_set = false, ba_uploaded = false, ba_pairs_set = false;
     int N = 0, P = 0, R = 0, n_lin = 0, n_newframe = 0;
-    std::vector<int> h_pair_of, h_by_point_off, h_by_point, h_by_pair_off, h_by_pair;
+    std::vector<int> h_pair_of, h_by_point_off, h_by_point, h_by_pair_off, h_by_pair;    // caller numbering (cmlhip_ba_get_index_maps)
+    std::vector<int> h_dev_of, h_caller_of;                   // caller r -> device r' (pair-sorted) and back
     DevBuf frames, pairs;                                     // FrameDev[N], cmlhip_ba_pair[N*N]
     DevBuf pt_x, pt_y, pt_idepth, pt_idepth_zero, pt_prior, pt_host, pt_colors, pt_weights, pt_backup;
     DevBuf pt_acc;                                            // P x 16 floats: HddA bdA HcdA[4] HddL bdL HcdL[4] HdiF bdSum pad pad
