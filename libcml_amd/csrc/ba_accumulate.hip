@@ -57,7 +57,9 @@ struct AccArgs {
     const double* adH; const double* adT; const float* adHTd; const double* cdelta;
     float* acc_out; int* num_out; double* pair_blocks;
     double* G; double* Wt; int ldg; int do_backup;
+    const float* part; const int* tile_off;                 // CML_MODE_ACTIVE_TILES: wave tiles of the resident residual kernel, tiles of pair q = [tile_off[q], tile_off[q+1])
 };
+#define CML_MODE_ACTIVE_TILES 3        // ACTIVE pair blocks summed from the 16x16 tiles k_ba_lin_rs left (no records read)
 
 // ------------------------------------------------------------------------------------------------ K3
 #define PAIR_TRIP 256          // residuals of a pair staged per trip (4 groups x 64 lanes)
@@ -76,7 +78,8 @@ typedef float float4_ __attribute__((ext_vector_type(4)));
 // operand elements from the staged record (distinct banks or broadcast).  The 16 wave tiles are added in wave order.
 // LINEARIZED mode (rare) computes res_toZero + J*delta per residual (BA.cpp:1699-1729) and stages the same 38 floats.
 __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const int mode) {
-    const bool LIN = mode != CMLHIP_MODE_ACTIVE;          // LINEARIZED and MARGINALIZED walk the plain pair list
+    const bool TILES = mode == CML_MODE_ACTIVE_TILES;
+    const bool LIN = mode != CMLHIP_MODE_ACTIVE && !TILES;  // LINEARIZED and MARGINALIZED walk the plain pair list
     __shared__ float s_rec[PAIR_TRIP][PAIR_REC];
     __shared__ float s_tile[16][256];
     __shared__ int s_cnt;
@@ -98,7 +101,17 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     else if (kq == 2 && e >= 10) { field = true; o1 = e == 10 ? 30 : e == 11 ? 32 : e == 12 ? 36 : e == 13 ? 33 : e == 14 ? 37 : 38; }
     const float a_const = (kq == 2 && e == 10) ? 1.f : 0.f;
     float4_ acc = {0.f, 0.f, 0.f, 0.f};
-    const int span = LIN ? end - beg : A.pair_stride;            // ACTIVE mode walks the fixed-stride list: no offset round trip
+    if (TILES) {
+        // the residual kernel of the resident loop already reduced its residuals on the matrix cores: add the pair's wave tiles
+        // (same D layout, lane for lane), wave w takes tiles w, w+16, ... and the 16 wave sums are added in wave order below
+        const float4* P4 = reinterpret_cast<const float4*>(X.part);
+        const int tb = X.tile_off[q], te = X.tile_off[q + 1];
+        for (int t = tb + wave; t < te; t += 16) {
+            const float4 v = P4[(size_t)t * 64 + ln];
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        }
+    }
+    const int span = TILES ? 0 : (LIN ? end - beg : A.pair_stride);            // ACTIVE mode walks the fixed-stride list: no offset round trip
     for (int t0 = 0; t0 < span; t0 += PAIR_TRIP) {
         const int trip = beg + t0;
         const int ntrip = min(PAIR_TRIP, span - t0);
@@ -163,13 +176,22 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
             }
         }
         __syncthreads();
+        {
+            // Summation order = the one of the resident residual kernel (ba_linearize_rs.hip), so that a loop driven from the host
+            // (records) and the device-resident loop (tiles) produce the same bits: a TILE is 16 consecutive slots of the pair
+            // list, accumulated from zero in slot order; wave w owns tile w of the trip and adds it to its running sum.
+#pragma clang fp contract(off)
+            float4_ tacc = {0.f, 0.f, 0.f, 0.f};
+            const int lbeg = 16 * wave, lend = min(lbeg + 16, ntrip);
 #pragma unroll 4
-        for (int li = wave; li < ntrip; li += 16) {
-            const float* S = s_rec[li];
-            const float v1 = S[o1], v2 = S[o2], m1 = S[o3], m2 = S[o4];
-            const float av = prod ? (kq == 0 ? v1 : v2) : a_const;
-            const float bv = prod ? m1 * v1 + m2 * v2 : (field ? v1 : 0.f);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            for (int li = lbeg; li < lend; li++) {
+                const float* S = s_rec[li];
+                const float v1 = S[o1], v2 = S[o2], m1 = S[o3], m2 = S[o4];
+                const float av = prod ? (kq == 0 ? v1 : v2) : a_const;
+                const float bv = prod ? m1 * v1 + m2 * v2 : (field ? v1 : 0.f);
+                tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, tacc, 0, 0, 0);
+            }
+            acc[0] += tacc[0]; acc[1] += tacc[1]; acc[2] += tacc[2]; acc[3] += tacc[3];
         }
         if (t0 + PAIR_TRIP < span) __syncthreads();               // the staging tile is reused
     }
@@ -283,19 +305,15 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
         float val = 0.f;
         if (good) {
             const int r = code >> 1;
-            const float* J = ((code & 1) ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
+            const float* PS = A.r_jpjdf + PS_STRIDE * (size_t)r;      // one 64-B line per residual: JpJdF + the residual's terms of Hcd, Hdd, bd (kept by applyRes)
             const int t = tgl & 255;
             const int q = host + t * A.N;
-            const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r + 4);
+            const float4 v0 = *reinterpret_cast<const float4*>(PS), v1 = *reinterpret_cast<const float4*>(PS + 4);
             const double4_* AH = reinterpret_cast<const double4_*>(X.adH + 64 * (size_t)q + 8 * a);
             const double4_* AT = reinterpret_cast<const double4_*>(X.adT + 64 * (size_t)q + 8 * a);
             const double4_ h0 = AH[0], h1 = AH[1], t0 = AT[0], t1 = AT[1];
-            const float d0 = J[O_DD], d1 = J[O_DD + 1];
-            const float g0 = J[O_JI2 + 0] * d0 + J[O_JI2 + 2] * d1;
-            const float g1 = J[O_JI2 + 1] * d0 + J[O_JI2 + 3] * d1;
-            const float c0 = a < 4 ? J[O_C0 + (a & 3)] : d0, c1 = a < 4 ? J[O_C1 + (a & 3)] : d1;
-            val = c0 * g0 + c1 * g1;                          // Hcd[a] (a < 4), Hdd (a == 4)
-            if (a == 5) val = lin ? 0.f : (float)((double)J[O_X_JIR] * (double)d0 + (double)J[O_X_JIR + 1] * (double)d1);   // bdL: k_ba_point_bdL
+            val = PS[8 + (a < 6 ? a : 0)];                    // Hcd[a] (a < 4), Hdd (a == 4), bd (a == 5)
+            if (a == 5 && lin) val = 0.f;                     // bdL: k_ba_point_bdL
             if (a == 6) val = 1.f;
             if (a == 7) val = 0.f;
             double st = 0.0;
@@ -416,7 +434,7 @@ __global__ void k_ba_point_rows_marg(BAArgs A, AccArgs X) {
         Hdd += g0 * J[O_DD] + g1 * J[O_DD + 1];
         for (int j = 0; j < 4; j++) Hcd[j] += J[O_C0 + j] * g0 + J[O_C1 + j] * g1;
         const int t = A.r_target[r], q = host + t * A.N;
-        const float* v = A.r_jpjdf + 8 * (size_t)r;
+        const float* v = A.r_jpjdf + PS_STRIDE * (size_t)r;
         const double* AH = X.adH + 64 * (size_t)q; const double* AT = X.adT + 64 * (size_t)q;
         for (int a = 0; a < 8; a++) {
             double sh = 0, st = 0;
@@ -1006,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
             const int code = A.point_code[slot], tgl = A.point_tgt[slot];         // efsJ code kept by applyRes, static target
             const bool good = pv && code >= 0;
             const int r = max(code, 0) >> 1;
-            const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + 8 * (size_t)r + 4);
+            const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r + 4);
             const double* xa = s_xAd + 8 * (host * N + (max(tgl, 0) & 255));
             double d = ((xa[0] * (double)v0.x + xa[1] * (double)v0.y) + (xa[2] * (double)v0.z + xa[3] * (double)v0.w))
                      + ((xa[4] * (double)v1.x + xa[5] * (double)v1.y) + (xa[6] * (double)v1.z + xa[7] * (double)v1.w));
@@ -1091,6 +1109,7 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     X.adH = c->adH.as<double>(); X.adT = c->adT.as<double>(); X.adHTd = c->adHTd.as<float>(); X.cdelta = vs;
     X.acc_out = c->acc_pair[0].as<float>(); X.num_out = c->acc_num[0].as<int>(); X.pair_blocks = c->pair_blocks.as<double>();
     X.ldg = ldg_of(n); X.G = c->G.as<double>(); X.Wt = X.G + (size_t)A.P * X.ldg; X.do_backup = do_backup ? 1 : 0;
+    X.part = c->rs_part.as<float>(); X.tile_off = c->rs_tile_off.as<int>();
     double* pbL = c->pair_blocks.as<double>() + (size_t)PB_STRIDE * NN;
     if (marg) {                                          // marginalizePointsF: MARGINALIZED-mode blocks of the selected points only
         k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, X, CMLHIP_MODE_MARGINALIZED);
@@ -1102,7 +1121,7 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
             k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
             if (A.P > 0) k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
         }
-        CML_LAUNCH_EV(c, k_ba_acc, NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, A, X, 0);
+        CML_LAUNCH_EV(c, k_ba_acc, NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, A, X, c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0);
     }
     SysArgs S;
     S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = (c->n_lin > 0 && !marg) ? 1 : 0;

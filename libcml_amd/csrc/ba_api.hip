@@ -37,7 +37,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.by_pair_off = c->by_pair_off.as<int>(); A.by_pair = c->by_pair.as<int>();
     A.point_code = c->point_code.as<int>(); A.point_tgt = c->point_tgt.as<int>(); A.point_pos = c->point_pos.as<int>(); A.pt_stride = c->pt_stride;
     A.pair_code = c->pair_code.as<int>(); A.pair_pos = c->pair_pos.as<int>(); A.pair_stride = c->pair_stride;
-    A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0;
+    A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0; A.records_only = 0;
     A.dbg = c->dbg_on ? c->dbg.as<long long>() : nullptr;
     return CMLHIP_OK;
 }
@@ -145,7 +145,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->pt_acc, 4 * PT_ACC_STRIDE * P); ENS(c->pt_step, 8 * P);
     ENS(c->r_point, 4 * R); ENS(c->r_host, 4 * R); ENS(c->r_target, 4 * R); ENS(c->r_state, 4 * R); ENS(c->r_new_state, 4 * R);
     ENS(c->r_energy, 4 * R); ENS(c->r_new_energy, 4 * R); ENS(c->r_new_energy_wo, 4 * R); ENS(c->r_ret_energy, 4 * R);
-    ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 32 * R); ENS(c->r_rtz, 32 * R);
+    ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 4 * (size_t)PS_STRIDE * R); ENS(c->r_rtz, 32 * R);
     ENS(c->rj[0], 4 * (size_t)RJ_STRIDE * R); ENS(c->rj[1], 4 * (size_t)RJ_STRIDE * R);
     ENS(c->by_point_off, 4 * (P + 1)); ENS(c->by_point, 4 * R); ENS(c->by_pair_off, 4 * (N * N + 1)); ENS(c->by_pair, 4 * R);
     ENS(c->newframe_res, 4 * newframe.size());
@@ -155,7 +155,21 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->HA, 8 * n * n); ENS(c->HL, 8 * n * n); ENS(c->Hsc, 8 * n * n); ENS(c->HM, 8 * n * n);
     ENS(c->bA, 8 * n); ENS(c->bL, 8 * n); ENS(c->bsc, 8 * n); ENS(c->bM, 8 * n); ENS(c->xvec, 8 * n);
     ENS(c->Hf, 8 * n * n); ENS(c->bf, 8 * n);
-    c->n_lin_partial = (R + 31) / 32;
+    // ---- wave tiles of the resident residual kernel: <= 16 consecutive device residuals of ONE pair each
+    std::vector<int> tiles, tile_off(N * N + 1, 0);
+    for (int q = 0; q < N * N; q++) {
+        const int host = q % N, target = q / N;                  // htIDX = host + target * N
+        for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i += 16) {
+            tiles.push_back(i); tiles.push_back(std::min(16, c->h_by_pair_off[q + 1] - i)); tiles.push_back(host); tiles.push_back(target);
+        }
+        tile_off[q + 1] = (int)tiles.size() / 4;
+    }
+    c->n_tiles = (int)tiles.size() / 4;
+    ENS(c->rs_tiles, 16 * (size_t)std::max(c->n_tiles, 1)); ENS(c->rs_tile_off, 4 * (size_t)(N * N + 1));
+    ENS(c->rs_part, 1024 * (size_t)std::max(c->n_tiles, 1));
+    ENS(c->r_px, 4 * R); ENS(c->r_py, 4 * R); ENS(c->r_colors, 32 * R); ENS(c->r_weights, 32 * R);
+    c->n_lin_partial = std::max((R + 31) / 32, c->n_tiles);
+    c->lin_partial_n = 0; c->efs_in_partials = false;
     ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 31) / 32 + 1));
     ENS(c->G, 8 * ((size_t)P * ldg + P));
     ENS(c->syrk_part, 8 * 256 * (size_t)(ntile * (ntile + 1) / 2) * cml_sys_slices(P));
@@ -217,6 +231,17 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         UP(c->point_code, code); UP(c->point_tgt, tgt); UP(c->point_pos, pos);
     }
     UP(c->newframe_res, newframe);
+    {   // per-residual copies of the point's static inputs (the resident kernel addresses everything by the residual index)
+        std::vector<float> rx(R), ry(R), rc8(8 * (size_t)R), rw8(8 * (size_t)R);
+        for (int k = 0; k < R; k++) {
+            const int p = rp[k];
+            rx[k] = fx[p]; ry[k] = fy[p];
+            memcpy(&rc8[8 * (size_t)k], &col[8 * (size_t)p], 32); memcpy(&rw8[8 * (size_t)k], &wgt[8 * (size_t)p], 32);
+        }
+        UP(c->r_px, rx); UP(c->r_py, ry); UP(c->r_colors, rc8); UP(c->r_weights, rw8);
+        if (c->n_tiles) { UP(c->rs_tiles, tiles); }
+        UP(c->rs_tile_off, tile_off);
+    }
 #undef UP
     // resetOOB (DSOResidual.h:83-88): energies 0, flags cleared
     if ((rc = cml_zero(c, c->r_energy.p, c->r_energy.bytes))) return rc;
@@ -257,6 +282,7 @@ int cmlhip_ba_window_size(cmlhip_ctx* c, int* N, int* P, int* R) { CML_DEV(c);
 int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!pairs) return CMLHIP_ERR_INVALID;
     rc = cml_h2d(c, c->pairs.p, pairs, sizeof(cmlhip_ba_pair) * c->N * c->N);
     if (rc) return rc;
@@ -278,6 +304,7 @@ int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) { CML_DEV(c);
 int cmlhip_ba_set_idepth(cmlhip_ctx* c, const double* idepth, const float* idepth_zero) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!idepth) return CMLHIP_ERR_INVALID;
     rc = cml_h2d(c, c->pt_idepth.p, idepth, 8 * (size_t)c->P);
     if (!rc && idepth_zero) rc = cml_h2d(c, c->pt_idepth_zero.p, idepth_zero, 4 * (size_t)c->P);
@@ -292,6 +319,7 @@ int cmlhip_ba_get_idepth(cmlhip_ctx* c, double* idepth) { CML_DEV(c);
 int cmlhip_ba_linearize_async(cmlhip_ctx* c) { CML_DEV(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     BAArgs A;
     cml_make_ba_args(c, A);
     cml_launch_linearize(c, A);
@@ -316,6 +344,7 @@ int cmlhip_ba_linearize(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DEV(c);
 int cmlhip_ba_apply(cmlhip_ctx* c, int copy) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     BAArgs A;
     cml_make_ba_args(c, A);
     cml_launch_apply(c, A, copy);
@@ -432,6 +461,7 @@ int cmlhip_ba_backup_points(cmlhip_ctx* c) { CML_DEV(c);
 int cmlhip_ba_restore_points(cmlhip_ctx* c) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     BAArgs A;
     cml_make_ba_args(c, A);
     cml_launch_restore_points(c, A);
@@ -454,6 +484,7 @@ static int read_step_sums(cmlhip_ctx* c, float sums[3]) {
 int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     BAArgs A;
     cml_make_ba_args(c, A);
     cml_launch_step_points(c, A);
@@ -484,7 +515,12 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     if (prof) c->ext_stop = ev[1];                           // end timestamp of the K6 dispatch
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
     if (prof) { c->ext_start = ev[2]; c->ext_stop = ev[3]; } // begin / end timestamps of the K1 dispatch itself
-    cml_launch_linearize(c, A);                              // K1: residuals + Jacobians (+ applyRes)
+    if (c->rs_ok) {                                          // K1: residuals + Jacobians + applyRes, Jacobians kept in reduced form
+        cml_launch_linearize_rs(c, A);
+        c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
+    } else {
+        cml_launch_linearize(c, A);
+    }
     c->ext_start = c->ext_stop = nullptr;
     c->lin_finish_pending = true;
     if (prof) c->prof_n++;
@@ -507,6 +543,7 @@ static int upload_point_mask(cmlhip_ctx* c, int n, const int* idx) {
 int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good) { CML_DEV(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
         return CMLHIP_ERR_INVALID;
     if ((rc = upload_accum_in(c, in))) return rc;
@@ -533,6 +570,7 @@ int cmlhip_ba_marginalize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
                                  double* Msc, double* Mbsc) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
         return CMLHIP_ERR_INVALID;
     if ((rc = upload_accum_in(c, in))) return rc;
@@ -554,6 +592,7 @@ int cmlhip_ba_marginalize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
 int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* energy, int* num) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!in || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->adHost || !in->adTarget || !in->cprior) return CMLHIP_ERR_INVALID;
     if ((rc = upload_accum_in(c, in))) return rc;
     const int nb = (c->P + 255) / 256;
@@ -726,6 +765,7 @@ int cmlhip_ba_get_states(cmlhip_ctx* c, int* state, int* new_state, float* energ
 int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!out) return CMLHIP_ERR_INVALID;
     const size_t R = c->R;
     std::vector<float> b0(RJ_STRIDE * R), b1(RJ_STRIDE * R);
@@ -745,9 +785,9 @@ int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) { CML_DEV(c);
 int cmlhip_ba_get_jpjdf(cmlhip_ctx* c, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
-    ResRead rr(c);
-    rr.add(out, c->r_jpjdf.p, 32);
-    if ((rc = rr.read_now())) return rc;
+    std::vector<float> wide(PS_STRIDE * (size_t)c->R);               // the device keeps 16 floats per residual (JpJdF + point-sum terms)
+    if (c->R && (rc = cml_d2h(c, wide.data(), c->r_jpjdf.p, 4 * wide.size()))) return rc;
+    for (size_t r = 0; r < (size_t)c->R; r++) memcpy(out + 8 * r, &wide[PS_STRIDE * (size_t)c->h_dev_of[r]], 32);
     return CMLHIP_OK;
 }
 int cmlhip_ba_get_center_projected(cmlhip_ctx* c, float* out) { CML_DEV(c);

@@ -10,6 +10,11 @@ enum { O_RES = 0, O_XI0 = 8, O_XI1 = 14, O_C0 = 20, O_C1 = 24, O_DD = 28, O_JI0 
        O_X_RR = 78,     // r^T r    (1) + pad
        RJ_STRIDE = 80 };
 
+// per-residual reduced record kept by applyRes (r_jpjdf, PS_STRIDE floats): JpJdF[8] (BA.cpp:2066-2080) and this residual's terms
+// of the point sums of BA.cpp:1747-1750: Hcd[4] at PS_HCD, Hdd at PS_HDD, bd (ACTIVE mode) at PS_BD; what the point rows of
+// k_ba_acc and k_ba_backsub read instead of the 320-B record
+enum { PS_HCD = 8, PS_HDD = 12, PS_BD = 13, PS_STRIDE = 16 };
+
 #define ACC_STRIDE 96          // floats per (host,target) accumulator: 55 (10x10 upper) + 30 (10x3) + 6 (3x3 upper) = 91
 #define PT_ACC_STRIDE 16       // HddA bdA HcdA[4] HddL bdL HcdL[4] HdiF bdSum pad pad
 // per-pair stitched fp64 blocks (stitchDoubleTop, BA.cpp:1827-1843): HH TT HT (64 each) HC TC (32 each) bH bT (8 each) CC (16) bC (4)
@@ -65,7 +70,18 @@ struct BAArgs {
     const float* step_partial_ro;
     const unsigned char* pt_mask; // optional per-point selection (marginalisation passes); null = every point
     int fuse_apply;               // residual kernel also performs applyRes(copyJacobians=true) (valid when the step is always accepted)
+    int records_only;             // k_ba_linearize: only re-create the efsJ record of every good residual (cml_materialize_records)
 };
+
+// resident residual kernel (ba_linearize_rs.hip): wave tiles of <= 16 residuals of one (host,target) pair
+struct RsArgs {
+    const int4* tiles; int ntiles;                 // {first residual, count, host, target}
+    const float* r_px; const float* r_py;          // the point's pixel, per residual
+    const float* r_colors; const float* r_weights; // [R][8] the point's pattern colours / weights, per residual
+    float* part;                                   // [ntiles][64][4]: the wave's 16x16 fp32 tile of its pair's 13x13 block (MFMA D layout)
+};
+int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A);
+int cml_materialize_records(cmlhip_ctx* c);        // re-create the efsJ records the resident kernel did not write (no state change)
 
 // point slices of the Schur SYRK (k_ba_system): more slices = more CUs pulling rows, but more partials for the consumer to add
 // (a power of two <= 8: the solve kernel is instantiated per slice count so that it issues exactly the loads it needs)

@@ -216,7 +216,14 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
 
     // ---- classification, BA.cpp:66-72,115-118,297-314
     if (k == 0) { s_write[g] = run ? 1 : 0; s_ret[g] = 0.0; s_ns[g] = -1; s_flip[g] = 0; s_app[g] = 0; s_sel[g] = pre_sel; s_pos[g] = pre_pos; s_ppos[g] = pre_ppos; }
-    if (live && k == 0) {
+    if (A.records_only) {
+        // cml_materialize_records: the resident kernel kept this pass's Jacobians in reduced form only; re-create the efsJ record of
+        // every good residual from the unchanged inputs (same expressions, same bits), touch no state
+        if (live && k == 0) {
+            const int good = A.r_good[r];
+            s_write[g] = good; s_flip[g] = good; s_app[g] = 1;
+        }
+    } else if (live && k == 0) {
         float ret = pre_energy;
         float nwo = -1.f;
         int ns_final = pre_new_state;
@@ -267,7 +274,14 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
         if (k < 6) v = Jn[O_XI0 + k] * g0 + Jn[O_XI1 + k] * g1;
         else if (k == 6) v = Jn[O_JABJI + 0] * Jn[O_DD] + Jn[O_JABJI + 2] * Jn[O_DD + 1];
         else v = Jn[O_JABJI + 1] * Jn[O_DD] + Jn[O_JABJI + 3] * Jn[O_DD + 1];
-        A.r_jpjdf[8 * (size_t)r + k] = v;
+        A.r_jpjdf[PS_STRIDE * (size_t)r + k] = v;
+        // this residual's terms of the point sums Hcd, Hdd, bd (BA.cpp:1747-1750), read by the point rows of k_ba_acc
+        float w;
+        if (k < 4) w = Jn[O_C0 + k] * g0 + Jn[O_C1 + k] * g1;
+        else if (k == 4) w = Jn[O_DD] * g0 + Jn[O_DD + 1] * g1;
+        else if (k == 5) w = (float)((double)Jn[O_X_JIR] * (double)Jn[O_DD] + (double)Jn[O_X_JIR + 1] * (double)Jn[O_DD + 1]);
+        else w = 0.f;
+        A.r_jpjdf[PS_STRIDE * (size_t)r + 8 + k] = w;
     }
 
     // ---- coalesced copy-out of the finished records into the residual's rJ buffer (the one that is not efsJ)
@@ -342,11 +356,16 @@ __global__ void k_ba_apply(BAArgs A, int copy) {
             const float* J = (sel ? A.rj1 : A.rj0) + (size_t)r * RJ_STRIDE;
             const float g0 = J[O_JI2 + 0] * J[O_DD] + J[O_JI2 + 2] * J[O_DD + 1];
             const float g1 = J[O_JI2 + 1] * J[O_DD] + J[O_JI2 + 3] * J[O_DD + 1];
-            float* o = A.r_jpjdf + 8 * (size_t)r;
+            float* o = A.r_jpjdf + PS_STRIDE * (size_t)r;
 #pragma unroll
             for (int i = 0; i < 6; i++) o[i] = J[O_XI0 + i] * g0 + J[O_XI1 + i] * g1;
             o[6] = J[O_JABJI + 0] * J[O_DD] + J[O_JABJI + 2] * J[O_DD + 1];
             o[7] = J[O_JABJI + 1] * J[O_DD] + J[O_JABJI + 3] * J[O_DD + 1];
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[PS_HCD + i] = J[O_C0 + i] * g0 + J[O_C1 + i] * g1;       // terms of Hcd, Hdd, bd (BA.cpp:1747-1750)
+            o[PS_HDD] = J[O_DD] * g0 + J[O_DD + 1] * g1;
+            o[PS_BD] = (float)((double)J[O_X_JIR] * (double)J[O_DD] + (double)J[O_X_JIR + 1] * (double)J[O_DD + 1]);
+            o[14] = 0.f; o[15] = 0.f;
         } else {
             A.r_good[r] = 0;
             A.pair_code[A.pair_pos[r]] = -1;
@@ -449,13 +468,14 @@ int cml_launch_lin_energy(cmlhip_ctx* c, const BAArgs& A, const float* adHTd, co
 
 int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A) {
     const int blocks = cml_div_up(A.R, RES_PER_BLOCK);
+    if (A.lin_partial) c->lin_partial_n = blocks;
     if (blocks == 0) return CMLHIP_OK;
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_ba_linearize<true>, blocks, 256, 0, A);
     else CML_LAUNCH_EV(c, k_ba_linearize<false>, blocks, 256, 0, A);
     return CMLHIP_OK;
 }
 int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A) {
-    k_ba_lin_finish<<<1, 1024, 0, c->stream>>>(A, c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->n_lin_partial,
+    k_ba_lin_finish<<<1, 1024, 0, c->stream>>>(A, c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n,
                                                 c->scal.as<LinSummary>(), c->frames.as<FrameDev>());
     return CMLHIP_OK;
 }
@@ -463,4 +483,18 @@ int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy) {
     if (A.R == 0) return CMLHIP_OK;
     k_ba_apply<<<cml_div_up(A.R, 256), 256, 0, c->stream>>>(A, copy);
     return CMLHIP_OK;
+}
+
+// The resident residual kernel (ba_linearize_rs.hip) keeps a pass's Jacobians in reduced form (pair tiles + 14 floats per residual).
+// Before anything reads a 74-float record, or changes the state the records would be re-created from, the efsJ record of every good
+// residual is re-created here: k_ba_linearize in records-only mode on the unchanged inputs (bit-identical by construction), selector
+// flip and pair / point codes as applyRes would have left them.  No state, energy or classification is touched.
+int cml_materialize_records(cmlhip_ctx* c) {
+    if (!c->efs_in_partials) return CMLHIP_OK;
+    c->efs_in_partials = false;
+    if (!c->ba_uploaded || !c->ba_pairs_set || c->R == 0) return CMLHIP_OK;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    A.records_only = 1; A.fuse_apply = 1; A.lin_partial = nullptr; A.ctl = nullptr;
+    return cml_launch_linearize(c, A);
 }

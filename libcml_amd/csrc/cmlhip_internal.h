@@ -85,6 +85,12 @@ struct cmlhip_ctx {
     DevBuf by_point_off, by_point, by_pair_off, by_pair, newframe_res;
     DevBuf point_code, point_tgt, point_pos; int pt_stride = 0; // [P][pt_stride]: efsJ code per point slot (kept by applyRes), static target | lin << 8, slot of r
     DevBuf pair_code, pair_pos; int pair_stride = 0;          // [N*N][pair_stride] efsJ code (2r+sel, -1 = not in the ACTIVE sum) kept by applyRes; position of r
+    // resident residual kernel (ba_linearize_rs.hip)
+    DevBuf rs_tiles, rs_tile_off, rs_part, r_px, r_py, r_colors, r_weights; int n_tiles = 0;
+    bool efs_in_partials = false;                             // the last residual pass was the resident kernel: the pair blocks of the good
+                                                              // residuals live in rs_part, their efsJ records are NOT materialised
+    bool rs_ok = true;                                        // use the resident kernel in cmlhip_ba_iteration_async (CMLHIP_NO_RS=1 in the environment: the record-writing kernel)
+    int lin_partial_n = 0;                                    // number of energy partials the last residual pass wrote
     DevBuf acc_pair[2];                                       // N*N x 96 floats (91 used) ACTIVE / LINEARIZED
     DevBuf acc_num[2];                                        // N*N ints
     DevBuf pair_blocks;                                       // N*N x PAIR_BLK doubles (stitched per-pair blocks)

@@ -1,0 +1,75 @@
+"""The residual kernel of the device-resident loop (k_ba_lin_rs: pair-sorted residuals, 4 lanes per residual, Jacobians kept in
+reduced form) against the record-writing kernel k_ba_linearize — which tests/test_ba_parity_gpu.py and tests/test_config_e_gpu.py
+hold bit-exact against the oracle — on identical device state:
+  * per-residual outputs (states, energies, JpJdF, centre projection): BIT-EXACT (same expressions in the same order);
+  * the pair blocks summed from the kernel's matrix-core tiles against the blocks summed from the records, and everything
+    downstream (H_A, b_A, H_sc, b_sc): fp32 accumulation-order tolerance;
+  * the 74-float records re-created on demand (cml_materialize_records): BIT-EXACT against the records the other kernel wrote."""
+import os
+
+import numpy as np
+import pytest
+
+from libcml_amd import abi
+from tests import ba_setup as S
+from tests import dev_setup as D
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(I, use_rs, texel_format):
+    if use_rs:
+        os.environ.pop("CMLHIP_NO_RS", None)
+    else:
+        os.environ["CMLHIP_NO_RS"] = "1"
+    try:
+        ctx = D.make_ctx(I, texel_format=texel_format)
+    finally:
+        os.environ.pop("CMLHIP_NO_RS", None)
+    return ctx
+
+
+@pytest.mark.parametrize("config,half", [("tiny", False), ("small", False), ("small", True), ("B", False)])
+def test_resident_kernel_matches_record_kernel(config, half):
+    I = S.make_inputs(config)
+    if half:
+        for k in range(I.N):
+            for lvl in range(len(I.grads[k])):
+                I.grads[k][lvl] = I.grads[k][lvl].astype(np.float16).astype(np.float32)
+    fmt = abi.TEXEL_F16 if half else abi.TEXEL_F32
+    a, b = _make(I, False, fmt), _make(I, True, fmt)          # a: record-writing kernel in the loop, b: resident kernel
+    try:
+        for c in (a, b):
+            c.ba_linearize(); c.ba_apply(1)
+            D.accumulate(c, I)                                 # leaves adjoints / priors on the device
+            c.ba_iteration_async(1e-5)                         # K3..K6 identical in both (records path), then the residual kernel under test
+            c.sync()
+        sa, sb = a.ba_states(), b.ba_states()
+        for k in ("state", "new_state", "good"):
+            assert np.array_equal(sa[k], sb[k]), k
+        for k in ("energy", "new_energy", "new_energy_wo"):
+            assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)), k
+        g = sa["good"] == 1
+        assert g.sum() > 10
+        assert np.array_equal(a.ba_get_idepth().view(np.uint64), b.ba_get_idepth().view(np.uint64))
+        assert np.array_equal(a.ba_jpjdf()[g].view(np.uint32), b.ba_jpjdf()[g].view(np.uint32)), "JpJdF differs"
+        IN = sa["new_state"] == 0
+        assert np.array_equal(a.ba_center()[IN].view(np.uint32), b.ba_center()[IN].view(np.uint32))
+        # accumulate: records (a) vs matrix-core tiles of the resident kernel (b)
+        Ha, Hb = D.accumulate(a, I), D.accumulate(b, I)
+        pa, pb = a.ba_pair_acc(0), b.ba_pair_acc(0)
+        for q in range(I.N * I.N):
+            assert np.abs(pa[q] - pb[q]).max() <= 2e-5 * max(np.abs(pa[q]).max(), 1e-30), q
+        assert D.rel(Hb[0], Ha[0]) < 2e-5 and D.rel(Hb[1], Ha[1]) < 2e-5
+        assert D.rel(Hb[4], Ha[4]) < 5e-5 and D.rel(Hb[5], Ha[5]) < 5e-5
+        qa, qb = a.ba_point_acc(), b.ba_point_acc()
+        assert np.abs(qa - qb).max() <= 2e-5 * np.abs(qa).max()
+        # the records the resident kernel did not write, re-created on demand
+        assert np.array_equal(a.ba_rj(1)[g].view(np.uint32), b.ba_rj(1)[g].view(np.uint32)), "re-materialised records differ"
+        # and the loop goes on from there identically in structure: one more iteration, same classification
+        for c in (a, b):
+            c.ba_iteration_async(1e-5); c.sync()
+        sa2, sb2 = a.ba_states(), b.ba_states()
+        assert (sa2["new_state"] != sb2["new_state"]).sum() <= max(2, I.R // 2000)      # inputs now differ by fp32 accumulation noise
+    finally:
+        a.close(); b.close()
