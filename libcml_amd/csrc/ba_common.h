@@ -78,6 +78,7 @@ struct RsArgs {
     const int4* tiles; int ntiles;                 // {first residual, count, host, target}
     const float* r_px; const float* r_py;          // the point's pixel, per residual
     const float* r_colors; const float* r_weights; // [R][8] the point's pattern colours / weights, per residual
+    int dbg_flags;                                 // development switches (CMLHIP_RS_DBG)
     float* part;                                   // [ntiles][64][4]: the wave's 16x16 fp32 tile of its pair's 13x13 block (MFMA D layout)
 };
 int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A);

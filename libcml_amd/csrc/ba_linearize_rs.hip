@@ -17,6 +17,7 @@
 //     (BA.cpp:1747-1750).  The full records are re-materialised on demand by k_ba_linearize (cml_materialize_records).
 #include "cmlhip_internal.h"
 #include "ba_common.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -55,8 +56,27 @@ __device__ __forceinline__ float rs_sel4(const int j, const float a, const float
 __constant__ unsigned c_rs_mfma_off[64] = {0x1816100Cu, 0x1816110Du, 0x1816120Eu, 0x1816130Fu, 0x18160600u, 0x18160701u, 0x18160802u, 0x18160903u, 0x18160A04u, 0x18160B05u, 0x1427141Au, 0x1427141Bu, 0x14271422u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1918100Cu, 0x1918110Du, 0x1918120Eu, 0x1918130Fu, 0x19180600u, 0x19180701u, 0x19180802u, 0x19180903u, 0x19180A04u, 0x19180B05u, 0x1427141Cu, 0x1427141Du, 0x14271423u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1427141Eu, 0x14271420u, 0x14271424u, 0x14271421u, 0x14271425u, 0x14271426u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u};
 __constant__ unsigned char c_rs_mfma_a[64] = {12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 20, 20, 20, 20, 20, 20, 16, 17, 18, 19, 6, 7, 8, 9, 10, 11, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 39, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
 
+// fp64 division x / z as the compiler lowers it (v_rcp_f64, two Newton steps, quotient, remainder, one correction), WITHOUT the
+// v_div_scale / v_div_fixup wrapping that only acts on operands at the ends of the exponent range or on non-finite ones: for every
+// finite operand pair in the normal range the bits are those of the IEEE quotient; a zero, infinite or NaN denominator yields a
+// non-finite result here as there (inf may become NaN: every consumer below only asks whether the value is inside the image).
+// Splitting it lets the two projections of a pixel (x/z, y/z) share the reciprocal.
+__device__ __forceinline__ double rs_rcp_refined(const double z) {
+    double r = __builtin_amdgcn_rcp(z);
+    double e = __builtin_fma(-z, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-z, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double rs_div(const double x, const double z, const double r) {
+    const double q = x * r;
+    const double rem = __builtin_fma(-z, q, x);
+    return __builtin_fma(rem, r, q);
+}
+
 #define RS_RES 16            // residuals per wave
-#define RS_DSTRIDE 92        // doubles per residual in the fp64 operand rows (10 rows x 9): 184 dwords = 56 mod 64, 8 residuals on distinct banks
+#define RS_DSTRIDE 90        // doubles per residual in the fp64 operand rows (10 rows x 9): 180 dwords = 52 mod 64, 8 residuals on distinct bank pairs
 #define RS_FSTRIDE 25        // floats per residual in the fp32 operand rows (3 rows x 8)
 #define RS_SSTRIDE 45        // floats per residual of the staged reduced record (odd: conflict-free lane-per-record reads)
 
@@ -64,12 +84,13 @@ __constant__ unsigned char c_rs_mfma_a[64] = {12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 
 template <bool LO>
 __device__ __forceinline__ float rs_jpdc(const int k, const double E0, const double E1, const double E3, const double E4, const double E6,
                                          const double E7, const float u, const float v, const float fxf, const float fyf, const float drescale,
-                                         const double rx, const double ry, const double scale_f, const double scale_c) {
+                                         const double rx, const double ry, const double scale_f, const double scale_c, const double rfx, const double rfy) {
     const bool odd = k & 1;
     const double Ea = odd ? E7 : E6, Eb = LO ? (odd ? E1 : E0) : (odd ? E4 : E3);
     const float wq = LO ? u : v;
     const float sfac = LO ? (odd ? fxf : 1.f) : (odd ? 1.f : fyf), s2 = LO ? (odd ? fyf : 1.f) : (odd ? 1.f : fxf);
-    const double q = (sfac * drescale) * (Ea * wq - Eb) / s2;
+    const double rs2 = LO ? (odd ? rfy : 1.0) : (odd ? 1.0 : rfx);             // refined reciprocal of s2 (exactly 1 for s2 = 1: the division is then exact)
+    const double q = rs_div((sfac * drescale) * (Ea * wq - Eb), (double)s2, rs2);
     const double m = (k & 2) ? 1.0 : (odd ? ry : rx);
     const double add = k == 0 ? (double)u : (k == 5 ? (double)v : ((k == 2 || k == 7) ? 1.0 : -0.0));
     const double scl = (k & 2) ? scale_c : scale_f;
@@ -77,10 +98,11 @@ __device__ __forceinline__ float rs_jpdc(const int k, const double E0, const dou
 }
 
 template <bool HALF>
-__global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
+__global__ __launch_bounds__(256, 3) void k_ba_lin_rs(BAArgs A, RsArgs X) {
     __shared__ double s_shd[4][RS_RES * RS_DSTRIDE];                                   // [wave][residual * RS_DSTRIDE + quantity * 9 + pixel]
     __shared__ float s_shf[4][RS_RES * RS_FSTRIDE];                                    // [wave][residual * RS_FSTRIDE + quantity * 8 + pixel]
-    __shared__ float s_stg[4][RS_RES * RS_SSTRIDE];                                    // staged reduced record (layout of k_ba_acc's s_rec + Jpdd at 40,41)
+    // the staged reduced record (layout of k_ba_acc's s_rec + Jpdd at 40,41) reuses the wave's fp64 rows once the sums are taken (a wave's
+    // LDS operations execute in order): 52.5 KB per workgroup, three workgroups per CU
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, g = ln >> 2, j = ln & 3;
     if (A.ctl && A.ctl->stop_lin) return;                  // converged in an earlier launch (raised by k_ba_acc), BA.cpp:879
     const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
@@ -114,7 +136,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
     const bool run = live && st != CMLHIP_RES_OOB;
 
     // ---- the lane's two pattern pixels, BA.cpp:193-212 (star8 offsets + 2 packed by nibble, types.h:1381-1393)
-    double qx[2], qy[2], ppx[2], ppy[2], ppz[2], kx[2], ky[2];
+    double qx[2], qy[2], ppx[2], ppy[2], ppz[2], kx[2], ky[2], rz[2];
     bool pix_in[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -125,7 +147,8 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
         ppx[u] = (R0_ * qx[u] + R1_ * qy[u] + R2_ * 1.0) + t0_ * idepth;
         ppy[u] = (R3_ * qx[u] + R4_ * qy[u] + R5_ * 1.0) + t1_ * idepth;
         ppz[u] = (R6_ * qx[u] + R7_ * qy[u] + R8_ * 1.0) + t2_ * idepth;
-        kx[u] = (ppx[u] / ppz[u]) * A.fx + A.cx; ky[u] = (ppy[u] / ppz[u]) * A.fy + A.cy;
+        rz[u] = rs_rcp_refined(ppz[u]);
+        kx[u] = rs_div(ppx[u], ppz[u], rz[u]) * A.fx + A.cx; ky[u] = rs_div(ppy[u], ppz[u], rz[u]) * A.fy + A.cy;
         pix_in[u] = (kx[u] >= 2 && ky[u] >= 2 && kx[u] < A.w - 2 && ky[u] < A.h - 2);
     }
     // ---- centre projection, BA.cpp:102-131: pattern pixel 4 is the offset (0,0) = first pixel of quad lane 2: the very same
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
     const double rx = quad_bcast_d<2>(qx[0]), ry = quad_bcast_d<2>(qy[0]);
     const double px = quad_bcast_d<2>(ppx[0]), py = quad_bcast_d<2>(ppy[0]), pz = quad_bcast_d<2>(ppz[0]);
     const double Kud = quad_bcast_d<2>(kx[0]), Kvd = quad_bcast_d<2>(ky[0]);
-    const float drescale = (float)(1.0 / pz);
+    const float drescale = quad_bcast_f<2>((float)rs_div(1.0, ppz[0], rz[0]));     // (float)(1.0 / pz) of the centre pixel
     const bool centre_in = (Kud >= 2 && Kvd >= 2 && Kud < A.w - 2 && Kvd < A.h - 2);
 
     // ---- GradientImage::interpolate (Array2D.h:265-286) of both pixels: eight unconditional loads on clamped addresses
@@ -148,7 +171,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
         const float dx = x - (float)ix, dy = y - (float)iy;
         const float dxdy = dx * dy;
         tw00[u] = 1 - dx - dy + dxdy; tw01[u] = dx - dxdy; tw10[u] = dy - dxdy; tw11[u] = dxdy;
-        const size_t i1 = sample[u] ? (size_t)iy * A.w + ix : (size_t)0;
+        const size_t i1 = (sample[u] && !(X.dbg_flags & 1)) ? (size_t)iy * A.w + ix : (size_t)0;
         ta[u] = rs_load_texel<HALF>(ft.grad0, i1); tb[u] = rs_load_texel<HALF>(ft.grad0, i1 + 1);
         tc[u] = rs_load_texel<HALF>(ft.grad0, i1 + A.w); td[u] = rs_load_texel<HALF>(ft.grad0, i1 + A.w + 1);
     }
@@ -190,7 +213,8 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
         const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
         const float residual = I[u] - refRealColor;
         float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
-        float wgt = sqrtf((float)(A.oth_d / (A.oth_d + (double)(gx[u] * gx[u] + gy[u] * gy[u]))));
+        const double wden = A.oth_d + (double)(gx[u] * gx[u] + gy[u] * gy[u]);
+        float wgt = sqrtf((float)rs_div(A.oth_d, wden, rs_rcp_refined(wden)));
         wgt = (float)(0.5f * ((double)wgt + (double)(u == 0 ? wgt2.x : wgt2.y)));
         const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
         const float hw0 = hw;
@@ -283,20 +307,22 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
 
     // ---- geometric Jacobians, BA.cpp:120-188: every lane evaluates two entries of each group (k = j and k = j + 4), same
     //      expression shapes as k_ba_linearize; a residual that is not IN stages zeros (the matrix-core loop below is branch-free)
-    float* S = &s_stg[wv][g * RS_SSTRIDE];
+    float* const stg = reinterpret_cast<float*>(&s_shd[wv][0]);
+    float* S = &stg[g * RS_SSTRIDE];
     {
         // Every lane issues the SAME stores with per-lane addresses (a lane with nothing to contribute to a group writes a spare slot,
         // 42..44): a lane-divergent `if` around an LDS access costs a branch each.
         const float u = (float)px, v = (float)py;            // BA.cpp:121-122: un-normalised x,y, literal
         const float fxf = (float)A.fx, fyf = (float)A.fy;
+        const double rfx = rs_rcp_refined((double)fxf), rfy = rs_rcp_refined((double)fyf);      // wave-uniform
         // Jpdxi[0][k], Jpdxi[1][k], k = j (0..3) and k = j + 4 (4, 5 for j < 2)          (fp32, BA.cpp:133-147)
         const float xa0 = rs_sel4(j, new_idepth * fxf, 0.f, -new_idepth * u * fxf, -u * v * fxf);
         const float xa1 = rs_sel4(j, 0.f, new_idepth * fyf, -new_idepth * v * fyf, -(1 + v * v) * fyf);
         const float xb0 = rs_sel4(j, (1 + u * u) * fxf, -v * fxf, 0.f, 0.f);
         const float xb1 = rs_sel4(j, u * v * fyf, u * fyf, 0.f, 0.f);
         // Jpdc[0][j], Jpdc[1][j]                                                         (:150-176)
-        const float c0 = rs_jpdc<true>(j, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c);
-        const float c1 = rs_jpdc<false>(j + 4, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c);
+        const float c0 = rs_jpdc<true>(j, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
+        const float c1 = rs_jpdc<false>(j + 4, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
         // Jpdd[j], j < 2                                                                 (:178-182)
         const bool odd = j & 1;
         const double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
         o.z = P2 * s2 + Q2 * t2;
         o.w = P3 * s2 + Q3 * t2;
         if (j == 3) { o.y = bd; o.z = 0.f; o.w = 0.f; }
-        if (flip) reinterpret_cast<float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r)[j] = o;
+        if (flip && !(X.dbg_flags & 2)) reinterpret_cast<float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r)[j] = o;
     }
 
     // ---- the wave's contribution to the 13x13 block of its pair: one v_mfma_f32_16x16x4_f32 per residual (see acc_pair_block)
@@ -347,7 +373,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
         const unsigned off = c_rs_mfma_off[ln];
         const int oa = c_rs_mfma_a[ln], o1 = off & 255, o2 = (off >> 8) & 255, o3 = (off >> 16) & 255, o4 = off >> 24;
         float4_ acc = {0.f, 0.f, 0.f, 0.f};
-        const float* SW = &s_stg[wv][0];
+        const float* SW = stg;
 #pragma unroll 4
         for (int li = 0; li < RS_RES; li++) {
             const float* SL = SW + li * RS_SSTRIDE;
@@ -356,7 +382,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_rs(BAArgs A, RsArgs X) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
         // a residual slot beyond the tile's count (or not IN) staged zeros: the ones slot then multiplies zero fields only
-        reinterpret_cast<float4*>(X.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (!(X.dbg_flags & 2)) reinterpret_cast<float4*>(X.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 
     // ---- per-tile partials {energy, n_in, n_oob, n_outlier} (BA.cpp:1565): fixed butterfly order over the 16 residuals
@@ -391,6 +417,7 @@ int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
     X.tiles = c->rs_tiles.as<int4>(); X.ntiles = c->n_tiles;
     X.r_px = c->r_px.as<float>(); X.r_py = c->r_py.as<float>(); X.r_colors = c->r_colors.as<float>(); X.r_weights = c->r_weights.as<float>();
     X.part = c->rs_part.as<float>();
+    { static const char* e = getenv("CMLHIP_RS_DBG"); X.dbg_flags = e ? atoi(e) : 0; }      // development: 1 = all texel taps at texel 0, 2 = no tile / reduced-record stores
     const int blocks = cml_div_up(c->n_tiles, 4);
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_ba_lin_rs<true>, blocks, 256, 0, A, X);
     else CML_LAUNCH_EV(c, k_ba_lin_rs<false>, blocks, 256, 0, A, X);
