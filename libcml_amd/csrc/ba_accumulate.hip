@@ -57,6 +57,7 @@ struct AccArgs {
     const double* adH; const double* adT; const float* adHTd; const double* cdelta;
     float* acc_out; int* num_out; double* pair_blocks;
     double* G; double* Wt; int ldg; int do_backup;
+    int tile;                                               // residual slots per tile of this window (16 or 64)
     const float* part; const int* tile_off;                 // CML_MODE_ACTIVE_TILES: wave tiles of the resident residual kernel, tiles of pair q = [tile_off[q], tile_off[q+1])
 };
 #define CML_MODE_ACTIVE_TILES 3        // ACTIVE pair blocks summed from the 16x16 tiles k_ba_lin_rs left (no records read)
@@ -103,10 +104,11 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     float4_ acc = {0.f, 0.f, 0.f, 0.f};
     if (TILES) {
         // the residual kernel of the resident loop already reduced its residuals on the matrix cores: add the pair's wave tiles
-        // (same D layout, lane for lane), wave w takes tiles w, w+16, ... and the 16 wave sums are added in wave order below
+        // (same D layout, lane for lane); wave w < 256 / tile takes tiles w, w + 256 / tile, ... (the assignment of the record path below) and the wave sums are added in wave order below
         const float4* P4 = reinterpret_cast<const float4*>(X.part);
         const int tb = X.tile_off[q], te = X.tile_off[q + 1];
-        for (int t = tb + wave; t < te; t += 16) {
+        const int tpt = PAIR_TRIP / X.tile;                  // tiles per trip = waves that own a tile
+        for (int t = tb + wave; wave < tpt && t < te; t += tpt) {
             const float4 v = P4[(size_t)t * 64 + ln];
             acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
         }
@@ -178,11 +180,11 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
         __syncthreads();
         {
             // Summation order = the one of the resident residual kernel (ba_linearize_rs.hip), so that a loop driven from the host
-            // (records) and the device-resident loop (tiles) produce the same bits: a TILE is 16 consecutive slots of the pair
-            // list, accumulated from zero in slot order; wave w owns tile w of the trip and adds it to its running sum.
+            // (records) and the device-resident loop (tiles) produce the same bits: a TILE is X.tile (16 or 64) consecutive slots of the pair
+            // list, accumulated from zero in slot order; wave w < 256 / tile owns tile w of the trip and adds it to its running sum.
 #pragma clang fp contract(off)
             float4_ tacc = {0.f, 0.f, 0.f, 0.f};
-            const int lbeg = 16 * wave, lend = min(lbeg + 16, ntrip);
+            const int lbeg = X.tile * wave, lend = min(lbeg + X.tile, ntrip);
 #pragma unroll 4
             for (int li = lbeg; li < lend; li++) {
                 const float* S = s_rec[li];
@@ -1038,6 +1040,8 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
             st = -bb * (double)pa12;
             if (pv && i == 0 && !isfinite(st)) atomicAdd(&sum->nonfinite, 1);
         }
+        double nid_w = 0.0;
+        int nid_ok = 0;
         if (pv && i == 0) {
             A.pt_step[p] = st;
             if (do_step) {
@@ -1046,7 +1050,18 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
                     A.pt_idepth[p] = nid;
                     sumID = (float)(st * st); sumNID = (float)fabs((double)A.pt_backup[p]); numID = 1.f;
                     A.pt_idepth_zero[p] = (float)nid;
+                    nid_w = nid; nid_ok = 1;
                 }
+            }
+        }
+        if (do_step) {
+            // the residual kernel of the resident loop reads the inverse depth per RESIDUAL (no hop through the point index): the
+            // 8 lanes of the point refresh the copies of its residuals
+            const int src = threadIdx.x & 56;                 // (blockDim = 256: the 8-lane group never straddles a wave)
+            nid_w = __shfl(nid_w, src); nid_ok = __shfl(nid_ok, src);
+            for (int base = 0; base < A.pt_stride; base += 8) {
+                const int res = A.point_res[pp * A.pt_stride + base + i];
+                if (pv && nid_ok && res >= 0) A.r_idepth[res] = nid_w;
             }
         }
     }
@@ -1109,7 +1124,7 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     X.adH = c->adH.as<double>(); X.adT = c->adT.as<double>(); X.adHTd = c->adHTd.as<float>(); X.cdelta = vs;
     X.acc_out = c->acc_pair[0].as<float>(); X.num_out = c->acc_num[0].as<int>(); X.pair_blocks = c->pair_blocks.as<double>();
     X.ldg = ldg_of(n); X.G = c->G.as<double>(); X.Wt = X.G + (size_t)A.P * X.ldg; X.do_backup = do_backup ? 1 : 0;
-    X.part = c->rs_part.as<float>(); X.tile_off = c->rs_tile_off.as<int>();
+    X.part = c->rs_part.as<float>(); X.tile_off = c->rs_tile_off.as<int>(); X.tile = c->rs_tile;
     double* pbL = c->pair_blocks.as<double>() + (size_t)PB_STRIDE * NN;
     if (marg) {                                          // marginalizePointsF: MARGINALIZED-mode blocks of the selected points only
         k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, X, CMLHIP_MODE_MARGINALIZED);
@@ -1162,7 +1177,7 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
 #define LAUNCH_SOLVE(NSL) do { \
         if (!(c->attr_done & (1u << NSL))) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c->attr_done |= 1u << NSL; } \
         k_ba_solve<NSL><<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag, \
-            c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->n_lin_partial, c->scal.as<LinSummary>(), \
+            c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n, c->scal.as<LinSummary>(), \
             c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr); } while (0)
     switch (Y.nsl) {
         case 1: LAUNCH_SOLVE(1); break;

@@ -36,6 +36,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.by_point_off = c->by_point_off.as<int>(); A.by_point = c->by_point.as<int>();
     A.by_pair_off = c->by_pair_off.as<int>(); A.by_pair = c->by_pair.as<int>();
     A.point_code = c->point_code.as<int>(); A.point_tgt = c->point_tgt.as<int>(); A.point_pos = c->point_pos.as<int>(); A.pt_stride = c->pt_stride;
+    A.r_idepth = c->r_idepth.as<double>(); A.point_res = c->point_res.as<int>();
     A.pair_code = c->pair_code.as<int>(); A.pair_pos = c->pair_pos.as<int>(); A.pair_stride = c->pair_stride;
     A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0; A.records_only = 0;
     A.dbg = c->dbg_on ? c->dbg.as<long long>() : nullptr;
@@ -155,19 +156,28 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->HA, 8 * n * n); ENS(c->HL, 8 * n * n); ENS(c->Hsc, 8 * n * n); ENS(c->HM, 8 * n * n);
     ENS(c->bA, 8 * n); ENS(c->bL, 8 * n); ENS(c->bsc, 8 * n); ENS(c->bM, 8 * n); ENS(c->xvec, 8 * n);
     ENS(c->Hf, 8 * n * n); ENS(c->bf, 8 * n);
-    // ---- wave tiles of the resident residual kernel: <= 16 consecutive device residuals of ONE pair each
+    // ---- wave tiles of the resident residual kernel: <= RS_TILE consecutive device residuals of ONE pair each
+    // Tile size by regime: a window that gives the lane-per-residual kernel at least one wave per SIMD runs it (throughput);
+    // smaller windows are latency-bound and take 4 lanes per residual.  CMLHIP_RS_TILE=16|64 forces one (development).
+    {
+        const char* e = getenv("CMLHIP_RS_TILE");
+        const int forced = e ? atoi(e) : 0;
+        c->rs_tile = (forced == 16 || forced == 64) ? forced : (R >= 64 * 1024 ? 64 : 16);
+    }
+    const int TS = c->rs_tile;
     std::vector<int> tiles, tile_off(N * N + 1, 0);
     for (int q = 0; q < N * N; q++) {
         const int host = q % N, target = q / N;                  // htIDX = host + target * N
-        for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i += 16) {
-            tiles.push_back(i); tiles.push_back(std::min(16, c->h_by_pair_off[q + 1] - i)); tiles.push_back(host); tiles.push_back(target);
+        for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i += TS) {
+            tiles.push_back(i); tiles.push_back(std::min(TS, c->h_by_pair_off[q + 1] - i)); tiles.push_back(host); tiles.push_back(target);
         }
         tile_off[q + 1] = (int)tiles.size() / 4;
     }
     c->n_tiles = (int)tiles.size() / 4;
     ENS(c->rs_tiles, 16 * (size_t)std::max(c->n_tiles, 1)); ENS(c->rs_tile_off, 4 * (size_t)(N * N + 1));
     ENS(c->rs_part, 1024 * (size_t)std::max(c->n_tiles, 1));
-    ENS(c->r_px, 4 * R); ENS(c->r_py, 4 * R); ENS(c->r_colors, 32 * R); ENS(c->r_weights, 32 * R);
+    ENS(c->r_px, 4 * R); ENS(c->r_py, 4 * R); ENS(c->r_colors, 32 * R); ENS(c->r_weights, 32 * R); ENS(c->r_idepth, 8 * R);
+    c->r_idepth_dirty = true;
     c->n_lin_partial = std::max((R + 31) / 32, c->n_tiles);
     c->lin_partial_n = 0; c->efs_in_partials = false;
     ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 31) / 32 + 1));
@@ -218,17 +228,19 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         for (int p = 0; p < P; p++) mx = std::max(mx, c->h_by_point_off[p + 1] - c->h_by_point_off[p]);
         c->pt_stride = (mx + 7) & ~7;
         const size_t tot = (size_t)std::max(P, 1) * c->pt_stride;
-        std::vector<int> code(tot, -1), tgt(tot, -1), pos(std::max(R, 1), 0);
+        std::vector<int> code(tot, -1), tgt(tot, -1), pos(std::max(R, 1), 0), pres(tot, -1);
         for (int p = 0; p < P; p++)
             for (int i = c->h_by_point_off[p]; i < c->h_by_point_off[p + 1]; i++) {
                 const int r = c->h_by_point[i], slot = p * c->pt_stride + (i - c->h_by_point_off[p]);
                 pos[c->h_dev_of[r]] = slot;
+                pres[slot] = c->h_dev_of[r];
                 tgt[slot] = res[r].target | (res[r].is_linearized ? 256 : 0);
             }
         if ((rc = cml_ensure(c, c->point_code, 4 * code.size()))) return rc;
         if ((rc = cml_ensure(c, c->point_tgt, 4 * tgt.size()))) return rc;
         if ((rc = cml_ensure(c, c->point_pos, 4 * pos.size()))) return rc;
-        UP(c->point_code, code); UP(c->point_tgt, tgt); UP(c->point_pos, pos);
+        if ((rc = cml_ensure(c, c->point_res, 4 * pres.size()))) return rc;
+        UP(c->point_code, code); UP(c->point_tgt, tgt); UP(c->point_pos, pos); UP(c->point_res, pres);
     }
     UP(c->newframe_res, newframe);
     {   // per-residual copies of the point's static inputs (the resident kernel addresses everything by the residual index)
@@ -306,6 +318,7 @@ int cmlhip_ba_set_idepth(cmlhip_ctx* c, const double* idepth, const float* idept
     if (rc) return rc;
     if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!idepth) return CMLHIP_ERR_INVALID;
+    c->r_idepth_dirty = true;
     rc = cml_h2d(c, c->pt_idepth.p, idepth, 8 * (size_t)c->P);
     if (!rc && idepth_zero) rc = cml_h2d(c, c->pt_idepth_zero.p, idepth_zero, 4 * (size_t)c->P);
     return rc;
@@ -464,6 +477,7 @@ int cmlhip_ba_restore_points(cmlhip_ctx* c) { CML_DEV(c);
     if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     BAArgs A;
     cml_make_ba_args(c, A);
+    c->r_idepth_dirty = true;
     cml_launch_restore_points(c, A);
     CML_CHECK(c, hipGetLastError());
     return CMLHIP_OK;
@@ -487,6 +501,7 @@ int cmlhip_ba_step_points(cmlhip_ctx* c, float sums[3]) { CML_DEV(c);
     if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     BAArgs A;
     cml_make_ba_args(c, A);
+    c->r_idepth_dirty = true;
     cml_launch_step_points(c, A);
     CML_CHECK(c, hipGetLastError());
     if (sums) return read_step_sums(c, sums);

@@ -61,6 +61,7 @@ struct BAArgs {
     unsigned char* r_lin_rw; int* point_tgt_rw;    // writable views for the marginalisation kernels (isLinearized changes there)
     float* r_center; float* r_jpjdf; float* r_rtz; float* rj0; float* rj1;
     const int* by_point_off; const int* by_point; const int* by_pair_off; const int* by_pair;
+    double* r_idepth; const int* point_res;         // per-residual copy of the point's inverse depth; [P][pt_stride] residual of the slot (-1 = empty)
     int* point_code; const int* point_tgt; const int* point_pos; int pt_stride;   // [P][pt_stride]: 2r+sel of the point's good residuals else -1; target | lin << 8 (-1 = empty slot); slot of r
     int* pair_code; const int* pair_pos; int pair_stride;     // [N*N][pair_stride]: 2r+sel of the ACTIVE good residuals of the pair, else -1 (written by applyRes); slot of r
     double* lin_partial;          // per-block {energy, n_in, n_oob, n_outlier} of the residual kernel (may be null)
@@ -73,15 +74,18 @@ struct BAArgs {
     int records_only;             // k_ba_linearize: only re-create the efsJ record of every good residual (cml_materialize_records)
 };
 
-// resident residual kernel (ba_linearize_rs.hip): wave tiles of <= 16 residuals of one (host,target) pair
+#define RS_TILE 64                                 // residuals per wave tile of the lane-per-residual kernel (16 for the 4-lane kernel: cmlhip_ctx::rs_tile)
+// resident residual kernel (ba_linearize_rs.hip): wave tiles of <= RS_TILE residuals of one (host,target) pair
 struct RsArgs {
     const int4* tiles; int ntiles;                 // {first residual, count, host, target}
     const float* r_px; const float* r_py;          // the point's pixel, per residual
     const float* r_colors; const float* r_weights; // [R][8] the point's pattern colours / weights, per residual
+    const double* r_idepth;                        // the point's inverse depth, per residual (kept current by k_ba_backsub's point step; refreshed when another path wrote pt_idepth)
     int dbg_flags;                                 // development switches (CMLHIP_RS_DBG)
     float* part;                                   // [ntiles][64][4]: the wave's 16x16 fp32 tile of its pair's 13x13 block (MFMA D layout)
 };
 int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X);
 int cml_materialize_records(cmlhip_ctx* c);        // re-create the efsJ records the resident kernel did not write (no state change)
 
 // point slices of the Schur SYRK (k_ba_system): more slices = more CUs pulling rows, but more partials for the consumer to add

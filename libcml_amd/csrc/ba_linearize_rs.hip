@@ -2,26 +2,33 @@
 // Same arithmetic as k_ba_linearize (ba_linearize.hip: DSOBundleAdjustmentLinearizationContext::linearize BA.cpp:62-316 with the
 // fused applyRes BA.cpp:2051-2093, statement order kept, FP contraction off), re-mapped for throughput:
 //
-//   * the device residual order is (host,target)-pair-sorted (cmlhip_ba_upload_window), a WAVE owns 16 residuals of ONE pair: the
-//     pair record (R, t, R0, t0, affine), both frame descriptors and the camera are wave-uniform and live in SGPRs (scalar
-//     loads, scalar operands) instead of 60 VGPRs per lane;
-//   * 4 lanes per residual, two pattern pixels per lane (8 texel loads of a lane in flight together, unconditional on clamped
-//     addresses); the 19 pattern sums are spread 5/5/5/4 over the quad and every one is still added in pattern order
-//     (per-pixel operands exchanged through wave-private LDS rows: no workgroup barrier anywhere in the kernel);
+//   * the device residual order is (host,target)-pair-sorted (cmlhip_ba_upload_window), a WAVE owns up to 64 residuals of ONE pair:
+//     the pair record (R, t, R0, t0, affine), both frame descriptors and the camera are wave-uniform and live in SGPRs (scalar
+//     loads, scalar operands);
+//   * ONE LANE PER RESIDUAL.  Measured on the way here (profiles/round2_*): with 8 or 4 lanes per residual only a quarter of the
+//     issued lane-instructions is the per-pixel work, the rest is per-residual work replicated in every lane of the group, lane
+//     selects, and the exchange of per-pixel operands through LDS; with one lane per residual the 8 pattern pixels are a plain
+//     unrolled loop, the 19 pattern sums are register accumulators updated in pattern order (the reference's order by
+//     construction), the geometric Jacobians are evaluated once, and there is no exchange, no ballot, no lane select at all;
 //   * every per-residual input is addressed directly by the residual index (static copies of the point's pixel, colours and
-//     weights are kept per residual), only the inverse depth goes through the point index;
+//     weights are kept per residual, the copy of the inverse depth is refreshed by the point step of k_ba_backsub): after ONE round
+//     trip for the inputs the 32 texel loads of a lane are issued together, unconditional on clamped addresses;
 //   * nothing of the 74-float DSORawResidualJacobian is written to memory.  What the next iteration consumes leaves the kernel in
 //     reduced form: the wave's contribution to the 13x13 AccumulatorApprox block of its pair (BA.cpp:1731-1745, ACC.h:776-932) as
 //     ONE 16x16 fp32 tile accumulated on the matrix cores over the wave's residuals (v_mfma_f32_16x16x4_f32, one per residual,
-//     the formulation of k_ba_acc), and per residual 14 floats: JpJdF (BA.cpp:2066-2080) and the terms of Hdd / bd / Hcd
-//     (BA.cpp:1747-1750).  The full records are re-materialised on demand by k_ba_linearize (cml_materialize_records).
+//     the formulation of k_ba_acc; the only LDS use of the kernel is the transposition of the 40 operands per residual), and per
+//     residual 14 floats: JpJdF (BA.cpp:2066-2080) and the terms of Hdd / bd / Hcd (BA.cpp:1747-1750).  The full records are
+//     re-materialised on demand by k_ba_linearize (cml_materialize_records).
 #include "cmlhip_internal.h"
 #include "ba_common.h"
 #include <cstdlib>
+#include <cstddef>
 
 #pragma clang fp contract(off)
 
 typedef float float4_ __attribute__((ext_vector_type(4)));
+typedef int rs_int8 __attribute__((ext_vector_type(8)));
+static_assert(offsetof(cmlhip_ba_pair, R0) == 0x60 && offsetof(cmlhip_ba_pair, t0) == 0xa8, "cmlhip_ba_pair layout (explicit scalar loads in k_ba_lin_rs)");
 
 template <bool HALF>
 __device__ __forceinline__ float4 rs_load_texel(const void* img, size_t i) {
@@ -32,29 +39,6 @@ __device__ __forceinline__ float4 rs_load_texel(const void* img, size_t i) {
     }
     return reinterpret_cast<const float4*>(img)[i];
 }
-
-// value held by quad lane `L` (0..3) of this lane's group of 4: DPP quad_perm, no LDS
-template <int L>
-__device__ __forceinline__ int quad_bcast_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, L * 0x55, 0xf, 0xf, true);       // quad_perm:[L,L,L,L]
-}
-template <int L>
-__device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<L>(__float_as_int(v))); }
-template <int L>
-__device__ __forceinline__ double quad_bcast_d(double v) {
-    const int lo = quad_bcast_i<L>(__double2loint(v)), hi = quad_bcast_i<L>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-// exact select by quad lane without control flow (a nested ?: over lane-varying conditions becomes a branch tree)
-__device__ __forceinline__ float rs_sel4(const int j, const float a, const float b, const float c, const float d) {
-    const int m0 = -(int)(j == 0), m1 = -(int)(j == 1), m2 = -(int)(j == 2), m3 = -(int)(j == 3);
-    return __int_as_float((__float_as_int(a) & m0) | (__float_as_int(b) & m1) | (__float_as_int(c) & m2) | (__float_as_int(d) & m3));
-}
-// matrix-core operand offsets into the staged record, per lane (e = lane & 15, kq = lane >> 4), the formulation of acc_pair_block
-// (ba_accumulate.hip) made branch-free: A = S[a], B = S[o3] * S[o1] + S[o4] * S[o2], with a slot of ones (39) and a slot of zeros (20)
-__constant__ unsigned c_rs_mfma_off[64] = {0x1816100Cu, 0x1816110Du, 0x1816120Eu, 0x1816130Fu, 0x18160600u, 0x18160701u, 0x18160802u, 0x18160903u, 0x18160A04u, 0x18160B05u, 0x1427141Au, 0x1427141Bu, 0x14271422u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1918100Cu, 0x1918110Du, 0x1918120Eu, 0x1918130Fu, 0x19180600u, 0x19180701u, 0x19180802u, 0x19180903u, 0x19180A04u, 0x19180B05u, 0x1427141Cu, 0x1427141Du, 0x14271423u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1427141Eu, 0x14271420u, 0x14271424u, 0x14271421u, 0x14271425u, 0x14271426u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u};
-__constant__ unsigned char c_rs_mfma_a[64] = {12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 20, 20, 20, 20, 20, 20, 16, 17, 18, 19, 6, 7, 8, 9, 10, 11, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 39, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
 
 // fp64 division x / z as the compiler lowers it (v_rcp_f64, two Newton steps, quotient, remainder, one correction), WITHOUT the
 // v_div_scale / v_div_fixup wrapping that only acts on operands at the ends of the exponent range or on non-finite ones: for every
@@ -75,39 +59,26 @@ __device__ __forceinline__ double rs_div(const double x, const double z, const d
     return __builtin_fma(rem, r, q);
 }
 
-#define RS_RES 16            // residuals per wave
-#define RS_DSTRIDE 90        // doubles per residual in the fp64 operand rows (10 rows x 9): 180 dwords = 52 mod 64, 8 residuals on distinct bank pairs
-#define RS_FSTRIDE 25        // floats per residual in the fp32 operand rows (3 rows x 8)
-#define RS_SSTRIDE 45        // floats per residual of the staged reduced record (odd: conflict-free lane-per-record reads)
+// matrix-core operand offsets into the staged record, per lane (e = lane & 15, kq = lane >> 4), the formulation of acc_pair_block
+// (ba_accumulate.hip) made branch-free: A = S[a], B = S[o3] * S[o1] + S[o4] * S[o2], with a slot of ones (39) and a slot of zeros (20)
+__constant__ unsigned c_rs_mfma_off[64] = {0x1816100Cu, 0x1816110Du, 0x1816120Eu, 0x1816130Fu, 0x18160600u, 0x18160701u, 0x18160802u, 0x18160903u, 0x18160A04u, 0x18160B05u, 0x1427141Au, 0x1427141Bu, 0x14271422u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1918100Cu, 0x1918110Du, 0x1918120Eu, 0x1918130Fu, 0x19180600u, 0x19180701u, 0x19180802u, 0x19180903u, 0x19180A04u, 0x19180B05u, 0x1427141Cu, 0x1427141Du, 0x14271423u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1427141Eu, 0x14271420u, 0x14271424u, 0x14271421u, 0x14271425u, 0x14271426u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u};
+__constant__ unsigned char c_rs_mfma_a[64] = {12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 20, 20, 20, 20, 20, 20, 16, 17, 18, 19, 6, 7, 8, 9, 10, 11, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 39, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
 
-// one entry of Jpdc (BA.cpp:150-176), k = 0..3 -> Jpdc[0][k] (LO), k = 4..7 -> Jpdc[1][k-4]; same expression shape as k_ba_linearize
-template <bool LO>
-__device__ __forceinline__ float rs_jpdc(const int k, const double E0, const double E1, const double E3, const double E4, const double E6,
-                                         const double E7, const float u, const float v, const float fxf, const float fyf, const float drescale,
-                                         const double rx, const double ry, const double scale_f, const double scale_c, const double rfx, const double rfy) {
-    const bool odd = k & 1;
-    const double Ea = odd ? E7 : E6, Eb = LO ? (odd ? E1 : E0) : (odd ? E4 : E3);
-    const float wq = LO ? u : v;
-    const float sfac = LO ? (odd ? fxf : 1.f) : (odd ? 1.f : fyf), s2 = LO ? (odd ? fyf : 1.f) : (odd ? 1.f : fxf);
-    const double rs2 = LO ? (odd ? rfy : 1.0) : (odd ? 1.0 : rfx);             // refined reciprocal of s2 (exactly 1 for s2 = 1: the division is then exact)
-    const double q = rs_div((sfac * drescale) * (Ea * wq - Eb), (double)s2, rs2);
-    const double m = (k & 2) ? 1.0 : (odd ? ry : rx);
-    const double add = k == 0 ? (double)u : (k == 5 ? (double)v : ((k == 2 || k == 7) ? 1.0 : -0.0));
-    const double scl = (k & 2) ? scale_c : scale_f;
-    return (float)(((m * q) + add) * scl);
-}
+#define RS_SSTRIDE 41        // floats per residual of the staged reduced record (odd: conflict-free lane-per-record accesses)
+
+// star8 pattern offsets, types.h:1381-1393
+#define RS_OX(k) ((k) == 0 ? 0 : (k) == 1 ? -1 : (k) == 2 ? 1 : (k) == 3 ? -2 : (k) == 4 ? 0 : (k) == 5 ? 2 : (k) == 6 ? -1 : 0)
+#define RS_OY(k) ((k) == 0 ? -2 : (k) == 1 ? -1 : (k) == 2 ? -1 : (k) == 3 ? 0 : (k) == 4 ? 0 : (k) == 5 ? 0 : (k) == 6 ? 1 : 2)
 
 template <bool HALF>
-__global__ __launch_bounds__(256, 3) void k_ba_lin_rs(BAArgs A, RsArgs X) {
-    __shared__ double s_shd[4][RS_RES * RS_DSTRIDE];                                   // [wave][residual * RS_DSTRIDE + quantity * 9 + pixel]
-    __shared__ float s_shf[4][RS_RES * RS_FSTRIDE];                                    // [wave][residual * RS_FSTRIDE + quantity * 8 + pixel]
-    // the staged reduced record (layout of k_ba_acc's s_rec + Jpdd at 40,41) reuses the wave's fp64 rows once the sums are taken (a wave's
-    // LDS operations execute in order): 52.5 KB per workgroup, three workgroups per CU
-    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, g = ln >> 2, j = ln & 3;
+__global__ __launch_bounds__(64) void k_ba_lin_rs(BAArgs A, RsArgs X) {
+    // staged reduced record of the wave's residuals: the layout of k_ba_acc's s_rec (0..5 Jpdxi[0], 6..11 Jpdxi[1], 12..15 Jpdc[0], 16..19 Jpdc[1],
+    // 20 zeros, 22..25 JIdx2, 26..29 JabJIdx, 30..33 Jab2, 34,35 JI^T r, 36,37 Jab^T r, 38 r^T r, 39 ones)
+    __shared__ float s_stg[RS_TILE * RS_SSTRIDE];
+    const int ln = threadIdx.x;
     if (A.ctl && A.ctl->stop_lin) return;                  // converged in an earlier launch (raised by k_ba_acc), BA.cpp:879
-    const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
-    if (ti >= X.ntiles) return;                            // wave-uniform; there is no workgroup barrier below
-    // ---- wave-uniform data: tile -> pair record, frames (scalar loads)
+    const int ti = blockIdx.x;
+    // ---- wave-uniform data: tile -> pair record, frames (scalar loads, before any store)
     const int4 T = X.tiles[ti];                            // {first residual, count, host, target}
     const int first = T.x, cnt = T.y, host = T.z, target = T.w;
     const cmlhip_ba_pair* pc = &A.pairs[host * A.N + target];
@@ -116,153 +87,122 @@ __global__ __launch_bounds__(256, 3) void k_ba_lin_rs(BAArgs A, RsArgs X) {
                  R6_ = pc->R[6], R7_ = pc->R[7], R8_ = pc->R[8];
     const double t0_ = pc->t[0], t1_ = pc->t[1], t2_ = pc->t[2];
     const double aff_a = pc->aff_a, aff_b = pc->aff_b;
-    // evaluation-point pair (PRE_RTll_0 / PRE_tTll_0) for the calibration / depth Jacobians: scalar loads with the rest, before any store
-    const double E0 = pc->R0[0], E1 = pc->R0[1], E3 = pc->R0[3], E4 = pc->R0[4], E6 = pc->R0[6], E7 = pc->R0[7];
-    const double et0 = pc->t0[0], et1 = pc->t0[1], et2 = pc->t0[2];
 
-    // ---- per-residual inputs, all addressed by the residual index (the 4 lanes of a quad read the same addresses: broadcast)
-    const bool valid = g < cnt;
-    const int r = first + (valid ? g : 0);
-    const int lin_ = A.r_lin[r], st_ = A.r_state[r], p_ = A.r_point[r];
+    // ---- per-residual inputs, all addressed by the residual index
+    const bool valid = ln < cnt;
+    const int r = first + (valid ? ln : 0);
+    const int lin_ = A.r_lin[r], st_ = A.r_state[r];
     const float pre_energy = A.r_energy[r];
     const int pre_new_state = A.r_new_state[r], pre_ppos = A.point_pos[r];
     const unsigned char pre_sel = A.r_sel[r];
     const double cxd = (double)X.r_px[r], cyd = (double)X.r_py[r];
-    const float2 col2 = reinterpret_cast<const float2*>(X.r_colors)[4 * (size_t)r + j];     // colours / weights of pattern pixels 2j, 2j+1
-    const float2 wgt2 = reinterpret_cast<const float2*>(X.r_weights)[4 * (size_t)r + j];
-    const double idepth = A.pt_idepth[p_];
+    const float4 colA = reinterpret_cast<const float4*>(X.r_colors)[2 * (size_t)r], colB = reinterpret_cast<const float4*>(X.r_colors)[2 * (size_t)r + 1];
+    const float4 wgtA = reinterpret_cast<const float4*>(X.r_weights)[2 * (size_t)r], wgtB = reinterpret_cast<const float4*>(X.r_weights)[2 * (size_t)r + 1];
+    const float colors[8] = {colA.x, colA.y, colA.z, colA.w, colB.x, colB.y, colB.z, colB.w};
+    const float weights[8] = {wgtA.x, wgtA.y, wgtA.z, wgtA.w, wgtB.x, wgtB.y, wgtB.z, wgtB.w};
+    const double idepth = X.r_idepth[r];                   // == pt_idepth[r_point[r]] (cml_launch_linearize_rs refreshes the copies when needed)
     const bool live = valid && !lin_;
     const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
 
-    // ---- the lane's two pattern pixels, BA.cpp:193-212 (star8 offsets + 2 packed by nibble, types.h:1381-1393)
-    double qx[2], qy[2], ppx[2], ppy[2], ppz[2], kx[2], ky[2], rz[2];
-    bool pix_in[2];
+    // ---- projection of the 8 pattern pixels, BA.cpp:193-212; the centre (BA.cpp:102-131) is pattern pixel 4, offset (0,0): the very
+    //      same expressions on the very same operands
+    const double tid0 = t0_ * idepth, tid1 = t1_ * idepth, tid2 = t2_ * idepth;
+    float kxf[8], kyf[8];
+    unsigned m_in = 0;
+    double rx = 0, ry = 0, px = 0, py = 0, Kud = 0, Kvd = 0;
+    float drescale = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int pk = 2 * j + u;
-        const int ox = (int)((0x21420312u >> (4 * pk)) & 15u) - 2, oy = (int)((0x43222110u >> (4 * pk)) & 15u) - 2;
-        const double sx = cxd + ox, sy = cyd + oy;
-        qx[u] = (sx - A.cx) * A.fxi; qy[u] = (sy - A.cy) * A.fyi;
-        ppx[u] = (R0_ * qx[u] + R1_ * qy[u] + R2_ * 1.0) + t0_ * idepth;
-        ppy[u] = (R3_ * qx[u] + R4_ * qy[u] + R5_ * 1.0) + t1_ * idepth;
-        ppz[u] = (R6_ * qx[u] + R7_ * qy[u] + R8_ * 1.0) + t2_ * idepth;
-        rz[u] = rs_rcp_refined(ppz[u]);
-        kx[u] = rs_div(ppx[u], ppz[u], rz[u]) * A.fx + A.cx; ky[u] = rs_div(ppy[u], ppz[u], rz[u]) * A.fy + A.cy;
-        pix_in[u] = (kx[u] >= 2 && ky[u] >= 2 && kx[u] < A.w - 2 && ky[u] < A.h - 2);
+    for (int k = 0; k < 8; k++) {
+        const double sx = cxd + RS_OX(k), sy = cyd + RS_OY(k);
+        const double qx = (sx - A.cx) * A.fxi, qy = (sy - A.cy) * A.fyi;
+        const double ppx = (R0_ * qx + R1_ * qy + R2_ * 1.0) + tid0;
+        const double ppy = (R3_ * qx + R4_ * qy + R5_ * 1.0) + tid1;
+        const double ppz = (R6_ * qx + R7_ * qy + R8_ * 1.0) + tid2;
+        const double rz = rs_rcp_refined(ppz);
+        const double kx = rs_div(ppx, ppz, rz) * A.fx + A.cx, ky = rs_div(ppy, ppz, rz) * A.fy + A.cy;
+        if (kx >= 2 && ky >= 2 && kx < A.w - 2 && ky < A.h - 2) m_in |= 1u << k;
+        kxf[k] = (float)kx; kyf[k] = (float)ky;
+        if (k == 4) {
+            rx = qx; ry = qy; px = ppx; py = ppy; Kud = kx; Kvd = ky;
+            drescale = (float)rs_div(1.0, ppz, rz);            // (float)(1.0 / pz)
+        }
     }
-    // ---- centre projection, BA.cpp:102-131: pattern pixel 4 is the offset (0,0) = first pixel of quad lane 2: the very same
-    //      expressions on the very same operands, taken from there
-    const double rx = quad_bcast_d<2>(qx[0]), ry = quad_bcast_d<2>(qy[0]);
-    const double px = quad_bcast_d<2>(ppx[0]), py = quad_bcast_d<2>(ppy[0]), pz = quad_bcast_d<2>(ppz[0]);
-    const double Kud = quad_bcast_d<2>(kx[0]), Kvd = quad_bcast_d<2>(ky[0]);
-    const float drescale = quad_bcast_f<2>((float)rs_div(1.0, ppz[0], rz[0]));     // (float)(1.0 / pz) of the centre pixel
-    const bool centre_in = (Kud >= 2 && Kvd >= 2 && Kud < A.w - 2 && Kvd < A.h - 2);
+    const bool centre_in = (m_in >> 4) & 1u;
 
-    // ---- GradientImage::interpolate (Array2D.h:265-286) of both pixels: eight unconditional loads on clamped addresses
-    bool sample[2];
-    float tw00[2], tw01[2], tw10[2], tw11[2];
-    float4 ta[2], tb[2], tc[2], td[2];
+    // ---- photometric terms and pattern sums, pixel by pixel in pattern order (BA.cpp:214-271 and the ACTIVE-mode inner products of
+    //      BA.cpp:1719-1729).  Form A: acc = (float)((double)acc + X*Y); form B: acc += rF*Y in fp64 (a masked column adds rF * 0);
+    //      form C: acc += ((p*q)*r)*s in fp32 — the forms and operand conversions of k_ba_linearize.
+    float J00 = 0, J10 = 0, J11 = 0, Q00 = 0, Q10 = 0, Q01 = 0, Q11 = 0, rr = 0, E = 0, wJI2 = 0;
+    double JIr0 = 0, JIr1 = 0, Jabr0 = 0, Jabr1 = 0;
+    float B00 = 0, B01 = 0, B11 = 0;
+    unsigned m_nf = 0;
+    // GradientImage::interpolate (Array2D.h:265-286): the 32 texel loads of the lane are issued together, unconditional on clamped
+    // addresses (ONE memory round trip for the whole pattern), then consumed in pattern order
+    float4 ta[8], tb[8], tc[8], td[8];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        sample[u] = run && centre_in && pix_in[u];
-        const float x = (float)kx[u], y = (float)ky[u];
-        const int ix = (int)x, iy = (int)y;
-        const float dx = x - (float)ix, dy = y - (float)iy;
-        const float dxdy = dx * dy;
-        tw00[u] = 1 - dx - dy + dxdy; tw01[u] = dx - dxdy; tw10[u] = dy - dxdy; tw11[u] = dxdy;
-        const size_t i1 = (sample[u] && !(X.dbg_flags & 1)) ? (size_t)iy * A.w + ix : (size_t)0;
-        ta[u] = rs_load_texel<HALF>(ft.grad0, i1); tb[u] = rs_load_texel<HALF>(ft.grad0, i1 + 1);
-        tc[u] = rs_load_texel<HALF>(ft.grad0, i1 + A.w); td[u] = rs_load_texel<HALF>(ft.grad0, i1 + A.w + 1);
+    for (int k = 0; k < 8; k++) {
+        const bool smp = run && centre_in && ((m_in >> k) & 1u);
+        const int ix = (int)kxf[k], iy = (int)kyf[k];
+        const size_t i1 = (smp && !(X.dbg_flags & 1)) ? (size_t)iy * A.w + ix : (size_t)0;
+        ta[k] = rs_load_texel<HALF>(ft.grad0, i1); tb[k] = rs_load_texel<HALF>(ft.grad0, i1 + 1);
+        tc[k] = rs_load_texel<HALF>(ft.grad0, i1 + A.w); td[k] = rs_load_texel<HALF>(ft.grad0, i1 + A.w + 1);
     }
-    float I[2], gx[2], gy[2];
-    bool finite[2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const float Iv = ta[u].x * tw00[u] + tb[u].x * tw01[u] + tc[u].x * tw10[u] + td[u].x * tw11[u];
-        const float gxv = ta[u].y * tw00[u] + tb[u].y * tw01[u] + tc[u].y * tw10[u] + td[u].y * tw11[u];
-        const float gyv = ta[u].z * tw00[u] + tb[u].z * tw01[u] + tc[u].z * tw10[u] + td[u].z * tw11[u];
-        I[u] = sample[u] ? Iv : 0.f; gx[u] = sample[u] ? gxv : 0.f; gy[u] = sample[u] ? gyv : 0.f;
-        finite[u] = isfinite(I[u]) && isfinite(gx[u]) && isfinite(gy[u]);
+    for (int k = 0; k < 8; k++) {
+        {
+            const bool smp = run && centre_in && ((m_in >> k) & 1u);
+            const float x = kxf[k], y = kyf[k];
+            const int ix = (int)x, iy = (int)y;
+            const float dx = x - (float)ix, dy = y - (float)iy;
+            const float dxdy = dx * dy;
+            const float tw00 = 1 - dx - dy + dxdy, tw01 = dx - dxdy, tw10 = dy - dxdy, tw11 = dxdy;
+            const float Iv = ta[k].x * tw00 + tb[k].x * tw01 + tc[k].x * tw10 + td[k].x * tw11;
+            const float gxv = ta[k].y * tw00 + tb[k].y * tw01 + tc[k].y * tw10 + td[k].y * tw11;
+            const float gyv = ta[k].z * tw00 + tb[k].z * tw01 + tc[k].z * tw10 + td[k].z * tw11;
+            const float I = smp ? Iv : 0.f, gx = smp ? gxv : 0.f, gy = smp ? gyv : 0.f;
+            const bool finite = isfinite(I) && isfinite(gx) && isfinite(gy);
+            if (((m_in >> k) & 1u) && !finite) m_nf |= 1u << k;
+            const float refColor = colors[k];
+            const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
+            const float residual = I - refRealColor;
+            float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
+            const double wden = A.oth_d + (double)(gx * gx + gy * gy);
+            float wgt = sqrtf((float)rs_div(A.oth_d, wden, rs_rcp_refined(wden)));
+            wgt = (float)(0.5f * ((double)wgt + (double)weights[k]));
+            const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
+            const float hw0 = hw;
+            if (hw < 1) hw = sqrtf(hw);
+            hw = hw * wgt;
+            const float f1 = gx * hw, f2 = gy * hw;                     // hitColor[1], hitColor[2]
+            const float drdA = I - fh.b0;
+            const float a_ = drdA * hw;
+            const float rF = residual * hw;
+            const double f1d = (double)f1, f2d = (double)f2, ad = (double)a_, hwd = (double)hw, rFd = (double)rF;
+            J00 = (float)((double)J00 + f1d * f1d); J10 = (float)((double)J10 + f1d * f2d); J11 = (float)((double)J11 + f2d * f2d);
+            Q00 = (float)((double)Q00 + ad * f1d); Q10 = (float)((double)Q10 + hwd * f1d);
+            Q01 = (float)((double)Q01 + ad * f2d); Q11 = (float)((double)Q11 + hwd * f2d);
+            rr = (float)((double)rr + rFd * rFd);
+            E = (float)((double)E + (double)pf * (2.0 - (double)hw0));                            // energyLeft, BA.cpp:237
+            wJI2 = (float)((double)wJI2 + (double)(hw * hw) * (f1d * f1d + f2d * f2d));           // wJI2_sum, BA.cpp:257
+            JIr0 += rFd * f1d; JIr1 += rFd * f2d;
+            Jabr0 += rFd * (A.opt_a ? ad : 0.0); Jabr1 += rFd * (A.opt_b ? hwd : 0.0);           // BA.cpp:273-278: a zeroed column contributes rF * 0
+            B00 += drdA * drdA * hw * hw; B01 += drdA * hw * hw * 1.f; B11 += hw * hw * 1.f * 1.f;
+        }
     }
 
     // first failing pixel in pattern order decides between setNewState(OOB) (:209-212) and setState(OOB) (:220-223)
-    const int shift = ln & ~3;
-    unsigned m_oob, m_nf;
-    {
-        const unsigned o0 = (unsigned)(__ballot(!pix_in[0]) >> shift) & 0xFu, o1 = (unsigned)(__ballot(!pix_in[1]) >> shift) & 0xFu;
-        const unsigned n0 = (unsigned)(__ballot(pix_in[0] && !finite[0]) >> shift) & 0xFu, n1 = (unsigned)(__ballot(pix_in[1] && !finite[1]) >> shift) & 0xFu;
-        // bit (2 * lane + u) of the 8-bit pattern mask
-#define RS_SPREAD(x) (((x) & 1u) | (((x) & 2u) << 1) | (((x) & 4u) << 2) | (((x) & 8u) << 3))
-        m_oob = RS_SPREAD(o0) | (RS_SPREAD(o1) << 1);
-        m_nf = RS_SPREAD(n0) | (RS_SPREAD(n1) << 1);
-#undef RS_SPREAD
-    }
+    const unsigned m_oob = ~m_in & 0xFFu;
     const unsigned m_bad = m_oob | m_nf;
     const int first_bad = m_bad ? __ffs((int)m_bad) - 1 : 8;
     const bool fail_new_oob = !centre_in || (m_bad && ((m_oob >> first_bad) & 1u));
     const bool fail_state_oob = centre_in && m_bad && !((m_oob >> first_bad) & 1u);
 
-    // ---- photometric terms of the two pixels, BA.cpp:214-255; every operand of the pattern sums is converted once by its lane
-    double* D = &s_shd[wv][g * RS_DSTRIDE];
-    float* F = &s_shf[wv][g * RS_FSTRIDE];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int pk = 2 * j + u;
-        const float refColor = u == 0 ? col2.x : col2.y;
-        const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
-        const float residual = I[u] - refRealColor;
-        float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
-        const double wden = A.oth_d + (double)(gx[u] * gx[u] + gy[u] * gy[u]);
-        float wgt = sqrtf((float)rs_div(A.oth_d, wden, rs_rcp_refined(wden)));
-        wgt = (float)(0.5f * ((double)wgt + (double)(u == 0 ? wgt2.x : wgt2.y)));
-        const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
-        const float hw0 = hw;
-        if (hw < 1) hw = sqrtf(hw);
-        hw = hw * wgt;
-        const float f1 = gx[u] * hw, f2 = gy[u] * hw;               // hitColor[1], hitColor[2]
-        const float drdA = I[u] - fh.b0;
-        const float a_ = drdA * hw;
-        const float rF = residual * hw;
-        const double f1d = (double)f1, f2d = (double)f2;
-        D[0 * 9 + pk] = f1d; D[1 * 9 + pk] = f2d; D[2 * 9 + pk] = (double)a_; D[3 * 9 + pk] = (double)hw; D[4 * 9 + pk] = (double)rF;
-        D[5 * 9 + pk] = (double)pf; D[6 * 9 + pk] = 2.0 - (double)hw0;                          // energy term, BA.cpp:237
-        D[7 * 9 + pk] = (double)(hw * hw); D[8 * 9 + pk] = f1d * f1d + f2d * f2d;              // wJI2_sum, BA.cpp:257
-        D[9 * 9 + pk] = 0.0;
-        F[pk] = drdA; F[8 + pk] = hw; F[16 + pk] = 1.f;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // rows are wave-private and a wave's LDS operations execute in order:
-    __builtin_amdgcn_wave_barrier();                        // only the compiler has to be kept from moving the reads up
-
-    // ---- pattern-order sums, BA.cpp:237,257-271 and the ACTIVE-mode inner products of BA.cpp:1719-1729; three arithmetic forms
-    //   A  acc = (float)((double)acc + X*Y)   slot 0: lane j: J00 J10 J11 Q00   slot 1: Q10 Q01 Q11 r^T r   slot 2: energy, wJI2_sum, -, -
-    //   B  acc += rF*Y (fp64)                 lane j: JI^T r (2), Jab^T r (2)   (a masked column reads the row of zeros: BA.cpp:273-278)
-    //   C  acc += ((p*q)*r)*s (fp32)          lane j: B00 B01 B11 -
-    // fp64 rows: 0 F1, 1 F2, 2 a, 3 hw, 4 rF, 5 pf, 6 2-hw0, 7 hw*hw, 8 F1^2+F2^2, 9 zeros.   fp32 rows: 0 drdA, 1 hw, 2 ones
-    const int ax0 = (0x2100 >> (4 * j)) & 15, ay0 = (0x0110 >> (4 * j)) & 15;
-    const int ax1 = (0x4323 >> (4 * j)) & 15, ay1 = (0x4110 >> (4 * j)) & 15;
-    const int ax2 = (0x9975 >> (4 * j)) & 15, ay2 = (0x9986 >> (4 * j)) & 15;
-    const int by = ((j == 2 && !A.opt_a) || (j == 3 && !A.opt_b)) ? 9 : j;
-    const int cp = j < 2 ? 0 : (j == 2 ? 1 : 2), cq = j == 0 ? 0 : (j < 3 ? 1 : 2);
-    const int cr = j < 2 ? 1 : 2, cs = j == 0 ? 1 : 2;
-    float sumA0 = 0, sumA1 = 0, sumA2 = 0, sumC = 0;
-    double sumB = 0;
-#pragma unroll
-    for (int jj = 0; jj < 8; jj++) {
-        sumA0 = (float)((double)sumA0 + D[ax0 * 9 + jj] * D[ay0 * 9 + jj]);
-        sumA1 = (float)((double)sumA1 + D[ax1 * 9 + jj] * D[ay1 * 9 + jj]);
-        sumA2 = (float)((double)sumA2 + D[ax2 * 9 + jj] * D[ay2 * 9 + jj]);
-        sumB += D[4 * 9 + jj] * D[by * 9 + jj];
-        sumC += F[cp * 8 + jj] * F[cq * 8 + jj] * F[cr * 8 + jj] * F[cs * 8 + jj];
-    }
-    const float E = quad_bcast_f<0>(sumA2);                // quad lane 0: the energy; lane 1: wJI2_sum
-    const float wJI2 = quad_bcast_f<1>(sumA2);
-
-    // ---- classification, BA.cpp:66-72,115-118,297-314, and the fused applyRes(copyJacobians = true), BA.cpp:2051-2093 — quad lane 0
+    // ---- classification, BA.cpp:66-72,115-118,297-314, and the fused applyRes(copyJacobians = true), BA.cpp:2051-2093
     const float new_idepth = (float)(drescale * idepth);
     double ret_d = 0.0;
     int ns_cnt = -1, flip = 0;
-    if (live && j == 0) {
+    if (live) {
         float ret = pre_energy;
         float nwo = -1.f;
         int ns_final = pre_new_state;
@@ -303,91 +243,84 @@ __global__ __launch_bounds__(256, 3) void k_ba_lin_rs(BAArgs A, RsArgs X) {
             A.point_code[pre_ppos] = code;                          // read by the point rows of k_ba_acc and by k_ba_backsub
         }
     }
-    flip = quad_bcast_i<0>(flip);
 
-    // ---- geometric Jacobians, BA.cpp:120-188: every lane evaluates two entries of each group (k = j and k = j + 4), same
-    //      expression shapes as k_ba_linearize; a residual that is not IN stages zeros (the matrix-core loop below is branch-free)
-    float* const stg = reinterpret_cast<float*>(&s_shd[wv][0]);
-    float* S = &stg[g * RS_SSTRIDE];
+    // ---- geometric Jacobians, BA.cpp:120-188 (the expression shapes of k_ba_linearize with its per-lane constants folded)
+    float* S = &s_stg[ln * RS_SSTRIDE];
     {
-        // Every lane issues the SAME stores with per-lane addresses (a lane with nothing to contribute to a group writes a spare slot,
-        // 42..44): a lane-divergent `if` around an LDS access costs a branch each.
+        // evaluation-point pair (PRE_RTll_0 / PRE_tTll_0) for the calibration / depth Jacobians: explicit scalar loads HERE (the
+        // compiler only scalarises loads it can prove unclobbered, i.e. before the first store of the kernel; holding these 18
+        // SGPRs across the pixel loop spilled scalars, and a kernel with a scratch frame pays for it at every dispatch)
+        rs_int8 w0, w1, w2;
+        asm volatile("s_load_dwordx8 %0, %3, 0x60\n\ts_load_dwordx8 %1, %3, 0x80\n\ts_load_dwordx8 %2, %3, 0xa0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(w0), "=&s"(w1), "=&s"(w2) : "s"(pc) : "memory");
+#define RS_D(w, i) __hiloint2double((w)[2 * (i) + 1], (w)[2 * (i)])
+        const double E0 = RS_D(w0, 0), E1 = RS_D(w0, 1), E3 = RS_D(w0, 3), E4 = RS_D(w1, 0), E6 = RS_D(w1, 2), E7 = RS_D(w1, 3);   // R0[0,1,3,4,6,7]
+        const double et0 = RS_D(w2, 1), et1 = RS_D(w2, 2), et2 = RS_D(w2, 3);                                                     // t0[0..2]
+#undef RS_D
         const float u = (float)px, v = (float)py;            // BA.cpp:121-122: un-normalised x,y, literal
         const float fxf = (float)A.fx, fyf = (float)A.fy;
         const double rfx = rs_rcp_refined((double)fxf), rfy = rs_rcp_refined((double)fyf);      // wave-uniform
-        // Jpdxi[0][k], Jpdxi[1][k], k = j (0..3) and k = j + 4 (4, 5 for j < 2)          (fp32, BA.cpp:133-147)
-        const float xa0 = rs_sel4(j, new_idepth * fxf, 0.f, -new_idepth * u * fxf, -u * v * fxf);
-        const float xa1 = rs_sel4(j, 0.f, new_idepth * fyf, -new_idepth * v * fyf, -(1 + v * v) * fyf);
-        const float xb0 = rs_sel4(j, (1 + u * u) * fxf, -v * fxf, 0.f, 0.f);
-        const float xb1 = rs_sel4(j, u * v * fyf, u * fyf, 0.f, 0.f);
-        // Jpdc[0][j], Jpdc[1][j]                                                         (:150-176)
-        const float c0 = rs_jpdc<true>(j, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
-        const float c1 = rs_jpdc<false>(j + 4, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
-        // Jpdd[j], j < 2                                                                 (:178-182)
-        const bool odd = j & 1;
-        const double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
-        const bool lo2 = j < 2;
-        S[j] = flip ? xa0 : 0.f; S[6 + j] = flip ? xa1 : 0.f;
-        S[lo2 ? 4 + j : 42] = flip ? xb0 : 0.f; S[lo2 ? 10 + j : 43] = flip ? xb1 : 0.f;
-        S[12 + j] = flip ? c0 : 0.f; S[16 + j] = flip ? c1 : 0.f;
-        S[lo2 ? 40 + j : 44] = flip ? (float)dd : 0.f;
-        // the sums of this lane (staged layout of k_ba_acc: 22..25 JIdx2, 26..29 JabJIdx, 30..33 Jab2, 34,35 JI^T r, 36,37 Jab^T r, 38 r^T r)
-        //   lane 0: J00 -> 22, Q10 -> 27, B00 -> 30     lane 1: J10 -> 23, 24, Q01 -> 28, B01 -> 31, 32
-        //   lane 2: J11 -> 25, Q11 -> 29, B11 -> 33     lane 3: Q00 -> 26, r^T r -> 38
-        const float a0 = flip ? sumA0 : 0.f, a1 = flip ? sumA1 : 0.f, sb = flip ? (float)sumB : 0.f, sc = flip ? sumC : 0.f;
-        const int oa0 = (0x1A191716 >> (8 * j)) & 255, oa1 = (0x261D1C1B >> (8 * j)) & 255, osc = (0x2A211F1E >> (8 * j)) & 255;
-        S[oa0] = a0; S[j == 1 ? 24 : 43] = a0;
-        S[oa1] = a1;
-        S[osc] = sc; S[j == 1 ? 32 : 44] = sc;
-        S[34 + j] = sb;
-        S[(0x2B271514 >> (8 * j)) & 255] = j == 2 ? 1.f : 0.f;          // slots of zeros (20, 21) and of ones (39) for the matrix-core operands
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+        // Jpdxi (fp32, BA.cpp:133-147)
+        const float xi0[6] = {new_idepth * fxf, 0.f, -new_idepth * u * fxf, -u * v * fxf, (1 + u * u) * fxf, -v * fxf};
+        const float xi1[6] = {0.f, new_idepth * fyf, -new_idepth * v * fyf, -(1 + v * v) * fyf, u * v * fyf, u * fyf};
+        // Jpdc (:150-176): q = (sfac * drescale) * (Ea * w - Eb) / s2, entry = ((m * q) + add) * scale; entries 0,2 / 1,3 / 4,6 / 5,7 share q
+        const double q02 = (double)(1.f * drescale) * (E6 * u - E0);
+        const double q13 = rs_div((double)(fxf * drescale) * (E7 * u - E1), (double)fyf, rfy);
+        const double q46 = rs_div((double)(fyf * drescale) * (E6 * v - E3), (double)fxf, rfx);
+        const double q57 = (double)(1.f * drescale) * (E7 * v - E4);
+        const float c0[4] = {(float)(((rx * q02) + (double)u) * A.scale_f), (float)(((ry * q13) + -0.0) * A.scale_f),
+                             (float)(((1.0 * q02) + 1.0) * A.scale_c), (float)(((1.0 * q13) + -0.0) * A.scale_c)};
+        const float c1[4] = {(float)(((rx * q46) + -0.0) * A.scale_f), (float)(((ry * q57) + (double)v) * A.scale_f),
+                             (float)(((1.0 * q46) + -0.0) * A.scale_c), (float)(((1.0 * q57) + 1.0) * A.scale_c)};
+        // Jpdd (:178-182)
+        const float d0 = (float)(drescale * (et0 - et2 * u) * fxf), d1 = (float)(drescale * (et1 - et2 * v) * fyf);
 
-    // ---- per residual: JpJdF (BA.cpp:2066-2080) and the terms of Hcd, Hdd, bd (BA.cpp:1747-1750): 4 floats per quad lane, each
-    //      P*s + Q*t with per-lane LDS offsets (all loads unconditional):
-    //        lane 0: JpJdF[0..3] = Jpdxi[0][i] g0 + Jpdxi[1][i] g1        lane 1: JpJdF[4,5] likewise, JpJdF[6,7] = JabJIdx(.,0) d0 + JabJIdx(.,1) d1
-    //        lane 2: Hcd[i] = Jpdc[0][i] g0 + Jpdc[1][i] g1               lane 3: Hdd = d0 g0 + d1 g1, bd = JI^T r . Jpdd (fp64 as BA.cpp:1748), 0, 0
-    {
-        const float d0 = S[40], d1 = S[41];
-        const float g0 = S[22] * d0 + S[24] * d1;
-        const float g1 = S[23] * d0 + S[25] * d1;
-        const int pa = (0x280C0400 >> (8 * j)) & 255, pb = (0x29100A06 >> (8 * j)) & 255;          // {0, 4, 12, 40}, {6, 10, 16, 41}
-        const int pa2 = j == 1 ? 26 : pa + 2, pb2 = j == 1 ? 28 : pb + 2;             // lane 1: JabJIdx (0,0),(1,0) | (0,1),(1,1)
-        const float P0 = S[pa], P1 = S[pa + 1], P2 = S[pa2], P3 = S[pa2 + 1];
-        const float Q0 = S[pb], Q1 = S[pb + 1], Q2 = S[pb2], Q3 = S[pb2 + 1];
-        const float s2 = j == 1 ? d0 : g0, t2 = j == 1 ? d1 : g1;
-        const float bd = (float)((double)S[34] * (double)d0 + (double)S[35] * (double)d1);
-        float4 o;
-        o.x = P0 * g0 + Q0 * g1;
-        o.y = P1 * g0 + Q1 * g1;
-        o.z = P2 * s2 + Q2 * t2;
-        o.w = P3 * s2 + Q3 * t2;
-        if (j == 3) { o.y = bd; o.z = 0.f; o.w = 0.f; }
-        if (flip && !(X.dbg_flags & 2)) reinterpret_cast<float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r)[j] = o;
+        // ---- per residual: JpJdF (BA.cpp:2066-2080) and the terms of Hcd, Hdd, bd (BA.cpp:1747-1750)
+        if (flip && !(X.dbg_flags & 2)) {
+            const float g0 = J00 * d0 + J10 * d1;
+            const float g1 = J10 * d0 + J11 * d1;
+            float4* o = reinterpret_cast<float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r);
+            o[0] = make_float4(xi0[0] * g0 + xi1[0] * g1, xi0[1] * g0 + xi1[1] * g1, xi0[2] * g0 + xi1[2] * g1, xi0[3] * g0 + xi1[3] * g1);
+            o[1] = make_float4(xi0[4] * g0 + xi1[4] * g1, xi0[5] * g0 + xi1[5] * g1, Q00 * d0 + Q01 * d1, Q10 * d0 + Q11 * d1);
+            o[2] = make_float4(c0[0] * g0 + c1[0] * g1, c0[1] * g0 + c1[1] * g1, c0[2] * g0 + c1[2] * g1, c0[3] * g0 + c1[3] * g1);
+            o[3] = make_float4(d0 * g0 + d1 * g1, (float)((double)(float)JIr0 * (double)d0 + (double)(float)JIr1 * (double)d1), 0.f, 0.f);
+        }
+        // ---- staged operands of the matrix-core reduction; a residual that is not IN (or a lane beyond the tile) stages zeros
+#define RS_ST(i, val) S[i] = flip ? (val) : 0.f
+#pragma unroll
+        for (int i = 0; i < 6; i++) { RS_ST(i, xi0[i]); RS_ST(6 + i, xi1[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { RS_ST(12 + i, c0[i]); RS_ST(16 + i, c1[i]); }
+        S[20] = 0.f;
+        RS_ST(22, J00); RS_ST(23, J10); RS_ST(24, J10); RS_ST(25, J11);
+        RS_ST(26, Q00); RS_ST(27, Q10); RS_ST(28, Q01); RS_ST(29, Q11);
+        RS_ST(30, B00); RS_ST(31, B01); RS_ST(32, B01); RS_ST(33, B11);
+        RS_ST(34, (float)JIr0); RS_ST(35, (float)JIr1); RS_ST(36, (float)Jabr0); RS_ST(37, (float)Jabr1);
+        RS_ST(38, rr);
+        S[39] = 1.f;
+#undef RS_ST
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the workgroup is ONE wave and a wave's LDS operations execute in order:
+    __builtin_amdgcn_wave_barrier();                        // only the compiler has to be kept from moving the reads up
 
     // ---- the wave's contribution to the 13x13 block of its pair: one v_mfma_f32_16x16x4_f32 per residual (see acc_pair_block)
     {
         const unsigned off = c_rs_mfma_off[ln];
         const int oa = c_rs_mfma_a[ln], o1 = off & 255, o2 = (off >> 8) & 255, o3 = (off >> 16) & 255, o4 = off >> 24;
         float4_ acc = {0.f, 0.f, 0.f, 0.f};
-        const float* SW = stg;
-#pragma unroll 4
-        for (int li = 0; li < RS_RES; li++) {
-            const float* SL = SW + li * RS_SSTRIDE;
+#pragma unroll 8
+        for (int li = 0; li < RS_TILE; li++) {
+            const float* SL = s_stg + li * RS_SSTRIDE;
             const float av = SL[oa];
             const float bv = SL[o3] * SL[o1] + SL[o4] * SL[o2];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
-        // a residual slot beyond the tile's count (or not IN) staged zeros: the ones slot then multiplies zero fields only
         if (!(X.dbg_flags & 2)) reinterpret_cast<float4*>(X.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 
-    // ---- per-tile partials {energy, n_in, n_oob, n_outlier} (BA.cpp:1565): fixed butterfly order over the 16 residuals
+    // ---- per-tile partials {energy, n_in, n_oob, n_outlier} (BA.cpp:1565): fixed butterfly order over the wave's residuals
     if (A.lin_partial) {
-        double e = ret_d;                                            // non-zero in quad lane 0 only
+        double e = ret_d;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
         const int c0 = __popcll(__ballot(ns_cnt == CMLHIP_RES_IN)), c1 = __popcll(__ballot(ns_cnt == CMLHIP_RES_OOB)), c2 = __popcll(__ballot(ns_cnt == CMLHIP_RES_OUTLIER));
@@ -411,15 +344,24 @@ __global__ __launch_bounds__(256, 3) void k_ba_lin_rs(BAArgs A, RsArgs X) {
     }
 }
 
+__global__ void k_ba_idepth_to_res(BAArgs A) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < A.R) A.r_idepth[r] = A.pt_idepth[A.r_point[r]];
+}
+
 int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
     if (c->n_tiles == 0) return CMLHIP_OK;
+    if (c->r_idepth_dirty) {                               // pt_idepth was written outside the resident point step (upload, set_idepth, restore, standalone step)
+        k_ba_idepth_to_res<<<cml_div_up(A.R, 256), 256, 0, c->stream>>>(A);
+        c->r_idepth_dirty = false;
+    }
     RsArgs X;
     X.tiles = c->rs_tiles.as<int4>(); X.ntiles = c->n_tiles;
     X.r_px = c->r_px.as<float>(); X.r_py = c->r_py.as<float>(); X.r_colors = c->r_colors.as<float>(); X.r_weights = c->r_weights.as<float>();
-    X.part = c->rs_part.as<float>();
+    X.part = c->rs_part.as<float>(); X.r_idepth = c->r_idepth.as<double>();
     { static const char* e = getenv("CMLHIP_RS_DBG"); X.dbg_flags = e ? atoi(e) : 0; }      // development: 1 = all texel taps at texel 0, 2 = no tile / reduced-record stores
-    const int blocks = cml_div_up(c->n_tiles, 4);
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_ba_lin_rs<true>, blocks, 256, 0, A, X);
-    else CML_LAUNCH_EV(c, k_ba_lin_rs<false>, blocks, 256, 0, A, X);
+    if (c->rs_tile == 16) return cml_launch_linearize_rs4(c, A, X);                         // small window: 4 lanes per residual (ba_linearize_rs4.hip)
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_ba_lin_rs<true>, c->n_tiles, 64, 0, A, X);
+    else CML_LAUNCH_EV(c, k_ba_lin_rs<false>, c->n_tiles, 64, 0, A, X);
     return CMLHIP_OK;
 }

@@ -14,6 +14,7 @@
 #include "../../include/cmlhip.h"
 
 #define CML_WAVE 64
+#define RS_TILE_DEFAULT 64
 
 struct DevBuf {
     void* p = nullptr;
@@ -86,7 +87,9 @@ struct cmlhip_ctx {
     DevBuf point_code, point_tgt, point_pos; int pt_stride = 0; // [P][pt_stride]: efsJ code per point slot (kept by applyRes), static target | lin << 8, slot of r
     DevBuf pair_code, pair_pos; int pair_stride = 0;          // [N*N][pair_stride] efsJ code (2r+sel, -1 = not in the ACTIVE sum) kept by applyRes; position of r
     // resident residual kernel (ba_linearize_rs.hip)
-    DevBuf rs_tiles, rs_tile_off, rs_part, r_px, r_py, r_colors, r_weights; int n_tiles = 0;
+    DevBuf rs_tiles, rs_tile_off, rs_part, r_px, r_py, r_colors, r_weights, r_idepth, point_res; int n_tiles = 0;
+    int rs_tile = RS_TILE_DEFAULT;                            // residuals per wave tile of this window: 64 = lane per residual (large windows), 16 = 4 lanes per residual
+    bool r_idepth_dirty = true;                               // pt_idepth was written by something else than the resident point step
     bool efs_in_partials = false;                             // the last residual pass was the resident kernel: the pair blocks of the good
                                                               // residuals live in rs_part, their efsJ records are NOT materialised
     bool rs_ok = true;                                        // use the resident kernel in cmlhip_ba_iteration_async (CMLHIP_NO_RS=1 in the environment: the record-writing kernel)

@@ -17,27 +17,32 @@ from tests import dev_setup as D
 pytestmark = pytest.mark.gpu
 
 
-def _make(I, use_rs, texel_format):
+def _make(I, use_rs, texel_format, tile):
     if use_rs:
         os.environ.pop("CMLHIP_NO_RS", None)
     else:
         os.environ["CMLHIP_NO_RS"] = "1"
+    os.environ["CMLHIP_RS_TILE"] = str(tile)          # both contexts: the tile size also fixes the summation order of the record path
     try:
         ctx = D.make_ctx(I, texel_format=texel_format)
     finally:
         os.environ.pop("CMLHIP_NO_RS", None)
+        os.environ.pop("CMLHIP_RS_TILE", None)
     return ctx
 
 
+# tile 16 = k_ba_lin_rs4 (4 lanes per residual, small windows), tile 64 = k_ba_lin_rs (one lane per residual, large windows);
+# the library picks by window size, the test forces each on every window
+@pytest.mark.parametrize("tile", [16, 64])
 @pytest.mark.parametrize("config,half", [("tiny", False), ("small", False), ("small", True), ("B", False)])
-def test_resident_kernel_matches_record_kernel(config, half):
+def test_resident_kernel_matches_record_kernel(config, half, tile):
     I = S.make_inputs(config)
     if half:
         for k in range(I.N):
             for lvl in range(len(I.grads[k])):
                 I.grads[k][lvl] = I.grads[k][lvl].astype(np.float16).astype(np.float32)
     fmt = abi.TEXEL_F16 if half else abi.TEXEL_F32
-    a, b = _make(I, False, fmt), _make(I, True, fmt)          # a: record-writing kernel in the loop, b: resident kernel
+    a, b = _make(I, False, fmt, tile), _make(I, True, fmt, tile)          # a: record-writing kernel in the loop, b: resident kernel
     try:
         for c in (a, b):
             c.ba_linearize(); c.ba_apply(1)
