@@ -65,6 +65,11 @@ def lib():
         L.cmlhost_tracker_optimize.argtypes = [_vp, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_i), _P(_i), _P(_d),
                                                _P(_d), _P(_d), _P(_i), _P(_i), _P(_i)]
         L.cmlhost_tracker_last_error.restype = C.c_char_p; L.cmlhost_tracker_last_error.argtypes = [_vp]
+        L.cmlhost_tracker_set_eval.argtypes = [_vp, _vp, _vp]
+        L.cmlhost_tracker_steps.argtypes = [_vp, _i, _P(_i), _P(_i), _P(_i), _P(_d)]
+        L.cmlhost_tracker_set_last_residual.argtypes = [_vp, _i, _i, _P(_d)]
+        L.cmlhost_tracker_track_with_motion_model.argtypes = [_vp, C.c_uint64, _i, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_i), _P(_i),
+                                                              _P(_i), _P(_i), _P(_i), _P(_i), _P(_d)]
         L.cmlhost_tracer_create.restype = _vp; L.cmlhost_tracer_create.argtypes = [_vp]
         L.cmlhost_tracer_destroy.argtypes = [_vp]
         L.cmlhost_tracer_add_point.argtypes = [_vp, _f, _f, _i, _P(_f), _P(_f), _P(_d), _f]
@@ -263,11 +268,54 @@ class HostBA:
         return e[:n]
 
 
+# computeResidual + computeHessian provider signature of cml_amd::DSOTracker::EvalFn
+TRACKER_EVAL_FN = C.CFUNCTYPE(_i, _vp, _i, _P(_d), _P(_d), _P(_d), _P(_d), _d, _P(abi.TrackerParams), _P(abi.TrackerResult))
+
+
 class HostTracker:
     def __init__(self, ctx):
+        """ctx = device.Ctx, or None for a tracker whose evaluations come from set_eval() (control-flow tests without a GPU)."""
         self.ctx = ctx
         self.L = lib()
-        self.h = self.L.cmlhost_tracker_create(ctx.h)
+        self.h = self.L.cmlhost_tracker_create(ctx.h if ctx is not None else None)
+        self._eval_keep = None
+
+    def set_eval(self, fn):
+        """fn(level, R[9], t[3], K[4], aff[2], b0, prm, result) -> int; None restores the device evaluation."""
+        if fn is None:
+            self._eval_keep = None
+            self.L.cmlhost_tracker_set_eval(self.h, None, None)
+            return
+
+        def tramp(user, level, R, t, K, aff, b0, prm, out):
+            return int(fn(level, np.array(R[:9]), np.array(t[:3]), np.array(K[:4]), np.array(aff[:2]), float(b0), prm.contents, out))
+        self._eval_keep = TRACKER_EVAL_FN(tramp)
+        self.L.cmlhost_tracker_set_eval(self.h, C.cast(self._eval_keep, _vp), None)
+
+    def steps(self, cap=512):
+        lv = np.zeros(cap, np.int32); it = np.zeros(cap, np.int32); ac = np.zeros(cap, np.int32); lam = np.zeros(cap)
+        n = self.L.cmlhost_tracker_steps(self.h, cap, _p(lv, _i), _p(it, _i), _p(ac, _i), _p(lam, _d))
+        n = min(n, cap)
+        return lv[:n].copy(), it[:n].copy(), ac[:n].copy(), lam[:n].copy()
+
+    def set_last_residual(self, is_correct, rmse):
+        r = np.ascontiguousarray(rmse, np.float64)
+        self.L.cmlhost_tracker_set_last_residual(self.h, int(is_correct), len(r), _p(r, _d))
+
+    def track_with_motion_model(self, new_image, levels, hyps, ref_exp, init_exp):
+        """hyps: list of (R, t) refToNew candidates.  Returns the adopted try (DSOTracker.h:238-383)."""
+        H = np.zeros((len(hyps), 12))
+        for i, (R, t) in enumerate(hyps):
+            H[i, :9] = np.asarray(R, np.float64).ravel(); H[i, 9:] = t
+        re = np.ascontiguousarray(ref_exp, np.float64); ie = np.ascontiguousarray(init_exp, np.float64)
+        R = np.zeros(9); t = np.zeros(3); oe = np.zeros(2); E = np.zeros(8); nt = np.zeros(8, np.int32); ns = np.zeros(8, np.int32)
+        ok, sat, win, tries = _i(), _i(), _i(), _i()
+        lcr = _d()
+        good = self.L.cmlhost_tracker_track_with_motion_model(self.h, int(new_image), levels, len(hyps), _p(H, _d), _p(re, _d), _p(ie, _d), _p(R, _d), _p(t, _d),
+                                                              _p(oe, _d), _p(E, _d), _p(nt, _i), _p(ns, _i), C.byref(ok), C.byref(sat), C.byref(win),
+                                                              C.byref(tries), C.byref(lcr))
+        return dict(haveOneGood=bool(good), R=R.reshape(3, 3), t=t, exposure=oe, E=E, numTerms=nt, numSat=ns, isCorrect=bool(ok.value),
+                    tooManySaturated=bool(sat.value), winner=win.value, tries=tries.value, lastCoarseRMSE=lcr.value)
 
     def close(self):
         if self.h:

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 namespace cml_amd {
 
@@ -95,7 +96,8 @@ DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLeve
         refExposure.to(ex, aff[0], aff[1]);
         prm.cutoff = (float)(mCutoffThreshold * levelCutoffRepeat[level]);
         cmlhip_tracker_result tr;
-        const int rc = cmlhip_tracker_eval(mCtx, new_image_id, level, R, T.t, K, aff, refExposure.b, &prm, wantH ? 1 : 0, &tr);
+        const int rc = evalOverride ? evalOverride(evalUser, level, R, T.t, K, aff, refExposure.b, &prm, &tr)
+                                    : cmlhip_tracker_eval(mCtx, new_image_id, level, R, T.t, K, aff, refExposure.b, &prm, wantH ? 1 : 0, &tr);
         if (rc && rc != CMLHIP_ERR_NONFINITE) { mError = std::string("cmlhip_tracker_eval: ") + cmlhip_last_error(mCtx); return false; }
         out.E[level] = tr.E; out.numTermsInE[level] = tr.numTermsInE; out.numSaturated[level] = tr.numSaturated; out.numRobust[level] = tr.numRobust;
         for (int k = 0; k < 3; k++) out.flowVector[k] = tr.flow[k];
@@ -103,6 +105,7 @@ DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLeve
         return true;
     };
 
+    lastSteps.clear();
     for (int level = maxLevel; level >= 0; level--) {
         levelCutoffRepeat[level] = 1;
         if (!eval(level, currentRefToNew, currentExposure, oldR, true, H, bvec)) { oldR.isCorrect = false; return oldR; }
@@ -158,6 +161,7 @@ DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLeve
             newExposure.a += incS[6]; newExposure.b += incS[7];                                          // :159
             if (!eval(level, newRefToNew, newExposure, newR, true, Hn, bn)) { oldR.isCorrect = false; return oldR; }
             const bool accept = (newR.E[level] / (double)newR.numTermsInE[level]) < (oldR.E[level] / (double)oldR.numTermsInE[level]);   // :163
+            lastSteps.push_back(Step{level, iteration, accept ? 1 : 0, lambda, newR.E[level], oldR.E[level], newR.numTermsInE[level], oldR.numTermsInE[level]});
             if (accept) {
                 std::memcpy(H, Hn, sizeof H); std::memcpy(bvec, bn, sizeof bvec);                        // computeHessian at the accepted state, :166
                 const std::vector<int> its = oldR.iterations;
@@ -171,6 +175,10 @@ DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLeve
             double nrm = 0;
             for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
             if (std::sqrt(nrm) < 1e-3) break;                                                             // :176-179
+        }
+        if (mLastResidual.isCorrect && level < (int)mLastResidual.E.size() && oldR.rmse(level) > 1.5 * mLastResidual.rmse(level)) {   // :183-189
+            oldR.isCorrect = false;
+            return oldR;
         }
         if (levelCutoffRepeat[level] > 1 && !haveRepeated) { level++; haveRepeated = true; }            // :192-195
     }
@@ -191,6 +199,56 @@ DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLeve
     inverseSmall(H, 8, Hi);                                                                              // :243
     for (int k = 0; k < 6; k++) oldR.covariance[k] = Hi[k * 8 + k];
     return oldR;
+}
+
+bool DSOTracker::trackWithMotionModel(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
+                                      const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
+                                      int* winner, int* tries) {
+    residual = Residual();
+    bool haveOneGood = false;
+    Residual trackingResult, testTrackingResult;
+    double achievedRes = std::numeric_limits<double>::max();
+    if (winner) *winner = -1;
+    auto rmse0 = [](const Residual& r) { return (!r.E.empty() && r.numTermsInE[0] > 0) ? r.rmse() : std::numeric_limits<double>::quiet_NaN(); };
+    int i = 0;
+    for (; i < n_hyp; i++) {
+        SE3 testRefToNew = hyp[i];
+        Exposure testExposure = initialExposure;                                           // :268-269
+        mLastResidual = trackingResult;                                                    // :272
+        testTrackingResult = optimize(new_image_id, pyramidLevels, testRefToNew, referenceExposure, testExposure);
+        const double rm = rmse0(testTrackingResult);
+        auto adopt = [&]() {
+            haveOneGood = true; bestRefToNew = testRefToNew; bestExposure = testExposure; trackingResult = testTrackingResult;
+            if (winner) *winner = i;
+        };
+        if (trackingResult.tooManySaturated == true && testTrackingResult.tooManySaturated == false && testTrackingResult.isCorrect && std::isfinite(rm)) adopt();   // :280-285
+        if (testTrackingResult.isCorrect && std::isfinite(rm) && !(rm >= achievedRes)) {   // do we have a new winner? :288-296
+            if (trackingResult.tooManySaturated || !testTrackingResult.tooManySaturated) adopt();
+        }
+        if (haveOneGood) {                                                                 // take over achieved res (always), :299-304
+            if (!testTrackingResult.numTermsInE.empty() && testTrackingResult.numTermsInE[0] > 0 && rm < achievedRes) achievedRes = rm;
+        }
+        const float setting_reTrackThreshold = 1.5f;
+        if (haveOneGood && achievedRes < mLastCoarseRMSE * setting_reTrackThreshold) { i++; break; }   // :306-309
+        if (haveOneGood && i >= 50) { i++; break; }                                        // :311-313
+    }
+    if (tries) *tries = i;
+    if (!haveOneGood) {
+        if ((mFailureMode == 1 || mFailureMode == 2) && n_hyp > 0) {                       // :324-352 (mode 2: the caller then overrides the camera with frame * cameras[0])
+            bestRefToNew = hyp[0];
+            bestExposure = initialExposure;
+            mLastResidual = trackingResult;
+            trackingResult = optimize(new_image_id, pyramidLevels, bestRefToNew, referenceExposure, bestExposure);
+            if (winner) *winner = 0;
+            haveOneGood = true;
+        } else {
+            return false;                                                                  // :353-355
+        }
+    } else {
+        mLastCoarseRMSE = achievedRes;                                                     // :357 (mFirstRMSE of the reference keyframe is the caller's)
+    }
+    residual = trackingResult;
+    return haveOneGood;
 }
 
 }  // namespace cml_amd

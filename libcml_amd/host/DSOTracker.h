@@ -23,6 +23,13 @@ public:
         double rmse(size_t i = 0) const { return E[i] / (double)numTermsInE[i]; }
     };
 
+    // one Levenberg-Marquardt trial of optimize(): the accept / reject decision of TR.cpp:163 and what it compared
+    struct Step { int level, iteration, accept; double lambda, E_new, E_old; int n_new, n_old; };
+    // computeResidual + computeHessian provider.  Default: cmlhip_tracker_eval on the device.  Tests install the oracle's evaluation
+    // here to compare the control flow of optimize() with the oracle's restatement on identical numbers.
+    typedef int (*EvalFn)(void* user, int level, const double R[9], const double t[3], const double K[4], const double aff[2], double b0,
+                          const cmlhip_tracker_params* prm, cmlhip_tracker_result* out);
+
     explicit DSOTracker(cmlhip_ctx* ctx) : mCtx(ctx) {}
 
     // parameters, DSOTracker.h:473-520
@@ -31,12 +38,24 @@ public:
     bool mOptimizeA = true, mOptimizeB = true, mBackupSolver = false;
     double mSaturatedRatioThreshold = 0.33;
     int maxLevelOverride = -1;
+    int mFailureMode = 0;                               // DSOTracker.h:517
+    double mLastCoarseRMSE = 100;                       // DSOTracker.h:470
+    Residual mLastResidual;                             // set by trackWithMotionModel before every try (DSOTracker.h:272), read by optimize (TR.cpp:183-189)
+    std::vector<Step> lastSteps;                        // the trials of the last optimize()
+    EvalFn evalOverride = nullptr; void* evalUser = nullptr;
 
     void setCalibration(double fx, double fy, double cx, double cy) { mK[0] = fx; mK[1] = fy; mK[2] = cx; mK[3] = cy; }
     // makeCoarseDepthL0 (DSOTracker.cpp:494-724): pts = n x {Ku,Kv,new_idepth,weight} projected by the caller (:521-540)
     bool makeCoarseDepthL0(uint64_t ref_image_id, int levels, const double* pts, int n, int* n_out);
     // optimize (DSOTracker.cpp:15-246): refToNew and currentExposure are updated in place
     Residual optimize(uint64_t new_image_id, int pyramidLevels, SE3& refToNew, const Exposure& referenceExposure, Exposure& currentExposure);
+    // trackWithMotionModel (DSOTracker.h:238-383): the hypothesis loop around optimize.  hyp = reference->getCamera().to(c) for every
+    // camera c of Map::multiConstantVelocityMotionModel (the caller owns the map).  Every try starts from initialExposure's
+    // parameters.  On success bestRefToNew / bestExposure / residual hold the adopted try (the caller applies
+    // frame->setCamera(reference.compose(bestRefToNew)), setExposureParameters); *tries = hypotheses run, *winner = adopted index.
+    bool trackWithMotionModel(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
+                              const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
+                              int* winner, int* tries);
     const std::string& lastError() const { return mError; }
 
 private:

@@ -166,6 +166,8 @@ int cmlhost_tracker_set_param(void* h, const char* name, double v) {
     else if (n == "Huber threshold") t->mHuberThreshold = v;
     else if (n == "saturatedThreshold") t->mSaturatedRatioThreshold = v;
     else if (n == "maxLevel") t->maxLevelOverride = (int)v;
+    else if (n == "failureMode") t->mFailureMode = (int)v;
+    else if (n == "lastCoarseRMSE") t->mLastCoarseRMSE = v;
     else return 1;
     return 0;
 }
@@ -191,6 +193,39 @@ int cmlhost_tracker_optimize(void* h, uint64_t new_image, int levels, double R[9
     return res.isCorrect ? 1 : 0;
 }
 const char* cmlhost_tracker_last_error(void* h) { return static_cast<DSOTracker*>(h)->lastError().c_str(); }
+// tests: install the evaluation provider (the oracle's computeResidual + computeHessian) / read the trial log of the last optimize()
+void cmlhost_tracker_set_eval(void* h, DSOTracker::EvalFn fn, void* user) { DSOTracker* t = static_cast<DSOTracker*>(h); t->evalOverride = fn; t->evalUser = user; }
+int cmlhost_tracker_steps(void* h, int cap, int* level, int* iteration, int* accept, double* lambda) {
+    const auto& s = static_cast<DSOTracker*>(h)->lastSteps;
+    for (int i = 0; i < (int)s.size() && i < cap; i++) { level[i] = s[i].level; iteration[i] = s[i].iteration; accept[i] = s[i].accept; lambda[i] = s[i].lambda; }
+    return (int)s.size();
+}
+void cmlhost_tracker_set_last_residual(void* h, int isCorrect, int levels, const double* rmse) {
+    DSOTracker* t = static_cast<DSOTracker*>(h);
+    t->mLastResidual = DSOTracker::Residual();
+    t->mLastResidual.isCorrect = isCorrect != 0;
+    t->mLastResidual.E.assign(levels, 0.0); t->mLastResidual.numTermsInE.assign(levels, 1);
+    for (int l = 0; l < levels; l++) t->mLastResidual.E[l] = rmse[l];
+}
+// trackWithMotionModel(): hypotheses as n x {R[9], t[3]}; outputs the adopted try
+int cmlhost_tracker_track_with_motion_model(void* h, uint64_t new_image, int levels, int n_hyp, const double* hypRt, const double refExp[3], const double initExp[3],
+                                            double R[9], double t[3], double outExp[2], double* E, int* numTerms, int* numSat, int* isCorrect,
+                                            int* tooManySaturated, int* winner, int* tries, double* lastCoarseRMSE) {
+    DSOTracker* T = static_cast<DSOTracker*>(h);
+    std::vector<SE3> hyp(n_hyp);
+    for (int i = 0; i < n_hyp; i++) hyp[i] = SE3::fromRt(hypRt + 12 * i, hypRt + 12 * i + 9);
+    Exposure ref(refExp[2], refExp[0], refExp[1]), init(initExp[2], initExp[0], initExp[1]), best = init;
+    SE3 bestT;
+    DSOTracker::Residual res;
+    const bool ok = T->trackWithMotionModel(new_image, levels, n_hyp, hyp.data(), ref, init, bestT, best, res, winner, tries);
+    if (ok) {
+        bestT.matrix(R); std::memcpy(t, bestT.t, 3 * sizeof(double));
+        outExp[0] = best.a; outExp[1] = best.b;
+        for (int l = 0; l < levels && l < (int)res.E.size(); l++) { E[l] = res.E[l]; numTerms[l] = res.numTermsInE[l]; numSat[l] = res.numSaturated[l]; }
+    }
+    *isCorrect = res.isCorrect; *tooManySaturated = res.tooManySaturated; *lastCoarseRMSE = T->mLastCoarseRMSE;
+    return ok ? 1 : 0;
+}
 
 // ---- DSOTracer mirror
 void* cmlhost_tracer_create(cmlhip_ctx* ctx) { return new cml_amd::DSOTracer(ctx); }

@@ -187,6 +187,29 @@ void orc_tracker_eval(const float* aos3, int w, int h, const float* uvic, int n,
                       const cmlhip_tracker_params* prm, int want_hessian,
                       cmlhip_tracker_result* out, float* warped, int cap);
 
+/* DSOTracker::optimize (TR.cpp:15-246) and trackWithMotionModel (TR.h:238-383) on top of orc_tracker_eval */
+typedef struct { int level, iteration, accept; double lambda, E_new, E_old; int n_new, n_old; } orc_trk_step;
+typedef struct {
+    int levels;                                  /* pyramid levels of the frame to track (maxLevel = min(levels - 1, 4)) */
+    const float* aos3[5]; int w[5], h[5];        /* its gradient images */
+    const float* uvic[5]; int n[5];              /* reference lists (makeCoarseDepthL0) */
+    double K[4];                                 /* level-0 pinhole fx fy cx cy */
+    double ref_a, ref_b, ref_t, new_t;           /* reference exposure parameters / time, exposure time of the new frame */
+    cmlhip_tracker_params prm;                   /* huber, cutoff_base, scales (cutoff is derived per level) */
+    int optimize_a, optimize_b; double saturated_ratio_th;
+    int have_last; double last_rmse[5];          /* mLastResidual.isCorrect, mLastResidual.rmse(level) */
+} orc_trk_problem;
+typedef struct {
+    int isCorrect, tooManySaturated;
+    double E[5]; int numTermsInE[5], numSaturated[5], numRobust[5]; double levelCutoffRepeat[5];
+    double relAff[2], covariance[6], flow[3]; int n_steps;
+} orc_trk_result;
+int orc_tracker_optimize(const orc_trk_problem* P, orc_se3* refToNew, double* cur_a, double* cur_b, orc_trk_result* out,
+                         orc_trk_step* log, int log_cap);
+int orc_tracker_track_with_motion_model(orc_trk_problem* P, int n_hyp, const orc_se3* hyp, double init_a, double init_b, double last_coarse_rmse,
+                                        int failure_mode, orc_se3* best_pose, double* best_a, double* best_b, orc_trk_result* best,
+                                        double* achieved_out, int* winner, int* tries);
+
 /* ------------------------------------------------------------------ hybrid ORB term */
 /* ReprojectionError::jacobian, src/cml/optimization/Residual.h:59-100 ; returns 0 if not finite */
 int  orc_reproj_jacobian(const double R[9], const double t[3], const double X[3], double gx, double gy,

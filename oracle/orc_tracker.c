@@ -5,6 +5,7 @@
  */
 #include "cml_oracle.h"
 #include <math.h>
+#include <float.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -315,4 +316,206 @@ void orc_reproj_accumulate(int N, const double* poses, int M, const double* poin
             b6[6 * i + a] += f[a] * res;                   /* :2655 */
         }
     }
+}
+
+/* ================================================================== DSOTracker::optimize, TR.cpp:15-246
+ * Coarse-to-fine Levenberg-Marquardt over 8 parameters on top of orc_tracker_eval (computeResidual + computeHessian); every
+ * statement of the reference's loop is restated in order: per-level iteration caps (:23), minimum term counts (:65,:77), the
+ * saturation repeat (:71-75), the four optimizeA/B solver branches (:96-119), the extrapolation below lambda 1e-3 (:140-142),
+ * the literal lane / scale pairing of incrementScaled (:144-148), accept / reject (:163-174), the increment-norm exit (:176),
+ * the rmse test against mLastResidual (:183-189), the single level repeat (:192-195), light / saturation validity (:203-240). */
+static void trk_level_K(const double K0[4], int level, double K[4]) {        /* InternalCalibration.h:116-127 */
+    const double d = (double)(1 << level);
+    K[0] = K0[0] / d; K[1] = K0[1] / d; K[2] = (K0[2] + 0.5) / d - 0.5; K[3] = (K0[3] + 0.5) / d - 0.5;
+}
+static void trk_eval(const orc_trk_problem* P, int level, const orc_se3* T, double a, double b, double cutoff_mult,
+                     cmlhip_tracker_result* out) {
+    double R[9], K[4], aff[2];
+    orc_se3_matrix(T, R);
+    trk_level_K(P->K, level, K);
+    orc_exposure_to(P->ref_a, P->ref_b, P->ref_t, a, b, P->new_t, &aff[0], &aff[1]);      /* reference->getExposure().to(exposure), :269 */
+    cmlhip_tracker_params prm = P->prm;
+    prm.cutoff = (float)((double)P->prm.cutoff_base * cutoff_mult);                       /* mCutoffThreshold.f() * levelCutoffRepeat[level] */
+    orc_tracker_eval(P->aos3[level], P->w[level], P->h[level], P->uvic[level], P->n[level], level, R, T->t, K, aff, P->ref_b, &prm, 1, out, NULL, 0);
+}
+
+int orc_tracker_optimize(const orc_trk_problem* P, orc_se3* refToNew, double* cur_a, double* cur_b, orc_trk_result* out,
+                         orc_trk_step* log, int log_cap) {
+    static const int maxIterations[5] = {10, 20, 50, 50, 50};                            /* :23 */
+    int maxLevel = P->levels - 1 < 4 ? P->levels - 1 : 4;
+    memset(out, 0, sizeof *out);
+    for (int k = 0; k < 6; k++) out->covariance[k] = 999999;
+    out->tooManySaturated = 1;
+    double E[5] = {0}, levelCutoffRepeat[5] = {0};
+    int nT[5] = {0}, nS[5] = {0}, nR[5] = {0};
+    double E_new[5] = {0};                       /* newResidual: every level slot keeps the LAST trial evaluated there, accepted or not */
+    int nT_new[5] = {0}, nS_new[5] = {0}, nR_new[5] = {0};
+    double flow[3] = {0, 0, 0};
+    int haveRepeated = 0, nlog = 0;
+    orc_se3 cur = *refToNew, nw;
+    double a = *cur_a, b = *cur_b, na, nb_;
+    double H[64], bv[8];
+    cmlhip_tracker_result tr;
+#define TRK_FAIL() do { out->isCorrect = 0; goto fill; } while (0)
+    for (int level = maxLevel; level >= 0; level--) {
+        levelCutoffRepeat[level] = 1;
+        trk_eval(P, level, &cur, a, b, levelCutoffRepeat[level], &tr);
+        E[level] = tr.E; nT[level] = tr.numTermsInE; nS[level] = tr.numSaturated; nR[level] = tr.numRobust;
+        for (int k = 0; k < 3; k++) flow[k] = tr.flow[k];
+        if (nT[level] < 20) TRK_FAIL();                                                  /* :65-69 */
+        while ((nS[level] / (double)nT[level]) > 0.6 && levelCutoffRepeat[level] < 50) { /* :71-75 */
+            levelCutoffRepeat[level] *= 2;
+            trk_eval(P, level, &cur, a, b, levelCutoffRepeat[level], &tr);
+            E[level] = tr.E; nT[level] = tr.numTermsInE; nS[level] = tr.numSaturated; nR[level] = tr.numRobust;
+            for (int k = 0; k < 3; k++) flow[k] = tr.flow[k];
+        }
+        if (nT[level] - nS[level] < 10) TRK_FAIL();                                      /* :77-81 */
+        memcpy(H, tr.H, sizeof H); memcpy(bv, tr.b, sizeof bv);                          /* computeHessian, :85 */
+        double lambda = 0.01;
+        const double lambdaExtrapolationLimit = 0.001;
+        for (int iteration = 0; iteration < maxIterations[level]; iteration++) {
+            double D[64], inc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nbv[8];
+            memcpy(D, H, sizeof D);
+            for (int i = 0; i < 8; i++) { D[i * 8 + i] *= (1 + lambda); nbv[i] = -bv[i]; }
+            int ok = 1;
+            if (P->optimize_a && P->optimize_b) {
+                ok = orc_ldlt_solve(D, nbv, 8, inc) == 0;                                 /* :96-98 */
+            } else if (P->optimize_a && !P->optimize_b) {                                 /* :99-102 */
+                double S[49], x7[7];
+                for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) S[i * 7 + j] = D[i * 8 + j];
+                ok = orc_ldlt_solve(S, nbv, 7, x7) == 0;
+                for (int i = 0; i < 7; i++) inc[i] = x7[i];
+                inc[7] = 0;
+            } else if (!P->optimize_a && P->optimize_b) {                                 /* :103-114 */
+                double Hs[64], bs[8], S[49], nb7[7], x7[7];
+                memcpy(Hs, D, sizeof Hs); memcpy(bs, bv, sizeof bs);
+                for (int i = 0; i < 8; i++) Hs[i * 8 + 6] = Hs[i * 8 + 7];
+                for (int j = 0; j < 8; j++) Hs[6 * 8 + j] = Hs[7 * 8 + j];
+                bs[6] = bs[7];
+                for (int i = 0; i < 7; i++) { for (int j = 0; j < 7; j++) S[i * 7 + j] = Hs[i * 8 + j]; nb7[i] = -bs[i]; }
+                ok = orc_ldlt_solve(S, nb7, 7, x7) == 0;
+                for (int i = 0; i < 6; i++) inc[i] = x7[i];
+                inc[6] = 0; inc[7] = x7[6];
+            } else {                                                                      /* :115-119 */
+                double S[36], x6[6];
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S[i * 6 + j] = D[i * 8 + j];
+                ok = orc_ldlt_solve(S, nbv, 6, x6) == 0;
+                for (int i = 0; i < 6; i++) inc[i] = x6[i];
+            }
+            for (int i = 0; i < 8; i++) if (!isfinite(inc[i])) ok = 0;
+            if (!ok) TRK_FAIL();                                                          /* :121-138 (mBackupSolver off: the default) */
+            double extrapFac = 1;
+            if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit / lambda));   /* :140-142 */
+            for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+            double incS[8];
+            memcpy(incS, inc, sizeof incS);
+            for (int i = 0; i < 3; i++) { incS[i] *= (double)P->prm.scale_rot; incS[3 + i] *= (double)P->prm.scale_trans; }   /* :144-146, literal pairing */
+            incS[6] *= (double)P->prm.scale_a; incS[7] *= (double)P->prm.scale_b;
+            orc_se3 ex;
+            orc_se3_exp(incS, &ex);
+            orc_se3_mul(&ex, &cur, &nw);                                                  /* newRefToNew = se3 * currentRefToNew, :157 */
+            na = a + incS[6]; nb_ = b + incS[7];                                          /* currentExposure.add(...), :159 */
+            cmlhip_tracker_result tn;
+            trk_eval(P, level, &nw, na, nb_, levelCutoffRepeat[level], &tn);
+            E_new[level] = tn.E; nT_new[level] = tn.numTermsInE; nS_new[level] = tn.numSaturated; nR_new[level] = tn.numRobust;
+            const int accept = (tn.E / (double)tn.numTermsInE) < (E[level] / (double)nT[level]);   /* :163 */
+            if (log && nlog < log_cap) {
+                orc_trk_step* s = &log[nlog];
+                s->level = level; s->iteration = iteration; s->accept = accept; s->lambda = lambda;
+                s->E_new = tn.E; s->E_old = E[level]; s->n_new = tn.numTermsInE; s->n_old = nT[level];
+            }
+            nlog++;
+            if (accept) {
+                memcpy(H, tn.H, sizeof H); memcpy(bv, tn.b, sizeof bv);                   /* computeHessian at the accepted state, :166 */
+                /* oldResidual = newResidual, :167: a whole-struct copy — the slots of the coarser levels become those of the last TRIAL
+                   evaluated there (literal behaviour; only reporting is affected, every test of the loop reads the current level) */
+                for (int l = 0; l < 5; l++) { E[l] = E_new[l]; nT[l] = nT_new[l]; nS[l] = nS_new[l]; nR[l] = nR_new[l]; }
+                for (int k = 0; k < 3; k++) flow[k] = tn.flow[k];
+                cur = nw; a = na; b = nb_;
+                lambda *= 0.5;
+            } else {
+                lambda *= 4;
+            }
+            double nrm = 0;
+            for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+            if (sqrt(nrm) < 1e-3) break;                                                  /* :176-179 */
+        }
+        if (P->have_last && (E[level] / (double)nT[level]) > 1.5 * P->last_rmse[level]) TRK_FAIL();   /* :183-189 */
+        if (levelCutoffRepeat[level] > 1 && !haveRepeated) { level++; haveRepeated = 1; } /* :192-195 */
+    }
+    {
+        double relA, relB;
+        orc_exposure_to(P->ref_a, P->ref_b, P->ref_t, a, b, P->new_t, &relA, &relB);      /* :203 */
+        int haveGoodLight = 1;
+        if (P->optimize_a) { if (fabs(a) > 1.2) haveGoodLight = 0; }
+        else if (fabs(logf((float)relA)) > 1.5) haveGoodLight = 0;
+        if (P->optimize_b) { if (fabs(b) > 200) haveGoodLight = 0; }
+        else if (fabs((float)relB) > 200) haveGoodLight = 0;
+        int haveGoodPoints = 1;
+        if ((double)nS[0] / (double)nT[0] > P->saturated_ratio_th) haveGoodPoints = 0;    /* :231-235 */
+        out->isCorrect = haveGoodLight;
+        out->tooManySaturated = haveGoodPoints;                                           /* sic, :240 */
+        out->relAff[0] = relA; out->relAff[1] = relB;
+        double Hi[64];
+        orc_inverse(H, 8, Hi);                                                            /* :243 */
+        for (int k = 0; k < 6; k++) out->covariance[k] = Hi[k * 8 + k];
+        *refToNew = cur; *cur_a = a; *cur_b = b;                                          /* the caller composes reference * refToNew, :237 */
+    }
+fill:
+    for (int l = 0; l < 5; l++) { out->E[l] = E[l]; out->numTermsInE[l] = nT[l]; out->numSaturated[l] = nS[l]; out->numRobust[l] = nR[l]; out->levelCutoffRepeat[l] = levelCutoffRepeat[l]; }
+    for (int k = 0; k < 3; k++) out->flow[k] = flow[k];
+    out->n_steps = nlog;
+    return out->isCorrect;
+#undef TRK_FAIL
+}
+
+/* DSOTracker::trackWithMotionModel, TR.h:238-383: the hypothesis loop around optimize.  hyp = n_hyp candidate refToNew poses
+ * (reference->getCamera().to(testCamera) of Map::multiConstantVelocityMotionModel's list, built by the caller); every try starts
+ * from the frame's initial exposure parameters; winner selection, the achieved-residual bookkeeping and the two early exits
+ * (:300-309) are the reference's.  Returns haveOneGood; *winner = index of the adopted hypothesis (-1: none), *tries = hypotheses run. */
+int orc_tracker_track_with_motion_model(orc_trk_problem* P, int n_hyp, const orc_se3* hyp, double init_a, double init_b, double last_coarse_rmse,
+                                        int failure_mode, orc_se3* best_pose, double* best_a, double* best_b, orc_trk_result* best,
+                                        double* achieved_out, int* winner, int* tries) {
+    int haveOneGood = 0;
+    orc_trk_result trackingResult, test;
+    memset(&trackingResult, 0, sizeof trackingResult);
+    trackingResult.tooManySaturated = 1;                                                  /* Residual(): isCorrect = false, tooManySaturated = true */
+    double achievedRes = DBL_MAX;
+    *winner = -1;
+    int i = 0;
+    for (; i < n_hyp; i++) {
+        orc_se3 T = hyp[i];
+        double a = init_a, b = init_b;
+        P->have_last = trackingResult.isCorrect;                                          /* mLastResidual = trackingResult, :272 */
+        for (int l = 0; l < 5; l++) P->last_rmse[l] = trackingResult.numTermsInE[l] > 0 ? trackingResult.E[l] / (double)trackingResult.numTermsInE[l] : 0.0;
+        orc_tracker_optimize(P, &T, &a, &b, &test, NULL, 0);
+        const double rm = test.numTermsInE[0] > 0 ? test.E[0] / (double)test.numTermsInE[0] : NAN;   /* rmse(): asserts numTermsInE[0] > 0 upstream */
+        if (trackingResult.tooManySaturated == 1 && test.tooManySaturated == 0 && test.isCorrect && isfinite(rm)) {   /* :280-285 */
+            haveOneGood = 1; *best_pose = T; *best_a = a; *best_b = b; trackingResult = test; *winner = i;
+        }
+        if (test.isCorrect && isfinite(rm) && !(rm >= achievedRes)) {                     /* :288-296 */
+            if (trackingResult.tooManySaturated || !test.tooManySaturated) {
+                haveOneGood = 1; *best_pose = T; *best_a = a; *best_b = b; trackingResult = test; *winner = i;
+            }
+        }
+        if (haveOneGood) {                                                                /* :299-304 */
+            if (test.numTermsInE[0] > 0 && rm < achievedRes) achievedRes = rm;
+        }
+        const float setting_reTrackThreshold = 1.5f;
+        if (haveOneGood && achievedRes < last_coarse_rmse * (double)setting_reTrackThreshold) { i++; break; }   /* :306-309 */
+        if (haveOneGood && i >= 50) { i++; break; }                                       /* :311-313 */
+    }
+    *tries = i;
+    if (!haveOneGood && (failure_mode == 1 || failure_mode == 2) && n_hyp > 0) {          /* :322-352 (mode 2 additionally overrides the camera afterwards) */
+        orc_se3 T = hyp[0];
+        double a = init_a, b = init_b;
+        P->have_last = trackingResult.isCorrect;
+        for (int l = 0; l < 5; l++) P->last_rmse[l] = trackingResult.numTermsInE[l] > 0 ? trackingResult.E[l] / (double)trackingResult.numTermsInE[l] : 0.0;
+        orc_tracker_optimize(P, &T, &a, &b, &trackingResult, NULL, 0);
+        *best_pose = T; *best_a = a; *best_b = b; *winner = 0;
+        haveOneGood = 1;
+    }
+    *best = trackingResult;
+    *achieved_out = achievedRes;
+    return haveOneGood;
 }

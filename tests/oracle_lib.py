@@ -26,6 +26,25 @@ class OrcSE3(C.Structure):
     _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3)]
 
 
+class OrcTrkStep(C.Structure):
+    _fields_ = [("level", C.c_int), ("iteration", C.c_int), ("accept", C.c_int), ("lambda_", C.c_double), ("E_new", C.c_double),
+                ("E_old", C.c_double), ("n_new", C.c_int), ("n_old", C.c_int)]
+
+
+class OrcTrkProblem(C.Structure):
+    _fields_ = [("levels", C.c_int), ("aos3", C.POINTER(C.c_float) * 5), ("w", C.c_int * 5), ("h", C.c_int * 5),
+                ("uvic", C.POINTER(C.c_float) * 5), ("n", C.c_int * 5), ("K", C.c_double * 4),
+                ("ref_a", C.c_double), ("ref_b", C.c_double), ("ref_t", C.c_double), ("new_t", C.c_double),
+                ("prm", abi.TrackerParams), ("optimize_a", C.c_int), ("optimize_b", C.c_int), ("saturated_ratio_th", C.c_double),
+                ("have_last", C.c_int), ("last_rmse", C.c_double * 5)]
+
+
+class OrcTrkResult(C.Structure):
+    _fields_ = [("isCorrect", C.c_int), ("tooManySaturated", C.c_int), ("E", C.c_double * 5), ("numTermsInE", C.c_int * 5),
+                ("numSaturated", C.c_int * 5), ("numRobust", C.c_int * 5), ("levelCutoffRepeat", C.c_double * 5),
+                ("relAff", C.c_double * 2), ("covariance", C.c_double * 6), ("flow", C.c_double * 3), ("n_steps", C.c_int)]
+
+
 class OrcFrame(C.Structure):
     _fields_ = [("w2c_eval", OrcSE3), ("state", C.c_double * 10), ("state_zero", C.c_double * 10),
                 ("state_scaled", C.c_double * 10), ("step", C.c_double * 10), ("state_backup", C.c_double * 10),
