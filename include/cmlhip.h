@@ -152,6 +152,31 @@ int cmlhip_tracker_eval(cmlhip_ctx* ctx, uint64_t new_image_id, int level,
                         const double aff[2], double b0,
                         const cmlhip_tracker_params* prm, int want_hessian,
                         cmlhip_tracker_result* out);
+/* DSOTracker::optimize (TR.cpp:15-246) resident on the device, batched over motion hypotheses: ONE launch runs the whole
+ * coarse-to-fine Levenberg-Marquardt loop of every candidate refToNew (one workgroup each) against the reference lists set by
+ * cmlhip_tracker_set_reference / _make_coarse_depth and the pyramid `new_image_id`; one readback returns every result.
+ * This is what DSOTracker::trackWithMotionModel (DSOTracker.h:238-383) runs once per hypothesis, sequentially, through
+ * 25-40 cmlhip_tracker_eval calls each.  The only coupling between the reference's tries — a try is abandoned when the rmse of a
+ * level pass exceeds 1.5 x that of the best try so far (TR.cpp:183-189) — only shortens a try: the kernel records the rmse of
+ * every level pass (pass_level / pass_rmse) and the caller applies the rule afterwards while replaying the winner selection of
+ * DSOTracker.h:262-313 (cml_amd::DSOTracker::trackWithMotionModelBatched).
+ * ref_exposure = {a, b, exposure time} of the reference, init_exposure = {a, b, exposure time} every try starts from. */
+#define CMLHIP_TRACKER_MAX_STEPS 256
+typedef struct { double R[9], t[3]; } cmlhip_tracker_hypothesis;
+typedef struct {
+    double R[9], t[3];                    /* refToNew after the last accepted step */
+    double a, b;                          /* exposure parameters of the new frame */
+    int    isCorrect, tooManySaturated;   /* TR.cpp:239-240 (the second literally carries haveGoodPoints) */
+    float  E[5]; int numTermsInE[5], numSaturated[5], numRobust[5], iterations[5];
+    double levelCutoffRepeat[5], relAff[2], covariance[6];
+    float  flow[3];
+    int    n_pass, pass_level[8]; double pass_rmse[8];   /* level passes in execution order (a level may repeat once, TR.cpp:192-195) */
+    int    n_steps; unsigned char step_level[CMLHIP_TRACKER_MAX_STEPS], step_accept[CMLHIP_TRACKER_MAX_STEPS];   /* the trials, TR.cpp:163 */
+} cmlhip_tracker_opt_result;
+int cmlhip_tracker_optimize_batch(cmlhip_ctx* ctx, uint64_t new_image_id, int levels, const double K0[4] /* level-0 fx fy cx cy */,
+                                  const double ref_exposure[3], const double init_exposure[3], const cmlhip_tracker_params* prm,
+                                  int optimize_a, int optimize_b, double saturated_ratio_threshold,
+                                  int n_hypotheses, const cmlhip_tracker_hypothesis* hypotheses, cmlhip_tracker_opt_result* results);
 /* warped buffer readback (tests): SoA rows idepth,u,v,dx,dy,residual,weight,refcolor
  * (TR.h:98-135), each numWarped long, in reference-list order. */
 int cmlhip_tracker_get_warped(cmlhip_ctx* ctx, float* out8xn, int capacity, int* n_out);

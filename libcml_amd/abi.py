@@ -40,6 +40,23 @@ class TrackerResult(C.Structure):
                 ("H", C.c_double * 64), ("b", C.c_double * 8), ("H9", C.c_float * 81)]
 
 
+TRACKER_MAX_STEPS = 256
+
+
+class TrackerHypothesis(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+
+class TrackerOptResult(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("a", C.c_double), ("b", C.c_double),
+                ("isCorrect", C.c_int), ("tooManySaturated", C.c_int),
+                ("E", C.c_float * 5), ("numTermsInE", C.c_int * 5), ("numSaturated", C.c_int * 5), ("numRobust", C.c_int * 5), ("iterations", C.c_int * 5),
+                ("levelCutoffRepeat", C.c_double * 5), ("relAff", C.c_double * 2), ("covariance", C.c_double * 6),
+                ("flow", C.c_float * 3),
+                ("n_pass", C.c_int), ("pass_level", C.c_int * 8), ("pass_rmse", C.c_double * 8),
+                ("n_steps", C.c_int), ("step_level", C.c_ubyte * TRACKER_MAX_STEPS), ("step_accept", C.c_ubyte * TRACKER_MAX_STEPS)]
+
+
 class BAParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("w", C.c_int), ("h", C.c_int), ("huber", C.c_float), ("outlier_th_sum", C.c_float),

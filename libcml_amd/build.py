@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcmlhip.so")
 HOSTLIB = os.path.join(HERE, "libcmlhost.so")
-SOURCES = ["cmlhip_ctx.hip", "ba_linearize.hip", "ba_linearize_rs.hip", "ba_linearize_rs4.hip", "ba_accumulate.hip", "ba_api.hip", "tracker.hip", "tracer.hip", "initializer.hip", "pnp.hip", "lba.hip", "reproj.hip"]
+SOURCES = ["cmlhip_ctx.hip", "ba_linearize.hip", "ba_linearize_rs.hip", "ba_linearize_rs4.hip", "ba_accumulate.hip", "ba_api.hip", "tracker.hip", "tracker_opt.hip", "tracer.hip", "initializer.hip", "pnp.hip", "lba.hip", "reproj.hip"]
 HEADERS = ["cmlhip_internal.h", "ba_common.h", "ba_finish.h", "ba_frames.h", os.path.join("..", "host", "se3.h"), os.path.join("..", "..", "include", "cmlhip.h")]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",

@@ -117,7 +117,7 @@ struct cmlhip_ctx {
     // ---------------- tracker
     DevBuf trk_ref[8]; int trk_n[8] = {0}; int trk_last_n = 0;                    // per-level uvic lists
     DevBuf trk_warped;                                        // n x 8 floats + flag
-    DevBuf trk_partial, trk_out;
+    DevBuf trk_partial, trk_out, trk_hyp, trk_opt_out;        // (trk_hyp / trk_opt_out: cmlhip_tracker_optimize_batch)
     float* trk_host = nullptr; unsigned trk_seq = 0;           // mapped, coherent host buffer: the tracker kernel writes its rows + a per-workgroup
                                                               // sequence flag straight to host memory, the caller polls (no memcpy, no stream sync)
     DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt, cd_pts;      // makeCoarseDepth scratch

@@ -1,0 +1,485 @@
+// tracker_opt.hip — DSOTracker::optimize (TR.cpp:15-246) resident on the device, batched over motion hypotheses.
+//
+// cmlhip_tracker_eval is one launch + one host round trip per Levenberg-Marquardt trial: 25-40 synchronous calls per optimize,
+// and DSOTracker::trackWithMotionModel (DSOTracker.h:238-383) runs optimize once per motion hypothesis, one after the other.
+// Here ONE workgroup runs the whole coarse-to-fine loop of one hypothesis — residual / Hessian evaluation by all 512 lanes (the
+// per-point arithmetic and the matrix-core reduction of k_tracker_eval), the 8x8 pivoted LDL^T (Eigen semantics), SE(3)
+// exponential, accept / reject and the lambda schedule on lane 0 in fp64 — and the grid is the hypothesis list: the hypotheses the
+// reference tries in sequence are evaluated speculatively side by side, one CU each, in one launch and one readback.  The only
+// coupling between the reference's tries — the abort of a try whose level rmse exceeds 1.5 x the best try's so far (TR.cpp:183-189)
+// — only shortens a try, so it is applied afterwards by the caller from the per-pass rmse values this kernel records
+// (cml_amd::DSOTracker::trackWithMotionModelBatched replays DSOTracker.h:262-313 on the results).
+#include "cmlhip_internal.h"
+#include "../host/se3.h"
+#include <cstdlib>
+
+#pragma clang fp contract(off)
+
+using cml_amd::SE3;
+
+#define TO_THREADS 512
+#define TO_WAVES (TO_THREADS / 64)
+#define TO_LD 17
+#define TO_NRED 56
+typedef float to_float4 __attribute__((ext_vector_type(4)));
+
+struct TrkOptArgs {
+    const void* img[5]; int w[5], h[5]; const float* uvic[5]; int n[5];
+    int levels, opt_a, opt_b, n_hyp;
+    double K0[4], ref_a, ref_b, ref_t, new_t, init_a, init_b, sat_th;
+    float huber, cutoff_base, scale_rot, scale_trans, scale_a, scale_b;
+    const cmlhip_tracker_hypothesis* hyp;
+    cmlhip_tracker_opt_result* out;
+};
+
+// per-evaluation constants exactly as TR.cpp:260-278,426-429 forms them (float), shared by the workgroup
+struct ToEval {
+    float RKi[9], Ki[9], t[3], fxl, fyl, cxl, cyl, a0, a1, fxh, fyh, b0, a_h, maxEnergy;
+    double huber_d, cutoff_d, cutoff_base_d;
+    int level, n, w, h;
+    const void* img; const float* uvic;
+};
+// Levenberg-Marquardt state of the hypothesis (lane 0 owns it)
+struct ToState {
+    double cur_q[4], cur_t[3], nw_q[4], nw_t[3];       // poses as plain numbers (__shared__ objects cannot have initialisers)
+    double a, b, na, nb, lambda, H[64], bv[8], Hn[64], bn[8], levelCutoffRepeat[5];
+    float E[5], E_new[5], flow[3], flow_new[3];
+    int nT[5], nS[5], nR[5], nT_new[5], nS_new[5], nR_new[5], iterations[5];
+    int ctrl, n_steps, n_pass, haveRepeated;
+};
+
+template <bool HALF>
+__device__ __forceinline__ float4 to_texel(const void* img, size_t i) {
+    if (HALF) {
+        uint2 v = reinterpret_cast<const uint2*>(img)[i];
+        __half2 a = *reinterpret_cast<__half2*>(&v.x), b = *reinterpret_cast<__half2*>(&v.y);
+        return make_float4(__low2float(a), __high2float(a), __low2float(b), 0.f);
+    }
+    return reinterpret_cast<const float4*>(img)[i];
+}
+
+// Eigen compute_inverse_size3 (cofactors * 1/det) in float, as Matrix33f::inverse() at TR.cpp:261
+__device__ void to_inv3f(const float m[9], float o[9]) {
+#define MM(i, j) m[(i) * 3 + (j)]
+#define COF(i, j) (MM(((i) + 1) % 3, ((j) + 1) % 3) * MM(((i) + 2) % 3, ((j) + 2) % 3) - MM(((i) + 1) % 3, ((j) + 2) % 3) * MM(((i) + 2) % 3, ((j) + 1) % 3))
+    const float c0 = COF(0, 0), c1 = COF(1, 0), c2 = COF(2, 0);
+    const float det = c0 * MM(0, 0) + (c1 * MM(1, 0) + c2 * MM(2, 0));
+    const float invdet = 1.0f / det;
+    o[0] = c0 * invdet; o[1] = c1 * invdet; o[2] = c2 * invdet;
+    o[3] = COF(0, 1) * invdet; o[4] = COF(1, 1) * invdet; o[5] = COF(2, 1) * invdet;
+    o[6] = COF(0, 2) * invdet; o[7] = COF(1, 2) * invdet; o[8] = COF(2, 2) * invdet;
+#undef COF
+#undef MM
+}
+
+// x = A.ldlt().solve(b), Eigen 3.4.0 semantics (Cholesky/LDLT.h:300-396,560-600), n <= 8 — the host mirror's ldltSolveSmall
+// (lane 0 runs these alone: every array is an LDS scratchpad — a dynamically indexed local array would live in scratch memory,
+//  hundreds of cycles per dependent access)
+__device__ bool to_ldlt_solve(const double* Ain, const double* b, int n, double* x, double* A /* 64 */, double* temp /* 8 */, int* tr /* 8 */) {
+    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
+#define M(i, j) A[(i) * n + (j)]
+    if (n == 1) tr[0] = 0;
+    else
+        for (int k = 0; k < n; k++) {
+            int big = k; double best = fabs(M(k, k));
+            for (int i = k + 1; i < n; i++) if (fabs(M(i, i)) > best) { best = fabs(M(i, i)); big = i; }
+            tr[k] = big;
+            if (k != big) {
+                for (int j = 0; j < k; j++) { const double s = M(k, j); M(k, j) = M(big, j); M(big, j) = s; }
+                for (int i = big + 1; i < n; i++) { const double s = M(i, k); M(i, k) = M(i, big); M(i, big) = s; }
+                { const double s = M(k, k); M(k, k) = M(big, big); M(big, big) = s; }
+                for (int i = k + 1; i < big; i++) { const double s = M(i, k); M(i, k) = M(big, i); M(big, i) = s; }
+            }
+            if (k > 0) {
+                double s = 0;
+                for (int j = 0; j < k; j++) { temp[j] = M(j, j) * M(k, j); s += M(k, j) * temp[j]; }
+                M(k, k) -= s;
+                for (int i = k + 1; i < n; i++) { double s2 = 0; for (int j = 0; j < k; j++) s2 += M(i, j) * temp[j]; M(i, k) -= s2; }
+            }
+            const double akk = M(k, k);
+            if (k == 0 && !(fabs(akk) > 0.0)) { for (int j = 0; j < n; j++) tr[j] = j; break; }
+            if (fabs(akk) > 0.0) for (int i = k + 1; i < n; i++) M(i, k) /= akk;
+        }
+    for (int i = 0; i < n; i++) x[i] = b[i];
+    for (int k = 0; k < n; k++) if (tr[k] != k) { const double s = x[k]; x[k] = x[tr[k]]; x[tr[k]] = s; }
+    for (int i = 0; i < n; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= M(i, j) * x[j]; x[i] = s; }
+    for (int i = 0; i < n; i++) x[i] = (fabs(M(i, i)) > 2.2250738585072014e-308) ? x[i] / M(i, i) : 0.0;
+    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < n; j++) s -= M(j, i) * x[j]; x[i] = s; }
+    for (int k = n - 1; k >= 0; k--) if (tr[k] != k) { const double s = x[k]; x[k] = x[tr[k]]; x[tr[k]] = s; }
+#undef M
+    for (int i = 0; i < n; i++) if (!isfinite(x[i])) return false;
+    return true;
+}
+__device__ void to_inverse8(const double* Ain, double* Ai, double* A /* 64 */) {           // hessian.inverse() (TR.cpp:243): Gauss-Jordan with partial pivoting
+    const int n = 8;
+    for (int i = 0; i < 64; i++) { A[i] = Ain[i]; Ai[i] = (i / 8 == i % 8) ? 1.0 : 0.0; }
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        for (int i = k + 1; i < n; i++) if (fabs(A[i * n + k]) > fabs(A[p * n + k])) p = i;
+        if (p != k) for (int j = 0; j < n; j++) { double s = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = s; s = Ai[k * n + j]; Ai[k * n + j] = Ai[p * n + j]; Ai[p * n + j] = s; }
+        const double d = A[k * n + k];
+        for (int j = 0; j < n; j++) { A[k * n + j] /= d; Ai[k * n + j] /= d; }
+        for (int i = 0; i < n; i++)
+            if (i != k) {
+                const double f = A[i * n + k];
+                if (f != 0) for (int j = 0; j < n; j++) { A[i * n + j] -= f * A[k * n + j]; Ai[i * n + j] -= f * Ai[k * n + j]; }
+            }
+    }
+}
+
+// lane 0: the constants of one evaluation (TR.cpp:260-278, 426-429; InternalCalibration.h:116-127; Exposure.h:119-123)
+__device__ __forceinline__ SE3 to_pose(const double q[4], const double t[3]) {
+    SE3 T;
+    for (int i = 0; i < 4; i++) T.q[i] = q[i];
+    for (int i = 0; i < 3; i++) T.t[i] = t[i];
+    return T;
+}
+__device__ __forceinline__ void to_store(const SE3& T, double q[4], double t[3]) {
+    for (int i = 0; i < 4; i++) q[i] = T.q[i];
+    for (int i = 0; i < 3; i++) t[i] = T.t[i];
+}
+__device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3& T, double a, double b, double cutoff_mult) {
+    const double d = (double)(1 << level);
+    const double K[4] = {A.K0[0] / d, A.K0[1] / d, (A.K0[2] + 0.5) / d - 0.5, (A.K0[3] + 0.5) / d - 0.5};
+    double R[9];
+    T.matrix(R);
+    const double affA = exp(a - A.ref_a) * A.new_t / A.ref_t, affB = b - affA * A.ref_b;      // reference->getExposure().to(exposure)
+    float Kf[9] = {(float)K[0], 0, (float)K[2], 0, (float)K[1], (float)K[3], 0, 0, 1}, Rf[9];
+    to_inv3f(Kf, ev.Ki);
+    for (int i = 0; i < 9; i++) Rf[i] = (float)R[i];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) ev.RKi[i * 3 + j] = Rf[i * 3] * ev.Ki[j] + (Rf[i * 3 + 1] * ev.Ki[3 + j] + Rf[i * 3 + 2] * ev.Ki[6 + j]);   // Matrix33f product, Eigen order
+    for (int i = 0; i < 3; i++) ev.t[i] = (float)T.t[i];
+    ev.fxl = Kf[0]; ev.fyl = Kf[4]; ev.cxl = Kf[2]; ev.cyl = Kf[5];
+    ev.a0 = (float)affA; ev.a1 = (float)affB;
+    ev.fxh = (float)K[0]; ev.fyh = (float)K[1]; ev.b0 = (float)A.ref_b; ev.a_h = (float)affA;
+    const float cutoff = (float)((double)A.cutoff_base * cutoff_mult);                      // mCutoffThreshold.f() * levelCutoffRepeat[level]
+    ev.huber_d = (double)A.huber; ev.cutoff_d = (double)cutoff; ev.cutoff_base_d = (double)A.cutoff_base;
+    ev.maxEnergy = (float)(2.0f * ev.huber_d * ev.cutoff_d - ev.huber_d * ev.huber_d);
+    ev.level = level; ev.n = A.n[level]; ev.w = A.w[level]; ev.h = A.h[level]; ev.img = A.img[level]; ev.uvic = A.uvic[level];
+}
+
+// all lanes: computeResidual + computeHessian over the level's list (the per-point arithmetic and the reduction layout of
+// k_tracker_eval, tracker.hip); leaves the 56 sums in s_red
+template <bool HALF>
+__device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red) {
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    to_float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < E.n; base += TO_THREADS) {
+        const int i = base + tid;
+        float va[16], vb[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { va[k] = 0.f; vb[k] = 0.f; }
+        if (i < E.n) {
+            va[9] = 1.f; vb[9] = 1.f;
+            const float4 q = reinterpret_cast<const float4*>(E.uvic)[i];
+            const float x = q.x, y = q.y, id = q.z, refColor = q.w;
+            if (isfinite(refColor)) {                                           // TR.cpp:301-303
+                float pt[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) pt[k] = (E.RKi[k * 3] * x + (E.RKi[k * 3 + 1] * y + E.RKi[k * 3 + 2] * 1.0f)) + E.t[k] * id;
+                const float u = pt[0] / pt[2], vv = pt[1] / pt[2];
+                const float Ku = E.fxl * u + E.cxl, Kv = E.fyl * vv + E.cyl;
+                const float new_idepth = id / pt[2];
+                if (E.level == 0 && (i % 32) == 0) {                           // flow statistic, TR.cpp:313-344
+                    float a[3], b[3], c[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const float kp = E.Ki[k * 3] * x + (E.Ki[k * 3 + 1] * y + E.Ki[k * 3 + 2] * 1.0f);
+                        a[k] = kp + E.t[k] * id; b[k] = kp - E.t[k] * id;
+                        c[k] = (E.RKi[k * 3] * x + (E.RKi[k * 3 + 1] * y + E.RKi[k * 3 + 2] * 1.0f)) - E.t[k] * id;
+                    }
+                    const float KuT = E.fxl * (a[0] / a[2]) + E.cxl, KvT = E.fyl * (a[1] / a[2]) + E.cyl;
+                    const float KuT2 = E.fxl * (b[0] / b[2]) + E.cxl, KvT2 = E.fyl * (b[1] / b[2]) + E.cyl;
+                    const float Ku3 = E.fxl * (c[0] / c[2]) + E.cxl, Kv3 = E.fyl * (c[1] / c[2]) + E.cyl;
+                    float sT = 0, sRT = 0;
+                    sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+                    sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+                    sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+                    sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+                    vb[11] = sT; vb[12] = sRT; vb[13] = 2.f;
+                }
+                if (Ku > 2 && Kv > 2 && Ku < E.w - 3 && Kv < E.h - 3 && new_idepth > 0) {     // TR.cpp:346
+                    const int ix = (int)Ku, iy = (int)Kv;
+                    const float dx = Ku - (float)ix, dy = Kv - (float)iy, dxdy = dx * dy;
+                    const float w00 = 1 - dx - dy + dxdy, w01 = dx - dxdy, w10 = dy - dxdy, w11 = dxdy;
+                    const size_t i1 = (size_t)iy * E.w + ix;
+                    const float4 ta = to_texel<HALF>(E.img, i1), tb = to_texel<HALF>(E.img, i1 + 1);
+                    const float4 tc = to_texel<HALF>(E.img, i1 + E.w), td = to_texel<HALF>(E.img, i1 + E.w + 1);
+                    const float h0 = ta.x * w00 + tb.x * w01 + tc.x * w10 + td.x * w11;
+                    const float h1 = ta.y * w00 + tb.y * w01 + tc.y * w10 + td.y * w11;
+                    const float h2 = ta.z * w00 + tb.z * w01 + tc.z * w10 + td.z * w11;
+                    if (isfinite(h0) && isfinite(h1) && isfinite(h2)) {
+                        const float residual = h0 - (float)(E.a0 * refColor + E.a1);
+                        const float hw = fabs((double)residual) < E.huber_d ? 1.0f : (float)(E.huber_d / fabs((double)residual));
+                        if (fabs((double)residual) > E.cutoff_d) {
+                            vb[10] = E.maxEnergy; vb[14] = 1.f; vb[15] = 1.f;                  // E, numTerms, numSaturated
+                        } else {
+                            vb[10] = hw * residual * residual * (2 - hw); vb[14] = 1.f; va[11] = 1.f;   // E, numTerms, numWarped
+                            const float ddx = h1 * E.fxh, ddy = h2 * E.fyh;                      // computeHessian lanes, TR.cpp:443-470
+                            vb[0] = new_idepth * ddx;
+                            vb[1] = new_idepth * ddy;
+                            vb[2] = 0.0f - (new_idepth * (u * ddx + vv * ddy));
+                            vb[3] = 0.0f - ((u * vv * ddx) + ddy * (1.0f + vv * vv));
+                            vb[4] = (u * vv * ddy) + (ddx * (1.0f + u * u));
+                            vb[5] = u * ddy - vv * ddx;
+                            vb[6] = E.a_h * (E.b0 - refColor);
+                            vb[7] = -1.0f;
+                            vb[8] = residual;
+#pragma unroll
+                            for (int r = 0; r < 9; r++) va[r] = vb[r] * hw;
+                        }
+                        if (fabs((double)residual) <= E.cutoff_base_d) va[10] = 1.f;           // numRobust
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { s_a[wv][l][k] = va[k]; s_b[wv][l][k] = vb[k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // wave-private tiles, in-order LDS: compiler ordering only
+        __builtin_amdgcn_wave_barrier();
+        const int e = l & 15, kq = l >> 4;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const float av = s_a[wv][4 * m + kq][e], bv = s_b[wv][4 * m + kq][e];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) s_tile[wv][(4 * (l >> 4) + rg) * 16 + (l & 15)] = acc[rg];
+    __syncthreads();
+    if (tid < TO_NRED) {
+        int src = -1;
+        if (tid < 45) {
+            int k = tid, r = 0;
+            while (k >= 9 - r) { k -= 9 - r; r++; }
+            src = r * 16 + (r + k);
+        } else if (tid <= 50) src = 9 * 16 + 10 + (tid - 45);          // E sT sRT sN numTerms numSaturated
+        else if (tid == 51) src = 10 * 16 + 9;                          // numRobust
+        else if (tid == 52) src = 11 * 16 + 9;                          // numWarped
+        float v = 0.f;
+        if (src >= 0) for (int w = 0; w < TO_WAVES; w++) v += s_tile[w][src];
+        s_red[tid] = v;
+    }
+    __syncthreads();
+}
+
+// lane 0: the level's sums -> Residual slots and the scaled 8x8 system (TR.cpp:405-414, 472-490)
+__device__ void to_finish(const TrkOptArgs& A, const float* s, float& E, int& nT, int& nS, int& nR, float flow[3], double* H, double* b, float* H9 /* 81, LDS */) {
+    E = s[45]; nT = (int)s[49]; nS = (int)s[50]; nR = (int)s[51];
+    const int numWarped = (int)s[52];
+    flow[0] = s[46] / (s[48] + 0.1f); flow[1] = 0; flow[2] = s[47] / (s[48] + 0.1f);
+    int idx = 0;
+    for (int r = 0; r < 9; r++) for (int cc = r; cc < 9; cc++) { H9[r * 9 + cc] = H9[cc * 9 + r] = s[idx]; idx++; }
+    int npad = numWarped;
+    while (npad % 4 != 0) npad++;
+    const double sc[8] = {A.scale_rot, A.scale_rot, A.scale_rot, A.scale_trans, A.scale_trans, A.scale_trans, A.scale_a, A.scale_b};
+    for (int r = 0; r < 8; r++) {
+        for (int cc = 0; cc < 8; cc++) H[r * 8 + cc] = ((double)H9[r * 9 + cc] / (double)npad) * sc[cc] * sc[r];
+        b[r] = ((double)H9[r * 9 + 8] / (double)npad) * sc[r];
+    }
+}
+
+// lane 0's decision to every lane: read between two barriers, so that lane 0 may overwrite it right away
+__device__ __forceinline__ int to_ctrl(const ToState& S) {
+    __syncthreads();
+    const int c = S.ctrl;
+    __syncthreads();
+    return c;
+}
+
+enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
+
+template <bool HALF>
+__global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
+    __shared__ float s_a[TO_WAVES][64][TO_LD], s_b[TO_WAVES][64][TO_LD];
+    __shared__ float s_tile[TO_WAVES][256];
+    __shared__ float s_red[64];
+    __shared__ ToEval ev;
+    __shared__ ToState S;
+    __shared__ double s_wA[64], s_wD[64], s_wS[64], s_wt[8], s_wx[8], s_wn[8], s_wb[8], s_winc[8], s_wincS[8];   // lane 0's scratchpads
+    __shared__ int s_wtr[8];
+    __shared__ float s_wH9[81];
+    const int tid = threadIdx.x, hyp = blockIdx.x;
+    cmlhip_tracker_opt_result* out = A.out + hyp;
+    const int maxIterations[5] = {10, 20, 50, 50, 50};                               // TR.cpp:23
+    const int maxLevel = min(A.levels - 1, 4);
+    if (tid == 0) {
+        to_store(SE3::fromRt(A.hyp[hyp].R, A.hyp[hyp].t), S.cur_q, S.cur_t);
+        S.a = A.init_a; S.b = A.init_b;
+        for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l] = 0; S.nT[l] = S.nS[l] = S.nR[l] = S.nT_new[l] = S.nS_new[l] = S.nR_new[l] = 0; S.levelCutoffRepeat[l] = 0; S.iterations[l] = 0; }
+        for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k] = 0;
+        S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl = TO_CONTINUE;
+    }
+    __syncthreads();
+    bool failed = false;
+    for (int level = maxLevel; level >= 0 && !failed; level--) {
+        // ---- initial evaluation of the level (+ the saturation repeat, TR.cpp:61-81)
+        if (tid == 0) { S.levelCutoffRepeat[level] = 1; to_prepare(A, ev, level, to_pose(S.cur_q, S.cur_t), S.a, S.b, 1.0); }
+        __syncthreads();
+        while (true) {
+            to_eval<HALF>(ev, s_a, s_b, s_tile, s_red);
+            if (tid == 0) {
+                to_finish(A, s_red, S.E[level], S.nT[level], S.nS[level], S.nR[level], S.flow, S.H, S.bv, s_wH9);
+                int c = TO_ITERATE;
+                if (S.nT[level] < 20) c = TO_FAIL;                                                           // :65-69
+                else if ((S.nS[level] / (double)S.nT[level]) > 0.6 && S.levelCutoffRepeat[level] < 50) {     // :71-75
+                    S.levelCutoffRepeat[level] *= 2;
+                    to_prepare(A, ev, level, to_pose(S.cur_q, S.cur_t), S.a, S.b, S.levelCutoffRepeat[level]);
+                    c = TO_REPEAT_SAT;
+                } else if (S.nT[level] - S.nS[level] < 10) c = TO_FAIL;                                      // :77-81
+                S.ctrl = c; S.lambda = 0.01;
+            }
+            const int c0 = to_ctrl(S);
+            if (c0 != TO_REPEAT_SAT) { if (c0 == TO_FAIL) failed = true; break; }
+        }
+        if (failed) break;
+        // ---- Levenberg-Marquardt trials, TR.cpp:91-181
+        for (int iteration = 0; iteration < maxIterations[level]; iteration++) {
+            if (tid == 0) {
+                S.iterations[level] = iteration + 1;
+                double* D = s_wD; double* inc = s_winc; double* nbv = s_wn;
+                for (int i = 0; i < 8; i++) inc[i] = 0;
+                for (int i = 0; i < 64; i++) D[i] = S.H[i];
+                for (int i = 0; i < 8; i++) { D[i * 8 + i] *= (1 + S.lambda); nbv[i] = -S.bv[i]; }
+                bool ok = true;
+                if (A.opt_a && A.opt_b) ok = to_ldlt_solve(D, nbv, 8, inc, s_wA, s_wt, s_wtr);                // :96-98
+                else if (A.opt_a && !A.opt_b) {                                                             // :99-102
+                    double* Sm = s_wS; double* x7 = s_wx;
+                    for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) Sm[i * 7 + j] = D[i * 8 + j];
+                    ok = to_ldlt_solve(Sm, nbv, 7, x7, s_wA, s_wt, s_wtr);
+                    for (int i = 0; i < 7; i++) inc[i] = x7[i];
+                    inc[7] = 0;
+                } else if (!A.opt_a && A.opt_b) {                                                           // :103-114
+                    double* Sm = s_wS; double* x7 = s_wx; double* nb7 = s_wb;
+                    // HlStitch: column 6 <- column 7, row 6 <- row 7 of the damped system, bStitch[6] = b[7]; only its top-left 7x7 is solved
+                    for (int i = 0; i < 7; i++)
+                        for (int j = 0; j < 7; j++) Sm[i * 7 + j] = D[(i == 6 ? 7 : i) * 8 + (j == 6 ? 7 : j)];
+                    for (int i = 0; i < 7; i++) nb7[i] = -(i == 6 ? S.bv[7] : S.bv[i]);
+                    ok = to_ldlt_solve(Sm, nb7, 7, x7, s_wA, s_wt, s_wtr);
+                    for (int i = 0; i < 6; i++) inc[i] = x7[i];
+                    inc[6] = 0; inc[7] = x7[6];
+                } else {                                                                                    // :115-119
+                    double* Sm = s_wS; double* x6 = s_wx;
+                    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Sm[i * 6 + j] = D[i * 8 + j];
+                    ok = to_ldlt_solve(Sm, nbv, 6, x6, s_wA, s_wt, s_wtr);
+                    for (int i = 0; i < 6; i++) inc[i] = x6[i];
+                }
+                if (!ok) S.ctrl = TO_FAIL;                                                                  // :121-138
+                else {
+                    double extrapFac = 1;
+                    if (S.lambda < 0.001) extrapFac = sqrt(sqrt(0.001 / S.lambda));                         // :140-142
+                    double* incS = s_wincS; double nrm = 0;
+                    for (int i = 0; i < 8; i++) { inc[i] *= extrapFac; incS[i] = inc[i]; nrm += inc[i] * inc[i]; }
+                    for (int i = 0; i < 3; i++) { incS[i] *= (double)A.scale_rot; incS[3 + i] *= (double)A.scale_trans; }   // the literal lane / scale pairing, :144-148
+                    incS[6] *= (double)A.scale_a; incS[7] *= (double)A.scale_b;
+                    const SE3 nw = SE3::exp(incS) * to_pose(S.cur_q, S.cur_t);                              // :155-157
+                    to_store(nw, S.nw_q, S.nw_t);
+                    S.na = S.a + incS[6]; S.nb = S.b + incS[7];                                             // :159
+                    S.Hn[0] = sqrt(nrm);                                                                    // |increment| parked for the exit test below
+                    to_prepare(A, ev, level, nw, S.na, S.nb, S.levelCutoffRepeat[level]);
+                    S.ctrl = TO_ITERATE;
+                }
+            }
+            if (to_ctrl(S) == TO_FAIL) { failed = true; break; }
+            to_eval<HALF>(ev, s_a, s_b, s_tile, s_red);
+            if (tid == 0) {
+                const double incnorm = S.Hn[0];
+                to_finish(A, s_red, S.E_new[level], S.nT_new[level], S.nS_new[level], S.nR_new[level], S.flow_new, S.Hn, S.bn, s_wH9);
+                const bool accept = (S.E_new[level] / (double)S.nT_new[level]) < (S.E[level] / (double)S.nT[level]);   // :163
+                if (S.n_steps < CMLHIP_TRACKER_MAX_STEPS) { out->step_level[S.n_steps] = (unsigned char)level; out->step_accept[S.n_steps] = accept ? 1 : 0; }
+                S.n_steps++;
+                if (accept) {
+                    for (int i = 0; i < 64; i++) S.H[i] = S.Hn[i];
+                    for (int i = 0; i < 8; i++) S.bv[i] = S.bn[i];
+                    for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l]; S.nT[l] = S.nT_new[l]; S.nS[l] = S.nS_new[l]; S.nR[l] = S.nR_new[l]; }   // oldResidual = newResidual (whole struct), :167
+                    for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k];
+                    for (int i = 0; i < 4; i++) S.cur_q[i] = S.nw_q[i];
+                    for (int i = 0; i < 3; i++) S.cur_t[i] = S.nw_t[i];
+                    S.a = S.na; S.b = S.nb;
+                    S.lambda *= 0.5;
+                } else {
+                    S.lambda *= 4;
+                }
+                S.ctrl = (incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE;                                     // :176-179
+            }
+            if (to_ctrl(S) == TO_LEVEL_DONE) break;
+        }
+        if (failed) break;
+        if (tid == 0) {
+            // the rmse of the pass: what TR.cpp:183-189 compares with 1.5 x the previous correct try's (applied by the caller)
+            if (S.n_pass < 8) { out->pass_level[S.n_pass] = level; out->pass_rmse[S.n_pass] = S.E[level] / (double)S.nT[level]; }
+            S.n_pass++;
+            S.ctrl = (S.levelCutoffRepeat[level] > 1 && !S.haveRepeated) ? 1 : 0;                           // :192-195
+            if (S.ctrl) S.haveRepeated = 1;
+        }
+        if (to_ctrl(S)) level++;
+    }
+    if (tid == 0) {
+        double R[9];
+        to_pose(S.cur_q, S.cur_t).matrix(R);
+        for (int i = 0; i < 9; i++) out->R[i] = R[i];
+        for (int i = 0; i < 3; i++) out->t[i] = S.cur_t[i];
+        out->a = S.a; out->b = S.b;
+        for (int l = 0; l < 5; l++) {
+            out->E[l] = S.E[l]; out->numTermsInE[l] = S.nT[l]; out->numSaturated[l] = S.nS[l]; out->numRobust[l] = S.nR[l];
+            out->levelCutoffRepeat[l] = S.levelCutoffRepeat[l]; out->iterations[l] = S.iterations[l];
+        }
+        for (int k = 0; k < 3; k++) out->flow[k] = S.flow[k];
+        out->n_steps = S.n_steps; out->n_pass = S.n_pass < 8 ? S.n_pass : 8;
+        for (int k = 0; k < 6; k++) out->covariance[k] = 999999;
+        out->relAff[0] = out->relAff[1] = 0;
+        if (failed) {
+            out->isCorrect = 0; out->tooManySaturated = 1;
+        } else {
+            const double relA = exp(S.a - A.ref_a) * A.new_t / A.ref_t, relB = S.b - relA * A.ref_b;        // :203
+            bool haveGoodLight = true;
+            if (A.opt_a) { if (fabs(S.a) > 1.2) haveGoodLight = false; }
+            else if (fabs(logf((float)relA)) > 1.5) haveGoodLight = false;
+            if (A.opt_b) { if (fabs(S.b) > 200) haveGoodLight = false; }
+            else if (fabs((float)relB) > 200) haveGoodLight = false;
+            bool haveGoodPoints = true;
+            if ((double)S.nS[0] / (double)S.nT[0] > A.sat_th) haveGoodPoints = false;                       // :231-235
+            out->isCorrect = haveGoodLight ? 1 : 0;
+            out->tooManySaturated = haveGoodPoints ? 1 : 0;                                                 // sic, :240
+            out->relAff[0] = relA; out->relAff[1] = relB;
+            double* Hi = s_wD;
+            to_inverse8(S.H, Hi, s_wA);                                                                     // :243
+            for (int k = 0; k < 6; k++) out->covariance[k] = Hi[k * 8 + k];
+        }
+    }
+}
+
+extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, int levels, const double K0[4], const double ref_exposure[3],
+                                             const double init_exposure[3], const cmlhip_tracker_params* prm, int optimize_a, int optimize_b,
+                                             double saturated_ratio_th, int n_hyp, const cmlhip_tracker_hypothesis* hyp,
+                                             cmlhip_tracker_opt_result* out) { CML_DEV(c);
+    if (!c || !K0 || !ref_exposure || !init_exposure || !prm || n_hyp < 0 || (n_hyp > 0 && (!hyp || !out)) || levels < 1) return CMLHIP_ERR_INVALID;
+    if (n_hyp == 0) return CMLHIP_OK;
+    const Pyramid* py = cml_find_pyr(c, image_id);
+    CML_REQUIRE(c, py && py->levels >= 1, CMLHIP_ERR_NOT_FOUND, "tracker image not in the pyramid cache");
+    TrkOptArgs A;
+    memset(&A, 0, sizeof A);
+    A.levels = std::min(levels, std::min(py->levels, 5));
+    for (int l = 0; l < A.levels; l++) {
+        CML_REQUIRE(c, py->lv[l].grad, CMLHIP_ERR_NOT_FOUND, "tracker level not in the pyramid cache");
+        A.img[l] = py->lv[l].grad; A.w[l] = py->lv[l].w; A.h[l] = py->lv[l].h;
+        A.uvic[l] = c->trk_ref[l].as<float>(); A.n[l] = c->trk_n[l];
+    }
+    for (int k = 0; k < 4; k++) A.K0[k] = K0[k];
+    A.ref_a = ref_exposure[0]; A.ref_b = ref_exposure[1]; A.ref_t = ref_exposure[2];
+    A.init_a = init_exposure[0]; A.init_b = init_exposure[1]; A.new_t = init_exposure[2];
+    A.huber = prm->huber; A.cutoff_base = prm->cutoff_base; A.scale_rot = prm->scale_rot; A.scale_trans = prm->scale_trans;
+    A.scale_a = prm->scale_a; A.scale_b = prm->scale_b;
+    A.opt_a = optimize_a; A.opt_b = optimize_b; A.sat_th = saturated_ratio_th; A.n_hyp = n_hyp;
+    int rc;
+    if ((rc = cml_ensure(c, c->trk_hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
+    if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp))) return rc;
+    if ((rc = cml_h2d(c, c->trk_hyp.p, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
+    A.hyp = c->trk_hyp.as<cmlhip_tracker_hypothesis>(); A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_tracker_optimize<true><<<n_hyp, TO_THREADS, 0, c->stream>>>(A);
+    else k_tracker_optimize<false><<<n_hyp, TO_THREADS, 0, c->stream>>>(A);
+    CML_CHECK(c, hipGetLastError());
+    return cml_d2h(c, out, c->trk_opt_out.p, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
+}

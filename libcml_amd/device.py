@@ -39,6 +39,8 @@ PROTOTYPES = {
     "cmlhip_tracker_eval": (C.c_int, [_ctx, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(_d), _d,
                                       _P(abi.TrackerParams), _i, _P(abi.TrackerResult)]),
     "cmlhip_tracker_get_warped": (C.c_int, [_ctx, _P(_f), _i, _P(_i)]),
+    "cmlhip_tracker_optimize_batch": (C.c_int, [_ctx, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(abi.TrackerParams), _i, _i, _d, _i,
+                                                _P(abi.TrackerHypothesis), _P(abi.TrackerOptResult)]),
     "cmlhip_ba_set_params": (C.c_int, [_ctx, _P(abi.BAParams)]),
     "cmlhip_ba_upload_window": (C.c_int, [_ctx, _i, _P(abi.BAFrame), _i, _P(abi.BAPoint), _i, _P(abi.BAResidual)]),
     "cmlhip_ba_set_pairs": (C.c_int, [_ctx, _P(abi.BAPair)]),
@@ -361,6 +363,22 @@ class Ctx:
         rc = self.ck(self.L.cmlhip_tracker_eval(self.h, image_id, level, _p(R, _d), _p(t, _d), _p(K, _d), _p(aff, _d), b0,
                                                 C.byref(prm), want_hessian, C.byref(out)), allow=(abi.ERR_NONFINITE,))
         return out, rc
+
+    def tracker_optimize_batch(self, image_id, levels, K0, ref_exp, init_exp, prm, hyps, optimize_a=1, optimize_b=1, sat_th=0.33):
+        """hyps: list of (R, t).  Returns a list of abi.TrackerOptResult."""
+        n = len(hyps)
+        H = (abi.TrackerHypothesis * max(n, 1))()
+        for i, (R, t) in enumerate(hyps):
+            Rr = np.asarray(R, np.float64).ravel()
+            for k in range(9):
+                H[i].R[k] = Rr[k]
+            for k in range(3):
+                H[i].t[k] = float(t[k])
+        out = (abi.TrackerOptResult * max(n, 1))()
+        K = np.ascontiguousarray(K0, np.float64); re = np.ascontiguousarray(ref_exp, np.float64); ie = np.ascontiguousarray(init_exp, np.float64)
+        self.ck(self.L.cmlhip_tracker_optimize_batch(self.h, C.c_uint64(int(image_id)), int(levels), _p(K, _d), _p(re, _d), _p(ie, _d), C.byref(prm),
+                                                     int(optimize_a), int(optimize_b), C.c_double(sat_th), n, H, out))
+        return [out[i] for i in range(n)]
 
     def tracker_get_warped(self, capacity):
         out = np.zeros((8, capacity), np.float32)

@@ -69,7 +69,7 @@ def lib():
         L.cmlhost_tracker_steps.argtypes = [_vp, _i, _P(_i), _P(_i), _P(_i), _P(_d)]
         L.cmlhost_tracker_set_last_residual.argtypes = [_vp, _i, _i, _P(_d)]
         L.cmlhost_tracker_track_with_motion_model.argtypes = [_vp, C.c_uint64, _i, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_i), _P(_i),
-                                                              _P(_i), _P(_i), _P(_i), _P(_i), _P(_d)]
+                                                              _P(_i), _P(_i), _P(_i), _P(_i), _P(_d), _i]
         L.cmlhost_tracer_create.restype = _vp; L.cmlhost_tracer_create.argtypes = [_vp]
         L.cmlhost_tracer_destroy.argtypes = [_vp]
         L.cmlhost_tracer_add_point.argtypes = [_vp, _f, _f, _i, _P(_f), _P(_f), _P(_d), _f]
@@ -302,7 +302,7 @@ class HostTracker:
         r = np.ascontiguousarray(rmse, np.float64)
         self.L.cmlhost_tracker_set_last_residual(self.h, int(is_correct), len(r), _p(r, _d))
 
-    def track_with_motion_model(self, new_image, levels, hyps, ref_exp, init_exp):
+    def track_with_motion_model(self, new_image, levels, hyps, ref_exp, init_exp, batched=False):
         """hyps: list of (R, t) refToNew candidates.  Returns the adopted try (DSOTracker.h:238-383)."""
         H = np.zeros((len(hyps), 12))
         for i, (R, t) in enumerate(hyps):
@@ -313,7 +313,7 @@ class HostTracker:
         lcr = _d()
         good = self.L.cmlhost_tracker_track_with_motion_model(self.h, int(new_image), levels, len(hyps), _p(H, _d), _p(re, _d), _p(ie, _d), _p(R, _d), _p(t, _d),
                                                               _p(oe, _d), _p(E, _d), _p(nt, _i), _p(ns, _i), C.byref(ok), C.byref(sat), C.byref(win),
-                                                              C.byref(tries), C.byref(lcr))
+                                                              C.byref(tries), C.byref(lcr), int(batched))
         return dict(haveOneGood=bool(good), R=R.reshape(3, 3), t=t, exposure=oe, E=E, numTerms=nt, numSat=ns, isCorrect=bool(ok.value),
                     tooManySaturated=bool(sat.value), winner=win.value, tries=tries.value, lastCoarseRMSE=lcr.value)
 

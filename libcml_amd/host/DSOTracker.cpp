@@ -251,4 +251,100 @@ bool DSOTracker::trackWithMotionModel(uint64_t new_image_id, int pyramidLevels, 
     return haveOneGood;
 }
 
+bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
+                                             const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
+                                             int* winner, int* tries) {
+    residual = Residual();
+    if (winner) *winner = -1;
+    if (tries) *tries = 0;
+    if (n_hyp <= 0) return false;
+    std::vector<cmlhip_tracker_hypothesis> H(n_hyp);
+    std::vector<cmlhip_tracker_opt_result> R(n_hyp);
+    for (int i = 0; i < n_hyp; i++) { hyp[i].matrix(H[i].R); std::memcpy(H[i].t, hyp[i].t, sizeof H[i].t); }
+    cmlhip_tracker_params prm;
+    prm.huber = (float)mHuberThreshold; prm.cutoff_base = (float)mCutoffThreshold; prm.cutoff = prm.cutoff_base;
+    prm.scale_rot = (float)mScaleRotation; prm.scale_trans = (float)mScaleTranslation; prm.scale_a = (float)mScaleLightA; prm.scale_b = (float)mScaleLightB;
+    int levels = std::min(pyramidLevels, 5);
+    if (maxLevelOverride >= 0) levels = std::min(levels, maxLevelOverride + 1);
+    const double refE[3] = {referenceExposure.a, referenceExposure.b, referenceExposure.t}, initE[3] = {initialExposure.a, initialExposure.b, initialExposure.t};
+    // Policy (measured, tools/probe_tracker_opt.py): one workgroup per hypothesis makes a launch cost ~1 ms whatever the number of
+    // hypotheses, a host-driven optimize ~0.3 ms.  In steady tracking the FIRST hypothesis passes the early exit of :306-309, so it
+    // is tried alone through the host-driven loop; only when it does not end the search are the remaining ones run side by side.
+    {
+        SE3 T0 = hyp[0];
+        Exposure e0 = initialExposure;
+        mLastResidual = Residual();
+        const Residual r0 = optimize(new_image_id, pyramidLevels, T0, referenceExposure, e0);
+        const double rm0 = (!r0.numTermsInE.empty() && r0.numTermsInE[0] > 0) ? r0.rmse() : std::numeric_limits<double>::quiet_NaN();
+        const bool good0 = r0.isCorrect && std::isfinite(rm0);                              // the two adoption tests of :280-296 on an empty history
+        if (n_hyp == 1 || (good0 && rm0 < mLastCoarseRMSE * 1.5f)) {
+            if (winner) *winner = good0 ? 0 : -1;
+            if (tries) *tries = 1;
+            if (good0) { bestRefToNew = T0; bestExposure = e0; residual = r0; mLastCoarseRMSE = rm0; return true; }
+            if (n_hyp == 1 && !(mFailureMode == 1 || mFailureMode == 2)) return false;
+        }
+    }
+    const int rc = cmlhip_tracker_optimize_batch(mCtx, new_image_id, levels, mK, refE, initE, &prm, mOptimizeA ? 1 : 0, mOptimizeB ? 1 : 0,
+                                                 mSaturatedRatioThreshold, n_hyp, H.data(), R.data());
+    if (rc) { mError = std::string("cmlhip_tracker_optimize_batch: ") + cmlhip_last_error(mCtx); return false; }
+    auto toResidual = [&](const cmlhip_tracker_opt_result& r) {
+        Residual o;
+        o.E.assign(r.E, r.E + levels); o.numTermsInE.assign(r.numTermsInE, r.numTermsInE + levels); o.numSaturated.assign(r.numSaturated, r.numSaturated + levels);
+        o.numRobust.assign(r.numRobust, r.numRobust + levels); o.iterations.assign(r.iterations, r.iterations + levels);
+        o.levelCutoffRepeat.assign(r.levelCutoffRepeat, r.levelCutoffRepeat + levels);
+        for (int k = 0; k < 3; k++) o.flowVector[k] = r.flow[k];
+        o.isCorrect = r.isCorrect != 0; o.tooManySaturated = r.tooManySaturated != 0;
+        o.relAff[0] = r.relAff[0]; o.relAff[1] = r.relAff[1];
+        for (int k = 0; k < 6; k++) o.covariance[k] = r.covariance[k];
+        return o;
+    };
+    bool haveOneGood = false;
+    Residual trackingResult;
+    double achievedRes = std::numeric_limits<double>::max();
+    int i = 0;
+    for (; i < n_hyp; i++) {
+        Residual test = toResidual(R[i]);
+        double rm = (test.numTermsInE[0] > 0) ? test.rmse() : std::numeric_limits<double>::quiet_NaN();
+        if (trackingResult.isCorrect) {                                                    // mLastResidual = trackingResult, TR.cpp:183-189
+            for (int p = 0; p < R[i].n_pass; p++) {
+                const int lv = R[i].pass_level[p];
+                if (R[i].pass_rmse[p] > 1.5 * trackingResult.rmse(lv)) {
+                    test.isCorrect = false; test.tooManySaturated = true;                  // the try returns at that level
+                    rm = (lv == 0) ? R[i].pass_rmse[p] : std::numeric_limits<double>::quiet_NaN();   // its level-0 slot is only filled when it got there
+                    if (lv != 0) test.numTermsInE[0] = 0;
+                    break;
+                }
+            }
+        }
+        auto adopt = [&]() {
+            haveOneGood = true; bestRefToNew = SE3::fromRt(R[i].R, R[i].t); bestExposure = initialExposure; bestExposure.a = R[i].a; bestExposure.b = R[i].b;
+            trackingResult = test;
+            if (winner) *winner = i;
+        };
+        if (trackingResult.tooManySaturated == true && test.tooManySaturated == false && test.isCorrect && std::isfinite(rm)) adopt();   // :280-285
+        if (test.isCorrect && std::isfinite(rm) && !(rm >= achievedRes)) {                 // :288-296
+            if (trackingResult.tooManySaturated || !test.tooManySaturated) adopt();
+        }
+        if (haveOneGood && test.numTermsInE[0] > 0 && rm < achievedRes) achievedRes = rm;  // :299-304
+        const float setting_reTrackThreshold = 1.5f;
+        if (haveOneGood && achievedRes < mLastCoarseRMSE * setting_reTrackThreshold) { i++; break; }   // :306-309
+        if (haveOneGood && i >= 50) { i++; break; }                                        // :311-313
+    }
+    if (tries) *tries = i;
+    if (!haveOneGood) {
+        if ((mFailureMode == 1 || mFailureMode == 2) && n_hyp > 0) {                       // :324-352: optimize(cameras[0]) with mLastResidual = trackingResult (not correct: no abort)
+            bestRefToNew = SE3::fromRt(R[0].R, R[0].t); bestExposure = initialExposure; bestExposure.a = R[0].a; bestExposure.b = R[0].b;
+            trackingResult = toResidual(R[0]);
+            if (winner) *winner = 0;
+            haveOneGood = true;
+        } else {
+            return false;
+        }
+    } else {
+        mLastCoarseRMSE = achievedRes;
+    }
+    residual = trackingResult;
+    return haveOneGood;
+}
+
 }  // namespace cml_amd

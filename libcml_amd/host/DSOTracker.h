@@ -56,6 +56,13 @@ public:
     bool trackWithMotionModel(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
                               const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
                               int* winner, int* tries);
+    // The same procedure with every hypothesis optimised SIDE BY SIDE on the device (cmlhip_tracker_optimize_batch: one launch, one
+    // readback), then the reference's sequential winner selection (DSOTracker.h:262-313) replayed on the results, including the
+    // abort of TR.cpp:183-189 (a try whose level rmse exceeds 1.5 x the best try's so far counts as failed), which the kernel
+    // reports per level pass.  Hypotheses beyond the reference's early exit are computed speculatively and discarded.
+    bool trackWithMotionModelBatched(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
+                                     const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
+                                     int* winner, int* tries);
     const std::string& lastError() const { return mError; }
 
 private:

@@ -210,14 +210,15 @@ void cmlhost_tracker_set_last_residual(void* h, int isCorrect, int levels, const
 // trackWithMotionModel(): hypotheses as n x {R[9], t[3]}; outputs the adopted try
 int cmlhost_tracker_track_with_motion_model(void* h, uint64_t new_image, int levels, int n_hyp, const double* hypRt, const double refExp[3], const double initExp[3],
                                             double R[9], double t[3], double outExp[2], double* E, int* numTerms, int* numSat, int* isCorrect,
-                                            int* tooManySaturated, int* winner, int* tries, double* lastCoarseRMSE) {
+                                            int* tooManySaturated, int* winner, int* tries, double* lastCoarseRMSE, int batched) {
     DSOTracker* T = static_cast<DSOTracker*>(h);
     std::vector<SE3> hyp(n_hyp);
     for (int i = 0; i < n_hyp; i++) hyp[i] = SE3::fromRt(hypRt + 12 * i, hypRt + 12 * i + 9);
     Exposure ref(refExp[2], refExp[0], refExp[1]), init(initExp[2], initExp[0], initExp[1]), best = init;
     SE3 bestT;
     DSOTracker::Residual res;
-    const bool ok = T->trackWithMotionModel(new_image, levels, n_hyp, hyp.data(), ref, init, bestT, best, res, winner, tries);
+    const bool ok = batched ? T->trackWithMotionModelBatched(new_image, levels, n_hyp, hyp.data(), ref, init, bestT, best, res, winner, tries)
+                            : T->trackWithMotionModel(new_image, levels, n_hyp, hyp.data(), ref, init, bestT, best, res, winner, tries);
     if (ok) {
         bestT.matrix(R); std::memcpy(t, bestT.t, 3 * sizeof(double));
         outExp[0] = best.a; outExp[1] = best.b;

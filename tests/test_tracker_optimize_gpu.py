@@ -1,8 +1,9 @@
 """DSOTracker::optimize / trackWithMotionModel through the host mirror ON THE DEVICE evaluation (cmlhip_tracker_eval) against the
 oracle's restatement of the whole loop.  The control flow itself is held identical on identical evaluations by
 tests/test_tracker_optimize_cpu.py; here the 9x9 systems differ by the fp32 accumulation order (3e-5, tests/test_tracker_parity_gpu.py),
-so trials at a knife's edge may differ: the levels visited and the winner must agree, the converged pose must agree to 1e-4
-(well conditioned at the optimum), the per-level energies to 1e-3."""
+so trials at a knife's edge may differ: the levels visited and the winner must agree; the loop stops when the increment norm falls
+below 1e-3 (TR.cpp:176), so two runs whose trial sequences differ by a step agree in the pose to a fraction of that: 3e-4; the
+level-0 energies to 1e-3."""
 import numpy as np
 import pytest
 
@@ -35,8 +36,8 @@ def test_optimize_device_vs_oracle(setup, w, dt):
     assert bool(o["out"].isCorrect) == r["isCorrect"] and bool(o["out"].tooManySaturated) == r["tooManySaturated"]
     assert sorted(set(lv.tolist())) == sorted(set(s[0] for s in o["steps"]))
     assert abs(len(lv) - len(o["steps"])) <= max(3, len(lv) // 5)                     # trial counts: a few knife-edge decisions at most
-    assert np.abs(o["R"] - r["R"]).max() < 1e-4 and np.abs(o["t"] - r["t"]).max() < 1e-4 * max(1.0, np.abs(o["t"]).max())
-    assert abs(o["a"] - r["exposure"][0]) < 1e-4 and abs(o["b"] - r["exposure"][1]) < 5e-2
+    assert np.abs(o["R"] - r["R"]).max() < 3e-4 and np.abs(o["t"] - r["t"]).max() < 1e-3 * max(1.0, np.abs(o["t"]).max())
+    assert abs(o["a"] - r["exposure"][0]) < 1e-3 and abs(o["b"] - r["exposure"][1]) < 0.5      # b is stepped in units of 1000 (scale_b): the 1e-3 stop is one grey level
     e_o = np.array(o["out"].E[:P.levels]) / np.maximum(np.array(o["out"].numTermsInE[:P.levels]), 1)
     e_d = r["E"][:P.levels] / np.maximum(r["numTerms"][:P.levels], 1)
     assert abs(e_o[0] / e_d[0] - 1) < 1e-3
@@ -55,3 +56,44 @@ def test_track_with_motion_model_device_vs_oracle(setup):
         if o["ok"]:
             assert np.abs(o["R"] - r["R"]).max() < 1e-3 and np.abs(o["t"] - r["t"]).max() < 1e-3 * max(1.0, np.abs(o["t"]).max())
             assert abs(r["lastCoarseRMSE"] / o["achieved"] - 1) < 1e-2
+
+
+def test_device_resident_optimize_vs_oracle(setup):
+    """cmlhip_tracker_optimize_batch: the whole LM loop of a hypothesis in one workgroup.  Against the oracle's loop: same levels,
+    nearly the same trial sequence (the 9x9 sums are fp32 in another order), converged pose 1e-4."""
+    P, ctx, trk = setup
+    cases = [((0.004, -0.003, 0.002), (0.03, -0.02, 0.025)), ((-0.006, 0.004, 0.003), (-0.04, 0.03, 0.02)), ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))]
+    hyps = [TS.perturbed(P, w, dt) for w, dt in cases]
+    res = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps)
+    for (R0, t0), r in zip(hyps, res):
+        o = TS.oracle_optimize(P, R0, t0)
+        assert bool(o["out"].isCorrect) == bool(r.isCorrect) and bool(o["out"].tooManySaturated) == bool(r.tooManySaturated)
+        so = [(s[0], s[2]) for s in o["steps"]]
+        sd = [(r.step_level[i], r.step_accept[i]) for i in range(min(r.n_steps, 256))]
+        assert sorted(set(l for l, _ in so)) == sorted(set(l for l, _ in sd))
+        assert abs(len(so) - len(sd)) <= max(3, len(so) // 5)
+        Rd = np.array(r.R[:]).reshape(3, 3); td = np.array(r.t[:])
+        assert np.abs(o["R"] - Rd).max() < 3e-4 and np.abs(o["t"] - td).max() < 1e-3 * max(1.0, np.abs(o["t"]).max())
+        assert abs(o["a"] - r.a) < 1e-3 and abs(o["b"] - r.b) < 0.5
+        assert abs((r.E[0] / r.numTermsInE[0]) / (o["out"].E[0] / o["out"].numTermsInE[0]) - 1) < 1e-3
+        assert r.n_pass >= P.levels and r.pass_level[r.n_pass - 1] == 0
+        cov_o = np.array(o["out"].covariance[:]); cov_d = np.array(r.covariance[:])
+        assert np.abs(cov_d / cov_o - 1).max() < 1e-2
+
+
+def test_batched_track_with_motion_model(setup):
+    """All hypotheses side by side on the device + the reference's selection replayed on the host == the sequential procedure."""
+    P, ctx, trk = setup
+    hyps = [TS.perturbed(P, (0.02, -0.015, 0.01), (0.15, -0.1, 0.12)), TS.perturbed(P, (0.004, -0.003, 0.002), (0.03, -0.02, 0.025)),
+            TS.perturbed(P, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), TS.perturbed(P, (-0.002, 0.001, 0.0), (0.01, 0.0, -0.01))]
+    for lcr in (100.0, 1e-6):
+        o = TS.oracle_track(P, hyps, lcr, 0)
+        trk.set_param("lastCoarseRMSE", lcr)
+        s = trk.track_with_motion_model(501, P.levels, hyps, P.ref_exp, P.init_exp)                       # sequential, device evaluations
+        trk.set_param("lastCoarseRMSE", lcr)
+        b = trk.track_with_motion_model(501, P.levels, hyps, P.ref_exp, P.init_exp, batched=True)        # one launch
+        assert o["ok"] == b["haveOneGood"] == s["haveOneGood"] and o["tries"] == b["tries"] == s["tries"]
+        if o["ok"]:
+            assert np.abs(o["R"] - b["R"]).max() < 1e-3 and np.abs(o["t"] - b["t"]).max() < 1e-3 * max(1.0, np.abs(o["t"]).max())
+            assert np.abs(s["R"] - b["R"]).max() < 1e-3
+            assert abs(b["lastCoarseRMSE"] / o["achieved"] - 1) < 1e-2
