@@ -153,7 +153,9 @@ def main():
 
     _dbg('group ready')
     seed = 0xC0FFEE
-    W = synth.make_window(args.config, seed=seed, shard=rank)             # one independent sequence shard per rank
+    hybrid = args.config == "C"                                          # BASELINE.json configs[2]: config B + 1000 ORB reprojection residuals
+    wcfg = "B" if hybrid else args.config
+    W = synth.make_window(wcfg, seed=seed, shard=rank)                   # one independent sequence shard per rank
     N, P = W.N, W.P
     _dbg('window made')
     from libcml_amd import abi
@@ -163,6 +165,14 @@ def main():
     ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (rank + 1), levels=1)
     _dbg('ba built')
     ba.set_param("iterations", 1)
+    if hybrid:                                                            # mixed into the pose solution inside the device solve (BA.cpp:1327-1329)
+        import numpy as np
+        _, ipts, iobs = synth.indirect_observations(W, n_obs=1000, n_pts=300, seed=11 + rank)
+        o = np.zeros(len(iobs), abi.REPROJ_OBS_DTYPE)
+        for f in ("frame", "point", "gx", "gy"):
+            o[f] = iobs[f]
+        ba.set_param("mixedBundleAdjustment", 1)
+        ba.set_indirect_points(ipts, o)
     if not ba.run():                                                      # uploads the window, leaves adjoints/priors resident
         raise RuntimeError("BA run failed: " + ba.last_error())
     _dbg('run done')
@@ -224,8 +234,8 @@ def main():
             "value": total_units / dt, "unit": "point-residuals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "
-                                   "gradient images, %s texels / fp32 arithmetic; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (args.config, N, P, R, W.w, W.h, "fp16" if half else "fp32"),
+            "config": {"workload": ("config C = config B + 1000 ORB reprojection residuals of 300 points mixed into the pose solution in every iteration; " if hybrid else "") + "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "
+                                   "gradient images, %s texels / fp32 arithmetic; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (wcfg, N, P, R, W.w, W.h, "fp16" if half else "fp32"),
                        "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
             "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
             "roofline": {"bound": "hbm", "kernel": "k_ba_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

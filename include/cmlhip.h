@@ -497,6 +497,14 @@ typedef struct {
  * row-major, zero rows allowed) of the gauge nullspace: from the third iteration on x -= U^T (U x) (BA.cpp:1196-1261,1404). */
 int cmlhip_ba_set_resident_state(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, const cmlhip_ba_frame_state* frames,
                                  const double scales[4], const double* nullspace_basis /* 7*(8N+4) or NULL */);
+/* The hybrid ORB term INSIDE the resident iteration (MODSLAM's mixedBundleAdjustment, BA.cpp:1327-1329 -> addIndirectToProblem
+ * :2574-2729): the indirect points (M x world XYZ) and observations are kept on the device; every cmlhip_ba_iteration_async then
+ * evaluates the reprojection Jacobians on the CURRENT resident frame poses, solves the per-frame 6x6 systems and replaces the pose
+ * part of x by that solution (the reference's literal weighting, :2714-2727) before the nullspace projection — no host round trip.
+ * Only windows with more than 4 frames mix (:1327).  Call after cmlhip_ba_set_resident_state; M = 0 switches the term off.
+ * get: x of the last iteration (8N+4), the last indirect solution (6N) and the per-point Jacobian sums (3M, for setUncertainty :2690). */
+int cmlhip_ba_set_resident_indirect(cmlhip_ctx* ctx, int M, const double* points_xyz, int n_obs, const cmlhip_reproj_obs* obs, double fx, double fy);
+int cmlhip_ba_get_resident_indirect(cmlhip_ctx* ctx, double* x, double* x6, double* Jpoints);
 /* Mirror of BA::run's early exit (`if (canbreak && it >= 1) break`, BA.cpp:879, canbreak from doStepFromBackup :996-1027 with
  * thOptIterations): after the call, the iteration whose step passes the test is the last one that runs — the kernels of the
  * iterations enqueued behind it return at once.  th <= 0 switches the test off (every enqueued iteration runs). */

@@ -756,7 +756,7 @@ template <int NSL>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
                                                             const int* newframe_res, int n_newframe, const double* lin_partial,
                                                             int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
-                                                            const double* __restrict__ nullU) {
+                                                            const double* __restrict__ nullU, const double* __restrict__ indirect_x) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
     DBG_BLK(A.dbg, 3, 0);
@@ -936,13 +936,33 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     }
     DBG_T(A, 52);
     int bad = 0;
+    double* xs = Wk;                                    // n: the solution in the caller's scaling
+    double* dots = Wk + mp + 16;                        // 7
+    for (int i = tid; i < n; i += SOLVE_THREADS) xs[i] = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
+    __syncthreads();
+    if (indirect_x) {
+        // hybrid ORB term, addIndirectToProblem (BA.cpp:2702-2727): unless the indirect solution has a non-finite entry, the pose part
+        // of x becomes x * directRatio + indirectX * indirectRatio with the literal constants numIndirectPoint = 1, numDirectPoint = 0
+        int* ind_flag = reinterpret_cast<int*>(dots + 8);     // (dynamic LDS: the kernel may take the whole 160 KB, a static variable —
+        if (tid == 0) *ind_flag = 0;                          //  or __syncthreads_or's hidden one — would make that request invalid)
+        __syncthreads();
+        int mybad = 0;
+        for (int i = tid; i < 6 * A.N; i += SOLVE_THREADS) mybad |= !isfinite(indirect_x[i]);
+        if (mybad) *ind_flag = 1;
+        __syncthreads();
+        const int ind_bad = *ind_flag;
+        if (!ind_bad) {
+            const double indirectRatio = 1.0 / (1.0 + 0.0), directRatio = 1.0 - indirectRatio;
+            for (int i = tid; i < 6 * A.N; i += SOLVE_THREADS) {
+                const int f = i / 6, k = i % 6;
+                xs[4 + 8 * f + k] = xs[4 + 8 * f + k] * directRatio + indirect_x[i] * indirectRatio;
+            }
+        }
+        __syncthreads();
+    }
     if (nullU) {
         // orthogonalize (BA.cpp:1196-1261): x -= U^T (U x), U = orthonormal basis of the kept gauge directions (7 x n).
         // The basis entries were fetched at kernel start (registers), the products only wait for x.
-        double* xs = Wk;                                    // n
-        double* dots = Wk + mp + 16;                        // 7
-        for (int i = tid; i < n; i += SOLVE_THREADS) xs[i] = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
-        __syncthreads();
         if (wv < 7) {
             double sdot = 0;
 #pragma unroll
@@ -966,7 +986,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
         }
     } else {
         for (int i = tid; i < n; i += SOLVE_THREADS) {
-            const double v = (i < off) ? 0.0 : Sv[i - off] * y[i - off];
+            const double v = xs[i];
             x[i] = v;
             bad |= !isfinite(v);
         }
@@ -1163,7 +1183,7 @@ int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A) {
     return CMLHIP_OK;
 }
 
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho) {
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho, const double* indirect_x) {
     const int n = A.n, off = optcal ? 0 : 4, m = n - off;
     const size_t sh = solve_lds_bytes(m);
     int* flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
@@ -1178,7 +1198,7 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
         if (!(c->attr_done & (1u << NSL))) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c->attr_done |= 1u << NSL; } \
         k_ba_solve<NSL><<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag, \
             c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n, c->scal.as<LinSummary>(), \
-            c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr); } while (0)
+            c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr, indirect_x); } while (0)
     switch (Y.nsl) {
         case 1: LAUNCH_SOLVE(1); break;
         case 2: LAUNCH_SOLVE(2); break;

@@ -525,7 +525,9 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     hipEvent_t* ev = prof ? &c->prof_ev[4 * (size_t)c->prof_n] : nullptr;
     if (prof) c->ext_start = ev[0];                          // begin timestamp of the K3 dispatch
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
-    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2))) return rc;   // K5: solve (+ orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
+    const bool mix = c->resident_on && c->rp_resident && c->N > 4;      // addIndirectToProblem, BA.cpp:1327-1329 (only with more than 4 frames)
+    if (mix && (rc = cml_launch_reproj_resident(c, lambda))) return rc;
+    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rp_x.as<double>() : nullptr))) return rc;   // K5: solve (+ hybrid term, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
     c->resident_iter++;
     if (prof) c->ext_stop = ev[1];                           // end timestamp of the K6 dispatch
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
@@ -660,7 +662,7 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, co
     c->have_null = nullspace_basis != nullptr;
     if (c->have_null && (rc = cml_h2d(c, c->null_basis.p, nullspace_basis, 8 * 7 * (size_t)n))) return rc;
     if ((rc = cml_h2d_batch_flush(c))) return rc;
-    c->resident_on = true; c->resident_iter = 0; c->conv_th = 0; c->conv_on = false;
+    c->resident_on = true; c->resident_iter = 0; c->conv_th = 0; c->conv_on = false; c->rp_resident = false;
     return CMLHIP_OK;
 }
 

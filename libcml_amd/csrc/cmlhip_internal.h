@@ -123,6 +123,7 @@ struct cmlhip_ctx {
     DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt, cd_pts;      // makeCoarseDepth scratch
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x;
+    bool rp_resident = false; int rp_res_M = 0, rp_res_n = 0; double rp_res_fx = 0, rp_res_fy = 0;   // hybrid term inside the resident iteration (cmlhip_ba_set_resident_indirect)
 };
 
 // every extern "C" entry selects its context's device first: the current device is per-thread state and a process may own

@@ -8,6 +8,7 @@
 // block is block-diagonal: M6[i,i] = sum_j f_ij f_ij^T.  Here each observation is one lane; the 21+6 unique sums
 // per frame are reduced in LDS per workgroup and added to global with fp64 atomics.  All arithmetic is fp64.
 #include "cmlhip_internal.h"
+#include "../host/se3.h"
 
 struct FramePre { double q[4]; double D[42]; };      // CML quaternion (w,x,y,z) of R, and Dx_exp_x(log(T)) 7x6
 
@@ -261,7 +262,80 @@ __global__ void k_reproj_solve(int N, double lambda, const double* __restrict__ 
     for (int i = 0; i < 6; i++) x6[6 * f + i] = x[i];
 }
 
+// PRE_worldToCam of every frame from the resident frame states (the expression of frame_step_block, ba_frames.h: exp(scaled state) *
+// evaluation point), as the 12 doubles (R, t) the kernels above take: frame->getCamera() of BA.cpp:2617
+__global__ void k_reproj_poses_from_state(int N, const cmlhip_ba_frame_state* __restrict__ fs, double sc_t, double sc_r, double* __restrict__ poses) {
+    using cml_amd::SE3;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const cmlhip_ba_frame_state& S = fs[i];
+    const double ss[6] = {sc_t * S.state[0], sc_t * S.state[1], sc_t * S.state[2], sc_r * S.state[3], sc_r * S.state[4], sc_r * S.state[5]};
+    SE3 ev;
+    for (int k = 0; k < 4; k++) ev.q[k] = S.eval_q[k];
+    for (int k = 0; k < 3; k++) ev.t[k] = S.eval_t[k];
+    const SE3 W = SE3::exp(ss) * ev;
+    double R[9];
+    W.matrix(R);
+    for (int k = 0; k < 9; k++) poses[12 * (size_t)i + k] = R[k];
+    for (int k = 0; k < 3; k++) poses[12 * (size_t)i + 9 + k] = W.t[k];
+}
+
+// addIndirectToProblem inside the device-resident iteration (BA.cpp:1327-1329, 2574-2729): poses from the resident frame states,
+// accumulation and the per-frame 6x6 solves enqueued on the context stream; the solve kernel of the iteration then replaces the
+// pose part of x by rp_x (the literal weighting of :2714-2727) before the nullspace projection.  No host round trip.
+int cml_launch_reproj_resident(cmlhip_ctx* c, double lambda) {
+    const int N = c->N, M = c->rp_res_M, n = c->rp_res_n, m = 6 * N;
+    CML_CHECK(c, hipMemsetAsync(c->rp_M.p, 0, 8 * (size_t)m * m, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->rp_b.p, 0, 8 * (size_t)m, c->stream));
+    CML_CHECK(c, hipMemsetAsync(c->rp_Jp.p, 0, 8 * 3 * (size_t)(M ? M : 1), c->stream));
+    FramePre* pre = reinterpret_cast<FramePre*>(c->rp_poses.as<double>() + 12 * (size_t)N);
+    k_reproj_poses_from_state<<<1, 64, 0, c->stream>>>(N, c->frame_state.as<cmlhip_ba_frame_state>(), c->res_scales[0], c->res_scales[1], c->rp_poses.as<double>());
+    k_reproj_frames<<<1, 64, 0, c->stream>>>(N, c->rp_poses.as<double>(), pre);
+    if (n > 0)
+        k_reproj_obs<<<cml_div_up(n, 256), 256, 27 * N * sizeof(double), c->stream>>>(N, c->rp_poses.as<double>(), pre, c->rp_points.as<double>(), n,
+                                                                                     c->rp_obs.as<cmlhip_reproj_obs>(), c->rp_res_fx, c->rp_res_fy, c->rp_M.as<double>(),
+                                                                                     c->rp_b.as<double>(), c->rp_Jp.as<double>(),
+                                                                                     c->rp_used.as<unsigned char>());
+    k_reproj_solve<<<1, 64, 0, c->stream>>>(N, lambda, c->rp_M.as<double>(), c->rp_b.as<double>(), c->rp_x.as<double>());
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
+}
+
 extern "C" {
+
+int cmlhip_ba_set_resident_indirect(cmlhip_ctx* c, int M, const double* points, int n, const cmlhip_reproj_obs* obs, double fx, double fy) { CML_DEV(c);
+    if (!c || M < 0 || n < 0 || (M > 0 && !points) || (n > 0 && !obs)) return CMLHIP_ERR_INVALID;
+    c->rp_resident = false;
+    if (M == 0) return CMLHIP_OK;                                  // BA.cpp:2587-2589: nothing to mix
+    CML_REQUIRE(c, c->ba_uploaded && c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
+    CML_REQUIRE(c, n <= c->lim.max_reproj_obs, CMLHIP_ERR_INVALID, "observations exceed max_reproj_obs");
+    const int N = c->N, m = 6 * N;
+    for (int k = 0; k < n; k++)
+        CML_REQUIRE(c, obs[k].frame >= 0 && obs[k].frame < N && obs[k].point >= 0 && obs[k].point < M, CMLHIP_ERR_INVALID, "bad observation index");
+    int rc;
+#define ENS(buf, bytes) if ((rc = cml_ensure(c, buf, (size_t)(bytes)))) return rc
+    ENS(c->rp_obs, sizeof(cmlhip_reproj_obs) * (size_t)(n ? n : 1)); ENS(c->rp_poses, 8 * 12 * (size_t)N + sizeof(FramePre) * (size_t)N);
+    ENS(c->rp_points, 8 * 3 * (size_t)M); ENS(c->rp_M, 8 * (size_t)m * m); ENS(c->rp_b, 8 * (size_t)m);
+    ENS(c->rp_Jp, 8 * 3 * (size_t)M); ENS(c->rp_used, (size_t)(n ? n : 1)); ENS(c->rp_x, 8 * (size_t)m);
+#undef ENS
+    if ((rc = cml_h2d(c, c->rp_points.p, points, 8 * 3 * (size_t)M))) return rc;
+    if (n && (rc = cml_h2d(c, c->rp_obs.p, obs, sizeof(cmlhip_reproj_obs) * (size_t)n))) return rc;
+    c->rp_res_M = M; c->rp_res_n = n; c->rp_res_fx = fx; c->rp_res_fy = fy;
+    c->rp_resident = true;
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_get_resident_indirect(cmlhip_ctx* c, double* x, double* x6, double* Jpoints) { CML_DEV(c);
+    if (!c) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, c->ba_uploaded && c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
+    int rc;
+    if (x && (rc = cml_d2h(c, x, c->xvec.p, 8 * (8 * (size_t)c->N + 4)))) return rc;
+    if (c->rp_resident) {
+        if (x6 && (rc = cml_d2h(c, x6, c->rp_x.p, 8 * 6 * (size_t)c->N))) return rc;
+        if (Jpoints && (rc = cml_d2h(c, Jpoints, c->rp_Jp.p, 8 * 3 * (size_t)c->rp_res_M))) return rc;
+    }
+    return CMLHIP_OK;
+}
 
 int cmlhip_reproj_accumulate(cmlhip_ctx* c, int N, const double* poses, int M, const double* points, int n,
                              const cmlhip_reproj_obs* obs, double fx, double fy, double* M6, double* b6, double* Jpoints,

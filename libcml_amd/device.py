@@ -41,6 +41,8 @@ PROTOTYPES = {
     "cmlhip_tracker_get_warped": (C.c_int, [_ctx, _P(_f), _i, _P(_i)]),
     "cmlhip_tracker_optimize_batch": (C.c_int, [_ctx, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(abi.TrackerParams), _i, _i, _d, _i,
                                                 _P(abi.TrackerHypothesis), _P(abi.TrackerOptResult)]),
+    "cmlhip_ba_set_resident_indirect": (C.c_int, [_ctx, _i, _P(_d), _i, _P(abi.ReprojObs), _d, _d]),
+    "cmlhip_ba_get_resident_indirect": (C.c_int, [_ctx, _P(_d), _P(_d), _P(_d)]),
     "cmlhip_ba_set_params": (C.c_int, [_ctx, _P(abi.BAParams)]),
     "cmlhip_ba_upload_window": (C.c_int, [_ctx, _i, _P(abi.BAFrame), _i, _P(abi.BAPoint), _i, _P(abi.BAResidual)]),
     "cmlhip_ba_set_pairs": (C.c_int, [_ctx, _P(abi.BAPair)]),

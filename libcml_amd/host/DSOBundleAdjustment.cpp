@@ -511,6 +511,19 @@ void DSOBundleAdjustment::setIndirectPoints(const std::vector<double>& worldXYZ,
 // Dx_exp_x), the pose block of J J^T, b and the per-point Jacobian sums (cmlhip_reproj_accumulate), then
 // ldlt(M with diag*(1+fixedLambda)).solve(-bM) (cmlhip_reproj_solve).  Host: the literal weighting of :2714-2727 —
 // numIndirectPoint = 1 and numDirectPoint = 0 are constants there, so the pose part of x is REPLACED by the indirect solution.
+void DSOBundleAdjustment::indirectUncertaintyFrom(const std::vector<double>& Jp) {
+    const int M = (int)(mIndirectPoints.size() / 3);
+    for (int j = 0; j < M; j++) {                                             // (Jp Jp^T).inverse().diagonal().norm(), :2690-2692: the inverse of
+        const double* a = &Jp[3 * j];                                         // a rank-one 3x3 by cofactors / determinant, whatever that gives
+        double A[9], C[3];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[3 * r + c] = a[r] * a[c];
+        C[0] = A[4] * A[8] - A[5] * A[7]; C[1] = A[0] * A[8] - A[2] * A[6]; C[2] = A[0] * A[4] - A[1] * A[3];
+        const double det = A[0] * C[0] - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+        const double d0 = C[0] / det, d1 = C[1] / det, d2 = C[2] / det;
+        mIndirectUncertainty[j] = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+}
+
 bool DSOBundleAdjustment::addIndirectToProblem(std::vector<double>& X) {
     if (!mMixedBundleAdjustment) return true;                                 // :2575-2577
     const int N = (int)mFrames.size(), M = (int)(mIndirectPoints.size() / 3), n = (int)mIndirectObs.size();
@@ -523,15 +536,7 @@ bool DSOBundleAdjustment::addIndirectToProblem(std::vector<double>& X) {
     int rc = cmlhip_reproj_accumulate(mCtx, N, poses.data(), M, mIndirectPoints.data(), n, mIndirectObs.data(), mPrm.fx, mPrm.fy,
                                       nullptr, nullptr, Jp.data(), nullptr);
     if (rc) return fail("cmlhip_reproj_accumulate", rc);
-    for (int j = 0; j < M; j++) {                                             // (Jp Jp^T).inverse().diagonal().norm(), :2690-2692: the inverse of
-        const double* a = &Jp[3 * j];                                         // a rank-one 3x3 by cofactors / determinant, whatever that gives
-        double A[9], C[3];
-        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[3 * r + c] = a[r] * a[c];
-        C[0] = A[4] * A[8] - A[5] * A[7]; C[1] = A[0] * A[8] - A[2] * A[6]; C[2] = A[0] * A[4] - A[1] * A[3];
-        const double det = A[0] * C[0] - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
-        const double d0 = C[0] / det, d1 = C[1] / det, d2 = C[2] / det;
-        mIndirectUncertainty[j] = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    }
+    indirectUncertaintyFrom(Jp);
     mIndirectX.assign(6 * (size_t)N, 0.0);
     rc = cmlhip_reproj_solve(mCtx, N, mFixedLambda, mIndirectX.data());       // :2695-2700
     if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_reproj_solve", rc);
@@ -619,9 +624,8 @@ bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // 
 bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        // BA.cpp:744-910
     // forceAccept + fixLambda + no marginalisation prior (the reference's defaults, BA.h:265-270): every step is accepted and
     // lambda never changes, so the loop body has no host decision left except the early exit, which the device mirrors
-    // (the hybrid ORB term replaces part of x on the host between the solve and the step: host loop)
-    if (mResidentLoop && mForceAccept && mFixLambda && mDisableMarginalization && mNumIterations <= 40 &&
-        !(mMixedBundleAdjustment && !mIndirectObs.empty())) return runResident(updatePointsOnly);
+    // (the hybrid ORB term is mixed into x inside the device solve: cmlhip_ba_set_resident_indirect)
+    if (mResidentLoop && mForceAccept && mFixLambda && mDisableMarginalization && mNumIterations <= 40) return runResident(updatePointsOnly);
     return runHostLoop(updatePointsOnly);
 }
 
@@ -972,6 +976,11 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
     nullspaceBasis(U);
     rc = cmlhip_ba_set_resident_state(mCtx, &in, fs.data(), sc, U.data());
     if (rc) return fail("cmlhip_ba_set_resident_state", rc);
+    // hybrid ORB term (BA.cpp:1327-1329, 2574-2729) evaluated and mixed on the device inside every iteration
+    const int M = mMixedBundleAdjustment ? (int)(mIndirectPoints.size() / 3) : 0;
+    rc = cmlhip_ba_set_resident_indirect(mCtx, M, M ? mIndirectPoints.data() : nullptr, M ? (int)mIndirectObs.size() : 0,
+                                         M ? mIndirectObs.data() : nullptr, mPrm.fx, mPrm.fy);
+    if (rc) return fail("cmlhip_ba_set_resident_indirect", rc);
     return true;
 }
 
@@ -998,6 +1007,16 @@ bool DSOBundleAdjustment::endResident(double* lastEnergy) {
     }
     mFrames.back().frameEnergyTH = last.new_frame_energy_th;                  // setNewFrameEnergyTH of the last pass
     if (lastEnergy) *lastEnergy = last.energy;
+    {   // x of the last solve; with the hybrid term also the last indirect solution and the point uncertainties (:2690-2692)
+        const int M = mMixedBundleAdjustment ? (int)(mIndirectPoints.size() / 3) : 0;
+        const bool mixed = M > 0 && N > 4;
+        mX.assign(8 * (size_t)N + CMLHIP_CPARS, 0.0);
+        std::vector<double> Jp(3 * (size_t)(mixed ? M : 0));
+        if (mixed) mIndirectX.assign(6 * (size_t)N, 0.0);
+        rc = cmlhip_ba_get_resident_indirect(mCtx, mX.data(), mixed ? mIndirectX.data() : nullptr, mixed ? Jp.data() : nullptr);
+        if (rc) return fail("cmlhip_ba_get_resident_indirect", rc);
+        if (mixed) indirectUncertaintyFrom(Jp);
+    }
     computeDelta();
     return std::isfinite(last.energy);
 }

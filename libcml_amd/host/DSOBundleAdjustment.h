@@ -121,6 +121,7 @@ public:
     // (world coordinates) and their feature observations {DSOFrame id, point index, undistorted position}, handed over flat;
     // solveSystem mixes the indirect pose solution into x between the solve and the orthogonalisation (BA.cpp:1327-1329)
     void setIndirectPoints(const std::vector<double>& worldXYZ, const std::vector<cmlhip_reproj_obs>& observations);
+    void indirectUncertaintyFrom(const std::vector<double>& Jp);                // setUncertainty of the indirect points, BA.cpp:2690-2692
     bool addIndirectToProblem(std::vector<double>& X);
     const std::vector<double>& indirectUncertainty() const { return mIndirectUncertainty; }     // MapPoint::setUncertainty, BA.cpp:2690-2692
     const std::vector<double>& lastIndirectX() const { return mIndirectX; }

@@ -199,3 +199,30 @@ def residual_list(W, R_eval, t_eval):
             inside = (0 <= u < W.w) and (0 <= v < W.h)   # Frame::isInside(p, 0, 0), src/cml/map/Frame.h:136-138
             res.append((i, t_, 0 if inside else 1, 0))
     return np.array(res, dtype=[("point", "i4"), ("target", "i4"), ("state", "i4"), ("is_linearized", "i4")])
+
+
+def indirect_observations(W, n_obs=1000, n_pts=300, seed=3):
+    """BASELINE.json configs[2] (hybrid path): n_obs ORB observations of n_pts 3-D points at depth U(2,20) m in front of keyframe 0,
+    observed with 0.5 px Gaussian noise, one in fifty a gross outlier.  Returns (poses N x 12 at the evaluation
+    point, points n_pts x 3 world XYZ, observations as a structured array {frame, point, gx, gy} in normalised image coordinates)."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = W.K
+    N = W.N
+    poses = np.zeros((N, 12))
+    for k in range(N):
+        poses[k, :9] = W.R_eval[k].ravel(); poses[k, 9:] = W.t_eval[k]
+    pts = np.zeros((n_pts, 3))
+    for j in range(n_pts):
+        z = rng.uniform(2, 20)
+        u = rng.uniform(0, W.w); v = rng.uniform(0, W.h)
+        Xc = np.array([(u - cx) / fx * z, (v - cy) / fy * z, z])
+        pts[j] = W.R_true[0].T @ (Xc - W.t_true[0])
+    obs = np.zeros(n_obs, dtype=[("frame", "i4"), ("point", "i4"), ("gx", "f8"), ("gy", "f8")])
+    for k in range(n_obs):
+        i = int(rng.integers(0, N)); j = int(rng.integers(0, n_pts))
+        Xc = W.R_true[i] @ pts[j] + W.t_true[i]
+        noise = rng.normal(0, 0.5, 2) / np.array([fx, fy])
+        if k % 50 == 0:
+            noise += 0.2      # gross outliers: beyond the Tukey threshold -> zero loss / zero Jacobian
+        obs[k] = (i, j, Xc[0] / Xc[2] + noise[0], Xc[1] / Xc[2] + noise[1])
+    return poses, pts, obs

@@ -44,8 +44,10 @@ def test_hybrid_term_mixed_into_the_pose_solution(config):
         f = mixed.frame(i)
         poses[i, :9] = f["R"].ravel(); poses[i, 9:] = f["t"]
     st0 = [mixed.frame(i)["state"].copy() for i in range(N)]
-    assert plain.run_host_loop(), plain.last_error()  # (the resident loop keeps x on the device)
-    assert mixed.run(), mixed.last_error()            # run() takes the host loop by itself in mixed mode
+    mixed_h = _build(ctx, W, 3000, True, pts, obs)
+    assert plain.run_host_loop(), plain.last_error()
+    assert mixed.run(), mixed.last_error()            # run() keeps the loop on the device: the term is evaluated and mixed inside the solve kernel
+    assert mixed_h.run_host_loop(), mixed_h.last_error()   # the literal host-side procedure (cmlhip_reproj_accumulate / _solve + host weighting)
     x6p, _, xp = plain.indirect()
     x6, unc, x = mixed.indirect()
     assert x6p is None and x6 is not None             # mixedBundleAdjustment off: addIndirectToProblem returns at once (:2575)
@@ -68,3 +70,12 @@ def test_hybrid_term_mixed_into_the_pose_solution(config):
         assert np.allclose(st[:6] - st0[i][:6], -xr[i, :6], rtol=0, atol=1e-12 * max(1.0, np.abs(xr[i, :6]).max()))
     assert len(unc) == len(pts)                       # setUncertainty of every indirect point (:2690-2692), the inverse of a rank-one matrix
     assert np.isfinite(mixed.energies()).all()
+    # device-resident mixing == the host-side procedure
+    x6h, unch, xh = mixed_h.indirect()
+    assert np.abs(x6 - x6h).max() <= 1e-12 * np.abs(x6h).max() and np.abs(x - xh).max() <= 1e-12 * np.abs(xh).max()
+    assert len(unc) == len(unch)                      # (the values are the cofactor 'inverse' of a rank-one matrix, :2690-2692: 0/0-like, last-bit
+                                                      #  differences of the per-point Jacobian sums change them arbitrarily — nothing to compare)
+    for i in range(N):
+        a, b = mixed.frame(i), mixed_h.frame(i)
+        assert np.abs(a["state"] - b["state"]).max() < 1e-10 * max(1.0, np.abs(a["state"]).max())
+    assert np.abs(mixed.energies() / mixed_h.energies() - 1).max() < 1e-9

@@ -85,28 +85,11 @@ def oracle_tracker_eval(s, level, uvic, R, t, K, aff, b0, prm):
 
 def reproj_inputs(s, n_obs=1000, n_pts=300, seed=3):
     W = s.W
-    rng = np.random.default_rng(seed)
-    fx, fy, cx, cy = W.K
-    N = W.N
-    poses = np.zeros((N, 12))
-    for k in range(N):
-        poses[k, :9] = W.R_eval[k].ravel(); poses[k, 9:] = W.t_eval[k]
-    # 3-D points at depth U(2,20) m in front of keyframe 0, observed with 0.5 px noise
-    pts = np.zeros((n_pts, 3))
-    for j in range(n_pts):
-        z = rng.uniform(2, 20)
-        u = rng.uniform(0, W.w); v = rng.uniform(0, W.h)
-        Xc = np.array([(u - cx) / fx * z, (v - cy) / fy * z, z])
-        pts[j] = W.R_true[0].T @ (Xc - W.t_true[0])
-    obs = np.zeros(n_obs, abi.REPROJ_OBS_DTYPE)
-    for k in range(n_obs):
-        i = int(rng.integers(0, N)); j = int(rng.integers(0, n_pts))
-        Xc = W.R_true[i] @ pts[j] + W.t_true[i]
-        noise = rng.normal(0, 0.5, 2) / np.array([fx, fy])
-        if k % 50 == 0:
-            noise += 0.2      # gross outliers: beyond the Tukey threshold -> zero loss / zero Jacobian
-        obs[k] = (i, j, Xc[0] / Xc[2] + noise[0], Xc[1] / Xc[2] + noise[1])
-    return poses, pts, obs, fx, fy
+    poses, pts, obs = synth.indirect_observations(W, n_obs=n_obs, n_pts=n_pts, seed=seed)
+    o = np.zeros(n_obs, abi.REPROJ_OBS_DTYPE)
+    for f in ("frame", "point", "gx", "gy"):
+        o[f] = obs[f]
+    return poses, pts, o, W.K[0], W.K[1]
 
 
 def oracle_reproj(poses, points, obs, fx, fy):
