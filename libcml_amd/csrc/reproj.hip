@@ -109,10 +109,7 @@ __device__ void d_dx_exp_x(const double xi[6], double J[42]) {
     }
 }
 
-__global__ void k_reproj_frames(int N, const double* __restrict__ poses, FramePre* __restrict__ pre) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const double* R = poses + 12 * (size_t)i; const double* t = R + 9;
+__device__ void reproj_frame_pre(const double* R, const double* t, FramePre& P) {
     // Quaternion::logHati + normalise, Rotation.cpp:205-221, Rotation.h:246-252
     double q[4];
     q[0] = sqrt(fmax(0.0, 1.0 + R[0] + R[4] + R[8])) / 2.0;
@@ -121,10 +118,15 @@ __global__ void k_reproj_frames(int N, const double* __restrict__ poses, FramePr
     q[3] = sqrt(fmax(0.0, 1.0 - R[0] - R[4] + R[8])) / 2.0;
     q[1] = copysign(q[1], R[7] - R[5]); q[2] = copysign(q[2], R[2] - R[6]); q[3] = copysign(q[3], R[3] - R[1]);
     const double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int k = 0; k < 4; k++) pre[i].q[k] = q[k] / nn;
+    for (int k = 0; k < 4; k++) P.q[k] = q[k] / nn;
     double xi[6];
     d_se3_log(R, t, xi);                // BA.cpp:2621-2622
-    d_dx_exp_x(xi, pre[i].D);           // BA.cpp:2623
+    d_dx_exp_x(xi, P.D);                // BA.cpp:2623
+}
+__global__ void k_reproj_frames(int N, const double* __restrict__ poses, FramePre* __restrict__ pre) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    reproj_frame_pre(poses + 12 * (size_t)i, poses + 12 * (size_t)i + 9, pre[i]);
 }
 
 __device__ __forceinline__ double d_tukey(double v, double th) {            // Derivative.h:35-39
@@ -264,9 +266,15 @@ __global__ void k_reproj_solve(int N, double lambda, const double* __restrict__ 
 
 // PRE_worldToCam of every frame from the resident frame states (the expression of frame_step_block, ba_frames.h: exp(scaled state) *
 // evaluation point), as the 12 doubles (R, t) the kernels above take: frame->getCamera() of BA.cpp:2617
-__global__ void k_reproj_poses_from_state(int N, const cmlhip_ba_frame_state* __restrict__ fs, double sc_t, double sc_r, double* __restrict__ poses) {
+__global__ __launch_bounds__(256) void k_reproj_poses_from_state(int N, const cmlhip_ba_frame_state* __restrict__ fs, double sc_t, double sc_r, double* __restrict__ poses,
+                                                                 FramePre* __restrict__ pre, double* __restrict__ zero0, int n0, double* __restrict__ zero1, int n1,
+                                                                 double* __restrict__ zero2, int n2) {
     using cml_amd::SE3;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one launch for the whole preamble of the accumulation: the sums start at zero, then per frame the pose and its FramePre
+    for (int k = threadIdx.x; k < n0; k += blockDim.x) zero0[k] = 0.0;
+    for (int k = threadIdx.x; k < n1; k += blockDim.x) zero1[k] = 0.0;
+    for (int k = threadIdx.x; k < n2; k += blockDim.x) zero2[k] = 0.0;
+    const int i = threadIdx.x;
     if (i >= N) return;
     const cmlhip_ba_frame_state& S = fs[i];
     const double ss[6] = {sc_t * S.state[0], sc_t * S.state[1], sc_t * S.state[2], sc_r * S.state[3], sc_r * S.state[4], sc_r * S.state[5]};
@@ -278,6 +286,7 @@ __global__ void k_reproj_poses_from_state(int N, const cmlhip_ba_frame_state* __
     W.matrix(R);
     for (int k = 0; k < 9; k++) poses[12 * (size_t)i + k] = R[k];
     for (int k = 0; k < 3; k++) poses[12 * (size_t)i + 9 + k] = W.t[k];
+    reproj_frame_pre(R, W.t, pre[i]);
 }
 
 // addIndirectToProblem inside the device-resident iteration (BA.cpp:1327-1329, 2574-2729): poses from the resident frame states,
@@ -285,12 +294,9 @@ __global__ void k_reproj_poses_from_state(int N, const cmlhip_ba_frame_state* __
 // pose part of x by rp_x (the literal weighting of :2714-2727) before the nullspace projection.  No host round trip.
 int cml_launch_reproj_resident(cmlhip_ctx* c, double lambda) {
     const int N = c->N, M = c->rp_res_M, n = c->rp_res_n, m = 6 * N;
-    CML_CHECK(c, hipMemsetAsync(c->rp_M.p, 0, 8 * (size_t)m * m, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->rp_b.p, 0, 8 * (size_t)m, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->rp_Jp.p, 0, 8 * 3 * (size_t)(M ? M : 1), c->stream));
     FramePre* pre = reinterpret_cast<FramePre*>(c->rp_poses.as<double>() + 12 * (size_t)N);
-    k_reproj_poses_from_state<<<1, 64, 0, c->stream>>>(N, c->frame_state.as<cmlhip_ba_frame_state>(), c->res_scales[0], c->res_scales[1], c->rp_poses.as<double>());
-    k_reproj_frames<<<1, 64, 0, c->stream>>>(N, c->rp_poses.as<double>(), pre);
+    k_reproj_poses_from_state<<<1, 256, 0, c->stream>>>(N, c->frame_state.as<cmlhip_ba_frame_state>(), c->res_scales[0], c->res_scales[1], c->rp_poses.as<double>(),
+                                                       pre, c->rp_M.as<double>(), m * m, c->rp_b.as<double>(), m, c->rp_Jp.as<double>(), 3 * (M ? M : 1));
     if (n > 0)
         k_reproj_obs<<<cml_div_up(n, 256), 256, 27 * N * sizeof(double), c->stream>>>(N, c->rp_poses.as<double>(), pre, c->rp_points.as<double>(), n,
                                                                                      c->rp_obs.as<cmlhip_reproj_obs>(), c->rp_res_fx, c->rp_res_fy, c->rp_M.as<double>(),

@@ -11,6 +11,43 @@ from tests import dev_setup as D
 pytestmark = pytest.mark.gpu
 
 
+def gauge_free_pose_update_error(I, xd, xo):
+    """max |P xd - P xo| / max |P xo| over the frame blocks, P = the reference's nullspace projection (computeNullspaces BA.cpp:2365-2417,
+    orthogonalize :1196-1261) as the oracle restates them."""
+    import ctypes as C
+    from tests import oracle_lib as O
+    n = 8 * I.N + 4
+    ns = np.zeros(7 * n)
+    O.lib().orc_ba_nullspaces(I.frames, I.N, C.byref(I.scales), O.ptr(ns, C.c_double))
+    pd, po = O.orthogonalize(xd, ns.reshape(7, n), 1e-5), O.orthogonalize(xo, ns.reshape(7, n), 1e-5)
+    return float(np.abs(pd[4:] - po[4:]).max() / max(np.abs(po[4:]).max(), 1e-300))
+
+
+def reduced_system_conditioning(I, Ho, lam=1e-5):
+    """(cancellation, kappa) of the system the pose update solves: H = (H_L + H_A) diag*(1+lam) - H_sc/(1+lam), Jacobi-scaled as
+    BA.cpp:1312-1316, restricted to the complement of the 7 gauge directions.  cancellation = |H_A| / |H| (how much of H_A the Schur
+    complement cancels), kappa = largest / smallest eigenvalue.  A relative difference eps of the accumulated matrices can move the
+    gauge-free update by up to about eps * cancellation * kappa."""
+    import ctypes as C
+    from tests import oracle_lib as O
+    HAo, bAo, HLo, bLo, Hso, bso = Ho
+    n = 8 * I.N + 4
+    H = HLo + HAo
+    H[np.diag_indices(n)] *= (1 + lam)
+    H = H - Hso / (1 + lam)
+    Sv = 1.0 / np.sqrt(np.diag(H) + 10.0)
+    Hs = (Sv[:, None] * H * Sv[None, :])[4:, 4:]
+    ns = np.zeros(7 * n)
+    O.lib().orc_ba_nullspaces(I.frames, I.N, C.byref(I.scales), O.ptr(ns, C.c_double))
+    Nn = (ns.reshape(7, n)[:, 4:] / Sv[None, 4:]).T                      # gauge directions in the scaled coordinates
+    Q, _ = np.linalg.qr(Nn)
+    Pm = np.eye(n - 4) - Q @ Q.T
+    ev = np.linalg.eigvalsh(Pm @ Hs @ Pm)
+    ev = ev[np.abs(ev) > 1e-12 * np.abs(ev).max()]
+    HAs = (Sv[:, None] * HAo * Sv[None, :])[4:, 4:]
+    return float(np.abs(HAs).max() / np.abs(Hs).max()), float(np.abs(ev).max() / np.abs(ev).min())
+
+
 @pytest.fixture(scope="module", params=["tiny", "small", "A", "B"])     # A, B: BASELINE.json configs[0] and configs[1] at full size
 def pair(request):
     I = S.make_inputs(request.param)
@@ -100,6 +137,17 @@ def test_apply_and_accumulate(pair):
     r = Sv[4:] * (H[4:, 4:] @ xd[4:] - b[4:])
     assert np.linalg.norm(r) <= 2e-4 * np.linalg.norm(Sv[4:] * b[4:]), np.linalg.norm(r) / np.linalg.norm(Sv[4:] * b[4:])
     assert D.rel(xd, xo) < 5e-2
+    # (c) the POSE UPDATE with the gauge removed (orthogonalize, BA.cpp:1196-1261: x minus its component in the 7-dimensional
+    # nullspace of global pose + scale).  The raw x differs in the weakly determined gauge directions (b); what the frames are
+    # actually stepped by is compared here, device against oracle, relative to the largest component of the update:
+    gf = gauge_free_pose_update_error(I, xd, xo)
+    # Measured (profiles/round2_parity_soak.txt, tools/probe_pose_update.py): 1.6e-4 ... 5.7e-4 at config B over six seeds, up to
+    # 9.8e-3 on 300-point windows over 60 seeds, with the accumulated matrices themselves agreeing to 1.0e-7 ... 1.9e-7 (fp32 sums in
+    # another order).  The amplification of ~3e3 is the window's: the update solves H_A - H_sc, a difference in which the Schur
+    # complement cancels H_A 5- to 10-fold, scaled by 1/sqrt(diag + 10) and damped by lambda = 1e-5 only.  A bar of 1e-4 would need
+    # the matrices to agree to ~3e-8, below one fp32 rounding of a single accumulation; the stated bars are 1e-3 at config B and
+    # 2e-2 for windows of a few hundred points.
+    assert gf < (1e-3 if I.P >= 2000 else 2e-2), gf
     # same x into both back-substitutions isolates that kernel
     sto, _ = ob.backsub(xo)
     std, rc = ctx.ba_backsub(xo)
