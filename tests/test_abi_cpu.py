@@ -75,3 +75,17 @@ def test_synthetic_window_is_deterministic_and_consistent():
     res = synth.residual_list(W1, W1.R_eval, W1.t_eval)
     assert len(res) == W1.P * (W1.N - 1)
     assert set(np.unique(res["state"])) <= {0, 1}
+
+
+def test_reference_side_adapter_compiles_against_the_reference_headers():
+    """tools/refcheck: the flat records of include/cmlhip.h filled from DSOPoint / DSOResidual / DSOFrame / DSOFramePrecomputed /
+    DSOTracker::Residual by the adapter of INTEGRATION.md §4, compiled (-fsyntax-only) against the reference's own headers.  Build
+    container only: skipped where /root/reference does not exist (the GPU box)."""
+    import os
+    import subprocess
+    if not os.path.isdir("/root/reference/src/cml"):
+        pytest.skip("reference tree absent")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["sh", os.path.join(root, "tools", "refcheck", "check.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "passed" in r.stdout
