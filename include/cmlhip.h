@@ -172,6 +172,7 @@ typedef struct {
     float  flow[3];
     int    n_pass, pass_level[8]; double pass_rmse[8];   /* level passes in execution order (a level may repeat once, TR.cpp:192-195) */
     int    n_steps; unsigned char step_level[CMLHIP_TRACKER_MAX_STEPS], step_accept[CMLHIP_TRACKER_MAX_STEPS];   /* the trials, TR.cpp:163 */
+    double eval_us, algebra_us;           /* where the workgroup's time went: residual / Hessian evaluations, lane-0 algebra between them */
 } cmlhip_tracker_opt_result;
 int cmlhip_tracker_optimize_batch(cmlhip_ctx* ctx, uint64_t new_image_id, int levels, const double K0[4] /* level-0 fx fy cx cy */,
                                   const double ref_exposure[3], const double init_exposure[3], const cmlhip_tracker_params* prm,

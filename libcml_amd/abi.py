@@ -54,7 +54,8 @@ class TrackerOptResult(C.Structure):
                 ("levelCutoffRepeat", C.c_double * 5), ("relAff", C.c_double * 2), ("covariance", C.c_double * 6),
                 ("flow", C.c_float * 3),
                 ("n_pass", C.c_int), ("pass_level", C.c_int * 8), ("pass_rmse", C.c_double * 8),
-                ("n_steps", C.c_int), ("step_level", C.c_ubyte * TRACKER_MAX_STEPS), ("step_accept", C.c_ubyte * TRACKER_MAX_STEPS)]
+                ("n_steps", C.c_int), ("step_level", C.c_ubyte * TRACKER_MAX_STEPS), ("step_accept", C.c_ubyte * TRACKER_MAX_STEPS),
+                ("eval_us", C.c_double), ("algebra_us", C.c_double)]
 
 
 class BAParams(C.Structure):

@@ -46,6 +46,7 @@ struct ToState {
     float E[5], E_new[5], flow[3], flow_new[3];
     int nT[5], nS[5], nR[5], nT_new[5], nS_new[5], nR_new[5], iterations[5];
     int ctrl, n_steps, n_pass, haveRepeated;
+    long long t_eval, t_alg, t_mark;                   // wall_clock64 ticks (10 ns): evaluations / lane-0 algebra
 };
 
 template <bool HALF>
@@ -289,6 +290,11 @@ __device__ __forceinline__ int to_ctrl(const ToState& S) {
     return c;
 }
 
+// lane 0 books the time since the last mark as algebra, runs the evaluation, books it as evaluation
+#define TO_TIMED_EVAL() do { if (tid == 0) { const long long t_ = wall_clock64(); S.t_alg += t_ - S.t_mark; S.t_mark = t_; } \
+        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red); \
+        if (tid == 0) { const long long t_ = wall_clock64(); S.t_eval += t_ - S.t_mark; S.t_mark = t_; } } while (0)
+
 enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
 
 template <bool HALF>
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l] = 0; S.nT[l] = S.nS[l] = S.nR[l] = S.nT_new[l] = S.nS_new[l] = S.nR_new[l] = 0; S.levelCutoffRepeat[l] = 0; S.iterations[l] = 0; }
         for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k] = 0;
         S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl = TO_CONTINUE;
+        S.t_eval = 0; S.t_alg = 0; S.t_mark = wall_clock64();
     }
     __syncthreads();
     bool failed = false;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         if (tid == 0) { S.levelCutoffRepeat[level] = 1; to_prepare(A, ev, level, to_pose(S.cur_q, S.cur_t), S.a, S.b, 1.0); }
         __syncthreads();
         while (true) {
-            to_eval<HALF>(ev, s_a, s_b, s_tile, s_red);
+            TO_TIMED_EVAL();
             if (tid == 0) {
                 to_finish(A, s_red, S.E[level], S.nT[level], S.nS[level], S.nR[level], S.flow, S.H, S.bv, s_wH9);
                 int c = TO_ITERATE;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                 }
             }
             if (to_ctrl(S) == TO_FAIL) { failed = true; break; }
-            to_eval<HALF>(ev, s_a, s_b, s_tile, s_red);
+            TO_TIMED_EVAL();
             if (tid == 0) {
                 const double incnorm = S.Hn[0];
                 to_finish(A, s_red, S.E_new[level], S.nT_new[level], S.nS_new[level], S.nR_new[level], S.flow_new, S.Hn, S.bn, s_wH9);
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         }
         for (int k = 0; k < 3; k++) out->flow[k] = S.flow[k];
         out->n_steps = S.n_steps; out->n_pass = S.n_pass < 8 ? S.n_pass : 8;
+        out->eval_us = 0.01 * (double)S.t_eval; out->algebra_us = 0.01 * (double)(S.t_alg + (wall_clock64() - S.t_mark));
         for (int k = 0; k < 6; k++) out->covariance[k] = 999999;
         out->relAff[0] = out->relAff[1] = 0;
         if (failed) {
