@@ -22,10 +22,12 @@ class Group:
         self.rank, self.local_rank, self.world = env_world()
         self.dist = None
         self.device = device
-        if self.world > 1:
+        # CML_SHARD_FORCE_DIST=1: form the process group even for one rank (exercises the RCCL path on a single-GPU box)
+        if self.world > 1 or os.environ.get("CML_SHARD_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
