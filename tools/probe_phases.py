@@ -16,15 +16,18 @@ ctx.sync()
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 0, out.ctypes.data_as(C.POINTER(C.c_longlong))))
 def seg(name, a, b): print("%-34s %7.2f us" % (name, (out[b] - out[a]) * 0.01))
 seg("acc pair: load+accumulate loop", 16, 17); seg("acc pair: tile sum + H", 17, 18); seg("acc pair: fp64 stitch", 18, 19)
-seg("solve: loads landed (wave 0)", 48, 54); seg("solve: Sv + barrier", 54, 55); seg("solve: scaled store", 55, 49); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
+seg("solve: load+scale (total)", 48, 49); seg("solve:   loads landed (wave 0)", 48, 54); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
 seg("solve: total", 48, 53)
+nbk = (4 + 8 * W.N - 4 + 15) // 16
+print("solve per block column (elimination | trailing update) us:", " ".join("%.2f|%.2f" % ((out[65 + 2 * k] - out[64 + 2 * k]) * 0.01, ((out[66 + 2 * k] if k + 1 < nbk else out[50]) - out[65 + 2 * k]) * 0.01) for k in range(nbk)))
 
 names = ["linearize", "acc", "system", "solve", "backsub"]
 blk = out[128:].reshape(5, 1024, 2)
 # pipeline order inside one iteration: acc, system, solve, backsub, linearize
-t0 = min(b[b[:, 0] > 0, 0].min() for b in blk)
+t0 = min(b[b[:, 0] > 0, 0].min() for b in blk if (b[:, 0] > 0).any())
 for k in (1, 2, 3, 4, 0):
     b = blk[k]; b = b[b[:, 0] > 0]
+    if len(b) == 0: continue
     st = (b[:, 0] - t0) * 0.01; en = (b[:, 1] - t0) * 0.01; d = en - st
     print("%-10s blocks %4d  first start %7.2f  last start %7.2f  last end %7.2f | block us: min %6.2f med %6.2f max %6.2f" %
           (names[k], len(b), st.min(), st.max(), en.max(), d.min(), np.median(d), d.max()))
