@@ -297,35 +297,44 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
     // component a of a slot computes one of the per-residual scalars: a<4 Hcd[a], a=4 Hdd, a=5 bd, a=6 good count
     float accA = 0.f, accL = 0.f;
     double hostacc = 0.0;
-    for (int base = 0; base < A.pt_stride; base += 8) {      // one pass for N <= 9
-        // two memory round trips per pass: {efsJ code kept by applyRes, static target} of the slot, then the record fields
-        const int slot = p * A.pt_stride + base + s;
-        const int code = A.point_code[slot], tgl = A.point_tgt[slot];
+    // Round trips: {efsJ code kept by applyRes, static target} of EVERY slot of the point first (up to 4 passes of 8 slots: one trip
+    // for all of them), then per pass the record fields — every load unconditional on clamped indices, so that the next pass's loads
+    // are in flight under the arithmetic of the current one (one pass for N <= 9).
+    int codes[4], tgls[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+        const int slot = p * A.pt_stride + min(8 * ps + s, A.pt_stride - 1);
+        const bool live = 8 * ps + s < A.pt_stride;
+        const int cd = A.point_code[slot], tg = A.point_tgt[slot];
+        codes[ps] = live ? cd : -1; tgls[ps] = live ? tg : 0;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+        if (8 * ps >= A.pt_stride) break;                     // wave-uniform
+        const int code = codes[ps], tgl = tgls[ps];
         const bool good = code >= 0;
         const bool lin = good && (tgl & 256);
-        double sh = 0.0;
-        float val = 0.f;
-        if (good) {
-            const int r = code >> 1;
-            const float* PS = A.r_jpjdf + PS_STRIDE * (size_t)r;      // one 64-B line per residual: JpJdF + the residual's terms of Hcd, Hdd, bd (kept by applyRes)
-            const int t = tgl & 255;
-            const int q = host + t * A.N;
-            const float4 v0 = *reinterpret_cast<const float4*>(PS), v1 = *reinterpret_cast<const float4*>(PS + 4);
-            const double4_* AH = reinterpret_cast<const double4_*>(X.adH + 64 * (size_t)q + 8 * a);
-            const double4_* AT = reinterpret_cast<const double4_*>(X.adT + 64 * (size_t)q + 8 * a);
-            const double4_ h0 = AH[0], h1 = AH[1], t0 = AT[0], t1 = AT[1];
-            val = PS[8 + (a < 6 ? a : 0)];                    // Hcd[a] (a < 4), Hdd (a == 4), bd (a == 5)
-            if (a == 5 && lin) val = 0.f;                     // bdL: k_ba_point_bdL
-            if (a == 6) val = 1.f;
-            if (a == 7) val = 0.f;
-            double st = 0.0;
-            const double v[8] = {(double)v0.x, (double)v0.y, (double)v0.z, (double)v0.w, (double)v1.x, (double)v1.y, (double)v1.z, (double)v1.w};
+        const int r = max(code, 0) >> 1;
+        const float* PS = A.r_jpjdf + PS_STRIDE * (size_t)r;          // one 64-B line per residual: JpJdF + the residual's terms of Hcd, Hdd, bd (kept by applyRes)
+        const int t = min(max(tgl, 0) & 255, A.N - 1);        // (clamped: empty slots load pair 0..N-1 and are masked)
+        const int q = host + t * A.N;
+        const float4 v0 = *reinterpret_cast<const float4*>(PS), v1 = *reinterpret_cast<const float4*>(PS + 4);
+        const double4_* AH = reinterpret_cast<const double4_*>(X.adH + 64 * (size_t)q + 8 * a);
+        const double4_* AT = reinterpret_cast<const double4_*>(X.adT + 64 * (size_t)q + 8 * a);
+        const double4_ h0 = AH[0], h1 = AH[1], t0 = AT[0], t1 = AT[1];
+        float val = PS[8 + (a < 6 ? a : 0)];                  // Hcd[a] (a < 4), Hdd (a == 4), bd (a == 5)
+        if (a == 5 && lin) val = 0.f;                         // bdL: k_ba_point_bdL
+        if (a == 6) val = 1.f;
+        if (a == 7) val = 0.f;
+        if (!good) val = 0.f;
+        double sh = 0.0, st = 0.0;
+        const double v[8] = {(double)v0.x, (double)v0.y, (double)v0.z, (double)v0.w, (double)v1.x, (double)v1.y, (double)v1.z, (double)v1.w};
 #pragma unroll
-            for (int j = 0; j < 4; j++) { sh += h0[j] * v[j]; st += t0[j] * v[j]; }
+        for (int j = 0; j < 4; j++) { sh += h0[j] * v[j]; st += t0[j] * v[j]; }
 #pragma unroll
-            for (int j = 0; j < 4; j++) { sh += h1[j] * v[4 + j]; st += t1[j] * v[4 + j]; }
-            srow[4 + 8 * t + a] = st;                          // one residual per (point, target): plain store
-        }
+        for (int j = 0; j < 4; j++) { sh += h1[j] * v[4 + j]; st += t1[j] * v[4 + j]; }
+        if (good) srow[4 + 8 * t + a] = st;                   // one residual per (point, target): plain store
+        else sh = 0.0;
         // every lane takes part in every shuffle; LINEARIZED residuals (rare) are routed to the L sums by masking
         accA += sum_slots(lin ? 0.f : val);
         accL += sum_slots(lin ? val : 0.f);
@@ -1091,10 +1100,39 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
 }
 
 // ------------------------------------------------------------------------------------------------ K6
+// xAd[(host*N + target)*8 + j] = x_host . adHost(:, j) + x_target . adTarget(:, j)   (BA.cpp:1447)
+__device__ __forceinline__ double xad_entry(const double* __restrict__ adH, const double* __restrict__ adT, const double* __restrict__ x, int N, int e) {
+    const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N;
+    const double* AH = adH + 64 * (size_t)(h + N * t); const double* AT = adT + 64 * (size_t)(h + N * t);
+    double s = 0, s2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { s += x[4 + 8 * h + i] * AH[i * 8 + j]; s2 += x[4 + 8 * t + i] * AT[i * 8 + j]; }
+    return s + s2;
+}
+// Wide windows: every back-substitution workgroup needs the whole N*N*8 table (1 KB of adjoints behind each pair) — built once here
+// instead of once per workgroup (251 workgroups x 400 KB at 20 frames).
+__global__ __launch_bounds__(256) void k_ba_xad(const double* __restrict__ adH, const double* __restrict__ adT, const double* __restrict__ x,
+                                                int N, double* __restrict__ xad, const int* __restrict__ stop, FrameStepArgs F) {
+    if (stop && *stop) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * N * 8) return;
+    xad[e] = xad_entry(adH, adT, x, N, e);
+    if (F.on) {
+        // the same adjoint columns, against the STEPPED delta: adHTd of computeDelta (BA.cpp:1120-1135) for the state the frame
+        // workgroup of the back-substitution is about to write (this launch only reads the old state)
+        const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N, idx = h + N * t;
+        const double* AH = adH + 64 * (size_t)idx; const double* AT = adT + 64 * (size_t)idx;
+        double s = 0, s2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { s += frame_stepped_delta(F.fs, x, h, i) * AH[i * 8 + j]; s2 += frame_stepped_delta(F.fs, x, t, i) * AT[i * 8 + j]; }
+        F.adHTd[8 * (size_t)idx + j] = (float)(s + s2);
+    }
+}
+
 // back-substitution (BA.cpp:1427-1487) + optional point update (doStepFromBackup, BA.cpp:976-994)
 __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
                                                     const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
-                                                    int do_step, FrameStepArgs F) {
+                                                    int do_step, FrameStepArgs F, const double* __restrict__ xad) {
     extern __shared__ __attribute__((aligned(16))) double s_xAd[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
     __shared__ float s_red[3][4];
     const int N = A.N;
@@ -1105,13 +1143,10 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
         DBG_BLK_END(A.dbg, 4);
         return;
     }
-    for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) {
-        const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N;
-        const double* AH = adH + 64 * (size_t)(h + N * t); const double* AT = adT + 64 * (size_t)(h + N * t);
-        double s = 0, s2 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { s += x[4 + 8 * h + i] * AH[i * 8 + j]; s2 += x[4 + 8 * t + i] * AT[i * 8 + j]; }
-        s_xAd[e] = s + s2;
+    if (xad) {                                               // wide windows: the table was built once by k_ba_xad
+        for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) s_xAd[e] = xad[e];
+    } else {
+        for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) s_xAd[e] = xad_entry(adH, adT, x, N, e);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) sum->nonfinite = 0;
     __syncthreads();
@@ -1322,8 +1357,16 @@ int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
         F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
     }
     if (cml_div_up(A.P * 8, 256) + F.on == 0) return CMLHIP_OK;     // no points and no frame step: nothing to launch (a zero grid is a HIP error)
+    const double* xad = nullptr;
+    if (A.N >= 12 && A.P >= 2048) {                                  // many workgroups x a large table: build it once
+        if (int rc = cml_ensure(c, c->xad, 8 * (size_t)A.N * A.N * 8)) return rc;
+        k_ba_xad<<<cml_div_up(A.N * A.N * 8, 256), 256, 0, c->stream>>>(c->adH.as<double>(), c->adT.as<double>(), c->xvec.as<double>(), A.N,
+                                                                       c->xad.as<double>(), A.ctl ? &A.ctl->stop : nullptr, F);
+        xad = c->xad.as<double>();
+        F.adhtd_done = F.on;
+    }
     CML_LAUNCH_EV(c, k_ba_backsub, cml_div_up(A.P * 8, 256) + F.on, 256, sh, A, (const double*)c->adH.as<double>(), (const double*)c->adT.as<double>(),
-                  (const double*)c->xvec.as<double>(), c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0, F);
+                  (const double*)c->xvec.as<double>(), c->scal.as<LinSummary>(), c->step_partial.as<float>(), do_step ? 1 : 0, F, xad);
     return CMLHIP_OK;
 }
 int cml_launch_backup_points(cmlhip_ctx* c, const BAArgs& A) {

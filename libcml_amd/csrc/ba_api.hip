@@ -183,6 +183,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 31) / 32 + 1));
     ENS(c->G, 8 * ((size_t)P * ldg + P));
     ENS(c->syrk_part, 8 * 256 * (size_t)(ntile * (ntile + 1) / 2) * cml_sys_slices(P));
+    ENS(c->xad, 8 * 8 * (size_t)N * N);
     ENS(c->solve_image, 8 * ((size_t)(ntile * (ntile + 1) / 2) * 16 * 17 + 32 * (size_t)ntile));      // k_ba_assemble (wide windows)
     ENS(c->scal, 1024);
 #undef ENS

@@ -16,6 +16,7 @@ struct FrameStepArgs {
     double* dprior;                // 8N: state - prior_zero
     double sc[4];                  // scale translation / rotation / a / b
     int N, on;
+    int adhtd_done;                // wide windows: adHTd of the stepped state was already written by k_ba_xad
     float* frame_sums;             // optional: sumA sumB sumT sumR of doStepFromBackup (BA.cpp:957-972) for the convergence test
 };
 
@@ -84,6 +85,7 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
         double a, b;
         Exposure(s_aff[h][0], s_aff[h][1], s_aff[h][2]).to(Exposure(s_aff[t][0], s_aff[t][1], s_aff[t][2]), a, b);
         P.aff_a = a; P.aff_b = b;
+        if (F.adhtd_done) continue;
         const int idx = h + t * N;                                     // computeDelta, BA.cpp:1120-1135
         const double* AH = F.adH + 64 * (size_t)idx; const double* AT = F.adT + 64 * (size_t)idx;
         for (int j = 0; j < 8; j++) {
@@ -93,5 +95,18 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
             F.adHTd[8 * (size_t)idx + j] = (float)(s + s2);
         }
     }
+}
+
+// state + step - state_zero of frame f, entry k, exactly as frame_step_block forms it (setStep's non-finite and fix_pose rules included)
+__device__ __forceinline__ double frame_stepped_delta(const cmlhip_ba_frame_state* fs, const double* __restrict__ x, int f, int k) {
+    const cmlhip_ba_frame_state& S = fs[f];
+    bool fin = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) fin = fin && isfinite(-x[4 + 8 * f + i]);
+    double step = -x[4 + 8 * f + k];
+    if (!fin) step = 0.0;
+    if (S.fix_pose && k < 6) step = 0.0;
+    const double st = S.state[k] + step;
+    return st - S.state_zero[k];
 }
 #pragma clang fp contract(fast)

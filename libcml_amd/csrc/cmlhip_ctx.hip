@@ -210,7 +210,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
                      &c->trk_hyp, &c->trk_opt_out, &c->rs_tiles, &c->rs_tile_off, &c->rs_part, &c->r_idepth, &c->point_res, &c->r_px, &c->r_py, &c->r_colors, &c->r_weights, &c->by_point_off, &c->by_point, &c->by_pair_off, &c->by_pair, &c->pair_code, &c->pair_pos, &c->point_code, &c->point_tgt, &c->point_pos, &c->frame_state, &c->pre_w2c, &c->null_basis, &c->pt_mask, &c->marg_scratch, &c->tr_points, &c->tr_pairs, &c->tr_out, &c->tr_resident, &c->ini_points, &c->ini_partial, &c->pnp_matches, &c->pnp_flags, &c->pnp_out, &c->lba_frames, &c->lba_cams, &c->lba_points, &c->lba_off, &c->lba_edges, &c->lba_err, &c->lba_flags, &c->lba_work, &c->newframe_res, &c->acc_pair[0],
                      &c->acc_pair[1], &c->acc_num[0], &c->acc_num[1], &c->pair_blocks, &c->adH, &c->adT, &c->adHTd,
                      &c->vec_small, &c->HA, &c->bA, &c->HL, &c->bL, &c->Hsc, &c->bsc, &c->HM, &c->bM, &c->xvec, &c->G,
-                     &c->syrk_part, &c->solve_image, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,
+                     &c->syrk_part, &c->solve_image, &c->xad, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,
                      &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }

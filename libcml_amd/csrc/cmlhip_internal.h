@@ -112,6 +112,7 @@ struct cmlhip_ctx {
     int n_lin_partial = 0; double last_lambda = 1e-5; bool last_have_hm = false; double sys_lambda = 1e-5;
     DevBuf G;                                                 // P x ldg doubles (Schur rows [g | bdSum])
     DevBuf syrk_part;                                         // partial SYRK tiles
+    DevBuf xad;                                               // wide windows: x . adjoints table of the back-substitution (k_ba_xad)
     DevBuf solve_image;                                       // wide windows: the assembled, scaled LM system in the solver's LDS layout
     DevBuf scal;                                              // small scalar scratch (energy partials, counters, th)
     DevBuf lin_partial;                                       // per-block energy / count partials
