@@ -73,43 +73,115 @@ __device__ void to_inv3f(const float m[9], float o[9]) {
 #undef MM
 }
 
-// x = A.ldlt().solve(b), Eigen 3.4.0 semantics (Cholesky/LDLT.h:300-396,560-600), n <= 8 — the host mirror's ldltSolveSmall
-// (lane 0 runs these alone: every array is an LDS scratchpad — a dynamically indexed local array would live in scratch memory,
-//  hundreds of cycles per dependent access)
-__device__ bool to_ldlt_solve(const double* Ain, const double* b, int n, double* x, double* A /* 64 */, double* temp /* 8 */, int* tr /* 8 */) {
-    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
-#define M(i, j) A[(i) * n + (j)]
-    if (n == 1) tr[0] = 0;
-    else
-        for (int k = 0; k < n; k++) {
-            int big = k; double best = fabs(M(k, k));
-            for (int i = k + 1; i < n; i++) if (fabs(M(i, i)) > best) { best = fabs(M(i, i)); big = i; }
-            tr[k] = big;
-            if (k != big) {
-                for (int j = 0; j < k; j++) { const double s = M(k, j); M(k, j) = M(big, j); M(big, j) = s; }
-                for (int i = big + 1; i < n; i++) { const double s = M(i, k); M(i, k) = M(i, big); M(i, big) = s; }
-                { const double s = M(k, k); M(k, k) = M(big, big); M(big, big) = s; }
-                for (int i = k + 1; i < big; i++) { const double s = M(i, k); M(i, k) = M(big, i); M(big, i) = s; }
+// x = A.ldlt().solve(b), Eigen 3.4.0 semantics (Cholesky/LDLT.h:300-396,560-600), n <= 8 — the host mirror's ldltSolveSmall —
+// by the 64 lanes of ONE wave, in registers: lane (l & 7) holds row l & 7 of the (symmetric, mirrored from the lower
+// triangle Eigen reads) damped system.  Every operation of the scalar algorithm keeps its operands and its order — the left-looking update
+// of column k is one lane per row, the sums over j < k run in j order, `/= akk` is the IEEE division — but nothing goes through
+// LDS: the pivot search, row k of L and the pivots travel by v_readlane (k is a compile-time lane, the pivot index a scalar),
+// the symmetric transposition is a two-lane row exchange plus an in-lane column exchange.  The substitutions run on wave-uniform
+// copies (all lanes the same numbers).  17 us -> 2 us per Levenberg-Marquardt trial against lane 0 alone on LDS scratchpads.
+// Hs: 8x8 row-major (LDS), rows/cols taken through map[] (the 7x7 / stitched / 6x6 variants of TR.cpp:96-119), diagonal * (1 + lambda).
+__device__ __forceinline__ double to_rl(double v, int lane) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+__device__ bool to_ldlt_solve_wave(const double* Hs, const double* bs, const double lambda, const int n, const int map6, double (&xs)[8]) {
+    const int i = threadIdx.x & 7;
+    auto mp = [&](int a) { return (a == 6) ? map6 : a; };
+    double row[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int r = max(i, j), c = min(i, j);
+        double v = (r < n) ? Hs[mp(r) * 8 + mp(c)] : 0.0;
+        if (r == c) v *= (1 + lambda);
+        row[j] = (r < n) ? v : 0.0;
+    }
+    int tr[8]; double dd[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { tr[k] = k; dd[k] = 0.0; }
+    bool stop = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= n || stop) continue;                        // wave-uniform
+        int big = k; double best = fabs(to_rl(row[k], k));
+#pragma unroll
+        for (int ii = k + 1; ii < 8; ii++)
+            if (ii < n) { const double v = fabs(to_rl(row[ii], ii)); if (v > best) { best = v; big = ii; } }
+        tr[k] = big;
+        if (big != k) {                                      // symmetric transposition k <-> big
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double a = to_rl(row[j], k), bq = to_rl(row[j], big);
+                row[j] = (i == k) ? bq : ((i == big) ? a : row[j]);
             }
-            if (k > 0) {
-                double s = 0;
-                for (int j = 0; j < k; j++) { temp[j] = M(j, j) * M(k, j); s += M(k, j) * temp[j]; }
-                M(k, k) -= s;
-                for (int i = k + 1; i < n; i++) { double s2 = 0; for (int j = 0; j < k; j++) s2 += M(i, j) * temp[j]; M(i, k) -= s2; }
-            }
-            const double akk = M(k, k);
-            if (k == 0 && !(fabs(akk) > 0.0)) { for (int j = 0; j < n; j++) tr[j] = j; break; }
-            if (fabs(akk) > 0.0) for (int i = k + 1; i < n; i++) M(i, k) /= akk;
+#pragma unroll
+            for (int j = k + 1; j < 8; j++)
+                if (j == big) { const double t = row[k]; row[k] = row[j]; row[j] = t; }
         }
-    for (int i = 0; i < n; i++) x[i] = b[i];
-    for (int k = 0; k < n; k++) if (tr[k] != k) { const double s = x[k]; x[k] = x[tr[k]]; x[tr[k]] = s; }
-    for (int i = 0; i < n; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= M(i, j) * x[j]; x[i] = s; }
-    for (int i = 0; i < n; i++) x[i] = (fabs(M(i, i)) > 2.2250738585072014e-308) ? x[i] / M(i, i) : 0.0;
-    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < n; j++) s -= M(j, i) * x[j]; x[i] = s; }
-    for (int k = n - 1; k >= 0; k--) if (tr[k] != k) { const double s = x[k]; x[k] = x[tr[k]]; x[tr[k]] = s; }
-#undef M
-    for (int i = 0; i < n; i++) if (!isfinite(x[i])) return false;
-    return true;
+        double akk = to_rl(row[k], k);
+        if (k > 0) {
+            double temp[8], s = 0;
+#pragma unroll
+            for (int j = 0; j < k; j++) { const double lkj = to_rl(row[j], k); temp[j] = dd[j] * lkj; s += lkj * temp[j]; }
+            akk -= s;
+            double s2 = 0;
+#pragma unroll
+            for (int j = 0; j < k; j++) s2 += row[j] * temp[j];
+            if (i > k) row[k] -= s2;
+        }
+        if (i == k) row[k] = akk;
+        if (k == 0 && !(fabs(akk) > 0.0)) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) tr[j] = j;
+            stop = true;
+        } else if (fabs(akk) > 0.0) {
+            if (i > k) row[k] /= akk;
+        }
+        dd[k] = akk;
+    }
+    if (stop) {                                              // Eigen leaves the matrix untouched: D is its diagonal, L what sits below it
+#pragma unroll
+        for (int k = 0; k < 8; k++) dd[k] = to_rl(row[k], k);
+    }
+    // substitutions on wave-uniform copies: x = P^T L^-T D^-1 L^-1 P b (LDLT.h:560-600)
+#pragma unroll
+    for (int k = 0; k < 8; k++) xs[k] = (k < n) ? -bs[mp(k)] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k < n && tr[k] != k) {
+#pragma unroll
+            for (int j = k + 1; j < 8; j++) if (j == tr[k]) { const double t = xs[k]; xs[k] = xs[j]; xs[j] = t; }
+        }
+    double Lm[8][8];
+#pragma unroll
+    for (int a = 1; a < 8; a++)
+#pragma unroll
+        for (int j = 0; j < a; j++) Lm[a][j] = to_rl(row[j], a);
+#pragma unroll
+    for (int a = 0; a < 8; a++) if (a < n) { double t = xs[a];
+#pragma unroll
+        for (int j = 0; j < a; j++) t -= Lm[a][j] * xs[j];
+        xs[a] = t; }
+#pragma unroll
+    for (int a = 0; a < 8; a++) if (a < n) xs[a] = (fabs(dd[a]) > 2.2250738585072014e-308) ? xs[a] / dd[a] : 0.0;
+#pragma unroll
+    for (int a = 7; a >= 0; a--) if (a < n) { double t = xs[a];
+#pragma unroll
+        for (int j = a + 1; j < 8; j++) if (j < n) t -= Lm[j][a] * xs[j];
+        xs[a] = t; }
+#pragma unroll
+    for (int k = 7; k >= 0; k--)
+        if (k < n && tr[k] != k) {
+#pragma unroll
+            for (int j = k + 1; j < 8; j++) if (j == tr[k]) { const double t = xs[k]; xs[k] = xs[j]; xs[j] = t; }
+        }
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 8; a++) if (a < n && !isfinite(xs[a])) ok = false;
+    return ok;
 }
 __device__ void to_inverse8(const double* Ain, double* Ai, double* A /* 64 */) {           // hessian.inverse() (TR.cpp:243): Gauss-Jordan with partial pivoting
     const int n = 8;
@@ -266,20 +338,22 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
     __syncthreads();
 }
 
-// lane 0: the level's sums -> Residual slots and the scaled 8x8 system (TR.cpp:405-414, 472-490)
-__device__ void to_finish(const TrkOptArgs& A, const float* s, float& E, int& nT, int& nS, int& nR, float flow[3], double* H, double* b, float* H9 /* 81, LDS */) {
-    E = s[45]; nT = (int)s[49]; nS = (int)s[50]; nR = (int)s[51];
+// wave 0: the level's sums -> Residual slots (lane 0) and the scaled 8x8 system, one entry per lane (TR.cpp:405-414, 472-490);
+// s holds the upper triangle of the 9x9 accumulator in row order (entry (r, c >= r) at 9r - r(r-1)/2 + c - r), then the counters
+__device__ __forceinline__ void to_finish(const TrkOptArgs& A, const float* s, float& E, int& nT, int& nS, int& nR, float flow[3], double* H, double* b) {
+    const int l = threadIdx.x;                             // < 64
+    if (l == 0) {
+        E = s[45]; nT = (int)s[49]; nS = (int)s[50]; nR = (int)s[51];
+        flow[0] = s[46] / (s[48] + 0.1f); flow[1] = 0; flow[2] = s[47] / (s[48] + 0.1f);
+    }
     const int numWarped = (int)s[52];
-    flow[0] = s[46] / (s[48] + 0.1f); flow[1] = 0; flow[2] = s[47] / (s[48] + 0.1f);
-    int idx = 0;
-    for (int r = 0; r < 9; r++) for (int cc = r; cc < 9; cc++) { H9[r * 9 + cc] = H9[cc * 9 + r] = s[idx]; idx++; }
     int npad = numWarped;
     while (npad % 4 != 0) npad++;
-    const double sc[8] = {A.scale_rot, A.scale_rot, A.scale_rot, A.scale_trans, A.scale_trans, A.scale_trans, A.scale_a, A.scale_b};
-    for (int r = 0; r < 8; r++) {
-        for (int cc = 0; cc < 8; cc++) H[r * 8 + cc] = ((double)H9[r * 9 + cc] / (double)npad) * sc[cc] * sc[r];
-        b[r] = ((double)H9[r * 9 + 8] / (double)npad) * sc[r];
-    }
+    auto sc = [&](int k) { return (double)(k < 3 ? A.scale_rot : (k < 6 ? A.scale_trans : (k == 6 ? A.scale_a : A.scale_b))); };
+    auto h9 = [&](int r, int c) { const int lo = min(r, c), hi = max(r, c); return s[9 * lo - (lo * (lo - 1)) / 2 + (hi - lo)]; };
+    const int r = l >> 3, cc = l & 7;
+    H[r * 8 + cc] = ((double)h9(r, cc) / (double)npad) * sc(cc) * sc(r);
+    if (l < 8) b[l] = ((double)h9(l, 8) / (double)npad) * sc(l);
 }
 
 // lane 0's decision to every lane: read between two barriers, so that lane 0 may overwrite it right away
@@ -304,9 +378,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ float s_red[64];
     __shared__ ToEval ev;
     __shared__ ToState S;
-    __shared__ double s_wA[64], s_wD[64], s_wS[64], s_wt[8], s_wx[8], s_wn[8], s_wb[8], s_winc[8], s_wincS[8];   // lane 0's scratchpads
-    __shared__ int s_wtr[8];
-    __shared__ float s_wH9[81];
+    __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
     const int tid = threadIdx.x, hyp = blockIdx.x;
     cmlhip_tracker_opt_result* out = A.out + hyp;
     const int maxIterations[5] = {10, 20, 50, 50, 50};                               // TR.cpp:23
@@ -327,8 +399,8 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         __syncthreads();
         while (true) {
             TO_TIMED_EVAL();
+            if (tid < 64) to_finish(A, s_red, S.E[level], S.nT[level], S.nS[level], S.nR[level], S.flow, S.H, S.bv);
             if (tid == 0) {
-                to_finish(A, s_red, S.E[level], S.nT[level], S.nS[level], S.nR[level], S.flow, S.H, S.bv, s_wH9);
                 int c = TO_ITERATE;
                 if (S.nT[level] < 20) c = TO_FAIL;                                                           // :65-69
                 else if ((S.nS[level] / (double)S.nT[level]) > 0.6 && S.levelCutoffRepeat[level] < 50) {     // :71-75
@@ -344,35 +416,21 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         if (failed) break;
         // ---- Levenberg-Marquardt trials, TR.cpp:91-181
         for (int iteration = 0; iteration < maxIterations[level]; iteration++) {
-            if (tid == 0) {
+            if (tid < 64) {                                                                                 // wave 0: the damped solve, :96-119
+                // which system: 8x8 (a and b), top-left 7x7 (a only), column/row 6 <- 7 stitched 7x7 (b only: HlStitch, bStitch[6] = b[7]),
+                // top-left 6x6 (neither); the increment's lanes the variant does not solve stay 0
+                const int nsolve = (A.opt_a && A.opt_b) ? 8 : ((A.opt_a || A.opt_b) ? 7 : 6);
+                const int map6 = (!A.opt_a && A.opt_b) ? 7 : 6;
+                double xs[8];
+                const bool ok = to_ldlt_solve_wave(S.H, S.bv, S.lambda, nsolve, map6, xs);
+              if (tid == 0) {
                 S.iterations[level] = iteration + 1;
-                double* D = s_wD; double* inc = s_winc; double* nbv = s_wn;
+                double* inc = s_winc;
                 for (int i = 0; i < 8; i++) inc[i] = 0;
-                for (int i = 0; i < 64; i++) D[i] = S.H[i];
-                for (int i = 0; i < 8; i++) { D[i * 8 + i] *= (1 + S.lambda); nbv[i] = -S.bv[i]; }
-                bool ok = true;
-                if (A.opt_a && A.opt_b) ok = to_ldlt_solve(D, nbv, 8, inc, s_wA, s_wt, s_wtr);                // :96-98
-                else if (A.opt_a && !A.opt_b) {                                                             // :99-102
-                    double* Sm = s_wS; double* x7 = s_wx;
-                    for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) Sm[i * 7 + j] = D[i * 8 + j];
-                    ok = to_ldlt_solve(Sm, nbv, 7, x7, s_wA, s_wt, s_wtr);
-                    for (int i = 0; i < 7; i++) inc[i] = x7[i];
-                    inc[7] = 0;
-                } else if (!A.opt_a && A.opt_b) {                                                           // :103-114
-                    double* Sm = s_wS; double* x7 = s_wx; double* nb7 = s_wb;
-                    // HlStitch: column 6 <- column 7, row 6 <- row 7 of the damped system, bStitch[6] = b[7]; only its top-left 7x7 is solved
-                    for (int i = 0; i < 7; i++)
-                        for (int j = 0; j < 7; j++) Sm[i * 7 + j] = D[(i == 6 ? 7 : i) * 8 + (j == 6 ? 7 : j)];
-                    for (int i = 0; i < 7; i++) nb7[i] = -(i == 6 ? S.bv[7] : S.bv[i]);
-                    ok = to_ldlt_solve(Sm, nb7, 7, x7, s_wA, s_wt, s_wtr);
-                    for (int i = 0; i < 6; i++) inc[i] = x7[i];
-                    inc[6] = 0; inc[7] = x7[6];
-                } else {                                                                                    // :115-119
-                    double* Sm = s_wS; double* x6 = s_wx;
-                    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Sm[i * 6 + j] = D[i * 8 + j];
-                    ok = to_ldlt_solve(Sm, nbv, 6, x6, s_wA, s_wt, s_wtr);
-                    for (int i = 0; i < 6; i++) inc[i] = x6[i];
-                }
+                if (A.opt_a && A.opt_b) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[6] = xs[6]; inc[7] = xs[7]; }
+                else if (A.opt_a) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[6] = xs[6]; }
+                else if (A.opt_b) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[7] = xs[6]; }
+                else { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; }
                 if (!ok) S.ctrl = TO_FAIL;                                                                  // :121-138
                 else {
                     double extrapFac = 1;
@@ -388,28 +446,33 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     to_prepare(A, ev, level, nw, S.na, S.nb, S.levelCutoffRepeat[level]);
                     S.ctrl = TO_ITERATE;
                 }
+              }
             }
             if (to_ctrl(S) == TO_FAIL) { failed = true; break; }
             TO_TIMED_EVAL();
-            if (tid == 0) {
-                const double incnorm = S.Hn[0];
-                to_finish(A, s_red, S.E_new[level], S.nT_new[level], S.nS_new[level], S.nR_new[level], S.flow_new, S.Hn, S.bn, s_wH9);
-                const bool accept = (S.E_new[level] / (double)S.nT_new[level]) < (S.E[level] / (double)S.nT[level]);   // :163
-                if (S.n_steps < CMLHIP_TRACKER_MAX_STEPS) { out->step_level[S.n_steps] = (unsigned char)level; out->step_accept[S.n_steps] = accept ? 1 : 0; }
-                S.n_steps++;
-                if (accept) {
-                    for (int i = 0; i < 64; i++) S.H[i] = S.Hn[i];
-                    for (int i = 0; i < 8; i++) S.bv[i] = S.bn[i];
-                    for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l]; S.nT[l] = S.nT_new[l]; S.nS[l] = S.nS_new[l]; S.nR[l] = S.nR_new[l]; }   // oldResidual = newResidual (whole struct), :167
-                    for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k];
-                    for (int i = 0; i < 4; i++) S.cur_q[i] = S.nw_q[i];
-                    for (int i = 0; i < 3; i++) S.cur_t[i] = S.nw_t[i];
-                    S.a = S.na; S.b = S.nb;
-                    S.lambda *= 0.5;
-                } else {
-                    S.lambda *= 4;
+            if (tid < 64) {
+                const double incnorm = S.Hn[0];                                                             // (lane 0's own note, read before its slot is rewritten)
+                to_finish(A, s_red, S.E_new[level], S.nT_new[level], S.nS_new[level], S.nR_new[level], S.flow_new, S.Hn, S.bn);
+                const bool accept = ((double)s_red[45] / (double)(int)s_red[49]) < (S.E[level] / (double)S.nT[level]);   // E_new / n_new < E / n, :163
+                if (accept) {                                                                               // every lane moves the entries it wrote
+                    S.H[tid] = S.Hn[tid];
+                    if (tid < 8) S.bv[tid] = S.bn[tid];
                 }
-                S.ctrl = (incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE;                                     // :176-179
+                if (tid == 0) {
+                    if (S.n_steps < CMLHIP_TRACKER_MAX_STEPS) { out->step_level[S.n_steps] = (unsigned char)level; out->step_accept[S.n_steps] = accept ? 1 : 0; }
+                    S.n_steps++;
+                    if (accept) {
+                        for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l]; S.nT[l] = S.nT_new[l]; S.nS[l] = S.nS_new[l]; S.nR[l] = S.nR_new[l]; }   // oldResidual = newResidual (whole struct), :167
+                        for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k];
+                        for (int i = 0; i < 4; i++) S.cur_q[i] = S.nw_q[i];
+                        for (int i = 0; i < 3; i++) S.cur_t[i] = S.nw_t[i];
+                        S.a = S.na; S.b = S.nb;
+                        S.lambda *= 0.5;
+                    } else {
+                        S.lambda *= 4;
+                    }
+                    S.ctrl = (incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE;                                 // :176-179
+                }
             }
             if (to_ctrl(S) == TO_LEVEL_DONE) break;
         }
