@@ -155,10 +155,11 @@ def test_apply_and_accumulate(pair):
     assert np.abs(sto - std).max() <= 5e-5 * np.abs(sto).max()
 
 
-@pytest.mark.parametrize("N,P", [(12, 1100), (9, 700)])
+@pytest.mark.parametrize("N,P", [(12, 1100), (9, 700), (14, 2100)])
 def test_system_and_solver_wide_window(N, P):
     """Windows wider than the default: several Schur slices per tile (P > 512), block columns whose panel does not fit
-    one wave (8N+4 > 64+...), with and without the calibration block and a marginalisation prior.  Bars as above:
+    one wave (8N+4 > 64+...), systems assembled by k_ba_assemble (more than 16 blocks), with and without the calibration block and a
+    marginalisation prior.  Bars as above:
     Schur/Hessian blocks at fp32 accumulation tolerance, the factorisation isolated on the DEVICE's matrices at 1e-7."""
     I = S.make_inputs((N, P, 320, 240, 3, 260.0, 260.0, 159.5, 119.5))
     ob = S.OracleBA(I)
@@ -184,6 +185,11 @@ def test_system_and_solver_wide_window(N, P):
                 assert D.rel(xd, xo) < 1e-7, (optcal, hm is not None, D.rel(xd, xo))
                 if not optcal:
                     assert np.all(xd[:4] == 0)
+        # the back-substitution on the same x (from 12 frames x 2048 points on, its x . adjoint table comes from k_ba_xad)
+        sto, _ = ob.backsub(xo)
+        std, rc = ctx.ba_backsub(xo)
+        assert rc == 0
+        assert np.abs(sto - std).max() <= 5e-5 * np.abs(sto).max()
     finally:
         ctx.close()
 
