@@ -516,9 +516,16 @@ __device__ __forceinline__ double frame_sum(const double* pb, int N, int a, int 
 //   then N+1         row blocks of H_A, H_L (+ priors) and Hb = (H_L + H_M) + H_A (BA.cpp:1299), the lambda-independent part of
 //                    the final system: workgroup 0 = calibration rows, workgroup 1+a = the 8 rows of frame a.
 #define SYS_NW 8
+// SYRK trip: 4 * SYS_U points per wave (3 * SYS_U loads in flight per lane, SYS_U MFMAs on two accumulators).  Small trips on
+// purpose: at 60 VGPRs three 512-thread workgroups share a CU (6 waves per SIMD), so the 549 workgroups of a 20-frame window are
+// resident at once and the loads of one wave hide under the matrix instructions of the others.  Measured (config E / B, us per
+// iteration): SYS_U 16 at 1 workgroup per CU 162.6 / 52.0 (three dispatch rounds at E), 12 at 2: 159.4 / 54.1, 8 at 2: 156.8 / 52.9,
+// 6 at 3: 157.4 / 52.0, 4 at 3: 155.5 / 51.7.
+#define SYS_U 4
+#define SYS_WPE 6
 __device__ __forceinline__ int sys_tile_index(int ti, int tj, int ntile) { return ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti); }
 
-__global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
+__global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SYS_WPE, SYS_WPE))) void k_ba_system(SysArgs S) {
     __shared__ double s_part[SYS_NW][256];
     __shared__ double s_f[2][FS_STRIDE];          // [ACTIVE | LINEARIZED] D (64) C (32) B (8) of this frame, or CC (16) bC (4)
     DBG_BLK(S.dbg, 2, 0);
@@ -537,11 +544,11 @@ __global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
         const int per = ((max(s_end - s_beg, 0) + SYS_NW - 1) / SYS_NW + 3) & ~3;
         const int p_beg = s_beg + wv * per, p_end = min(s_end, p_beg + per);
         double4_ acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-        for (int sp = p_beg; sp < p_end; sp += 64) {               // 16 MFMAs per trip on two independent accumulators
-            // all 48 loads of the trip are issued before the first use (clamped rows, masks multiplied in afterwards)
-            double a[16], b[16], w[16];
+        for (int sp = p_beg; sp < p_end; sp += 4 * SYS_U) {               // SYS_U MFMAs per trip on two independent accumulators
+            // all 3 * SYS_U loads of the trip are issued before the first use (clamped rows, masks multiplied in afterwards)
+            double a[SYS_U], b[SYS_U], w[SYS_U];
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
+            for (int u = 0; u < SYS_U; u++) {
                 const int p = min(sp + 4 * u + kk, p_end - 1);
                 const double* row = S.G + (size_t)p * S.ldg;
                 a[u] = row[16 * ti + c];
@@ -551,13 +558,13 @@ __global__ __launch_bounds__(64 * SYS_NW) void k_ba_system(SysArgs S) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one wait for the whole batch (measured: a staggered wait chain is ~1 us slower)
             if (S.dbg && tid == 0 && blockIdx.x == 33) S.dbg[32] = wall_clock64();
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
+            for (int u = 0; u < SYS_U; u++) {
                 const double mk = (sp + 4 * u + kk < p_end) ? 1.0 : 0.0;
                 a[u] *= mk;
                 b[u] = (w[u] * b[u]) * mk;
             }
 #pragma unroll
-            for (int u = 0; u < 16; u += 2) {
+            for (int u = 0; u < SYS_U; u += 2) {
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], b[u + 1], acc2, 0, 0, 0);
             }
