@@ -14,7 +14,7 @@ SOURCES = ["cmlhip_ctx.hip", "ba_linearize.hip", "ba_linearize_rs.hip", "ba_line
 HEADERS = ["cmlhip_internal.h", "ba_common.h", "ba_finish.h", "ba_frames.h", os.path.join("..", "host", "se3.h"), os.path.join("..", "..", "include", "cmlhip.h")]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
-         "-Wno-unused-but-set-variable", "-Wno-unused-value"]
+         "-Wno-unused-but-set-variable", "-Wno-unused-value"] + os.environ.get("CML_HIPCC_EXTRA", "").split()   # e.g. -DCML_RS_STAMPS (tools/probe_rs_tiles.py)
 
 
 def _stamp(paths):

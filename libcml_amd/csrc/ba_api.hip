@@ -724,11 +724,19 @@ int cmlhip_ba_get_resident_state(cmlhip_ctx* c, cmlhip_ba_frame_state* frames, d
 int cmlhip_debug_timestamps(cmlhip_ctx* c, int enable, long long* out128) { CML_DEV(c);
     const size_t NS = CMLHIP_DEBUG_SLOTS;
     if (!c) return CMLHIP_ERR_INVALID;
-    int rc = cml_ensure(c, c->dbg, NS * sizeof(long long));
+    const size_t NX = CML_DEBUG_RS_TILES * 8;              // development: 7 phase stamps + hw id per tile of the lane-per-residual kernel (-DCML_RS_STAMPS)
+    int rc = cml_ensure(c, c->dbg, (NS + NX) * sizeof(long long));
     if (rc) return rc;
     if (out128 && (rc = cml_d2h(c, out128, c->dbg.p, NS * sizeof(long long)))) return rc;
+    if (out128) {
+        if (const char* f = getenv("CMLHIP_RS_TS_FILE")) {
+            std::vector<long long> x(NX);
+            if ((rc = cml_d2h(c, x.data(), (char*)c->dbg.p + NS * sizeof(long long), NX * sizeof(long long)))) return rc;
+            if (FILE* fp = fopen(f, "wb")) { fwrite(x.data(), sizeof(long long), NX, fp); fclose(fp); }
+        }
+    }
     c->dbg_on = enable != 0;
-    if (enable) CML_CHECK(c, hipMemsetAsync(c->dbg.p, 0, NS * sizeof(long long), c->stream));
+    if (enable) CML_CHECK(c, hipMemsetAsync(c->dbg.p, 0, (NS + NX) * sizeof(long long), c->stream));
     return CMLHIP_OK;
 }
 

@@ -74,6 +74,7 @@ struct BAArgs {
     int records_only;             // k_ba_linearize: only re-create the efsJ record of every good residual (cml_materialize_records)
 };
 
+#define CML_DEBUG_RS_TILES 4096                 // development: per-tile stamps of k_ba_lin_rs behind the CMLHIP_DEBUG_SLOTS (cmlhip_debug_timestamps)
 #define RS_TILE 64                                 // residuals per wave tile of the lane-per-residual kernel (16 for the 4-lane kernel: cmlhip_ctx::rs_tile)
 // resident residual kernel (ba_linearize_rs.hip): wave tiles of <= RS_TILE residuals of one (host,target) pair
 struct RsArgs {

@@ -23,6 +23,7 @@
 #include "ba_common.h"
 #include <cstdlib>
 #include <cstddef>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -70,37 +71,111 @@ __constant__ unsigned char c_rs_mfma_a[64] = {12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 
 #define RS_OX(k) ((k) == 0 ? 0 : (k) == 1 ? -1 : (k) == 2 ? 1 : (k) == 3 ? -2 : (k) == 4 ? 0 : (k) == 5 ? 2 : (k) == 6 ? -1 : 0)
 #define RS_OY(k) ((k) == 0 ? -2 : (k) == 1 ? -1 : (k) == 2 ? -1 : (k) == 3 ? 0 : (k) == 4 ? 0 : (k) == 5 ? 0 : (k) == 6 ? 1 : 2)
 
-template <bool HALF>
-__global__ __launch_bounds__(64) void k_ba_lin_rs(BAArgs A, RsArgs X) {
+// per-residual element of an array through a 32-bit byte offset from the (scalar) base: one offset VGPR serves every array of the
+// same element size (global_load ... v_off, s[base:base+1]) instead of a 64-bit address pair per array
+template <class T> __device__ __forceinline__ T& rs_at(T* base, unsigned byte_off) { return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off); }
+template <class T> __device__ __forceinline__ const T& rs_at(const T* base, unsigned byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
+
+// the two texels of a bilinear row (x, x+1) as ONE load: fp16 texels are 8 B, the pair is 16 B at 8-byte alignment (global loads
+// only need dword alignment on gfx950); fp32 texels stay two 16-B loads
+typedef unsigned rs_u4v __attribute__((ext_vector_type(4)));
+typedef rs_u4v rs_u4v_a8 __attribute__((aligned(8)));
+typedef float rs_f4v __attribute__((ext_vector_type(4)));
+template <bool HALF, int LDM> struct RsRow;           // LDM (development): 0 = plain loads, 1 = nontemporal
+template <int LDM> struct RsRow<true, LDM> {
+    rs_u4v v;
+    __device__ __forceinline__ void load(const void* img, size_t i) {
+        const rs_u4v_a8* p = reinterpret_cast<const rs_u4v_a8*>(reinterpret_cast<const uint2*>(img) + i);
+        v = LDM ? __builtin_nontemporal_load(p) : *p;
+    }
+    static __device__ __forceinline__ float lo(unsigned u) { return __low2float(*reinterpret_cast<const __half2*>(&u)); }
+    static __device__ __forceinline__ float hi(unsigned u) { return __high2float(*reinterpret_cast<const __half2*>(&u)); }
+    __device__ __forceinline__ float I0() const { return lo(v.x); }
+    __device__ __forceinline__ float X0() const { return hi(v.x); }
+    __device__ __forceinline__ float Y0() const { return lo(v.y); }
+    __device__ __forceinline__ float I1() const { return lo(v.z); }
+    __device__ __forceinline__ float X1() const { return hi(v.z); }
+    __device__ __forceinline__ float Y1() const { return lo(v.w); }
+};
+template <int LDM> struct RsRow<false, LDM> {
+    rs_f4v a, b;
+    __device__ __forceinline__ void load(const void* img, size_t i) {
+        const rs_f4v* p = reinterpret_cast<const rs_f4v*>(img) + i;
+        a = LDM ? __builtin_nontemporal_load(p) : p[0]; b = LDM ? __builtin_nontemporal_load(p + 1) : p[1];
+    }
+    __device__ __forceinline__ float I0() const { return a.x; }
+    __device__ __forceinline__ float X0() const { return a.y; }
+    __device__ __forceinline__ float Y0() const { return a.z; }
+    __device__ __forceinline__ float I1() const { return b.x; }
+    __device__ __forceinline__ float X1() const { return b.y; }
+    __device__ __forceinline__ float Y1() const { return b.z; }
+};
+
+// slots of the staged row that hold something else until the sums are staged: the point's pattern colours / weights (read by the
+// pixel loop from LDS instead of sixteen registers) and the depth Jacobian
+#define RS_S_COL 22          // 22..29 colours, 30..37 weights: overwritten by the sums after the pixel loop
+#define RS_S_D0 21
+#define RS_S_D1 40
+
+template <bool HALF, int WPE, int WPB, int LDM>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE))) void k_ba_lin_rs(BAArgs A, RsArgs X) {
     // staged reduced record of the wave's residuals: the layout of k_ba_acc's s_rec (0..5 Jpdxi[0], 6..11 Jpdxi[1], 12..15 Jpdc[0], 16..19 Jpdc[1],
     // 20 zeros, 22..25 JIdx2, 26..29 JabJIdx, 30..33 Jab2, 34,35 JI^T r, 36,37 Jab^T r, 38 r^T r, 39 ones)
-    __shared__ float s_stg[RS_TILE * RS_SSTRIDE];
-    const int ln = threadIdx.x;
+    // WPB independent waves per workgroup (no workgroup barrier anywhere): a workgroup is the unit the dispatcher hands out
+    __shared__ float s_stg_all[WPB * RS_TILE * RS_SSTRIDE];
+    const int ln = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* s_stg = s_stg_all + wv * (RS_TILE * RS_SSTRIDE);
     if (A.ctl && A.ctl->stop_lin) return;                  // converged in an earlier launch (raised by k_ba_acc), BA.cpp:879
-    const int ti = blockIdx.x;
+    const int ti = blockIdx.x * WPB + wv;
+    if (ti >= X.ntiles) return;
+#ifdef CML_RS_STAMPS                                       // development build (CML_HIPCC_EXTRA=-DCML_RS_STAMPS): per-tile phase stamps, tools/probe_rs_tiles.py
+    long long* const ts = (A.dbg && ti < CML_DEBUG_RS_TILES) ? A.dbg + CMLHIP_DEBUG_SLOTS + 8 * (size_t)ti : nullptr;
+#define RS_STAMP(i) do { if (ts && ln == 0) ts[i] = wall_clock64(); } while (0)
+#else
+    long long* const ts = nullptr;
+#define RS_STAMP(i) do { } while (0)
+#endif
     // ---- wave-uniform data: tile -> pair record, frames (scalar loads, before any store)
     const int4 T = X.tiles[ti];                            // {first residual, count, host, target}
     const int first = T.x, cnt = T.y, host = T.z, target = T.w;
     const cmlhip_ba_pair* pc = &A.pairs[host * A.N + target];
     const FrameDev fh = A.frames[host], ft = A.frames[target];
-    const double R0_ = pc->R[0], R1_ = pc->R[1], R2_ = pc->R[2], R3_ = pc->R[3], R4_ = pc->R[4], R5_ = pc->R[5],
-                 R6_ = pc->R[6], R7_ = pc->R[7], R8_ = pc->R[8];
-    const double t0_ = pc->t[0], t1_ = pc->t[1], t2_ = pc->t[2];
+    double R0_ = pc->R[0], R1_ = pc->R[1], R2_ = pc->R[2], R3_ = pc->R[3], R4_ = pc->R[4], R5_ = pc->R[5],
+           R6_ = pc->R[6], R7_ = pc->R[7], R8_ = pc->R[8];
+    double t0_ = pc->t[0], t1_ = pc->t[1], t2_ = pc->t[2];
     const double aff_a = pc->aff_a, aff_b = pc->aff_b;
+    float th = fh.frame_energy_th > ft.frame_energy_th ? fh.frame_energy_th : ft.frame_energy_th;             // BA.cpp:297-300
+    asm volatile("" : "+v"(th));                           // evaluated here: one register held over the kernel instead of two scalars and a late compare
+    // each entry an opaque scalar: as a <4 x double> load the vectoriser shuffles two of them together, which the backend lowers
+    // through a stack temporary — and a kernel with a scratch frame pays for it at every dispatch
+#define RS_OPAQUE(x) asm volatile("" : "+s"(x))
+    RS_OPAQUE(R0_); RS_OPAQUE(R1_); RS_OPAQUE(R2_); RS_OPAQUE(R3_); RS_OPAQUE(R4_); RS_OPAQUE(R5_); RS_OPAQUE(R6_); RS_OPAQUE(R7_); RS_OPAQUE(R8_);
+    RS_OPAQUE(t0_); RS_OPAQUE(t1_); RS_OPAQUE(t2_);
+#undef RS_OPAQUE
+    {   // development (CMLHIP_RS_DBG bits 8..): stagger the waves of a SIMD by their slot, n x 0.43 us per slot
+        const int stag = (X.dbg_flags >> 8) * (int)(__builtin_amdgcn_s_getreg(63492) & 15u);
+        for (int i = 0; i < stag; i++) __builtin_amdgcn_s_sleep(16);
+    }
+    const long long ts_begin = ts ? wall_clock64() : 0;    // (taken and stored behind the scalar loads above: anything with a side effect before them turns them into vector loads)
+    if (ts && ln == 0) { ts[0] = ts_begin; ts[7] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); }
 
     // ---- per-residual inputs, all addressed by the residual index
     const bool valid = ln < cnt;
     const int r = first + (valid ? ln : 0);
-    const int lin_ = A.r_lin[r], st_ = A.r_state[r];
-    const float pre_energy = A.r_energy[r];
-    const int pre_new_state = A.r_new_state[r], pre_ppos = A.point_pos[r];
-    const unsigned char pre_sel = A.r_sel[r];
-    const double cxd = (double)X.r_px[r], cyd = (double)X.r_py[r];
-    const float4 colA = reinterpret_cast<const float4*>(X.r_colors)[2 * (size_t)r], colB = reinterpret_cast<const float4*>(X.r_colors)[2 * (size_t)r + 1];
-    const float4 wgtA = reinterpret_cast<const float4*>(X.r_weights)[2 * (size_t)r], wgtB = reinterpret_cast<const float4*>(X.r_weights)[2 * (size_t)r + 1];
-    const float colors[8] = {colA.x, colA.y, colA.z, colA.w, colB.x, colB.y, colB.z, colB.w};
-    const float weights[8] = {wgtA.x, wgtA.y, wgtA.z, wgtA.w, wgtB.x, wgtB.y, wgtB.z, wgtB.w};
-    const double idepth = X.r_idepth[r];                   // == pt_idepth[r_point[r]] (cml_launch_linearize_rs refreshes the copies when needed)
+    const unsigned r1 = (unsigned)r, r4 = r1 * 4u;          // byte offsets of the residual in 1- and 4-byte arrays
+    const int lin_ = rs_at(A.r_lin, r1), st_ = rs_at(A.r_state, r4);
+    const double cxd = (double)rs_at(X.r_px, r4), cyd = (double)rs_at(X.r_py, r4);
+    float* S = &s_stg[ln * RS_SSTRIDE];
+    {
+        const float4 colA = rs_at(reinterpret_cast<const float4*>(X.r_colors), r4 * 8u), colB = rs_at(reinterpret_cast<const float4*>(X.r_colors), r4 * 8u + 16u);
+        const float4 wgtA = rs_at(reinterpret_cast<const float4*>(X.r_weights), r4 * 8u), wgtB = rs_at(reinterpret_cast<const float4*>(X.r_weights), r4 * 8u + 16u);
+        S[RS_S_COL + 0] = colA.x; S[RS_S_COL + 1] = colA.y; S[RS_S_COL + 2] = colA.z; S[RS_S_COL + 3] = colA.w;
+        S[RS_S_COL + 4] = colB.x; S[RS_S_COL + 5] = colB.y; S[RS_S_COL + 6] = colB.z; S[RS_S_COL + 7] = colB.w;
+        S[RS_S_COL + 8] = wgtA.x; S[RS_S_COL + 9] = wgtA.y; S[RS_S_COL + 10] = wgtA.z; S[RS_S_COL + 11] = wgtA.w;
+        S[RS_S_COL + 12] = wgtB.x; S[RS_S_COL + 13] = wgtB.y; S[RS_S_COL + 14] = wgtB.z; S[RS_S_COL + 15] = wgtB.w;
+    }
+    const double idepth = rs_at(X.r_idepth, r4 * 2u);                   // == pt_idepth[r_point[r]] (cml_launch_linearize_rs refreshes the copies when needed)
     const bool live = valid && !lin_;
     const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
@@ -108,6 +183,9 @@ __global__ __launch_bounds__(64) void k_ba_lin_rs(BAArgs A, RsArgs X) {
     // ---- projection of the 8 pattern pixels, BA.cpp:193-212; the centre (BA.cpp:102-131) is pattern pixel 4, offset (0,0): the very
     //      same expressions on the very same operands
     const double tid0 = t0_ * idepth, tid1 = t1_ * idepth, tid2 = t2_ * idepth;
+#ifdef CML_RS_STAMPS
+    { double dep = tid0 + cxd + (double)st; asm volatile("" : "+v"(dep)); RS_STAMP(1); }        // every input of the lane has arrived
+#endif
     float kxf[8], kyf[8];
     unsigned m_in = 0;
     double rx = 0, ry = 0, px = 0, py = 0, Kud = 0, Kvd = 0;
@@ -130,126 +208,41 @@ __global__ __launch_bounds__(64) void k_ba_lin_rs(BAArgs A, RsArgs X) {
     }
     const bool centre_in = (m_in >> 4) & 1u;
 
-    // ---- photometric terms and pattern sums, pixel by pixel in pattern order (BA.cpp:214-271 and the ACTIVE-mode inner products of
-    //      BA.cpp:1719-1729).  Form A: acc = (float)((double)acc + X*Y); form B: acc += rF*Y in fp64 (a masked column adds rF * 0);
-    //      form C: acc += ((p*q)*r)*s in fp32 — the forms and operand conversions of k_ba_linearize.
-    float J00 = 0, J10 = 0, J11 = 0, Q00 = 0, Q10 = 0, Q01 = 0, Q11 = 0, rr = 0, E = 0, wJI2 = 0;
-    double JIr0 = 0, JIr1 = 0, Jabr0 = 0, Jabr1 = 0;
-    float B00 = 0, B01 = 0, B11 = 0;
-    unsigned m_nf = 0;
-    // GradientImage::interpolate (Array2D.h:265-286): the 32 texel loads of the lane are issued together, unconditional on clamped
+    // GradientImage::interpolate (Array2D.h:265-286): the texel loads of the lane are issued together, unconditional on clamped
     // addresses (ONE memory round trip for the whole pattern), then consumed in pattern order
-    float4 ta[8], tb[8], tc[8], td[8];
+    RsRow<HALF, LDM> t0r[8], t1r[8];
+    size_t tix[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const bool smp = run && centre_in && ((m_in >> k) & 1u);
         const int ix = (int)kxf[k], iy = (int)kyf[k];
-        const size_t i1 = (smp && !(X.dbg_flags & 1)) ? (size_t)iy * A.w + ix : (size_t)0;
-        ta[k] = rs_load_texel<HALF>(ft.grad0, i1); tb[k] = rs_load_texel<HALF>(ft.grad0, i1 + 1);
-        tc[k] = rs_load_texel<HALF>(ft.grad0, i1 + A.w); td[k] = rs_load_texel<HALF>(ft.grad0, i1 + A.w + 1);
+        tix[k] = (smp && !(X.dbg_flags & 1)) ? (size_t)iy * A.w + ix : (size_t)0;
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        {
-            const bool smp = run && centre_in && ((m_in >> k) & 1u);
-            const float x = kxf[k], y = kyf[k];
-            const int ix = (int)x, iy = (int)y;
-            const float dx = x - (float)ix, dy = y - (float)iy;
-            const float dxdy = dx * dy;
-            const float tw00 = 1 - dx - dy + dxdy, tw01 = dx - dxdy, tw10 = dy - dxdy, tw11 = dxdy;
-            const float Iv = ta[k].x * tw00 + tb[k].x * tw01 + tc[k].x * tw10 + td[k].x * tw11;
-            const float gxv = ta[k].y * tw00 + tb[k].y * tw01 + tc[k].y * tw10 + td[k].y * tw11;
-            const float gyv = ta[k].z * tw00 + tb[k].z * tw01 + tc[k].z * tw10 + td[k].z * tw11;
-            const float I = smp ? Iv : 0.f, gx = smp ? gxv : 0.f, gy = smp ? gyv : 0.f;
-            const bool finite = isfinite(I) && isfinite(gx) && isfinite(gy);
-            if (((m_in >> k) & 1u) && !finite) m_nf |= 1u << k;
-            const float refColor = colors[k];
-            const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
-            const float residual = I - refRealColor;
-            float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
-            const double wden = A.oth_d + (double)(gx * gx + gy * gy);
-            float wgt = sqrtf((float)rs_div(A.oth_d, wden, rs_rcp_refined(wden)));
-            wgt = (float)(0.5f * ((double)wgt + (double)weights[k]));
-            const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
-            const float hw0 = hw;
-            if (hw < 1) hw = sqrtf(hw);
-            hw = hw * wgt;
-            const float f1 = gx * hw, f2 = gy * hw;                     // hitColor[1], hitColor[2]
-            const float drdA = I - fh.b0;
-            const float a_ = drdA * hw;
-            const float rF = residual * hw;
-            const double f1d = (double)f1, f2d = (double)f2, ad = (double)a_, hwd = (double)hw, rFd = (double)rF;
-            J00 = (float)((double)J00 + f1d * f1d); J10 = (float)((double)J10 + f1d * f2d); J11 = (float)((double)J11 + f2d * f2d);
-            Q00 = (float)((double)Q00 + ad * f1d); Q10 = (float)((double)Q10 + hwd * f1d);
-            Q01 = (float)((double)Q01 + ad * f2d); Q11 = (float)((double)Q11 + hwd * f2d);
-            rr = (float)((double)rr + rFd * rFd);
-            E = (float)((double)E + (double)pf * (2.0 - (double)hw0));                            // energyLeft, BA.cpp:237
-            wJI2 = (float)((double)wJI2 + (double)(hw * hw) * (f1d * f1d + f2d * f2d));           // wJI2_sum, BA.cpp:257
-            JIr0 += rFd * f1d; JIr1 += rFd * f2d;
-            Jabr0 += rFd * (A.opt_a ? ad : 0.0); Jabr1 += rFd * (A.opt_b ? hwd : 0.0);           // BA.cpp:273-278: a zeroed column contributes rF * 0
-            B00 += drdA * drdA * hw * hw; B01 += drdA * hw * hw * 1.f; B11 += hw * hw * 1.f * 1.f;
-        }
-    }
+    // Issue order = image row by image row (star8: rows -2 | -1 -1 | 0 0 0 | +1 | +2, each tap reads its row and the next): the
+    // requests of a lane that fall into the same 128-byte line follow each other, so the line is still in the L1 (or its miss
+    // pending) when the next one asks for it — 6 line fills per residual instead of 16.  (The asm statements only pin the order.)
+#define RS_ORDER() asm volatile("" ::: "memory")
+    t0r[0].load(ft.grad0, tix[0]); RS_ORDER();
+    t1r[0].load(ft.grad0, tix[0] + A.w); t0r[1].load(ft.grad0, tix[1]); t0r[2].load(ft.grad0, tix[2]); RS_ORDER();
+    t1r[1].load(ft.grad0, tix[1] + A.w); t1r[2].load(ft.grad0, tix[2] + A.w); t0r[3].load(ft.grad0, tix[3]); t0r[4].load(ft.grad0, tix[4]); t0r[5].load(ft.grad0, tix[5]); RS_ORDER();
+    t1r[3].load(ft.grad0, tix[3] + A.w); t1r[4].load(ft.grad0, tix[4] + A.w); t1r[5].load(ft.grad0, tix[5] + A.w); t0r[6].load(ft.grad0, tix[6]); RS_ORDER();
+    t1r[6].load(ft.grad0, tix[6] + A.w); t0r[7].load(ft.grad0, tix[7]); RS_ORDER();
+    t1r[7].load(ft.grad0, tix[7] + A.w);
+#undef RS_ORDER
+    RS_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
 
-    // first failing pixel in pattern order decides between setNewState(OOB) (:209-212) and setState(OOB) (:220-223)
-    const unsigned m_oob = ~m_in & 0xFFu;
-    const unsigned m_bad = m_oob | m_nf;
-    const int first_bad = m_bad ? __ffs((int)m_bad) - 1 : 8;
-    const bool fail_new_oob = !centre_in || (m_bad && ((m_oob >> first_bad) & 1u));
-    const bool fail_state_oob = centre_in && m_bad && !((m_oob >> first_bad) & 1u);
-
-    // ---- classification, BA.cpp:66-72,115-118,297-314, and the fused applyRes(copyJacobians = true), BA.cpp:2051-2093
-    const float new_idepth = (float)(drescale * idepth);
-    double ret_d = 0.0;
-    int ns_cnt = -1, flip = 0;
-    if (live) {
-        float ret = pre_energy;
-        float nwo = -1.f;
-        int ns_final = pre_new_state;
-        bool state_now_oob = (st == CMLHIP_RES_OOB), wrote_e = false;
-        if (run) {
-            if (centre_in) {                                        // setCenterProjectedTo, :131
-                A.r_center[3 * (size_t)r] = (float)Kud; A.r_center[3 * (size_t)r + 1] = (float)Kvd;
-                A.r_center[3 * (size_t)r + 2] = new_idepth;
-            }
-            if (fail_new_oob) {
-                ns_final = CMLHIP_RES_OOB;
-            } else if (fail_state_oob) {
-                A.r_state[r] = CMLHIP_RES_OOB;
-                state_now_oob = true;
-            } else if (!isfinite(E)) {
-                ns_final = CMLHIP_RES_OOB;
-            } else {
-                nwo = E;
-                const float th = fh.frame_energy_th > ft.frame_energy_th ? fh.frame_energy_th : ft.frame_energy_th;
-                float e = E;
-                ns_final = CMLHIP_RES_IN;
-                if (E > th || wJI2 < 2) { e = th; ns_final = CMLHIP_RES_OUTLIER; }
-                A.r_new_energy[r] = e;
-                ret = e;
-                wrote_e = true;
-            }
-            A.r_new_state[r] = ns_final;
-        }
-        A.r_new_energy_wo[r] = nwo;
-        A.r_ret_energy[r] = ret;
-        ret_d = (double)ret; ns_cnt = ns_final;
-        int code = -1;
-        if (!state_now_oob) {                                       // applyRes
-            if (ns_final == CMLHIP_RES_IN) { A.r_good[r] = 1; flip = 1; code = 2 * r + pre_sel; }
-            else A.r_good[r] = 0;
-            A.r_state[r] = ns_final;
-            A.r_energy[r] = wrote_e ? ret : A.r_new_energy[r];      // state_energy = state_NewEnergy
-            A.point_code[pre_ppos] = code;                          // read by the point rows of k_ba_acc and by k_ba_backsub
-        }
-    }
-
-    // ---- geometric Jacobians, BA.cpp:120-188 (the expression shapes of k_ba_linearize with its per-lane constants folded)
-    float* S = &s_stg[ln * RS_SSTRIDE];
+    // ---- geometric Jacobians, BA.cpp:120-188 (the expression shapes of k_ba_linearize with its per-lane constants folded), evaluated
+    //      while the texels are in flight and parked in the staged row: nothing of the geometry stays in registers over the pixel loop
     {
+        const float new_idepth = (float)(drescale * idepth);
+        if (run && centre_in) {                                  // setCenterProjectedTo, :131
+            rs_at(A.r_center, r4 * 3u) = (float)Kud; rs_at(A.r_center, r4 * 3u + 4u) = (float)Kvd;
+            rs_at(A.r_center, r4 * 3u + 8u) = new_idepth;
+        }
         // evaluation-point pair (PRE_RTll_0 / PRE_tTll_0) for the calibration / depth Jacobians: explicit scalar loads HERE (the
         // compiler only scalarises loads it can prove unclobbered, i.e. before the first store of the kernel; holding these 18
-        // SGPRs across the pixel loop spilled scalars, and a kernel with a scratch frame pays for it at every dispatch)
+        // SGPRs across the projection loop spilled scalars, and a kernel with a scratch frame pays for it at every dispatch)
         rs_int8 w0, w1, w2;
         asm volatile("s_load_dwordx8 %0, %3, 0x60\n\ts_load_dwordx8 %1, %3, 0x80\n\ts_load_dwordx8 %2, %3, 0xa0\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(w0), "=&s"(w1), "=&s"(w2) : "s"(pc) : "memory");
@@ -274,31 +267,156 @@ __global__ __launch_bounds__(64) void k_ba_lin_rs(BAArgs A, RsArgs X) {
                              (float)(((1.0 * q46) + -0.0) * A.scale_c), (float)(((1.0 * q57) + 1.0) * A.scale_c)};
         // Jpdd (:178-182)
         const float d0 = (float)(drescale * (et0 - et2 * u) * fxf), d1 = (float)(drescale * (et1 - et2 * v) * fyf);
+#pragma unroll
+        for (int i = 0; i < 6; i++) { S[i] = xi0[i]; S[6 + i] = xi1[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { S[12 + i] = c0[i]; S[16 + i] = c1[i]; }
+        S[RS_S_D0] = d0; S[RS_S_D1] = d1;
+        S[20] = 0.f; S[39] = 1.f;
+    }
+    RS_STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);
+    // what the classification needs of the previous state: requested here, behind the texels, so that the round trip runs under the pixel loop
+    const float pre_energy = rs_at(A.r_energy, r4);
+    const int pre_new_state = rs_at(A.r_new_state, r4), pre_ppos = rs_at(A.point_pos, r4);
+    const unsigned char pre_sel = rs_at(A.r_sel, r1);
 
-        // ---- per residual: JpJdF (BA.cpp:2066-2080) and the terms of Hcd, Hdd, bd (BA.cpp:1747-1750)
-        if (flip && !(X.dbg_flags & 2)) {
+    // ---- photometric terms and pattern sums, pixel by pixel in pattern order (BA.cpp:214-271 and the ACTIVE-mode inner products of
+    //      BA.cpp:1719-1729).  Form A: acc = (float)((double)acc + X*Y); form B: acc += rF*Y in fp64 (a masked column adds rF * 0);
+    //      form C: acc += ((p*q)*r)*s in fp32 — the forms and operand conversions of k_ba_linearize.
+    // RS_XFMA(x, y, z) = z + x*y where x and y are floats widened to double: the 48-bit product is exact in fp64, so the fused form
+    // rounds once exactly where the reference's separate multiply and add round once — same bits, one instruction less
+#define RS_XFMA(x, y, z) __builtin_fma((x), (y), (z))
+    float J00 = 0, J10 = 0, J11 = 0, Q00 = 0, Q10 = 0, Q01 = 0, Q11 = 0, rr = 0, E = 0, wJI2 = 0;
+    double JIr0 = 0, JIr1 = 0, Jabr0 = 0, Jabr1 = 0;
+    float B00 = 0, B01 = 0, B11 = 0;
+    unsigned m_nf = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        {
+            const bool smp = run && centre_in && ((m_in >> k) & 1u);
+            const float x = kxf[k], y = kyf[k];
+            const int ix = (int)x, iy = (int)y;
+            const float dx = x - (float)ix, dy = y - (float)iy;
+            const float dxdy = dx * dy;
+            const float tw00 = 1 - dx - dy + dxdy, tw01 = dx - dxdy, tw10 = dy - dxdy, tw11 = dxdy;
+            const float Iv = t0r[k].I0() * tw00 + t0r[k].I1() * tw01 + t1r[k].I0() * tw10 + t1r[k].I1() * tw11;
+            const float gxv = t0r[k].X0() * tw00 + t0r[k].X1() * tw01 + t1r[k].X0() * tw10 + t1r[k].X1() * tw11;
+            const float gyv = t0r[k].Y0() * tw00 + t0r[k].Y1() * tw01 + t1r[k].Y0() * tw10 + t1r[k].Y1() * tw11;
+            const float I = smp ? Iv : 0.f, gx = smp ? gxv : 0.f, gy = smp ? gyv : 0.f;
+            const bool finite = isfinite(I) && isfinite(gx) && isfinite(gy);
+            if (((m_in >> k) & 1u) && !finite) m_nf |= 1u << k;
+            const float refColor = S[RS_S_COL + k];
+            const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
+            const float residual = I - refRealColor;
+            float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
+            const double wden = A.oth_d + (double)(gx * gx + gy * gy);
+            float wgt = sqrtf((float)rs_div(A.oth_d, wden, rs_rcp_refined(wden)));
+            wgt = (float)(0.5f * ((double)wgt + (double)S[RS_S_COL + 8 + k]));
+            const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
+            const float hw0 = hw;
+            if (hw < 1) hw = sqrtf(hw);
+            hw = hw * wgt;
+            const float f1 = gx * hw, f2 = gy * hw;                     // hitColor[1], hitColor[2]
+            const float drdA = I - fh.b0;
+            const float a_ = drdA * hw;
+            const float rF = residual * hw;
+            const double f1d = (double)f1, f2d = (double)f2, ad = (double)a_, hwd = (double)hw, rFd = (double)rF;
+            J00 = (float)RS_XFMA(f1d, f1d, (double)J00); J10 = (float)RS_XFMA(f1d, f2d, (double)J10); J11 = (float)RS_XFMA(f2d, f2d, (double)J11);
+            Q00 = (float)RS_XFMA(ad, f1d, (double)Q00); Q10 = (float)RS_XFMA(hwd, f1d, (double)Q10);
+            Q01 = (float)RS_XFMA(ad, f2d, (double)Q01); Q11 = (float)RS_XFMA(hwd, f2d, (double)Q11);
+            rr = (float)RS_XFMA(rFd, rFd, (double)rr);
+            E = (float)((double)E + (double)pf * (2.0 - (double)hw0));                            // energyLeft, BA.cpp:237
+            wJI2 = (float)((double)wJI2 + (double)(hw * hw) * RS_XFMA(f2d, f2d, f1d * f1d));           // wJI2_sum, BA.cpp:257
+            JIr0 = RS_XFMA(rFd, f1d, JIr0); JIr1 = RS_XFMA(rFd, f2d, JIr1);
+            Jabr0 = RS_XFMA(rFd, (A.opt_a ? ad : 0.0), Jabr0); Jabr1 = RS_XFMA(rFd, (A.opt_b ? hwd : 0.0), Jabr1);           // BA.cpp:273-278: a zeroed column contributes rF * 0
+            B00 += drdA * drdA * hw * hw; B01 += drdA * hw * hw * 1.f; B11 += hw * hw * 1.f * 1.f;
+        }
+    }
+
+#ifdef CML_RS_STAMPS
+    { float dep = J00 + E + B11; asm volatile("" : "+v"(dep)); RS_STAMP(4); }
+#endif
+    // first failing pixel in pattern order decides between setNewState(OOB) (:209-212) and setState(OOB) (:220-223)
+    const unsigned m_oob = ~m_in & 0xFFu;
+    const unsigned m_bad = m_oob | m_nf;
+    const int first_bad = m_bad ? __ffs((int)m_bad) - 1 : 8;
+    const bool fail_new_oob = !centre_in || (m_bad && ((m_oob >> first_bad) & 1u));
+    const bool fail_state_oob = centre_in && m_bad && !((m_oob >> first_bad) & 1u);
+
+    // ---- classification, BA.cpp:66-72,115-118,297-314, and the fused applyRes(copyJacobians = true), BA.cpp:2051-2093
+    // From here on the kernel arguments are read AGAIN from the argument segment (through a pointer the compiler cannot connect with
+    // the first reads): otherwise the pointers of the stores below are held — or split, spilled and rematerialised, leaving a scratch
+    // frame behind — across the pixel loop.
+    typedef const __attribute__((address_space(4))) char* rs_karg_ptr;
+    rs_karg_ptr kargs = (rs_karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kargs));
+    const __attribute__((address_space(4))) BAArgs& B = *(const __attribute__((address_space(4))) BAArgs*)kargs;
+    const __attribute__((address_space(4))) RsArgs& Y = *(const __attribute__((address_space(4))) RsArgs*)(kargs + ((sizeof(BAArgs) + alignof(RsArgs) - 1) / alignof(RsArgs)) * alignof(RsArgs));
+    double ret_d = 0.0;
+    int ns_cnt = -1, flip = 0;
+    if (live) {
+        float ret = pre_energy;
+        float nwo = -1.f;
+        int ns_final = pre_new_state;
+        bool state_now_oob = (st == CMLHIP_RES_OOB), wrote_e = false;
+        if (run) {
+            if (fail_new_oob) {
+                ns_final = CMLHIP_RES_OOB;
+            } else if (fail_state_oob) {
+                rs_at(B.r_state, r4) = CMLHIP_RES_OOB;
+                state_now_oob = true;
+            } else if (!isfinite(E)) {
+                ns_final = CMLHIP_RES_OOB;
+            } else {
+                nwo = E;
+                float e = E;
+                ns_final = CMLHIP_RES_IN;
+                if (E > th || wJI2 < 2) { e = th; ns_final = CMLHIP_RES_OUTLIER; }
+                rs_at(B.r_new_energy, r4) = e;
+                ret = e;
+                wrote_e = true;
+            }
+            rs_at(B.r_new_state, r4) = ns_final;
+        }
+        rs_at(B.r_new_energy_wo, r4) = nwo;
+        rs_at(B.r_ret_energy, r4) = ret;
+        ret_d = (double)ret; ns_cnt = ns_final;
+        int code = -1;
+        if (!state_now_oob) {                                       // applyRes
+            if (ns_final == CMLHIP_RES_IN) { rs_at(B.r_good, r1) = 1; flip = 1; code = 2 * r + pre_sel; }
+            else rs_at(B.r_good, r1) = 0;
+            rs_at(B.r_state, r4) = ns_final;
+            rs_at(B.r_energy, r4) = wrote_e ? ret : rs_at(B.r_new_energy, r4);      // state_energy = state_NewEnergy
+            rs_at(B.point_code, (unsigned)pre_ppos * 4u) = code;                          // read by the point rows of k_ba_acc and by k_ba_backsub
+        }
+    }
+
+    RS_STAMP(5);
+    if (flip) {
+        // ---- per residual: JpJdF (BA.cpp:2066-2080) and the terms of Hcd, Hdd, bd (BA.cpp:1747-1750); the geometry comes back from the staged row
+        if (!(Y.dbg_flags & 2)) {
+            const float d0 = S[RS_S_D0], d1 = S[RS_S_D1];
             const float g0 = J00 * d0 + J10 * d1;
             const float g1 = J10 * d0 + J11 * d1;
-            float4* o = reinterpret_cast<float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r);
-            o[0] = make_float4(xi0[0] * g0 + xi1[0] * g1, xi0[1] * g0 + xi1[1] * g1, xi0[2] * g0 + xi1[2] * g1, xi0[3] * g0 + xi1[3] * g1);
-            o[1] = make_float4(xi0[4] * g0 + xi1[4] * g1, xi0[5] * g0 + xi1[5] * g1, Q00 * d0 + Q01 * d1, Q10 * d0 + Q11 * d1);
-            o[2] = make_float4(c0[0] * g0 + c1[0] * g1, c0[1] * g0 + c1[1] * g1, c0[2] * g0 + c1[2] * g1, c0[3] * g0 + c1[3] * g1);
+            float4* o = &rs_at(reinterpret_cast<float4*>(B.r_jpjdf), r4 * (unsigned)PS_STRIDE);
+            o[0] = make_float4(S[0] * g0 + S[6] * g1, S[1] * g0 + S[7] * g1, S[2] * g0 + S[8] * g1, S[3] * g0 + S[9] * g1);
+            o[1] = make_float4(S[4] * g0 + S[10] * g1, S[5] * g0 + S[11] * g1, Q00 * d0 + Q01 * d1, Q10 * d0 + Q11 * d1);
+            o[2] = make_float4(S[12] * g0 + S[16] * g1, S[13] * g0 + S[17] * g1, S[14] * g0 + S[18] * g1, S[15] * g0 + S[19] * g1);
             o[3] = make_float4(d0 * g0 + d1 * g1, (float)((double)(float)JIr0 * (double)d0 + (double)(float)JIr1 * (double)d1), 0.f, 0.f);
         }
-        // ---- staged operands of the matrix-core reduction; a residual that is not IN (or a lane beyond the tile) stages zeros
-#define RS_ST(i, val) S[i] = flip ? (val) : 0.f
+        // ---- staged operands of the matrix-core reduction
+        S[22] = J00; S[23] = J10; S[24] = J10; S[25] = J11;
+        S[26] = Q00; S[27] = Q10; S[28] = Q01; S[29] = Q11;
+        S[30] = B00; S[31] = B01; S[32] = B01; S[33] = B11;
+        S[34] = (float)JIr0; S[35] = (float)JIr1; S[36] = (float)Jabr0; S[37] = (float)Jabr1;
+        S[38] = rr;
+    } else {
+        // a residual that is not IN (or a lane beyond the tile) stages zeros
 #pragma unroll
-        for (int i = 0; i < 6; i++) { RS_ST(i, xi0[i]); RS_ST(6 + i, xi1[i]); }
+        for (int i = 0; i < 20; i++) S[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { RS_ST(12 + i, c0[i]); RS_ST(16 + i, c1[i]); }
-        S[20] = 0.f;
-        RS_ST(22, J00); RS_ST(23, J10); RS_ST(24, J10); RS_ST(25, J11);
-        RS_ST(26, Q00); RS_ST(27, Q10); RS_ST(28, Q01); RS_ST(29, Q11);
-        RS_ST(30, B00); RS_ST(31, B01); RS_ST(32, B01); RS_ST(33, B11);
-        RS_ST(34, (float)JIr0); RS_ST(35, (float)JIr1); RS_ST(36, (float)Jabr0); RS_ST(37, (float)Jabr1);
-        RS_ST(38, rr);
-        S[39] = 1.f;
-#undef RS_ST
+        for (int i = 22; i < 39; i++) S[i] = 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the workgroup is ONE wave and a wave's LDS operations execute in order:
     __builtin_amdgcn_wave_barrier();                        // only the compiler has to be kept from moving the reads up
@@ -315,32 +433,35 @@ __global__ __launch_bounds__(64) void k_ba_lin_rs(BAArgs A, RsArgs X) {
             const float bv = SL[o3] * SL[o1] + SL[o4] * SL[o2];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
-        if (!(X.dbg_flags & 2)) reinterpret_cast<float4*>(X.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (!(Y.dbg_flags & 2)) reinterpret_cast<float4*>(Y.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 
     // ---- per-tile partials {energy, n_in, n_oob, n_outlier} (BA.cpp:1565): fixed butterfly order over the wave's residuals
-    if (A.lin_partial) {
+    if (B.lin_partial) {
         double e = ret_d;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
         const int c0 = __popcll(__ballot(ns_cnt == CMLHIP_RES_IN)), c1 = __popcll(__ballot(ns_cnt == CMLHIP_RES_OOB)), c2 = __popcll(__ballot(ns_cnt == CMLHIP_RES_OUTLIER));
         if (ln == 0) {
-            double* o = A.lin_partial + 4 * (size_t)ti;
+            double* o = B.lin_partial + 4 * (size_t)ti;
             o[0] = e; o[1] = (double)c0; o[2] = (double)c1; o[3] = (double)c2;
         }
     }
+    RS_STAMP(6);
     // ---- resident loop: the convergence test of doStepFromBackup (BA.cpp:996-1027) on the sums of the step that preceded this
     //      pass; `if (canbreak && it >= 1) break` (BA.cpp:879) becomes a sticky flag that every later kernel checks first
-    if (A.ctl && ti == 0 && ln == 0) {
+    ResidentCtl* ctl_end = B.ctl;
+    asm volatile("" : "+s"(ctl_end));                        // (re-read from the kernel arguments here instead of a flag held in SGPRs over the whole kernel)
+    if (ti == 0 && ln == 0 && ctl_end) {
         float sumID = 0, sumNID = 0, numID = 0;
-        for (int b = 0; b < A.n_step_blocks; b++) { sumID += A.step_partial_ro[4 * b]; sumNID += A.step_partial_ro[4 * b + 1]; numID += A.step_partial_ro[4 * b + 2]; }
-        float sumA = A.ctl->frame_sums[0], sumB_ = A.ctl->frame_sums[1], sumT = A.ctl->frame_sums[2], sumR = A.ctl->frame_sums[3];
-        const float nf = (float)A.N;
+        for (int b = 0; b < B.n_step_blocks; b++) { sumID += B.step_partial_ro[4 * b]; sumNID += B.step_partial_ro[4 * b + 1]; numID += B.step_partial_ro[4 * b + 2]; }
+        float sumA = ctl_end->frame_sums[0], sumB_ = ctl_end->frame_sums[1], sumT = ctl_end->frame_sums[2], sumR = ctl_end->frame_sums[3];
+        const float nf = (float)B.N;
         sumA /= nf; sumB_ /= nf; sumR /= nf; sumT /= nf; sumID /= numID; sumNID /= numID;
-        const bool canbreak = sqrtf(sumA) < 0.0005 * A.th_opt && sqrtf(sumB_) < 0.00005 * A.th_opt && sqrtf(sumR) < 0.00005 * A.th_opt &&
-                              sqrtf(sumT) * sumNID < 0.00005 * A.th_opt;
-        A.ctl->iters_done = A.it_index + 1;
-        if (canbreak && A.it_index >= 1) A.ctl->stop = 1;
+        const bool canbreak = sqrtf(sumA) < 0.0005 * B.th_opt && sqrtf(sumB_) < 0.00005 * B.th_opt && sqrtf(sumR) < 0.00005 * B.th_opt &&
+                              sqrtf(sumT) * sumNID < 0.00005 * B.th_opt;
+        ctl_end->iters_done = B.it_index + 1;
+        if (canbreak && B.it_index >= 1) ctl_end->stop = 1;
     }
 }
 
@@ -361,7 +482,20 @@ int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
     X.part = c->rs_part.as<float>(); X.r_idepth = c->r_idepth.as<double>();
     { static const char* e = getenv("CMLHIP_RS_DBG"); X.dbg_flags = e ? atoi(e) : 0; }      // development: 1 = all texel taps at texel 0, 2 = no tile / reduced-record stores
     if (c->rs_tile == 16) return cml_launch_linearize_rs4(c, A, X);                         // small window: 4 lanes per residual (ba_linearize_rs4.hip)
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_ba_lin_rs<true>, c->n_tiles, 64, 0, A, X);
-    else CML_LAUNCH_EV(c, k_ba_lin_rs<false>, c->n_tiles, 64, 0, A, X);
+    // fp16 texels: 168 VGPRs, three waves per SIMD — every tile of a 20-frame window resident at once; fp32 texels hold twice the
+    // registers in flight and stay at two
+    static const char* e_mt = getenv("CMLHIP_RS_MAXTILES");    // development: launch only the first n tiles (timing experiments)
+    const int nt = e_mt ? (atoi(e_mt) < c->n_tiles ? atoi(e_mt) : c->n_tiles) : c->n_tiles;
+    static const char* e_wpb = getenv("CMLHIP_RS_WPB");        // development: waves per workgroup (1 or 4)
+    const int wpb = e_wpb ? atoi(e_wpb) : 4;
+    X.ntiles = nt;
+    static const char* e_ldm = getenv("CMLHIP_RS_LDM");        // development: 1 = nontemporal texel loads
+    const int ldm = e_ldm ? atoi(e_ldm) : 0;
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) {
+        if (ldm == 1 && wpb == 1) CML_LAUNCH_EV(c, (k_ba_lin_rs<true, 3, 1, 1>), nt, 64, 0, A, X);
+        else if (ldm == 1) CML_LAUNCH_EV(c, (k_ba_lin_rs<true, 3, 4, 1>), cml_div_up(nt, 4), 256, 0, A, X);
+        else if (wpb == 1) CML_LAUNCH_EV(c, (k_ba_lin_rs<true, 3, 1, 0>), nt, 64, 0, A, X);
+        else CML_LAUNCH_EV(c, (k_ba_lin_rs<true, 3, 4, 0>), cml_div_up(nt, 4), 256, 0, A, X);
+    } else CML_LAUNCH_EV(c, (k_ba_lin_rs<false, 2, 1, 0>), nt, 64, 0, A, X);
     return CMLHIP_OK;
 }
