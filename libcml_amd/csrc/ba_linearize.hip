@@ -105,9 +105,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BAArgs A) {
     const float drescale = (float)(1.0 / pz);
     const bool centre_in = (Kud >= 2 && Kvd >= 2 && Kud < A.w - 2 && Kvd < A.h - 2);
 
-    float I = 0.f, gx = 0.f, gy = 0.f;
+    // BA.cpp:218.  The four texel loads are unconditional on a clamped position (a lane that does not sample reads texel (0,0) and
+    // drops the result): inside a lane-divergent `if` the compiler gives every load its own branch and wait
     const bool sample = run && centre_in && pix_in;
-    if (sample) tap3<HALF>(ft.grad0, A.w, (float)kx, (float)ky, I, gx, gy);     // BA.cpp:218
+    float Iv, gxv, gyv;
+    tap3<HALF>(ft.grad0, A.w, sample ? (float)kx : 0.f, sample ? (float)ky : 0.f, Iv, gxv, gyv);
+    const float I = sample ? Iv : 0.f, gx = sample ? gxv : 0.f, gy = sample ? gyv : 0.f;
     const bool finite = isfinite(I) && isfinite(gx) && isfinite(gy);
 
     // first failing pixel in pattern order decides between setNewState(OOB) (:209-212) and setState(OOB) (:220-223)

@@ -122,10 +122,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
     // staged reduced record of the wave's residuals: the layout of k_ba_acc's s_rec (0..5 Jpdxi[0], 6..11 Jpdxi[1], 12..15 Jpdc[0], 16..19 Jpdc[1],
     // 20 zeros, 22..25 JIdx2, 26..29 JabJIdx, 30..33 Jab2, 34,35 JI^T r, 36,37 Jab^T r, 38 r^T r, 39 ones)
     // WPB independent waves per workgroup (no workgroup barrier anywhere): a workgroup is the unit the dispatcher hands out
-    __shared__ float s_stg_all[WPB * RS_TILE * RS_SSTRIDE];
+    __shared__ float s_stg_all[WPB * (RS_TILE + 1) * RS_SSTRIDE];      // (+ one row of zeros per wave: the padding of the matrix-core loop)
     const int ln = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* s_stg = s_stg_all + wv * (RS_TILE * RS_SSTRIDE);
+    float* s_stg = s_stg_all + wv * ((RS_TILE + 1) * RS_SSTRIDE);
     if (A.ctl && A.ctl->stop_lin) return;                  // converged in an earlier launch (raised by k_ba_acc), BA.cpp:879
     const int ti = blockIdx.x * WPB + wv;
     if (ti >= X.ntiles) return;
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
 #pragma unroll
         for (int i = 22; i < 39; i++) S[i] = 0.f;
     }
+    if (ln < RS_SSTRIDE) s_stg[RS_TILE * RS_SSTRIDE + ln] = 0.f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the workgroup is ONE wave and a wave's LDS operations execute in order:
     __builtin_amdgcn_wave_barrier();                        // only the compiler has to be kept from moving the reads up
 
@@ -426,12 +427,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
         const unsigned off = c_rs_mfma_off[ln];
         const int oa = c_rs_mfma_a[ln], o1 = off & 255, o2 = (off >> 8) & 255, o3 = (off >> 16) & 255, o4 = off >> 24;
         float4_ acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int li = 0; li < RS_TILE; li++) {
-            const float* SL = s_stg + li * RS_SSTRIDE;
-            const float av = SL[oa];
-            const float bv = SL[o3] * SL[o1] + SL[o4] * SL[o2];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        // only the residuals that are IN contribute (every product of a staged-zero row is +0, and acc + 0 == acc): the loop walks the
+        // set bits of the wave's IN mask in ascending order, eight rows per trip, padded with the row of zeros
+        unsigned long long inm = __ballot(flip != 0);
+        while (inm) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int li = inm ? __builtin_ctzll(inm) : RS_TILE;
+                inm &= inm - 1;
+                const float* SL = s_stg + li * RS_SSTRIDE;
+                const float av = SL[oa];
+                const float bv = SL[o3] * SL[o1] + SL[o4] * SL[o2];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
         }
         if (!(Y.dbg_flags & 2)) reinterpret_cast<float4*>(Y.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
