@@ -100,6 +100,10 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         CML_REQUIRE(c, py && py->lv[0].grad, CMLHIP_ERR_NOT_FOUND, "frame image not in the pyramid cache");
         CML_REQUIRE(c, py->lv[0].w == c->ba_prm.w && py->lv[0].h == c->ba_prm.h, CMLHIP_ERR_INVALID, "image size != BA params");
         fd[i].grad0 = py->lv[0].grad; fd[i].frame_energy_th = frames[i].frame_energy_th; fd[i].b0 = frames[i].b0;
+        fd[i].grad0t = nullptr;
+        if (c->lim.texel_format == CMLHIP_TEXEL_F16) {              // the tiled copy the lane-per-residual kernel gathers from (built once per image)
+            if (int rc_t = cml_tiled_level0(c, frames[i].image_id, &fd[i].grad0t)) return rc_t;
+        }
     }
     // ---- index bookkeeping (exact): htIDX = host + target*N (BA.cpp:1677), CSR by point and by pair
     c->h_pair_of.assign(R, 0);

@@ -65,6 +65,9 @@ __device__ __forceinline__ double rs_div(const double x, const double z, const d
 __constant__ unsigned c_rs_mfma_off[64] = {0x1816100Cu, 0x1816110Du, 0x1816120Eu, 0x1816130Fu, 0x18160600u, 0x18160701u, 0x18160802u, 0x18160903u, 0x18160A04u, 0x18160B05u, 0x1427141Au, 0x1427141Bu, 0x14271422u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1918100Cu, 0x1918110Du, 0x1918120Eu, 0x1918130Fu, 0x19180600u, 0x19180701u, 0x19180802u, 0x19180903u, 0x19180A04u, 0x19180B05u, 0x1427141Cu, 0x1427141Du, 0x14271423u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x1427141Eu, 0x14271420u, 0x14271424u, 0x14271421u, 0x14271425u, 0x14271426u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u, 0x14141414u};
 __constant__ unsigned char c_rs_mfma_a[64] = {12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 20, 20, 20, 20, 20, 20, 16, 17, 18, 19, 6, 7, 8, 9, 10, 11, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 39, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
 
+#ifndef RS_DEPTH
+#define RS_DEPTH 3           // pixels whose texels are in flight ahead of the sums (3 or 5)
+#endif
 #define RS_SSTRIDE 41        // floats per residual of the staged reduced record (odd: conflict-free lane-per-record accesses)
 
 // star8 pattern offsets, types.h:1381-1393
@@ -83,26 +86,38 @@ typedef rs_u4v rs_u4v_a8 __attribute__((aligned(8)));
 typedef float rs_f4v __attribute__((ext_vector_type(4)));
 template <bool HALF, int LDM> struct RsRow;           // LDM (development): 0 = plain loads, 1 = nontemporal
 template <int LDM> struct RsRow<true, LDM> {
-    rs_u4v v;
-    __device__ __forceinline__ void load(const void* img, size_t i) {
-        const rs_u4v_a8* p = reinterpret_cast<const rs_u4v_a8*>(reinterpret_cast<const uint2*>(img) + i);
-        v = LDM ? __builtin_nontemporal_load(p) : *p;
+    // fp16 texels come from the TILED level 0 (cml_tiled_level0, cmlhip_internal.h): texel (ix, row) and its right neighbour are 12
+    // contiguous bytes at offset (ix & 3) * 6 of a 32-byte tile row — one 16-byte load from the dword below it, then a 0- or 16-bit
+    // funnel shift (v_alignbit) lines the six halves up
+    unsigned e0, e1, e2;
+    rs_u4v raw; unsigned sh;
+    __device__ __forceinline__ void load(const void* img, int tw, int ix, int row) {
+        const unsigned o = (unsigned)(ix & 3) * 6u;
+        const size_t byte = ((size_t)(row >> 2) * tw + (ix >> 2)) * 128u + (unsigned)(row & 3) * 32u + (o & ~3u);
+        typedef rs_u4v rs_u4v_a4 __attribute__((aligned(4)));
+        const rs_u4v_a4* p = reinterpret_cast<const rs_u4v_a4*>(reinterpret_cast<const char*>(img) + byte);
+        raw = LDM ? __builtin_nontemporal_load(p) : *p;
+        sh = (o & 2u) * 8u;
+    }
+    __device__ __forceinline__ void unpack() {
+        e0 = __builtin_amdgcn_alignbit(raw.y, raw.x, sh); e1 = __builtin_amdgcn_alignbit(raw.z, raw.y, sh); e2 = __builtin_amdgcn_alignbit(raw.w, raw.z, sh);
     }
     static __device__ __forceinline__ float lo(unsigned u) { return __low2float(*reinterpret_cast<const __half2*>(&u)); }
     static __device__ __forceinline__ float hi(unsigned u) { return __high2float(*reinterpret_cast<const __half2*>(&u)); }
-    __device__ __forceinline__ float I0() const { return lo(v.x); }
-    __device__ __forceinline__ float X0() const { return hi(v.x); }
-    __device__ __forceinline__ float Y0() const { return lo(v.y); }
-    __device__ __forceinline__ float I1() const { return lo(v.z); }
-    __device__ __forceinline__ float X1() const { return hi(v.z); }
-    __device__ __forceinline__ float Y1() const { return lo(v.w); }
+    __device__ __forceinline__ float I0() const { return lo(e0); }
+    __device__ __forceinline__ float X0() const { return hi(e0); }
+    __device__ __forceinline__ float Y0() const { return lo(e1); }
+    __device__ __forceinline__ float I1() const { return hi(e1); }
+    __device__ __forceinline__ float X1() const { return lo(e2); }
+    __device__ __forceinline__ float Y1() const { return hi(e2); }
 };
 template <int LDM> struct RsRow<false, LDM> {
     rs_f4v a, b;
-    __device__ __forceinline__ void load(const void* img, size_t i) {
-        const rs_f4v* p = reinterpret_cast<const rs_f4v*>(img) + i;
+    __device__ __forceinline__ void load(const void* img, int w, int ix, int row) {
+        const rs_f4v* p = reinterpret_cast<const rs_f4v*>(img) + ((size_t)row * w + ix);
         a = LDM ? __builtin_nontemporal_load(p) : p[0]; b = LDM ? __builtin_nontemporal_load(p + 1) : p[1];
     }
+    __device__ __forceinline__ void unpack() {}
     __device__ __forceinline__ float I0() const { return a.x; }
     __device__ __forceinline__ float X0() const { return a.y; }
     __device__ __forceinline__ float Y0() const { return a.z; }
@@ -190,47 +205,44 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
     unsigned m_in = 0;
     double rx = 0, ry = 0, px = 0, py = 0, Kud = 0, Kvd = 0;
     float drescale = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const double sx = cxd + RS_OX(k), sy = cyd + RS_OY(k);
-        const double qx = (sx - A.cx) * A.fxi, qy = (sy - A.cy) * A.fyi;
-        const double ppx = (R0_ * qx + R1_ * qy + R2_ * 1.0) + tid0;
-        const double ppy = (R3_ * qx + R4_ * qy + R5_ * 1.0) + tid1;
-        const double ppz = (R6_ * qx + R7_ * qy + R8_ * 1.0) + tid2;
-        const double rz = rs_rcp_refined(ppz);
-        const double kx = rs_div(ppx, ppz, rz) * A.fx + A.cx, ky = rs_div(ppy, ppz, rz) * A.fy + A.cy;
-        if (kx >= 2 && ky >= 2 && kx < A.w - 2 && ky < A.h - 2) m_in |= 1u << k;
-        kxf[k] = (float)kx; kyf[k] = (float)ky;
-        if (k == 4) {
-            rx = qx; ry = qy; px = ppx; py = ppy; Kud = kx; Kvd = ky;
-            drescale = (float)rs_div(1.0, ppz, rz);            // (float)(1.0 / pz)
-        }
-    }
-    const bool centre_in = (m_in >> 4) & 1u;
-
-    // GradientImage::interpolate (Array2D.h:265-286): the texel loads of the lane are issued together, unconditional on clamped
-    // addresses (ONE memory round trip for the whole pattern), then consumed in pattern order
+    // The kernel is a software pipeline over the pattern pixels (stages pinned by scheduling barriers): projection P(k), the two
+    // 16-byte texel loads L(k) of its bilinear rows, and the photometric sums S(k) — always in pattern order — run interleaved,
+    //     P4 P0 L0 P1 L1 [geometry] P2 L2 | S0 P3 L3 | S1 L4 | S2 P5 L5 | S3 P6 L6 | S4 P7 L7 | S5 S6 S7,
+    // so that the sixteen scattered loads of a lane (64 distinct lines per instruction: ~64 cycles of the CU's address pipeline each)
+    // are spread over the whole arithmetic instead of arriving from all twelve waves of the CU at once, and only three pixels'
+    // texels are in flight per lane.  The centre (pattern pixel 4, offset (0,0)) goes first: every sampling mask needs it.
+#define RS_PROJ(k) do { \
+        const double sx = cxd + RS_OX(k), sy = cyd + RS_OY(k); \
+        const double qx = (sx - A.cx) * A.fxi, qy = (sy - A.cy) * A.fyi; \
+        const double ppx = (R0_ * qx + R1_ * qy + R2_ * 1.0) + tid0; \
+        const double ppy = (R3_ * qx + R4_ * qy + R5_ * 1.0) + tid1; \
+        const double ppz = (R6_ * qx + R7_ * qy + R8_ * 1.0) + tid2; \
+        const double rz = rs_rcp_refined(ppz); \
+        const double kx = rs_div(ppx, ppz, rz) * A.fx + A.cx, ky = rs_div(ppy, ppz, rz) * A.fy + A.cy; \
+        if (kx >= 2 && ky >= 2 && kx < A.w - 2 && ky < A.h - 2) m_in |= 1u << (k); \
+        kxf[k] = (float)kx; kyf[k] = (float)ky; \
+        if ((k) == 4) { \
+            rx = qx; ry = qy; px = ppx; py = ppy; Kud = kx; Kvd = ky; \
+            drescale = (float)rs_div(1.0, ppz, rz);            /* (float)(1.0 / pz) */ \
+        } \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+    // GradientImage::interpolate (Array2D.h:265-286): unconditional loads on clamped addresses (a lane that does not sample reads texel 0)
     RsRow<HALF, LDM> t0r[8], t1r[8];
-    size_t tix[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const bool smp = run && centre_in && ((m_in >> k) & 1u);
-        const int ix = (int)kxf[k], iy = (int)kyf[k];
-        tix[k] = (smp && !(X.dbg_flags & 1)) ? (size_t)iy * A.w + ix : (size_t)0;
-    }
-    // Issue order = image row by image row (star8: rows -2 | -1 -1 | 0 0 0 | +1 | +2, each tap reads its row and the next): the
-    // requests of a lane that fall into the same 128-byte line follow each other, so the line is still in the L1 (or its miss
-    // pending) when the next one asks for it — 6 line fills per residual instead of 16.  (The asm statements only pin the order.)
-#define RS_ORDER() asm volatile("" ::: "memory")
-    t0r[0].load(ft.grad0, tix[0]); RS_ORDER();
-    t1r[0].load(ft.grad0, tix[0] + A.w); t0r[1].load(ft.grad0, tix[1]); t0r[2].load(ft.grad0, tix[2]); RS_ORDER();
-    t1r[1].load(ft.grad0, tix[1] + A.w); t1r[2].load(ft.grad0, tix[2] + A.w); t0r[3].load(ft.grad0, tix[3]); t0r[4].load(ft.grad0, tix[4]); t0r[5].load(ft.grad0, tix[5]); RS_ORDER();
-    t1r[3].load(ft.grad0, tix[3] + A.w); t1r[4].load(ft.grad0, tix[4] + A.w); t1r[5].load(ft.grad0, tix[5] + A.w); t0r[6].load(ft.grad0, tix[6]); RS_ORDER();
-    t1r[6].load(ft.grad0, tix[6] + A.w); t0r[7].load(ft.grad0, tix[7]); RS_ORDER();
-    t1r[7].load(ft.grad0, tix[7] + A.w);
-#undef RS_ORDER
+#define RS_LOAD(k) do { \
+        const bool smp_ = run && centre_in && ((m_in >> (k)) & 1u) && !(X.dbg_flags & 1); \
+        int ix_ = smp_ ? (int)kxf[k] : 0, iy_ = smp_ ? (int)kyf[k] : 0; \
+        if (X.dbg_flags & 4) { ix_ = (ln & 7) * 64; iy_ = (ln >> 3) * 4 + ((X.dbg_flags & 8) ? (ti & 31) * 32 : 0); }     /* development: a line per lane, always cached (8: per tile) */ \
+        t0r[k].load(img0, ldw, ix_, iy_); t1r[k].load(img0, ldw, ix_, iy_ + 1); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+    const void* const img0 = HALF ? ft.grad0t : ft.grad0;                         // fp16: the tiled copy
+    const int ldw = HALF ? (A.w + CML_TILE_W - 1) / CML_TILE_W : A.w;             // tiles per tile row / texels per row
+    RS_PROJ(4);
+    const bool centre_in = (m_in >> 4) & 1u;
+    RS_PROJ(0); RS_LOAD(0); RS_PROJ(1); RS_LOAD(1);
+#if RS_DEPTH >= 5
+    RS_PROJ(2); RS_LOAD(2);
+#endif
     RS_STAMP(2);
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- geometric Jacobians, BA.cpp:120-188 (the expression shapes of k_ba_linearize with its per-lane constants folded), evaluated
     //      while the texels are in flight and parked in the staged row: nothing of the geometry stays in registers over the pixel loop
@@ -276,6 +288,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
     }
     RS_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
+#if RS_DEPTH >= 5
+    RS_PROJ(3); RS_LOAD(3); RS_LOAD(4);
+#else
+    RS_PROJ(2); RS_LOAD(2);
+#endif
     // what the classification needs of the previous state: requested here, behind the texels, so that the round trip runs under the pixel loop
     const float pre_energy = rs_at(A.r_energy, r4);
     const int pre_new_state = rs_at(A.r_new_state, r4), pre_ppos = rs_at(A.point_pos, r4);
@@ -291,48 +308,62 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
     double JIr0 = 0, JIr1 = 0, Jabr0 = 0, Jabr1 = 0;
     float B00 = 0, B01 = 0, B11 = 0;
     unsigned m_nf = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        {
-            const bool smp = run && centre_in && ((m_in >> k) & 1u);
-            const float x = kxf[k], y = kyf[k];
-            const int ix = (int)x, iy = (int)y;
-            const float dx = x - (float)ix, dy = y - (float)iy;
-            const float dxdy = dx * dy;
-            const float tw00 = 1 - dx - dy + dxdy, tw01 = dx - dxdy, tw10 = dy - dxdy, tw11 = dxdy;
-            const float Iv = t0r[k].I0() * tw00 + t0r[k].I1() * tw01 + t1r[k].I0() * tw10 + t1r[k].I1() * tw11;
-            const float gxv = t0r[k].X0() * tw00 + t0r[k].X1() * tw01 + t1r[k].X0() * tw10 + t1r[k].X1() * tw11;
-            const float gyv = t0r[k].Y0() * tw00 + t0r[k].Y1() * tw01 + t1r[k].Y0() * tw10 + t1r[k].Y1() * tw11;
-            const float I = smp ? Iv : 0.f, gx = smp ? gxv : 0.f, gy = smp ? gyv : 0.f;
-            const bool finite = isfinite(I) && isfinite(gx) && isfinite(gy);
-            if (((m_in >> k) & 1u) && !finite) m_nf |= 1u << k;
-            const float refColor = S[RS_S_COL + k];
-            const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
-            const float residual = I - refRealColor;
-            float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
-            const double wden = A.oth_d + (double)(gx * gx + gy * gy);
-            float wgt = sqrtf((float)rs_div(A.oth_d, wden, rs_rcp_refined(wden)));
-            wgt = (float)(0.5f * ((double)wgt + (double)S[RS_S_COL + 8 + k]));
-            const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
-            const float hw0 = hw;
-            if (hw < 1) hw = sqrtf(hw);
-            hw = hw * wgt;
-            const float f1 = gx * hw, f2 = gy * hw;                     // hitColor[1], hitColor[2]
-            const float drdA = I - fh.b0;
-            const float a_ = drdA * hw;
-            const float rF = residual * hw;
-            const double f1d = (double)f1, f2d = (double)f2, ad = (double)a_, hwd = (double)hw, rFd = (double)rF;
-            J00 = (float)RS_XFMA(f1d, f1d, (double)J00); J10 = (float)RS_XFMA(f1d, f2d, (double)J10); J11 = (float)RS_XFMA(f2d, f2d, (double)J11);
-            Q00 = (float)RS_XFMA(ad, f1d, (double)Q00); Q10 = (float)RS_XFMA(hwd, f1d, (double)Q10);
-            Q01 = (float)RS_XFMA(ad, f2d, (double)Q01); Q11 = (float)RS_XFMA(hwd, f2d, (double)Q11);
-            rr = (float)RS_XFMA(rFd, rFd, (double)rr);
-            E = (float)((double)E + (double)pf * (2.0 - (double)hw0));                            // energyLeft, BA.cpp:237
-            wJI2 = (float)((double)wJI2 + (double)(hw * hw) * RS_XFMA(f2d, f2d, f1d * f1d));           // wJI2_sum, BA.cpp:257
-            JIr0 = RS_XFMA(rFd, f1d, JIr0); JIr1 = RS_XFMA(rFd, f2d, JIr1);
-            Jabr0 = RS_XFMA(rFd, (A.opt_a ? ad : 0.0), Jabr0); Jabr1 = RS_XFMA(rFd, (A.opt_b ? hwd : 0.0), Jabr1);           // BA.cpp:273-278: a zeroed column contributes rF * 0
-            B00 += drdA * drdA * hw * hw; B01 += drdA * hw * hw * 1.f; B11 += hw * hw * 1.f * 1.f;
-        }
-    }
+#define RS_SUM(k) do { \
+        t0r[k].unpack(); t1r[k].unpack(); \
+        const bool smp = run && centre_in && ((m_in >> (k)) & 1u); \
+        const float x = kxf[(k)], y = kyf[(k)]; \
+        const int ix = (int)x, iy = (int)y; \
+        const float dx = x - (float)ix, dy = y - (float)iy; \
+        const float dxdy = dx * dy; \
+        const float tw00 = 1 - dx - dy + dxdy, tw01 = dx - dxdy, tw10 = dy - dxdy, tw11 = dxdy; \
+        const float Iv = t0r[(k)].I0() * tw00 + t0r[(k)].I1() * tw01 + t1r[(k)].I0() * tw10 + t1r[(k)].I1() * tw11; \
+        const float gxv = t0r[(k)].X0() * tw00 + t0r[(k)].X1() * tw01 + t1r[(k)].X0() * tw10 + t1r[(k)].X1() * tw11; \
+        const float gyv = t0r[(k)].Y0() * tw00 + t0r[(k)].Y1() * tw01 + t1r[(k)].Y0() * tw10 + t1r[(k)].Y1() * tw11; \
+        const float I = smp ? Iv : 0.f, gx = smp ? gxv : 0.f, gy = smp ? gyv : 0.f; \
+        const bool finite = isfinite(I) && isfinite(gx) && isfinite(gy); \
+        if (((m_in >> (k)) & 1u) && !finite) m_nf |= 1u << (k); \
+        const float refColor = S[RS_S_COL + (k)]; \
+        const float refRealColor = (float)(aff_a * (double)refColor + aff_b); \
+        const float residual = I - refRealColor; \
+        float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual)); \
+        const double wden = A.oth_d + (double)(gx * gx + gy * gy); \
+        float wgt = sqrtf((float)rs_div(A.oth_d, wden, rs_rcp_refined(wden))); \
+        wgt = (float)(0.5f * ((double)wgt + (double)S[RS_S_COL + 8 + (k)])); \
+        const float pf = wgt * wgt * hw * residual * residual;      /* energy term factor, :237 */ \
+        const float hw0 = hw; \
+        if (hw < 1) hw = sqrtf(hw); \
+        hw = hw * wgt; \
+        const float f1 = gx * hw, f2 = gy * hw;                     /* hitColor[1], hitColor[2] */ \
+        const float drdA = I - fh.b0; \
+        const float a_ = drdA * hw; \
+        const float rF = residual * hw; \
+        const double f1d = (double)f1, f2d = (double)f2, ad = (double)a_, hwd = (double)hw, rFd = (double)rF; \
+        J00 = (float)RS_XFMA(f1d, f1d, (double)J00); J10 = (float)RS_XFMA(f1d, f2d, (double)J10); J11 = (float)RS_XFMA(f2d, f2d, (double)J11); \
+        Q00 = (float)RS_XFMA(ad, f1d, (double)Q00); Q10 = (float)RS_XFMA(hwd, f1d, (double)Q10); \
+        Q01 = (float)RS_XFMA(ad, f2d, (double)Q01); Q11 = (float)RS_XFMA(hwd, f2d, (double)Q11); \
+        rr = (float)RS_XFMA(rFd, rFd, (double)rr); \
+        E = (float)((double)E + (double)pf * (2.0 - (double)hw0));                            /* energyLeft, BA.cpp:237 */ \
+        wJI2 = (float)((double)wJI2 + (double)(hw * hw) * RS_XFMA(f2d, f2d, f1d * f1d));           /* wJI2_sum, BA.cpp:257 */ \
+        JIr0 = RS_XFMA(rFd, f1d, JIr0); JIr1 = RS_XFMA(rFd, f2d, JIr1); \
+        Jabr0 = RS_XFMA(rFd, (A.opt_a ? ad : 0.0), Jabr0); Jabr1 = RS_XFMA(rFd, (A.opt_b ? hwd : 0.0), Jabr1);           /* BA.cpp:273-278: a zeroed column contributes rF * 0 */ \
+        B00 += drdA * drdA * hw * hw; B01 += drdA * hw * hw * 1.f; B11 += hw * hw * 1.f * 1.f; \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+#if RS_DEPTH >= 5
+    RS_SUM(0); RS_PROJ(5); RS_LOAD(5);
+    RS_SUM(1); RS_PROJ(6); RS_LOAD(6);
+    RS_SUM(2); RS_PROJ(7); RS_LOAD(7);
+    RS_SUM(3); RS_SUM(4); RS_SUM(5); RS_SUM(6); RS_SUM(7);
+#else
+    RS_SUM(0); RS_PROJ(3); RS_LOAD(3);
+    RS_SUM(1); RS_LOAD(4);
+    RS_SUM(2); RS_PROJ(5); RS_LOAD(5);
+    RS_SUM(3); RS_PROJ(6); RS_LOAD(6);
+    RS_SUM(4); RS_PROJ(7); RS_LOAD(7);
+    RS_SUM(5); RS_SUM(6); RS_SUM(7);
+#endif
+#undef RS_SUM
+#undef RS_LOAD
+#undef RS_PROJ
 
 #ifdef CML_RS_STAMPS
     { float dep = J00 + E + B11; asm volatile("" : "+v"(dep)); RS_STAMP(4); }

@@ -200,7 +200,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pyr)
-        for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) (void)hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) (void)hipFree(kv.second.lv[l].gray); }
+        for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) (void)hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) (void)hipFree(kv.second.lv[l].gray); if (kv.second.lv[l].tiled) (void)hipFree(kv.second.lv[l].tiled); }
     for (auto& kv : c->img_pool) (void)hipFree(kv.second);
     c->img_pool.clear();
     DevBuf* all[] = {&c->img_tmp, &c->h2d_blob, &c->h2d_desc, &c->d2h_blob, &c->frames, &c->pairs, &c->pt_x, &c->pt_y, &c->pt_idepth, &c->pt_idepth_zero, &c->pt_prior, &c->pt_host,
@@ -326,7 +326,42 @@ static void free_level(cmlhip_ctx* c, PyrLevel& L) {
     const size_t n = (size_t)L.w * L.h;
     pool_release(c, L.grad, n * texel_bytes(c));
     pool_release(c, L.gray, n * sizeof(float));
+    pool_release(c, L.tiled, cml_tiled_bytes(L.w, L.h));
     L = PyrLevel();
+}
+
+// one thread per tile row (32 bytes): texels x0 .. x0+4 of row y (clamped at the image border) as 5 x {I, dI/dx, dI/dy} halves
+__global__ void k_tile_level0_f16(const uint2* __restrict__ img, int w, int h, int tw, int th, uint4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tw * th * CML_TILE_H) return;
+    const int r = i & (CML_TILE_H - 1), t = i / CML_TILE_H, tx = t % tw, ty = t / tw;
+    const int y = min(CML_TILE_H * ty + r, h - 1);
+    unsigned short hv[16];
+#pragma unroll
+    for (int cidx = 0; cidx < 5; cidx++) {
+        const uint2 v = img[(size_t)y * w + min(CML_TILE_W * tx + cidx, w - 1)];       // {I | dx << 16, dy | 0}
+        hv[3 * cidx] = (unsigned short)(v.x & 0xffffu); hv[3 * cidx + 1] = (unsigned short)(v.x >> 16); hv[3 * cidx + 2] = (unsigned short)(v.y & 0xffffu);
+    }
+    hv[15] = 0;
+    uint4 o0, o1;
+    o0.x = hv[0] | ((unsigned)hv[1] << 16); o0.y = hv[2] | ((unsigned)hv[3] << 16); o0.z = hv[4] | ((unsigned)hv[5] << 16); o0.w = hv[6] | ((unsigned)hv[7] << 16);
+    o1.x = hv[8] | ((unsigned)hv[9] << 16); o1.y = hv[10] | ((unsigned)hv[11] << 16); o1.z = hv[12] | ((unsigned)hv[13] << 16); o1.w = hv[14] | ((unsigned)hv[15] << 16);
+    out[2 * (size_t)i] = o0; out[2 * (size_t)i + 1] = o1;
+}
+
+int cml_tiled_level0(cmlhip_ctx* c, uint64_t id, const void** out) {
+    auto it = c->pyr.find(id);
+    if (it == c->pyr.end() || !it->second.lv[0].grad || c->lim.texel_format != CMLHIP_TEXEL_F16) return CMLHIP_ERR_NOT_FOUND;
+    PyrLevel& L = it->second.lv[0];
+    if (!L.tiled) { if (int rc = pool_alloc(c, cml_tiled_bytes(L.w, L.h), &L.tiled)) return rc; L.tiled_valid = false; }
+    if (!L.tiled_valid) {
+        const int tw = (L.w + CML_TILE_W - 1) / CML_TILE_W, th = (L.h + CML_TILE_H - 1) / CML_TILE_H, nthr = tw * th * CML_TILE_H;
+        k_tile_level0_f16<<<cml_div_up(nthr, 256), 256, 0, c->stream>>>(reinterpret_cast<const uint2*>(L.grad), L.w, L.h, tw, th, reinterpret_cast<uint4*>(L.tiled));
+        CML_CHECK(c, hipGetLastError());
+        L.tiled_valid = true;
+    }
+    *out = L.tiled;
+    return CMLHIP_OK;
 }
 
 extern "C" {
@@ -337,6 +372,7 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
     PyrLevel& L = P.lv[level];
     (void)hipStreamSynchronize(c->stream);
     if (L.w != w || L.h != h) free_level(c, L);
+    L.tiled_valid = false;
     size_t n = (size_t)w * h;
     int rc;
     if (!L.grad && (rc = pool_alloc(c, n * texel_bytes(c), &L.grad))) return rc;

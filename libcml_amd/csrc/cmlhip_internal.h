@@ -26,6 +26,8 @@ struct PyrLevel {
     int w = 0, h = 0;
     void* grad = nullptr;   // float4 {I,dx,dy,0} (or 4 halves) per texel, x fastest
     float* gray = nullptr;  // may be null when only the gradient image was put
+    void* tiled = nullptr;  // fp16 level 0 only: the same texels in 128-byte tiles (cml_tiled_level0), built when a BA window first names the frame
+    bool tiled_valid = false;
 };
 struct Pyramid {
     int levels = 0;
@@ -44,7 +46,15 @@ struct FrameDev {
     const void* grad0;      // level-0 gradient image of the frame
     float frame_energy_th;
     float b0;
+    const void* grad0t;     // fp16 texels: the level-0 image again in 128-byte tiles (null otherwise), see cml_tiled_level0
 };
+// Tiled fp16 level 0 (read by the lane-per-residual kernel of the resident loop).  One 128-byte line = a tile of 4 rows x 4 texels
+// plus, in every row, a copy of the first texel of the next tile (5 texels x 6 bytes {I, dI/dx, dI/dy} + 2 bytes pad = 32 bytes per
+// row): the two texels of a bilinear row always lie in ONE tile row, and the 6 x 6 texel footprint of a pattern covers on average
+// (1 + 5/4)^2 = 5.1 lines instead of the 7.9 of the row-major image (6 rows x (1 + 5/16)).
+#define CML_TILE_W 4
+#define CML_TILE_H 4
+static inline size_t cml_tiled_bytes(int w, int h) { return (size_t)((w + CML_TILE_W - 1) / CML_TILE_W) * ((h + CML_TILE_H - 1) / CML_TILE_H) * 128; }
 
 struct cmlhip_ctx {
     cmlhip_limits lim{};
@@ -160,6 +170,7 @@ int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // sync 
 void cml_d2h_batch_begin(cmlhip_ctx* c);
 int cml_d2h_batch_flush(cmlhip_ctx* c);
 const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id);
+int cml_tiled_level0(cmlhip_ctx* c, uint64_t id, const void** out);      // builds (once) and returns the tiled fp16 level 0 of a cached pyramid
 
 static inline int cml_div_up(int a, int b) { return (a + b - 1) / b; }
 
