@@ -457,6 +457,11 @@ typedef struct {
  * marginalised; frames with fixed == 0 are optimised (1..32 of them: the reduced pose system is factorised in the LDS of one
  * CU), the others only constrain the points.  points (n_points x 3) and the R, t of the free frames are updated in place;
  * edge_bad (one byte per edge) receives apply()'s removal test. */
+/* pbStopFlag of localOptimize (IndirectBundleAdjustment.cpp:7, handed to g2o by setForceStopFlag :65-67): a byte the caller may set
+ * from another thread while cmlhip_lba_optimize runs.  g2o tests it before every optimize() iteration (sparse_optimizer.cpp,
+ * `!terminate()`); here it is tested before every Levenberg iteration and, in the structure-only mode (one launch per pass), before
+ * each pass.  iterations_done reports what ran.  NULL (the default) = no flag.  The pointer must stay valid until it is reset. */
+int cmlhip_lba_set_stop_flag(cmlhip_ctx* ctx, const unsigned char* flag);
 int cmlhip_lba_optimize(cmlhip_ctx* ctx, int n_frames, cmlhip_lba_frame* frames, int n_points, double* points,
                         const int* point_offsets, const cmlhip_lba_edge* edges, int fix_frames, int num_iterations,
                         int refine_iterations, unsigned char* edge_bad, cmlhip_lba_result* out);

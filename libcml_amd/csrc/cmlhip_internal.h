@@ -113,6 +113,7 @@ struct cmlhip_ctx {
     DevBuf ini_points, ini_partial;          // coarse initializer (initializer.hip)
     DevBuf pnp_matches, pnp_flags, pnp_out;  // pose-only optimisation (pnp.hip)
     DevBuf lba_frames, lba_cams, lba_points, lba_off, lba_edges, lba_err, lba_flags, lba_work;   // local bundle adjustment (lba.hip)
+    const volatile unsigned char* lba_stop = nullptr;         // the caller's pbStopFlag (cmlhip_lba_set_stop_flag): g2o's forceStopFlag
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)

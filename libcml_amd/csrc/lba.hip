@@ -662,7 +662,7 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
         double currentChi = h4[0], maxdiag = h4[2], lambda = 0.0, ni = 2.0;
         int done = 0;
         bool ok = true;
-        for (int it = 0; it < iters && ok; it++) {                          // optimization_algorithm_levenberg.cpp:58-160
+        for (int it = 0; it < iters && ok && !(c->lba_stop && *c->lba_stop); it++) {      // sparse_optimizer.cpp: `i < iterations && !terminate() && ok`; optimization_algorithm_levenberg.cpp:58-160
             if (it == 0) { lambda = 1e-5 * maxdiag; ni = 2.0; }
             double rho = 0.0;
             int qmax = 0;
@@ -722,6 +722,12 @@ static int lba_levenberg(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, 
 
 extern "C" {
 
+int cmlhip_lba_set_stop_flag(cmlhip_ctx* c, const unsigned char* flag) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    c->lba_stop = flag;
+    return CMLHIP_OK;
+}
+
 int cmlhip_lba_optimize(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, int n_points, double* points, const int* point_offsets,
                         const cmlhip_lba_edge* edges, int fix_frames, int num_iterations, int refine_iterations, unsigned char* edge_bad,
                         cmlhip_lba_result* out) { CML_DEV(c);
@@ -756,9 +762,12 @@ int cmlhip_lba_optimize(cmlhip_ctx* c, int n_frames, cmlhip_lba_frame* frames, i
     A.n_points = n_points; A.delta = (double)sqrtf(5.991f);             // const float thHuberIndirect = sqrt(5.991), :111
     const int nb = cml_div_up(n_points, 64);
     A.iterations = num_iterations; A.robust = 1;                        // startOptimization(mNumIteration, true, false), :193
-    if (num_iterations > 0) k_lba_structure_only<<<nb, 64, 0, c->stream>>>(A);
-    out->iterations_done[0] = num_iterations;
-    if (refine_iterations > 0) {                                        // startOptimization(mRefineIteration, true, true), :196-207
+    // forceStopFlag (setForceStopFlag(pbStopFlag), IBA.cpp:65-67): g2o tests it before every iteration; a pass of the structure-only
+    // solver is ONE launch here, so the flag is tested before each pass
+    const bool stop0 = c->lba_stop && *c->lba_stop;
+    if (num_iterations > 0 && !stop0) k_lba_structure_only<<<nb, 64, 0, c->stream>>>(A);
+    out->iterations_done[0] = stop0 ? 0 : num_iterations;
+    if (refine_iterations > 0 && !(c->lba_stop && *c->lba_stop)) {                                        // startOptimization(mRefineIteration, true, true), :196-207
         k_lba_edge_test<<<nb, 64, 0, c->stream>>>(A.cams, A.edges, A.off, A.points, A.err, n_points, level1);
         A.iterations = refine_iterations; A.robust = 0;
         k_lba_structure_only<<<nb, 64, 0, c->stream>>>(A);

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "cmlhip_ba_finish_keyframe": (C.c_int, [_ctx, C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_ubyte), _P(C.c_double), _P(C.c_float)]),
     "cmlhip_pnp_optimize": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_double), _P(C.c_double), _i, C.c_void_p, _P(C.c_ubyte), _i, _i, _i, _P(abi.PnpResult)]),
+    "cmlhip_lba_set_stop_flag": (C.c_int, [_ctx, C.c_void_p]),
     "cmlhip_lba_optimize": (C.c_int, [_ctx, _i, C.c_void_p, _i, _P(C.c_double), _P(C.c_int), C.c_void_p, _i, _i, _i, _P(C.c_ubyte), _P(abi.LbaResult)]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
@@ -443,6 +444,10 @@ class Ctx:
         return out
 
     # ------------------------------------------------------------------ ORB side: local bundle adjustment (IndirectBundleAdjustment)
+    def lba_set_stop_flag(self, flag):
+        """flag: a 1-element uint8 array the caller keeps alive (pbStopFlag), or None."""
+        self.ck(self.L.cmlhip_lba_set_stop_flag(self.h, flag.ctypes.data if flag is not None else None))
+
     def lba_optimize(self, frames, points, point_offsets, edges, fix_frames=True, num_iterations=5, refine_iterations=0):
         """frames (LBA_FRAME_DTYPE) and points (n x 3 float64) are updated in place.  Returns (edge_bad uint8, abi.LbaResult)."""
         assert frames.dtype == abi.LBA_FRAME_DTYPE and edges.dtype == abi.LBA_EDGE_DTYPE and frames.flags.c_contiguous and edges.flags.c_contiguous

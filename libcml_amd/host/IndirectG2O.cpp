@@ -65,7 +65,7 @@ IndirectCameraOptimizerResult IndirectCameraOptimizer::optimize(const double fra
 }
 
 bool IndirectBundleAdjustment::localOptimize(const std::vector<Frame>& localKeyFrames, const std::vector<Frame>& fixedCameras, const std::vector<Point>& points,
-                                             bool fixFrames) {
+                                             bool fixFrames, bool* pbStopFlag) {
     mHaveSolution = false;
     if (points.empty()) { mError = "G2O BA : No points"; return false; }                               // IBA.cpp:37-40
     if (localKeyFrames.size() <= 2) { mError = "G2O BA : Not enough frames"; return false; }           // :43-46
@@ -97,7 +97,11 @@ bool IndirectBundleAdjustment::localOptimize(const std::vector<Frame>& localKeyF
         mOff.push_back((int)mEdges.size());
     }
     if (numIndirect < 10) { mError = "G2O Ba : Not enough indirect points"; return false; }            // :167-170
+    if (pbStopFlag != nullptr && *pbStopFlag) { mError = "G2O Ba: Stop flag is set to true"; return false; }   // :173-178
     mBad.assign(mEdges.size(), 0);
+    static_assert(sizeof(bool) == 1, "pbStopFlag is read as a byte");
+    cmlhip_lba_set_stop_flag(mCtx, reinterpret_cast<const unsigned char*>(pbStopFlag));                 // setForceStopFlag, :65-67; also the test before the refinement pass, :193-198
+    struct Reset { cmlhip_ctx* c; ~Reset() { cmlhip_lba_set_stop_flag(c, nullptr); } } reset{mCtx};
     const int rc = cmlhip_lba_optimize(mCtx, (int)mFrames.size(), mFrames.data(), (int)points.size(), mX.data(), mOff.data(), mEdges.data(),
                                        fixFrames ? 1 : 0, mNumIteration, mRefineIteration, mBad.data(), &mResult);
     if (rc != CMLHIP_OK) { mError = cmlhip_last_error(mCtx); return false; }

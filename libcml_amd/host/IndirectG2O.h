@@ -63,7 +63,10 @@ public:
     // localOptimize (IndirectBundleAdjustment.cpp:7-208) with the covisibility search already done by the caller:
     // localKeyFrames = lLocalKeyFrames, fixedCameras = lFixedCameras, points = lLocalIndirectPoints (with ALL their indirect
     // apparitions; those into frames outside the two sets are ignored, :131).  Returns what the reference returns.
-    bool localOptimize(const std::vector<Frame>& localKeyFrames, const std::vector<Frame>& fixedCameras, const std::vector<Point>& points, bool fixFrames);
+    // pbStopFlag as in the reference's signature (IBA.h:27): tested before the optimisation starts (:173-178, returns false), handed to
+    // the solver (setForceStopFlag, :65-67 -> cmlhip_lba_set_stop_flag) and tested again before the refinement pass (:193-198)
+    bool localOptimize(const std::vector<Frame>& localKeyFrames, const std::vector<Frame>& fixedCameras, const std::vector<Point>& points, bool fixFrames,
+                       bool* pbStopFlag = nullptr);
     // apply() (:238-337): the optimised keyframe cameras and point positions, and the (frameId, pointId) observations the
     // reference would remove (chi2 > 5.991 or negative depth, mRemoveEdge, not the point's reference frame, :325-334)
     struct Removal { int frameId, pointId; };

@@ -82,6 +82,8 @@ def test_local_ba_mirror(fix_frames):
         assert not ba.local_optimize(hf[:nl], hf[nl:nl + 2], hp, ap, fix_frames) and "fixed cameras" in ba.last_error()    # :95-98
         lo0, X0, rem0, _ = ba.apply()
         assert len(rem0) == 0                                                       # nothing optimised yet: apply() is a no-op
+        stop = np.ones(1, np.uint8)                                                 # pbStopFlag set before the call: refused, :173-178
+        assert not ba.local_optimize(hf[:nl], hf[nl:], hp, ap, fix_frames, stop_flag=stop) and "Stop flag" in ba.last_error()
         assert ba.local_optimize(hf[:nl], hf[nl:], hp, ap, fix_frames), ba.last_error()
         lo, X, rem, res = ba.apply()
         ba.close()

@@ -53,6 +53,28 @@ def test_lba_edge_cases():
         ctx.close()
 
 
+@pytest.mark.parametrize("fix_frames", [True, False])
+def test_lba_stop_flag(fix_frames):
+    """pbStopFlag (IndirectBundleAdjustment.cpp:65-67 -> g2o forceStopFlag): a set flag ends the optimisation before its next
+    iteration (Levenberg) / pass (structure-only); nothing moves, the removal test still runs on the untouched state."""
+    S = LS.scene(pose_noise=0.0 if fix_frames else 0.02, n_points=300, seed=4)
+    ctx = device.Ctx(max_frames=2)
+    try:
+        flag = np.ones(1, np.uint8)
+        ctx.lba_set_stop_flag(flag)
+        fr, pts = S["frames"].copy(), S["points"].copy()
+        bad, r = ctx.lba_optimize(fr, pts, S["off"], S["edges"], fix_frames, 5, 3)
+        assert r.ok == 1 and list(r.iterations_done) == [0, 0]
+        assert np.array_equal(pts, S["points"])
+        assert np.abs(fr["R"] - S["frames"]["R"]).max() < 1e-12 and np.abs(fr["t"] - S["frames"]["t"]).max() < 1e-12      # (written back from the device's pose form)
+        flag[0] = 0                                                     # cleared: the same call now optimises
+        bad, r = ctx.lba_optimize(fr, pts, S["off"], S["edges"], fix_frames, 5, 0)
+        assert r.iterations_done[0] > 0 and np.abs(pts - S["points"]).max() > 0
+        ctx.lba_set_stop_flag(None)
+    finally:
+        ctx.close()
+
+
 def _pose_diff(a, b):
     return float(np.abs(a["R"] - b["R"]).max()), float(np.abs(a["t"] - b["t"]).max())
 
