@@ -100,8 +100,11 @@ __device__ __forceinline__ float rs4_jpdc(const int k, const double E0, const do
     return (float)(((m * q) + add) * scl);
 }
 
-template <bool HALF>
-__global__ __launch_bounds__(256, 3) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
+// MINB: workgroups per CU the register budget is sized for — 3 (168 VGPRs: the 13-18 registers beyond that spill to a scratch frame) for
+// the mid-size windows that fill the chip; 1 for the usual small window, which does not even put one wave on every SIMD: no register
+// bound, no scratch frame (a kernel with one pays for it at every dispatch)
+template <bool HALF, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     __shared__ double s_shd[4][RS_RES * RS_DSTRIDE];                                   // [wave][residual * RS_DSTRIDE + quantity * 9 + pixel]
     __shared__ float s_shf[4][RS_RES * RS_FSTRIDE];                                    // [wave][residual * RS_FSTRIDE + quantity * 8 + pixel]
     // the staged reduced record (layout of k_ba_acc's s_rec + Jpdd at 40,41) reuses the wave's fp64 rows once the sums are taken (a wave's
@@ -178,6 +181,27 @@ __global__ __launch_bounds__(256, 3) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
         ta[u] = rs4_load_texel<HALF>(ft.grad0, i1); tb[u] = rs4_load_texel<HALF>(ft.grad0, i1 + 1);
         tc[u] = rs4_load_texel<HALF>(ft.grad0, i1 + A.w); td[u] = rs4_load_texel<HALF>(ft.grad0, i1 + A.w + 1);
     }
+    // ---- geometric Jacobians, BA.cpp:120-188, evaluated HERE — behind the issue of the texel loads, ahead of their first use: they
+    //      depend on the projection only, and at small windows a wave is alone on its SIMD, so whatever runs under the texel round
+    //      trip is free (the values wait in eight registers for the staging below).  Every lane evaluates two entries of each group
+    //      (k = j and k = j + 4), same expression shapes as k_ba_linearize.
+    __builtin_amdgcn_sched_barrier(0);
+    const float new_idepth = (float)(drescale * idepth);
+    const float u = (float)px, v = (float)py;            // BA.cpp:121-122: un-normalised x,y, literal
+    const float fxf = (float)A.fx, fyf = (float)A.fy;
+    const double rfx = rs4_rcp_refined((double)fxf), rfy = rs4_rcp_refined((double)fyf);      // wave-uniform
+    // Jpdxi[0][k], Jpdxi[1][k], k = j (0..3) and k = j + 4 (4, 5 for j < 2)          (fp32, BA.cpp:133-147)
+    const float xa0 = rs4_sel4(j, new_idepth * fxf, 0.f, -new_idepth * u * fxf, -u * v * fxf);
+    const float xa1 = rs4_sel4(j, 0.f, new_idepth * fyf, -new_idepth * v * fyf, -(1 + v * v) * fyf);
+    const float xb0 = rs4_sel4(j, (1 + u * u) * fxf, -v * fxf, 0.f, 0.f);
+    const float xb1 = rs4_sel4(j, u * v * fyf, u * fyf, 0.f, 0.f);
+    // Jpdc[0][j], Jpdc[1][j]                                                         (:150-176)
+    const float c0 = rs4_jpdc<true>(j, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
+    const float c1 = rs4_jpdc<false>(j + 4, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
+    // Jpdd[j], j < 2                                                                 (:178-182)
+    const bool odd = j & 1;
+    const double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
+    __builtin_amdgcn_sched_barrier(0);
     float I[2], gx[2], gy[2];
     bool finite[2];
 #pragma unroll
@@ -262,7 +286,6 @@ __global__ __launch_bounds__(256, 3) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     const float wJI2 = rs4_quad_bcast_f<1>(sumA2);
 
     // ---- classification, BA.cpp:66-72,115-118,297-314, and the fused applyRes(copyJacobians = true), BA.cpp:2051-2093 — quad lane 0
-    const float new_idepth = (float)(drescale * idepth);
     double ret_d = 0.0;
     int ns_cnt = -1, flip = 0;
     if (live && j == 0) {
@@ -308,27 +331,13 @@ __global__ __launch_bounds__(256, 3) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     }
     flip = rs4_quad_bcast_i<0>(flip);
 
-    // ---- geometric Jacobians, BA.cpp:120-188: every lane evaluates two entries of each group (k = j and k = j + 4), same
-    //      expression shapes as k_ba_linearize; a residual that is not IN stages zeros (the matrix-core loop below is branch-free)
+    // ---- staging of the geometric Jacobians (evaluated above, under the texel round trip) and of the sums; a residual that is not IN
+    //      stages zeros (the matrix-core loop below is branch-free)
     float* const stg = reinterpret_cast<float*>(&s_shd[wv][0]);
     float* S = &stg[g * RS_SSTRIDE];
     {
         // Every lane issues the SAME stores with per-lane addresses (a lane with nothing to contribute to a group writes a spare slot,
         // 42..44): a lane-divergent `if` around an LDS access costs a branch each.
-        const float u = (float)px, v = (float)py;            // BA.cpp:121-122: un-normalised x,y, literal
-        const float fxf = (float)A.fx, fyf = (float)A.fy;
-        const double rfx = rs4_rcp_refined((double)fxf), rfy = rs4_rcp_refined((double)fyf);      // wave-uniform
-        // Jpdxi[0][k], Jpdxi[1][k], k = j (0..3) and k = j + 4 (4, 5 for j < 2)          (fp32, BA.cpp:133-147)
-        const float xa0 = rs4_sel4(j, new_idepth * fxf, 0.f, -new_idepth * u * fxf, -u * v * fxf);
-        const float xa1 = rs4_sel4(j, 0.f, new_idepth * fyf, -new_idepth * v * fyf, -(1 + v * v) * fyf);
-        const float xb0 = rs4_sel4(j, (1 + u * u) * fxf, -v * fxf, 0.f, 0.f);
-        const float xb1 = rs4_sel4(j, u * v * fyf, u * fyf, 0.f, 0.f);
-        // Jpdc[0][j], Jpdc[1][j]                                                         (:150-176)
-        const float c0 = rs4_jpdc<true>(j, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
-        const float c1 = rs4_jpdc<false>(j + 4, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
-        // Jpdd[j], j < 2                                                                 (:178-182)
-        const bool odd = j & 1;
-        const double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
         const bool lo2 = j < 2;
         S[j] = flip ? xa0 : 0.f; S[6 + j] = flip ? xa1 : 0.f;
         S[lo2 ? 4 + j : 42] = flip ? xb0 : 0.f; S[lo2 ? 10 + j : 43] = flip ? xb1 : 0.f;
@@ -416,7 +425,13 @@ __global__ __launch_bounds__(256, 3) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
 
 int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
     const int blocks = cml_div_up(c->n_tiles, 4);
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_ba_lin_rs4<true>, blocks, 256, 0, A, X);
-    else CML_LAUNCH_EV(c, k_ba_lin_rs4<false>, blocks, 256, 0, A, X);
+    const bool small = blocks <= 512;                      // at most two workgroups per CU: 196 VGPRs still leave two waves per SIMD
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) {
+        if (small) CML_LAUNCH_EV(c, (k_ba_lin_rs4<true, 1>), blocks, 256, 0, A, X);
+        else CML_LAUNCH_EV(c, (k_ba_lin_rs4<true, 3>), blocks, 256, 0, A, X);
+    } else {
+        if (small) CML_LAUNCH_EV(c, (k_ba_lin_rs4<false, 1>), blocks, 256, 0, A, X);
+        else CML_LAUNCH_EV(c, (k_ba_lin_rs4<false, 3>), blocks, 256, 0, A, X);
+    }
     return CMLHIP_OK;
 }
