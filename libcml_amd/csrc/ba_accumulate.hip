@@ -883,7 +883,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
             double2 v[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) v[u] = src[min(base + u * SOLVE_THREADS + tid, nd2 - 1)];
-            if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(A, 54); }
+            // (no "loads landed" stamp here: behind an asm with a memory clobber the compiler keeps v[] in a scratch frame — 16 scratch
+            //  round trips per thread on this path, and a kernel with a scratch frame pays for it at every dispatch, small windows too)
 #pragma unroll
             for (int u = 0; u < 16; u++) if (base + u * SOLVE_THREADS + tid < nd2) dst2[base + u * SOLVE_THREADS + tid] = v[u];
         }
