@@ -190,6 +190,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
         S[RS_S_COL + 8] = wgtA.x; S[RS_S_COL + 9] = wgtA.y; S[RS_S_COL + 10] = wgtA.z; S[RS_S_COL + 11] = wgtA.w;
         S[RS_S_COL + 12] = wgtB.x; S[RS_S_COL + 13] = wgtB.y; S[RS_S_COL + 14] = wgtB.z; S[RS_S_COL + 15] = wgtB.w;
     }
+    // the lane's matrix-core operand offsets (c_rs_mfma_*): requested HERE with the inputs — left to the compiler the two table loads
+    // sink to the matrix-core loop at the end of the kernel, an exposed memory round trip
+    unsigned mf_off = c_rs_mfma_off[ln];
+    int mf_a = c_rs_mfma_a[ln];
     const double idepth = rs_at(X.r_idepth, r4 * 2u);                   // == pt_idepth[r_point[r]] (cml_launch_linearize_rs refreshes the copies when needed)
     const bool live = valid && !lin_;
     const int st = live ? st_ : CMLHIP_RES_OOB;
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
     // ---- projection of the 8 pattern pixels, BA.cpp:193-212; the centre (BA.cpp:102-131) is pattern pixel 4, offset (0,0): the very
     //      same expressions on the very same operands
     const double tid0 = t0_ * idepth, tid1 = t1_ * idepth, tid2 = t2_ * idepth;
+    asm volatile("" : "+v"(mf_off), "+v"(mf_a));            // (pins the table loads to the input round trip)
 #ifdef CML_RS_STAMPS
     { double dep = tid0 + cxd + (double)st; asm volatile("" : "+v"(dep)); RS_STAMP(1); }        // every input of the lane has arrived
 #endif
@@ -442,35 +447,33 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
         S[30] = B00; S[31] = B01; S[32] = B01; S[33] = B11;
         S[34] = (float)JIr0; S[35] = (float)JIr1; S[36] = (float)Jabr0; S[37] = (float)Jabr1;
         S[38] = rr;
-    } else {
-        // a residual that is not IN (or a lane beyond the tile) stages zeros
-#pragma unroll
-        for (int i = 0; i < 20; i++) S[i] = 0.f;
-#pragma unroll
-        for (int i = 22; i < 39; i++) S[i] = 0.f;
-    }
+    }                                                        // (rows of residuals that are not IN are never read: the loop below walks the IN mask)
     if (ln < RS_SSTRIDE) s_stg[RS_TILE * RS_SSTRIDE + ln] = 0.f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the workgroup is ONE wave and a wave's LDS operations execute in order:
     __builtin_amdgcn_wave_barrier();                        // only the compiler has to be kept from moving the reads up
 
     // ---- the wave's contribution to the 13x13 block of its pair: one v_mfma_f32_16x16x4_f32 per residual (see acc_pair_block)
     {
-        const unsigned off = c_rs_mfma_off[ln];
-        const int oa = c_rs_mfma_a[ln], o1 = off & 255, o2 = (off >> 8) & 255, o3 = (off >> 16) & 255, o4 = off >> 24;
+        const int oa = mf_a, o1 = mf_off & 255, o2 = (mf_off >> 8) & 255, o3 = (mf_off >> 16) & 255, o4 = mf_off >> 24;
         float4_ acc = {0.f, 0.f, 0.f, 0.f};
         // only the residuals that are IN contribute (every product of a staged-zero row is +0, and acc + 0 == acc): the loop walks the
-        // set bits of the wave's IN mask in ascending order, eight rows per trip, padded with the row of zeros
+        // set bits of the wave's IN mask in ascending order, eight rows per trip, padded with the row of zeros.  All forty operand reads
+        // of a trip are issued before the first product (the scheduling barrier keeps them together: one LDS latency per trip, not
+        // one per row).
         unsigned long long inm = __ballot(flip != 0);
         while (inm) {
+            float av[8], b1[8], b2[8], b3[8], b4[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int li = inm ? __builtin_ctzll(inm) : RS_TILE;
                 inm &= inm - 1;
                 const float* SL = s_stg + li * RS_SSTRIDE;
-                const float av = SL[oa];
-                const float bv = SL[o3] * SL[o1] + SL[o4] * SL[o2];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                av[u] = SL[oa]; b1[u] = SL[o1]; b2[u] = SL[o2]; b3[u] = SL[o3]; b4[u] = SL[o4];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b3[u] * b1[u] + b4[u] * b2[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (!(Y.dbg_flags & 2)) reinterpret_cast<float4*>(Y.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }

@@ -136,10 +136,15 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     const double cxd = (double)X.r_px[r], cyd = (double)X.r_py[r];
     const float2 col2 = reinterpret_cast<const float2*>(X.r_colors)[4 * (size_t)r + j];     // colours / weights of pattern pixels 2j, 2j+1
     const float2 wgt2 = reinterpret_cast<const float2*>(X.r_weights)[4 * (size_t)r + j];
+    // the lane's matrix-core operand offsets (c_rs4_mfma_*): requested HERE with the inputs — left to the compiler the two table loads
+    // sink to the matrix-core loop at the end of the kernel, an exposed memory round trip
+    unsigned mf_off = c_rs4_mfma_off[ln];
+    int mf_a = c_rs4_mfma_a[ln];
     const double idepth = X.r_idepth[r];                   // == pt_idepth[r_point[r]] (the launcher refreshes the copies when needed)
     const bool live = valid && !lin_;
     const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
+    asm volatile("" : "+v"(mf_off), "+v"(mf_a));            // (pins the table loads to the input round trip)
 
     // ---- the lane's two pattern pixels, BA.cpp:193-212 (star8 offsets + 2 packed by nibble, types.h:1381-1393)
     double qx[2], qy[2], ppx[2], ppy[2], ppz[2], kx[2], ky[2], rz[2];
@@ -382,16 +387,22 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
 
     // ---- the wave's contribution to the 13x13 block of its pair: one v_mfma_f32_16x16x4_f32 per residual (see acc_pair_block)
     {
-        const unsigned off = c_rs4_mfma_off[ln];
-        const int oa = c_rs4_mfma_a[ln], o1 = off & 255, o2 = (off >> 8) & 255, o3 = (off >> 16) & 255, o4 = off >> 24;
+        const int oa = mf_a, o1 = mf_off & 255, o2 = (mf_off >> 8) & 255, o3 = (mf_off >> 16) & 255, o4 = mf_off >> 24;
         float4_ acc = {0.f, 0.f, 0.f, 0.f};
         const float* SW = stg;
-#pragma unroll 4
-        for (int li = 0; li < RS_RES; li++) {
-            const float* SL = SW + li * RS_SSTRIDE;
-            const float av = SL[oa];
-            const float bv = SL[o3] * SL[o1] + SL[o4] * SL[o2];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        // eight residuals per trip: all forty operand reads are issued before the first product (one LDS latency per trip, not one per row)
+#pragma unroll
+        for (int l0 = 0; l0 < RS_RES; l0 += 8) {
+            float av[8], b1[8], b2[8], b3[8], b4[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float* SL = SW + (l0 + u) * RS_SSTRIDE;
+                av[u] = SL[oa]; b1[u] = SL[o1]; b2[u] = SL[o2]; b3[u] = SL[o3]; b4[u] = SL[o4];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b3[u] * b1[u] + b4[u] * b2[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // a residual slot beyond the tile's count (or not IN) staged zeros: the ones slot then multiplies zero fields only
         if (!(X.dbg_flags & 2)) reinterpret_cast<float4*>(X.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
