@@ -300,6 +300,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
 #endif
     // what the classification needs of the previous state: requested here, behind the texels, so that the round trip runs under the pixel loop
     const float pre_energy = rs_at(A.r_energy, r4);
+    const float pre_new_energy = rs_at(A.r_new_energy, r4); // (read here: behind the stores of the classification it would wait for every one of them)
     const int pre_new_state = rs_at(A.r_new_state, r4), pre_ppos = rs_at(A.point_pos, r4);
     const unsigned char pre_sel = rs_at(A.r_sel, r1);
 
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
             if (ns_final == CMLHIP_RES_IN) { rs_at(B.r_good, r1) = 1; flip = 1; code = 2 * r + pre_sel; }
             else rs_at(B.r_good, r1) = 0;
             rs_at(B.r_state, r4) = ns_final;
-            rs_at(B.r_energy, r4) = wrote_e ? ret : rs_at(B.r_new_energy, r4);      // state_energy = state_NewEnergy
+            rs_at(B.r_energy, r4) = wrote_e ? ret : pre_new_energy;      // state_energy = state_NewEnergy
             rs_at(B.point_code, (unsigned)pre_ppos * 4u) = code;                          // read by the point rows of k_ba_acc and by k_ba_backsub
         }
     }

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     const int r = first + (valid ? g : 0);
     const int lin_ = A.r_lin[r], st_ = A.r_state[r];
     const float pre_energy = A.r_energy[r];
+    const float pre_new_energy = A.r_new_energy[r];        // (read with the inputs: behind the stores of the classification it would wait for every one of them)
     const int pre_new_state = A.r_new_state[r], pre_ppos = A.point_pos[r];
     const unsigned char pre_sel = A.r_sel[r];
     const double cxd = (double)X.r_px[r], cyd = (double)X.r_py[r];
@@ -145,6 +146,14 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
     asm volatile("" : "+v"(mf_off), "+v"(mf_a));            // (pins the table loads to the input round trip)
+#ifdef CML_RS_STAMPS                                       // development build (CML_HIPCC_EXTRA=-DCML_RS_STAMPS): per-tile phase stamps, tools/probe_rs_tiles.py
+    long long* const ts = (A.dbg && ti < CML_DEBUG_RS_TILES) ? A.dbg + CMLHIP_DEBUG_SLOTS + 8 * (size_t)ti : nullptr;
+#define RS4_STAMP(i) do { if (ts && ln == 0) ts[i] = wall_clock64(); } while (0)
+    if (ts && ln == 0) { ts[0] = wall_clock64(); ts[7] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); }
+    { double dep = idepth + cxd + (double)st + (double)col2.x + (double)wgt2.x; asm volatile("" : "+v"(dep)); RS4_STAMP(1); }
+#else
+#define RS4_STAMP(i) do { } while (0)
+#endif
 
     // ---- the lane's two pattern pixels, BA.cpp:193-212 (star8 offsets + 2 packed by nibble, types.h:1381-1393)
     double qx[2], qy[2], ppx[2], ppy[2], ppz[2], kx[2], ky[2], rz[2];
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     //      depend on the projection only, and at small windows a wave is alone on its SIMD, so whatever runs under the texel round
     //      trip is free (the values wait in eight registers for the staging below).  Every lane evaluates two entries of each group
     //      (k = j and k = j + 4), same expression shapes as k_ba_linearize.
+    RS4_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
     const float new_idepth = (float)(drescale * idepth);
     const float u = (float)px, v = (float)py;            // BA.cpp:121-122: un-normalised x,y, literal
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     const bool odd = j & 1;
     const double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
     __builtin_amdgcn_sched_barrier(0);
+    RS4_STAMP(3);
     float I[2], gx[2], gy[2];
     bool finite[2];
 #pragma unroll
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
         sumB += D[4 * 9 + jj] * D[by * 9 + jj];
         sumC += F[cp * 8 + jj] * F[cq * 8 + jj] * F[cr * 8 + jj] * F[cs * 8 + jj];
     }
+    RS4_STAMP(4);
     const float E = rs4_quad_bcast_f<0>(sumA2);                // quad lane 0: the energy; lane 1: wJI2_sum
     const float wJI2 = rs4_quad_bcast_f<1>(sumA2);
 
@@ -330,11 +342,12 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
             if (ns_final == CMLHIP_RES_IN) { A.r_good[r] = 1; flip = 1; code = 2 * r + pre_sel; }
             else A.r_good[r] = 0;
             A.r_state[r] = ns_final;
-            A.r_energy[r] = wrote_e ? ret : A.r_new_energy[r];      // state_energy = state_NewEnergy
+            A.r_energy[r] = wrote_e ? ret : pre_new_energy;      // state_energy = state_NewEnergy
             A.point_code[pre_ppos] = code;                          // read by the point rows of k_ba_acc and by k_ba_backsub
         }
     }
     flip = rs4_quad_bcast_i<0>(flip);
+    RS4_STAMP(5);
 
     // ---- staging of the geometric Jacobians (evaluated above, under the texel round trip) and of the sums; a residual that is not IN
     //      stages zeros (the matrix-core loop below is branch-free)
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
         if (!(X.dbg_flags & 2)) reinterpret_cast<float4*>(X.part)[(size_t)ti * 64 + ln] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 
+    RS4_STAMP(6);
     // ---- per-tile partials {energy, n_in, n_oob, n_outlier} (BA.cpp:1565): fixed butterfly order over the 16 residuals
     if (A.lin_partial) {
         double e = ret_d;                                            // non-zero in quad lane 0 only

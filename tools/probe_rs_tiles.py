@@ -32,10 +32,12 @@ print("end:   min %.2f med %.2f p90 %.2f max %.2f us" % (e.min(), np.median(e), 
 d = e - b
 print("wave duration: min %.2f med %.2f p90 %.2f max %.2f us" % (d.min(), np.median(d), np.percentile(d, 90), d.max()))
 names = ["pair record -> inputs arrived", "projection (+ texel loads issued)", "geometry -> staged", "pixel loop (texel wait + sums)", "classification + state stores", "reduced record + matrix-core tile + partials"]
+if cfg != "E":      # small windows: k_ba_lin_rs4 (stamp 6 is taken before the partials)
+    names = ["pair record -> inputs arrived", "projection, texel loads issued", "geometry (under the texel round trip)", "texel wait, photometric terms, exchange, pattern sums", "classification + state stores", "staging, JpJdF, matrix-core tile"]
 key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
 slot = key * 4 + simd
 u, cnt = np.unique(slot, return_counts=True)
-for n in (2, 3):
+for n in (1, 2, 3):
     sel = np.isin(slot, u[cnt == n])
     if not sel.any(): continue
     print("SIMDs with %d waves (%d SIMDs): wave duration med %.2f us, last end med %.2f us; phases (median us):" % (n, (cnt == n).sum(), np.median(d[sel]), np.median([e[slot == s_].max() for s_ in u[cnt == n]])))
