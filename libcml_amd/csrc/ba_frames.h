@@ -28,32 +28,44 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
     if (tid < N) {
         cmlhip_ba_frame_state& S = F.fs[tid];
         double step[8], st[8];
+        // Everything the step reads is fetched first, in ONE round trip: written field by field against the record in memory, every
+        // load waits behind the store before it (same type, possibly aliased — the compiler must keep the order): eight dependent
+        // round trips on the one workgroup the whole launch waits for.
+        double s_old[8], s_zero[8], p_zero[8], evq[4], evt[3];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s_old[k] = S.state[k]; s_zero[k] = S.state_zero[k]; p_zero[k] = S.prior_zero[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) evq[k] = S.eval_q[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) evt[k] = S.eval_t[k];
+        const bool fix_pose = S.fix_pose != 0;
+        const double ab_exposure = S.ab_exposure;
         bool fin = true;
 #pragma unroll
         for (int k = 0; k < 8; k++) { step[k] = -x[4 + 8 * tid + k]; fin = fin && isfinite(step[k]); }     // BA.cpp:1433-1441
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (!fin) step[k] = 0.0;                                   // setStep, DSOFrame.h:205-214
-            if (S.fix_pose && k < 6) step[k] = 0.0;                    // BA.cpp:957-960
+            if (fix_pose && k < 6) step[k] = 0.0;                      // BA.cpp:957-960
             s_step[tid][k] = step[k];
-            st[k] = S.state[k] + step[k];                              // state_backup == state: every step is accepted here
-            S.state[k] = st[k];
-            s_delta[tid][k] = st[k] - S.state_zero[k];
-            F.dprior[8 * tid + k] = st[k] - S.prior_zero[k];
+            st[k] = s_old[k] + step[k];                                // state_backup == state: every step is accepted here
+            s_delta[tid][k] = st[k] - s_zero[k];
         }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { S.state[k] = st[k]; F.dprior[8 * tid + k] = st[k] - p_zero[k]; }
         const double ss[6] = {F.sc[0] * st[0], F.sc[0] * st[1], F.sc[0] * st[2], F.sc[1] * st[3], F.sc[1] * st[4], F.sc[1] * st[5]};
         SE3 ev;
 #pragma unroll
-        for (int k = 0; k < 4; k++) ev.q[k] = S.eval_q[k];
+        for (int k = 0; k < 4; k++) ev.q[k] = evq[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) ev.t[k] = S.eval_t[k];
+        for (int k = 0; k < 3; k++) ev.t[k] = evt[k];
         const SE3 W = SE3::exp(ss) * ev;                               // PRE_worldToCam, DSOFrame.h:119
         const SE3 Ci = W.inverse();
 #pragma unroll
         for (int k = 0; k < 4; k++) { s_w2c[tid][k] = W.q[k]; s_c2w[tid][k] = Ci.q[k]; F.pre_w2c[7 * tid + k] = W.q[k]; }
 #pragma unroll
         for (int k = 0; k < 3; k++) { s_w2c[tid][4 + k] = W.t[k]; s_c2w[tid][4 + k] = Ci.t[k]; F.pre_w2c[7 * tid + 4 + k] = W.t[k]; }
-        s_aff[tid][0] = S.ab_exposure; s_aff[tid][1] = F.sc[2] * st[6]; s_aff[tid][2] = F.sc[3] * st[7];    // aff_g2l
+        s_aff[tid][0] = ab_exposure; s_aff[tid][1] = F.sc[2] * st[6]; s_aff[tid][2] = F.sc[3] * st[7];    // aff_g2l
     }
     __syncthreads();
     if (F.frame_sums && tid == 0) {                                    // fp32 sums in frame order, as the host loop forms them
