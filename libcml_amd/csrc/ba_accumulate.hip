@@ -89,6 +89,7 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63;
     const int beg = A.by_pair_off[q], end = A.by_pair_off[q + 1];
     const double ahv = X.adH[64 * (size_t)q + ln], atv = X.adT[64 * (size_t)q + ln];      // adjoints for the stitch: in flight under the loop
+    const int tb = TILES ? X.tile_off[q] : 0, te = TILES ? X.tile_off[q + 1] : 0;           // (requested here: behind the barrier it is a round trip of its own)
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (A.dbg && tid == 0 && q == 1) A.dbg[16] = wall_clock64();
@@ -106,7 +107,6 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
         // the residual kernel of the resident loop already reduced its residuals on the matrix cores: add the pair's wave tiles
         // (same D layout, lane for lane); wave w < 256 / tile takes tiles w, w + 256 / tile, ... (the assignment of the record path below) and the wave sums are added in wave order below
         const float4* P4 = reinterpret_cast<const float4*>(X.part);
-        const int tb = X.tile_off[q], te = X.tile_off[q + 1];
         const int tpt = PAIR_TRIP / X.tile;                  // tiles per trip = waves that own a tile
         for (int t = tb + wave; wave < tpt && t < te; t += tpt) {
             const float4 v = P4[(size_t)t * 64 + ln];
@@ -294,6 +294,12 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
     double* srow = s_row[wv];
     for (int c = l; c < X.ldg; c += 64) srow[c] = 0.0;
     const int host = A.pt_host[p];
+    // (requested with the first round trip: read where they are used — behind the shuffles, inside `if (ngood > 0)` — they are a third one)
+    float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
+    const float bdLv = pa[7];                              // written by the LINEARIZED pre-pass (0 when none)
+    const float prior_p = A.pt_prior[p];
+    const double idepth_p = A.pt_idepth[p];
+    const float idepth_zero_p = A.pt_idepth_zero[p];
     // component a of a slot computes one of the per-residual scalars: a<4 Hcd[a], a=4 Hdd, a=5 bd, a=6 good count
     float accA = 0.f, accL = 0.f;
     double hostacc = 0.0;
@@ -344,16 +350,14 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
     const float HcdA_a = __shfl(accA, a & 3), HcdL_a = __shfl(accL, a & 3);
     const float HddA = __shfl(accA, 4), HddL = __shfl(accL, 4), bdA = __shfl(accA, 5);
     const int ngood = (int)(__shfl(accA, 6) + __shfl(accL, 6));
-    float* pa = A.pt_acc + (size_t)p * PT_ACC_STRIDE;
     float HdiF = 0.f, bdSum = 0.f;
     if (ngood > 0) {
-        const float bdLv = pa[7];                          // written by the LINEARIZED pre-pass (0 when none)
-        float H = HddA + HddL + A.pt_prior[p];
+        float H = HddA + HddL + prior_p;
         if (H < 1e-10) H = 1e-10;
         HdiF = (float)(1.0 / H);
         bdSum = bdA + bdLv;
-        const float deltaF = (float)(A.pt_idepth[p] - (double)A.pt_idepth_zero[p]);
-        bdSum += A.pt_prior[p] * deltaF;                   // shiftPriorToZero, :1904
+        const float deltaF = (float)(idepth_p - (double)idepth_zero_p);
+        bdSum += prior_p * deltaF;                         // shiftPriorToZero, :1904
         if (s == 0) {
             srow[4 + 8 * host + a] = hostacc;
             if (a < 4) srow[a] = (double)(HcdA_a + HcdL_a);
@@ -366,7 +370,7 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
         else if (a == 4) { pa[0] = HddA; pa[6] = HddL; }
         else if (a == 5) { pa[1] = bdA; pa[12] = HdiF; }
         else if (a == 6) { pa[13] = bdSum; X.Wt[p] = (double)HdiF; }
-        else if (X.do_backup) A.pt_backup[p] = (float)A.pt_idepth[p];          // backupState, BA.cpp:919-922
+        else if (X.do_backup) A.pt_backup[p] = (float)idepth_p;                // backupState, BA.cpp:919-922
     }
     double* row = X.G + (size_t)p * X.ldg;                 // LDS accesses of one wave are ordered: no barrier needed
     for (int c = l; c < X.ldg; c += 64) row[c] = srow[c];
@@ -1151,6 +1155,22 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
         DBG_BLK_END(A.dbg, 4);
         return;
     }
+    // 8 lanes per point, one residual per lane per pass (a point has at most N-1 residuals): the chain by_point -> r ->
+    // {good, target, JpJdF} is walked once per point, every load unconditional (clamped), masks multiplied in.
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = gid >> 3, i = gid & 7;
+    const bool pv = p < A.P;
+    const int pp = pv ? p : 0;
+    // Everything that does not depend on the x.adjoint table is requested BEFORE the table is built (the barrier below would pin these
+    // loads behind it: one more dependent round trip on a launch that is nothing but round trips): the point's sums, its host, the
+    // calibration step, the first pass's codes / targets / residual slots and the backed-up inverse depth.
+    const float* pa = A.pt_acc + (size_t)pp * PT_ACC_STRIDE;
+    const int host = A.pt_host[pp];
+    const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
+    const double xc = x[i & 3];
+    const int code0 = A.point_code[pp * A.pt_stride + i], tgl0 = A.point_tgt[pp * A.pt_stride + i];
+    const int res0 = A.point_res[pp * A.pt_stride + i];
+    const float backup_p = A.pt_backup[pp];
     if (xad) {                                               // wide windows: the table was built once by k_ba_xad
         for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) s_xAd[e] = xad[e];
     } else {
@@ -1158,18 +1178,8 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) sum->nonfinite = 0;
     __syncthreads();
-    // 8 lanes per point, one residual per lane per pass (a point has at most N-1 residuals): the chain by_point -> r ->
-    // {good, target, JpJdF} is walked once per point, every load unconditional (clamped), masks multiplied in.
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int p = gid >> 3, i = gid & 7;
-    const bool pv = p < A.P;
-    const int pp = pv ? p : 0;
     float sumID = 0, sumNID = 0, numID = 0;
     {
-        const float* pa = A.pt_acc + (size_t)pp * PT_ACC_STRIDE;
-        const int host = A.pt_host[pp];
-        const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
-        const double xc = x[i & 3];
         int ngood = 0;
         // scalar_t b = bdSumF; b -= mCalibStep.dot(Hcd_A + Hcd_L); then b -= xAd * JpJdF for every good residual IN LIST ORDER
         // (BA.cpp:1469-1479).  Both dots reduce by halves in Eigen (pinned on the reference's vendored Eigen, tests/golden) — the
@@ -1178,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
         double bb = (double)pa13 - sum8d(i < 4 ? (-xc) * ((double)hcd + (double)hcl) : 0.0);
         for (int base = 0; base < A.pt_stride; base += 8) {
             const int slot = pp * A.pt_stride + base + i;
-            const int code = A.point_code[slot], tgl = A.point_tgt[slot];         // efsJ code kept by applyRes, static target
+            const int code = base == 0 ? code0 : A.point_code[slot], tgl = base == 0 ? tgl0 : A.point_tgt[slot];         // efsJ code kept by applyRes, static target
             const bool good = pv && code >= 0;
             const int r = max(code, 0) >> 1;
             const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r + 4);
@@ -1200,10 +1210,10 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
         if (pv && i == 0) {
             A.pt_step[p] = st;
             if (do_step) {
-                const double nid = (double)A.pt_backup[p] + st;
+                const double nid = (double)backup_p + st;
                 if (isfinite(nid) && nid > 0) {
                     A.pt_idepth[p] = nid;
-                    sumID = (float)(st * st); sumNID = (float)fabs((double)A.pt_backup[p]); numID = 1.f;
+                    sumID = (float)(st * st); sumNID = (float)fabs((double)backup_p); numID = 1.f;
                     A.pt_idepth_zero[p] = (float)nid;
                     nid_w = nid; nid_ok = 1;
                 }
@@ -1215,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
             const int src = threadIdx.x & 56;                 // (blockDim = 256: the 8-lane group never straddles a wave)
             nid_w = __shfl(nid_w, src); nid_ok = __shfl(nid_ok, src);
             for (int base = 0; base < A.pt_stride; base += 8) {
-                const int res = A.point_res[pp * A.pt_stride + base + i];
+                const int res = base == 0 ? res0 : A.point_res[pp * A.pt_stride + base + i];
                 if (pv && nid_ok && res >= 0) A.r_idepth[res] = nid_w;
             }
         }

@@ -86,26 +86,34 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
         for (int k = 0; k < 4; k++) { Wt.q[k] = s_w2c[t][k]; Ch.q[k] = s_c2w[h][k]; }
 #pragma unroll
         for (int k = 0; k < 3; k++) { Wt.t[k] = s_w2c[t][4 + k]; Ch.t[k] = s_c2w[h][4 + k]; }
+        // computeDelta, BA.cpp:1120-1135 — FIRST, with all 128 adjoint entries of the pair requested together and the eight results held
+        // back: written per column between the stores of the pair record, every column's loads waited behind the stores before them
+        // (a chain of eight round trips on the one workgroup the launch waits for).  Same sums in the same order.
+        const int idx = h + t * N;
+        double sH[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sT[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!F.adhtd_done) {
+            const double* AH = F.adH + 64 * (size_t)idx; const double* AT = F.adT + 64 * (size_t)idx;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double dh = s_delta[h][i], dt = s_delta[t][i];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { sH[j] += dh * AH[i * 8 + j]; sT[j] += dt * AT[i * 8 + j]; }
+            }
+        }
         const SE3 ll = Wt * Ch;                                        // DSOFrame.h:259-273
         cmlhip_ba_pair& P = F.pairs[q];
         double R[9];
         ll.matrix(R);
+        double a, b;
+        Exposure(s_aff[h][0], s_aff[h][1], s_aff[h][2]).to(Exposure(s_aff[t][0], s_aff[t][1], s_aff[t][2]), a, b);
 #pragma unroll
         for (int k = 0; k < 9; k++) P.R[k] = R[k];
 #pragma unroll
         for (int k = 0; k < 3; k++) P.t[k] = ll.t[k];
-        double a, b;
-        Exposure(s_aff[h][0], s_aff[h][1], s_aff[h][2]).to(Exposure(s_aff[t][0], s_aff[t][1], s_aff[t][2]), a, b);
         P.aff_a = a; P.aff_b = b;
         if (F.adhtd_done) continue;
-        const int idx = h + t * N;                                     // computeDelta, BA.cpp:1120-1135
-        const double* AH = F.adH + 64 * (size_t)idx; const double* AT = F.adT + 64 * (size_t)idx;
-        for (int j = 0; j < 8; j++) {
-            double s = 0, s2 = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) { s += s_delta[h][i] * AH[i * 8 + j]; s2 += s_delta[t][i] * AT[i * 8 + j]; }
-            F.adHTd[8 * (size_t)idx + j] = (float)(s + s2);
-        }
+        for (int j = 0; j < 8; j++) F.adHTd[8 * (size_t)idx + j] = (float)(sH[j] + sT[j]);
     }
 }
 

@@ -72,7 +72,9 @@ def test_hybrid_term_mixed_into_the_pose_solution(config):
     assert np.isfinite(mixed.energies()).all()
     # device-resident mixing == the host-side procedure
     x6h, unch, xh = mixed_h.indirect()
-    assert np.abs(x6 - x6h).max() <= 1e-12 * np.abs(x6h).max() and np.abs(x - xh).max() <= 1e-12 * np.abs(xh).max()
+    # (1e-10: the per-frame sums of the reprojection term are added with fp64 atomics — the order of the additions, and with it the
+    #  last bits, differ from launch to launch; observed up to 1.5e-12 of the largest entry)
+    assert np.abs(x6 - x6h).max() <= 1e-10 * np.abs(x6h).max() and np.abs(x - xh).max() <= 1e-10 * np.abs(xh).max()
     assert len(unc) == len(unch)                      # (the values are the cofactor 'inverse' of a rank-one matrix, :2690-2692: 0/0-like, last-bit
                                                       #  differences of the per-point Jacobian sums change them arbitrarily — nothing to compare)
     for i in range(N):
