@@ -72,7 +72,10 @@ typedef struct {
     int max_residuals;   /* R  */
     int max_tracker_points; /* per level, upper bound of DSOTrackerPrivateLevel::n() (TR.h:62) */
     int max_reproj_obs;  /* ORB observations (BA.cpp:2607-2659) */
-    int texel_format;    /* CMLHIP_TEXEL_F32 | CMLHIP_TEXEL_F16 (config E: fp16 taps, fp32 accumulate) */
+    int texel_format;    /* CMLHIP_TEXEL_F32 | CMLHIP_TEXEL_F16 (config E: fp16 taps, fp32 accumulate).  With fp16 texels a frame that a
+                          * BA window names keeps a second, tiled copy of its level 0 (8 more bytes per pixel) for the resident loop's
+                          * residual kernel; it is built on the device at the first cmlhip_ba_upload_window that names the image and
+                          * follows cmlhip_pyramid_put / _build / _drop of that image. */
 } cmlhip_limits;
 
 /* ---------------------------------------------------------------- context */

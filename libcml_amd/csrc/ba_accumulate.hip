@@ -1163,14 +1163,28 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
     const int pp = pv ? p : 0;
     // Everything that does not depend on the x.adjoint table is requested BEFORE the table is built (the barrier below would pin these
     // loads behind it: one more dependent round trip on a launch that is nothing but round trips): the point's sums, its host, the
-    // calibration step, the first pass's codes / targets / residual slots and the backed-up inverse depth.
+    // calibration step, every pass's codes / targets / residual slots, the backed-up inverse depth, and — behind the codes — the JpJdF.
     const float* pa = A.pt_acc + (size_t)pp * PT_ACC_STRIDE;
     const int host = A.pt_host[pp];
     const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
     const double xc = x[i & 3];
-    const int code0 = A.point_code[pp * A.pt_stride + i], tgl0 = A.point_tgt[pp * A.pt_stride + i];
-    const int res0 = A.point_res[pp * A.pt_stride + i];
+    // (all passes' codes / targets / residual slots: up to 4 passes of 8 slots, CMLHIP_MAX_FRAMES = 32; clamped slots are masked)
+    int codes[4], tgls[4], ress[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+        const bool lv = 8 * ps + i < A.pt_stride;
+        const int slot = pp * A.pt_stride + min(8 * ps + i, A.pt_stride - 1);
+        const int cd = A.point_code[slot], tg = A.point_tgt[slot], rs = A.point_res[slot];
+        codes[ps] = lv ? cd : -1; tgls[ps] = lv ? tg : 0; ress[ps] = lv ? rs : -1;
+    }
     const float backup_p = A.pt_backup[pp];
+    // second round trip: the JpJdF of every pass, requested together (unconditional, clamped) — also ahead of the table's barrier
+    float4 v0s[4], v1s[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+        const int r = max(codes[ps], 0) >> 1;
+        v0s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r); v1s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r + 4);
+    }
     if (xad) {                                               // wide windows: the table was built once by k_ba_xad
         for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) s_xAd[e] = xad[e];
     } else {
@@ -1186,12 +1200,12 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
         // 8-lane butterfly below and the bracketing of `d` are exactly that order — and the subtractions are replayed one
         // residual at a time, so the point step is the reference's bit for bit.
         double bb = (double)pa13 - sum8d(i < 4 ? (-xc) * ((double)hcd + (double)hcl) : 0.0);
-        for (int base = 0; base < A.pt_stride; base += 8) {
-            const int slot = pp * A.pt_stride + base + i;
-            const int code = base == 0 ? code0 : A.point_code[slot], tgl = base == 0 ? tgl0 : A.point_tgt[slot];         // efsJ code kept by applyRes, static target
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            if (8 * ps >= A.pt_stride) break;                 // uniform
+            const int code = codes[ps], tgl = tgls[ps];       // efsJ code kept by applyRes, static target
             const bool good = pv && code >= 0;
-            const int r = max(code, 0) >> 1;
-            const float4 v0 = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r), v1 = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r + 4);
+            const float4 v0 = v0s[ps], v1 = v1s[ps];
             const double* xa = s_xAd + 8 * (host * N + (max(tgl, 0) & 255));
             double d = ((xa[0] * (double)v0.x + xa[1] * (double)v0.y) + (xa[2] * (double)v0.z + xa[3] * (double)v0.w))
                      + ((xa[4] * (double)v1.x + xa[5] * (double)v1.y) + (xa[6] * (double)v1.z + xa[7] * (double)v1.w));
@@ -1224,10 +1238,8 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
             // 8 lanes of the point refresh the copies of its residuals
             const int src = threadIdx.x & 56;                 // (blockDim = 256: the 8-lane group never straddles a wave)
             nid_w = __shfl(nid_w, src); nid_ok = __shfl(nid_ok, src);
-            for (int base = 0; base < A.pt_stride; base += 8) {
-                const int res = base == 0 ? res0 : A.point_res[pp * A.pt_stride + base + i];
-                if (pv && nid_ok && res >= 0) A.r_idepth[res] = nid_w;
-            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) if (pv && nid_ok && ress[ps] >= 0) A.r_idepth[ress[ps]] = nid_w;
         }
     }
     if (do_step) {                                           // fixed-order block partials; the host adds the few blocks

@@ -385,6 +385,10 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_expand_aos3<true><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
     else k_expand_aos3<false><<<blocks, 256, 0, c->stream>>>(tmp, L.grad, (int)n);
     CML_CHECK(c, hipGetLastError());
+    if (level == 0 && L.tiled) {                                        // a window may already hold the pointer of the tiled copy: keep it in step
+        const void* t_ = nullptr;
+        if (int rc_t = cml_tiled_level0(c, id, &t_)) return rc_t;
+    }
     return CMLHIP_OK;                                                   // (the staging buffer is reused in stream order)
 }
 
