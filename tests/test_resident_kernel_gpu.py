@@ -32,6 +32,7 @@ def _make(I, use_rs, texel_format, tile):
 
 
 ODD = (4, 300, 323, 241, 3, 260.0, 260.0, 161.0, 120.0)       # a window on images whose sides are not multiples of 4
+MID = (8, 5000, 640, 480, 3, 525.0, 525.0, 319.5, 239.5)      # R = 35 000: with 16-residual tiles more than two workgroups per CU, the register-bounded instantiation of k_ba_lin_rs4
 
 
 # tile 16 = k_ba_lin_rs4 (4 lanes per residual, small windows), tile 64 = k_ba_lin_rs (one lane per residual, large windows);
@@ -39,7 +40,7 @@ ODD = (4, 300, 323, 241, 3, 260.0, 260.0, 161.0, 120.0)       # a window on imag
 @pytest.mark.parametrize("tile", [16, 64])
 # (B with fp16 texels: 1241 is not a multiple of the 4-texel tile width of the tiled level 0 the lane-per-residual kernel gathers from)
 #  and an image whose width AND height are not multiples of the 4 x 4 tile: the clamped border tiles)
-@pytest.mark.parametrize("config,half", [("tiny", False), ("small", False), ("small", True), ("B", False), ("B", True), (ODD, True)])
+@pytest.mark.parametrize("config,half", [("tiny", False), ("small", False), ("small", True), ("B", False), ("B", True), (ODD, True), (MID, False)])
 def test_resident_kernel_matches_record_kernel(config, half, tile):
     I = S.make_inputs(config)
     if half:
