@@ -238,7 +238,7 @@ def main():
                                    "gradient images, %s texels / fp32 arithmetic; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (wcfg, N, P, R, W.w, W.h, "fp16" if half else "fp32"),
                        "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
             "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
-            "roofline": {"bound": "hbm", "kernel": ("k_ba_lin_rs (lane per residual, tiled fp16 level 0)" if R >= 64 * 1024 else "k_ba_lin_rs4 (4 lanes per residual)") + " = linearize + applyRes of the resident loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_ba_lin_rs (lane per residual, tiled fp16 level 0)" if R >= 36 * 1024 else "k_ba_lin_rs4 (4 lanes per residual)") + " = linearize + applyRes of the resident loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": R * bytes_per_residual, "bytes_per_residual": bytes_per_residual,
                          "launch_us": 1e3 * lin_ms.value, "launch_samples": n_samples,

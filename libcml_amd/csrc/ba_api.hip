@@ -166,7 +166,10 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     {
         const char* e = getenv("CMLHIP_RS_TILE");
         const int forced = e ? atoi(e) : 0;
-        c->rs_tile = (forced == 16 || forced == 64) ? forced : (R >= 64 * 1024 ? 64 : 16);
+        // (crossover measured with tools/probe_rs_regime.sh: R = 25 200: 11.2 (4 lanes) / 15.5 us (lane per residual); 35 000: 15.3 / 15.9; the
+        //  lane-per-residual kernel stays at 15-16 us up to one wave per SIMD = 65 000 residuals, the 4-lane kernel starts a second round of
+        //  waves at 2048 x 16 = 32 768)
+        c->rs_tile = (forced == 16 || forced == 64) ? forced : (R >= 36 * 1024 ? 64 : 16);
     }
     const int TS = c->rs_tile;
     std::vector<int> tiles, tile_off(N * N + 1, 0);

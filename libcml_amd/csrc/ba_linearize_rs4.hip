@@ -100,9 +100,8 @@ __device__ __forceinline__ float rs4_jpdc(const int k, const double E0, const do
     return (float)(((m * q) + add) * scl);
 }
 
-// MINB: workgroups per CU the register budget is sized for — 3 (168 VGPRs: the 13-18 registers beyond that spill to a scratch frame) for
-// the mid-size windows that fill the chip; 1 for the usual small window, which does not even put one wave on every SIMD: no register
-// bound, no scratch frame (a kernel with one pays for it at every dispatch)
+// MINB: workgroups per CU the register budget is sized for — 1: no register bound (196 VGPRs, two waves per SIMD), no scratch frame;
+// 3: 168 VGPRs, the 13-23 registers beyond that spill to a scratch frame — measured slower at every window size (see the launcher)
 template <bool HALF, int MINB>
 __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     __shared__ double s_shd[4][RS_RES * RS_DSTRIDE];                                   // [wave][residual * RS_DSTRIDE + quantity * 9 + pixel]
@@ -450,7 +449,11 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
 
 int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
     const int blocks = cml_div_up(c->n_tiles, 4);
-    const bool small = blocks <= 512;                      // at most two workgroups per CU: 196 VGPRs still leave two waves per SIMD
+    // Measured (tools/probe_rs_regime.sh, fp32 windows of 8 keyframes): the register-bounded instantiation loses at every size this
+    // kernel is used for (R = 25 200: 15.2 against 11.2 us; R = 35 000: 18.4 against 15.3 us, k_ba_lin_rs 15.9) — it stays for the
+    // development switch only.
+    static const char* e_minb = getenv("CMLHIP_RS4_MINB");   // development: 3 forces the 168-VGPR instantiation
+    const bool small = !(e_minb && atoi(e_minb) == 3);                      // at most two workgroups per CU: 196 VGPRs still leave two waves per SIMD
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) {
         if (small) CML_LAUNCH_EV(c, (k_ba_lin_rs4<true, 1>), blocks, 256, 0, A, X);
         else CML_LAUNCH_EV(c, (k_ba_lin_rs4<true, 3>), blocks, 256, 0, A, X);

@@ -18,6 +18,9 @@ CONFIGS = {
     "tiny": (3, 64, 160, 120, 2, 140.0, 140.0, 79.5, 59.5),
     "small": (4, 300, 320, 240, 3, 260.0, 260.0, 159.5, 119.5),
     "medium": (5, 600, 480, 360, 4, 390.0, 390.0, 239.5, 179.5),
+    "M2": (8, 2800, 640, 480, 3, 525.0, 525.0, 319.5, 239.5),
+    "M3": (8, 3600, 640, 480, 3, 525.0, 525.0, 319.5, 239.5),
+    "M": (8, 5000, 640, 480, 3, 525.0, 525.0, 319.5, 239.5),          # R = 35 000: between the small-window and the large-window regime of the residual kernel
 }
 
 
