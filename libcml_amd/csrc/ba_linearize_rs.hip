@@ -11,12 +11,17 @@
 //     unrolled loop, the 19 pattern sums are register accumulators updated in pattern order (the reference's order by
 //     construction), the geometric Jacobians are evaluated once, and there is no exchange, no ballot, no lane select at all;
 //   * every per-residual input is addressed directly by the residual index (static copies of the point's pixel, colours and
-//     weights are kept per residual, the copy of the inverse depth is refreshed by the point step of k_ba_backsub): after ONE round
-//     trip for the inputs the 32 texel loads of a lane are issued together, unconditional on clamped addresses;
+//     weights are kept per residual, the copy of the inverse depth is refreshed by the point step of k_ba_backsub);
+//   * the kernel's time at a 20-frame window follows the number of DISTINCT CACHE LINES it pulls from beyond the L2 (measured with the
+//     development switches of cml_launch_linearize_rs: DESIGN.md section 7), so fp16 texels are gathered from a TILED copy of the level 0
+//     (cml_tiled_level0: 4 x 4 texels + one overlap column per 128-byte line, 5.1 instead of 7.9 lines per residual), the two texels
+//     of a bilinear row as one 16-byte load, unconditional on clamped positions;
+//   * the pattern pixels run as a software pipeline (projection / loads / sums interleaved, three pixels in flight), the geometry is
+//     evaluated while texels are in flight and parked in LDS: 135 VGPRs, three waves per SIMD, no scratch frame;
 //   * nothing of the 74-float DSORawResidualJacobian is written to memory.  What the next iteration consumes leaves the kernel in
 //     reduced form: the wave's contribution to the 13x13 AccumulatorApprox block of its pair (BA.cpp:1731-1745, ACC.h:776-932) as
 //     ONE 16x16 fp32 tile accumulated on the matrix cores over the wave's residuals (v_mfma_f32_16x16x4_f32, one per residual,
-//     the formulation of k_ba_acc; the only LDS use of the kernel is the transposition of the 40 operands per residual), and per
+//     the formulation of k_ba_acc, over the residuals that are IN), and per
 //     residual 14 floats: JpJdF (BA.cpp:2066-2080) and the terms of Hdd / bd / Hcd (BA.cpp:1747-1750).  The full records are
 //     re-materialised on demand by k_ba_linearize (cml_materialize_records).
 #include "cmlhip_internal.h"
