@@ -166,6 +166,48 @@ def lba(seed):
     return same(pts, pts_o) and np.array_equal(bad, bad_o), len(pts)
 
 
+def resident(seed):
+    """The residual kernels of the resident loop (4 lanes per residual / lane per residual, fp32 / fp16 + tiled level 0 by seed)
+    against the record-writing kernel on identical device state: per-residual outputs bit for bit."""
+    rng = np.random.default_rng(seed)
+    tile = 16 if seed % 2 else 64
+    half = bool((seed // 2) % 2)
+    cfg = (int(rng.integers(3, 7)), int(rng.integers(100, 500)), int(rng.integers(300, 420)), int(rng.integers(230, 300)), 3, 260.0, 260.0, 160.0, 120.0)
+    I = S.make_inputs(cfg, seed=seed)
+    if half:
+        for k in range(I.N):
+            for lvl in range(len(I.grads[k])):
+                I.grads[k][lvl] = I.grads[k][lvl].astype(np.float16).astype(np.float32)
+    fmt = abi.TEXEL_F16 if half else abi.TEXEL_F32
+    ctxs = []
+    try:
+        for use_rs in (False, True):
+            os.environ["CMLHIP_RS_TILE"] = str(tile)
+            if use_rs:
+                os.environ.pop("CMLHIP_NO_RS", None)
+            else:
+                os.environ["CMLHIP_NO_RS"] = "1"
+            try:
+                ctxs.append(D.make_ctx(I, texel_format=fmt))
+            finally:
+                os.environ.pop("CMLHIP_NO_RS", None); os.environ.pop("CMLHIP_RS_TILE", None)
+        for c in ctxs:
+            c.ba_linearize(); c.ba_apply(1)
+            D.accumulate(c, I)
+            c.ba_iteration_async(1e-5); c.sync()
+        a, b = ctxs
+        sa, sb = a.ba_states(), b.ba_states()
+        g = sa["good"] == 1
+        IN = sa["new_state"] == 0
+        ok = all(same(sa[k], sb[k]) for k in ("state", "new_state", "good", "energy", "new_energy", "new_energy_wo"))
+        ok = ok and same(a.ba_get_idepth(), b.ba_get_idepth()) and same(a.ba_jpjdf()[g], b.ba_jpjdf()[g]) and same(a.ba_center()[IN], b.ba_center()[IN])
+        ok = ok and same(a.ba_rj(1)[g], b.ba_rj(1)[g])
+        return ok, I.R
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def tolerance_families(n):
     """The comparisons that are NOT bit-exact (different summation order): worst relative deviation over the seeds, next to the
     bar the parity tests apply."""
@@ -232,7 +274,7 @@ def tolerance_families(n):
 fail = 0
 if "--tolerance" in sys.argv:
     sys.exit(tolerance_families(n_seeds))
-for name, fn in (("BA linearize/apply records", ba), ("marginalisation res_toZero", marginalisation), ("tracker pyramid/lists/warped", tracker), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba)):
+for name, fn in (("BA linearize/apply records", ba), ("marginalisation res_toZero", marginalisation), ("tracker pyramid/lists/warped", tracker), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba), ("resident residual kernels vs record kernel", resident)):
     n_ok, units = 0, 0
     for s in range(n_seeds):
         ok, u = fn(1000 + 17 * s)
