@@ -473,6 +473,7 @@ __global__ void k_ba_point_rows_marg(BAArgs A, AccArgs X) {
 struct SysArgs {
     const int* stop;                                        // early-exit flag of the resident loop (may be null)
     int N, n, ldg, ntile, P, use_lin_blocks, nsl, nsyrk;    // nsl point slices per tile, nsyrk = ntiles*nsl SYRK workgroups (0: row blocks only)
+    int nt2;                                                // wide systems (k_ba_system<true>): SYRK workgroups own 2 x 2 SUPER-tiles, nt2 = ceil(ntile / 2), nsyrk = nt2 (nt2 + 1) / 2 * nsl
     double* part;                                           // SYRK partial tiles [tile][slice][256]
     const double* G; const double* Wt;
     const double* pbA; const double* pbL;                   // per-pair stitched blocks (ACTIVE / LINEARIZED)
@@ -529,14 +530,85 @@ __device__ __forceinline__ double frame_sum(const double* pb, int N, int a, int 
 #define SYS_WPE 6
 __device__ __forceinline__ int sys_tile_index(int ti, int tj, int ntile) { return ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti); }
 
-__global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SYS_WPE, SYS_WPE))) void k_ba_system(SysArgs S) {
+// SUPER (wide systems, ntile >= 8): a SYRK workgroup owns a 2 x 2 block of tiles — the two 16-column panels on either side are
+// loaded once for four matrix products on four independent accumulators: half the reads of G per product (at a 20-frame window the 66
+// plain tiles re-read 135 MB of G from beyond the L2s: the launch was bound by that, not by the matrix cores) and four chains in
+// flight; operands of the next trip are requested before the current trip's products.  Partials land in the same per-tile slots.
+template <bool SUPER>
+__global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SUPER ? 3 : SYS_WPE, SUPER ? 3 : SYS_WPE))) void k_ba_system(SysArgs S) {
     __shared__ double s_part[SYS_NW][256];
     __shared__ double s_f[2][FS_STRIDE];          // [ACTIVE | LINEARIZED] D (64) C (32) B (8) of this frame, or CC (16) bC (4)
     DBG_BLK(S.dbg, 2, 0);
     if (S.stop && *S.stop) return;
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, NT = 64 * SYS_NW;
     const int N = S.N, n = S.n;
-    if ((int)blockIdx.x < S.nsyrk) {
+    if (SUPER && (int)blockIdx.x < S.nsyrk) {
+        const int st = blockIdx.x / S.nsl, sl = blockIdx.x % S.nsl;
+        int Ti = 0, rem = st;
+        while (rem >= S.nt2 - Ti) { rem -= S.nt2 - Ti; Ti++; }
+        const int Tj = Ti + rem;
+        const int ti0 = 2 * Ti, ti1 = min(2 * Ti + 1, S.ntile - 1), tj0 = 2 * Tj, tj1 = min(2 * Tj + 1, S.ntile - 1);   // (clamped panels are loaded and dropped)
+        const int kk = l >> 4, c = l & 15;
+        const int per_s = ((S.P + S.nsl - 1) / S.nsl + 3) & ~3;
+        const int s_beg = sl * per_s, s_end = min(S.P, s_beg + per_s);
+        const int per = ((max(s_end - s_beg, 0) + SYS_NW - 1) / SYS_NW + 3) & ~3;
+        const int p_beg = s_beg + wv * per, p_end = min(s_end, p_beg + per);
+        double4_ acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};   // (ti0,tj0) (ti0,tj1) (ti1,tj0) (ti1,tj1)
+        constexpr int U = 4;
+        double a0[2][U], a1[2][U], b0[2][U], b1[2][U], w[2][U];
+        auto request = [&](int sp, int buf) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int p = min(sp + 4 * u + kk, max(p_end - 1, 0));
+                const double* row = S.G + (size_t)p * S.ldg;
+                a0[buf][u] = row[16 * ti0 + c]; a1[buf][u] = row[16 * ti1 + c];
+                b0[buf][u] = row[16 * tj0 + c]; b1[buf][u] = row[16 * tj1 + c];
+                w[buf][u] = S.Wt[p];
+            }
+        };
+        auto products = [&](int sp, int buf) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double mk = (sp + 4 * u + kk < p_end) ? 1.0 : 0.0;
+                const double x0 = a0[buf][u] * mk, x1 = a1[buf][u] * mk;
+                const double y0 = (w[buf][u] * b0[buf][u]) * mk, y1 = (w[buf][u] * b1[buf][u]) * mk;
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, acc[3], 0, 0, 0);
+            }
+        };
+        if (p_beg < p_end) request(p_beg, 0);
+        for (int sp = p_beg; sp < p_end; sp += 8 * U) {               // two trips per turn: static buffer indices
+            if (sp + 4 * U < p_end) request(sp + 4 * U, 1);
+            products(sp, 0);
+            if (sp + 4 * U < p_end) {
+                if (sp + 8 * U < p_end) request(sp + 8 * U, 0);
+                products(sp + 4 * U, 1);
+            }
+        }
+        // the four tiles, one after the other through the per-wave LDS rows; slots of tiles outside the upper triangle / the matrix are skipped
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ti = (q & 2) ? 2 * Ti + 1 : 2 * Ti, tj = (q & 1) ? 2 * Tj + 1 : 2 * Tj;
+            const bool live = ti < S.ntile && tj < S.ntile && ti <= tj;          // wave-uniform
+            if (live) {
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) s_part[wv][(kk + 4 * rg) * 16 + c] = acc[q][rg];
+            }
+            __syncthreads();
+            if (live && tid < 256) {
+                double sum = s_part[0][tid];
+#pragma unroll
+                for (int wq = 1; wq < SYS_NW; wq++) sum += s_part[wq][tid];
+                S.part[((size_t)sys_tile_index(ti, tj, S.ntile) * S.nsl + sl) * 256 + tid] = sum;
+            }
+            __syncthreads();
+        }
+        DBG_BLK_END(S.dbg, 2);
+        return;
+    }
+    if (!SUPER && (int)blockIdx.x < S.nsyrk) {
         const int tile = blockIdx.x / S.nsl, sl = blockIdx.x % S.nsl;
         int ti = 0, rem = tile;
         while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
@@ -1326,9 +1398,14 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     const int ntiles = S.ntile * (S.ntile + 1) / 2;
     S.nsl = cml_sys_slices(A.P);
     S.nsyrk = system_only ? 0 : ntiles * S.nsl;             // the Schur slices only change with the residuals
+    static const char* e_super = getenv("CMLHIP_SYS_SUPER");  // development: 0 / 1 forces the plain / the super-tile SYRK
+    const bool super = e_super ? atoi(e_super) != 0 : S.ntile >= 8;
+    S.nt2 = (S.ntile + 1) / 2;
+    if (super && !system_only) S.nsyrk = S.nt2 * (S.nt2 + 1) / 2 * S.nsl;
     S.part = c->syrk_part.as<double>();
     c->sys_lambda = lambda;
-    k_ba_system<<<S.nsyrk + N + 1, 64 * SYS_NW, 0, c->stream>>>(S);
+    if (super) k_ba_system<true><<<S.nsyrk + N + 1, 64 * SYS_NW, 0, c->stream>>>(S);
+    else k_ba_system<false><<<S.nsyrk + N + 1, 64 * SYS_NW, 0, c->stream>>>(S);
     return CMLHIP_OK;
 }
 
