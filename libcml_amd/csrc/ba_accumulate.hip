@@ -386,8 +386,11 @@ __global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) 
         if (blockIdx.x == 0 && threadIdx.x == 0) A.ctl->stop_lin = 1;
         return;
     }
-    if ((int)blockIdx.x < NN) acc_pair_block(A, X, blockIdx.x, mode);
-    else point_rows_block(A, X, blockIdx.x - NN);      // 16 points per 1024-thread block
+    // the point-row workgroups (16 points per 1024-thread block) take about twice as long as the pair workgroups at a wide window: they
+    // are handed out FIRST, the short pair workgroups fill the tail of the launch
+    const int npt = (int)gridDim.x - NN;
+    if ((int)blockIdx.x < npt) point_rows_block(A, X, blockIdx.x);
+    else acc_pair_block(A, X, blockIdx.x - npt, mode);
     DBG_BLK_END(A.dbg, 1);
 }
 

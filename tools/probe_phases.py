@@ -33,7 +33,8 @@ for k in (1, 2, 3, 4, 0):
           (names[k], len(b), st.min(), st.max(), en.max(), d.min(), np.median(d), d.max()))
     if k == 1:
         NN = W.N * W.N
-        print("   pair blocks: med %.2f max %.2f ; point blocks: med %.2f max %.2f" % (np.median(d[:NN]), d[:NN].max(), np.median(d[NN:]), d[NN:].max()))
+        npt = len(d) - NN                                # the point-row workgroups come first in the grid
+        print("   pair blocks: med %.2f max %.2f ; point blocks: med %.2f max %.2f" % (np.median(d[npt:]), d[npt:].max(), np.median(d[:npt]), d[:npt].max()))
 b = blk[2]; nb_ = int((b[:, 0] > 0).sum()); d = (b[:nb_, 1] - b[:nb_, 0]) * 0.01
 nrow = W.N + 1
 print("system: SYRK blocks %d dur med %.2f max %.2f ; row blocks dur med %.2f max %.2f" % (nb_ - nrow, np.median(d[:-nrow]), d[:-nrow].max(), np.median(d[-nrow:]), d[-nrow:].max()))
