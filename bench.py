@@ -249,7 +249,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
-                out["cpu_baseline"] = cpu_baseline(args.config, seed)
+                out["cpu_baseline"] = cpu_baseline(wcfg, seed)          # (config C: the photometric window of config B; the ORB term is not part of the CPU port's timing)
+                if hybrid and isinstance(out["cpu_baseline"], dict):
+                    out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", "")) + " — the config-B window WITHOUT the 1000 ORB residuals of config C"
             except Exception as e:      # the checker must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "point-residuals/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
