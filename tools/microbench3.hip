@@ -78,6 +78,41 @@ __global__ void lds_ind(long long* out, double seed) {
     if (acc == 12345.678f) out[100] = 1;
 }
 
+
+// matrix instructions: one dependent chain / four independent chains per wave
+typedef double mb_d4 __attribute__((ext_vector_type(4)));
+typedef float mb_f4 __attribute__((ext_vector_type(4)));
+template <int CH> __global__ void mfma64(long long* out, double seed) {
+    mb_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    double a = seed + threadIdx.x * 1e-3, b = 1.0 - seed * 1e-3;
+    long long t0 = clock64();
+    for (int o = 0; o < OUTER; o++) {
+#pragma unroll
+        for (int i = 0; i < REP / 4; i++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[CH == 1 ? 0 : c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[CH == 1 ? 0 : c], 0, 0, 0);
+        }
+    }
+    long long t1 = clock64();
+    if (threadIdx.x % 64 == 0) out[blockIdx.x * 16 + threadIdx.x / 64] = t1 - t0;
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678) out[100] = 1;
+}
+template <int CH> __global__ void mfma32(long long* out, double seed) {
+    mb_f4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    float a = (float)seed + threadIdx.x * 1e-3f, b = 1.0f - (float)seed * 1e-3f;
+    long long t0 = clock64();
+    for (int o = 0; o < OUTER; o++) {
+#pragma unroll
+        for (int i = 0; i < REP / 4; i++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[CH == 1 ? 0 : c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[CH == 1 ? 0 : c], 0, 0, 0);
+        }
+    }
+    long long t1 = clock64();
+    if (threadIdx.x % 64 == 0) out[blockIdx.x * 16 + threadIdx.x / 64] = t1 - t0;
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) out[100] = 1;
+}
+
 template <class K> static void run(const char* name, K kd, K ki, int nper, long long* d_out, int ops_dep, int ops_ind) {
     long long h[16];
     printf("%-10s", name);
@@ -98,6 +133,8 @@ int main() {
     long long* d_out; hipMalloc(&d_out, 4096);
     const int N = REP * OUTER;
 #define RUN(name, mult) run(#name, name##_dep, name##_ind, 0, d_out, N * mult, N * mult)
+    run("mfma_f64", mfma64<1>, mfma64<4>, 0, d_out, N, N);      // v_mfma_f64_16x16x4_f64: "dep" = one accumulator chain, "ind" = four chains
+    run("mfma_f32", mfma32<1>, mfma32<4>, 0, d_out, N, N);      // v_mfma_f32_16x16x4_f32
     RUN(fma64, 1); RUN(mul64, 1); RUN(add64, 1); RUN(rcp64, 1); RUN(fma32, 1); RUN(mul32, 1); RUN(sqrt32, 1); RUN(rcp32, 1); RUN(cvt, 2); RUN(sumform, 4); RUN(pkfma32, 1);
     {
         long long h[16];
