@@ -131,6 +131,37 @@ def _dbg(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` started WITHOUT a torchrun environment: launch the N ranks ourselves (one process per GPU, the same
+    command line the driver uses for N > 1) and pass their output through.  Rank 0 prints the JSON line; n_gpus in it is the size of
+    the process group that actually formed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def _launch_only(args):
+    """--launch-only: form the process group, run the timing contract (barrier, sync, max over ranks) around an EMPTY step list and print
+    the line skeleton.  Exists so that the N > 1 launch path of this file can be exercised where there is no GPU (gloo, tests/test_shard_cpu.py);
+    it touches no device code and reports no throughput."""
+    from libcml_amd import shard
+    group = shard.Group()
+    dt = shard.timed_region(group, lambda: None, lambda: None)
+    ranks = group.sum(1.0)
+    if group.rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": int(round(ranks)), "requested_gpus": args.gpus, "backend": getattr(group, "backend", None),
+                          "steps": 0, "elapsed_s": dt}))
+    group.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,7 +169,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="B", help="synthetic window (libcml_amd.synth.CONFIGS); B is the benchmark workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tracker and multi-window objects (headline + roofline + parity only)")
+    ap.add_argument("--launch-only", action="store_true", help="exercise the rank launch + process group only (no device work; CPU test)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:              # not under torchrun: start the ranks ourselves
+        sys.exit(_spawn_ranks(args.gpus))
+    if args.launch_only:
+        return _launch_only(args)
 
     from libcml_amd import device, host, shard, synth
     rank, local_rank, world = shard.env_world()
@@ -202,12 +240,30 @@ def main():
     _dbg('profile enabled')
     dt = shard.timed_region(group, sync, run_steps)
     _dbg('timed region done')
+    ranks_joined = int(round(group.sum(1.0)))
     lin_v, ss_v, _empty, n_samples = ctx.profile_read()
     # the events are the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL): no bracket overhead to subtract
     lin_ms, ss_ms = C.c_float(lin_v), C.c_float(ss_v)
     _dbg('profile read')
     st = ctx.ba_states()
     n_good = int(st["good"].sum())
+    n_sampled = int((st["state"] != 1).sum())        # residuals of the timed passes that enter the pixel loop and gather texels (OOB is absorbing, BA.cpp:68-72)
+    # ---- parity gate ("a throughput figure is only valid if the same run passes the fixture comparison"): one more
+    # iteration from the state the timed region left, its residual pass replayed on the oracle from the device's own state and compared
+    # bit for bit over ALL R residuals (tests/resident_check.py) — after the timed region, outside it
+    parity = {"parity_checked": False}
+    if rank == 0 and not hybrid:
+        try:
+            from tests import resident_check as RC
+            replay = RC.make_replay(ctx, ba, W)
+            rep = RC.check_one_pass(ctx, replay, lam, with_records=True)
+            replay.close()
+            parity = {"parity_checked": True, "parity_ok": bool(rep["ok"]), "parity": rep,
+                      "parity_note": "one resident iteration after the timed region; its residual pass (%s) replayed by oracle/orc_ba.c from the device's "
+                                     "pairs / thresholds / inverse depths / prior states: states, energies, JpJdF, centre projections and the re-materialised "
+                                     "74-float records compared bit for bit over all R residuals" % ("k_ba_lin_rs" if R >= 36 * 1024 else "k_ba_lin_rs4")}
+        except Exception as e:
+            parity = {"parity_checked": False, "parity_error": repr(e)}
     total_units = group.sum(float(R) * args.steps)
     lin_ms_max = group.max(lin_ms.value)
     ss_ms_max = group.max(ss_ms.value)
@@ -232,14 +288,17 @@ def main():
         out = {
             "metric": "point-residuals/sec + Schur-reduce+solve ms, 8 KF x 2000 pts window",
             "value": total_units / dt, "unit": "point-residuals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "n_gpus": ranks_joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("config C = config B + 1000 ORB reprojection residuals of 300 points mixed into the pose solution in every iteration; " if hybrid else "") + "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "
                                    "gradient images, %s texels / fp32 arithmetic; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (wcfg, N, P, R, W.w, W.h, "fp16" if half else "fp32"),
                        "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
-            "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good,
+            "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good, "n_sampled": n_sampled,
             "roofline": {"bound": "hbm", "kernel": ("k_ba_lin_rs (lane per residual, tiled fp16 level 0)" if R >= 36 * 1024 else "k_ba_lin_rs4 (4 lanes per residual)") + " = linearize + applyRes of the resident loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "n_sampled": n_sampled, "frac_sampled": (achieved / HBM_PEAK_GBS) * n_sampled / max(R, 1),
+                         "frac_sampled_note": "the same fraction billed only for the residuals that gather texels (state != OOB before the pass)",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": R * bytes_per_residual, "bytes_per_residual": bytes_per_residual,
                          "launch_us": 1e3 * lin_ms.value, "launch_samples": n_samples,
                          "launch_us_note": "mean over the sampled steps of the timed region of hipEventElapsedTime between the start and stop events "
@@ -247,6 +306,9 @@ def main():
                                            "timestamps, the quantity rocprofv3 --kernel-trace reports",
                          "rocprof_avg_us": rocprof_us},
         }
+        out.update(parity)
+        if parity.get("parity_checked") and not parity.get("parity_ok"):
+            out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wcfg, seed)          # (config C: the photometric window of config B; the ORB term is not part of the CPU port's timing)

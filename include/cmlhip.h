@@ -303,6 +303,12 @@ int cmlhip_ba_get_states(cmlhip_ctx* ctx, int* state, int* new_state, float* ene
 int cmlhip_ba_get_rj(cmlhip_ctx* ctx, int which, float* out /* R*74 */);
 int cmlhip_ba_get_jpjdf(cmlhip_ctx* ctx, float* out /* R*8 */);
 int cmlhip_ba_get_center_projected(cmlhip_ctx* ctx, float* out /* R*3 */);
+/* What the residual kernel reads besides points and residuals, as the device holds it NOW: the N*N DSOFramePrecomputed records
+ * (DSOFrame.h:248-291; layout of cmlhip_ba_set_pairs — inside the resident loop they are rewritten by the device frame step every
+ * iteration) and the per-frame frameEnergyTH / b0 (DSOFrame.h:35,197-199).  A plain copy with no side effect (the pending
+ * setNewFrameEnergyTH of the last resident pass is NOT run): the values are exactly those the last residual pass used, which is what
+ * lets a checker replay that pass (tests/resident_check.py, bench.py's parity gate).  Any pointer may be NULL. */
+int cmlhip_ba_get_pairs(cmlhip_ctx* ctx, cmlhip_ba_pair* pairs /* N*N */, float* frame_energy_th /* N */, float* b0 /* N */);
 /* per point: Hdd_accAF, bd_accAF, Hcd_accAF[4], Hdd_accLF, bd_accLF, Hcd_accLF[4], HdiF, bdSumF (14 floats) */
 int cmlhip_ba_get_point_acc(cmlhip_ctx* ctx, float* out /* P*14 */);
 /* raw per-pair 13x13 accumulators (AccumulatorApprox::H after finish, ACC.h:639-673), index h + t*N */

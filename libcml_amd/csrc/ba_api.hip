@@ -796,6 +796,18 @@ int cmlhip_ba_get_states(cmlhip_ctx* c, int* state, int* new_state, float* energ
     return CMLHIP_OK;
 }
 
+int cmlhip_ba_get_pairs(cmlhip_ctx* c, cmlhip_ba_pair* pairs, float* frame_energy_th, float* b0) { CML_DEV(c);
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    if (pairs && (rc = cml_d2h(c, pairs, c->pairs.p, sizeof(cmlhip_ba_pair) * (size_t)c->N * c->N))) return rc;
+    if (frame_energy_th || b0) {
+        std::vector<FrameDev> fd(c->N);
+        if ((rc = cml_d2h(c, fd.data(), c->frames.p, sizeof(FrameDev) * (size_t)c->N))) return rc;
+        for (int i = 0; i < c->N; i++) { if (frame_energy_th) frame_energy_th[i] = fd[i].frame_energy_th; if (b0) b0[i] = fd[i].b0; }
+    }
+    return CMLHIP_OK;
+}
+
 int cmlhip_ba_get_rj(cmlhip_ctx* c, int which, float* out) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;

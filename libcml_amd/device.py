@@ -92,6 +92,7 @@ PROTOTYPES = {
     "cmlhip_reproj_solve": (C.c_int, [_ctx, _i, _d, _P(_d)]),
     "cmlhip_event_mark": (C.c_int, [_ctx, _i]),
     "cmlhip_event_elapsed_ms": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_get_pairs": (C.c_int, [_ctx, C.c_void_p, _P(_f), _P(_f)]),
     "cmlhip_ba_linearize_async": (C.c_int, [_ctx]),
     "cmlhip_ba_iteration_async": (C.c_int, [_ctx, _d]),
 }
@@ -316,6 +317,12 @@ class Ctx:
         out = np.zeros((self.R, 3), np.float32)
         self.ck(self.L.cmlhip_ba_get_center_projected(self.h, _p(out, _f)))
         return out
+
+    def ba_pairs(self):
+        """(pairs N*N, frame_energy_th N, b0 N) as the device holds them now — no side effect (cmlhip_ba_get_pairs)."""
+        pairs = np.zeros(self.N * self.N, abi.BA_PAIR_DTYPE); th = np.zeros(self.N, np.float32); b0 = np.zeros(self.N, np.float32)
+        self.ck(self.L.cmlhip_ba_get_pairs(self.h, pairs.ctypes.data_as(C.c_void_p), _p(th, _f), _p(b0, _f)))
+        return pairs, th, b0
 
     def ba_point_acc(self):
         out = np.zeros((self.P, 14), np.float32)

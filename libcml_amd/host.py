@@ -421,6 +421,7 @@ def window_to_host_ba(ctx, W, image_id_base=1000, levels=1):
     colors, weights = synth.point_colors_weights(W, grads0)
     for i in range(W.P):
         ba.add_point(W.pts["x"][i], W.pts["y"][i], W.pts["idepth"][i], W.pts["host"][i], colors[i], weights[i])
+    ba.synth_inputs = {"colors": colors, "weights": weights, "grads0": grads0}      # what was registered (for checkers that replay the window)
     return ba
 
 

@@ -46,3 +46,17 @@ def test_shard_assignment_is_a_partition():
         got = sorted(s for r in range(world) for s in shard.shards_for_rank(8, r, world))
         assert got == list(range(8))
         assert all(len(shard.shards_for_rank(8, r, world)) == 8 // world for r in range(world))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started WITHOUT a torchrun environment (as the driver starts N = 1) must start 2 ranks itself and report
+    the size of the group that formed.  --launch-only keeps the device out of it: gloo, no GPU here."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-only"], capture_output=True, text=True,
+                         env=env, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["requested_gpus"] == 2 and r["launch_only"] is True and r["backend"] == "gloo"
