@@ -48,7 +48,7 @@ def _one_socket_cores():
 
 
 def _time_oracle(L, O, S, config, seed, runs=20, warm=3, iters_per_run=5):
-    """median over `runs` (after `warm` warm-ups) of one run = iters_per_run Gauss-Newton iterations of the window."""
+    """per-run times (after `warm` warm-ups) of one run = iters_per_run Gauss-Newton iterations of the window: (R, [linearize s], [rest s])"""
     I = S.make_inputs(config, seed=seed)
     ob = S.OracleBA(I)
     ob.linearize(); ob.apply(1)
@@ -68,26 +68,54 @@ def _time_oracle(L, O, S, config, seed, runs=20, warm=3, iters_per_run=5):
             b += t1 - t0; a += t2 - t1
         if k >= warm:
             t_lin.append(a / iters_per_run); t_rest.append(b / iters_per_run)
+    return I.R, t_lin, t_rest
+
+
+def _cpu_worker(config, seed, mode):
+    """Runs in a FRESH interpreter (no torch: its libgomp would have read the OpenMP environment before we could set it).
+    mode "single": oracle C port, -O3 -march=native, one thread.  mode "omp": the same sources with -fopenmp — residual loop, pair /
+    point accumulation, point Schur and back-substitution spread over the threads (timing build only; the checker build is serial)."""
     import statistics
-    return I.R, statistics.median(t_lin), statistics.median(t_rest), min(t_lin), max(t_lin)
+    from tests import ba_setup as S
+    from tests import oracle_lib as O
+    target, soname = ("fast", "libcml_oracle_fast.so") if mode == "single" else ("fast_omp", "libcml_oracle_omp.so")
+    build = "-O3 -march=native" + ("" if mode == "single" else " -fopenmp")
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), target], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(ROOT, "oracle", soname))
+        L.orc_ba_create.restype = C.POINTER(O.OrcBAWindow)
+        L.orc_ba_linearize_one.restype = C.c_double
+        O._lib = L
+    except Exception:
+        if mode != "single":
+            raise
+        L = O.lib(); build = "-O2 (portable checker build)"
+    R, t_lin, t_rest = _time_oracle(L, O, S, config, seed)
+    tot = [a + b for a, b in zip(t_lin, t_rest)]
+    med = statistics.median(tot)
+    print(json.dumps({"R": R, "value": R / med, "value_minmax": [R / max(tot), R / min(tot)],
+                      "linearize_residuals_per_s": R / statistics.median(t_lin), "linearize_residuals_per_s_minmax": [R / max(t_lin), R / min(t_lin)],
+                      "schur_solve_ms": 1e3 * statistics.median(t_rest), "schur_solve_ms_minmax": [1e3 * min(t_rest), 1e3 * max(t_rest)],
+                      "build": build, "threads": int(os.environ.get("OMP_NUM_THREADS", "1"))}))
 
 
-def _load_oracle(O, target, soname):
-    so = os.path.join(ROOT, "oracle", soname)
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), target], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    L = C.CDLL(so)
-    L.orc_ba_create.restype = C.POINTER(O.OrcBAWindow)
-    L.orc_ba_linearize_one.restype = C.c_double
-    O._lib = L
-    return L
+def _run_cpu_worker(config, seed, mode, env_extra):
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "GOMP_CPU_AFFINITY", "OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", config, str(seed), mode], capture_output=True, text=True,
+                       env=env, cwd=ROOT, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline worker failed: " + r.stderr[-500:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
 def cpu_baseline(config, seed):
-    """The oracle (plain-C port of the reference CPU path, "kind": "port") timed on this box's host cores, SURVEY §8(d):
-    median of 20 runs after 3 warm-ups, (i) single thread — the reference's BA is serial (BA.cpp:1551-1565) — and
-    (ii) the residual loop spread with OpenMP over the physical cores of one socket (accumulate / Schur / solve stay serial)."""
-    from tests import ba_setup as S
-    from tests import oracle_lib as O
+    """The oracle (plain-C port of the reference CPU path, "kind": "port") timed on this box's host cores, SURVEY §8(d): median of 20
+    runs (3 warm-ups) of 5 Gauss-Newton iterations of the same window, (i) single thread — the reference's BA loop is serial
+    (BA.cpp:1551-1565) — and (ii) OpenMP over the physical cores of one socket (threads bound one per core, passive waiting, 64 / 32 / 16
+    threads tried, best kept).  `value` = the better of (i) and (ii): the single-socket figure the >= 30x target is judged on."""
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -96,33 +124,31 @@ def cpu_baseline(config, seed):
                 break
     except Exception:
         pass
-    try:            # -O3 -march=native build on the box it is timed on (falls back to the portable -O2 checker build)
-        L = _load_oracle(O, "fast", "libcml_oracle_fast.so")
-        build = "-O3 -march=native"
-    except Exception:
-        O._lib = None
-        L = O.lib()
-        build = "-O2"
-    R, lin1, rest1, lo1, hi1 = _time_oracle(L, O, S, config, seed)
-    out = {"value": R / (lin1 + rest1), "unit": "point-residuals/s", "cores": 1, "kind": "port",
-           "sample": "median of 20 runs (3 warm-ups) of 5 Gauss-Newton iterations of the same window (R=%d), oracle C port %s, single thread "
-                     "(the reference's BA loop is serial)" % (R, build),
-           "linearize_residuals_per_s": R / lin1, "linearize_residuals_per_s_minmax": [R / hi1, R / lo1], "schur_solve_ms": 1e3 * rest1,
-           "host_cpu": model, "host_logical_cpus": os.cpu_count()}
+    one = _run_cpu_worker(config, seed, "single", {"OMP_NUM_THREADS": "1"})
+    R = one["R"]
+    out = {"value": one["value"], "unit": "point-residuals/s", "cores": 1, "kind": "port",
+           "sample": "median of 20 runs (3 warm-ups) of 5 full Gauss-Newton iterations of the same window (R=%d) by the oracle C port" % R,
+           "single_thread": one, "host_cpu": model, "host_logical_cpus": os.cpu_count()}
     try:
         cores = _one_socket_cores()
-        os.environ["OMP_NUM_THREADS"] = str(len(cores))
-        os.environ["GOMP_CPU_AFFINITY"] = " ".join(str(c) for c in cores)
-        L = _load_oracle(O, "fast_omp", "libcml_oracle_omp.so")
-        R, linN, restN, loN, hiN = _time_oracle(L, O, S, config, seed)
-        out["all_cores_one_socket"] = {"value": R / (linN + restN), "unit": "point-residuals/s", "cores": len(cores),
-                                       "linearize_residuals_per_s": R / linN, "schur_solve_ms": 1e3 * restN,
-                                       "sample": "same protocol, -fopenmp over the residual loop on the %d physical cores of socket 0; "
-                                                 "accumulate / Schur / solve serial as in the reference" % len(cores)}
+        best = None
+        tried = []
+        for nt in sorted({len(cores), max(len(cores) // 2, 1), max(len(cores) // 4, 1)}, reverse=True):
+            use = cores[:nt]
+            r = _run_cpu_worker(config, seed, "omp", {"OMP_NUM_THREADS": str(nt), "GOMP_CPU_AFFINITY": " ".join(str(c) for c in use),
+                                                      "OMP_PROC_BIND": "true", "OMP_WAIT_POLICY": "passive"})
+            tried.append({"threads": nt, "value": r["value"]})
+            if best is None or r["value"] > best["value"]:
+                best = r
+        out["all_cores_one_socket"] = dict(best, cores_available=len(cores), tried=tried,
+                                           sample="same protocol, -fopenmp build: residual loop, pair / point accumulation, point Schur and "
+                                                  "back-substitution over the threads (one per physical core of socket 0, bound, passive waiting); "
+                                                  "stitch + dense solve serial")
+        if best["value"] > out["value"]:
+            out["value"] = best["value"]; out["cores"] = best["threads"]
     except Exception as e:
         out["all_cores_one_socket"] = {"value": None, "sample": "failed: %r" % (e,)}
-    finally:
-        O._lib = None
+    out["sample"] += "; value = max(single thread, OpenMP on one socket); threads used by that figure = cores"
     return out
 
 
@@ -171,8 +197,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the tracker and multi-window objects (headline + roofline + parity only)")
     ap.add_argument("--launch-only", action="store_true", help="exercise the rank launch + process group only (no device work; CPU test)")
+    ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("CONFIG", "SEED", "MODE"), help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_baseline_worker:
+        return _cpu_worker(args.cpu_baseline_worker[0], int(args.cpu_baseline_worker[1]), args.cpu_baseline_worker[2])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:              # not under torchrun: start the ranks ourselves
         sys.exit(_spawn_ranks(args.gpus))
     if args.launch_only:
@@ -312,6 +341,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wcfg, seed)          # (config C: the photometric window of config B; the ORB term is not part of the CPU port's timing)
+                if out["cpu_baseline"].get("value"):
+                    out["gpu_over_cpu_single_socket"] = out["value"] / out["cpu_baseline"]["value"]     # what north_star's ">= 30x" is judged on
+                    out["gpu_over_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["single_thread"]["value"]
                 if hybrid and isinstance(out["cpu_baseline"], dict):
                     out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", "")) + " — the config-B window WITHOUT the 1000 ORB residuals of config C"
             except Exception as e:      # the checker must never take the measurement down

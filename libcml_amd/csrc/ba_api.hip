@@ -536,7 +536,7 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
     const bool mix = c->resident_on && c->rp_resident && c->N > 4;      // addIndirectToProblem, BA.cpp:1327-1329 (only with more than 4 frames)
     if (mix && (rc = cml_launch_reproj_resident(c, lambda))) return rc;
-    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rp_x.as<double>() : nullptr))) return rc;   // K5: solve (+ hybrid term, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
+    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rr_x.as<double>() : nullptr))) return rc;   // K5: solve (+ hybrid term, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
     c->resident_iter++;
     if (prof) c->ext_stop = ev[1];                           // end timestamp of the K6 dispatch
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update

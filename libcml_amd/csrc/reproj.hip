@@ -5,8 +5,12 @@
 //
 // The reference builds a sparse J of size (6N+3M) x (N*M), forms the DENSE H = J J^T ((6N+3M)^2 doubles, tens of
 // MB) and then keeps only the 6N x 6N pose block.  Each column of J touches one frame and one point, so that pose
-// block is block-diagonal: M6[i,i] = sum_j f_ij f_ij^T.  Here each observation is one lane; the 21+6 unique sums
-// per frame are reduced in LDS per workgroup and added to global with fp64 atomics.  All arithmetic is fp64.
+// block is block-diagonal: M6[i,i] = sum_j f_ij f_ij^T.  Here ONE WORKGROUP OWNS ONE FRAME: the observations are sorted by frame on
+// upload (stable: the caller's order inside a frame), each lane walks its share of the frame's list in order, and the 21+6 unique
+// sums are reduced in a FIXED order (lane partials -> wave butterfly -> the four waves in sequence) — no atomics anywhere, so the term
+// and everything mixed from it are bit-reproducible from run to run (round 2 summed with fp64 atomicAdd and was not).  The per-point
+// Jacobian sums (setUncertainty, BA.cpp:2690) leave the device per observation and are added on the host in the caller's order.
+// All arithmetic is fp64.
 #include "cmlhip_internal.h"
 #include "../host/se3.h"
 
@@ -123,12 +127,6 @@ __device__ void reproj_frame_pre(const double* R, const double* t, FramePre& P) 
     d_se3_log(R, t, xi);                // BA.cpp:2621-2622
     d_dx_exp_x(xi, P.D);                // BA.cpp:2623
 }
-__global__ void k_reproj_frames(int N, const double* __restrict__ poses, FramePre* __restrict__ pre) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    reproj_frame_pre(poses + 12 * (size_t)i, poses + 12 * (size_t)i + 9, pre[i]);
-}
-
 __device__ __forceinline__ double d_tukey(double v, double th) {            // Derivative.h:35-39
     if (fabs(v) > th) return 0;
     const double l = 1.0 - (v * v) / (th * th);
@@ -140,97 +138,16 @@ __device__ __forceinline__ double d_dtukey(double v, double d, double th) { // D
     return d * (-4.0 * v2 * o + o * o);
 }
 
-#define RP_MAXN CMLHIP_MAX_FRAMES
-__global__ __launch_bounds__(256) void k_reproj_obs(int N, const double* __restrict__ poses, const FramePre* __restrict__ pre,
-                                                    const double* __restrict__ points, int n, const cmlhip_reproj_obs* __restrict__ obs,
-                                                    double fx, double fy, double* __restrict__ M6, double* __restrict__ b6,
-                                                    double* __restrict__ Jpoints, unsigned char* __restrict__ used) {
-    extern __shared__ double s_acc[];                 // N x 27 : 21 upper-tri of f f^T + 6 of f*res
-    for (int e = threadIdx.x; e < N * 27; e += blockDim.x) s_acc[e] = 0.0;
-    __syncthreads();
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) {
-        const int i = obs[k].frame, j = obs[k].point;
-        const double* R = poses + 12 * (size_t)i; const double* t = R + 9; const double* X = points + 3 * (size_t)j;
-        double T[3];
-        for (int a = 0; a < 3; a++) T[a] = (R[a * 3] * X[0] + R[a * 3 + 1] * X[1] + R[a * 3 + 2] * X[2]) + t[a];
-        const double dx = T[0] / T[2] - obs[k].gx, dy = T[1] / T[2] - obs[k].gy;
-        const double norm = sqrt(dx * dx + dy * dy);
-        const double th = 3.0 / sqrt(fx * fx + fy * fy);
-        const double res = d_tukey(norm, th);
-        double cam[7], Jp[3];
-        bool ok = true;
-        for (int a = 0; a < 3; a++) {
-            const double d[3] = {R[a], R[3 + a], R[6 + a]};                                   // Camera.h:317-321: R e_a
-            const double hx = (d[0] * T[2] - T[0] * d[2]) / (T[2] * T[2]), hy = (d[1] * T[2] - T[1] * d[2]) / (T[2] * T[2]);
-            const double dsq = 2.0 * hx * dx + 2.0 * hy * dy;
-            double v = (norm == 0) ? 0 : dsq / (2.0 * norm);
-            v = d_dtukey(res, v, th);
-            ok = ok && isfinite(v);
-            cam[a] = v; Jp[a] = -v;
-        }
-        const double* q = pre[i].q;
-        const double Pt[3] = {X[0] + t[0], X[1] + t[1], X[2] + t[2]};                         // Camera.h:323-325: R'(q)_a (P + t)
-        for (int a = 0; a < 4; a++) {
-            const double qa = q[0], qb = q[1], qc = q[2], qd = q[3];
-            double _2b2 = 0, _2c2 = 0, _2d2 = 0, _2bc = 0, _2ad = 0, _2bd = 0, _2ac = 0, _2cd = 0, _2ab = 0;
-            if (a == 0) { _2ad = 2 * qd; _2ac = 2 * qc; _2ab = 2 * qb; }
-            else if (a == 1) { _2b2 = 4 * qb; _2bc = 2 * qc; _2bd = 2 * qd; _2ab = 2 * qa; }
-            else if (a == 2) { _2c2 = 4 * qc; _2bc = 2 * qb; _2ac = 2 * qa; _2cd = 2 * qd; }
-            else { _2d2 = 4 * qd; _2ad = 2 * qa; _2bd = 2 * qb; _2cd = 2 * qc; }
-            const double D[9] = {-_2c2 - _2d2, _2bc - _2ad, _2bd + _2ac, _2bc + _2ad, -_2b2 - _2d2, _2cd - _2ab,
-                                 _2bd - _2ac, _2cd + _2ab, -_2b2 - _2c2};
-            double d[3];
-            for (int b = 0; b < 3; b++) d[b] = D[b * 3] * Pt[0] + D[b * 3 + 1] * Pt[1] + D[b * 3 + 2] * Pt[2];
-            const double hx = (d[0] * T[2] - T[0] * d[2]) / (T[2] * T[2]), hy = (d[1] * T[2] - T[1] * d[2]) / (T[2] * T[2]);
-            const double dsq = 2.0 * hx * dx + 2.0 * hy * dy;
-            double v = (norm == 0) ? 0 : dsq / (2.0 * norm);
-            v = d_dtukey(res, v, th);
-            ok = ok && isfinite(v);
-            cam[3 + a] = v;
-        }
-        const bool use = ok && !(res > 4 * 4);                                               // BA.cpp:2630
-        if (used) used[k] = use ? 1 : 0;
-        if (use) {
-            double f[6];
-            for (int c = 0; c < 6; c++) {                                                     // BA.cpp:2641
-                double s = 0;
-                for (int r = 0; r < 7; r++) s += cam[r] * pre[i].D[r * 6 + c];
-                f[c] = s;
-            }
-            int idx = 0;
-            for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { atomicAdd(&s_acc[i * 27 + idx], f[a] * f[c]); idx++; }
-            for (int a = 0; a < 6; a++) atomicAdd(&s_acc[i * 27 + 21 + a], f[a] * res);       // BA.cpp:2655
-            if (Jpoints) for (int c = 0; c < 3; c++) atomicAdd(&Jpoints[3 * (size_t)j + c], Jp[c]);
-        }
-    }
-    __syncthreads();
-    const int m = 6 * N;
-    for (int e = threadIdx.x; e < N * 27; e += blockDim.x) {
-        const double v = s_acc[e];
-        if (v == 0.0) continue;
-        const int i = e / 27, r = e % 27;
-        if (r >= 21) { atomicAdd(&b6[6 * i + r - 21], v); continue; }
-        int a = 0, rem = r;
-        while (rem >= 6 - a) { rem -= 6 - a; a++; }
-        const int c = a + rem;
-        atomicAdd(&M6[(size_t)(6 * i + a) * m + 6 * i + c], v);
-        if (c != a) atomicAdd(&M6[(size_t)(6 * i + c) * m + 6 * i + a], v);
-    }
-}
 
 // indirectX = M.ldlt().solve(-bM) with M(i,i) *= (1+lambda) (BA.cpp:2695-2700); M is block diagonal, so one 6x6
-// diagonally-pivoted LDL^T per frame (Eigen LDLT.h:300-396 / :560-600 semantics incl. the zero-pivot rule).
-__global__ void k_reproj_solve(int N, double lambda, const double* __restrict__ M6, const double* __restrict__ b6, double* __restrict__ x6) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= N) return;
-    const int m = 6 * N;
+// diagonally-pivoted LDL^T per frame (Eigen LDLT.h:300-396 / :560-600 semantics incl. the zero-pivot rule).  One lane.
+__device__ void reproj_solve6(const double* __restrict__ Min /* 6x6 row-major */, const double* __restrict__ bin, double lambda, double* __restrict__ xout) {
     double A[36], x[6];
     int tr[6];
     for (int i = 0; i < 6; i++) {
-        for (int j = 0; j < 6; j++) A[i * 6 + j] = M6[(size_t)(6 * f + i) * m + 6 * f + j];
+        for (int j = 0; j < 6; j++) A[i * 6 + j] = Min[i * 6 + j];
         A[i * 6 + i] *= (1 + lambda);
-        x[i] = -b6[6 * f + i];
+        x[i] = -bin[i];
     }
     for (int k = 0; k < 6; k++) {
         int big = k; double best = fabs(A[k * 6 + k]);
@@ -261,48 +178,199 @@ __global__ void k_reproj_solve(int N, double lambda, const double* __restrict__ 
     for (int i = 0; i < 6; i++) x[i] = (fabs(A[i * 6 + i]) > 2.2250738585072014e-308) ? x[i] / A[i * 6 + i] : 0.0;
     for (int i = 5; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < 6; j++) s -= A[j * 6 + i] * x[j]; x[i] = s; }
     for (int k = 5; k >= 0; k--) if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
-    for (int i = 0; i < 6; i++) x6[6 * f + i] = x[i];
+    for (int i = 0; i < 6; i++) xout[i] = x[i];
 }
 
-// PRE_worldToCam of every frame from the resident frame states (the expression of frame_step_block, ba_frames.h: exp(scaled state) *
-// evaluation point), as the 12 doubles (R, t) the kernels above take: frame->getCamera() of BA.cpp:2617
-__global__ __launch_bounds__(256) void k_reproj_poses_from_state(int N, const cmlhip_ba_frame_state* __restrict__ fs, double sc_t, double sc_r, double* __restrict__ poses,
-                                                                 FramePre* __restrict__ pre, double* __restrict__ zero0, int n0, double* __restrict__ zero1, int n1,
-                                                                 double* __restrict__ zero2, int n2) {
-    using cml_amd::SE3;
-    // one launch for the whole preamble of the accumulation: the sums start at zero, then per frame the pose and its FramePre
-    for (int k = threadIdx.x; k < n0; k += blockDim.x) zero0[k] = 0.0;
-    for (int k = threadIdx.x; k < n1; k += blockDim.x) zero1[k] = 0.0;
-    for (int k = threadIdx.x; k < n2; k += blockDim.x) zero2[k] = 0.0;
-    const int i = threadIdx.x;
-    if (i >= N) return;
-    const cmlhip_ba_frame_state& S = fs[i];
-    const double ss[6] = {sc_t * S.state[0], sc_t * S.state[1], sc_t * S.state[2], sc_r * S.state[3], sc_r * S.state[4], sc_r * S.state[5]};
-    SE3 ev;
-    for (int k = 0; k < 4; k++) ev.q[k] = S.eval_q[k];
-    for (int k = 0; k < 3; k++) ev.t[k] = S.eval_t[k];
-    const SE3 W = SE3::exp(ss) * ev;
-    double R[9];
-    W.matrix(R);
-    for (int k = 0; k < 9; k++) poses[12 * (size_t)i + k] = R[k];
-    for (int k = 0; k < 3; k++) poses[12 * (size_t)i + 9 + k] = W.t[k];
-    reproj_frame_pre(R, W.t, pre[i]);
+// One observation (BA.cpp:2607-2660, Residual.h:59-100): f = J_cam^T D (6), the Tukey loss value, the point Jacobian; false when the
+// observation is not used (:2630 or a non-finite derivative).
+__device__ __forceinline__ bool reproj_one(const double* __restrict__ R, const double* __restrict__ t, const FramePre& pre, const double* __restrict__ X,
+                                           double gx, double gy, double fx, double fy, double f[6], double& res_out, double Jp[3]) {
+    double T[3];
+    for (int a = 0; a < 3; a++) T[a] = (R[a * 3] * X[0] + R[a * 3 + 1] * X[1] + R[a * 3 + 2] * X[2]) + t[a];
+    const double dx = T[0] / T[2] - gx, dy = T[1] / T[2] - gy;
+    const double norm = sqrt(dx * dx + dy * dy);
+    const double th = 3.0 / sqrt(fx * fx + fy * fy);
+    const double res = d_tukey(norm, th);
+    double cam[7];
+    bool ok = true;
+    for (int a = 0; a < 3; a++) {
+        const double d[3] = {R[a], R[3 + a], R[6 + a]};                                   // Camera.h:317-321: R e_a
+        const double hx = (d[0] * T[2] - T[0] * d[2]) / (T[2] * T[2]), hy = (d[1] * T[2] - T[1] * d[2]) / (T[2] * T[2]);
+        const double dsq = 2.0 * hx * dx + 2.0 * hy * dy;
+        double v = (norm == 0) ? 0 : dsq / (2.0 * norm);
+        v = d_dtukey(res, v, th);
+        ok = ok && isfinite(v);
+        cam[a] = v; Jp[a] = -v;
+    }
+    const double* q = pre.q;
+    const double Pt[3] = {X[0] + t[0], X[1] + t[1], X[2] + t[2]};                         // Camera.h:323-325: R'(q)_a (P + t)
+    for (int a = 0; a < 4; a++) {
+        const double qa = q[0], qb = q[1], qc = q[2], qd = q[3];
+        double _2b2 = 0, _2c2 = 0, _2d2 = 0, _2bc = 0, _2ad = 0, _2bd = 0, _2ac = 0, _2cd = 0, _2ab = 0;
+        if (a == 0) { _2ad = 2 * qd; _2ac = 2 * qc; _2ab = 2 * qb; }
+        else if (a == 1) { _2b2 = 4 * qb; _2bc = 2 * qc; _2bd = 2 * qd; _2ab = 2 * qa; }
+        else if (a == 2) { _2c2 = 4 * qc; _2bc = 2 * qb; _2ac = 2 * qa; _2cd = 2 * qd; }
+        else { _2d2 = 4 * qd; _2ad = 2 * qa; _2bd = 2 * qb; _2cd = 2 * qc; }
+        const double D[9] = {-_2c2 - _2d2, _2bc - _2ad, _2bd + _2ac, _2bc + _2ad, -_2b2 - _2d2, _2cd - _2ab,
+                             _2bd - _2ac, _2cd + _2ab, -_2b2 - _2c2};
+        double d[3];
+        for (int b = 0; b < 3; b++) d[b] = D[b * 3] * Pt[0] + D[b * 3 + 1] * Pt[1] + D[b * 3 + 2] * Pt[2];
+        const double hx = (d[0] * T[2] - T[0] * d[2]) / (T[2] * T[2]), hy = (d[1] * T[2] - T[1] * d[2]) / (T[2] * T[2]);
+        const double dsq = 2.0 * hx * dx + 2.0 * hy * dy;
+        double v = (norm == 0) ? 0 : dsq / (2.0 * norm);
+        v = d_dtukey(res, v, th);
+        ok = ok && isfinite(v);
+        cam[3 + a] = v;
+    }
+    for (int c = 0; c < 6; c++) {                                                         // BA.cpp:2641
+        double s = 0;
+        for (int r = 0; r < 7; r++) s += cam[r] * pre.D[r * 6 + c];
+        f[c] = s;
+    }
+    res_out = res;
+    return ok && !(res > 4 * 4);                                                          // BA.cpp:2630
 }
 
-// addIndirectToProblem inside the device-resident iteration (BA.cpp:1327-1329, 2574-2729): poses from the resident frame states,
-// accumulation and the per-frame 6x6 solves enqueued on the context stream; the solve kernel of the iteration then replaces the
-// pose part of x by rp_x (the literal weighting of :2714-2727) before the nullspace projection.  No host round trip.
+// Frame-sorted observation list of one call: off[N+1] into obs / orig (orig[k] = the caller's index of sorted observation k).
+struct ReprojArgs {
+    int N;
+    const double* poses;                       // N x 12 (R, t) given by the caller, or null: taken from the resident frame states
+    const cmlhip_ba_frame_state* fs; double sc_t, sc_r;
+    const int* off; const cmlhip_reproj_obs* obs; const int* orig; const double* points;
+    double fx, fy, lambda;
+    double* M6; double* b6;                    // 6N x 6N block-diagonal matrix and 6N vector (host path), may be null
+    double* x6;                                // per-frame solution of the damped 6x6 system, may be null
+    double* jp_obs; unsigned char* used;       // per observation, in the caller's numbering: point Jacobian (3) and the use flag
+};
+#define RP_THREADS 256
+#define RP_LDS_DOUBLES (12 + 46 + 4 * 27 + 27)
+
+// the whole term of frame `i` by one workgroup of RP_THREADS lanes; lds: RP_LDS_DOUBLES doubles
+__device__ void reproj_frame_block(const ReprojArgs& a, int i, double* __restrict__ lds) {
+    const int tid = threadIdx.x;
+    double* sR = lds; FramePre* sPre = reinterpret_cast<FramePre*>(lds + 12); double* sW = lds + 58; double* sTot = sW + 4 * 27;
+    if (tid == 0) {
+        double R[9], t[3];
+        if (a.poses) {
+            for (int k = 0; k < 9; k++) R[k] = a.poses[12 * (size_t)i + k];
+            for (int k = 0; k < 3; k++) t[k] = a.poses[12 * (size_t)i + 9 + k];
+        } else {                               // PRE_worldToCam from the resident frame state (frame_step_block, ba_frames.h): exp(scaled state) * evaluation point
+            using cml_amd::SE3;
+            const cmlhip_ba_frame_state& S = a.fs[i];
+            const double ss[6] = {a.sc_t * S.state[0], a.sc_t * S.state[1], a.sc_t * S.state[2], a.sc_r * S.state[3], a.sc_r * S.state[4], a.sc_r * S.state[5]};
+            SE3 ev;
+            for (int k = 0; k < 4; k++) ev.q[k] = S.eval_q[k];
+            for (int k = 0; k < 3; k++) ev.t[k] = S.eval_t[k];
+            const SE3 W = SE3::exp(ss) * ev;
+            W.matrix(R);
+            for (int k = 0; k < 3; k++) t[k] = W.t[k];
+        }
+        for (int k = 0; k < 9; k++) sR[k] = R[k];
+        for (int k = 0; k < 3; k++) sR[9 + k] = t[k];
+        reproj_frame_pre(R, t, *sPre);
+    }
+    __syncthreads();
+    double acc[27];
+    for (int e = 0; e < 27; e++) acc[e] = 0.0;
+    for (int k = a.off[i] + tid; k < a.off[i + 1]; k += RP_THREADS) {          // a lane's share of the list, in list order
+        const cmlhip_reproj_obs o = a.obs[k];
+        double f[6], res, Jp[3];
+        const bool use = reproj_one(sR, sR + 9, *sPre, a.points + 3 * (size_t)o.point, o.gx, o.gy, a.fx, a.fy, f, res, Jp);
+        const int ok = a.orig[k];
+        if (a.used) a.used[ok] = use ? 1 : 0;
+        if (a.jp_obs) for (int c = 0; c < 3; c++) a.jp_obs[3 * (size_t)ok + c] = use ? Jp[c] : 0.0;
+        if (use) {
+            int idx = 0;
+            for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { acc[idx] += f[r] * f[c]; idx++; }
+            for (int r = 0; r < 6; r++) acc[21 + r] += f[r] * res;                  // BA.cpp:2655
+        }
+    }
+    for (int e = 0; e < 27; e++) {                                              // fixed-order butterfly inside the wave
+        double v = acc[e];
+        for (int s = 32; s >= 1; s >>= 1) v += __shfl_down(v, s, 64);
+        if ((tid & 63) == 0) sW[(tid >> 6) * 27 + e] = v;
+    }
+    __syncthreads();
+    if (tid < 27) sTot[tid] = ((sW[tid] + sW[27 + tid]) + sW[54 + tid]) + sW[81 + tid];
+    __syncthreads();
+    if (tid == 0) {
+        double Mf[36], bf[6];
+        int idx = 0;
+        for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { Mf[r * 6 + c] = Mf[c * 6 + r] = sTot[idx]; idx++; }
+        for (int r = 0; r < 6; r++) bf[r] = sTot[21 + r];
+        const int m = 6 * a.N;
+        if (a.M6) for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) a.M6[(size_t)(6 * i + r) * m + 6 * i + c] = Mf[r * 6 + c];
+        if (a.b6) for (int r = 0; r < 6; r++) a.b6[6 * i + r] = bf[r];
+        if (a.x6) reproj_solve6(Mf, bf, a.lambda, a.x6 + 6 * (size_t)i);
+    }
+}
+
+__global__ __launch_bounds__(RP_THREADS) void k_reproj_frames(ReprojArgs a) {
+    __shared__ double lds[RP_LDS_DOUBLES];
+    reproj_frame_block(a, blockIdx.x, lds);
+}
+
+__global__ void k_reproj_solve(int N, double lambda, const double* __restrict__ M6, const double* __restrict__ b6, double* __restrict__ x6) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= N) return;
+    const int m = 6 * N;
+    double A[36];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) A[i * 6 + j] = M6[(size_t)(6 * f + i) * m + 6 * f + j];
+    reproj_solve6(A, b6 + 6 * f, lambda, x6 + 6 * f);
+}
+
+// observations sorted by frame (stable), CSR offsets, and the caller's index of every sorted observation
+static void sort_by_frame(int N, int n, const cmlhip_reproj_obs* obs, std::vector<cmlhip_reproj_obs>& sorted, std::vector<int>& off, std::vector<int>& orig) {
+    off.assign(N + 1, 0);
+    for (int k = 0; k < n; k++) off[obs[k].frame + 1]++;
+    for (int i = 0; i < N; i++) off[i + 1] += off[i];
+    sorted.resize(n ? n : 1); orig.resize(n ? n : 1);
+    std::vector<int> cur(off.begin(), off.end() - 1);
+    for (int k = 0; k < n; k++) { const int p = cur[obs[k].frame]++; sorted[p] = obs[k]; orig[p] = k; }
+}
+
+struct ReprojBufs { DevBuf *obs, *off, *orig, *points, *jp, *used, *x; };
+static int upload_obs(cmlhip_ctx* c, const ReprojBufs& B, int N, int M, const double* points, int n, const cmlhip_reproj_obs* obs) {
+    std::vector<cmlhip_reproj_obs> sorted; std::vector<int> off, orig;
+    sort_by_frame(N, n, obs, sorted, off, orig);
+    int rc;
+#define ENS(buf, bytes) if ((rc = cml_ensure(c, *(buf), (size_t)(bytes)))) return rc
+    ENS(B.obs, sizeof(cmlhip_reproj_obs) * sorted.size()); ENS(B.off, 4 * (size_t)(N + 1)); ENS(B.orig, 4 * orig.size());
+    ENS(B.points, 8 * 3 * (size_t)(M ? M : 1)); ENS(B.jp, 8 * 3 * (size_t)(n ? n : 1)); ENS(B.used, (size_t)(n ? n : 1)); ENS(B.x, 8 * 6 * (size_t)N);
+#undef ENS
+    if (M && (rc = cml_h2d(c, B.points->p, points, 8 * 3 * (size_t)M))) return rc;
+    if ((rc = cml_h2d(c, B.obs->p, sorted.data(), sizeof(cmlhip_reproj_obs) * sorted.size()))) return rc;
+    if ((rc = cml_h2d(c, B.off->p, off.data(), 4 * off.size()))) return rc;
+    return cml_h2d(c, B.orig->p, orig.data(), 4 * orig.size());
+}
+
+// per-point sums of the point Jacobians over the used observations (BA.cpp:2657-2659), added in the caller's observation order
+static int read_point_jacobians(cmlhip_ctx* c, DevBuf& jp, int M, int n, const cmlhip_reproj_obs* obs_caller_order, const int* point_of, double* Jpoints) {
+    std::vector<double> j(3 * (size_t)(n ? n : 1));
+    int rc = n ? cml_d2h(c, j.data(), jp.p, 8 * 3 * (size_t)n) : 0;
+    if (rc) return rc;
+    for (int k = 0; k < 3 * M; k++) Jpoints[k] = 0.0;
+    for (int k = 0; k < n; k++) {
+        const int p = obs_caller_order ? obs_caller_order[k].point : point_of[k];
+        for (int cc = 0; cc < 3; cc++) Jpoints[3 * (size_t)p + cc] += j[3 * (size_t)k + cc];
+    }
+    return CMLHIP_OK;
+}
+
+static ReprojArgs resident_args(cmlhip_ctx* c, double lambda) {
+    ReprojArgs a = {};
+    a.N = c->N; a.poses = nullptr; a.fs = c->frame_state.as<cmlhip_ba_frame_state>(); a.sc_t = c->res_scales[0]; a.sc_r = c->res_scales[1];
+    a.off = c->rr_off.as<int>(); a.obs = c->rr_obs.as<cmlhip_reproj_obs>(); a.orig = c->rr_orig.as<int>(); a.points = c->rr_points.as<double>();
+    a.fx = c->rp_res_fx; a.fy = c->rp_res_fy; a.lambda = lambda; a.M6 = nullptr; a.b6 = nullptr; a.x6 = c->rr_x.as<double>();
+    a.jp_obs = c->rr_jp.as<double>(); a.used = c->rr_used.as<unsigned char>();
+    return a;
+}
+
+// addIndirectToProblem inside the device-resident iteration (BA.cpp:1327-1329, 2574-2729): ONE launch, a workgroup per frame — pose
+// from the resident frame state, the frame's observations, the fixed-order sums and the damped 6x6 solve; the solve kernel of the
+// iteration then replaces the pose part of x by rr_x (the literal weighting of :2714-2727) before the nullspace projection.
 int cml_launch_reproj_resident(cmlhip_ctx* c, double lambda) {
-    const int N = c->N, M = c->rp_res_M, n = c->rp_res_n, m = 6 * N;
-    FramePre* pre = reinterpret_cast<FramePre*>(c->rp_poses.as<double>() + 12 * (size_t)N);
-    k_reproj_poses_from_state<<<1, 256, 0, c->stream>>>(N, c->frame_state.as<cmlhip_ba_frame_state>(), c->res_scales[0], c->res_scales[1], c->rp_poses.as<double>(),
-                                                       pre, c->rp_M.as<double>(), m * m, c->rp_b.as<double>(), m, c->rp_Jp.as<double>(), 3 * (M ? M : 1));
-    if (n > 0)
-        k_reproj_obs<<<cml_div_up(n, 256), 256, 27 * N * sizeof(double), c->stream>>>(N, c->rp_poses.as<double>(), pre, c->rp_points.as<double>(), n,
-                                                                                     c->rp_obs.as<cmlhip_reproj_obs>(), c->rp_res_fx, c->rp_res_fy, c->rp_M.as<double>(),
-                                                                                     c->rp_b.as<double>(), c->rp_Jp.as<double>(),
-                                                                                     c->rp_used.as<unsigned char>());
-    k_reproj_solve<<<1, 64, 0, c->stream>>>(N, lambda, c->rp_M.as<double>(), c->rp_b.as<double>(), c->rp_x.as<double>());
+    k_reproj_frames<<<c->N, RP_THREADS, 0, c->stream>>>(resident_args(c, lambda));
     CML_CHECK(c, hipGetLastError());
     return CMLHIP_OK;
 }
@@ -315,17 +383,15 @@ int cmlhip_ba_set_resident_indirect(cmlhip_ctx* c, int M, const double* points, 
     if (M == 0) return CMLHIP_OK;                                  // BA.cpp:2587-2589: nothing to mix
     CML_REQUIRE(c, c->ba_uploaded && c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
     CML_REQUIRE(c, n <= c->lim.max_reproj_obs, CMLHIP_ERR_INVALID, "observations exceed max_reproj_obs");
-    const int N = c->N, m = 6 * N;
+    const int N = c->N;
     for (int k = 0; k < n; k++)
         CML_REQUIRE(c, obs[k].frame >= 0 && obs[k].frame < N && obs[k].point >= 0 && obs[k].point < M, CMLHIP_ERR_INVALID, "bad observation index");
-    int rc;
-#define ENS(buf, bytes) if ((rc = cml_ensure(c, buf, (size_t)(bytes)))) return rc
-    ENS(c->rp_obs, sizeof(cmlhip_reproj_obs) * (size_t)(n ? n : 1)); ENS(c->rp_poses, 8 * 12 * (size_t)N + sizeof(FramePre) * (size_t)N);
-    ENS(c->rp_points, 8 * 3 * (size_t)M); ENS(c->rp_M, 8 * (size_t)m * m); ENS(c->rp_b, 8 * (size_t)m);
-    ENS(c->rp_Jp, 8 * 3 * (size_t)M); ENS(c->rp_used, (size_t)(n ? n : 1)); ENS(c->rp_x, 8 * (size_t)m);
-#undef ENS
-    if ((rc = cml_h2d(c, c->rp_points.p, points, 8 * 3 * (size_t)M))) return rc;
-    if (n && (rc = cml_h2d(c, c->rp_obs.p, obs, sizeof(cmlhip_reproj_obs) * (size_t)n))) return rc;
+    // the resident term owns its buffers (rr_*): a host-path cmlhip_reproj_accumulate between iterations cannot disturb it
+    const ReprojBufs B{&c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x};
+    int rc = upload_obs(c, B, N, M, points, n, obs);
+    if (rc) return rc;
+    c->rr_point_of.resize(n);
+    for (int k = 0; k < n; k++) c->rr_point_of[k] = obs[k].point;
     c->rp_res_M = M; c->rp_res_n = n; c->rp_res_fx = fx; c->rp_res_fy = fy;
     c->rp_resident = true;
     return CMLHIP_OK;
@@ -337,8 +403,8 @@ int cmlhip_ba_get_resident_indirect(cmlhip_ctx* c, double* x, double* x6, double
     int rc;
     if (x && (rc = cml_d2h(c, x, c->xvec.p, 8 * (8 * (size_t)c->N + 4)))) return rc;
     if (c->rp_resident) {
-        if (x6 && (rc = cml_d2h(c, x6, c->rp_x.p, 8 * 6 * (size_t)c->N))) return rc;
-        if (Jpoints && (rc = cml_d2h(c, Jpoints, c->rp_Jp.p, 8 * 3 * (size_t)c->rp_res_M))) return rc;
+        if (x6 && (rc = cml_d2h(c, x6, c->rr_x.p, 8 * 6 * (size_t)c->N))) return rc;
+        if (Jpoints && (rc = read_point_jacobians(c, c->rr_jp, c->rp_res_M, c->rp_res_n, nullptr, c->rr_point_of.data(), Jpoints))) return rc;
     }
     return CMLHIP_OK;
 }
@@ -352,35 +418,30 @@ int cmlhip_reproj_accumulate(cmlhip_ctx* c, int N, const double* poses, int M, c
         CML_REQUIRE(c, obs[k].frame >= 0 && obs[k].frame < N && obs[k].point >= 0 && obs[k].point < M, CMLHIP_ERR_INVALID, "bad observation index");
     const int m = 6 * N;
     int rc;
-#define ENS(buf, bytes) if ((rc = cml_ensure(c, buf, (size_t)(bytes)))) return rc
-    ENS(c->rp_obs, sizeof(cmlhip_reproj_obs) * (size_t)(n ? n : 1)); ENS(c->rp_poses, 8 * 12 * (size_t)N + sizeof(FramePre) * (size_t)N);
-    ENS(c->rp_points, 8 * 3 * (size_t)(M ? M : 1)); ENS(c->rp_M, 8 * (size_t)m * m); ENS(c->rp_b, 8 * (size_t)m);
-    ENS(c->rp_Jp, 8 * 3 * (size_t)(M ? M : 1)); ENS(c->rp_used, (size_t)(n ? n : 1)); ENS(c->rp_x, 8 * (size_t)m);
-#undef ENS
+    const ReprojBufs B{&c->rp_obs, &c->rp_off, &c->rp_orig, &c->rp_points, &c->rp_Jp, &c->rp_used, &c->rp_x};
+    if ((rc = upload_obs(c, B, N, M, points, n, obs))) return rc;
+    if ((rc = cml_ensure(c, c->rp_poses, 8 * 12 * (size_t)N))) return rc;
+    if ((rc = cml_ensure(c, c->rp_M, 8 * (size_t)m * m))) return rc;
+    if ((rc = cml_ensure(c, c->rp_b, 8 * (size_t)m))) return rc;
     if ((rc = cml_h2d(c, c->rp_poses.p, poses, 8 * 12 * (size_t)N))) return rc;
-    if (M && (rc = cml_h2d(c, c->rp_points.p, points, 8 * 3 * (size_t)M))) return rc;
-    if (n && (rc = cml_h2d(c, c->rp_obs.p, obs, sizeof(cmlhip_reproj_obs) * (size_t)n))) return rc;
     CML_CHECK(c, hipMemsetAsync(c->rp_M.p, 0, 8 * (size_t)m * m, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->rp_b.p, 0, 8 * (size_t)m, c->stream));
-    CML_CHECK(c, hipMemsetAsync(c->rp_Jp.p, 0, 8 * 3 * (size_t)(M ? M : 1), c->stream));
-    FramePre* pre = reinterpret_cast<FramePre*>(c->rp_poses.as<double>() + 12 * (size_t)N);
-    k_reproj_frames<<<1, 64, 0, c->stream>>>(N, c->rp_poses.as<double>(), pre);
-    if (n > 0)
-        k_reproj_obs<<<cml_div_up(n, 256), 256, 27 * N * sizeof(double), c->stream>>>(N, c->rp_poses.as<double>(), pre, c->rp_points.as<double>(), n,
-                                                                                     c->rp_obs.as<cmlhip_reproj_obs>(), fx, fy, c->rp_M.as<double>(),
-                                                                                     c->rp_b.as<double>(), c->rp_Jp.as<double>(),
-                                                                                     c->rp_used.as<unsigned char>());
+    ReprojArgs a = {};
+    a.N = N; a.poses = c->rp_poses.as<double>(); a.off = c->rp_off.as<int>(); a.obs = c->rp_obs.as<cmlhip_reproj_obs>(); a.orig = c->rp_orig.as<int>();
+    a.points = c->rp_points.as<double>(); a.fx = fx; a.fy = fy; a.lambda = 0; a.M6 = c->rp_M.as<double>(); a.b6 = c->rp_b.as<double>(); a.x6 = nullptr;
+    a.jp_obs = c->rp_Jp.as<double>(); a.used = c->rp_used.as<unsigned char>();
+    k_reproj_frames<<<N, RP_THREADS, 0, c->stream>>>(a);
     CML_CHECK(c, hipGetLastError());
+    c->rp_acc_N = N;
     if (M6 && (rc = cml_d2h(c, M6, c->rp_M.p, 8 * (size_t)m * m))) return rc;
     if (b6 && (rc = cml_d2h(c, b6, c->rp_b.p, 8 * (size_t)m))) return rc;
-    if (Jpoints && M && (rc = cml_d2h(c, Jpoints, c->rp_Jp.p, 8 * 3 * (size_t)M))) return rc;
+    if (Jpoints && M && (rc = read_point_jacobians(c, c->rp_Jp, M, n, obs, nullptr, Jpoints))) return rc;
     if (used && n && (rc = cml_d2h(c, used, c->rp_used.p, (size_t)n))) return rc;
     return CMLHIP_OK;
 }
 
 int cmlhip_reproj_solve(cmlhip_ctx* c, int N, double lambda, double* x6) { CML_DEV(c);
     if (!c || N < 1 || N > CMLHIP_MAX_FRAMES || !x6) return CMLHIP_ERR_INVALID;
-    CML_REQUIRE(c, c->rp_M.p && c->rp_x.p, CMLHIP_ERR_STATE, "cmlhip_reproj_accumulate not called");
+    CML_REQUIRE(c, c->rp_M.p && c->rp_x.p && c->rp_acc_N == N, CMLHIP_ERR_STATE, "cmlhip_reproj_accumulate not called for this N");
     k_reproj_solve<<<1, 64, 0, c->stream>>>(N, lambda, c->rp_M.as<double>(), c->rp_b.as<double>(), c->rp_x.as<double>());
     CML_CHECK(c, hipGetLastError());
     int rc = cml_d2h(c, x6, c->rp_x.p, 8 * 6 * (size_t)N);

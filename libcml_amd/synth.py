@@ -35,11 +35,11 @@ def so3_exp(w):
 class Texture:
     """Continuous procedural texture tex(a, b) on plane coordinates (metres)."""
 
-    def __init__(self, rng, scale=1.0, edge_width=0.0):
+    def __init__(self, rng, scale=1.0, edge_width=0.0, octave_gain=0.5):
         self.edge_width = edge_width      # metres on the plane over which a step edge ramps (0 = a hard step)
         self.lat = [rng.uniform(0, 1, size=(64, 64)) for _ in range(6)]
         self.freq = [scale * 2 ** o for o in range(6)]
-        self.amp = [0.5 ** o for o in range(6)]
+        self.amp = [octave_gain ** o for o in range(6)]      # 0.5: smooth value noise; larger: more of the amplitude in the fine octaves (stronger gradients)
         ang = rng.uniform(0, np.pi, size=40)
         self.en = np.stack([np.cos(ang), np.sin(ang)], 1)
         self.eo = rng.uniform(-12, 12, size=40)
@@ -91,16 +91,18 @@ class Window:
 # Scene defaults per named configuration.  The BASELINE windows (B, E) model the window a keyframe's run() iterates on: points that
 # are still visible in the newest keyframe, inverse depths as accurate as the activation leaves them, and band-limited texture edges —
 # so that >= 90 % of the R = P (N-1) residuals are IN after the first pass (the headline must not be billed for
-# residuals that gather nothing).  The small test windows keep hard edges and every candidate point, OOB residuals included.
-SCENE_DEFAULTS = {"pose_noise": 1.0, "idepth_noise": 0.03, "state_noise": 2e-3, "eval_noise": 1.0, "edge_px": 0.0, "covisible": False}
+# residuals that gather nothing).  octave_gain 0.7 puts enough of the value noise into the fine octaves that a point's pattern keeps
+# gradient when a later keyframe sees it magnified (with 0.5 one residual in ten was an OUTLIER by `wJI2_sum < 2`, BA.cpp:303, at
+# the TRUE state).  The small test windows keep hard edges, smooth noise and every candidate point, OOB residuals included.
+SCENE_DEFAULTS = {"pose_noise": 1.0, "idepth_noise": 0.03, "state_noise": 2e-3, "eval_noise": 1.0, "edge_px": 0.0, "covisible": False, "octave_gain": 0.5}
 SCENES = {
-    "B": {"idepth_noise": 0.005, "eval_noise": 0.3, "edge_px": 4.0, "covisible": True},
-    "E": {"idepth_noise": 0.005, "eval_noise": 0.3, "edge_px": 4.0, "covisible": True},
+    "B": {"idepth_noise": 0.005, "eval_noise": 0.3, "edge_px": 4.0, "covisible": True, "octave_gain": 0.7},
+    "E": {"idepth_noise": 0.005, "eval_noise": 0.3, "edge_px": 4.0, "covisible": True, "octave_gain": 0.7},
 }
 
 
 def make_window(config="B", seed=0xC0FFEE, shard=0, pose_noise=None, idepth_noise=None, state_noise=None,
-                eval_noise=None, edge_px=None, covisible=None):
+                eval_noise=None, edge_px=None, covisible=None, octave_gain=None):
     """covisible: keep a candidate point only if it projects inside the NEWEST keyframe (for points hosted there: inside at least one
     other keyframe) — the window the reference's policy leaves behind: points that left the newest frames are marginalised or dropped
     (isOOB / flagPointsForRemoval, BA.cpp:2240-2363), and the closing linearizeAll(true) of every run removes each residual that is
@@ -113,6 +115,7 @@ def make_window(config="B", seed=0xC0FFEE, shard=0, pose_noise=None, idepth_nois
     eval_noise = scene["eval_noise"] if eval_noise is None else eval_noise
     edge_px = scene["edge_px"] if edge_px is None else edge_px
     covisible = scene["covisible"] if covisible is None else covisible
+    octave_gain = scene["octave_gain"] if octave_gain is None else octave_gain
     rng = np.random.default_rng(seed + shard)
     W = Window()
     W.config = config; W.N, W.P, W.w, W.h, W.levels = N, P, w, h, levels
@@ -120,7 +123,7 @@ def make_window(config="B", seed=0xC0FFEE, shard=0, pose_noise=None, idepth_nois
     n = np.array([0.12, -0.08, 1.0]); n /= np.linalg.norm(n)
     d = 9.0
     # highest octave (x32) at ~0.07 cycles/pixel at the plane distance, so the renderings are not aliased
-    tex = Texture(rng, scale=0.07 * fx / (d * 32.0), edge_width=edge_px * d / fx)
+    tex = Texture(rng, scale=0.07 * fx / (d * 32.0), edge_width=edge_px * d / fx, octave_gain=octave_gain)
     # true keyframe poses (world -> cam): forward motion 0.8 m / KF + jitter, SURVEY §8d
     W.R_true, W.t_true, W.aff_true, W.gray, W.depth = [], [], [], [], []
     step = 0.8 if N <= 8 else 0.3

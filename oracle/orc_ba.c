@@ -7,6 +7,9 @@
  * Build with -ffp-contract=off so the statement order below is the arithmetic order.
  */
 #include "cml_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -554,6 +557,25 @@ static void schur_points(orc_ba_window* w, const cmlhip_ba_accum_in* in, const u
     for (int i = 0; i < NN * N; i++) tier_init(&accD[i], 64);
     for (int i = 0; i < NN; i++) { tier_init(&accE[i], 32); tier_init(&accEB[i], 8); }
     tier_init(&accHcc, 16); tier_init(&accbc, 4);
+#ifdef _OPENMP
+    /* TIMING BUILD ONLY (see orc_ba_accumulate): one accumulator set per thread over a static split of the points, reduced below */
+    tier_acc* const accD0 = accD; tier_acc* const accE0 = accE; tier_acc* const accEB0 = accEB;
+    tier_acc* const accHcc0 = &accHcc; tier_acc* const accbc0 = &accbc;
+    const int T_ = omp_get_max_threads();
+    const size_t per = (size_t)NN * N + 2 * (size_t)NN + 2;
+    tier_acc* pool = (tier_acc*)zalloc(sizeof(tier_acc) * per * (size_t)T_);
+#pragma omp parallel
+    {
+    tier_acc* base = pool + per * (size_t)omp_get_thread_num();
+    tier_acc* accD = base; tier_acc* accE = base + (size_t)NN * N; tier_acc* accEB = accE + NN;
+    tier_acc* accHccP = accEB + NN; tier_acc* accbcP = accHccP + 1;
+    for (int i = 0; i < NN * N; i++) tier_init(&accD[i], 64);
+    for (int i = 0; i < NN; i++) { tier_init(&accE[i], 32); tier_init(&accEB[i], 8); }
+    tier_init(accHccP, 16); tier_init(accbcP, 4);
+#define accHcc (*accHccP)
+#define accbc (*accbcP)
+#pragma omp for schedule(static)
+#endif
     for (int p = 0; p < w->P; p++) {
         if (sel && !sel[p]) continue;
         const cmlhip_ba_point* pt = &w->points[p];
@@ -583,9 +605,41 @@ static void schur_points(orc_ba_window* w, const cmlhip_ba_accum_in* in, const u
             tier_update_vec(&accEB[r1ht], w->JpJdF + 8 * r1, 8, w->HdiF[p] * w->bdSumF[p]);
         }
     }
+#ifdef _OPENMP
+#undef accHcc
+#undef accbc
+    }   /* omp parallel */
+    for (int t = 0; t < T_; t++) {          /* reduce the per-thread sets into the first-level slots of the shared ones (finish() folds them) */
+        tier_acc* base = pool + per * (size_t)t;
+        for (size_t i = 0; i < per; i++) {
+            tier_acc* src = &base[i];
+            tier_acc* dst = i < (size_t)NN * N ? &accD0[i] : i < (size_t)NN * N + NN ? &accE0[i - (size_t)NN * N]
+                          : i < (size_t)NN * N + 2 * (size_t)NN ? &accEB0[i - (size_t)NN * N - NN] : i == per - 2 ? accHcc0 : accbc0;
+            const float cnt = src->numIn1 + src->numIn1k + src->numIn1m;
+            if (cnt == 0) continue;
+            tier_shift(src, 1);
+            for (int k = 0; k < src->n; k++) dst->A1m[k] += src->A1m[k];
+            dst->numIn1m += cnt;
+        }
+    }
+    free(pool);
+#endif
     /* stitchDoubleSC, BA.cpp:1939-2043 */
     memset(tH, 0, sizeof(double) * n * n); memset(tb, 0, sizeof(double) * n);
+#ifdef _OPENMP
+    /* TIMING BUILD ONLY: the N^2 (i, j) blocks of the stitch over the threads, each into its own copy of H / b, summed afterwards */
+    double* const tH_shared = tH; double* const tb_shared = tb;
+    const int T2_ = omp_get_max_threads();
+    double* tHpool = (double*)zalloc(sizeof(double) * ((size_t)n * n + n) * (size_t)T2_);
+#pragma omp parallel
+    {
+    double* tH = tHpool + ((size_t)n * n + n) * (size_t)omp_get_thread_num();
+    double* tb = tH + (size_t)n * n;
+#endif
 #define TH(i, j) tH[(size_t)(i) * n + (j)]
+#ifdef _OPENMP
+#pragma omp for collapse(2) schedule(static)
+#endif
     for (int i = 0; i < N; i++)
         for (int j = 0; j < N; j++) {
             int iIdx = 4 + i * 8, jIdx = 4 + j * 8, ij = i + N * j;
@@ -617,6 +671,15 @@ static void schur_points(orc_ba_window* w, const cmlhip_ba_accum_in* in, const u
                 for (int a = 0; a < 8; a++) for (int b = 0; b < 8; b++) TH(iIdx + a, kIdx + b) += blk[a * 8 + b];
             }
         }
+#ifdef _OPENMP
+    }   /* omp parallel */
+    for (int t = 0; t < T2_; t++) {
+        const double* src = tHpool + ((size_t)n * n + n) * (size_t)t;
+        for (size_t k = 0; k < (size_t)n * n; k++) tH_shared[k] += src[k];
+        for (int k = 0; k < n; k++) tb_shared[k] += src[(size_t)n * n + k];
+    }
+    free(tHpool);
+#endif
     tier_finish(&accHcc); tier_finish(&accbc);
     for (int a = 0; a < 4; a++) { for (int b = 0; b < 4; b++) TH(a, b) = (double)accHcc.A1m[a * 4 + b]; tb[a] = (double)accbc.A1m[a]; }
     for (int h = 0; h < N; h++)
@@ -632,8 +695,36 @@ void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* H
     approx_acc* acc = (approx_acc*)zalloc(sizeof(approx_acc) * NN);
     double* tH = (double*)zalloc(sizeof(double) * n * n); double* tb = (double*)zalloc(sizeof(double) * n);
     /* ACTIVE, BA.cpp:1368-1371 */
+#ifdef _OPENMP
+    /* TIMING BUILD ONLY (make fast_omp: bench.py's all-cores CPU baseline; the checker build is serial and literal).  The reference
+       loop is serial; here the points are spread over the cores with one accumulator set per thread, summed afterwards — the order of
+       the fp32 sums differs from the serial pass, which is why no parity test loads this build. */
+    {
+        const int T = omp_get_max_threads();
+        approx_acc* accT = (approx_acc*)zalloc(sizeof(approx_acc) * NN * (size_t)T);
+#pragma omp parallel
+        {
+            approx_acc* mine = accT + (size_t)omp_get_thread_num() * NN;
+#pragma omp for schedule(static)
+            for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_ACTIVE, mine, in);
+        }
+        for (int q = 0; q < NN; q++) {
+            float Hq[169];
+            memset(w->accA + 169 * q, 0, sizeof(float) * 169); w->accA_num[q] = 0;
+            for (int t = 0; t < T; t++) {
+                approx_acc* a = &accT[(size_t)t * NN + q];
+                if (a->num == 0) continue;
+                approx_finish(a, Hq);
+                for (int i = 0; i < 169; i++) w->accA[169 * q + i] += Hq[i];
+                w->accA_num[q] += a->num;
+            }
+        }
+        free(accT);
+    }
+#else
     for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_ACTIVE, acc, in);
     for (int q = 0; q < NN; q++) { approx_finish(&acc[q], w->accA + 169 * q); w->accA_num[q] = acc[q].num; }
+#endif
     stitch_top(w, w->accA, w->accA_num, in, 0, tH, tb);
     if (HA) memcpy(HA, tH, sizeof(double) * n * n);
     if (bA) memcpy(bA, tb, sizeof(double) * n);
@@ -697,6 +788,9 @@ int orc_ba_backsub(orc_ba_window* w, const cmlhip_ba_accum_in* in, const double*
             }
         }
     int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+#endif
     for (int p = 0; p < w->P; p++) {
         int ngood = 0;
         for (int k = w->by_point_off[p]; k < w->by_point_off[p + 1]; k++) if (w->r_good[w->by_point[k]]) ngood++;

@@ -141,13 +141,22 @@ def test_apply_and_accumulate(pair):
     # nullspace of global pose + scale).  The raw x differs in the weakly determined gauge directions (b); what the frames are
     # actually stepped by is compared here, device against oracle, relative to the largest component of the update:
     gf = gauge_free_pose_update_error(I, xd, xo)
-    # Measured (profiles/round2_parity_soak.txt, tools/probe_pose_update.py): 1.6e-4 ... 5.7e-4 at config B over six seeds, up to
-    # 9.8e-3 on 300-point windows over 60 seeds, with the accumulated matrices themselves agreeing to 1.0e-7 ... 1.9e-7 (fp32 sums in
-    # another order).  The amplification of ~3e3 is the window's: the update solves H_A - H_sc, a difference in which the Schur
-    # complement cancels H_A 5- to 10-fold, scaled by 1/sqrt(diag + 10) and damped by lambda = 1e-5 only.  A bar of 1e-4 would need
-    # the matrices to agree to ~3e-8, below one fp32 rounding of a single accumulation; the stated bars are 1e-3 at config B and
-    # 2e-2 for windows of a few hundred points.
-    assert gf < (1e-3 if I.P >= 2000 else 2e-2), gf
+    # The size of gf is the window's conditioning times the fp32 accumulation noise of the matrices (measured 1.6e-4 ... 1.4e-3 at config B
+    # over seeds and scene variants, up to 9.8e-3 on 300-point windows: profiles/round2_parity_soak.txt), so a fixed bar on it says little
+    # (ADVICE round 2).  The tight, conditioning-independent statement is in two parts: the accumulated matrices agree (bars above,
+    # measured ~1e-7), and on the DEVICE's matrices the device's assemble / factorise / substitute path gives the pose update an
+    # independent fp64 solve gives (numpy, LU with partial pivoting) — compared with the gauge removed, relative to the update:
+    Hd = HLd + HAd
+    Hd[np.diag_indices(n)] *= (1 + lam)
+    Hd = Hd - Hsd / (1 + lam)
+    bd_ = bLd + bAd - bsd
+    Svd = 1.0 / np.sqrt(np.diag(Hd) + 10.0)
+    xn = np.zeros(n)
+    xn[4:] = Svd[4:] * np.linalg.solve(Svd[4:, None] * Hd[4:, 4:] * Svd[None, 4:], Svd[4:] * bd_[4:])
+    gf_solver = gauge_free_pose_update_error(I, xd, xn)
+    print("gauge-free pose update: device vs oracle %.3g; device solve vs numpy solve on the device's matrices %.3g" % (gf, gf_solver))
+    assert gf_solver < 1e-9, (gf_solver, gf)                                    # measured 1e-13 ... 1e-12
+    assert gf < 2e-2, gf                                                          # sanity only
     # same x into both back-substitutions isolates that kernel
     sto, _ = ob.backsub(xo)
     std, rc = ctx.ba_backsub(xo)
