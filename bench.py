@@ -152,6 +152,93 @@ def cpu_baseline(config, seed):
     return out
 
 
+TRACKER_READ_BYTES_PER_POINT = 64      # 4 taps x 12 B + 16 B (u, v, idepth, colour)
+
+
+def tracker_bench(device_id, seed, want_cpu):
+    """The tracker half of north_star on the config-B shape (1241x376, 5 pyramid levels, the 2000 active points of the window splatted
+    into the reference keyframe by makeCoarseDepthL0): k_tracker_eval per level (kernel duration from events attached to the dispatch,
+    achieved GB/s on 64 B per reference point against the HBM roof), DSOTracker::optimize for one motion hypothesis (host-driven loop and
+    device-resident) and for 50 (one launch), and the oracle's orc_tracker_optimize on the host cores beside it."""
+    import statistics
+    import numpy as np
+    from libcml_amd import abi, device, host, synth
+    W = synth.make_window("B", seed=seed)
+    fx, fy, cx, cy = W.K
+    ref, new, L = W.N - 2, W.N - 1, 5
+    ctx = device.Ctx(device_id=device_id, max_frames=8)
+    ctx.pyramid_build(1, W.gray[ref], L); ctx.pyramid_build(2, W.gray[new], L)
+    pts = []
+    for i in range(W.P):                                   # host part of makeCoarseDepthL0 (TR.cpp:521-540): the active points seen from the reference
+        h = int(W.pts["host"][i]); x, y, idp = float(W.pts["x"][i]), float(W.pts["y"][i]), float(W.pts["idepth"][i])
+        Rht = W.R_eval[ref] @ W.R_eval[h].T; tht = W.t_eval[ref] - Rht @ W.t_eval[h]
+        q = Rht @ np.array([(x - cx) / fx, (y - cy) / fy, 1.0]) + tht * idp
+        pts.append(((q[0] / q[2]) * fx + cx, (q[1] / q[2]) * fy + cy, idp / q[2], 1.0))
+    nout = ctx.tracker_make_coarse_depth(1, L, np.array(pts))
+    Rt = W.R_true[new] @ W.R_true[ref].T; tt = W.t_true[new] - Rt @ W.t_true[ref]
+    prm = abi.default_tracker_params()
+    a_r, b_r = W.aff_true[ref]
+    ref_exp = [a_r, b_r, float(W.ab_exposure[ref])]; init_exp = [a_r, b_r, float(W.ab_exposure[new])]
+    levels = []
+    for lvl in range(L):
+        d = float(1 << lvl)
+        K = np.array([fx / d, fy / d, (cx + 0.5) / d - 0.5, (cy + 0.5) / d - 0.5])
+        us = []
+        for k in range(25):
+            if k >= 5:
+                ctx.profile_next_launch()
+            r, _ = ctx.tracker_eval(2, lvl, Rt, tt, K, np.array([1.0, 0.0]), 0.0, prm, 1)
+            if k >= 5:
+                us.append(1e3 * ctx.elapsed_ms())
+        t = statistics.median(us)
+        gbs = nout[lvl] * TRACKER_READ_BYTES_PER_POINT / (t * 1e-6) / 1e9
+        levels.append({"level": lvl, "points": int(nout[lvl]), "warped": int(r.numWarped), "kernel_us": t, "kernel_us_minmax": [min(us), max(us)],
+                       "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+    out = {"shape": "config B: %dx%d, %d levels, %d active points -> reference lists %s" % (W.w, W.h, L, W.P, [int(x) for x in nout[:L]]),
+           "bytes_per_point": TRACKER_READ_BYTES_PER_POINT, "eval": levels,
+           "eval_note": "k_tracker_eval = computeResidual + computeHessian of one level in one launch; kernel_us = median of 20 of the dispatch's own duration "
+                        "(events attached to the dispatch)"}
+    so3 = synth.so3_exp
+
+    def hyp(i):
+        return so3(np.array([0.004 + 0.0002 * i, -0.003, 0.002])) @ Rt, tt + np.array([0.03, -0.02 + 0.001 * i, 0.025])
+
+    trk = host.HostTracker(ctx); trk.set_calibration(*W.K)
+    R0, t0 = hyp(0)
+    ts = []
+    for k in range(23):
+        t_ = time.perf_counter(); trk.optimize(2, L, R0, t0, ref_exp, init_exp); ts.append(time.perf_counter() - t_)
+    out["optimize_host_driven_ms"] = 1e3 * statistics.median(ts[3:])
+    out["optimize_trials"] = int(len(trk.steps()[0]))
+    for nh in (1, 50):
+        hyps = [hyp(i) for i in range(nh)]
+        ts, ks = [], []
+        for k in range(23):
+            ctx.profile_next_launch()
+            t_ = time.perf_counter(); res = ctx.tracker_optimize_batch(2, L, W.K, ref_exp, init_exp, prm, hyps); ts.append(time.perf_counter() - t_)
+            ks.append(ctx.elapsed_ms())
+        out["optimize_device_resident_%d_hyp" % nh] = {"call_ms": 1e3 * statistics.median(ts[3:]), "kernel_ms": statistics.median(ks[3:]),
+                                                      "trials_first": int(res[0].n_steps), "in_kernel_eval_us": float(res[0].eval_us),
+                                                      "in_kernel_algebra_us": float(res[0].algebra_us)}
+    if want_cpu:
+        try:
+            from tests import trk_opt_setup as TS
+            P = TS.Problem()
+            P.W, P.levels, P.prm, P.ref_exp, P.init_exp = W, L, prm, ref_exp, init_exp
+            P.uvic = [np.ascontiguousarray(ctx.tracker_get_reference(l), np.float32) for l in range(L)]      # the device's lists and images are the oracle's input here
+            P.imgs = [np.ascontiguousarray(ctx.pyramid_get(2, l), np.float32) for l in range(L)]
+            P.Rt, P.tt = Rt, tt
+            ts = []
+            for k in range(23):
+                t_ = time.perf_counter(); o = TS.oracle_optimize(P, R0, t0); ts.append(time.perf_counter() - t_)
+            out["cpu_baseline"] = {"optimize_ms": 1e3 * statistics.median(ts[3:]), "optimize_ms_minmax": [1e3 * min(ts[3:]), 1e3 * max(ts[3:])], "cores": 1, "kind": "port",
+                                   "trials": int(o["out"].n_steps), "sample": "median of 20 orc_tracker_optimize calls (oracle C port, checker build -O2, one thread) on the same problem"}
+        except Exception as e:
+            out["cpu_baseline"] = {"optimize_ms": None, "sample": "failed: %r" % (e,)}
+    trk.close(); ctx.close()
+    return out
+
+
 def _dbg(*a):
     if os.environ.get("CML_BENCH_DEBUG"):
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -338,6 +425,11 @@ def main():
         out.update(parity)
         if parity.get("parity_checked") and not parity.get("parity_ok"):
             out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
+        if not args.no_extras and world == 1 and not hybrid and args.config == "B":
+            try:
+                out["tracker"] = tracker_bench(local_rank, seed, not args.no_cpu_baseline)
+            except Exception as e:
+                out["tracker"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wcfg, seed)          # (config C: the photometric window of config B; the ORB term is not part of the CPU port's timing)

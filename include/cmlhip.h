@@ -534,6 +534,10 @@ int cmlhip_ba_get_resident_state(cmlhip_ctx* ctx, cmlhip_ba_frame_state* frames,
  * HIP events on the context stream; ms between the two most recent marks. */
 int cmlhip_event_mark(cmlhip_ctx* ctx, int which /* 0 = start, 1 = stop */);
 int cmlhip_event_elapsed_ms(cmlhip_ctx* ctx, float* ms);
+/* attach the two events to the NEXT instrumented dispatch itself (tracker evaluation, tracker optimisation batch, the kernels of the
+ * resident iteration) instead of recording them around it: cmlhip_event_elapsed_ms then returns that kernel's own duration
+ * (begin / end timestamps of the dispatch — the quantity rocprofv3 --kernel-trace reports), without launch overhead */
+int cmlhip_profile_next_launch(cmlhip_ctx* ctx);
 /* enqueue-only variants for throughput measurement: no host readback, no sync */
 int cmlhip_ba_linearize_async(cmlhip_ctx* ctx);
 /* one resident iteration (see above); without cmlhip_ba_set_resident_state only the points are stepped */

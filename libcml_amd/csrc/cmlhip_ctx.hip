@@ -239,6 +239,11 @@ int cmlhip_event_mark(cmlhip_ctx* c, int which) { CML_DEV(c);
     CML_CHECK(c, hipEventRecord(c->ev[which], c->stream));
     return CMLHIP_OK;
 }
+int cmlhip_profile_next_launch(cmlhip_ctx* c) { CML_DEV(c);
+    if (!c) return CMLHIP_ERR_INVALID;
+    c->ext_start = c->ev[0]; c->ext_stop = c->ev[1];          // consumed by the next instrumented dispatch (CML_LAUNCH_EV)
+    return CMLHIP_OK;
+}
 int cmlhip_event_elapsed_ms(cmlhip_ctx* c, float* ms) { CML_DEV(c);
     if (!c || !ms) return CMLHIP_ERR_INVALID;
     CML_CHECK(c, hipEventSynchronize(c->ev[1]));

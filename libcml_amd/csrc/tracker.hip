@@ -403,8 +403,8 @@ int cmlhip_tracker_eval(cmlhip_ctx* c, uint64_t image_id, int level, const doubl
         A.seq = ++c->trk_seq;
         if (A.seq == 0) A.seq = ++c->trk_seq;
     }
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_tracker_eval<true><<<blocks, 256, 0, c->stream>>>(A);
-    else k_tracker_eval<false><<<blocks, 256, 0, c->stream>>>(A);
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_tracker_eval<true>, blocks, 256, 0, A);
+    else CML_LAUNCH_EV(c, k_tracker_eval<false>, blocks, 256, 0, A);
     CML_CHECK(c, hipGetLastError());
     // the workgroup rows are added here, in block order, fp64 (what the last-block pass of a fused finish would do)
     std::vector<float> part((size_t)blocks * TRK_NRED);

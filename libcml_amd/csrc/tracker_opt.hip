@@ -549,8 +549,8 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp))) return rc;
     if ((rc = cml_h2d(c, c->trk_hyp.p, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
     A.hyp = c->trk_hyp.as<cmlhip_tracker_hypothesis>(); A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_tracker_optimize<true><<<n_hyp, TO_THREADS, 0, c->stream>>>(A);
-    else k_tracker_optimize<false><<<n_hyp, TO_THREADS, 0, c->stream>>>(A);
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp, TO_THREADS, 0, A);
+    else CML_LAUNCH_EV(c, k_tracker_optimize<false>, n_hyp, TO_THREADS, 0, A);
     CML_CHECK(c, hipGetLastError());
     return cml_d2h(c, out, c->trk_opt_out.p, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
 }

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "cmlhip_reproj_solve": (C.c_int, [_ctx, _i, _d, _P(_d)]),
     "cmlhip_event_mark": (C.c_int, [_ctx, _i]),
     "cmlhip_event_elapsed_ms": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_profile_next_launch": (C.c_int, [_ctx]),
     "cmlhip_ba_get_pairs": (C.c_int, [_ctx, C.c_void_p, _P(_f), _P(_f)]),
     "cmlhip_ba_linearize_async": (C.c_int, [_ctx]),
     "cmlhip_ba_iteration_async": (C.c_int, [_ctx, _d]),
@@ -489,6 +490,9 @@ class Ctx:
 
     def mark(self, which):
         self.ck(self.L.cmlhip_event_mark(self.h, which))
+
+    def profile_next_launch(self):
+        self.ck(self.L.cmlhip_profile_next_launch(self.h))
 
     def elapsed_ms(self):
         ms = _f()

@@ -12,10 +12,16 @@ pytestmark = pytest.mark.gpu
 
 # "tiny" (64 points, 3 keyframes) is not used here: its Gauss-Newton iteration is unstable (energy grows), so fp32-level
 # differences are amplified chaotically and a forward comparison of the final state is meaningless there.
-@pytest.mark.parametrize("config", ["small", "medium"])
+@pytest.mark.parametrize("config", ["small", "medium", "B", "E"])      # B, E: BASELINE.json configs[1] and configs[4] at FULL size
 def test_host_algebra_and_run(config):
     I = S.make_inputs(config)
-    ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R)
+    half = config == "E"
+    if half:                                                            # config E stores fp16 texels: the oracle gets the same rounded images
+        for k in range(I.N):
+            for lvl in range(len(I.grads[k])):
+                I.grads[k][lvl] = I.grads[k][lvl].astype(np.float16).astype(np.float32)
+    from libcml_amd import abi
+    ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R, texel_format=abi.TEXEL_F16 if half else abi.TEXEL_F32)
     ba = host.window_to_host_ba(ctx, I.W)
     c = ba.counts()
     assert (c["frames"], c["points"], c["residuals"]) == (I.N, I.P, I.R)
@@ -29,9 +35,11 @@ def test_host_algebra_and_run(config):
     assert np.abs(A["pairs"]["aff_a"] - I.pairs["aff_a"]).max() < 1e-14
     assert np.array_equal(A["prior"], I.prior)
     # full run
-    ok = ba.run()
+    ok = ba.run()                       # 4 iterations; on these parameters run() keeps the loop resident on the device (runResident)
     assert ok, ba.last_error()
     ref = ba_ref_run.oracle_run(I)
+    print("run() vs oracle_run at %s: R=%d flips=%d energies dev %s ref %s" % (config, I.R, int((ba.residual_states()[2].astype(bool) != ref["good"]).sum()),
+          np.array2string(np.asarray(ba.energies()), precision=6), np.array2string(np.array(ref["log"]["energy"]), precision=6)))
     # residual bookkeeping (set membership) must be exact away from thresholds: allow a handful of flips
     st, alive, good = ba.residual_states()
     flips = int((good.astype(bool) != ref["good"]).sum())
@@ -56,7 +64,7 @@ def test_host_algebra_and_run(config):
     k = min(len(e_dev) - 1, len(e_ref) - 2)
     assert k >= 1
     assert np.abs(e_dev[1:1 + k] / e_ref[1:1 + k] - 1).max() < 5e-3, (e_dev, e_ref)
-    assert abs(e_dev[0] * I.R / e_ref[0] - 1) < 1e-9          # first entry is energy / #residuals (BA.cpp:798)
+    assert abs(e_dev[0] * I.R / e_ref[0] - 1) < (1e-5 if half else 1e-9)          # first entry is energy / #residuals (BA.cpp:798)
     ba.close(); ctx.close()
 
 
