@@ -152,6 +152,62 @@ def cpu_baseline(config, seed):
     return out
 
 
+def multi_window_bench(device_id, seed, config, steps, half, s_list=(2, 4, 8)):
+    """Throughput mode on ONE GPU (north_star: independent keyframe windows / sequence shards): S independent windows of the benchmark
+    shape stepped by cmlhip_ba_iteration_batch — one launch per kernel family for all S windows, five launches per round whatever S is.
+    value = point-residuals of all S windows per second; parity: after the timed rounds one more batched round whose residual pass is
+    replayed on the oracle for the first and the last window (bit for bit, tests/resident_check.py).  The headline stays 1 window / GPU."""
+    from libcml_amd import abi, device, host, synth
+    smax = max(s_list)
+    wins = []
+    for k in range(smax):
+        W = synth.make_window(config, seed=seed, shard=100 + k)
+        ctx = device.Ctx(device_id=device_id, max_frames=max(W.N, 2), max_points=W.P, max_residuals=W.P * W.N,
+                         texel_format=abi.TEXEL_F16 if half else abi.TEXEL_F32)
+        ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (k + 1), levels=1)
+        ba.set_param("iterations", 1)
+        if not ba.run() or not ba.begin_resident():
+            raise RuntimeError("multi-window set-up failed: " + ba.last_error())
+        _, _, R = ctx.refresh_window_size()
+        wins.append((W, ctx, ba, R))
+    lam = 1e-5
+    out = {"note": "S windows of the benchmark shape per GPU, one cmlhip_ba_iteration_batch per round (5 launches for all S windows)", "runs": []}
+    for S in s_list:
+        ctxs = [w[1] for w in wins[:S]]
+        for _ in range(60):
+            device.ba_iteration_batch(ctxs, lam)
+        ctxs[0].sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            device.ba_iteration_batch(ctxs, lam)
+        ctxs[0].sync()
+        dt = time.perf_counter() - t0
+        Rs = sum(w[3] for w in wins[:S])
+        out["runs"].append({"S": S, "value": Rs * steps / dt, "unit": "point-residuals/s", "ms_per_round": 1e3 * dt / steps, "residuals_per_round": Rs, "rounds": steps})
+    try:
+        from tests import resident_check as RC
+        ctxs = [w[1] for w in wins]
+        pick = [0, smax - 1]
+        replays = {k: RC.make_replay(wins[k][1], wins[k][2], wins[k][0]) for k in pick}
+        ctxs[0].sync()
+        pres = {k: wins[k][1].ba_states() for k in pick}
+        device.ba_iteration_batch(ctxs, lam)
+        ctxs[0].sync()
+        reps = {k: RC.compare_pass(wins[k][1], replays[k], pres[k], with_records=False) for k in pick}
+        for r in replays.values():
+            r.close()
+        out["parity_checked"] = True
+        out["parity_ok"] = all(r["ok"] for r in reps.values())
+        out["parity"] = {"windows": pick, "S": smax, "mismatches": {str(k): {a: b for a, b in r.items() if a.endswith("_mismatch")} for k, r in reps.items()}}
+    except Exception as e:
+        out["parity_checked"] = False; out["parity_error"] = repr(e)
+    best = max(out["runs"], key=lambda r: r["value"])
+    out["S"], out["value"], out["ms_per_round"] = best["S"], best["value"], best["ms_per_round"]
+    for W, ctx, ba, R in wins:
+        ba.close(); ctx.close()
+    return out
+
+
 TRACKER_READ_BYTES_PER_POINT = 64      # SURVEY §8(d): 4 taps x 12 B + 16 B (u, v, idepth, colour)
 
 
@@ -426,6 +482,10 @@ def main():
         if parity.get("parity_checked") and not parity.get("parity_ok"):
             out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
         if not args.no_extras and world == 1 and not hybrid and args.config == "B":
+            try:
+                out["multi_window"] = multi_window_bench(local_rank, seed, wcfg, max(args.steps, 50), half)
+            except Exception as e:
+                out["multi_window"] = {"error": repr(e)}
             try:
                 out["tracker"] = tracker_bench(local_rank, seed, not args.no_cpu_baseline)
             except Exception as e:

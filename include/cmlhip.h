@@ -542,6 +542,14 @@ int cmlhip_profile_next_launch(cmlhip_ctx* ctx);
 int cmlhip_ba_linearize_async(cmlhip_ctx* ctx);
 /* one resident iteration (see above); without cmlhip_ba_set_resident_state only the points are stepped */
 int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);
+/* Several windows per launch (throughput mode: more sequence shards than GPUs, north_star "independent keyframe windows / sequence
+ * shards"): ONE resident iteration of each of the S windows held by ctxs[0..S), in the five launches one window takes (gridDim.y =
+ * window, S solve workgroups side by side) on the stream of ctxs[0].  Every window must be uploaded, have its resident state set
+ * (cmlhip_ba_set_resident_state) and be a small window (R < 36 k: the 4-lane residual kernel; no hybrid term, no LINEARIZED
+ * residuals, no convergence control) — anything else is refused with CMLHIP_ERR_INVALID / _STATE, never routed elsewhere.  A window's
+ * result is bit-identical to the one cmlhip_ba_iteration_async gives it (same kernel bodies, same arguments).  Synchronise through
+ * cmlhip_synchronize(ctxs[0]) before reading any of the windows back or using their contexts on their own again. */
+int cmlhip_ba_iteration_batch(cmlhip_ctx* const* ctxs, int n_windows, double lambda);
 /* Per-kernel HIP-event timing of the iteration pipeline: when enabled, cmlhip_ba_iteration_async attaches HIP events to the
  * DISPATCHES themselves (hipExtLaunchKernelGGL start / stop events, i.e. the begin / end timestamps of the kernel, the same
  * quantity rocprofv3 --kernel-trace reports): (a) begin and end of the residual/Jacobian kernel, (b) begin of the

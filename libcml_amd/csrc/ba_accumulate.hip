@@ -377,22 +377,24 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
 }
 
 // mode: ACTIVE = pair blocks + point rows; LINEARIZED / MARGINALIZED = pair blocks only (rare paths, own point kernels)
-__global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) {
+__device__ __forceinline__ void k_ba_acc_body(const BAArgs& A, const AccArgs& X, const int mode, const int bx_, const int gx_) {
     const int NN = A.N * A.N;
     DBG_BLK(A.dbg, 1, 0);
     if (A.ctl && A.ctl->stop) {                            // converged: the loop of BA::run has left (BA.cpp:879)
         // the residual kernel must not test the flag its own launch publishes (blocks scheduled after the publishing one would
         // skip residuals of the pass that must still complete): it tests `stop_lin`, which is raised HERE, one launch later
-        if (blockIdx.x == 0 && threadIdx.x == 0) A.ctl->stop_lin = 1;
+        if (bx_ == 0 && threadIdx.x == 0) A.ctl->stop_lin = 1;
         return;
     }
     // the point-row workgroups (16 points per 1024-thread block) take about twice as long as the pair workgroups at a wide window: they
     // are handed out FIRST, the short pair workgroups fill the tail of the launch
-    const int npt = (int)gridDim.x - NN;
-    if ((int)blockIdx.x < npt) point_rows_block(A, X, blockIdx.x);
-    else acc_pair_block(A, X, blockIdx.x - npt, mode);
+    const int npt = (int)gx_ - NN;
+    if ((int)bx_ < npt) point_rows_block(A, X, bx_);
+    else acc_pair_block(A, X, bx_ - npt, mode);
     DBG_BLK_END(A.dbg, 1);
 }
+__global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) { k_ba_acc_body(A, X, mode, blockIdx.x, gridDim.x); }
+
 
 // LINEARIZED-mode bd (BA.cpp:1699-1750), rare path: one thread per point
 __global__ void k_ba_point_bdL(BAArgs A, const float* __restrict__ adHTd, const double* __restrict__ cdelta) {
@@ -538,15 +540,15 @@ __device__ __forceinline__ int sys_tile_index(int ti, int tj, int ntile) { retur
 // plain tiles re-read 135 MB of G from beyond the L2s: the launch was bound by that, not by the matrix cores) and four chains in
 // flight; operands of the next trip are requested before the current trip's products.  Partials land in the same per-tile slots.
 template <bool SUPER>
-__global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SUPER ? 3 : SYS_WPE, SUPER ? 3 : SYS_WPE))) void k_ba_system(SysArgs S) {
+__device__ __forceinline__ void k_ba_system_body(const SysArgs& S, const int bx_) {
     __shared__ double s_part[SYS_NW][256];
     __shared__ double s_f[2][FS_STRIDE];          // [ACTIVE | LINEARIZED] D (64) C (32) B (8) of this frame, or CC (16) bC (4)
     DBG_BLK(S.dbg, 2, 0);
     if (S.stop && *S.stop) return;
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, NT = 64 * SYS_NW;
     const int N = S.N, n = S.n;
-    if (SUPER && (int)blockIdx.x < S.nsyrk) {
-        const int st = blockIdx.x / S.nsl, sl = blockIdx.x % S.nsl;
+    if (SUPER && (int)bx_ < S.nsyrk) {
+        const int st = bx_ / S.nsl, sl = bx_ % S.nsl;
         int Ti = 0, rem = st;
         while (rem >= S.nt2 - Ti) { rem -= S.nt2 - Ti; Ti++; }
         const int Tj = Ti + rem;
@@ -611,8 +613,8 @@ __global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SUP
         DBG_BLK_END(S.dbg, 2);
         return;
     }
-    if (!SUPER && (int)blockIdx.x < S.nsyrk) {
-        const int tile = blockIdx.x / S.nsl, sl = blockIdx.x % S.nsl;
+    if (!SUPER && (int)bx_ < S.nsyrk) {
+        const int tile = bx_ / S.nsl, sl = bx_ % S.nsl;
         int ti = 0, rem = tile;
         while (rem >= S.ntile - ti) { rem -= S.ntile - ti; ti++; }
         const int tj = ti + rem;
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SUP
                 w[u] = S.Wt[p];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one wait for the whole batch (measured: a staggered wait chain is ~1 us slower)
-            if (S.dbg && tid == 0 && blockIdx.x == 33) S.dbg[32] = wall_clock64();
+            if (S.dbg && tid == 0 && bx_ == 33) S.dbg[32] = wall_clock64();
 #pragma unroll
             for (int u = 0; u < SYS_U; u++) {
                 const double mk = (sp + 4 * u + kk < p_end) ? 1.0 : 0.0;
@@ -652,19 +654,19 @@ __global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SUP
         for (int rg = 0; rg < 4; rg++) acc[rg] += acc2[rg];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) s_part[wv][(kk + 4 * rg) * 16 + c] = acc[rg];
-        if (S.dbg && tid == 0 && blockIdx.x == 33) S.dbg[33] = wall_clock64();
+        if (S.dbg && tid == 0 && bx_ == 33) S.dbg[33] = wall_clock64();
         __syncthreads();
-        if (S.dbg && tid == 0 && blockIdx.x == 33) S.dbg[34] = wall_clock64();
+        if (S.dbg && tid == 0 && bx_ == 33) S.dbg[34] = wall_clock64();
         if (tid < 256) {
             double sum = s_part[0][tid];
 #pragma unroll
             for (int w = 1; w < SYS_NW; w++) sum += s_part[w][tid];
-            S.part[(size_t)blockIdx.x * 256 + tid] = sum;
+            S.part[(size_t)bx_ * 256 + tid] = sum;
         }
         DBG_BLK_END(S.dbg, 2);
         return;
     }
-    const int a = (int)blockIdx.x - S.nsyrk - 1;                             // -1: calibration rows
+    const int a = (int)bx_ - S.nsyrk - 1;                             // -1: calibration rows
     const int nmat = S.use_lin_blocks ? 2 : 1;
     if (a < 0) {
         // CC (16) + bC (4) sums over the N^2 pairs: 8 groups of pairs per entry, 8 loads in flight per trip, then a fixed-order add
@@ -745,6 +747,9 @@ __global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SUP
     }
     DBG_BLK_END(S.dbg, 2);
 }
+template <bool SUPER>
+__global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SUPER ? 3 : SYS_WPE, SUPER ? 3 : SYS_WPE))) void k_ba_system(SysArgs S) { k_ba_system_body<SUPER>(S, blockIdx.x); }
+
 
 // H_sc / b_sc for the host (statistics, tests): slices added in slice order.  Not on the iteration path.
 __global__ __launch_bounds__(256) void k_ba_schur_out(SysArgs S) {
@@ -913,16 +918,16 @@ __global__ __launch_bounds__(256) void k_ba_assemble(int n, int off, SolveSys Y,
     }
 }
 
-template <int NSL>
-__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
-                                                            const int* newframe_res, int n_newframe, const double* lin_partial,
-                                                            int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
-                                                            const double* __restrict__ nullU, const double* __restrict__ indirect_x) {
+template <int NSL, bool WIDE_OK = true>
+__device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off, const SolveSys& Y, double* __restrict__ x, int* __restrict__ flag,
+                                                const int* newframe_res, int n_newframe, const double* lin_partial,
+                                                int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
+                                                const double* __restrict__ nullU, const double* __restrict__ indirect_x, const int bx_) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
     DBG_BLK(A.dbg, 3, 0);
     if (A.ctl && A.ctl->stop) return;
-    if (blockIdx.x == 1) {
+    if (bx_ == 1) {
         if (do_finish) lin_finish_block(A, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw,
                                         reinterpret_cast<unsigned*>(sm), sm + 2048);
         DBG_BLK_END(A.dbg, 3);
@@ -953,7 +958,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     const int items = (nb * (nb + 1) / 2) * 256;                 // (lower block, element) pairs
     if (items <= 5 * SOLVE_THREADS) solve_load_direct<NSL, 5>(A, Y, n, off, m, mp, items, tid, L, Sv, y);
     else if (items <= SOLVE_IPT * SOLVE_THREADS) solve_load_direct<NSL, SOLVE_IPT>(A, Y, n, off, m, mp, items, tid, L, Sv, y);
-    else {
+    else if constexpr (WIDE_OK) {          // (the batched instantiation refuses wide windows on the host: without this path it has no scratch frame)
         // wide windows: k_ba_assemble left the scaled system in this layout — one flat copy, 16 bytes per lane, every load in flight at once
         const int nd2 = ((nb * (nb + 1) / 2) * BSZ) / 2;                              // BSZ is even
         const double2* src = reinterpret_cast<const double2*>(Y.image);
@@ -1185,6 +1190,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
     DBG_T(A, 53);
     DBG_BLK_END(A.dbg, 3);
 }
+template <int NSL>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
+                                                            const int* newframe_res, int n_newframe, const double* lin_partial,
+                                                            int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
+                                                            const double* __restrict__ nullU, const double* __restrict__ indirect_x) {
+    k_ba_solve_body<NSL>(A, n, off, Y, x, flag, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw, do_finish, nullU, indirect_x, blockIdx.x);
+}
+
 
 // ------------------------------------------------------------------------------------------------ K6
 // xAd[(host*N + target)*8 + j] = x_host . adHost(:, j) + x_target . adTarget(:, j)   (BA.cpp:1447)
@@ -1217,22 +1230,22 @@ __global__ __launch_bounds__(256) void k_ba_xad(const double* __restrict__ adH, 
 }
 
 // back-substitution (BA.cpp:1427-1487) + optional point update (doStepFromBackup, BA.cpp:976-994)
-__global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
-                                                    const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
-                                                    int do_step, FrameStepArgs F, const double* __restrict__ xad) {
+__device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double* __restrict__ adH, const double* __restrict__ adT,
+                                                  const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
+                                                  int do_step, const FrameStepArgs& F, const double* __restrict__ xad, const int bx_, const int gx_) {
     extern __shared__ __attribute__((aligned(16))) double s_xAd[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
     __shared__ float s_red[3][4];
     const int N = A.N;
     DBG_BLK(A.dbg, 4, 0);
     if (A.ctl && A.ctl->stop) return;
-    if (F.on && blockIdx.x == gridDim.x - 1) {               // last workgroup: the frames' half of doStepFromBackup
+    if (F.on && bx_ == gx_ - 1) {               // last workgroup: the frames' half of doStepFromBackup
         frame_step_block(F, x);
         DBG_BLK_END(A.dbg, 4);
         return;
     }
     // 8 lanes per point, one residual per lane per pass (a point has at most N-1 residuals): the chain by_point -> r ->
     // {good, target, JpJdF} is walked once per point, every load unconditional (clamped), masks multiplied in.
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = bx_ * blockDim.x + threadIdx.x;
     const int p = gid >> 3, i = gid & 7;
     const bool pv = p < A.P;
     const int pp = pv ? p : 0;
@@ -1265,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
     } else {
         for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) s_xAd[e] = xad_entry(adH, adT, x, N, e);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) sum->nonfinite = 0;
+    if (bx_ == 0 && threadIdx.x == 0) sum->nonfinite = 0;
     __syncthreads();
     float sumID = 0, sumNID = 0, numID = 0;
     {
@@ -1323,11 +1336,17 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
         __syncthreads();
         if (threadIdx.x < 3) {
             const int k = threadIdx.x;
-            step_partial[4 * blockIdx.x + k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
+            step_partial[4 * bx_ + k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
         }
     }
     DBG_BLK_END(A.dbg, 4);
 }
+__global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
+                                                    const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
+                                                    int do_step, FrameStepArgs F, const double* __restrict__ xad) {
+    k_ba_backsub_body(A, adH, adT, x, sum, step_partial, do_step, F, xad, blockIdx.x, gridDim.x);
+}
+
 
 __global__ void k_ba_backup_points(BAArgs A) {          // BA.cpp:919-922
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1369,28 +1388,18 @@ static size_t solve_lds_bytes(int m) {
     return d * sizeof(double);
 }
 
-int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only, bool marg) {
-    const int N = A.N, n = A.n, NN = N * N;
-    const double* vs = c->vec_small.as<double>();        // cdelta[4] cprior[4] prior[8N] dprior[8N]
-    AccArgs X;
-    X.adH = c->adH.as<double>(); X.adT = c->adT.as<double>(); X.adHTd = c->adHTd.as<float>(); X.cdelta = vs;
+// arguments of K3 / K4 for the ACTIVE pass of a window as the context stands (shared by the solo launcher and the batched iteration)
+static void fill_acc_args(cmlhip_ctx* c, const BAArgs& A, bool do_backup, AccArgs& X) {
+    const int n = A.n;
+    X.adH = c->adH.as<double>(); X.adT = c->adT.as<double>(); X.adHTd = c->adHTd.as<float>(); X.cdelta = c->vec_small.as<double>();
     X.acc_out = c->acc_pair[0].as<float>(); X.num_out = c->acc_num[0].as<int>(); X.pair_blocks = c->pair_blocks.as<double>();
     X.ldg = ldg_of(n); X.G = c->G.as<double>(); X.Wt = X.G + (size_t)A.P * X.ldg; X.do_backup = do_backup ? 1 : 0;
     X.part = c->rs_part.as<float>(); X.tile_off = c->rs_tile_off.as<int>(); X.tile = c->rs_tile;
+}
+static bool fill_sys_args(cmlhip_ctx* c, const BAArgs& A, const AccArgs& X, double lambda, bool have_hm, bool system_only, bool marg, SysArgs& S) {
+    const int N = A.N, n = A.n, NN = N * N;
+    const double* vs = c->vec_small.as<double>();        // cdelta[4] cprior[4] prior[8N] dprior[8N]
     double* pbL = c->pair_blocks.as<double>() + (size_t)PB_STRIDE * NN;
-    if (marg) {                                          // marginalizePointsF: MARGINALIZED-mode blocks of the selected points only
-        k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, X, CMLHIP_MODE_MARGINALIZED);
-        if (A.P > 0) k_ba_point_rows_marg<<<cml_div_up(A.P, 64), 64, 0, c->stream>>>(A, X);
-    } else if (!system_only) {
-        if (c->n_lin > 0) {                              // rare path: LINEARIZED residuals present
-            AccArgs XL = X;
-            XL.acc_out = c->acc_pair[1].as<float>(); XL.num_out = c->acc_num[1].as<int>(); XL.pair_blocks = pbL;
-            k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
-            if (A.P > 0) k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
-        }
-        CML_LAUNCH_EV(c, k_ba_acc, NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, A, X, c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0);
-    }
-    SysArgs S;
     S.N = N; S.n = n; S.ldg = X.ldg; S.ntile = X.ldg / 16; S.P = A.P; S.use_lin_blocks = (c->n_lin > 0 && !marg) ? 1 : 0;
     S.G = X.G; S.Wt = X.Wt; S.pbA = c->pair_blocks.as<double>(); S.pbL = pbL; S.dbg = A.dbg; S.stop = A.ctl ? &A.ctl->stop : nullptr;
     S.cdelta = vs; S.cprior = vs + 4; S.prior = vs + 8; S.dprior = vs + 8 + 8 * N;
@@ -1406,6 +1415,29 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
     S.nt2 = (S.ntile + 1) / 2;
     if (super && !system_only) S.nsyrk = S.nt2 * (S.nt2 + 1) / 2 * S.nsl;
     S.part = c->syrk_part.as<double>();
+    return super;
+}
+
+int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only, bool marg) {
+    const int N = A.N, NN = N * N;
+    const double* vs = c->vec_small.as<double>();
+    AccArgs X;
+    fill_acc_args(c, A, do_backup, X);
+    double* pbL = c->pair_blocks.as<double>() + (size_t)PB_STRIDE * NN;
+    if (marg) {                                          // marginalizePointsF: MARGINALIZED-mode blocks of the selected points only
+        k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, X, CMLHIP_MODE_MARGINALIZED);
+        if (A.P > 0) k_ba_point_rows_marg<<<cml_div_up(A.P, 64), 64, 0, c->stream>>>(A, X);
+    } else if (!system_only) {
+        if (c->n_lin > 0) {                              // rare path: LINEARIZED residuals present
+            AccArgs XL = X;
+            XL.acc_out = c->acc_pair[1].as<float>(); XL.num_out = c->acc_num[1].as<int>(); XL.pair_blocks = pbL;
+            k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
+            if (A.P > 0) k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
+        }
+        CML_LAUNCH_EV(c, k_ba_acc, NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, A, X, c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0);
+    }
+    SysArgs S;
+    const bool super = fill_sys_args(c, A, X, lambda, have_hm, system_only, marg, S);
     c->sys_lambda = lambda;
     if (super) k_ba_system<true><<<S.nsyrk + N + 1, 64 * SYS_NW, 0, c->stream>>>(S);
     else k_ba_system<false><<<S.nsyrk + N + 1, 64 * SYS_NW, 0, c->stream>>>(S);
@@ -1489,5 +1521,137 @@ int cml_launch_restore_points(cmlhip_ctx* c, const BAArgs& A) {
 }
 int cml_launch_step_points(cmlhip_ctx* c, const BAArgs& A) {
     if (A.P > 0) k_ba_step_points<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->step_partial.as<float>());
+    return CMLHIP_OK;
+}
+
+// ================================================================================================ several windows per launch
+// cmlhip_ba_iteration_batch: ONE resident Gauss-Newton iteration of S independent windows (sequence shards mapped to one GPU) in the
+// five launches a single window takes — gridDim.y = window.  A small latency-bound window occupies well under a third of the chip
+// and S host threads launching S streams are host-bound from S = 4 on (tools/probe_concurrent.py), so throughput mode batches.
+// Every kernel body is the one the solo path runs (k_*_body), on the window's own buffers, with the arguments it would get solo: a
+// window's result is bit-identical to its solo run.  The per-window argument blocks live in device memory (read through uniform
+// addresses: scalar loads, like the kernel-argument segment they replace) and are re-uploaded only when they change.
+struct BatchWin {
+    BAArgs A; AccArgs X; SysArgs S; SolveSys Y; FrameStepArgs F;
+    int acc_mode, g_acc, g_sys, g_back;
+    int n, off, n_newframe, n_partial;
+    double* x; int* flag; const int* newframe_res; const double* lin_partial; LinSummary* lin_out; FrameDev* frames_rw; const double* nullU;
+    const double* adH; const double* adT; float* step_partial;
+};
+__global__ __launch_bounds__(1024) void k_ba_acc_batch(const BatchWin* __restrict__ W) {
+    const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
+    if ((int)blockIdx.x >= w.g_acc) return;
+    k_ba_acc_body(w.A, w.X, w.acc_mode, blockIdx.x, w.g_acc);
+}
+__global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SYS_WPE, SYS_WPE))) void k_ba_system_batch(const BatchWin* __restrict__ W) {
+    const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
+    if ((int)blockIdx.x >= w.g_sys) return;
+    k_ba_system_body<false>(w.S, blockIdx.x);
+}
+template <int NSL>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_batch(const BatchWin* __restrict__ W) {
+    const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
+    k_ba_solve_body<NSL, false>(w.A, w.n, w.off, w.Y, w.x, w.flag, w.newframe_res, w.n_newframe, w.lin_partial, w.n_partial, w.lin_out, w.frames_rw, 1, w.nullU,
+                         nullptr, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_ba_backsub_batch(const BatchWin* __restrict__ W) {
+    const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
+    if ((int)blockIdx.x >= w.g_back) return;
+    k_ba_backsub_body(w.A, w.adH, w.adT, w.x, w.lin_out, w.step_partial, 1, w.F, nullptr, blockIdx.x, w.g_back);
+}
+
+int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
+    cmlhip_ctx* c0 = ctxs[0];
+    std::vector<BatchWin> H((size_t)S);
+    std::vector<unsigned char> Hrs;
+    int g_acc = 0, g_sys = 0, g_back = 0, nsl = 0, rs_blocks = 0;
+    size_t solve_lds = 0, back_lds = 0;
+    for (int k = 0; k < S; k++) {
+        cmlhip_ctx* c = ctxs[k];
+        BatchWin& w = H[k];
+        memset(&w, 0, sizeof w);
+        BAArgs& A = w.A;
+        cml_make_ba_args(c, A);
+        A.fuse_apply = 1;                                    // the step is always accepted here (forceAccept, BA.h:265)
+        A.ctl = nullptr;                                     // throughput mode: every enqueued iteration runs (no early exit)
+        A.dbg = nullptr;
+        fill_acc_args(c, A, true, w.X);
+        w.acc_mode = c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0;
+        w.g_acc = A.N * A.N + cml_div_up(A.P, PT_PER_BLOCK);
+        const bool super = fill_sys_args(c, A, w.X, lambda, false, false, false, w.S);
+        if (super) { c0->err = "cmlhip_ba_iteration_batch: a window this wide fills the chip on its own (use cmlhip_ba_iteration_async)"; return CMLHIP_ERR_INVALID; }
+        w.g_sys = w.S.nsyrk + A.N + 1;
+        // K5, as cml_launch_solve
+        const int n = A.n, off = 4, m = n - off;
+        const size_t sh = solve_lds_bytes(m);
+        const int nb = (m + 15) / 16, nblk = nb * (nb + 1) / 2;
+        if (sh > 160 * 1024 || nblk * 256 > SOLVE_IPT * SOLVE_THREADS) { c0->err = "cmlhip_ba_iteration_batch: window too wide for the batched solve"; return CMLHIP_ERR_INVALID; }
+        w.n = n; w.off = off;
+        w.Y.Hb = c->Hf.as<double>(); w.Y.bb = c->bf.as<double>(); w.Y.part = c->syrk_part.as<double>();
+        w.Y.nsl = cml_sys_slices(A.P); w.Y.ntile = ldg_of(n) / 16; w.Y.lambda = lambda; w.Y.image = nullptr;
+        if (k == 0) nsl = w.Y.nsl;
+        if (w.Y.nsl != nsl) { c0->err = "cmlhip_ba_iteration_batch: the windows of a batch must fall into one point-slice class (P <= 512 / 1024 / 2048 / more)"; return CMLHIP_ERR_INVALID; }
+        w.x = c->xvec.as<double>(); w.flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
+        w.newframe_res = c->newframe_res.as<int>(); w.n_newframe = c->n_newframe; w.lin_partial = c->lin_partial.as<double>(); w.n_partial = c->lin_partial_n;
+        w.lin_out = c->scal.as<LinSummary>(); w.frames_rw = c->frames.as<FrameDev>();
+        w.nullU = (c->resident_on && c->have_null && c->resident_iter >= 2) ? c->null_basis.as<double>() : nullptr;
+        // K6, as cml_launch_backsub(do_step = true)
+        if (A.N >= 12 && A.P >= 2048) { c0->err = "cmlhip_ba_iteration_batch: window too wide for the batched back-substitution"; return CMLHIP_ERR_INVALID; }
+        FrameStepArgs& F = w.F;
+        F.on = c->resident_on ? 1 : 0;
+        if (F.on) {
+            F.fs = c->frame_state.as<cmlhip_ba_frame_state>(); F.pairs = c->pairs.as<cmlhip_ba_pair>(); F.pre_w2c = c->pre_w2c.as<double>();
+            F.adH = c->adH.as<double>(); F.adT = c->adT.as<double>(); F.adHTd = c->adHTd.as<float>();
+            F.dprior = c->vec_small.as<double>() + 8 + 8 * A.N;
+            for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
+            F.N = A.N; F.frame_sums = nullptr;
+        }
+        w.g_back = cml_div_up(A.P * 8, 256) + F.on;
+        w.adH = c->adH.as<double>(); w.adT = c->adT.as<double>(); w.step_partial = c->step_partial.as<float>();
+        g_acc = std::max(g_acc, w.g_acc); g_sys = std::max(g_sys, w.g_sys); g_back = std::max(g_back, w.g_back);
+        solve_lds = std::max(solve_lds, sh); back_lds = std::max(back_lds, (size_t)A.N * A.N * 8 * sizeof(double));
+        if (c->r_idepth_dirty) { cml_refresh_r_idepth(c, A, c0->stream); c->r_idepth_dirty = false; }
+        int blocks = 0;
+        if (int rc = cml_fill_rs4_batch(c, A, Hrs, blocks)) { c0->err = c->err; return rc; }
+        rs_blocks = std::max(rs_blocks, blocks);
+        c->sys_lambda = lambda;
+    }
+    if (g_back == 0 || g_acc == 0) { c0->err = "cmlhip_ba_iteration_batch: empty windows"; return CMLHIP_ERR_INVALID; }
+    // argument blocks -> device (only when something changed: the first iterations of a loop, a new lambda, a new window)
+    const size_t bytes_main = sizeof(BatchWin) * (size_t)S;
+    int rc;
+    if ((rc = cml_ensure(c0, c0->batch_main, bytes_main))) return rc;
+    if ((rc = cml_ensure(c0, c0->batch_rs, Hrs.size()))) return rc;
+    if (c0->batch_main_host.size() != bytes_main || memcmp(c0->batch_main_host.data(), H.data(), bytes_main) != 0) {
+        c0->batch_main_host.assign(reinterpret_cast<unsigned char*>(H.data()), reinterpret_cast<unsigned char*>(H.data()) + bytes_main);
+        CML_CHECK(c0, hipMemcpyAsync(c0->batch_main.p, c0->batch_main_host.data(), bytes_main, hipMemcpyHostToDevice, c0->stream));
+    }
+    if (c0->batch_rs_host != Hrs) {
+        c0->batch_rs_host = Hrs;
+        CML_CHECK(c0, hipMemcpyAsync(c0->batch_rs.p, c0->batch_rs_host.data(), Hrs.size(), hipMemcpyHostToDevice, c0->stream));
+    }
+    const BatchWin* W = c0->batch_main.as<BatchWin>();
+    k_ba_acc_batch<<<dim3(g_acc, S), 1024, 0, c0->stream>>>(W);                        // K3
+    k_ba_system_batch<<<dim3(g_sys, S), 64 * SYS_NW, 0, c0->stream>>>(W);              // K4
+#define LAUNCH_SOLVE_B(NSL) do { \
+        if (!(c0->attr_done_batch & (1u << NSL))) { (void)hipFuncSetAttribute((const void*)k_ba_solve_batch<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c0->attr_done_batch |= 1u << NSL; } \
+        k_ba_solve_batch<NSL><<<dim3(2, S), SOLVE_THREADS, solve_lds, c0->stream>>>(W); } while (0)
+    switch (nsl) {                                                                     // K5: S solve workgroups side by side (+ S threshold workgroups)
+        case 1: LAUNCH_SOLVE_B(1); break;
+        case 2: LAUNCH_SOLVE_B(2); break;
+        case 4: LAUNCH_SOLVE_B(4); break;
+        default: LAUNCH_SOLVE_B(8); break;
+    }
+#undef LAUNCH_SOLVE_B
+    k_ba_backsub_batch<<<dim3(g_back, S), 256, back_lds, c0->stream>>>(W);             // K6
+    if ((rc = cml_launch_linearize_rs4_batch(c0, c0->batch_rs.p, S, rs_blocks))) return rc;   // K1
+    CML_CHECK(c0, hipGetLastError());
+    for (int k = 0; k < S; k++) {
+        cmlhip_ctx* c = ctxs[k];
+        c->resident_iter++;
+        c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
+        c->lin_finish_pending = true;
+        c->last_lambda = lambda;
+    }
     return CMLHIP_OK;
 }

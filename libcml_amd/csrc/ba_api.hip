@@ -554,6 +554,24 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     return CMLHIP_OK;
 }
 
+int cmlhip_ba_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
+    if (!ctxs || S < 1 || S > 64 || !ctxs[0]) return CMLHIP_ERR_INVALID;
+    cmlhip_ctx* c0 = ctxs[0];
+    CML_DEV(c0);
+    for (int k = 0; k < S; k++) {
+        cmlhip_ctx* c = ctxs[k];
+        if (!c) return CMLHIP_ERR_INVALID;
+        for (int q = 0; q < k; q++) if (ctxs[q] == c) { c0->err = "cmlhip_ba_iteration_batch: a context appears twice"; return CMLHIP_ERR_INVALID; }
+        int rc = ba_check(c, true);
+        if (rc) { if (c != c0) c0->err = c->err; return rc; }
+        CML_REQUIRE(c0, c->device == c0->device && c->lim.texel_format == c0->lim.texel_format, CMLHIP_ERR_INVALID, "cmlhip_ba_iteration_batch: contexts of one device and one texel format");
+        CML_REQUIRE(c0, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_iteration_batch: cmlhip_ba_set_resident_state not called for a window");
+        CML_REQUIRE(c0, !(c->rp_resident && c->N > 4), CMLHIP_ERR_STATE, "cmlhip_ba_iteration_batch: the hybrid term is not batched (use cmlhip_ba_iteration_async)");
+        CML_REQUIRE(c0, c->n_lin == 0 && !c->conv_on, CMLHIP_ERR_STATE, "cmlhip_ba_iteration_batch: no LINEARIZED residuals and no convergence control in a batch");
+    }
+    return cml_iteration_batch(ctxs, S, lambda);
+}
+
 // ---------------------------------------------------------------------------------------------- marginalisation
 static int upload_point_mask(cmlhip_ctx* c, int n, const int* idx) {
     std::vector<unsigned char> m((size_t)std::max(c->P, 1), 0);

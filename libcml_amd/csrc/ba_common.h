@@ -85,9 +85,15 @@ struct RsArgs {
     int dbg_flags;                                 // development switches (CMLHIP_RS_DBG)
     float* part;                                   // [ntiles][64][4]: the wave's 16x16 fp32 tile of its pair's 13x13 block (MFMA D layout)
 };
+struct BatchRs { BAArgs A; RsArgs X; int blocks; int pad; };      // one window of a batched residual launch
 int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A);
 int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X);
-int cml_materialize_records(cmlhip_ctx* c);        // re-create the efsJ records the resident kernel did not write (no state change)
+int cml_materialize_records(cmlhip_ctx* c);
+// several windows per launch (cmlhip_ba_iteration_batch): per-window {BAArgs, RsArgs, blocks} records appended to `blob`
+int cml_fill_rs4_batch(cmlhip_ctx* c, const BAArgs& A, std::vector<unsigned char>& blob, int& blocks);
+int cml_launch_linearize_rs4_batch(cmlhip_ctx* c0, const void* dev_records, int S, int max_blocks);
+void cml_refresh_r_idepth(cmlhip_ctx* c, const BAArgs& A, hipStream_t stream);
+int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda);        // re-create the efsJ records the resident kernel did not write (no state change)
 
 // point slices of the Schur SYRK (k_ba_system): more slices = more CUs pulling rows, but more partials for the consumer to add
 // (a power of two <= 8: the solve kernel is instantiated per slice count so that it issues exactly the loads it needs)

@@ -518,17 +518,37 @@ __global__ void k_ba_idepth_to_res(BAArgs A) {
     if (r < A.R) A.r_idepth[r] = A.pt_idepth[A.r_point[r]];
 }
 
-int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
-    if (c->n_tiles == 0) return CMLHIP_OK;
-    if (c->r_idepth_dirty) {                               // pt_idepth was written outside the resident point step (upload, set_idepth, restore, standalone step)
-        k_ba_idepth_to_res<<<cml_div_up(A.R, 256), 256, 0, c->stream>>>(A);
-        c->r_idepth_dirty = false;
-    }
-    RsArgs X;
+void cml_refresh_r_idepth(cmlhip_ctx* c, const BAArgs& A, hipStream_t stream) {
+    k_ba_idepth_to_res<<<cml_div_up(A.R, 256), 256, 0, stream>>>(A);
+}
+static void fill_rs_args(cmlhip_ctx* c, RsArgs& X) {
     X.tiles = c->rs_tiles.as<int4>(); X.ntiles = c->n_tiles;
     X.r_px = c->r_px.as<float>(); X.r_py = c->r_py.as<float>(); X.r_colors = c->r_colors.as<float>(); X.r_weights = c->r_weights.as<float>();
     X.part = c->rs_part.as<float>(); X.r_idepth = c->r_idepth.as<double>();
     { static const char* e = getenv("CMLHIP_RS_DBG"); X.dbg_flags = e ? atoi(e) : 0; }      // development: 1 = all texel taps at texel 0, 2 = no tile / reduced-record stores
+}
+int cml_fill_rs4_batch(cmlhip_ctx* c, const BAArgs& A, std::vector<unsigned char>& blob, int& blocks) {
+    if (!c->rs_ok || c->rs_tile != 16 || c->n_tiles == 0) {
+        c->err = "cmlhip_ba_iteration_batch takes small windows only (4-lane residual kernel, R < 36 k): a larger window fills the chip on its own";
+        return CMLHIP_ERR_INVALID;
+    }
+    BatchRs r;
+    memset(&r, 0, sizeof r);
+    r.A = A;
+    fill_rs_args(c, r.X);
+    r.blocks = blocks = cml_div_up(c->n_tiles, 4);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(&r);
+    blob.insert(blob.end(), b, b + sizeof r);
+    return CMLHIP_OK;
+}
+int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
+    if (c->n_tiles == 0) return CMLHIP_OK;
+    if (c->r_idepth_dirty) {                               // pt_idepth was written outside the resident point step (upload, set_idepth, restore, standalone step)
+        cml_refresh_r_idepth(c, A, c->stream);
+        c->r_idepth_dirty = false;
+    }
+    RsArgs X;
+    fill_rs_args(c, X);
     if (c->rs_tile == 16) return cml_launch_linearize_rs4(c, A, X);                         // small window: 4 lanes per residual (ba_linearize_rs4.hip)
     // fp16 texels: 168 VGPRs, three waves per SIMD — every tile of a 20-frame window resident at once; fp32 texels hold twice the
     // registers in flight and stay at two

@@ -103,14 +103,14 @@ __device__ __forceinline__ float rs4_jpdc(const int k, const double E0, const do
 // MINB: workgroups per CU the register budget is sized for — 1: no register bound (196 VGPRs, two waves per SIMD), no scratch frame;
 // 3: 168 VGPRs, the 13-23 registers beyond that spill to a scratch frame — measured slower at every window size (see the launcher)
 template <bool HALF, int MINB>
-__global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
+__device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs& X, const int bx_) {
     __shared__ double s_shd[4][RS_RES * RS_DSTRIDE];                                   // [wave][residual * RS_DSTRIDE + quantity * 9 + pixel]
     __shared__ float s_shf[4][RS_RES * RS_FSTRIDE];                                    // [wave][residual * RS_FSTRIDE + quantity * 8 + pixel]
     // the staged reduced record (layout of k_ba_acc's s_rec + Jpdd at 40,41) reuses the wave's fp64 rows once the sums are taken (a wave's
     // LDS operations execute in order): 52.5 KB per workgroup, three workgroups per CU
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, g = ln >> 2, j = ln & 3;
     if (A.ctl && A.ctl->stop_lin) return;                  // converged in an earlier launch (raised by k_ba_acc), BA.cpp:879
-    const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    const int ti = __builtin_amdgcn_readfirstlane(bx_ * 4 + wv);
     if (ti >= X.ntiles) return;                            // wave-uniform; there is no workgroup barrier below
     // ---- wave-uniform data: tile -> pair record, frames (scalar loads)
     const int4 T = X.tiles[ti];                            // {first residual, count, host, target}
@@ -446,6 +446,9 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
         if (canbreak && A.it_index >= 1) A.ctl->stop = 1;
     }
 }
+template <bool HALF, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) { k_ba_lin_rs4_body<HALF, MINB>(A, X, blockIdx.x); }
+
 
 int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
     const int blocks = cml_div_up(c->n_tiles, 4);
@@ -461,5 +464,19 @@ int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
         if (small) CML_LAUNCH_EV(c, (k_ba_lin_rs4<false, 1>), blocks, 256, 0, A, X);
         else CML_LAUNCH_EV(c, (k_ba_lin_rs4<false, 3>), blocks, 256, 0, A, X);
     }
+    return CMLHIP_OK;
+}
+
+// several windows per launch (cmlhip_ba_iteration_batch): gridDim.y = window, the body and the arguments of the solo kernel
+template <bool HALF>
+__global__ __launch_bounds__(256, 1) void k_ba_lin_rs4_batch(const BatchRs* __restrict__ W) {
+    const BatchRs& w = *(const BatchRs*)(const BatchRs __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
+    if ((int)blockIdx.x >= w.blocks) return;
+    k_ba_lin_rs4_body<HALF, 1>(w.A, w.X, blockIdx.x);
+}
+int cml_launch_linearize_rs4_batch(cmlhip_ctx* c0, const void* dev_records, int S, int max_blocks) {
+    const BatchRs* W = static_cast<const BatchRs*>(dev_records);
+    if (c0->lim.texel_format == CMLHIP_TEXEL_F16) k_ba_lin_rs4_batch<true><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
+    else k_ba_lin_rs4_batch<false><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
     return CMLHIP_OK;
 }

@@ -136,6 +136,7 @@ struct cmlhip_ctx {
     DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt, cd_pts;      // makeCoarseDepth scratch
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x, rp_off, rp_orig; int rp_acc_N = 0;
+    DevBuf batch_main, batch_rs; std::vector<unsigned char> batch_main_host, batch_rs_host; unsigned attr_done_batch = 0;   // cmlhip_ba_iteration_batch (kept by the first context of the batch)
     DevBuf rr_obs, rr_off, rr_orig, rr_points, rr_jp, rr_used, rr_x; std::vector<int> rr_point_of;     // the resident hybrid term's own buffers
     bool rp_resident = false; int rp_res_M = 0, rp_res_n = 0; double rp_res_fx = 0, rp_res_fy = 0;   // hybrid term inside the resident iteration (cmlhip_ba_set_resident_indirect)
 };

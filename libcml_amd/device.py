@@ -96,6 +96,7 @@ PROTOTYPES = {
     "cmlhip_ba_get_pairs": (C.c_int, [_ctx, C.c_void_p, _P(_f), _P(_f)]),
     "cmlhip_ba_linearize_async": (C.c_int, [_ctx]),
     "cmlhip_ba_iteration_async": (C.c_int, [_ctx, _d]),
+    "cmlhip_ba_iteration_batch": (C.c_int, [_P(_ctx), C.c_int, _d]),
 }
 
 
@@ -113,6 +114,12 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def ba_iteration_batch(ctxs, lam):
+    """One resident iteration of every window in `ctxs` (device.Ctx objects) in five launches; see cmlhip_ba_iteration_batch."""
+    arr = (_ctx * len(ctxs))(*[c.h for c in ctxs])
+    ctxs[0].ck(lib().cmlhip_ba_iteration_batch(arr, len(ctxs), lam))
 
 
 class CmlHipError(RuntimeError):

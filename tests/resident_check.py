@@ -107,6 +107,22 @@ def check_one_pass(ctx, replay, lam=1e-5, with_records=False):
     pre = ctx.ba_states()
     ctx.ba_iteration_async(lam)
     ctx.sync()
+    return compare_pass(ctx, replay, pre, with_records)
+
+
+def check_one_batched_pass(ctxs, replays, lam=1e-5, with_records=False):
+    """The same for S windows stepped by ONE cmlhip_ba_iteration_batch: a report per window."""
+    from libcml_amd import device
+    ctxs[0].sync()
+    pres = [c.ba_states() for c in ctxs]
+    device.ba_iteration_batch(ctxs, lam)
+    ctxs[0].sync()
+    return [compare_pass(c, r, p, with_records) for c, r, p in zip(ctxs, replays, pres)]
+
+
+def compare_pass(ctx, replay, pre, with_records=False):
+    """Replay the residual pass the device just ran (from `pre` = the residual states before it and the device's current pairs /
+    thresholds / inverse depths) and compare every per-residual output bit for bit."""
     pairs, th, _b0 = ctx.ba_pairs()
     idepth = ctx.ba_get_idepth()
     post = ctx.ba_states()
