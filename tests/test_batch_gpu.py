@@ -28,7 +28,8 @@ def _state(ctx, N):
     return st, ctx.ba_get_idepth().copy(), ctx.ba_jpjdf().copy(), np.frombuffer(bytes(fs), np.uint8).copy()
 
 
-MIXED = [("small", 0), ("medium", 1), ("small", 2), (("M1", (6, 900, 400, 300, 3, 330.0, 330.0, 199.5, 149.5)), 3)]
+# windows of different shapes in one batch (they must share the point-slice class of the Schur SYRK: all P <= 512 here)
+MIXED = [("small", 0), (("M0", (5, 400, 480, 360, 4, 390.0, 390.0, 239.5, 179.5)), 1), ("small", 2), (("M1", (6, 500, 400, 300, 3, 330.0, 330.0, 199.5, 149.5)), 3)]
 
 
 @pytest.mark.parametrize("spec", ["mixed", "B4"])
@@ -79,5 +80,11 @@ def test_batch_refuses_what_it_does_not_take():
         with pytest.raises(device.CmlHipError):                  # the same context twice
             device.ba_iteration_batch([ctx, ctx], 1e-5)
         c2.close()
+        W2, ctx2, ba2 = _window("medium", 1)                     # 600 points: another point-slice class than "small" (300)
+        try:
+            with pytest.raises(device.CmlHipError):
+                device.ba_iteration_batch([ctx, ctx2], 1e-5)
+        finally:
+            ba2.close(); ctx2.close()
     finally:
         ba.close(); ctx.close()
