@@ -885,6 +885,63 @@ __device__ __forceinline__ void solve_load_direct(const BAArgs& A, const SolveSy
     if (yi < mp) y[yi] = (yi < m) ? Sv[yi] * yraw : 0.0;
 }
 
+// The same loader with 16-BYTE loads: a thread's item is a PAIR of vertically adjacent elements (i, i+1) of a lower block — adjacent
+// addresses in Hb and in every Schur slice (i is the fast index of both; off = 4 and n = 8N + 4 are even, so a pair never straddles a
+// tile and is 16-byte aligned).  Half the load instructions through the ONE CU that pulls the whole system (the load count, not the
+// latency, is what that CU feels).  Same expressions per element as solve_load_items.
+template <int NSL, int IPT2>
+__device__ __forceinline__ void solve_load_direct2(const BAArgs& A, const SolveSys& Y, int n, int off, int m, int mp, int items2, int tid,
+                                                   double* L, double* Sv, double* y) {
+    const double il = 1.0 / (1 + Y.lambda);
+    const int yi = SOLVE_THREADS - 1 - tid;                  // rhs on the last waves (fewest live matrix items), issued first
+    const double yraw = (Y.bb[off + min(yi, m - 1)] - schur_entry<NSL>(Y, off + min(yi, m - 1), n)) * (yi < m ? 1.0 : 0.0);
+    double2 hb[IPT2], ps[IPT2][NSL];
+    int dst[IPT2], ij[IPT2];
+    bool real0[IPT2], real1[IPT2], live0[IPT2], live1[IPT2];
+#pragma unroll
+    for (int u = 0; u < IPT2; u++) {
+        const int it = tid + u * SOLVE_THREADS;
+        int I = 0, rem = it >> 7;
+        while (rem >= I + 1) { rem -= I + 1; I++; }
+        const int J = rem, i = 16 * I + 2 * (it & 7), j = 16 * J + ((it >> 3) & 15);
+        const bool in = it < items2;
+        live0[u] = in && j <= i; live1[u] = in && j <= i + 1;
+        real0[u] = live0[u] && i < m; real1[u] = live1[u] && i + 1 < m;
+        const bool any = real0[u] || real1[u];
+        dst[u] = blk_off(I, J) + (i & 15) * BLD + (j & 15);
+        ij[u] = (i << 16) | j;
+        const int gr = off + j, gc = off + i;                 // upper-tile storage of the Schur slices: row <= col
+        const double* q = any ? Y.part + ((size_t)sys_tile_index(gr >> 4, gc >> 4, Y.ntile) * Y.nsl) * 256 + (gr & 15) * 16 + (gc & 15) : Y.part;
+        hb[u] = *reinterpret_cast<const double2*>(Y.Hb + (any ? (size_t)gr * n + gc : 0));
+#pragma unroll
+        for (int k = 0; k < NSL; k++) ps[u][k] = *reinterpret_cast<const double2*>(q + (size_t)k * 256);
+    }
+    if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(A, 54); }
+    double v0[IPT2], v1[IPT2];
+#pragma unroll
+    for (int u = 0; u < IPT2; u++) {
+        const int i = ij[u] >> 16, j = ij[u] & 0xffff;
+        double h0 = 0, h1 = 0;
+#pragma unroll
+        for (int k = 0; k < NSL; k++) { h0 += ps[u][k].x * (real0[u] ? 1.0 : 0.0); h1 += ps[u][k].y * (real1[u] ? 1.0 : 0.0); }
+        double a0 = real0[u] ? hb[u].x : (i == j ? 1.0 : 0.0), a1 = real1[u] ? hb[u].y : (i + 1 == j ? 1.0 : 0.0);
+        if (real0[u] && i == j) a0 *= (1 + Y.lambda);
+        if (real1[u] && i + 1 == j) a1 *= (1 + Y.lambda);
+        v0[u] = a0 - h0 * il; v1[u] = a1 - h1 * il;
+        if (live0[u] && i == j) Sv[i] = (i < m) ? fast_rsqrt(v0[u] + 10.0) : 0.0;                 // SVecI, :1312
+        if (live1[u] && i + 1 == j) Sv[i + 1] = (i + 1 < m) ? fast_rsqrt(v1[u] + 10.0) : 0.0;
+    }
+    __syncthreads();
+    DBG_T(A, 55);
+#pragma unroll
+    for (int u = 0; u < IPT2; u++) {
+        const int i = ij[u] >> 16, j = ij[u] & 0xffff;
+        if (live0[u]) L[dst[u]] = (i < m) ? (Sv[i] * v0[u]) * Sv[j] : v0[u];
+        if (live1[u]) L[dst[u] + BLD] = (i + 1 < m) ? (Sv[i + 1] * v1[u]) * Sv[j] : v1[u];
+    }
+    if (yi < mp) y[yi] = (yi < m) ? Sv[yi] * yraw : 0.0;
+}
+
 // Wide windows (more than SOLVE_IPT items per solve thread): the final system is assembled and Jacobi-scaled by one workgroup per
 // lower 16x16 block — all CUs pull the (1 + nsl) sources, the solve workgroup then copies ONE image, already in its LDS layout
 // (blocks | SVecI | scaled rhs).  Same expressions, in the same order, as solve_load_items + the scaling in k_ba_solve.
@@ -956,8 +1013,8 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
     double* dinv = dvec + mp;                        // mp (1/D)
     // one global round trip for the whole system, then the Jacobi scaling SVecI = (diag + 10)^-1/2 (:1312)
     const int items = (nb * (nb + 1) / 2) * 256;                 // (lower block, element) pairs
-    if (items <= 5 * SOLVE_THREADS) solve_load_direct<NSL, 5>(A, Y, n, off, m, mp, items, tid, L, Sv, y);
-    else if (items <= SOLVE_IPT * SOLVE_THREADS) solve_load_direct<NSL, SOLVE_IPT>(A, Y, n, off, m, mp, items, tid, L, Sv, y);
+    if (items <= 6 * SOLVE_THREADS) solve_load_direct2<NSL, 3>(A, Y, n, off, m, mp, items / 2, tid, L, Sv, y);
+    else if (items <= SOLVE_IPT * SOLVE_THREADS) solve_load_direct2<NSL, SOLVE_IPT / 2>(A, Y, n, off, m, mp, items / 2, tid, L, Sv, y);
     else if constexpr (WIDE_OK) {          // (the batched instantiation refuses wide windows on the host: without this path it has no scratch frame)
         // wide windows: k_ba_assemble left the scaled system in this layout — one flat copy, 16 bytes per lane, every load in flight at once
         const int nd2 = ((nb * (nb + 1) / 2) * BSZ) / 2;                              // BSZ is even
@@ -1002,21 +1059,22 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
             // the chain does not wait behind the 14 independent updates.
             // A zero pivot of a positive SEMI-definite system (frames without any good residual and without a pose prior) has a
             // zero column below it and is skipped — Eigen's pivoted LDLT stops at a zero corner (LDLT.h:300-396) and pseudo-inverts
-            // D (:580-587), D^-1 below maps it to x = 0: on the uniform (scalar) copy of d_k a zero/denormal exponent swaps in
-            // 2^1000, so the multipliers underflow to nothing without a select on the chain.
+            // D (:580-587), D^-1 below maps it to x = 0: the exponent test runs on the uniform (scalar) copy of d_k BESIDE the chain and
+            // one select zeroes the multipliers at its end (tools/microbench6.hip: with the guard between the readlanes and the
+            // reciprocal a bare step is 126 cycles, without 86).
             double dk, cid;
 #define SOLVE_PIVOT_CHAIN(K_, DK_, CID_) do { \
-                union { double d; int i[2]; } ud_, us_; \
+                union { double d; int i[2]; } ud_; \
                 ud_.d = row[K_]; \
                 const int dlo_ = __builtin_amdgcn_readlane(ud_.i[0], K_), dhi_ = __builtin_amdgcn_readlane(ud_.i[1], K_); \
-                const bool tiny_ = (dhi_ & 0x7ff00000) == 0; \
-                us_.i[0] = tiny_ ? 0 : dlo_; us_.i[1] = tiny_ ? 0x7e700000 : dhi_; \
+                const bool tiny_ = (dhi_ & 0x7ff00000) == 0;        /* scalar side, BESIDE the chain (round 3: it sat on it, +40 cycles per pivot) */ \
                 ud_.i[0] = dlo_; ud_.i[1] = dhi_; \
                 DK_ = ud_.d; \
-                const double x0_ = __builtin_amdgcn_rcp(us_.d); \
-                const double e0_ = __builtin_fma(-us_.d, x0_, 1.0), p_ = row[K_] * x0_; \
+                const double x0_ = __builtin_amdgcn_rcp(ud_.d); \
+                const double e0_ = __builtin_fma(-ud_.d, x0_, 1.0), p_ = row[K_] * x0_; \
                 const double t_ = __builtin_fma(p_, e0_, p_), e2_ = e0_ * e0_; \
-                CID_ = __builtin_fma(t_, e2_, t_); } while (0)
+                const double c_ = __builtin_fma(t_, e2_, t_); \
+                CID_ = tiny_ ? 0.0 : c_; } while (0)
             SOLVE_PIVOT_CHAIN(0, dk, cid);
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -1029,7 +1087,8 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
                 }
 #pragma unroll
                 for (int j = k + 2; j < 16; j++) row[j] -= cid * rl(row[k], j);   // lanes above the pivot compute unused values
-                if (l > k) { row[k] = cid; yv -= cid * zk; }
+                row[k] = cid;                  // every lane: the entries on and above the diagonal of the factor are never read (D lives in dvec)
+                if (l > k) yv -= cid * zk;
                 if (l == k) mydk = dk;
                 dk = dk_next; cid = cid_next;
             }
@@ -1088,7 +1147,7 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
                 const double* Lrow = L + blk_off(kb, min(l >> 4, kb)) + (l & 15);
                 double col[16];
 #pragma unroll
-                for (int kk = 0; kk < 16; kk++) col[kk] = (l < 16 * kb + kk) ? Lrow[kk * BLD] : 0.0;
+                for (int kk = 0; kk < 16; kk++) { const double c_ = Lrow[kk * BLD]; col[kk] = (l < 16 * kb + kk) ? c_ : 0.0; }   // unconditional loads (valid addresses), select afterwards: no branch per load
 #pragma unroll
                 for (int kk = 15; kk >= 0; kk--) yv -= col[kk] * rl(yv, 16 * kb + kk);
             }
