@@ -448,13 +448,14 @@ def main():
         # (tools/profile_bench.py; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide) and are only
         # quoted for the workload they were collected on
         traffic, traffic_src, rocprof_us = None, None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_linearize_%s.json" % args.config)
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_pmc_linearize_%s.json" % args.config)
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
                 traffic = pmc.get("traffic_bytes_per_launch")
                 rocprof_us = pmc.get("linearize_avg_us")   # kernel-trace average of the same command (dispatches serialised by the profiler)
-                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % os.path.basename(pmc_path)
+                traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; taken at commit %s: stale if the residual "
+                               "kernel changed since)" % (os.path.basename(pmc_path), pmc.get("commit", "?")))
             except Exception:
                 traffic = None
         out = {

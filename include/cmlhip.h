@@ -75,7 +75,10 @@ typedef struct {
     int texel_format;    /* CMLHIP_TEXEL_F32 | CMLHIP_TEXEL_F16 (config E: fp16 taps, fp32 accumulate).  With fp16 texels a frame that a
                           * BA window names keeps a second, tiled copy of its level 0 (8 more bytes per pixel) for the resident loop's
                           * residual kernel; it is built on the device at the first cmlhip_ba_upload_window that names the image and
-                          * follows cmlhip_pyramid_put / _build / _drop of that image. */
+                          * is refreshed by a same-size cmlhip_pyramid_put.  A window holds pointers into its images: rebuilding
+                          * (cmlhip_pyramid_build, a put with another size) or dropping an image the uploaded window names releases
+                          * those blocks and INVALIDATES the window — the BA entry points then return CMLHIP_ERR_STATE until the next
+                          * cmlhip_ba_upload_window. */
 } cmlhip_limits;
 
 /* ---------------------------------------------------------------- context */

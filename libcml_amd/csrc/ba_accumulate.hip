@@ -20,6 +20,7 @@
 //  K6 k_ba_backsub  xAd in LDS, per-point step, point update (doStepFromBackup), fixed-order partial sums.
 #include "cmlhip_internal.h"
 #include "ba_common.h"
+#include "reproj_dev.h"
 #include "ba_finish.h"
 #include "ba_frames.h"
 
@@ -975,11 +976,11 @@ __global__ __launch_bounds__(256) void k_ba_assemble(int n, int off, SolveSys Y,
     }
 }
 
-template <int NSL, bool WIDE_OK = true>
+template <int NSL, bool WIDE_OK = true, bool HYBRID = false>
 __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off, const SolveSys& Y, double* __restrict__ x, int* __restrict__ flag,
                                                 const int* newframe_res, int n_newframe, const double* lin_partial,
                                                 int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
-                                                const double* __restrict__ nullU, const double* __restrict__ indirect_x, const int bx_) {
+                                                const double* __restrict__ nullU, const double* __restrict__ indirect_x, const ReprojArgs& RP, const int bx_) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
     DBG_BLK(A.dbg, 3, 0);
@@ -988,6 +989,13 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
         if (do_finish) lin_finish_block(A, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw,
                                         reinterpret_cast<unsigned*>(sm), sm + 2048);
         DBG_BLK_END(A.dbg, 3);
+        return;
+    }
+    if (bx_ >= 2) {
+        // hybrid ORB term (config C): the per-frame workgroups of addIndirectToProblem run BESIDE the factorisation, in its launch — they
+        // depend only on the frame states of the previous iteration; workgroup 0 picks their solutions up at its tail (tickets below)
+        static_assert(RP_THREADS == SOLVE_THREADS, "the frame workgroups of the hybrid term run in the solve launch");
+        if constexpr (HYBRID) { if (RP.N > 0 && bx_ - 2 < RP.N) reproj_frame_block(RP, bx_ - 2, sm); }      // (its own instantiation: the term's local arrays give the kernel a scratch frame)
         return;
     }
     const int m = n - off, nb = (m + 15) / 16, mp = nb * 16;
@@ -1198,16 +1206,32 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
         int* ind_flag = reinterpret_cast<int*>(dots + 8);     // (dynamic LDS: the kernel may take the whole 160 KB, a static variable —
         if (tid == 0) *ind_flag = 0;                          //  or __syncthreads_or's hidden one — would make that request invalid)
         __syncthreads();
+        const bool same_launch = RP.ready != nullptr;        // produced by workgroups 2.. of THIS launch: wait for every frame's ticket
+        if (same_launch) {
+            if (tid < A.N) {
+                int spins = 0;
+                while (__hip_atomic_load(RP.ready + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != RP.ticket) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 21)) { *ind_flag = 2; break; }      // never spin forever: reported as a failed solve
+                }
+            }
+            __syncthreads();
+        }
         int mybad = 0;
-        for (int i = tid; i < 6 * A.N; i += SOLVE_THREADS) mybad |= !isfinite(indirect_x[i]);
-        if (mybad) *ind_flag = 1;
+        for (int i = tid; i < 6 * A.N; i += SOLVE_THREADS) {
+            const double v = same_launch ? __hip_atomic_load(indirect_x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : indirect_x[i];
+            mybad |= !isfinite(v);
+        }
+        if (mybad && *ind_flag == 0) *ind_flag = 1;
         __syncthreads();
         const int ind_bad = *ind_flag;
+        if (ind_bad == 2) bad = 1;
         if (!ind_bad) {
             const double indirectRatio = 1.0 / (1.0 + 0.0), directRatio = 1.0 - indirectRatio;
             for (int i = tid; i < 6 * A.N; i += SOLVE_THREADS) {
                 const int f = i / 6, k = i % 6;
-                xs[4 + 8 * f + k] = xs[4 + 8 * f + k] * directRatio + indirect_x[i] * indirectRatio;
+                const double xi = same_launch ? __hip_atomic_load(indirect_x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : indirect_x[i];
+                xs[4 + 8 * f + k] = xs[4 + 8 * f + k] * directRatio + xi * indirectRatio;
             }
         }
         __syncthreads();
@@ -1249,12 +1273,12 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
     DBG_T(A, 53);
     DBG_BLK_END(A.dbg, 3);
 }
-template <int NSL>
+template <int NSL, bool HYBRID>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
                                                             const int* newframe_res, int n_newframe, const double* lin_partial,
                                                             int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
-                                                            const double* __restrict__ nullU, const double* __restrict__ indirect_x) {
-    k_ba_solve_body<NSL>(A, n, off, Y, x, flag, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw, do_finish, nullU, indirect_x, blockIdx.x);
+                                                            const double* __restrict__ nullU, const double* __restrict__ indirect_x, ReprojArgs RP) {
+    k_ba_solve_body<NSL, true, HYBRID>(A, n, off, Y, x, flag, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw, do_finish, nullU, indirect_x, RP, blockIdx.x);
 }
 
 
@@ -1511,7 +1535,7 @@ int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A) {
     return CMLHIP_OK;
 }
 
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho, const double* indirect_x) {
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho, const double* indirect_x, const ReprojArgs* rp) {
     const int n = A.n, off = optcal ? 0 : 4, m = n - off;
     const size_t sh = solve_lds_bytes(m);
     int* flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
@@ -1530,12 +1554,17 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
         Y.image = c->solve_image.as<double>();
     }
     const int* stopp = A.ctl ? &A.ctl->stop : nullptr;
+    ReprojArgs RPv;
+    memset(&RPv, 0, sizeof RPv);
+    if (rp) RPv = *rp;                                          // hybrid term: its per-frame workgroups ride in this launch (blocks 2 .. 2 + N)
+#define LAUNCH_SOLVE_H(NSL, HYB, BIT) do { \
+        if (!(c->attr_done & (1u << (BIT)))) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL, HYB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c->attr_done |= 1u << (BIT); } \
+        k_ba_solve<NSL, HYB><<<rp ? 2 + rp->N : (with_lin_finish ? 2 : 1), SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag, \
+            c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n, c->scal.as<LinSummary>(), \
+            c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr, indirect_x, RPv); } while (0)
 #define LAUNCH_SOLVE(NSL) do { \
         if (wide) k_ba_assemble<NSL><<<nblk, 256, 0, c->stream>>>(n, off, Y, stopp); \
-        if (!(c->attr_done & (1u << NSL))) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c->attr_done |= 1u << NSL; } \
-        k_ba_solve<NSL><<<with_lin_finish ? 2 : 1, SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag, \
-            c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n, c->scal.as<LinSummary>(), \
-            c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr, indirect_x); } while (0)
+        if (rp) LAUNCH_SOLVE_H(NSL, true, 16 + NSL); else LAUNCH_SOLVE_H(NSL, false, NSL); } while (0)
     switch (Y.nsl) {
         case 1: LAUNCH_SOLVE(1); break;
         case 2: LAUNCH_SOLVE(2); break;
@@ -1543,6 +1572,7 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
         default: LAUNCH_SOLVE(8); break;
     }
 #undef LAUNCH_SOLVE
+#undef LAUNCH_SOLVE_H
     return CMLHIP_OK;
 }
 
@@ -1610,8 +1640,10 @@ __global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SYS
 template <int NSL>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_batch(const BatchWin* __restrict__ W) {
     const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
+    ReprojArgs RP0;
+    RP0.N = 0; RP0.ready = nullptr; RP0.ticket = 0;         // the hybrid term is not batched
     k_ba_solve_body<NSL, false>(w.A, w.n, w.off, w.Y, w.x, w.flag, w.newframe_res, w.n_newframe, w.lin_partial, w.n_partial, w.lin_out, w.frames_rw, 1, w.nullU,
-                         nullptr, blockIdx.x);
+                         nullptr, RP0, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_ba_backsub_batch(const BatchWin* __restrict__ W) {
     const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "ba_common.h"
+#include "reproj_dev.h"
 #include <cmath>
 
 static int ba_check(cmlhip_ctx* c, bool need_pairs) {
@@ -287,6 +288,8 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     if ((rc = cml_h2d_batch_flush(c))) return rc;
     lap_("flushed");
     c->ba_uploaded = true;
+    c->ba_image_ids.clear();
+    for (int i = 0; i < N; i++) c->ba_image_ids.push_back(frames[i].image_id);
     c->ba_pairs_set = false;
     c->resident_on = false; c->resident_iter = 0;
     return CMLHIP_OK;
@@ -535,8 +538,10 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     if (prof) c->ext_start = ev[0];                          // begin timestamp of the K3 dispatch
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
     const bool mix = c->resident_on && c->rp_resident && c->N > 4;      // addIndirectToProblem, BA.cpp:1327-1329 (only with more than 4 frames)
-    if (mix && (rc = cml_launch_reproj_resident(c, lambda))) return rc;
-    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rr_x.as<double>() : nullptr))) return rc;   // K5: solve (+ hybrid term, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
+    ReprojArgs rp;
+    if (mix) cml_resident_reproj_args(c, lambda, c->resident_iter + 1, &rp);   // its per-frame workgroups ride in the solve launch
+    // K5: solve (+ hybrid term beside it, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
+    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rr_x.as<double>() : nullptr, mix ? &rp : nullptr))) return rc;
     c->resident_iter++;
     if (prof) c->ext_stop = ev[1];                           // end timestamp of the K6 dispatch
     cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update

@@ -212,7 +212,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
                      &c->vec_small, &c->HA, &c->bA, &c->HL, &c->bL, &c->Hsc, &c->bsc, &c->HM, &c->bM, &c->xvec, &c->G,
                      &c->syrk_part, &c->solve_image, &c->xad, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,
                      &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x, &c->rp_off, &c->rp_orig,
-                     &c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x, &c->batch_main, &c->batch_rs};
+                     &c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x, &c->rr_ready, &c->batch_main, &c->batch_rs};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -328,6 +328,13 @@ static void pool_release(cmlhip_ctx* c, void* p, size_t bytes) {
     if (off || c->img_pool_bytes + bytes > IMG_POOL_CAP) { (void)hipFree(p); return; }
     c->img_pool.emplace(bytes, p); c->img_pool_bytes += bytes;
 }
+// A BA window holds raw pointers into the level-0 images it names (FrameDev::grad0 / grad0t): when such an image is rebuilt with
+// another size, rebuilt from gray or dropped, its blocks go back to the pool and the window must not be used again before the next
+// cmlhip_ba_upload_window (the entry points then fail with CMLHIP_ERR_STATE instead of reading recycled memory)
+static void window_forget_image(cmlhip_ctx* c, uint64_t id) {
+    for (uint64_t u : c->ba_image_ids)
+        if (u == id) { c->ba_uploaded = false; c->resident_on = false; c->ba_image_ids.clear(); return; }
+}
 static void free_level(cmlhip_ctx* c, PyrLevel& L) {
     const size_t n = (size_t)L.w * L.h;
     pool_release(c, L.grad, n * texel_bytes(c));
@@ -377,7 +384,7 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
     Pyramid& P = c->pyr[id];
     PyrLevel& L = P.lv[level];
     (void)hipStreamSynchronize(c->stream);
-    if (L.w != w || L.h != h) free_level(c, L);
+    if (L.w != w || L.h != h) { if (level == 0 && L.grad) window_forget_image(c, id); free_level(c, L); }
     L.tiled_valid = false;
     size_t n = (size_t)w * h;
     int rc;
@@ -402,6 +409,7 @@ int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, i
     if (!c || !gray || levels < 1 || levels > 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
     (void)hipStreamSynchronize(c->stream);
+    if (P.lv[0].grad) window_forget_image(c, id);
     for (int l = 0; l < 8; l++) free_level(c, P.lv[l]);
     P.levels = levels;
     int cw = w, ch = h;
@@ -434,6 +442,7 @@ int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) { CML_DEV(c);
     auto it = c->pyr.find(id);
     if (it == c->pyr.end()) return CMLHIP_ERR_NOT_FOUND;
     (void)hipStreamSynchronize(c->stream);
+    window_forget_image(c, id);
     for (int l = 0; l < 8; l++) free_level(c, it->second.lv[l]);
     c->pyr.erase(it);
     return CMLHIP_OK;

@@ -83,6 +83,7 @@ struct cmlhip_ctx {
     // ---------------- BA window
     cmlhip_ba_params ba_prm{};
     bool ba_prm_set = false, ba_uploaded = false, ba_pairs_set = false;
+    std::vector<uint64_t> ba_image_ids;                      // level-0 images the uploaded window points into (see window_forget_image)
     int N = 0, P = 0, R = 0, n_lin = 0, n_newframe = 0;
     std::vector<int> h_pair_of, h_by_point_off, h_by_point, h_by_pair_off, h_by_pair;    // caller numbering (cmlhip_ba_get_index_maps)
     std::vector<int> h_dev_of, h_caller_of;                   // caller r -> device r' (pair-sorted) and back
@@ -137,7 +138,7 @@ struct cmlhip_ctx {
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x, rp_off, rp_orig; int rp_acc_N = 0;
     DevBuf batch_main, batch_rs; std::vector<unsigned char> batch_main_host, batch_rs_host; unsigned attr_done_batch = 0;   // cmlhip_ba_iteration_batch (kept by the first context of the batch)
-    DevBuf rr_obs, rr_off, rr_orig, rr_points, rr_jp, rr_used, rr_x; std::vector<int> rr_point_of;     // the resident hybrid term's own buffers
+    DevBuf rr_obs, rr_off, rr_orig, rr_points, rr_jp, rr_used, rr_x, rr_ready; std::vector<int> rr_point_of;     // the resident hybrid term's own buffers
     bool rp_resident = false; int rp_res_M = 0, rp_res_n = 0; double rp_res_fx = 0, rp_res_fy = 0;   // hybrid term inside the resident iteration (cmlhip_ba_set_resident_indirect)
 };
 

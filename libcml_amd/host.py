@@ -83,8 +83,7 @@ def lib():
         L.cmlhost_lba_create.restype = _vp; L.cmlhost_lba_create.argtypes = [_vp]
         L.cmlhost_lba_destroy.argtypes = [_vp]
         L.cmlhost_lba_set_params.argtypes = [_vp, _i, _i, _i]
-        L.cmlhost_lba_local_optimize.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i]
-        L.cmlhost_lba_set_stop_flag.restype = None; L.cmlhost_lba_set_stop_flag.argtypes = [_vp]
+        L.cmlhost_lba_local_optimize.argtypes = [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]
         L.cmlhost_lba_apply.argtypes = [_vp, _i, _vp, _i, _P(_d), _P(_i), _i, _P(abi.LbaResult)]
         L.cmlhost_lba_last_error.restype = C.c_char_p; L.cmlhost_lba_last_error.argtypes = [_vp]
         L.cmlhost_init_create.restype = _vp; L.cmlhost_init_create.argtypes = [_vp]
@@ -482,11 +481,10 @@ class HostLocalBA:
     def local_optimize(self, local, fixed, points, apparitions, fix_frames, stop_flag=None):
         """stop_flag: a 1-element uint8 array = the reference's pbStopFlag (IndirectBundleAdjustment.h:27), or None."""
         self._nl, self._np = len(local), len(points)
-        self.L.cmlhost_lba_set_stop_flag(stop_flag.ctypes.data if stop_flag is not None else None)
         lo = np.ascontiguousarray(local, HOST_LBA_FRAME_DTYPE); fx = np.ascontiguousarray(fixed, HOST_LBA_FRAME_DTYPE)
         pt = np.ascontiguousarray(points, HOST_LBA_POINT_DTYPE); ap = np.ascontiguousarray(apparitions, HOST_LBA_APPARITION_DTYPE)
         return bool(self.L.cmlhost_lba_local_optimize(self.h, len(lo), lo.ctypes.data, len(fx), fx.ctypes.data, len(pt), pt.ctypes.data, len(ap), ap.ctypes.data,
-                                                       int(bool(fix_frames))))
+                                                       int(bool(fix_frames)), stop_flag.ctypes.data if stop_flag is not None else None))
 
     def last_error(self):
         return self.L.cmlhost_lba_last_error(self.h).decode()

@@ -69,8 +69,9 @@ bool DSOTracker::makeCoarseDepthL0(uint64_t ref_image_id, int levels, const doub
     return true;
 }
 
-DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLevels, SE3& currentRefToNew,
+DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLevels, SE3& refToNewInOut,
                                           const Exposure& refExposure, Exposure& currentExposure) {
+    SE3 currentRefToNew = refToNewInOut;          // the reference writes `camera` only on the normal exit (TR.cpp:237): an aborted call leaves the caller's pose untouched
     const int maxIterations[] = {10, 20, 50, 50, 50};                     // TR.cpp:23
     int maxLevel = std::min(pyramidLevels - 1, 4);
     if (maxLevelOverride >= 0) maxLevel = std::min(maxLevel, maxLevelOverride);
@@ -198,6 +199,7 @@ DSOTracker::Residual DSOTracker::optimize(uint64_t new_image_id, int pyramidLeve
     double Hi[64];
     inverseSmall(H, 8, Hi);                                                                              // :243
     for (int k = 0; k < 6; k++) oldR.covariance[k] = Hi[k * 8 + k];
+    refToNewInOut = currentRefToNew;
     return oldR;
 }
 
@@ -333,8 +335,10 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
     if (tries) *tries = i;
     if (!haveOneGood) {
         if ((mFailureMode == 1 || mFailureMode == 2) && n_hyp > 0) {                       // :324-352: optimize(cameras[0]) with mLastResidual = trackingResult (not correct: no abort)
-            bestRefToNew = SE3::fromRt(R[0].R, R[0].t); bestExposure = initialExposure; bestExposure.a = R[0].a; bestExposure.b = R[0].b;
-            trackingResult = toResidual(R[0]);
+            bestRefToNew = hyp[0];                                                         // the reference re-runs optimize() on cameras[0]; an aborted run leaves the pose at cameras[0]
+            bestExposure = initialExposure;
+            mLastResidual = trackingResult;
+            trackingResult = optimize(new_image_id, pyramidLevels, bestRefToNew, referenceExposure, bestExposure);
             if (winner) *winner = 0;
             haveOneGood = true;
         } else {

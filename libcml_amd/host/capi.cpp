@@ -318,9 +318,9 @@ static std::vector<cml_amd::IndirectBundleAdjustment::Frame> to_frames(int n, co
     }
     return v;
 }
-static unsigned char* g_lba_stop = nullptr;
 int cmlhost_lba_local_optimize(void* h, int n_local, const cmlhost_lba_frame* local, int n_fixed, const cmlhost_lba_frame* fixed, int n_points,
-                               const cmlhost_lba_point* points, int n_app, const cmlhost_lba_apparition* app, int fix_frames) {
+                               const cmlhost_lba_point* points, int n_app, const cmlhost_lba_apparition* app, int fix_frames,
+                               unsigned char* stop_flag /* the reference's pbStopFlag for THIS call (IndirectBundleAdjustment.h:27), may be null */) {
     std::vector<cml_amd::IndirectBundleAdjustment::Point> P((size_t)n_points);
     for (int i = 0; i < n_points; i++) { P[i].id = points[i].id; P[i].referenceFrameId = points[i].reference_frame_id; for (int k = 0; k < 3; k++) P[i].X[k] = points[i].X[k]; }
     for (int a = 0; a < n_app; a++) {
@@ -329,9 +329,8 @@ int cmlhost_lba_local_optimize(void* h, int n_local, const cmlhost_lba_frame* lo
         P[(size_t)app[a].point].apparitions.push_back(A);
     }
     return static_cast<cml_amd::IndirectBundleAdjustment*>(h)->localOptimize(to_frames(n_local, local), to_frames(n_fixed, fixed), P, fix_frames != 0,
-                                                                             reinterpret_cast<bool*>(g_lba_stop)) ? 1 : 0;
+                                                                             reinterpret_cast<bool*>(stop_flag)) ? 1 : 0;
 }
-void cmlhost_lba_set_stop_flag(unsigned char* flag) { g_lba_stop = flag; }      // the pbStopFlag the next cmlhost_lba_local_optimize call passes (tests)
 int cmlhost_lba_apply(void* h, int n_local, cmlhost_lba_frame* local_out, int n_points, double* X_out, int* removals, int cap, cmlhip_lba_result* res) {
     std::vector<cml_amd::IndirectBundleAdjustment::Frame> F; std::vector<cml_amd::IndirectBundleAdjustment::Point> P;
     std::vector<cml_amd::IndirectBundleAdjustment::Removal> Rm;
