@@ -976,11 +976,26 @@ __global__ __launch_bounds__(256) void k_ba_assemble(int n, int off, SolveSys Y,
     }
 }
 
-template <int NSL, bool WIDE_OK = true, bool HYBRID = false>
+// K6 inside the K5 launch (round 3): the back-substitution's point workgroups and its frame-step workgroup ride in the solve launch as
+// further blocks, request everything that does not depend on x while the factorisation runs and continue when the solve workgroup
+// publishes x — one launch, its gap and the head of K6 less per iteration.  g_pts = 0: not merged.
+struct BacksubCall {
+    const double* adH; const double* adT; float* step_partial; FrameStepArgs F;
+    int g_pts;                 // point blocks of 512 threads (two virtual 256-thread blocks each)
+    int* xticket; int ticket;  // published by the solve workgroup after x
+};
+__device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket, const double* __restrict__ x, int n, double* __restrict__ s_x, int nthreads);
+template <int NT, bool INLAUNCH>
+__device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double* __restrict__ adH, const double* __restrict__ adT,
+                                                  const double* __restrict__ x_in, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
+                                                  int do_step, const FrameStepArgs& F, const double* __restrict__ xad, const int bx_, const int gx_,
+                                                  double* __restrict__ s_xAd, float* __restrict__ s_redf, const int* xticket, const int ticket);
+
+template <int NSL, bool WIDE_OK = true, bool HYBRID = false, bool MERGE = false>
 __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off, const SolveSys& Y, double* __restrict__ x, int* __restrict__ flag,
                                                 const int* newframe_res, int n_newframe, const double* lin_partial,
                                                 int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
-                                                const double* __restrict__ nullU, const double* __restrict__ indirect_x, const ReprojArgs& RP, const int bx_) {
+                                                const double* __restrict__ nullU, const double* __restrict__ indirect_x, const ReprojArgs& RP, const BacksubCall& BC, const int bx_) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
     DBG_BLK(A.dbg, 3, 0);
@@ -995,7 +1010,23 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
         // hybrid ORB term (config C): the per-frame workgroups of addIndirectToProblem run BESIDE the factorisation, in its launch — they
         // depend only on the frame states of the previous iteration; workgroup 0 picks their solutions up at its tail (tickets below)
         static_assert(RP_THREADS == SOLVE_THREADS, "the frame workgroups of the hybrid term run in the solve launch");
-        if constexpr (HYBRID) { if (RP.N > 0 && bx_ - 2 < RP.N) reproj_frame_block(RP, bx_ - 2, sm); }      // (its own instantiation: the term's local arrays give the kernel a scratch frame)
+        const int nrp = HYBRID ? RP.N : 0;
+        if constexpr (HYBRID) { if (bx_ - 2 < nrp) { reproj_frame_block(RP, bx_ - 2, sm); return; } }      // (its own instantiation: the term's local arrays give the kernel a scratch frame)
+        if constexpr (MERGE) {
+            const int b6 = bx_ - 2 - nrp;                     // block of the back-substitution: [frame step] [point blocks ...]
+            if (BC.g_pts > 0 && b6 >= 0) {
+                if (BC.F.on && b6 == 0) {
+                    if (wait_and_fetch_x(BC.xticket, BC.ticket, x, n, sm, SOLVE_THREADS)) frame_step_block(BC.F, sm);
+                    else if (tid == 0) atomicAdd(&lin_out->nonfinite, 1);
+                    return;
+                }
+                const int pb = b6 - (BC.F.on ? 1 : 0);
+                if (pb < BC.g_pts) {
+                    float* red = reinterpret_cast<float*>(sm + A.N * A.N * 8 + ((n + 1) & ~1));
+                    k_ba_backsub_body<SOLVE_THREADS, true>(A, BC.adH, BC.adT, x, lin_out, BC.step_partial, 1, BC.F, nullptr, pb, BC.g_pts, sm, red, BC.xticket, BC.ticket);
+                }
+            }
+        }
         return;
     }
     const int m = n - off, nb = (m + 15) / 16, mp = nb * 16;
@@ -1210,10 +1241,11 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
         if (same_launch) {
             if (tid < A.N) {
                 int spins = 0;
-                while (__hip_atomic_load(RP.ready + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != RP.ticket) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 21)) { *ind_flag = 2; break; }      // never spin forever: reported as a failed solve
+                while (__hip_atomic_load(RP.ready + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != RP.ticket) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 22)) { *ind_flag = 2; break; }      // never spin forever: reported as a failed solve
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
         }
@@ -1257,15 +1289,22 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
             } else {
                 for (int e = 0; e < 7; e++) v -= nullU[(size_t)e * n + i] * dots[e];
             }
-            x[i] = v;
+            if (MERGE && BC.g_pts > 0) __hip_atomic_store(x + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else x[i] = v;
             bad |= !isfinite(v);
         }
     } else {
         for (int i = tid; i < n; i += SOLVE_THREADS) {
             const double v = xs[i];
-            x[i] = v;
+            if (MERGE && BC.g_pts > 0) __hip_atomic_store(x + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else x[i] = v;
             bad |= !isfinite(v);
         }
+    }
+    if (MERGE && BC.g_pts > 0) {
+        // x is consumed by the back-substitution blocks of THIS launch: every writer fences at device scope, the workgroup meets, one lane
+        // publishes the ticket
+        if (tid < n) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // (the lanes that stored an entry of x)
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(BC.xticket, BC.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) *flag = 0;
     __syncthreads();
@@ -1273,12 +1312,12 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
     DBG_T(A, 53);
     DBG_BLK_END(A.dbg, 3);
 }
-template <int NSL, bool HYBRID>
+template <int NSL, bool HYBRID, bool MERGE>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int off, SolveSys Y, double* __restrict__ x, int* __restrict__ flag,
                                                             const int* newframe_res, int n_newframe, const double* lin_partial,
                                                             int n_partial, LinSummary* lin_out, FrameDev* frames_rw, int do_finish,
-                                                            const double* __restrict__ nullU, const double* __restrict__ indirect_x, ReprojArgs RP) {
-    k_ba_solve_body<NSL, true, HYBRID>(A, n, off, Y, x, flag, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw, do_finish, nullU, indirect_x, RP, blockIdx.x);
+                                                            const double* __restrict__ nullU, const double* __restrict__ indirect_x, ReprojArgs RP, BacksubCall BC) {
+    k_ba_solve_body<NSL, !MERGE, HYBRID, MERGE>(A, n, off, Y, x, flag, newframe_res, n_newframe, lin_partial, n_partial, lin_out, frames_rw, do_finish, nullU, indirect_x, RP, BC, blockIdx.x);
 }
 
 
@@ -1313,22 +1352,48 @@ __global__ __launch_bounds__(256) void k_ba_xad(const double* __restrict__ adH, 
 }
 
 // back-substitution (BA.cpp:1427-1487) + optional point update (doStepFromBackup, BA.cpp:976-994)
+// wait until the solve workgroup of THIS launch has published x (ticket, acquire at device scope), then copy x into LDS with
+// device-scope loads (a plain load could be served from a stale line of this XCD's L2).  false: gave up (never spin forever).
+__device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket, const double* __restrict__ x, int n, double* __restrict__ s_x, int nthreads) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int spins = 0, ok = 1;
+        // relaxed polls (an acquire load per poll would invalidate caches chip-wide at every turn), ONE acquire fence once the ticket is seen
+        while (__hip_atomic_load(xticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) { ok = 0; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += nthreads) s_x[e] = __hip_atomic_load(x + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// NT = 256: the standalone launch.  NT = 512, INLAUNCH: the point workgroups ride in the SOLVE launch (blocks of 512 threads = two
+// virtual 256-thread blocks: same points per virtual block, same partial sums, bit-identical results), request everything that does
+// not depend on x while the factorisation runs, and continue when the solve workgroup publishes x.
+template <int NT, bool INLAUNCH>
 __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double* __restrict__ adH, const double* __restrict__ adT,
-                                                  const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
-                                                  int do_step, const FrameStepArgs& F, const double* __restrict__ xad, const int bx_, const int gx_) {
-    extern __shared__ __attribute__((aligned(16))) double s_xAd[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
-    __shared__ float s_red[3][4];
+                                                  const double* __restrict__ x_in, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
+                                                  int do_step, const FrameStepArgs& F, const double* __restrict__ xad, const int bx_, const int gx_,
+                                                  double* __restrict__ s_xAd /* N*N*8 (+ n with INLAUNCH) */, float* __restrict__ s_redf /* [NT/256][3][4] */,
+                                                  const int* xticket, const int ticket) {
     const int N = A.N;
     DBG_BLK(A.dbg, 4, 0);
     if (A.ctl && A.ctl->stop) return;
-    if (F.on && bx_ == gx_ - 1) {               // last workgroup: the frames' half of doStepFromBackup
+    const double* __restrict__ x = x_in;
+    if (!INLAUNCH && F.on && bx_ == gx_ - 1) {               // last workgroup: the frames' half of doStepFromBackup
         frame_step_block(F, x);
         DBG_BLK_END(A.dbg, 4);
         return;
     }
+    const int half = NT == 512 ? (int)(threadIdx.x >> 8) : 0, t256 = threadIdx.x & 255, vbx = NT == 512 ? 2 * bx_ + half : bx_;
     // 8 lanes per point, one residual per lane per pass (a point has at most N-1 residuals): the chain by_point -> r ->
     // {good, target, JpJdF} is walked once per point, every load unconditional (clamped), masks multiplied in.
-    const int gid = bx_ * blockDim.x + threadIdx.x;
+    const int gid = vbx * 256 + t256;
     const int p = gid >> 3, i = gid & 7;
     const bool pv = p < A.P;
     const int pp = pv ? p : 0;
@@ -1338,7 +1403,6 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
     const float* pa = A.pt_acc + (size_t)pp * PT_ACC_STRIDE;
     const int host = A.pt_host[pp];
     const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
-    const double xc = x[i & 3];
     // (all passes' codes / targets / residual slots: up to 4 passes of 8 slots, CMLHIP_MAX_FRAMES = 32; clamped slots are masked)
     int codes[4], tgls[4], ress[4];
 #pragma unroll
@@ -1356,12 +1420,18 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
         const int r = max(codes[ps], 0) >> 1;
         v0s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r); v1s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r + 4);
     }
-    if (xad) {                                               // wide windows: the table was built once by k_ba_xad
-        for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) s_xAd[e] = xad[e];
-    } else {
-        for (int e = threadIdx.x; e < N * N * 8; e += blockDim.x) s_xAd[e] = xad_entry(adH, adT, x, N, e);
+    if (INLAUNCH) {
+        double* s_x = s_xAd + N * N * 8;
+        if (!wait_and_fetch_x(xticket, ticket, x_in, A.n, s_x, NT)) { if (threadIdx.x == 0) atomicAdd(&sum->nonfinite, 1); return; }
+        x = s_x;
     }
-    if (bx_ == 0 && threadIdx.x == 0) sum->nonfinite = 0;
+    const double xc = x[i & 3];
+    if (xad) {                                               // wide windows: the table was built once by k_ba_xad
+        for (int e = threadIdx.x; e < N * N * 8; e += NT) s_xAd[e] = xad[e];
+    } else {
+        for (int e = threadIdx.x; e < N * N * 8; e += NT) s_xAd[e] = xad_entry(adH, adT, x, N, e);
+    }
+    if (!INLAUNCH && bx_ == 0 && threadIdx.x == 0) sum->nonfinite = 0;      // (in the solve launch its workgroup 0 reset the counter at its start)
     __syncthreads();
     float sumID = 0, sumNID = 0, numID = 0;
     {
@@ -1415,11 +1485,12 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
     }
     if (do_step) {                                           // fixed-order block partials; the host adds the few blocks
         sumID = wave_sum(sumID); sumNID = wave_sum(sumNID); numID = wave_sum(numID);
-        if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = sumID; s_red[1][threadIdx.x >> 6] = sumNID; s_red[2][threadIdx.x >> 6] = numID; }
+        float* red = s_redf + 12 * half;                      // [3][4] of this virtual block
+        if ((threadIdx.x & 63) == 0) { red[0 * 4 + (t256 >> 6)] = sumID; red[1 * 4 + (t256 >> 6)] = sumNID; red[2 * 4 + (t256 >> 6)] = numID; }
         __syncthreads();
-        if (threadIdx.x < 3) {
-            const int k = threadIdx.x;
-            step_partial[4 * bx_ + k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
+        if (t256 < 3 && vbx < A.n_step_blocks) {
+            const int k = t256;
+            step_partial[4 * vbx + k] = ((red[k * 4 + 0] + red[k * 4 + 1]) + red[k * 4 + 2]) + red[k * 4 + 3];
         }
     }
     DBG_BLK_END(A.dbg, 4);
@@ -1427,7 +1498,9 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
 __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,
                                                     const double* __restrict__ x, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
                                                     int do_step, FrameStepArgs F, const double* __restrict__ xad) {
-    k_ba_backsub_body(A, adH, adT, x, sum, step_partial, do_step, F, xad, blockIdx.x, gridDim.x);
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
+    __shared__ float s_red[12];
+    k_ba_backsub_body<256, false>(A, adH, adT, x, sum, step_partial, do_step, F, xad, blockIdx.x, gridDim.x, s_dyn, s_red, nullptr, 0);
 }
 
 
@@ -1535,7 +1608,7 @@ int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A) {
     return CMLHIP_OK;
 }
 
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho, const double* indirect_x, const ReprojArgs* rp) {
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho, const double* indirect_x, const ReprojArgs* rp, bool merge_backsub) {
     const int n = A.n, off = optcal ? 0 : 4, m = n - off;
     const size_t sh = solve_lds_bytes(m);
     int* flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
@@ -1557,19 +1630,46 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
     ReprojArgs RPv;
     memset(&RPv, 0, sizeof RPv);
     if (rp) RPv = *rp;                                          // hybrid term: its per-frame workgroups ride in this launch (blocks 2 .. 2 + N)
-#define LAUNCH_SOLVE_H(NSL, HYB, BIT) do { \
-        if (!(c->attr_done & (1u << (BIT)))) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL, HYB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c->attr_done |= 1u << (BIT); } \
-        k_ba_solve<NSL, HYB><<<rp ? 2 + rp->N : (with_lin_finish ? 2 : 1), SOLVE_THREADS, sh, c->stream>>>(A, n, off, Y, c->xvec.as<double>(), flag, \
-            c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n, c->scal.as<LinSummary>(), \
-            c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, ortho ? c->null_basis.as<double>() : nullptr, indirect_x, RPv); } while (0)
-#define LAUNCH_SOLVE(NSL) do { \
+    // K6 in this launch (see BacksubCall): small windows of the resident loop only
+    BacksubCall BC;
+    memset(&BC, 0, sizeof BC);
+    const bool merge = merge_backsub && !wide && with_lin_finish && !(A.N >= 12 && A.P >= 2048) && A.P > 0;
+    if (merge) {
+        BC.adH = c->adH.as<double>(); BC.adT = c->adT.as<double>(); BC.step_partial = c->step_partial.as<float>();
+        FrameStepArgs& F = BC.F;
+        F.on = c->resident_on ? 1 : 0;
+        if (F.on) {
+            F.fs = c->frame_state.as<cmlhip_ba_frame_state>(); F.pairs = c->pairs.as<cmlhip_ba_pair>(); F.pre_w2c = c->pre_w2c.as<double>();
+            F.adH = c->adH.as<double>(); F.adT = c->adT.as<double>(); F.adHTd = c->adHTd.as<float>();
+            F.dprior = c->vec_small.as<double>() + 8 + 8 * A.N;
+            for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
+            F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
+        }
+        BC.g_pts = cml_div_up(A.P * 8, 512);
+        if (int rc = cml_ensure(c, c->x_ticket, 64)) return rc;
+        if (!c->x_ticket_zeroed) { CML_CHECK(c, hipMemsetAsync(c->x_ticket.p, 0, 64, c->stream)); c->x_ticket_zeroed = true; }
+        BC.xticket = c->x_ticket.as<int>(); BC.ticket = ++c->x_ticket_seq;
+    }
+    if (merge && c->ext_stop_if_merged) c->ext_stop = c->ext_stop_if_merged;
+    c->ext_stop_if_merged = nullptr;
+    const int grid = (rp || merge) ? 2 + (rp ? rp->N : 0) + (merge ? BC.F.on + BC.g_pts : 0) : (with_lin_finish ? 2 : 1);
+    size_t shm = sh;
+    if (merge) shm = std::max(shm, (size_t)(A.N * A.N * 8 + ((n + 1) & ~1) + 16) * sizeof(double));
+#define LAUNCH_SOLVE_H(NSL, HYB, MRG, BIT) do { \
+        if (!(c->attr_done & (1u << (BIT)))) { (void)hipFuncSetAttribute((const void*)k_ba_solve<NSL, HYB, MRG>, hipFuncAttributeMaxDynamicSharedMemorySize, (MRG) ? 96 * 1024 : 160 * 1024); c->attr_done |= 1u << (BIT); } \
+        CML_LAUNCH_EV(c, (k_ba_solve<NSL, HYB, MRG>), grid, SOLVE_THREADS, shm, A, n, off, Y, c->xvec.as<double>(), flag, \
+            (const int*)c->newframe_res.as<int>(), c->n_newframe, (const double*)c->lin_partial.as<double>(), c->lin_partial_n, c->scal.as<LinSummary>(), \
+            c->frames.as<FrameDev>(), with_lin_finish ? 1 : 0, (const double*)(ortho ? c->null_basis.as<double>() : nullptr), indirect_x, RPv, BC); } while (0)
+#define LAUNCH_SOLVE(NSL, B0) do { \
         if (wide) k_ba_assemble<NSL><<<nblk, 256, 0, c->stream>>>(n, off, Y, stopp); \
-        if (rp) LAUNCH_SOLVE_H(NSL, true, 16 + NSL); else LAUNCH_SOLVE_H(NSL, false, NSL); } while (0)
+        if (rp && merge) LAUNCH_SOLVE_H(NSL, true, true, (B0) + 3); else if (rp) LAUNCH_SOLVE_H(NSL, true, false, (B0) + 2); \
+        else if (merge) LAUNCH_SOLVE_H(NSL, false, true, (B0) + 1); else LAUNCH_SOLVE_H(NSL, false, false, (B0)); } while (0)
+    c->backsub_merged = merge;
     switch (Y.nsl) {
-        case 1: LAUNCH_SOLVE(1); break;
-        case 2: LAUNCH_SOLVE(2); break;
-        case 4: LAUNCH_SOLVE(4); break;
-        default: LAUNCH_SOLVE(8); break;
+        case 1: LAUNCH_SOLVE(1, 0); break;
+        case 2: LAUNCH_SOLVE(2, 4); break;
+        case 4: LAUNCH_SOLVE(4, 8); break;
+        default: LAUNCH_SOLVE(8, 12); break;
     }
 #undef LAUNCH_SOLVE
 #undef LAUNCH_SOLVE_H
@@ -1642,13 +1742,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_batch(const BatchWin
     const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
     ReprojArgs RP0;
     RP0.N = 0; RP0.ready = nullptr; RP0.ticket = 0;         // the hybrid term is not batched
+    BacksubCall BC0;
+    BC0.g_pts = 0; BC0.xticket = nullptr; BC0.ticket = 0; BC0.F.on = 0;
     k_ba_solve_body<NSL, false>(w.A, w.n, w.off, w.Y, w.x, w.flag, w.newframe_res, w.n_newframe, w.lin_partial, w.n_partial, w.lin_out, w.frames_rw, 1, w.nullU,
-                         nullptr, RP0, blockIdx.x);
+                         nullptr, RP0, BC0, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_ba_backsub_batch(const BatchWin* __restrict__ W) {
     const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
     if ((int)blockIdx.x >= w.g_back) return;
-    k_ba_backsub_body(w.A, w.adH, w.adT, w.x, w.lin_out, w.step_partial, 1, w.F, nullptr, blockIdx.x, w.g_back);
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    __shared__ float s_red[12];
+    k_ba_backsub_body<256, false>(w.A, w.adH, w.adT, w.x, w.lin_out, w.step_partial, 1, w.F, nullptr, blockIdx.x, w.g_back, s_dyn, s_red, nullptr, 0);
 }
 
 int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {

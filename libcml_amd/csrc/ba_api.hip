@@ -541,10 +541,14 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     ReprojArgs rp;
     if (mix) cml_resident_reproj_args(c, lambda, c->resident_iter + 1, &rp);   // its per-frame workgroups ride in the solve launch
     // K5: solve (+ hybrid term beside it, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
-    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rr_x.as<double>() : nullptr, mix ? &rp : nullptr))) return rc;
+    static const bool no_merge = getenv("CMLHIP_NO_MERGE") != nullptr;          // development: K6 as its own launch
+    c->ext_stop_if_merged = (prof && !no_merge) ? ev[1] : nullptr;      // (merged: the end of the K5 + K6 dispatch closes the Schur-reduce + solve group)
+    if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rr_x.as<double>() : nullptr, mix ? &rp : nullptr, !no_merge))) return rc;
     c->resident_iter++;
-    if (prof) c->ext_stop = ev[1];                           // end timestamp of the K6 dispatch
-    cml_launch_backsub(c, A, true);                          // K6: back-substitution + point update
+    if (!c->backsub_merged) {
+        if (prof) c->ext_stop = ev[1];                        // end timestamp of the K6 dispatch
+        cml_launch_backsub(c, A, true);                       // K6: back-substitution + point update
+    }
     if (prof) { c->ext_start = ev[2]; c->ext_stop = ev[3]; } // begin / end timestamps of the K1 dispatch itself
     if (c->rs_ok) {                                          // K1: residuals + Jacobians + applyRes, Jacobians kept in reduced form
         cml_launch_linearize_rs(c, A);

@@ -105,7 +105,8 @@ int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy);
 // K3 (pair blocks + point rows) and K4 (system tiles: H_A, H_L, H_sc and the final LM system for `lambda` / optional HM)
 int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only = false, bool marg = false);
 struct ReprojArgs;
-int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho = false, const double* indirect_x = nullptr, const ReprojArgs* rp = nullptr);
+int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_finish, bool ortho = false, const double* indirect_x = nullptr, const ReprojArgs* rp = nullptr,
+                     bool merge_backsub = false);      // merge_backsub: the back-substitution rides in this launch (c->backsub_merged tells whether it did)
 void cml_resident_reproj_args(cmlhip_ctx* c, double lambda, int ticket, ReprojArgs* out);      // reproj.hip: the hybrid term of the resident iteration
 int cml_launch_reproj_resident(cmlhip_ctx* c, double lambda);        // reproj.hip: addIndirectToProblem on the resident frame states -> rp_x
 int cml_launch_schur_out(cmlhip_ctx* c, const BAArgs& A);

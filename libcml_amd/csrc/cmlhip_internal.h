@@ -77,6 +77,7 @@ struct cmlhip_ctx {
     // Kernel timing of the resident iteration (cmlhip_profile_enable): the events ride ON the dispatches (hipExtLaunchKernelGGL
     // start / stop events = the dispatch's own begin / end timestamps, what rocprofv3 --kernel-trace reads), not around them
     hipEvent_t ext_start = nullptr, ext_stop = nullptr;       // consumed by the next CML_LAUNCH_EV
+    hipEvent_t ext_stop_if_merged = nullptr;                  // stop event for the solve launch when the back-substitution rides in it
     std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration: K3 begin, K6 end, K1 begin, K1 end
     int prof_cap = 0, prof_n = 0, prof_stride = 1, prof_tick = 0;
 
@@ -137,6 +138,7 @@ struct cmlhip_ctx {
     DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt, cd_pts;      // makeCoarseDepth scratch
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x, rp_off, rp_orig; int rp_acc_N = 0;
+    DevBuf x_ticket; bool x_ticket_zeroed = false, backsub_merged = false; int x_ticket_seq = 0;      // K6 inside the K5 launch (BacksubCall)
     DevBuf batch_main, batch_rs; std::vector<unsigned char> batch_main_host, batch_rs_host; unsigned attr_done_batch = 0;   // cmlhip_ba_iteration_batch (kept by the first context of the batch)
     DevBuf rr_obs, rr_off, rr_orig, rr_points, rr_jp, rr_used, rr_x, rr_ready; std::vector<int> rr_point_of;     // the resident hybrid term's own buffers
     bool rp_resident = false; int rp_res_M = 0, rp_res_n = 0; double rp_res_fx = 0, rp_res_fy = 0;   // hybrid term inside the resident iteration (cmlhip_ba_set_resident_indirect)
