@@ -43,7 +43,7 @@ rows = list(csv.DictReader(open(find(d1, "kernel_stats.csv"))))
 with open(os.path.join(OUT, tag + "_kernels.md"), "w") as f:
     f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py %s` on 1x MI355X\n\n" % " ".join(bench_args))
     f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
-    for r in rows[:16]:
+    for r in rows[:26]:
         f.write("| `%s` | %s | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
                                                              float(r["MaxNs"]) / 1e3, r["Percentage"]))
 KERNEL = os.environ.get("CML_PROF_KERNEL", "k_ba_lin")          # the residual kernel (k_ba_linearize<..> / k_ba_lin_rs<..>)
