@@ -417,10 +417,10 @@ def main():
     # spread: the contract region above is ONE sample (K steps can be a millisecond); eight more regions of the same K steps, same
     # protocol, reported beside it (not used for `value`)
     ctx.profile_enable(0)
-    rep = []
+    rep_ms = []
     for _ in range(8):
-        rep.append(1e3 * shard.timed_region(group, sync, run_steps) / args.steps)
-    rep.sort()
+        rep_ms.append(1e3 * shard.timed_region(group, sync, run_steps) / args.steps)
+    rep_ms.sort()
     # the events are the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL): no bracket overhead to subtract
     lin_ms, ss_ms = C.c_float(lin_v), C.c_float(ss_v)
     _dbg('profile read')
@@ -469,7 +469,7 @@ def main():
             "metric": "point-residuals/sec + Schur-reduce+solve ms, 8 KF x 2000 pts window",
             "value": total_units / dt, "unit": "point-residuals/s",
             "n_gpus": ranks_joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "ms_per_step_repeats": {"n": len(rep), "min": rep[0], "median": rep[len(rep) // 2], "max": rep[-1],
+            "ms_per_step_repeats": {"n": len(rep_ms), "min": rep_ms[0], "median": rep_ms[len(rep_ms) // 2], "max": rep_ms[-1],
                                     "note": "eight further timed regions of the same K steps after the contract region (same barrier / sync protocol)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("config C = config B + 1000 ORB reprojection residuals of 300 points mixed into the pose solution in every iteration; " if hybrid else "") + "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "

@@ -14,7 +14,11 @@ ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 1, None))
 for _ in range(1): ctx.ba_iteration_async(1e-5)
 ctx.sync()
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 0, out.ctypes.data_as(C.POINTER(C.c_longlong))))
-def seg(name, a, b): print("%-34s %7.2f us" % (name, (out[b] - out[a]) * 0.01))
+def seg(name, a, b):
+    if out[a] <= 0 or out[b] <= 0:
+        print("%-34s     n/a (not stamped on this path)" % name)
+    else:
+        print("%-34s %7.2f us" % (name, (out[b] - out[a]) * 0.01))
 seg("acc pair: load+accumulate loop", 16, 17); seg("acc pair: tile sum + H", 17, 18); seg("acc pair: fp64 stitch", 18, 19)
 seg("solve: load+scale (total)", 48, 49); seg("solve:   loads landed (wave 0)", 48, 54); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
 seg("solve: total", 48, 53)
@@ -26,7 +30,7 @@ blk = out[128:].reshape(5, 1024, 2)
 # pipeline order inside one iteration: acc, system, solve, backsub, linearize
 t0 = min(b[b[:, 0] > 0, 0].min() for b in blk if (b[:, 0] > 0).any())
 for k in (1, 2, 3, 4, 0):
-    b = blk[k]; b = b[b[:, 0] > 0]
+    b = blk[k]; b = b[(b[:, 0] > 0) & (b[:, 1] >= b[:, 0])]          # (blocks that only ride in a launch — hybrid-term / merged blocks — leave no end stamp)
     if len(b) == 0: continue
     st = (b[:, 0] - t0) * 0.01; en = (b[:, 1] - t0) * 0.01; d = en - st
     print("%-10s blocks %4d  first start %7.2f  last start %7.2f  last end %7.2f | block us: min %6.2f med %6.2f max %6.2f" %
