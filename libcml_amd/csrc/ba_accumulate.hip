@@ -79,11 +79,11 @@ typedef float float4_ __attribute__((ext_vector_type(4)));
 // (10 per record), PAIR_TRIP residuals per trip; wave w takes residuals w, w+16, ... of the trip and every lane reads its
 // operand elements from the staged record (distinct banks or broadcast).  The 16 wave tiles are added in wave order.
 // LINEARIZED mode (rare) computes res_toZero + J*delta per residual (BA.cpp:1699-1729) and stages the same 38 floats.
-__device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const int mode) {
+__device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const int mode, unsigned char* arena) {
     const bool TILES = mode == CML_MODE_ACTIVE_TILES;
     const bool LIN = mode != CMLHIP_MODE_ACTIVE && !TILES;  // LINEARIZED and MARGINALIZED walk the plain pair list
-    __shared__ float s_rec[PAIR_TRIP][PAIR_REC];
-    __shared__ float s_tile[16][256];
+    float (*s_rec)[PAIR_REC] = reinterpret_cast<float (*)[PAIR_REC]>(arena);
+    float (*s_tile)[256] = reinterpret_cast<float (*)[256]>(arena + sizeof(float) * PAIR_TRIP * PAIR_REC);
     __shared__ int s_cnt;
     __shared__ double s_H[13][13];
     __shared__ double s_AH[64], s_AT[64], s_T1[64], s_T2[64];
@@ -287,8 +287,8 @@ __device__ __forceinline__ double sum_slots_d(double v) {
     v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     return v;
 }
-__device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs& X, const int blk) {
-    __shared__ __attribute__((aligned(16))) double s_row[PT_PER_BLOCK][LDG_MAX];
+__device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs& X, const int blk, unsigned char* arena) {
+    double (*s_row)[LDG_MAX] = reinterpret_cast<double (*)[LDG_MAX]>(arena);
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, s = l >> 3, a = l & 7;
     const int p = blk * PT_PER_BLOCK + wv;
     if (p >= A.P) return;                                    // wave-uniform
@@ -390,11 +390,18 @@ __device__ __forceinline__ void k_ba_acc_body(const BAArgs& A, const AccArgs& X,
     // the point-row workgroups (16 points per 1024-thread block) take about twice as long as the pair workgroups at a wide window: they
     // are handed out FIRST, the short pair workgroups fill the tail of the launch
     const int npt = (int)gx_ - NN;
-    if ((int)bx_ < npt) point_rows_block(A, X, bx_);
-    else acc_pair_block(A, X, bx_ - npt, mode);
+    __shared__ __attribute__((aligned(16))) unsigned char s_arena[sizeof(float) * PAIR_TRIP * PAIR_REC + sizeof(float) * 16 * 256];
+    static_assert(sizeof(s_arena) >= sizeof(double) * PT_PER_BLOCK * LDG_MAX, "arena");
+    if ((int)bx_ < npt) point_rows_block(A, X, bx_, s_arena);
+    else acc_pair_block(A, X, bx_ - npt, mode, s_arena);
     DBG_BLK_END(A.dbg, 1);
 }
-__global__ __launch_bounds__(1024) void k_ba_acc(BAArgs A, AccArgs X, int mode) { k_ba_acc_body(A, X, mode, blockIdx.x, gridDim.x); }
+#ifdef CML_ACC_WPE8
+#define CML_ACC_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))      /* development: two 1024-thread workgroups per CU at 64 VGPRs (192 B of scratch) */
+#else
+#define CML_ACC_ATTR
+#endif
+__global__ __launch_bounds__(1024) CML_ACC_ATTR void k_ba_acc(BAArgs A, AccArgs X, int mode) { k_ba_acc_body(A, X, mode, blockIdx.x, gridDim.x); }
 
 
 // LINEARIZED-mode bd (BA.cpp:1699-1750), rare path: one thread per point
