@@ -29,7 +29,14 @@ struct TrkOptArgs {
     double K0[4], ref_a, ref_b, ref_t, new_t, init_a, init_b, sat_th;
     float huber, cutoff_base, scale_rot, scale_trans, scale_a, scale_b;
     const cmlhip_tracker_hypothesis* hyp;
-    cmlhip_tracker_opt_result* out;
+    cmlhip_tracker_opt_result* out;                    // n_hyp x G results (every workgroup of a hypothesis runs the whole loop; the host keeps the first)
+    // round 3: G workgroups per hypothesis.  A level with more than split_min reference points is evaluated in G parts, the 56 sums are
+    // exchanged through memory (device-scope stores + a ticket per workgroup) and added in workgroup order by EVERY workgroup — all of
+    // them then run the identical Levenberg-Marquardt algebra on identical numbers, no second exchange; smaller levels are evaluated
+    // whole by every workgroup (no exchange at all)
+    int G, split_min;
+    float* xch;                                        // [n_hyp][2 parities][G][64]
+    int* tick;                                         // [n_hyp][G]
 };
 
 // per-evaluation constants exactly as TR.cpp:260-278,426-429 forms them (float), shared by the workgroup
@@ -234,11 +241,43 @@ __device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3
 
 // all lanes: computeResidual + computeHessian over the level's list (the per-point arithmetic and the reduction layout of
 // k_tracker_eval, tracker.hip); leaves the 56 sums in s_red
+// the sums of this workgroup's part -> the sums of the level, in every workgroup of the hypothesis (see TrkOptArgs::G)
+__device__ __forceinline__ void to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, float* __restrict__ s_red) {
+    const int tid = threadIdx.x;
+    float* mine = xch + ((size_t)(seq & 1) * G + g) * 64;
+    if (tid < TO_NRED) __hip_atomic_store(mine + tid, s_red[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(tick + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ int s_late;
+    if (tid == 0) s_late = 0;
+    __syncthreads();
+    if (tid < G) {
+        int spins = 0;
+        // (a workgroup publishes ticket seq + 1 only after it has read every part of seq, so >= seq is "this part is there" and the
+        //  parity-indexed slots are never overwritten under a reader)
+        while (__hip_atomic_load(tick + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { s_late = 1; break; }          // never spin forever: the level then fails (no terms)
+        }
+    }
+    __syncthreads();
+    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid < TO_NRED) {
+        float v = 0.f;
+        for (int q = 0; q < G; q++) v += __hip_atomic_load(xch + ((size_t)(seq & 1) * G + q) * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_red[tid] = s_late ? 0.f : v;
+    }
+    __syncthreads();
+}
+
 template <bool HALF>
-__device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red) {
+__device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red,
+                        const int g, const int G, const int split_min, float* xch, int* tick, int& seq) {
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     to_float4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < E.n; base += TO_THREADS) {
+    const int Ge = (G > 1 && E.n > split_min) ? G : 1;       // parts of this level (1: every workgroup evaluates all of it)
+    for (int base = (Ge > 1 ? g : 0) * TO_THREADS; base < E.n; base += Ge * TO_THREADS) {
         const int i = base + tid;
         float va[16], vb[16];
 #pragma unroll
@@ -336,6 +375,7 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
         s_red[tid] = v;
     }
     __syncthreads();
+    if (Ge > 1) { seq++; to_exchange(xch, tick, g, G, seq, s_red); }
 }
 
 // wave 0: the level's sums -> Residual slots (lane 0) and the scaled 8x8 system, one entry per lane (TR.cpp:405-414, 472-490);
@@ -366,7 +406,7 @@ __device__ __forceinline__ int to_ctrl(const ToState& S) {
 
 // lane 0 books the time since the last mark as algebra, runs the evaluation, books it as evaluation
 #define TO_TIMED_EVAL() do { if (tid == 0) { const long long t_ = wall_clock64(); S.t_alg += t_ - S.t_mark; S.t_mark = t_; } \
-        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red); \
+        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, g, A.G, A.split_min, xch, tick, seq); \
         if (tid == 0) { const long long t_ = wall_clock64(); S.t_eval += t_ - S.t_mark; S.t_mark = t_; } } while (0)
 
 enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
@@ -379,8 +419,11 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ ToEval ev;
     __shared__ ToState S;
     __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
-    const int tid = threadIdx.x, hyp = blockIdx.x;
-    cmlhip_tracker_opt_result* out = A.out + hyp;
+    const int tid = threadIdx.x, hyp = blockIdx.x / A.G, g = blockIdx.x % A.G;
+    cmlhip_tracker_opt_result* out = A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical)
+    float* xch = A.xch + (size_t)hyp * 2 * A.G * 64;
+    int* tick = A.tick + (size_t)hyp * A.G;
+    int seq = 0;
     const int maxIterations[5] = {10, 20, 50, 50, 50};                               // TR.cpp:23
     const int maxLevel = min(A.levels - 1, 4);
     if (tid == 0) {
@@ -545,12 +588,26 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     A.scale_a = prm->scale_a; A.scale_b = prm->scale_b;
     A.opt_a = optimize_a; A.opt_b = optimize_b; A.sat_th = saturated_ratio_th; A.n_hyp = n_hyp;
     int rc;
+    // workgroups per hypothesis: as many as keep every workgroup of the launch resident at once (they wait for one another), at most 8
+    static const char* e_g = getenv("CMLHIP_TRACKER_G");                  // development: force G
+    int G = e_g ? atoi(e_g) : std::min(8, 256 / n_hyp);
+    if (G < 1) G = 1;
+    if (n_hyp * G > 256) G = std::max(1, 256 / n_hyp);
+    A.G = G; A.split_min = 2 * TO_THREADS;
     if ((rc = cml_ensure(c, c->trk_hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
-    if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp))) return rc;
+    if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp * G))) return rc;
+    const size_t xch_bytes = sizeof(float) * 2 * 64 * (size_t)G * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
+    if ((rc = cml_ensure(c, c->trk_xch, xch_bytes + tick_bytes))) return rc;
     if ((rc = cml_h2d(c, c->trk_hyp.p, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
     A.hyp = c->trk_hyp.as<cmlhip_tracker_hypothesis>(); A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp, TO_THREADS, 0, A);
-    else CML_LAUNCH_EV(c, k_tracker_optimize<false>, n_hyp, TO_THREADS, 0, A);
+    A.xch = c->trk_xch.as<float>(); A.tick = reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes);
+    if (G > 1) CML_CHECK(c, hipMemsetAsync(A.tick, 0, tick_bytes, c->stream));
+    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp * G, TO_THREADS, 0, A);
+    else CML_LAUNCH_EV(c, k_tracker_optimize<false>, n_hyp * G, TO_THREADS, 0, A);
     CML_CHECK(c, hipGetLastError());
-    return cml_d2h(c, out, c->trk_opt_out.p, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
+    if (G == 1) return cml_d2h(c, out, c->trk_opt_out.p, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
+    std::vector<cmlhip_tracker_opt_result> all((size_t)n_hyp * G);
+    if ((rc = cml_d2h(c, all.data(), c->trk_opt_out.p, sizeof(cmlhip_tracker_opt_result) * all.size()))) return rc;
+    for (int i = 0; i < n_hyp; i++) out[i] = all[(size_t)i * G];
+    return CMLHIP_OK;
 }
