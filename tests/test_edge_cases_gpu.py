@@ -197,3 +197,34 @@ def test_reproj_without_observations():
         assert not M6.any() and not b6.any() and len(used) == 0
     finally:
         ctx.close()
+
+
+def test_window_is_invalidated_when_its_images_go_away():
+    """An uploaded window points into the level-0 images it names: rebuilding, resizing or dropping one of them must make the BA entry
+    points fail with CMLHIP_ERR_STATE (round 3, ADVICE: they used to read the recycled blocks), a same-size put must not."""
+    I = S.make_inputs("tiny")
+    ctx = D.make_ctx(I)
+    try:
+        r0 = ctx.ba_linearize()
+        img = int(I.frames_dev["image_id"][1])
+        ctx.pyramid_put(img, 0, I.grads[1][0])                    # same size: texels rewritten in place, the window stays valid
+        r1 = ctx.ba_linearize()
+        assert r1.n_in > 0
+        pairs, th, b0 = ctx.ba_pairs()                              # (the readback the replay checker uses)
+        assert np.array_equal(pairs["R"], I.pairs["R"]) and np.array_equal(b0, I.frames_dev["b0"])
+        ctx.pyramid_drop(img)
+        with pytest.raises(device.CmlHipError) as e:
+            ctx.ba_linearize()
+        assert e.value.code == abi.ERR_STATE
+        ctx.pyramid_put(img, 0, I.grads[1][0])
+        with pytest.raises(device.CmlHipError):                     # still invalid until the window is uploaded again
+            ctx.ba_linearize()
+        ctx.ba_upload_window(I.frames_dev, I.points, I.residuals)
+        ctx.ba_set_pairs(I.pairs)
+        r2 = ctx.ba_linearize()
+        assert (r2.n_in, r2.n_oob, r2.n_outlier) == (r0.n_in, r0.n_oob, r0.n_outlier)        # a fresh upload: the first pass again
+        ctx.pyramid_build(img, I.W.gray[1], 1)                      # rebuilt from gray: new blocks
+        with pytest.raises(device.CmlHipError):
+            ctx.ba_linearize()
+    finally:
+        ctx.close()
