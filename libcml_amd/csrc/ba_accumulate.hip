@@ -1252,8 +1252,7 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1 << 22)) { *ind_flag = 2; break; }      // never spin forever: reported as a failed solve
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
+            }                                            // (the solutions are then read with device-scope loads: no acquire fence)
             __syncthreads();
         }
         int mybad = 0;
@@ -1309,7 +1308,9 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
     if (MERGE && BC.g_pts > 0) {
         // x is consumed by the back-substitution blocks of THIS launch: every writer fences at device scope, the workgroup meets, one lane
         // publishes the ticket
-        if (tid < n) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // (the lanes that stored an entry of x)
+        // (x was written with device-scope stores — they go past the non-coherent caches —, so the lanes only have to see them
+        //  acknowledged before the workgroup meets: no release fence, which would write the whole L2 back)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(BC.xticket, BC.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1370,8 +1371,7 @@ __device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket,
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1 << 22)) { ok = 0; break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        s_ok = ok;
+        s_ok = ok;                                // (x is then read with device-scope loads: no acquire fence, which would invalidate the caches)
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += nthreads) s_x[e] = __hip_atomic_load(x + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -308,9 +308,10 @@ __device__ inline void reproj_frame_block(const ReprojArgs& a, int i, double* __
             reproj_solve6(Mf, bf, a.lambda, xs);
             if (a.ready) {
                 // consumed by ANOTHER workgroup of the same launch (the solve workgroup of the resident iteration): device-scope stores,
-                // then the frame's ticket with release semantics — the consumer spins on it with acquire loads
+                // then, once they are acknowledged, the frame's ticket — the consumer polls it and reads the solution with device-scope loads
                 for (int r = 0; r < 6; r++) __hip_atomic_store(a.x6 + 6 * (size_t)i + r, xs[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.ready + i, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // device-scope stores acknowledged: no release fence (an L2 write-back) needed
+                __hip_atomic_store(a.ready + i, a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 for (int r = 0; r < 6; r++) a.x6[6 * (size_t)i + r] = xs[r];
             }
