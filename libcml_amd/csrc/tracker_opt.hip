@@ -54,6 +54,9 @@ struct ToState {
     int nT[5], nS[5], nR[5], nT_new[5], nS_new[5], nR_new[5], iterations[5];
     int ctrl, n_steps, n_pass, haveRepeated;
     long long t_eval, t_alg, t_mark;                   // wall_clock64 ticks (10 ns): evaluations / lane-0 algebra
+#ifdef TO_PROFILE
+    long long t_ldlt, t_pose, t_fin;
+#endif
 };
 
 template <bool HALF>
@@ -218,21 +221,25 @@ __device__ __forceinline__ void to_store(const SE3& T, double q[4], double t[3])
     for (int i = 0; i < 4; i++) q[i] = T.q[i];
     for (int i = 0; i < 3; i++) t[i] = T.t[i];
 }
-__device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3& T, double a, double b, double cutoff_mult) {
-    const double d = (double)(1 << level);
-    const double K[4] = {A.K0[0] / d, A.K0[1] / d, (A.K0[2] + 0.5) / d - 0.5, (A.K0[3] + 0.5) / d - 0.5};
+__device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3& T, double a, double b, double cutoff_mult, const bool same_level = false) {
     double R[9];
     T.matrix(R);
     const double affA = exp(a - A.ref_a) * A.new_t / A.ref_t, affB = b - affA * A.ref_b;      // reference->getExposure().to(exposure)
-    float Kf[9] = {(float)K[0], 0, (float)K[2], 0, (float)K[1], (float)K[3], 0, 0, 1}, Rf[9];
-    to_inv3f(Kf, ev.Ki);
+    float Rf[9];
+    if (!same_level) {                                      // the level's pinhole and its inverse: once per level, not once per trial (same values)
+        const double d = (double)(1 << level);
+        const double K[4] = {A.K0[0] / d, A.K0[1] / d, (A.K0[2] + 0.5) / d - 0.5, (A.K0[3] + 0.5) / d - 0.5};
+        float Kf[9] = {(float)K[0], 0, (float)K[2], 0, (float)K[1], (float)K[3], 0, 0, 1};
+        to_inv3f(Kf, ev.Ki);
+        ev.fxl = Kf[0]; ev.fyl = Kf[4]; ev.cxl = Kf[2]; ev.cyl = Kf[5];
+        ev.fxh = (float)K[0]; ev.fyh = (float)K[1];
+    }
     for (int i = 0; i < 9; i++) Rf[i] = (float)R[i];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) ev.RKi[i * 3 + j] = Rf[i * 3] * ev.Ki[j] + (Rf[i * 3 + 1] * ev.Ki[3 + j] + Rf[i * 3 + 2] * ev.Ki[6 + j]);   // Matrix33f product, Eigen order
     for (int i = 0; i < 3; i++) ev.t[i] = (float)T.t[i];
-    ev.fxl = Kf[0]; ev.fyl = Kf[4]; ev.cxl = Kf[2]; ev.cyl = Kf[5];
     ev.a0 = (float)affA; ev.a1 = (float)affB;
-    ev.fxh = (float)K[0]; ev.fyh = (float)K[1]; ev.b0 = (float)A.ref_b; ev.a_h = (float)affA;
+    ev.b0 = (float)A.ref_b; ev.a_h = (float)affA;
     const float cutoff = (float)((double)A.cutoff_base * cutoff_mult);                      // mCutoffThreshold.f() * levelCutoffRepeat[level]
     ev.huber_d = (double)A.huber; ev.cutoff_d = (double)cutoff; ev.cutoff_base_d = (double)A.cutoff_base;
     ev.maxEnergy = (float)(2.0f * ev.huber_d * ev.cutoff_d - ev.huber_d * ev.huber_d);
@@ -433,6 +440,9 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k] = 0;
         S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl = TO_CONTINUE;
         S.t_eval = 0; S.t_alg = 0; S.t_mark = wall_clock64();
+#ifdef TO_PROFILE
+        S.t_ldlt = S.t_pose = S.t_fin = 0;
+#endif
     }
     __syncthreads();
     bool failed = false;
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                 if (S.nT[level] < 20) c = TO_FAIL;                                                           // :65-69
                 else if ((S.nS[level] / (double)S.nT[level]) > 0.6 && S.levelCutoffRepeat[level] < 50) {     // :71-75
                     S.levelCutoffRepeat[level] *= 2;
-                    to_prepare(A, ev, level, to_pose(S.cur_q, S.cur_t), S.a, S.b, S.levelCutoffRepeat[level]);
+                    to_prepare(A, ev, level, to_pose(S.cur_q, S.cur_t), S.a, S.b, S.levelCutoffRepeat[level], true);
                     c = TO_REPEAT_SAT;
                 } else if (S.nT[level] - S.nS[level] < 10) c = TO_FAIL;                                      // :77-81
                 S.ctrl = c; S.lambda = 0.01;
@@ -465,7 +475,14 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                 const int nsolve = (A.opt_a && A.opt_b) ? 8 : ((A.opt_a || A.opt_b) ? 7 : 6);
                 const int map6 = (!A.opt_a && A.opt_b) ? 7 : 6;
                 double xs[8];
+#ifdef TO_PROFILE
+                const long long tp0 = wall_clock64();
+#endif
                 const bool ok = to_ldlt_solve_wave(S.H, S.bv, S.lambda, nsolve, map6, xs);
+#ifdef TO_PROFILE
+                const long long tp1 = wall_clock64();
+                if (tid == 0) S.t_ldlt += tp1 - tp0;
+#endif
               if (tid == 0) {
                 S.iterations[level] = iteration + 1;
                 double* inc = s_winc;
@@ -486,13 +503,19 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     to_store(nw, S.nw_q, S.nw_t);
                     S.na = S.a + incS[6]; S.nb = S.b + incS[7];                                             // :159
                     S.Hn[0] = sqrt(nrm);                                                                    // |increment| parked for the exit test below
-                    to_prepare(A, ev, level, nw, S.na, S.nb, S.levelCutoffRepeat[level]);
+                    to_prepare(A, ev, level, nw, S.na, S.nb, S.levelCutoffRepeat[level], true);
                     S.ctrl = TO_ITERATE;
                 }
+#ifdef TO_PROFILE
+                S.t_pose += wall_clock64() - tp1;
+#endif
               }
             }
             if (to_ctrl(S) == TO_FAIL) { failed = true; break; }
             TO_TIMED_EVAL();
+#ifdef TO_PROFILE
+            const long long tf0 = wall_clock64();
+#endif
             if (tid < 64) {
                 const double incnorm = S.Hn[0];                                                             // (lane 0's own note, read before its slot is rewritten)
                 to_finish(A, s_red, S.E_new[level], S.nT_new[level], S.nS_new[level], S.nR_new[level], S.flow_new, S.Hn, S.bn);
@@ -517,6 +540,9 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     S.ctrl = (incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE;                                 // :176-179
                 }
             }
+#ifdef TO_PROFILE
+            if (tid == 0) S.t_fin += wall_clock64() - tf0;
+#endif
             if (to_ctrl(S) == TO_LEVEL_DONE) break;
         }
         if (failed) break;
@@ -543,6 +569,9 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         out->n_steps = S.n_steps; out->n_pass = S.n_pass < 8 ? S.n_pass : 8;
         out->eval_us = 0.01 * (double)S.t_eval; out->algebra_us = 0.01 * (double)(S.t_alg + (wall_clock64() - S.t_mark));
         for (int k = 0; k < 6; k++) out->covariance[k] = 999999;
+#ifdef TO_PROFILE
+        out->pass_rmse[7] = 0.01 * (double)S.t_ldlt; out->pass_rmse[6] = 0.01 * (double)S.t_pose; out->pass_rmse[5] = 0.01 * (double)S.t_fin;
+#endif
         out->relAff[0] = out->relAff[1] = 0;
         if (failed) {
             out->isCorrect = 0; out->tooManySaturated = 1;
