@@ -38,8 +38,10 @@ extern "C" {
 #define CMLHIP_CPARS 4          /* calibration block size, ACC.h:26 */
 #define CMLHIP_MAX_FRAMES 32    /* window size limit of the upload / accumulate / Schur kernels (reference default maxFrames = 6, BA.h:271) */
 /* Hard caps that are REFUSALS (CMLHIP_ERR_INVALID with a message in cmlhip_last_error), not fallbacks:
- *   - cmlhip_ba_solve / cmlhip_ba_iteration_async: the factorisation is LDS-resident, 8N (+4 with optimize_calibration) <= 160,
- *     i.e. N <= 20 (19 with the calibration block).  Wider windows upload, linearize and accumulate, and are refused by the solve.
+ *   - cmlhip_ba_iteration_batch and the hybrid (ORB) term of cmlhip_ba_iteration_async: windows whose factorisation is LDS-resident,
+ *     8N (+4 with optimize_calibration) <= 160, i.e. N <= CMLHIP_MAX_SOLVE_FRAMES (19 with the calibration block).
+ *     cmlhip_ba_solve and the plain cmlhip_ba_iteration_async take every window up to CMLHIP_MAX_FRAMES: above that size the
+ *     factorisation runs in global memory (one workgroup, ~1 ms at N = 32; a correctness path — the reference's windows hold 6-7 keyframes).
  *   - cmlhip_pnp_optimize: at most CMLHIP_PNP_MAX_MATCHES matches (LDS-resident match list).
  *   - the dense LDL^T is unpivoted (Eigen's ldlt() pivots): it relies on the Jacobi scaling 1/sqrt(diag + 10) of BA.cpp:1312-1316,
  *     which bounds the scaled diagonal; a non-finite or non-positive pivot is reported as CMLHIP_ERR_NONFINITE. */

@@ -1329,6 +1329,88 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(BAArgs A, int n, int
 }
 
 
+// Windows wider than the LDS-resident factorisation takes (8N (+4) > 160, i.e. N = 21 ... 32): the same system — assembled and Jacobi-
+// scaled by k_ba_assemble in the block-packed layout — factorised IN GLOBAL MEMORY by one workgroup, column by column (right-looking
+// LDL^T, the right-hand side riding along; same zero-pivot rule, same D^-1 and back-substitution, same tail as k_ba_solve).  A
+// correctness path, not a fast one (the reference's windows hold 6-7 keyframes; this one is ~1 ms at N = 32): it exists so that
+// CMLHIP_MAX_FRAMES is a limit of the whole iteration and not only of its first half.
+#define SG_THREADS 1024
+#define SG_MAX 272
+__global__ __launch_bounds__(SG_THREADS) void k_ba_solve_global(BAArgs A, int n, int off, double* __restrict__ image, double* __restrict__ x, int* __restrict__ flag,
+                                                               LinSummary* lin_out, const double* __restrict__ nullU, const double* __restrict__ indirect_x) {
+    __shared__ double s_w[SG_MAX], s_l[SG_MAX], s_y[SG_MAX], s_d[SG_MAX], s_sv[SG_MAX], s_x[SG_MAX], s_dot[8];
+    __shared__ double s_dk, s_yk;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    if (A.ctl && A.ctl->stop) return;
+    const int m = n - off, nb = (m + 15) / 16, mp = nb * 16;
+    double* L = image;
+    const double* tail = image + (size_t)(nb * (nb + 1) / 2) * BSZ;                // SVecI | scaled rhs
+    auto at = [&](int i, int j) -> double& { return L[blk_off(i >> 4, j >> 4) + (i & 15) * BLD + (j & 15)]; };    // j <= i
+    if (tid == 0) { lin_out->nonfinite = 0; s_bad = 0; }
+    for (int i = tid; i < mp; i += SG_THREADS) { s_sv[i] = tail[i]; s_y[i] = tail[mp + i]; }
+    __syncthreads();
+    for (int k = 0; k < mp; k++) {
+        if (tid == 0) { s_dk = at(k, k); s_yk = s_y[k]; }
+        __syncthreads();
+        const double d = s_dk, yk = s_yk;
+        const bool tiny = !(fabs(d) > 2.2250738585072014e-308);                  // zero pivot of a positive semi-definite system: column skipped (see k_ba_solve)
+        for (int i = k + 1 + tid; i < mp; i += SG_THREADS) {
+            const double w = at(i, k), l = tiny ? 0.0 : w / d;
+            s_w[i] = w; s_l[i] = l;
+            at(i, k) = l;
+            s_y[i] -= l * yk;
+        }
+        if (tid == 0) s_d[k] = d;
+        __syncthreads();
+        // trailing update A_ij -= w_i l_j, k < j <= i: 32 rows per pass, a row's columns over 32 lanes
+        for (int i = k + 1 + (tid >> 5); i < mp; i += SG_THREADS / 32) {
+            const double wi = s_w[i];
+            for (int j = k + 1 + (tid & 31); j <= i; j += 32) at(i, j) -= wi * s_l[j];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int i = tid; i < mp; i += SG_THREADS) { const double d = s_d[i]; s_y[i] = (fabs(d) > 2.2250738585072014e-308) ? s_y[i] / d : 0.0; }
+    __syncthreads();
+    for (int k = mp - 1; k >= 0; k--) {                                           // L^T x = z
+        const double xk = s_y[k];
+        for (int i = tid; i < k; i += SG_THREADS) s_y[i] -= at(k, i) * xk;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += SG_THREADS) s_x[i] = (i < off) ? 0.0 : s_sv[i - off] * s_y[i - off];
+    __syncthreads();
+    if (indirect_x) {                                                             // hybrid ORB term, the literal weighting of BA.cpp:2714-2727
+        int mybad = 0;
+        for (int i = tid; i < 6 * A.N; i += SG_THREADS) mybad |= !isfinite(indirect_x[i]);
+        if (mybad) s_bad = 1;
+        __syncthreads();
+        if (!s_bad) {
+            const double indirectRatio = 1.0 / (1.0 + 0.0), directRatio = 1.0 - indirectRatio;
+            for (int i = tid; i < 6 * A.N; i += SG_THREADS) { const int f = i / 6, kk = i % 6; s_x[4 + 8 * f + kk] = s_x[4 + 8 * f + kk] * directRatio + indirect_x[i] * indirectRatio; }
+        }
+        __syncthreads();
+    }
+    if (nullU) {                                                                  // orthogonalize, BA.cpp:1196-1261
+        const int wv = tid >> 6, l = tid & 63;
+        if (wv < 7) {
+            double sdot = 0;
+            for (int i = l; i < n; i += 64) sdot += nullU[(size_t)wv * n + i] * s_x[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
+            if (l == 0) s_dot[wv] = sdot;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += SG_THREADS) { double v = s_x[i]; for (int e = 0; e < 7; e++) v -= nullU[(size_t)e * n + i] * s_dot[e]; s_x[i] = v; }
+        __syncthreads();
+    }
+    int bad = 0;
+    for (int i = tid; i < n; i += SG_THREADS) { const double v = s_x[i]; x[i] = v; bad |= !isfinite(v); }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (bad) atomicOr(flag, 1);
+}
+
 // ------------------------------------------------------------------------------------------------ K6
 // xAd[(host*N + target)*8 + j] = x_host . adHost(:, j) + x_target . adTarget(:, j)   (BA.cpp:1447)
 __device__ __forceinline__ double xad_entry(const double* __restrict__ adH, const double* __restrict__ adT, const double* __restrict__ x, int N, int e) {
@@ -1619,9 +1701,28 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
     const int n = A.n, off = optcal ? 0 : 4, m = n - off;
     const size_t sh = solve_lds_bytes(m);
     int* flag = reinterpret_cast<int*>(c->scal.as<char>() + 256);
-    if (sh > 160 * 1024) {                                   // the factorisation is LDS-resident: 8N+4 <= 160 (+4 with the calibration block)
-        c->err = "window too wide for the LDS-resident solver";
-        return CMLHIP_ERR_INVALID;
+    if (sh > 160 * 1024) {                                   // the LDS-resident factorisation takes 8N (+4 with the calibration block) <= 160: wider windows factorise in global memory
+        CML_REQUIRE(c, ((m + 15) / 16) * 16 <= SG_MAX, CMLHIP_ERR_INVALID, "window too wide for the solver");
+        CML_REQUIRE(c, !rp, CMLHIP_ERR_INVALID, "hybrid term inside the solve launch: windows of up to 20 frames");
+        SolveSys Yg;
+        Yg.Hb = c->Hf.as<double>(); Yg.bb = c->bf.as<double>(); Yg.part = c->syrk_part.as<double>();
+        Yg.nsl = cml_sys_slices(A.P); Yg.ntile = ldg_of(n) / 16; Yg.lambda = c->sys_lambda;
+        const int nbg = (m + 15) / 16, nblkg = nbg * (nbg + 1) / 2;
+        if (int rc = cml_ensure(c, c->solve_image, 8 * ((size_t)nblkg * BSZ + 2 * (size_t)nbg * 16))) return rc;
+        Yg.image = c->solve_image.as<double>();
+        const int* stopg = A.ctl ? &A.ctl->stop : nullptr;
+        switch (Yg.nsl) {
+            case 1: k_ba_assemble<1><<<nblkg, 256, 0, c->stream>>>(n, off, Yg, stopg); break;
+            case 2: k_ba_assemble<2><<<nblkg, 256, 0, c->stream>>>(n, off, Yg, stopg); break;
+            case 4: k_ba_assemble<4><<<nblkg, 256, 0, c->stream>>>(n, off, Yg, stopg); break;
+            default: k_ba_assemble<8><<<nblkg, 256, 0, c->stream>>>(n, off, Yg, stopg); break;
+        }
+        if (c->ext_stop_if_merged) c->ext_stop_if_merged = nullptr;
+        k_ba_solve_global<<<1, SG_THREADS, 0, c->stream>>>(A, n, off, Yg.image, c->xvec.as<double>(), flag, c->scal.as<LinSummary>(),
+                                                          ortho ? c->null_basis.as<double>() : nullptr, indirect_x);
+        c->backsub_merged = false;
+        if (with_lin_finish) return cml_launch_lin_finish(c, A);
+        return CMLHIP_OK;
     }
     SolveSys Y;
     Y.Hb = c->Hf.as<double>(); Y.bb = c->bf.as<double>(); Y.part = c->syrk_part.as<double>();

@@ -164,11 +164,12 @@ def test_apply_and_accumulate(pair):
     assert np.abs(sto - std).max() <= 5e-5 * np.abs(sto).max()
 
 
-@pytest.mark.parametrize("N,P", [(12, 1100), (9, 700), (14, 2100)])
+@pytest.mark.parametrize("N,P", [(12, 1100), (9, 700), (14, 2100), (21, 300), (26, 600), (32, 400)])
 def test_system_and_solver_wide_window(N, P):
     """Windows wider than the default: several Schur slices per tile (P > 512), block columns whose panel does not fit
     one wave (8N+4 > 64+...), systems assembled by k_ba_assemble (more than 16 blocks), with and without the calibration block and a
-    marginalisation prior.  Bars as above:
+    marginalisation prior; from 21 frames on (8N > 160) the factorisation leaves the LDS and runs in global memory (k_ba_solve_global).
+    Bars as above:
     Schur/Hessian blocks at fp32 accumulation tolerance, the factorisation isolated on the DEVICE's matrices at 1e-7."""
     I = S.make_inputs((N, P, 320, 240, 3, 260.0, 260.0, 159.5, 119.5))
     ob = S.OracleBA(I)

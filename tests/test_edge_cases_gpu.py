@@ -117,7 +117,9 @@ def test_limits_are_errors_not_crashes():
             ctx.ba_linearize()                                                  # nothing uploaded: call-order error
     finally:
         ctx.close()
-    # a window wider than the LDS-resident solver supports is refused by the solve, everything before it works
+    # a window wider than the LDS-resident solver takes (N > 20) is not refused any more: it factorises in global memory
+    # (tests/test_ba_parity_gpu.py::test_system_and_solver_wide_window checks its result); the hybrid term and the batched
+    # iteration stay limited to 20 frames and say so
     N = 22
     I = S.make_inputs((N, 60, 160, 120, 2, 140.0, 140.0, 79.5, 59.5))
     ctx = D.make_ctx(I)
@@ -125,8 +127,8 @@ def test_limits_are_errors_not_crashes():
         ctx.ba_linearize(); ctx.ba_apply(1)
         Hd = D.accumulate(ctx, I)
         assert all(np.all(np.isfinite(h)) for h in Hd)
-        with pytest.raises(device.CmlHipError):
-            ctx.ba_solve(1e-5)
+        x, rc = ctx.ba_solve(1e-5)
+        assert rc == 0 and np.all(np.isfinite(x))
     finally:
         ctx.close()
 

@@ -106,7 +106,10 @@ def test_run_is_deterministic():
         assert np.array_equal(o[2].view(np.uint64), outs[0][2].view(np.uint64))
 
 
-@pytest.mark.parametrize("config", ["small", "medium"])
+WIDE22 = (22, 300, 320, 240, 3, 260.0, 260.0, 159.5, 119.5)       # 8N > 160: the solve leaves the LDS (k_ba_solve_global)
+
+
+@pytest.mark.parametrize("config", ["small", "medium", WIDE22], ids=["small", "medium", "wide22"])
 def test_resident_iterations_match_host_loop(config):
     """run() steps the frames on the host between device calls; runResident() keeps the whole loop on the device (frame
     step, pair precomputation, computeDelta, orthogonalize in kernels).  Same arithmetic, different place: the results
