@@ -398,6 +398,7 @@ def main():
     _dbg('warmup queued')
     stride = 4 if args.steps >= 16 else (2 if args.steps >= 4 else 1)     # every stride-th step carries the profile events on its dispatches
     ctx.profile_stride(stride)
+    ctx.profile_select(1)                                                 # contract region: events on the roofline kernel's dispatch only
     ctx.profile_enable((args.steps + stride - 1) // stride)
 
     def run_steps():
@@ -413,7 +414,14 @@ def main():
     dt = shard.timed_region(group, sync, run_steps)
     _dbg('timed region done')
     ranks_joined = int(round(group.sum(1.0)))
-    lin_v, ss_v, _empty, n_samples = ctx.profile_read()
+    lin_v, _ss0, _empty, n_samples = ctx.profile_read()
+    # the Schur-reduce + solve group (K3 begin -> K6 end) is sampled in a region of its own, after the contract region: every
+    # event-carrying dispatch costs the pipeline a few microseconds, and the contract region needs the roofline kernel's only
+    ctx.profile_select(2)
+    ctx.profile_enable((args.steps + stride - 1) // stride)
+    shard.timed_region(group, sync, run_steps)
+    _lin0, ss_v, _empty, _n = ctx.profile_read()
+    ctx.profile_select(3)
     # spread: the contract region above is ONE sample (K steps can be a millisecond); eight more regions of the same K steps, same
     # protocol, reported beside it (not used for `value`)
     ctx.profile_enable(0)

@@ -563,6 +563,10 @@ int cmlhip_ba_iteration_batch(cmlhip_ctx* const* ctxs, int n_windows, double lam
 int cmlhip_profile_enable(cmlhip_ctx* ctx, int max_iterations);
 /* record only every stride-th iteration (default 1), so that the event records do not perturb a timed run */
 int cmlhip_profile_stride(cmlhip_ctx* ctx, int stride);
+/* which of the two groups carry events: 1 = (a) the residual kernel, 2 = (b) the Schur-reduce + solve group, 3 = both (default).
+ * An event-carrying dispatch costs the pipeline ~3 us (its completion is signalled to the host side of the queue), so a timed run
+ * that needs only the roofline kernel's duration asks for (a) alone; the group that is not selected reads back as 0. */
+int cmlhip_profile_select(cmlhip_ctx* ctx, int mask);
 /* development aid: in-kernel phase timestamps (wall clock, 10 ns ticks), 16 slots per kernel: [0,16) residual kernel,
  * [16,32) accumulate, [32,48) system tiles, [48,64) solve, [64,80) back-substitution; then, from slot 128, per-workgroup
  * {begin, end} pairs for the five kernels (1024 workgroups each).  `out` holds CMLHIP_DEBUG_SLOTS values.

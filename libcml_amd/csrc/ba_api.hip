@@ -174,13 +174,20 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     }
     const int TS = c->rs_tile;
     std::vector<int> tiles, tile_off(N * N + 1, 0);
+    c->h_rs_pair_tab.clear(); c->rs_pair_max_tiles = 0;
     for (int q = 0; q < N * N; q++) {
         const int host = q % N, target = q / N;                  // htIDX = host + target * N
         for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i += TS) {
             tiles.push_back(i); tiles.push_back(std::min(TS, c->h_by_pair_off[q + 1] - i)); tiles.push_back(host); tiles.push_back(target);
         }
         tile_off[q + 1] = (int)tiles.size() / 4;
+        if (tile_off[q + 1] > tile_off[q]) {                     // the pair table of the 2-D launch (ba_linearize_rs4.hip): travels in the kernel-argument segment
+            c->h_rs_pair_tab.push_back(c->h_by_pair_off[q]); c->h_rs_pair_tab.push_back(c->h_by_pair_off[q + 1] - c->h_by_pair_off[q]);
+            c->h_rs_pair_tab.push_back(tile_off[q]); c->h_rs_pair_tab.push_back(host | (target << 16));
+            c->rs_pair_max_tiles = std::max(c->rs_pair_max_tiles, tile_off[q + 1] - tile_off[q]);
+        }
     }
+    c->rs_pair_n = (int)c->h_rs_pair_tab.size() / 4;
     c->n_tiles = (int)tiles.size() / 4;
     ENS(c->rs_tiles, 16 * (size_t)std::max(c->n_tiles, 1)); ENS(c->rs_tile_off, 4 * (size_t)(N * N + 1));
     ENS(c->rs_part, 1024 * (size_t)std::max(c->n_tiles, 1));
@@ -535,21 +542,22 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     }
     const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap && (c->prof_tick++ % c->prof_stride) == 0;
     hipEvent_t* ev = prof ? &c->prof_ev[4 * (size_t)c->prof_n] : nullptr;
-    if (prof) c->ext_start = ev[0];                          // begin timestamp of the K3 dispatch
+    const bool prof_ss = prof && (c->prof_mask & 2), prof_k1 = prof && (c->prof_mask & 1);
+    if (prof_ss) c->ext_start = ev[0];                       // begin timestamp of the K3 dispatch
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
     const bool mix = c->resident_on && c->rp_resident && c->N > 4;      // addIndirectToProblem, BA.cpp:1327-1329 (only with more than 4 frames)
     ReprojArgs rp;
     if (mix) cml_resident_reproj_args(c, lambda, c->resident_iter + 1, &rp);   // its per-frame workgroups ride in the solve launch
     // K5: solve (+ hybrid term beside it, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
     static const bool no_merge = getenv("CMLHIP_NO_MERGE") != nullptr;          // development: K6 as its own launch
-    c->ext_stop_if_merged = (prof && !no_merge) ? ev[1] : nullptr;      // (merged: the end of the K5 + K6 dispatch closes the Schur-reduce + solve group)
+    c->ext_stop_if_merged = (prof_ss && !no_merge) ? ev[1] : nullptr;      // (merged: the end of the K5 + K6 dispatch closes the Schur-reduce + solve group)
     if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rr_x.as<double>() : nullptr, mix ? &rp : nullptr, !no_merge))) return rc;
     c->resident_iter++;
     if (!c->backsub_merged) {
-        if (prof) c->ext_stop = ev[1];                        // end timestamp of the K6 dispatch
+        if (prof_ss) c->ext_stop = ev[1];                     // end timestamp of the K6 dispatch
         cml_launch_backsub(c, A, true);                       // K6: back-substitution + point update
     }
-    if (prof) { c->ext_start = ev[2]; c->ext_stop = ev[3]; } // begin / end timestamps of the K1 dispatch itself
+    if (prof_k1) { c->ext_start = ev[2]; c->ext_stop = ev[3]; } // begin / end timestamps of the K1 dispatch itself
     if (c->rs_ok) {                                          // K1: residuals + Jacobians + applyRes, Jacobians kept in reduced form
         cml_launch_linearize_rs(c, A);
         c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
@@ -791,14 +799,20 @@ int cmlhip_profile_stride(cmlhip_ctx* c, int stride) { CML_DEV(c);
     return CMLHIP_OK;
 }
 
+int cmlhip_profile_select(cmlhip_ctx* c, int mask) { CML_DEV(c);
+    if (!c || (mask & ~3) || !mask) return CMLHIP_ERR_INVALID;
+    c->prof_mask = mask;
+    return CMLHIP_OK;
+}
+
 int cmlhip_profile_read(cmlhip_ctx* c, float* lin_ms, float* ss_ms, float* empty_ms, int* n) { CML_DEV(c);
     if (!c) return CMLHIP_ERR_INVALID;
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     double a = 0, b = 0, e = 0;
     for (int i = 0; i < c->prof_n; i++) {
         float m0 = 0, m1 = 0;
-        CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[4 * (size_t)i + 0], c->prof_ev[4 * (size_t)i + 1]));   // K3 begin -> K6 end
-        CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[4 * (size_t)i + 2], c->prof_ev[4 * (size_t)i + 3]));   // K1 begin -> K1 end
+        if (c->prof_mask & 2) CML_CHECK(c, hipEventElapsedTime(&m0, c->prof_ev[4 * (size_t)i + 0], c->prof_ev[4 * (size_t)i + 1]));   // K3 begin -> K6 end
+        if (c->prof_mask & 1) CML_CHECK(c, hipEventElapsedTime(&m1, c->prof_ev[4 * (size_t)i + 2], c->prof_ev[4 * (size_t)i + 3]));   // K1 begin -> K1 end
         b += m0; a += m1;
     }
     if (n) *n = c->prof_n;

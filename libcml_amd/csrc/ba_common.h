@@ -47,6 +47,7 @@ struct ResidentCtl {
     double energy[40];        // photometric energy after iteration i (statEnergyP)
 };
 #define CML_CTL_OFFSET 640
+#define CML_ZERO_WORD_OFFSET 1008       // a word of the scalar scratch that is cleared with it at upload and never written
 
 struct BAArgs {
     int N, P, R, w, h, opt_a, opt_b, n;            // n = 8N+4
@@ -83,6 +84,7 @@ struct RsArgs {
     const float* r_colors; const float* r_weights; // [R][8] the point's pattern colours / weights, per residual
     const double* r_idepth;                        // the point's inverse depth, per residual (kept current by k_ba_backsub's point step; refreshed when another path wrote pt_idepth)
     int dbg_flags;                                 // development switches (CMLHIP_RS_DBG)
+    const int* stop_lin;                           // never null: ResidentCtl::stop_lin of the window, or a word that stays zero (read with the inputs, tested behind them)
     float* part;                                   // [ntiles][64][4]: the wave's 16x16 fp32 tile of its pair's 13x13 block (MFMA D layout)
 };
 struct BatchRs { BAArgs A; RsArgs X; int blocks; int pad; };      // one window of a batched residual launch

@@ -526,6 +526,7 @@ static void fill_rs_args(cmlhip_ctx* c, RsArgs& X) {
     X.r_px = c->r_px.as<float>(); X.r_py = c->r_py.as<float>(); X.r_colors = c->r_colors.as<float>(); X.r_weights = c->r_weights.as<float>();
     X.part = c->rs_part.as<float>(); X.r_idepth = c->r_idepth.as<double>();
     { static const char* e = getenv("CMLHIP_RS_DBG"); X.dbg_flags = e ? atoi(e) : 0; }      // development: 1 = all texel taps at texel 0, 2 = no tile / reduced-record stores
+    X.stop_lin = reinterpret_cast<const int*>(c->scal.as<char>() + CML_ZERO_WORD_OFFSET);
 }
 int cml_fill_rs4_batch(cmlhip_ctx* c, const BAArgs& A, std::vector<unsigned char>& blob, int& blocks) {
     if (!c->rs_ok || c->rs_tile != 16 || c->n_tiles == 0) {
@@ -549,6 +550,7 @@ int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
     }
     RsArgs X;
     fill_rs_args(c, X);
+    if (A.ctl) X.stop_lin = &A.ctl->stop_lin;
     if (c->rs_tile == 16) return cml_launch_linearize_rs4(c, A, X);                         // small window: 4 lanes per residual (ba_linearize_rs4.hip)
     // fp16 texels: 168 VGPRs, three waves per SIMD — every tile of a 20-frame window resident at once; fp32 texels hold twice the
     // registers in flight and stay at two

@@ -28,12 +28,18 @@ typedef float float4_ __attribute__((ext_vector_type(4)));
 
 template <bool HALF>
 __device__ __forceinline__ float4 rs4_load_texel(const void* img, size_t i) {
+    // (global address space spelled out: the image pointer comes out of a frame record, and a generic pointer makes these flat loads)
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    typedef const u2v __attribute__((address_space(1)))* g_u2;
+    typedef const float4_ __attribute__((address_space(1)))* g_f4;
     if (HALF) {
-        uint2 v = reinterpret_cast<const uint2*>(img)[i];
+        const u2v w = ((g_u2)img)[i];
+        uint2 v = make_uint2(w.x, w.y);
         __half2 a = *reinterpret_cast<__half2*>(&v.x), b = *reinterpret_cast<__half2*>(&v.y);
         return make_float4(__low2float(a), __high2float(a), __low2float(b), 0.f);
     }
-    return reinterpret_cast<const float4*>(img)[i];
+    const float4_ t = ((g_f4)img)[i];
+    return make_float4(t.x, t.y, t.z, t.w);
 }
 
 // value held by quad lane `L` (0..3) of this lane's group of 4: DPP quad_perm, no LDS
@@ -103,17 +109,15 @@ __device__ __forceinline__ float rs4_jpdc(const int k, const double E0, const do
 // MINB: workgroups per CU the register budget is sized for — 1: no register bound (196 VGPRs, two waves per SIMD), no scratch frame;
 // 3: 168 VGPRs, the 13-23 registers beyond that spill to a scratch frame — measured slower at every window size (see the launcher)
 template <bool HALF, int MINB>
-__device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs& X, const int bx_) {
+__device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs& X, const int ti, const int4 T, const bool dead = false) {
     __shared__ double s_shd[4][RS_RES * RS_DSTRIDE];                                   // [wave][residual * RS_DSTRIDE + quantity * 9 + pixel]
     __shared__ float s_shf[4][RS_RES * RS_FSTRIDE];                                    // [wave][residual * RS_FSTRIDE + quantity * 8 + pixel]
     // the staged reduced record (layout of k_ba_acc's s_rec + Jpdd at 40,41) reuses the wave's fp64 rows once the sums are taken (a wave's
     // LDS operations execute in order): 52.5 KB per workgroup, three workgroups per CU
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, g = ln >> 2, j = ln & 3;
-    if (A.ctl && A.ctl->stop_lin) return;                  // converged in an earlier launch (raised by k_ba_acc), BA.cpp:879
-    const int ti = __builtin_amdgcn_readfirstlane(bx_ * 4 + wv);
-    if (ti >= X.ntiles) return;                            // wave-uniform; there is no workgroup barrier below
-    // ---- wave-uniform data: tile -> pair record, frames (scalar loads)
-    const int4 T = X.tiles[ti];                            // {first residual, count, host, target}
+    const int stop_lin = *X.stop_lin;                      // converged in an earlier launch (raised by k_ba_acc), BA.cpp:879: requested with the
+                                                           // pair record and the inputs, tested behind them (a test up here is a trip of its own)
+    // ---- wave-uniform data: tile {first residual, count, host, target} (from the caller) -> pair record, frames (scalar loads)
     const int first = T.x, cnt = T.y, host = T.z, target = T.w;
     const cmlhip_ba_pair* pc = &A.pairs[host * A.N + target];
     const FrameDev fh = A.frames[host], ft = A.frames[target];
@@ -144,7 +148,14 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     const bool live = valid && !lin_;
     const int st = live ? st_ : CMLHIP_RES_OOB;
     const bool run = live && st != CMLHIP_RES_OOB;
-    asm volatile("" : "+v"(mf_off), "+v"(mf_a));            // (pins the table loads to the input round trip)
+    // (pins the table loads, the stop word and the target's image pointer to the input round trip: left to the compiler the pointer is
+    //  requested in the middle of the projections and waited for ahead of the first texel load)
+    int stop_pin = stop_lin;
+    unsigned long long g0 = (unsigned long long)ft.grad0;
+    unsigned g0lo = __builtin_amdgcn_readfirstlane((unsigned)g0), g0hi = __builtin_amdgcn_readfirstlane((unsigned)(g0 >> 32));
+    asm volatile("" : "+v"(mf_off), "+v"(mf_a), "+v"(stop_pin), "+s"(g0lo), "+s"(g0hi));
+    const void* const grad0 = (const void*)(((unsigned long long)g0hi << 32) | g0lo);
+    __builtin_amdgcn_sched_barrier(0);                     // (an asm statement alone is moved down past the projections by the scheduler)
 #ifdef CML_RS_STAMPS                                       // development build (CML_HIPCC_EXTRA=-DCML_RS_STAMPS): per-tile phase stamps, tools/probe_rs_tiles.py
     long long* const ts = (A.dbg && ti < CML_DEBUG_RS_TILES) ? A.dbg + CMLHIP_DEBUG_SLOTS + 8 * (size_t)ti : nullptr;
 #define RS4_STAMP(i) do { if (ts && ln == 0) ts[i] = wall_clock64(); } while (0)
@@ -191,8 +202,8 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         const float dxdy = dx * dy;
         tw00[u] = 1 - dx - dy + dxdy; tw01[u] = dx - dxdy; tw10[u] = dy - dxdy; tw11[u] = dxdy;
         const size_t i1 = (sample[u] && !(X.dbg_flags & 1)) ? (size_t)iy * A.w + ix : (size_t)0;
-        ta[u] = rs4_load_texel<HALF>(ft.grad0, i1); tb[u] = rs4_load_texel<HALF>(ft.grad0, i1 + 1);
-        tc[u] = rs4_load_texel<HALF>(ft.grad0, i1 + A.w); td[u] = rs4_load_texel<HALF>(ft.grad0, i1 + A.w + 1);
+        ta[u] = rs4_load_texel<HALF>(grad0, i1); tb[u] = rs4_load_texel<HALF>(grad0, i1 + 1);
+        tc[u] = rs4_load_texel<HALF>(grad0, i1 + A.w); td[u] = rs4_load_texel<HALF>(grad0, i1 + A.w + 1);
     }
     // ---- geometric Jacobians, BA.cpp:120-188, evaluated HERE — behind the issue of the texel loads, ahead of their first use: they
     //      depend on the projection only, and at small windows a wave is alone on its SIMD, so whatever runs under the texel round
@@ -228,6 +239,11 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         finite[u] = isfinite(I[u]) && isfinite(gx[u]) && isfinite(gy[u]);
     }
 
+    // (wave-uniform; nothing has been stored yet.  Tested HERE, behind the first use of the texels: wherever the branch stands the compiler
+    //  keeps the loads of whatever is first used beyond it on its far side — ahead of the projections that was the pair record, ahead
+    //  of the interpolation the image pointer and the texels themselves: a dependent trip more each.  A wave that leaves has requested
+    //  texel 0 only: none of its lanes is `live`.)
+    if (__builtin_amdgcn_readfirstlane(stop_pin) || dead) return;
     // first failing pixel in pattern order decides between setNewState(OOB) (:209-212) and setState(OOB) (:220-223)
     const int shift = ln & ~3;
     unsigned m_oob, m_nf;
@@ -447,7 +463,28 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     }
 }
 template <bool HALF, int MINB>
-__global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) { k_ba_lin_rs4_body<HALF, MINB>(A, X, blockIdx.x); }
+__global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
+    const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (ti >= X.ntiles) return;                            // wave-uniform; there is no workgroup barrier in the body
+    k_ba_lin_rs4_body<HALF, MINB>(A, X, ti, X.tiles[ti]);
+}
+// The same kernel launched over (tile group of a pair, pair): the pair's entry {first residual, residuals, first tile, host | target << 16}
+// is indexed by blockIdx.y inside the KERNEL-ARGUMENT segment, so it arrives with the arguments — the solo kernel above reads its tile
+// from a table in memory first, a dependent trip of its own ahead of the pair record and the inputs (4 trips: arguments, tile, pair +
+// inputs, texels; here 3).  Waves beyond a pair's last tile return at once.  Windows with more pairs than the table holds take the
+// 1-D launch.
+#define RS4_PAIR_TAB 128
+struct RsPairTab { int4 e[RS4_PAIR_TAB]; };
+template <bool HALF>
+__global__ __launch_bounds__(256, 1) void k_ba_lin_rs4_2d(BAArgs A, RsArgs X, RsPairTab Q) {
+    const int4 e = Q.e[blockIdx.y];
+    const int lt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));        // tile of the pair
+    const int left = e.y - lt * RS_RES;
+    // a wave beyond its pair's last tile leaves where the stop flag is tested — behind the loads of the input trip (clamped onto the
+    // pair's first residuals), not up here: a branch ahead of them makes the entry, the control word and the arguments three waits
+    const bool dead = left <= 0;
+    k_ba_lin_rs4_body<HALF, 1>(A, X, e.z + lt, make_int4(dead ? e.x : e.x + lt * RS_RES, left < RS_RES ? left : RS_RES, e.w & 0xffff, e.w >> 16), dead);
+}
 
 
 int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
@@ -457,6 +494,15 @@ int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
     // development switch only.
     static const char* e_minb = getenv("CMLHIP_RS4_MINB");   // development: 3 forces the 168-VGPR instantiation
     const bool small = !(e_minb && atoi(e_minb) == 3);                      // at most two workgroups per CU: 196 VGPRs still leave two waves per SIMD
+    static const char* e_1d = getenv("CMLHIP_RS4_1D");      // development: 1 = the 1-D launch (tile table in memory) whatever the window
+    if (small && !(e_1d && atoi(e_1d)) && c->rs_pair_n > 0 && c->rs_pair_n <= RS4_PAIR_TAB) {
+        RsPairTab Q;
+        memcpy(Q.e, c->h_rs_pair_tab.data(), 16 * (size_t)c->rs_pair_n);
+        const dim3 grid(cml_div_up(c->rs_pair_max_tiles, 4), c->rs_pair_n);
+        if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<true>), grid, 256, 0, A, X, Q);
+        else CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<false>), grid, 256, 0, A, X, Q);
+        return CMLHIP_OK;
+    }
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) {
         if (small) CML_LAUNCH_EV(c, (k_ba_lin_rs4<true, 1>), blocks, 256, 0, A, X);
         else CML_LAUNCH_EV(c, (k_ba_lin_rs4<true, 3>), blocks, 256, 0, A, X);
@@ -472,7 +518,9 @@ template <bool HALF>
 __global__ __launch_bounds__(256, 1) void k_ba_lin_rs4_batch(const BatchRs* __restrict__ W) {
     const BatchRs& w = *(const BatchRs*)(const BatchRs __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
     if ((int)blockIdx.x >= w.blocks) return;
-    k_ba_lin_rs4_body<HALF, 1>(w.A, w.X, blockIdx.x);
+    const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (ti >= w.X.ntiles) return;
+    k_ba_lin_rs4_body<HALF, 1>(w.A, w.X, ti, w.X.tiles[ti]);
 }
 int cml_launch_linearize_rs4_batch(cmlhip_ctx* c0, const void* dev_records, int S, int max_blocks) {
     const BatchRs* W = static_cast<const BatchRs*>(dev_records);

@@ -79,7 +79,7 @@ struct cmlhip_ctx {
     hipEvent_t ext_start = nullptr, ext_stop = nullptr;       // consumed by the next CML_LAUNCH_EV
     hipEvent_t ext_stop_if_merged = nullptr;                  // stop event for the solve launch when the back-substitution rides in it
     std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration: K3 begin, K6 end, K1 begin, K1 end
-    int prof_cap = 0, prof_n = 0, prof_stride = 1, prof_tick = 0;
+    int prof_cap = 0, prof_n = 0, prof_stride = 1, prof_tick = 0, prof_mask = 3;    // prof_mask: 1 = the residual kernel, 2 = the Schur-reduce + solve group
 
     // ---------------- BA window
     cmlhip_ba_params ba_prm{};
@@ -100,6 +100,7 @@ struct cmlhip_ctx {
     DevBuf pair_code, pair_pos; int pair_stride = 0;          // [N*N][pair_stride] efsJ code (2r+sel, -1 = not in the ACTIVE sum) kept by applyRes; position of r
     // resident residual kernel (ba_linearize_rs.hip)
     DevBuf rs_tiles, rs_tile_off, rs_part, r_px, r_py, r_colors, r_weights, r_idepth, point_res; int n_tiles = 0;
+    std::vector<int> h_rs_pair_tab; int rs_pair_n = 0, rs_pair_max_tiles = 0;    // 4-lane kernel, 2-D launch: {first residual, residuals, first tile, host | target << 16} per pair that has residuals
     int rs_tile = RS_TILE_DEFAULT;                            // residuals per wave tile of this window: 64 = lane per residual (large windows), 16 = 4 lanes per residual
     bool r_idepth_dirty = true;                               // pt_idepth was written by something else than the resident point step
     bool efs_in_partials = false;                             // the last residual pass was the resident kernel: the pair blocks of the good

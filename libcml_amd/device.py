@@ -50,6 +50,7 @@ PROTOTYPES = {
     "cmlhip_profile_enable": (C.c_int, [_ctx, _i]),
     "cmlhip_debug_timestamps": (C.c_int, [_ctx, _i, _P(C.c_longlong)]),
     "cmlhip_profile_stride": (C.c_int, [_ctx, _i]),
+    "cmlhip_profile_select": (C.c_int, [_ctx, _i]),
     "cmlhip_trace_points": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, C.c_void_p]),
     "cmlhip_tracer_set_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_tracer_trace_resident": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, _P(C.c_int)]),
@@ -170,6 +171,9 @@ class Ctx:
 
     def profile_stride(self, stride):
         self.ck(self.L.cmlhip_profile_stride(self.h, stride))
+
+    def profile_select(self, mask):
+        self.ck(self.L.cmlhip_profile_select(self.h, mask))
 
     def profile_enable(self, max_iterations):
         self.ck(self.L.cmlhip_profile_enable(self.h, max_iterations))
