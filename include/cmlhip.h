@@ -565,7 +565,8 @@ int cmlhip_profile_enable(cmlhip_ctx* ctx, int max_iterations);
 int cmlhip_profile_stride(cmlhip_ctx* ctx, int stride);
 /* which of the two groups carry events: 1 = (a) the residual kernel, 2 = (b) the Schur-reduce + solve group, 3 = both (default).
  * An event-carrying dispatch costs the pipeline ~3 us (its completion is signalled to the host side of the queue), so a timed run
- * that needs only the roofline kernel's duration asks for (a) alone; the group that is not selected reads back as 0. */
+ * that needs only the roofline kernel's duration asks for (a) alone (the dispatch ahead of the residual kernel keeps its end event, so
+ * that the kernel's begin timestamp is taken as rocprofv3 takes it); the group that is not selected reads back as 0. */
 int cmlhip_profile_select(cmlhip_ctx* ctx, int mask);
 /* development aid: in-kernel phase timestamps (wall clock, 10 ns ticks), 16 slots per kernel: [0,16) residual kernel,
  * [16,32) accumulate, [32,48) system tiles, [48,64) solve, [64,80) back-substitution; then, from slot 128, per-workgroup

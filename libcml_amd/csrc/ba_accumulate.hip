@@ -989,15 +989,22 @@ __global__ __launch_bounds__(256) void k_ba_assemble(int n, int off, SolveSys Y,
 struct BacksubCall {
     const double* adH; const double* adT; float* step_partial; FrameStepArgs F;
     int g_pts;                 // point blocks of 512 threads (two virtual 256-thread blocks each)
-    int* xticket; int ticket;  // published by the solve workgroup after x
+    int* xticket; int ticket;  // published by the solve workgroup behind x
+    unsigned long long* xpub;  // x as the waiting workgroups read it: two self-validating words per entry, {low half | ticket << 32}, {high half | ticket << 32}
 };
-__device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket, const double* __restrict__ x, int n, double* __restrict__ s_x, int nthreads);
+__device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket, const unsigned long long* xpub, int n, double* __restrict__ s_x, int nthreads);
 template <int NT, bool INLAUNCH>
 __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double* __restrict__ adH, const double* __restrict__ adT,
                                                   const double* __restrict__ x_in, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
                                                   int do_step, const FrameStepArgs& F, const double* __restrict__ xad, const int bx_, const int gx_,
-                                                  double* __restrict__ s_xAd, float* __restrict__ s_redf, const int* xticket, const int ticket);
+                                                  double* __restrict__ s_xAd, float* __restrict__ s_redf, const int* xticket, const int ticket,
+                                                  const unsigned long long* xpub);
 
+__device__ __forceinline__ void publish_x_entry(const BacksubCall& BC, const int i, const double v) {
+    const unsigned long long tk = (unsigned long long)(unsigned)BC.ticket << 32;
+    __hip_atomic_store(BC.xpub + 2 * i, tk | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(BC.xpub + 2 * i + 1, tk | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int NSL, bool WIDE_OK = true, bool HYBRID = false, bool MERGE = false>
 __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off, const SolveSys& Y, double* __restrict__ x, int* __restrict__ flag,
                                                 const int* newframe_res, int n_newframe, const double* lin_partial,
@@ -1023,14 +1030,14 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
             const int b6 = bx_ - 2 - nrp;                     // block of the back-substitution: [frame step] [point blocks ...]
             if (BC.g_pts > 0 && b6 >= 0) {
                 if (BC.F.on && b6 == 0) {
-                    if (wait_and_fetch_x(BC.xticket, BC.ticket, x, n, sm, SOLVE_THREADS)) frame_step_block(BC.F, sm);
+                    if (wait_and_fetch_x(BC.xticket, BC.ticket, BC.xpub, n, sm, SOLVE_THREADS)) frame_step_block(BC.F, sm);
                     else if (tid == 0) atomicAdd(&lin_out->nonfinite, 1);
                     return;
                 }
                 const int pb = b6 - (BC.F.on ? 1 : 0);
                 if (pb < BC.g_pts) {
                     float* red = reinterpret_cast<float*>(sm + A.N * A.N * 8 + ((n + 1) & ~1));
-                    k_ba_backsub_body<SOLVE_THREADS, true>(A, BC.adH, BC.adT, x, lin_out, BC.step_partial, 1, BC.F, nullptr, pb, BC.g_pts, sm, red, BC.xticket, BC.ticket);
+                    k_ba_backsub_body<SOLVE_THREADS, true>(A, BC.adH, BC.adT, x, lin_out, BC.step_partial, 1, BC.F, nullptr, pb, BC.g_pts, sm, red, BC.xticket, BC.ticket, BC.xpub);
                 }
             }
         }
@@ -1295,25 +1302,24 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
             } else {
                 for (int e = 0; e < 7; e++) v -= nullU[(size_t)e * n + i] * dots[e];
             }
-            if (MERGE && BC.g_pts > 0) __hip_atomic_store(x + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else x[i] = v;
+            x[i] = v;
+            if (MERGE && BC.g_pts > 0) publish_x_entry(BC, i, v);
             bad |= !isfinite(v);
         }
     } else {
         for (int i = tid; i < n; i += SOLVE_THREADS) {
             const double v = xs[i];
-            if (MERGE && BC.g_pts > 0) __hip_atomic_store(x + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else x[i] = v;
+            x[i] = v;
+            if (MERGE && BC.g_pts > 0) publish_x_entry(BC, i, v);
             bad |= !isfinite(v);
         }
     }
-    if (MERGE && BC.g_pts > 0) {
-        // x is consumed by the back-substitution blocks of THIS launch: every writer fences at device scope, the workgroup meets, one lane
-        // publishes the ticket
-        // (x was written with device-scope stores — they go past the non-coherent caches —, so the lanes only have to see them
-        //  acknowledged before the workgroup meets: no release fence, which would write the whole L2 back)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(BC.xticket, BC.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // x is consumed by the back-substitution blocks of THIS launch.  Every entry travels as two device-scope words that carry the
+    // launch's ticket beside their half of the value (they go past the non-coherent caches; a word is valid on its own), so the
+    // ticket word can follow WITHOUT the writers waiting for their acknowledgements and without the workgroup meeting: a reader that
+    // sees the ticket ahead of an entry simply reads that entry again.  (Round 3, first form: device-scope stores of x, s_waitcnt
+    // vmcnt(0), barrier, ticket — an exposed store round trip on the critical path of the iteration.)
+    if (MERGE && BC.g_pts > 0 && tid == (n - 1) % SOLVE_THREADS) __hip_atomic_store(BC.xticket, BC.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) *flag = 0;
     __syncthreads();
     if (bad) atomicOr(flag, 1);
@@ -1442,21 +1448,35 @@ __global__ __launch_bounds__(256) void k_ba_xad(const double* __restrict__ adH, 
 }
 
 // back-substitution (BA.cpp:1427-1487) + optional point update (doStepFromBackup, BA.cpp:976-994)
-// wait until the solve workgroup of THIS launch has published x (ticket, acquire at device scope), then copy x into LDS with
-// device-scope loads (a plain load could be served from a stale line of this XCD's L2).  false: gave up (never spin forever).
-__device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket, const double* __restrict__ x, int n, double* __restrict__ s_x, int nthreads) {
+// wait until the solve workgroup of THIS launch has published x, then copy x into LDS.  One lane polls the ticket word (relaxed
+// device-scope loads: an acquire per poll would invalidate caches chip-wide at every turn); the entries are then read as the
+// self-validating device-scope words the solve workgroup wrote (publish_x_entry) — a word that does not carry the ticket yet is read
+// again, so the producer does not have to order its ticket behind its entries.  false: gave up (never spin forever).
+__device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket, const unsigned long long* xpub, int n, double* __restrict__ s_x, int nthreads) {
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
         int spins = 0, ok = 1;
-        // relaxed polls (an acquire load per poll would invalidate caches chip-wide at every turn), ONE acquire fence once the ticket is seen
         while (__hip_atomic_load(xticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1 << 22)) { ok = 0; break; }
         }
-        s_ok = ok;                                // (x is then read with device-scope loads: no acquire fence, which would invalidate the caches)
+        s_ok = ok;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += nthreads) s_x[e] = __hip_atomic_load(x + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool mine_ok = true;
+    for (int e = threadIdx.x; e < n; e += nthreads) {
+        unsigned long long a, b;
+        int spins = 0;
+        for (;;) {
+            a = __hip_atomic_load(xpub + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(xpub + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(a >> 32) == (unsigned)ticket && (unsigned)(b >> 32) == (unsigned)ticket) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 20)) { mine_ok = false; break; }
+        }
+        s_x[e] = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+    }
+    if (!mine_ok) s_ok = 0;
     __syncthreads();
     return s_ok != 0;
 }
@@ -1469,7 +1489,7 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
                                                   const double* __restrict__ x_in, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
                                                   int do_step, const FrameStepArgs& F, const double* __restrict__ xad, const int bx_, const int gx_,
                                                   double* __restrict__ s_xAd /* N*N*8 (+ n with INLAUNCH) */, float* __restrict__ s_redf /* [NT/256][3][4] */,
-                                                  const int* xticket, const int ticket) {
+                                                  const int* xticket, const int ticket, const unsigned long long* xpub) {
     const int N = A.N;
     DBG_BLK(A.dbg, 4, 0);
     if (A.ctl && A.ctl->stop) return;
@@ -1509,16 +1529,43 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
         const int r = max(codes[ps], 0) >> 1;
         v0s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r); v1s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r + 4);
     }
+    // third: the adjoint columns behind this thread's entries of the x.adjoint table (static over the iteration) — with the table built
+    // after the wait they were a dependent trip of their own behind the arrival of x
+    const int ne = N * N * 8;
+    const bool pre_ad = INLAUNCH && !xad && ne <= 2 * NT;
+    double ahc[2][8], atc[2][8];
+    if (pre_ad) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = min((int)threadIdx.x + u * NT, ne - 1);
+            const int j = e & 7, ht = e >> 3, h = ht / N, t = ht % N;
+            const double* AH = adH + 64 * (size_t)(h + N * t); const double* AT = adT + 64 * (size_t)(h + N * t);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { ahc[u][k] = AH[k * 8 + j]; atc[u][k] = AT[k * 8 + j]; }
+        }
+    }
     if (INLAUNCH) {
         double* s_x = s_xAd + N * N * 8;
-        if (!wait_and_fetch_x(xticket, ticket, x_in, A.n, s_x, NT)) { if (threadIdx.x == 0) atomicAdd(&sum->nonfinite, 1); return; }
+        if (!wait_and_fetch_x(xticket, ticket, xpub, A.n, s_x, NT)) { if (threadIdx.x == 0) atomicAdd(&sum->nonfinite, 1); return; }
         x = s_x;
     }
     const double xc = x[i & 3];
     if (xad) {                                               // wide windows: the table was built once by k_ba_xad
-        for (int e = threadIdx.x; e < N * N * 8; e += NT) s_xAd[e] = xad[e];
+        for (int e = threadIdx.x; e < ne; e += NT) s_xAd[e] = xad[e];
+    } else if (pre_ad) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = (int)threadIdx.x + u * NT;
+            if (e < ne) {
+                const int ht = e >> 3, h = ht / N, t = ht % N;
+                double s = 0, s2 = 0;                        // (xad_entry's sums, operand for operand)
+#pragma unroll
+                for (int k = 0; k < 8; k++) { s += x[4 + 8 * h + k] * ahc[u][k]; s2 += x[4 + 8 * t + k] * atc[u][k]; }
+                s_xAd[e] = s + s2;
+            }
+        }
     } else {
-        for (int e = threadIdx.x; e < N * N * 8; e += NT) s_xAd[e] = xad_entry(adH, adT, x, N, e);
+        for (int e = threadIdx.x; e < ne; e += NT) s_xAd[e] = xad_entry(adH, adT, x, N, e);
     }
     if (!INLAUNCH && bx_ == 0 && threadIdx.x == 0) sum->nonfinite = 0;      // (in the solve launch its workgroup 0 reset the counter at its start)
     __syncthreads();
@@ -1589,7 +1636,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __re
                                                     int do_step, FrameStepArgs F, const double* __restrict__ xad) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];     // N*N*8, index (host*N + target)*8 + j  (:1447)
     __shared__ float s_red[12];
-    k_ba_backsub_body<256, false>(A, adH, adT, x, sum, step_partial, do_step, F, xad, blockIdx.x, gridDim.x, s_dyn, s_red, nullptr, 0);
+    k_ba_backsub_body<256, false>(A, adH, adT, x, sum, step_partial, do_step, F, xad, blockIdx.x, gridDim.x, s_dyn, s_red, nullptr, 0, nullptr);
 }
 
 
@@ -1754,9 +1801,10 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
             F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
         }
         BC.g_pts = cml_div_up(A.P * 8, 512);
-        if (int rc = cml_ensure(c, c->x_ticket, 64)) return rc;
-        if (!c->x_ticket_zeroed) { CML_CHECK(c, hipMemsetAsync(c->x_ticket.p, 0, 64, c->stream)); c->x_ticket_zeroed = true; }
+        if (int rc = cml_ensure(c, c->x_ticket, 64 + 16 * (8 * CMLHIP_MAX_FRAMES + 4))) return rc;
+        if (!c->x_ticket_zeroed) { CML_CHECK(c, hipMemsetAsync(c->x_ticket.p, 0, c->x_ticket.bytes, c->stream)); c->x_ticket_zeroed = true; }
         BC.xticket = c->x_ticket.as<int>(); BC.ticket = ++c->x_ticket_seq;
+        BC.xpub = reinterpret_cast<unsigned long long*>(c->x_ticket.as<char>() + 64);
     }
     if (merge && c->ext_stop_if_merged) c->ext_stop = c->ext_stop_if_merged;
     c->ext_stop_if_merged = nullptr;
@@ -1851,7 +1899,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_batch(const BatchWin
     ReprojArgs RP0;
     RP0.N = 0; RP0.ready = nullptr; RP0.ticket = 0;         // the hybrid term is not batched
     BacksubCall BC0;
-    BC0.g_pts = 0; BC0.xticket = nullptr; BC0.ticket = 0; BC0.F.on = 0;
+    BC0.g_pts = 0; BC0.xticket = nullptr; BC0.ticket = 0; BC0.xpub = nullptr; BC0.F.on = 0;
     k_ba_solve_body<NSL, false>(w.A, w.n, w.off, w.Y, w.x, w.flag, w.newframe_res, w.n_newframe, w.lin_partial, w.n_partial, w.lin_out, w.frames_rw, 1, w.nullU,
                          nullptr, RP0, BC0, blockIdx.x);
 }
@@ -1860,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub_batch(const BatchWin* __rest
     if ((int)blockIdx.x >= w.g_back) return;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     __shared__ float s_red[12];
-    k_ba_backsub_body<256, false>(w.A, w.adH, w.adT, w.x, w.lin_out, w.step_partial, 1, w.F, nullptr, blockIdx.x, w.g_back, s_dyn, s_red, nullptr, 0);
+    k_ba_backsub_body<256, false>(w.A, w.adH, w.adT, w.x, w.lin_out, w.step_partial, 1, w.F, nullptr, blockIdx.x, w.g_back, s_dyn, s_red, nullptr, 0, nullptr);
 }
 
 int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {

@@ -542,6 +542,9 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     }
     const bool prof = c->prof_cap > 0 && c->prof_n < c->prof_cap && (c->prof_tick++ % c->prof_stride) == 0;
     hipEvent_t* ev = prof ? &c->prof_ev[4 * (size_t)c->prof_n] : nullptr;
+    // (the dispatch AHEAD of the residual kernel always carries its end event when the residual kernel is timed: a dispatch that follows
+    //  one without a completion signal takes its begin timestamp while the predecessor is still draining — measured 9.8 us against the
+    //  8.8 us rocprofv3 reports for the same kernel, whose tracer puts a signal on every dispatch)
     const bool prof_ss = prof && (c->prof_mask & 2), prof_k1 = prof && (c->prof_mask & 1);
     if (prof_ss) c->ext_start = ev[0];                       // begin timestamp of the K3 dispatch
     cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
@@ -550,11 +553,11 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     if (mix) cml_resident_reproj_args(c, lambda, c->resident_iter + 1, &rp);   // its per-frame workgroups ride in the solve launch
     // K5: solve (+ hybrid term beside it, + orthogonalize, BA.cpp:1404) || energy threshold of the previous residual pass
     static const bool no_merge = getenv("CMLHIP_NO_MERGE") != nullptr;          // development: K6 as its own launch
-    c->ext_stop_if_merged = (prof_ss && !no_merge) ? ev[1] : nullptr;      // (merged: the end of the K5 + K6 dispatch closes the Schur-reduce + solve group)
+    c->ext_stop_if_merged = (prof && !no_merge) ? ev[1] : nullptr;      // (merged: the end of the K5 + K6 dispatch closes the Schur-reduce + solve group)
     if ((rc = cml_launch_solve(c, A, 0, true, c->resident_on && c->have_null && c->resident_iter >= 2, mix ? c->rr_x.as<double>() : nullptr, mix ? &rp : nullptr, !no_merge))) return rc;
     c->resident_iter++;
     if (!c->backsub_merged) {
-        if (prof_ss) c->ext_stop = ev[1];                     // end timestamp of the K6 dispatch
+        if (prof) c->ext_stop = ev[1];                        // end timestamp of the K6 dispatch
         cml_launch_backsub(c, A, true);                       // K6: back-substitution + point update
     }
     if (prof_k1) { c->ext_start = ev[2]; c->ext_stop = ev[3]; } // begin / end timestamps of the K1 dispatch itself
