@@ -79,11 +79,15 @@ typedef float float4_ __attribute__((ext_vector_type(4)));
 // (10 per record), PAIR_TRIP residuals per trip; wave w takes residuals w, w+16, ... of the trip and every lane reads its
 // operand elements from the staged record (distinct banks or broadcast).  The 16 wave tiles are added in wave order.
 // LINEARIZED mode (rare) computes res_toZero + J*delta per residual (BA.cpp:1699-1729) and stages the same 38 floats.
+// NW = 16: the 1024-thread workgroup of every mode.  NW = 4 (resident loop only, mode == CML_MODE_ACTIVE_TILES): the same sums by a
+// 256-thread workgroup — wave w carries the running sums of the virtual waves w, w + 4, w + 8, w + 12 of the 16-wave form, and the 16
+// sums are added in the same order: bit-identical, at a quarter of the threads (k_ba_acc_rs).
+template <int NW = 16>
 __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X, const int q, const int mode, unsigned char* arena) {
-    const bool TILES = mode == CML_MODE_ACTIVE_TILES;
+    const bool TILES = mode == CML_MODE_ACTIVE_TILES || NW != 16;
     const bool LIN = mode != CMLHIP_MODE_ACTIVE && !TILES;  // LINEARIZED and MARGINALIZED walk the plain pair list
     float (*s_rec)[PAIR_REC] = reinterpret_cast<float (*)[PAIR_REC]>(arena);
-    float (*s_tile)[256] = reinterpret_cast<float (*)[256]>(arena + sizeof(float) * PAIR_TRIP * PAIR_REC);
+    float (*s_tile)[256] = reinterpret_cast<float (*)[256]>(arena + (NW == 16 ? sizeof(float) * PAIR_TRIP * PAIR_REC : 0));
     __shared__ int s_cnt;
     __shared__ double s_H[13][13];
     __shared__ double s_AH[64], s_AT[64], s_T1[64], s_T2[64];
@@ -104,7 +108,22 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     else if (kq == 2 && e >= 10) { field = true; o1 = e == 10 ? 30 : e == 11 ? 32 : e == 12 ? 36 : e == 13 ? 33 : e == 14 ? 37 : 38; }
     const float a_const = (kq == 2 && e == 10) ? 1.f : 0.f;
     float4_ acc = {0.f, 0.f, 0.f, 0.f};
-    if (TILES) {
+    if constexpr (NW != 16) {
+        // four virtual waves per wave: all their tiles requested together, each virtual wave's sum taken in its own order
+        const float4* P4 = reinterpret_cast<const float4*>(X.part);
+        const int tpt = PAIR_TRIP / X.tile;
+#pragma unroll
+        for (int u = 0; u < 16 / NW; u++) {
+            const int vw = wave + NW * u;
+            float4_ va = {0.f, 0.f, 0.f, 0.f};
+            for (int t = tb + vw; vw < tpt && t < te; t += tpt) {
+                const float4 v = P4[(size_t)t * 64 + ln];
+                va[0] += v.x; va[1] += v.y; va[2] += v.z; va[3] += v.w;
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) s_tile[vw][(4 * kq + rg) * 16 + e] = va[rg];
+        }
+    } else if (TILES) {
         // the residual kernel of the resident loop already reduced its residuals on the matrix cores: add the pair's wave tiles
         // (same D layout, lane for lane); wave w < 256 / tile takes tiles w, w + 256 / tile, ... (the assignment of the record path below) and the wave sums are added in wave order below
         const float4* P4 = reinterpret_cast<const float4*>(X.part);
@@ -200,8 +219,10 @@ __device__ __forceinline__ void acc_pair_block(const BAArgs& A, const AccArgs& X
     }
     if (A.dbg && tid == 0 && q == 1) A.dbg[17] = wall_clock64();
     // D: col = lane & 15, row = 4 * (lane >> 4) + reg
+    if constexpr (NW == 16) {
 #pragma unroll
-    for (int rg = 0; rg < 4; rg++) s_tile[wave][(4 * kq + rg) * 16 + e] = acc[rg];
+        for (int rg = 0; rg < 4; rg++) s_tile[wave][(4 * kq + rg) * 16 + e] = acc[rg];
+    }
     if (tid < 64) { s_AH[tid] = ahv; s_AT[tid] = atv; }
     __syncthreads();
     if (tid < 91) {
@@ -287,10 +308,11 @@ __device__ __forceinline__ double sum_slots_d(double v) {
     v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     return v;
 }
+template <int PPB = PT_PER_BLOCK>
 __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs& X, const int blk, unsigned char* arena) {
     double (*s_row)[LDG_MAX] = reinterpret_cast<double (*)[LDG_MAX]>(arena);
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, s = l >> 3, a = l & 7;
-    const int p = blk * PT_PER_BLOCK + wv;
+    const int p = blk * PPB + wv;
     if (p >= A.P) return;                                    // wave-uniform
     double* srow = s_row[wv];
     for (int c = l; c < X.ldg; c += 64) srow[c] = 0.0;
@@ -396,6 +418,26 @@ __device__ __forceinline__ void k_ba_acc_body(const BAArgs& A, const AccArgs& X,
     else acc_pair_block(A, X, bx_ - npt, mode, s_arena);
     DBG_BLK_END(A.dbg, 1);
 }
+// Resident loop (mode CML_MODE_ACTIVE_TILES): the same two kinds of workgroups at 256 threads — 4 points, or one pair summed by 4 waves
+// (acc_pair_block<4>).  Neither kind needs 16 waves there (a point row is one wave's work; the pair's tiles are 16 KB), and a
+// 1024-thread workgroup at 94 VGPRs is alone on its CU: 900 of them at 20 keyframes x 8000 points were 3.5 rounds, eight batched
+// config-B windows six.  20 KB of LDS instead of 62.
+#define PT_PER_BLOCK_RS 4
+__device__ __forceinline__ void k_ba_acc_rs_body(const BAArgs& A, const AccArgs& X, const int bx_, const int gx_) {
+    const int NN = A.N * A.N;
+    DBG_BLK(A.dbg, 1, 0);
+    if (A.ctl && A.ctl->stop) {
+        if (bx_ == 0 && threadIdx.x == 0) A.ctl->stop_lin = 1;          // (see k_ba_acc_body)
+        return;
+    }
+    const int npt = (int)gx_ - NN;
+    __shared__ __attribute__((aligned(16))) unsigned char s_arena[sizeof(float) * 16 * 256];
+    static_assert(sizeof(s_arena) >= sizeof(double) * PT_PER_BLOCK_RS * LDG_MAX, "arena");
+    if ((int)bx_ < npt) point_rows_block<PT_PER_BLOCK_RS>(A, X, bx_, s_arena);
+    else acc_pair_block<4>(A, X, bx_ - npt, CML_MODE_ACTIVE_TILES, s_arena);
+    DBG_BLK_END(A.dbg, 1);
+}
+__global__ __launch_bounds__(256) void k_ba_acc_rs(BAArgs A, AccArgs X) { k_ba_acc_rs_body(A, X, blockIdx.x, gridDim.x); }
 #ifdef CML_ACC_WPE8
 #define CML_ACC_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))      /* development: two 1024-thread workgroups per CU at 64 VGPRs (192 B of scratch) */
 #else
@@ -1726,7 +1768,9 @@ int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool ha
             k_ba_acc<<<NN, 1024, 0, c->stream>>>(A, XL, 1);
             if (A.P > 0) k_ba_point_bdL<<<cml_div_up(A.P, 256), 256, 0, c->stream>>>(A, c->adHTd.as<float>(), vs);
         }
-        CML_LAUNCH_EV(c, k_ba_acc, NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, A, X, c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0);
+        static const bool acc16 = getenv("CMLHIP_ACC_1024") != nullptr;          // development: the 1024-thread workgroups in the resident loop too
+        if (c->efs_in_partials && !acc16) CML_LAUNCH_EV(c, k_ba_acc_rs, NN + cml_div_up(A.P, PT_PER_BLOCK_RS), 256, 0, A, X);
+        else CML_LAUNCH_EV(c, k_ba_acc, NN + cml_div_up(A.P, PT_PER_BLOCK), 1024, 0, A, X, c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0);
     }
     SysArgs S;
     const bool super = fill_sys_args(c, A, X, lambda, have_hm, system_only, marg, S);
@@ -1888,6 +1932,11 @@ __global__ __launch_bounds__(1024) void k_ba_acc_batch(const BatchWin* __restric
     if ((int)blockIdx.x >= w.g_acc) return;
     k_ba_acc_body(w.A, w.X, w.acc_mode, blockIdx.x, w.g_acc);
 }
+__global__ __launch_bounds__(256) void k_ba_acc_rs_batch(const BatchWin* __restrict__ W) {          // every window's Jacobians in tile form
+    const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);
+    if ((int)blockIdx.x >= w.g_acc) return;
+    k_ba_acc_rs_body(w.A, w.X, blockIdx.x, w.g_acc);
+}
 __global__ __launch_bounds__(64 * SYS_NW) __attribute__((amdgpu_waves_per_eu(SYS_WPE, SYS_WPE))) void k_ba_system_batch(const BatchWin* __restrict__ W) {
     const BatchWin& w = *(const BatchWin*)(const BatchWin __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
     if ((int)blockIdx.x >= w.g_sys) return;
@@ -1916,6 +1965,7 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
     std::vector<BatchWin> H((size_t)S);
     std::vector<unsigned char> Hrs;
     int g_acc = 0, g_sys = 0, g_back = 0, nsl = 0, rs_blocks = 0;
+    bool all_tiles = true;
     size_t solve_lds = 0, back_lds = 0;
     for (int k = 0; k < S; k++) {
         cmlhip_ctx* c = ctxs[k];
@@ -1928,7 +1978,8 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
         A.dbg = nullptr;
         fill_acc_args(c, A, true, w.X);
         w.acc_mode = c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0;
-        w.g_acc = A.N * A.N + cml_div_up(A.P, PT_PER_BLOCK);
+        w.g_acc = A.N * A.N + cml_div_up(A.P, PT_PER_BLOCK);            // (re-sized below when every window takes the 256-thread form)
+        all_tiles = all_tiles && c->efs_in_partials;
         const bool super = fill_sys_args(c, A, w.X, lambda, false, false, false, w.S);
         if (super) { c0->err = "cmlhip_ba_iteration_batch: a window this wide fills the chip on its own (use cmlhip_ba_iteration_async)"; return CMLHIP_ERR_INVALID; }
         w.g_sys = w.S.nsyrk + A.N + 1;
@@ -1968,6 +2019,13 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
         c->sys_lambda = lambda;
     }
     if (g_back == 0 || g_acc == 0) { c0->err = "cmlhip_ba_iteration_batch: empty windows"; return CMLHIP_ERR_INVALID; }
+    // every window's Jacobians in tile form (every round but the first of a loop that starts from records): K3 at 256 threads (k_ba_acc_rs_body)
+    static const bool acc16 = getenv("CMLHIP_ACC_1024") != nullptr;
+    const bool acc_rs = all_tiles && !acc16;
+    if (acc_rs) {
+        g_acc = 0;
+        for (int k = 0; k < S; k++) { H[k].g_acc = H[k].A.N * H[k].A.N + cml_div_up(H[k].A.P, PT_PER_BLOCK_RS); g_acc = std::max(g_acc, H[k].g_acc); }
+    }
     // argument blocks -> device (only when something changed: the first iterations of a loop, a new lambda, a new window)
     const size_t bytes_main = sizeof(BatchWin) * (size_t)S;
     int rc;
@@ -1982,7 +2040,8 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
         CML_CHECK(c0, hipMemcpyAsync(c0->batch_rs.p, c0->batch_rs_host.data(), Hrs.size(), hipMemcpyHostToDevice, c0->stream));
     }
     const BatchWin* W = c0->batch_main.as<BatchWin>();
-    k_ba_acc_batch<<<dim3(g_acc, S), 1024, 0, c0->stream>>>(W);                        // K3
+    if (acc_rs) k_ba_acc_rs_batch<<<dim3(g_acc, S), 256, 0, c0->stream>>>(W);          // K3
+    else k_ba_acc_batch<<<dim3(g_acc, S), 1024, 0, c0->stream>>>(W);
     k_ba_system_batch<<<dim3(g_sys, S), 64 * SYS_NW, 0, c0->stream>>>(W);              // K4
 #define LAUNCH_SOLVE_B(NSL) do { \
         if (!(c0->attr_done_batch & (1u << NSL))) { (void)hipFuncSetAttribute((const void*)k_ba_solve_batch<NSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c0->attr_done_batch |= 1u << NSL; } \
