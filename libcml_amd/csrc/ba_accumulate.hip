@@ -1042,6 +1042,109 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
                                                   double* __restrict__ s_xAd, float* __restrict__ s_redf, const int* xticket, const int ticket,
                                                   const unsigned long long* xpub);
 
+
+// Factorisation with LOOK-AHEAD for wide systems (nb >= SOLVE_LOOKAHEAD_NB block columns).  The plain loop below
+// runs elimination(K) | barrier | all trailing tiles of step K | barrier: at 20 keyframes 45 tiles on 8 waves are six rounds per step
+// with the elimination wave(s) waiting behind them (12.7 us of the 48).  Here step K first updates the tiles of block column K + 1 only;
+// then the waves that carry rows of column K + 1 eliminate it WHILE the other waves — and the eliminating ones when they are done —
+// draw the remaining tiles of step K from a counter in LDS.  The trailing operand W_IK = L_IK D_K is formed from the factor and D
+// when it is read (the plain loop keeps the pre-scaling values in a second panel, for which there is no room beside a double
+// buffer at 160 unknowns): same factorisation, last-bit differences against the plain loop, same 1e-7 bar against the oracle.
+#define SOLVE_LOOKAHEAD_NB 6
+__device__ __forceinline__ void solve_eliminate_column_la(double* __restrict__ L, double* __restrict__ y, double* __restrict__ dvec,
+                                                          double* __restrict__ dinv, const int K, const int nb, const int wv, const int l) {
+    const int nbelow = (nb - K - 1) * 16;
+    const int gi = (l < 16) ? 16 * K + l : 16 * (K + 1) + wv * 48 + (l - 16);
+    const bool prow = l >= 16 && (wv * 48 + (l - 16)) < nbelow;
+    const bool have = l < 16 || prow;
+    double* Rrow = L + blk_off(have ? gi >> 4 : K, K) + (gi & 15) * BLD;
+    double row[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) row[j] = have ? Rrow[j] : 0.0;
+    double yv = have ? y[gi] : 0.0, mydk = 0.0;
+    double dk, cid;                                         // (the pivot chain of the plain loop, statement for statement)
+#define SOLVE_PIVOT_CHAIN_LA(K_, DK_, CID_) do { \
+        union { double d; int i[2]; } ud_; \
+        ud_.d = row[K_]; \
+        const int dlo_ = __builtin_amdgcn_readlane(ud_.i[0], K_), dhi_ = __builtin_amdgcn_readlane(ud_.i[1], K_); \
+        const bool tiny_ = (dhi_ & 0x7ff00000) == 0; \
+        ud_.i[0] = dlo_; ud_.i[1] = dhi_; \
+        DK_ = ud_.d; \
+        const double x0_ = __builtin_amdgcn_rcp(ud_.d); \
+        const double e0_ = __builtin_fma(-ud_.d, x0_, 1.0), p_ = row[K_] * x0_; \
+        const double t_ = __builtin_fma(p_, e0_, p_), e2_ = e0_ * e0_; \
+        const double c_ = __builtin_fma(t_, e2_, t_); \
+        CID_ = tiny_ ? 0.0 : c_; } while (0)
+    SOLVE_PIVOT_CHAIN_LA(0, dk, cid);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const double zk = rl(yv, k);
+        double dk_next = 0.0, cid_next = 0.0;
+        if (k + 1 < 16) {
+            row[k + 1] -= cid * rl(row[k], k + 1);
+            SOLVE_PIVOT_CHAIN_LA(k + 1, dk_next, cid_next);
+        }
+#pragma unroll
+        for (int j = k + 2; j < 16; j++) row[j] -= cid * rl(row[k], j);
+        row[k] = cid;
+        if (l > k) yv -= cid * zk;
+        if (l == k) mydk = dk;
+        dk = dk_next; cid = cid_next;
+    }
+#undef SOLVE_PIVOT_CHAIN_LA
+    const double mydi = fabs(mydk) > 2.2250738585072014e-308 ? fast_rcp(mydk) : 0.0;
+    if (have && (l >= 16 || wv == 0)) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) Rrow[j] = row[j];
+        y[gi] = yv;
+    }
+    if (wv == 0 && l < 16) { dvec[16 * K + l] = mydk; dinv[16 * K + l] = mydi; }
+}
+// A_IJ -= (L_IK D_K) L_JK^T on the matrix cores, one tile per call
+__device__ __forceinline__ void solve_update_tile_la(double* __restrict__ L, const double* __restrict__ dvec, const int K, const int I, const int J, const int l) {
+    double* C = L + blk_off(I, J);
+    const double* Li = L + blk_off(I, K);
+    const double* Lj = L + blk_off(J, K);
+    const int kq = l >> 4, cidx = l & 15;
+    double4_ acc;
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) acc[rg] = C[(kq + 4 * rg) * BLD + cidx];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+        const double av = -(Li[cidx * BLD + 4 * s4 + kq] * dvec[16 * K + 4 * s4 + kq]);
+        const double bv = Lj[cidx * BLD + 4 * s4 + kq];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) C[(kq + 4 * rg) * BLD + cidx] = acc[rg];
+}
+__device__ __forceinline__ void solve_factor_lookahead(double* __restrict__ L, int* __restrict__ s_q, double* __restrict__ y, double* __restrict__ dvec,
+                                                       double* __restrict__ dinv, const int nb, const int tid) {
+    const int wv = tid >> 6, l = tid & 63, NWV = SOLVE_THREADS / 64;
+    if (wv * 48 < (nb - 1) * 16 || wv == 0) solve_eliminate_column_la(L, y, dvec, dinv, 0, nb, wv, l);
+    __syncthreads();
+    for (int K = 0; K + 1 < nb; K++) {
+        // (a) the tiles of block column K + 1: (I, K + 1), I = K + 1 .. nb - 1
+        for (int I = K + 1 + wv; I < nb; I += NWV) solve_update_tile_la(L, dvec, K, I, K + 1, l);
+        if (tid == 0) *s_q = 0;
+        __syncthreads();
+        // (b) column K + 1 is eliminated by the waves that carry its rows; every wave then draws the remaining tiles (I, J), K + 2 <= J <= I, of step K
+        const int nbelow1 = (nb - K - 2) * 16;
+        if (wv * 48 < nbelow1 || wv == 0) solve_eliminate_column_la(L, y, dvec, dinv, K + 1, nb, wv, l);
+        const int nt = nb - K - 2, ntiles = nt * (nt + 1) / 2;
+        for (;;) {
+            int tix = 0;
+            if (l == 0) tix = atomicAdd(s_q, 1);
+            tix = __builtin_amdgcn_readfirstlane(tix);
+            if (tix >= ntiles) break;
+            int a = 0, rem = tix;
+            while (rem >= a + 1) { rem -= a + 1; a++; }
+            solve_update_tile_la(L, dvec, K, K + 2 + a, K + 2 + rem, l);
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ void publish_x_entry(const BacksubCall& BC, const int i, const double v) {
     const unsigned long long tk = (unsigned long long)(unsigned)BC.ticket << 32;
     __hip_atomic_store(BC.xpub + 2 * i, tk | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1129,7 +1232,11 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
     __syncthreads();
     DBG_T(A, 49);
     const int wv = tid >> 6, l = tid & 63, NWV = SOLVE_THREADS / 64;
-    for (int K = 0; K < nb; K++) {
+    bool factored = false;
+    if constexpr (WIDE_OK && !HYBRID && !MERGE) {
+        if (nb >= SOLVE_LOOKAHEAD_NB && !A.no_lookahead) { solve_factor_lookahead(L, reinterpret_cast<int*>(Wk), y, dvec, dinv, nb, tid); factored = true; }
+    }
+    for (int K = 0; K < nb && !factored; K++) {
         DBG_T(A, 64 + 2 * K);
         // (1) block column K, ONE ROW PER LANE in registers: lanes 0-15 carry the diagonal block, lanes 16-63 up to 48 rows
         //     of the panel below it (further waves repeat the diagonal rows and take the next 48 panel rows).  The 16

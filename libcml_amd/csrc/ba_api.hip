@@ -40,6 +40,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.r_idepth = c->r_idepth.as<double>(); A.point_res = c->point_res.as<int>();
     A.pair_code = c->pair_code.as<int>(); A.pair_pos = c->pair_pos.as<int>(); A.pair_stride = c->pair_stride;
     A.lin_partial = c->lin_partial.as<double>(); A.fuse_apply = 0; A.records_only = 0;
+    { static const bool nla = getenv("CMLHIP_NO_LOOKAHEAD") != nullptr; A.no_lookahead = nla ? 1 : 0; }
     A.dbg = c->dbg_on ? c->dbg.as<long long>() : nullptr;
     return CMLHIP_OK;
 }

@@ -73,6 +73,7 @@ struct BAArgs {
     const unsigned char* pt_mask; // optional per-point selection (marginalisation passes); null = every point
     int fuse_apply;               // residual kernel also performs applyRes(copyJacobians=true) (valid when the step is always accepted)
     int records_only;             // k_ba_linearize: only re-create the efsJ record of every good residual (cml_materialize_records)
+    int no_lookahead;             // development (CMLHIP_NO_LOOKAHEAD): the plain factorisation loop for wide systems too
 };
 
 #define CML_DEBUG_RS_TILES 4096                 // development: per-tile stamps of k_ba_lin_rs behind the CMLHIP_DEBUG_SLOTS (cmlhip_debug_timestamps)
