@@ -396,7 +396,9 @@ def main():
     for _ in range(args.warmup):
         ctx.ba_iteration_async(lam)
     _dbg('warmup queued')
-    stride = 4 if args.steps >= 16 else (2 if args.steps >= 4 else 1)     # every stride-th step carries the profile events on its dispatches
+    # every stride-th step carries the profile events on its dispatches (an event-carrying dispatch costs the pipeline ~3 us: at
+    # stride 4 the contract region ran 1.4 us per step behind the regions without events)
+    stride = 8 if args.steps >= 16 else (2 if args.steps >= 4 else 1)
     ctx.profile_stride(stride)
     ctx.profile_select(1)                                                 # contract region: events on the roofline kernel's dispatch only
     ctx.profile_enable((args.steps + stride - 1) // stride)

@@ -71,6 +71,9 @@ def test_resident_kernel_matches_record_kernel(config, half, tile):
         pa, pb = a.ba_pair_acc(0), b.ba_pair_acc(0)
         for q in range(I.N * I.N):
             assert np.abs(pa[q] - pb[q]).max() <= 2e-5 * max(np.abs(pa[q]).max(), 1e-30), q
+        # ... and in fact in every bit: the tiles are accumulated in the slot order of the record path, and the 256-thread accumulate
+        # launch of the resident loop (k_ba_acc_rs: 4 waves carry the 16 running sums) adds them in the order of the 1024-thread one
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), "pair blocks: records / k_ba_acc vs tiles / k_ba_acc_rs"
         assert D.rel(Hb[0], Ha[0]) < 2e-5 and D.rel(Hb[1], Ha[1]) < 2e-5
         assert D.rel(Hb[4], Ha[4]) < 5e-5 and D.rel(Hb[5], Ha[5]) < 5e-5
         qa, qb = a.ba_point_acc(), b.ba_point_acc()
