@@ -11,7 +11,9 @@ ctx.sync()
 NS = 128 + 5 * 1024 * 2
 out = np.zeros(NS, np.int64)
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 1, None))
-for _ in range(1): ctx.ba_iteration_async(1e-5)
+# several iterations: the stamps kept are those of the LAST one, which runs with the queue ahead of the device (the first launches after
+# the synchronising enable call wait for the host between kernels: 'first start' columns 10-20 us apart that no steady-state step shows)
+for _ in range(6): ctx.ba_iteration_async(1e-5)
 ctx.sync()
 ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 0, out.ctypes.data_as(C.POINTER(C.c_longlong))))
 def seg(name, a, b):
