@@ -38,8 +38,11 @@ __device__ __forceinline__ float4 rs4_load_texel(const void* img, size_t i) {
         __half2 a = *reinterpret_cast<__half2*>(&v.x), b = *reinterpret_cast<__half2*>(&v.y);
         return make_float4(__low2float(a), __high2float(a), __low2float(b), 0.f);
     }
-    const float4_ t = ((g_f4)img)[i];
-    return make_float4(t.x, t.y, t.z, t.w);
+    // (three dwords: with the pad lane loaded too the register allocator hands that dead register to the next temporary and waits for
+    //  the load to land first — an s_waitcnt right behind the texel loads)
+    typedef float float3_ __attribute__((ext_vector_type(3)));
+    const float3_ t = *reinterpret_cast<const float3_ __attribute__((address_space(1)))*>((g_f4)img + i);
+    return make_float4(t.x, t.y, t.z, 0.f);
 }
 
 // value held by quad lane `L` (0..3) of this lane's group of 4: DPP quad_perm, no LDS
@@ -225,7 +228,14 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     const float c1 = rs4_jpdc<false>(j + 4, E0, E1, E3, E4, E6, E7, u, v, fxf, fyf, drescale, rx, ry, A.scale_f, A.scale_c, rfx, rfy);
     // Jpdd[j], j < 2                                                                 (:178-182)
     const bool odd = j & 1;
-    const double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
+    double dd = drescale * ((odd ? et1 : et0) - et2 * (odd ? v : u)) * (odd ? fyf : fxf);
+    // (pinned: the values are first used in the staging, beyond the exit branch below, and the compiler's code sinking moves the whole
+    //  evaluation down there — 130 instructions on the wave's critical path instead of under the texel round trip; the scheduling
+    //  barriers alone do not hold it, they act after the sinking)
+    float xa0p = xa0, xa1p = xa1, xb0p = xb0, xb1p = xb1, c0p = c0, c1p = c1;
+#ifndef RS4_NO_GEOM_PIN
+    asm volatile("" : "+v"(xa0p), "+v"(xa1p), "+v"(xb0p), "+v"(xb1p), "+v"(c0p), "+v"(c1p), "+v"(dd));
+#endif
     __builtin_amdgcn_sched_barrier(0);
     RS4_STAMP(3);
     float I[2], gx[2], gy[2];
@@ -372,9 +382,9 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         // Every lane issues the SAME stores with per-lane addresses (a lane with nothing to contribute to a group writes a spare slot,
         // 42..44): a lane-divergent `if` around an LDS access costs a branch each.
         const bool lo2 = j < 2;
-        S[j] = flip ? xa0 : 0.f; S[6 + j] = flip ? xa1 : 0.f;
-        S[lo2 ? 4 + j : 42] = flip ? xb0 : 0.f; S[lo2 ? 10 + j : 43] = flip ? xb1 : 0.f;
-        S[12 + j] = flip ? c0 : 0.f; S[16 + j] = flip ? c1 : 0.f;
+        S[j] = flip ? xa0p : 0.f; S[6 + j] = flip ? xa1p : 0.f;
+        S[lo2 ? 4 + j : 42] = flip ? xb0p : 0.f; S[lo2 ? 10 + j : 43] = flip ? xb1p : 0.f;
+        S[12 + j] = flip ? c0p : 0.f; S[16 + j] = flip ? c1p : 0.f;
         S[lo2 ? 40 + j : 44] = flip ? (float)dd : 0.f;
         // the sums of this lane (staged layout of k_ba_acc: 22..25 JIdx2, 26..29 JabJIdx, 30..33 Jab2, 34,35 JI^T r, 36,37 Jab^T r, 38 r^T r)
         //   lane 0: J00 -> 22, Q10 -> 27, B00 -> 30     lane 1: J10 -> 23, 24, Q01 -> 28, B01 -> 31, 32
