@@ -486,9 +486,12 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
 #define RS4_PAIR_TAB 128
 struct RsPairTab { int4 e[RS4_PAIR_TAB]; };
 template <bool HALF>
-__global__ __launch_bounds__(256, 1) void k_ba_lin_rs4_2d(BAArgs A, RsArgs X, RsPairTab Q) {
+#ifndef RS4_2D_WPB
+#define RS4_2D_WPB 4         // waves per workgroup of the 2-D launch
+#endif
+__global__ __launch_bounds__(64 * RS4_2D_WPB, 1) void k_ba_lin_rs4_2d(BAArgs A, RsArgs X, RsPairTab Q) {
     const int4 e = Q.e[blockIdx.y];
-    const int lt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));        // tile of the pair
+    const int lt = __builtin_amdgcn_readfirstlane(blockIdx.x * RS4_2D_WPB + (threadIdx.x >> 6));        // tile of the pair
     const int left = e.y - lt * RS_RES;
     // a wave beyond its pair's last tile leaves where the stop flag is tested — behind the loads of the input trip (clamped onto the
     // pair's first residuals), not up here: a branch ahead of them makes the entry, the control word and the arguments three waits
@@ -508,9 +511,9 @@ int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
     if (small && !(e_1d && atoi(e_1d)) && c->rs_pair_n > 0 && c->rs_pair_n <= RS4_PAIR_TAB) {
         RsPairTab Q;
         memcpy(Q.e, c->h_rs_pair_tab.data(), 16 * (size_t)c->rs_pair_n);
-        const dim3 grid(cml_div_up(c->rs_pair_max_tiles, 4), c->rs_pair_n);
-        if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<true>), grid, 256, 0, A, X, Q);
-        else CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<false>), grid, 256, 0, A, X, Q);
+        const dim3 grid(cml_div_up(c->rs_pair_max_tiles, RS4_2D_WPB), c->rs_pair_n);
+        if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<true>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);
+        else CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<false>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);
         return CMLHIP_OK;
     }
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) {
