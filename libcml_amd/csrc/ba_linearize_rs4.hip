@@ -507,9 +507,10 @@ int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
     // development switch only.
     static const char* e_minb = getenv("CMLHIP_RS4_MINB");   // development: 3 forces the 168-VGPR instantiation
     const bool small = !(e_minb && atoi(e_minb) == 3);                      // at most two workgroups per CU: 196 VGPRs still leave two waves per SIMD
-    static const char* e_1d = getenv("CMLHIP_RS4_1D");      // development: 1 = the 1-D launch (tile table in memory) whatever the window
+    const char* e_1d = getenv("CMLHIP_RS4_1D");             // development / tests: 1 = the 1-D launch (tile table in memory) whatever the window (read per launch)
     if (small && !(e_1d && atoi(e_1d)) && c->rs_pair_n > 0 && c->rs_pair_n <= RS4_PAIR_TAB) {
         RsPairTab Q;
+        memset(&Q, 0, sizeof Q);
         memcpy(Q.e, c->h_rs_pair_tab.data(), 16 * (size_t)c->rs_pair_n);
         const dim3 grid(cml_div_up(c->rs_pair_max_tiles, RS4_2D_WPB), c->rs_pair_n);
         if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<true>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);

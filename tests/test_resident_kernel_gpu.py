@@ -87,3 +87,42 @@ def test_resident_kernel_matches_record_kernel(config, half, tile):
         assert (sa2["new_state"] != sb2["new_state"]).sum() <= max(2, I.R // 2000)      # inputs now differ by fp32 accumulation noise
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("config", ["small", "B"])
+def test_two_launch_forms_of_the_4_lane_kernel_agree(config):
+    """k_ba_lin_rs4 is launched over (tile group, pair) with the pair table in the kernel arguments when the window has at most 128
+    pairs, and over a tile table in memory otherwise (CMLHIP_RS4_1D=1 forces that form): same body, same bits — states, energies,
+    JpJdF, centre projections, pair blocks and the state after two more iterations."""
+    I = S.make_inputs(config)
+    out = []
+    for one_d in (False, True):
+        if one_d:
+            os.environ["CMLHIP_RS4_1D"] = "1"
+        try:
+            c = _make(I, True, abi.TEXEL_F32, 16)
+            try:
+                c.ba_linearize(); c.ba_apply(1)
+                D.accumulate(c, I)
+                for _ in range(3):
+                    c.ba_iteration_async(1e-5)
+                c.sync()
+                st = c.ba_states()
+                D.accumulate(c, I)
+                out.append((st, c.ba_jpjdf().copy(), c.ba_center().copy(), c.ba_get_idepth().copy(), c.ba_pair_acc(0).copy()))
+            finally:
+                c.close()
+        finally:
+            os.environ.pop("CMLHIP_RS4_1D", None)
+    a, b = out
+    for k in ("state", "new_state", "good"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    for k in ("energy", "new_energy", "new_energy_wo"):
+        assert np.array_equal(a[0][k].view(np.uint32), b[0][k].view(np.uint32)), k
+    g = a[0]["good"] == 1
+    assert g.sum() > 10
+    assert np.array_equal(a[1][g].view(np.uint32), b[1][g].view(np.uint32))
+    IN = a[0]["new_state"] == 0
+    assert np.array_equal(a[2][IN].view(np.uint32), b[2][IN].view(np.uint32))
+    assert np.array_equal(a[3].view(np.uint64), b[3].view(np.uint64))
+    assert np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32))
