@@ -27,7 +27,9 @@ __global__ void k_reproj_solve(int N, double lambda, const double* __restrict__ 
     const int m = 6 * N;
     double A[36];
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) A[i * 6 + j] = M6[(size_t)(6 * f + i) * m + 6 * f + j];
-    reproj_solve6(A, b6 + 6 * f, lambda, x6 + 6 * f);
+    double wA[36], wx[6];
+    int wtr[6];
+    reproj_solve6(A, b6 + 6 * f, lambda, x6 + 6 * f, wA, wx, wtr);
 }
 
 // observations sorted by frame (stable), CSR offsets, and the caller's index of every sorted observation

@@ -131,9 +131,10 @@ __device__ __forceinline__ double d_dtukey(double v, double d, double th) { // D
 
 // indirectX = M.ldlt().solve(-bM) with M(i,i) *= (1+lambda) (BA.cpp:2695-2700); M is block diagonal, so one 6x6
 // diagonally-pivoted LDL^T per frame (Eigen LDLT.h:300-396 / :560-600 semantics incl. the zero-pivot rule).  One lane.
-__device__ inline void reproj_solve6(const double* __restrict__ Min /* 6x6 row-major */, const double* __restrict__ bin, double lambda, double* __restrict__ xout) {
-    double A[36], x[6];
-    int tr[6];
+// A (36), x (6), tr (6): the caller's work storage — the pivoting indexes them dynamically, so private arrays live in a scratch frame (memory
+// round trips on a single lane, and a kernel with a scratch frame pays for it at every dispatch): the frame workgroup passes LDS.
+__device__ inline void reproj_solve6(const double* __restrict__ Min /* 6x6 row-major */, const double* __restrict__ bin, double lambda, double* __restrict__ xout,
+                                     double* __restrict__ A, double* __restrict__ x, int* __restrict__ tr) {
     for (int i = 0; i < 6; i++) {
         for (int j = 0; j < 6; j++) A[i * 6 + j] = Min[i * 6 + j];
         A[i * 6 + i] *= (1 + lambda);
@@ -234,7 +235,7 @@ struct ReprojArgs {
     int* ready; int ticket;                    // non-null: per-frame completion tickets for a consumer inside the same launch
 };
 #define RP_THREADS 512             // lanes of a frame's workgroup (the reduction order depends on it: the standalone launch and the solve launch use the same)
-#define RP_LDS_DOUBLES (12 + 46 + (RP_THREADS / 64) * 27 + 27)
+#define RP_LDS_DOUBLES (12 + 46 + (RP_THREADS / 64) * 27 + 27 + 36 + 6 + 36 + 6 + 3 + 6 + 1)      // ... + lane 0's M, b and the work storage of the 6x6 solve
 
 // the whole term of frame `i` by one workgroup of RP_THREADS lanes; lds: RP_LDS_DOUBLES doubles
 __device__ inline void reproj_frame_block(const ReprojArgs& a, int i, double* __restrict__ lds) {
@@ -287,16 +288,31 @@ __device__ inline void reproj_frame_block(const ReprojArgs& a, int i, double* __
             for (int r = 0; r < 6; r++) acc[21 + r] += f[r] * res;                  // BA.cpp:2655
         }
     }
-    for (int e = 0; e < 27; e++) {                                              // fixed-order butterfly inside the wave
+    // fixed-order sums inside the wave on the DPP path: row_shr 1 / 2 / 4 / 8 inside each 16-lane row, then row_bcast:15 and row_bcast:31
+    // carry the row totals forward — the total is valid in lane 63.  (Round 3, first form: six __shfl_down steps per sum, i.e. 27 x 6
+    // dependent LDS-crossbar round trips of two ds_bpermute each: 6.9 of the frame workgroup's 19.6 us; in-kernel stamps.)  The 27 chains
+    // are independent: unrolled, they interleave.
+#pragma unroll
+    for (int e = 0; e < 27; e++) {
         double v = acc[e];
-        for (int s = 32; s >= 1; s >>= 1) v += __shfl_down(v, s, 64);
-        if ((tid & 63) == 0) sW[(tid >> 6) * 27 + e] = v;
+#define RP_DPP_ADD(ctrl, rmask) do { \
+            const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false); \
+            const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false); \
+            v += __hiloint2double(hi_, lo_); } while (0)
+        RP_DPP_ADD(0x111, 0xf);      // row_shr:1   (lanes without a source add +0.0)
+        RP_DPP_ADD(0x112, 0xf);      // row_shr:2
+        RP_DPP_ADD(0x114, 0xf);      // row_shr:4
+        RP_DPP_ADD(0x118, 0xf);      // row_shr:8
+        RP_DPP_ADD(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+        RP_DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2 and 3
+#undef RP_DPP_ADD
+        if ((tid & 63) == 63) sW[(tid >> 6) * 27 + e] = v;
     }
     __syncthreads();
     if (tid < 27) { double v = sW[tid]; for (int wq = 1; wq < RP_THREADS / 64; wq++) v += sW[27 * wq + tid]; sTot[tid] = v; }      // the waves in sequence
     __syncthreads();
     if (tid == 0) {
-        double Mf[36], bf[6];
+        double* Mf = sTot + 27; double* bf = Mf + 36;          // lane 0's scratchpads in LDS (see reproj_solve6)
         int idx = 0;
         for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { Mf[r * 6 + c] = Mf[c * 6 + r] = sTot[idx]; idx++; }
         for (int r = 0; r < 6; r++) bf[r] = sTot[21 + r];
@@ -304,8 +320,8 @@ __device__ inline void reproj_frame_block(const ReprojArgs& a, int i, double* __
         if (a.M6) for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) a.M6[(size_t)(6 * i + r) * m + 6 * i + c] = Mf[r * 6 + c];
         if (a.b6) for (int r = 0; r < 6; r++) a.b6[6 * i + r] = bf[r];
         if (a.x6) {
-            double xs[6];
-            reproj_solve6(Mf, bf, a.lambda, xs);
+            double* xs = bf + 6 + 36 + 6 + 3;
+            reproj_solve6(Mf, bf, a.lambda, xs, bf + 6, bf + 6 + 36, reinterpret_cast<int*>(bf + 6 + 36 + 6));
             if (a.ready) {
                 // consumed by ANOTHER workgroup of the same launch (the solve workgroup of the resident iteration): device-scope stores,
                 // then, once they are acknowledged, the frame's ticket — the consumer polls it and reads the solution with device-scope loads
