@@ -1177,7 +1177,9 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
             const int b6 = bx_ - 2 - nrp;                     // block of the back-substitution: [frame step] [point blocks ...]
             if (BC.g_pts > 0 && b6 >= 0) {
                 if (BC.F.on && b6 == 0) {
-                    if (wait_and_fetch_x(BC.xticket, BC.ticket, BC.xpub, n, sm, SOLVE_THREADS)) frame_step_block(BC.F, sm);
+                    FrameStepPre FP;
+                    frame_step_prefetch(BC.F, FP);                  // (ahead of the wait: see FrameStepPre)
+                    if (wait_and_fetch_x(BC.xticket, BC.ticket, BC.xpub, n, sm, SOLVE_THREADS)) frame_step_block(BC.F, sm, FP);
                     else if (tid == 0) atomicAdd(&lin_out->nonfinite, 1);
                     return;
                 }
@@ -1646,7 +1648,9 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
     if (A.ctl && A.ctl->stop) return;
     const double* __restrict__ x = x_in;
     if (!INLAUNCH && F.on && bx_ == gx_ - 1) {               // last workgroup: the frames' half of doStepFromBackup
-        frame_step_block(F, x);
+        FrameStepPre FP;
+        frame_step_prefetch(F, FP);
+        frame_step_block(F, x, FP);
         DBG_BLK_END(A.dbg, 4);
         return;
     }

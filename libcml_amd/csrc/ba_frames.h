@@ -20,26 +20,53 @@ struct FrameStepArgs {
     float* frame_sums;             // optional: sumA sumB sumT sumR of doStepFromBackup (BA.cpp:957-972) for the convergence test
 };
 
-__device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const double* __restrict__ x) {
+// What the frame step reads that does NOT depend on x — requested by frame_step_prefetch AHEAD of the wait for x when the block rides in the
+// solve launch (in-kernel stamps, round 3: this block, not the point blocks, ended the launch — 6.8 against 4.0 us behind the solve
+// workgroup's last stamp: the frame states were a trip behind x, and each of 64 lanes then pulled the 128 adjoint entries of its pair,
+// 8192 scattered 8-byte loads, for the 128 multiply-adds of computeDelta).  With up to two (pair, column) entries of adHTd per thread
+// the adjoint columns are 16 values per entry, held in registers across the wait; the sums keep their order (same bits).
+struct FrameStepPre {
+    double ahc[2][8], atc[2][8];
+    double s_old[8], s_zero[8], p_zero[8], evq[4], evt[3], ab_exposure;
+    bool fix_pose, dist;
+};
+__device__ __forceinline__ void frame_step_prefetch(const FrameStepArgs& F, FrameStepPre& P) {
+    const int tid = threadIdx.x, N = F.N, ne = N * N * 8, bd = blockDim.x;
+    P.dist = !F.adhtd_done && ne <= 2 * bd;
+    if (P.dist) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = min(tid + u * bd, ne - 1);
+            const int j = e & 7, q = e >> 3, h = q / N, t = q % N, idx = h + t * N;
+            const double* AH = F.adH + 64 * (size_t)idx; const double* AT = F.adT + 64 * (size_t)idx;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { P.ahc[u][i] = AH[i * 8 + j]; P.atc[u][i] = AT[i * 8 + j]; }
+        }
+    }
+    const cmlhip_ba_frame_state& S = F.fs[min(tid, N - 1)];
+    // Everything the step reads, in ONE round trip: written field by field against the record in memory, every load waits behind the
+    // store before it (same type, possibly aliased — the compiler must keep the order): eight dependent round trips.
+#pragma unroll
+    for (int k = 0; k < 8; k++) { P.s_old[k] = S.state[k]; P.s_zero[k] = S.state_zero[k]; P.p_zero[k] = S.prior_zero[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) P.evq[k] = S.eval_q[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) P.evt[k] = S.eval_t[k];
+    P.fix_pose = S.fix_pose != 0;
+    P.ab_exposure = S.ab_exposure;
+}
+__device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const double* __restrict__ x, const FrameStepPre& P) {
     using cml_amd::SE3;
     using cml_amd::Exposure;
     __shared__ double s_w2c[CMLHIP_MAX_FRAMES][7], s_c2w[CMLHIP_MAX_FRAMES][7], s_aff[CMLHIP_MAX_FRAMES][3], s_delta[CMLHIP_MAX_FRAMES][8], s_step[CMLHIP_MAX_FRAMES][8];
     const int tid = threadIdx.x, N = F.N;
+    const bool dist = P.dist;
     if (tid < N) {
         cmlhip_ba_frame_state& S = F.fs[tid];
         double step[8], st[8];
-        // Everything the step reads is fetched first, in ONE round trip: written field by field against the record in memory, every
-        // load waits behind the store before it (same type, possibly aliased — the compiler must keep the order): eight dependent
-        // round trips on the one workgroup the whole launch waits for.
-        double s_old[8], s_zero[8], p_zero[8], evq[4], evt[3];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { s_old[k] = S.state[k]; s_zero[k] = S.state_zero[k]; p_zero[k] = S.prior_zero[k]; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) evq[k] = S.eval_q[k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) evt[k] = S.eval_t[k];
-        const bool fix_pose = S.fix_pose != 0;
-        const double ab_exposure = S.ab_exposure;
+        const double* s_old = P.s_old; const double* s_zero = P.s_zero; const double* p_zero = P.p_zero; const double* evq = P.evq; const double* evt = P.evt;
+        const bool fix_pose = P.fix_pose;
+        const double ab_exposure = P.ab_exposure;
         bool fin = true;
 #pragma unroll
         for (int k = 0; k < 8; k++) { step[k] = -x[4 + 8 * tid + k]; fin = fin && isfinite(step[k]); }     // BA.cpp:1433-1441
@@ -79,6 +106,22 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
         }
         F.frame_sums[0] = sumA; F.frame_sums[1] = sumB; F.frame_sums[2] = sumT; F.frame_sums[3] = sumR;
     }
+    if (dist) {
+        // computeDelta, BA.cpp:1120-1135, one (pair, column) entry per thread and pass from the adjoint columns requested ahead: the
+        // sums of the per-pair form below, term for term
+        const int ne = N * N * 8, bd = blockDim.x;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = tid + u * bd;
+            if (e < ne) {
+                const int j = e & 7, q = e >> 3, h = q / N, t = q % N, idx = h + t * N;
+                double sH = 0, sT = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { sH += s_delta[h][i] * P.ahc[u][i]; sT += s_delta[t][i] * P.atc[u][i]; }
+                F.adHTd[8 * (size_t)idx + j] = (float)(sH + sT);
+            }
+        }
+    }
     for (int q = tid; q < N * N; q += blockDim.x) {
         const int h = q / N, t = q % N;
         SE3 Wt, Ch;
@@ -91,7 +134,7 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
         // (a chain of eight round trips on the one workgroup the launch waits for).  Same sums in the same order.
         const int idx = h + t * N;
         double sH[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sT[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (!F.adhtd_done) {
+        if (!F.adhtd_done && !dist) {
             const double* AH = F.adH + 64 * (size_t)idx; const double* AT = F.adT + 64 * (size_t)idx;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -111,7 +154,7 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
 #pragma unroll
         for (int k = 0; k < 3; k++) P.t[k] = ll.t[k];
         P.aff_a = a; P.aff_b = b;
-        if (F.adhtd_done) continue;
+        if (F.adhtd_done || dist) continue;
 #pragma unroll
         for (int j = 0; j < 8; j++) F.adHTd[8 * (size_t)idx + j] = (float)(sH[j] + sT[j]);
     }
