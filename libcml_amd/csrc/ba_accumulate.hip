@@ -45,6 +45,16 @@ __device__ __forceinline__ float wave_sum_dpp63(float v) {
     return v;
 }
 
+__device__ __forceinline__ double wave_sum_dpp63_d(double v) {      // the same path for a double (two 32-bit DPP moves per step, one fp64 add)
+#define DPP_ADD_D(ctrl, rmask) do { \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false); \
+        v += __hiloint2double(hi_, lo_); } while (0)
+    DPP_ADD_D(0x111, 0xf); DPP_ADD_D(0x112, 0xf); DPP_ADD_D(0x114, 0xf); DPP_ADD_D(0x118, 0xf); DPP_ADD_D(0x142, 0xa); DPP_ADD_D(0x143, 0xc);
+#undef DPP_ADD_D
+    return v;
+}
+
 __device__ __forceinline__ float sum8(float v) {          // sum over 8 consecutive lanes (xor butterflies stay inside the group)
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
     return v;
@@ -1179,7 +1189,7 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
                 if (BC.F.on && b6 == 0) {
                     FrameStepPre FP;
                     frame_step_prefetch(BC.F, FP);                  // (ahead of the wait: see FrameStepPre)
-                    if (wait_and_fetch_x(BC.xticket, BC.ticket, BC.xpub, n, sm, SOLVE_THREADS)) frame_step_block(BC.F, sm, FP);
+                    if (wait_and_fetch_x(BC.xticket, BC.ticket, BC.xpub, n, sm, SOLVE_THREADS)) frame_step_block(BC.F, sm, FP, A.dbg ? A.dbg + 104 : nullptr);
                     else if (tid == 0) atomicAdd(&lin_out->nonfinite, 1);
                     return;
                 }
@@ -1442,9 +1452,9 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
 #pragma unroll
             for (int k = 0; k < ORTHO_K; k++) { const int i = l + 64 * k; sdot += u_dot[k] * xs[min(i, n - 1)]; }
             for (int i = l + 64 * ORTHO_K; i < n; i += 64) sdot += nullU[(size_t)wv * n + i] * xs[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
-            if (l == 0) dots[wv] = sdot;
+            // (DPP path, total in lane 63: six xor-shuffles of a double are twelve LDS-crossbar round trips on the critical path of the iteration)
+            sdot = wave_sum_dpp63_d(sdot);
+            if (l == 63) dots[wv] = sdot;
         }
         __syncthreads();
         for (int i = tid; i < n; i += SOLVE_THREADS) {
@@ -1637,6 +1647,9 @@ __device__ __forceinline__ bool wait_and_fetch_x(const int* xticket, int ticket,
 // NT = 256: the standalone launch.  NT = 512, INLAUNCH: the point workgroups ride in the SOLVE launch (blocks of 512 threads = two
 // virtual 256-thread blocks: same points per virtual block, same partial sums, bit-identical results), request everything that does
 // not depend on x while the factorisation runs, and continue when the solve workgroup publishes x.
+// development stamps (cmlhip_debug_timestamps, slots 96..100): the second point block of the merged launch — wait begun, x in LDS, table built,
+// steps stored, partials stored (tools/probe_phases.py)
+#define BS_STAMP(k) do { if (INLAUNCH && A.dbg && bx_ == 1 && threadIdx.x == 0) A.dbg[96 + (k)] = wall_clock64(); } while (0)
 template <int NT, bool INLAUNCH>
 __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double* __restrict__ adH, const double* __restrict__ adT,
                                                   const double* __restrict__ x_in, LinSummary* __restrict__ sum, float* __restrict__ step_partial,
@@ -1701,8 +1714,10 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
     }
     if (INLAUNCH) {
         double* s_x = s_xAd + N * N * 8;
+        BS_STAMP(0);
         if (!wait_and_fetch_x(xticket, ticket, xpub, A.n, s_x, NT)) { if (threadIdx.x == 0) atomicAdd(&sum->nonfinite, 1); return; }
         x = s_x;
+        BS_STAMP(1);
     }
     const double xc = x[i & 3];
     if (xad) {                                               // wide windows: the table was built once by k_ba_xad
@@ -1724,6 +1739,7 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
     }
     if (!INLAUNCH && bx_ == 0 && threadIdx.x == 0) sum->nonfinite = 0;      // (in the solve launch its workgroup 0 reset the counter at its start)
     __syncthreads();
+    BS_STAMP(2);
     float sumID = 0, sumNID = 0, numID = 0;
     {
         int ngood = 0;
@@ -1774,16 +1790,18 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
             for (int ps = 0; ps < 4; ps++) if (pv && nid_ok && ress[ps] >= 0) A.r_idepth[ress[ps]] = nid_w;
         }
     }
+    BS_STAMP(3);
     if (do_step) {                                           // fixed-order block partials; the host adds the few blocks
-        sumID = wave_sum(sumID); sumNID = wave_sum(sumNID); numID = wave_sum(numID);
+        sumID = wave_sum_dpp63(sumID); sumNID = wave_sum_dpp63(sumNID); numID = wave_sum_dpp63(numID);      // (totals in lane 63)
         float* red = s_redf + 12 * half;                      // [3][4] of this virtual block
-        if ((threadIdx.x & 63) == 0) { red[0 * 4 + (t256 >> 6)] = sumID; red[1 * 4 + (t256 >> 6)] = sumNID; red[2 * 4 + (t256 >> 6)] = numID; }
+        if ((threadIdx.x & 63) == 63) { red[0 * 4 + (t256 >> 6)] = sumID; red[1 * 4 + (t256 >> 6)] = sumNID; red[2 * 4 + (t256 >> 6)] = numID; }
         __syncthreads();
         if (t256 < 3 && vbx < A.n_step_blocks) {
             const int k = t256;
             step_partial[4 * vbx + k] = ((red[k * 4 + 0] + red[k * 4 + 1]) + red[k * 4 + 2]) + red[k * 4 + 3];
         }
     }
+    BS_STAMP(4);
     DBG_BLK_END(A.dbg, 4);
 }
 __global__ __launch_bounds__(256) void k_ba_backsub(BAArgs A, const double* __restrict__ adH, const double* __restrict__ adT,

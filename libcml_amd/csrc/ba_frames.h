@@ -55,8 +55,11 @@ __device__ __forceinline__ void frame_step_prefetch(const FrameStepArgs& F, Fram
     P.fix_pose = S.fix_pose != 0;
     P.ab_exposure = S.ab_exposure;
 }
-__device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const double* __restrict__ x, const FrameStepPre& P) {
+// fsdbg: optional development stamps (x in LDS = entry, states stepped, barrier passed, pair records stored)
+#define FS_STAMP(k) do { if (fsdbg && threadIdx.x == 0) fsdbg[k] = wall_clock64(); } while (0)
+__device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const double* __restrict__ x, const FrameStepPre& P, long long* fsdbg = nullptr) {
     using cml_amd::SE3;
+    FS_STAMP(0);
     using cml_amd::Exposure;
     __shared__ double s_w2c[CMLHIP_MAX_FRAMES][7], s_c2w[CMLHIP_MAX_FRAMES][7], s_aff[CMLHIP_MAX_FRAMES][3], s_delta[CMLHIP_MAX_FRAMES][8], s_step[CMLHIP_MAX_FRAMES][8];
     const int tid = threadIdx.x, N = F.N;
@@ -93,8 +96,10 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
 #pragma unroll
         for (int k = 0; k < 3; k++) { s_w2c[tid][4 + k] = W.t[k]; s_c2w[tid][4 + k] = Ci.t[k]; F.pre_w2c[7 * tid + 4 + k] = W.t[k]; }
         s_aff[tid][0] = ab_exposure; s_aff[tid][1] = F.sc[2] * st[6]; s_aff[tid][2] = F.sc[3] * st[7];    // aff_g2l
+        FS_STAMP(1);
     }
     __syncthreads();
+    FS_STAMP(2);
     if (F.frame_sums && tid == 0) {                                    // fp32 sums in frame order, as the host loop forms them
         float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
         for (int f = 0; f < N; f++) {
@@ -158,6 +163,7 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
 #pragma unroll
         for (int j = 0; j < 8; j++) F.adHTd[8 * (size_t)idx + j] = (float)(sH[j] + sT[j]);
     }
+    FS_STAMP(3);
 }
 
 // state + step - state_zero of frame f, entry k, exactly as frame_step_block forms it (setStep's non-finite and fix_pose rules included)

@@ -75,8 +75,14 @@ struct SE3 {
             real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * p4;
         } else {
             theta = std::sqrt(th2);
+#ifdef __HIP_DEVICE_COMPILE__
+            double sh_, ch_;                          // (device: one argument reduction for the pair — the frame step is a single-lane chain
+            ::sincos(0.5 * theta, &sh_, &ch_);         //  on the workgroup that ends the solve launch)
+            imag = sh_ / theta; real = ch_;
+#else
             imag = std::sin(0.5 * theta) / theta;
             real = std::cos(0.5 * theta);
+#endif
         }
         SE3 T;
         T.q[0] = real; T.q[1] = imag * om[0]; T.q[2] = imag * om[1]; T.q[3] = imag * om[2];
@@ -85,7 +91,13 @@ struct SE3 {
         mm(O, O, O2);
         if (theta < eps) T.matrix(V);
         else {
+#ifdef __HIP_DEVICE_COMPILE__
+            double st_, ct_;
+            ::sincos(theta, &st_, &ct_);
+            const double a = (1.0 - ct_) / (theta * theta), b = (theta - st_) / (theta * theta * theta);
+#else
             const double a = (1.0 - std::cos(theta)) / (theta * theta), b = (theta - std::sin(theta)) / (theta * theta * theta);
+#endif
             for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + b * O2[i];
         }
         mv(V, xi, T.t);

@@ -45,3 +45,10 @@ b = blk[2]; nb_ = int((b[:, 0] > 0).sum()); d = (b[:nb_, 1] - b[:nb_, 0]) * 0.01
 nrow = W.N + 1
 print("system: SYRK blocks %d dur med %.2f max %.2f ; row blocks dur med %.2f max %.2f" % (nb_ - nrow, np.median(d[:-nrow]), d[:-nrow].max(), np.median(d[-nrow:]), d[-nrow:].max()))
 
+
+if out[96] and out[100]:      # us behind the solve workgroup's last stamp (53)
+    print("a point block of the merged launch: x in LDS %.2f us behind the solve workgroup's last stamp | x.adjoint table %.2f | point steps + stores %.2f | block partials %.2f" % (
+        (out[97] - out[53]) * 0.01, (out[98] - out[97]) * 0.01, (out[99] - out[98]) * 0.01, (out[100] - out[99]) * 0.01))
+if out[104]:
+    print("frame-step block: x in LDS %.2f us behind the solve workgroup's last stamp | states stepped, exp %.2f | barrier %.2f | adHTd + pair records %.2f" % (
+        (out[104] - out[53]) * 0.01, (out[105] - out[104]) * 0.01, (out[106] - out[105]) * 0.01, (out[107] - out[106]) * 0.01))
