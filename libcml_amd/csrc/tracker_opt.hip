@@ -35,7 +35,8 @@ struct TrkOptArgs {
     // them then run the identical Levenberg-Marquardt algebra on identical numbers, no second exchange; smaller levels are evaluated
     // whole by every workgroup (no exchange at all)
     int G, split_min;
-    float* xch;                                        // [n_hyp][2 parities][G][64]
+    float* xch;                                        // [n_hyp][2 parities][G][64] 8-byte words {sum | launch number, exchange number}
+    int epoch;                                         // launch number of this context (16 bits used)
     int* tick;                                         // [n_hyp][G]
 };
 
@@ -249,38 +250,44 @@ __device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3
 // all lanes: computeResidual + computeHessian over the level's list (the per-point arithmetic and the reduction layout of
 // k_tracker_eval, tracker.hip); leaves the 56 sums in s_red
 // the sums of this workgroup's part -> the sums of the level, in every workgroup of the hypothesis (see TrkOptArgs::G)
-__device__ __forceinline__ void to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, float* __restrict__ s_red) {
+__device__ __forceinline__ void to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, float* __restrict__ s_red, const int epoch) {
+    // Every sum travels as ONE self-validating device-scope word {value | seq << 32} (past the non-coherent caches; valid on its own): the
+    // writers neither wait for acknowledgements nor publish a ticket, the readers poll the G words of their sum directly and add them in
+    // workgroup order.  (First form: device-scope stores, a release fence — an L2 write-back —, barrier, ticket; readers polled the G
+    // tickets, fenced (acquire: an L2 invalidation) and then fetched the sums: two fences and a dependent trip more per exchange.)
+    // A workgroup can only write the sums of exchange seq + 2 — the next use of this parity's slots — after it has read every
+    // workgroup's words of seq + 1, which a workgroup still reading seq has not written yet: the slots are never overwritten under a reader.
+    (void)tick;
     const int tid = threadIdx.x;
-    float* mine = xch + ((size_t)(seq & 1) * G + g) * 64;
-    if (tid < TO_NRED) __hip_atomic_store(mine + tid, s_red[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(tick + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long* base = reinterpret_cast<unsigned long long*>(xch) + (size_t)(seq & 1) * G * 64;
+    const unsigned tagv = ((unsigned)epoch << 16) | ((unsigned)seq & 0xffffu);        // launch number | exchange number: words of an earlier call never match
+    const unsigned long long tag = (unsigned long long)tagv << 32;
+    if (tid < TO_NRED) __hip_atomic_store(base + (size_t)g * 64 + tid, tag | (unsigned)__float_as_int(s_red[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __shared__ int s_late;
     if (tid == 0) s_late = 0;
     __syncthreads();
-    if (tid < G) {
-        int spins = 0;
-        // (a workgroup publishes ticket seq + 1 only after it has read every part of seq, so >= seq is "this part is there" and the
-        //  parity-indexed slots are never overwritten under a reader)
-        while (__hip_atomic_load(tick + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) { s_late = 1; break; }          // never spin forever: the level then fails (no terms)
+    float v = 0.f;
+    if (tid < TO_NRED) {
+        bool late = false;
+        for (int q = 0; q < G; q++) {
+            unsigned long long w;
+            int spins = 0;
+            while (((w = __hip_atomic_load(base + (size_t)q * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { late = true; break; }           // never spin forever: the level then fails (no terms)
+            }
+            v += __int_as_float((int)(unsigned)w);
         }
+        if (late) s_late = 1;
     }
     __syncthreads();
-    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (tid < TO_NRED) {
-        float v = 0.f;
-        for (int q = 0; q < G; q++) v += __hip_atomic_load(xch + ((size_t)(seq & 1) * G + q) * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_red[tid] = s_late ? 0.f : v;
-    }
+    if (tid < TO_NRED) s_red[tid] = s_late ? 0.f : v;
     __syncthreads();
 }
 
 template <bool HALF>
 __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red,
-                        const int g, const int G, const int split_min, float* xch, int* tick, int& seq) {
+                        const int g, const int G, const int split_min, float* xch, int* tick, int& seq, const int epoch) {
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     to_float4 acc = {0.f, 0.f, 0.f, 0.f};
     const int Ge = (G > 1 && E.n > split_min) ? G : 1;       // parts of this level (1: every workgroup evaluates all of it)
@@ -382,7 +389,7 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
         s_red[tid] = v;
     }
     __syncthreads();
-    if (Ge > 1) { seq++; to_exchange(xch, tick, g, G, seq, s_red); }
+    if (Ge > 1) { seq++; to_exchange(xch, tick, g, G, seq, s_red, epoch); }
 }
 
 // wave 0: the level's sums -> Residual slots (lane 0) and the scaled 8x8 system, one entry per lane (TR.cpp:405-414, 472-490);
@@ -413,7 +420,7 @@ __device__ __forceinline__ int to_ctrl(const ToState& S) {
 
 // lane 0 books the time since the last mark as algebra, runs the evaluation, books it as evaluation
 #define TO_TIMED_EVAL() do { if (tid == 0) { const long long t_ = wall_clock64(); S.t_alg += t_ - S.t_mark; S.t_mark = t_; } \
-        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, g, A.G, A.split_min, xch, tick, seq); \
+        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, g, A.G, A.split_min, xch, tick, seq, A.epoch); \
         if (tid == 0) { const long long t_ = wall_clock64(); S.t_eval += t_ - S.t_mark; S.t_mark = t_; } } while (0)
 
 enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
     const int tid = threadIdx.x, hyp = blockIdx.x / A.G, g = blockIdx.x % A.G;
     cmlhip_tracker_opt_result* out = A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical)
-    float* xch = A.xch + (size_t)hyp * 2 * A.G * 64;
+    float* xch = A.xch + (size_t)hyp * 2 * 2 * A.G * 64;          // (8-byte words: see to_exchange)
     int* tick = A.tick + (size_t)hyp * A.G;
     int seq = 0;
     const int maxIterations[5] = {10, 20, 50, 50, 50};                               // TR.cpp:23
@@ -625,12 +632,15 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     A.G = G; A.split_min = 2 * TO_THREADS;
     if ((rc = cml_ensure(c, c->trk_hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
     if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp * G))) return rc;
-    const size_t xch_bytes = sizeof(float) * 2 * 64 * (size_t)G * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
+    const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)G * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
     if ((rc = cml_ensure(c, c->trk_xch, xch_bytes + tick_bytes))) return rc;
     if ((rc = cml_h2d(c, c->trk_hyp.p, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
     A.hyp = c->trk_hyp.as<cmlhip_tracker_hypothesis>(); A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
     A.xch = c->trk_xch.as<float>(); A.tick = reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes);
-    if (G > 1) CML_CHECK(c, hipMemsetAsync(A.tick, 0, tick_bytes, c->stream));
+    // (no per-call clearing: the words carry the launch number; a fresh or moved buffer is cleared once)
+    if (c->trk_xch.p != c->trk_xch_seen) { CML_CHECK(c, hipMemsetAsync(c->trk_xch.p, 0, c->trk_xch.bytes, c->stream)); c->trk_xch_seen = c->trk_xch.p; c->trk_epoch = 0; }
+    c->trk_epoch = (c->trk_epoch % 0xfffe) + 1;            // 1 .. 0xfffe: never the zero of a cleared buffer
+    A.epoch = c->trk_epoch;
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp * G, TO_THREADS, 0, A);
     else CML_LAUNCH_EV(c, k_tracker_optimize<false>, n_hyp * G, TO_THREADS, 0, A);
     CML_CHECK(c, hipGetLastError());
