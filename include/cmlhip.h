@@ -550,8 +550,10 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* ctx, double lambda);
 /* Several windows per launch (throughput mode: more sequence shards than GPUs, north_star "independent keyframe windows / sequence
  * shards"): ONE resident iteration of each of the S windows held by ctxs[0..S), in the five launches one window takes (gridDim.y =
  * window, S solve workgroups side by side) on the stream of ctxs[0].  Every window must be uploaded, have its resident state set
- * (cmlhip_ba_set_resident_state) and be a small window (R < 36 k: the 4-lane residual kernel; no hybrid term, no LINEARIZED
- * residuals, no convergence control) — anything else is refused with CMLHIP_ERR_INVALID / _STATE, never routed elsewhere.  A window's
+ * (cmlhip_ba_set_resident_state); the windows of a batch share one residual-kernel regime (all R < 36 k: the 4-lane kernel, or all
+ * R >= 36 k: the lane-per-residual kernel) and one point-slice class, carry no hybrid term, no LINEARIZED residuals and no
+ * convergence control, and fit the batched solve / back-substitution (reduced system resident in LDS; N < 12 or P < 2048) —
+ * anything else is refused with CMLHIP_ERR_INVALID / _STATE, never routed elsewhere.  A window's
  * result is bit-identical to the one cmlhip_ba_iteration_async gives it (same kernel bodies, same arguments).  Synchronise through
  * cmlhip_synchronize(ctxs[0]) before reading any of the windows back or using their contexts on their own again. */
 int cmlhip_ba_iteration_batch(cmlhip_ctx* const* ctxs, int n_windows, double lambda);

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcmlhip.so")
 HOSTLIB = os.path.join(HERE, "libcmlhost.so")
 SOURCES = ["cmlhip_ctx.hip", "ba_linearize.hip", "ba_linearize_rs.hip", "ba_linearize_rs4.hip", "ba_accumulate.hip", "ba_api.hip", "tracker.hip", "tracker_opt.hip", "tracer.hip", "initializer.hip", "pnp.hip", "lba.hip", "reproj.hip"]
-HEADERS = ["cmlhip_internal.h", "ba_common.h", "ba_finish.h", "ba_frames.h", "reproj_dev.h", os.path.join("..", "host", "se3.h"), os.path.join("..", "..", "include", "cmlhip.h")]
+HEADERS = ["cmlhip_internal.h", "ba_common.h", "ba_finish.h", "ba_frames.h", "reproj_dev.h", "ba_linearize_rs_body.inc", os.path.join("..", "host", "se3.h"), os.path.join("..", "..", "include", "cmlhip.h")]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-Wno-unused-but-set-variable", "-Wno-unused-value"] + os.environ.get("CML_HIPCC_EXTRA", "").split()   # e.g. -DCML_RS_STAMPS (tools/probe_rs_tiles.py)

@@ -2146,6 +2146,7 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
         if (c->r_idepth_dirty) { cml_refresh_r_idepth(c, A, c0->stream); c->r_idepth_dirty = false; }
         int blocks = 0;
         if (int rc = cml_fill_rs4_batch(c, A, Hrs, blocks)) { c0->err = c->err; return rc; }
+        if (c->rs_tile != c0->rs_tile) { c0->err = "cmlhip_ba_iteration_batch: the windows of a batch must be uploaded in one residual-kernel regime (cmlhip_ba_set_window_regime)"; return CMLHIP_ERR_INVALID; }
         rs_blocks = std::max(rs_blocks, blocks);
         c->sys_lambda = lambda;
     }
@@ -2185,7 +2186,7 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
     }
 #undef LAUNCH_SOLVE_B
     k_ba_backsub_batch<<<dim3(g_back, S), 256, back_lds, c0->stream>>>(W);             // K6
-    if ((rc = cml_launch_linearize_rs4_batch(c0, c0->batch_rs.p, S, rs_blocks))) return rc;   // K1
+    if ((rc = (c0->rs_tile == 16 ? cml_launch_linearize_rs4_batch : cml_launch_linearize_rs_batch)(c0, c0->batch_rs.p, S, rs_blocks))) return rc;   // K1
     CML_CHECK(c0, hipGetLastError());
     for (int k = 0; k < S; k++) {
         cmlhip_ctx* c = ctxs[k];

@@ -95,6 +95,7 @@ int cml_materialize_records(cmlhip_ctx* c);
 // several windows per launch (cmlhip_ba_iteration_batch): per-window {BAArgs, RsArgs, blocks} records appended to `blob`
 int cml_fill_rs4_batch(cmlhip_ctx* c, const BAArgs& A, std::vector<unsigned char>& blob, int& blocks);
 int cml_launch_linearize_rs4_batch(cmlhip_ctx* c0, const void* dev_records, int S, int max_blocks);
+int cml_launch_linearize_rs_batch(cmlhip_ctx* c0, const void* dev_records, int S, int max_blocks);      // windows in the throughput regime (tiles of 64)
 void cml_refresh_r_idepth(cmlhip_ctx* c, const BAArgs& A, hipStream_t stream);
 int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda);        // re-create the efsJ records the resident kernel did not write (no state change)
 

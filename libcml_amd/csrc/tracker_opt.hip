@@ -53,7 +53,7 @@ struct ToState {
     double a, b, na, nb, lambda, H[64], bv[8], Hn[64], bn[8], levelCutoffRepeat[5];
     float E[5], E_new[5], flow[3], flow_new[3];
     int nT[5], nS[5], nR[5], nT_new[5], nS_new[5], nR_new[5], iterations[5];
-    int ctrl, n_steps, n_pass, haveRepeated;
+    int ctrl[2], n_steps, n_pass, haveRepeated;
     long long t_eval, t_alg, t_mark;                   // wall_clock64 ticks (10 ns): evaluations / lane-0 algebra
 #ifdef TO_PROFILE
     long long t_ldlt, t_pose, t_fin;
@@ -250,39 +250,41 @@ __device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3
 // all lanes: computeResidual + computeHessian over the level's list (the per-point arithmetic and the reduction layout of
 // k_tracker_eval, tracker.hip); leaves the 56 sums in s_red
 // the sums of this workgroup's part -> the sums of the level, in every workgroup of the hypothesis (see TrkOptArgs::G)
-__device__ __forceinline__ void to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, float* __restrict__ s_red, const int epoch) {
+__device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, const float mine, const int epoch) {
     // Every sum travels as ONE self-validating device-scope word {value | seq << 32} (past the non-coherent caches; valid on its own): the
     // writers neither wait for acknowledgements nor publish a ticket, the readers poll the G words of their sum directly and add them in
     // workgroup order.  (First form: device-scope stores, a release fence — an L2 write-back —, barrier, ticket; readers polled the G
     // tickets, fenced (acquire: an L2 invalidation) and then fetched the sums: two fences and a dependent trip more per exchange.)
     // A workgroup can only write the sums of exchange seq + 2 — the next use of this parity's slots — after it has read every
     // workgroup's words of seq + 1, which a workgroup still reading seq has not written yet: the slots are never overwritten under a reader.
+    // Only wave 0 takes part (the 56 sums are its lanes' values) and nothing goes through LDS: no workgroup barrier in the exchange.
     (void)tick;
     const int tid = threadIdx.x;
     unsigned long long* base = reinterpret_cast<unsigned long long*>(xch) + (size_t)(seq & 1) * G * 64;
     const unsigned tagv = ((unsigned)epoch << 16) | ((unsigned)seq & 0xffffu);        // launch number | exchange number: words of an earlier call never match
     const unsigned long long tag = (unsigned long long)tagv << 32;
-    if (tid < TO_NRED) __hip_atomic_store(base + (size_t)g * 64 + tid, tag | (unsigned)__float_as_int(s_red[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __shared__ int s_late;
-    if (tid == 0) s_late = 0;
-    __syncthreads();
+    if (tid < TO_NRED) __hip_atomic_store(base + (size_t)g * 64 + tid, tag | (unsigned)__float_as_int(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float v = 0.f;
+    bool late = false;
     if (tid < TO_NRED) {
-        bool late = false;
-        for (int q = 0; q < G; q++) {
-            unsigned long long w;
-            int spins = 0;
-            while (((w = __hip_atomic_load(base + (size_t)q * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { late = true; break; }           // never spin forever: the level then fails (no terms)
-            }
-            v += __int_as_float((int)(unsigned)w);
+        // the G words of a sum are requested TOGETHER and polled as a set (G <= 8): one round trip per poll round — polled one after the
+        // other each word was a dependent device-scope load of its own, G round trips even when everything had arrived
+        unsigned long long w[8];
+        int spins = 0;
+        while (true) {
+            bool all = true;
+#pragma unroll
+            for (int q = 0; q < 8; q++) w[q] = q < G ? __hip_atomic_load(base + (size_t)q * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+#pragma unroll
+            for (int q = 0; q < 8; q++) all = all && (unsigned)(w[q] >> 32) == tagv;
+            if (all) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { late = true; break; }               // never spin forever: the level then fails (no terms)
         }
-        if (late) s_late = 1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q < G) v += __int_as_float((int)(unsigned)w[q]);
     }
-    __syncthreads();
-    if (tid < TO_NRED) s_red[tid] = s_late ? 0.f : v;
-    __syncthreads();
+    return __ballot(late) ? 0.f : v;
 }
 
 template <bool HALF>
@@ -375,7 +377,11 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) s_tile[wv][(4 * (l >> 4) + rg) * 16 + (l & 15)] = acc[rg];
     __syncthreads();
-    if (tid < TO_NRED) {
+    // from here to the next control barrier only wave 0 works: it adds the waves' tiles, exchanges the level's sums with the other
+    // workgroups of the hypothesis and leaves them in s_red for its own to_finish — no further workgroup barrier per evaluation
+    // (there were five: 512-thread barriers are a third of a microsecond each)
+    if (Ge > 1) seq++;                                                  // (every thread keeps the exchange number)
+    if (tid < 64) {
         int src = -1;
         if (tid < 45) {
             int k = tid, r = 0;
@@ -386,10 +392,11 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
         else if (tid == 52) src = 11 * 16 + 9;                          // numWarped
         float v = 0.f;
         if (src >= 0) for (int w = 0; w < TO_WAVES; w++) v += s_tile[w][src];
-        s_red[tid] = v;
+        if (Ge > 1) v = to_exchange(xch, tick, g, G, seq, v, epoch);
+        if (tid < TO_NRED) s_red[tid] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // read back by other lanes of this wave only: compiler ordering
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    if (Ge > 1) { seq++; to_exchange(xch, tick, g, G, seq, s_red, epoch); }
 }
 
 // wave 0: the level's sums -> Residual slots (lane 0) and the scaled 8x8 system, one entry per lane (TR.cpp:405-414, 472-490);
@@ -411,10 +418,12 @@ __device__ __forceinline__ void to_finish(const TrkOptArgs& A, const float* s, f
 }
 
 // lane 0's decision to every lane: read between two barriers, so that lane 0 may overwrite it right away
-__device__ __forceinline__ int to_ctrl(const ToState& S) {
+// (two slots used in turn: the writer of hand-over k + 2 has passed the barrier of hand-over k + 1, which every reader of k reached
+//  after its read — one barrier per hand-over instead of two)
+__device__ __forceinline__ int to_ctrl(const ToState& S, int& cseq) {
     __syncthreads();
-    const int c = S.ctrl;
-    __syncthreads();
+    const int c = S.ctrl[cseq & 1];
+    cseq++;
     return c;
 }
 
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     cmlhip_tracker_opt_result* out = A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical)
     float* xch = A.xch + (size_t)hyp * 2 * 2 * A.G * 64;          // (8-byte words: see to_exchange)
     int* tick = A.tick + (size_t)hyp * A.G;
-    int seq = 0;
+    int seq = 0, cseq = 0;
     const int maxIterations[5] = {10, 20, 50, 50, 50};                               // TR.cpp:23
     const int maxLevel = min(A.levels - 1, 4);
     if (tid == 0) {
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         S.a = A.init_a; S.b = A.init_b;
         for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l] = 0; S.nT[l] = S.nS[l] = S.nR[l] = S.nT_new[l] = S.nS_new[l] = S.nR_new[l] = 0; S.levelCutoffRepeat[l] = 0; S.iterations[l] = 0; }
         for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k] = 0;
-        S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl = TO_CONTINUE;
+        S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl[0] = S.ctrl[1] = TO_CONTINUE;
         S.t_eval = 0; S.t_alg = 0; S.t_mark = wall_clock64();
 #ifdef TO_PROFILE
         S.t_ldlt = S.t_pose = S.t_fin = 0;
@@ -468,9 +477,9 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     to_prepare(A, ev, level, to_pose(S.cur_q, S.cur_t), S.a, S.b, S.levelCutoffRepeat[level], true);
                     c = TO_REPEAT_SAT;
                 } else if (S.nT[level] - S.nS[level] < 10) c = TO_FAIL;                                      // :77-81
-                S.ctrl = c; S.lambda = 0.01;
+                S.ctrl[cseq & 1] = c; S.lambda = 0.01;
             }
-            const int c0 = to_ctrl(S);
+            const int c0 = to_ctrl(S, cseq);
             if (c0 != TO_REPEAT_SAT) { if (c0 == TO_FAIL) failed = true; break; }
         }
         if (failed) break;
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                 else if (A.opt_a) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[6] = xs[6]; }
                 else if (A.opt_b) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[7] = xs[6]; }
                 else { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; }
-                if (!ok) S.ctrl = TO_FAIL;                                                                  // :121-138
+                if (!ok) S.ctrl[cseq & 1] = TO_FAIL;                                                                  // :121-138
                 else {
                     double extrapFac = 1;
                     if (S.lambda < 0.001) extrapFac = sqrt(sqrt(0.001 / S.lambda));                         // :140-142
@@ -511,14 +520,14 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     S.na = S.a + incS[6]; S.nb = S.b + incS[7];                                             // :159
                     S.Hn[0] = sqrt(nrm);                                                                    // |increment| parked for the exit test below
                     to_prepare(A, ev, level, nw, S.na, S.nb, S.levelCutoffRepeat[level], true);
-                    S.ctrl = TO_ITERATE;
+                    S.ctrl[cseq & 1] = TO_ITERATE;
                 }
 #ifdef TO_PROFILE
                 S.t_pose += wall_clock64() - tp1;
 #endif
               }
             }
-            if (to_ctrl(S) == TO_FAIL) { failed = true; break; }
+            if (to_ctrl(S, cseq) == TO_FAIL) { failed = true; break; }
             TO_TIMED_EVAL();
 #ifdef TO_PROFILE
             const long long tf0 = wall_clock64();
@@ -544,23 +553,23 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     } else {
                         S.lambda *= 4;
                     }
-                    S.ctrl = (incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE;                                 // :176-179
+                    S.ctrl[cseq & 1] = (incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE;                                 // :176-179
                 }
             }
 #ifdef TO_PROFILE
             if (tid == 0) S.t_fin += wall_clock64() - tf0;
 #endif
-            if (to_ctrl(S) == TO_LEVEL_DONE) break;
+            if (to_ctrl(S, cseq) == TO_LEVEL_DONE) break;
         }
         if (failed) break;
         if (tid == 0) {
             // the rmse of the pass: what TR.cpp:183-189 compares with 1.5 x the previous correct try's (applied by the caller)
             if (S.n_pass < 8) { out->pass_level[S.n_pass] = level; out->pass_rmse[S.n_pass] = S.E[level] / (double)S.nT[level]; }
             S.n_pass++;
-            S.ctrl = (S.levelCutoffRepeat[level] > 1 && !S.haveRepeated) ? 1 : 0;                           // :192-195
-            if (S.ctrl) S.haveRepeated = 1;
+            S.ctrl[cseq & 1] = (S.levelCutoffRepeat[level] > 1 && !S.haveRepeated) ? 1 : 0;                 // :192-195
+            if (S.ctrl[cseq & 1]) S.haveRepeated = 1;
         }
-        if (to_ctrl(S)) level++;
+        if (to_ctrl(S, cseq)) level++;
     }
     if (tid == 0) {
         double R[9];

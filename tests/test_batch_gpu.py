@@ -32,10 +32,15 @@ def _state(ctx, N):
 MIXED = [("small", 0), (("M0", (5, 400, 480, 360, 4, 390.0, 390.0, 239.5, 179.5)), 1), ("small", 2), (("M1", (6, 500, 400, 300, 3, 330.0, 330.0, 199.5, 149.5)), 3)]
 
 
-@pytest.mark.parametrize("spec", ["mixed", "B4"])
+# two windows in the THROUGHPUT regime of the residual kernel (R = 42 000 >= 36 k: tiles of 64, lane per residual; batched through
+# k_ba_lin_rs_batch): refused until round 3
+THROUGHPUT = [(("T%d" % k, (8, 6000, 1241, 376, 4, 718.856, 718.856, 606.69, 184.72)), k) for k in range(2)]
+
+
+@pytest.mark.parametrize("spec", ["mixed", "B4", "T2"])
 def test_batched_iterations_equal_solo_iterations_bit_for_bit(spec):
-    wins = MIXED if spec == "mixed" else [("B", k) for k in range(4)]
-    its = 7
+    wins = MIXED if spec == "mixed" else (THROUGHPUT if spec == "T2" else [("B", k) for k in range(4)])
+    its = 3 if spec == "T2" else 7
     solo, batch = [], []
     for cfg, shard in wins:
         cfg = cfg[1] if isinstance(cfg, tuple) else cfg
