@@ -194,6 +194,106 @@ __device__ bool to_ldlt_solve_wave(const double* Hs, const double* bs, const dou
     for (int a = 0; a < 8; a++) if (a < n && !isfinite(xs[a])) ok = false;
     return ok;
 }
+// The same solve without the per-step pivot search and transposition.  Eigen's unblocked LDL^T is left-looking: when step k looks for
+// its pivot, the diagonal below it still holds the ORIGINAL entries (only column k and (k,k) are ever updated, LDLT.h:330-380), so the
+// pivot sequence is the order of the original |diagonal| — known before the first step.  When the active diagonal entries are pairwise
+// different (no tie for the search's first-maximum rule to break, no NaN) the sequence is their descending order: the wave ranks them
+// with one ballot, loads the matrix already permuted (P A P^T, pure data movement), and factorises without searches or exchanges — the
+// arithmetic of every step is the one the pivoting form performs on the same numbers, so L, D and x are bit-identical.  Ties / NaN /
+// an all-zero diagonal: `handled` stays false and the caller runs the pivoting form.  s_x: 8 doubles of LDS scratch.
+__device__ bool to_ldlt_solve_wave_sorted(const double* Hs, const double* bs, const double lambda, const int n, const int map6, double (&xs)[8],
+                                          double* s_x, bool& handled) {
+    const int l = threadIdx.x & 63, i = l & 7, a = l >> 3;
+    auto mp = [&](int q) { return (q == 6) ? map6 : q; };
+    handled = false;
+    const double da = (a < n) ? fabs(Hs[mp(a) * 8 + mp(a)] * (1 + lambda)) : 0.0;
+    const double di = (i < n) ? fabs(Hs[mp(i) * 8 + mp(i)] * (1 + lambda)) : 0.0;
+    const bool act = a < n && i < n;
+    const unsigned long long gt = __ballot(act && da > di);                               // bit a * 8 + i: |d[a]| > |d[i]|
+    const unsigned long long bad = __ballot(act && a != i && !(da > di) && !(di > da));   // a tie or a NaN
+    const unsigned long long zero = __ballot(act && a == i && !(da > 0.0));               // (the all-zero matrix is a tie already unless n == 1)
+    if (bad || zero) return false;
+    // pos[q] = number of active entries larger than d[q] = the step that picks q;  idx[k] = the entry step k picks
+    int idx_u[8], idx_k = i;
+#pragma unroll
+    for (int k = 0; k < 8; k++) idx_u[k] = k;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int pos = __popcll((gt >> q) & 0x0101010101010101ull);
+        if (q < n) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (pos == k) idx_u[k] = q;
+            if (pos == i) idx_k = q;
+        }
+    }
+    double row[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int r = max(idx_k, idx_u[j]), c = min(idx_k, idx_u[j]);
+        const bool in = i < n && j < n;
+        double v = in ? Hs[mp(r) * 8 + mp(c)] : 0.0;
+        if (i == j) v *= (1 + lambda);
+        row[j] = in ? v : 0.0;
+    }
+    double dd[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) dd[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= n) continue;                                // wave-uniform
+        double akk = to_rl(row[k], k);
+        if (k > 0) {
+            double temp[8], s = 0;
+#pragma unroll
+            for (int j = 0; j < k; j++) { const double lkj = to_rl(row[j], k); temp[j] = dd[j] * lkj; s += lkj * temp[j]; }
+            akk -= s;
+            double s2 = 0;
+#pragma unroll
+            for (int j = 0; j < k; j++) s2 += row[j] * temp[j];
+            if (i > k) row[k] -= s2;
+        }
+        if (i == k) row[k] = akk;
+        if (fabs(akk) > 0.0) {
+            if (i > k) row[k] /= akk;
+        }
+        dd[k] = akk;
+    }
+    // substitutions on wave-uniform copies: x = P^T L^-T D^-1 L^-1 P b (LDLT.h:560-600); P b is b in pick order
+#pragma unroll
+    for (int k = 0; k < 8; k++) xs[k] = (k < n) ? -bs[mp(idx_u[k])] : 0.0;
+    double Lm[8][8];
+#pragma unroll
+    for (int q = 1; q < 8; q++)
+#pragma unroll
+        for (int j = 0; j < q; j++) Lm[q][j] = to_rl(row[j], q);
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q < n) { double t = xs[q];
+#pragma unroll
+        for (int j = 0; j < q; j++) t -= Lm[q][j] * xs[j];
+        xs[q] = t; }
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q < n) xs[q] = (fabs(dd[q]) > 2.2250738585072014e-308) ? xs[q] / dd[q] : 0.0;
+#pragma unroll
+    for (int q = 7; q >= 0; q--) if (q < n) { double t = xs[q];
+#pragma unroll
+        for (int j = q + 1; j < 8; j++) if (j < n) t -= Lm[j][q] * xs[j];
+        xs[q] = t; }
+    // P^T: entry k of the permuted solution belongs to unknown idx[k] — through LDS (a register array cannot be indexed by idx)
+    double mine = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (i == k) mine = xs[k];
+    if (l < 8) s_x[idx_k] = mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // one wave, in-order LDS: compiler ordering only
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 8; k++) xs[k] = s_x[k];
+    __builtin_amdgcn_wave_barrier();
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q < n && !isfinite(xs[q])) ok = false;
+    handled = true;
+    return ok;
+}
 __device__ void to_inverse8(const double* Ain, double* Ai, double* A /* 64 */) {           // hessian.inverse() (TR.cpp:243): Gauss-Jordan with partial pivoting
     const int n = 8;
     for (int i = 0; i < 64; i++) { A[i] = Ain[i]; Ai[i] = (i / 8 == i % 8) ? 1.0 : 0.0; }
@@ -494,7 +594,9 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
 #ifdef TO_PROFILE
                 const long long tp0 = wall_clock64();
 #endif
-                const bool ok = to_ldlt_solve_wave(S.H, S.bv, S.lambda, nsolve, map6, xs);
+                bool sorted_ok = false;
+                bool ok = to_ldlt_solve_wave_sorted(S.H, S.bv, S.lambda, nsolve, map6, xs, s_wA, sorted_ok);
+                if (!sorted_ok) ok = to_ldlt_solve_wave(S.H, S.bv, S.lambda, nsolve, map6, xs);      // (wave-uniform: ties / NaN on the diagonal)
 #ifdef TO_PROFILE
                 const long long tp1 = wall_clock64();
                 if (tid == 0) S.t_ldlt += tp1 - tp0;
