@@ -369,20 +369,22 @@ __device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __res
     if (tid < TO_NRED) {
         // the G words of a sum are requested TOGETHER and polled as a set (G <= 8): one round trip per poll round — polled one after the
         // other each word was a dependent device-scope load of its own, G round trips even when everything had arrived
-        unsigned long long w[8];
         int spins = 0;
-        while (true) {
-            bool all = true;
+        for (int q0 = 0; q0 < G && !late; q0 += 8) {                       // (sets of eight: G <= 8 is one set)
+            unsigned long long w[8];
+            while (true) {
+                bool all = true;
 #pragma unroll
-            for (int q = 0; q < 8; q++) w[q] = q < G ? __hip_atomic_load(base + (size_t)q * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                for (int q = 0; q < 8; q++) w[q] = q0 + q < G ? __hip_atomic_load(base + (size_t)(q0 + q) * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
 #pragma unroll
-            for (int q = 0; q < 8; q++) all = all && (unsigned)(w[q] >> 32) == tagv;
-            if (all) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) { late = true; break; }               // never spin forever: the level then fails (no terms)
+                for (int q = 0; q < 8; q++) all = all && (unsigned)(w[q] >> 32) == tagv;
+                if (all) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { late = true; break; }           // never spin forever: the level then fails (no terms)
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (q0 + q < G) v += __int_as_float((int)(unsigned)w[q]);
         }
-#pragma unroll
-        for (int q = 0; q < 8; q++) if (q < G) v += __int_as_float((int)(unsigned)w[q]);
     }
     return __ballot(late) ? 0.f : v;
 }

@@ -44,7 +44,10 @@ for k in (1, 2, 3, 4, 0):
 b = blk[2]; nb_ = int((b[:, 0] > 0).sum()); d = (b[:nb_, 1] - b[:nb_, 0]) * 0.01
 nrow = W.N + 1
 print("system: SYRK blocks %d dur med %.2f max %.2f ; row blocks dur med %.2f max %.2f" % (nb_ - nrow, np.median(d[:-nrow]), d[:-nrow].max(), np.median(d[-nrow:]), d[-nrow:].max()))
-
+if out[32] and out[34] and blk[2][33][0] > 0:
+    b0 = blk[2][33][0]
+    print("SYRK workgroup 33: operands of the last trip landed %.2f us after its first stamp | products done %.2f | barrier %.2f | end %.2f" % (
+        (out[32] - b0) * 0.01, (out[33] - b0) * 0.01, (out[34] - b0) * 0.01, (blk[2][33][1] - b0) * 0.01))
 
 if out[96] and out[100]:      # us behind the solve workgroup's last stamp (53)
     print("a point block of the merged launch: x in LDS %.2f us behind the solve workgroup's last stamp | x.adjoint table %.2f | point steps + stores %.2f | block partials %.2f" % (
