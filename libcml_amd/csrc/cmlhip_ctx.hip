@@ -218,6 +218,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_d2h) (void)hipHostFree(c->pinned_d2h);
     if (c->trk_host) (void)hipHostFree(c->trk_host);
+    if (c->trk_opt_host) (void)hipHostFree(c->trk_opt_host);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev[0]);
     (void)hipEventDestroy(c->ev[1]);

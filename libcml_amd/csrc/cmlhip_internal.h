@@ -140,6 +140,7 @@ struct cmlhip_ctx {
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x, rp_off, rp_orig; int rp_acc_N = 0;
     DevBuf trk_xch;                                           // cmlhip_tracker_optimize_batch: partial sums + tickets of the workgroups of a hypothesis
+    void* trk_opt_host = nullptr; size_t trk_opt_host_bytes = 0;   // mapped, coherent host block of cmlhip_tracker_optimize_batch: hypotheses in, results out
     void* trk_xch_seen = nullptr; int trk_epoch = 0;           // tracker exchange buffer: cleared once per allocation, launch number in every word (tracker_opt.hip)
     DevBuf x_ticket; bool x_ticket_zeroed = false, backsub_merged = false; int x_ticket_seq = 0;      // K6 inside the K5 launch (BacksubCall)
     DevBuf batch_main, batch_rs; std::vector<unsigned char> batch_main_host, batch_rs_host; unsigned attr_done_batch = 0;   // cmlhip_ba_iteration_batch (kept by the first context of the batch)

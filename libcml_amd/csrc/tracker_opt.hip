@@ -12,6 +12,7 @@
 #include "cmlhip_internal.h"
 #include "../host/se3.h"
 #include <cstdlib>
+#include <atomic>
 
 #pragma clang fp contract(off)
 
@@ -30,6 +31,7 @@ struct TrkOptArgs {
     float huber, cutoff_base, scale_rot, scale_trans, scale_a, scale_b;
     const cmlhip_tracker_hypothesis* hyp;
     cmlhip_tracker_opt_result* out;                    // n_hyp x G results (every workgroup of a hypothesis runs the whole loop; the host keeps the first)
+    cmlhip_tracker_opt_result* out_host;               // n_hyp results in mapped host memory: written by the first workgroup of each hypothesis, no copy back
     // round 3: G workgroups per hypothesis.  A level with more than split_min reference points is evaluated in G parts, the 56 sums are
     // exchanged through memory (device-scope stores + a ticket per workgroup) and added in workgroup order by EVERY workgroup — all of
     // them then run the identical Levenberg-Marquardt algebra on identical numbers, no second exchange; smaller levels are evaluated
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ ToState S;
     __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
     const int tid = threadIdx.x, hyp = blockIdx.x / A.G, g = blockIdx.x % A.G;
-    cmlhip_tracker_opt_result* out = A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical)
+    cmlhip_tracker_opt_result* out = (g == 0 && A.out_host) ? A.out_host + hyp : A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical; the first one's goes straight to the host)
     float* xch = A.xch + (size_t)hyp * 2 * 2 * A.G * 64;          // (8-byte words: see to_exchange)
     int* tick = A.tick + (size_t)hyp * A.G;
     int seq = 0, cseq = 0;
@@ -743,23 +745,38 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     if (G < 1) G = 1;
     if (n_hyp * G > 256) G = std::max(1, 256 / n_hyp);
     A.G = G; A.split_min = 2 * TO_THREADS;
-    if ((rc = cml_ensure(c, c->trk_hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
     if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp * G))) return rc;
     const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)G * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
     if ((rc = cml_ensure(c, c->trk_xch, xch_bytes + tick_bytes))) return rc;
-    if ((rc = cml_h2d(c, c->trk_hyp.p, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp))) return rc;
-    A.hyp = c->trk_hyp.as<cmlhip_tracker_hypothesis>(); A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
+    // hypotheses in, results out through ONE mapped, coherent host block: the kernel reads the 96 bytes of its hypothesis and the first
+    // workgroup of each hypothesis writes its result there — no staged upload before the launch and no copy back behind it (each was a
+    // copy command of its own on the stream: 321 -> 299 us per call for one hypothesis, 421 -> 389 for fifty)
+    const size_t hyp_bytes = ((sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp + 255) / 256) * 256, res_bytes = sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp;
+    if (c->trk_opt_host_bytes < hyp_bytes + res_bytes) {
+        if (c->trk_opt_host) { CML_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->trk_opt_host); c->trk_opt_host = nullptr; c->trk_opt_host_bytes = 0; }
+        const size_t want = std::max<size_t>(2 * (hyp_bytes + res_bytes), 64 * 1024);
+        CML_CHECK(c, hipHostMalloc(&c->trk_opt_host, want, hipHostMallocMapped | hipHostMallocCoherent));
+        c->trk_opt_host_bytes = want;
+    }
+    char* const hb = static_cast<char*>(c->trk_opt_host);
+    memcpy(hb, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp);
+    memset(hb + hyp_bytes, 0, res_bytes);
+    void* dptr = nullptr;
+    CML_CHECK(c, hipHostGetDevicePointer(&dptr, c->trk_opt_host, 0));
+    A.hyp = reinterpret_cast<const cmlhip_tracker_hypothesis*>(dptr);
+    A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
+    A.out_host = reinterpret_cast<cmlhip_tracker_opt_result*>(static_cast<char*>(dptr) + hyp_bytes);
     A.xch = c->trk_xch.as<float>(); A.tick = reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes);
     // (no per-call clearing: the words carry the launch number; a fresh or moved buffer is cleared once)
     if (c->trk_xch.p != c->trk_xch_seen) { CML_CHECK(c, hipMemsetAsync(c->trk_xch.p, 0, c->trk_xch.bytes, c->stream)); c->trk_xch_seen = c->trk_xch.p; c->trk_epoch = 0; }
     c->trk_epoch = (c->trk_epoch % 0xfffe) + 1;            // 1 .. 0xfffe: never the zero of a cleared buffer
     A.epoch = c->trk_epoch;
+    std::atomic_thread_fence(std::memory_order_release);
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp * G, TO_THREADS, 0, A);
     else CML_LAUNCH_EV(c, k_tracker_optimize<false>, n_hyp * G, TO_THREADS, 0, A);
     CML_CHECK(c, hipGetLastError());
-    if (G == 1) return cml_d2h(c, out, c->trk_opt_out.p, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
-    std::vector<cmlhip_tracker_opt_result> all((size_t)n_hyp * G);
-    if ((rc = cml_d2h(c, all.data(), c->trk_opt_out.p, sizeof(cmlhip_tracker_opt_result) * all.size()))) return rc;
-    for (int i = 0; i < n_hyp; i++) out[i] = all[(size_t)i * G];
+    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(out, hb + hyp_bytes, res_bytes);
     return CMLHIP_OK;
 }
