@@ -1063,6 +1063,21 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
 // when it is read (the plain loop keeps the pre-scaling values in a second panel, for which there is no room beside a double
 // buffer at 160 unknowns): same factorisation, last-bit differences against the plain loop, same 1e-7 bar against the oracle.
 #define SOLVE_LOOKAHEAD_NB 6
+// Column updates behind a pivot, row[j] -= cid * broadcast(row[k], lane j) for j = k+2 .. 15: the broadcasts of FOUR columns first
+// (an empty asm that takes the four values as scalar operands keeps them live together, in four distinct scalar pairs), then their four
+// multiply-adds.  Left alone the compiler pairs every v_readlane pair with its v_fma_f64 on ONE reused scalar pair: tools/microbench7.hip
+// measures 23.7 cycles per column update that way, 21.1 in groups of four, 17.1 with all fourteen broadcasts first (which the kernel's
+// scalar registers do not allow); in the kernel the elimination of a block column drops from 2.08 to 1.96 us whatever the group size
+// (2 .. 6) — it is issue-bound: two readlanes at ~5 cycles and an fp64 multiply-add at ~7 per column, ~65 cycles of chain per pivot.
+#define SOLVE_COLUMN_UPDATES(row, cid, k) do { \
+        double bq_[16]; \
+        _Pragma("unroll") for (int j_ = (k) + 2; j_ < 16; j_++) bq_[j_] = rl(row[(k)], j_); \
+        _Pragma("unroll") for (int j0_ = (k) + 2; j0_ < 16; j0_ += 4) { \
+            if (16 - j0_ >= 4) asm volatile("" : "+s"(bq_[j0_]), "+s"(bq_[j0_ + 1]), "+s"(bq_[j0_ + 2]), "+s"(bq_[j0_ + 3])); \
+            else if (16 - j0_ == 3) asm volatile("" : "+s"(bq_[j0_]), "+s"(bq_[j0_ + 1]), "+s"(bq_[j0_ + 2])); \
+            else if (16 - j0_ == 2) asm volatile("" : "+s"(bq_[j0_]), "+s"(bq_[j0_ + 1])); \
+        } \
+        _Pragma("unroll") for (int j_ = (k) + 2; j_ < 16; j_++) row[j_] -= (cid) * bq_[j_]; } while (0)
 __device__ __forceinline__ void solve_eliminate_column_la(double* __restrict__ L, double* __restrict__ y, double* __restrict__ dvec,
                                                           double* __restrict__ dinv, const int K, const int nb, const int wv, const int l) {
     const int nbelow = (nb - K - 1) * 16;
@@ -1097,7 +1112,7 @@ __device__ __forceinline__ void solve_eliminate_column_la(double* __restrict__ L
             SOLVE_PIVOT_CHAIN_LA(k + 1, dk_next, cid_next);
         }
 #pragma unroll
-        for (int j = k + 2; j < 16; j++) row[j] -= cid * rl(row[k], j);
+        SOLVE_COLUMN_UPDATES(row, cid, k);
         row[k] = cid;
         if (l > k) yv -= cid * zk;
         if (l == k) mydk = dk;
@@ -1301,8 +1316,7 @@ __device__ __forceinline__ void k_ba_solve_body(const BAArgs& A, int n, int off,
                     row[k + 1] -= cid * rl(row[k], k + 1);
                     SOLVE_PIVOT_CHAIN(k + 1, dk_next, cid_next);
                 }
-#pragma unroll
-                for (int j = k + 2; j < 16; j++) row[j] -= cid * rl(row[k], j);   // lanes above the pivot compute unused values
+                SOLVE_COLUMN_UPDATES(row, cid, k);                                 // lanes above the pivot compute unused values
                 row[k] = cid;                  // every lane: the entries on and above the diagonal of the factor are never read (D lives in dvec)
                 if (l > k) yv -= cid * zk;
                 if (l == k) mydk = dk;
