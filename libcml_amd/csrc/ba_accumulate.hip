@@ -1111,7 +1111,6 @@ __device__ __forceinline__ void solve_eliminate_column_la(double* __restrict__ L
             row[k + 1] -= cid * rl(row[k], k + 1);
             SOLVE_PIVOT_CHAIN_LA(k + 1, dk_next, cid_next);
         }
-#pragma unroll
         SOLVE_COLUMN_UPDATES(row, cid, k);
         row[k] = cid;
         if (l > k) yv -= cid * zk;
