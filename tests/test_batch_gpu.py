@@ -10,9 +10,9 @@ from tests import resident_check as RC
 pytestmark = pytest.mark.gpu
 
 
-def _window(config, shard, seed=0xC0FFEE):
+def _window(config, shard, seed=0xC0FFEE, texel_format=abi.TEXEL_F32):
     W = synth.make_window(config, seed=seed, shard=shard)
-    ctx = device.Ctx(max_frames=max(W.N, 2), max_points=W.P, max_residuals=W.P * W.N)
+    ctx = device.Ctx(max_frames=max(W.N, 2), max_points=W.P, max_residuals=W.P * W.N, texel_format=texel_format)
     ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (shard + 1), levels=1)
     ba.set_param("iterations", 1)
     assert ba.run(), ba.last_error()
@@ -37,14 +37,15 @@ MIXED = [("small", 0), (("M0", (5, 400, 480, 360, 4, 390.0, 390.0, 239.5, 179.5)
 THROUGHPUT = [(("T%d" % k, (8, 6000, 1241, 376, 4, 718.856, 718.856, 606.69, 184.72)), k) for k in range(2)]
 
 
-@pytest.mark.parametrize("spec", ["mixed", "B4", "T2"])
+@pytest.mark.parametrize("spec", ["mixed", "B4", "T2", "T2h"])
 def test_batched_iterations_equal_solo_iterations_bit_for_bit(spec):
-    wins = MIXED if spec == "mixed" else (THROUGHPUT if spec == "T2" else [("B", k) for k in range(4)])
-    its = 3 if spec == "T2" else 7
+    wins = MIXED if spec == "mixed" else (THROUGHPUT if spec in ("T2", "T2h") else [("B", k) for k in range(4)])
+    its = 3 if spec in ("T2", "T2h") else 7
+    fmt = abi.TEXEL_F16 if spec == "T2h" else abi.TEXEL_F32              # T2h: fp16 texels, gathered from the tiled level 0
     solo, batch = [], []
     for cfg, shard in wins:
         cfg = cfg[1] if isinstance(cfg, tuple) else cfg
-        solo.append(_window(cfg, shard)); batch.append(_window(cfg, shard))
+        solo.append(_window(cfg, shard, texel_format=fmt)); batch.append(_window(cfg, shard, texel_format=fmt))
     try:
         for W, ctx, ba in solo:
             for _ in range(its):
