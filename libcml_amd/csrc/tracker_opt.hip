@@ -296,21 +296,44 @@ __device__ bool to_ldlt_solve_wave_sorted(const double* Hs, const double* bs, co
     handled = true;
     return ok;
 }
-__device__ void to_inverse8(const double* Ain, double* Ai, double* A /* 64 */) {           // hessian.inverse() (TR.cpp:243): Gauss-Jordan with partial pivoting
-    const int n = 8;
-    for (int i = 0; i < 64; i++) { A[i] = Ain[i]; Ai[i] = (i / 8 == i % 8) ? 1.0 : 0.0; }
-    for (int k = 0; k < n; k++) {
+// hessian.inverse() (TR.cpp:243) on ONE WAVE: Gauss-Jordan with partial pivoting, lane (r, c) = l >> 3, l & 7 carries A[r][c] and
+// Ai[r][c] in registers.  Per step: the pivot search on wave-uniform copies of column k (first largest |A[i][k]|, i >= k), the row
+// exchange as one cross-lane move, the IEEE divisions of row k, and every other row's update with its own multiplier — the arithmetic
+// of each entry is that of the scalar loop (same operations on the same numbers in the same order); only the lanes differ.  On lane 0
+// alone, on LDS scratchpads, this inverse was 40 of the kernel's 245 us (behind the last in-kernel clock, so neither "evaluation" nor
+// "algebra" showed it).
+__device__ __forceinline__ double to_shfl_d(double v, int lane) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_ds_bpermute(lane << 2, u.i[0]);
+    u.i[1] = __builtin_amdgcn_ds_bpermute(lane << 2, u.i[1]);
+    return u.d;
+}
+__device__ __forceinline__ double to_inverse8_wave(const double* Ain /* 64, LDS */, const int l) {
+    const int r = l >> 3, c = l & 7;
+    double a = Ain[l], ai = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
         int p = k;
-        for (int i = k + 1; i < n; i++) if (fabs(A[i * n + k]) > fabs(A[p * n + k])) p = i;
-        if (p != k) for (int j = 0; j < n; j++) { double s = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = s; s = Ai[k * n + j]; Ai[k * n + j] = Ai[p * n + j]; Ai[p * n + j] = s; }
-        const double d = A[k * n + k];
-        for (int j = 0; j < n; j++) { A[k * n + j] /= d; Ai[k * n + j] /= d; }
-        for (int i = 0; i < n; i++)
-            if (i != k) {
-                const double f = A[i * n + k];
-                if (f != 0) for (int j = 0; j < n; j++) { A[i * n + j] -= f * A[k * n + j]; Ai[i * n + j] -= f * Ai[k * n + j]; }
-            }
+        double best = fabs(to_rl(a, k * 8 + k));
+#pragma unroll
+        for (int i = k + 1; i < 8; i++) {
+            const double v = fabs(to_rl(a, i * 8 + k));
+            if (v > best) { best = v; p = i; }
+        }
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p != k) {                                      // wave-uniform
+            const int sr = (r == k) ? p : ((r == p) ? k : r);
+            a = to_shfl_d(a, sr * 8 + c); ai = to_shfl_d(ai, sr * 8 + c);
+        }
+        const double d = to_rl(a, k * 8 + k);
+        const double qa = a / d, qi = ai / d;
+        if (r == k) { a = qa; ai = qi; }
+        const double f = to_shfl_d(a, r * 8 + k);
+        const double pk = to_shfl_d(a, k * 8 + c), pik = to_shfl_d(ai, k * 8 + c);
+        if (r != k && f != 0) { a -= f * pk; ai -= f * pik; }
     }
+    return ai;
 }
 
 // lane 0: the constants of one evaluation (TR.cpp:260-278, 426-429; InternalCalibration.h:116-127; Exposure.h:119-123)
@@ -709,10 +732,11 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
             out->isCorrect = haveGoodLight ? 1 : 0;
             out->tooManySaturated = haveGoodPoints ? 1 : 0;                                                 // sic, :240
             out->relAff[0] = relA; out->relAff[1] = relB;
-            double* Hi = s_wD;
-            to_inverse8(S.H, Hi, s_wA);                                                                     // :243
-            for (int k = 0; k < 6; k++) out->covariance[k] = Hi[k * 8 + k];
         }
+    }
+    if (!failed && tid < 64) {                                                                              // :243, wave 0 (S.H is lane 0's no more: nothing writes it from here on)
+        const double hi = to_inverse8_wave(S.H, tid);
+        if ((tid >> 3) == (tid & 7) && (tid >> 3) < 6) out->covariance[tid >> 3] = hi;
     }
 }
 
