@@ -300,7 +300,7 @@ __device__ bool to_ldlt_solve_wave_sorted(const double* Hs, const double* bs, co
 // Ai[r][c] in registers.  Per step: the pivot search on wave-uniform copies of column k (first largest |A[i][k]|, i >= k), the row
 // exchange as one cross-lane move, the IEEE divisions of row k, and every other row's update with its own multiplier — the arithmetic
 // of each entry is that of the scalar loop (same operations on the same numbers in the same order); only the lanes differ.  On lane 0
-// alone, on LDS scratchpads, this inverse was 40 of the kernel's 245 us (behind the last in-kernel clock, so neither "evaluation" nor
+// alone, on LDS scratchpads, this inverse was 36 of the kernel's 245 us (behind the last in-kernel clock, so neither "evaluation" nor
 // "algebra" showed it).
 __device__ __forceinline__ double to_shfl_d(double v, int lane) {
     union { double d; int i[2]; } u;
