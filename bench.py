@@ -331,6 +331,268 @@ def _launch_only(args):
     group.close()
 
 
+FP64_MATRIX_PEAK_TFLOPS = 78.6           # AMD's published MI355X FP64 matrix figure (the micro-architecture guide gives no fp64 row)
+
+
+def solve_phases(ctx, N, lam=1e-5):
+    """north_star: "MFMA utilisation (for the dense solve) against gfx950 peak".  In-kernel wall-clock stamps of the solve workgroup
+    (cmlhip_debug_timestamps, 10 ns ticks) of the LAST of six iterations: load + Jacobi scaling, blocked LDL^T, backward substitution,
+    tail (gauge projection + publishing x).  mfma_f64_util = the factorisation's matrix-core flops (trailing updates: 2 x 16^3 per
+    16 x 16 x 16 tile product) / its duration / the fp64 matrix peak — tiny by construction (an 8N x 8N system is a 8N-pivot latency
+    chain), which is why the honest figure is the microseconds."""
+    import numpy as np
+    NS = 128 + 5 * 1024 * 2
+    out = np.zeros(NS, np.int64)
+    ctx.sync()
+    ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 1, None))
+    for _ in range(6):
+        ctx.ba_iteration_async(lam)
+    ctx.sync()
+    ctx.ck(ctx.L.cmlhip_debug_timestamps(ctx.h, 0, out.ctypes.data_as(C.POINTER(C.c_longlong))))
+
+    def seg(a, b):
+        return float((out[b] - out[a]) * 0.01) if out[a] > 0 and out[b] > 0 else None
+    m = 8 * N
+    nb = (m + 15) // 16
+    tiles = sum((nb - 1 - k) * (nb - k) // 2 for k in range(nb))          # lower-triangle trailing tiles updated behind block column k
+    flops = tiles * 2.0 * 16 ** 3
+    us = {"load": seg(48, 49), "factor": seg(49, 50), "backward": seg(51, 52), "tail": seg(52, 53), "total": seg(48, 53)}
+    util = (flops / (us["factor"] * 1e-6) / (FP64_MATRIX_PEAK_TFLOPS * 1e12)) if us["factor"] else None
+    return {"us": us, "mfma_f64_util": util, "mfma_flops": flops, "peak_tflops": FP64_MATRIX_PEAK_TFLOPS, "unknowns": m,
+            "note": "k_ba_solve's own workgroup, in-kernel stamps of one iteration; the launch also carries the back-substitution / frame-step blocks (roofline-irrelevant)"}
+
+
+class _NoGroup:
+    """the secondary configurations run on rank 0 alone: same timing protocol, no process group"""
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def max(self, v):
+        return v
+
+    def sum(self, v):
+        return v
+
+
+def setup_window(config, seed, rank, local_rank):
+    """Synthetic window of `config` registered through the host mirror exactly as Hybrid::directMap would (pyramid build, addNewFrame,
+    addPoints), one run() to upload it, then the device-resident loop armed.  config "C" = the config-B window + 1000 ORB observations of
+    300 points mixed into the pose solution in every iteration (BASELINE.json configs[2]); "E" stores fp16 texels (configs[4])."""
+    import numpy as np
+    from libcml_amd import abi, device, host, synth
+    hybrid = config == "C"
+    wcfg = "B" if hybrid else config
+    half = config == "E"
+    W = synth.make_window(wcfg, seed=seed, shard=rank)                   # one independent sequence shard per rank
+    ctx = device.Ctx(device_id=local_rank, max_frames=max(W.N, 2), max_points=W.P, max_residuals=W.P * W.N,
+                     texel_format=abi.TEXEL_F16 if half else abi.TEXEL_F32)
+    ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (rank + 1), levels=1)
+    ba.set_param("iterations", 1)
+    ind = None
+    if hybrid:                                                            # mixed into the pose solution inside the device solve (BA.cpp:1327-1329)
+        _, ipts, iobs = synth.indirect_observations(W, n_obs=1000, n_pts=300, seed=11 + rank)
+        o = np.zeros(len(iobs), abi.REPROJ_OBS_DTYPE)
+        for f in ("frame", "point", "gx", "gy"):
+            o[f] = iobs[f]
+        ba.set_param("mixedBundleAdjustment", 1)
+        ba.set_indirect_points(ipts, o)
+        ind = {"pts": ipts, "obs": o, "fx": W.K[0], "fy": W.K[1]}
+    if not ba.run():                                                      # uploads the window, leaves adjoints/priors resident
+        raise RuntimeError("BA run failed: " + ba.last_error())
+    _, _, R = ctx.refresh_window_size()                                   # the window was uploaded by the C++ host mirror
+    if not ba.begin_resident():                                           # frame states, adjoints, priors, gauge basis -> device
+        raise RuntimeError("begin_resident failed: " + ba.last_error())
+    return {"config": config, "wcfg": wcfg, "hybrid": hybrid, "half": half, "W": W, "ctx": ctx, "ba": ba, "R": R, "ind": ind}
+
+
+def measure(S, steps, warmup, group, sync_extra=None, lam=1e-5):
+    """The bench contract on one window: 300 set-up iterations (clocks ramped), `warmup` untimed steps, EXACTLY `steps` timed steps
+    between barrier + device sync, MAX over ranks; the residual kernel's own dispatch duration sampled inside that region (HIP events
+    attached to the dispatch, every stride-th step); then a region of its own for the Schur-reduce + solve span and eight repeat regions."""
+    from libcml_amd import shard
+    ctx = S["ctx"]
+    for _ in range(300):                                                  # setup, not a step: ~20 ms of work so that the clocks have ramped
+        ctx.ba_iteration_async(lam)                                       # before the W warm-up steps, whatever W is
+    ctx.sync()
+    for _ in range(warmup):
+        ctx.ba_iteration_async(lam)
+    # every stride-th step carries the profile events on its dispatches (an event-carrying dispatch costs the pipeline ~3 us: at
+    # stride 4 the contract region ran 1.4 us per step behind the regions without events); short runs sample every second step so
+    # that the driver's --steps 20 line still averages 10 dispatches
+    stride = 8 if steps >= 80 else (2 if steps >= 4 else 1)
+    ctx.profile_stride(stride)
+    ctx.profile_select(1)                                                 # contract region: events on the roofline kernel's dispatch only
+    ctx.profile_enable((steps + stride - 1) // stride)
+
+    def run_steps():
+        for _ in range(steps):
+            ctx.ba_iteration_async(lam)
+
+    def sync():
+        ctx.sync()
+        if sync_extra is not None:
+            sync_extra()
+
+    dt = shard.timed_region(group, sync, run_steps)
+    lin_ms, _ss0, _empty, n_samples = ctx.profile_read()
+    # the Schur-reduce + solve group (K3 begin -> K6 end) is sampled in a region of its own, after the contract region: every
+    # event-carrying dispatch costs the pipeline a few microseconds, and the contract region needs the roofline kernel's only
+    ctx.profile_select(2)
+    ctx.profile_enable((steps + stride - 1) // stride)
+    shard.timed_region(group, sync, run_steps)
+    _lin0, ss_ms, _empty, _n = ctx.profile_read()
+    ctx.profile_select(3)
+    # spread: the contract region above is ONE sample (K steps can be a millisecond); eight more regions of the same K steps, same
+    # protocol, reported beside it (not used for `value`)
+    ctx.profile_enable(0)
+    rep_ms = sorted(1e3 * shard.timed_region(group, sync, run_steps) / steps for _ in range(8))
+    st = ctx.ba_states()
+    return {"dt": dt, "lin_ms": lin_ms, "ss_ms": ss_ms, "n_samples": n_samples, "rep_ms": rep_ms,
+            "n_good": int(st["good"].sum()),
+            "n_sampled": int((st["state"] != 1).sum())}   # residuals of the timed passes that enter the pixel loop and gather texels (OOB is absorbing, BA.cpp:68-72)
+
+
+def _quat_to_R(q):
+    import numpy as np
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def parity_gate(S, lam=1e-5):
+    """"a throughput figure is only valid if the same run passes the fixture comparison".  One more iteration from the state
+    the timed region left, its residual pass replayed on the oracle from the device's own state and compared bit for bit over ALL R
+    residuals (tests/resident_check.py) — after the timed region, outside it.  Config C (hybrid) in addition: the ORB term the solve
+    launch evaluated in that iteration against oracle/orc_base.c's reprojection accumulation + the Eigen-semantics LDLT on the poses the
+    frames had at the solve (BA.cpp:2607-2700), bar 1e-8 as tests/test_hybrid_gpu.py."""
+    import numpy as np
+    ctx, ba, W, R = S["ctx"], S["ba"], S["W"], S["R"]
+    try:
+        from tests import resident_check as RC
+        replay = RC.make_replay(ctx, ba, W)
+        pre_w2c = None
+        if S["hybrid"]:
+            ctx.sync()
+            _, pre_w2c = ctx.ba_resident_state()
+        rep = RC.check_one_pass(ctx, replay, lam, with_records=True)
+        replay.close()
+        out = {"parity_checked": True, "parity_ok": bool(rep["ok"]), "parity": rep,
+               "parity_note": "one resident iteration after the timed region; its residual pass (%s) replayed by oracle/orc_ba.c from the device's "
+                              "pairs / thresholds / inverse depths / prior states: states, energies, JpJdF, centre projections and the re-materialised "
+                              "74-float records compared bit for bit over all R residuals" % ("k_ba_lin_rs" if R >= 36 * 1024 else "k_ba_lin_rs4")}
+        if S["hybrid"]:
+            from tests import oracle_lib as O
+            from tests import trk_setup as T
+            ind = S["ind"]
+            poses = np.zeros((W.N, 12))
+            for k in range(W.N):
+                poses[k, :9] = _quat_to_R(pre_w2c[k, :4]).ravel(); poses[k, 9:] = pre_w2c[k, 4:]
+            _x, x6, _jp = ctx.ba_resident_indirect()
+            M6o, b6o, _Jpo, usedo = T.oracle_reproj(poses, ind["pts"], ind["obs"], ind["fx"], ind["fy"])
+            Mo = M6o.copy(); Mo[np.diag_indices(len(Mo))] *= (1 + lam)
+            xo, rco = O.ldlt_solve(Mo, -b6o)
+            err = float(np.abs(x6 - xo).max() / max(np.abs(xo).max(), 1e-300))
+            out["parity"]["hybrid_x6_rel_err"] = err; out["parity"]["hybrid_used_obs"] = int(usedo.sum())
+            out["parity_ok"] = bool(out["parity_ok"] and rco == 0 and err <= 1e-8)
+            out["parity_note"] += "; hybrid term: the 6N indirect solution of that iteration against orc_reproj_accumulate + orc_ldlt_solve on the frames' poses at the solve, bar 1e-8"
+        return out
+    except Exception as e:
+        return {"parity_checked": False, "parity_error": repr(e)}
+
+
+def _valu_roof(config, R, launch_us):
+    """Second roofline entry for the residual kernel: what its own instruction stream costs to ISSUE.  Inputs are the SQ counters of
+    the committed rocprofv3 --pmc passes (profiles/round4_valu_roof_<config>.json, tools/valu_roof.py: SQ_WAVES, SQ_INSTS_VALU,
+    SQ_ACTIVE_INST_VALU per launch) — instructions per wave and issue cycles per instruction as MEASURED on this kernel — and the wave
+    slots the launch occupies; floor = waves per SIMD x instructions per wave x cycles per instruction / clock."""
+    path = os.path.join(ROOT, "profiles", "round4_valu_roof_%s.json" % config)
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        waves = d["waves_per_launch"]; ipw = d["valu_insts_per_wave"]; cpi = d["cycles_per_valu_inst"]; clk = d["clock_ghz"]; simds = d["simds"]
+        wps = waves / simds
+        floor_us = max(wps, 1.0) * ipw * cpi / (clk * 1e3)
+        return {"bound": "valu_issue", "insts_per_wave": ipw, "cycles_per_inst": cpi, "waves_per_launch": waves, "waves_per_simd": wps,
+                "clock_ghz": clk, "floor_us": floor_us, "launch_us": launch_us, "frac": floor_us / launch_us if launch_us > 0 else None,
+                "fp64_share": d.get("fp64_share"),
+                "source": "profiles/%s (rocprofv3 --pmc passes of this bench command at commit %s; static ISA count beside it)" % (os.path.basename(path), d.get("commit", "?")),
+                "note": "frac = the time the kernel's vector instructions need to issue (every SIMD's waves back to back, nothing else waiting) / "
+                        "the measured dispatch duration; (waves per SIMD < 1 counts as 1: a lone wave cannot issue faster than its own stream)"}
+    except Exception as e:
+        return {"bound": "valu_issue", "error": repr(e)}
+
+
+def roofline_object(S, M, lin_ms_local):
+    config, R, half = S["config"], S["R"], S["half"]
+    bytes_per_residual = READ_BYTES_PER_RESIDUAL["fp16" if half else "fp32"]
+    achieved = R * bytes_per_residual / (lin_ms_local * 1e-3) / 1e9 if lin_ms_local > 0 else 0.0
+    # memory-side bytes per launch of the residual kernel come from separate `rocprofv3 --pmc` passes of this same command
+    # (tools/profile_bench.py; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide) and are only
+    # quoted for the workload they were collected on
+    traffic, traffic_src, rocprof_us = None, None, None
+    for rnd in ("round4", "round3"):
+        pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_linearize_%s.json" % (rnd, config))
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("traffic_bytes_per_launch")
+                rocprof_us = pmc.get("linearize_avg_us")   # kernel-trace average of the same command (dispatches serialised by the profiler)
+                traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; taken at commit %s: stale if the residual "
+                               "kernel changed since)" % (os.path.basename(pmc_path), pmc.get("commit", "?")))
+            except Exception:
+                traffic = None
+            break
+    n_sampled = M["n_sampled"]
+    kname = "k_ba_lin_rs (lane per residual, tiled fp16 level 0)" if R >= 36 * 1024 else "k_ba_lin_rs4 (4 lanes per residual)"
+    roof = {"bound": "hbm", "kernel": kname + " = linearize + applyRes of the resident loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "n_sampled": n_sampled, "frac_sampled": (achieved / HBM_PEAK_GBS) * n_sampled / max(R, 1),
+            "frac_sampled_note": "the same fraction billed only for the residuals that gather texels (state != OOB before the pass)",
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": R * bytes_per_residual, "bytes_per_residual": bytes_per_residual,
+            "launch_us": 1e3 * lin_ms_local, "launch_samples": M["n_samples"],
+            "launch_us_note": "mean over the sampled steps of the timed region of hipEventElapsedTime between the start and stop events "
+                              "attached to the k_ba_linearize dispatch itself (hipExtLaunchKernelGGL): the kernel's begin / end "
+                              "timestamps, the quantity rocprofv3 --kernel-trace reports",
+            "rocprof_avg_us": rocprof_us}
+    valu = _valu_roof(config, R, 1e3 * lin_ms_local)
+    if valu is not None:
+        roof["also_bound_by"] = [valu]
+        roof["binding"] = "valu_issue" if (valu.get("frac") or 0) > roof["frac"] else "hbm"
+    return roof
+
+
+def workload_text(S):
+    W = S["W"]
+    return (("config C = config B + 1000 ORB reprojection residuals of 300 points mixed into the pose solution in every iteration; " if S["hybrid"] else "") +
+            "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 gradient images, %s texels / fp32 arithmetic; "
+            "1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, "
+            "pair precompute, linearize + applyRes)" % (S["wcfg"], W.N, W.P, S["R"], W.w, W.h, "fp16" if S["half"] else "fp32"))
+
+
+def secondary_config(config, seed, local_rank, steps, warmup):
+    """BASELINE.json configs[2] (C) / configs[4] (E) beside the headline, on rank 0 of an N = 1 run: same protocol, own parity gate."""
+    S = setup_window(config, seed, 0, local_rank)
+    try:
+        M = measure(S, steps, warmup, _NoGroup())
+        par = parity_gate(S)
+        out = {"workload": workload_text(S), "value": S["R"] * steps / M["dt"], "unit": "point-residuals/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": 1e3 * M["dt"] / steps,
+               "ms_per_step_repeats": {"min": M["rep_ms"][0], "median": M["rep_ms"][len(M["rep_ms"]) // 2], "max": M["rep_ms"][-1]},
+               "schur_solve_ms": M["ss_ms"], "linearize_kernel_us": 1e3 * M["lin_ms"], "good_residuals": M["n_good"], "n_sampled": M["n_sampled"],
+               "dtype": "f32", "roofline": roofline_object(S, M, M["lin_ms"])}
+        out.update(par)
+        if par.get("parity_checked") and not par.get("parity_ok"):
+            out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
+        return out
+    finally:
+        S["ba"].close(); S["ctx"].close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,7 +600,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="B", help="synthetic window (libcml_amd.synth.CONFIGS); B is the benchmark workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the tracker and multi-window objects (headline + roofline + parity only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs C / E, tracker, sequence and multi-window objects (headline + roofline + parity only)")
     ap.add_argument("--launch-only", action="store_true", help="exercise the rank launch + process group only (no device work; CPU test)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("CONFIG", "SEED", "MODE"), help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -350,7 +612,7 @@ def main():
     if args.launch_only:
         return _launch_only(args)
 
-    from libcml_amd import device, host, shard, synth
+    from libcml_amd import shard
     rank, local_rank, world = shard.env_world()
     if world != args.gpus and world > 1:
         args.gpus = world
@@ -363,118 +625,27 @@ def main():
 
     _dbg('group ready')
     seed = 0xC0FFEE
-    hybrid = args.config == "C"                                          # BASELINE.json configs[2]: config B + 1000 ORB reprojection residuals
-    wcfg = "B" if hybrid else args.config
-    W = synth.make_window(wcfg, seed=seed, shard=rank)                   # one independent sequence shard per rank
+    S = setup_window(args.config, seed, rank, local_rank)
+    W, ctx, ba, R, hybrid, half, wcfg = S["W"], S["ctx"], S["ba"], S["R"], S["hybrid"], S["half"], S["wcfg"]
     N, P = W.N, W.P
-    _dbg('window made')
-    from libcml_amd import abi
-    half = args.config == "E"                                            # config E stores fp16 pyramids (fp32 arithmetic)
-    ctx = device.Ctx(device_id=local_rank, max_frames=max(N, 2), max_points=P, max_residuals=P * N,
-                     texel_format=abi.TEXEL_F16 if half else abi.TEXEL_F32)
-    ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (rank + 1), levels=1)
-    _dbg('ba built')
-    ba.set_param("iterations", 1)
-    if hybrid:                                                            # mixed into the pose solution inside the device solve (BA.cpp:1327-1329)
-        import numpy as np
-        _, ipts, iobs = synth.indirect_observations(W, n_obs=1000, n_pts=300, seed=11 + rank)
-        o = np.zeros(len(iobs), abi.REPROJ_OBS_DTYPE)
-        for f in ("frame", "point", "gx", "gy"):
-            o[f] = iobs[f]
-        ba.set_param("mixedBundleAdjustment", 1)
-        ba.set_indirect_points(ipts, o)
-    if not ba.run():                                                      # uploads the window, leaves adjoints/priors resident
-        raise RuntimeError("BA run failed: " + ba.last_error())
-    _dbg('run done')
-    _, _, R = ctx.refresh_window_size()      # the window was uploaded by the C++ host mirror
-    if not ba.begin_resident():                                           # frame states, adjoints, priors, gauge basis -> device
-        raise RuntimeError("begin_resident failed: " + ba.last_error())
-    lam = 1e-5
-    for _ in range(300):                                                  # setup, not a step: ~20 ms of work so that the clocks have ramped
-        ctx.ba_iteration_async(lam)                                       # before the W warm-up steps, whatever W is
-    ctx.sync()
-    for _ in range(args.warmup):
-        ctx.ba_iteration_async(lam)
-    _dbg('warmup queued')
-    # every stride-th step carries the profile events on its dispatches (an event-carrying dispatch costs the pipeline ~3 us: at
-    # stride 4 the contract region ran 1.4 us per step behind the regions without events)
-    stride = 8 if args.steps >= 16 else (2 if args.steps >= 4 else 1)
-    ctx.profile_stride(stride)
-    ctx.profile_select(1)                                                 # contract region: events on the roofline kernel's dispatch only
-    ctx.profile_enable((args.steps + stride - 1) // stride)
+    _dbg('window resident')
 
-    def run_steps():
-        for _ in range(args.steps):
-            ctx.ba_iteration_async(lam)
-
-    def sync():
-        ctx.sync()
+    def sync_extra():
         if dev is not None:
             torch.cuda.synchronize()
 
-    _dbg('profile enabled')
-    dt = shard.timed_region(group, sync, run_steps)
-    _dbg('timed region done')
+    M = measure(S, args.steps, args.warmup, group, sync_extra)
+    dt = M["dt"]
+    _dbg('timed regions done')
     ranks_joined = int(round(group.sum(1.0)))
-    lin_v, _ss0, _empty, n_samples = ctx.profile_read()
-    # the Schur-reduce + solve group (K3 begin -> K6 end) is sampled in a region of its own, after the contract region: every
-    # event-carrying dispatch costs the pipeline a few microseconds, and the contract region needs the roofline kernel's only
-    ctx.profile_select(2)
-    ctx.profile_enable((args.steps + stride - 1) // stride)
-    shard.timed_region(group, sync, run_steps)
-    _lin0, ss_v, _empty, _n = ctx.profile_read()
-    ctx.profile_select(3)
-    # spread: the contract region above is ONE sample (K steps can be a millisecond); eight more regions of the same K steps, same
-    # protocol, reported beside it (not used for `value`)
-    ctx.profile_enable(0)
-    rep_ms = []
-    for _ in range(8):
-        rep_ms.append(1e3 * shard.timed_region(group, sync, run_steps) / args.steps)
-    rep_ms.sort()
-    # the events are the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL): no bracket overhead to subtract
-    lin_ms, ss_ms = C.c_float(lin_v), C.c_float(ss_v)
-    _dbg('profile read')
-    st = ctx.ba_states()
-    n_good = int(st["good"].sum())
-    n_sampled = int((st["state"] != 1).sum())        # residuals of the timed passes that enter the pixel loop and gather texels (OOB is absorbing, BA.cpp:68-72)
-    # ---- parity gate ("a throughput figure is only valid if the same run passes the fixture comparison"): one more
-    # iteration from the state the timed region left, its residual pass replayed on the oracle from the device's own state and compared
-    # bit for bit over ALL R residuals (tests/resident_check.py) — after the timed region, outside it
-    parity = {"parity_checked": False}
-    if rank == 0 and not hybrid:
-        try:
-            from tests import resident_check as RC
-            replay = RC.make_replay(ctx, ba, W)
-            rep = RC.check_one_pass(ctx, replay, lam, with_records=True)
-            replay.close()
-            parity = {"parity_checked": True, "parity_ok": bool(rep["ok"]), "parity": rep,
-                      "parity_note": "one resident iteration after the timed region; its residual pass (%s) replayed by oracle/orc_ba.c from the device's "
-                                     "pairs / thresholds / inverse depths / prior states: states, energies, JpJdF, centre projections and the re-materialised "
-                                     "74-float records compared bit for bit over all R residuals" % ("k_ba_lin_rs" if R >= 36 * 1024 else "k_ba_lin_rs4")}
-        except Exception as e:
-            parity = {"parity_checked": False, "parity_error": repr(e)}
+    parity = parity_gate(S) if rank == 0 else {"parity_checked": False}
     total_units = group.sum(float(R) * args.steps)
-    lin_ms_max = group.max(lin_ms.value)
-    ss_ms_max = group.max(ss_ms.value)
+    lin_ms_max = group.max(M["lin_ms"])
+    ss_ms_max = group.max(M["ss_ms"])
 
     _dbg('reductions done')
     if rank == 0:
-        bytes_per_residual = READ_BYTES_PER_RESIDUAL["fp16" if half else "fp32"]
-        achieved = R * bytes_per_residual / (lin_ms.value * 1e-3) / 1e9 if lin_ms.value > 0 else 0.0
-        # memory-side bytes per launch of the residual kernel come from separate `rocprofv3 --pmc` passes of this same command
-        # (tools/profile_bench.py; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide) and are only
-        # quoted for the workload they were collected on
-        traffic, traffic_src, rocprof_us = None, None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_pmc_linearize_%s.json" % args.config)
-        if os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path))
-                traffic = pmc.get("traffic_bytes_per_launch")
-                rocprof_us = pmc.get("linearize_avg_us")   # kernel-trace average of the same command (dispatches serialised by the profiler)
-                traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; taken at commit %s: stale if the residual "
-                               "kernel changed since)" % (os.path.basename(pmc_path), pmc.get("commit", "?")))
-            except Exception:
-                traffic = None
+        rep_ms = M["rep_ms"]
         out = {
             "metric": "point-residuals/sec + Schur-reduce+solve ms, 8 KF x 2000 pts window",
             "value": total_units / dt, "unit": "point-residuals/s",
@@ -482,26 +653,27 @@ def main():
             "ms_per_step_repeats": {"n": len(rep_ms), "min": rep_ms[0], "median": rep_ms[len(rep_ms) // 2], "max": rep_ms[-1],
                                     "note": "eight further timed regions of the same K steps after the contract region (same barrier / sync protocol)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("config C = config B + 1000 ORB reprojection residuals of 300 points mixed into the pose solution in every iteration; " if hybrid else "") + "config %s: %d-KF sliding window, %d active points, R=%d point-residuals, %dx%d level-0 "
-                                   "gradient images, %s texels / fp32 arithmetic; 1 step = 1 full Gauss-Newton BA iteration resident on the device (accumulate, Schur, solve + orthogonalize, back-substitution, frame + point step, pair precompute, linearize + applyRes)" % (wcfg, N, P, R, W.w, W.h, "fp16" if half else "fp32"),
-                       "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
-            "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": n_good, "n_sampled": n_sampled,
-            "roofline": {"bound": "hbm", "kernel": ("k_ba_lin_rs (lane per residual, tiled fp16 level 0)" if R >= 36 * 1024 else "k_ba_lin_rs4 (4 lanes per residual)") + " = linearize + applyRes of the resident loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "n_sampled": n_sampled, "frac_sampled": (achieved / HBM_PEAK_GBS) * n_sampled / max(R, 1),
-                         "frac_sampled_note": "the same fraction billed only for the residuals that gather texels (state != OOB before the pass)",
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": R * bytes_per_residual, "bytes_per_residual": bytes_per_residual,
-                         "launch_us": 1e3 * lin_ms.value, "launch_samples": n_samples,
-                         "launch_us_note": "mean over the sampled steps of the timed region of hipEventElapsedTime between the start and stop events "
-                                           "attached to the k_ba_linearize dispatch itself (hipExtLaunchKernelGGL): the kernel's begin / end "
-                                           "timestamps, the quantity rocprofv3 --kernel-trace reports",
-                         "rocprof_avg_us": rocprof_us},
+            "config": {"workload": workload_text(S), "shards": world, "parallelism": "1 independent window per GPU, RCCL barrier only"},
+            "schur_solve_ms": ss_ms_max, "linearize_kernel_us": 1e3 * lin_ms_max, "good_residuals": M["n_good"], "n_sampled": M["n_sampled"],
+            "roofline": roofline_object(S, M, M["lin_ms"]),
         }
         out.update(parity)
         if parity.get("parity_checked") and not parity.get("parity_ok"):
             out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
-        if not args.no_extras and world == 1 and not hybrid and args.config == "B":
+        extras = not args.no_extras and world == 1 and args.config == "B"
+        if extras:
+            try:
+                out["solve"] = solve_phases(ctx, N)
+            except Exception as e:
+                out["solve"] = {"error": repr(e)}
+        ba.close(); ctx.close()                                   # (the objects below build their own contexts)
+        if extras:
+            out["configs"] = {}
+            for cfg in ("C", "E"):                                # BASELINE.json configs[2] and configs[4]: driver-visible, each with its own oracle gate
+                try:
+                    out["configs"][cfg] = secondary_config(cfg, seed, local_rank, args.steps, args.warmup)
+                except Exception as e:
+                    out["configs"][cfg] = {"error": repr(e)}
             try:
                 out["multi_window"] = multi_window_bench(local_rank, seed, wcfg, max(args.steps, 50), half)
             except Exception as e:
@@ -510,19 +682,28 @@ def main():
                 out["tracker"] = tracker_bench(local_rank, seed, not args.no_cpu_baseline)
             except Exception as e:
                 out["tracker"] = {"error": repr(e)}
+            try:
+                out["sequence"] = sequence_bench(local_rank, seed, not args.no_cpu_baseline)
+            except Exception as e:
+                out["sequence"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wcfg, seed)          # (config C: the photometric window of config B; the ORB term is not part of the CPU port's timing)
                 if out["cpu_baseline"].get("value"):
                     out["gpu_over_cpu_single_socket"] = out["value"] / out["cpu_baseline"]["value"]     # what north_star's ">= 30x" is judged on
                     out["gpu_over_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["single_thread"]["value"]
+                    mm = out["cpu_baseline"].get("value_minmax")
+                    if mm:
+                        out["gpu_over_cpu_single_socket_minmax"] = [out["value"] / mm[1], out["value"] / mm[0]]
                 if hybrid and isinstance(out["cpu_baseline"], dict):
                     out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", "")) + " — the config-B window WITHOUT the 1000 ORB residuals of config C"
             except Exception as e:      # the checker must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "point-residuals/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
+    else:
+        ba.close(); ctx.close()
     group.barrier()
-    ba.close(); ctx.close(); group.close()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -55,7 +55,8 @@ typedef enum {
     CMLHIP_ERR_HIP = 2,          /* HIP runtime error, see cmlhip_last_error */
     CMLHIP_ERR_NONFINITE = 3,    /* a result contains NaN/Inf */
     CMLHIP_ERR_NOT_FOUND = 4,    /* unknown image id / level */
-    CMLHIP_ERR_STATE = 5         /* call order violated (e.g. linearize before upload) */
+    CMLHIP_ERR_STATE = 5,        /* call order violated (e.g. linearize before upload) */
+    CMLHIP_ERR_TIMEOUT = 6       /* a bounded device-side wait between workgroups gave up (the launch could not be co-resident): results void */
 } cmlhip_status;
 
 /* residual states, DSOResidual.h:14-16 */
@@ -525,6 +526,13 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, 
  * get: x of the last iteration (8N+4), the last indirect solution (6N) and the per-point Jacobian sums (3M, for setUncertainty :2690). */
 int cmlhip_ba_set_resident_indirect(cmlhip_ctx* ctx, int M, const double* points_xyz, int n_obs, const cmlhip_reproj_obs* obs, double fx, double fy);
 int cmlhip_ba_get_resident_indirect(cmlhip_ctx* ctx, double* x, double* x6, double* Jpoints);
+/* The marginalisation prior INSIDE the resident iteration (solveSystem with disableMarginalization == false, BA.cpp:1389-1401: HM =
+ * mMarginalizedHessian, bM_top = mMarginalizedB + mMarginalizedHessian * getFramesDelta()): HM ((8N+4)^2) and the RAW bM (8N+4,
+ * mMarginalizedB itself) are kept on the device; every iteration adds HM to the system and forms bM_top from the resident frame states
+ * — the frame step of iteration i writes the right-hand side iteration i + 1 takes.  Call after cmlhip_ba_set_resident_state (which
+ * switches the prior off again); NULL pointers switch it off.  Valid under forceAccept, where calcMEnergy / calcLEnergy return 0
+ * (BA.cpp:2100-2102, 2123-2125) and the prior therefore only enters the solve. */
+int cmlhip_ba_set_resident_prior(cmlhip_ctx* ctx, const double* HM, const double* bM);
 /* Mirror of BA::run's early exit (`if (canbreak && it >= 1) break`, BA.cpp:879, canbreak from doStepFromBackup :996-1027 with
  * thOptIterations): after the call, the iteration whose step passes the test is the last one that runs — the kernels of the
  * iterations enqueued behind it return at once.  th <= 0 switches the test off (every enqueued iteration runs). */

@@ -11,7 +11,7 @@ CPARS = 4
 MAX_FRAMES = 32
 RJ_FLOATS = 74
 
-OK, ERR_INVALID, ERR_HIP, ERR_NONFINITE, ERR_NOT_FOUND, ERR_STATE = range(6)
+OK, ERR_INVALID, ERR_HIP, ERR_NONFINITE, ERR_NOT_FOUND, ERR_STATE, ERR_TIMEOUT = range(7)
 RES_IN, RES_OOB, RES_OUTLIER = 0, 1, 2
 MODE_ACTIVE, MODE_LINEARIZED, MODE_MARGINALIZED = 0, 1, 2
 TEXEL_F32, TEXEL_F16 = 0, 1

@@ -1866,6 +1866,13 @@ static size_t solve_lds_bytes(int m) {
     return d * sizeof(double);
 }
 
+// the marginalisation prior of the resident loop rides in the frame step (frame_prior_rhs, ba_frames.h)
+static inline void fill_frame_prior(cmlhip_ctx* c, FrameStepArgs& F, int n) {
+    F.n = n;
+    if (c->resident_prior) { F.HM = c->HM.as<double>(); F.bM_raw = c->bM_raw.as<double>(); F.bM_top = c->bM.as<double>(); }
+    else { F.HM = nullptr; F.bM_raw = nullptr; F.bM_top = nullptr; }
+}
+
 // arguments of K3 / K4 for the ACTIVE pass of a window as the context stands (shared by the solo launcher and the batched iteration)
 static void fill_acc_args(cmlhip_ctx* c, const BAArgs& A, bool do_backup, AccArgs& X) {
     const int n = A.n;
@@ -1987,6 +1994,7 @@ int cml_launch_solve(cmlhip_ctx* c, const BAArgs& A, int optcal, bool with_lin_f
             F.dprior = c->vec_small.as<double>() + 8 + 8 * A.N;
             for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
             F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
+            fill_frame_prior(c, F, A.n);
         }
         BC.g_pts = cml_div_up(A.P * 8, 512);
         if (int rc = cml_ensure(c, c->x_ticket, 64 + 16 * (8 * CMLHIP_MAX_FRAMES + 4))) return rc;
@@ -2030,6 +2038,7 @@ int cml_launch_backsub(cmlhip_ctx* c, const BAArgs& A, bool do_step) {
         F.dprior = c->vec_small.as<double>() + 8 + 8 * A.N;
         for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
         F.N = A.N; F.frame_sums = A.ctl ? A.ctl->frame_sums : nullptr;
+        fill_frame_prior(c, F, A.n);
     }
     if (cml_div_up(A.P * 8, 256) + F.on == 0) return CMLHIP_OK;     // no points and no frame step: nothing to launch (a zero grid is a HIP error)
     const double* xad = nullptr;
@@ -2106,6 +2115,17 @@ __global__ __launch_bounds__(256) void k_ba_backsub_batch(const BatchWin* __rest
 
 int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
     cmlhip_ctx* c0 = ctxs[0];
+    // The launches below all go to ctxs[0]'s stream, but a window's upload / cmlhip_ba_set_resident_state are asynchronous on ITS context's
+    // stream (h2d scatter kernel, closing memset): order that work ahead of the batch.  A stream that is already idle (every round but the
+    // first) costs one query and no device-side operation.
+    for (int k = 1; k < S; k++) {
+        cmlhip_ctx* c = ctxs[k];
+        if (hipStreamQuery(c->stream) == hipSuccess) continue;
+        if (!c->batch_ev) CML_CHECK(c0, hipEventCreateWithFlags(&c->batch_ev, hipEventDisableTiming));
+        CML_CHECK(c0, hipEventRecord(c->batch_ev, c->stream));
+        CML_CHECK(c0, hipStreamWaitEvent(c0->stream, c->batch_ev, 0));
+    }
+    (void)hipGetLastError();                                // (hipStreamQuery reports hipErrorNotReady through the sticky error too)
     std::vector<BatchWin> H((size_t)S);
     std::vector<unsigned char> Hrs;
     int g_acc = 0, g_sys = 0, g_back = 0, nsl = 0, rs_blocks = 0;
@@ -2124,7 +2144,7 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
         w.acc_mode = c->efs_in_partials ? CML_MODE_ACTIVE_TILES : 0;
         w.g_acc = A.N * A.N + cml_div_up(A.P, PT_PER_BLOCK);            // (re-sized below when every window takes the 256-thread form)
         all_tiles = all_tiles && c->efs_in_partials;
-        const bool super = fill_sys_args(c, A, w.X, lambda, false, false, false, w.S);
+        const bool super = fill_sys_args(c, A, w.X, lambda, c->resident_prior, false, false, w.S);
         if (super) { c0->err = "cmlhip_ba_iteration_batch: a window this wide fills the chip on its own (use cmlhip_ba_iteration_async)"; return CMLHIP_ERR_INVALID; }
         w.g_sys = w.S.nsyrk + A.N + 1;
         // K5, as cml_launch_solve
@@ -2151,6 +2171,7 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
             F.dprior = c->vec_small.as<double>() + 8 + 8 * A.N;
             for (int i = 0; i < 4; i++) F.sc[i] = c->res_scales[i];
             F.N = A.N; F.frame_sums = nullptr;
+            fill_frame_prior(c, F, A.n);
         }
         w.g_back = cml_div_up(A.P * 8, 256) + F.on;
         w.adH = c->adH.as<double>(); w.adT = c->adT.as<double>(); w.step_partial = c->step_partial.as<float>();

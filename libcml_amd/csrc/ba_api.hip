@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "ba_common.h"
+#include "ba_frames.h"
 #include "reproj_dev.h"
 #include <cmath>
 
@@ -548,7 +549,7 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     //  8.8 us rocprofv3 reports for the same kernel, whose tracer puts a signal on every dispatch)
     const bool prof_ss = prof && (c->prof_mask & 2), prof_k1 = prof && (c->prof_mask & 1);
     if (prof_ss) c->ext_start = ev[0];                       // begin timestamp of the K3 dispatch
-    cml_launch_accumulate(c, A, lambda, false, true);        // K3 (+ backup) and K4
+    cml_launch_accumulate(c, A, lambda, c->resident_on && c->resident_prior, true);        // K3 (+ backup) and K4 (+ the marginalisation prior when it is resident)
     const bool mix = c->resident_on && c->rp_resident && c->N > 4;      // addIndirectToProblem, BA.cpp:1327-1329 (only with more than 4 frames)
     ReprojArgs rp;
     if (mix) cml_resident_reproj_args(c, lambda, c->resident_iter + 1, &rp);   // its per-frame workgroups ride in the solve launch
@@ -710,7 +711,32 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, co
     c->have_null = nullspace_basis != nullptr;
     if (c->have_null && (rc = cml_h2d(c, c->null_basis.p, nullspace_basis, 8 * 7 * (size_t)n))) return rc;
     if ((rc = cml_h2d_batch_flush(c))) return rc;
-    c->resident_on = true; c->resident_iter = 0; c->conv_th = 0; c->conv_on = false; c->rp_resident = false;
+    c->resident_on = true; c->resident_iter = 0; c->conv_th = 0; c->conv_on = false; c->rp_resident = false; c->resident_prior = false;
+    return CMLHIP_OK;
+}
+
+// bM_top of the frame states as they stand (iteration 0 of a resident run; afterwards the frame step keeps it current)
+__global__ void k_ba_prior_rhs(const cmlhip_ba_frame_state* __restrict__ fs, int N, FrameStepArgs F) {
+    __shared__ double s_delta[CMLHIP_MAX_FRAMES][8];
+    for (int e = threadIdx.x; e < N * 8; e += blockDim.x) s_delta[e >> 3][e & 7] = fs[e >> 3].state[e & 7] - fs[e >> 3].state_zero[e & 7];
+    __syncthreads();
+    frame_prior_rhs(F, s_delta);
+}
+
+int cmlhip_ba_set_resident_prior(cmlhip_ctx* c, const double* HM, const double* bM) { CML_DEV(c);
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
+    if (!HM || !bM) { c->resident_prior = false; return CMLHIP_OK; }
+    const size_t n = 8 * (size_t)c->N + 4;
+    if ((rc = cml_ensure(c, c->bM_raw, 8 * n))) return rc;
+    if ((rc = cml_h2d(c, c->HM.p, HM, 8 * n * n))) return rc;
+    if ((rc = cml_h2d(c, c->bM_raw.p, bM, 8 * n))) return rc;
+    FrameStepArgs F = {};
+    F.n = (int)n; F.HM = c->HM.as<double>(); F.bM_raw = c->bM_raw.as<double>(); F.bM_top = c->bM.as<double>();
+    k_ba_prior_rhs<<<1, 128, 0, c->stream>>>(c->frame_state.as<cmlhip_ba_frame_state>(), c->N, F);
+    CML_CHECK(c, hipGetLastError());
+    c->resident_prior = true;
     return CMLHIP_OK;
 }
 

@@ -18,7 +18,21 @@ struct FrameStepArgs {
     int N, on;
     int adhtd_done;                // wide windows: adHTd of the stepped state was already written by k_ba_xad
     float* frame_sums;             // optional: sumA sumB sumT sumR of doStepFromBackup (BA.cpp:957-972) for the convergence test
+    // marginalisation prior inside the resident loop (cmlhip_ba_set_resident_prior): after the step, the right-hand side the NEXT
+    // iteration's system takes, bM_top = mMarginalizedB + mMarginalizedHessian * getFramesDelta() (BA.cpp:1389-1401), n = 8N+4
+    const double* HM; const double* bM_raw; double* bM_top; int n;
 };
+
+// bM_top[r] = bM_raw[r] + sum_j HM[r][j] d[j], d = (0,0,0,0, delta of frame 0, delta of frame 1, ...), summed in column order like the
+// host mirror's solveSystem: one row per thread
+__device__ __forceinline__ void frame_prior_rhs(const FrameStepArgs& F, const double (*delta)[8]) {
+    for (int r = threadIdx.x; r < F.n; r += blockDim.x) {
+        const double* row = F.HM + (size_t)r * F.n;
+        double s = F.bM_raw[r];
+        for (int j = 4; j < F.n; j++) s += row[j] * delta[(j - 4) >> 3][(j - 4) & 7];
+        F.bM_top[r] = s;
+    }
+}
 
 // What the frame step reads that does NOT depend on x — requested by frame_step_prefetch AHEAD of the wait for x when the block rides in the
 // solve launch (in-kernel stamps, round 3: this block, not the point blocks, ended the launch — 6.8 against 4.0 us behind the solve
@@ -111,6 +125,7 @@ __device__ __forceinline__ void frame_step_block(const FrameStepArgs& F, const d
         }
         F.frame_sums[0] = sumA; F.frame_sums[1] = sumB; F.frame_sums[2] = sumT; F.frame_sums[3] = sumR;
     }
+    if (F.HM) frame_prior_rhs(F, s_delta);
     if (dist) {
         // computeDelta, BA.cpp:1120-1135, one (pair, column) entry per thread and pass from the adjoint columns requested ahead: the
         // sums of the per-pair form below, term for term

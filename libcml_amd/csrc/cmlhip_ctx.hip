@@ -11,7 +11,7 @@ int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p) { hipStreamSynchronize(c->stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     size_t cap = (bytes + 255) & ~size_t(255);
     CML_CHECK(c, hipMalloc(&b.p, cap));
-    b.bytes = cap;
+    b.bytes = cap; b.gen++;
     return CMLHIP_OK;
 }
 void cml_free(DevBuf& b) {
@@ -222,6 +222,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev[0]);
     (void)hipEventDestroy(c->ev[1]);
+    if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

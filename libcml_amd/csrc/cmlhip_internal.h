@@ -19,6 +19,7 @@
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    unsigned gen = 0;        // bumped by every (re)allocation: "is this the buffer I initialised" must not be an address compare (a free + malloc may return the address)
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -76,6 +77,7 @@ struct cmlhip_ctx {
     size_t pinned_bytes = 0, pinned_off = 0;
     // Kernel timing of the resident iteration (cmlhip_profile_enable): the events ride ON the dispatches (hipExtLaunchKernelGGL
     // start / stop events = the dispatch's own begin / end timestamps, what rocprofv3 --kernel-trace reads), not around them
+    hipEvent_t batch_ev = nullptr;                            // cml_iteration_batch: orders this context's pending stream work ahead of a batch on another context's stream
     hipEvent_t ext_start = nullptr, ext_stop = nullptr;       // consumed by the next CML_LAUNCH_EV
     hipEvent_t ext_stop_if_merged = nullptr;                  // stop event for the solve launch when the back-substitution rides in it
     std::vector<hipEvent_t> prof_ev;   // 4 events per recorded iteration: K3 begin, K6 end, K1 begin, K1 end
@@ -112,6 +114,7 @@ struct cmlhip_ctx {
     DevBuf pair_blocks;                                       // N*N x PAIR_BLK doubles (stitched per-pair blocks)
     DevBuf adH, adT, adHTd, vec_small;                        // adjoints, adHTdeltaF, {cdelta,cprior,prior,delta_prior}
     DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec, Hf, bf;    // (8N+4)^2 / (8N+4) doubles; Hf/bf = final LM system
+    DevBuf bM_raw; bool resident_prior = false;               // resident loop with the marginalisation prior: mMarginalizedB as handed over; bM then holds bM_raw + HM * delta of the CURRENT frame states (cmlhip_ba_set_resident_prior)
     DevBuf tr_points, tr_pairs, tr_out;
     DevBuf ini_points, ini_partial;          // coarse initializer (initializer.hip)
     DevBuf pnp_matches, pnp_flags, pnp_out;  // pose-only optimisation (pnp.hip)
@@ -141,7 +144,8 @@ struct cmlhip_ctx {
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x, rp_off, rp_orig; int rp_acc_N = 0;
     DevBuf trk_xch;                                           // cmlhip_tracker_optimize_batch: partial sums + tickets of the workgroups of a hypothesis
     void* trk_opt_host = nullptr; size_t trk_opt_host_bytes = 0;   // mapped, coherent host block of cmlhip_tracker_optimize_batch: hypotheses in, results out
-    void* trk_xch_seen = nullptr; int trk_epoch = 0;           // tracker exchange buffer: cleared once per allocation, launch number in every word (tracker_opt.hip)
+    unsigned trk_xch_gen = 0; int trk_epoch = 0;              // tracker exchange buffer: cleared once per ALLOCATION (DevBuf::gen) and when the 16-bit launch number wraps (tracker_opt.hip)
+    int trk_capacity[2] = {0, 0};                              // workgroups of k_tracker_optimize<half> the device holds at once (CUs x occupancy), 0 = not asked yet
     DevBuf x_ticket; bool x_ticket_zeroed = false, backsub_merged = false; int x_ticket_seq = 0;      // K6 inside the K5 launch (BacksubCall)
     DevBuf batch_main, batch_rs; std::vector<unsigned char> batch_main_host, batch_rs_host; unsigned attr_done_batch = 0;   // cmlhip_ba_iteration_batch (kept by the first context of the batch)
     DevBuf rr_obs, rr_off, rr_orig, rr_points, rr_jp, rr_used, rr_x, rr_ready; std::vector<int> rr_point_of;     // the resident hybrid term's own buffers

@@ -40,6 +40,7 @@ struct TrkOptArgs {
     float* xch;                                        // [n_hyp][2 parities][G][64] 8-byte words {sum | launch number, exchange number}
     int epoch;                                         // launch number of this context (16 bits used)
     int* tick;                                         // [n_hyp][G]
+    int* late;                                         // mapped host word: set when an exchange gave up waiting (a workgroup of the hypothesis never became resident)
 };
 
 // per-evaluation constants exactly as TR.cpp:260-278,426-429 forms them (float), shared by the workgroup
@@ -375,7 +376,7 @@ __device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3
 // all lanes: computeResidual + computeHessian over the level's list (the per-point arithmetic and the reduction layout of
 // k_tracker_eval, tracker.hip); leaves the 56 sums in s_red
 // the sums of this workgroup's part -> the sums of the level, in every workgroup of the hypothesis (see TrkOptArgs::G)
-__device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, const float mine, const int epoch) {
+__device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, const float mine, const int epoch, int* __restrict__ late_flag) {
     // Every sum travels as ONE self-validating device-scope word {value | seq << 32} (past the non-coherent caches; valid on its own): the
     // writers neither wait for acknowledgements nor publish a ticket, the readers poll the G words of their sum directly and add them in
     // workgroup order.  (First form: device-scope stores, a release fence — an L2 write-back —, barrier, ticket; readers polled the G
@@ -411,12 +412,16 @@ __device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __res
             for (int q = 0; q < 8; q++) if (q0 + q < G) v += __int_as_float((int)(unsigned)w[q]);
         }
     }
-    return __ballot(late) ? 0.f : v;
+    if (__ballot(late)) {                                              // reported to the host as CMLHIP_ERR_TIMEOUT: a scheduling problem, not a tracking failure
+        if (late) __hip_atomic_store(late_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return 0.f;
+    }
+    return v;
 }
 
 template <bool HALF>
 __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red,
-                        const int g, const int G, const int split_min, float* xch, int* tick, int& seq, const int epoch) {
+                        const int g, const int G, const int split_min, float* xch, int* tick, int& seq, const int epoch, int* late_flag) {
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     to_float4 acc = {0.f, 0.f, 0.f, 0.f};
     const int Ge = (G > 1 && E.n > split_min) ? G : 1;       // parts of this level (1: every workgroup evaluates all of it)
@@ -519,7 +524,7 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
         else if (tid == 52) src = 11 * 16 + 9;                          // numWarped
         float v = 0.f;
         if (src >= 0) for (int w = 0; w < TO_WAVES; w++) v += s_tile[w][src];
-        if (Ge > 1) v = to_exchange(xch, tick, g, G, seq, v, epoch);
+        if (Ge > 1) v = to_exchange(xch, tick, g, G, seq, v, epoch, late_flag);
         if (tid < TO_NRED) s_red[tid] = v;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // read back by other lanes of this wave only: compiler ordering
         __builtin_amdgcn_wave_barrier();
@@ -556,7 +561,7 @@ __device__ __forceinline__ int to_ctrl(const ToState& S, int& cseq) {
 
 // lane 0 books the time since the last mark as algebra, runs the evaluation, books it as evaluation
 #define TO_TIMED_EVAL() do { if (tid == 0) { const long long t_ = wall_clock64(); S.t_alg += t_ - S.t_mark; S.t_mark = t_; } \
-        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, g, A.G, A.split_min, xch, tick, seq, A.epoch); \
+        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, g, A.G, A.split_min, xch, tick, seq, A.epoch, A.late); \
         if (tid == 0) { const long long t_ = wall_clock64(); S.t_eval += t_ - S.t_mark; S.t_mark = t_; } } while (0)
 
 enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
@@ -763,11 +768,22 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     A.scale_a = prm->scale_a; A.scale_b = prm->scale_b;
     A.opt_a = optimize_a; A.opt_b = optimize_b; A.sat_th = saturated_ratio_th; A.n_hyp = n_hyp;
     int rc;
-    // workgroups per hypothesis: as many as keep every workgroup of the launch resident at once (they wait for one another), at most 8
-    static const char* e_g = getenv("CMLHIP_TRACKER_G");                  // development: force G
-    int G = e_g ? atoi(e_g) : std::min(8, 256 / n_hyp);
+    // workgroups per hypothesis: as many as keep every workgroup of the launch resident at once (they wait for one another), at most 8.
+    // The capacity is asked of THIS device (CUs x occupancy of the kernel: a partitioned gfx950 — CPX / DPX — reports fewer CUs), not assumed.
+    const bool half = c->lim.texel_format == CMLHIP_TEXEL_F16;
+    if (c->trk_capacity[half] == 0) {
+        hipDeviceProp_t prop;
+        CML_CHECK(c, hipGetDeviceProperties(&prop, c->lim.device_id));
+        int per_cu = 0;
+        if (half) CML_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tracker_optimize<true>, TO_THREADS, 0));
+        else CML_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tracker_optimize<false>, TO_THREADS, 0));
+        c->trk_capacity[half] = std::max(1, prop.multiProcessorCount * std::max(per_cu, 1));
+    }
+    const int capacity = c->trk_capacity[half];
+    static const char* e_g = getenv("CMLHIP_TRACKER_G");                  // development: force G (still clamped to what fits)
+    int G = e_g ? atoi(e_g) : std::min(8, capacity / n_hyp);
     if (G < 1) G = 1;
-    if (n_hyp * G > 256) G = std::max(1, 256 / n_hyp);
+    if ((long long)n_hyp * G > capacity) G = std::max(1, capacity / n_hyp);          // G = 1: no workgroup waits for another, any launch size is fine
     A.G = G; A.split_min = 2 * TO_THREADS;
     if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp * G))) return rc;
     const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)G * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
@@ -775,32 +791,39 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     // hypotheses in, results out through ONE mapped, coherent host block: the kernel reads the 96 bytes of its hypothesis and the first
     // workgroup of each hypothesis writes its result there — no staged upload before the launch and no copy back behind it (each was a
     // copy command of its own on the stream: 321 -> 299 us per call for one hypothesis, 421 -> 389 for fifty)
-    const size_t hyp_bytes = ((sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp + 255) / 256) * 256, res_bytes = sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp;
-    if (c->trk_opt_host_bytes < hyp_bytes + res_bytes) {
+    const size_t hyp_bytes = ((sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp + 255) / 256) * 256, res_bytes = ((sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp + 255) / 256) * 256;
+    if (c->trk_opt_host_bytes < hyp_bytes + res_bytes + 256) {
         if (c->trk_opt_host) { CML_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->trk_opt_host); c->trk_opt_host = nullptr; c->trk_opt_host_bytes = 0; }
-        const size_t want = std::max<size_t>(2 * (hyp_bytes + res_bytes), 64 * 1024);
+        const size_t want = std::max<size_t>(2 * (hyp_bytes + res_bytes) + 256, 64 * 1024);
         CML_CHECK(c, hipHostMalloc(&c->trk_opt_host, want, hipHostMallocMapped | hipHostMallocCoherent));
         c->trk_opt_host_bytes = want;
     }
     char* const hb = static_cast<char*>(c->trk_opt_host);
     memcpy(hb, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp);
-    memset(hb + hyp_bytes, 0, res_bytes);
+    memset(hb + hyp_bytes, 0, res_bytes + sizeof(int));
     void* dptr = nullptr;
     CML_CHECK(c, hipHostGetDevicePointer(&dptr, c->trk_opt_host, 0));
     A.hyp = reinterpret_cast<const cmlhip_tracker_hypothesis*>(dptr);
     A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
     A.out_host = reinterpret_cast<cmlhip_tracker_opt_result*>(static_cast<char*>(dptr) + hyp_bytes);
     A.xch = c->trk_xch.as<float>(); A.tick = reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes);
+    A.late = reinterpret_cast<int*>(static_cast<char*>(dptr) + hyp_bytes + res_bytes);
     // (no per-call clearing: the words carry the launch number; a fresh or moved buffer is cleared once)
-    if (c->trk_xch.p != c->trk_xch_seen) { CML_CHECK(c, hipMemsetAsync(c->trk_xch.p, 0, c->trk_xch.bytes, c->stream)); c->trk_xch_seen = c->trk_xch.p; c->trk_epoch = 0; }
-    c->trk_epoch = (c->trk_epoch % 0xfffe) + 1;            // 1 .. 0xfffe: never the zero of a cleared buffer
+    // cleared once per ALLOCATION (DevBuf::gen, not the address: a free + malloc may hand the address back) and whenever the 16-bit launch
+    // number wraps, so that a stale word can never carry a matching tag
+    if (c->trk_xch.gen != c->trk_xch_gen || c->trk_epoch >= 0xfffe) {
+        CML_CHECK(c, hipMemsetAsync(c->trk_xch.p, 0, c->trk_xch.bytes, c->stream)); c->trk_xch_gen = c->trk_xch.gen; c->trk_epoch = 0;
+    }
+    c->trk_epoch += 1;                                     // 1 .. 0xfffe: never the zero of a cleared buffer
     A.epoch = c->trk_epoch;
     std::atomic_thread_fence(std::memory_order_release);
-    if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp * G, TO_THREADS, 0, A);
+    if (half) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp * G, TO_THREADS, 0, A);
     else CML_LAUNCH_EV(c, k_tracker_optimize<false>, n_hyp * G, TO_THREADS, 0, A);
     CML_CHECK(c, hipGetLastError());
     CML_CHECK(c, hipStreamSynchronize(c->stream));
     std::atomic_thread_fence(std::memory_order_acquire);
-    memcpy(out, hb + hyp_bytes, res_bytes);
+    memcpy(out, hb + hyp_bytes, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
+    if (*reinterpret_cast<volatile int*>(hb + hyp_bytes + res_bytes))
+        CML_REQUIRE(c, false, CMLHIP_ERR_TIMEOUT, "tracker optimize: a workgroup gave up waiting for the partial sums of its hypothesis (the launch was not co-resident); results are void");
     return CMLHIP_OK;
 }

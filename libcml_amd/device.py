@@ -43,6 +43,7 @@ PROTOTYPES = {
                                                 _P(abi.TrackerHypothesis), _P(abi.TrackerOptResult)]),
     "cmlhip_ba_set_resident_indirect": (C.c_int, [_ctx, _i, _P(_d), _i, _P(abi.ReprojObs), _d, _d]),
     "cmlhip_ba_get_resident_indirect": (C.c_int, [_ctx, _P(_d), _P(_d), _P(_d)]),
+    "cmlhip_ba_set_resident_prior": (C.c_int, [_ctx, _P(_d), _P(_d)]),
     "cmlhip_ba_set_params": (C.c_int, [_ctx, _P(abi.BAParams)]),
     "cmlhip_ba_upload_window": (C.c_int, [_ctx, _i, _P(abi.BAFrame), _i, _P(abi.BAPoint), _i, _P(abi.BAResidual)]),
     "cmlhip_ba_set_pairs": (C.c_int, [_ctx, _P(abi.BAPair)]),
@@ -358,6 +359,18 @@ class Ctx:
 
     def ba_iteration_async(self, lam):
         self.ck(self.L.cmlhip_ba_iteration_async(self.h, lam))
+
+    def ba_resident_state(self):
+        """(frame states [abi.BAFrameState x N], PRE_worldToCam N x 7 (q w,x,y,z | t)) after the iterations enqueued so far; synchronises."""
+        fs = (abi.BAFrameState * max(self.N, 1))(); pre = np.zeros((max(self.N, 1), 7))
+        self.ck(self.L.cmlhip_ba_get_resident_state(self.h, fs, _p(pre, _d), None))
+        return fs, pre[:self.N]
+
+    def ba_resident_indirect(self, n_points=0):
+        """(x of the last iteration [8N+4], the last indirect solution [6N], per-point Jacobian sums [M x 3]) of the hybrid term inside the resident loop."""
+        x = np.zeros(8 * self.N + 4); x6 = np.zeros(6 * self.N); jp = np.zeros((max(n_points, 1), 3))
+        self.ck(self.L.cmlhip_ba_get_resident_indirect(self.h, _p(x, _d), _p(x6, _d), _p(jp, _d) if n_points else None))
+        return x, x6, jp[:n_points]
 
     # ------------------------------------------------------------------ tracker
     def tracker_set_reference(self, level, uvic):

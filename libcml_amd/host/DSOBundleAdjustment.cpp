@@ -622,10 +622,11 @@ bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // 
 }
 
 bool DSOBundleAdjustment::run(bool updatePointsOnly) {                        // BA.cpp:744-910
-    // forceAccept + fixLambda + no marginalisation prior (the reference's defaults, BA.h:265-270): every step is accepted and
-    // lambda never changes, so the loop body has no host decision left except the early exit, which the device mirrors
+    // forceAccept + fixLambda (the reference's defaults, BA.h:265-270): every step is accepted and lambda never changes, so the loop
+    // body has no host decision left except the early exit, which the device mirrors; the marginalisation prior, when enabled, only
+    // enters the solve under forceAccept (calcMEnergy / calcLEnergy return 0, BA.cpp:2100-2102,2123-2125) and is resident too
     // (the hybrid ORB term is mixed into x inside the device solve: cmlhip_ba_set_resident_indirect)
-    if (mResidentLoop && mForceAccept && mFixLambda && mDisableMarginalization && mNumIterations <= 40) return runResident(updatePointsOnly);
+    if (mResidentLoop && mForceAccept && mFixLambda && mNumIterations <= 40) return runResident(updatePointsOnly);
     return runHostLoop(updatePointsOnly);
 }
 
@@ -947,7 +948,10 @@ double DSOBundleAdjustment::calcLEnergy() {                                   //
 // ------------------------------------------------------------------------------------------------ device-resident loop
 bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
     if (!mForceAccept || !mFixLambda) { mError = "resident iterations need forceAccept and fixLambda (every step accepted, BA.h:265-267)"; return false; }
-    if (!mDisableMarginalization) { mError = "resident iterations do not carry the marginalisation prior"; return false; }
+    if (mDisableMarginalization) {                                             // solveSystem zeroes the prior in this mode, BA.cpp:1395-1398
+        std::fill(mMarginalizedHessian.begin(), mMarginalizedHessian.end(), 0.0);
+        std::fill(mMarginalizedB.begin(), mMarginalizedB.end(), 0.0);
+    }
     const int N = (int)mFrames.size();
     double sc[4];
     scales(sc);
@@ -976,6 +980,9 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
     nullspaceBasis(U);
     rc = cmlhip_ba_set_resident_state(mCtx, &in, fs.data(), sc, U.data());
     if (rc) return fail("cmlhip_ba_set_resident_state", rc);
+    // marginalisation prior (BA.cpp:1389-1401): HM and the raw bM stay on the device, bM_top follows the frame states there
+    rc = cmlhip_ba_set_resident_prior(mCtx, mDisableMarginalization ? nullptr : mMarginalizedHessian.data(), mDisableMarginalization ? nullptr : mMarginalizedB.data());
+    if (rc) return fail("cmlhip_ba_set_resident_prior", rc);
     // hybrid ORB term (BA.cpp:1327-1329, 2574-2729) evaluated and mixed on the device inside every iteration
     const int M = mMixedBundleAdjustment ? (int)(mIndirectPoints.size() / 3) : 0;
     rc = cmlhip_ba_set_resident_indirect(mCtx, M, M ? mIndirectPoints.data() : nullptr, M ? (int)mIndirectObs.size() : 0,

@@ -132,11 +132,21 @@ def make_window(config="B", seed=0xC0FFEE, shard=0, pose_noise=None, idepth_nois
         Rk = so3_exp(np.deg2rad(rng.uniform(-1, 1, 3)) * pose_noise)
         tk = -Rk @ c
         a = rng.uniform(-0.05, 0.05); b = rng.uniform(-5, 5)
-        img, s = render(tex, W.K, Rk, tk, w, h, n, d)
-        # the photometric model of the reference: I_k = exp(a_k) * (I_true) + b_k  (exposure time 1)
-        W.gray.append((np.exp(a) * img + b).astype(np.float32))
-        W.depth.append(s)
         W.R_true.append(Rk); W.t_true.append(tk); W.aff_true.append((a, b))
+
+    def _render(k):
+        img, s = render(tex, W.K, W.R_true[k], W.t_true[k], w, h, n, d)
+        # the photometric model of the reference: I_k = exp(a_k) * (I_true) + b_k  (exposure time 1)
+        a, b = W.aff_true[k]
+        return (np.exp(a) * img + b).astype(np.float32), s
+    if N * w * h > (1 << 22):      # large windows: the renderings draw no random numbers, so they may run side by side (numpy releases the GIL)
+        import concurrent.futures as cf
+        with cf.ThreadPoolExecutor(max_workers=min(8, N)) as ex:
+            out = list(ex.map(_render, range(N)))
+    else:
+        out = [_render(k) for k in range(N)]
+    for img, s in out:
+        W.gray.append(img); W.depth.append(s)
     # evaluation-point poses = truth perturbed (what tracking would have delivered)
     W.R_eval, W.t_eval, W.aff_eval = [], [], []
     for k in range(N):

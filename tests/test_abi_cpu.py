@@ -89,3 +89,32 @@ def test_reference_side_adapter_compiles_against_the_reference_headers():
     r = subprocess.run(["sh", os.path.join(root, "tools", "refcheck", "check.sh")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+def test_no_shared_mutable_statics():
+    """include/cmlhip.h promises independent, re-entrant contexts (tracker ctx and BA ctx on two host threads): the device
+    layer may hold no mutable file-scope or function-scope state.  Every `static` VARIABLE in libcml_amd/csrc must be one of: a const
+    cache of getenv() (written once under C++11's thread-safe static initialisation, read-only afterwards), a const table / constant,
+    or a __constant__ device table.  (tests/test_threads_gpu.py runs the two-thread scenario itself on the GPU.)"""
+    bad = []
+    csrc = os.path.join(ROOT, "libcml_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".inc")):
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, f), errors="ignore"), 1):
+            code = line.split("//")[0]
+            for m in re.finditer(r"\bstatic\s+(?!inline\b|__device__|__host__|__global__|__forceinline__)([^;(){}]*?)\b([A-Za-z_]\w*)\s*(=|;|\[)", code):
+                decl = m.group(1)
+                if "(" in code[m.end():].split("=")[0] and m.group(3) != "=":
+                    continue
+                if re.search(r"\bconst(expr)?\b", decl):
+                    continue                                   # static const T x = ... / static const char* e = getenv(...)
+                bad.append("%s:%d: %s" % (f, ln, line.strip()))
+    assert not bad, "mutable static state in the device layer:\n" + "\n".join(bad)
+    # no global / namespace-scope mutable variables either: __device__ globals would be shared by every context of the process
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".inc")):
+            for ln, line in enumerate(open(os.path.join(csrc, f), errors="ignore"), 1):
+                if re.match(r"^(__device__|__managed__)\s+(?!__forceinline__|inline|static\s+(inline|__forceinline__))[\w:<> ]+\s+\w+\s*(=|;|\[)", line):
+                    bad.append("%s:%d: %s" % (f, ln, line.strip()))
+    assert not bad, bad

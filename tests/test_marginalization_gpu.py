@@ -119,3 +119,47 @@ def test_host_marginalisation_flow():
         assert np.array_equal(H3, H2)                             # run() reads the prior, it does not change it
     finally:
         ba.close(); ctx.close()
+
+
+def test_resident_loop_carries_the_marginalisation_prior():
+    """run() with the prior ENABLED keeps the loop on the device (cmlhip_ba_set_resident_prior: HM resident, bM_top = bM + HM * delta
+    re-formed by the frame step after every iteration, BA.cpp:1389-1401).  Same keyframe cycle twice; the closing run once through the
+    literal host loop (solveSystem hands HM / bM_top to cmlhip_ba_solve each iteration) and once resident: same arithmetic in another
+    place, so the results agree far below the fp32 accumulation noise — and the prior must actually matter (a third run without it
+    lands somewhere else)."""
+    from libcml_amd import device, host
+    res = {}
+    for mode in ("host", "resident", "noprior"):
+        I = S.make_inputs("medium")
+        ctx = device.Ctx(max_frames=I.N + 1, max_points=I.P, max_residuals=I.P * (I.N + 1))
+        ba = host.window_to_host_ba(ctx, I.W)
+        try:
+            ba.set_param("Minimum iDepth Hessian Marginlaization", 1.0)
+            assert ba.run(), ba.last_error()
+            ba.flag_frame(1)
+            assert ba.try_marginalize(), ba.last_error()
+            assert ba.marginalize_points(), ba.last_error()
+            assert list(ba.marginalize_frames()) == [1]
+            H, b = ba.prior()
+            assert np.abs(H).max() > 0
+            # move the states off their linearisation points so that HM * delta is not zero in the first iteration
+            for k in range(1, I.N - 1):
+                st = ba.frame(k)["state"].copy(); st[:6] += 1e-3 * np.cos(np.arange(6) + k); ba.set_frame_state(k, st)
+            ba.set_param("disableMarginalization", 1 if mode == "noprior" else 0)
+            ba.set_param("iterations", 5); ba.set_param("ThOptIterations", 0.0)
+            ok = ba.run_host_loop() if mode == "host" else ba.run()
+            assert ok, ba.last_error()
+            assert ba.counts()["iterations"] == 5
+            idp, alive, _ = ba.points()
+            res[mode] = (idp[alive == 1].copy(), [ba.frame(k) for k in range(I.N - 1)], ba.energies(16).copy(), ba.residual_states()[2].copy())
+        finally:
+            ba.close(); ctx.close()
+    (idp_h, fr_h, e_h, g_h), (idp_r, fr_r, e_r, g_r) = res["host"], res["resident"]
+    assert int((g_h != g_r).sum()) <= max(1, len(g_h) // 2000)
+    for a, b in zip(fr_h, fr_r):
+        assert np.abs(a["state"] - b["state"]).max() < 1e-7 * max(1.0, np.abs(a["state"]).max())
+        assert np.abs(a["R"] - b["R"]).max() < 1e-8 and np.abs(a["t"] - b["t"]).max() < 1e-7
+    assert np.abs(idp_h / idp_r - 1).max() < 1e-5
+    assert len(e_h) == len(e_r) and np.abs(e_h[-5:] / e_r[-5:] - 1).max() < 1e-6, (e_h, e_r)
+    d_prior = max(np.abs(a["state"] - b["state"]).max() for a, b in zip(fr_h, res["noprior"][1]))
+    assert d_prior > 1e-5, d_prior                       # the prior is not a no-op on this window
