@@ -249,6 +249,9 @@ int cmlhip_ba_window_size(cmlhip_ctx* ctx, int* N, int* P, int* R);
 /* per-iteration state: N*N pair transforms + frame thresholds (ba_update_state) */
 int cmlhip_ba_set_pairs(cmlhip_ctx* ctx, const cmlhip_ba_pair* pairs /* N*N, host*N+target */);
 int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* ctx, const float* th /* N */);
+/* DSOFrame::getB0 of every frame again (it follows state_zero: DSOFrame.h:197-199).  BA::run re-anchors the newest frame before its closing
+ * linearizeAll(true) (setEvalPT, BA.cpp:885-894): the b0 handed over with the window is stale for residuals hosted by that frame afterwards. */
+int cmlhip_ba_set_frame_b0(cmlhip_ctx* ctx, const float* b0 /* N */);
 int cmlhip_ba_set_idepth(cmlhip_ctx* ctx, const double* idepth /* P */, const float* idepth_zero /* P or NULL */);
 int cmlhip_ba_get_idepth(cmlhip_ctx* ctx, double* idepth /* P */);
 
@@ -261,7 +264,10 @@ int cmlhip_ba_apply(cmlhip_ctx* ctx, int copy_jacobians);
 /* The tail of DSOBundleAdjustment::run in one call and ONE readback: linearizeAll(true) (BA.cpp:896 = linearize + applyRes(true),
  * :1551-1569) followed by everything the host writes back afterwards — residual states / energies (:1571-1640), the points'
  * inverse depths and the per-point accumulators (HdiF -> setInverseDepthHessian, :1889-1901).  pairs must be current.
- * Any output pointer may be NULL; point_acc is P x 14 as cmlhip_ba_get_point_acc returns it. */
+ * Any output pointer may be NULL; point_acc is P x 14 as cmlhip_ba_get_point_acc returns it.
+ * linearizeAll(true) also REMOVES every active residual that is not good afterwards (toRemove, :1595-1598,1624-1638): after the readback
+ * the device retires them too — state OOB (absorbing, :68-72,2055-2059) — so that the residual loop of cmlhip_ba_relinearize_points
+ * (tryMarginalize walks the point's REMAINING residuals, :2291) cannot revive a residual the host has already dropped. */
 int cmlhip_ba_finish_keyframe(cmlhip_ctx* ctx, cmlhip_ba_lin_result* lin, int* state, int* new_state, float* energy,
                               float* new_energy, float* new_energy_without_outlier, unsigned char* is_good,
                               double* idepth, float* point_acc);

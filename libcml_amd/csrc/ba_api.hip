@@ -25,6 +25,7 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     A.frames = c->frames.as<FrameDev>(); A.pairs = c->pairs.as<cmlhip_ba_pair>();
     A.pt_x = c->pt_x.as<float>(); A.pt_y = c->pt_y.as<float>(); A.pt_idepth = c->pt_idepth.as<double>();
     A.pt_idepth_zero = c->pt_idepth_zero.as<float>(); A.pt_prior = c->pt_prior.as<float>(); A.pt_host = c->pt_host.as<int>();
+    A.r_dead = c->r_dead.as<unsigned char>();
     A.pt_colors = c->pt_colors.as<float>(); A.pt_weights = c->pt_weights.as<float>(); A.pt_backup = c->pt_backup.as<float>();
     A.pt_acc = c->pt_acc.as<float>(); A.pt_step = c->pt_step.as<double>();
     A.r_point = c->r_point.as<int>(); A.r_host = c->r_host.as<int>(); A.r_target = c->r_target.as<int>(); A.r_state = c->r_state.as<int>();
@@ -153,7 +154,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->pt_acc, 4 * PT_ACC_STRIDE * P); ENS(c->pt_step, 8 * P);
     ENS(c->r_point, 4 * R); ENS(c->r_host, 4 * R); ENS(c->r_target, 4 * R); ENS(c->r_state, 4 * R); ENS(c->r_new_state, 4 * R);
     ENS(c->r_energy, 4 * R); ENS(c->r_new_energy, 4 * R); ENS(c->r_new_energy_wo, 4 * R); ENS(c->r_ret_energy, 4 * R);
-    ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 4 * (size_t)PS_STRIDE * R); ENS(c->r_rtz, 32 * R);
+    ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_dead, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 4 * (size_t)PS_STRIDE * R); ENS(c->r_rtz, 32 * R);
     ENS(c->rj[0], 4 * (size_t)RJ_STRIDE * R); ENS(c->rj[1], 4 * (size_t)RJ_STRIDE * R);
     ENS(c->by_point_off, 4 * (P + 1)); ENS(c->by_point, 4 * R); ENS(c->by_pair_off, 4 * (N * N + 1)); ENS(c->by_pair, 4 * R);
     ENS(c->newframe_res, 4 * newframe.size());
@@ -281,6 +282,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     if ((rc = cml_zero(c, c->r_ret_energy.p, c->r_ret_energy.bytes))) return rc;
     if ((rc = cml_zero(c, c->r_good.p, c->r_good.bytes))) return rc;
     if ((rc = cml_zero(c, c->r_sel.p, c->r_sel.bytes))) return rc;
+    if ((rc = cml_zero(c, c->r_dead.p, c->r_dead.bytes))) return rc;
     if ((rc = cml_zero(c, c->r_center.p, c->r_center.bytes))) return rc;
     if ((rc = cml_zero(c, c->r_jpjdf.p, c->r_jpjdf.bytes))) return rc;
     if ((rc = cml_zero(c, c->r_rtz.p, c->r_rtz.bytes))) return rc;
@@ -332,6 +334,21 @@ int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) { CML_DEV(c);
     if (rc) return rc;
     for (int i = 0; i < c->N; i++) fd[i].frame_energy_th = th[i];
     return cml_h2d(c, c->frames.p, fd.data(), sizeof(FrameDev) * c->N);
+}
+
+// DSOFrame::getB0 follows state_zero (DSOFrame.h:197-199): run()'s epilogue re-anchors the newest frame (setEvalPT, BA.cpp:885-894), so
+// the b0 uploaded with the window is stale for residuals HOSTED by that frame from then on (the closing linearizeAll(true), tryMarginalize)
+struct B0Args { float b0[CMLHIP_MAX_FRAMES]; };
+__global__ void k_set_frame_b0(FrameDev* fd, int N, B0Args a) { const int i = threadIdx.x; if (i < N) fd[i].b0 = a.b0[i]; }
+int cmlhip_ba_set_frame_b0(cmlhip_ctx* c, const float* b0) { CML_DEV(c);
+    int rc = ba_check(c, false);
+    if (rc) return rc;
+    if (!b0) return CMLHIP_ERR_INVALID;
+    B0Args a;
+    for (int i = 0; i < CMLHIP_MAX_FRAMES; i++) a.b0[i] = i < c->N ? b0[i] : 0.f;
+    k_set_frame_b0<<<1, 64, 0, c->stream>>>(c->frames.as<FrameDev>(), c->N, a);
+    CML_CHECK(c, hipGetLastError());
+    return CMLHIP_OK;
 }
 
 int cmlhip_ba_set_idepth(cmlhip_ctx* c, const double* idepth, const float* idepth_zero) { CML_DEV(c);
@@ -386,6 +403,12 @@ int cmlhip_ba_apply(cmlhip_ctx* c, int copy) { CML_DEV(c);
     return CMLHIP_OK;
 }
 
+__global__ void k_ba_retire(BAArgs A) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.R || A.r_lin[r] || A.r_good[r]) return;
+    A.r_dead[r] = 1;
+    A.r_state[r] = CMLHIP_RES_OOB;
+}
 int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* state, int* new_state, float* energy, float* new_energy,
                               float* new_energy_wo, unsigned char* is_good, double* idepth, float* point_acc) { CML_DEV(c);
     int rc = cmlhip_ba_linearize_async(c);
@@ -408,6 +431,11 @@ int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* sta
     rr.deliver();
     if (point_acc) for (size_t p = 0; p < P; p++) memcpy(point_acc + 14 * p, &pacc[PT_ACC_STRIDE * p], 14 * 4);
     if (lin) { lin->energy = S.energy; lin->n_in = S.n_in; lin->n_oob = S.n_oob; lin->n_outlier = S.n_outlier; lin->new_frame_energy_th = S.new_frame_energy_th; }
+    // linearizeAll(true) REMOVES every active residual that is not good (toRemove, BA.cpp:1595-1598,1624-1638): from here on it is gone for
+    // the window on the device as well — state OOB (absorbing: linearize and applyRes return at once, BA.cpp:68-72,2055-2059), never reset by
+    // the residual loop of tryMarginalize (the reference walks the point's remaining residuals only, BA.cpp:2291)
+    if (R) k_ba_retire<<<cml_div_up((int)R, 256), 256, 0, c->stream>>>(A);
+    CML_CHECK(c, hipGetLastError());
     return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
 }
 

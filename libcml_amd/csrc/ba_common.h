@@ -60,6 +60,7 @@ struct BAArgs {
     float* r_energy; float* r_new_energy; float* r_new_energy_wo; float* r_ret_energy;
     unsigned char* r_good; const unsigned char* r_lin; unsigned char* r_sel;
     unsigned char* r_lin_rw; int* point_tgt_rw;    // writable views for the marginalisation kernels (isLinearized changes there)
+    unsigned char* r_dead;                         // 1: removed by the closing pass of the last run (absorbing, like OOB); never null after an upload
     float* r_center; float* r_jpjdf; float* r_rtz; float* rj0; float* rj1;
     const int* by_point_off; const int* by_point; const int* by_pair_off; const int* by_pair;
     double* r_idepth; const int* point_res;         // per-residual copy of the point's inverse depth; [P][pt_stride] residual of the slot (-1 = empty)

@@ -384,7 +384,7 @@ __global__ void k_ba_apply(BAArgs A, int copy) {
 // point mask and fused applyRes(true) -> k_ba_marg_fix.
 __global__ void k_ba_marg_reset(BAArgs A) {                      // resetOOB (DSOResidual.h:81-86) + isLinearized = false
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= A.R || !A.pt_mask[A.r_point[r]]) return;
+    if (r >= A.R || !A.pt_mask[A.r_point[r]] || A.r_dead[r]) return;        // (a residual the closing pass of the run removed stays removed)
     A.r_new_energy[r] = 0.f; A.r_energy[r] = 0.f;
     A.r_new_state[r] = CMLHIP_RES_OUTLIER; A.r_state[r] = CMLHIP_RES_IN;
     A.r_lin_rw[r] = 0;

@@ -94,6 +94,7 @@ struct cmlhip_ctx {
     DevBuf pt_x, pt_y, pt_idepth, pt_idepth_zero, pt_prior, pt_host, pt_colors, pt_weights, pt_backup;
     DevBuf pt_acc;                                            // P x 16 floats: HddA bdA HcdA[4] HddL bdL HcdL[4] HdiF bdSum pad pad
     DevBuf pt_step;                                           // P doubles
+    DevBuf r_dead;                                            // residuals the closing linearizeAll(true) of a run removed (BA.cpp:1595-1598,1624-1638): tryMarginalize's pass must not revive them
     DevBuf r_host;                                            // static copy of the point's host per residual (saves a dependent load)
     DevBuf r_point, r_target, r_state, r_new_state, r_energy, r_new_energy, r_new_energy_wo, r_ret_energy;
     DevBuf r_good, r_lin, r_sel, r_center, r_jpjdf, r_rtz, rj[2];

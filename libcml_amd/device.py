@@ -72,6 +72,7 @@ PROTOTYPES = {
     "cmlhip_ba_get_resident_state": (C.c_int, [_ctx, _P(abi.BAFrameState), _P(C.c_double), _P(abi.BALinResult)]),
     "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_set_frame_b0": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
     "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
     "cmlhip_ba_linearize": (C.c_int, [_ctx, _P(abi.BALinResult)]),

@@ -38,6 +38,8 @@ def lib():
         L.cmlhost_ba_flag_frame.argtypes = [_vp, _i, _i]
         L.cmlhost_ba_flag_frames_for_marginalization.argtypes = [_vp, _i]
         L.cmlhost_ba_try_marginalize.argtypes = [_vp]
+        L.cmlhost_ba_flag_frames_for_marginalization_v.argtypes = [_vp, _i, _P(_i)]
+        L.cmlhost_ba_export.argtypes = [_vp, _vp, _vp, _vp]
         L.cmlhost_ba_marginalize_points.argtypes = [_vp]
         L.cmlhost_ba_marginalize_frames.argtypes = [_vp, _P(_i), _i]
         L.cmlhost_ba_get_prior.argtypes = [_vp, _P(_d), _P(_d)]
@@ -73,6 +75,10 @@ def lib():
         L.cmlhost_tracer_create.restype = _vp; L.cmlhost_tracer_create.argtypes = [_vp]
         L.cmlhost_tracer_destroy.argtypes = [_vp]
         L.cmlhost_tracer_add_point.argtypes = [_vp, _f, _f, _i, _P(_f), _P(_f), _P(_d), _f]
+        L.cmlhost_tracer_add_points.argtypes = [_vp, _i, _P(_f), _i, _P(_f), _P(_f), _P(_d)]
+        L.cmlhost_tracer_compact.argtypes = [_vp]
+        L.cmlhost_tracer_get_frame_ids.argtypes = [_vp, _P(_i)]
+        L.cmlhost_ba_add_points.argtypes = [_vp, _i, _P(_f), _P(_d), _P(_i), _P(_f), _P(_f), _i]
         L.cmlhost_tracer_trace.argtypes = [_vp, C.c_uint64, _i, _i, _P(_i), _vp, _P(_i)]
         L.cmlhost_tracer_activate.argtypes = [_vp, _i, _P(_i), _P(C.c_uint64), _P(_d), _i, _i, _vp, _P(_i), _i]
         L.cmlhost_tracer_count.argtypes = [_vp]
@@ -140,6 +146,12 @@ class HostBA:
         c = np.ascontiguousarray(colors, np.float32); w = np.ascontiguousarray(weights, np.float32)
         return self.L.cmlhost_ba_add_point(self.h, float(x), float(y), float(idepth), int(host), _p(c, _f), _p(w, _f), int(prior))
 
+    def add_points(self, xy, idepth, host, colors, weights, prior=False):
+        """addPoints for n points in one call: xy (n, 2), idepth (n), host (n), colors / weights (n, 8)"""
+        xy = np.ascontiguousarray(xy, np.float32); idp = np.ascontiguousarray(idepth, np.float64); hs = np.ascontiguousarray(host, np.int32)
+        c = np.ascontiguousarray(colors, np.float32); w = np.ascontiguousarray(weights, np.float32)
+        return self.L.cmlhost_ba_add_points(self.h, len(xy), _p(xy, _f), _p(idp, _d), _p(hs, _i), _p(c, _f), _p(w, _f), int(prior))
+
     def run(self, update_points_only=False):
         return bool(self.L.cmlhost_ba_run(self.h, int(update_points_only)))
 
@@ -168,6 +180,20 @@ class HostBA:
 
     def flag_frames_for_marginalization(self, immature=0):
         self.L.cmlhost_ba_flag_frames_for_marginalization(self.h, int(immature))
+
+    def flag_frames_for_marginalization_v(self, immature_per_frame):
+        """flagFramesForMarginalization with every frame's own immature count (BA.cpp:617); call BEFORE add_frame, as addNewFrame does (:428)."""
+        a = np.ascontiguousarray(immature_per_frame, np.int32)
+        self.L.cmlhost_ba_flag_frames_for_marginalization_v(self.h, len(a), _p(a, _i))
+
+    def export(self):
+        """(frames, points, residuals) of the mirror as structured arrays (HOST_BA_*_DTYPE): everything an independent checker needs to
+        rebuild the window the mirror holds."""
+        c = self.counts()
+        fr = np.zeros(c["frames"], HOST_BA_FRAME_DTYPE); pt = np.zeros(c["points"], HOST_BA_POINT_DTYPE); rs = np.zeros(c["residuals"], HOST_BA_RESIDUAL_DTYPE)
+        sz = self.L.cmlhost_ba_export(self.h, fr.ctypes.data, pt.ctypes.data, rs.ctypes.data)
+        assert (sz & 1023, (sz >> 10) & 1023, sz >> 20) == (HOST_BA_FRAME_DTYPE.itemsize, HOST_BA_POINT_DTYPE.itemsize, HOST_BA_RESIDUAL_DTYPE.itemsize), sz
+        return fr, pt, rs
 
     def try_marginalize(self):
         return bool(self.L.cmlhost_ba_try_marginalize(self.h))
@@ -266,6 +292,17 @@ class HostBA:
         e = np.zeros(cap)
         n = self.L.cmlhost_ba_stats(self.h, _p(e, _d), cap)
         return e[:n]
+
+
+# cmlhost_ba_export records (libcml_amd/host/capi.cpp)
+HOST_BA_FRAME_DTYPE = np.dtype([("eval_q", "<f8", (4,)), ("eval_t", "<f8", (3,)), ("pre_q", "<f8", (4,)), ("pre_t", "<f8", (3,)), ("state", "<f8", (10,)),
+                                ("state_zero", "<f8", (10,)), ("prior_zero", "<f8", (10,)), ("ab_exposure", "<f8"), ("frameEnergyTH", "<f8"), ("image_id", "<u8"),
+                                ("id", "<i4"), ("keyid", "<i4"), ("flagged", "<i4"), ("numMarginalized", "<i4"), ("numResidualsOut", "<i4"), ("pad", "<i4")])
+HOST_BA_POINT_DTYPE = np.dtype([("idepth", "<f8"), ("x", "<f4"), ("y", "<f4"), ("colors", "<f4", (8,)), ("weights", "<f4", (8,)), ("idepth_zero", "<f4"),
+                                ("priorF", "<f4"), ("idepth_hessian", "<f4"), ("pad0", "<f4"), ("host", "<i4"), ("hasDepthPrior", "<i4"), ("numGoodResiduals", "<i4"),
+                                ("lastResidual", "<i4", (2,)), ("lastResidualState", "<i4", (2,)), ("toMarginalize", "<i4"), ("marginalized", "<i4"), ("alive", "<i4")])
+HOST_BA_RESIDUAL_DTYPE = np.dtype([("state_energy", "<f8"), ("state_NewEnergy", "<f8"), ("point", "<i4"), ("target", "<i4"), ("state_state", "<i4"),
+                                   ("state_NewState", "<i4"), ("isLinearized", "<i4"), ("good", "<i4"), ("alive", "<i4"), ("pad", "<i4")])
 
 
 # computeResidual + computeHessian provider signature of cml_amd::DSOTracker::EvalFn
@@ -376,6 +413,19 @@ class HostTracer:
     def add_point(self, x, y, host_frame_id, gray, dpatch, gradH, type=1.0):
         g = np.ascontiguousarray(gray, np.float32); d = np.ascontiguousarray(dpatch, np.float32); G = np.ascontiguousarray(gradH, np.float64)
         return self.L.cmlhost_tracer_add_point(self.h, float(x), float(y), int(host_frame_id), _p(g, _f), _p(d, _f), _p(G, _d), float(type))
+
+    def add_points(self, xy, host_frame_id, gray, dpatch, gradH):
+        """makeNewTraces' records of one keyframe in one call: xy (n, 2), gray (n, 8), dpatch (n, 24), gradH (n, 4)"""
+        xy = np.ascontiguousarray(xy, np.float32); g = np.ascontiguousarray(gray, np.float32); d = np.ascontiguousarray(dpatch, np.float32); G = np.ascontiguousarray(gradH, np.float64)
+        return self.L.cmlhost_tracer_add_points(self.h, len(xy), _p(xy, _f), int(host_frame_id), _p(g, _f), _p(d, _f), _p(G, _d))
+
+    def compact(self):
+        self.L.cmlhost_tracer_compact(self.h)
+
+    def frame_ids(self):
+        out = np.zeros(max(self.L.cmlhost_tracer_count(self.h), 1), np.int32)
+        self.L.cmlhost_tracer_get_frame_ids(self.h, _p(out, _i))
+        return out[:self.L.cmlhost_tracer_count(self.h)]
 
     def trace_new_coarse(self, image_id, traced_frame_id, frame_ids, pairs):
         ids = np.ascontiguousarray(frame_ids, np.int32); pr = np.ascontiguousarray(pairs, abi.TRACE_PAIR_DTYPE)

@@ -94,9 +94,29 @@ void DSOBundleAdjustment::setCalibration(double fx, double fy, double cx, double
     mHaveCalib = true;
 }
 
+void DSOBundleAdjustment::compactDead() {
+    std::vector<int> pmap(mPoints.size(), -1), rmap(mResiduals.size(), -1);
+    std::vector<DSOPoint> np;
+    std::vector<DSOResidual> nr;
+    for (size_t p = 0; p < mPoints.size(); p++) if (mPoints[p].alive) { pmap[p] = (int)np.size(); np.push_back(mPoints[p]); }
+    for (size_t r = 0; r < mResiduals.size(); r++) {
+        const DSOResidual& R = mResiduals[r];
+        if (!R.alive || R.point < 0 || pmap[R.point] < 0) continue;
+        rmap[r] = (int)nr.size();
+        nr.push_back(R);
+        nr.back().point = pmap[R.point];
+    }
+    for (auto& P : np) for (int q = 0; q < 2; q++) P.lastResidual[q] = P.lastResidual[q] >= 0 ? rmap[P.lastResidual[q]] : -1;
+    mPoints.swap(np); mResiduals.swap(nr);
+    mPointRes.assign(mPoints.size(), {});
+    for (size_t r = 0; r < mResiduals.size(); r++) mPointRes[mResiduals[r].point].push_back((int)r);
+    mOutliers.clear(); mActive.clear(); mActivePoints.clear(); mPointSlot.assign(mPoints.size(), -1);
+}
+
 int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, const Exposure& exposure) {
     double sc[4];
     scales(sc);
+    compactDead();                                                  // (between keyframes nothing refers to point / residual indices)
     DSOFrame f;
     f.id = (int)mFrames.size();
     f.keyid = mFrameKeyCounter++;                                   // DSOContext.h:49-50
@@ -134,6 +154,7 @@ int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, c
         r.state_state = inside ? DSORES_IN : DSORES_OOB;
         r.state_NewState = DSORES_OUTLIER;
         mResiduals.push_back(r);
+        mPointRes[p].push_back((int)mResiduals.size() - 1);
         mPoints[p].lastResidual[0] = (int)mResiduals.size() - 1;            // target is getFrames().back(), BA.cpp:374-375
         mPoints[p].lastResidualState[0] = r.state_state;
     }
@@ -150,6 +171,7 @@ int DSOBundleAdjustment::addPoint(float x, float y, double idepth, int host, con
     P.hasDepthPrior = hasDepthPrior;
     const int p = (int)mPoints.size();
     mPoints.push_back(P);
+    mPointRes.resize(mPoints.size());
     for (int t = 0; t < (int)mFrames.size(); t++) {                  // BA.cpp:398-400
         if (t == host) continue;
         const SE3 ht = mFrames[t].worldToCam_evalPT * mFrames[host].worldToCam_evalPT.inverse();
@@ -165,6 +187,7 @@ int DSOBundleAdjustment::addPoint(float x, float y, double idepth, int host, con
         const bool inside = Ku >= 0 && Kv >= 0 && Ku < mPrm.w && Kv < mPrm.h;
         r.state_state = inside ? DSORES_IN : DSORES_OOB;
         mResiduals.push_back(r);
+        mPointRes[p].push_back((int)mResiduals.size() - 1);
         const int nf = (int)mFrames.size();
         if (t == nf - 1) { mPoints[p].lastResidual[0] = (int)mResiduals.size() - 1; mPoints[p].lastResidualState[0] = r.state_state; }        // BA.cpp:374-378
         else if (nf >= 2 && t == nf - 2) { mPoints[p].lastResidual[1] = (int)mResiduals.size() - 1; mPoints[p].lastResidualState[1] = r.state_state; }
@@ -606,6 +629,12 @@ bool DSOBundleAdjustment::runEpilogue(double lastEnergy[3]) {                // 
     fb.setEvalPT(fb.PRE_worldToCam, nz, sc);
     computeAdjoints();
     computeDelta();
+    {   // getB0 follows state_zero (DSOFrame.h:197-199): the device's copy of the re-anchored frame's b0 is refreshed before the closing pass
+        std::vector<float> b0(mFrames.size());
+        for (size_t i = 0; i < mFrames.size(); i++) b0[i] = mFrames[i].getB0((float)mScaleLightB);
+        const int rcb = getenv("CMLHOST_NO_B0_REFRESH") ? 0 : cmlhip_ba_set_frame_b0(mCtx, b0.data());      // (development switch: the stale value)
+        if (rcb) return fail("cmlhip_ba_set_frame_b0", rcb);
+    }
     std::vector<double> idp;
     std::vector<float> pacc;
     if (!linearizeAll(true, lastEnergy, &idp, &pacc)) return false;           // :896 (+ the inverse depths and point accumulators, same readback)
@@ -686,21 +715,22 @@ void DSOBundleAdjustment::removePointsWithoutResidual() {                     //
     for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && nres[p] == 0) mPoints[p].alive = false;
 }
 
-void DSOBundleAdjustment::removePoint(int p, bool marginalize) {              // DSOContext.h:94-111,204-215
+void DSOBundleAdjustment::removePoint(int p, bool marginalize, bool sweep) {  // DSOContext.h:94-111,204-215
     if (!mPoints[p].alive) return;
     std::vector<char> seen(mFrames.size(), 0);
-    for (auto& r : mResiduals) {
-        if (!r.alive || r.point != p) continue;
+    for (int ri : mPointRes[p]) {
+        DSOResidual& r = mResiduals[ri];
+        if (!r.alive) continue;
         if (marginalize && !seen[r.target]) { seen[r.target] = 1; mFrames[r.target].numMarginalized++; }
         r.alive = false;
         mFrames[r.target].numResidualsOut++;
     }
     mPoints[p].alive = false;
-    removePointsWithoutResidual();
+    if (sweep) removePointsWithoutResidual();        // (callers that remove many points sweep once behind their loop: the end state is the same)
 }
 
 void DSOBundleAdjustment::removeFrame(int f) {                                // DSOContext.h:154-174
-    for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && mPoints[p].host == f) removePoint(p, false);
+    for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && mPoints[p].host == f) removePoint(p, false, false);
     for (auto& r : mResiduals) if (r.alive && r.target == f) { r.alive = false; mFrames[f].numResidualsOut++; }
     removePointsWithoutResidual();
     mFrames.erase(mFrames.begin() + f);
@@ -713,8 +743,9 @@ bool DSOBundleAdjustment::isOOB(int p, const std::vector<int>& toMarg) const {  
     const int setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4;
     const DSOPoint& P = mPoints[p];
     int visInToMarg = 0, numIn = 0;
-    for (const auto& r : mResiduals) {
-        if (!r.alive || r.point != p || r.state_state != DSORES_IN) continue;
+    for (int ri : mPointRes[p]) {
+        const DSOResidual& r = mResiduals[ri];
+        if (!r.alive || r.state_state != DSORES_IN) continue;
         numIn++;
         for (int k : toMarg) if (r.target == k) visInToMarg++;
     }
@@ -726,7 +757,11 @@ bool DSOBundleAdjustment::isOOB(int p, const std::vector<int>& toMarg) const {  
     return false;
 }
 
-void DSOBundleAdjustment::flagFramesForMarginalization(int numImmaturePerFrame) {   // BA.cpp:603-716
+void DSOBundleAdjustment::flagFramesForMarginalization(int numImmaturePerFrame) {
+    flagFramesForMarginalization(std::vector<int>(mFrames.size(), numImmaturePerFrame));
+}
+
+void DSOBundleAdjustment::flagFramesForMarginalization(const std::vector<int>& immaturePerFrame) {   // BA.cpp:603-716
     const int N = (int)mFrames.size();
     int flagged = 0;
     double sc[4];
@@ -735,7 +770,7 @@ void DSOBundleAdjustment::flagFramesForMarginalization(int numImmaturePerFrame) 
     for (const auto& r : mResiduals) if (r.alive) nresOfFrame[r.target]++;
     for (int i = 0; i < N; i++) {
         DSOFrame& f = mFrames[i];
-        const double in = nresOfFrame[i] + numImmaturePerFrame;
+        const double in = nresOfFrame[i] + (i < (int)immaturePerFrame.size() ? immaturePerFrame[i] : 0);
         const double out = f.numMarginalized + f.numResidualsOut;
         double a, b;
         mFrames.back().aff_g2l().to(f.aff_g2l(), a, b);                         // frameBack exposure -> frame exposure
@@ -823,7 +858,8 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
         if (mPoints[p].idepth_hessian > mMinIdepthHMarg) mPoints[p].toMarginalize = true;       // :2316-2325
         else toDrop.push_back(p);
     }
-    for (int p : toDrop) { removePoint(p, false); mOutliers.push_back(p); }    // :2344-2348
+    for (int p : toDrop) { removePoint(p, false, false); mOutliers.push_back(p); }    // :2344-2348
+    removePointsWithoutResidual();
     return true;
 }
 
@@ -843,8 +879,9 @@ bool DSOBundleAdjustment::marginalizePointsF() {                              //
     }
     for (int p : pts) {                                                        // :2490-2497
         mPoints[p].marginalized = true; mPoints[p].toMarginalize = false;
-        removePoint(p, true);
+        removePoint(p, true, false);
     }
+    removePointsWithoutResidual();
     const double setting_margWeightFac = 0.5 * 0.5;                            // :2502
     for (size_t i = 0; i < M.size(); i++) mMarginalizedHessian[i] += setting_margWeightFac * (M[i] - Msc[i]);
     for (int i = 0; i < n; i++) mMarginalizedB[i] += setting_margWeightFac * (Mb[i] - Mbsc[i]);

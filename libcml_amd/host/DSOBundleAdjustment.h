@@ -107,6 +107,10 @@ public:
     void nullspaceBasis(std::vector<double>& U7n) const;                                         // orthonormal basis used by orthogonalize
     // ---- marginalisation (BA.h:34-46), once per keyframe after run()
     void flagFramesForMarginalization(int numImmaturePerFrame = 0);                              // BA.cpp:603-716
+    // the same with the immature count of EVERY frame (frame->getReferenceGroupMapPoints(immatureGroup).size(), BA.cpp:617), and — as the
+    // reference calls it from addNewFrame BEFORE the frame is added (BA.cpp:428) — the exposure the new frame's affine test runs against
+    // is that of the newest frame of the window (getFrames().back(), :614)
+    void flagFramesForMarginalization(const std::vector<int>& immaturePerFrame);
     bool tryMarginalize();                                                                       // BA.cpp:2240-2363 (device: relinearize + fixLinearization)
     bool marginalizePointsF();                                                                   // BA.cpp:2466-2513 (device: MARGINALIZED accumulation)
     std::vector<int> marginalizeFrames();                                                        // BA.cpp:718-742; returns the removed DSOFrame ids (before renumbering)
@@ -149,7 +153,8 @@ public:
 private:
     bool uploadWindow();
     bool isOOB(int p, const std::vector<int>& toMarg) const;                  // BA.cpp:2515-2554
-    void removePoint(int p, bool marginalize);                                // DSOContext.h:94-111
+    void removePoint(int p, bool marginalize, bool sweep = true);             // DSOContext.h:94-111 (sweep: removePointsWithoutResidual behind it, :218-229)
+    void compactDead();                                                       // drops dead points / residuals from the lists and renumbers (the reference's sets simply lose them)
     void removeFrame(int f);                                                  // DSOContext.h:154-174
     void removePointsWithoutResidual();
     void fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double>& prior, std::vector<double>& dprior, double cdelta[4], double cprior[4]);
@@ -169,6 +174,7 @@ private:
     std::vector<DSOFrame> mFrames;
     std::vector<DSOPoint> mPoints;
     std::vector<DSOResidual> mResiduals;
+    std::vector<std::vector<int>> mPointRes;        // residual indices of every point (DSOPoint::residuals, DSOPoint.h:87), dead ones included until compactDead
     std::vector<int> mActive;                       // indices of residuals uploaded (alive), device order
     std::vector<int> mActivePoints, mPointSlot;     // device point order <-> mPoints
     std::vector<int> mOutliers;

@@ -30,6 +30,12 @@ int DSOTracer::addImmaturePoint(float x, float y, int host_frame_id, const float
     return (int)mPoints.size() - 1;
 }
 
+void DSOTracer::compact() {
+    std::vector<ImmaturePoint> keep;
+    for (auto& P : mPoints) if (P.alive && !P.activated) keep.push_back(P);
+    mPoints.swap(keep);
+}
+
 static int indexOf(const std::vector<int>& ids, int id) {
     for (size_t i = 0; i < ids.size(); i++) if (ids[i] == id) return (int)i;
     return -1;

@@ -42,6 +42,7 @@ public:
     bool activatePoints(const std::vector<int>& frame_ids, const std::vector<uint64_t>& image_ids, const double K[4], int w, int h,
                         const std::vector<cmlhip_activation_pair>& pairs, std::vector<int>& activated, const SpacingPolicy& spacing = nullptr);
 
+    void compact();                             // forget the points that were activated or removed (getMap().removeMapPoint in the reference): indices change
     std::vector<ImmaturePoint>& points() { return mPoints; }
     const std::string& lastError() const { return mError; }
     int numSkippedBecauseStatus = 0, numSkippedBecausePixelInterval = 0, numSkippedBecauseQuality = 0, numSkippedBecauseDepth = 0,

@@ -54,6 +54,13 @@ void cmlhost_ba_set_frame_energy_th(void* h, int f, double th) { static_cast<DSO
 int cmlhost_ba_add_point(void* h, float x, float y, double idepth, int host, const float colors[8], const float weights[8], int prior) {
     return static_cast<DSOBundleAdjustment*>(h)->addPoint(x, y, idepth, host, colors, weights, prior != 0);
 }
+// n points at once (addPoints, BA.cpp:382-415): xy n x 2, colors / weights n x 8; returns the index of the first
+int cmlhost_ba_add_points(void* h, int n, const float* xy, const double* idepth, const int* host, const float* colors, const float* weights, int prior) {
+    DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);
+    const int first = (int)b->getPoints().size();
+    for (int i = 0; i < n; i++) b->addPoint(xy[2 * i], xy[2 * i + 1], idepth[i], host[i], colors + 8 * (size_t)i, weights + 8 * (size_t)i, prior != 0);
+    return first;
+}
 int cmlhost_ba_run(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->run(updatePointsOnly != 0) ? 1 : 0; }
 int cmlhost_ba_run_host_loop(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->runHostLoop(updatePointsOnly != 0) ? 1 : 0; }
 int cmlhost_ba_run_resident(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->runResident(updatePointsOnly != 0) ? 1 : 0; }
@@ -63,6 +70,53 @@ int cmlhost_ba_end_resident(void* h, double* lastEnergy) { return static_cast<DS
 // ---- marginalisation (BA.h:34-46)
 void cmlhost_ba_flag_frame(void* h, int f, int flag) { static_cast<DSOBundleAdjustment*>(h)->getFrames()[f].flaggedForMarginalization = flag != 0; }
 void cmlhost_ba_flag_frames_for_marginalization(void* h, int immature) { static_cast<DSOBundleAdjustment*>(h)->flagFramesForMarginalization(immature); }
+void cmlhost_ba_flag_frames_for_marginalization_v(void* h, int n, const int* immaturePerFrame) {
+    static_cast<DSOBundleAdjustment*>(h)->flagFramesForMarginalization(std::vector<int>(immaturePerFrame, immaturePerFrame + n));
+}
+// ---- the mirror's whole state as flat records (sequence checker: an oracle window is built from exactly what the mirror holds)
+struct cmlhost_ba_frame_rec {
+    double eval_q[4], eval_t[3], pre_q[4], pre_t[3], state[10], state_zero[10], prior_zero[10], ab_exposure, frameEnergyTH;
+    uint64_t image_id;
+    int id, keyid, flagged, numMarginalized, numResidualsOut, pad;
+};
+struct cmlhost_ba_point_rec {
+    double idepth;
+    float x, y, colors[8], weights[8], idepth_zero, priorF, idepth_hessian, pad0;
+    int host, hasDepthPrior, numGoodResiduals, lastResidual[2], lastResidualState[2], toMarginalize, marginalized, alive;
+};
+struct cmlhost_ba_residual_rec {
+    double state_energy, state_NewEnergy;
+    int point, target, state_state, state_NewState, isLinearized, good, alive, pad;
+};
+int cmlhost_ba_export(void* h, cmlhost_ba_frame_rec* fr, cmlhost_ba_point_rec* pt, cmlhost_ba_residual_rec* rs) {
+    DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);
+    if (fr) for (size_t i = 0; i < b->getFrames().size(); i++) {
+        const DSOFrame& F = b->getFrames()[i]; cmlhost_ba_frame_rec& o = fr[i];
+        std::memset(&o, 0, sizeof o);
+        std::memcpy(o.eval_q, F.worldToCam_evalPT.q, sizeof o.eval_q); std::memcpy(o.eval_t, F.worldToCam_evalPT.t, sizeof o.eval_t);
+        std::memcpy(o.pre_q, F.PRE_worldToCam.q, sizeof o.pre_q); std::memcpy(o.pre_t, F.PRE_worldToCam.t, sizeof o.pre_t);
+        std::memcpy(o.state, F.state, sizeof o.state); std::memcpy(o.state_zero, F.state_zero, sizeof o.state_zero);
+        std::memcpy(o.prior_zero, F.prior_zero, sizeof o.prior_zero);
+        o.ab_exposure = F.ab_exposure; o.frameEnergyTH = F.frameEnergyTH; o.image_id = F.image_id; o.id = F.id; o.keyid = F.keyid;
+        o.flagged = F.flaggedForMarginalization; o.numMarginalized = F.numMarginalized; o.numResidualsOut = F.numResidualsOut;
+    }
+    if (pt) for (size_t i = 0; i < b->getPoints().size(); i++) {
+        const DSOPoint& P = b->getPoints()[i]; cmlhost_ba_point_rec& o = pt[i];
+        std::memset(&o, 0, sizeof o);
+        o.idepth = P.idepth; o.x = P.x; o.y = P.y; std::memcpy(o.colors, P.colors, sizeof o.colors); std::memcpy(o.weights, P.weights, sizeof o.weights);
+        o.idepth_zero = P.idepth_zero; o.priorF = P.priorF; o.idepth_hessian = P.idepth_hessian; o.host = P.host; o.hasDepthPrior = P.hasDepthPrior;
+        o.numGoodResiduals = P.numGoodResiduals;
+        for (int q = 0; q < 2; q++) { o.lastResidual[q] = P.lastResidual[q]; o.lastResidualState[q] = P.lastResidualState[q]; }
+        o.toMarginalize = P.toMarginalize; o.marginalized = P.marginalized; o.alive = P.alive;
+    }
+    if (rs) for (size_t i = 0; i < b->getResiduals().size(); i++) {
+        const DSOResidual& R = b->getResiduals()[i]; cmlhost_ba_residual_rec& o = rs[i];
+        std::memset(&o, 0, sizeof o);
+        o.state_energy = R.state_energy; o.state_NewEnergy = R.state_NewEnergy; o.point = R.point; o.target = R.target; o.state_state = R.state_state;
+        o.state_NewState = R.state_NewState; o.isLinearized = R.isLinearized; o.good = R.isActiveAndIsGoodNEW; o.alive = R.alive;
+    }
+    return (int)sizeof(cmlhost_ba_frame_rec) | ((int)sizeof(cmlhost_ba_point_rec) << 10) | ((int)sizeof(cmlhost_ba_residual_rec) << 20);
+}
 int cmlhost_ba_try_marginalize(void* h) { return static_cast<DSOBundleAdjustment*>(h)->tryMarginalize() ? 1 : 0; }
 int cmlhost_ba_marginalize_points(void* h) { return static_cast<DSOBundleAdjustment*>(h)->marginalizePointsF() ? 1 : 0; }
 int cmlhost_ba_marginalize_frames(void* h, int* removed, int cap) {
@@ -233,6 +287,18 @@ void* cmlhost_tracer_create(cmlhip_ctx* ctx) { return new cml_amd::DSOTracer(ctx
 void cmlhost_tracer_destroy(void* h) { delete static_cast<cml_amd::DSOTracer*>(h); }
 int cmlhost_tracer_add_point(void* h, float x, float y, int host_frame_id, const float gray[8], const float dpatch[24], const double gradH[4], float type) {
     return static_cast<cml_amd::DSOTracer*>(h)->addImmaturePoint(x, y, host_frame_id, gray, dpatch, gradH, type);
+}
+// n points of one keyframe at once (makeNewTraces): xy n x 2, gray n x 8, dpatch n x 24, gradH n x 4; returns the index of the first
+int cmlhost_tracer_add_points(void* h, int n, const float* xy, int host_frame_id, const float* gray, const float* dpatch, const double* gradH) {
+    cml_amd::DSOTracer* t = static_cast<cml_amd::DSOTracer*>(h);
+    const int first = (int)t->points().size();
+    for (int i = 0; i < n; i++) t->addImmaturePoint(xy[2 * i], xy[2 * i + 1], host_frame_id, gray + 8 * (size_t)i, dpatch + 24 * (size_t)i, gradH + 4 * (size_t)i, 1.f);
+    return first;
+}
+void cmlhost_tracer_compact(void* h) { static_cast<cml_amd::DSOTracer*>(h)->compact(); }
+void cmlhost_tracer_get_frame_ids(void* h, int* out) {
+    auto& P = static_cast<cml_amd::DSOTracer*>(h)->points();
+    for (size_t i = 0; i < P.size(); i++) out[i] = P[i].frame_id;
 }
 int cmlhost_tracer_trace(void* h, uint64_t image_id, int traced_frame_id, int n_frames, const int* frame_ids, const cmlhip_trace_pair* pairs, int counts[6]) {
     std::vector<int> ids(frame_ids, frame_ids + n_frames);

@@ -1,0 +1,444 @@
+"""A sequence shard, end to end, through the host mirror — the unit north_star fans out across GPUs.
+
+Order of calls = the reference's direct pipeline:
+  per frame     Hybrid::trackWithDso (slam/modslam/Hybrid.cpp:431-458): DSOTracker::trackWithMotionModel (DSOTracker.h:238-383)
+  non-keyframe  Hybrid::directMakeNonKeyFrame (direct/Mapping.cpp:43-45): DSOTracer::traceNewCoarse
+  keyframe      Hybrid::directMap (direct/Mapping.cpp:47-134): traceNewCoarse -> addNewFrame (which flags frames for marginalisation first,
+                BA.cpp:428) -> activatePoints -> addPoints -> run -> makeCoarseDepthL0(getGoodPointsForTracking) -> tryMarginalize ->
+                [outliers dropped] -> marginalizePointsF -> makeNewTraces -> marginalizeFrames -> free / makeUnactive of the marginalised
+                frames (here: cmlhip_pyramid_drop, the image id goes back to the pool and is handed to a later frame).
+
+What stays outside (SURVEY §2 OUT OF SCOPE, stood in for by seeded synthetic inputs): the map graph, the PixelSelector (best gradient
+of 12 random candidates per pick), the DistanceMap spacing of activatePoints (none), the coarse initializer's bootstrap (frame 0 is
+registered with noisy true inverse depths, hasDepthPrior as the initializer's points have), the motion-model hypothesis list (a short
+constant-velocity list).  Product-side plumbing for tests and bench.py: it talks to the C++ host mirror (libcmlhost.so) and the C ABI
+only — no oracle.  A checker can subscribe to every stage (`observer`) and is handed that stage's inputs and outputs."""
+import time
+
+import numpy as np
+
+from . import abi, host, synth
+
+STAR8 = synth.STAR8
+
+
+class Sequence:
+    pass
+
+
+def select_pixels(gray, n, rng, margin=10, taken=None):
+    """stand-in for Features::PixelSelector (out of scope): n distinct integer pixels, each the best-gradient one of 12 random candidates"""
+    h, w = gray.shape
+    out = []
+    seen = set() if taken is None else taken
+    tries = 0
+    while len(out) < n and tries < 40 * n:
+        tries += 1
+        cx = rng.integers(margin, w - margin, size=12); cy = rng.integers(margin, h - margin, size=12)
+        mag = np.abs(gray[cy, cx + 1] - gray[cy, cx - 1]) + np.abs(gray[cy + 1, cx] - gray[cy - 1, cx])
+        b = int(np.argmax(mag))
+        key = (int(cx[b]), int(cy[b]))
+        if key in seen or mag[b] < 4.0:
+            continue
+        seen.add(key)
+        out.append(key)
+    return np.array(out, np.int32).reshape(-1, 2)
+
+
+def make_sequence(n_frames=48, seed=0x5EED, config="B", shard=0, kf_gap=(3, 5), n_bootstrap=1500):
+    """Seeded synthetic sequence of the BASELINE image shape: one textured plane (the scene of synth.make_window's config B: band-limited
+    edges, value noise with fine octaves) seen from a camera that translates mostly sideways (≈ 12 px of parallax per frame at the plane
+    distance) with a little forward motion and smooth rotation / exposure drift.  Keyframes every kf_gap[0]..kf_gap[1] frames (seeded)."""
+    _N, _P, w, h, levels, fx, fy, cx, cy = synth.CONFIGS[config] if isinstance(config, str) else config
+    rng = np.random.default_rng(seed + 7919 * shard)
+    S = Sequence()
+    S.w, S.h, S.levels, S.K, S.n_frames = w, h, levels, (fx, fy, cx, cy), n_frames
+    n = np.array([0.12, -0.08, 1.0]); n /= np.linalg.norm(n)
+    d = 9.0
+    tex = synth.Texture(rng, scale=0.07 * fx / (d * 32.0), edge_width=4.0 * d / fx, octave_gain=0.7)
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    S.R_true, S.t_true, S.aff_true = [], [], []
+    for k in range(n_frames):
+        c = np.array([0.15 * k + 0.02 * np.sin(0.31 * k + ph[0]), 0.03 * np.sin(0.23 * k + ph[1]), 0.04 * k + 0.02 * np.sin(0.17 * k + ph[2])])
+        wv = np.deg2rad(np.array([0.4 * np.sin(0.19 * k + ph[3]), 0.6 * np.sin(0.13 * k + ph[4]), 0.3 * np.sin(0.29 * k + ph[5])]))
+        Rk = synth.so3_exp(wv)
+        S.R_true.append(Rk); S.t_true.append(-Rk @ c)
+        S.aff_true.append((0.03 * np.sin(0.11 * k + ph[0]), 3.0 * np.sin(0.07 * k + ph[1])))
+
+    def _render(k):
+        img, s = synth.render(tex, S.K, S.R_true[k], S.t_true[k], w, h, n, d)
+        a, b = S.aff_true[k]
+        return (np.exp(a) * img + b).astype(np.float32), (s if k == 0 else None)
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:
+        out = list(ex.map(_render, range(n_frames)))
+    S.gray = [o[0] for o in out]
+    depth0 = out[0][1]
+    # keyframe schedule: frame 0 (bootstrap), then every 3-5 frames
+    S.keyframes = [0]
+    k = 0
+    while True:
+        k += int(rng.integers(kf_gap[0], kf_gap[1] + 1))
+        if k >= n_frames:
+            break
+        S.keyframes.append(k)
+    # bootstrap points of frame 0 (what the coarse initializer hands over): pixels + inverse depths accurate to 2 %
+    px = select_pixels(S.gray[0], n_bootstrap, rng)
+    idp = 1.0 / depth0[px[:, 1], px[:, 0]]
+    S.boot_px = px
+    S.boot_idepth = idp * (1 + rng.normal(0, 0.02, len(px)))
+    S.seed = seed
+    return S
+
+
+def _patches(grad0, px):
+    """MapPoint::getGrayPatch / getDerivativePatch at the pattern pixels (integer-pixel lookups, MapObject.h:392-412) and gradH
+    (DSOTracer.cpp:516-521) of n integer pixels at once: gray (n, 8), dpatch (n, 24), gradH (n, 4)"""
+    px = np.asarray(px, np.int64).reshape(-1, 2)
+    xs = px[:, 0:1] + STAR8[None, :, 0]; ys = px[:, 1:2] + STAR8[None, :, 1]
+    t = grad0[ys, xs]                                                 # (n, 8, 3)
+    gray = np.ascontiguousarray(t[:, :, 0], np.float32)
+    dp = np.ascontiguousarray(t.reshape(len(px), 24), np.float32)
+    g = t[:, :, 1:3].astype(np.float64)
+    G = np.zeros((len(px), 4))
+    for k in range(8):                                                # summed in pattern order, like the reference's loop
+        G[:, 0] += g[:, k, 0] * g[:, k, 0]; G[:, 1] += g[:, k, 0] * g[:, k, 1]; G[:, 2] += g[:, k, 1] * g[:, k, 0]; G[:, 3] += g[:, k, 1] * g[:, k, 1]
+    return gray, dp, G
+
+
+def _weights(dpatch):
+    """BA::addPoints gradient weights sqrt(c / (c + |grad|^2)), c = 50^2 (BA.cpp:405-411), (n, 24) -> (n, 8)"""
+    d = np.asarray(dpatch, np.float32).reshape(-1, 8, 3).astype(np.float64)
+    return np.sqrt(2500.0 / (2500.0 + (d[:, :, 1] * d[:, :, 1] + d[:, :, 2] * d[:, :, 2]))).astype(np.float32)
+
+
+def _rel(Rh, th, Rt, tt):
+    """host -> target: Camera::to (src/cml/map/Camera.h)"""
+    R = Rt @ Rh.T
+    return R, tt - R @ th
+
+
+class DirectPipeline:
+    """Drives cml_amd::DSOTracker / DSOTracer / DSOBundleAdjustment (host mirror over the C ABI) in the reference's order on ONE context.
+    `observer(stage, info)` — when given — is called after every stage with that stage's inputs and outputs (a checker replays them)."""
+
+    def __init__(self, ctx, K, w, h, levels, n_immature=500, seed=1, observer=None, max_frames=6, id_pool=16):
+        self.ctx, self.K, self.w, self.h, self.levels = ctx, tuple(K), w, h, levels
+        self.ba = host.HostBA(ctx); self.ba.set_calibration(*K, w, h)
+        self.ba.set_param("disableMarginalization", 0)               # the marginalisation prior is live (BA.cpp:1389-1401)
+        self.ba.set_param("maxFrames", max_frames)
+        self.trk = host.HostTracker(ctx); self.trk.set_calibration(*K)
+        self.trc = host.HostTracer(ctx)
+        self.rng = np.random.default_rng(seed)
+        self.n_immature = n_immature
+        self.obs = observer
+        self.free_ids = list(range(1, id_pool + 1))                  # image ids: taken smallest first, recycled through cmlhip_pyramid_drop
+        self.kfs = []                                                # window keyframes in DSOFrame::id order: dict(fid, image_id, gray, grad0, taken)
+        self.history = []                                            # world->cam (R, t) of the tracked frames (motion model)
+        self.last_exposure = (0.0, 0.0)
+        self.last_coarse_rmse = 100.0                                # DSOTracker.h:470
+        self.n_fid = 0
+        self.times = {}                                              # stage -> list of seconds
+        self.tprm = abi.default_tracer_params()
+        self.stats = {"frames": 0, "keyframes": 0, "tracking_lost": 0, "ids_recycled": 0, "max_window": 0, "marginalized_frames": 0}
+
+    def close(self):
+        self.trc.close(); self.trk.close(); self.ba.close()
+
+    # ------------------------------------------------------------------ helpers
+    def _t(self, stage, t0):
+        self.ctx.sync()
+        self.times.setdefault(stage, []).append(time.perf_counter() - t0)
+
+    def _emit(self, stage, **info):
+        if self.obs is not None:
+            self.obs(stage, info)
+
+    def _take_id(self):
+        if not self.free_ids:
+            raise RuntimeError("image id pool exhausted")
+        return self.free_ids.pop(0)
+
+    def _drop(self, image_id):
+        self.ctx.pyramid_drop(image_id)
+        self.free_ids.append(image_id); self.free_ids.sort()
+        self.stats["ids_recycled"] += 1
+
+    def kf_poses(self):
+        """current (R, t, a, b) of the window's keyframes = frame->getCamera() / getExposure() (PRE_worldToCam, aff_g2l)"""
+        out = []
+        for i in range(len(self.kfs)):
+            f = self.ba.frame(i)
+            out.append((f["R"].copy(), f["t"].copy(), float(f["ab"][0]), float(f["ab"][1])))
+        return out
+
+    def _trace_pairs(self, poses, Rn, tn, an, bn):
+        fx, fy, cx, cy = self.K
+        Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]]); Ki = np.linalg.inv(Km)
+        pr = np.zeros(len(poses), abi.TRACE_PAIR_DTYPE)
+        for hh, (Rh, th, ah, bh) in enumerate(poses):
+            R, t = _rel(Rh, th, Rn, tn)
+            pr["KRKi"][hh] = ((Km @ R) @ Ki).ravel(); pr["Kt"][hh] = Km @ t
+            a = np.exp(an - ah)                                       # Exposure::to with exposure times 1 (Exposure.h:119-123)
+            pr["aff_a"][hh] = a; pr["aff_b"][hh] = bn - a * bh
+        return pr
+
+    def _activation_pairs(self, poses):
+        N = len(poses)
+        pr = np.zeros(N * N, abi.ACTIVATION_PAIR_DTYPE)
+        for hh, (Rh, th, ah, bh) in enumerate(poses):
+            for tt_, (Rt, tt, at, bt) in enumerate(poses):
+                R, t = _rel(Rh, th, Rt, tt)
+                a = np.exp(at - ah)
+                pr["R"][hh * N + tt_] = R.ravel(); pr["t"][hh * N + tt_] = t; pr["aff_a"][hh * N + tt_] = a; pr["aff_b"][hh * N + tt_] = bt - a * bh
+        return pr
+
+    def _immature_counts(self):
+        pts, alive, act, _ = self.trc.points()
+        fids = self.trc.frame_ids()
+        live = (alive == 1) & (act == 0)
+        return [int((live & (fids == kf["fid"])).sum()) for kf in self.kfs]
+
+    def _make_new_traces(self, kf):
+        """DSOTracer::makeNewTraces (DSOTracer.cpp:496-541) with the stand-in pixel selector"""
+        self.trc.compact()                                            # activated / removed points leave the list (removeMapPoint): indices change here only
+        px = select_pixels(kf["gray"], self.n_immature, self.rng, taken=kf["taken"])
+        g, dp, G = _patches(kf["grad0"], px)
+        self.trc.add_points(px.astype(np.float32), kf["fid"], g, dp, G)
+        return px
+
+    def _coarse_depth(self, kf_index):
+        """host half of makeCoarseDepthL0 (DSOTracker.cpp:521-553) over getGoodPointsForTracking (BA.h:76-85)"""
+        fr, pt, rs = self.ba.export()
+        good = np.flatnonzero((pt["alive"] == 1) & (pt["lastResidual"][:, 0] >= 0) & (pt["lastResidualState"][:, 0] == 0))
+        poses = self.kf_poses()
+        Rn, tn = poses[kf_index][0], poses[kf_index][1]
+        fx, fy, cx, cy = self.K
+        out = np.zeros((len(good), 4))
+        hosts = pt["host"][good]
+        for hh in np.unique(hosts):
+            m = hosts == hh
+            i = good[m]
+            R, t = _rel(poses[hh][0], poses[hh][1], Rn, tn)
+            idp = pt["idepth"][i].astype(np.float64)
+            ray = np.stack([(pt["x"][i].astype(np.float64) - cx) * (1.0 / fx), (pt["y"][i].astype(np.float64) - cy) * (1.0 / fy), np.ones(len(i))], 1)
+            p = ray @ R.T + idp[:, None] * t[None, :]
+            unc = 1.0 / (pt["idepth_hessian"][i].astype(np.float64) + 0.01)        # DSOPoint::updatePointUncertainty (DSOPoint.h:107-117)
+            wgt = np.sqrt((1e-3 / (unc + 1e-12)).astype(np.float32)).astype(np.float32)
+            out[m, 0] = (p[:, 0] / p[:, 2]) * fx + cx; out[m, 1] = (p[:, 1] / p[:, 2]) * fy + cy; out[m, 2] = (1.0 / p[:, 2]) * idp; out[m, 3] = wgt
+        return out
+
+    # ------------------------------------------------------------------ stages
+    def bootstrap(self, gray, R, t, px, idepth):
+        """Frame 0 as the first keyframe with the points an initializer would hand over (hasDepthPrior, BA.cpp:1182)."""
+        t0 = time.perf_counter()
+        iid = self._take_id()
+        self.ctx.pyramid_build(iid, gray, self.levels)
+        grad0 = self.ctx.pyramid_get(iid, 0)
+        kf = {"fid": self.n_fid, "image_id": iid, "gray": gray, "grad0": grad0, "taken": set()}
+        self.n_fid += 1
+        self.ba.add_frame(iid, R, t, 0.0, 0.0, 1.0)
+        self.kfs.append(kf)
+        kf["taken"].update((int(x), int(y)) for x, y in px)
+        g, dp, _G = _patches(grad0, px)
+        self.ba.add_points(px.astype(np.float32), idepth, np.zeros(len(px), np.int32), g, _weights(dp), prior=True)
+        # tracking reference lists straight from the bootstrap points (uniform weights: no Hessian yet)
+        pts = np.stack([px[:, 0].astype(np.float64), px[:, 1].astype(np.float64), np.asarray(idepth, np.float64), np.ones(len(px))], 1)
+        nout = self.trk.make_coarse_depth(iid, self.levels, pts)
+        self._make_new_traces(kf)
+        self.ref = 0
+        self.history.append((np.asarray(R, float).copy(), np.asarray(t, float).copy()))
+        self.last_exposure = (0.0, 0.0)
+        self.stats["frames"] += 1; self.stats["keyframes"] += 1
+        self._t("bootstrap", t0)
+        self._emit("bootstrap", image_id=iid, gray=gray, pts=pts, n_lists=nout)
+        return nout
+
+    def _hypotheses(self):
+        """a short Map::multiConstantVelocityMotionModel stand-in (world->cam candidates): constant velocity, no motion, half, double, and the
+        constant-velocity pose with six small extra rotations"""
+        R1, t1 = self.history[-1]
+        if len(self.history) < 2:
+            return [(R1, t1)]
+        R0, t0 = self.history[-2]
+        dR = R1 @ R0.T; dt = t1 - dR @ t0                           # last motion: prev -> last (world->cam composition)
+        w = _so3_log(dR)
+        out = [(dR @ R1, dR @ t1 + dt), (R1, t1)]
+        Rh = synth.so3_exp(0.5 * w); out.append((Rh @ R1, Rh @ t1 + 0.5 * dt))
+        R2 = dR @ dR; out.append((R2 @ R1, R2 @ t1 + (dR @ dt + dt)))
+        Rc, tc = out[0]
+        for ax in range(3):
+            for sg in (1.0, -1.0):
+                e = np.zeros(3); e[ax] = sg * 0.01
+                Re = synth.so3_exp(e)
+                out.append((Re @ Rc, Re @ tc))
+        return out
+
+    def track(self, gray):
+        """pyramid of the new frame + trackWithMotionModel against the newest keyframe.  Returns (image_id, R, t, a, b, ok)."""
+        t0 = time.perf_counter()
+        iid = self._take_id()
+        self.ctx.pyramid_build(iid, gray, self.levels)
+        self._t("pyramid_build", t0)
+        t0 = time.perf_counter()
+        ref = self.kfs[self.ref]
+        Rr, tr, ar, br = self.kf_poses()[self.ref]
+        hyps_w = self._hypotheses()
+        hyps = [_rel(Rr, tr, Rw, tw) for Rw, tw in hyps_w]           # reference->getCamera().to(camera)
+        ref_exp = [ar, br, 1.0]; init_exp = [self.last_exposure[0], self.last_exposure[1], 1.0]
+        res = self.trk.track_with_motion_model(iid, self.levels, hyps, ref_exp, init_exp, batched=True)
+        self._t("trackWithMotionModel", t0)
+        ok = bool(res["haveOneGood"])
+        if ok:
+            Rn = res["R"] @ Rr; tn = res["R"] @ tr + res["t"]          # frame->setCamera(reference.compose(refToNew))
+            a, b = float(res["exposure"][0]), float(res["exposure"][1])
+        else:                                                         # tracking lost: keep the constant-velocity guess (the reference would relocalise)
+            Rn, tn = hyps_w[0]; a, b = self.last_exposure
+            self.stats["tracking_lost"] += 1
+        self._emit("track", image_id=iid, gray=gray, ref_image_id=ref["image_id"], hyps=hyps, ref_exp=ref_exp, init_exp=init_exp, result=res,
+                   last_coarse_rmse=self.last_coarse_rmse, levels=self.levels)
+        if ok:
+            self.last_coarse_rmse = float(res["lastCoarseRMSE"])
+        self.history.append((Rn.copy(), tn.copy())); self.last_exposure = (a, b)
+        self.stats["frames"] += 1
+        return iid, Rn, tn, a, b, ok
+
+    def trace(self, iid, Rn, tn, a, b, traced_fid):
+        """DSOTracer::traceNewCoarse(frame, ACTIVEKEYFRAME)"""
+        t0 = time.perf_counter()
+        poses = self.kf_poses()
+        pairs = self._trace_pairs(poses, Rn, tn, a, b)
+        fids = [kf["fid"] for kf in self.kfs]
+        before = self.trc.points() if self.obs is not None else None
+        counts = self.trc.trace_new_coarse(iid, traced_fid, fids, pairs)
+        self._t("traceNewCoarse", t0)
+        if self.obs is not None:
+            self._emit("trace", image_id=iid, pairs=pairs, frame_ids=fids, traced_fid=traced_fid, before=before, after=self.trc.points(), counts=counts,
+                       tracer_fids=[int(f) for f in self.trc.frame_ids()])
+        return counts
+
+    def non_keyframe(self, gray):
+        iid, Rn, tn, a, b, ok = self.track(gray)
+        self.trace(iid, Rn, tn, a, b, traced_fid=-1)
+        t0 = time.perf_counter()
+        self._drop(iid)                                               # CaptureImage::makeUnactive: the id is free for the next frame
+        self._t("pyramid_drop", t0)
+        return ok
+
+    def keyframe(self, gray):
+        """Hybrid::directMap (direct/Mapping.cpp:47-134)"""
+        ctx, ba = self.ctx, self.ba
+        iid, Rn, tn, a, b, ok = self.track(gray)
+        fid = self.n_fid; self.n_fid += 1
+        self.trace(iid, Rn, tn, a, b, traced_fid=fid)
+        # ---- addNewFrame: flagFramesForMarginalization first (BA.cpp:428), then the frame, the prior block, residuals of the old points
+        t0 = time.perf_counter()
+        counts = self._immature_counts()
+        exp0 = ba.export() if self.obs is not None else None
+        ba.flag_frames_for_marginalization_v(counts)
+        ba.add_frame(iid, Rn, tn, a, b, 1.0)
+        grad0 = ctx.pyramid_get(iid, 0)
+        kf = {"fid": fid, "image_id": iid, "gray": gray, "grad0": grad0, "taken": set()}
+        self.kfs.append(kf)
+        self._t("addNewFrame", t0)
+        if self.obs is not None:
+            self._emit("flag", immature=counts, before=exp0, after=ba.export())
+        # ---- activatePoints + addPoints
+        t0 = time.perf_counter()
+        poses = self.kf_poses()
+        apairs = self._activation_pairs(poses)
+        fids = [k_["fid"] for k_ in self.kfs]; iids = [k_["image_id"] for k_ in self.kfs]
+        before = self.trc.points() if self.obs is not None else None
+        activated = self.trc.activate_points(fids, iids, self.K, self.w, self.h, apairs)
+        pts, alive, act, idp = self.trc.points()
+        tfids = self.trc.frame_ids()
+        if len(activated):
+            ia = np.asarray(activated, np.int64)
+            hh = np.array([fids.index(int(f)) for f in tfids[ia]], np.int32)
+            for i, h_ in zip(ia, hh):
+                self.kfs[h_]["taken"].add((int(pts["x"][i]), int(pts["y"][i])))
+            ba.add_points(np.stack([pts["x"][ia], pts["y"][ia]], 1), idp[ia].astype(np.float64), hh, pts["gray"][ia], _weights(pts["dpatch"][ia]), prior=False)
+        self._t("activatePoints+addPoints", t0)
+        if self.obs is not None:
+            self._emit("activate", frame_ids=fids, image_ids=iids, pairs=apairs, before=before, after=(pts, alive, act, idp), activated=activated,
+                       tracer_fids=[int(f) for f in tfids], grads0=[k_["grad0"] for k_ in self.kfs])
+        # ---- run
+        exp0 = (ba.export(), ba.prior()) if self.obs is not None else None
+        t0 = time.perf_counter()
+        ok_run = ba.run()
+        self._t("run", t0)
+        if not ok_run:
+            raise RuntimeError("BA run failed: " + ba.last_error())
+        self.stats["max_window"] = max(self.stats["max_window"], len(self.kfs))
+        if self.obs is not None:
+            self._emit("run", before=exp0[0], prior=exp0[1], after=ba.export(), energies=ba.energies(64), iterations=ba.counts()["iterations"],
+                       grads0=[k_["grad0"] for k_ in self.kfs], outliers=ba.outliers().copy())
+        # ---- makeCoarseDepthL0 on the new keyframe
+        t0 = time.perf_counter()
+        cd = self._coarse_depth(len(self.kfs) - 1)
+        nout = self.trk.make_coarse_depth(iid, self.levels, cd)
+        self._t("makeCoarseDepthL0", t0)
+        self._emit("coarse", image_id=iid, gray=gray, pts=cd, n_lists=nout, levels=self.levels)
+        # ---- tryMarginalize, marginalizePointsF
+        exp0 = (ba.export(), ba.algebra()) if self.obs is not None else None
+        t0 = time.perf_counter()
+        if not ba.try_marginalize():
+            raise RuntimeError("tryMarginalize failed: " + ba.last_error())
+        self._t("tryMarginalize", t0)
+        if self.obs is not None:
+            self._emit("try_marginalize", before=exp0[0], algebra=exp0[1], after=ba.export(), grads0=[k_["grad0"] for k_ in self.kfs])
+        exp0 = (ba.export(), ba.prior(), ba.algebra()) if self.obs is not None else None
+        t0 = time.perf_counter()
+        if not ba.marginalize_points():
+            raise RuntimeError("marginalizePointsF failed: " + ba.last_error())
+        self._t("marginalizePointsF", t0)
+        if self.obs is not None:
+            self._emit("marginalize_points", before=exp0[0], prior_before=exp0[1], algebra=exp0[2], prior_after=ba.prior(), after=ba.export(),
+                       grads0=[k_["grad0"] for k_ in self.kfs])
+        # ---- makeNewTraces on the new keyframe
+        t0 = time.perf_counter()
+        self._make_new_traces(kf)
+        self._t("makeNewTraces", t0)
+        # ---- marginalizeFrames + release of their images
+        exp0 = (ba.export(), ba.prior(), ba.algebra()) if self.obs is not None else None
+        t0 = time.perf_counter()
+        removed = list(ba.marginalize_frames())
+        for idx in sorted(removed, reverse=True):
+            self._drop(self.kfs[idx]["image_id"])
+            del self.kfs[idx]
+        self._t("marginalizeFrames", t0)
+        self.stats["marginalized_frames"] += len(removed)
+        if self.obs is not None:
+            self._emit("marginalize_frames", before=exp0[0], prior_before=exp0[1], algebra=exp0[2], removed=removed, prior_after=ba.prior(), after=ba.export())
+        self.ref = len(self.kfs) - 1
+        # the tracked pose of the newest frame is now the optimised one (the next motion model starts from it)
+        f = ba.frame(self.ref)
+        self.history[-1] = (f["R"].copy(), f["t"].copy()); self.last_exposure = (float(f["ab"][0]), float(f["ab"][1]))
+        self.stats["keyframes"] += 1
+        return ok
+
+    def run(self, seq, n_frames=None):
+        """the whole shard: bootstrap on frame 0, then every frame in order"""
+        self.bootstrap(seq.gray[0], seq.R_true[0], seq.t_true[0], seq.boot_px, seq.boot_idepth)
+        kfset = set(seq.keyframes)
+        for k in range(1, n_frames or seq.n_frames):
+            if k in kfset:
+                self.keyframe(seq.gray[k])
+            else:
+                self.non_keyframe(seq.gray[k])
+        return self.stats
+
+    def timing_summary(self):
+        out = {}
+        for k, v in self.times.items():
+            a = np.array(v)
+            out[k] = {"calls": int(len(a)), "mean_ms": float(1e3 * a.mean()), "median_ms": float(1e3 * np.median(a)), "max_ms": float(1e3 * a.max())}
+        return out
+
+
+def _so3_log(R):
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    if th < 1e-9:
+        return np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    return th / (2 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])

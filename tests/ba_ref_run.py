@@ -72,6 +72,7 @@ def oracle_run(I, iterations=4, fixed_lambda=1e-5, th_opt=1.2, force_accept=True
     fb.w2c_eval = fb.PRE_w2c
     lib.orc_frame_set_state(C.byref(fb), O.ptr(nz, C.c_double), C.byref(I.scales))
     lib.orc_frame_set_state_zero(C.byref(fb), O.ptr(nz, C.c_double), C.byref(I.scales))
+    ob.w.contents.b0[N - 1] = float(np.float32(fb.state_zero[7] * np.float32(I.scales.b)))      # getB0 follows state_zero (DSOFrame.h:197-199)
     I.pairs = S.frame_pairs(I.frames, N); ob.set_pairs(I.pairs)
     I.adH, I.adT, I.adHTd, I.prior, I.dprior = S.adjoints_and_delta(I.frames, N, I.scales)
     r = ob.linearize(); ob.apply(1)        # linearizeAll(true)

@@ -1,0 +1,556 @@
+"""Lock-step oracle checker for a sequence shard (libcml_amd/sequence.py): subscribes to every stage of the direct pipeline and replays
+that stage FROM THE STATE THE PRODUCT HAD AT ITS ENTRY with oracle primitives (oracle/*.c) and independent Python restatements of the
+reference's host logic, then compares the stage's outputs.
+
+Why lock-step and not two free-running systems: two correct implementations of this pipeline diverge like two roundings of it (DESIGN §5:
+by the fourth Gauss-Newton iteration two builds of the SAME sources differ in 21 of 14 000 residual decisions) — after forty frames a
+free-running comparison measures chaos, not errors.  Re-anchoring the oracle on the product's state at every stage keeps every stage's
+comparison at that stage's own bar, over a LIVE window (N growing 2 -> 7, sliding, prior on, image ids recycled).
+
+Bars (the `report`): bit-exact — pyramids, coarse-depth lists, immature-point traces, activation results, residual states / res_toZero of
+the marginalisation pass; exact — every index / set decision (flagged frames, activation candidates, marginalisation candidates / drops /
+marginalised points, removed frames); tolerance — tracker pose 1e-3 / 1e-3 (exposure a 1e-3, b 0.5), BA per-iteration energies 5e-3, BA
+poses 1e-3 (the first keyframe's 1e10 prior, later the marginalisation prior, holds the gauge), inverse depths 8e-2 relative on the 99th
+percentile, residual-set flips <= R/200 per run, prior blocks 5e-5 of their largest entry, frame marginalisation 1e-10.
+
+Checker side only (tests/, bench.py's sequence object for the oracle's CPU time)."""
+import ctypes as C
+import time
+
+import numpy as np
+
+from libcml_amd import abi
+from tests import ba_setup as S
+from tests import oracle_lib as O
+from tests import tracer_setup as TS
+from tests import trk_opt_setup as TO
+
+IN, OOB, OUTLIER = 0, 1, 2
+
+
+def _bits_equal(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype.kind == "f":
+        u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+        bad = a.view(u) != b.view(u)
+        bad &= ~(np.isnan(a) & np.isnan(b))
+        return not bad.any()
+    return bool(np.array_equal(a, b))
+
+
+def _se3(q, t):
+    T = O.OrcSE3()
+    for k in range(4):
+        T.q[k] = float(q[k])
+    for k in range(3):
+        T.t[k] = float(t[k])
+    return T
+
+
+# ------------------------------------------------------------------------------------------------ the window as an oracle problem
+def inputs_from_export(fr, pt, rs, grads0, K, w, h, reset_active=True):
+    """tests/ba_setup.BAInputs from the mirror's exported state, as DSOBundleAdjustment::run's preamble would upload it (BA.cpp:753-779:
+    alive points / residuals in list order, resetOOB of every non-linearised residual)."""
+    I = S.BAInputs()
+    N = len(fr)
+    I.N = N
+    I.scales = S.make_scales()
+    I.frames = (O.OrcFrame * N)()
+    lib = O.lib()
+    for k in range(N):
+        f = I.frames[k]
+        f.w2c_eval = _se3(fr["eval_q"][k], fr["eval_t"][k])
+        f.ab_exposure = float(fr["ab_exposure"][k]); f.keyid = int(fr["keyid"][k])
+        for i in range(10):
+            f.prior_zero[i] = float(fr["prior_zero"][k][i])
+        st = O.f64(fr["state"][k]); sz = O.f64(fr["state_zero"][k])
+        lib.orc_frame_set_state(C.byref(f), O.ptr(st, C.c_double), C.byref(I.scales))
+        lib.orc_frame_set_state_zero(C.byref(f), O.ptr(sz, C.c_double), C.byref(I.scales))
+    I.prm = abi.default_ba_params(*K, w, h)
+    alive_p = np.flatnonzero(pt["alive"] == 1)
+    slot = -np.ones(len(pt), np.int64); slot[alive_p] = np.arange(len(alive_p))
+    P = len(alive_p)
+    pts = np.zeros(P, abi.BA_POINT_DTYPE)
+    pts["x"] = pt["x"][alive_p]; pts["y"] = pt["y"][alive_p]; pts["idepth"] = pt["idepth"][alive_p]; pts["idepth_zero"] = pt["idepth_zero"][alive_p]
+    pts["prior"] = np.where(pt["hasDepthPrior"][alive_p] != 0, np.float32(50 * 50), np.float32(0))      # computeDelta, BA.cpp:1179-1184
+    pts["colors"] = pt["colors"][alive_p]; pts["weights"] = pt["weights"][alive_p]; pts["host"] = pt["host"][alive_p]
+    keep = np.flatnonzero((rs["alive"] == 1) & (pt["alive"][np.maximum(rs["point"], 0)] == 1))
+    R = len(keep)
+    res = np.zeros(R, abi.BA_RESIDUAL_DTYPE)
+    res["point"] = slot[rs["point"][keep]]; res["target"] = rs["target"][keep]
+    lin = rs["isLinearized"][keep] != 0
+    res["state"] = np.where(lin | (not reset_active), rs["state_state"][keep], IN)
+    res["is_linearized"] = lin
+    I.P, I.R, I.points, I.residuals = P, R, pts, res
+    I.point_ids, I.residual_ids = alive_p, keep
+    frd = np.zeros(N, abi.BA_FRAME_DTYPE)
+    frd["image_id"] = fr["image_id"]; frd["frame_energy_th"] = fr["frameEnergyTH"].astype(np.float32)
+    for k in range(N):
+        frd["b0"][k] = np.float32(I.frames[k].state_zero[7] * np.float32(I.scales.b))
+    I.frames_dev = frd
+    I.grads = [[np.ascontiguousarray(g, np.float32)] for g in grads0]
+    I.pairs = S.frame_pairs(I.frames, N)
+    I.adH, I.adT, I.adHTd, I.prior, I.dprior = S.adjoints_and_delta(I.frames, N, I.scales)
+    I.cdelta = np.zeros(4); I.cprior = np.full(4, 5e9)
+    return I
+
+
+def oracle_run(I, HM, bM, iterations=4, fixed_lambda=1e-5, th_opt=1.2):
+    """DSOBundleAdjustment::run (BA.cpp:744-910) under forceAccept / fixLambda WITH the marginalisation prior (BA.cpp:1389-1401), composed
+    from oracle primitives (tests/ba_ref_run.oracle_run is the same loop without the prior)."""
+    ob = S.OracleBA(I)
+    N, P = I.N, I.P
+    n = 8 * N + 4
+    lib = O.lib()
+    log = dict(energy=[], x=[])
+    r = ob.linearize()
+    ob.apply(1)
+    log["energy"].append(r.energy)
+    its = 0
+    for it in range(iterations):
+        its = it + 1
+        backup = [np.array(I.frames[k].state[:]) for k in range(N)]
+        lib.orc_ba_backup_points(ob.w)
+        HA, bA, HL, bL, Hsc, bsc = ob.accumulate()
+        d = np.zeros(n)
+        for k in range(N):
+            d[4 + 8 * k:12 + 8 * k] = np.array(I.frames[k].delta[:])
+        bMtop = bM + HM @ d
+        x, rc = ob.solve(fixed_lambda, HA, bA, HL, bL, Hsc, bsc, HM=np.ascontiguousarray(HM), bM=np.ascontiguousarray(bMtop))
+        if it >= 2:
+            ns = np.zeros(7 * n)
+            lib.orc_ba_nullspaces(I.frames, N, C.byref(I.scales), O.ptr(ns, C.c_double))
+            x = O.orthogonalize(x, ns.reshape(7, n), 1e-5)
+        log["x"].append(x.copy())
+        step, rc = ob.backsub(x)
+        sums = dict(A=np.float32(0), B=np.float32(0), T=np.float32(0), R=np.float32(0))
+        for k in range(N):
+            st = backup[k].copy(); stp = np.zeros(10); stp[:8] = -x[4 + 8 * k:12 + 8 * k]
+            st += stp
+            lib.orc_frame_set_state(C.byref(I.frames[k]), O.ptr(st, C.c_double), C.byref(I.scales))
+            sums["A"] += np.float32(stp[6] ** 2); sums["B"] += np.float32(stp[7] ** 2)
+            sums["T"] += np.float32((stp[:3] ** 2).sum()); sums["R"] += np.float32((stp[3:6] ** 2).sum())
+        ps = np.zeros(3, np.float32)
+        lib.orc_ba_step_points(ob.w, O.ptr(ps, C.c_float))
+        sumNID = ps[1] / ps[2] if ps[2] else np.float32(0)
+        canbreak = (np.sqrt(sums["A"] / N) < 0.0005 * th_opt and np.sqrt(sums["B"] / N) < 0.00005 * th_opt and
+                    np.sqrt(sums["R"] / N) < 0.00005 * th_opt and np.sqrt(sums["T"] / N) * sumNID < 0.00005 * th_opt)
+        I.pairs = S.frame_pairs(I.frames, N); ob.set_pairs(I.pairs)
+        I.adH, I.adT, I.adHTd, I.prior, I.dprior = S.adjoints_and_delta(I.frames, N, I.scales)
+        r = ob.linearize()
+        ob.apply(1)                                                   # forceAccept (BA.cpp:830-853)
+        log["energy"].append(r.energy)
+        if canbreak and it >= 1:
+            break
+    fb = I.frames[N - 1]                                              # re-anchor the newest frame (BA.cpp:885-894)
+    nz = np.zeros(10); nz[6] = fb.state[6]; nz[7] = fb.state[7]
+    fb.w2c_eval = fb.PRE_w2c
+    lib.orc_frame_set_state(C.byref(fb), O.ptr(nz, C.c_double), C.byref(I.scales))
+    lib.orc_frame_set_state_zero(C.byref(fb), O.ptr(nz, C.c_double), C.byref(I.scales))
+    ob.w.contents.b0[N - 1] = float(np.float32(fb.state_zero[7] * np.float32(I.scales.b)))      # getB0 follows state_zero (DSOFrame.h:197-199)
+    I.pairs = S.frame_pairs(I.frames, N); ob.set_pairs(I.pairs)
+    I.adH, I.adT, I.adHTd, I.prior, I.dprior = S.adjoints_and_delta(I.frames, N, I.scales)
+    r = ob.linearize(); ob.apply(1)                                   # linearizeAll(true)
+    log["energy"].append(r.energy)
+    st = ob.states()
+    poses = []
+    for k in range(N):
+        Rm, t = O.se3_matrix(I.frames[k].PRE_w2c)
+        poses.append((Rm, t, I.frames[k].state_scaled[6], I.frames[k].state_scaled[7]))
+    idepth = np.array([ob.w.contents.points[i].idepth for i in range(P)])
+    hdi = ob.view("HdiF", P, np.float32).copy()
+    return dict(poses=poses, idepth=idepth, good=st["good"] == 1, state=st["state"].copy(), log=log, iterations=its, ob=ob,
+                th=float(ob.w.contents.frame_energy_th[N - 1]), HdiF=hdi)
+
+
+# ------------------------------------------------------------------------------------------------ host logic, restated from the reference
+def flag_frames(fr, pt, rs, immature, max_frames=6, min_frame_age=1):
+    """flagFramesForMarginalization, BA.cpp:603-716 (called from addNewFrame BEFORE the new frame joins, :428).  Returns the flags."""
+    N = len(fr)
+    flags = [bool(f) for f in fr["flagged"]]
+    nres = np.bincount(rs["target"][(rs["alive"] == 1) & (rs["target"] >= 0)], minlength=N)
+    flagged = 0
+    a_b = fr["state"][N - 1][6] * 10.0                               # aff_g2l of getFrames().back(): state_scaled a (scale 10), exposure time 1
+    for i in range(N):
+        inn = nres[i] + immature[i]
+        out = fr["numMarginalized"][i] + fr["numResidualsOut"][i]
+        a_i = fr["state"][i][6] * 10.0
+        ref_to_fh_a = np.exp(a_i - a_b) * fr["ab_exposure"][i] / fr["ab_exposure"][N - 1]      # Exposure::to, Exposure.h:119-123
+        not_enough = inn < 0.05 * (inn + out)
+        too_big = abs(np.log(ref_to_fh_a)) > 0.7 and N - flagged > max_frames - 2
+        if not_enough or too_big:
+            flags[i] = True; flagged += 1
+    if N - flagged >= max_frames:
+        smallest, pick = 1.0, -1
+        kid_latest = fr["keyid"][N - 1]
+        cams = []
+        for i in range(N):
+            T = _se3(fr["pre_q"][i], fr["pre_t"][i])
+            cams.append(O.se3_matrix(T))
+        for ri in range(N):
+            if fr["keyid"][ri] > kid_latest - min_frame_age or fr["keyid"][ri] == 0:
+                continue
+            score = 0.0
+            Rr, tr = cams[ri]
+            for ti in range(N):
+                if ti == ri or fr["keyid"][ti] > kid_latest - min_frame_age + 1:
+                    continue
+                Rt, tt = cams[ti]
+                Rrel = Rt @ Rr.T
+                score += 1.0 / (1e-5 + np.linalg.norm(tt - Rrel @ tr))
+            Rb, tb = cams[N - 1]
+            Rrel = Rb @ Rr.T
+            score *= -np.sqrt(np.linalg.norm(tb - Rrel @ tr))
+            if score < smallest:
+                smallest, pick = score, ri
+        if pick >= 0:
+            flags[pick] = True
+    return flags
+
+
+def activation_candidates(pts, alive, act, tracer_fids, frame_ids, pairs, K, w, h, min_quality=3.0):
+    """candidate tests of DSOTracer::activatePoints, DSOTracer.cpp:114-197, without the DistanceMap (no spacing policy in the pipeline).
+    Returns (indices handed to optimizeImmaturePoint with their window host, indices removed)."""
+    N = len(frame_ids); last = N - 1
+    cand, removed = [], []
+    for i in range(len(pts)):
+        if not alive[i] or act[i]:
+            continue
+        fid = tracer_fids[i]
+        hst = frame_ids.index(fid) if fid in frame_ids else -1
+        if hst == last:
+            continue
+        if hst < 0:
+            removed.append(i); continue
+        p = pts[i]
+        if not np.isfinite(p["idepth_max"]) or p["last_status"] == abi.IPS_OUTLIER:
+            removed.append(i); continue
+        ok = (p["last_status"] in (abi.IPS_GOOD, abi.IPS_SKIPPED, abi.IPS_BADCONDITION, abi.IPS_OOB) and p["last_pixel_interval"] < 8 and
+              p["quality"] > min_quality and (p["idepth_max"] + p["idepth_min"]) > 0)
+        if not ok:
+            if p["last_status"] == abi.IPS_OOB:
+                removed.append(i)
+            continue
+        idepth = (p["idepth_min"] + p["idepth_max"]) / 2.0
+        pr = pairs[hst * N + last]
+        Rm = pr["R"].reshape(3, 3)
+        q = Rm @ np.array([(float(p["x"]) - K[2]) * (1.0 / K[0]), (float(p["y"]) - K[3]) * (1.0 / K[1]), 1.0]) + pr["t"] * idepth
+        u = (q[0] / q[2]) * K[0] + K[2]; v = (q[1] / q[2]) * K[1] + K[3]
+        if not (u >= 0 and v >= 0 and u < w and v < h):
+            removed.append(i); continue
+        cand.append((i, hst))
+    return cand, removed
+
+
+def is_oob(p, pt, res_of_point, rs, to_marg):
+    """isOOB, BA.cpp:2515-2554"""
+    vis, num_in = 0, 0
+    for r in res_of_point:
+        if rs["state_state"][r] != IN:
+            continue
+        num_in += 1
+        if rs["target"][r] in to_marg:
+            vis += 1
+    if num_in >= 3 and pt["numGoodResiduals"][p] > 4 + 10 and num_in - vis < 3:
+        return True
+    if pt["lastResidualState"][p][0] == OOB:
+        return True
+    if num_in < 2:
+        return False
+    return pt["lastResidualState"][p][0] == OUTLIER and pt["lastResidualState"][p][1] == OUTLIER
+
+
+def try_marginalize_sets(fr, pt, rs, min_idepth_h_marg=50.0):
+    """the point classification of tryMarginalize, BA.cpp:2240-2363: (candidates for the residual loop, dropped before it)"""
+    to_marg = set(int(i) for i in np.flatnonzero(fr["flagged"] != 0))
+    by_point = {}
+    for r in np.flatnonzero(rs["alive"] == 1):
+        by_point.setdefault(int(rs["point"][r]), []).append(int(r))
+    cand, drop = [], []
+    for p in np.flatnonzero(pt["alive"] == 1):
+        rl = by_point.get(int(p), [])
+        if pt["idepth"][p] < 0 or not rl:
+            drop.append(int(p))
+        elif is_oob(p, pt, rl, rs, to_marg) or fr["flagged"][pt["host"][p]] != 0:
+            if len(rl) >= 3 and pt["numGoodResiduals"][p] >= 4:
+                cand.append(int(p))
+            else:
+                drop.append(int(p))
+    return cand, drop
+
+
+# ------------------------------------------------------------------------------------------------ the checker
+class SequenceChecker:
+    def __init__(self, ctx, K, w, h, levels, strict=True):
+        self.ctx, self.K, self.w, self.h, self.levels = ctx, tuple(K), w, h, levels
+        self.strict = strict
+        self.debug = False
+        self.ref = None                       # oracle-side tracking reference: per-level uvic lists
+        self.oracle_seconds = {}
+        self.report = {"stages": {}, "worst": {}, "flips": {"run_residual_sets": 0, "run_residuals": 0, "tracker_winner": 0}, "failures": []}
+
+    # ---- bookkeeping
+    def __call__(self, stage, info):
+        t0 = time.perf_counter()
+        getattr(self, "on_" + stage)(info)
+        self.oracle_seconds[stage] = self.oracle_seconds.get(stage, 0.0) + time.perf_counter() - t0
+        self.report["stages"][stage] = self.report["stages"].get(stage, 0) + 1
+
+    def _worst(self, key, v):
+        self.report["worst"][key] = max(self.report["worst"].get(key, 0.0), float(v))
+
+    def _require(self, cond, what):
+        if not cond:
+            self.report["failures"].append(what)
+            if self.strict:
+                raise AssertionError(what)
+
+    # ---- pyramids and coarse-depth lists (bit-exact)
+    def _oracle_lists(self, gray, pts):
+        grays, grads = O.build_pyramid(gray, self.levels)
+        L = self.levels
+        ws = (C.c_int * L)(*[grays[l].shape[1] for l in range(L)]); hs = (C.c_int * L)(*[grays[l].shape[0] for l in range(L)])
+        gl = [np.ascontiguousarray(grays[l]) for l in range(L)]
+        gp = (C.POINTER(C.c_float) * L)(*[O.ptr(g, C.c_float) for g in gl])
+        lists = [np.zeros((gl[l].size, 4), np.float32) for l in range(L)]
+        lp = (C.POINTER(C.c_float) * L)(*[O.ptr(a, C.c_float) for a in lists])
+        nout = (C.c_int * L)()
+        p = np.ascontiguousarray(pts, np.float64)
+        O.lib().orc_tracker_make_coarse_depth(O.ptr(p, C.c_double), len(p), L, ws, hs, gp, lp, nout)
+        return grads, [np.ascontiguousarray(lists[l][:nout[l]]) for l in range(L)]
+
+    def _check_lists(self, info, tag):
+        grads, lists = self._oracle_lists(info["gray"], info["pts"])
+        dev0 = self.ctx.pyramid_get(info["image_id"], 0)
+        self._require(_bits_equal(dev0, grads[0]), "%s: level-0 gradient image differs from the oracle pyramid" % tag)
+        for l in range(self.levels):
+            d = self.ctx.tracker_get_reference(l)
+            self._require(len(d) == len(lists[l]) == info["n_lists"][l], "%s: coarse-depth list size at level %d" % (tag, l))
+            self._require(_bits_equal(d, lists[l]), "%s: coarse-depth list of level %d differs (order / pixel / idepth / colour bits)" % (tag, l))
+        self.ref = lists
+
+    def on_bootstrap(self, info):
+        self._check_lists(info, "bootstrap")
+
+    def on_coarse(self, info):
+        self._check_lists(info, "makeCoarseDepthL0")
+
+    # ---- tracking (tolerance)
+    def on_track(self, info):
+        P = TO.Problem()
+        _grays, grads = O.build_pyramid(info["gray"], self.levels)
+        P.levels = self.levels; P.imgs = [np.ascontiguousarray(g, np.float32) for g in grads]; P.uvic = self.ref
+        P.ref_exp = info["ref_exp"]; P.init_exp = info["init_exp"]; P.prm = abi.default_tracker_params()
+
+        class _W:
+            pass
+        P.W = _W(); P.W.K = self.K
+        o = TO.oracle_track(P, info["hyps"], info["last_coarse_rmse"], 0)
+        r = info["result"]
+        self._require(o["ok"] == bool(r["haveOneGood"]), "track: haveOneGood differs (oracle %s)" % o["ok"])
+        if not o["ok"]:
+            return
+        if o["winner"] != r["winner"] or o["tries"] != r["tries"]:
+            self.report["flips"]["tracker_winner"] += 1
+        dR = float(np.abs(o["R"] - r["R"]).max()); dt = float(np.abs(o["t"] - r["t"]).max() / max(1.0, np.abs(o["t"]).max()))
+        self._worst("track_R", dR); self._worst("track_t_rel", dt)
+        self._worst("track_a", abs(o["a"] - r["exposure"][0])); self._worst("track_b", abs(o["b"] - r["exposure"][1]))
+        self._worst("track_rmse_rel", abs(r["lastCoarseRMSE"] / o["achieved"] - 1))
+        self._require(dR < 1e-3 and dt < 1e-3, "track: pose differs from the oracle's (|dR| %.2e, |dt| %.2e)" % (dR, dt))
+        self._require(abs(o["a"] - r["exposure"][0]) < 1e-3 and abs(o["b"] - r["exposure"][1]) < 0.5, "track: exposure differs")
+        self._require(abs(r["lastCoarseRMSE"] / o["achieved"] - 1) < 1e-2, "track: achieved rmse differs")
+
+    # ---- immature points (bit-exact)
+    FIELDS = ("last_status", "idepth_min", "idepth_max", "quality", "last_uv", "last_pixel_interval")
+
+    def on_trace(self, info):
+        pts0, alive0, act0, _ = info["before"]
+        pts1, alive1, act1, _ = info["after"]
+        fids = info["frame_ids"]; tf = info["tracer_fids"]
+        grad = self.ctx.pyramid_get(info["image_id"], 0)
+        sel, hosts, gone = [], [], []
+        for i in range(len(pts0)):
+            if not alive0[i] or act0[i]:
+                continue
+            if tf[i] not in fids:
+                gone.append(i); continue                              # reference frame left the window, DSOTracer.cpp:20-26
+            if tf[i] == info["traced_fid"]:
+                continue
+            sel.append(i); hosts.append(fids.index(tf[i]))
+        self._require(all(alive1[i] == 0 for i in gone), "trace: points of departed frames still alive")
+        if not sel:
+            return
+        sub = pts0[sel].copy(); sub["host"] = hosts
+        o = TS.oracle_trace(grad, info["pairs"], abi.default_tracer_params(), sub)
+        for name in self.FIELDS:
+            self._require(_bits_equal(o[name], pts1[sel][name]), "trace: %s differs from the oracle in some bit" % name)
+        self.report["traced_points"] = self.report.get("traced_points", 0) + len(sel)
+
+    def on_activate(self, info):
+        pts0, alive0, act0, _ = info["before"]
+        pts1, alive1, act1, idp1 = info["after"]
+        fids = info["frame_ids"]
+        cand, removed = activation_candidates(pts0, alive0, act0, info["tracer_fids"], fids, info["pairs"], self.K, self.w, self.h)
+        self._require(all(alive1[i] == 0 for i in removed), "activate: a point the reference removes is still alive")
+        if not cand:
+            self._require(len(info["activated"]) == 0, "activate: activations without candidates")
+            return
+        idx = [c[0] for c in cand]
+        sub = pts0[idx].copy(); sub["host"] = [c[1] for c in cand]
+        ro, io, so = TS.oracle_optimize(info["grads0"], self.K, info["pairs"], abi.default_tracer_params(), 1, sub)
+        act_o = [idx[k] for k in range(len(idx)) if ro[k] == 1]
+        self._require(sorted(act_o) == sorted(int(i) for i in info["activated"]), "activate: activated set differs (oracle %d, product %d)" % (len(act_o), len(info["activated"])))
+        ia = np.array(act_o, int)
+        if len(ia):
+            self._require(_bits_equal(io[ro == 1], idp1[ia]), "activate: activated inverse depths differ in some bit")
+        for k, i in enumerate(idx):                                   # dropped: result -1 or OOB (DSOTracer.cpp:236-240)
+            if ro[k] != 1 and (ro[k] == -1 or pts0[i]["last_status"] == abi.IPS_OOB):
+                self._require(alive1[i] == 0, "activate: a dropped candidate is still alive")
+        self.report["activation_candidates"] = self.report.get("activation_candidates", 0) + len(idx)
+        self.report["activated"] = self.report.get("activated", 0) + len(act_o)
+
+    # ---- frames flagged for marginalisation (exact)
+    def on_flag(self, info):
+        fr, pt, rs = info["before"]
+        want = flag_frames(fr, pt, rs, info["immature"])
+        fra = info["after"][0]
+        got = [bool(f) for f in fra["flagged"][:len(fr)]]
+        self._require(want == got, "flagFramesForMarginalization: flags differ (oracle-side %s, product %s)" % (want, got))
+        self.report["frames_flagged"] = self.report.get("frames_flagged", 0) + sum(want)
+
+    # ---- DSOBundleAdjustment::run (tolerance + flips)
+    def on_run(self, info):
+        fr, pt, rs = info["before"]
+        HM, bM = info["prior"]
+        I = inputs_from_export(fr, pt, rs, info["grads0"], self.K, self.w, self.h)
+        o = oracle_run(I, HM, bM)
+        fra, pta, rsa = info["after"]
+        N = I.N
+        self._require(o["iterations"] == info["iterations"], "run: iteration count %d (oracle) vs %d" % (o["iterations"], info["iterations"]))
+        its = min(o["iterations"], info["iterations"])
+        e_dev = np.asarray(info["energies"])[-its:] if its else np.zeros(0)
+        e_orc = np.asarray(o["log"]["energy"][1:1 + its])
+        if its:
+            de = float(np.abs(e_dev / e_orc - 1).max())
+            self._worst("run_energy_rel", de)
+            self._require(de < 5e-3, "run: per-iteration energies differ by %.2e" % de)
+        for k in range(N):
+            Ro, to, ao, bo = o["poses"][k]
+            T = _se3(fra["pre_q"][k], fra["pre_t"][k]); Rd, td = O.se3_matrix(T)
+            dR = float(np.abs(Ro - Rd).max()); dt = float(np.abs(to - td).max())
+            self._worst("run_pose_R", dR); self._worst("run_pose_t", dt)
+            self._worst("run_aff_a", abs(ao - fra["state"][k][6] * 10.0)); self._worst("run_aff_b", abs(bo - fra["state"][k][7] * 1000.0))
+            self._require(dR < 1e-3 and dt < 1e-3, "run: pose of frame %d differs (|dR| %.2e, |dt| %.2e)" % (k, dR, dt))
+        idp_d = pta["idepth"][I.point_ids]
+        rel = np.abs(idp_d / o["idepth"] - 1)
+        self._worst("run_idepth_rel_p99", float(np.percentile(rel, 99))); self._worst("run_idepth_rel_median", float(np.median(rel)))
+        self._require(np.percentile(rel, 99) < 8e-2, "run: inverse depths differ (99th percentile %.2e)" % np.percentile(rel, 99))
+        # residual bookkeeping of BA.cpp:1568-1642: a residual survives the closing pass iff it is good
+        good_d = rsa["alive"][I.residual_ids] == 1
+        flips = int((good_d != o["good"]).sum())
+        self.report["flips"]["run_residual_sets"] += flips; self.report["flips"]["run_residuals"] += I.R
+        self._require(flips <= max(2, I.R // 200), "run: %d of %d residual decisions differ" % (flips, I.R))
+        # ... and, given the product's OWN residual decisions, its point bookkeeping must follow exactly: a point is an outlier iff no residual is left
+        nres = np.zeros(len(pt), int)
+        np.add.at(nres, rsa["point"][rsa["alive"] == 1], 1)
+        was = pt["alive"] == 1
+        self._require(np.array_equal(pta["alive"][was] == 1, nres[was] > 0), "run: point / residual bookkeeping inconsistent")
+        self._require(sorted(int(i) for i in info["outliers"]) == sorted(int(i) for i in np.flatnonzero(was & (nres == 0))), "run: outlier list differs from the points left without residual")
+        self.report["runs"] = self.report.get("runs", 0) + 1
+        self.report["max_window"] = max(self.report.get("max_window", 0), N)
+        self.report["max_residuals"] = max(self.report.get("max_residuals", 0), I.R)
+
+    # ---- tryMarginalize: classification exact, residual pass bit-exact
+    def on_try_marginalize(self, info):
+        fr, pt, rs = info["before"]
+        fra, pta, rsa = info["after"]
+        cand, drop = try_marginalize_sets(fr, pt, rs)
+        to_m = [p for p in cand if pt["idepth_hessian"][p] > 50.0]
+        drop_all = sorted(drop + [p for p in cand if not pt["idepth_hessian"][p] > 50.0])
+        self._require(sorted(int(p) for p in np.flatnonzero(pta["toMarginalize"] != 0)) == sorted(to_m), "tryMarginalize: points to marginalise differ")
+        died = sorted(int(p) for p in np.flatnonzero((pt["alive"] == 1) & (pta["alive"] == 0)))
+        nres = np.zeros(len(pt), int); np.add.at(nres, rsa["point"][rsa["alive"] == 1], 1)
+        self._require(set(drop_all) <= set(died), "tryMarginalize: a point the reference drops is still alive")
+        self._require(all(nres[p] == 0 for p in died), "tryMarginalize: a dropped point keeps residuals")
+        self.report["marg_candidates"] = self.report.get("marg_candidates", 0) + len(cand)
+        self.report["marg_dropped"] = self.report.get("marg_dropped", 0) + len(drop_all)
+        if not cand:
+            return
+        # residual loop of the candidates (resetOOB, linearize, applyRes(true), fixLinearization) on the oracle, from the product's state
+        I = inputs_from_export(fr, pt, rs, info["grads0"], self.K, self.w, self.h, reset_active=False)
+        ob = S.OracleBA(I)
+        R = I.R
+        ob.view("r_energy", R, np.float32)[:] = rs["state_energy"][I.residual_ids].astype(np.float32)
+        slot = {int(p): k for k, p in enumerate(I.point_ids)}
+        sel = np.array([slot[p] for p in cand], np.int32)
+        ob.relinearize_points(sel)
+        st = ob.states()
+        lin_o = ob.view("r_lin", R, np.uint8).copy()
+        mask = np.isin(I.residuals["point"], sel)
+        # the product's view of those residuals after the pass: rows still alive, or rows of points that were then dropped (their rows died with them)
+        rows = I.residual_ids[mask]
+        self._require(np.array_equal(rsa["state_state"][rows], st["state"][mask]), "tryMarginalize: residual states after the pass differ")
+        self._require(np.array_equal(rsa["isLinearized"][rows] != 0, lin_o[mask] != 0), "tryMarginalize: isLinearized flags differ")
+        self._require(_bits_equal(rsa["state_energy"][rows].astype(np.float32), st["energy"][mask]), "tryMarginalize: residual energies differ in some bit")
+        self.report["marg_relinearized_residuals"] = self.report.get("marg_relinearized_residuals", 0) + int(mask.sum())
+
+    def on_marginalize_points(self, info):
+        fr, pt, rs = info["before"]
+        H0, b0 = info["prior_before"]; H1, b1 = info["prior_after"]
+        sel_pts = np.flatnonzero(pt["toMarginalize"] != 0)
+        pta = info["after"][1]
+        self._require(np.all(pta["marginalized"][sel_pts] != 0) and np.all(pta["alive"][sel_pts] == 0), "marginalizePointsF: flags after the call")
+        if len(sel_pts) == 0:
+            self._require(_bits_equal(H0, H1), "marginalizePointsF: prior changed without points")
+            return
+        I = inputs_from_export(fr, pt, rs, info["grads0"], self.K, self.w, self.h, reset_active=False)
+        ob = S.OracleBA(I)
+        R = I.R
+        # the state fixLinearization left: linearised residuals carry res_toZero; rebuild it by repeating the pass on the oracle
+        ob.view("r_energy", R, np.float32)[:] = rs["state_energy"][I.residual_ids].astype(np.float32)
+        slot = {int(p): k for k, p in enumerate(I.point_ids)}
+        sel = np.array([slot[int(p)] for p in sel_pts], np.int32)
+        lin = I.residuals["is_linearized"].copy()
+        ob.view("r_lin", R, np.uint8)[:] = 0                          # relinearize_points repeats resetOOB -> linearize -> applyRes -> fixLinearization
+        ob.relinearize_points(sel)
+        M, Mb, Msc, Mbsc = ob.marginalize_points(sel)
+        Ho = H0 + 0.25 * (M - Msc); bo = b0 + 0.25 * (Mb - Mbsc)     # setting_margWeightFac^2, BA.cpp:2502-2507
+        dH = float(np.abs(H1 - Ho).max() / max(np.abs(Ho).max(), 1e-300)); db = float(np.abs(b1 - bo).max() / max(np.abs(bo).max(), 1e-300))
+        self._worst("marg_points_H_rel", dH); self._worst("marg_points_b_rel", db)
+        if not (dH < 5e-5 and db < 2e-4) and self.debug:
+            D = np.abs(H1 - Ho); n = len(D); Nf = (n - 4) // 8
+            print("marginalizePointsF mismatch: N=%d flagged=%s sel=%d hosts=%s max|Ho|=%.3e" % (Nf, list(np.flatnonzero(fr["flagged"] != 0)), len(sel_pts), np.bincount(pt["host"][sel_pts], minlength=Nf), np.abs(Ho).max()))
+            for a in range(Nf):
+                print("   " + " ".join("%8.1e" % D[4 + 8 * a:12 + 8 * a, 4 + 8 * b_:12 + 8 * b_].max() for b_ in range(Nf)))
+            ia, ib = np.unravel_index(np.argmax(D), D.shape)
+            print("   worst entry (%d, %d): product %.6e oracle %.6e; M %.6e Msc %.6e H0 %.6e" % (ia, ib, H1[ia, ib], Ho[ia, ib], M[ia, ib], Msc[ia, ib], H0[ia, ib]))
+        self._require(dH < 5e-5 and db < 2e-4, "marginalizePointsF: prior differs (H %.2e, b %.2e)" % (dH, db))
+        self.report["marginalized_points"] = self.report.get("marginalized_points", 0) + len(sel_pts)
+
+    def on_marginalize_frames(self, info):
+        fr, pt, rs = info["before"]
+        want = [int(i) for i in np.flatnonzero(fr["flagged"] != 0)]
+        self._require(want == [int(i) for i in info["removed"]], "marginalizeFrames: removed %s, flagged %s" % (info["removed"], want))
+        H, b = info["prior_before"]
+        A = info["algebra"]
+        N = len(fr)
+        live = list(range(N))
+        prior = A["prior"].reshape(N, 8); dprior = A["dprior"].reshape(N, 8)
+        for f in want:
+            k = live.index(f)
+            H, b = O.marginalize_frame(H, b, len(live), k, prior[f], dprior[f])
+            live.pop(k)
+        H1, b1 = info["prior_after"]
+        if want:
+            dH = float(np.abs(H1 - H).max() / max(np.abs(H).max(), 1e-300)); db = float(np.abs(b1 - b).max() / max(np.abs(b).max(), 1e-300))
+            self._worst("marg_frame_H_rel", dH); self._worst("marg_frame_b_rel", db)
+            self._require(dH < 1e-10 and db < 1e-10, "marginalizeFrame: prior differs (H %.2e, b %.2e)" % (dH, db))
+        fra, pta, rsa = info["after"]
+        self._require(len(fra) == N - len(want), "marginalizeFrames: window size")
+        # the removed frames take their points with them; surviving residuals never target a removed frame
+        hosts_gone = np.isin(pt["host"], want) & (pt["alive"] == 1)
+        self._require(np.all(pta["alive"][hosts_gone] == 0), "marginalizeFrames: a point of a removed frame is alive")
+        self._require(np.all(rsa["target"][rsa["alive"] == 1] >= 0), "marginalizeFrames: a residual targets a removed frame")
+        self.report["frames_marginalized"] = self.report.get("frames_marginalized", 0) + len(want)
