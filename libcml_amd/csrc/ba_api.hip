@@ -70,13 +70,60 @@ struct ResRead {
         return CMLHIP_OK;
     }
     void deliver() {
+        const size_t R = (size_t)c->R;
+        const int* dev_of = c->h_dev_of.data();
         for (auto& it : items) {
-            unsigned char* o = static_cast<unsigned char*>(it.out);
-            for (size_t r = 0; r < (size_t)c->R; r++) memcpy(o + it.esz * r, it.tmp.data() + it.esz * (size_t)c->h_dev_of[r], it.esz);
+            if (it.esz == 4) {                                   // typed gathers: a memcpy call per element was most of a readback's host time
+                uint32_t* o = static_cast<uint32_t*>(it.out); const uint32_t* t = reinterpret_cast<const uint32_t*>(it.tmp.data());
+                for (size_t r = 0; r < R; r++) o[r] = t[dev_of[r]];
+            } else if (it.esz == 1) {
+                unsigned char* o = static_cast<unsigned char*>(it.out); const unsigned char* t = it.tmp.data();
+                for (size_t r = 0; r < R; r++) o[r] = t[dev_of[r]];
+            } else {
+                unsigned char* o = static_cast<unsigned char*>(it.out);
+                for (size_t r = 0; r < R; r++) memcpy(o + it.esz * r, it.tmp.data() + it.esz * (size_t)dev_of[r], it.esz);
+            }
         }
     }
     std::vector<const void*> pending_dev;
 };
+
+// What the window's derived tables hold is a function of what was uploaded: built ON the device behind the one packed copy, so that the
+// copy carries the caller's data only (the per-residual copies of the point's static inputs alone were 72 B x R — nearly half the block —
+// and every byte of the block is ahead of the run's first kernel)
+struct ExpandArgs {
+    int R, P, N, pt_stride, pair_stride;
+    const int* r_point; const int* r_target; const unsigned char* r_lin; const int* pt_host;
+    const float* pt_x; const float* pt_y; const float* pt_colors; const float* pt_weights;
+    const int* by_point_off; const int* by_point; const int* by_pair_off;
+    int* r_host; int* r_new_state; int* by_pair; int* pair_pos;
+    float* r_px; float* r_py; float* r_colors; float* r_weights;
+    int* point_tgt; int* point_pos; int* point_res;
+};
+__global__ void k_window_expand(ExpandArgs E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E.R) {                                               // per residual (device order = pair-sorted)
+        const int p = E.r_point[i], host = E.pt_host[p], q = host + E.r_target[i] * E.N;
+        E.r_host[i] = host;
+        E.r_new_state[i] = CMLHIP_RES_OUTLIER;
+        E.by_pair[i] = i;
+        E.pair_pos[i] = q * E.pair_stride + (i - E.by_pair_off[q]);
+        E.r_px[i] = E.pt_x[p]; E.r_py[i] = E.pt_y[p];
+        const float4* c4 = reinterpret_cast<const float4*>(E.pt_colors + 8 * (size_t)p); const float4* w4 = reinterpret_cast<const float4*>(E.pt_weights + 8 * (size_t)p);
+        float4* oc = reinterpret_cast<float4*>(E.r_colors + 8 * (size_t)i); float4* ow = reinterpret_cast<float4*>(E.r_weights + 8 * (size_t)i);
+        oc[0] = c4[0]; oc[1] = c4[1]; ow[0] = w4[0]; ow[1] = w4[1];
+    }
+    const int slots = E.P * E.pt_stride;
+    for (int s = i; s < slots; s += gridDim.x * blockDim.x) {    // per point slot: the residual in it (device id), its target | lin << 8
+        const int p = s / E.pt_stride, j = s - p * E.pt_stride, o = E.by_point_off[p];
+        if (j < E.by_point_off[p + 1] - o) {
+            const int r = E.by_point[o + j];
+            E.point_res[s] = r;
+            E.point_tgt[s] = E.r_target[r] | (E.r_lin[r] ? 256 : 0);
+            E.point_pos[r] = s;
+        }
+    }
+}
 
 extern "C" {
 
@@ -217,63 +264,44 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         hst[p] = points[p].host;
         memcpy(&col[8 * (size_t)p], points[p].colors, 32); memcpy(&wgt[8 * (size_t)p], points[p].weights, 32);
     }
-    std::vector<int> rp(R), rt(R), rs(R), rns(R, CMLHIP_RES_OUTLIER);
+    std::vector<int> rp(R), rt(R), rs(R);
     std::vector<unsigned char> rl(R);
     for (int k = 0; k < R; k++) { const int r = c->h_caller_of[k]; rp[k] = res[r].point; rt[k] = res[r].target; rs[k] = res[r].state; rl[k] = res[r].is_linearized != 0; }
 #define UP(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
     UP(c->frames, fd);
     UP(c->pt_x, fx); UP(c->pt_y, fy); UP(c->pt_idepth, idp); UP(c->pt_idepth_zero, fz); UP(c->pt_prior, fp); UP(c->pt_host, hst);
     UP(c->pt_colors, col); UP(c->pt_weights, wgt);
-    { std::vector<int> rh(R); for (int k = 0; k < R; k++) rh[k] = points[res[c->h_caller_of[k]].point].host; UP(c->r_host, rh); }
-    UP(c->r_point, rp); UP(c->r_target, rt); UP(c->r_state, rs); UP(c->r_new_state, rns); UP(c->r_lin, rl);
+    UP(c->r_point, rp); UP(c->r_target, rt); UP(c->r_state, rs); UP(c->r_lin, rl);
     {   // device lists hold r': a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
-        std::vector<int> bp(R), bq(R);
-        for (int i = 0; i < R; i++) { bp[i] = c->h_dev_of[c->h_by_point[i]]; bq[i] = i; }
+        std::vector<int> bp(R);
+        for (int i = 0; i < R; i++) bp[i] = c->h_dev_of[c->h_by_point[i]];
         UP(c->by_point_off, c->h_by_point_off); UP(c->by_point, bp);
-        UP(c->by_pair_off, c->h_by_pair_off); UP(c->by_pair, bq);
+        UP(c->by_pair_off, c->h_by_pair_off);
     }
     {
         int mx = 1;
         for (int q = 0; q < N * N; q++) mx = std::max(mx, c->h_by_pair_off[q + 1] - c->h_by_pair_off[q]);
         c->pair_stride = (mx + 3) & ~3;
-        std::vector<int> code((size_t)N * N * c->pair_stride, -1), pos(std::max(R, 1), 0);   // nothing is good before the first applyRes
-        for (int q = 0; q < N * N; q++)
-            for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i++) pos[i] = q * c->pair_stride + (i - c->h_by_pair_off[q]);      // r' = i
-        if ((rc = cml_ensure(c, c->pair_code, 4 * code.size()))) return rc;
-        if ((rc = cml_ensure(c, c->pair_pos, 4 * pos.size()))) return rc;
-        UP(c->pair_code, code); UP(c->pair_pos, pos);
+        if ((rc = cml_ensure(c, c->pair_code, 4 * (size_t)N * N * c->pair_stride))) return rc;
+        if ((rc = cml_ensure(c, c->pair_pos, 4 * (size_t)std::max(R, 1)))) return rc;
+        if ((rc = cml_fill_ff(c, c->pair_code.p, 4 * (size_t)N * N * c->pair_stride))) return rc;      // nothing is good before the first applyRes
     }
     {
         int mx = 1;
         for (int p = 0; p < P; p++) mx = std::max(mx, c->h_by_point_off[p + 1] - c->h_by_point_off[p]);
         c->pt_stride = (mx + 7) & ~7;
         const size_t tot = (size_t)std::max(P, 1) * c->pt_stride;
-        std::vector<int> code(tot, -1), tgt(tot, -1), pos(std::max(R, 1), 0), pres(tot, -1);
-        for (int p = 0; p < P; p++)
-            for (int i = c->h_by_point_off[p]; i < c->h_by_point_off[p + 1]; i++) {
-                const int r = c->h_by_point[i], slot = p * c->pt_stride + (i - c->h_by_point_off[p]);
-                pos[c->h_dev_of[r]] = slot;
-                pres[slot] = c->h_dev_of[r];
-                tgt[slot] = res[r].target | (res[r].is_linearized ? 256 : 0);
-            }
-        if ((rc = cml_ensure(c, c->point_code, 4 * code.size()))) return rc;
-        if ((rc = cml_ensure(c, c->point_tgt, 4 * tgt.size()))) return rc;
-        if ((rc = cml_ensure(c, c->point_pos, 4 * pos.size()))) return rc;
-        if ((rc = cml_ensure(c, c->point_res, 4 * pres.size()))) return rc;
-        UP(c->point_code, code); UP(c->point_tgt, tgt); UP(c->point_pos, pos); UP(c->point_res, pres);
+        if ((rc = cml_ensure(c, c->point_code, 4 * tot))) return rc;
+        if ((rc = cml_ensure(c, c->point_tgt, 4 * tot))) return rc;
+        if ((rc = cml_ensure(c, c->point_pos, 4 * (size_t)std::max(R, 1)))) return rc;
+        if ((rc = cml_ensure(c, c->point_res, 4 * tot))) return rc;
+        if ((rc = cml_fill_ff(c, c->point_code.p, 4 * tot))) return rc;
+        if ((rc = cml_fill_ff(c, c->point_tgt.p, 4 * tot))) return rc;          // empty slots: -1 (filled by k_window_expand where a residual sits)
+        if ((rc = cml_fill_ff(c, c->point_res.p, 4 * tot))) return rc;
     }
     UP(c->newframe_res, newframe);
-    {   // per-residual copies of the point's static inputs (the resident kernel addresses everything by the residual index)
-        std::vector<float> rx(R), ry(R), rc8(8 * (size_t)R), rw8(8 * (size_t)R);
-        for (int k = 0; k < R; k++) {
-            const int p = rp[k];
-            rx[k] = fx[p]; ry[k] = fy[p];
-            memcpy(&rc8[8 * (size_t)k], &col[8 * (size_t)p], 32); memcpy(&rw8[8 * (size_t)k], &wgt[8 * (size_t)p], 32);
-        }
-        UP(c->r_px, rx); UP(c->r_py, ry); UP(c->r_colors, rc8); UP(c->r_weights, rw8);
-        if (c->n_tiles) { UP(c->rs_tiles, tiles); }
-        UP(c->rs_tile_off, tile_off);
-    }
+    if (c->n_tiles) { UP(c->rs_tiles, tiles); }
+    UP(c->rs_tile_off, tile_off);
 #undef UP
     // resetOOB (DSOResidual.h:83-88): energies 0, flags cleared
     if ((rc = cml_zero(c, c->r_energy.p, c->r_energy.bytes))) return rc;
@@ -297,6 +325,19 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     if ((rc = cml_zero(c, c->step_partial.p, c->step_partial.bytes))) return rc;
     lap_("staged");
     if ((rc = cml_h2d_batch_flush(c))) return rc;
+    if (R > 0) {
+        ExpandArgs E;
+        E.R = R; E.P = P; E.N = N; E.pt_stride = c->pt_stride; E.pair_stride = c->pair_stride;
+        E.r_point = c->r_point.as<int>(); E.r_target = c->r_target.as<int>(); E.r_lin = c->r_lin.as<unsigned char>(); E.pt_host = c->pt_host.as<int>();
+        E.pt_x = c->pt_x.as<float>(); E.pt_y = c->pt_y.as<float>(); E.pt_colors = c->pt_colors.as<float>(); E.pt_weights = c->pt_weights.as<float>();
+        E.by_point_off = c->by_point_off.as<int>(); E.by_point = c->by_point.as<int>(); E.by_pair_off = c->by_pair_off.as<int>();
+        E.r_host = c->r_host.as<int>(); E.r_new_state = c->r_new_state.as<int>(); E.by_pair = c->by_pair.as<int>(); E.pair_pos = c->pair_pos.as<int>();
+        E.r_px = c->r_px.as<float>(); E.r_py = c->r_py.as<float>(); E.r_colors = c->r_colors.as<float>(); E.r_weights = c->r_weights.as<float>();
+        E.point_tgt = c->point_tgt.as<int>(); E.point_pos = c->point_pos.as<int>(); E.point_res = c->point_res.as<int>();
+        const int work = std::max(R, P * c->pt_stride);
+        k_window_expand<<<cml_div_up(std::min(work, 1 << 20), 256), 256, 0, c->stream>>>(E);
+        CML_CHECK(c, hipGetLastError());
+    }
     lap_("flushed");
     c->ba_uploaded = true;
     c->ba_image_ids.clear();

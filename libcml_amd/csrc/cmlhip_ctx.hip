@@ -56,16 +56,17 @@ int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
 __global__ void k_h2d_scatter(const unsigned long long* __restrict__ segs, const char* __restrict__ blob) {
     const unsigned long long* S = segs + 3 * (size_t)blockIdx.y;
     char* dst = reinterpret_cast<char*>((uintptr_t)S[0]);
-    const bool zero = S[1] == ~0ull;                  // a fill segment
+    const bool zero = S[1] >= ~1ull;                  // a fill segment (~0: zeros, ~1: all bits set = -1 as int)
+    const unsigned fillw = S[1] == ~1ull ? 0xffffffffu : 0u;
     const char* src = zero ? blob : blob + S[1];
     const size_t bytes = (size_t)S[2], words = bytes / 16;
     const bool aligned = (((uintptr_t)dst) & 15) == 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (zero) {
         if (aligned) {
-            for (size_t i = t0; i < words; i += stride) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
-            for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = 0;
-        } else for (size_t i = t0; i < bytes; i += stride) dst[i] = 0;
+            for (size_t i = t0; i < words; i += stride) reinterpret_cast<uint4*>(dst)[i] = make_uint4(fillw, fillw, fillw, fillw);
+            for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = (char)fillw;
+        } else for (size_t i = t0; i < bytes; i += stride) dst[i] = (char)fillw;
     } else if (aligned) {
         for (size_t i = t0; i < words; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
         for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = src[i];
@@ -80,6 +81,15 @@ int cml_zero(cmlhip_ctx* c, void* dst, size_t bytes) {
         return CMLHIP_OK;
     }
     CML_CHECK(c, hipMemsetAsync(dst, 0, bytes, c->stream));
+    return CMLHIP_OK;
+}
+int cml_fill_ff(cmlhip_ctx* c, void* dst, size_t bytes) {       // every byte 0xff (ints: -1)
+    if (bytes == 0) return CMLHIP_OK;
+    if (c->h2d_batching) {
+        c->h2d_segs.push_back((unsigned long long)(uintptr_t)dst); c->h2d_segs.push_back(~1ull); c->h2d_segs.push_back((unsigned long long)bytes);
+        return CMLHIP_OK;
+    }
+    CML_CHECK(c, hipMemsetAsync(dst, 0xff, bytes, c->stream));
     return CMLHIP_OK;
 }
 void cml_h2d_batch_begin(cmlhip_ctx* c) {

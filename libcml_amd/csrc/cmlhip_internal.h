@@ -178,6 +178,7 @@ int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);
 // flush moves the packed block with ONE copy and scatters it to the destinations with one small kernel.
 void cml_h2d_batch_begin(cmlhip_ctx* c);
 int cml_zero(cmlhip_ctx* c, void* dst, size_t bytes);        // hipMemsetAsync(0), or a zero segment of the open batch
+int cml_fill_ff(cmlhip_ctx* c, void* dst, size_t bytes);      // 0xff fill (ints: -1), batched like cml_zero
 int cml_h2d_batch_flush(cmlhip_ctx* c);   // async on ctx stream via pinned staging
 int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // sync readback (inside a batch: recorded, delivered by the flush)
 // Several arrays, one round trip: between begin and flush cml_d2h only records; flush gathers the pieces into one device block,

@@ -45,6 +45,7 @@ def lib():
         L.cmlhost_ba_get_prior.argtypes = [_vp, _P(_d), _P(_d)]
         L.cmlhost_ba_get_point_flags.argtypes = [_vp, _P(_u8), _P(_u8), _P(_f)]
         L.cmlhost_ba_rejected.argtypes = [_vp]
+        L.cmlhost_ba_run_timing.argtypes = [_vp, _P(_d)]
         L.cmlhost_ba_last_lambda.restype = _d; L.cmlhost_ba_last_lambda.argtypes = [_vp]
         L.cmlhost_ba_calc_m_energy.restype = _d; L.cmlhost_ba_calc_m_energy.argtypes = [_vp]
         L.cmlhost_ba_calc_l_energy.restype = _d; L.cmlhost_ba_calc_l_energy.argtypes = [_vp]
@@ -217,6 +218,12 @@ class HostBA:
         tm = np.zeros(n, np.uint8); mg = np.zeros(n, np.uint8); ih = np.zeros(n, np.float32)
         self.L.cmlhost_ba_get_point_flags(self.h, _p(tm, _u8), _p(mg, _u8), _p(ih, _f))
         return tm, mg, ih
+
+    def run_timing(self):
+        """host clock of the last resident run(), microseconds: upload | first pass | resident state | enqueue | wait + readback | closing pass"""
+        t = np.zeros(6)
+        self.L.cmlhost_ba_run_timing(self.h, _p(t, _d))
+        return dict(zip(("upload", "first_pass", "resident_state", "enqueue", "wait_and_readback", "closing_pass"), [float(x) for x in t]))
 
     def rejected(self):
         return self.L.cmlhost_ba_rejected(self.h)

@@ -434,10 +434,14 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
     std::vector<unsigned char> good;
     if (fixLinearization) {
         // linearize + applyRes(r, true) (:1568-1569) + every array the host writes back afterwards: one device call, one readback
-        st.resize(R); ns.resize(R); e.resize(R); ne.resize(R); nw.resize(R); good.resize(R);
+        // (the host logic behind this pass reads state_state and isActiveAndIsGoodNEW only — isOOB, the removal rule, numGoodResiduals;
+        //  the energies and state_NewState stay on the device unless mKeepResidualEnergies asks for them)
+        st.resize(R); good.resize(R);
+        if (mKeepResidualEnergies) { ns.resize(R); e.resize(R); ne.resize(R); nw.resize(R); }
         if (idepthOut) idepthOut->resize(mActivePoints.size());
         if (pointAccOut) pointAccOut->resize(14 * mActivePoints.size() + 14);
-        rc = cmlhip_ba_finish_keyframe(mCtx, &lr, st.data(), ns.data(), e.data(), ne.data(), nw.data(), good.data(),
+        rc = cmlhip_ba_finish_keyframe(mCtx, &lr, st.data(), mKeepResidualEnergies ? ns.data() : nullptr, mKeepResidualEnergies ? e.data() : nullptr,
+                                       mKeepResidualEnergies ? ne.data() : nullptr, mKeepResidualEnergies ? nw.data() : nullptr, good.data(),
                                        idepthOut ? idepthOut->data() : nullptr, pointAccOut ? pointAccOut->data() : nullptr);
         if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_finish_keyframe", rc);
     } else {
@@ -450,8 +454,9 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
         std::vector<int> nres(mPoints.size(), 0);
         for (int k = 0; k < R; k++) {
             DSOResidual& Rr = mResiduals[mActive[k]];
-            Rr.state_state = st[k]; Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k];
-            Rr.state_NewEnergyWithOutlier = nw[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
+            Rr.state_state = st[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
+            if (mKeepResidualEnergies) { Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k]; Rr.state_NewEnergyWithOutlier = nw[k]; }
+            else Rr.state_NewState = st[k];                                         // applyNewState: state_state = state_NewState (DSOResidual.h)
             DSOPoint& Pp = mPoints[Rr.point];
             for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidualState[q] = Rr.state_state;   // setResidualState, :1618-1622
             if (Rr.isLinearized) continue;
@@ -611,6 +616,7 @@ bool DSOBundleAdjustment::runPreamble(double lastEnergy[3]) {                // 
     lap("adjoints+delta");
     if (!uploadWindow()) return false;
     lap("uploadWindow");
+    lastRunUs[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count();
     if (!linearizeAll(false, lastEnergy)) return false;
     lap("linearizeAll");
     int rc = cmlhip_ba_apply(mCtx, 1);                                        // applyActiveRes(true), :790
@@ -1069,18 +1075,27 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     double lastEnergy[3];
     const auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "  [run] %-28s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
+    auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
     if (!runPreamble(lastEnergy)) return false;
     lap("preamble done");
+    const double t_pre = us();
+    lastRunUs[1] = t_pre - lastRunUs[0];
     if (!beginResident(updatePointsOnly)) return false;
     lap("beginResident done");
+    const double t_begin = us();
+    lastRunUs[2] = t_begin - t_pre;
     int rc = cmlhip_ba_resident_convergence(mCtx, mThOptIterations);         // `if (canbreak && it >= 1) break`, BA.cpp:879
     if (rc) return fail("cmlhip_ba_resident_convergence", rc);
     if (!iterateResident(mNumIterations, mFixedLambda)) return false;
     lastLambda = mFixedLambda;
     double e = 0;
     lap("iterations enqueued");
+    const double t_enq = us();
+    lastRunUs[3] = t_enq - t_begin;
     if (!endResident(&e)) { mError = "non finite energy"; return false; }
     lap("endResident done");
+    const double t_end = us();
+    lastRunUs[4] = t_end - t_enq;
     std::vector<double> en(mNumIterations > 0 ? mNumIterations : 1, 0.0);
     int its = 0;
     rc = cmlhip_ba_get_resident_log(mCtx, &its, en.data(), (int)en.size());
@@ -1090,6 +1105,7 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     lastEnergy[0] = e;
     const bool ok = runEpilogue(lastEnergy);
     lap("epilogue done");
+    lastRunUs[5] = us() - t_end;
     return ok;
 }
 

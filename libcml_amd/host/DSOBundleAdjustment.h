@@ -89,6 +89,7 @@ public:
     double mMinIdepthHMarg = 50.0;                           // BA.h:263
     int    mMaxFrames = 6, mMinFrameAge = 1;                 // BA.h:271-272
     bool   mResidentLoop = true;                             // run(): keep the iteration loop on the device when the parameters allow it
+    bool   mKeepResidualEnergies = false;                    // run()'s closing pass also reads state_energy / state_NewEnergy / state_NewState of every residual back (nothing on the host uses them)
     double mCPriorValue = 5e9;                               // BA.cpp:2136-2137 (mCPrior is only assigned inside calcLEnergy)
 
     // ---- reference interface (BA.h:28-85), flat arguments
@@ -140,6 +141,7 @@ public:
     // ---- statistics of the last run (BA.h:215-233)
     std::vector<double> statEnergyP, statXNorm, statHessianP, statHessianSC, statBP, statBSC;
     int lastIterations = 0, statRejected = 0;                // iterations of the last run / rejected steps since construction
+    double lastRunUs[6] = {0, 0, 0, 0, 0, 0};                // host clock of the last runResident(): window build + upload | first linearize + apply | states / adjoints / prior to the device | enqueue of the iterations | wait for them + state readback | closing pass + write-back
     double lastLambda = 0;
     // exposed for tests
     void computeAdjoints();

@@ -35,6 +35,7 @@ int cmlhost_ba_set_param(void* h, const char* name, double v) {
     else if (n == "Solver mode delta") b->mSolverModeDelta = v;
     else if (n == "mixedBundleAdjustment") b->mMixedBundleAdjustment = v != 0;
     else if (n == "residentLoop") b->mResidentLoop = v != 0;
+    else if (n == "keepResidualEnergies") b->mKeepResidualEnergies = v != 0;
     else if (n == "Minimum iDepth Hessian Marginlaization") b->mMinIdepthHMarg = v;
     else if (n == "maxFrames") b->mMaxFrames = (int)v;
     else if (n == "frameMinAge") b->mMinFrameAge = (int)v;
@@ -145,6 +146,7 @@ int cmlhost_ba_get_indirect(void* h, double* x6, double* uncertainty, double* x)
     if (x) std::copy(b->lastX().begin(), b->lastX().end(), x);
     return (int)b->lastIndirectX().size();
 }
+void cmlhost_ba_run_timing(void* h, double us[6]) { for (int i = 0; i < 6; i++) us[i] = static_cast<DSOBundleAdjustment*>(h)->lastRunUs[i]; }
 int cmlhost_ba_rejected(void* h) { return static_cast<DSOBundleAdjustment*>(h)->statRejected; }
 double cmlhost_ba_last_lambda(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastLambda; }
 double cmlhost_ba_calc_m_energy(void* h) { return static_cast<DSOBundleAdjustment*>(h)->calcMEnergy(); }

@@ -27,21 +27,23 @@ class Sequence:
 
 
 def select_pixels(gray, n, rng, margin=10, taken=None):
-    """stand-in for Features::PixelSelector (out of scope): n distinct integer pixels, each the best-gradient one of 12 random candidates"""
+    """stand-in for Features::PixelSelector (out of scope): n distinct integer pixels, each the best-gradient one of 12 random candidates
+    (drawn in rounds of 2n picks; a pick is kept when its gradient clears a floor and its pixel is still free)"""
     h, w = gray.shape
     out = []
     seen = set() if taken is None else taken
-    tries = 0
-    while len(out) < n and tries < 40 * n:
-        tries += 1
-        cx = rng.integers(margin, w - margin, size=12); cy = rng.integers(margin, h - margin, size=12)
+    for _round in range(20):
+        m = 2 * n
+        cx = rng.integers(margin, w - margin, size=(m, 12)); cy = rng.integers(margin, h - margin, size=(m, 12))
         mag = np.abs(gray[cy, cx + 1] - gray[cy, cx - 1]) + np.abs(gray[cy + 1, cx] - gray[cy - 1, cx])
-        b = int(np.argmax(mag))
-        key = (int(cx[b]), int(cy[b]))
-        if key in seen or mag[b] < 4.0:
-            continue
-        seen.add(key)
-        out.append(key)
+        b = np.argmax(mag, axis=1); rows = np.arange(m)
+        bx, by, bm = cx[rows, b], cy[rows, b], mag[rows, b]
+        for x, y, g in zip(bx.tolist(), by.tolist(), bm.tolist()):
+            if g < 4.0 or (x, y) in seen:
+                continue
+            seen.add((x, y)); out.append((x, y))
+            if len(out) == n:
+                return np.array(out, np.int32).reshape(-1, 2)
     return np.array(out, np.int32).reshape(-1, 2)
 
 
@@ -139,6 +141,7 @@ class DirectPipeline:
         self.last_coarse_rmse = 100.0                                # DSOTracker.h:470
         self.n_fid = 0
         self.times = {}                                              # stage -> list of seconds
+        self.run_split = []                                          # per keyframe: the host clock of run()'s phases (HostBA.run_timing)
         self.tprm = abi.default_tracer_params()
         self.stats = {"frames": 0, "keyframes": 0, "tracking_lost": 0, "ids_recycled": 0, "max_window": 0, "marginalized_frames": 0}
 
@@ -367,6 +370,7 @@ class DirectPipeline:
         t0 = time.perf_counter()
         ok_run = ba.run()
         self._t("run", t0)
+        self.run_split.append(ba.run_timing())
         if not ok_run:
             raise RuntimeError("BA run failed: " + ba.last_error())
         self.stats["max_window"] = max(self.stats["max_window"], len(self.kfs))

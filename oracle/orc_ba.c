@@ -609,9 +609,12 @@ static void schur_points(orc_ba_window* w, const cmlhip_ba_accum_in* in, const u
 #undef accHcc
 #undef accbc
     }   /* omp parallel */
-    for (int t = 0; t < T_; t++) {          /* reduce the per-thread sets into the first-level slots of the shared ones (finish() folds them) */
-        tier_acc* base = pool + per * (size_t)t;
-        for (size_t i = 0; i < per; i++) {
+    /* reduce the per-thread sets into the first-level slots of the shared ones (finish() folds them): slot by slot over the threads,
+       the thread sets of one slot added in thread order */
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < per; i++) {
+        for (int t = 0; t < T_; t++) {
+            tier_acc* base = pool + per * (size_t)t;
             tier_acc* src = &base[i];
             tier_acc* dst = i < (size_t)NN * N ? &accD0[i] : i < (size_t)NN * N + NN ? &accE0[i - (size_t)NN * N]
                           : i < (size_t)NN * N + 2 * (size_t)NN ? &accEB0[i - (size_t)NN * N - NN] : i == per - 2 ? accHcc0 : accbc0;
@@ -708,6 +711,7 @@ void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* H
 #pragma omp for schedule(static)
             for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_ACTIVE, mine, in);
         }
+#pragma omp parallel for schedule(static)
         for (int q = 0; q < NN; q++) {
             float Hq[169];
             memset(w->accA + 169 * q, 0, sizeof(float) * 169); w->accA_num[q] = 0;
@@ -730,7 +734,12 @@ void orc_ba_accumulate(orc_ba_window* w, const cmlhip_ba_accum_in* in, double* H
     if (bA) memcpy(bA, tb, sizeof(double) * n);
     /* LINEARIZED, BA.cpp:1375-1378 */
     memset(acc, 0, sizeof(approx_acc) * NN);
-    for (int p = 0; p < w->P; p++) add_to_hessian_top(w, p, CMLHIP_MODE_LINEARIZED, acc, in);
+    int any_lin = 1;
+#ifdef _OPENMP
+    any_lin = 0;                                               /* TIMING BUILD ONLY: a window without LINEARIZED residuals skips the second walk over the points */
+    for (int r = 0; r < w->R && !any_lin; r++) any_lin = w->r_lin[r] != 0;
+#endif
+    for (int p = 0; p < w->P && any_lin; p++) add_to_hessian_top(w, p, CMLHIP_MODE_LINEARIZED, acc, in);
     for (int q = 0; q < NN; q++) { approx_finish(&acc[q], w->accL + 169 * q); w->accL_num[q] = acc[q].num; }
     stitch_top(w, w->accL, w->accL_num, in, 1, tH, tb);
     if (HL) memcpy(HL, tH, sizeof(double) * n * n);
