@@ -154,7 +154,7 @@ def cpu_baseline(config, seed):
     return out
 
 
-def multi_window_bench(device_id, seed, config, steps, half, s_list=(2, 4, 8)):
+def multi_window_bench(device_id, seed, config, steps, half, s_list=(2, 4, 8, 16, 32)):
     """Throughput mode on ONE GPU (north_star: independent keyframe windows / sequence shards): S independent windows of the benchmark
     shape stepped by cmlhip_ba_iteration_batch — one launch per kernel family for all S windows, five launches per round whatever S is.
     value = point-residuals of all S windows per second; parity: after the timed rounds one more batched round whose residual pass is
@@ -162,8 +162,11 @@ def multi_window_bench(device_id, seed, config, steps, half, s_list=(2, 4, 8)):
     from libcml_amd import abi, device, host, synth
     smax = max(s_list)
     wins = []
+    scenes = {}
     for k in range(smax):
-        W = synth.make_window(config, seed=seed, shard=100 + k)
+        if k % 8 not in scenes:                                       # eight distinct scenes; windows k and k + 8 hold the same scene in their own contexts
+            scenes[k % 8] = synth.make_window(config, seed=seed, shard=100 + k % 8)
+        W = scenes[k % 8]
         ctx = device.Ctx(device_id=device_id, max_frames=max(W.N, 2), max_points=W.P, max_residuals=W.P * W.N,
                          texel_format=abi.TEXEL_F16 if half else abi.TEXEL_F32)
         ba = host.window_to_host_ba(ctx, W, image_id_base=1000 * (k + 1), levels=1)

@@ -137,12 +137,14 @@ int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, c
     computeDelta();
     // residuals of the existing points into the new frame, BA.cpp:456-460 (createResidual, :336-380)
     const int t = f.id;
+    std::vector<SE3> relT(mFrames.size());                             // host -> new frame at the evaluation points, once per host (not per point)
+    std::vector<double> relR(9 * mFrames.size());
+    for (int h = 0; h < (int)mFrames.size(); h++) { relT[h] = mFrames[t].worldToCam_evalPT * mFrames[h].worldToCam_evalPT.inverse(); relT[h].matrix(&relR[9 * h]); }
     for (int p = 0; p < (int)mPoints.size(); p++) {
         if (!mPoints[p].alive || mPoints[p].host == t) continue;
         const DSOPoint& P = mPoints[p];
-        const SE3 ht = mFrames[t].worldToCam_evalPT * mFrames[P.host].worldToCam_evalPT.inverse();
-        double R[9];
-        ht.matrix(R);
+        const SE3& ht = relT[P.host];
+        const double* R = &relR[9 * P.host];
         const double rx = ((double)P.x - mPrm.cx) * (1.0 / mPrm.fx), ry = ((double)P.y - mPrm.cy) * (1.0 / mPrm.fy);
         const double px = R[0] * rx + R[1] * ry + R[2] + ht.t[0] * P.idepth, py = R[3] * rx + R[4] * ry + R[5] + ht.t[1] * P.idepth,
                      pz = R[6] * rx + R[7] * ry + R[8] + ht.t[2] * P.idepth;
@@ -172,11 +174,19 @@ int DSOBundleAdjustment::addPoint(float x, float y, double idepth, int host, con
     const int p = (int)mPoints.size();
     mPoints.push_back(P);
     mPointRes.resize(mPoints.size());
-    for (int t = 0; t < (int)mFrames.size(); t++) {                  // BA.cpp:398-400
+    const int NF = (int)mFrames.size();
+    if (mRelValidFor != NF) {                                        // host -> target at the evaluation points for every pair, rebuilt when the window changed
+        mRelT.assign((size_t)NF * NF, SE3()); mRelR.assign(9 * (size_t)NF * NF, 0.0);
+        for (int h = 0; h < NF; h++) {
+            const SE3 hi = mFrames[h].worldToCam_evalPT.inverse();
+            for (int t2 = 0; t2 < NF; t2++) { mRelT[(size_t)h * NF + t2] = mFrames[t2].worldToCam_evalPT * hi; mRelT[(size_t)h * NF + t2].matrix(&mRelR[9 * ((size_t)h * NF + t2)]); }
+        }
+        mRelValidFor = NF;
+    }
+    for (int t = 0; t < NF; t++) {                                   // BA.cpp:398-400
         if (t == host) continue;
-        const SE3 ht = mFrames[t].worldToCam_evalPT * mFrames[host].worldToCam_evalPT.inverse();
-        double R[9];
-        ht.matrix(R);
+        const SE3& ht = mRelT[(size_t)host * NF + t];
+        const double* R = &mRelR[9 * ((size_t)host * NF + t)];
         const double rx = ((double)x - mPrm.cx) * (1.0 / mPrm.fx), ry = ((double)y - mPrm.cy) * (1.0 / mPrm.fy);
         const double px = R[0] * rx + R[1] * ry + R[2] + ht.t[0] * idepth, py = R[3] * rx + R[4] * ry + R[5] + ht.t[1] * idepth,
                      pz = R[6] * rx + R[7] * ry + R[8] + ht.t[2] * idepth;
@@ -197,6 +207,7 @@ int DSOBundleAdjustment::addPoint(float x, float y, double idepth, int host, con
 
 void DSOBundleAdjustment::computeAdjoints() {                                 // BA.cpp:1030-1101
     const int N = (int)mFrames.size();
+    mRelValidFor = -1;                                              // (called whenever frames or evaluation points changed: the addPoint table follows)
     double sc[4];
     scales(sc);
     mAdHost.assign((size_t)N * N * 64, 0.0);

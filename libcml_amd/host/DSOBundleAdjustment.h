@@ -176,6 +176,7 @@ private:
     std::vector<DSOFrame> mFrames;
     std::vector<DSOPoint> mPoints;
     std::vector<DSOResidual> mResiduals;
+    std::vector<SE3> mRelT; std::vector<double> mRelR; int mRelValidFor = -1;   // addPoint: host -> target poses at the evaluation points (rebuilt after computeAdjoints)
     std::vector<std::vector<int>> mPointRes;        // residual indices of every point (DSOPoint::residuals, DSOPoint.h:87), dead ones included until compactDead
     std::vector<int> mActive;                       // indices of residuals uploaded (alive), device order
     std::vector<int> mActivePoints, mPointSlot;     // device point order <-> mPoints
