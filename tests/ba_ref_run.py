@@ -89,3 +89,24 @@ def oracle_run(I, iterations=4, fixed_lambda=1e-5, th_opt=1.2, force_accept=True
         poses.append((Rm, t, I.frames[k].state_scaled[6], I.frames[k].state_scaled[7]))
     idepth = np.array([ob.w.contents.points[i].idepth for i in range(P)])
     return dict(poses=poses, idepth=idepth, good=good, outliers=outliers, log=log, th=float(ob.w.contents.frame_energy_th[N - 1]), ob=ob)
+
+
+def oracle_run_release_rounding(I, **kw):
+    """The same procedure on the SAME oracle sources built with the reference's Release flags (-O3 -march=native, fused multiply-adds at the
+    compiler's discretion: oracle/Makefile `contract`, built on the box it runs on): a second correct rounding of the path.  The distance
+    between the two oracle runs is what this window does to rounding noise over the iterations — the yardstick a device-vs-oracle distance
+    is held against (tests/test_host_mirror_gpu.py)."""
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-C", O.ORACLE_DIR, "contract"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(O.ORACLE_DIR, "libcml_oracle_contract.so"))
+    L.orc_ba_create.restype = C.POINTER(O.OrcBAWindow)
+    L.orc_ba_linearize_one.restype = C.c_double
+    L.orc_ba_calc_l_energy.restype = C.c_double
+    L.orc_ba_calc_m_energy.restype = C.c_double
+    keep = O._lib
+    O._lib = L
+    try:
+        return oracle_run(I, **kw)
+    finally:
+        O._lib = keep

@@ -108,9 +108,12 @@ def test_apply_and_accumulate(pair):
     ad = ctx.ba_pair_acc(0)
     for q in range(I.N * I.N):
         assert np.abs(ao[q] - ad[q]).max() <= 2e-5 * max(np.abs(ao[q]).max(), 1e-30), q
-    assert D.rel(HAd, HAo) < 2e-5 and D.rel(bAd, bAo) < 2e-5
+    # (bars at ~10x the worst deviation of the seed sweeps — 1.3e-7 ... 5.5e-7, profiles/round*_parity_soak_tolerance.txt — so that a
+    #  10x loss of accumulation accuracy fails here; the fp32 pair accumulators above keep the looser per-block bar)
+    print("matrices, device vs oracle: H_A %.2e b_A %.2e H_sc %.2e b_sc %.2e" % (D.rel(HAd, HAo), D.rel(bAd, bAo), D.rel(Hsd, Hso), D.rel(bsd, bso)))
+    assert D.rel(HAd, HAo) < 3e-6 and D.rel(bAd, bAo) < 3e-6
     assert D.rel(HLd, HLo) < 1e-12 and D.rel(bLd, bLo) < 1e-12          # priors only
-    assert D.rel(Hsd, Hso) < 5e-5 and D.rel(bsd, bso) < 5e-5
+    assert D.rel(Hsd, Hso) < 5e-6 and D.rel(bsd, bso) < 5e-6
     assert np.abs(HAd - HAd.T).max() <= 1e-9 * np.abs(HAd).max()
     # per-point scalars
     pa = ctx.ba_point_acc()
@@ -156,7 +159,23 @@ def test_apply_and_accumulate(pair):
     gf_solver = gauge_free_pose_update_error(I, xd, xn)
     print("gauge-free pose update: device vs oracle %.3g; device solve vs numpy solve on the device's matrices %.3g" % (gf, gf_solver))
     assert gf_solver < 1e-9, (gf_solver, gf)                                    # measured 1e-13 ... 1e-12
-    assert gf < 2e-2, gf                                                          # sanity only
+    # ... and the device-vs-oracle difference itself is bounded FROM THE WINDOW (ADVICE rounds 2 / 3): it must be what the measured
+    # difference of the two sets of matrices propagates to — the same independent fp64 solve on the ORACLE's matrices gives the update
+    # the oracle's matrices imply; the distance between the two numpy updates is this window's (conditioning x accumulation noise), and
+    # the device-vs-oracle figure may exceed it only by the two solvers' own errors (1e-9 each, checked above / in (a))
+    Ho_ = HLo + HAo
+    Ho_[np.diag_indices(n)] *= (1 + lam)
+    Ho_ = Ho_ - Hso / (1 + lam)
+    bo_ = bLo + bAo - bso
+    Svo = 1.0 / np.sqrt(np.diag(Ho_) + 10.0)
+    xno = np.zeros(n)
+    xno[4:] = Svo[4:] * np.linalg.solve(Svo[4:, None] * Ho_[4:, 4:] * Svo[None, 4:], Svo[4:] * bo_[4:])
+    gf_window = gauge_free_pose_update_error(I, xn, xno)
+    gf_oracle_solver = gauge_free_pose_update_error(I, xo, xno)                  # the oracle's pivoted LDLT against numpy on the ORACLE's matrices
+    print("   window bound (numpy on the device's matrices vs numpy on the oracle's): %.3g; oracle LDLT vs numpy on its own matrices %.3g" % (gf_window, gf_oracle_solver))
+    # triangle: device -> numpy(device matrices) -> numpy(oracle matrices) -> oracle
+    assert gf <= 1.1 * (gf_solver + gf_window + gf_oracle_solver) + 1e-9, (gf, gf_solver, gf_window, gf_oracle_solver)
+    assert gf < (2e-3 if I.P >= 2000 else 2e-2), gf                              # outer sanity bar by window size (measured <= 1.4e-3 at config B, <= 9.8e-3 on 300-point windows)
     # same x into both back-substitutions isolates that kernel
     sto, _ = ob.backsub(xo)
     std, rc = ctx.ba_backsub(xo)
