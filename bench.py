@@ -189,6 +189,21 @@ def multi_window_bench(device_id, seed, config, steps, half, s_list=(2, 4, 8, 16
         dt = time.perf_counter() - t0
         Rs = sum(w[3] for w in wins[:S])
         out["runs"].append({"S": S, "value": Rs * steps / dt, "unit": "point-residuals/s", "ms_per_round": 1e3 * dt / steps, "residuals_per_round": Rs, "rounds": steps})
+    # the same windows as TWO half-batches on two streams (each half's five launches on the stream of its first context): the solve launch
+    # of one half — S/2 workgroups on a 256-CU chip — runs beside the residual / accumulate launches of the other half
+    out["two_streams"] = []
+    for S in [s_ for s_ in s_list if s_ >= 4]:
+        ha = [w[1] for w in wins[:S // 2]]; hb = [w[1] for w in wins[S // 2:S]]
+        for _ in range(60):
+            device.ba_iteration_batch(ha, lam); device.ba_iteration_batch(hb, lam)
+        ha[0].sync(); hb[0].sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            device.ba_iteration_batch(ha, lam); device.ba_iteration_batch(hb, lam)
+        ha[0].sync(); hb[0].sync()
+        dt = time.perf_counter() - t0
+        Rs = sum(w[3] for w in wins[:S])
+        out["two_streams"].append({"S": S, "value": Rs * steps / dt, "unit": "point-residuals/s", "ms_per_round": 1e3 * dt / steps, "rounds": steps})
     try:
         from tests import resident_check as RC
         ctxs = [w[1] for w in wins]
@@ -421,7 +436,11 @@ def sequence_bench(device_id, seed, want_cpu):
             out["parity_checked"] = True
             out["parity_ok"] = len(rep["failures"]) == 0
             out["parity"] = {"stages_replayed": rep["stages"], "worst": rep["worst"], "flips": rep["flips"], "failures": rep["failures"][:8],
-                             "counts": {k: v for k, v in rep.items() if isinstance(v, int)}}
+                             "counts": {k: v for k, v in rep.items() if isinstance(v, int)},
+                             "run_yardstick": rep.get("run_yardstick", []),
+                             "run_yardstick_note": "runs whose distance from the oracle exceeded the fixed bars and were held against the oracle's own response to "
+                                                   "rounding-sized noise instead: within the fixed bars of at least one member of {oracle with inverse depths perturbed by "
+                                                   "1e-7 (4 draws), oracle built with the Release flags} (tests/sequence_check.py)"}
             out["cpu_baseline"] = {"kind": "port", "cores": 1, "seconds": float(sum(chk.oracle_seconds.values())), "per_stage_s": {k: float(v) for k, v in chk.oracle_seconds.items()},
                                    "sample": "the oracle's replay of every stage of the same sequence from the product's state (tests/sequence_check.py: oracle/*.c through ctypes, "
                                              "checker build -O2, one thread; includes the checker's own set-up of each stage's window)"}
@@ -627,6 +646,12 @@ def roofline_object(S, M, lin_ms_local):
                               "attached to the k_ba_linearize dispatch itself (hipExtLaunchKernelGGL): the kernel's begin / end "
                               "timestamps, the quantity rocprofv3 --kernel-trace reports",
             "rocprof_avg_us": rocprof_us}
+    if traffic and lin_ms_local > 0:
+        # what the memory system actually moved for this launch (PMC, corrected as the guide prescribes) against the same roof: the residual
+        # kernel's gathers pull whole 128-byte lines (5.1 per residual from the tiled fp16 image, 7.9 from a row-major one) for 276 / 468
+        # algorithmic bytes, so the line traffic, not the algorithmic figure, is what the memory side sees
+        roof["traffic_frac"] = traffic / (lin_ms_local * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["traffic_over_algorithmic"] = traffic / max(R * bytes_per_residual, 1)
     valu = _valu_roof(config, R, 1e3 * lin_ms_local)
     if valu is not None:
         roof["also_bound_by"] = [valu]
