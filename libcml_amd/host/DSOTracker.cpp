@@ -269,10 +269,13 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
     int levels = std::min(pyramidLevels, 5);
     if (maxLevelOverride >= 0) levels = std::min(levels, maxLevelOverride + 1);
     const double refE[3] = {referenceExposure.a, referenceExposure.b, referenceExposure.t}, initE[3] = {initialExposure.a, initialExposure.b, initialExposure.t};
-    // Policy (measured, tools/probe_tracker_opt.py): one workgroup per hypothesis makes a launch cost ~1 ms whatever the number of
-    // hypotheses, a host-driven optimize ~0.3 ms.  In steady tracking the FIRST hypothesis passes the early exit of :306-309, so it
-    // is tried alone through the host-driven loop; only when it does not end the search are the remaining ones run side by side.
-    {
+    // Policy.  Round 2 (one workgroup per hypothesis: ~1 ms per launch whatever the number of hypotheses, a host-driven optimize ~0.3 ms)
+    // tried the FIRST hypothesis alone through the host-driven loop and launched the batch only when it did not end the search.  Since
+    // round 3 a hypothesis is spread over up to 8 workgroups and the whole batch costs what one device-resident optimize costs (0.21 ms
+    // for one, 0.24 ms for fifty: DESIGN §7) — less than the 14-25 evaluations of a host-driven loop with a launch, a mapped-memory poll
+    // and host algebra each (0.40 ms per frame in the sequence of round 4).  So the batch runs at once; the hypotheses behind the
+    // reference's early exit are computed speculatively and discarded by the replay below.  mBatchedFirstAlone restores the old order.
+    if (mBatchedFirstAlone) {
         SE3 T0 = hyp[0];
         Exposure e0 = initialExposure;
         mLastResidual = Residual();
