@@ -744,6 +744,43 @@ def main():
     lin_ms_max = group.max(M["lin_ms"])
     ss_ms_max = group.max(M["ss_ms"])
 
+    # N > 1: the unit north_star fans out is a sequence shard — every rank also runs ONE 48-frame shard (its own seeded sequence) through the
+    # host mirror between two barriers; the line carries the aggregate frames/s (weak scaling, no data-path collective)
+    seq_shards = None
+    if world > 1 and not args.no_extras:
+        # (every collective below is reached by every rank whatever happens on one of them: a rank that fails keeps meeting the others)
+        ok, err, seq, sctx, st, dts = 1.0, None, None, None, {"tracking_lost": 0}, 0.0
+        try:
+            from libcml_amd import device, sequence
+            seq = sequence.make_sequence(n_frames=48, seed=0x5EED, shard=rank)
+            sctx = device.Ctx(device_id=local_rank, max_frames=8, max_points=8192, max_residuals=8192 * 8)
+        except Exception as e:
+            ok, err = 0.0, repr(e)
+        if group.sum(ok) == world:
+            for rep in range(2):                                          # first pass warms pools and code objects
+                group.barrier()
+                t0 = time.perf_counter()
+                try:
+                    pipe = sequence.DirectPipeline(sctx, seq.K, seq.w, seq.h, seq.levels)
+                    st = pipe.run(seq)
+                    sctx.sync()
+                    pipe.close()
+                except Exception as e:
+                    ok, err = 0.0, repr(e)
+                group.barrier()
+                dts = group.max(time.perf_counter() - t0)
+        all_ok = group.sum(ok) == world
+        lost = int(round(group.sum(float(st["tracking_lost"]))))
+        if sctx is not None:
+            try:
+                sctx.close()
+            except Exception:
+                pass
+        if all_ok:
+            seq_shards = {"shards": world, "frames_per_shard": 48, "seconds_max_over_ranks": dts, "frames_per_s_total": 48.0 * world / dts, "tracking_lost_total": lost,
+                          "note": "one seeded 48-frame sequence shard per rank through libcml_amd/sequence.py (bootstrap included), barrier on both sides, max over ranks"}
+        else:
+            seq_shards = {"error": err or "a rank failed"}
     _dbg('reductions done')
     if rank == 0:
         rep_ms = M["rep_ms"]
@@ -761,6 +798,8 @@ def main():
         out.update(parity)
         if parity.get("parity_checked") and not parity.get("parity_ok"):
             out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
+        if seq_shards is not None:
+            out["sequence_shards"] = seq_shards
         extras = not args.no_extras and world == 1 and args.config == "B"
         if extras:
             try:

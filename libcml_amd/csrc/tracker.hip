@@ -201,20 +201,54 @@ __global__ void k_cd_splat(const double* __restrict__ pts, int n, int w0, int h0
     if (owner[pix] == i) { idepth[pix] = (float)((double)0.0f + p.x); wsum[pix] = 0.0f + p.weight; }     // the maps start at zero
     else late[atomicAdd(n_late, 1)] = i;
 }
-__global__ void k_cd_late(const double* __restrict__ pts, int w0, int h0, float* idepth, float* wsum, int* late, const int* n_late) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const int m = *n_late;
-    for (int a = 1; a < m; a++) {                                     // insertion sort: a handful of entries
-        const int key = late[a];
-        int b = a - 1;
-        while (b >= 0 && late[b] > key) { late[b + 1] = late[b]; b--; }
-        late[b + 1] = key;
+// The later points of shared pixels, applied in point-index order per pixel (the reference's sequential `+=`, TR.cpp:550-553).  Up to
+// CD_LATE_MAX of them: ranked by index in LDS (a comparison per pair, no sort loop), then every pixel's chain walked by the thread of
+// its FIRST late point — chains of different pixels are independent.  (Round 4: the one-thread insertion sort + walk over global memory
+// this replaces took 84 us on average, up to 160 us, per keyframe of the sequence test.)  Beyond CD_LATE_MAX: the one-thread form.
+#define CD_LATE_MAX 2048
+__global__ __launch_bounds__(1024) void k_cd_late(const double* __restrict__ pts, int w0, int h0, float* idepth, float* wsum, int* late, const int* n_late) {
+    if (blockIdx.x != 0) return;
+    const int m = *n_late, tid = threadIdx.x;
+    if (m > CD_LATE_MAX) {
+        if (tid != 0) return;
+        for (int a = 1; a < m; a++) {
+            const int key = late[a];
+            int b = a - 1;
+            while (b >= 0 && late[b] > key) { late[b + 1] = late[b]; b--; }
+            late[b + 1] = key;
+        }
+        for (int a = 0; a < m; a++) {
+            const CdPoint p = cd_point(pts, late[a], w0, h0);
+            const int pix = p.u + w0 * p.v;
+            idepth[pix] = (float)((double)idepth[pix] + p.x);
+            wsum[pix] += p.weight;
+        }
+        return;
     }
-    for (int a = 0; a < m; a++) {
-        const CdPoint p = cd_point(pts, late[a], w0, h0);
-        const int pix = p.u + w0 * p.v;
-        idepth[pix] = (float)((double)idepth[pix] + p.x);
-        wsum[pix] += p.weight;
+    __shared__ int s_raw[CD_LATE_MAX], s_idx[CD_LATE_MAX], s_pix[CD_LATE_MAX];
+    for (int a = tid; a < m; a += blockDim.x) s_raw[a] = late[a];
+    __syncthreads();
+    for (int a = tid; a < m; a += blockDim.x) {                       // rank = number of late points with a smaller index (indices are distinct)
+        const int key = s_raw[a];
+        int rank = 0;
+        for (int b = 0; b < m; b++) rank += s_raw[b] < key;
+        const CdPoint p = cd_point(pts, key, w0, h0);
+        s_idx[rank] = key; s_pix[rank] = p.u + w0 * p.v;
+    }
+    __syncthreads();
+    for (int a = tid; a < m; a += blockDim.x) {
+        const int pix = s_pix[a];
+        bool head = true;
+        for (int b = 0; b < a && head; b++) head = s_pix[b] != pix;
+        if (!head) continue;
+        float id = idepth[pix], ws = wsum[pix];
+        for (int c = a; c < m; c++) {
+            if (s_pix[c] != pix) continue;
+            const CdPoint p = cd_point(pts, s_idx[c], w0, h0);
+            id = (float)((double)id + p.x);
+            ws += p.weight;
+        }
+        idepth[pix] = id; wsum[pix] = ws;
     }
 }
 __global__ void k_cd_down(const float* __restrict__ idm, const float* __restrict__ wm, int wm1, int wl, int hl,
@@ -504,7 +538,7 @@ int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int l
         CML_CHECK(c, hipMemsetAsync(n_late, 0, 4, c->stream));
         k_cd_owner<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner);
         k_cd_splat<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner, L.idepth[0], L.wsum[0], late, n_late);
-        k_cd_late<<<1, 64, 0, c->stream>>>(dpts.as<double>(), py->lv[0].w, py->lv[0].h, L.idepth[0], L.wsum[0], late, n_late);
+        k_cd_late<<<1, 1024, 0, c->stream>>>(dpts.as<double>(), py->lv[0].w, py->lv[0].h, L.idepth[0], L.wsum[0], late, n_late);
     }
     CML_CHECK(c, hipMemcpyAsync(L.wbak[0], L.wsum[0], 4 * sz0, hipMemcpyDeviceToDevice, c->stream));   // backupWeightSum, level 0
     for (int l = 1; l < levels; l++) {

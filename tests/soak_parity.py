@@ -354,9 +354,42 @@ def tolerance_families(n):
     return int(bad)
 
 
+def sequence_family(n):
+    """a sequence shard per seed (28 frames at the BASELINE image shape, window 2 -> 7), every stage replayed by the oracle
+    (tests/sequence_check.py); prints the worst deviations over all sequences and how often the noise-ensemble yardstick was needed"""
+    from libcml_amd import sequence
+    from tests import sequence_check as SC
+    worst, fails, yard, runs, flips, resid = {}, [], 0, 0, 0, 0
+    for s_ in range(n):
+        seq = sequence.make_sequence(n_frames=28, seed=0x5EED + 101 * s_, shard=s_)
+        ctx = device.Ctx(max_frames=8, max_points=8192, max_residuals=8192 * 8)
+        chk = SC.SequenceChecker(ctx, seq.K, seq.w, seq.h, seq.levels, strict=False)
+        pipe = sequence.DirectPipeline(ctx, seq.K, seq.w, seq.h, seq.levels, observer=chk)
+        try:
+            st = pipe.run(seq)
+        finally:
+            pipe.close(); ctx.close()
+        rep = chk.report
+        for k, v in rep["worst"].items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        fails += ["seq %d: %s" % (s_, f) for f in rep["failures"]]
+        yard += rep.get("run_yardstick_used", 0); runs += rep.get("runs", 0)
+        flips += rep["flips"]["run_residual_sets"]; resid += rep["flips"]["run_residuals"]
+        print("sequence %d: %d frames, %d keyframes, max window %d, %d frames marginalised, tracking lost %d, failures %d, yardstick runs %d" % (
+            s_, st["frames"], st["keyframes"], st["max_window"], st["marginalized_frames"], st["tracking_lost"], len(rep["failures"]), rep.get("run_yardstick_used", 0)))
+    print("sequence family: %d sequences, %d runs (%d held against the noise ensemble), residual decisions differing %d of %d" % (n, runs, yard, flips, resid))
+    for k in sorted(worst):
+        print("   worst %-24s %.2e" % (k, worst[k]))
+    for f in fails:
+        print("   FAILURE " + f)
+    return int(bool(fails))
+
+
 fail = 0
 if "--tolerance" in sys.argv:
     sys.exit(tolerance_families(n_seeds))
+if "--sequence" in sys.argv:
+    sys.exit(sequence_family(n_seeds))
 for name, fn in (("BA linearize/apply records", ba), ("marginalisation res_toZero", marginalisation), ("tracker pyramid/lists/warped", tracker), ("tracer trace + activation", tracer), ("initializer calcResAndGS", initializer), ("local BA structure-only", lba), ("resident residual kernels vs record kernel", resident),
                  ("resident loop vs ORACLE replay", resident_oracle), ("batched iterations vs solo iterations", batch_vs_solo)):
     n_ok, units = 0, 0
