@@ -514,9 +514,10 @@ def measure(S, steps, warmup, group, sync_extra=None, lam=1e-5):
     for _ in range(warmup):
         ctx.ba_iteration_async(lam)
     # every stride-th step carries the profile events on its dispatches (an event-carrying dispatch costs the pipeline ~3 us: at
-    # stride 4 the contract region ran 1.4 us per step behind the regions without events); short runs sample every second step so
-    # that the driver's --steps 20 line still averages 10 dispatches
-    stride = 8 if steps >= 80 else (2 if steps >= 4 else 1)
+    # stride 4 the contract region ran 1.4 us per step behind the regions without events; at stride 2 a --steps 20 run lost 3 us per
+    # step).  The contract region therefore samples sparsely (5 dispatches at --steps 20) and a region of its own, after it, carries
+    # events on EVERY residual-kernel dispatch (`launch_us_all_steps`, K samples)
+    stride = 8 if steps >= 80 else (4 if steps >= 16 else (2 if steps >= 4 else 1))
     ctx.profile_stride(stride)
     ctx.profile_select(1)                                                 # contract region: events on the roofline kernel's dispatch only
     ctx.profile_enable((steps + stride - 1) // stride)
@@ -538,13 +539,20 @@ def measure(S, steps, warmup, group, sync_extra=None, lam=1e-5):
     ctx.profile_enable((steps + stride - 1) // stride)
     shard.timed_region(group, sync, run_steps)
     _lin0, ss_ms, _empty, _n = ctx.profile_read()
+    # every residual-kernel dispatch of K further steps (not the contract region: the events cost the pipeline)
+    ctx.profile_stride(1)
+    ctx.profile_select(1)
+    ctx.profile_enable(steps)
+    shard.timed_region(group, sync, run_steps)
+    lin_all_ms, _s, _e, n_all = ctx.profile_read()
+    ctx.profile_stride(stride)
     ctx.profile_select(3)
     # spread: the contract region above is ONE sample (K steps can be a millisecond); eight more regions of the same K steps, same
     # protocol, reported beside it (not used for `value`)
     ctx.profile_enable(0)
     rep_ms = sorted(1e3 * shard.timed_region(group, sync, run_steps) / steps for _ in range(8))
     st = ctx.ba_states()
-    return {"dt": dt, "lin_ms": lin_ms, "ss_ms": ss_ms, "n_samples": n_samples, "rep_ms": rep_ms,
+    return {"dt": dt, "lin_ms": lin_ms, "ss_ms": ss_ms, "n_samples": n_samples, "rep_ms": rep_ms, "lin_all_ms": lin_all_ms, "n_all": n_all,
             "n_good": int(st["good"].sum()),
             "n_sampled": int((st["state"] != 1).sum())}   # residuals of the timed passes that enter the pixel loop and gather texels (OOB is absorbing, BA.cpp:68-72)
 
@@ -650,6 +658,7 @@ def roofline_object(S, M, lin_ms_local):
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": R * bytes_per_residual, "bytes_per_residual": bytes_per_residual,
             "launch_us": 1e3 * lin_ms_local, "launch_samples": M["n_samples"],
+            "launch_us_all_steps": 1e3 * M.get("lin_all_ms", 0.0), "launch_samples_all_steps": M.get("n_all", 0),
             "launch_us_note": "mean over the sampled steps of the timed region of hipEventElapsedTime between the start and stop events "
                               "attached to the k_ba_linearize dispatch itself (hipExtLaunchKernelGGL): the kernel's begin / end "
                               "timestamps, the quantity rocprofv3 --kernel-trace reports",

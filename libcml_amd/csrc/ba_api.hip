@@ -101,8 +101,8 @@ struct ExpandArgs {
     int* point_tgt; int* point_pos; int* point_res;
 };
 __global__ void k_window_expand(ExpandArgs E) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < E.R) {                                               // per residual (device order = pair-sorted)
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = i0; i < E.R; i += gridDim.x * blockDim.x) {     // per residual (device order = pair-sorted)
         const int p = E.r_point[i], host = E.pt_host[p], q = host + E.r_target[i] * E.N;
         E.r_host[i] = host;
         E.r_new_state[i] = CMLHIP_RES_OUTLIER;
@@ -114,7 +114,7 @@ __global__ void k_window_expand(ExpandArgs E) {
         oc[0] = c4[0]; oc[1] = c4[1]; ow[0] = w4[0]; ow[1] = w4[1];
     }
     const int slots = E.P * E.pt_stride;
-    for (int s = i; s < slots; s += gridDim.x * blockDim.x) {    // per point slot: the residual in it (device id), its target | lin << 8
+    for (int s = i0; s < slots; s += gridDim.x * blockDim.x) {   // per point slot: the residual in it (device id), its target | lin << 8
         const int p = s / E.pt_stride, j = s - p * E.pt_stride, o = E.by_point_off[p];
         if (j < E.by_point_off[p + 1] - o) {
             const int r = E.by_point[o + j];
