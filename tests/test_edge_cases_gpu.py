@@ -230,3 +230,105 @@ def test_window_is_invalidated_when_its_images_go_away():
             ctx.ba_linearize()
     finally:
         ctx.close()
+
+
+def _resident_window(config="small", shard=0):
+    from libcml_amd import host, synth
+    W = synth.make_window(config, shard=shard)
+    ctx = device.Ctx(max_frames=max(W.N, 2), max_points=W.P, max_residuals=W.P * W.N)
+    ba = host.window_to_host_ba(ctx, W, image_id_base=100 * (shard + 1), levels=1)
+    ba.set_param("iterations", 1)
+    assert ba.run(), ba.last_error()
+    ctx.refresh_window_size()
+    assert ba.begin_resident(), ba.last_error()
+    return W, ctx, ba
+
+
+def _snapshot(ctx):
+    st = ctx.ba_states()
+    fs, pre = ctx.ba_resident_state()
+    return (st["state"].tobytes(), st["energy"].tobytes(), ctx.ba_get_idepth().tobytes(), ctx.ba_jpjdf().tobytes(), bytes(fs), pre.tobytes())
+
+
+def test_resident_prior_edge_cases():
+    """cmlhip_ba_set_resident_prior (round 4): refused before the resident state exists; NULL switches it off; an all-zero prior is the
+    prior-free iteration in every bit ((bL + 0) + bA and (HL + 0) + HA are exact); a real prior changes the step; cmlhip_ba_set_resident_state
+    switches it off again."""
+    import ctypes as C
+    W, ctx, ba = _resident_window()
+    n = 8 * W.N + 4
+    try:
+        base = []
+        for _ in range(3):
+            ctx.ba_iteration_async(1e-5)
+        base = _snapshot(ctx)
+    finally:
+        ba.close(); ctx.close()
+    W, ctx, ba = _resident_window()
+    try:
+        Z = np.zeros((n, n)); z = np.zeros(n)
+        ctx.ck(ctx.L.cmlhip_ba_set_resident_prior(ctx.h, Z.ctypes.data_as(C.POINTER(C.c_double)), z.ctypes.data_as(C.POINTER(C.c_double))))
+        for _ in range(3):
+            ctx.ba_iteration_async(1e-5)
+        assert _snapshot(ctx) == base, "a zero prior must not change a bit"
+    finally:
+        ba.close(); ctx.close()
+    W, ctx, ba = _resident_window()
+    try:
+        rng = np.random.default_rng(5)
+        Q = rng.standard_normal((n, n)) * 300.0
+        HM = Q @ Q.T; bM = rng.standard_normal(n) * 1e3
+        ctx.ck(ctx.L.cmlhip_ba_set_resident_prior(ctx.h, HM.ctypes.data_as(C.POINTER(C.c_double)), bM.ctypes.data_as(C.POINTER(C.c_double))))
+        ctx.ck(ctx.L.cmlhip_ba_set_resident_prior(ctx.h, None, None))                       # ... and off again
+        for _ in range(3):
+            ctx.ba_iteration_async(1e-5)
+        assert _snapshot(ctx) == base, "NULL must switch the prior off"
+        ctx.ck(ctx.L.cmlhip_ba_set_resident_prior(ctx.h, HM.ctypes.data_as(C.POINTER(C.c_double)), bM.ctypes.data_as(C.POINTER(C.c_double))))
+        ctx.ba_iteration_async(1e-5)
+        assert _snapshot(ctx) != base
+    finally:
+        ba.close(); ctx.close()
+    # call order: the resident state first
+    I = S.make_inputs("tiny")
+    ctx = D.make_ctx(I)
+    try:
+        Z = np.zeros((8 * I.N + 4, 8 * I.N + 4)); z = np.zeros(8 * I.N + 4)
+        rc = ctx.L.cmlhip_ba_set_resident_prior(ctx.h, Z.ctypes.data_as(C.POINTER(C.c_double)), z.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == abi.ERR_STATE
+        rc = ctx.L.cmlhip_ba_set_frame_b0(ctx.h, None)
+        assert rc == abi.ERR_INVALID
+    finally:
+        ctx.close()
+    c2 = device.Ctx(max_frames=4, max_points=10, max_residuals=10)
+    try:
+        b0 = np.zeros(4, np.float32)
+        assert c2.L.cmlhip_ba_set_frame_b0(c2.h, b0.ctypes.data_as(C.POINTER(C.c_float))) == abi.ERR_STATE      # no window uploaded
+    finally:
+        c2.close()
+    assert abi.ERR_TIMEOUT == 6
+
+
+def test_closing_pass_retires_what_it_removes():
+    """cmlhip_ba_finish_keyframe = linearizeAll(true): every active residual that is not good afterwards is removed (BA.cpp:1595-1598) — on the
+    device too (state OOB, absorbing), so that tryMarginalize's pass over a point cannot revive it (found by tests/test_sequence_gpu.py)."""
+    from libcml_amd import host, synth
+    W = synth.make_window("medium", idepth_noise=0.2)            # poor depths: a good share of the residuals ends OUTLIER / OOB
+    ctx = device.Ctx(max_frames=W.N, max_points=W.P, max_residuals=W.P * W.N)
+    ba = host.window_to_host_ba(ctx, W)
+    try:
+        assert ba.run(), ba.last_error()
+        st, alive, good = ba.residual_states()
+        dead = alive == 0
+        assert dead.sum() > 20 and (alive == 1).sum() > 100
+        ctx.refresh_window_size()
+        dev = ctx.ba_states()
+        assert np.all(dev["state"][dead] == 1) and np.all(dev["good"][dead] == 0)          # retired = OOB on the device
+        # a pass over EVERY point (what tryMarginalize does for its candidates): the retired residuals stay out
+        A = ba.algebra()
+        ain = (A["adH"], A["adT"], A["adHTd"], np.zeros(4), A["prior"], A["dprior"], np.full(4, 5e9))
+        ng = ctx.ba_relinearize_points(np.arange(ctx.P, dtype=np.int32), *ain)
+        dev2 = ctx.ba_states()
+        assert np.all(dev2["state"][dead] == 1) and np.all(dev2["good"][dead] == 0)
+        assert ng == int(dev2["good"].sum()) and ng <= int((alive == 1).sum())
+    finally:
+        ba.close(); ctx.close()
