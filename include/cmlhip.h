@@ -169,7 +169,10 @@ int cmlhip_tracker_eval(cmlhip_ctx* ctx, uint64_t new_image_id, int level,
  * level pass exceeds 1.5 x that of the best try so far (TR.cpp:183-189) — only shortens a try: the kernel records the rmse of
  * every level pass (pass_level / pass_rmse) and the caller applies the rule afterwards while replaying the winner selection of
  * DSOTracker.h:262-313 (cml_amd::DSOTracker::trackWithMotionModelBatched).
- * ref_exposure = {a, b, exposure time} of the reference, init_exposure = {a, b, exposure time} every try starts from. */
+ * ref_exposure = {a, b, exposure time} of the reference, init_exposure = {a, b, exposure time} every try starts from.
+ * A hypothesis is spread over G workgroups (G = 8, 4, 2 or 1: as many as keep the whole launch resident, asked of the device); the
+ * sums of a level are formed in parts that depend on the level's size alone, in a fixed order, so a hypothesis gives the same bits
+ * whatever batch it travels in.  CMLHIP_ERR_TIMEOUT: a workgroup never met its partners (the launch was not co-resident); results void. */
 #define CMLHIP_TRACKER_MAX_STEPS 256
 typedef struct { double R[9], t[3]; } cmlhip_tracker_hypothesis;
 typedef struct {

@@ -22,6 +22,7 @@ using cml_amd::SE3;
 #define TO_WAVES (TO_THREADS / 64)
 #define TO_LD 17
 #define TO_NRED 56
+#define TO_PARTS 8                   // parts of a level with more than split_min reference points (fixed: the sums must not depend on G)
 typedef float to_float4 __attribute__((ext_vector_type(4)));
 
 struct TrkOptArgs {
@@ -37,7 +38,7 @@ struct TrkOptArgs {
     // them then run the identical Levenberg-Marquardt algebra on identical numbers, no second exchange; smaller levels are evaluated
     // whole by every workgroup (no exchange at all)
     int G, split_min;
-    float* xch;                                        // [n_hyp][2 parities][G][64] 8-byte words {sum | launch number, exchange number}
+    float* xch;                                        // [n_hyp][2 parities][TO_PARTS][64] 8-byte words {sum | launch number, exchange number}
     int epoch;                                         // launch number of this context (16 bits used)
     int* tick;                                         // [n_hyp][G]
     int* late;                                         // mapped host word: set when an exchange gave up waiting (a workgroup of the hypothesis never became resident)
@@ -376,40 +377,44 @@ __device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3
 // all lanes: computeResidual + computeHessian over the level's list (the per-point arithmetic and the reduction layout of
 // k_tracker_eval, tracker.hip); leaves the 56 sums in s_red
 // the sums of this workgroup's part -> the sums of the level, in every workgroup of the hypothesis (see TrkOptArgs::G)
-__device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, const float mine, const int epoch, int* __restrict__ late_flag) {
-    // Every sum travels as ONE self-validating device-scope word {value | seq << 32} (past the non-coherent caches; valid on its own): the
-    // writers neither wait for acknowledgements nor publish a ticket, the readers poll the G words of their sum directly and add them in
-    // workgroup order.  (First form: device-scope stores, a release fence — an L2 write-back —, barrier, ticket; readers polled the G
-    // tickets, fenced (acquire: an L2 invalidation) and then fetched the sums: two fences and a dependent trip more per exchange.)
+__device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, const float* __restrict__ s_part, const int epoch, int* __restrict__ late_flag) {
+    // Every sum of every PART travels as ONE self-validating device-scope word {value | seq << 32} (past the non-coherent caches; valid on
+    // its own): the writers neither wait for acknowledgements nor publish a ticket, the readers poll the eight words of their sum directly
+    // and add them in PART order (round 4: the parts are a property of the level — eight, whatever G is — so the sums of a hypothesis do
+    // not depend on the batch it travels in; a workgroup owns the parts s = g, g + G, ...).
+    // (First form: device-scope stores, a release fence — an L2 write-back —, barrier, ticket; readers polled the tickets, fenced (acquire:
+    // an L2 invalidation) and then fetched the sums: two fences and a dependent trip more per exchange.)
     // A workgroup can only write the sums of exchange seq + 2 — the next use of this parity's slots — after it has read every
-    // workgroup's words of seq + 1, which a workgroup still reading seq has not written yet: the slots are never overwritten under a reader.
-    // Only wave 0 takes part (the 56 sums are its lanes' values) and nothing goes through LDS: no workgroup barrier in the exchange.
+    // part's words of seq + 1, which a workgroup still reading seq has not written yet: the slots are never overwritten under a reader.
+    // Only wave 0 takes part (the 56 sums are its lanes' values) and nothing goes through LDS but its own part sums: no workgroup barrier in the exchange.
     (void)tick;
     const int tid = threadIdx.x;
-    unsigned long long* base = reinterpret_cast<unsigned long long*>(xch) + (size_t)(seq & 1) * G * 64;
+    unsigned long long* base = reinterpret_cast<unsigned long long*>(xch) + (size_t)(seq & 1) * TO_PARTS * 64;
     const unsigned tagv = ((unsigned)epoch << 16) | ((unsigned)seq & 0xffffu);        // launch number | exchange number: words of an earlier call never match
     const unsigned long long tag = (unsigned long long)tagv << 32;
-    if (tid < TO_NRED) __hip_atomic_store(base + (size_t)g * 64 + tid, tag | (unsigned)__float_as_int(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < TO_NRED)
+        for (int sp = g, k = 0; sp < TO_PARTS; sp += G, k++)
+            __hip_atomic_store(base + (size_t)sp * 64 + tid, tag | (unsigned)__float_as_int(s_part[k * 64 + tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float v = 0.f;
     bool late = false;
     if (tid < TO_NRED) {
-        // the G words of a sum are requested TOGETHER and polled as a set (G <= 8): one round trip per poll round — polled one after the
-        // other each word was a dependent device-scope load of its own, G round trips even when everything had arrived
+        // the eight words of a sum are requested TOGETHER and polled as a set: one round trip per poll round — polled one after the
+        // other each word was a dependent device-scope load of its own, eight round trips even when everything had arrived
         int spins = 0;
-        for (int q0 = 0; q0 < G && !late; q0 += 8) {                       // (sets of eight: G <= 8 is one set)
-            unsigned long long w[8];
-            while (true) {
-                bool all = true;
+        while (true) {
+            unsigned long long w[TO_PARTS];
+            bool all = true;
 #pragma unroll
-                for (int q = 0; q < 8; q++) w[q] = q0 + q < G ? __hip_atomic_load(base + (size_t)(q0 + q) * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            for (int q = 0; q < TO_PARTS; q++) w[q] = __hip_atomic_load(base + (size_t)q * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int q = 0; q < 8; q++) all = all && (unsigned)(w[q] >> 32) == tagv;
-                if (all) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { late = true; break; }           // never spin forever: the level then fails (no terms)
+            for (int q = 0; q < TO_PARTS; q++) all = all && (unsigned)(w[q] >> 32) == tagv;
+            if (all) {
+#pragma unroll
+                for (int q = 0; q < TO_PARTS; q++) v += __int_as_float((int)(unsigned)w[q]);       // part order, from zero
+                break;
             }
-#pragma unroll
-            for (int q = 0; q < 8; q++) if (q0 + q < G) v += __int_as_float((int)(unsigned)w[q]);
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { late = true; break; }           // never spin forever: the level then fails (no terms)
         }
     }
     if (__ballot(late)) {                                              // reported to the host as CMLHIP_ERR_TIMEOUT: a scheduling problem, not a tracking failure
@@ -420,111 +425,128 @@ __device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __res
 }
 
 template <bool HALF>
-__device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red,
+__device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red, float* s_part,
                         const int g, const int G, const int split_min, float* xch, int* tick, int& seq, const int epoch, int* late_flag) {
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
-    to_float4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int Ge = (G > 1 && E.n > split_min) ? G : 1;       // parts of this level (1: every workgroup evaluates all of it)
-    for (int base = (Ge > 1 ? g : 0) * TO_THREADS; base < E.n; base += Ge * TO_THREADS) {
-        const int i = base + tid;
-        float va[16], vb[16];
+    // The parts of a level are fixed by its SIZE: eight for a level with more than split_min reference points (part s = the chunks s, s + 8,
+    // s + 16, ... of TO_THREADS points), one otherwise — NOT by G.  A workgroup evaluates the parts s = g, g + G, ... (G in {1, 2, 4, 8});
+    // the level's sums are the part sums added in part order by every workgroup.  So a hypothesis gives the same bits alone (G = 8),
+    // among 50 (G = 4) or among 200 (G = 1): ADVICE round 3.  A one-part level is evaluated whole by every workgroup, without exchange.
+    const int NP = E.n > split_min ? TO_PARTS : 1;
+    int src = -1;                                                       // wave 0: which tile entry this lane sums
+    if (tid < 45) {
+        int k = tid, r = 0;
+        while (k >= 9 - r) { k -= 9 - r; r++; }
+        src = r * 16 + (r + k);
+    } else if (tid <= 50) src = 9 * 16 + 10 + (tid - 45);              // E sT sRT sN numTerms numSaturated
+    else if (tid == 51) src = 10 * 16 + 9;                              // numRobust
+    else if (tid == 52) src = 11 * 16 + 9;                              // numWarped
+    int kown = 0;
+    for (int sp = (NP > 1 ? g : 0); sp < NP; sp += (NP > 1 ? G : 1), kown++) {
+        to_float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int base = sp * TO_THREADS; base < E.n; base += NP * TO_THREADS) {
+            const int i = base + tid;
+            float va[16], vb[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) { va[k] = 0.f; vb[k] = 0.f; }
-        if (i < E.n) {
-            va[9] = 1.f; vb[9] = 1.f;
-            const float4 q = reinterpret_cast<const float4*>(E.uvic)[i];
-            const float x = q.x, y = q.y, id = q.z, refColor = q.w;
-            if (isfinite(refColor)) {                                           // TR.cpp:301-303
-                float pt[3];
+            for (int k = 0; k < 16; k++) { va[k] = 0.f; vb[k] = 0.f; }
+            if (i < E.n) {
+                va[9] = 1.f; vb[9] = 1.f;
+                const float4 q = reinterpret_cast<const float4*>(E.uvic)[i];
+                const float x = q.x, y = q.y, id = q.z, refColor = q.w;
+                if (isfinite(refColor)) {                                           // TR.cpp:301-303
+                    float pt[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) pt[k] = (E.RKi[k * 3] * x + (E.RKi[k * 3 + 1] * y + E.RKi[k * 3 + 2] * 1.0f)) + E.t[k] * id;
-                const float u = pt[0] / pt[2], vv = pt[1] / pt[2];
-                const float Ku = E.fxl * u + E.cxl, Kv = E.fyl * vv + E.cyl;
-                const float new_idepth = id / pt[2];
-                if (E.level == 0 && (i % 32) == 0) {                           // flow statistic, TR.cpp:313-344
-                    float a[3], b[3], c[3];
+                    for (int k = 0; k < 3; k++) pt[k] = (E.RKi[k * 3] * x + (E.RKi[k * 3 + 1] * y + E.RKi[k * 3 + 2] * 1.0f)) + E.t[k] * id;
+                    const float u = pt[0] / pt[2], vv = pt[1] / pt[2];
+                    const float Ku = E.fxl * u + E.cxl, Kv = E.fyl * vv + E.cyl;
+                    const float new_idepth = id / pt[2];
+                    if (E.level == 0 && (i % 32) == 0) {                           // flow statistic, TR.cpp:313-344
+                        float a[3], b[3], c[3];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        const float kp = E.Ki[k * 3] * x + (E.Ki[k * 3 + 1] * y + E.Ki[k * 3 + 2] * 1.0f);
-                        a[k] = kp + E.t[k] * id; b[k] = kp - E.t[k] * id;
-                        c[k] = (E.RKi[k * 3] * x + (E.RKi[k * 3 + 1] * y + E.RKi[k * 3 + 2] * 1.0f)) - E.t[k] * id;
-                    }
-                    const float KuT = E.fxl * (a[0] / a[2]) + E.cxl, KvT = E.fyl * (a[1] / a[2]) + E.cyl;
-                    const float KuT2 = E.fxl * (b[0] / b[2]) + E.cxl, KvT2 = E.fyl * (b[1] / b[2]) + E.cyl;
-                    const float Ku3 = E.fxl * (c[0] / c[2]) + E.cxl, Kv3 = E.fyl * (c[1] / c[2]) + E.cyl;
-                    float sT = 0, sRT = 0;
-                    sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-                    sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-                    sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-                    sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-                    vb[11] = sT; vb[12] = sRT; vb[13] = 2.f;
-                }
-                if (Ku > 2 && Kv > 2 && Ku < E.w - 3 && Kv < E.h - 3 && new_idepth > 0) {     // TR.cpp:346
-                    const int ix = (int)Ku, iy = (int)Kv;
-                    const float dx = Ku - (float)ix, dy = Kv - (float)iy, dxdy = dx * dy;
-                    const float w00 = 1 - dx - dy + dxdy, w01 = dx - dxdy, w10 = dy - dxdy, w11 = dxdy;
-                    const size_t i1 = (size_t)iy * E.w + ix;
-                    const float4 ta = to_texel<HALF>(E.img, i1), tb = to_texel<HALF>(E.img, i1 + 1);
-                    const float4 tc = to_texel<HALF>(E.img, i1 + E.w), td = to_texel<HALF>(E.img, i1 + E.w + 1);
-                    const float h0 = ta.x * w00 + tb.x * w01 + tc.x * w10 + td.x * w11;
-                    const float h1 = ta.y * w00 + tb.y * w01 + tc.y * w10 + td.y * w11;
-                    const float h2 = ta.z * w00 + tb.z * w01 + tc.z * w10 + td.z * w11;
-                    if (isfinite(h0) && isfinite(h1) && isfinite(h2)) {
-                        const float residual = h0 - (float)(E.a0 * refColor + E.a1);
-                        const float hw = fabs((double)residual) < E.huber_d ? 1.0f : (float)(E.huber_d / fabs((double)residual));
-                        if (fabs((double)residual) > E.cutoff_d) {
-                            vb[10] = E.maxEnergy; vb[14] = 1.f; vb[15] = 1.f;                  // E, numTerms, numSaturated
-                        } else {
-                            vb[10] = hw * residual * residual * (2 - hw); vb[14] = 1.f; va[11] = 1.f;   // E, numTerms, numWarped
-                            const float ddx = h1 * E.fxh, ddy = h2 * E.fyh;                      // computeHessian lanes, TR.cpp:443-470
-                            vb[0] = new_idepth * ddx;
-                            vb[1] = new_idepth * ddy;
-                            vb[2] = 0.0f - (new_idepth * (u * ddx + vv * ddy));
-                            vb[3] = 0.0f - ((u * vv * ddx) + ddy * (1.0f + vv * vv));
-                            vb[4] = (u * vv * ddy) + (ddx * (1.0f + u * u));
-                            vb[5] = u * ddy - vv * ddx;
-                            vb[6] = E.a_h * (E.b0 - refColor);
-                            vb[7] = -1.0f;
-                            vb[8] = residual;
-#pragma unroll
-                            for (int r = 0; r < 9; r++) va[r] = vb[r] * hw;
+                        for (int k = 0; k < 3; k++) {
+                            const float kp = E.Ki[k * 3] * x + (E.Ki[k * 3 + 1] * y + E.Ki[k * 3 + 2] * 1.0f);
+                            a[k] = kp + E.t[k] * id; b[k] = kp - E.t[k] * id;
+                            c[k] = (E.RKi[k * 3] * x + (E.RKi[k * 3 + 1] * y + E.RKi[k * 3 + 2] * 1.0f)) - E.t[k] * id;
                         }
-                        if (fabs((double)residual) <= E.cutoff_base_d) va[10] = 1.f;           // numRobust
+                        const float KuT = E.fxl * (a[0] / a[2]) + E.cxl, KvT = E.fyl * (a[1] / a[2]) + E.cyl;
+                        const float KuT2 = E.fxl * (b[0] / b[2]) + E.cxl, KvT2 = E.fyl * (b[1] / b[2]) + E.cyl;
+                        const float Ku3 = E.fxl * (c[0] / c[2]) + E.cxl, Kv3 = E.fyl * (c[1] / c[2]) + E.cyl;
+                        float sT = 0, sRT = 0;
+                        sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+                        sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+                        sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+                        sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+                        vb[11] = sT; vb[12] = sRT; vb[13] = 2.f;
+                    }
+                    if (Ku > 2 && Kv > 2 && Ku < E.w - 3 && Kv < E.h - 3 && new_idepth > 0) {     // TR.cpp:346
+                        const int ix = (int)Ku, iy = (int)Kv;
+                        const float dx = Ku - (float)ix, dy = Kv - (float)iy, dxdy = dx * dy;
+                        const float w00 = 1 - dx - dy + dxdy, w01 = dx - dxdy, w10 = dy - dxdy, w11 = dxdy;
+                        const size_t i1 = (size_t)iy * E.w + ix;
+                        const float4 ta = to_texel<HALF>(E.img, i1), tb = to_texel<HALF>(E.img, i1 + 1);
+                        const float4 tc = to_texel<HALF>(E.img, i1 + E.w), td = to_texel<HALF>(E.img, i1 + E.w + 1);
+                        const float h0 = ta.x * w00 + tb.x * w01 + tc.x * w10 + td.x * w11;
+                        const float h1 = ta.y * w00 + tb.y * w01 + tc.y * w10 + td.y * w11;
+                        const float h2 = ta.z * w00 + tb.z * w01 + tc.z * w10 + td.z * w11;
+                        if (isfinite(h0) && isfinite(h1) && isfinite(h2)) {
+                            const float residual = h0 - (float)(E.a0 * refColor + E.a1);
+                            const float hw = fabs((double)residual) < E.huber_d ? 1.0f : (float)(E.huber_d / fabs((double)residual));
+                            if (fabs((double)residual) > E.cutoff_d) {
+                                vb[10] = E.maxEnergy; vb[14] = 1.f; vb[15] = 1.f;                  // E, numTerms, numSaturated
+                            } else {
+                                vb[10] = hw * residual * residual * (2 - hw); vb[14] = 1.f; va[11] = 1.f;   // E, numTerms, numWarped
+                                const float ddx = h1 * E.fxh, ddy = h2 * E.fyh;                      // computeHessian lanes, TR.cpp:443-470
+                                vb[0] = new_idepth * ddx;
+                                vb[1] = new_idepth * ddy;
+                                vb[2] = 0.0f - (new_idepth * (u * ddx + vv * ddy));
+                                vb[3] = 0.0f - ((u * vv * ddx) + ddy * (1.0f + vv * vv));
+                                vb[4] = (u * vv * ddy) + (ddx * (1.0f + u * u));
+                                vb[5] = u * ddy - vv * ddx;
+                                vb[6] = E.a_h * (E.b0 - refColor);
+                                vb[7] = -1.0f;
+                                vb[8] = residual;
+#pragma unroll
+                                for (int r = 0; r < 9; r++) va[r] = vb[r] * hw;
+                            }
+                            if (fabs((double)residual) <= E.cutoff_base_d) va[10] = 1.f;           // numRobust
+                        }
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int k = 0; k < 16; k++) { s_a[wv][l][k] = va[k]; s_b[wv][l][k] = vb[k]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // wave-private tiles, in-order LDS: compiler ordering only
-        __builtin_amdgcn_wave_barrier();
-        const int e = l & 15, kq = l >> 4;
+            for (int k = 0; k < 16; k++) { s_a[wv][l][k] = va[k]; s_b[wv][l][k] = vb[k]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // wave-private tiles, in-order LDS: compiler ordering only
+            __builtin_amdgcn_wave_barrier();
+            const int e = l & 15, kq = l >> 4;
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const float av = s_a[wv][4 * m + kq][e], bv = s_b[wv][4 * m + kq][e];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            for (int m = 0; m < 16; m++) {
+                const float av = s_a[wv][4 * m + kq][e], bv = s_b[wv][4 * m + kq][e];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        if (kown) __syncthreads();                                      // wave 0 has read the tiles of the part before
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) s_tile[wv][(4 * (l >> 4) + rg) * 16 + (l & 15)] = acc[rg];
+        __syncthreads();
+        // from here on only wave 0 works on the sums: it adds the waves' tiles (wave order) and keeps the part's 56 sums
+        if (tid < 64) {
+            float v = 0.f;
+            if (src >= 0) for (int w = 0; w < TO_WAVES; w++) v += s_tile[w][src];
+            s_part[kown * 64 + tid] = v;
+        }
     }
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) s_tile[wv][(4 * (l >> 4) + rg) * 16 + (l & 15)] = acc[rg];
-    __syncthreads();
-    // from here to the next control barrier only wave 0 works: it adds the waves' tiles, exchanges the level's sums with the other
-    // workgroups of the hypothesis and leaves them in s_red for its own to_finish — no further workgroup barrier per evaluation
-    // (there were five: 512-thread barriers are a third of a microsecond each)
-    if (Ge > 1) seq++;                                                  // (every thread keeps the exchange number)
+    const bool xchg = NP > 1 && G > 1;
+    if (xchg) seq++;                                                    // (every thread keeps the exchange number)
     if (tid < 64) {
-        int src = -1;
-        if (tid < 45) {
-            int k = tid, r = 0;
-            while (k >= 9 - r) { k -= 9 - r; r++; }
-            src = r * 16 + (r + k);
-        } else if (tid <= 50) src = 9 * 16 + 10 + (tid - 45);          // E sT sRT sN numTerms numSaturated
-        else if (tid == 51) src = 10 * 16 + 9;                          // numRobust
-        else if (tid == 52) src = 11 * 16 + 9;                          // numWarped
-        float v = 0.f;
-        if (src >= 0) for (int w = 0; w < TO_WAVES; w++) v += s_tile[w][src];
-        if (Ge > 1) v = to_exchange(xch, tick, g, G, seq, v, epoch, late_flag);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // s_part: written and read by this wave only
+        __builtin_amdgcn_wave_barrier();
+        float v;
+        if (xchg) v = to_exchange(xch, tick, g, G, seq, s_part, epoch, late_flag);
+        else {                                                          // every part is this workgroup's own: the same sum, part by part, from zero
+            v = 0.f;
+            for (int k = 0; k < kown; k++) v += s_part[k * 64 + tid];
+        }
         if (tid < TO_NRED) s_red[tid] = v;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // read back by other lanes of this wave only: compiler ordering
         __builtin_amdgcn_wave_barrier();
@@ -561,7 +583,7 @@ __device__ __forceinline__ int to_ctrl(const ToState& S, int& cseq) {
 
 // lane 0 books the time since the last mark as algebra, runs the evaluation, books it as evaluation
 #define TO_TIMED_EVAL() do { if (tid == 0) { const long long t_ = wall_clock64(); S.t_alg += t_ - S.t_mark; S.t_mark = t_; } \
-        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, g, A.G, A.split_min, xch, tick, seq, A.epoch, A.late); \
+        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, s_part, g, A.G, A.split_min, xch, tick, seq, A.epoch, A.late); \
         if (tid == 0) { const long long t_ = wall_clock64(); S.t_eval += t_ - S.t_mark; S.t_mark = t_; } } while (0)
 
 enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
@@ -571,12 +593,13 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ float s_a[TO_WAVES][64][TO_LD], s_b[TO_WAVES][64][TO_LD];
     __shared__ float s_tile[TO_WAVES][256];
     __shared__ float s_red[64];
+    __shared__ float s_part[TO_PARTS * 64];
     __shared__ ToEval ev;
     __shared__ ToState S;
     __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
     const int tid = threadIdx.x, hyp = blockIdx.x / A.G, g = blockIdx.x % A.G;
     cmlhip_tracker_opt_result* out = (g == 0 && A.out_host) ? A.out_host + hyp : A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical; the first one's goes straight to the host)
-    float* xch = A.xch + (size_t)hyp * 2 * 2 * A.G * 64;          // (8-byte words: see to_exchange)
+    float* xch = A.xch + (size_t)hyp * 2 * 2 * TO_PARTS * 64;     // (8-byte words, [2 parities][TO_PARTS][64]: see to_exchange)
     int* tick = A.tick + (size_t)hyp * A.G;
     int seq = 0, cseq = 0;
     const int maxIterations[5] = {10, 20, 50, 50, 50};                               // TR.cpp:23
@@ -781,12 +804,14 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     }
     const int capacity = c->trk_capacity[half];
     static const char* e_g = getenv("CMLHIP_TRACKER_G");                  // development: force G (still clamped to what fits)
-    int G = e_g ? atoi(e_g) : std::min(8, capacity / n_hyp);
+    int G = e_g ? atoi(e_g) : std::min(TO_PARTS, capacity / n_hyp);
     if (G < 1) G = 1;
     if ((long long)n_hyp * G > capacity) G = std::max(1, capacity / n_hyp);          // G = 1: no workgroup waits for another, any launch size is fine
+    G = std::min(G, TO_PARTS);
+    G = G >= 8 ? 8 : (G >= 4 ? 4 : (G >= 2 ? 2 : 1));                                // a divisor of TO_PARTS: a workgroup owns whole parts
     A.G = G; A.split_min = 2 * TO_THREADS;
     if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp * G))) return rc;
-    const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)G * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
+    const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)TO_PARTS * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
     if ((rc = cml_ensure(c, c->trk_xch, xch_bytes + tick_bytes))) return rc;
     // hypotheses in, results out through ONE mapped, coherent host block: the kernel reads the 96 bytes of its hypothesis and the first
     // workgroup of each hypothesis writes its result there — no staged upload before the launch and no copy back behind it (each was a

@@ -99,26 +99,23 @@ def test_batched_track_with_motion_model(setup):
             assert abs(b["lastCoarseRMSE"] / o["achieved"] - 1) < 1e-2
 
 
-def test_batch_size_changes_the_partition_not_the_answer(setup):
-    """the number of workgroups a hypothesis is spread over follows the batch size (G = min(8, resident capacity /
-    hypotheses): 8 for one, 5 for fifty, 2 for a hundred), and a level with more than 1024 reference points is summed in G parts — the
-    fp32 sums of the SAME hypothesis therefore differ in their last bits between batch sizes (and from the host-driven loop, whose sums
-    come from k_tracker_eval).  That is rounding, not a different answer: whatever the batch size, the hypothesis must converge to the same
-    pose at the bar every other comparison of this file uses (3e-4 / 1e-3, the loop's own stopping rule), with the same correctness
-    flags, and a batch must not depend on the ORDER of its hypotheses."""
+def test_a_hypothesis_does_not_depend_on_its_batch(setup):
+    """ADVICE round 3, closed in round 4: the number of workgroups a hypothesis is spread over follows the batch size (G = 8 for one, 4 for
+    fifty, 2 for a hundred, 1 beyond the resident capacity), but the PARTS a level is summed in are fixed by the level's size — eight, in a
+    fixed order, whichever workgroup evaluates them.  So the same hypothesis must give the same BITS alone, among 3, 50, 100 or 300, and
+    wherever it stands in the batch."""
     P, ctx, trk = setup
     base = TS.perturbed(P, (0.004, -0.003, 0.002), (0.03, -0.02, 0.025))
-    outs = []
-    for n_hyp in (1, 3, 50, 100):
-        hyps = [base] + [TS.perturbed(P, (0.004 + 1e-4 * i, -0.003, 0.002), (0.03, -0.02 + 1e-3 * i, 0.025)) for i in range(1, n_hyp)]
-        res = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps)
-        r = res[0]
-        outs.append((np.array(r.R[:]).reshape(3, 3), np.array(r.t[:]), r.a, r.b, bool(r.isCorrect), bool(r.tooManySaturated)))
-        if n_hyp == 50:                                           # the same 50 in reverse order: hypothesis 0 is now the last workgroup group
+    keep = 8 * 14 + 8          # R, t, a, b and the two flags
+    ref = None
+    for n_hyp in (1, 3, 50, 100, 300):
+        hyps = [base] + [TS.perturbed(P, (0.004 + 1e-4 * (i % 40), -0.003, 0.002), (0.03, -0.02 + 1e-3 * (i % 25), 0.025)) for i in range(1, n_hyp)]
+        r = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps)[0]
+        b = bytes(bytearray(bytes(r))[:keep]) + bytes(r.E) + bytes(r.numTermsInE) + bytes(r.step_accept[:r.n_steps])
+        if ref is None:
+            ref = b
+            assert r.isCorrect and r.n_steps >= 5
+        assert b == ref, "hypothesis 0 differs in a batch of %d" % n_hyp
+        if n_hyp == 50:                                           # the same 50 in reverse order: hypothesis 0 is now the last group of workgroups
             rev = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps[::-1])[-1]
-            assert bytes(bytearray(bytes(rev))[:8 * 14]) == bytes(bytearray(bytes(r))[:8 * 14])      # R, t, a, b: identical bits (same G, same partition)
-    R0, t0 = outs[0][0], outs[0][1]
-    for R, t, a, b, ok, sat in outs[1:]:
-        assert np.abs(R - R0).max() < 3e-4 and np.abs(t - t0).max() < 1e-3 * max(1.0, np.abs(t0).max())
-        assert abs(a - outs[0][2]) < 1e-3 and abs(b - outs[0][3]) < 0.5
-        assert (ok, sat) == (outs[0][4], outs[0][5])
+            assert bytes(bytearray(bytes(rev))[:keep]) == ref[:keep]
