@@ -756,7 +756,7 @@ def main():
     # N > 1: the unit north_star fans out is a sequence shard — every rank also runs ONE 48-frame shard (its own seeded sequence) through the
     # host mirror between two barriers; the line carries the aggregate frames/s (weak scaling, no data-path collective)
     seq_shards = None
-    if world > 1 and not args.no_extras:
+    if (world > 1 or os.environ.get("CML_BENCH_FORCE_SEQ_SHARDS")) and not args.no_extras:      # (the variable: exercise this path with one rank)
         # (every collective below is reached by every rank whatever happens on one of them: a rank that fails keeps meeting the others)
         ok, err, seq, sctx, st, dts = 1.0, None, None, None, {"tracking_lost": 0}, 0.0
         try:
@@ -848,11 +848,21 @@ def main():
                     out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", "")) + " — the config-B window WITHOUT the 1000 ORB residuals of config C"
             except Exception as e:      # the checker must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "point-residuals/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+        line = json.dumps(out)
     else:
+        line = None
         ba.close(); ctx.close()
     group.barrier()
     group.close()
+    if line is not None:
+        # the JSON line goes out LAST: RCCL prints a version banner through C stdio when the first communicator forms, which would otherwise
+        # land behind a line printed earlier (stdout is block-buffered under a pipe)
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -44,9 +44,12 @@ class Group:
 
     def barrier(self):
         if self.dist is not None:
-            # a 1-element all-reduce is the barrier (works for nccl and gloo alike)
-            x = self._tensor(1.0)
-            self.dist.all_reduce(x)
+            # a 1-element all-reduce is the barrier (works for nccl and gloo alike).  The tensor is allocated ONCE: the closing barrier of a
+            # timed region sits inside the region (the bench contract), and a fresh device tensor per call is a host-to-device copy on top
+            # of the collective (tools/probe_barrier.py: 41 us per barrier with one rank, most of it not the all-reduce)
+            if getattr(self, "_bar", None) is None:
+                self._bar = self._tensor(0.0, dtype=self.torch.float32)
+            self.dist.all_reduce(self._bar)
             if self.backend == "nccl":
                 self.torch.cuda.synchronize()
 
