@@ -434,10 +434,13 @@ bool DSOBundleAdjustment::uploadWindow() {
 }
 
 bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut) {   // BA.cpp:1497-1646
+    const auto TL0 = std::chrono::steady_clock::now();
+    auto lapL = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "      [linearizeAll] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TL0).count()); };
     std::vector<cmlhip_ba_pair> pairs;
     framePairs(pairs);
     int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
     if (rc) return fail("cmlhip_ba_set_pairs", rc);
+    lapL("pairs set");
     cmlhip_ba_lin_result lr;
     const int R = (int)mActive.size();
     std::vector<int> st, ns;
@@ -459,6 +462,7 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
         rc = cmlhip_ba_linearize(mCtx, &lr);
         if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_linearize", rc);
     }
+    lapL("device call done");
     energy[0] = lr.energy; energy[1] = 0; energy[2] = 0;
     mFrames.back().frameEnergyTH = lr.new_frame_energy_th;                // setNewFrameEnergyTH, :1610
     if (fixLinearization) {
@@ -482,6 +486,7 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
         for (int p = 0; p < (int)mPoints.size(); p++)                               // points left without residual, :1638-1640
             if (mPoints[p].alive && nres[p] == 0) { mPoints[p].alive = false; mOutliers.push_back(p); }
     }
+    lapL("bookkeeping done");
     return true;
 }
 
