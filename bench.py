@@ -499,6 +499,8 @@ def setup_window(config, seed, rank, local_rank):
     _, _, R = ctx.refresh_window_size()                                   # the window was uploaded by the C++ host mirror
     if not ba.begin_resident():                                           # frame states, adjoints, priors, gauge basis -> device
         raise RuntimeError("begin_resident failed: " + ba.last_error())
+    if os.environ.get("BENCH_ARITH_RELAXED"):                              # development: A/B of CMLHIP_ARITH_RELAXED (the bit-exact gate then reports a mismatch)
+        ctx.ba_set_arithmetic(True)
     return {"config": config, "wcfg": wcfg, "hybrid": hybrid, "half": half, "W": W, "ctx": ctx, "ba": ba, "R": R, "ind": ind}
 
 
@@ -698,9 +700,45 @@ def secondary_config(config, seed, local_rank, steps, warmup):
         out.update(par)
         if par.get("parity_checked") and not par.get("parity_ok"):
             out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
+        if S["R"] >= 36 * 1024 and not S["hybrid"]:
+            out["relaxed_arithmetic"] = relaxed_arithmetic_leg(S, steps, warmup, out)
         return out
     finally:
         S["ba"].close(); S["ctx"].close()
+
+
+def relaxed_arithmetic_leg(S, steps, warmup, exact):
+    """The same window, same protocol, with cmlhip_ba_set_arithmetic(CMLHIP_ARITH_RELAXED) — the opt-in mode of the throughput-regime residual
+    kernel (include/cmlhip.h) — after the exact figures and their bit-for-bit gate: K1 and the step beside the exact mode's, and the pass after
+    the timed region held against the oracle at the stated tolerances (tests/test_relaxed_arithmetic_gpu.py: 1e-4 relative, classification
+    identical up to a reported count)."""
+    ctx = S["ctx"]
+    try:
+        from tests import resident_check as RC
+        ctx.ba_set_arithmetic(True)
+        M = measure(S, steps, warmup, _NoGroup())
+        replay = RC.make_replay(ctx, S["ba"], S["W"])
+        ctx.sync()
+        pre = ctx.ba_states()
+        ctx.ba_iteration_async(1e-5)
+        ctx.sync()
+        rep = RC.compare_pass_tolerant(ctx, replay, pre)
+        replay.close()
+        flips = max(rep["new_state_flips"], rep["state_flips"], rep["good_flips"])
+        ok = (flips <= max(2, S["R"] // 5000) and max(rep["energy_rel"], rep["new_energy_rel"], rep["new_energy_wo_rel"], rep["jpjdf_rel_p999"]) < 1e-4
+              and rep["jpjdf_rel"] < 1e-3 and rep["center_abs"] < 1e-3)
+        k1 = 1e3 * M["lin_ms"]
+        return {"mode": "CMLHIP_ARITH_RELAXED (opt-in; the headline and the figures above are CMLHIP_ARITH_EXACT)",
+                "value": S["R"] * steps / M["dt"], "ms_per_step": 1e3 * M["dt"] / steps, "linearize_kernel_us": k1,
+                "linearize_kernel_us_exact": exact["linearize_kernel_us"], "kernel_ratio": k1 / exact["linearize_kernel_us"],
+                "roofline_frac": roofline_object(S, M, M["lin_ms"])["frac"],
+                "tolerance_checked": True, "tolerance_ok": bool(ok), "tolerance": rep,
+                "tolerance_note": "the residual pass after the timed region replayed by the oracle from the device's state: energies relative to the oracle's (bar 1e-4), JpJdF rows against their largest entry (99.9 % within 1e-4, every row within 1e-3), "
+                                  "centre projections in pixels (bar 1e-3), residuals classified differently (bar R / 5000)"}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        ctx.ba_set_arithmetic(False)
 
 
 def main():

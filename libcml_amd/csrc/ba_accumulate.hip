@@ -2135,6 +2135,7 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda) {
         cmlhip_ctx* c = ctxs[k];
         BatchWin& w = H[k];
         memset(&w, 0, sizeof w);
+        if (c->arith_relaxed != ctxs[0]->arith_relaxed) { ctxs[0]->err = "cmlhip_ba_iteration_batch: the windows of a batch must share one arithmetic mode (cmlhip_ba_set_arithmetic)"; return CMLHIP_ERR_INVALID; }
         BAArgs& A = w.A;
         cml_make_ba_args(c, A);
         A.fuse_apply = 1;                                    // the step is always accepted here (forceAccept, BA.h:265)

@@ -256,28 +256,37 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     // ---- SoA staging + upload: everything below is staged and leaves in ONE copy + one scatter / fill kernel (cml_h2d_batch_flush)
     cml_h2d_batch_begin(c);
     struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};   // error returns close the batch
-    std::vector<float> fx(P), fy(P), fz(P), fp(P), col(8 * (size_t)P), wgt(8 * (size_t)P);
-    std::vector<double> idp(P);
-    std::vector<int> hst(P);
-    for (int p = 0; p < P; p++) {
-        fx[p] = points[p].x; fy[p] = points[p].y; idp[p] = points[p].idepth; fz[p] = points[p].idepth_zero; fp[p] = points[p].prior;
-        hst[p] = points[p].host;
-        memcpy(&col[8 * (size_t)p], points[p].colors, 32); memcpy(&wgt[8 * (size_t)p], points[p].weights, 32);
+    // the SoA arrays are written where the packed copy starts from (cml_h2d_stage); the vectors below exist only when the ring has no room
+    struct Staged { void* p = nullptr; std::vector<unsigned char> fb; void* dst = nullptr; size_t bytes = 0; };
+    auto stage = [&](Staged& s, DevBuf& buf, size_t bytes) -> void* {
+        s.dst = buf.p; s.bytes = bytes;
+        s.p = cml_h2d_stage(c, buf.p, bytes);
+        if (!s.p) { s.fb.resize(bytes ? bytes : 1); s.p = s.fb.data(); }
+        return s.p;
+    };
+    auto commit = [&](Staged& s) -> int { return s.fb.empty() ? CMLHIP_OK : cml_h2d(c, s.dst, s.fb.data(), s.bytes); };
+    Staged s_fx, s_fy, s_fz, s_fp, s_col, s_wgt, s_idp, s_hst, s_rp, s_rt, s_rs, s_rl, s_bp;
+    {
+        float* fx = (float*)stage(s_fx, c->pt_x, 4 * (size_t)P); float* fy = (float*)stage(s_fy, c->pt_y, 4 * (size_t)P);
+        double* idp = (double*)stage(s_idp, c->pt_idepth, 8 * (size_t)P); float* fz = (float*)stage(s_fz, c->pt_idepth_zero, 4 * (size_t)P);
+        float* fp = (float*)stage(s_fp, c->pt_prior, 4 * (size_t)P); int* hst = (int*)stage(s_hst, c->pt_host, 4 * (size_t)P);
+        float* col = (float*)stage(s_col, c->pt_colors, 32 * (size_t)P); float* wgt = (float*)stage(s_wgt, c->pt_weights, 32 * (size_t)P);
+        for (int p = 0; p < P; p++) {
+            fx[p] = points[p].x; fy[p] = points[p].y; idp[p] = points[p].idepth; fz[p] = points[p].idepth_zero; fp[p] = points[p].prior;
+            hst[p] = points[p].host;
+            memcpy(&col[8 * (size_t)p], points[p].colors, 32); memcpy(&wgt[8 * (size_t)p], points[p].weights, 32);
+        }
+        int* rp = (int*)stage(s_rp, c->r_point, 4 * (size_t)R); int* rt = (int*)stage(s_rt, c->r_target, 4 * (size_t)R);
+        int* rs = (int*)stage(s_rs, c->r_state, 4 * (size_t)R); unsigned char* rl = (unsigned char*)stage(s_rl, c->r_lin, (size_t)R);
+        int* bp = (int*)stage(s_bp, c->by_point, 4 * (size_t)R);
+        for (int k = 0; k < R; k++) { const int r = c->h_caller_of[k]; rp[k] = res[r].point; rt[k] = res[r].target; rs[k] = res[r].state; rl[k] = res[r].is_linearized != 0; }
+        for (int i = 0; i < R; i++) bp[i] = c->h_dev_of[c->h_by_point[i]];      // device lists hold r': a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
+        for (Staged* s : {&s_fx, &s_fy, &s_idp, &s_fz, &s_fp, &s_hst, &s_col, &s_wgt, &s_rp, &s_rt, &s_rs, &s_rl, &s_bp}) if ((rc = commit(*s))) return rc;
     }
-    std::vector<int> rp(R), rt(R), rs(R);
-    std::vector<unsigned char> rl(R);
-    for (int k = 0; k < R; k++) { const int r = c->h_caller_of[k]; rp[k] = res[r].point; rt[k] = res[r].target; rs[k] = res[r].state; rl[k] = res[r].is_linearized != 0; }
 #define UP(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
     UP(c->frames, fd);
-    UP(c->pt_x, fx); UP(c->pt_y, fy); UP(c->pt_idepth, idp); UP(c->pt_idepth_zero, fz); UP(c->pt_prior, fp); UP(c->pt_host, hst);
-    UP(c->pt_colors, col); UP(c->pt_weights, wgt);
-    UP(c->r_point, rp); UP(c->r_target, rt); UP(c->r_state, rs); UP(c->r_lin, rl);
-    {   // device lists hold r': a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
-        std::vector<int> bp(R);
-        for (int i = 0; i < R; i++) bp[i] = c->h_dev_of[c->h_by_point[i]];
-        UP(c->by_point_off, c->h_by_point_off); UP(c->by_point, bp);
-        UP(c->by_pair_off, c->h_by_pair_off);
-    }
+    UP(c->by_point_off, c->h_by_point_off);
+    UP(c->by_pair_off, c->h_by_pair_off);
     {
         int mx = 1;
         for (int q = 0; q < N * N; q++) mx = std::max(mx, c->h_by_pair_off[q + 1] - c->h_by_pair_off[q]);
@@ -377,6 +386,12 @@ int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) { CML_DEV(c);
     return cml_h2d(c, c->frames.p, fd.data(), sizeof(FrameDev) * c->N);
 }
 
+int cmlhip_ba_set_arithmetic(cmlhip_ctx* c, int mode) { CML_DEV(c);
+    if (!c || (mode != CMLHIP_ARITH_EXACT && mode != CMLHIP_ARITH_RELAXED)) return CMLHIP_ERR_INVALID;
+    c->arith_relaxed = mode == CMLHIP_ARITH_RELAXED;
+    return CMLHIP_OK;
+}
+
 // DSOFrame::getB0 follows state_zero (DSOFrame.h:197-199): run()'s epilogue re-anchors the newest frame (setEvalPT, BA.cpp:885-894), so
 // the b0 uploaded with the window is stale for residuals HOSTED by that frame from then on (the closing linearizeAll(true), tryMarginalize)
 struct B0Args { float b0[CMLHIP_MAX_FRAMES]; };
@@ -452,11 +467,14 @@ __global__ void k_ba_retire(BAArgs A) {
 }
 int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* state, int* new_state, float* energy, float* new_energy,
                               float* new_energy_wo, unsigned char* is_good, double* idepth, float* point_acc) { CML_DEV(c);
-    int rc = cmlhip_ba_linearize_async(c);
+    int rc = ba_check(c, true);
     if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;        // (pair codes and selectors of the residuals this pass does not evaluate: state OOB)
     BAArgs A;
     cml_make_ba_args(c, A);
-    cml_launch_apply(c, A, 1);
+    A.fuse_apply = 1;                                        // linearize + applyRes(r, true) in ONE pass over the residuals (BA.cpp:1568-1569: nothing sits between them)
+    cml_launch_linearize(c, A);
+    cml_launch_lin_finish(c, A);
     CML_CHECK(c, hipGetLastError());
     const size_t R = c->R, P = c->P;
     LinSummary S;

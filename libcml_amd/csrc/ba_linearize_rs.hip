@@ -59,6 +59,11 @@ __device__ __forceinline__ double rs_rcp_refined(const double z) {
     r = __builtin_fma(r, e, r);
     return r;
 }
+// RELAX arithmetic (cmlhip_ba_set_arithmetic): v_rcp_f64 + ONE Newton step (relative error ~2^-50 from the ~2^-26 seed)
+__device__ __forceinline__ double rs_rcp_once(const double z) {
+    const double r = __builtin_amdgcn_rcp(z);
+    return __builtin_fma(r, __builtin_fma(-z, r, 1.0), r);
+}
 __device__ __forceinline__ double rs_div(const double x, const double z, const double r) {
     const double q = x * r;
     const double rem = __builtin_fma(-z, q, x);
@@ -137,7 +142,7 @@ template <int LDM> struct RsRow<false, LDM> {
 #define RS_S_D0 21
 #define RS_S_D1 40
 
-template <bool HALF, int WPE, int WPB, int LDM>
+template <bool HALF, int WPE, int WPB, int LDM, bool RELAX = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE))) void k_ba_lin_rs(BAArgs A, RsArgs X) {
 #define RS_BATCH 0
 #include "ba_linearize_rs_body.inc"
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
 }
 // several windows per launch (cmlhip_ba_iteration_batch, windows uploaded in the throughput regime: tiles of 64): gridDim.y = window, the
 // body of the solo kernel on the window's own argument block
-template <bool HALF, int WPE, int WPB, int LDM>
+template <bool HALF, int WPE, int WPB, int LDM, bool RELAX = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE))) void k_ba_lin_rs_batch(const BatchRs* __restrict__ W) {
     const BatchRs __attribute__((address_space(4)))* rs_window = (const BatchRs __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
     const BatchRs& rs_w = *(const BatchRs*)rs_window;
@@ -158,7 +163,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE)))
 }
 int cml_launch_linearize_rs_batch(cmlhip_ctx* c0, const void* dev_records, int S, int max_blocks) {
     const BatchRs* W = static_cast<const BatchRs*>(dev_records);
-    if (c0->lim.texel_format == CMLHIP_TEXEL_F16) k_ba_lin_rs_batch<true, 3, 4, 0><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
+    // (the arithmetic mode of a batch is its first context's: cmlhip_ba_iteration_batch refuses windows that differ)
+    if (c0->lim.texel_format == CMLHIP_TEXEL_F16) {
+        if (c0->arith_relaxed) k_ba_lin_rs_batch<true, 3, 4, 0, true><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
+        else k_ba_lin_rs_batch<true, 3, 4, 0><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
+    } else if (c0->arith_relaxed) k_ba_lin_rs_batch<false, 2, 1, 0, true><<<dim3(max_blocks, S), 64, 0, c0->stream>>>(W);
     else k_ba_lin_rs_batch<false, 2, 1, 0><<<dim3(max_blocks, S), 64, 0, c0->stream>>>(W);
     return CMLHIP_OK;
 }
@@ -212,6 +221,11 @@ int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
     X.ntiles = nt;
     static const char* e_ldm = getenv("CMLHIP_RS_LDM");        // development: 1 = nontemporal texel loads
     const int ldm = e_ldm ? atoi(e_ldm) : 0;
+    if (c->arith_relaxed) {                                 // CMLHIP_ARITH_RELAXED: the throughput-regime kernel only (small windows keep the exact 4-lane kernel)
+        if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs<true, 3, 4, 0, true>), cml_div_up(nt, 4), 256, 0, A, X);
+        else CML_LAUNCH_EV(c, (k_ba_lin_rs<false, 2, 1, 0, true>), nt, 64, 0, A, X);
+        return CMLHIP_OK;
+    }
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) {
         if (ldm == 1 && wpb == 1) CML_LAUNCH_EV(c, (k_ba_lin_rs<true, 3, 1, 1>), nt, 64, 0, A, X);
         else if (ldm == 1) CML_LAUNCH_EV(c, (k_ba_lin_rs<true, 3, 4, 1>), cml_div_up(nt, 4), 256, 0, A, X);

@@ -52,6 +52,18 @@ int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
     CML_CHECK(c, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, c->stream));
     return CMLHIP_OK;
 }
+// Batch mode only: room for `bytes` in the packed block, registered for `dst` — the caller WRITES its array there instead of building it in
+// pageable memory and having cml_h2d copy it (the window upload builds ~0.6 MB of SoA arrays per keyframe).  nullptr: no room / no ring
+// yet / not batching — the caller falls back to cml_h2d.
+void* cml_h2d_stage(cmlhip_ctx* c, void* dst, size_t bytes) {
+    if (!c->h2d_batching || !c->pinned || bytes == 0 || c->pinned_off + bytes > c->pinned_bytes) return nullptr;
+    char* stage = static_cast<char*>(c->pinned) + c->pinned_off;
+    c->h2d_segs.push_back((unsigned long long)(uintptr_t)dst);
+    c->h2d_segs.push_back((unsigned long long)(c->pinned_off - c->h2d_batch_start));
+    c->h2d_segs.push_back((unsigned long long)bytes);
+    c->pinned_off += (bytes + 255) & ~size_t(255);
+    return stage;
+}
 // one workgroup row per segment: 16-byte words, then the byte tail (block offsets and DevBuf bases are 256-byte aligned)
 __global__ void k_h2d_scatter(const unsigned long long* __restrict__ segs, const char* __restrict__ blob) {
     const unsigned long long* S = segs + 3 * (size_t)blockIdx.y;

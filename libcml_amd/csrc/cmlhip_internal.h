@@ -115,6 +115,7 @@ struct cmlhip_ctx {
     DevBuf pair_blocks;                                       // N*N x PAIR_BLK doubles (stitched per-pair blocks)
     DevBuf adH, adT, adHTd, vec_small;                        // adjoints, adHTdeltaF, {cdelta,cprior,prior,delta_prior}
     DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec, Hf, bf;    // (8N+4)^2 / (8N+4) doubles; Hf/bf = final LM system
+    bool arith_relaxed = false;                               // cmlhip_ba_set_arithmetic(CMLHIP_ARITH_RELAXED): see ba_linearize_rs_body.inc
     DevBuf bM_raw; bool resident_prior = false;               // resident loop with the marginalisation prior: mMarginalizedB as handed over; bM then holds bM_raw + HM * delta of the CURRENT frame states (cmlhip_ba_set_resident_prior)
     DevBuf tr_points, tr_pairs, tr_out;
     DevBuf ini_points, ini_partial;          // coarse initializer (initializer.hip)
@@ -174,6 +175,7 @@ struct cmlhip_ctx {
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes);          // grow-only device allocation
 void cml_free(DevBuf& b);
 int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);
+void* cml_h2d_stage(cmlhip_ctx* c, void* dst, size_t bytes);      // batch mode: the staging bytes themselves (nullptr: use cml_h2d)
 // Batched form for the many small arrays of a window upload: between begin and flush every cml_h2d only stages its bytes;
 // flush moves the packed block with ONE copy and scatters it to the destinations with one small kernel.
 void cml_h2d_batch_begin(cmlhip_ctx* c);

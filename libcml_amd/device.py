@@ -73,6 +73,7 @@ PROTOTYPES = {
     "cmlhip_profile_read": (C.c_int, [_ctx, _P(_f), _P(_f), _P(_f), _P(_i)]),
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_frame_b0": (C.c_int, [_ctx, _P(_f)]),
+    "cmlhip_ba_set_arithmetic": (C.c_int, [_ctx, _i]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
     "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
     "cmlhip_ba_linearize": (C.c_int, [_ctx, _P(abi.BALinResult)]),
@@ -222,6 +223,10 @@ class Ctx:
     def ba_set_frame_energy_th(self, th):
         th = np.ascontiguousarray(th, np.float32)
         self.ck(self.L.cmlhip_ba_set_frame_energy_th(self.h, _p(th, _f)))
+
+    def ba_set_arithmetic(self, relaxed):
+        """cmlhip_ba_set_arithmetic: False = CMLHIP_ARITH_EXACT (default), True = CMLHIP_ARITH_RELAXED (throughput-regime residual kernel only)"""
+        self.ck(self.L.cmlhip_ba_set_arithmetic(self.h, 1 if relaxed else 0))
 
     def ba_get_idepth(self):
         out = np.zeros(self.P)

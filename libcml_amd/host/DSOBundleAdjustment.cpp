@@ -400,7 +400,9 @@ bool DSOBundleAdjustment::uploadWindow() {
     }
     mActivePoints.clear();
     mPointSlot.assign(mPoints.size(), -1);
-    std::vector<cmlhip_ba_point> pts;
+    std::vector<cmlhip_ba_point>& pts = mUploadPoints;      // (members: the window-sized arrays are allocated once, not per keyframe)
+    pts.clear();
+    pts.reserve(mPoints.size()); mActivePoints.reserve(mPoints.size());
     for (int p = 0; p < (int)mPoints.size(); p++) {
         if (!mPoints[p].alive) continue;
         const DSOPoint& P = mPoints[p];
@@ -413,7 +415,9 @@ bool DSOBundleAdjustment::uploadWindow() {
         pts.push_back(q);
     }
     mActive.clear();
-    std::vector<cmlhip_ba_residual> rs;
+    std::vector<cmlhip_ba_residual>& rs = mUploadResiduals;
+    rs.clear();
+    rs.reserve(mResiduals.size()); mActive.reserve(mResiduals.size());
     for (int r = 0; r < (int)mResiduals.size(); r++) {
         DSOResidual& R = mResiduals[r];
         if (!R.alive || !mPoints[R.point].alive) continue;

@@ -153,6 +153,7 @@ public:
     void orthogonalize(std::vector<double>& x) const;                                            // BA.cpp:1196-1261
 
 private:
+    std::vector<cmlhip_ba_point> mUploadPoints; std::vector<cmlhip_ba_residual> mUploadResiduals;      // uploadWindow's arrays, kept between keyframes
     bool uploadWindow();
     bool isOOB(int p, const std::vector<int>& toMarg) const;                  // BA.cpp:2515-2554
     void removePoint(int p, bool marginalize, bool sweep = true);             // DSOContext.h:94-111 (sweep: removePointsWithoutResidual behind it, :218-229)
