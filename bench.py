@@ -410,12 +410,12 @@ def sequence_bench(device_id, seed, want_cpu):
         t0 = time.perf_counter()
         stats = pipe.run(seq)
         dt = time.perf_counter() - t0
-        out = (dict(stats), dt, pipe.timing_summary(), list(pipe.run_split), obs, [pipe.history[-1][0].copy(), pipe.history[-1][1].copy()])
+        out = (dict(stats), dt, pipe.timing_summary(), list(pipe.run_split), obs, [pipe.history[-1][0].copy(), pipe.history[-1][1].copy()], pipe.library_summary())
         pipe.close(); ctx.close()
         return out
 
     one_pass()                                                            # warm-up: allocations, pools, code objects
-    stats, dt, stages, split, _o, last = one_pass()
+    stats, dt, stages, split, _o, last, lib = one_pass()
     t_boot = stages.get("bootstrap", {}).get("mean_ms", 0.0) * 1e-3
     R, t = last
     c = -R.T @ t; ct = -seq.R_true[n_frames - 1].T @ seq.t_true[n_frames - 1]
@@ -429,6 +429,11 @@ def sequence_bench(device_id, seed, want_cpu):
            "per_frame_ms": sum(stages[k]["median_ms"] for k in ("pyramid_build", "trackWithMotionModel", "traceNewCoarse") if k in stages),
            "per_keyframe_ms": sum(stages[k]["median_ms"] for k in ("addNewFrame", "activatePoints+addPoints", "run", "makeCoarseDepthL0", "tryMarginalize",
                                                                   "marginalizePointsF", "makeNewTraces", "marginalizeFrames") if k in stages),
+           "library_ms_per_stage": {k: v for k, v in lib.items() if k != "bootstrap"},
+           "library_seconds": float(sum(v["total_ms"] for k, v in lib.items() if k != "bootstrap")) * 1e-3,
+           "library_frames_per_s": (n_frames - 1) / max(float(sum(v["total_ms"] for k, v in lib.items() if k != "bootstrap")) * 1e-3, 1e-9),
+           "library_note": "time inside the library's own calls (C++ host mirror + C ABI, device sync behind each) — frames_per_s above is the wall clock of the Python "
+                           "driver that stands in for the reference's host code around them (map accessors, motion model, pixel selector: out of scope)",
            "run_us_split_median": run_split,
            "run_us_split_note": "host clock inside DSOBundleAdjustment::run at the sliding window size: upload = window build + packed copy; first_pass = linearizeAll + applyRes; "
                                 "resident_state = adjoints / states / prior to the device; enqueue = the iterations' launches; wait_and_readback = the kernels of the "
@@ -439,7 +444,7 @@ def sequence_bench(device_id, seed, want_cpu):
     if want_cpu:
         try:
             from tests import sequence_check as SC
-            stats2, dt2, _st, _sp, chk, _l = one_pass(lambda ctx: SC.SequenceChecker(ctx, seq.K, seq.w, seq.h, seq.levels, strict=False))
+            stats2, dt2, _st, _sp, chk, _l, _lib = one_pass(lambda ctx: SC.SequenceChecker(ctx, seq.K, seq.w, seq.h, seq.levels, strict=False))
             rep = chk.report
             out["parity_checked"] = True
             out["parity_ok"] = len(rep["failures"]) == 0

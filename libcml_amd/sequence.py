@@ -141,6 +141,8 @@ class DirectPipeline:
         self.last_coarse_rmse = 100.0                                # DSOTracker.h:470
         self.n_fid = 0
         self.times = {}                                              # stage -> list of seconds
+        self._poses = None
+        self.lib_times = {}                                          # stage -> seconds inside the library's calls of that stage (see _c)
         self.run_split = []                                          # per keyframe: the host clock of run()'s phases (HostBA.run_timing)
         self.tprm = abi.default_tracer_params()
         self.stats = {"frames": 0, "keyframes": 0, "tracking_lost": 0, "ids_recycled": 0, "max_window": 0, "marginalized_frames": 0}
@@ -152,6 +154,15 @@ class DirectPipeline:
     def _t(self, stage, t0):
         self.ctx.sync()
         self.times.setdefault(stage, []).append(time.perf_counter() - t0)
+
+    def _c(self, stage, fn, *a, **kw):
+        """a call INTO the library (C++ host mirror / C ABI), timed on its own with a device sync behind it: `lib_times` separates the product from
+        this Python driver, which stands in for the reference's own host code around these calls (map accessors, motion model, pixel selector)"""
+        t0 = time.perf_counter()
+        r = fn(*a, **kw)
+        self.ctx.sync()
+        self.lib_times.setdefault(stage, []).append(time.perf_counter() - t0)
+        return r
 
     def _emit(self, stage, **info):
         if self.obs is not None:
@@ -169,10 +180,13 @@ class DirectPipeline:
 
     def kf_poses(self):
         """current (R, t, a, b) of the window's keyframes = frame->getCamera() / getExposure() (PRE_worldToCam, aff_g2l)"""
+        if self._poses is not None and len(self._poses) == len(self.kfs):     # (they move in run() and when frames join / leave: invalidated there)
+            return self._poses
         out = []
         for i in range(len(self.kfs)):
             f = self.ba.frame(i)
             out.append((f["R"].copy(), f["t"].copy(), float(f["ab"][0]), float(f["ab"][1])))
+        self._poses = out
         return out
 
     def _trace_pairs(self, poses, Rn, tn, an, bn):
@@ -204,10 +218,10 @@ class DirectPipeline:
 
     def _make_new_traces(self, kf):
         """DSOTracer::makeNewTraces (DSOTracer.cpp:496-541) with the stand-in pixel selector"""
-        self.trc.compact()                                            # activated / removed points leave the list (removeMapPoint): indices change here only
+        self._c("makeNewTraces", self.trc.compact)                      # activated / removed points leave the list (removeMapPoint): indices change here only
         px = select_pixels(kf["gray"], self.n_immature, self.rng, taken=kf["taken"])
         g, dp, G = _patches(kf["grad0"], px)
-        self.trc.add_points(px.astype(np.float32), kf["fid"], g, dp, G)
+        self._c("makeNewTraces", self.trc.add_points, px.astype(np.float32), kf["fid"], g, dp, G)
         return px
 
     def _coarse_depth(self, kf_index):
@@ -281,7 +295,7 @@ class DirectPipeline:
         """pyramid of the new frame + trackWithMotionModel against the newest keyframe.  Returns (image_id, R, t, a, b, ok)."""
         t0 = time.perf_counter()
         iid = self._take_id()
-        self.ctx.pyramid_build(iid, gray, self.levels)
+        self._c("pyramid_build", self.ctx.pyramid_build, iid, gray, self.levels)
         self._t("pyramid_build", t0)
         t0 = time.perf_counter()
         ref = self.kfs[self.ref]
@@ -289,7 +303,7 @@ class DirectPipeline:
         hyps_w = self._hypotheses()
         hyps = [_rel(Rr, tr, Rw, tw) for Rw, tw in hyps_w]           # reference->getCamera().to(camera)
         ref_exp = [ar, br, 1.0]; init_exp = [self.last_exposure[0], self.last_exposure[1], 1.0]
-        res = self.trk.track_with_motion_model(iid, self.levels, hyps, ref_exp, init_exp, batched=True)
+        res = self._c("trackWithMotionModel", self.trk.track_with_motion_model, iid, self.levels, hyps, ref_exp, init_exp, batched=True)
         self._t("trackWithMotionModel", t0)
         ok = bool(res["haveOneGood"])
         if ok:
@@ -313,7 +327,7 @@ class DirectPipeline:
         pairs = self._trace_pairs(poses, Rn, tn, a, b)
         fids = [kf["fid"] for kf in self.kfs]
         before = self.trc.points() if self.obs is not None else None
-        counts = self.trc.trace_new_coarse(iid, traced_fid, fids, pairs)
+        counts = self._c("traceNewCoarse", self.trc.trace_new_coarse, iid, traced_fid, fids, pairs)
         self._t("traceNewCoarse", t0)
         if self.obs is not None:
             self._emit("trace", image_id=iid, pairs=pairs, frame_ids=fids, traced_fid=traced_fid, before=before, after=self.trc.points(), counts=counts,
@@ -338,8 +352,9 @@ class DirectPipeline:
         t0 = time.perf_counter()
         counts = self._immature_counts()
         exp0 = ba.export() if self.obs is not None else None
-        ba.flag_frames_for_marginalization_v(counts)
-        ba.add_frame(iid, Rn, tn, a, b, 1.0)
+        self._c("addNewFrame", ba.flag_frames_for_marginalization_v, counts)
+        self._c("addNewFrame", ba.add_frame, iid, Rn, tn, a, b, 1.0)
+        self._poses = None
         grad0 = ctx.pyramid_get(iid, 0)
         kf = {"fid": fid, "image_id": iid, "gray": gray, "grad0": grad0, "taken": set()}
         self.kfs.append(kf)
@@ -352,7 +367,7 @@ class DirectPipeline:
         apairs = self._activation_pairs(poses)
         fids = [k_["fid"] for k_ in self.kfs]; iids = [k_["image_id"] for k_ in self.kfs]
         before = self.trc.points() if self.obs is not None else None
-        activated = self.trc.activate_points(fids, iids, self.K, self.w, self.h, apairs)
+        activated = self._c("activatePoints+addPoints", self.trc.activate_points, fids, iids, self.K, self.w, self.h, apairs)
         pts, alive, act, idp = self.trc.points()
         tfids = self.trc.frame_ids()
         if len(activated):
@@ -360,7 +375,7 @@ class DirectPipeline:
             hh = np.array([fids.index(int(f)) for f in tfids[ia]], np.int32)
             for i, h_ in zip(ia, hh):
                 self.kfs[h_]["taken"].add((int(pts["x"][i]), int(pts["y"][i])))
-            ba.add_points(np.stack([pts["x"][ia], pts["y"][ia]], 1), idp[ia].astype(np.float64), hh, pts["gray"][ia], _weights(pts["dpatch"][ia]), prior=False)
+            self._c("activatePoints+addPoints", ba.add_points, np.stack([pts["x"][ia], pts["y"][ia]], 1), idp[ia].astype(np.float64), hh, pts["gray"][ia], _weights(pts["dpatch"][ia]), prior=False)
         self._t("activatePoints+addPoints", t0)
         if self.obs is not None:
             self._emit("activate", frame_ids=fids, image_ids=iids, pairs=apairs, before=before, after=(pts, alive, act, idp), activated=activated,
@@ -368,7 +383,8 @@ class DirectPipeline:
         # ---- run
         exp0 = (ba.export(), ba.prior()) if self.obs is not None else None
         t0 = time.perf_counter()
-        ok_run = ba.run()
+        ok_run = self._c("run", ba.run)
+        self._poses = None
         self._t("run", t0)
         self.run_split.append(ba.run_timing())
         if not ok_run:
@@ -380,20 +396,20 @@ class DirectPipeline:
         # ---- makeCoarseDepthL0 on the new keyframe
         t0 = time.perf_counter()
         cd = self._coarse_depth(len(self.kfs) - 1)
-        nout = self.trk.make_coarse_depth(iid, self.levels, cd)
+        nout = self._c("makeCoarseDepthL0", self.trk.make_coarse_depth, iid, self.levels, cd)
         self._t("makeCoarseDepthL0", t0)
         self._emit("coarse", image_id=iid, gray=gray, pts=cd, n_lists=nout, levels=self.levels)
         # ---- tryMarginalize, marginalizePointsF
         exp0 = (ba.export(), ba.algebra()) if self.obs is not None else None
         t0 = time.perf_counter()
-        if not ba.try_marginalize():
+        if not self._c("tryMarginalize", ba.try_marginalize):
             raise RuntimeError("tryMarginalize failed: " + ba.last_error())
         self._t("tryMarginalize", t0)
         if self.obs is not None:
             self._emit("try_marginalize", before=exp0[0], algebra=exp0[1], after=ba.export(), grads0=[k_["grad0"] for k_ in self.kfs])
         exp0 = (ba.export(), ba.prior(), ba.algebra()) if self.obs is not None else None
         t0 = time.perf_counter()
-        if not ba.marginalize_points():
+        if not self._c("marginalizePointsF", ba.marginalize_points):
             raise RuntimeError("marginalizePointsF failed: " + ba.last_error())
         self._t("marginalizePointsF", t0)
         if self.obs is not None:
@@ -406,7 +422,8 @@ class DirectPipeline:
         # ---- marginalizeFrames + release of their images
         exp0 = (ba.export(), ba.prior(), ba.algebra()) if self.obs is not None else None
         t0 = time.perf_counter()
-        removed = list(ba.marginalize_frames())
+        removed = list(self._c("marginalizeFrames", ba.marginalize_frames))
+        self._poses = None
         for idx in sorted(removed, reverse=True):
             self._drop(self.kfs[idx]["image_id"])
             del self.kfs[idx]
@@ -431,6 +448,15 @@ class DirectPipeline:
             else:
                 self.non_keyframe(seq.gray[k])
         return self.stats
+
+    def library_summary(self):
+        """per stage: seconds spent inside the library's calls (summed over the calls of one stage invocation), as timing_summary reports the stage's wall clock"""
+        out = {}
+        for k, v in self.lib_times.items():
+            n = max(len(self.times.get(k, [])), 1)                      # several calls of one stage invocation are one entry
+            tot = float(np.sum(v))
+            out[k] = {"calls": int(len(v)), "total_ms": 1e3 * tot, "mean_ms_per_stage": 1e3 * tot / n}
+        return out
 
     def timing_summary(self):
         out = {}
