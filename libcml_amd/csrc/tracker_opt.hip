@@ -809,7 +809,8 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     if ((long long)n_hyp * G > capacity) G = std::max(1, capacity / n_hyp);          // G = 1: no workgroup waits for another, any launch size is fine
     G = std::min(G, TO_PARTS);
     G = G >= 8 ? 8 : (G >= 4 ? 4 : (G >= 2 ? 2 : 1));                                // a divisor of TO_PARTS: a workgroup owns whole parts
-    A.G = G; A.split_min = 2 * TO_THREADS;
+    static const char* e_sp = getenv("CMLHIP_TRACKER_SPLIT");         // development: the level size above which a level is evaluated in parts
+    A.G = G; A.split_min = e_sp ? atoi(e_sp) : TO_THREADS;          // (measured, one hypothesis, 15 trials: 0 / 512 / 1024 / 2560 / 5120 -> 0.225 / 0.224 / 0.233 / 0.280 / 0.313 ms: a level of more than one chunk is worth its exchange)
     if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp * G))) return rc;
     const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)TO_PARTS * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
     if ((rc = cml_ensure(c, c->trk_xch, xch_bytes + tick_bytes))) return rc;
