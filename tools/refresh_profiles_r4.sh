@@ -10,10 +10,13 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>/dev/null
 for cfg in B C E; do
   python tools/profile_bench.py refresh4/prof_$cfg --config $cfg --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/profile_$cfg.log 2>&1
 done
+BENCH_ARITH_RELAXED=1 python tools/profile_bench.py refresh4/prof_E_relaxed --config E --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/profile_E_relaxed.log 2>&1      # CMLHIP_ARITH_RELAXED (the bench line's bit-exact gate reports its mismatch: expected)
 python tools/valu_roof.py B > $OUT/valu_B.log 2>&1
 python tools/valu_roof.py E > $OUT/valu_E.log 2>&1
 python tools/probe_phases.py B > $OUT/phases_B.txt 2>&1
 python tools/probe_phases.py E > $OUT/phases_E.txt 2>&1
+bash tools/probe_rs_scaling.sh > $OUT/rs_scaling_E.txt 2>&1
+bash tools/probe_rs_stagger.sh > $OUT/rs_stagger_E.txt 2>&1
 python tools/probe_run_cost.py 48 > $OUT/run_cost.txt 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_seq -- python $OLDPWD/tools/probe_sequence.py 48 > /dev/null 2>&1 )
 python - <<'PY'
