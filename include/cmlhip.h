@@ -255,13 +255,14 @@ int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* ctx, const float* th /* N */);
 /* DSOFrame::getB0 of every frame again (it follows state_zero: DSOFrame.h:197-199).  BA::run re-anchors the newest frame before its closing
  * linearizeAll(true) (setEvalPT, BA.cpp:885-894): the b0 handed over with the window is stale for residuals hosted by that frame afterwards. */
 int cmlhip_ba_set_frame_b0(cmlhip_ctx* ctx, const float* b0 /* N */);
-/* Arithmetic of the residual kernel of the device-resident loop in the THROUGHPUT regime (windows of >= 36 864 residuals: a lane per residual,
- * ba_linearize_rs.hip).  CMLHIP_ARITH_EXACT (default): DSOBundleAdjustmentLinearizationContext::linearize statement for statement, bit-identical
- * to the reference's contraction-free reading (BA.cpp:62-316).  CMLHIP_ARITH_RELAXED (opt-in): the same formulas with fused multiply-adds, one
- * Newton step on the projection's reciprocal, and the photometric terms / pattern sums of a pixel (BA.cpp:214-271) in fp32 where the reference
- * widens to double and rounds every partial sum back to float — what a -ffast-math Release build of the reference is allowed to do.  Per-residual
- * outputs then agree with the exact mode to ~1e-6 relative (tests/test_relaxed_arithmetic_gpu.py: bars 1e-4, classification identical up to a
- * reported count of residuals at a threshold).  Small windows, the record kernel and every other call stay exact in both modes. */
+/* Arithmetic of the residual kernels of the device-resident loop (cmlhip_ba_iteration_async / _batch: ba_linearize_rs.hip for windows of
+ * >= 36 864 residuals, ba_linearize_rs4.hip below).  CMLHIP_ARITH_EXACT (default): DSOBundleAdjustmentLinearizationContext::linearize statement
+ * for statement, bit-identical to the reference's contraction-free reading (BA.cpp:62-316).  CMLHIP_ARITH_RELAXED (opt-in): the same formulas with
+ * fused multiply-adds, one Newton step on the projection's reciprocal, and the photometric terms / pattern sums of a pixel (BA.cpp:214-271) in fp32
+ * where the reference widens to double and rounds every partial sum back to float — what a -ffast-math Release build of the reference is allowed
+ * to do.  Per-residual outputs then agree with the exact mode to ~1e-6 relative (tests/test_relaxed_arithmetic_gpu.py: bars 1e-4, classification
+ * identical up to a reported count of residuals at a threshold).  The record kernel (cmlhip_ba_linearize, the closing pass of a run, the
+ * marginalisation passes) and every other call stay exact in both modes. */
 #define CMLHIP_ARITH_EXACT   0
 #define CMLHIP_ARITH_RELAXED 1
 int cmlhip_ba_set_arithmetic(cmlhip_ctx* ctx, int mode);

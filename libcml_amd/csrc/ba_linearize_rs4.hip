@@ -81,6 +81,11 @@ __device__ __forceinline__ double rs4_rcp_refined(const double z) {
     r = __builtin_fma(r, e, r);
     return r;
 }
+// CMLHIP_ARITH_RELAXED (cmlhip_ba_set_arithmetic; see ba_linearize_rs_body.inc): v_rcp_f64 + one Newton step
+__device__ __forceinline__ double rs4_rcp_once(const double z) {
+    const double r = __builtin_amdgcn_rcp(z);
+    return __builtin_fma(r, __builtin_fma(-z, r, 1.0), r);
+}
 __device__ __forceinline__ double rs4_div(const double x, const double z, const double r) {
     const double q = x * r;
     const double rem = __builtin_fma(-z, q, x);
@@ -111,7 +116,7 @@ __device__ __forceinline__ float rs4_jpdc(const int k, const double E0, const do
 
 // MINB: workgroups per CU the register budget is sized for — 1: no register bound (196 VGPRs, two waves per SIMD), no scratch frame;
 // 3: 168 VGPRs, the 13-23 registers beyond that spill to a scratch frame — measured slower at every window size (see the launcher)
-template <bool HALF, int MINB>
+template <bool HALF, int MINB, bool RELAX = false>
 __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs& X, const int ti, const int4 T, const bool dead = false) {
     __shared__ double s_shd[4][RS_RES * RS_DSTRIDE];                                   // [wave][residual * RS_DSTRIDE + quantity * 9 + pixel]
     __shared__ float s_shf[4][RS_RES * RS_FSTRIDE];                                    // [wave][residual * RS_FSTRIDE + quantity * 8 + pixel]
@@ -171,17 +176,25 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     // ---- the lane's two pattern pixels, BA.cpp:193-212 (star8 offsets + 2 packed by nibble, types.h:1381-1393)
     double qx[2], qy[2], ppx[2], ppy[2], ppz[2], kx[2], ky[2], rz[2];
     bool pix_in[2];
+    const double rc0 = R2_ + t0_ * idepth, rc1 = R5_ + t1_ * idepth, rc2 = R8_ + t2_ * idepth;      // RELAX only
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int pk = 2 * j + u;
         const int ox = (int)((0x21420312u >> (4 * pk)) & 15u) - 2, oy = (int)((0x43222110u >> (4 * pk)) & 15u) - 2;
         const double sx = cxd + ox, sy = cyd + oy;
         qx[u] = (sx - A.cx) * A.fxi; qy[u] = (sy - A.cy) * A.fyi;
-        ppx[u] = (R0_ * qx[u] + R1_ * qy[u] + R2_ * 1.0) + t0_ * idepth;
-        ppy[u] = (R3_ * qx[u] + R4_ * qy[u] + R5_ * 1.0) + t1_ * idepth;
-        ppz[u] = (R6_ * qx[u] + R7_ * qy[u] + R8_ * 1.0) + t2_ * idepth;
-        rz[u] = rs4_rcp_refined(ppz[u]);
-        kx[u] = rs4_div(ppx[u], ppz[u], rz[u]) * A.fx + A.cx; ky[u] = rs4_div(ppy[u], ppz[u], rz[u]) * A.fy + A.cy;
+        if (RELAX) {                                           // fused multiply-adds, one Newton step, a plain product per quotient (still fp64)
+            ppx[u] = __builtin_fma(R0_, qx[u], __builtin_fma(R1_, qy[u], rc0)); ppy[u] = __builtin_fma(R3_, qx[u], __builtin_fma(R4_, qy[u], rc1));
+            ppz[u] = __builtin_fma(R6_, qx[u], __builtin_fma(R7_, qy[u], rc2));
+            rz[u] = rs4_rcp_once(ppz[u]);
+            kx[u] = __builtin_fma(ppx[u] * rz[u], A.fx, A.cx); ky[u] = __builtin_fma(ppy[u] * rz[u], A.fy, A.cy);
+        } else {
+            ppx[u] = (R0_ * qx[u] + R1_ * qy[u] + R2_ * 1.0) + t0_ * idepth;
+            ppy[u] = (R3_ * qx[u] + R4_ * qy[u] + R5_ * 1.0) + t1_ * idepth;
+            ppz[u] = (R6_ * qx[u] + R7_ * qy[u] + R8_ * 1.0) + t2_ * idepth;
+            rz[u] = rs4_rcp_refined(ppz[u]);
+            kx[u] = rs4_div(ppx[u], ppz[u], rz[u]) * A.fx + A.cx; ky[u] = rs4_div(ppy[u], ppz[u], rz[u]) * A.fy + A.cy;
+        }
         pix_in[u] = (kx[u] >= 2 && ky[u] >= 2 && kx[u] < A.w - 2 && ky[u] < A.h - 2);
     }
     // ---- centre projection, BA.cpp:102-131: pattern pixel 4 is the offset (0,0) = first pixel of quad lane 2: the very same
@@ -189,7 +202,7 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     const double rx = rs4_quad_bcast_d<2>(qx[0]), ry = rs4_quad_bcast_d<2>(qy[0]);
     const double px = rs4_quad_bcast_d<2>(ppx[0]), py = rs4_quad_bcast_d<2>(ppy[0]), pz = rs4_quad_bcast_d<2>(ppz[0]);
     const double Kud = rs4_quad_bcast_d<2>(kx[0]), Kvd = rs4_quad_bcast_d<2>(ky[0]);
-    const float drescale = rs4_quad_bcast_f<2>((float)rs4_div(1.0, ppz[0], rz[0]));     // (float)(1.0 / pz) of the centre pixel
+    const float drescale = rs4_quad_bcast_f<2>(RELAX ? (float)rz[0] : (float)rs4_div(1.0, ppz[0], rz[0]));     // (float)(1.0 / pz) of the centre pixel
     const bool centre_in = (Kud >= 2 && Kvd >= 2 && Kud < A.w - 2 && Kvd < A.h - 2);
 
     // ---- GradientImage::interpolate (Array2D.h:265-286) of both pixels: eight unconditional loads on clamped addresses
@@ -278,25 +291,46 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     for (int u = 0; u < 2; u++) {
         const int pk = 2 * j + u;
         const float refColor = u == 0 ? col2.x : col2.y;
-        const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
-        const float residual = I[u] - refRealColor;
-        float hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
-        const double wden = A.oth_d + (double)(gx[u] * gx[u] + gy[u] * gy[u]);
-        float wgt = sqrtf((float)rs4_div(A.oth_d, wden, rs4_rcp_refined(wden)));
-        wgt = (float)(0.5f * ((double)wgt + (double)(u == 0 ? wgt2.x : wgt2.y)));
-        const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
-        const float hw0 = hw;
-        if (hw < 1) hw = sqrtf(hw);
-        hw = hw * wgt;
-        const float f1 = gx[u] * hw, f2 = gy[u] * hw;               // hitColor[1], hitColor[2]
-        const float drdA = I[u] - fh.b0;
-        const float a_ = drdA * hw;
-        const float rF = residual * hw;
-        const double f1d = (double)f1, f2d = (double)f2;
-        D[0 * 9 + pk] = f1d; D[1 * 9 + pk] = f2d; D[2 * 9 + pk] = (double)a_; D[3 * 9 + pk] = (double)hw; D[4 * 9 + pk] = (double)rF;
-        D[5 * 9 + pk] = (double)pf; D[6 * 9 + pk] = 2.0 - (double)hw0;                          // energy term, BA.cpp:237
-        D[7 * 9 + pk] = (double)(hw * hw); D[8 * 9 + pk] = f1d * f1d + f2d * f2d;              // wJI2_sum, BA.cpp:257
-        D[9 * 9 + pk] = 0.0;
+        float hw, drdA;
+        if (RELAX) {                                           // photometric terms in fp32 (v_rcp_f32 / v_sqrt_f32), operand rows as floats; the colour term stays fp64: I and it cancel
+            const float huber_f = (float)A.huber_d, oth_f = (float)A.oth_d;
+            const float residual = I[u] - (float)__builtin_fma(aff_a, (double)refColor, aff_b);
+            const float ares = fabsf(residual);
+            hw = ares < huber_f ? 1.0f : huber_f * __builtin_amdgcn_rcpf(ares);
+            float wgt = __builtin_amdgcn_sqrtf(oth_f * __builtin_amdgcn_rcpf(oth_f + __builtin_fmaf(gx[u], gx[u], gy[u] * gy[u])));
+            wgt = 0.5f * (wgt + (u == 0 ? wgt2.x : wgt2.y));
+            const float pf = wgt * wgt * hw * residual * residual;
+            const float hw0 = hw;
+            if (hw < 1) hw = __builtin_amdgcn_sqrtf(hw);
+            hw = hw * wgt;
+            const float f1 = gx[u] * hw, f2 = gy[u] * hw;
+            drdA = I[u] - fh.b0;
+            float* DF = reinterpret_cast<float*>(D);
+            DF[0 * 9 + pk] = f1; DF[1 * 9 + pk] = f2; DF[2 * 9 + pk] = drdA * hw; DF[3 * 9 + pk] = hw; DF[4 * 9 + pk] = residual * hw;
+            DF[5 * 9 + pk] = pf; DF[6 * 9 + pk] = 2.0f - hw0;
+            DF[7 * 9 + pk] = hw * hw; DF[8 * 9 + pk] = __builtin_fmaf(f2, f2, f1 * f1);
+            DF[9 * 9 + pk] = 0.f;
+        } else {
+            const float refRealColor = (float)(aff_a * (double)refColor + aff_b);
+            const float residual = I[u] - refRealColor;
+            hw = fabs((double)residual) < A.huber_d ? 1.0f : (float)(A.huber_d / (double)fabsf(residual));
+            const double wden = A.oth_d + (double)(gx[u] * gx[u] + gy[u] * gy[u]);
+            float wgt = sqrtf((float)rs4_div(A.oth_d, wden, rs4_rcp_refined(wden)));
+            wgt = (float)(0.5f * ((double)wgt + (double)(u == 0 ? wgt2.x : wgt2.y)));
+            const float pf = wgt * wgt * hw * residual * residual;      // energy term factor, :237
+            const float hw0 = hw;
+            if (hw < 1) hw = sqrtf(hw);
+            hw = hw * wgt;
+            const float f1 = gx[u] * hw, f2 = gy[u] * hw;               // hitColor[1], hitColor[2]
+            drdA = I[u] - fh.b0;
+            const float a_ = drdA * hw;
+            const float rF = residual * hw;
+            const double f1d = (double)f1, f2d = (double)f2;
+            D[0 * 9 + pk] = f1d; D[1 * 9 + pk] = f2d; D[2 * 9 + pk] = (double)a_; D[3 * 9 + pk] = (double)hw; D[4 * 9 + pk] = (double)rF;
+            D[5 * 9 + pk] = (double)pf; D[6 * 9 + pk] = 2.0 - (double)hw0;                          // energy term, BA.cpp:237
+            D[7 * 9 + pk] = (double)(hw * hw); D[8 * 9 + pk] = f1d * f1d + f2d * f2d;              // wJI2_sum, BA.cpp:257
+            D[9 * 9 + pk] = 0.0;
+        }
         F[pk] = drdA; F[8 + pk] = hw; F[16 + pk] = 1.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // rows are wave-private and a wave's LDS operations execute in order:
@@ -313,14 +347,22 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     const int by = ((j == 2 && !A.opt_a) || (j == 3 && !A.opt_b)) ? 9 : j;
     const int cp = j < 2 ? 0 : (j == 2 ? 1 : 2), cq = j == 0 ? 0 : (j < 3 ? 1 : 2);
     const int cr = j < 2 ? 1 : 2, cs = j == 0 ? 1 : 2;
-    float sumA0 = 0, sumA1 = 0, sumA2 = 0, sumC = 0;
+    float sumA0 = 0, sumA1 = 0, sumA2 = 0, sumC = 0, sumBf = 0;
     double sumB = 0;
+    const float* DFr = reinterpret_cast<const float*>(D);
 #pragma unroll
     for (int jj = 0; jj < 8; jj++) {
-        sumA0 = (float)((double)sumA0 + D[ax0 * 9 + jj] * D[ay0 * 9 + jj]);
-        sumA1 = (float)((double)sumA1 + D[ax1 * 9 + jj] * D[ay1 * 9 + jj]);
-        sumA2 = (float)((double)sumA2 + D[ax2 * 9 + jj] * D[ay2 * 9 + jj]);
-        sumB += D[4 * 9 + jj] * D[by * 9 + jj];
+        if (RELAX) {                                           // fp32 fused multiply-adds where the exact mode widens, adds in fp64 and rounds back per term
+            sumA0 = __builtin_fmaf(DFr[ax0 * 9 + jj], DFr[ay0 * 9 + jj], sumA0);
+            sumA1 = __builtin_fmaf(DFr[ax1 * 9 + jj], DFr[ay1 * 9 + jj], sumA1);
+            sumA2 = __builtin_fmaf(DFr[ax2 * 9 + jj], DFr[ay2 * 9 + jj], sumA2);
+            sumBf = __builtin_fmaf(DFr[4 * 9 + jj], DFr[by * 9 + jj], sumBf);
+        } else {
+            sumA0 = (float)((double)sumA0 + D[ax0 * 9 + jj] * D[ay0 * 9 + jj]);
+            sumA1 = (float)((double)sumA1 + D[ax1 * 9 + jj] * D[ay1 * 9 + jj]);
+            sumA2 = (float)((double)sumA2 + D[ax2 * 9 + jj] * D[ay2 * 9 + jj]);
+            sumB += D[4 * 9 + jj] * D[by * 9 + jj];
+        }
         sumC += F[cp * 8 + jj] * F[cq * 8 + jj] * F[cr * 8 + jj] * F[cs * 8 + jj];
     }
     RS4_STAMP(4);
@@ -389,7 +431,7 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         // the sums of this lane (staged layout of k_ba_acc: 22..25 JIdx2, 26..29 JabJIdx, 30..33 Jab2, 34,35 JI^T r, 36,37 Jab^T r, 38 r^T r)
         //   lane 0: J00 -> 22, Q10 -> 27, B00 -> 30     lane 1: J10 -> 23, 24, Q01 -> 28, B01 -> 31, 32
         //   lane 2: J11 -> 25, Q11 -> 29, B11 -> 33     lane 3: Q00 -> 26, r^T r -> 38
-        const float a0 = flip ? sumA0 : 0.f, a1 = flip ? sumA1 : 0.f, sb = flip ? (float)sumB : 0.f, sc = flip ? sumC : 0.f;
+        const float a0 = flip ? sumA0 : 0.f, a1 = flip ? sumA1 : 0.f, sb = flip ? (RELAX ? sumBf : (float)sumB) : 0.f, sc = flip ? sumC : 0.f;
         const int oa0 = (0x1A191716 >> (8 * j)) & 255, oa1 = (0x261D1C1B >> (8 * j)) & 255, osc = (0x2A211F1E >> (8 * j)) & 255;
         S[oa0] = a0; S[j == 1 ? 24 : 43] = a0;
         S[oa1] = a1;
@@ -413,7 +455,7 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         const float P0 = S[pa], P1 = S[pa + 1], P2 = S[pa2], P3 = S[pa2 + 1];
         const float Q0 = S[pb], Q1 = S[pb + 1], Q2 = S[pb2], Q3 = S[pb2 + 1];
         const float s2 = j == 1 ? d0 : g0, t2 = j == 1 ? d1 : g1;
-        const float bd = (float)((double)S[34] * (double)d0 + (double)S[35] * (double)d1);
+        const float bd = RELAX ? __builtin_fmaf(S[34], d0, S[35] * d1) : (float)((double)S[34] * (double)d0 + (double)S[35] * (double)d1);
         float4 o;
         o.x = P0 * g0 + Q0 * g1;
         o.y = P1 * g0 + Q1 * g1;
@@ -472,11 +514,11 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         if (canbreak && A.it_index >= 1) A.ctl->stop = 1;
     }
 }
-template <bool HALF, int MINB>
+template <bool HALF, int MINB, bool RELAX = false>
 __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
     const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (ti >= X.ntiles) return;                            // wave-uniform; there is no workgroup barrier in the body
-    k_ba_lin_rs4_body<HALF, MINB>(A, X, ti, X.tiles[ti]);
+    k_ba_lin_rs4_body<HALF, MINB, RELAX>(A, X, ti, X.tiles[ti]);
 }
 // The same kernel launched over (tile group of a pair, pair): the pair's entry {first residual, residuals, first tile, host | target << 16}
 // is indexed by blockIdx.y inside the KERNEL-ARGUMENT segment, so it arrives with the arguments — the solo kernel above reads its tile
@@ -485,7 +527,7 @@ __global__ __launch_bounds__(256, MINB) void k_ba_lin_rs4(BAArgs A, RsArgs X) {
 // 1-D launch.
 #define RS4_PAIR_TAB 128
 struct RsPairTab { int4 e[RS4_PAIR_TAB]; };
-template <bool HALF>
+template <bool HALF, bool RELAX = false>
 #ifndef RS4_2D_WPB
 #define RS4_2D_WPB 4         // waves per workgroup of the 2-D launch
 #endif
@@ -496,7 +538,7 @@ __global__ __launch_bounds__(64 * RS4_2D_WPB, 1) void k_ba_lin_rs4_2d(BAArgs A, 
     // a wave beyond its pair's last tile leaves where the stop flag is tested — behind the loads of the input trip (clamped onto the
     // pair's first residuals), not up here: a branch ahead of them makes the entry, the control word and the arguments three waits
     const bool dead = left <= 0;
-    k_ba_lin_rs4_body<HALF, 1>(A, X, e.z + lt, make_int4(dead ? e.x : e.x + lt * RS_RES, left < RS_RES ? left : RS_RES, e.w & 0xffff, e.w >> 16), dead);
+    k_ba_lin_rs4_body<HALF, 1, RELAX>(A, X, e.z + lt, make_int4(dead ? e.x : e.x + lt * RS_RES, left < RS_RES ? left : RS_RES, e.w & 0xffff, e.w >> 16), dead);
 }
 
 
@@ -513,8 +555,16 @@ int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
         memset(&Q, 0, sizeof Q);
         memcpy(Q.e, c->h_rs_pair_tab.data(), 16 * (size_t)c->rs_pair_n);
         const dim3 grid(cml_div_up(c->rs_pair_max_tiles, RS4_2D_WPB), c->rs_pair_n);
-        if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<true>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);
+        if (c->arith_relaxed) {
+            if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<true, true>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);
+            else CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<false, true>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);
+        } else if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<true>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);
         else CML_LAUNCH_EV(c, (k_ba_lin_rs4_2d<false>), grid, 64 * RS4_2D_WPB, 0, A, X, Q);
+        return CMLHIP_OK;
+    }
+    if (c->arith_relaxed) {
+        if (c->lim.texel_format == CMLHIP_TEXEL_F16) CML_LAUNCH_EV(c, (k_ba_lin_rs4<true, 1, true>), blocks, 256, 0, A, X);
+        else CML_LAUNCH_EV(c, (k_ba_lin_rs4<false, 1, true>), blocks, 256, 0, A, X);
         return CMLHIP_OK;
     }
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) {
@@ -528,17 +578,20 @@ int cml_launch_linearize_rs4(cmlhip_ctx* c, const BAArgs& A, RsArgs X) {
 }
 
 // several windows per launch (cmlhip_ba_iteration_batch): gridDim.y = window, the body and the arguments of the solo kernel
-template <bool HALF>
+template <bool HALF, bool RELAX = false>
 __global__ __launch_bounds__(256, 1) void k_ba_lin_rs4_batch(const BatchRs* __restrict__ W) {
     const BatchRs& w = *(const BatchRs*)(const BatchRs __attribute__((address_space(4)))*)(W + blockIdx.y);     // constant address space: scalar loads
     if ((int)blockIdx.x >= w.blocks) return;
     const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (ti >= w.X.ntiles) return;
-    k_ba_lin_rs4_body<HALF, 1>(w.A, w.X, ti, w.X.tiles[ti]);
+    k_ba_lin_rs4_body<HALF, 1, RELAX>(w.A, w.X, ti, w.X.tiles[ti]);
 }
 int cml_launch_linearize_rs4_batch(cmlhip_ctx* c0, const void* dev_records, int S, int max_blocks) {
     const BatchRs* W = static_cast<const BatchRs*>(dev_records);
-    if (c0->lim.texel_format == CMLHIP_TEXEL_F16) k_ba_lin_rs4_batch<true><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
+    if (c0->arith_relaxed) {                                 // (one arithmetic mode per batch: cml_iteration_batch checks)
+        if (c0->lim.texel_format == CMLHIP_TEXEL_F16) k_ba_lin_rs4_batch<true, true><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
+        else k_ba_lin_rs4_batch<false, true><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
+    } else if (c0->lim.texel_format == CMLHIP_TEXEL_F16) k_ba_lin_rs4_batch<true><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
     else k_ba_lin_rs4_batch<false><<<dim3(max_blocks, S), 256, 0, c0->stream>>>(W);
     return CMLHIP_OK;
 }

@@ -1,5 +1,5 @@
-"""CMLHIP_ARITH_RELAXED (cmlhip_ba_set_arithmetic, include/cmlhip.h) against the oracle — the opt-in arithmetic of the throughput-regime
-residual kernel (k_ba_lin_rs<..., RELAX = true>, ba_linearize_rs_body.inc): fused multiply-adds, one Newton step on the projection's
+"""CMLHIP_ARITH_RELAXED (cmlhip_ba_set_arithmetic, include/cmlhip.h) against the oracle — the opt-in arithmetic of the resident
+residual kernels (k_ba_lin_rs<..., RELAX = true>: ba_linearize_rs_body.inc; k_ba_lin_rs4*<..., RELAX = true>: ba_linearize_rs4.hip): fused multiply-adds, one Newton step on the projection's
 reciprocal, the photometric terms and pattern sums of a pixel in fp32.  It is NOT bit-exact; this file states what it is instead, in the
 terms SURVEY §7 uses for a kernel that does not reproduce the reference's rounding: per-residual energies within 1e-4 relative of the
 oracle's (observed 2e-7), Jacobian products JpJdF within 1e-4 of the row's largest entry for 99.9 % of the residuals (median below 1e-6; rows
@@ -44,7 +44,7 @@ def _window(config, relaxed, force_tile64=False):
     return W, ctx, ba
 
 
-@pytest.mark.parametrize("config,force", [("E", False), ("B", True)])
+@pytest.mark.parametrize("config,force", [("E", False), ("B", True), ("B", False), ("medium", False)])      # lane-per-residual kernel (E; B forced into it), 4-lane kernel (B, medium)
 def test_relaxed_pass_against_the_oracle(config, force):
     """each relaxed residual pass replayed on the oracle FROM THE DEVICE'S OWN STATE (so differences do not accumulate across passes)"""
     W, ctx, ba = _window(config, True, force)
