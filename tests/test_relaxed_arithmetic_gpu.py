@@ -95,8 +95,37 @@ def test_relaxed_loop_converges_to_the_exact_loop():
 
 def test_arithmetic_mode_is_validated_and_batch_refuses_mixed_modes():
     W, ctx, ba = _window("small", False)
+    W2, ctx2, ba2 = _window("small", True)
     try:
         assert ctx.L.cmlhip_ba_set_arithmetic(ctx.h, 2) == abi.ERR_INVALID
         assert ctx.L.cmlhip_ba_set_arithmetic(ctx.h, 1) == abi.OK and ctx.L.cmlhip_ba_set_arithmetic(ctx.h, 0) == abi.OK
+        with pytest.raises(device.CmlHipError) as e:                # one exact, one relaxed window in a batch
+            device.ba_iteration_batch([ctx, ctx2], 1e-5)
+        assert e.value.code == abi.ERR_INVALID and "arithmetic" in str(e.value)
+        ctx.ba_set_arithmetic(True)
+        device.ba_iteration_batch([ctx, ctx2], 1e-5)               # both relaxed: accepted
+        ctx.sync()
     finally:
-        ba.close(); ctx.close()
+        ba.close(); ctx.close(); ba2.close(); ctx2.close()
+
+
+def test_relaxed_batch_equals_relaxed_solo():
+    """the relaxed mode keeps the batched launch's property: a window stepped in a batch ends bit-identical to the same window stepped alone"""
+    outs = []
+    for batched in (False, True):
+        Ws = [_window("small", True) for _ in range(3)]
+        try:
+            ctxs = [w[1] for w in Ws]
+            for _ in range(4):
+                if batched:
+                    device.ba_iteration_batch(ctxs, 1e-5)
+                else:
+                    for c in ctxs:
+                        c.ba_iteration_async(1e-5)
+            for c in ctxs:
+                c.sync()
+            outs.append([(c.ba_states()["energy"].tobytes(), c.ba_get_idepth().tobytes(), c.ba_jpjdf().tobytes()) for c in ctxs])
+        finally:
+            for w in Ws:
+                w[2].close(); w[1].close()
+    assert outs[0] == outs[1]
