@@ -1021,7 +1021,9 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
     computeDelta();
     std::vector<cmlhip_ba_pair> pairs;
     framePairs(pairs);
-    int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+    int rc = cmlhip_ba_set_arithmetic(mCtx, mRelaxedArithmetic ? CMLHIP_ARITH_RELAXED : CMLHIP_ARITH_EXACT);
+    if (rc) return fail("cmlhip_ba_set_arithmetic", rc);
+    rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
     if (rc) return fail("cmlhip_ba_set_pairs", rc);
     std::vector<double> prior(8 * (size_t)N), dprior(8 * (size_t)N);
     for (int i = 0; i < N; i++) for (int k = 0; k < 8; k++) { prior[8 * i + k] = mFrames[i].prior[k]; dprior[8 * i + k] = mFrames[i].delta_prior[k]; }

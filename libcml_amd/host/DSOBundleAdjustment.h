@@ -89,6 +89,7 @@ public:
     double mMinIdepthHMarg = 50.0;                           // BA.h:263
     int    mMaxFrames = 6, mMinFrameAge = 1;                 // BA.h:271-272
     bool   mResidentLoop = true;                             // run(): keep the iteration loop on the device when the parameters allow it
+    bool   mRelaxedArithmetic = false;                       // cmlhip_ba_set_arithmetic(CMLHIP_ARITH_RELAXED) for the iterations of the device-resident loop (include/cmlhip.h; default: exact)
     bool   mKeepResidualEnergies = false;                    // run()'s closing pass also reads state_energy / state_NewEnergy / state_NewState of every residual back (nothing on the host uses them)
     double mCPriorValue = 5e9;                               // BA.cpp:2136-2137 (mCPrior is only assigned inside calcLEnergy)
 

@@ -36,6 +36,7 @@ int cmlhost_ba_set_param(void* h, const char* name, double v) {
     else if (n == "mixedBundleAdjustment") b->mMixedBundleAdjustment = v != 0;
     else if (n == "residentLoop") b->mResidentLoop = v != 0;
     else if (n == "keepResidualEnergies") b->mKeepResidualEnergies = v != 0;
+    else if (n == "relaxedArithmetic") b->mRelaxedArithmetic = v != 0;
     else if (n == "Minimum iDepth Hessian Marginlaization") b->mMinIdepthHMarg = v;
     else if (n == "maxFrames") b->mMaxFrames = (int)v;
     else if (n == "frameMinAge") b->mMinFrameAge = (int)v;

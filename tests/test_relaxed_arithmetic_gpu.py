@@ -129,3 +129,24 @@ def test_relaxed_batch_equals_relaxed_solo():
             for w in Ws:
                 w[2].close(); w[1].close()
     assert outs[0] == outs[1]
+
+
+def test_host_mirror_run_with_the_relaxed_parameter():
+    """cml_amd::DSOBundleAdjustment::run with `relaxedArithmetic` (the mirror's switch for cmlhip_ba_set_arithmetic): same iterations, energies and poses
+    as the exact run (energies 1e-4, poses 2e-4)"""
+    res = []
+    for relaxed in (0, 1):
+        W = synth.make_window("medium")
+        ctx = device.Ctx(max_frames=W.N, max_points=W.P, max_residuals=W.P * W.N)
+        ba = host.window_to_host_ba(ctx, W, image_id_base=7100, levels=1)
+        try:
+            ba.set_param("iterations", 4)
+            ba.set_param("relaxedArithmetic", relaxed)
+            assert ba.run(), ba.last_error()
+            res.append((ba.energies(16).copy(), ba.counts()["iterations"], np.concatenate([np.r_[ba.frame(i)["R"].ravel(), ba.frame(i)["t"]] for i in range(W.N)])))
+        finally:
+            ba.close(); ctx.close()
+    (e0, it0, p0), (e1, it1, p1) = res
+    assert it0 == it1 and len(e0) == len(e1)
+    assert np.all(np.abs(e0 - e1) <= 1e-4 * np.abs(e0)), (e0, e1)
+    assert np.abs(p0 - p1).max() < 2e-4, np.abs(p0 - p1).max()      # (observed 3e-5 in the translation of the last frame of this 2 400-residual window; the bars of the exact run against the ORACLE loop are 1e-3 / 5e-3)
