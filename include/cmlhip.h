@@ -186,6 +186,13 @@ typedef struct {
     int    n_steps; unsigned char step_level[CMLHIP_TRACKER_MAX_STEPS], step_accept[CMLHIP_TRACKER_MAX_STEPS];   /* the trials, TR.cpp:163 */
     double eval_us, algebra_us;           /* where the workgroup's time went: residual / Hessian evaluations, lane-0 algebra between them */
 } cmlhip_tracker_opt_result;
+/* The reference leaves its loop over the motion hypotheses behind the first good try: `haveOneGood && achievedRes < lastCoarseRMSE * 1.5`
+ * (DSOTracker.h:306-309) — with the usual constant-velocity guess in front, behind the FIRST.  rmse_bar > 0 (the caller's lastCoarseRMSE * 1.5)
+ * lets the batches that follow do the same: when hypothesis 0 ends adopted (isCorrect, finite E/n of level 0) with E/n below the bar, the
+ * other hypotheses give up at their next exchange and return n_steps = -1 (nothing else of such a result is meaningful).  The caller's replay
+ * of the selection (DSOTracker.h:262-313) decides as before; should it ever ask for a result that was given up (a bar that differs by a
+ * rounding), it runs the batch again with rmse_bar = 0.  rmse_bar <= 0 (default): every hypothesis runs to its end. */
+int cmlhip_tracker_set_early_exit(cmlhip_ctx* ctx, double rmse_bar);
 int cmlhip_tracker_optimize_batch(cmlhip_ctx* ctx, uint64_t new_image_id, int levels, const double K0[4] /* level-0 fx fy cx cy */,
                                   const double ref_exposure[3], const double init_exposure[3], const cmlhip_tracker_params* prm,
                                   int optimize_a, int optimize_b, double saturated_ratio_threshold,

@@ -115,6 +115,7 @@ struct cmlhip_ctx {
     DevBuf pair_blocks;                                       // N*N x PAIR_BLK doubles (stitched per-pair blocks)
     DevBuf adH, adT, adHTd, vec_small;                        // adjoints, adHTdeltaF, {cdelta,cprior,prior,delta_prior}
     DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec, Hf, bf;    // (8N+4)^2 / (8N+4) doubles; Hf/bf = final LM system
+    double trk_early_rmse = 0.0;                              // cmlhip_tracker_set_early_exit: > 0: hypothesis 0 may end the batch (tracker_opt.hip)
     bool arith_relaxed = false;                               // cmlhip_ba_set_arithmetic(CMLHIP_ARITH_RELAXED): see ba_linearize_rs_body.inc
     DevBuf bM_raw; bool resident_prior = false;               // resident loop with the marginalisation prior: mMarginalizedB as handed over; bM then holds bM_raw + HM * delta of the CURRENT frame states (cmlhip_ba_set_resident_prior)
     DevBuf tr_points, tr_pairs, tr_out;

@@ -42,6 +42,10 @@ struct TrkOptArgs {
     int epoch;                                         // launch number of this context (16 bits used)
     int* tick;                                         // [n_hyp][G]
     int* late;                                         // mapped host word: set when an exchange gave up waiting (a workgroup of the hypothesis never became resident)
+    // cmlhip_tracker_set_early_exit: the reference tries its hypotheses one after the other and leaves the loop behind the first good one
+    // (DSOTracker.h:306-309).  early_flag (device word, holds the launch number once raised) is raised by hypothesis 0 when it ends correct
+    // with E/n of level 0 below early_rmse; the other hypotheses see it at their next exchange and give up (n_steps = -1).
+    int* early_flag; float early_rmse;
 };
 
 // per-evaluation constants exactly as TR.cpp:260-278,426-429 forms them (float), shared by the workgroup
@@ -377,7 +381,8 @@ __device__ void to_prepare(const TrkOptArgs& A, ToEval& ev, int level, const SE3
 // all lanes: computeResidual + computeHessian over the level's list (the per-point arithmetic and the reduction layout of
 // k_tracker_eval, tracker.hip); leaves the 56 sums in s_red
 // the sums of this workgroup's part -> the sums of the level, in every workgroup of the hypothesis (see TrkOptArgs::G)
-__device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, const float* __restrict__ s_part, const int epoch, int* __restrict__ late_flag) {
+__device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __restrict__ tick, const int g, const int G, const int seq, const float* __restrict__ s_part, const int epoch, int* __restrict__ late_flag,
+                                             const int give_up_mine, int* __restrict__ s_abort) {
     // Every sum of every PART travels as ONE self-validating device-scope word {value | seq << 32} (past the non-coherent caches; valid on
     // its own): the writers neither wait for acknowledgements nor publish a ticket, the readers poll the eight words of their sum directly
     // and add them in PART order (round 4: the parts are a property of the level — eight, whatever G is — so the sums of a hypothesis do
@@ -395,8 +400,20 @@ __device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __res
     if (tid < TO_NRED)
         for (int sp = g, k = 0; sp < TO_PARTS; sp += G, k++)
             __hip_atomic_store(base + (size_t)sp * 64 + tid, tag | (unsigned)__float_as_int(s_part[k * 64 + tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // word 56 of part 0: the control word of the hypothesis — written by the workgroup that owns part 0 (g == 0) with the exchange, read by
+    // every workgroup with the sums: "give up" (early exit) reaches all G workgroups at the same exchange, so that none is left waiting
+    if (tid == TO_NRED && g == 0) __hip_atomic_store(base + TO_NRED, tag | (unsigned)(give_up_mine ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float v = 0.f;
     bool late = false;
+    if (tid == TO_NRED) {
+        int spins = 0;
+        while (true) {
+            const unsigned long long w = __hip_atomic_load(base + TO_NRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == tagv) { if ((unsigned)w & 1u) *s_abort = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { late = true; break; }
+        }
+    }
     if (tid < TO_NRED) {
         // the eight words of a sum are requested TOGETHER and polled as a set: one round trip per poll round — polled one after the
         // other each word was a dependent device-scope load of its own, eight round trips even when everything had arrived
@@ -426,13 +443,17 @@ __device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __res
 
 template <bool HALF>
 __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red, float* s_part,
-                        const int g, const int G, const int split_min, float* xch, int* tick, int& seq, const int epoch, int* late_flag) {
+                        const int g, const int G, const int split_min, float* xch, int* tick, int& seq, const int epoch, int* late_flag,
+                        const int* early_flag, int* s_abort) {
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     // The parts of a level are fixed by its SIZE: eight for a level with more than split_min reference points (part s = the chunks s, s + 8,
     // s + 16, ... of TO_THREADS points), one otherwise — NOT by G.  A workgroup evaluates the parts s = g, g + G, ... (G in {1, 2, 4, 8});
     // the level's sums are the part sums added in part order by every workgroup.  So a hypothesis gives the same bits alone (G = 8),
     // among 50 (G = 4) or among 200 (G = 1): ADVICE round 3.  A one-part level is evaluated whole by every workgroup, without exchange.
     const int NP = E.n > split_min ? TO_PARTS : 1;
+    // early exit: the word is requested here, ahead of the evaluation, by the one lane that will pass it on (hypotheses > 0 only: early_flag is null for hypothesis 0)
+    int give_up = 0;
+    if (early_flag && g == 0 && tid == TO_NRED) give_up = __hip_atomic_load(early_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
     int src = -1;                                                       // wave 0: which tile entry this lane sums
     if (tid < 45) {
         int k = tid, r = 0;
@@ -542,8 +563,10 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // s_part: written and read by this wave only
         __builtin_amdgcn_wave_barrier();
         float v;
-        if (xchg) v = to_exchange(xch, tick, g, G, seq, s_part, epoch, late_flag);
-        else {                                                          // every part is this workgroup's own: the same sum, part by part, from zero
+        if (xchg) v = to_exchange(xch, tick, g, G, seq, s_part, epoch, late_flag, give_up, s_abort);
+        else {
+            if (G == 1 && give_up) *s_abort = 1;                      // one workgroup per hypothesis: nobody to agree with
+                                                          // every part is this workgroup's own: the same sum, part by part, from zero
             v = 0.f;
             for (int k = 0; k < kown; k++) v += s_part[k * 64 + tid];
         }
@@ -583,7 +606,7 @@ __device__ __forceinline__ int to_ctrl(const ToState& S, int& cseq) {
 
 // lane 0 books the time since the last mark as algebra, runs the evaluation, books it as evaluation
 #define TO_TIMED_EVAL() do { if (tid == 0) { const long long t_ = wall_clock64(); S.t_alg += t_ - S.t_mark; S.t_mark = t_; } \
-        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, s_part, g, A.G, A.split_min, xch, tick, seq, A.epoch, A.late); \
+        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, s_part, g, A.G, A.split_min, xch, tick, seq, A.epoch, A.late, hyp > 0 ? A.early_flag : nullptr, &s_abort); \
         if (tid == 0) { const long long t_ = wall_clock64(); S.t_eval += t_ - S.t_mark; S.t_mark = t_; } } while (0)
 
 enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
@@ -596,6 +619,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ float s_part[TO_PARTS * 64];
     __shared__ ToEval ev;
     __shared__ ToState S;
+    __shared__ int s_abort;                                  // raised by an exchange that carried "give up" (early exit)
     __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
     const int tid = threadIdx.x, hyp = blockIdx.x / A.G, g = blockIdx.x % A.G;
     cmlhip_tracker_opt_result* out = (g == 0 && A.out_host) ? A.out_host + hyp : A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical; the first one's goes straight to the host)
@@ -609,7 +633,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         S.a = A.init_a; S.b = A.init_b;
         for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l] = 0; S.nT[l] = S.nS[l] = S.nR[l] = S.nT_new[l] = S.nS_new[l] = S.nR_new[l] = 0; S.levelCutoffRepeat[l] = 0; S.iterations[l] = 0; }
         for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k] = 0;
-        S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl[0] = S.ctrl[1] = TO_CONTINUE;
+        S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl[0] = S.ctrl[1] = TO_CONTINUE; s_abort = 0;
         S.t_eval = 0; S.t_alg = 0; S.t_mark = wall_clock64();
 #ifdef TO_PROFILE
         S.t_ldlt = S.t_pose = S.t_fin = 0;
@@ -626,7 +650,8 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
             if (tid < 64) to_finish(A, s_red, S.E[level], S.nT[level], S.nS[level], S.nR[level], S.flow, S.H, S.bv);
             if (tid == 0) {
                 int c = TO_ITERATE;
-                if (S.nT[level] < 20) c = TO_FAIL;                                                           // :65-69
+                if (s_abort) c = TO_FAIL;                                                                    // early exit: another hypothesis ended the search
+                else if (S.nT[level] < 20) c = TO_FAIL;                                                           // :65-69
                 else if ((S.nS[level] / (double)S.nT[level]) > 0.6 && S.levelCutoffRepeat[level] < 50) {     // :71-75
                     S.levelCutoffRepeat[level] *= 2;
                     to_prepare(A, ev, level, to_pose(S.cur_q, S.cur_t), S.a, S.b, S.levelCutoffRepeat[level], true);
@@ -710,13 +735,13 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     } else {
                         S.lambda *= 4;
                     }
-                    S.ctrl[cseq & 1] = (incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE;                                 // :176-179
+                    S.ctrl[cseq & 1] = s_abort ? TO_FAIL : ((incnorm < 1e-3) ? TO_LEVEL_DONE : TO_ITERATE);           // :176-179 (TO_FAIL: early exit)
                 }
             }
 #ifdef TO_PROFILE
             if (tid == 0) S.t_fin += wall_clock64() - tf0;
 #endif
-            if (to_ctrl(S, cseq) == TO_LEVEL_DONE) break;
+            { const int c1 = to_ctrl(S, cseq); if (c1 == TO_FAIL) { failed = true; break; } if (c1 == TO_LEVEL_DONE) break; }
         }
         if (failed) break;
         if (tid == 0) {
@@ -739,7 +764,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
             out->levelCutoffRepeat[l] = S.levelCutoffRepeat[l]; out->iterations[l] = S.iterations[l];
         }
         for (int k = 0; k < 3; k++) out->flow[k] = S.flow[k];
-        out->n_steps = S.n_steps; out->n_pass = S.n_pass < 8 ? S.n_pass : 8;
+        out->n_steps = s_abort ? -1 : S.n_steps; out->n_pass = S.n_pass < 8 ? S.n_pass : 8;      // -1: given up (early exit), nothing else of the result is meaningful
         out->eval_us = 0.01 * (double)S.t_eval; out->algebra_us = 0.01 * (double)(S.t_alg + (wall_clock64() - S.t_mark));
         for (int k = 0; k < 6; k++) out->covariance[k] = 999999;
 #ifdef TO_PROFILE
@@ -759,6 +784,11 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
             if ((double)S.nS[0] / (double)S.nT[0] > A.sat_th) haveGoodPoints = false;                       // :231-235
             out->isCorrect = haveGoodLight ? 1 : 0;
             out->tooManySaturated = haveGoodPoints ? 1 : 0;                                                 // sic, :240
+            // early exit: the first try ends the search when it is adopted and its E/n of level 0 is below the bar (DSOTracker.h:288-309 on an empty history)
+            if (A.early_flag && hyp == 0 && g == 0 && haveGoodLight && S.nT[0] > 0) {      // (adoption of the first try: isCorrect and a finite E/n — the history's tooManySaturated starts true)
+                const double rm = (double)S.E[0] / (double)S.nT[0];
+                if (isfinite(rm) && rm < (double)A.early_rmse) __hip_atomic_store(A.early_flag, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             out->relAff[0] = relA; out->relAff[1] = relB;
         }
     }
@@ -766,6 +796,12 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         const double hi = to_inverse8_wave(S.H, tid);
         if ((tid >> 3) == (tid & 7) && (tid >> 3) < 6) out->covariance[tid >> 3] = hi;
     }
+}
+
+extern "C" int cmlhip_tracker_set_early_exit(cmlhip_ctx* c, double rmse_bar) {
+    if (!c || !(rmse_bar == rmse_bar)) return CMLHIP_ERR_INVALID;
+    c->trk_early_rmse = rmse_bar > 0.0 ? rmse_bar : 0.0;
+    return CMLHIP_OK;
 }
 
 extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, int levels, const double K0[4], const double ref_exposure[3],
@@ -812,8 +848,8 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     static const char* e_sp = getenv("CMLHIP_TRACKER_SPLIT");         // development: the level size above which a level is evaluated in parts
     A.G = G; A.split_min = e_sp ? atoi(e_sp) : TO_THREADS;          // (measured, one hypothesis, 15 trials: 0 / 512 / 1024 / 2560 / 5120 -> 0.225 / 0.224 / 0.233 / 0.280 / 0.313 ms: a level of more than one chunk is worth its exchange)
     if ((rc = cml_ensure(c, c->trk_opt_out, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp * G))) return rc;
-    const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)TO_PARTS * n_hyp, tick_bytes = sizeof(int) * (size_t)G * n_hyp;
-    if ((rc = cml_ensure(c, c->trk_xch, xch_bytes + tick_bytes))) return rc;
+    const size_t xch_bytes = sizeof(unsigned long long) * 2 * 64 * (size_t)TO_PARTS * n_hyp, tick_bytes = ((sizeof(int) * (size_t)G * n_hyp + 63) / 64) * 64;
+    if ((rc = cml_ensure(c, c->trk_xch, xch_bytes + tick_bytes + 64))) return rc;
     // hypotheses in, results out through ONE mapped, coherent host block: the kernel reads the 96 bytes of its hypothesis and the first
     // workgroup of each hypothesis writes its result there — no staged upload before the launch and no copy back behind it (each was a
     // copy command of its own on the stream: 321 -> 299 us per call for one hypothesis, 421 -> 389 for fifty)
@@ -833,6 +869,8 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
     A.out_host = reinterpret_cast<cmlhip_tracker_opt_result*>(static_cast<char*>(dptr) + hyp_bytes);
     A.xch = c->trk_xch.as<float>(); A.tick = reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes);
+    A.early_rmse = (float)c->trk_early_rmse;
+    A.early_flag = (c->trk_early_rmse > 0.0 && n_hyp > 1) ? reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes + tick_bytes) : nullptr;
     A.late = reinterpret_cast<int*>(static_cast<char*>(dptr) + hyp_bytes + res_bytes);
     // (no per-call clearing: the words carry the launch number; a fresh or moved buffer is cleared once)
     // cleared once per ALLOCATION (DevBuf::gen, not the address: a free + malloc may hand the address back) and whenever the 16-bit launch

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_frame_b0": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_arithmetic": (C.c_int, [_ctx, _i]),
+    "cmlhip_tracker_set_early_exit": (C.c_int, [_ctx, _d]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
     "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
     "cmlhip_ba_linearize": (C.c_int, [_ctx, _P(abi.BALinResult)]),
@@ -223,6 +224,10 @@ class Ctx:
     def ba_set_frame_energy_th(self, th):
         th = np.ascontiguousarray(th, np.float32)
         self.ck(self.L.cmlhip_ba_set_frame_energy_th(self.h, _p(th, _f)))
+
+    def tracker_set_early_exit(self, rmse_bar):
+        """cmlhip_tracker_set_early_exit: > 0: hypothesis 0 of the following batches may end them (results given up carry n_steps = -1); 0: off"""
+        self.ck(self.L.cmlhip_tracker_set_early_exit(self.h, float(rmse_bar)))
 
     def ba_set_arithmetic(self, relaxed):
         """cmlhip_ba_set_arithmetic: False = CMLHIP_ARITH_EXACT (default), True = CMLHIP_ARITH_RELAXED (throughput-regime residual kernel only)"""

@@ -289,8 +289,18 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
             if (n_hyp == 1 && !(mFailureMode == 1 || mFailureMode == 2)) return false;
         }
     }
-    const int rc = cmlhip_tracker_optimize_batch(mCtx, new_image_id, levels, mK, refE, initE, &prm, mOptimizeA ? 1 : 0, mOptimizeB ? 1 : 0,
-                                                 mSaturatedRatioThreshold, n_hyp, H.data(), R.data());
+    // early exit on the device: the bar of the break below (lastCoarseRMSE * setting_reTrackThreshold), valid while the selection state is
+    // still empty — i.e. for the FIRST try only (the try the motion model puts its best guess in).  Results behind it come back "given up"
+    // (n_steps = -1); the replay below never reads them unless its own test of try 0 disagrees with the device's by a rounding, in which
+    // case the batch runs again in full.
+    double bar = (mBatchedEarlyExit && n_hyp > 1 && std::isfinite((double)mLastCoarseRMSE) && mLastCoarseRMSE > 0) ? (double)(mLastCoarseRMSE * 1.5f) : 0.0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    bool hit_given_up = false;
+    int rc = cmlhip_tracker_set_early_exit(mCtx, bar);
+    if (rc) { mError = std::string("cmlhip_tracker_set_early_exit: ") + cmlhip_last_error(mCtx); return false; }
+    rc = cmlhip_tracker_optimize_batch(mCtx, new_image_id, levels, mK, refE, initE, &prm, mOptimizeA ? 1 : 0, mOptimizeB ? 1 : 0,
+                                       mSaturatedRatioThreshold, n_hyp, H.data(), R.data());
+    (void)cmlhip_tracker_set_early_exit(mCtx, 0.0);
     if (rc) { mError = std::string("cmlhip_tracker_optimize_batch: ") + cmlhip_last_error(mCtx); return false; }
     auto toResidual = [&](const cmlhip_tracker_opt_result& r) {
         Residual o;
@@ -308,6 +318,7 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
     double achievedRes = std::numeric_limits<double>::max();
     int i = 0;
     for (; i < n_hyp; i++) {
+        if (R[i].n_steps < 0) { hit_given_up = true; break; }                            // given up on the device behind try 0's early exit: not a result
         Residual test = toResidual(R[i]);
         double rm = (test.numTermsInE[0] > 0) ? test.rmse() : std::numeric_limits<double>::quiet_NaN();
         if (trackingResult.isCorrect) {                                                    // mLastResidual = trackingResult, TR.cpp:183-189
@@ -335,6 +346,7 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
         if (haveOneGood && achievedRes < mLastCoarseRMSE * setting_reTrackThreshold) { i++; break; }   // :306-309
         if (haveOneGood && i >= 50) { i++; break; }                                        // :311-313
     }
+    if (hit_given_up && attempt == 0) { bar = 0.0; if (winner) *winner = -1; continue; }   // (the device's test of try 0 and this one differ by a rounding: all hypotheses, in full)
     if (tries) *tries = i;
     if (!haveOneGood) {
         if ((mFailureMode == 1 || mFailureMode == 2) && n_hyp > 0) {                       // :324-352: optimize(cameras[0]) with mLastResidual = trackingResult (not correct: no abort)
@@ -352,6 +364,8 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
     }
     residual = trackingResult;
     return haveOneGood;
+  }
+    return false;
 }
 
 }  // namespace cml_amd

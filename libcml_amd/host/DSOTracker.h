@@ -39,6 +39,7 @@ public:
     double mSaturatedRatioThreshold = 0.33;
     int maxLevelOverride = -1;
     int mFailureMode = 0;                               // DSOTracker.h:517
+    bool mBatchedEarlyExit = true;                      // trackWithMotionModelBatched: hypothesis 0 may end the batch on the device (cmlhip_tracker_set_early_exit with lastCoarseRMSE * 1.5: the break of DSOTracker.h:306-309 behind the first try)
     bool mBatchedFirstAlone = false;                    // trackWithMotionModelBatched: try hypothesis 0 through the host-driven loop before launching the batch (the round-2 policy)
     double mLastCoarseRMSE = 100;                       // DSOTracker.h:470
     Residual mLastResidual;                             // set by trackWithMotionModel before every try (DSOTracker.h:272), read by optimize (TR.cpp:183-189)

@@ -226,6 +226,7 @@ int cmlhost_tracker_set_param(void* h, const char* name, double v) {
     else if (n == "failureMode") t->mFailureMode = (int)v;
     else if (n == "lastCoarseRMSE") t->mLastCoarseRMSE = v;
     else if (n == "batchedFirstAlone") t->mBatchedFirstAlone = v != 0;
+    else if (n == "batchedEarlyExit") t->mBatchedEarlyExit = v != 0;
     else return 1;
     return 0;
 }

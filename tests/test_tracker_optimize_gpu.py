@@ -119,3 +119,53 @@ def test_a_hypothesis_does_not_depend_on_its_batch(setup):
         if n_hyp == 50:                                           # the same 50 in reverse order: hypothesis 0 is now the last group of workgroups
             rev = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps[::-1])[-1]
             assert bytes(bytearray(bytes(rev))[:keep]) == ref[:keep]
+
+
+def test_early_exit_behind_the_first_hypothesis(setup):
+    """cmlhip_tracker_set_early_exit: the reference leaves its hypothesis loop behind the first good try (DSOTracker.h:306-309).  With the bar set,
+    hypothesis 0's result is bit-identical to the run without, the others come back given up (n_steps = -1) once it has ended — at every batch
+    shape (G = 8, 4, 1 workgroups per hypothesis) — and a bar hypothesis 0 does not meet changes nothing."""
+    P, ctx, trk = setup
+    base = TS.perturbed(P, (0.004, -0.003, 0.002), (0.03, -0.02, 0.025))
+    keep = 8 * 14 + 8
+    for n_hyp in (6, 50, 300):
+        # the others start far off: they need many more trials than hypothesis 0
+        hyps = [base] + [TS.perturbed(P, (0.02 + 1e-3 * (i % 7), -0.015, 0.01), (0.15, -0.1 + 1e-2 * (i % 5), 0.12)) for i in range(1, n_hyp)]
+        ctx.tracker_set_early_exit(0.0)
+        ctx.profile_next_launch()
+        full = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps)
+        t_full = ctx.elapsed_ms()
+        r0 = full[0]
+        assert r0.isCorrect and r0.n_steps >= 5 and all(r.n_steps >= 0 for r in full)
+        rm0 = r0.E[0] / r0.numTermsInE[0]
+        ctx.tracker_set_early_exit(1.5 * rm0)
+        ctx.profile_next_launch()
+        cut = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps)
+        t_cut = ctx.elapsed_ms()
+        assert bytes(bytearray(bytes(cut[0]))[:keep]) == bytes(bytearray(bytes(r0))[:keep]) and cut[0].n_steps == r0.n_steps
+        gave_up = sum(1 for r in cut[1:] if r.n_steps < 0)
+        for a, b in zip(cut[1:], full[1:]):                       # a hypothesis that finished before the flag rose is a complete result, the same one
+            if a.n_steps >= 0:
+                assert bytes(bytearray(bytes(a))[:keep]) == bytes(bytearray(bytes(b))[:keep])
+        slower = sum(1 for r in full[1:] if r.n_steps > r0.n_steps + 4)
+        assert gave_up >= max(1, slower // 2), (n_hyp, gave_up, slower)
+        assert t_cut <= t_full * 1.02, (n_hyp, t_cut, t_full)
+        print("early exit, %d hypotheses: kernel %.3f -> %.3f ms, %d of %d given up" % (n_hyp, t_full, t_cut, gave_up, n_hyp - 1))
+        ctx.tracker_set_early_exit(0.5 * rm0)                     # a bar hypothesis 0 does not meet: nothing gives up
+        none = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps)
+        assert all(r.n_steps >= 0 for r in none)
+        ctx.tracker_set_early_exit(0.0)
+
+
+def test_batched_tracking_with_and_without_early_exit_agree(setup):
+    """the host mirror's trackWithMotionModelBatched: same winner, same pose bits, same number of tries with the early exit on (default) and off"""
+    P, ctx, trk = setup
+    hyps = [TS.perturbed(P, (0.004, -0.003, 0.002), (0.03, -0.02, 0.025))] + [TS.perturbed(P, (0.02, -0.015 + 1e-3 * i, 0.01), (0.15, -0.1, 0.12)) for i in range(5)]
+    out = []
+    for on in (1, 0):
+        t2 = host.HostTracker(ctx); t2.set_calibration(*P.W.K)
+        t2.set_param("batchedEarlyExit", on)
+        t2.set_param("lastCoarseRMSE", 1e6)                       # (any first try that is correct ends the search)
+        res = t2.track_with_motion_model(501, P.levels, hyps, P.ref_exp, P.init_exp, batched=True)
+        out.append((bool(res["haveOneGood"]), res["R"].tobytes(), res["t"].tobytes(), int(res["winner"]), int(res["tries"])))
+    assert out[0] == out[1] and out[0][0] and out[0][3] == 0 and out[0][4] == 1
