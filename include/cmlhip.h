@@ -111,6 +111,12 @@ int cmlhip_pyramid_put(cmlhip_ctx* ctx, uint64_t image_id, int level,
  * levels (needed by tracker reference colors, TR.cpp:702). */
 int cmlhip_pyramid_build(cmlhip_ctx* ctx, uint64_t image_id, const float* gray,
                          int w, int h, int levels);
+/* The same build, handed to the context's image worker: the call returns once the levels are allocated; the staging copy of `gray`, its
+ * transfer and the kernels of every level run on a host thread and a stream of their own — beside whatever the context is doing (the
+ * reference builds a frame's pyramid on the capture thread, ahead of the SLAM thread: capture/CaptureImage.cpp:39-78,216-221).  `gray` must stay
+ * valid and unchanged until the first call that names image_id returns (that call orders itself behind the build) or until
+ * cmlhip_pyramid_drop(image_id).  An image_id that is already in the cache is rebuilt synchronously (cmlhip_pyramid_build). */
+int cmlhip_pyramid_build_async(cmlhip_ctx* ctx, uint64_t image_id, const float* gray, int w, int h, int levels);
 int cmlhip_pyramid_drop(cmlhip_ctx* ctx, uint64_t image_id);   /* CaptureImage::makeUnactive, CaptureImage.cpp:364-403 */
 int cmlhip_pyramid_level_size(cmlhip_ctx* ctx, uint64_t image_id, int level, int* w, int* h);
 /* read one level back as AoS3 floats (tests) */

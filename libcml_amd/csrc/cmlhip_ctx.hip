@@ -184,10 +184,31 @@ int cml_d2h_batch_flush(cmlhip_ctx* c) {
     c->d2h_segs.clear(); c->d2h_dst.clear();
     return CMLHIP_OK;
 }
+// a pyramid that is still being built by the image worker: wait until everything is ENQUEUED on the worker's stream (host side), then order
+// the context's stream behind its last kernel (device side: no host wait for the build itself)
+static int pyr_settle(cmlhip_ctx* c, uint64_t id, Pyramid& P) {
+    if (!P.pending) return CMLHIP_OK;
+    int st;
+    {
+        std::unique_lock<std::mutex> lk(c->pyr_mu);
+        c->pyr_cv.wait(lk, [&] { auto it = c->pyr_state.find(id); return it == c->pyr_state.end() || it->second != 1; });
+        auto it = c->pyr_state.find(id);
+        st = it == c->pyr_state.end() ? 2 : it->second;
+        if (it != c->pyr_state.end()) c->pyr_state.erase(it);
+    }
+    P.pending = false;
+    if (st < 0) { c->err = "cmlhip_pyramid_build_async: the image worker failed to copy / build the pyramid"; return CMLHIP_ERR_HIP; }
+    CML_CHECK(c, hipStreamWaitEvent(c->stream, P.ready, 0));
+    return CMLHIP_OK;
+}
 const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id) {
     auto it = c->pyr.find(id);
-    return it == c->pyr.end() ? nullptr : &it->second;
+    if (it == c->pyr.end()) return nullptr;
+    if (it->second.pending && pyr_settle(c, id, it->second)) return nullptr;
+    return &it->second;
 }
+
+static void pyr_worker_main(cmlhip_ctx* c);
 
 extern "C" {
 
@@ -213,6 +234,12 @@ int cmlhip_create(cmlhip_ctx** out, const cmlhip_limits* lim) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CMLHIP_ERR_HIP; }
     (void)hipEventCreate(&c->ev[0]);
     (void)hipEventCreate(&c->ev[1]);
+    // the image worker's stream and thread (cmlhip_pyramid_build_async) are set up HERE: creating a stream takes 4-9 ms on this stack,
+    // which belongs to the start of a sequence, not in front of its second frame; the thread sleeps on a condition variable until used
+    if (hipStreamCreateWithFlags(&c->pyr_stream, hipStreamNonBlocking) == hipSuccess) {
+        c->pyr_thread = std::thread(pyr_worker_main, c);
+        c->pyr_started = true;
+    }
     *out = c;
     return CMLHIP_OK;
 }
@@ -220,7 +247,15 @@ int cmlhip_create(cmlhip_ctx** out, const cmlhip_limits* lim) {
 void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->pyr_started) {                                    // the image worker: finish what is queued, then leave
+        { std::lock_guard<std::mutex> lk(c->pyr_mu); c->pyr_quit = true; }
+        c->pyr_cv.notify_all();
+        c->pyr_thread.join();
+        (void)hipStreamSynchronize(c->pyr_stream);
+        (void)hipStreamDestroy(c->pyr_stream);
+    }
     (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pyr) if (kv.second.ready) (void)hipEventDestroy(kv.second.ready);
     for (auto& kv : c->pyr)
         for (int l = 0; l < 8; l++) { if (kv.second.lv[l].grad) (void)hipFree(kv.second.lv[l].grad); if (kv.second.lv[l].gray) (void)hipFree(kv.second.lv[l].gray); if (kv.second.lv[l].tiled) (void)hipFree(kv.second.lv[l].tiled); }
     for (auto& kv : c->img_pool) (void)hipFree(kv.second);
@@ -432,6 +467,7 @@ int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3,
 int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, int h, int levels) { CML_DEV(c);
     if (!c || !gray || levels < 1 || levels > 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
+    if (P.pending) (void)pyr_settle(c, id, P);
     (void)hipStreamSynchronize(c->stream);
     if (P.lv[0].grad) window_forget_image(c, id);
     for (int l = 0; l < 8; l++) free_level(c, P.lv[l]);
@@ -461,13 +497,75 @@ int cmlhip_pyramid_build(cmlhip_ctx* c, uint64_t id, const float* gray, int w, i
     return CMLHIP_OK;
 }
 
+// ---- cmlhip_pyramid_build_async.  The caller's thread allocates the levels (pool + cache map are its own) and hands the rest to the
+// context's image worker: the copy of the (pageable) image to the device and the reduce / gradient kernels of every level on the
+// worker's stream.  Neither the staging of the image (~0.1 ms on a host core) nor the transfer nor the kernels sit on the caller's thread or on the
+// context's stream; the first call that names the image (cml_find_pyr) orders the stream behind the build.
+static void pyr_worker_main(cmlhip_ctx* c) {
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        PyrJob J;
+        {
+            std::unique_lock<std::mutex> lk(c->pyr_mu);
+            c->pyr_cv.wait(lk, [&] { return c->pyr_quit || !c->pyr_jobs.empty(); });
+            if (c->pyr_jobs.empty()) return;                 // (quit with nothing left)
+            J = c->pyr_jobs.front(); c->pyr_jobs.pop_front();
+        }
+        // (the caller's image is pageable memory: the runtime stages it through its own pinned pool and this call returns when the source
+        //  has been read — on this thread that is exactly what is wanted, and the context needs no staging buffers of its own: two
+        //  hipHostMalloc of an image cost 4-10 ms at the first call)
+        const size_t bytes = (size_t)J.w[0] * J.h[0] * sizeof(float);
+        bool ok = hipMemcpyAsync(J.gray[0], J.src, bytes, hipMemcpyHostToDevice, c->pyr_stream) == hipSuccess;
+        for (int l = 0; ok && l < J.levels; l++) {
+            const dim3 g(cml_div_up(J.w[l], 256), J.h[l]);
+            if (l > 0) k_reduce_by_two<<<g, 256, 0, c->pyr_stream>>>(J.gray[l - 1], J.w[l - 1], J.h[l - 1], J.gray[l]);
+            if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_gradient<true><<<g, 256, 0, c->pyr_stream>>>(J.gray[l], J.w[l], J.h[l], J.grad[l]);
+            else k_gradient<false><<<g, 256, 0, c->pyr_stream>>>(J.gray[l], J.w[l], J.h[l], J.grad[l]);
+        }
+        ok = ok && hipGetLastError() == hipSuccess && hipEventRecord(J.ready, c->pyr_stream) == hipSuccess;
+        { std::lock_guard<std::mutex> lk(c->pyr_mu); c->pyr_state[J.id] = ok ? 2 : -1; }
+        c->pyr_cv.notify_all();
+    }
+}
+
+int cmlhip_pyramid_build_async(cmlhip_ctx* c, uint64_t id, const float* gray, int w, int h, int levels) { CML_DEV(c);
+    if (!c || !gray || levels < 1 || levels > 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
+    if (c->pyr.find(id) != c->pyr.end()) return cmlhip_pyramid_build(c, id, gray, w, h, levels);     // an id that is in use: the synchronous path (its blocks may be in flight)
+    if (!c->pyr_started) return cmlhip_pyramid_build(c, id, gray, w, h, levels);      // (no worker: its stream could not be created)
+    Pyramid& P = c->pyr[id];
+    PyrJob J;
+    memset(&J, 0, sizeof J);
+    J.id = id; J.src = gray;
+    int cw = w, ch = h, rc = 0;
+    P.levels = levels;
+    for (int l = 0; l < levels; l++) {
+        PyrLevel& L = P.lv[l];
+        L.w = cw; L.h = ch;
+        const size_t n = (size_t)cw * ch;
+        if ((rc = pool_alloc(c, n * sizeof(float), (void**)&L.gray)) || (rc = pool_alloc(c, n * texel_bytes(c), &L.grad))) break;
+        J.w[l] = cw; J.h[l] = ch; J.gray[l] = L.gray; J.grad[l] = L.grad;
+        cw /= 2; ch /= 2;
+        if (cw < 1 || ch < 1) { P.levels = l + 1; break; }
+    }
+    if (rc) { for (int l = 0; l < 8; l++) free_level(c, P.lv[l]); c->pyr.erase(id); return rc; }
+    J.levels = P.levels;
+    if (!P.ready) CML_CHECK(c, hipEventCreateWithFlags(&P.ready, hipEventDisableTiming));
+    J.ready = P.ready;
+    P.pending = true;
+    { std::lock_guard<std::mutex> lk(c->pyr_mu); c->pyr_state[id] = 1; c->pyr_jobs.push_back(J); }
+    c->pyr_cv.notify_all();
+    return CMLHIP_OK;
+}
+
 int cmlhip_pyramid_drop(cmlhip_ctx* c, uint64_t id) { CML_DEV(c);
     if (!c) return CMLHIP_ERR_INVALID;
     auto it = c->pyr.find(id);
     if (it == c->pyr.end()) return CMLHIP_ERR_NOT_FOUND;
+    if (it->second.pending) (void)pyr_settle(c, id, it->second);
     (void)hipStreamSynchronize(c->stream);
     window_forget_image(c, id);
     for (int l = 0; l < 8; l++) free_level(c, it->second.lv[l]);
+    if (it->second.ready) (void)hipEventDestroy(it->second.ready);
     c->pyr.erase(it);
     return CMLHIP_OK;
 }

@@ -11,6 +11,10 @@
 #include <map>
 #include <unordered_map>
 #include <vector>
+#include <deque>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include "../../include/cmlhip.h"
 
 #define CML_WAVE 64
@@ -33,7 +37,13 @@ struct PyrLevel {
 struct Pyramid {
     int levels = 0;
     PyrLevel lv[8];
+    // cmlhip_pyramid_build_async: the levels are allocated, their contents arrive from the context's image worker on its own stream.
+    // `ready` is recorded behind the last kernel; the first consumer (cml_find_pyr) waits for the worker to have enqueued everything and
+    // orders the context's stream behind the event.
+    bool pending = false;
+    hipEvent_t ready = nullptr;
 };
+struct PyrJob { uint64_t id; const float* src; int levels; int w[8], h[8]; float* gray[8]; void* grad[8]; hipEvent_t ready; };
 
 // per-frame device descriptor used by the BA kernels
 // the flat records cross the ABI by value from other languages (ctypes / numpy dtypes in libcml_amd/abi.py): pin their sizes
@@ -65,6 +75,13 @@ struct cmlhip_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::string err;
     std::unordered_map<uint64_t, Pyramid> pyr;
+    // image worker (cmlhip_pyramid_build_async): one host thread per context that copies the caller's image
+    // and builds the levels on pyr_stream — beside whatever the context's own stream is running (the reference builds a frame's pyramid on
+    // its capture thread, ahead of the SLAM thread: capture/CaptureImage.cpp).  The worker touches neither the cache map nor the pool.
+    std::thread pyr_thread; std::mutex pyr_mu; std::condition_variable pyr_cv;
+    std::deque<PyrJob> pyr_jobs; bool pyr_quit = false, pyr_started = false;
+    std::unordered_map<uint64_t, int> pyr_state;              // image id -> 1 with the worker, 2 enqueued on pyr_stream (ready recorded), -1 failed
+    hipStream_t pyr_stream = nullptr;
     std::multimap<size_t, void*> img_pool;                    // released pyramid levels by byte size: a new frame reuses them (no hipMalloc / hipFree per frame)
     size_t img_pool_bytes = 0;
     DevBuf img_tmp;

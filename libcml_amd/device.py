@@ -30,6 +30,7 @@ PROTOTYPES = {
     "cmlhip_stream": (C.c_void_p, [_ctx]),
     "cmlhip_pyramid_put": (C.c_int, [_ctx, C.c_uint64, _i, _P(_f), _i, _i]),
     "cmlhip_pyramid_build": (C.c_int, [_ctx, C.c_uint64, _P(_f), _i, _i, _i]),
+    "cmlhip_pyramid_build_async": (C.c_int, [_ctx, C.c_uint64, _P(_f), _i, _i, _i]),
     "cmlhip_pyramid_drop": (C.c_int, [_ctx, C.c_uint64]),
     "cmlhip_pyramid_level_size": (C.c_int, [_ctx, C.c_uint64, _i, _P(_i), _P(_i)]),
     "cmlhip_pyramid_get": (C.c_int, [_ctx, C.c_uint64, _i, _P(_f)]),
@@ -196,6 +197,14 @@ class Ctx:
         g = np.ascontiguousarray(gray, np.float32)
         self.ck(self.L.cmlhip_pyramid_build(self.h, image_id, _p(g, _f), g.shape[1], g.shape[0], levels))
 
+    def pyramid_build_async(self, image_id, gray, levels):
+        """cmlhip_pyramid_build_async: returns at once; the array is kept alive here until the image is dropped or rebuilt"""
+        g = np.ascontiguousarray(gray, np.float32)
+        if not hasattr(self, "_async_images"):
+            self._async_images = {}
+        self._async_images[int(image_id)] = g
+        self.ck(self.L.cmlhip_pyramid_build_async(self.h, image_id, _p(g, _f), g.shape[1], g.shape[0], levels))
+
     def pyramid_get(self, image_id, level):
         w, h = _i(), _i()
         self.ck(self.L.cmlhip_pyramid_level_size(self.h, image_id, level, C.byref(w), C.byref(h)))
@@ -204,7 +213,9 @@ class Ctx:
         return out
 
     def pyramid_drop(self, image_id):
-        return self.L.cmlhip_pyramid_drop(self.h, image_id)
+        rc = self.L.cmlhip_pyramid_drop(self.h, image_id)
+        getattr(self, "_async_images", {}).pop(int(image_id), None)
+        return rc
 
     # ------------------------------------------------------------------ BA
     def ba_set_params(self, prm):

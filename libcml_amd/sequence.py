@@ -142,6 +142,8 @@ class DirectPipeline:
         self.n_fid = 0
         self.times = {}                                              # stage -> list of seconds
         self._poses = None
+        self._prefetched = None                                      # (image id, gray) of the next frame, handed to the image worker
+        self.prefetch = True
         self.lib_times = {}                                          # stage -> seconds inside the library's calls of that stage (see _c)
         self.run_split = []                                          # per keyframe: the host clock of run()'s phases (HostBA.run_timing)
         self.tprm = abi.default_tracer_params()
@@ -291,11 +293,22 @@ class DirectPipeline:
                 out.append((Re @ Rc, Re @ tc))
         return out
 
-    def track(self, gray):
-        """pyramid of the new frame + trackWithMotionModel against the newest keyframe.  Returns (image_id, R, t, a, b, ok)."""
+    def track(self, gray, next_gray=None):
+        """pyramid of the new frame + trackWithMotionModel against the newest keyframe.  Returns (image_id, R, t, a, b, ok).
+        next_gray: the frame after this one, when the reader already has it — its pyramid is handed to the context's image worker
+        (cmlhip_pyramid_build_async) BEFORE this frame is tracked, as the reference's capture thread builds pyramids ahead of the SLAM thread
+        (capture/CaptureImage.cpp): staging copy, transfer and level kernels then run beside the tracker instead of in front of the next one."""
         t0 = time.perf_counter()
-        iid = self._take_id()
-        self._c("pyramid_build", self.ctx.pyramid_build, iid, gray, self.levels)
+        if self._prefetched is not None and self._prefetched[1] is gray:
+            iid = self._prefetched[0]                                 # built (or being built) by the image worker: the first call that names it waits on the device
+        else:
+            iid = self._take_id()
+            self._c("pyramid_build", self.ctx.pyramid_build, iid, gray, self.levels)
+        self._prefetched = None
+        if next_gray is not None and self.prefetch:
+            nid = self._take_id()
+            self._c("pyramid_build", self.ctx.pyramid_build_async, nid, next_gray, self.levels)
+            self._prefetched = (nid, next_gray)
         self._t("pyramid_build", t0)
         t0 = time.perf_counter()
         ref = self.kfs[self.ref]
@@ -334,18 +347,18 @@ class DirectPipeline:
                        tracer_fids=[int(f) for f in self.trc.frame_ids()])
         return counts
 
-    def non_keyframe(self, gray):
-        iid, Rn, tn, a, b, ok = self.track(gray)
+    def non_keyframe(self, gray, next_gray=None):
+        iid, Rn, tn, a, b, ok = self.track(gray, next_gray)
         self.trace(iid, Rn, tn, a, b, traced_fid=-1)
         t0 = time.perf_counter()
         self._drop(iid)                                               # CaptureImage::makeUnactive: the id is free for the next frame
         self._t("pyramid_drop", t0)
         return ok
 
-    def keyframe(self, gray):
+    def keyframe(self, gray, next_gray=None):
         """Hybrid::directMap (direct/Mapping.cpp:47-134)"""
         ctx, ba = self.ctx, self.ba
-        iid, Rn, tn, a, b, ok = self.track(gray)
+        iid, Rn, tn, a, b, ok = self.track(gray, next_gray)
         fid = self.n_fid; self.n_fid += 1
         self.trace(iid, Rn, tn, a, b, traced_fid=fid)
         # ---- addNewFrame: flagFramesForMarginalization first (BA.cpp:428), then the frame, the prior block, residuals of the old points
@@ -442,11 +455,13 @@ class DirectPipeline:
         """the whole shard: bootstrap on frame 0, then every frame in order"""
         self.bootstrap(seq.gray[0], seq.R_true[0], seq.t_true[0], seq.boot_px, seq.boot_idepth)
         kfset = set(seq.keyframes)
-        for k in range(1, n_frames or seq.n_frames):
+        last = n_frames or seq.n_frames
+        for k in range(1, last):
+            nxt = seq.gray[k + 1] if k + 1 < last else None
             if k in kfset:
-                self.keyframe(seq.gray[k])
+                self.keyframe(seq.gray[k], nxt)
             else:
-                self.non_keyframe(seq.gray[k])
+                self.non_keyframe(seq.gray[k], nxt)
         return self.stats
 
     def library_summary(self):
