@@ -735,11 +735,12 @@ int cmlhip_ba_marginalize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
     cml_launch_schur_out(c, A);
     CML_CHECK(c, hipGetLastError());
     const size_t nn = 8 * (size_t)c->N + 4;
-    if (M && (rc = cml_d2h(c, M, c->HA.p, 8 * nn * nn))) return rc;
-    if (Mb && (rc = cml_d2h(c, Mb, c->bA.p, 8 * nn))) return rc;
-    if (Msc && (rc = cml_d2h(c, Msc, c->Hsc.p, 8 * nn * nn))) return rc;
-    if (Mbsc && (rc = cml_d2h(c, Mbsc, c->bsc.p, 8 * nn))) return rc;
-    return CMLHIP_OK;
+    cml_d2h_batch_begin(c);                                  // the four results in ONE gather + copy + wait (they were four synchronous copies)
+    if (M) cml_d2h(c, M, c->HA.p, 8 * nn * nn);
+    if (Mb) cml_d2h(c, Mb, c->bA.p, 8 * nn);
+    if (Msc) cml_d2h(c, Msc, c->Hsc.p, 8 * nn * nn);
+    if (Mbsc) cml_d2h(c, Mbsc, c->bsc.p, 8 * nn);
+    return cml_d2h_batch_flush(c);
 }
 
 int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* energy, int* num) { CML_DEV(c);
@@ -758,8 +759,10 @@ int cmlhip_ba_lin_energy(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, double* en
     CML_CHECK(c, hipGetLastError());
     std::vector<double> hp(std::max(nb, 1)); std::vector<int> hn(std::max(nb, 1));
     if (nb > 0) {
-        if ((rc = cml_d2h(c, hp.data(), part, 8 * (size_t)nb))) return rc;
-        if ((rc = cml_d2h(c, hn.data(), nums, 4 * (size_t)nb))) return rc;
+        cml_d2h_batch_begin(c);
+        cml_d2h(c, hp.data(), part, 8 * (size_t)nb);
+        cml_d2h(c, hn.data(), nums, 4 * (size_t)nb);
+        if ((rc = cml_d2h_batch_flush(c))) return rc;
     }
     double F = 0;                                            // BA.cpp:2131-2142
     for (int i = 0; i < 8 * c->N; i++) F += in->delta_prior[i] * in->prior[i] * in->delta_prior[i];
