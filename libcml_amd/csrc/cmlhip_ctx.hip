@@ -423,6 +423,7 @@ __global__ void k_tile_level0_f16(const uint2* __restrict__ img, int w, int h, i
 
 int cml_tiled_level0(cmlhip_ctx* c, uint64_t id, const void** out) {
     auto it = c->pyr.find(id);
+    if (it != c->pyr.end() && it->second.pending && pyr_settle(c, id, it->second)) return CMLHIP_ERR_HIP;
     if (it == c->pyr.end() || !it->second.lv[0].grad || c->lim.texel_format != CMLHIP_TEXEL_F16) return CMLHIP_ERR_NOT_FOUND;
     PyrLevel& L = it->second.lv[0];
     if (!L.tiled) { if (int rc = pool_alloc(c, cml_tiled_bytes(L.w, L.h), &L.tiled)) return rc; L.tiled_valid = false; }
@@ -441,6 +442,7 @@ extern "C" {
 int cmlhip_pyramid_put(cmlhip_ctx* c, uint64_t id, int level, const float* aos3, int w, int h) { CML_DEV(c);
     if (!c || !aos3 || level < 0 || level >= 8 || w <= 0 || h <= 0) return CMLHIP_ERR_INVALID;
     Pyramid& P = c->pyr[id];
+    if (P.pending) (void)pyr_settle(c, id, P);              // (an image the worker is still building: ordered ahead of the put)
     PyrLevel& L = P.lv[level];
     (void)hipStreamSynchronize(c->stream);
     if (L.w != w || L.h != h) { if (level == 0 && L.grad) window_forget_image(c, id); free_level(c, L); }
