@@ -288,6 +288,9 @@ int cmlhip_ba_get_idepth(cmlhip_ctx* ctx, double* idepth /* P */);
 int cmlhip_ba_linearize(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);
 /* applyActiveRes(copyJacobians) (BA.cpp:2045-2093) */
 int cmlhip_ba_apply(cmlhip_ctx* ctx, int copy_jacobians);
+/* cmlhip_ba_linearize followed by cmlhip_ba_apply(ctx, 1) as ONE pass over the residuals (the preamble of BA::run, BA.cpp:785-790: linearizeAll(false),
+ * then applyRes(r, true) of every residual with nothing in between).  Same results as the two calls. */
+int cmlhip_ba_linearize_apply(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);
 /* The tail of DSOBundleAdjustment::run in one call and ONE readback: linearizeAll(true) (BA.cpp:896 = linearize + applyRes(true),
  * :1551-1569) followed by everything the host writes back afterwards — residual states / energies (:1571-1640), the points'
  * inverse depths and the per-point accumulators (HdiF -> setInverseDepthHessian, :1889-1901).  pairs must be current.

@@ -448,6 +448,23 @@ int cmlhip_ba_linearize(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DEV(c);
     return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
 }
 
+// linearizeAll(false) + applyRes(r, true) of BA::run's preamble (BA.cpp:785-790: nothing sits between them) as ONE pass over the residuals
+int cmlhip_ba_linearize_apply(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DEV(c);
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    A.fuse_apply = 1;
+    cml_launch_linearize(c, A);
+    cml_launch_lin_finish(c, A);
+    CML_CHECK(c, hipGetLastError());
+    LinSummary S;
+    if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
+    if (out) { out->energy = S.energy; out->n_in = S.n_in; out->n_oob = S.n_oob; out->n_outlier = S.n_outlier; out->new_frame_energy_th = S.new_frame_energy_th; }
+    return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
+}
+
 int cmlhip_ba_apply(cmlhip_ctx* c, int copy) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
     "cmlhip_ba_linearize": (C.c_int, [_ctx, _P(abi.BALinResult)]),
     "cmlhip_ba_apply": (C.c_int, [_ctx, _i]),
+    "cmlhip_ba_linearize_apply": (C.c_int, [_ctx, _P(abi.BALinResult)]),
     "cmlhip_ba_accumulate": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d)]),
     "cmlhip_ba_solve": (C.c_int, [_ctx, _d, _P(_d), _P(_d), _i, _P(_d)]),
     "cmlhip_ba_backsub": (C.c_int, [_ctx, _P(_d), _P(_d)]),

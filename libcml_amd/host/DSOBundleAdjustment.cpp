@@ -437,7 +437,7 @@ bool DSOBundleAdjustment::uploadWindow() {
     return true;
 }
 
-bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut) {   // BA.cpp:1497-1646
+bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut, bool applyToo) {   // BA.cpp:1497-1646
     const auto TL0 = std::chrono::steady_clock::now();
     auto lapL = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "      [linearizeAll] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TL0).count()); };
     std::vector<cmlhip_ba_pair> pairs;
@@ -463,7 +463,7 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
                                        idepthOut ? idepthOut->data() : nullptr, pointAccOut ? pointAccOut->data() : nullptr);
         if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_finish_keyframe", rc);
     } else {
-        rc = cmlhip_ba_linearize(mCtx, &lr);
+        rc = applyToo ? cmlhip_ba_linearize_apply(mCtx, &lr) : cmlhip_ba_linearize(mCtx, &lr);
         if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_linearize", rc);
     }
     lapL("device call done");
@@ -637,10 +637,8 @@ bool DSOBundleAdjustment::runPreamble(double lastEnergy[3]) {                // 
     if (!uploadWindow()) return false;
     lap("uploadWindow");
     lastRunUs[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count();
-    if (!linearizeAll(false, lastEnergy)) return false;
+    if (!linearizeAll(false, lastEnergy, nullptr, nullptr, true)) return false;   // linearizeAll(false) + applyActiveRes(true), :785-790, one pass on the device
     lap("linearizeAll");
-    int rc = cmlhip_ba_apply(mCtx, 1);                                        // applyActiveRes(true), :790
-    if (rc) return fail("cmlhip_ba_apply", rc);
     statEnergyP.push_back(lastEnergy[0] / std::max<size_t>(1, mActive.size()));
     return true;
 }

@@ -164,7 +164,7 @@ private:
     void fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double>& prior, std::vector<double>& dprior, double cdelta[4], double cprior[4]);
     bool runPreamble(double lastEnergy[3]);
     bool runEpilogue(double lastEnergy[3]);
-    bool linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut = nullptr, std::vector<float>* pointAccOut = nullptr);
+    bool linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut = nullptr, std::vector<float>* pointAccOut = nullptr, bool applyToo = false);
     bool solveSystem(int iteration, double lambda);
     bool doStepFromBackup(bool fixCamera);
     void backupState();
