@@ -17,23 +17,42 @@ __device__ __forceinline__ void lin_finish_block(const BAArgs& A, const int* new
         e += lin_partial[4 * (size_t)b]; c0 += lin_partial[4 * (size_t)b + 1];
         c1 += lin_partial[4 * (size_t)b + 2]; c2 += lin_partial[4 * (size_t)b + 3];
     }
+    // (round 4: the four sums through ONE exchange — a fixed butterfly inside each wave, then the waves' sums added in wave order by every
+    //  thread — instead of four ten-level trees of workgroup barriers; the order is fixed by the block size alone)
     double tot[4];
     double vals[4] = {e, c0, c1, c2};
+#pragma unroll
     for (int k = 0; k < 4; k++) {
-        s_f64[tid] = vals[k];
-        __syncthreads();
-        for (int s = nt >> 1; s > 0; s >>= 1) {
-            if (tid < s) s_f64[tid] += s_f64[tid + s];
-            __syncthreads();
-        }
-        tot[k] = s_f64[0];
-        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vals[k] += __shfl_xor(vals[k], o);
     }
+    const int nw = nt >> 6;
+    if ((tid & 63) == 0) { for (int k = 0; k < 4; k++) s_f64[4 * (tid >> 6) + k] = vals[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) { double t_ = 0; for (int w = 0; w < nw; w++) t_ += s_f64[4 * w + k]; tot[k] = t_; }
+    __syncthreads();
     // ---- number of valid candidates (residuals into the newest frame with NewEnergyWithOutlier >= 0)
     if (tid == 0) s_misc[2] = 0;
     __syncthreads();
+    // the candidates of this thread, fetched ONCE (bit patterns; 0xFFFFFFFF = not a candidate: a negative or NaN energy, a LINEARIZED residual) —
+    // the four passes of the select below then run from registers; candidates beyond LF_CACHE per thread are re-read as before
+    constexpr int LF_CACHE = 4;
+    unsigned cand[LF_CACHE];
     unsigned nvalid = 0;
-    for (int i = tid; i < n_newframe; i += nt) {
+#pragma unroll
+    for (int q = 0; q < LF_CACHE; q++) {
+        const int i = tid + q * nt;
+        unsigned b = 0xFFFFFFFFu;
+        if (i < n_newframe) {
+            const int r = newframe_res[i];
+            const float v = A.r_new_energy_wo[r];
+            if (!A.r_lin[r] && v >= 0.f) b = __float_as_uint(v);
+        }
+        cand[q] = b;
+        nvalid += b != 0xFFFFFFFFu;
+    }
+    for (int i = tid + LF_CACHE * nt; i < n_newframe; i += nt) {
         const int r = newframe_res[i];
         nvalid += (!A.r_lin[r] && A.r_new_energy_wo[r] >= 0.f);
     }
@@ -52,7 +71,12 @@ __device__ __forceinline__ void lin_finish_block(const BAArgs& A, const int* new
             __syncthreads();
             const unsigned prefix = s_misc[0];
             const unsigned hmask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
-            for (int i = tid; i < n_newframe; i += nt) {
+#pragma unroll
+            for (int q = 0; q < LF_CACHE; q++) {
+                const unsigned b = cand[q];
+                if (b != 0xFFFFFFFFu && (b & hmask) == prefix) atomicAdd(&s_hist[(b >> (8 * pass)) & 0xFFu], 1u);
+            }
+            for (int i = tid + LF_CACHE * nt; i < n_newframe; i += nt) {
                 const int r = newframe_res[i];
                 const float v = A.r_new_energy_wo[r];
                 if (A.r_lin[r] || !(v >= 0.f)) continue;
