@@ -489,7 +489,7 @@ def sequence_bench(device_id, seed, want_cpu):
             out["parity_ok"] = len(rep["failures"]) == 0
             out["parity"] = {"stages_replayed": rep["stages"], "worst": rep["worst"], "flips": rep["flips"], "failures": rep["failures"][:8],
                              "counts": {k: v for k, v in rep.items() if isinstance(v, int)},
-                             "run_yardstick": rep.get("run_yardstick", []),
+                             "run_yardstick": rep.get("run_yardstick", []), "track_yardstick_used": rep.get("track_yardstick_used", 0),
                              "run_yardstick_note": "runs whose distance from the oracle exceeded the fixed bars and were held against the oracle's own response to "
                                                    "rounding-sized noise instead: within the fixed bars of at least one member of {oracle with inverse depths perturbed by "
                                                    "1e-7 (4 draws), oracle built with the Release flags} (tests/sequence_check.py)"}
