@@ -358,6 +358,8 @@ class SequenceChecker:
             return
         if o["winner"] != r["winner"] or o["tries"] != r["tries"]:
             self.report["flips"]["tracker_winner"] += 1
+            self.report.setdefault("tracker_winner_detail", []).append(dict(oracle=(o["winner"], o["tries"], float(o["achieved"])), product=(int(r["winner"]), int(r["tries"]), float(r["lastCoarseRMSE"])),
+                                                                           last_coarse_rmse=float(info["last_coarse_rmse"])))
         dR = float(np.abs(o["R"] - r["R"]).max()); dt = float(np.abs(o["t"] - r["t"]).max() / max(1.0, np.abs(o["t"]).max()))
         self._worst("track_R", dR); self._worst("track_t_rel", dt)
         self._worst("track_a", abs(o["a"] - r["exposure"][0])); self._worst("track_b", abs(o["b"] - r["exposure"][1]))

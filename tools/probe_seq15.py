@@ -16,3 +16,5 @@ st = pipe.run(seq)
 rep = chk.report
 print("seq", s_, "early", early, "prefetch", prefetch, "split", os.environ.get("CMLHIP_TRACKER_SPLIT"), "failures", rep["failures"], "worst track", {k: "%.2e" % v for k, v in rep["worst"].items() if k.startswith("track")}, "flips", rep["flips"])
 pipe.close(); ctx.close()
+for d in rep.get("tracker_winner_detail", []):
+    print("   winner/tries flip:", d)
