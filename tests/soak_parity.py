@@ -359,7 +359,7 @@ def sequence_family(n):
     (tests/sequence_check.py); prints the worst deviations over all sequences and how often the noise-ensemble yardstick was needed"""
     from libcml_amd import sequence
     from tests import sequence_check as SC
-    worst, fails, yard, runs, flips, resid, tyard, tflips = {}, [], 0, 0, 0, 0, 0, 0
+    worst, fails, yard, runs, flips, resid, tyard, tflips, margins = {}, [], 0, 0, 0, 0, 0, 0, []
     for s_ in range(n):
         seq = sequence.make_sequence(n_frames=28, seed=0x5EED + 101 * s_, shard=s_)
         ctx = device.Ctx(max_frames=8, max_points=8192, max_residuals=8192 * 8)
@@ -376,10 +376,12 @@ def sequence_family(n):
         yard += rep.get("run_yardstick_used", 0); runs += rep.get("runs", 0)
         flips += rep["flips"]["run_residual_sets"]; resid += rep["flips"]["run_residuals"]
         tyard += rep.get("track_yardstick_used", 0); tflips += rep["flips"]["tracker_winner"]
+        margins += [t_["margin"] for t_ in rep.get("track_decisions_on_rounding", []) if t_["margin"] is not None]
         print("sequence %d: %d frames, %d keyframes, max window %d, %d frames marginalised, tracking lost %d, failures %d, yardstick runs %d" % (
             s_, st["frames"], st["keyframes"], st["max_window"], st["marginalized_frames"], st["tracking_lost"], len(rep["failures"]), rep.get("run_yardstick_used", 0)))
     print("sequence family: %d sequences, %d runs (%d held against the noise ensemble), residual decisions differing %d of %d" % (n, runs, yard, flips, resid))
-    print("   tracked frames whose winner / number of tries differ from the oracle's: %d; held against the oracle's noise ensemble: %d" % (tflips, tyard))
+    print("   tracked frames whose winner / number of tries differ from the oracle's: %d; held against the oracle's noise ensemble: %d; separated from the oracle by an accept decision on a rounding-sized margin: %s" % (
+        tflips, tyard, ["%.1e" % m for m in margins]))
     for k in sorted(worst):
         print("   worst %-24s %.2e" % (k, worst[k]))
     for f in fails:

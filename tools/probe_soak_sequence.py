@@ -18,3 +18,9 @@ print("seq", s_, "early", early, "prefetch", prefetch, "split", os.environ.get("
 pipe.close(); ctx.close()
 for d in rep.get("tracker_winner_detail", []):
     print("   winner/tries flip:", d)
+for y in rep.get("run_yardstick", []):
+    print("   run yardstick: N", y["N"], "R", y["R"], "iterations", y.get("iterations"), "accepted by", y.get("accepted_by"), "spread", {k: "%.2e" % v for k, v in y.get("ensemble_spread", {}).items()}, "device vs oracle", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in y["device_vs_oracle"].items()})
+    print("      energies device", ["%.6g" % x for x in y.get("energies_device", [])], "oracle", ["%.6g" % x for x in y.get("energies_oracle", [])])
+    print("      device vs nearest member", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in y["device_vs_nearest_member"].items()})
+    for name, dd in y["members_vs_oracle"].items():
+        print("      member vs oracle  %-34s" % name, {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in dd.items()})
