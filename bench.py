@@ -490,9 +490,12 @@ def sequence_bench(device_id, seed, want_cpu):
             out["parity"] = {"stages_replayed": rep["stages"], "worst": rep["worst"], "flips": rep["flips"], "failures": rep["failures"][:8],
                              "counts": {k: v for k, v in rep.items() if isinstance(v, int)},
                              "run_yardstick": rep.get("run_yardstick", []), "track_yardstick_used": rep.get("track_yardstick_used", 0),
+                             "track_decisions_on_rounding": rep.get("track_decisions_on_rounding", []),
                              "run_yardstick_note": "runs whose distance from the oracle exceeded the fixed bars and were held against the oracle's own response to "
-                                                   "rounding-sized noise instead: within the fixed bars of at least one member of {oracle with inverse depths perturbed by "
-                                                   "1e-7 (4 draws), oracle built with the Release flags} (tests/sequence_check.py)"}
+                                                   "rounding-sized noise instead: within the fixed bars of a member of {oracle with inverse depths perturbed by 1e-7 (2 draws) / "
+                                                   "1e-6 (4 draws: the rounding of the fp32 accumulations), oracle built with the Release flags}, or no further from the oracle than "
+                                                   "four times that ensemble's spread; tracked frames likewise, or separated from the oracle by ONE accept decision taken on a "
+                                                   "margin below 1e-4 (tests/sequence_check.py)"}
             out["cpu_baseline"] = {"kind": "port", "cores": 1, "seconds": float(sum(chk.oracle_seconds.values())), "per_stage_s": {k: float(v) for k, v in chk.oracle_seconds.items()},
                                    "sample": "the oracle's replay of every stage of the same sequence from the product's state (tests/sequence_check.py: oracle/*.c through ctypes, "
                                              "checker build -O2, one thread; includes the checker's own set-up of each stage's window)"}
