@@ -456,7 +456,10 @@ int cmlhip_ba_linearize_apply(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DE
     BAArgs A;
     cml_make_ba_args(c, A);
     A.fuse_apply = 1;
-    cml_launch_linearize(c, A);
+    if (c->rs_ok && c->n_tiles > 0 && c->n_lin == 0) {      // the resident loop's own residual kernel: the pass leaves the pair tiles its first accumulation reads
+        cml_launch_linearize_rs(c, A);                      // (28 us of record-path accumulation become 10 at the sequence's window; records re-materialise on demand)
+        c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
+    } else cml_launch_linearize(c, A);
     cml_launch_lin_finish(c, A);
     CML_CHECK(c, hipGetLastError());
     LinSummary S;

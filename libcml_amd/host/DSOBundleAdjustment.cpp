@@ -434,7 +434,18 @@ bool DSOBundleAdjustment::uploadWindow() {
     }
     rc = cmlhip_ba_upload_window(mCtx, N, fr.data(), (int)pts.size(), pts.data(), (int)rs.size(), rs.data());
     if (rc) return fail("cmlhip_ba_upload_window", rc);
+    mPairsValid = false;                                     // (an upload forgets the pair records)
     return true;
+}
+
+// cmlhip_ba_set_pairs unless the device already holds exactly these records for this upload (run()'s preamble and beginResident compute the
+// same N^2 records from the same frame states)
+int DSOBundleAdjustment::setPairs(const std::vector<cmlhip_ba_pair>& pairs) {
+    if (mPairsValid && mPairsSent.size() == pairs.size() && std::memcmp(mPairsSent.data(), pairs.data(), sizeof(cmlhip_ba_pair) * pairs.size()) == 0) return CMLHIP_OK;
+    const int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+    mPairsValid = rc == CMLHIP_OK;
+    if (mPairsValid) mPairsSent = pairs;
+    return rc;
 }
 
 bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut, bool applyToo) {   // BA.cpp:1497-1646
@@ -442,7 +453,7 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
     auto lapL = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "      [linearizeAll] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TL0).count()); };
     std::vector<cmlhip_ba_pair> pairs;
     framePairs(pairs);
-    int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+    int rc = setPairs(pairs);
     if (rc) return fail("cmlhip_ba_set_pairs", rc);
     lapL("pairs set");
     cmlhip_ba_lin_result lr;
@@ -854,7 +865,7 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
         computeDelta();
         std::vector<cmlhip_ba_pair> pairs;
         framePairs(pairs);
-        int rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+        int rc = setPairs(pairs);
         if (rc) return fail("cmlhip_ba_set_pairs", rc);
         cmlhip_ba_accum_in in; std::vector<double> prior, dprior; double cdelta[4], cprior[4];
         fillAccumIn(in, prior, dprior, cdelta, cprior);
@@ -1021,7 +1032,7 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
     framePairs(pairs);
     int rc = cmlhip_ba_set_arithmetic(mCtx, mRelaxedArithmetic ? CMLHIP_ARITH_RELAXED : CMLHIP_ARITH_EXACT);
     if (rc) return fail("cmlhip_ba_set_arithmetic", rc);
-    rc = cmlhip_ba_set_pairs(mCtx, pairs.data());
+    rc = setPairs(pairs);                                    // (unchanged since run()'s preamble: not sent again — a new set would also discard the pass's pair tiles)
     if (rc) return fail("cmlhip_ba_set_pairs", rc);
     std::vector<double> prior(8 * (size_t)N), dprior(8 * (size_t)N);
     for (int i = 0; i < N; i++) for (int k = 0; k < 8; k++) { prior[8 * i + k] = mFrames[i].prior[k]; dprior[8 * i + k] = mFrames[i].delta_prior[k]; }
@@ -1063,6 +1074,7 @@ bool DSOBundleAdjustment::iterateResident(int k, double lambda) {
 }
 
 bool DSOBundleAdjustment::endResident(double* lastEnergy) {
+    mPairsValid = false;                                     // (the device's frame step has rewritten the pair records)
     const int N = (int)mFrames.size();
     double sc[4];
     scales(sc);

@@ -155,6 +155,8 @@ public:
 
 private:
     std::vector<cmlhip_ba_point> mUploadPoints; std::vector<cmlhip_ba_residual> mUploadResiduals;      // uploadWindow's arrays, kept between keyframes
+    int setPairs(const std::vector<cmlhip_ba_pair>& pairs);
+    std::vector<cmlhip_ba_pair> mPairsSent; bool mPairsValid = false;      // the pair records the device holds for the current upload
     bool uploadWindow();
     bool isOOB(int p, const std::vector<int>& toMarg) const;                  // BA.cpp:2515-2554
     void removePoint(int p, bool marginalize, bool sweep = true);             // DSOContext.h:94-111 (sweep: removePointsWithoutResidual behind it, :218-229)
