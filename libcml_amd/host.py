@@ -46,6 +46,7 @@ def lib():
         L.cmlhost_ba_get_point_flags.argtypes = [_vp, _P(_u8), _P(_u8), _P(_f)]
         L.cmlhost_ba_rejected.argtypes = [_vp]
         L.cmlhost_ba_run_timing.argtypes = [_vp, _P(_d)]
+        L.cmlhost_ba_coarse_depth_points.argtypes = [_vp, _i, _P(_d), _P(_d), _i]
         L.cmlhost_ba_last_lambda.restype = _d; L.cmlhost_ba_last_lambda.argtypes = [_vp]
         L.cmlhost_ba_calc_m_energy.restype = _d; L.cmlhost_ba_calc_m_energy.argtypes = [_vp]
         L.cmlhost_ba_calc_l_energy.restype = _d; L.cmlhost_ba_calc_l_energy.argtypes = [_vp]
@@ -218,6 +219,16 @@ class HostBA:
         tm = np.zeros(n, np.uint8); mg = np.zeros(n, np.uint8); ih = np.zeros(n, np.float32)
         self.L.cmlhost_ba_get_point_flags(self.h, _p(tm, _u8), _p(mg, _u8), _p(ih, _f))
         return tm, mg, ih
+
+    def coarse_depth_points(self, kf_index, K):
+        """getGoodPointsForTracking + the host half of makeCoarseDepthL0 (TR.cpp:521-553): (n, 4) array of (u, v, idepth, weight) in keyframe kf_index"""
+        cap = max(self.counts()["points"], 1)
+        out = np.zeros((cap, 4))
+        k = np.ascontiguousarray(K, np.float64)
+        n = self.L.cmlhost_ba_coarse_depth_points(self.h, int(kf_index), _p(k, _d), _p(out, _d), cap)
+        if n < 0:
+            raise RuntimeError("cmlhost_ba_coarse_depth_points: %d" % n)
+        return out[:n]
 
     def run_timing(self):
         """host clock of the last resident run(), microseconds: upload | first pass | resident state | enqueue | wait + readback | closing pass"""

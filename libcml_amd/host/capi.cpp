@@ -147,6 +147,39 @@ int cmlhost_ba_get_indirect(void* h, double* x6, double* uncertainty, double* x)
     if (x) std::copy(b->lastX().begin(), b->lastX().end(), x);
     return (int)b->lastIndirectX().size();
 }
+// getGoodPointsForTracking (BA.h:76-85) + the host half of DSOTracker::makeCoarseDepthL0 (TR.cpp:521-553): every live point whose newest residual is
+// IN, projected from its host frame into keyframe `kf` — (u, v, idepth in kf, weight) per point, 4 doubles each; returns the count (cap: room in `out`)
+int cmlhost_ba_coarse_depth_points(void* h, int kf, const double K[4], double* out, int cap) {
+    DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);
+    const auto& F = b->getFrames(); const auto& Pts = b->getPoints();
+    if (kf < 0 || kf >= (int)F.size()) return -1;
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    std::vector<double> Rr(9 * F.size()), tr(3 * F.size());
+    double Rn[9]; F[kf].PRE_worldToCam.matrix(Rn);
+    const double* tn = F[kf].PRE_worldToCam.t;
+    for (size_t hh = 0; hh < F.size(); hh++) {                       // host -> kf: R = Rn Rh^T, t = tn - R th (Camera::to)
+        double Rh[9]; F[hh].PRE_worldToCam.matrix(Rh);
+        const double* th = F[hh].PRE_worldToCam.t;
+        double* R = &Rr[9 * hh];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = Rn[i * 3] * Rh[j * 3] + Rn[i * 3 + 1] * Rh[j * 3 + 1] + Rn[i * 3 + 2] * Rh[j * 3 + 2];
+        for (int i = 0; i < 3; i++) tr[3 * hh + i] = tn[i] - (R[i * 3] * th[0] + R[i * 3 + 1] * th[1] + R[i * 3 + 2] * th[2]);
+    }
+    int n = 0;
+    for (const auto& P : Pts) {
+        if (!P.alive || P.lastResidual[0] < 0 || P.lastResidualState[0] != DSORES_IN) continue;
+        if (n >= cap) return -2;
+        const double* R = &Rr[9 * (size_t)P.host]; const double* t = &tr[3 * (size_t)P.host];
+        const double idp = (double)P.idepth;
+        const double r0 = ((double)P.x - cx) * (1.0 / fx), r1 = ((double)P.y - cy) * (1.0 / fy);
+        const double p0 = R[0] * r0 + R[1] * r1 + R[2] + idp * t[0], p1 = R[3] * r0 + R[4] * r1 + R[5] + idp * t[1], p2 = R[6] * r0 + R[7] * r1 + R[8] + idp * t[2];
+        const double unc = 1.0 / ((double)P.idepth_hessian + 0.01);                        // DSOPoint::updatePointUncertainty (DSOPoint.h:107-117)
+        const float wgt = std::sqrt((float)(1e-3 / (unc + 1e-12)));
+        double* o = out + 4 * (size_t)n;
+        o[0] = (p0 / p2) * fx + cx; o[1] = (p1 / p2) * fy + cy; o[2] = (1.0 / p2) * idp; o[3] = (double)wgt;
+        n++;
+    }
+    return n;
+}
 void cmlhost_ba_run_timing(void* h, double us[6]) { for (int i = 0; i < 6; i++) us[i] = static_cast<DSOBundleAdjustment*>(h)->lastRunUs[i]; }
 int cmlhost_ba_rejected(void* h) { return static_cast<DSOBundleAdjustment*>(h)->statRejected; }
 double cmlhost_ba_last_lambda(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastLambda; }

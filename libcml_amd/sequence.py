@@ -227,25 +227,8 @@ class DirectPipeline:
         return px
 
     def _coarse_depth(self, kf_index):
-        """host half of makeCoarseDepthL0 (DSOTracker.cpp:521-553) over getGoodPointsForTracking (BA.h:76-85)"""
-        fr, pt, rs = self.ba.export()
-        good = np.flatnonzero((pt["alive"] == 1) & (pt["lastResidual"][:, 0] >= 0) & (pt["lastResidualState"][:, 0] == 0))
-        poses = self.kf_poses()
-        Rn, tn = poses[kf_index][0], poses[kf_index][1]
-        fx, fy, cx, cy = self.K
-        out = np.zeros((len(good), 4))
-        hosts = pt["host"][good]
-        for hh in np.unique(hosts):
-            m = hosts == hh
-            i = good[m]
-            R, t = _rel(poses[hh][0], poses[hh][1], Rn, tn)
-            idp = pt["idepth"][i].astype(np.float64)
-            ray = np.stack([(pt["x"][i].astype(np.float64) - cx) * (1.0 / fx), (pt["y"][i].astype(np.float64) - cy) * (1.0 / fy), np.ones(len(i))], 1)
-            p = ray @ R.T + idp[:, None] * t[None, :]
-            unc = 1.0 / (pt["idepth_hessian"][i].astype(np.float64) + 0.01)        # DSOPoint::updatePointUncertainty (DSOPoint.h:107-117)
-            wgt = np.sqrt((1e-3 / (unc + 1e-12)).astype(np.float32)).astype(np.float32)
-            out[m, 0] = (p[:, 0] / p[:, 2]) * fx + cx; out[m, 1] = (p[:, 1] / p[:, 2]) * fy + cy; out[m, 2] = (1.0 / p[:, 2]) * idp; out[m, 3] = wgt
-        return out
+        """host half of makeCoarseDepthL0 (DSOTracker.cpp:521-553) over getGoodPointsForTracking (BA.h:76-85): in the host mirror (capi.cpp)"""
+        return self.ba.coarse_depth_points(kf_index, self.K)
 
     # ------------------------------------------------------------------ stages
     def bootstrap(self, gray, R, t, px, idepth):
@@ -408,7 +391,7 @@ class DirectPipeline:
                        grads0=[k_["grad0"] for k_ in self.kfs], outliers=ba.outliers().copy())
         # ---- makeCoarseDepthL0 on the new keyframe
         t0 = time.perf_counter()
-        cd = self._coarse_depth(len(self.kfs) - 1)
+        cd = self._c("makeCoarseDepthL0", self._coarse_depth, len(self.kfs) - 1)
         nout = self._c("makeCoarseDepthL0", self.trk.make_coarse_depth, iid, self.levels, cd)
         self._t("makeCoarseDepthL0", t0)
         self._emit("coarse", image_id=iid, gray=gray, pts=cd, n_lists=nout, levels=self.levels)
