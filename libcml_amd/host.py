@@ -80,6 +80,7 @@ def lib():
         L.cmlhost_tracer_add_points.argtypes = [_vp, _i, _P(_f), _i, _P(_f), _P(_f), _P(_d)]
         L.cmlhost_tracer_compact.argtypes = [_vp]
         L.cmlhost_tracer_get_frame_ids.argtypes = [_vp, _P(_i)]
+        L.cmlhost_tracer_immature_counts.argtypes = [_vp, _i, _P(_i), _P(_i)]
         L.cmlhost_ba_add_points.argtypes = [_vp, _i, _P(_f), _P(_d), _P(_i), _P(_f), _P(_f), _i]
         L.cmlhost_tracer_trace.argtypes = [_vp, C.c_uint64, _i, _i, _P(_i), _vp, _P(_i)]
         L.cmlhost_tracer_activate.argtypes = [_vp, _i, _P(_i), _P(C.c_uint64), _P(_d), _i, _i, _vp, _P(_i), _i]
@@ -444,6 +445,12 @@ class HostTracer:
         out = np.zeros(max(self.L.cmlhost_tracer_count(self.h), 1), np.int32)
         self.L.cmlhost_tracer_get_frame_ids(self.h, _p(out, _i))
         return out[:self.L.cmlhost_tracer_count(self.h)]
+
+    def immature_counts(self, frame_ids):
+        """live immature points per frame id"""
+        ids = np.ascontiguousarray(frame_ids, np.int32); out = np.zeros(max(len(ids), 1), np.int32)
+        self.L.cmlhost_tracer_immature_counts(self.h, len(ids), _p(ids, _i), _p(out, _i))
+        return [int(x) for x in out[:len(ids)]]
 
     def trace_new_coarse(self, image_id, traced_frame_id, frame_ids, pairs):
         ids = np.ascontiguousarray(frame_ids, np.int32); pr = np.ascontiguousarray(pairs, abi.TRACE_PAIR_DTYPE)

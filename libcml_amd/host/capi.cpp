@@ -354,6 +354,15 @@ int cmlhost_tracer_activate(void* h, int n_frames, const int* frame_ids, const u
     return (int)act.size();
 }
 int cmlhost_tracer_count(void* h) { return (int)static_cast<cml_amd::DSOTracer*>(h)->points().size(); }
+// immature points still alive per frame id (what flagFramesForMarginalization weighs, BA.cpp:428-462 via DSOContext's per-frame groups)
+void cmlhost_tracer_immature_counts(void* h, int n_frames, const int* frame_ids, int* counts) {
+    auto& P = static_cast<cml_amd::DSOTracer*>(h)->points();
+    for (int k = 0; k < n_frames; k++) counts[k] = 0;
+    for (size_t i = 0; i < P.size(); i++) {
+        if (!P[i].alive || P[i].activated) continue;
+        for (int k = 0; k < n_frames; k++) if (frame_ids[k] == P[i].frame_id) { counts[k]++; break; }
+    }
+}
 void cmlhost_tracer_get_points(void* h, cmlhip_immature_point* out, unsigned char* alive, unsigned char* activated, float* idepth) {
     auto& P = static_cast<cml_amd::DSOTracer*>(h)->points();
     for (size_t i = 0; i < P.size(); i++) { out[i] = P[i].d; alive[i] = P[i].alive; activated[i] = P[i].activated; idepth[i] = P[i].idepth; }

@@ -213,10 +213,7 @@ class DirectPipeline:
         return pr
 
     def _immature_counts(self):
-        pts, alive, act, _ = self.trc.points()
-        fids = self.trc.frame_ids()
-        live = (alive == 1) & (act == 0)
-        return [int((live & (fids == kf["fid"])).sum()) for kf in self.kfs]
+        return self.trc.immature_counts([kf["fid"] for kf in self.kfs])
 
     def _make_new_traces(self, kf):
         """DSOTracer::makeNewTraces (DSOTracer.cpp:496-541) with the stand-in pixel selector"""
