@@ -81,6 +81,7 @@ def lib():
         L.cmlhost_tracer_compact.argtypes = [_vp]
         L.cmlhost_tracer_get_frame_ids.argtypes = [_vp, _P(_i)]
         L.cmlhost_tracer_immature_counts.argtypes = [_vp, _i, _P(_i), _P(_i)]
+        L.cmlhost_tracer_add_activated_to_ba.argtypes = [_vp, _vp, _i, _P(_i), _i, _P(_i), _P(_i)]
         L.cmlhost_ba_add_points.argtypes = [_vp, _i, _P(_f), _P(_d), _P(_i), _P(_f), _P(_f), _i]
         L.cmlhost_tracer_trace.argtypes = [_vp, C.c_uint64, _i, _i, _P(_i), _vp, _P(_i)]
         L.cmlhost_tracer_activate.argtypes = [_vp, _i, _P(_i), _P(C.c_uint64), _P(_d), _i, _i, _vp, _P(_i), _i]
@@ -445,6 +446,16 @@ class HostTracer:
         out = np.zeros(max(self.L.cmlhost_tracer_count(self.h), 1), np.int32)
         self.L.cmlhost_tracer_get_frame_ids(self.h, _p(out, _i))
         return out[:self.L.cmlhost_tracer_count(self.h)]
+
+    def add_activated_to_ba(self, ba, activated, frame_ids):
+        """the activated points handed to BA::addPoints (colours = gray patch, gradient weights, host = window index of the point's keyframe);
+        returns (first BA point index, (n, 2) int pixels)"""
+        idx = np.ascontiguousarray(activated, np.int32); ids = np.ascontiguousarray(frame_ids, np.int32)
+        xy = np.zeros((max(len(idx), 1), 2), np.int32)
+        first = self.L.cmlhost_tracer_add_activated_to_ba(self.h, ba.h, len(idx), _p(idx, _i), len(ids), _p(ids, _i), _p(xy, _i))
+        if first < 0:
+            raise RuntimeError("cmlhost_tracer_add_activated_to_ba: bad point index / frame id")
+        return first, xy[:len(idx)]
 
     def immature_counts(self, frame_ids):
         """live immature points per frame id"""

@@ -354,6 +354,29 @@ int cmlhost_tracer_activate(void* h, int n_frames, const int* frame_ids, const u
     return (int)act.size();
 }
 int cmlhost_tracer_count(void* h) { return (int)static_cast<cml_amd::DSOTracer*>(h)->points().size(); }
+// DSOTracer::activatePoints hands its activated points to BA::addPoints (DSOTracer.cpp:199-210 -> BA.cpp:343-415): pixel, activated inverse depth,
+// host keyframe (window index of the point's frame id), the gray patch as colours, gradient weights sqrt(c / (c + |grad|^2)), c = 50^2 (BA.cpp:405-411).
+// xy_out (n x 2 ints, optional): the pixels handed over (the caller's pixel selector keeps them occupied).  Returns the first BA point index or -1.
+int cmlhost_tracer_add_activated_to_ba(void* tr, void* ba, int n, const int* idx, int n_frames, const int* frame_ids, int* xy_out) {
+    auto& P = static_cast<cml_amd::DSOTracer*>(tr)->points();
+    DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(ba);
+    const int first = (int)b->getPoints().size();
+    for (int k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= (int)P.size()) return -1;
+        const auto& q = P[(size_t)idx[k]];
+        int host = -1;
+        for (int f = 0; f < n_frames; f++) if (frame_ids[f] == q.frame_id) { host = f; break; }
+        if (host < 0) return -1;
+        float w[8];
+        for (int j = 0; j < 8; j++) {
+            const double gx = (double)q.d.dpatch[3 * j + 1], gy = (double)q.d.dpatch[3 * j + 2];
+            w[j] = (float)std::sqrt(2500.0 / (2500.0 + (gx * gx + gy * gy)));
+        }
+        b->addPoint(q.d.x, q.d.y, (double)q.idepth, host, q.d.gray, w, false);
+        if (xy_out) { xy_out[2 * k] = (int)q.d.x; xy_out[2 * k + 1] = (int)q.d.y; }
+    }
+    return first;
+}
 // immature points still alive per frame id (what flagFramesForMarginalization weighs, BA.cpp:428-462 via DSOContext's per-frame groups)
 void cmlhost_tracer_immature_counts(void* h, int n_frames, const int* frame_ids, int* counts) {
     auto& P = static_cast<cml_amd::DSOTracer*>(h)->points();

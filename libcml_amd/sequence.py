@@ -361,14 +361,14 @@ class DirectPipeline:
         fids = [k_["fid"] for k_ in self.kfs]; iids = [k_["image_id"] for k_ in self.kfs]
         before = self.trc.points() if self.obs is not None else None
         activated = self._c("activatePoints+addPoints", self.trc.activate_points, fids, iids, self.K, self.w, self.h, apairs)
-        pts, alive, act, idp = self.trc.points()
-        tfids = self.trc.frame_ids()
-        if len(activated):
-            ia = np.asarray(activated, np.int64)
-            hh = np.array([fids.index(int(f)) for f in tfids[ia]], np.int32)
-            for i, h_ in zip(ia, hh):
-                self.kfs[h_]["taken"].add((int(pts["x"][i]), int(pts["y"][i])))
-            self._c("activatePoints+addPoints", ba.add_points, np.stack([pts["x"][ia], pts["y"][ia]], 1), idp[ia].astype(np.float64), hh, pts["gray"][ia], _weights(pts["dpatch"][ia]), prior=False)
+        if len(activated):                                            # DSOTracer::activatePoints -> BA::addPoints, in the host mirror (capi.cpp)
+            _first, xy = self._c("activatePoints+addPoints", self.trc.add_activated_to_ba, ba, activated, fids)
+            tf = self.trc.frame_ids()[np.asarray(activated, np.int64)]
+            for (x_, y_), f_ in zip(xy.tolist(), tf.tolist()):
+                self.kfs[fids.index(int(f_))]["taken"].add((x_, y_))
+        if self.obs is not None:
+            pts, alive, act, idp = self.trc.points()
+            tfids = self.trc.frame_ids()
         self._t("activatePoints+addPoints", t0)
         if self.obs is not None:
             self._emit("activate", frame_ids=fids, image_ids=iids, pairs=apairs, before=before, after=(pts, alive, act, idp), activated=activated,
