@@ -192,24 +192,30 @@ class DirectPipeline:
         return out
 
     def _trace_pairs(self, poses, Rn, tn, an, bn):
+        """host h -> traced frame, every keyframe at once: K R K^-1, K t, affine (Exposure::to with exposure times 1, Exposure.h:119-123)"""
         fx, fy, cx, cy = self.K
         Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]]); Ki = np.linalg.inv(Km)
+        Rh = np.stack([p[0] for p in poses]); th = np.stack([p[1] for p in poses])
+        ah = np.array([p[2] for p in poses]); bh = np.array([p[3] for p in poses])
+        R = np.einsum("ij,hkj->hik", Rn, Rh)                          # Rn Rh^T (Camera::to)
+        t = tn[None, :] - np.einsum("hij,hj->hi", R, th)
         pr = np.zeros(len(poses), abi.TRACE_PAIR_DTYPE)
-        for hh, (Rh, th, ah, bh) in enumerate(poses):
-            R, t = _rel(Rh, th, Rn, tn)
-            pr["KRKi"][hh] = ((Km @ R) @ Ki).ravel(); pr["Kt"][hh] = Km @ t
-            a = np.exp(an - ah)                                       # Exposure::to with exposure times 1 (Exposure.h:119-123)
-            pr["aff_a"][hh] = a; pr["aff_b"][hh] = bn - a * bh
+        pr["KRKi"] = np.einsum("ij,hjk,kl->hil", Km, R, Ki).reshape(len(poses), 9)
+        pr["Kt"] = np.einsum("ij,hj->hi", Km, t)
+        a = np.exp(an - ah)
+        pr["aff_a"] = a; pr["aff_b"] = bn - a * bh
         return pr
 
     def _activation_pairs(self, poses):
+        """host h -> target t for every ordered pair of the window (row h * N + t)"""
         N = len(poses)
+        Rw = np.stack([p[0] for p in poses]); tw = np.stack([p[1] for p in poses])
+        aw = np.array([p[2] for p in poses]); bw = np.array([p[3] for p in poses])
+        R = np.einsum("tij,hkj->htik", Rw, Rw)                        # Rt Rh^T
+        t = tw[None, :, :] - np.einsum("htij,hj->hti", R, tw)
+        a = np.exp(aw[None, :] - aw[:, None])
         pr = np.zeros(N * N, abi.ACTIVATION_PAIR_DTYPE)
-        for hh, (Rh, th, ah, bh) in enumerate(poses):
-            for tt_, (Rt, tt, at, bt) in enumerate(poses):
-                R, t = _rel(Rh, th, Rt, tt)
-                a = np.exp(at - ah)
-                pr["R"][hh * N + tt_] = R.ravel(); pr["t"][hh * N + tt_] = t; pr["aff_a"][hh * N + tt_] = a; pr["aff_b"][hh * N + tt_] = bt - a * bh
+        pr["R"] = R.reshape(N * N, 9); pr["t"] = t.reshape(N * N, 3); pr["aff_a"] = a.reshape(-1); pr["aff_b"] = (bw[None, :] - a * bw[:, None]).reshape(-1)
         return pr
 
     def _immature_counts(self):
