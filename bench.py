@@ -733,7 +733,7 @@ def workload_text(S):
             "pair precompute, linearize + applyRes)" % (S["wcfg"], W.N, W.P, S["R"], W.w, W.h, "fp16" if S["half"] else "fp32"))
 
 
-def secondary_config(config, seed, local_rank, steps, warmup):
+def secondary_config(config, seed, local_rank, steps, warmup, relaxed=False):
     """BASELINE.json configs[2] (C) / configs[4] (E) beside the headline, on rank 0 of an N = 1 run: same protocol, own parity gate."""
     S = setup_window(config, seed, 0, local_rank)
     try:
@@ -747,7 +747,7 @@ def secondary_config(config, seed, local_rank, steps, warmup):
         out.update(par)
         if par.get("parity_checked") and not par.get("parity_ok"):
             out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
-        if not S["hybrid"]:
+        if relaxed and not S["hybrid"]:
             out["relaxed_arithmetic"] = relaxed_arithmetic_leg(S, steps, warmup, out)
         return out
     finally:
@@ -787,6 +787,87 @@ def relaxed_arithmetic_leg(S, steps, warmup, exact):
     finally:
         ctx.ba_set_arithmetic(False)
 
+LINE_LIMIT = 3072                         # the driver keeps ~8 KB of stdout: the last line stays far below that (tests/test_bench_contract_gpu.py)
+
+
+def _r(v, sig=5):
+    """numbers of the compact line at `sig` significant digits"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    try:
+        return float("%.*g" % (sig, float(v)))
+    except Exception:
+        return None
+
+
+def compact_line(out, detail_path, contract_only=False):
+    """The ONE stdout line: the bench contract + roofline + cpu_baseline + one-number summaries.  Everything else (notes, per-stage tables,
+    min/max lists, sweeps) is in `detail_path` (the full object `out`)."""
+    roof = out.get("roofline") or {}
+    also = [{"bound": a.get("bound"), "frac": _r(a.get("frac"))} for a in roof.get("also_bound_by", []) if isinstance(a, dict)]
+    cb = out.get("cpu_baseline") or {}
+    line = {
+        "metric": out["metric"], "value": out["value"], "unit": out["unit"], "n_gpus": out["n_gpus"], "steps": out["steps"], "warmup": out["warmup"],
+        "ms_per_step": out["ms_per_step"], "higher_is_better": True, "scaling": out["scaling"], "vs_baseline": None, "dtype": out["dtype"], "data": out["data"],
+        "config": {"workload": out["config"]["workload"].split("; 1 step")[0], "shards": out["config"]["shards"], "parallelism": out["config"]["parallelism"]},
+        "schur_solve_ms": _r(out.get("schur_solve_ms")),
+        "roofline": {"bound": roof.get("bound"), "kernel": str(roof.get("kernel", "")).split(" ")[0], "achieved": roof.get("achieved"), "peak": roof.get("peak"),
+                     "unit": roof.get("unit"), "frac": roof.get("frac"), "traffic": _r(roof.get("traffic"), 6),
+                     "traffic_over_algorithmic": _r(roof.get("traffic_over_algorithmic")), "launch_us": roof.get("launch_us"),
+                     "launch_samples": roof.get("launch_samples"), "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"),
+                     "rocprof_avg_us": _r(roof.get("rocprof_avg_us")), "also_bound_by": also},
+        "parity_checked": bool(out.get("parity_checked")), "parity_ok": bool(out.get("parity_ok")),
+    }
+    if out.get("invalid"):
+        line["invalid"] = True
+    if cb:
+        st = cb.get("single_thread") or {}
+        line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "single_thread_value": _r(st.get("value")), "sample": "median of 20 runs x 5 GN iterations of the same window, oracle C port (-O3 -march=native, OpenMP on one socket)"}
+        if cb.get("value") is None:
+            line["cpu_baseline"]["sample"] = str(cb.get("sample"))[:120]
+        if out.get("gpu_over_cpu_single_socket") is not None:
+            line["gpu_over_cpu"] = _r(out["gpu_over_cpu_single_socket"], 4)
+    if contract_only:
+        line["detail"] = detail_path
+        return line
+    if isinstance(out.get("configs"), dict):
+        line["configs"] = {}
+        for k, c in out["configs"].items():
+            if "error" in c:
+                line["configs"][k] = {"error": str(c["error"])[:80]}
+            else:
+                line["configs"][k] = {"value": _r(c.get("value")), "ms_per_step": _r(c.get("ms_per_step")), "frac": _r((c.get("roofline") or {}).get("frac")),
+                                      "parity_ok": bool(c.get("parity_ok"))}
+    sq = out.get("sequence")
+    if isinstance(sq, dict):
+        if "error" in sq:
+            line["sequence"] = {"error": str(sq["error"])[:80]}
+        else:
+            par = sq.get("parity") or {}
+            line["sequence"] = {"frames_per_s": _r(sq.get("frames_per_s")), "library_frames_per_s": _r(sq.get("library_frames_per_s")),
+                                "run_ms": _r(sum((sq.get("run_us_split_median") or {}).values()) * 1e-3 or None),
+                                "parity_ok": sq.get("parity_ok"), "yardstick_used": len(par.get("run_yardstick", []) or []) + int(par.get("track_yardstick_used", 0) or 0)}
+            for k in ("library_frames_per_s_two_threads", "frames_per_s_two_threads"):
+                if sq.get(k) is not None:
+                    line["sequence"][k] = _r(sq[k])
+    tr = out.get("tracker")
+    if isinstance(tr, dict):
+        if "error" in tr:
+            line["tracker"] = {"error": str(tr["error"])[:80]}
+        else:
+            line["tracker"] = {"optimize_ms_1": _r((tr.get("optimize_device_resident_1_hyp") or {}).get("kernel_ms")),
+                               "optimize_ms_50": _r((tr.get("optimize_device_resident_50_hyp") or {}).get("kernel_ms"))}
+    sv = out.get("solve")
+    if isinstance(sv, dict) and "error" not in sv:
+        line["solve"] = {"us": _r((sv.get("us") or {}).get("total")), "mfma_f64_util": _r(sv.get("mfma_f64_util"))}
+    ss = out.get("sequence_shards")
+    if isinstance(ss, dict):
+        line["sequence_shards"] = {k: _r(v) for k, v in ss.items() if k in ("shards", "frames_per_s_total", "tracking_lost_total")} if "error" not in ss else {"error": str(ss["error"])[:80]}
+    line["commit"] = out.get("commit")
+    line["detail"] = detail_path
+    return line
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -796,6 +877,8 @@ def main():
     ap.add_argument("--config", default="B", help="synthetic window (libcml_amd.synth.CONFIGS); B is the benchmark workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs C / E, tracker, sequence and multi-window objects (headline + roofline + parity only)")
+    ap.add_argument("--extras", action="store_true", help="also run the sweeps (multi-window S = 2..32, stream groups, relaxed-arithmetic legs); they go to bench_detail.json only")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full (uncompacted) result object is written")
     ap.add_argument("--launch-only", action="store_true", help="exercise the rank launch + process group only (no device work; CPU test)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("CONFIG", "SEED", "MODE"), help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -900,19 +983,21 @@ def main():
                 out["solve"] = solve_phases(ctx, N)
             except Exception as e:
                 out["solve"] = {"error": repr(e)}
-            out["relaxed_arithmetic"] = relaxed_arithmetic_leg(S, args.steps, args.warmup, out)      # opt-in mode, after the exact headline and its gate
+            if args.extras:
+                out["relaxed_arithmetic"] = relaxed_arithmetic_leg(S, args.steps, args.warmup, out)      # opt-in mode, after the exact headline and its gate
         ba.close(); ctx.close()                                   # (the objects below build their own contexts)
         if extras:
             out["configs"] = {}
             for cfg in ("C", "E"):                                # BASELINE.json configs[2] and configs[4]: driver-visible, each with its own oracle gate
                 try:
-                    out["configs"][cfg] = secondary_config(cfg, seed, local_rank, args.steps, args.warmup)
+                    out["configs"][cfg] = secondary_config(cfg, seed, local_rank, args.steps, args.warmup, relaxed=args.extras)
                 except Exception as e:
                     out["configs"][cfg] = {"error": repr(e)}
-            try:
-                out["multi_window"] = multi_window_bench(local_rank, seed, wcfg, max(args.steps, 50), half)
-            except Exception as e:
-                out["multi_window"] = {"error": repr(e)}
+            if args.extras:
+                try:
+                    out["multi_window"] = multi_window_bench(local_rank, seed, wcfg, max(args.steps, 50), half)
+                except Exception as e:
+                    out["multi_window"] = {"error": repr(e)}
             try:
                 out["tracker"] = tracker_bench(local_rank, seed, not args.no_cpu_baseline)
             except Exception as e:
@@ -934,7 +1019,19 @@ def main():
                     out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", "")) + " — the config-B window WITHOUT the 1000 ORB residuals of config C"
             except Exception as e:      # the checker must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "point-residuals/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
-        line = json.dumps(out)
+        try:
+            out["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None
+        except Exception:
+            out["commit"] = None
+        try:
+            with open(args.detail, "w") as f:
+                json.dump(out, f, indent=1)
+        except Exception as e:
+            print("[bench] could not write %s: %r" % (args.detail, e), file=sys.stderr)
+        line = json.dumps(compact_line(out, os.path.relpath(args.detail, ROOT)), separators=(",", ":"))
+        if len(line) > LINE_LIMIT:                                # never again a line the driver cannot read: drop the summaries, keep the contract
+            small = compact_line(out, os.path.relpath(args.detail, ROOT), contract_only=True)
+            line = json.dumps(small, separators=(",", ":"))
     else:
         line = None
         ba.close(); ctx.close()

@@ -457,7 +457,10 @@ int cmlhip_ba_linearize_apply(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DE
     cml_make_ba_args(c, A);
     A.fuse_apply = 1;
     if (c->rs_ok && c->n_tiles > 0 && c->n_lin == 0) {      // the resident loop's own residual kernel: the pass leaves the pair tiles its first accumulation reads
+        const bool relaxed = c->arith_relaxed;              // include/cmlhip.h: only cmlhip_ba_iteration_async / _batch honour CMLHIP_ARITH_RELAXED; this pass
+        c->arith_relaxed = false;                           // commits states and frameEnergyTH through applyRes(true), so it is always the exact kernel
         cml_launch_linearize_rs(c, A);                      // (28 us of record-path accumulation become 10 at the sequence's window; records re-materialise on demand)
+        c->arith_relaxed = relaxed;
         c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
     } else cml_launch_linearize(c, A);
     cml_launch_lin_finish(c, A);

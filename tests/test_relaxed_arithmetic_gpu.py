@@ -174,3 +174,25 @@ def test_relaxed_mode_contains_a_non_finite_point_like_the_exact_mode():
     ok = g0 == 1
     # (this 628-residual window amplifies a 1e-6 difference of the first step to 2e-4 in pose after two: the energies are compared loosely, the statement is containment)
     assert np.all(np.isfinite(e1[ok])) and np.abs(e0[ok] - e1[ok]).max() <= 1e-2 * max(np.abs(e0[ok]).max(), 1.0)
+
+
+def test_run_preamble_stays_exact_under_the_relaxed_flag():
+    """include/cmlhip.h: only cmlhip_ba_iteration_async / _batch honour CMLHIP_ARITH_RELAXED.  cmlhip_ba_linearize_apply — run()'s preamble, which commits states
+    and frameEnergyTH through applyRes(true) — goes through the resident residual kernel when the window is armed; with the sticky flag set it must still be the
+    exact kernel: same energy bits, same states, same thresholds as on a context that never saw the flag (round-4 advisor finding)."""
+    import ctypes as C
+    outs = []
+    for relaxed in (False, True):
+        W, ctx, ba = _window("medium", relaxed)
+        try:
+            lr = abi.BALinResult()
+            ctx.ck(ctx.L.cmlhip_ba_linearize_apply(ctx.h, C.byref(lr)))
+            st = ctx.ba_states()
+            outs.append((np.float64(lr.energy).view(np.uint64), lr.n_in, lr.n_oob, lr.n_outlier, np.float32(lr.new_frame_energy_th).view(np.uint32),
+                         st["state"].copy(), st["energy"].view(np.uint32).copy(), st["good"].copy()))
+        finally:
+            ba.close(); ctx.close()
+    a, b = outs
+    assert a[:4] == b[:4], (a[:4], b[:4])
+    for x, y in zip(a[5:], b[5:]):
+        assert np.array_equal(x, y)

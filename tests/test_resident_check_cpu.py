@@ -41,3 +41,25 @@ def test_replay_reproduces_an_oracle_pass():
     o2 = rp.replay(pre, pairs, th * 0.01, idepth)
     assert (o2["new_state"] != new_state).sum() > 0
     rp.close()
+
+
+def test_bench_compact_line_stays_under_the_driver_limit():
+    """round 4's full result object (27.5 KB as one line: the driver could not parse it) through bench.compact_line: < 3 KB, contract keys kept"""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    out = json.load(open(os.path.join(root, "profiles", "round4_bench_driver_cmd.json")))
+    assert len(json.dumps(out)) > 20000
+    line = json.dumps(bench.compact_line(out, "bench_detail.json"), separators=(",", ":"))
+    assert len(line) < bench.LINE_LIMIT
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity_checked", "parity_ok", "configs", "sequence", "tracker", "solve"):
+        assert k in d, k
+    assert d["value"] == out["value"] and d["roofline"]["frac"] == out["roofline"]["frac"]
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    small = json.dumps(bench.compact_line(out, "bench_detail.json", contract_only=True), separators=(",", ":"))
+    assert len(small) < len(line) and "roofline" in json.loads(small)
