@@ -787,6 +787,16 @@ def relaxed_arithmetic_leg(S, steps, warmup, exact):
     finally:
         ctx.ba_set_arithmetic(False)
 
+def _commit():
+    """HEAD where there is a .git; on the GPU box (snapshot without .git) what libcml_amd/build.py left beside the libraries"""
+    try:
+        if os.path.isdir(os.path.join(ROOT, ".git")):
+            return subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None
+        return open(os.path.join(ROOT, "libcml_amd", "BUILD_COMMIT")).read().strip() or None
+    except Exception:
+        return None
+
+
 LINE_LIMIT = 3072                         # the driver keeps ~8 KB of stdout: the last line stays far below that (tests/test_bench_contract_gpu.py)
 
 
@@ -1019,10 +1029,7 @@ def main():
                     out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", "")) + " — the config-B window WITHOUT the 1000 ORB residuals of config C"
             except Exception as e:      # the checker must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "point-residuals/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
-        try:
-            out["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None
-        except Exception:
-            out["commit"] = None
+        out["commit"] = _commit()
         try:
             with open(args.detail, "w") as f:
                 json.dump(out, f, indent=1)

@@ -60,9 +60,25 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     build_host(force)
+    _write_commit()
     if verbose:
         print("built", OUT)
     return OUT
+
+
+def _write_commit():
+    """the snapshot that travels to the GPU box has no .git: leave the commit the build was made from beside the libraries (bench.py / the profile
+    tools stamp their records with it; `+dirty` when the tree had uncommitted changes)"""
+    root = os.path.dirname(HERE)
+    if not os.path.isdir(os.path.join(root, ".git")):
+        return
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=root).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, cwd=root).stdout.strip()
+        with open(os.path.join(HERE, "BUILD_COMMIT"), "w") as f:
+            f.write(head + ("+dirty" if dirty else ""))
+    except Exception:
+        pass
 
 
 def build_host(force=False):

@@ -390,7 +390,9 @@ class SequenceChecker:
             sp["rmse"] = max(sp["rmse"], abs(o2["achieved"] / o["achieved"] - 1))
         # (b) as for run(): no further from the oracle than four times the spread of the oracle's own answers under noise of 1e-7 / 1e-6 (the
         #     size of the rounding of the fp32 sums a trial's accept / reject test sits on)
-        ok_scale = dR <= max(1e-3, 4 * sp["R"]) and dt <= max(1e-3, 4 * sp["t"]) and abs(r["lastCoarseRMSE"] / o["achieved"] - 1) <= max(1e-2, 4 * sp["rmse"])
+        #     — REMOVED in round 5 for tracked frames: the 60-sequence soak (profiles/round5_parity_soak_sequence.txt) accepted every use through a
+        #     member (3) or a margin (1, 3.7e-6), never through the spread; the spread is still measured and reported
+        ok_scale = False
         # (c) the decision that separates the two runs: the winning hypothesis optimised again by the oracle (with its trial log) and by the device
         #     (with its accept sequence) — at the first trial where they part, the oracle's own accept test E_new / n_new < E / n must have been
         #     taken on a margin below what the ORDER of an fp32 sum over the level's terms is worth (1e-4 relative: n eps / 2 at 3 000 terms; the
@@ -411,6 +413,9 @@ class SequenceChecker:
                     ok_margin = log_[i].level == dres.step_level[i] and margin is not None and margin < 1e-4
                     break
             self.report.setdefault("track_decisions_on_rounding", []).append({"winner": w_, "margin": margin, "dR": dR, "dt": dt})
+        # every use of the hatch says which path accepted it (tests/test_sequence_gpu.py asserts the reason, tests/soak_parity.py tallies them)
+        self.report.setdefault("track_yardstick", []).append({"accepted_by": "member" if ok_any else ("spread" if ok_scale else ("margin" if ok_margin else None)),
+                                                              "margin": margin, "dR": dR, "dt": dt, "rmse_rel": abs(r["lastCoarseRMSE"] / o["achieved"] - 1), "spread": sp})
         self._require(ok_any or ok_scale or ok_margin, "track: pose / exposure / rmse outside the bars of the oracle, of its noise ensemble and of four times its spread (|dR| %.2e, |dt| %.2e, rmse %.2e; spread %s), and no accept decision on a rounding-sized margin separates the runs (margin %s)" % (
             dR, dt, abs(r["lastCoarseRMSE"] / o["achieved"] - 1), sp, margin))
 
@@ -529,7 +534,7 @@ class SequenceChecker:
             import os
             import subprocess
             members = []
-            for trial, sigma in enumerate((1e-7, 1e-7, 1e-6, 1e-6, 1e-6, 1e-6)):
+            for trial, sigma in enumerate((1e-7, 1e-7, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6)):
                 I2 = inputs_from_export(fr, pt, rs, info["grads0"], self.K, self.w, self.h)
                 I2.points["idepth"] *= (1 + sigma * np.random.default_rng(1000 + trial).standard_normal(I2.P))
                 members.append(("idepth x (1 + %.0e N(0,1)) #%d" % (sigma, trial), oracle_run(I2, HM, bM)))
@@ -550,7 +555,9 @@ class SequenceChecker:
             ok_member = bool(near) and within_fixed_bars(best[2], best[1])
             sp = {k_: max([dd[k_] for _n, _i, dd in spread] + [0.0]) for k_ in ("energy", "R", "t", "idepth_p99")}
             sp_flips = max([dd["flips"] for _n, _i, dd in spread] + [0])
-            ok_scale = iter_ok and all(d[k_] <= max(BARS[k_], 4.0 * sp[k_]) for k_ in sp) and d["flips"] <= max(2, I.R // 200) + sp_flips
+            # (b) is kept for the two-keyframe bootstrap window ONLY (round 5: the 60-sequence soak needed it once in 380 runs — sequence 36, N = 2, pose
+            #     inside the fixed bars, energy 1.7e-2 against 5e-3 — and never at N > 2)
+            ok_scale = N == 2 and iter_ok and all(d[k_] <= max(BARS[k_], 4.0 * sp[k_]) for k_ in sp) and d["flips"] <= max(2, I.R // 200) + sp_flips
             self.report["run_yardstick_used"] = self.report.get("run_yardstick_used", 0) + 1
             self.report.setdefault("run_yardstick", []).append({"N": N, "R": I.R, "iterations": (o["iterations"], info["iterations"]), "device_vs_oracle": d,
                                                                 "energies_device": [float(x) for x in all_e[-info["iterations"]:]] if info["iterations"] else [], "energies_oracle": [float(x) for x in o["log"]["energy"]],

@@ -361,6 +361,7 @@ def sequence_family(n):
     from libcml_amd import sequence
     from tests import sequence_check as SC
     worst, fails, yard, runs, flips, resid, tyard, tflips, margins = {}, [], 0, 0, 0, 0, 0, 0, []
+    by = {}
     for s_ in range(n):
         seq = sequence.make_sequence(n_frames=28, seed=0x5EED + 101 * s_, shard=s_)
         ctx = device.Ctx(max_frames=8, max_points=8192, max_residuals=8192 * 8)
@@ -378,11 +379,19 @@ def sequence_family(n):
         flips += rep["flips"]["run_residual_sets"]; resid += rep["flips"]["run_residuals"]
         tyard += rep.get("track_yardstick_used", 0); tflips += rep["flips"]["tracker_winner"]
         margins += [t_["margin"] for t_ in rep.get("track_decisions_on_rounding", []) if t_["margin"] is not None]
+        for u in rep.get("run_yardstick", []):
+            by["run:%s" % u.get("accepted_by")] = by.get("run:%s" % u.get("accepted_by"), 0) + 1
+            print("   yardstick run  (sequence %d): N=%d R=%d iterations %s accepted_by=%s nearest member %s; device vs oracle energy %.2e R %.2e t %.2e" % (
+                s_, u["N"], u["R"], u["iterations"], u.get("accepted_by"), u["device_vs_nearest_member"]["member"], u["device_vs_oracle"]["energy"], u["device_vs_oracle"]["R"], u["device_vs_oracle"]["t"]))
+        for u in rep.get("track_yardstick", []):
+            by["track:%s" % u.get("accepted_by")] = by.get("track:%s" % u.get("accepted_by"), 0) + 1
+            print("   yardstick track (sequence %d): accepted_by=%s margin %s dR %.2e dt %.2e rmse %.2e" % (s_, u.get("accepted_by"), u["margin"], u["dR"], u["dt"], u["rmse_rel"]))
         print("sequence %d: %d frames, %d keyframes, max window %d, %d frames marginalised, tracking lost %d, failures %d, yardstick runs %d" % (
             s_, st["frames"], st["keyframes"], st["max_window"], st["marginalized_frames"], st["tracking_lost"], len(rep["failures"]), rep.get("run_yardstick_used", 0)))
     print("sequence family: %d sequences, %d runs (%d held against the noise ensemble), residual decisions differing %d of %d" % (n, runs, yard, flips, resid))
     print("   tracked frames whose winner / number of tries differ from the oracle's: %d; held against the oracle's noise ensemble: %d; separated from the oracle by an accept decision on a rounding-sized margin: %s" % (
         tflips, tyard, ["%.1e" % m for m in margins]))
+    print("   hatch uses by accepting path: %s" % (", ".join("%s=%d" % kv for kv in sorted(by.items())) or "none"))
     for k in sorted(worst):
         print("   worst %-24s %.2e" % (k, worst[k]))
     for f in fails:
