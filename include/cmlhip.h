@@ -260,6 +260,27 @@ int cmlhip_ba_set_params(cmlhip_ctx* ctx, const cmlhip_ba_params* prm);
 int cmlhip_ba_upload_window(cmlhip_ctx* ctx, int N, const cmlhip_ba_frame* frames,
                             int P, const cmlhip_ba_point* points,
                             int R, const cmlhip_ba_residual* residuals);
+/* ---- The window kept across keyframes.  The reference edits its window in place: BA::addPoints appends points and their residuals
+ * (BA.cpp:382-415), BA::addNewFrame appends one residual per active point (:417-462), removePoint / removeFrame drop entries and renumber the
+ * frames (DSOContext.h:94-111,154-174), and BA::run (:744-910) works on what is there.  These calls give a caller the same hand-over: the
+ * library keeps the window (points, residuals {point, target, state, linearized}) between keyframes, the caller sends the EDITS, and
+ * cmlhip_ba_window_commit makes the edited window the device window of the next run — index maps, device order and every derived table
+ * exactly as cmlhip_ba_upload_window builds them from the same lists (that call IS reset + append + commit).
+ *   numbering: points and residuals are numbered in append order; cmlhip_ba_window_compact drops the entries whose flag is 0 and renumbers
+ *   the survivors by rank (a surviving residual must name a surviving point) — the caller renumbers its own lists the same way;
+ *   cmlhip_ba_window_retire_frame is removeFrame's renumbering: frame ids above `frame` move down by one, entries that still name the frame
+ *   get -1 and must be dropped by the next compact.
+ *   commit: `frames` as for cmlhip_ba_upload_window (image ids, thresholds, b0 of the N frames as they are NOW); idepth / idepth_zero / prior
+ *   (P each, or NULL = keep the values appended) refresh the per-point values a run changes; reset_states != 0 applies BA::run's resetOOB
+ *   (:766-779): every residual gets state IN / not linearized except the n_lin listed ones, which keep the given state and stay LINEARIZED. */
+int cmlhip_ba_window_reset(cmlhip_ctx* ctx);
+int cmlhip_ba_window_append_points(cmlhip_ctx* ctx, int n, const cmlhip_ba_point* points);
+int cmlhip_ba_window_append_residuals(cmlhip_ctx* ctx, int n, const cmlhip_ba_residual* residuals);
+int cmlhip_ba_window_retire_frame(cmlhip_ctx* ctx, int frame);
+int cmlhip_ba_window_compact(cmlhip_ctx* ctx, int n_points, const unsigned char* point_alive, int n_residuals, const unsigned char* residual_alive);
+int cmlhip_ba_window_counts(cmlhip_ctx* ctx, int* P, int* R);      /* entries the library holds (committed or not) */
+int cmlhip_ba_window_commit(cmlhip_ctx* ctx, int N, const cmlhip_ba_frame* frames, const double* idepth, const float* idepth_zero,
+                            const float* prior, int reset_states, int n_lin, const int* lin_residuals, const int* lin_states);
 /* sizes of the uploaded window (N frames, P points, R residuals) */
 int cmlhip_ba_window_size(cmlhip_ctx* ctx, int* N, int* P, int* R);
 /* per-iteration state: N*N pair transforms + frame thresholds (ba_update_state) */
@@ -290,7 +311,7 @@ int cmlhip_ba_linearize(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);
 int cmlhip_ba_apply(cmlhip_ctx* ctx, int copy_jacobians);
 /* cmlhip_ba_linearize followed by cmlhip_ba_apply(ctx, 1) as ONE pass over the residuals (the preamble of BA::run, BA.cpp:785-790: linearizeAll(false),
  * then applyRes(r, true) of every residual with nothing in between).  Same results as the two calls. */
-int cmlhip_ba_linearize_apply(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);
+int cmlhip_ba_linearize_apply(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);   /* out == NULL: enqueue only (no host wait); the summary is kept for cmlhip_ba_finish_run */
 /* The tail of DSOBundleAdjustment::run in one call and ONE readback: linearizeAll(true) (BA.cpp:896 = linearize + applyRes(true),
  * :1551-1569) followed by everything the host writes back afterwards — residual states / energies (:1571-1640), the points'
  * inverse depths and the per-point accumulators (HdiF -> setInverseDepthHessian, :1889-1901).  pairs must be current.
@@ -578,6 +599,25 @@ int cmlhip_ba_get_resident_log(cmlhip_ctx* ctx, int* iterations, double* energie
 /* frame states after the iterations enqueued so far (synchronises); pre_w2c: N x 7 (q, t) of PRE_worldToCam, may be NULL;
  * last_pass: energy / census / setNewFrameEnergyTH of the last residual pass (what cmlhip_ba_linearize returns), may be NULL */
 int cmlhip_ba_get_resident_state(cmlhip_ctx* ctx, cmlhip_ba_frame_state* frames, double* pre_w2c, cmlhip_ba_lin_result* last_pass);
+
+/* The tail of DSOBundleAdjustment::run (BA.cpp:882-910) when the loop ran resident, with ONE host wait: everything the three getters above return
+ * (after the iterations enqueued so far), then — reanchor_newest != 0 — the re-anchoring of the newest frame's evaluation point ON THE DEVICE
+ * (setEvalPT(PRE_worldToCam, (0,..,0,a,b)), :885-894: evaluation point = current pose, PRE_RTll_0 / PRE_tTll_0 of the pairs that name the frame,
+ * b0) and the closing linearizeAll(true) with cmlhip_ba_finish_keyframe's outputs.  `first` = the summary of the preamble pass enqueued by
+ * cmlhip_ba_linearize_apply(ctx, NULL); `last` = the last iteration's pass; frames / pre_w2c are the states BEFORE the re-anchoring (the host mirror
+ * re-anchors its own copy from pre_w2c[N-1], the pose the device used).  Any pointer may be NULL.  Replaces: the host round trip between
+ * BA::run's loop and its closing pass (frame states up, DSOFramePrecomputed + b0 down). */
+typedef struct {
+    cmlhip_ba_frame_state* frames;      /* N */
+    double* pre_w2c;                    /* N x 7 (q, t) of PRE_worldToCam */
+    cmlhip_ba_lin_result* first;        /* preamble pass (cmlhip_ba_linearize_apply with out == NULL) */
+    cmlhip_ba_lin_result* last;         /* last pass of the loop */
+    int* iterations; double* energies; int capacity;      /* as cmlhip_ba_get_resident_log */
+    double* x;                          /* 8N+4: x of the last solve */
+} cmlhip_ba_resident_out;
+int cmlhip_ba_finish_run(cmlhip_ctx* ctx, int reanchor_newest, const cmlhip_ba_resident_out* resident, cmlhip_ba_lin_result* lin, int* state,
+                         int* new_state, float* energy, float* new_energy, float* new_energy_without_outlier, unsigned char* is_good,
+                         double* idepth, float* point_acc);
 
 /* ---------------------------------------------------------------- timing helpers (bench.py)
  * HIP events on the context stream; ms between the two most recent marks. */

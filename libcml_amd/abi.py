@@ -137,6 +137,12 @@ class BAFrameState(C.Structure):
                 ("prior_zero", C.c_double * 8), ("ab_exposure", C.c_double), ("fix_pose", C.c_int), ("pad", C.c_int)]
 
 
+class BAResidentOut(C.Structure):
+    """cmlhip_ba_resident_out (cmlhip_ba_finish_run: the resident loop's results, read back with the closing pass in one copy)."""
+    _fields_ = [("frames", C.POINTER(BAFrameState)), ("pre_w2c", c_double_p), ("first", C.POINTER(BALinResult)), ("last", C.POINTER(BALinResult)),
+                ("iterations", C.POINTER(C.c_int)), ("energies", c_double_p), ("capacity", C.c_int), ("x", c_double_p)]
+
+
 # ---- immature points (DSOTracer, SURVEY §8 f1)
 IPS_GOOD, IPS_OOB, IPS_OUTLIER, IPS_SKIPPED, IPS_BADCONDITION, IPS_UNINITIALIZED = range(6)
 IMMATURE_POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("host", "<i4"), ("last_status", "<i4"), ("idepth_min", "<f8"), ("idepth_max", "<f8"),

@@ -135,15 +135,141 @@ int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) { CML_DEV(c
     return CMLHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The window kept by the library across keyframes (cmlhip_ba_window_*): SoA shadows in the layout the device arrays have, edited in place by
+// what BA::addPoints (BA.cpp:382-415), BA::addNewFrame (:417-462), removePoint / removeFrame (DSOContext.h:94-111,154-174) do to the
+// reference's sets — append, retire, renumber — so that a keyframe's run() hands over a DELTA instead of rebuilding and re-copying the whole
+// window.  cmlhip_ba_window_commit turns the shadows into the device window: index bookkeeping (exact: htIDX = host + target*N, BA.cpp:1677,
+// CSR by point and by pair, pair-sorted device order) in two passes over the int shadows, the arrays memcpy'd into the packed copy.
+// cmlhip_ba_upload_window is reset + append + commit: one code path, a window built by edits is the window a fresh upload builds.
+static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames);
+
+int cmlhip_ba_window_reset(cmlhip_ctx* c) { CML_DEV(c);
+    if (!c) return CMLHIP_ERR_INVALID;
+    WindowShadow& W = c->win;
+    W.x.clear(); W.y.clear(); W.idz.clear(); W.prior.clear(); W.colors.clear(); W.weights.clear(); W.idepth.clear(); W.host.clear();
+    W.rpoint.clear(); W.rtarget.clear(); W.rstate.clear(); W.rlin.clear();
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_window_append_points(cmlhip_ctx* c, int n, const cmlhip_ba_point* pts) { CML_DEV(c);
+    if (!c || n < 0 || (n > 0 && !pts)) return CMLHIP_ERR_INVALID;
+    WindowShadow& W = c->win;
+    const size_t P0 = W.host.size();
+    CML_REQUIRE(c, P0 + (size_t)n <= (size_t)c->lim.max_points, CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
+    W.x.resize(P0 + n); W.y.resize(P0 + n); W.idz.resize(P0 + n); W.prior.resize(P0 + n); W.idepth.resize(P0 + n); W.host.resize(P0 + n);
+    W.colors.resize(8 * (P0 + n)); W.weights.resize(8 * (P0 + n));
+    for (int i = 0; i < n; i++) {
+        const cmlhip_ba_point& q = pts[i];
+        const size_t p = P0 + i;
+        W.x[p] = q.x; W.y[p] = q.y; W.idepth[p] = q.idepth; W.idz[p] = q.idepth_zero; W.prior[p] = q.prior; W.host[p] = q.host;
+        memcpy(&W.colors[8 * p], q.colors, 32); memcpy(&W.weights[8 * p], q.weights, 32);
+    }
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_window_append_residuals(cmlhip_ctx* c, int n, const cmlhip_ba_residual* res) { CML_DEV(c);
+    if (!c || n < 0 || (n > 0 && !res)) return CMLHIP_ERR_INVALID;
+    WindowShadow& W = c->win;
+    const size_t R0 = W.rpoint.size(), P = W.host.size();
+    CML_REQUIRE(c, R0 + (size_t)n <= (size_t)c->lim.max_residuals, CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
+    for (int i = 0; i < n; i++) CML_REQUIRE(c, res[i].point >= 0 && (size_t)res[i].point < P, CMLHIP_ERR_INVALID, "residual index out of range");
+    W.rpoint.resize(R0 + n); W.rtarget.resize(R0 + n); W.rstate.resize(R0 + n); W.rlin.resize(R0 + n);
+    for (int i = 0; i < n; i++) { W.rpoint[R0 + i] = res[i].point; W.rtarget[R0 + i] = res[i].target; W.rstate[R0 + i] = res[i].state; W.rlin[R0 + i] = res[i].is_linearized != 0; }
+    return CMLHIP_OK;
+}
+
+// removeFrame's renumbering (DSOContext.h:154-174 + makeFrameId): ids above `frame` move down by one; whatever still names the frame itself gets -1
+// (the caller drops those entries with the next cmlhip_ba_window_compact, as the reference's sets lose them)
+int cmlhip_ba_window_retire_frame(cmlhip_ctx* c, int frame) { CML_DEV(c);
+    if (!c || frame < 0) return CMLHIP_ERR_INVALID;
+    WindowShadow& W = c->win;
+    for (int& h : W.host) { if (h == frame) h = -1; else if (h > frame) h--; }
+    for (int& t : W.rtarget) { if (t == frame) t = -1; else if (t > frame) t--; }
+    return CMLHIP_OK;
+}
+
+// the survivors keep their order and are renumbered by rank (points AND residuals; a residual's point index follows); a residual that survives
+// must name a surviving point
+int cmlhip_ba_window_compact(cmlhip_ctx* c, int n_points, const unsigned char* point_alive, int n_res, const unsigned char* res_alive) { CML_DEV(c);
+    if (!c || (n_points > 0 && !point_alive) || (n_res > 0 && !res_alive)) return CMLHIP_ERR_INVALID;
+    WindowShadow& W = c->win;
+    CML_REQUIRE(c, (size_t)n_points == W.host.size() && (size_t)n_res == W.rpoint.size(), CMLHIP_ERR_STATE, "cmlhip_ba_window_compact: the caller's lists and the window differ in length");
+    for (int r = 0; r < n_res; r++)                          // checked before anything moves: a refused call leaves the window as it was
+        CML_REQUIRE(c, !res_alive[r] || point_alive[W.rpoint[r]], CMLHIP_ERR_INVALID, "cmlhip_ba_window_compact: a surviving residual names a dropped point");
+    std::vector<int> pmap((size_t)n_points);
+    size_t np = 0;
+    for (int p = 0; p < n_points; p++) {
+        pmap[p] = point_alive[p] ? (int)np : -1;
+        if (!point_alive[p]) continue;
+        if (np != (size_t)p) {
+            W.x[np] = W.x[p]; W.y[np] = W.y[p]; W.idepth[np] = W.idepth[p]; W.idz[np] = W.idz[p]; W.prior[np] = W.prior[p]; W.host[np] = W.host[p];
+            memcpy(&W.colors[8 * np], &W.colors[8 * (size_t)p], 32); memcpy(&W.weights[8 * np], &W.weights[8 * (size_t)p], 32);
+        }
+        np++;
+    }
+    W.x.resize(np); W.y.resize(np); W.idepth.resize(np); W.idz.resize(np); W.prior.resize(np); W.host.resize(np); W.colors.resize(8 * np); W.weights.resize(8 * np);
+    size_t nr = 0;
+    for (int r = 0; r < n_res; r++) {
+        if (!res_alive[r]) continue;
+        const int pn = pmap[W.rpoint[r]];
+        CML_REQUIRE(c, pn >= 0, CMLHIP_ERR_INVALID, "cmlhip_ba_window_compact: a surviving residual names a dropped point");
+        W.rpoint[nr] = pn; W.rtarget[nr] = W.rtarget[r]; W.rstate[nr] = W.rstate[r]; W.rlin[nr] = W.rlin[r];
+        nr++;
+    }
+    W.rpoint.resize(nr); W.rtarget.resize(nr); W.rstate.resize(nr); W.rlin.resize(nr);
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_window_counts(cmlhip_ctx* c, int* P, int* R) { CML_DEV(c);
+    if (!c) return CMLHIP_ERR_INVALID;
+    if (P) *P = (int)c->win.host.size();
+    if (R) *R = (int)c->win.rpoint.size();
+    return CMLHIP_OK;
+}
+
+int cmlhip_ba_window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames, const double* idepth, const float* idepth_zero, const float* prior,
+                            int reset_states, int n_lin, const int* lin_residuals, const int* lin_states) { CML_DEV(c);
+    if (!c || !frames || n_lin < 0 || (n_lin > 0 && (!lin_residuals || !lin_states))) return CMLHIP_ERR_INVALID;
+    WindowShadow& W = c->win;
+    const size_t P = W.host.size(), R = W.rpoint.size();
+    if (idepth) memcpy(W.idepth.data(), idepth, 8 * P);
+    if (idepth_zero) memcpy(W.idz.data(), idepth_zero, 4 * P);
+    if (prior) memcpy(W.prior.data(), prior, 4 * P);
+    if (reset_states) {                                      // resetOOB of BA::run's preamble (BA.cpp:766-779) for everything but the listed LINEARIZED residuals
+        std::fill(W.rstate.begin(), W.rstate.end(), (int)CMLHIP_RES_IN);
+        std::fill(W.rlin.begin(), W.rlin.end(), (unsigned char)0);
+    }
+    for (int i = 0; i < n_lin; i++) {
+        CML_REQUIRE(c, lin_residuals[i] >= 0 && (size_t)lin_residuals[i] < R, CMLHIP_ERR_INVALID, "residual index out of range");
+        W.rstate[lin_residuals[i]] = lin_states[i]; W.rlin[lin_residuals[i]] = 1;
+    }
+    return window_commit(c, N, frames);
+}
+
 int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames, int P, const cmlhip_ba_point* points,
                             int R, const cmlhip_ba_residual* res) { CML_DEV(c);
     if (!c || !frames || (P > 0 && !points) || (R > 0 && !res)) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, c->ba_prm_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_params not called");
     CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P >= 0 && P <= c->lim.max_points && R >= 0 && R <= c->lim.max_residuals,
                 CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
+    int rc;
+    if ((rc = cmlhip_ba_window_reset(c))) return rc;
+    if ((rc = cmlhip_ba_window_append_points(c, P, points))) return rc;
+    if ((rc = cmlhip_ba_window_append_residuals(c, R, res))) return rc;
+    return window_commit(c, N, frames);
+}
+
+static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
+    WindowShadow& W = c->win;
+    const int P = (int)W.host.size(), R = (int)W.rpoint.size();
+    CML_REQUIRE(c, c->ba_prm_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_params not called");
+    CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P <= c->lim.max_points && R <= c->lim.max_residuals,
+                CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
     (void)hipSetDevice(c->device);
     const auto T0_ = std::chrono::steady_clock::now();
-    auto lap_ = [&](const char* w) { if (getenv("CMLHIP_TIMING")) fprintf(stderr, "      [upload] %-18s %.0f us\n", w, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0_).count()); };
+    static const bool timing_ = getenv("CMLHIP_TIMING") != nullptr;
+    auto lap_ = [&](const char* w) { if (timing_ || getenv("CMLHIP_TIMING")) fprintf(stderr, "      [upload] %-18s %.0f us\n", w, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0_).count()); };
     // ---- frames: resolve pyramids
     std::vector<FrameDev> fd(N);
     for (int i = 0; i < N; i++) {
@@ -156,41 +282,31 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
             if (int rc_t = cml_tiled_level0(c, frames[i].image_id, &fd[i].grad0t)) return rc_t;
         }
     }
-    // ---- index bookkeeping (exact): htIDX = host + target*N (BA.cpp:1677), CSR by point and by pair
-    c->h_pair_of.assign(R, 0);
-    c->h_by_point_off.assign(P + 1, 0); c->h_by_point.assign(R, 0);
-    c->h_by_pair_off.assign(N * N + 1, 0); c->h_by_pair.assign(R, 0);
-    std::vector<int> newframe;
-    int n_lin = 0;
-    for (int r = 0; r < R; r++) {
-        CML_REQUIRE(c, res[r].point >= 0 && res[r].point < P && res[r].target >= 0 && res[r].target < N, CMLHIP_ERR_INVALID,
-                    "residual index out of range");
-        const int host = points[res[r].point].host;
-        CML_REQUIRE(c, host >= 0 && host < N && host != res[r].target, CMLHIP_ERR_INVALID, "bad host frame (BA.cpp:338-340)");
-        c->h_pair_of[r] = host + res[r].target * N;
-        c->h_by_point_off[res[r].point + 1]++;
-        c->h_by_pair_off[c->h_pair_of[r] + 1]++;
-        if (res[r].target == N - 1) newframe.push_back(r);
-        n_lin += res[r].is_linearized != 0;
-    }
-    for (int p = 0; p < P; p++) c->h_by_point_off[p + 1] += c->h_by_point_off[p];
-    for (int q = 0; q < N * N; q++) c->h_by_pair_off[q + 1] += c->h_by_pair_off[q];
+    // ---- index bookkeeping (exact): htIDX = host + target*N (BA.cpp:1677), CSR by point and by pair — pass 1: counts
+    const int NN = N * N;
+    c->h_pair_of.resize(R);
+    c->h_by_point_off.assign(P + 1, 0); c->h_by_pair_off.assign(NN + 1, 0);
+    int n_lin = 0, n_newframe = 0;
     {
-        std::vector<int> c1(P, 0), c2(N * N, 0);
+        const int* rp = W.rpoint.data(); const int* rt = W.rtarget.data(); const int* hst = W.host.data();
+        int* pair_of = c->h_pair_of.data(); int* cp = c->h_by_point_off.data() + 1; int* cq = c->h_by_pair_off.data() + 1;
+        const unsigned char* rl = W.rlin.data();
+        bool ok = true;
         for (int r = 0; r < R; r++) {
-            const int p = res[r].point, q = c->h_pair_of[r];
-            c->h_by_point[c->h_by_point_off[p] + c1[p]++] = r;
-            c->h_by_pair[c->h_by_pair_off[q] + c2[q]++] = r;
+            const int p = rp[r], t = rt[r];
+            const int host = hst[p];                         // (p was range-checked when the residual was appended; compaction keeps it valid)
+            ok = ok && ((unsigned)t < (unsigned)N) && ((unsigned)host < (unsigned)N) && host != t;
+            if (!ok) break;
+            const int q = host + t * N;
+            pair_of[r] = q; cp[p]++; cq[q]++;
+            n_newframe += t == N - 1; n_lin += rl[r];
         }
+        CML_REQUIRE(c, ok, CMLHIP_ERR_INVALID, "residual index out of range / bad host frame (BA.cpp:338-340)");
     }
-    // ---- DEVICE residual order = (host,target)-pair-sorted: r' = position in the by-pair list.  Every R-length device array, the
-    //      by-point lists and the new-frame list hold r'; the ABI keeps the caller's numbering (inputs are permuted here, readbacks
-    //      are permuted back, cmlhip_ba_get_index_maps reports the caller-order maps).  Residuals of one pair are contiguous on the
-    //      device, so the residual kernel of the resident loop reads the pair record through scalar loads.
-    c->h_dev_of.assign(R, 0); c->h_caller_of.assign(R, 0);
-    for (int k = 0; k < R; k++) { c->h_caller_of[k] = c->h_by_pair[k]; c->h_dev_of[c->h_by_pair[k]] = k; }
-    for (size_t i = 0; i < newframe.size(); i++) newframe[i] = c->h_dev_of[newframe[i]];
-    c->N = N; c->P = P; c->R = R; c->n_lin = n_lin; c->n_newframe = (int)newframe.size();
+    int mx_pt = 1, mx_pair = 1;
+    for (int p = 0; p < P; p++) { mx_pt = std::max(mx_pt, c->h_by_point_off[p + 1]); c->h_by_point_off[p + 1] += c->h_by_point_off[p]; }
+    for (int q = 0; q < NN; q++) { mx_pair = std::max(mx_pair, c->h_by_pair_off[q + 1]); c->h_by_pair_off[q + 1] += c->h_by_pair_off[q]; }
+    c->N = N; c->P = P; c->R = R; c->n_lin = n_lin; c->n_newframe = n_newframe;
     const int n = 8 * N + 4, ldg = ldg_of(n), ntile = ldg / 16;
     // ---- allocations
     int rc = 0;
@@ -204,7 +320,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_dead, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 4 * (size_t)PS_STRIDE * R); ENS(c->r_rtz, 32 * R);
     ENS(c->rj[0], 4 * (size_t)RJ_STRIDE * R); ENS(c->rj[1], 4 * (size_t)RJ_STRIDE * R);
     ENS(c->by_point_off, 4 * (P + 1)); ENS(c->by_point, 4 * R); ENS(c->by_pair_off, 4 * (N * N + 1)); ENS(c->by_pair, 4 * R);
-    ENS(c->newframe_res, 4 * newframe.size());
+    ENS(c->newframe_res, 4 * (size_t)n_newframe);
     for (int m = 0; m < 2; m++) { ENS(c->acc_pair[m], 4 * ACC_STRIDE * N * N); ENS(c->acc_num[m], 4 * N * N); }
     ENS(c->pair_blocks, 2 * 8 * (size_t)PB_STRIDE * N * N);
     ENS(c->adH, 8 * 64 * N * N); ENS(c->adT, 8 * 64 * N * N); ENS(c->adHTd, 4 * 8 * N * N); ENS(c->vec_small, 8 * (8 + 16 * N));
@@ -223,9 +339,10 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         c->rs_tile = (forced == 16 || forced == 64) ? forced : (R >= 36 * 1024 ? 64 : 16);
     }
     const int TS = c->rs_tile;
-    std::vector<int> tiles, tile_off(N * N + 1, 0);
+    std::vector<int>& tiles = c->h_tiles; std::vector<int>& tile_off = c->h_tile_off;
+    tiles.clear(); tile_off.assign(NN + 1, 0);
     c->h_rs_pair_tab.clear(); c->rs_pair_max_tiles = 0;
-    for (int q = 0; q < N * N; q++) {
+    for (int q = 0; q < NN; q++) {
         const int host = q % N, target = q / N;                  // htIDX = host + target * N
         for (int i = c->h_by_pair_off[q]; i < c->h_by_pair_off[q + 1]; i += TS) {
             tiles.push_back(i); tiles.push_back(std::min(TS, c->h_by_pair_off[q + 1] - i)); tiles.push_back(host); tiles.push_back(target);
@@ -251,12 +368,17 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     ENS(c->xad, 8 * 8 * (size_t)N * N);
     ENS(c->solve_image, 8 * ((size_t)(ntile * (ntile + 1) / 2) * 16 * 17 + 32 * (size_t)ntile));      // k_ba_assemble (wide windows)
     ENS(c->scal, 1024);
+    c->pair_stride = (mx_pair + 3) & ~3;
+    c->pt_stride = (mx_pt + 7) & ~7;
+    const size_t pt_tot = (size_t)std::max(P, 1) * c->pt_stride;
+    ENS(c->pair_code, 4 * (size_t)NN * c->pair_stride); ENS(c->pair_pos, 4 * (size_t)std::max(R, 1));
+    ENS(c->point_code, 4 * pt_tot); ENS(c->point_tgt, 4 * pt_tot); ENS(c->point_pos, 4 * (size_t)std::max(R, 1)); ENS(c->point_res, 4 * pt_tot);
 #undef ENS
-    lap_("index lists+ensure");
+    lap_("counts+ensure");
     // ---- SoA staging + upload: everything below is staged and leaves in ONE copy + one scatter / fill kernel (cml_h2d_batch_flush)
     cml_h2d_batch_begin(c);
     struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};   // error returns close the batch
-    // the SoA arrays are written where the packed copy starts from (cml_h2d_stage); the vectors below exist only when the ring has no room
+    // the device-order arrays are written where the packed copy starts from (cml_h2d_stage); the vectors exist only when the ring has no room
     struct Staged { void* p = nullptr; std::vector<unsigned char> fb; void* dst = nullptr; size_t bytes = 0; };
     auto stage = [&](Staged& s, DevBuf& buf, size_t bytes) -> void* {
         s.dst = buf.p; s.bytes = bytes;
@@ -265,73 +387,72 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         return s.p;
     };
     auto commit = [&](Staged& s) -> int { return s.fb.empty() ? CMLHIP_OK : cml_h2d(c, s.dst, s.fb.data(), s.bytes); };
-    Staged s_fx, s_fy, s_fz, s_fp, s_col, s_wgt, s_idp, s_hst, s_rp, s_rt, s_rs, s_rl, s_bp;
+    // points: the shadows ARE the device layout (caller order)
+#define UPS(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
+    UPS(c->pt_x, W.x); UPS(c->pt_y, W.y); UPS(c->pt_idepth, W.idepth); UPS(c->pt_idepth_zero, W.idz); UPS(c->pt_prior, W.prior);
+    UPS(c->pt_host, W.host); UPS(c->pt_colors, W.colors); UPS(c->pt_weights, W.weights);
+    // ---- pass 2: DEVICE residual order = (host,target)-pair-sorted: r' = position in the by-pair list.  Every R-length device array, the
+    //      by-point lists and the new-frame list hold r'; the ABI keeps the caller's numbering (inputs are permuted here, readbacks
+    //      are permuted back, cmlhip_ba_get_index_maps reports the caller-order maps).  Residuals of one pair are contiguous on the
+    //      device, so the residual kernel of the resident loop reads the pair record through scalar loads.
+    c->h_by_point.resize(R); c->h_by_pair.resize(R); c->h_dev_of.resize(R); c->h_caller_of.resize(R);
     {
-        float* fx = (float*)stage(s_fx, c->pt_x, 4 * (size_t)P); float* fy = (float*)stage(s_fy, c->pt_y, 4 * (size_t)P);
-        double* idp = (double*)stage(s_idp, c->pt_idepth, 8 * (size_t)P); float* fz = (float*)stage(s_fz, c->pt_idepth_zero, 4 * (size_t)P);
-        float* fp = (float*)stage(s_fp, c->pt_prior, 4 * (size_t)P); int* hst = (int*)stage(s_hst, c->pt_host, 4 * (size_t)P);
-        float* col = (float*)stage(s_col, c->pt_colors, 32 * (size_t)P); float* wgt = (float*)stage(s_wgt, c->pt_weights, 32 * (size_t)P);
-        for (int p = 0; p < P; p++) {
-            fx[p] = points[p].x; fy[p] = points[p].y; idp[p] = points[p].idepth; fz[p] = points[p].idepth_zero; fp[p] = points[p].prior;
-            hst[p] = points[p].host;
-            memcpy(&col[8 * (size_t)p], points[p].colors, 32); memcpy(&wgt[8 * (size_t)p], points[p].weights, 32);
+        Staged s_rp, s_rt, s_rs, s_rl, s_bp, s_nf;
+        int* rpd = (int*)stage(s_rp, c->r_point, 4 * (size_t)R); int* rtd = (int*)stage(s_rt, c->r_target, 4 * (size_t)R);
+        int* rsd = (int*)stage(s_rs, c->r_state, 4 * (size_t)R); unsigned char* rld = (unsigned char*)stage(s_rl, c->r_lin, (size_t)R);
+        int* bpd = (int*)stage(s_bp, c->by_point, 4 * (size_t)R); int* nfd = (int*)stage(s_nf, c->newframe_res, 4 * (size_t)n_newframe);
+        c->w_cnt_p.assign(P, 0); c->w_cnt_q.assign(NN, 0);
+        int* c1 = c->w_cnt_p.data(); int* c2 = c->w_cnt_q.data();
+        const int* rp = W.rpoint.data(); const int* rt = W.rtarget.data(); const int* rs = W.rstate.data(); const unsigned char* rl = W.rlin.data();
+        const int* pair_of = c->h_pair_of.data(); const int* opt = c->h_by_point_off.data(); const int* oq = c->h_by_pair_off.data();
+        int* by_point = c->h_by_point.data(); int* by_pair = c->h_by_pair.data(); int* dev_of = c->h_dev_of.data(); int* caller_of = c->h_caller_of.data();
+        int nf = 0;
+        for (int r = 0; r < R; r++) {
+            const int p = rp[r], q = pair_of[r], t = rt[r];
+            const int k = oq[q] + c2[q]++;                   // device id
+            const int j = opt[p] + c1[p]++;                  // a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
+            by_pair[k] = r; caller_of[k] = r; dev_of[r] = k; by_point[j] = r;
+            rpd[k] = p; rtd[k] = t; rsd[k] = rs[r]; rld[k] = rl[r];
+            bpd[j] = k;                                      // device lists hold r'
+            if (t == N - 1) nfd[nf++] = k;
         }
-        int* rp = (int*)stage(s_rp, c->r_point, 4 * (size_t)R); int* rt = (int*)stage(s_rt, c->r_target, 4 * (size_t)R);
-        int* rs = (int*)stage(s_rs, c->r_state, 4 * (size_t)R); unsigned char* rl = (unsigned char*)stage(s_rl, c->r_lin, (size_t)R);
-        int* bp = (int*)stage(s_bp, c->by_point, 4 * (size_t)R);
-        for (int k = 0; k < R; k++) { const int r = c->h_caller_of[k]; rp[k] = res[r].point; rt[k] = res[r].target; rs[k] = res[r].state; rl[k] = res[r].is_linearized != 0; }
-        for (int i = 0; i < R; i++) bp[i] = c->h_dev_of[c->h_by_point[i]];      // device lists hold r': a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
-        for (Staged* s : {&s_fx, &s_fy, &s_idp, &s_fz, &s_fp, &s_hst, &s_col, &s_wgt, &s_rp, &s_rt, &s_rs, &s_rl, &s_bp}) if ((rc = commit(*s))) return rc;
+        for (Staged* s : {&s_rp, &s_rt, &s_rs, &s_rl, &s_bp, &s_nf}) if ((rc = commit(*s))) return rc;
     }
 #define UP(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
     UP(c->frames, fd);
     UP(c->by_point_off, c->h_by_point_off);
     UP(c->by_pair_off, c->h_by_pair_off);
-    {
-        int mx = 1;
-        for (int q = 0; q < N * N; q++) mx = std::max(mx, c->h_by_pair_off[q + 1] - c->h_by_pair_off[q]);
-        c->pair_stride = (mx + 3) & ~3;
-        if ((rc = cml_ensure(c, c->pair_code, 4 * (size_t)N * N * c->pair_stride))) return rc;
-        if ((rc = cml_ensure(c, c->pair_pos, 4 * (size_t)std::max(R, 1)))) return rc;
-        if ((rc = cml_fill_ff(c, c->pair_code.p, 4 * (size_t)N * N * c->pair_stride))) return rc;      // nothing is good before the first applyRes
-    }
-    {
-        int mx = 1;
-        for (int p = 0; p < P; p++) mx = std::max(mx, c->h_by_point_off[p + 1] - c->h_by_point_off[p]);
-        c->pt_stride = (mx + 7) & ~7;
-        const size_t tot = (size_t)std::max(P, 1) * c->pt_stride;
-        if ((rc = cml_ensure(c, c->point_code, 4 * tot))) return rc;
-        if ((rc = cml_ensure(c, c->point_tgt, 4 * tot))) return rc;
-        if ((rc = cml_ensure(c, c->point_pos, 4 * (size_t)std::max(R, 1)))) return rc;
-        if ((rc = cml_ensure(c, c->point_res, 4 * tot))) return rc;
-        if ((rc = cml_fill_ff(c, c->point_code.p, 4 * tot))) return rc;
-        if ((rc = cml_fill_ff(c, c->point_tgt.p, 4 * tot))) return rc;          // empty slots: -1 (filled by k_window_expand where a residual sits)
-        if ((rc = cml_fill_ff(c, c->point_res.p, 4 * tot))) return rc;
-    }
-    UP(c->newframe_res, newframe);
+    if ((rc = cml_fill_ff(c, c->pair_code.p, 4 * (size_t)NN * c->pair_stride))) return rc;      // nothing is good before the first applyRes
+    if ((rc = cml_fill_ff(c, c->point_code.p, 4 * pt_tot))) return rc;
+    if ((rc = cml_fill_ff(c, c->point_tgt.p, 4 * pt_tot))) return rc;          // empty slots: -1 (filled by k_window_expand where a residual sits)
+    if ((rc = cml_fill_ff(c, c->point_res.p, 4 * pt_tot))) return rc;
     if (c->n_tiles) { UP(c->rs_tiles, tiles); }
     UP(c->rs_tile_off, tile_off);
 #undef UP
-    // resetOOB (DSOResidual.h:83-88): energies 0, flags cleared
-    if ((rc = cml_zero(c, c->r_energy.p, c->r_energy.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_new_energy.p, c->r_new_energy.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_new_energy_wo.p, c->r_new_energy_wo.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_ret_energy.p, c->r_ret_energy.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_good.p, c->r_good.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_sel.p, c->r_sel.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_dead.p, c->r_dead.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_center.p, c->r_center.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_jpjdf.p, c->r_jpjdf.bytes))) return rc;
-    if ((rc = cml_zero(c, c->r_rtz.p, c->r_rtz.bytes))) return rc;
-    if ((rc = cml_zero(c, c->rj[0].p, c->rj[0].bytes))) return rc;
-    if ((rc = cml_zero(c, c->rj[1].p, c->rj[1].bytes))) return rc;
-    if ((rc = cml_zero(c, c->pt_acc.p, c->pt_acc.bytes))) return rc;
-    if ((rc = cml_zero(c, c->pt_step.p, c->pt_step.bytes))) return rc;
-    if ((rc = cml_zero(c, c->pt_backup.p, c->pt_backup.bytes))) return rc;
+#undef UPS
+    // resetOOB (DSOResidual.h:83-88): energies 0, flags cleared — only the R (P) entries of this window, not the buffers' high-water capacity
+    //  (+ 64 entries of slack: a tile's tail lanes may look past R)
+    auto zr = [&](DevBuf& b, size_t elem, size_t count) -> int { return cml_zero(c, b.p, std::min(b.bytes, elem * (count + 64))); };
+    const size_t Rz = (size_t)R, Pz = (size_t)P;
+    if ((rc = zr(c->r_energy, 4, Rz))) return rc;
+    if ((rc = zr(c->r_new_energy, 4, Rz))) return rc;
+    if ((rc = zr(c->r_new_energy_wo, 4, Rz))) return rc;
+    if ((rc = zr(c->r_ret_energy, 4, Rz))) return rc;
+    if ((rc = zr(c->r_good, 1, Rz))) return rc;
+    if ((rc = zr(c->r_sel, 1, Rz))) return rc;
+    if ((rc = zr(c->r_dead, 1, Rz))) return rc;
+    if ((rc = zr(c->r_center, 12, Rz))) return rc;
+    if ((rc = zr(c->r_jpjdf, 4 * (size_t)PS_STRIDE, Rz))) return rc;
+    if ((rc = zr(c->r_rtz, 32, Rz))) return rc;
+    if ((rc = zr(c->rj[0], 4 * (size_t)RJ_STRIDE, Rz))) return rc;
+    if ((rc = zr(c->rj[1], 4 * (size_t)RJ_STRIDE, Rz))) return rc;
+    if ((rc = zr(c->pt_acc, 4 * (size_t)PT_ACC_STRIDE, Pz))) return rc;
+    if ((rc = zr(c->pt_step, 8, Pz))) return rc;
+    if ((rc = zr(c->pt_backup, 4, Pz))) return rc;
     if ((rc = cml_zero(c, c->scal.p, c->scal.bytes))) return rc;
-    if ((rc = cml_zero(c, c->pair_blocks.p, c->pair_blocks.bytes))) return rc;
-    if ((rc = cml_zero(c, c->lin_partial.p, c->lin_partial.bytes))) return rc;
-    if ((rc = cml_zero(c, c->step_partial.p, c->step_partial.bytes))) return rc;
+    if ((rc = cml_zero(c, c->pair_blocks.p, 2 * 8 * (size_t)PB_STRIDE * NN))) return rc;
+    if ((rc = cml_zero(c, c->lin_partial.p, 32 * (size_t)(c->n_lin_partial + 1)))) return rc;
+    if ((rc = cml_zero(c, c->step_partial.p, 16 * (size_t)((P + 31) / 32 + 1)))) return rc;
     lap_("staged");
     if ((rc = cml_h2d_batch_flush(c))) return rc;
     if (R > 0) {
@@ -465,9 +586,13 @@ int cmlhip_ba_linearize_apply(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DE
     } else cml_launch_linearize(c, A);
     cml_launch_lin_finish(c, A);
     CML_CHECK(c, hipGetLastError());
+    if (!out) {                                             // enqueue only: the summary is kept beside the live one and comes back with cmlhip_ba_finish_run's one copy
+        CML_CHECK(c, hipMemcpyAsync(c->scal.as<char>() + CML_PRE_OFFSET, c->scal.p, sizeof(LinSummary), hipMemcpyDeviceToDevice, c->stream));
+        return CMLHIP_OK;
+    }
     LinSummary S;
     if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
-    if (out) { out->energy = S.energy; out->n_in = S.n_in; out->n_oob = S.n_oob; out->n_outlier = S.n_outlier; out->new_frame_energy_th = S.new_frame_energy_th; }
+    out->energy = S.energy; out->n_in = S.n_in; out->n_oob = S.n_oob; out->n_outlier = S.n_outlier; out->new_frame_energy_th = S.new_frame_energy_th;
     return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
 }
 
@@ -518,6 +643,113 @@ int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* sta
     // the residual loop of tryMarginalize (the reference walks the point's remaining residuals only, BA.cpp:2291)
     if (R) k_ba_retire<<<cml_div_up((int)R, 256), 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
+    return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
+}
+
+// BA::run's re-anchoring of the newest frame (BA.cpp:885-894: setEvalPT(PRE_worldToCam, (0,...,0,a,b))) on the device, between the last iteration
+// and the closing linearizeAll(true): the frame's evaluation point becomes its current pose, its state keeps the affine entries only, the
+// DSOFramePrecomputed of every pair that names it gets its PRE_RTll_0 / PRE_tTll_0 from the new evaluation points (DSOFrame.h:261-267) and its b0
+// follows state_zero (DSOFrame.h:197-199).  Saves run() the host round trip (frame states back, pairs + b0 down) ahead of the closing pass.
+// The host mirror adopts the same evaluation point from the pose read back (pre_w2c).
+__global__ void k_ba_reanchor_newest(cmlhip_ba_frame_state* __restrict__ fs, const double* __restrict__ pre_w2c, cmlhip_ba_pair* __restrict__ pairs,
+                                     FrameDev* __restrict__ frames, int N, double scale_b) {
+    using cml_amd::SE3;
+    __shared__ double s_ev[CMLHIP_MAX_FRAMES][7];
+    const int tid = threadIdx.x, f = N - 1;
+    if (tid < N) {
+        cmlhip_ba_frame_state& S = fs[tid];
+        if (tid == f) {
+            for (int k = 0; k < 4; k++) { S.eval_q[k] = pre_w2c[7 * f + k]; s_ev[f][k] = S.eval_q[k]; }
+            for (int k = 0; k < 3; k++) { S.eval_t[k] = pre_w2c[7 * f + 4 + k]; s_ev[f][4 + k] = S.eval_t[k]; }
+            for (int k = 0; k < 10; k++) { const double v = (k == 6 || k == 7) ? S.state[k] : 0.0; S.state[k] = v; S.state_zero[k] = v; }
+            frames[f].b0 = (float)(S.state_zero[7] * scale_b);
+        } else {
+            for (int k = 0; k < 4; k++) s_ev[tid][k] = S.eval_q[k];
+            for (int k = 0; k < 3; k++) s_ev[tid][4 + k] = S.eval_t[k];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * N; e += blockDim.x) {          // pairs (h, f) and (f, t)
+        const int h = e < N ? e : f, t = e < N ? f : e - N;
+        if (e >= N && t == f) continue;                      // (f, f) once
+        SE3 Et, Eh;
+        for (int k = 0; k < 4; k++) { Et.q[k] = s_ev[t][k]; Eh.q[k] = s_ev[h][k]; }
+        for (int k = 0; k < 3; k++) { Et.t[k] = s_ev[t][4 + k]; Eh.t[k] = s_ev[h][4 + k]; }
+        const SE3 l0 = Et * Eh.inverse();
+        cmlhip_ba_pair& P = pairs[(size_t)h * N + t];
+        double R0[9];
+        l0.matrix(R0);
+        for (int k = 0; k < 9; k++) P.R0[k] = R0[k];
+        for (int k = 0; k < 3; k++) P.t0[k] = l0.t[k];
+    }
+}
+
+// The tail of DSOBundleAdjustment::run with the loop resident on the device, in ONE readback: what cmlhip_ba_get_resident_state / _log / _indirect return
+// after the iterations (frame states, PRE_worldToCam, the preamble pass's and the last pass's summaries, the energy log, x), then — reanchor_newest —
+// the newest frame re-anchored on the device (k_ba_reanchor_newest) and cmlhip_ba_finish_keyframe's closing pass with its outputs.
+int cmlhip_ba_finish_run(cmlhip_ctx* c, int reanchor_newest, const cmlhip_ba_resident_out* ro, cmlhip_ba_lin_result* lin, int* state, int* new_state,
+                         float* energy, float* new_energy, float* new_energy_wo, unsigned char* is_good, double* idepth, float* point_acc) { CML_DEV(c);
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
+    CML_REQUIRE(c, !reanchor_newest || c->resident_iter > 0, CMLHIP_ERR_STATE, "cmlhip_ba_finish_run: no iteration has run (PRE_worldToCam is not on the device)");
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    if (c->lin_finish_pending) {                             // the tail of the last residual pass normally rides in the NEXT solve launch
+        if (c->conv_on) A.ctl = reinterpret_cast<ResidentCtl*>(c->scal.as<char>() + CML_CTL_OFFSET);
+        cml_launch_lin_finish(c, A);
+        CML_CHECK(c, hipGetLastError());
+        c->lin_finish_pending = false;
+        A.ctl = nullptr;
+    }
+    const size_t N = c->N, n = 8 * N + 4, R = c->R, P = c->P;
+    // the loop's results are snapshotted on the device (the closing pass overwrites the summary; the re-anchoring the frame states)
+    const size_t snap_bytes = sizeof(LinSummary) + sizeof(cmlhip_ba_frame_state) * N;
+    if ((rc = cml_ensure(c, c->run_snap, snap_bytes))) return rc;
+    CML_CHECK(c, hipMemcpyAsync(c->run_snap.p, c->scal.p, sizeof(LinSummary), hipMemcpyDeviceToDevice, c->stream));
+    CML_CHECK(c, hipMemcpyAsync(c->run_snap.as<char>() + sizeof(LinSummary), c->frame_state.p, sizeof(cmlhip_ba_frame_state) * N, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = cml_materialize_records(c))) return rc;        // (with the loop's own pair records, as cmlhip_ba_set_pairs does ahead of a new set)
+    if (reanchor_newest) {
+        k_ba_reanchor_newest<<<1, 64, 0, c->stream>>>(c->frame_state.as<cmlhip_ba_frame_state>(), c->pre_w2c.as<double>(), c->pairs.as<cmlhip_ba_pair>(),
+                                                        c->frames.as<FrameDev>(), (int)N, c->res_scales[3]);
+        CML_CHECK(c, hipGetLastError());
+    }
+    A.fuse_apply = 1;
+    cml_launch_linearize(c, A);
+    cml_launch_lin_finish(c, A);
+    CML_CHECK(c, hipGetLastError());
+    LinSummary S, Sfirst, Slast;
+    ResidentCtl ctl;
+    std::vector<float> pacc(point_acc ? PT_ACC_STRIDE * P : 0);
+    ResRead rr(c);
+    cml_d2h_batch_begin(c);
+    cml_d2h(c, &S, c->scal.p, sizeof S);
+    if (ro) {
+        cml_d2h(c, &Sfirst, c->scal.as<char>() + CML_PRE_OFFSET, sizeof Sfirst);
+        cml_d2h(c, &Slast, c->run_snap.p, sizeof Slast);
+        cml_d2h(c, &ctl, c->scal.as<char>() + CML_CTL_OFFSET, sizeof ctl);
+        if (ro->frames) cml_d2h(c, ro->frames, c->run_snap.as<char>() + sizeof(LinSummary), sizeof(cmlhip_ba_frame_state) * N);
+        if (ro->pre_w2c) cml_d2h(c, ro->pre_w2c, c->pre_w2c.p, 8 * 7 * N);
+        if (ro->x) cml_d2h(c, ro->x, c->xvec.p, 8 * n);
+    }
+    rr.add(state, c->r_state.p, 4); rr.add(new_state, c->r_new_state.p, 4); rr.add(energy, c->r_energy.p, 4);
+    rr.add(new_energy, c->r_new_energy.p, 4); rr.add(new_energy_wo, c->r_new_energy_wo.p, 4); rr.add(is_good, c->r_good.p, 1);
+    if (idepth) cml_d2h(c, idepth, c->pt_idepth.p, 8 * P);
+    if (point_acc && P) cml_d2h(c, pacc.data(), c->pt_acc.p, 4 * pacc.size());
+    if ((rc = cml_d2h_batch_flush(c))) return rc;
+    rr.deliver();
+    if (point_acc) for (size_t p = 0; p < P; p++) memcpy(point_acc + 14 * p, &pacc[PT_ACC_STRIDE * p], 14 * 4);
+    auto put = [](cmlhip_ba_lin_result* o, const LinSummary& s) { if (o) { o->energy = s.energy; o->n_in = s.n_in; o->n_oob = s.n_oob; o->n_outlier = s.n_outlier; o->new_frame_energy_th = s.new_frame_energy_th; } };
+    put(lin, S);
+    if (ro) {
+        put(ro->first, Sfirst); put(ro->last, Slast);
+        const int nit = c->conv_on ? ctl.iters_done : c->resident_iter;
+        if (ro->iterations) *ro->iterations = nit;
+        if (ro->energies) for (int i = 0; i < ro->capacity && i < nit && i < 40; i++) ro->energies[i] = ctl.energy[i];
+    }
+    if (R) k_ba_retire<<<cml_div_up((int)R, 256), 256, 0, c->stream>>>(A);
+    CML_CHECK(c, hipGetLastError());
+    if (ro && !std::isfinite(Slast.energy)) return CMLHIP_ERR_NONFINITE;
     return std::isfinite(S.energy) ? CMLHIP_OK : CMLHIP_ERR_NONFINITE;
 }
 

@@ -47,6 +47,7 @@ struct ResidentCtl {
     double energy[40];        // photometric energy after iteration i (statEnergyP)
 };
 #define CML_CTL_OFFSET 640
+#define CML_PRE_OFFSET 128              // copy of the LinSummary of run()'s preamble pass (cmlhip_ba_linearize_apply with out == NULL), read back by cmlhip_ba_finish_run
 #define CML_ZERO_WORD_OFFSET 1008       // a word of the scalar scratch that is cleared with it at upload and never written
 
 struct BAArgs {

@@ -67,6 +67,15 @@ struct FrameDev {
 #define CML_TILE_H 4
 static inline size_t cml_tiled_bytes(int w, int h) { return (size_t)((w + CML_TILE_W - 1) / CML_TILE_W) * ((h + CML_TILE_H - 1) / CML_TILE_H) * 128; }
 
+// the BA window as the library keeps it between keyframes (cmlhip_ba_window_*): SoA, caller order, the layout of the device's point arrays
+struct WindowShadow {
+    std::vector<float> x, y, idz, prior, colors, weights;     // colors / weights: 8 per point
+    std::vector<double> idepth;
+    std::vector<int> host;
+    std::vector<int> rpoint, rtarget, rstate;
+    std::vector<unsigned char> rlin;
+};
+
 struct cmlhip_ctx {
     cmlhip_limits lim{};
     int device = 0;
@@ -107,6 +116,7 @@ struct cmlhip_ctx {
     int N = 0, P = 0, R = 0, n_lin = 0, n_newframe = 0;
     std::vector<int> h_pair_of, h_by_point_off, h_by_point, h_by_pair_off, h_by_pair;    // caller numbering (cmlhip_ba_get_index_maps)
     std::vector<int> h_dev_of, h_caller_of;                   // caller r -> device r' (pair-sorted) and back
+    WindowShadow win; std::vector<int> h_tiles, h_tile_off, w_cnt_p, w_cnt_q;     // window kept across keyframes + commit scratch (allocated once)
     DevBuf frames, pairs;                                     // FrameDev[N], cmlhip_ba_pair[N*N]
     DevBuf pt_x, pt_y, pt_idepth, pt_idepth_zero, pt_prior, pt_host, pt_colors, pt_weights, pt_backup;
     DevBuf pt_acc;                                            // P x 16 floats: HddA bdA HcdA[4] HddL bdL HcdL[4] HdiF bdSum pad pad
@@ -143,6 +153,7 @@ struct cmlhip_ctx {
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)
+    DevBuf run_snap;                                          // cmlhip_ba_finish_run: the loop's last summary + frame states, kept across the re-anchoring and the closing pass
     bool resident_on = false, have_null = false, lin_finish_pending = false; int resident_iter = 0; double res_scales[4] = {1, 1, 1, 1}; double conv_th = 0; bool conv_on = false;
     DevBuf dbg; bool dbg_on = false;                          // phase timestamps (tools)
     DevBuf step_partial;                                      // per-block {sumID, sumNID, numID, pad} of the point update

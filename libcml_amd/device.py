@@ -59,6 +59,14 @@ PROTOTYPES = {
     "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "cmlhip_ba_finish_keyframe": (C.c_int, [_ctx, C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_ubyte), _P(C.c_double), _P(C.c_float)]),
+    "cmlhip_ba_window_reset": (C.c_int, [_ctx]),
+    "cmlhip_ba_window_append_points": (C.c_int, [_ctx, _i, C.c_void_p]),
+    "cmlhip_ba_window_append_residuals": (C.c_int, [_ctx, _i, C.c_void_p]),
+    "cmlhip_ba_window_retire_frame": (C.c_int, [_ctx, _i]),
+    "cmlhip_ba_window_compact": (C.c_int, [_ctx, _i, _P(C.c_ubyte), _i, _P(C.c_ubyte)]),
+    "cmlhip_ba_window_counts": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_int)]),
+    "cmlhip_ba_window_commit": (C.c_int, [_ctx, _i, C.c_void_p, _P(C.c_double), _P(C.c_float), _P(C.c_float), _i, _i, _P(C.c_int), _P(C.c_int)]),
+    "cmlhip_ba_finish_run": (C.c_int, [_ctx, _i, _P(abi.BAResidentOut), C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_ubyte), _P(C.c_double), _P(C.c_float)]),
     "cmlhip_pnp_optimize": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_double), _P(C.c_double), _i, C.c_void_p, _P(C.c_ubyte), _i, _i, _i, _P(abi.PnpResult)]),
     "cmlhip_lba_set_stop_flag": (C.c_int, [_ctx, C.c_void_p]),
     "cmlhip_lba_optimize": (C.c_int, [_ctx, _i, C.c_void_p, _i, _P(C.c_double), _P(C.c_int), C.c_void_p, _i, _i, _i, _P(C.c_ubyte), _P(abi.LbaResult)]),

@@ -94,23 +94,73 @@ void DSOBundleAdjustment::setCalibration(double fx, double fy, double cx, double
     mHaveCalib = true;
 }
 
+// The library keeps the window between keyframes (cmlhip_ba_window_*, include/cmlhip.h) index for index with mPoints / mResiduals: entries this
+// object has not handed over yet are appended, in list order.  A window the library no longer holds (somebody uploaded another one through the
+// context) is handed over again from the start.
+bool DSOBundleAdjustment::syncWindowAppends() {
+    int wp = 0, wr = 0;
+    int rc = cmlhip_ba_window_counts(mCtx, &wp, &wr);
+    if (rc) return fail("cmlhip_ba_window_counts", rc);
+    if (wp != (int)mWinPoints || wr != (int)mWinResiduals || mWinPoints > mPoints.size() || mWinResiduals > mResiduals.size()) {
+        if ((rc = cmlhip_ba_window_reset(mCtx))) return fail("cmlhip_ba_window_reset", rc);
+        mWinPoints = mWinResiduals = 0;
+    }
+    if (mWinPoints < mPoints.size()) {
+        std::vector<cmlhip_ba_point>& pts = mUploadPoints;
+        pts.resize(mPoints.size() - mWinPoints);
+        for (size_t p = mWinPoints; p < mPoints.size(); p++) {
+            const DSOPoint& P = mPoints[p];
+            cmlhip_ba_point& q = pts[p - mWinPoints];
+            q.x = P.x; q.y = P.y; q.idepth = P.idepth; q.idepth_zero = P.idepth_zero; q.prior = P.priorF; q.host = P.host;
+            std::memcpy(q.colors, P.colors, sizeof q.colors);
+            std::memcpy(q.weights, P.weights, sizeof q.weights);
+        }
+        if ((rc = cmlhip_ba_window_append_points(mCtx, (int)pts.size(), pts.data()))) return fail("cmlhip_ba_window_append_points", rc);
+        mWinPoints = mPoints.size();
+    }
+    if (mWinResiduals < mResiduals.size()) {
+        std::vector<cmlhip_ba_residual>& rs = mUploadResiduals;
+        rs.resize(mResiduals.size() - mWinResiduals);
+        for (size_t r = mWinResiduals; r < mResiduals.size(); r++) {
+            const DSOResidual& R = mResiduals[r];
+            rs[r - mWinResiduals] = cmlhip_ba_residual{R.point < 0 ? 0 : R.point, R.target, R.state_state, R.isLinearized ? 1 : 0};
+        }
+        if ((rc = cmlhip_ba_window_append_residuals(mCtx, (int)rs.size(), rs.data()))) return fail("cmlhip_ba_window_append_residuals", rc);
+        mWinResiduals = mResiduals.size();
+    }
+    return true;
+}
+
 void DSOBundleAdjustment::compactDead() {
+    mOutliers.clear(); mActive.clear(); mActivePoints.clear();
+    if (mDeadSinceCompact == 0) { mPointSlot.assign(mPoints.size(), -1); return; }      // nothing was dropped since the lists were last renumbered
     std::vector<int> pmap(mPoints.size(), -1), rmap(mResiduals.size(), -1);
+    std::vector<unsigned char> pAlive(mPoints.size(), 0), rAlive(mResiduals.size(), 0);
     std::vector<DSOPoint> np;
     std::vector<DSOResidual> nr;
-    for (size_t p = 0; p < mPoints.size(); p++) if (mPoints[p].alive) { pmap[p] = (int)np.size(); np.push_back(mPoints[p]); }
+    np.reserve(mPoints.size()); nr.reserve(mResiduals.size());
+    for (size_t p = 0; p < mPoints.size(); p++) if (mPoints[p].alive) { pmap[p] = (int)np.size(); pAlive[p] = 1; np.push_back(mPoints[p]); }
+    mLinearizedAlive = 0;
     for (size_t r = 0; r < mResiduals.size(); r++) {
         const DSOResidual& R = mResiduals[r];
         if (!R.alive || R.point < 0 || pmap[R.point] < 0) continue;
-        rmap[r] = (int)nr.size();
+        rmap[r] = (int)nr.size(); rAlive[r] = 1;
         nr.push_back(R);
         nr.back().point = pmap[R.point];
+        mLinearizedAlive += R.isLinearized;
     }
+    // the library's copy of the window is renumbered the same way (everything appended first, so that the lists have the same length)
+    if (syncWindowAppends()) {
+        const int rc = cmlhip_ba_window_compact(mCtx, (int)pAlive.size(), pAlive.data(), (int)rAlive.size(), rAlive.data());
+        if (rc) { cmlhip_ba_window_reset(mCtx); mWinPoints = mWinResiduals = 0; }        // (handed over again from the start by the next run)
+        else { mWinPoints = np.size(); mWinResiduals = nr.size(); }
+    } else { cmlhip_ba_window_reset(mCtx); mWinPoints = mWinResiduals = 0; mError.clear(); }
     for (auto& P : np) for (int q = 0; q < 2; q++) P.lastResidual[q] = P.lastResidual[q] >= 0 ? rmap[P.lastResidual[q]] : -1;
     mPoints.swap(np); mResiduals.swap(nr);
     mPointRes.assign(mPoints.size(), {});
     for (size_t r = 0; r < mResiduals.size(); r++) mPointRes[mResiduals[r].point].push_back((int)r);
-    mOutliers.clear(); mActive.clear(); mActivePoints.clear(); mPointSlot.assign(mPoints.size(), -1);
+    mPointSlot.assign(mPoints.size(), -1);
+    mDeadSinceCompact = 0;
 }
 
 int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, const Exposure& exposure) {
@@ -385,12 +435,17 @@ void DSOBundleAdjustment::orthogonalize(std::vector<double>& x) const {
     for (int i = 0; i < n; i++) x[i] -= proj[i];
 }
 
+// The window of this run on the device: the library already holds everything up to the last keyframe (cmlhip_ba_window_*); what BA::addNewFrame
+// and BA::addPoints added since is appended, the per-point values a run changes (inverse depth, its linearisation point, the prior) and the
+// frames' thresholds / b0 are refreshed, and the commit applies the preamble's resetOOB (BA.cpp:766-779) — no rebuild, no copy of the whole window.
 bool DSOBundleAdjustment::uploadWindow() {
     if (!mHaveCalib) { mError = "setCalibration not called"; return false; }
     mPrm.huber = (float)mHuberThreshold; mPrm.outlier_th_sum = (float)mSettingOutlierTHSumComponent;
     mPrm.scale_f = mScaleF; mPrm.scale_c = mScaleC; mPrm.optimize_a = mOptimizeA; mPrm.optimize_b = mOptimizeB;
     int rc = cmlhip_ba_set_params(mCtx, &mPrm);
     if (rc) return fail("cmlhip_ba_set_params", rc);
+    if (mDeadSinceCompact) compactDead();                    // (entries dropped since the last addNewFrame: the window holds live entries only)
+    if (!syncWindowAppends()) return false;
     const int N = (int)mFrames.size();
     std::vector<cmlhip_ba_frame> fr(N);
     for (int i = 0; i < N; i++) {
@@ -398,42 +453,21 @@ bool DSOBundleAdjustment::uploadWindow() {
         fr[i].frame_energy_th = (float)mFrames[i].frameEnergyTH;
         fr[i].b0 = mFrames[i].getB0((float)mScaleLightB);
     }
-    mActivePoints.clear();
-    mPointSlot.assign(mPoints.size(), -1);
-    std::vector<cmlhip_ba_point>& pts = mUploadPoints;      // (members: the window-sized arrays are allocated once, not per keyframe)
-    pts.clear();
-    pts.reserve(mPoints.size()); mActivePoints.reserve(mPoints.size());
-    for (int p = 0; p < (int)mPoints.size(); p++) {
-        if (!mPoints[p].alive) continue;
-        const DSOPoint& P = mPoints[p];
-        cmlhip_ba_point q;
-        q.x = P.x; q.y = P.y; q.idepth = P.idepth; q.idepth_zero = P.idepth_zero; q.prior = P.priorF; q.host = P.host;
-        std::memcpy(q.colors, P.colors, sizeof q.colors);
-        std::memcpy(q.weights, P.weights, sizeof q.weights);
-        mPointSlot[p] = (int)pts.size();
-        mActivePoints.push_back(p);
-        pts.push_back(q);
-    }
-    mActive.clear();
-    std::vector<cmlhip_ba_residual>& rs = mUploadResiduals;
-    rs.clear();
-    rs.reserve(mResiduals.size()); mActive.reserve(mResiduals.size());
-    for (int r = 0; r < (int)mResiduals.size(); r++) {
-        DSOResidual& R = mResiduals[r];
-        if (!R.alive || !mPoints[R.point].alive) continue;
-        if (!R.isLinearized || mAddLinearizedPoints) {                   // BA.cpp:766-779: resetOOB
-            R.state_NewEnergy = R.state_energy = 0;
-            R.state_NewState = DSORES_OUTLIER;
-            R.state_state = DSORES_IN;
-            if (R.isLinearized) R.isLinearized = false;
-        }
-        cmlhip_ba_residual q;
-        q.point = mPointSlot[R.point]; q.target = R.target; q.state = R.state_state; q.is_linearized = R.isLinearized;
-        mActive.push_back(r);
-        rs.push_back(q);
-    }
-    rc = cmlhip_ba_upload_window(mCtx, N, fr.data(), (int)pts.size(), pts.data(), (int)rs.size(), rs.data());
-    if (rc) return fail("cmlhip_ba_upload_window", rc);
+    const size_t P = mPoints.size(), R = mResiduals.size();
+    mDynIdepth.resize(P); mDynZero.resize(P); mDynPrior.resize(P);
+    for (size_t p = 0; p < P; p++) { const DSOPoint& Q = mPoints[p]; mDynIdepth[p] = Q.idepth; mDynZero[p] = Q.idepth_zero; mDynPrior[p] = Q.priorF; }
+    // residuals that stay LINEARIZED over this run keep their state (:766-779); everything else is reset by the commit (and, for this object's own
+    // copies of the fields, by the closing pass's bookkeeping)
+    std::vector<int> linIdx, linState;
+    if (mLinearizedAlive > 0 && !mAddLinearizedPoints)
+        for (size_t r = 0; r < R; r++) if (mResiduals[r].isLinearized) { linIdx.push_back((int)r); linState.push_back(mResiduals[r].state_state); }
+    if (mAddLinearizedPoints && mLinearizedAlive > 0) { for (auto& Rr : mResiduals) Rr.isLinearized = false; mLinearizedAlive = 0; }
+    rc = cmlhip_ba_window_commit(mCtx, N, fr.data(), mDynIdepth.data(), mDynZero.data(), mDynPrior.data(), 1, (int)linIdx.size(), linIdx.data(), linState.data());
+    if (rc) return fail("cmlhip_ba_window_commit", rc);
+    // every entry is live: the device numbering is the lists' own
+    mActive.resize(R); mActivePoints.resize(P); mPointSlot.resize(P);
+    for (size_t r = 0; r < R; r++) mActive[r] = (int)r;
+    for (size_t p = 0; p < P; p++) { mActivePoints[p] = (int)p; mPointSlot[p] = (int)p; }
     mPairsValid = false;                                     // (an upload forgets the pair records)
     return true;
 }
@@ -448,7 +482,7 @@ int DSOBundleAdjustment::setPairs(const std::vector<cmlhip_ba_pair>& pairs) {
     return rc;
 }
 
-bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut, bool applyToo) {   // BA.cpp:1497-1646
+bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut, bool applyToo, bool enqueueOnly) {   // BA.cpp:1497-1646
     const auto TL0 = std::chrono::steady_clock::now();
     auto lapL = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "      [linearizeAll] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TL0).count()); };
     std::vector<cmlhip_ba_pair> pairs;
@@ -474,35 +508,49 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
                                        idepthOut ? idepthOut->data() : nullptr, pointAccOut ? pointAccOut->data() : nullptr);
         if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_finish_keyframe", rc);
     } else {
+        if (applyToo && enqueueOnly) {                                              // run()'s preamble when the loop is resident: no host wait, the summary comes back with
+            rc = cmlhip_ba_linearize_apply(mCtx, nullptr);                          // cmlhip_ba_finish_run's one copy
+            if (rc) return fail("cmlhip_ba_linearize_apply", rc);
+            energy[0] = energy[1] = energy[2] = 0;
+            return true;
+        }
         rc = applyToo ? cmlhip_ba_linearize_apply(mCtx, &lr) : cmlhip_ba_linearize(mCtx, &lr);
         if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_linearize", rc);
     }
     lapL("device call done");
     energy[0] = lr.energy; energy[1] = 0; energy[2] = 0;
     mFrames.back().frameEnergyTH = lr.new_frame_energy_th;                // setNewFrameEnergyTH, :1610
-    if (fixLinearization) {
-        std::vector<int> nres(mPoints.size(), 0);
-        for (int k = 0; k < R; k++) {
-            DSOResidual& Rr = mResiduals[mActive[k]];
-            Rr.state_state = st[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
-            if (mKeepResidualEnergies) { Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k]; Rr.state_NewEnergyWithOutlier = nw[k]; }
-            else Rr.state_NewState = st[k];                                         // applyNewState: state_state = state_NewState (DSOResidual.h)
-            DSOPoint& Pp = mPoints[Rr.point];
-            for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidualState[q] = Rr.state_state;   // setResidualState, :1618-1622
-            if (Rr.isLinearized) continue;
-            if (Rr.isActiveAndIsGoodNEW) Pp.numGoodResiduals++;                     // :1592
-            else {                                                                  // toRemove, :1595-1598,1624-1638
-                Rr.alive = false;
-                mFrames[Rr.target].numResidualsOut++;                               // removeResiduals, DSOContext.h:210
-                for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidual[q] = -1;
-            }
-        }
-        for (const auto& Rr : mResiduals) if (Rr.alive) nres[Rr.point]++;
-        for (int p = 0; p < (int)mPoints.size(); p++)                               // points left without residual, :1638-1640
-            if (mPoints[p].alive && nres[p] == 0) { mPoints[p].alive = false; mOutliers.push_back(p); }
-    }
+    if (fixLinearization) closingBookkeeping(st, good, ns, e, ne, nw);
     lapL("bookkeeping done");
     return true;
+}
+
+// host bookkeeping behind linearizeAll(true), BA.cpp:1571-1640, from the arrays the device's closing pass returned (caller order = mActive)
+void DSOBundleAdjustment::closingBookkeeping(const std::vector<int>& st, const std::vector<unsigned char>& good, const std::vector<int>& ns,
+                                             const std::vector<float>& e, const std::vector<float>& ne, const std::vector<float>& nw) {
+    const int R = (int)mActive.size();
+    std::vector<int> nres(mPoints.size(), 0);
+    for (int k = 0; k < R; k++) {
+        DSOResidual& Rr = mResiduals[mActive[k]];
+        Rr.state_state = st[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
+        if (mKeepResidualEnergies) { Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k]; Rr.state_NewEnergyWithOutlier = nw[k]; }
+        else {
+            Rr.state_NewState = st[k];                                          // applyNewState: state_state = state_NewState (DSOResidual.h)
+            if (!Rr.isLinearized) Rr.state_NewEnergy = Rr.state_energy = 0;     // resetOOB of the preamble (:766-779); the energies stay on the device in this mode
+        }
+        DSOPoint& Pp = mPoints[Rr.point];
+        for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidualState[q] = Rr.state_state;   // setResidualState, :1618-1622
+        if (Rr.isLinearized) continue;
+        if (Rr.isActiveAndIsGoodNEW) Pp.numGoodResiduals++;                     // :1592
+        else {                                                                  // toRemove, :1595-1598,1624-1638
+            Rr.alive = false; mDeadSinceCompact++;
+            mFrames[Rr.target].numResidualsOut++;                               // removeResiduals, DSOContext.h:210
+            for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidual[q] = -1;
+        }
+    }
+    for (const auto& Rr : mResiduals) if (Rr.alive) nres[Rr.point]++;
+    for (int p = 0; p < (int)mPoints.size(); p++)                               // points left without residual, :1638-1640
+        if (mPoints[p].alive && nres[p] == 0) { mPoints[p].alive = false; mDeadSinceCompact++; mOutliers.push_back(p); }
 }
 
 void DSOBundleAdjustment::backupState() {                                     // BA.cpp:912-926
@@ -633,7 +681,7 @@ bool DSOBundleAdjustment::doStepFromBackup(bool fixCamera) {                  //
            std::sqrt(sumR) < 0.00005 * mThOptIterations && std::sqrt(sumT) * sumNID < 0.00005 * mThOptIterations;
 }
 
-bool DSOBundleAdjustment::runPreamble(double lastEnergy[3]) {                // BA.cpp:744-802
+bool DSOBundleAdjustment::runPreamble(double lastEnergy[3], bool enqueueOnly) {                // BA.cpp:744-802
     const auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "    [preamble] %-22s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
     mOutliers.clear();
@@ -648,9 +696,9 @@ bool DSOBundleAdjustment::runPreamble(double lastEnergy[3]) {                // 
     if (!uploadWindow()) return false;
     lap("uploadWindow");
     lastRunUs[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count();
-    if (!linearizeAll(false, lastEnergy, nullptr, nullptr, true)) return false;   // linearizeAll(false) + applyActiveRes(true), :785-790, one pass on the device
+    if (!linearizeAll(false, lastEnergy, nullptr, nullptr, true, enqueueOnly)) return false;   // linearizeAll(false) + applyActiveRes(true), :785-790, one pass on the device
     lap("linearizeAll");
-    statEnergyP.push_back(lastEnergy[0] / std::max<size_t>(1, mActive.size()));
+    if (!enqueueOnly) statEnergyP.push_back(lastEnergy[0] / std::max<size_t>(1, mActive.size()));
     return true;
 }
 
@@ -747,7 +795,7 @@ void DSOBundleAdjustment::fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double
 void DSOBundleAdjustment::removePointsWithoutResidual() {                     // DSOContext.h:218-229
     std::vector<int> nres(mPoints.size(), 0);
     for (const auto& r : mResiduals) if (r.alive) nres[r.point]++;
-    for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && nres[p] == 0) mPoints[p].alive = false;
+    for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && nres[p] == 0) { mPoints[p].alive = false; mDeadSinceCompact++; }
 }
 
 void DSOBundleAdjustment::removePoint(int p, bool marginalize, bool sweep) {  // DSOContext.h:94-111,204-215
@@ -760,14 +808,18 @@ void DSOBundleAdjustment::removePoint(int p, bool marginalize, bool sweep) {  //
         r.alive = false;
         mFrames[r.target].numResidualsOut++;
     }
-    mPoints[p].alive = false;
+    mPoints[p].alive = false; mDeadSinceCompact++;
     if (sweep) removePointsWithoutResidual();        // (callers that remove many points sweep once behind their loop: the end state is the same)
 }
 
 void DSOBundleAdjustment::removeFrame(int f) {                                // DSOContext.h:154-174
     for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && mPoints[p].host == f) removePoint(p, false, false);
-    for (auto& r : mResiduals) if (r.alive && r.target == f) { r.alive = false; mFrames[f].numResidualsOut++; }
+    for (auto& r : mResiduals) if (r.alive && r.target == f) { r.alive = false; mDeadSinceCompact++; mFrames[f].numResidualsOut++; }
     removePointsWithoutResidual();
+    mDeadSinceCompact++;                                                       // (the frame's entries carry -1 from here on: the next addNewFrame / run renumbers)
+    if (syncWindowAppends()) {                                                 // the library's copy of the window: same renumbering of the frame ids
+        if (cmlhip_ba_window_retire_frame(mCtx, f)) { cmlhip_ba_window_reset(mCtx); mWinPoints = mWinResiduals = 0; }
+    } else { cmlhip_ba_window_reset(mCtx); mWinPoints = mWinResiduals = 0; mError.clear(); }
     mFrames.erase(mFrames.begin() + f);
     for (int i = 0; i < (int)mFrames.size(); i++) mFrames[i].id = i;          // makeFrameId
     for (auto& P : mPoints) { if (P.host == f) P.host = -1; else if (P.host > f) P.host--; }
@@ -887,6 +939,7 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
             if (!isCand[Rr.point]) continue;
             Rr.state_state = st[k]; Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k];
             Rr.state_NewEnergyWithOutlier = nw[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0; Rr.isLinearized = lin[k] != 0;
+            mLinearizedAlive += lin[k] != 0;
         }
     }
     for (int p : candidates) {
@@ -1103,7 +1156,89 @@ bool DSOBundleAdjustment::endResident(double* lastEnergy) {
     return std::isfinite(last.energy);
 }
 
+// run() with the loop resident and ONE host wait: the preamble pass, the resident state, the iterations, the re-anchoring of the newest frame and the
+// closing pass are enqueued back to back; cmlhip_ba_finish_run brings everything back in one copy.  (The hybrid term reads its point Jacobians back
+// through a path of its own and an empty loop leaves no pose on the device: both take the step-by-step flow, runResidentStepwise.)
 bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
+    if (mMixedBundleAdjustment || mNumIterations < 1 || mFrames.empty() || getenv("CMLHOST_RUN_STEPWISE")) return runResidentStepwise(updatePointsOnly);
+    double lastEnergy[3];
+    const auto T0 = std::chrono::steady_clock::now();
+    auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
+    auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "  [run] %-28s %.0f us\n", what, us()); };
+    if (!runPreamble(lastEnergy, true)) return false;
+    const double t_pre = us();
+    lastRunUs[1] = t_pre - lastRunUs[0];
+    lap("preamble enqueued");
+    if (!beginResident(updatePointsOnly)) return false;
+    const double t_begin = us();
+    lastRunUs[2] = t_begin - t_pre;
+    lap("beginResident done");
+    int rc = cmlhip_ba_resident_convergence(mCtx, mThOptIterations);         // `if (canbreak && it >= 1) break`, BA.cpp:879
+    if (rc) return fail("cmlhip_ba_resident_convergence", rc);
+    if (!iterateResident(mNumIterations, mFixedLambda)) return false;
+    lastLambda = mFixedLambda;
+    const double t_enq = us();
+    lastRunUs[3] = t_enq - t_begin;
+    lap("iterations enqueued");
+    // ---- everything back in one copy
+    const int N = (int)mFrames.size(), R = (int)mActive.size();
+    double sc[4];
+    scales(sc);
+    std::vector<cmlhip_ba_frame_state> fs(N);
+    std::vector<double> pre(7 * (size_t)N), en(mNumIterations, 0.0);
+    cmlhip_ba_lin_result first{}, last{}, lr{};
+    int its = 0;
+    mX.assign(8 * (size_t)N + CMLHIP_CPARS, 0.0);
+    cmlhip_ba_resident_out ro{fs.data(), pre.data(), &first, &last, &its, en.data(), (int)en.size(), mX.data()};
+    std::vector<int> st(R), ns;
+    std::vector<float> e, ne, nw;
+    std::vector<unsigned char> good(R);
+    if (mKeepResidualEnergies) { ns.resize(R); e.resize(R); ne.resize(R); nw.resize(R); }
+    std::vector<double> idp(mActivePoints.size());
+    std::vector<float> pacc(14 * mActivePoints.size() + 14);
+    rc = cmlhip_ba_finish_run(mCtx, 1, &ro, &lr, st.data(), mKeepResidualEnergies ? ns.data() : nullptr, mKeepResidualEnergies ? e.data() : nullptr,
+                              mKeepResidualEnergies ? ne.data() : nullptr, mKeepResidualEnergies ? nw.data() : nullptr, good.data(), idp.data(), pacc.data());
+    if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_finish_run", rc);
+    const double t_end = us();
+    lastRunUs[4] = t_end - t_enq;
+    lap("finish_run returned");
+    mPairsValid = false;                                     // (the device's frame step and the re-anchoring have rewritten the pair records)
+    statEnergyP.push_back(first.energy / std::max<size_t>(1, mActive.size()));      // the preamble's entry, :792
+    for (int i = 0; i < N; i++) {                                              // the loop's frame states (endResident)
+        DSOFrame& f = mFrames[i];
+        for (int k = 0; k < 10; k++) f.step[k] = fs[i].state[k] - f.state[k];
+        f.setState(fs[i].state, sc);
+    }
+    lastIterations = its;
+    for (int i = 0; i < its && i < (int)en.size(); i++) statEnergyP.push_back(en[i]);
+    if (!std::isfinite(last.energy)) { mError = "non finite energy"; return false; }
+    // re-anchor the newest frame's evaluation point, :885-894 — at the pose the DEVICE re-anchored at (its own PRE_worldToCam of the last step)
+    DSOFrame& fb = mFrames.back();
+    double nz[10] = {0};
+    nz[6] = fb.state[6]; nz[7] = fb.state[7];
+    SE3 anchor;
+    std::memcpy(anchor.q, &pre[7 * (size_t)(N - 1)], sizeof anchor.q);
+    std::memcpy(anchor.t, &pre[7 * (size_t)(N - 1) + 4], sizeof anchor.t);
+    fb.setEvalPT(anchor, nz, sc);
+    computeAdjoints();
+    computeDelta();
+    lastEnergy[0] = lr.energy; lastEnergy[1] = lastEnergy[2] = 0;
+    fb.frameEnergyTH = lr.new_frame_energy_th;                                 // setNewFrameEnergyTH of the closing pass, :1610
+    closingBookkeeping(st, good, ns, e, ne, nw);
+    if (!std::isfinite(lastEnergy[0])) { mError = "Not finite energy"; return false; }
+    for (size_t k = 0; k < mActivePoints.size(); k++) {                        // MapPoint::setReferenceInverseDepth / setInverseDepthHessian
+        DSOPoint& P = mPoints[mActivePoints[k]];
+        P.idepth = idp[k];
+        P.idepth_zero = (float)idp[k];
+        const float hdi = pacc[14 * k + 12];
+        P.idepth_hessian = hdi > 0 ? 1.0f / hdi : 0.f;
+    }
+    lastRunUs[5] = us() - t_end;
+    lap("bookkeeping done");
+    return true;
+}
+
+bool DSOBundleAdjustment::runResidentStepwise(bool updatePointsOnly) {
     double lastEnergy[3];
     const auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "  [run] %-28s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };

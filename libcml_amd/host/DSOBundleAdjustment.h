@@ -101,6 +101,7 @@ public:
     // The same run with the iteration loop resident on the device (forceAccept + fixLambda, no early break):
     // preamble and epilogue as run(), mNumIterations x cmlhip_ba_iteration_async in between, no host round trip per iteration.
     bool runResident(bool updatePointsOnly = false);
+    bool runResidentStepwise(bool updatePointsOnly = false);                                     // the same with a host wait behind every stage (hybrid term; CMLHOST_RUN_STEPWISE=1)
     bool runHostLoop(bool updatePointsOnly = false);                                             // the literal loop: one device call per reference statement
     // pieces of runResident, for callers that keep iterating (bench): states to the device / k iterations / states back
     bool beginResident(bool updatePointsOnly = false);
@@ -158,15 +159,21 @@ private:
     int setPairs(const std::vector<cmlhip_ba_pair>& pairs);
     std::vector<cmlhip_ba_pair> mPairsSent; bool mPairsValid = false;      // the pair records the device holds for the current upload
     bool uploadWindow();
+    bool syncWindowAppends();                                                  // hands the library the points / residuals added since the last hand-over (cmlhip_ba_window_append_*)
+    size_t mWinPoints = 0, mWinResiduals = 0;                                  // how much of mPoints / mResiduals the library's window holds (index for index)
+    int mDeadSinceCompact = 0, mLinearizedAlive = 0;                           // entries dropped since the lists were renumbered; residuals that may carry isLinearized
+    std::vector<double> mDynIdepth; std::vector<float> mDynZero, mDynPrior;    // per-point values refreshed at every commit
     bool isOOB(int p, const std::vector<int>& toMarg) const;                  // BA.cpp:2515-2554
     void removePoint(int p, bool marginalize, bool sweep = true);             // DSOContext.h:94-111 (sweep: removePointsWithoutResidual behind it, :218-229)
     void compactDead();                                                       // drops dead points / residuals from the lists and renumbers (the reference's sets simply lose them)
     void removeFrame(int f);                                                  // DSOContext.h:154-174
     void removePointsWithoutResidual();
     void fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double>& prior, std::vector<double>& dprior, double cdelta[4], double cprior[4]);
-    bool runPreamble(double lastEnergy[3]);
+    bool runPreamble(double lastEnergy[3], bool enqueueOnly = false);
+    void closingBookkeeping(const std::vector<int>& st, const std::vector<unsigned char>& good, const std::vector<int>& ns,
+                            const std::vector<float>& e, const std::vector<float>& ne, const std::vector<float>& nw);
     bool runEpilogue(double lastEnergy[3]);
-    bool linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut = nullptr, std::vector<float>* pointAccOut = nullptr, bool applyToo = false);
+    bool linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut = nullptr, std::vector<float>* pointAccOut = nullptr, bool applyToo = false, bool enqueueOnly = false);
     bool solveSystem(int iteration, double lambda);
     bool doStepFromBackup(bool fixCamera);
     void backupState();
