@@ -281,6 +281,12 @@ int cmlhip_ba_window_compact(cmlhip_ctx* ctx, int n_points, const unsigned char*
 int cmlhip_ba_window_counts(cmlhip_ctx* ctx, int* P, int* R);      /* entries the library holds (committed or not) */
 int cmlhip_ba_window_commit(cmlhip_ctx* ctx, int N, const cmlhip_ba_frame* frames, const double* idepth, const float* idepth_zero,
                             const float* prior, int reset_states, int n_lin, const int* lin_residuals, const int* lin_states);
+/* Upload scope: between begin and end the host-to-device copies of cmlhip_ba_set_params, cmlhip_ba_window_commit, cmlhip_ba_set_pairs,
+ * cmlhip_ba_set_arithmetic, cmlhip_ba_set_resident_state / _prior / _indirect (M = 0) and cmlhip_ba_resident_convergence are collected and leave as ONE
+ * packed block when the scope ends (the few kernels those calls launch behind their own copies run then, in call order) — the preamble of BA::run
+ * (BA.cpp:744-802) as one transfer instead of four.  Any OTHER call on the context ends the scope first; ending a scope that is not open is a no-op. */
+int cmlhip_upload_scope_begin(cmlhip_ctx* ctx);
+int cmlhip_upload_scope_end(cmlhip_ctx* ctx);
 /* sizes of the uploaded window (N frames, P points, R residuals) */
 int cmlhip_ba_window_size(cmlhip_ctx* ctx, int* N, int* P, int* R);
 /* per-iteration state: N*N pair transforms + frame thresholds (ba_update_state) */
@@ -311,7 +317,8 @@ int cmlhip_ba_linearize(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);
 int cmlhip_ba_apply(cmlhip_ctx* ctx, int copy_jacobians);
 /* cmlhip_ba_linearize followed by cmlhip_ba_apply(ctx, 1) as ONE pass over the residuals (the preamble of BA::run, BA.cpp:785-790: linearizeAll(false),
  * then applyRes(r, true) of every residual with nothing in between).  Same results as the two calls. */
-int cmlhip_ba_linearize_apply(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);   /* out == NULL: enqueue only (no host wait); the summary is kept for cmlhip_ba_finish_run */
+int cmlhip_ba_linearize_apply(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);   /* out == NULL: enqueue only (no host wait); the pass's tail (energy sum, new threshold) rides in
+                                                                               * the next resident iteration's solve launch, its energy comes back as cmlhip_ba_finish_run's `first` */
 /* The tail of DSOBundleAdjustment::run in one call and ONE readback: linearizeAll(true) (BA.cpp:896 = linearize + applyRes(true),
  * :1551-1569) followed by everything the host writes back afterwards — residual states / energies (:1571-1640), the points'
  * inverse depths and the per-point accumulators (HdiF -> setInverseDepthHessian, :1889-1901).  pairs must be current.

@@ -17,6 +17,12 @@ static int ba_check(cmlhip_ctx* c, bool need_pairs) {
     return CMLHIP_OK;
 }
 
+// a launch that reads what the caller has just staged: inside an upload scope (cmlhip_upload_scope_begin) it waits for the scope's one packed copy
+template <class F> static int cml_defer(cmlhip_ctx* c, F&& f) {
+    if (c->h2d_scope) { c->deferred.emplace_back(std::forward<F>(f)); return CMLHIP_OK; }
+    return f();
+}
+
 int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
     const cmlhip_ba_params& p = c->ba_prm;
     A.N = c->N; A.P = c->P; A.R = c->R; A.w = p.w; A.h = p.h; A.opt_a = p.optimize_a; A.opt_b = p.optimize_b; A.n = 8 * c->N + 4;
@@ -93,41 +99,42 @@ struct ResRead {
 // and every byte of the block is ahead of the run's first kernel)
 struct ExpandArgs {
     int R, P, N, pt_stride, pair_stride;
-    const int* r_point; const int* r_target; const unsigned char* r_lin; const int* pt_host;
-    const float* pt_x; const float* pt_y; const float* pt_colors; const float* pt_weights;
-    const int* by_point_off; const int* by_point; const int* by_pair_off;
-    int* r_host; int* r_new_state; int* by_pair; int* pair_pos;
+    // caller order (the library's window shadows, copied as they are) + the two positions the host's counting pass assigned
+    const int* c_point; const int* c_target; const int* c_state; const unsigned char* c_lin; const int* c_dev_of; const int* c_bpos;
+    const int* pt_host; const float* pt_x; const float* pt_y; const float* pt_colors; const float* pt_weights;
+    const int* by_point_off; const int* by_pair_off;
+    // device order
+    int* r_point; int* r_target; int* r_state; unsigned char* r_lin; int* r_host; int* r_new_state; int* by_pair; int* pair_pos; int* by_point;
     float* r_px; float* r_py; float* r_colors; float* r_weights;
     int* point_tgt; int* point_pos; int* point_res;
 };
+// one thread per residual of the CALLER's list: r' = c_dev_of[r] is its place in the pair-sorted device order, c_bpos[r] its place in the by-point
+// lists; every R-length device array, the per-residual copies of the point's static inputs and the point-slot tables are written from here
 __global__ void k_window_expand(ExpandArgs E) {
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = i0; i < E.R; i += gridDim.x * blockDim.x) {     // per residual (device order = pair-sorted)
-        const int p = E.r_point[i], host = E.pt_host[p], q = host + E.r_target[i] * E.N;
-        E.r_host[i] = host;
-        E.r_new_state[i] = CMLHIP_RES_OUTLIER;
-        E.by_pair[i] = i;
-        E.pair_pos[i] = q * E.pair_stride + (i - E.by_pair_off[q]);
-        E.r_px[i] = E.pt_x[p]; E.r_py[i] = E.pt_y[p];
+    for (int r = i0; r < E.R; r += gridDim.x * blockDim.x) {
+        const int k = E.c_dev_of[r], p = E.c_point[r], t = E.c_target[r], host = E.pt_host[p], q = host + t * E.N, lin = E.c_lin[r];
+        E.r_point[k] = p; E.r_target[k] = t; E.r_state[k] = E.c_state[r]; E.r_lin[k] = (unsigned char)lin;
+        E.r_host[k] = host;
+        E.r_new_state[k] = CMLHIP_RES_OUTLIER;
+        E.by_pair[k] = k;
+        E.pair_pos[k] = q * E.pair_stride + (k - E.by_pair_off[q]);
+        E.r_px[k] = E.pt_x[p]; E.r_py[k] = E.pt_y[p];
         const float4* c4 = reinterpret_cast<const float4*>(E.pt_colors + 8 * (size_t)p); const float4* w4 = reinterpret_cast<const float4*>(E.pt_weights + 8 * (size_t)p);
-        float4* oc = reinterpret_cast<float4*>(E.r_colors + 8 * (size_t)i); float4* ow = reinterpret_cast<float4*>(E.r_weights + 8 * (size_t)i);
+        float4* oc = reinterpret_cast<float4*>(E.r_colors + 8 * (size_t)k); float4* ow = reinterpret_cast<float4*>(E.r_weights + 8 * (size_t)k);
         oc[0] = c4[0]; oc[1] = c4[1]; ow[0] = w4[0]; ow[1] = w4[1];
-    }
-    const int slots = E.P * E.pt_stride;
-    for (int s = i0; s < slots; s += gridDim.x * blockDim.x) {   // per point slot: the residual in it (device id), its target | lin << 8
-        const int p = s / E.pt_stride, j = s - p * E.pt_stride, o = E.by_point_off[p];
-        if (j < E.by_point_off[p + 1] - o) {
-            const int r = E.by_point[o + j];
-            E.point_res[s] = r;
-            E.point_tgt[s] = E.r_target[r] | (E.r_lin[r] ? 256 : 0);
-            E.point_pos[r] = s;
-        }
+        const int jb = E.c_bpos[r];                              // device lists hold r'; a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
+        E.by_point[jb] = k;
+        const int s_ = p * E.pt_stride + (jb - E.by_point_off[p]);   // the point's slot table: the residual in the slot (device id), its target | lin << 8
+        E.point_res[s_] = k;
+        E.point_tgt[s_] = t | (lin ? 256 : 0);
+        E.point_pos[k] = s_;
     }
 }
 
 extern "C" {
 
-int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) { CML_DEV(c);
+int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) { CML_DEV_SCOPED(c);
     if (!c || !prm) return CMLHIP_ERR_INVALID;
     CML_REQUIRE(c, prm->w > 4 && prm->h > 4 && prm->fx != 0 && prm->fy != 0, CMLHIP_ERR_INVALID, "bad BA params");
     c->ba_prm = *prm;
@@ -144,7 +151,7 @@ int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) { CML_DEV(c
 // cmlhip_ba_upload_window is reset + append + commit: one code path, a window built by edits is the window a fresh upload builds.
 static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames);
 
-int cmlhip_ba_window_reset(cmlhip_ctx* c) { CML_DEV(c);
+int cmlhip_ba_window_reset(cmlhip_ctx* c) { CML_DEV_SCOPED(c);
     if (!c) return CMLHIP_ERR_INVALID;
     WindowShadow& W = c->win;
     W.x.clear(); W.y.clear(); W.idz.clear(); W.prior.clear(); W.colors.clear(); W.weights.clear(); W.idepth.clear(); W.host.clear();
@@ -152,7 +159,7 @@ int cmlhip_ba_window_reset(cmlhip_ctx* c) { CML_DEV(c);
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_window_append_points(cmlhip_ctx* c, int n, const cmlhip_ba_point* pts) { CML_DEV(c);
+int cmlhip_ba_window_append_points(cmlhip_ctx* c, int n, const cmlhip_ba_point* pts) { CML_DEV_SCOPED(c);
     if (!c || n < 0 || (n > 0 && !pts)) return CMLHIP_ERR_INVALID;
     WindowShadow& W = c->win;
     const size_t P0 = W.host.size();
@@ -168,7 +175,7 @@ int cmlhip_ba_window_append_points(cmlhip_ctx* c, int n, const cmlhip_ba_point* 
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_window_append_residuals(cmlhip_ctx* c, int n, const cmlhip_ba_residual* res) { CML_DEV(c);
+int cmlhip_ba_window_append_residuals(cmlhip_ctx* c, int n, const cmlhip_ba_residual* res) { CML_DEV_SCOPED(c);
     if (!c || n < 0 || (n > 0 && !res)) return CMLHIP_ERR_INVALID;
     WindowShadow& W = c->win;
     const size_t R0 = W.rpoint.size(), P = W.host.size();
@@ -181,7 +188,7 @@ int cmlhip_ba_window_append_residuals(cmlhip_ctx* c, int n, const cmlhip_ba_resi
 
 // removeFrame's renumbering (DSOContext.h:154-174 + makeFrameId): ids above `frame` move down by one; whatever still names the frame itself gets -1
 // (the caller drops those entries with the next cmlhip_ba_window_compact, as the reference's sets lose them)
-int cmlhip_ba_window_retire_frame(cmlhip_ctx* c, int frame) { CML_DEV(c);
+int cmlhip_ba_window_retire_frame(cmlhip_ctx* c, int frame) { CML_DEV_SCOPED(c);
     if (!c || frame < 0) return CMLHIP_ERR_INVALID;
     WindowShadow& W = c->win;
     for (int& h : W.host) { if (h == frame) h = -1; else if (h > frame) h--; }
@@ -191,7 +198,7 @@ int cmlhip_ba_window_retire_frame(cmlhip_ctx* c, int frame) { CML_DEV(c);
 
 // the survivors keep their order and are renumbered by rank (points AND residuals; a residual's point index follows); a residual that survives
 // must name a surviving point
-int cmlhip_ba_window_compact(cmlhip_ctx* c, int n_points, const unsigned char* point_alive, int n_res, const unsigned char* res_alive) { CML_DEV(c);
+int cmlhip_ba_window_compact(cmlhip_ctx* c, int n_points, const unsigned char* point_alive, int n_res, const unsigned char* res_alive) { CML_DEV_SCOPED(c);
     if (!c || (n_points > 0 && !point_alive) || (n_res > 0 && !res_alive)) return CMLHIP_ERR_INVALID;
     WindowShadow& W = c->win;
     CML_REQUIRE(c, (size_t)n_points == W.host.size() && (size_t)n_res == W.rpoint.size(), CMLHIP_ERR_STATE, "cmlhip_ba_window_compact: the caller's lists and the window differ in length");
@@ -221,7 +228,7 @@ int cmlhip_ba_window_compact(cmlhip_ctx* c, int n_points, const unsigned char* p
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_window_counts(cmlhip_ctx* c, int* P, int* R) { CML_DEV(c);
+int cmlhip_ba_window_counts(cmlhip_ctx* c, int* P, int* R) { CML_DEV_SCOPED(c);
     if (!c) return CMLHIP_ERR_INVALID;
     if (P) *P = (int)c->win.host.size();
     if (R) *R = (int)c->win.rpoint.size();
@@ -229,7 +236,7 @@ int cmlhip_ba_window_counts(cmlhip_ctx* c, int* P, int* R) { CML_DEV(c);
 }
 
 int cmlhip_ba_window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames, const double* idepth, const float* idepth_zero, const float* prior,
-                            int reset_states, int n_lin, const int* lin_residuals, const int* lin_states) { CML_DEV(c);
+                            int reset_states, int n_lin, const int* lin_residuals, const int* lin_states) { CML_DEV_SCOPED(c);
     if (!c || !frames || n_lin < 0 || (n_lin > 0 && (!lin_residuals || !lin_states))) return CMLHIP_ERR_INVALID;
     WindowShadow& W = c->win;
     const size_t P = W.host.size(), R = W.rpoint.size();
@@ -377,7 +384,7 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     lap_("counts+ensure");
     // ---- SoA staging + upload: everything below is staged and leaves in ONE copy + one scatter / fill kernel (cml_h2d_batch_flush)
     cml_h2d_batch_begin(c);
-    struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};   // error returns close the batch
+    struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching && !c->h2d_scope) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};   // error returns close the batch
     // the device-order arrays are written where the packed copy starts from (cml_h2d_stage); the vectors exist only when the ring has no room
     struct Staged { void* p = nullptr; std::vector<unsigned char> fb; void* dst = nullptr; size_t bytes = 0; };
     auto stage = [&](Staged& s, DevBuf& buf, size_t bytes) -> void* {
@@ -395,29 +402,34 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     //      by-point lists and the new-frame list hold r'; the ABI keeps the caller's numbering (inputs are permuted here, readbacks
     //      are permuted back, cmlhip_ba_get_index_maps reports the caller-order maps).  Residuals of one pair are contiguous on the
     //      device, so the residual kernel of the resident loop reads the pair record through scalar loads.
-    c->h_by_point.resize(R); c->h_by_pair.resize(R); c->h_dev_of.resize(R); c->h_caller_of.resize(R);
+    //      The host only ASSIGNS the two positions of every residual (sequential writes); the permutation itself runs on the device (k_window_expand).
+    c->h_dev_of.resize(R); c->h_maps_valid = false;
+    if ((rc = cml_ensure(c, c->c_point, 4 * (size_t)R))) return rc;
+    if ((rc = cml_ensure(c, c->c_target, 4 * (size_t)R))) return rc;
+    if ((rc = cml_ensure(c, c->c_state, 4 * (size_t)R))) return rc;
+    if ((rc = cml_ensure(c, c->c_lin, (size_t)R))) return rc;
+    if ((rc = cml_ensure(c, c->c_dev_of, 4 * (size_t)R))) return rc;
+    if ((rc = cml_ensure(c, c->c_bpos, 4 * (size_t)R))) return rc;
     {
-        Staged s_rp, s_rt, s_rs, s_rl, s_bp, s_nf;
-        int* rpd = (int*)stage(s_rp, c->r_point, 4 * (size_t)R); int* rtd = (int*)stage(s_rt, c->r_target, 4 * (size_t)R);
-        int* rsd = (int*)stage(s_rs, c->r_state, 4 * (size_t)R); unsigned char* rld = (unsigned char*)stage(s_rl, c->r_lin, (size_t)R);
-        int* bpd = (int*)stage(s_bp, c->by_point, 4 * (size_t)R); int* nfd = (int*)stage(s_nf, c->newframe_res, 4 * (size_t)n_newframe);
+        Staged s_dv, s_bp, s_nf;
+        int* dvd = (int*)stage(s_dv, c->c_dev_of, 4 * (size_t)R); int* bpd = (int*)stage(s_bp, c->c_bpos, 4 * (size_t)R);
+        int* nfd = (int*)stage(s_nf, c->newframe_res, 4 * (size_t)n_newframe);
         c->w_cnt_p.assign(P, 0); c->w_cnt_q.assign(NN, 0);
         int* c1 = c->w_cnt_p.data(); int* c2 = c->w_cnt_q.data();
-        const int* rp = W.rpoint.data(); const int* rt = W.rtarget.data(); const int* rs = W.rstate.data(); const unsigned char* rl = W.rlin.data();
+        const int* rp = W.rpoint.data(); const int* rt = W.rtarget.data();
         const int* pair_of = c->h_pair_of.data(); const int* opt = c->h_by_point_off.data(); const int* oq = c->h_by_pair_off.data();
-        int* by_point = c->h_by_point.data(); int* by_pair = c->h_by_pair.data(); int* dev_of = c->h_dev_of.data(); int* caller_of = c->h_caller_of.data();
+        int* dev_of = c->h_dev_of.data();
         int nf = 0;
         for (int r = 0; r < R; r++) {
-            const int p = rp[r], q = pair_of[r], t = rt[r];
+            const int p = rp[r], q = pair_of[r];
             const int k = oq[q] + c2[q]++;                   // device id
-            const int j = opt[p] + c1[p]++;                  // a point's residuals stay in the caller's list order (BA.cpp:1469-1479 walks them in that order)
-            by_pair[k] = r; caller_of[k] = r; dev_of[r] = k; by_point[j] = r;
-            rpd[k] = p; rtd[k] = t; rsd[k] = rs[r]; rld[k] = rl[r];
-            bpd[j] = k;                                      // device lists hold r'
-            if (t == N - 1) nfd[nf++] = k;
+            dev_of[r] = k; dvd[r] = k;
+            bpd[r] = opt[p] + c1[p]++;
+            if (rt[r] == N - 1) nfd[nf++] = k;
         }
-        for (Staged* s : {&s_rp, &s_rt, &s_rs, &s_rl, &s_bp, &s_nf}) if ((rc = commit(*s))) return rc;
+        for (Staged* s : {&s_dv, &s_bp, &s_nf}) if ((rc = commit(*s))) return rc;
     }
+    UPS(c->c_point, W.rpoint); UPS(c->c_target, W.rtarget); UPS(c->c_state, W.rstate); UPS(c->c_lin, W.rlin);
 #define UP(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
     UP(c->frames, fd);
     UP(c->by_point_off, c->h_by_point_off);
@@ -458,15 +470,19 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     if (R > 0) {
         ExpandArgs E;
         E.R = R; E.P = P; E.N = N; E.pt_stride = c->pt_stride; E.pair_stride = c->pair_stride;
-        E.r_point = c->r_point.as<int>(); E.r_target = c->r_target.as<int>(); E.r_lin = c->r_lin.as<unsigned char>(); E.pt_host = c->pt_host.as<int>();
-        E.pt_x = c->pt_x.as<float>(); E.pt_y = c->pt_y.as<float>(); E.pt_colors = c->pt_colors.as<float>(); E.pt_weights = c->pt_weights.as<float>();
-        E.by_point_off = c->by_point_off.as<int>(); E.by_point = c->by_point.as<int>(); E.by_pair_off = c->by_pair_off.as<int>();
-        E.r_host = c->r_host.as<int>(); E.r_new_state = c->r_new_state.as<int>(); E.by_pair = c->by_pair.as<int>(); E.pair_pos = c->pair_pos.as<int>();
+        E.c_point = c->c_point.as<int>(); E.c_target = c->c_target.as<int>(); E.c_state = c->c_state.as<int>(); E.c_lin = c->c_lin.as<unsigned char>();
+        E.c_dev_of = c->c_dev_of.as<int>(); E.c_bpos = c->c_bpos.as<int>();
+        E.pt_host = c->pt_host.as<int>(); E.pt_x = c->pt_x.as<float>(); E.pt_y = c->pt_y.as<float>(); E.pt_colors = c->pt_colors.as<float>(); E.pt_weights = c->pt_weights.as<float>();
+        E.by_point_off = c->by_point_off.as<int>(); E.by_pair_off = c->by_pair_off.as<int>();
+        E.r_point = c->r_point.as<int>(); E.r_target = c->r_target.as<int>(); E.r_state = c->r_state.as<int>(); E.r_lin = c->r_lin.as<unsigned char>();
+        E.r_host = c->r_host.as<int>(); E.r_new_state = c->r_new_state.as<int>(); E.by_pair = c->by_pair.as<int>(); E.pair_pos = c->pair_pos.as<int>(); E.by_point = c->by_point.as<int>();
         E.r_px = c->r_px.as<float>(); E.r_py = c->r_py.as<float>(); E.r_colors = c->r_colors.as<float>(); E.r_weights = c->r_weights.as<float>();
         E.point_tgt = c->point_tgt.as<int>(); E.point_pos = c->point_pos.as<int>(); E.point_res = c->point_res.as<int>();
-        const int work = std::max(R, P * c->pt_stride);
-        k_window_expand<<<cml_div_up(std::min(work, 1 << 20), 256), 256, 0, c->stream>>>(E);
-        CML_CHECK(c, hipGetLastError());
+        const int work = R;
+        if ((rc = cml_defer(c, [c, E, work]() -> int {
+                k_window_expand<<<cml_div_up(std::min(work, 1 << 20), 256), 256, 0, c->stream>>>(E);
+                CML_CHECK(c, hipGetLastError());
+                return CMLHIP_OK; }))) return rc;
     }
     lap_("flushed");
     c->ba_uploaded = true;
@@ -485,9 +501,10 @@ int cmlhip_ba_window_size(cmlhip_ctx* c, int* N, int* P, int* R) { CML_DEV(c);
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) { CML_DEV(c);
+int cmlhip_ba_set_pairs(cmlhip_ctx* c, const cmlhip_ba_pair* pairs) { CML_DEV_SCOPED(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
+    if (c->h2d_scope && c->efs_in_partials && (rc = cml_scope_end(c))) return rc;      // (records to re-create: a launch)
     if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!pairs) return CMLHIP_ERR_INVALID;
     rc = cml_h2d(c, c->pairs.p, pairs, sizeof(cmlhip_ba_pair) * c->N * c->N);
@@ -507,7 +524,7 @@ int cmlhip_ba_set_frame_energy_th(cmlhip_ctx* c, const float* th) { CML_DEV(c);
     return cml_h2d(c, c->frames.p, fd.data(), sizeof(FrameDev) * c->N);
 }
 
-int cmlhip_ba_set_arithmetic(cmlhip_ctx* c, int mode) { CML_DEV(c);
+int cmlhip_ba_set_arithmetic(cmlhip_ctx* c, int mode) { CML_DEV_SCOPED(c);
     if (!c || (mode != CMLHIP_ARITH_EXACT && mode != CMLHIP_ARITH_RELAXED)) return CMLHIP_ERR_INVALID;
     c->arith_relaxed = mode == CMLHIP_ARITH_RELAXED;
     return CMLHIP_OK;
@@ -584,12 +601,13 @@ int cmlhip_ba_linearize_apply(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DE
         c->arith_relaxed = relaxed;
         c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
     } else cml_launch_linearize(c, A);
-    cml_launch_lin_finish(c, A);
-    CML_CHECK(c, hipGetLastError());
-    if (!out) {                                             // enqueue only: the summary is kept beside the live one and comes back with cmlhip_ba_finish_run's one copy
-        CML_CHECK(c, hipMemcpyAsync(c->scal.as<char>() + CML_PRE_OFFSET, c->scal.p, sizeof(LinSummary), hipMemcpyDeviceToDevice, c->stream));
+    if (!out) {                                             // enqueue only: the pass's tail (energy sum, setNewFrameEnergyTH) stays pending — it rides in the next
+        c->lin_finish_pending = true;                       // iteration's solve launch like every later pass's (its energy is logged as ResidentCtl::energy0 when
+        CML_CHECK(c, hipGetLastError());                    // cmlhip_ba_resident_convergence armed the log), or runs when a getter / cmlhip_ba_finish_run asks
         return CMLHIP_OK;
     }
+    cml_launch_lin_finish(c, A);
+    CML_CHECK(c, hipGetLastError());
     LinSummary S;
     if ((rc = cml_d2h(c, &S, c->scal.p, sizeof S))) return rc;
     out->energy = S.energy; out->n_in = S.n_in; out->n_oob = S.n_oob; out->n_outlier = S.n_outlier; out->new_frame_energy_th = S.new_frame_energy_th;
@@ -652,12 +670,13 @@ int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* sta
 // follows state_zero (DSOFrame.h:197-199).  Saves run() the host round trip (frame states back, pairs + b0 down) ahead of the closing pass.
 // The host mirror adopts the same evaluation point from the pose read back (pre_w2c).
 __global__ void k_ba_reanchor_newest(cmlhip_ba_frame_state* __restrict__ fs, const double* __restrict__ pre_w2c, cmlhip_ba_pair* __restrict__ pairs,
-                                     FrameDev* __restrict__ frames, int N, double scale_b) {
+                                     FrameDev* __restrict__ frames, int N, double scale_b, cmlhip_ba_frame_state* __restrict__ snap) {
     using cml_amd::SE3;
     __shared__ double s_ev[CMLHIP_MAX_FRAMES][7];
     const int tid = threadIdx.x, f = N - 1;
     if (tid < N) {
         cmlhip_ba_frame_state& S = fs[tid];
+        snap[tid] = S;                                       // the loop's result, as the host reads it back (the edit below is the run's epilogue)
         if (tid == f) {
             for (int k = 0; k < 4; k++) { S.eval_q[k] = pre_w2c[7 * f + k]; s_ev[f][k] = S.eval_q[k]; }
             for (int k = 0; k < 3; k++) { S.eval_t[k] = pre_w2c[7 * f + 4 + k]; s_ev[f][4 + k] = S.eval_t[k]; }
@@ -703,32 +722,29 @@ int cmlhip_ba_finish_run(cmlhip_ctx* c, int reanchor_newest, const cmlhip_ba_res
         A.ctl = nullptr;
     }
     const size_t N = c->N, n = 8 * N + 4, R = c->R, P = c->P;
-    // the loop's results are snapshotted on the device (the closing pass overwrites the summary; the re-anchoring the frame states)
-    const size_t snap_bytes = sizeof(LinSummary) + sizeof(cmlhip_ba_frame_state) * N;
-    if ((rc = cml_ensure(c, c->run_snap, snap_bytes))) return rc;
-    CML_CHECK(c, hipMemcpyAsync(c->run_snap.p, c->scal.p, sizeof(LinSummary), hipMemcpyDeviceToDevice, c->stream));
-    CML_CHECK(c, hipMemcpyAsync(c->run_snap.as<char>() + sizeof(LinSummary), c->frame_state.p, sizeof(cmlhip_ba_frame_state) * N, hipMemcpyDeviceToDevice, c->stream));
+    // (the loop's last summary stays at offset 0 of the scalar scratch: the closing pass writes its own slot; the frame states of the loop are kept by
+    //  the re-anchoring kernel before it edits them)
+    if ((rc = cml_ensure(c, c->run_snap, sizeof(cmlhip_ba_frame_state) * N))) return rc;
     if ((rc = cml_materialize_records(c))) return rc;        // (with the loop's own pair records, as cmlhip_ba_set_pairs does ahead of a new set)
     if (reanchor_newest) {
         k_ba_reanchor_newest<<<1, 64, 0, c->stream>>>(c->frame_state.as<cmlhip_ba_frame_state>(), c->pre_w2c.as<double>(), c->pairs.as<cmlhip_ba_pair>(),
-                                                        c->frames.as<FrameDev>(), (int)N, c->res_scales[3]);
+                                                        c->frames.as<FrameDev>(), (int)N, c->res_scales[3], c->run_snap.as<cmlhip_ba_frame_state>());
         CML_CHECK(c, hipGetLastError());
     }
     A.fuse_apply = 1;
     cml_launch_linearize(c, A);
-    cml_launch_lin_finish(c, A);
+    cml_launch_lin_finish(c, A, CML_CLOSE_OFFSET);
     CML_CHECK(c, hipGetLastError());
     LinSummary S, Sfirst, Slast;
     ResidentCtl ctl;
     std::vector<float> pacc(point_acc ? PT_ACC_STRIDE * P : 0);
     ResRead rr(c);
     cml_d2h_batch_begin(c);
-    cml_d2h(c, &S, c->scal.p, sizeof S);
+    cml_d2h(c, &S, c->scal.as<char>() + CML_CLOSE_OFFSET, sizeof S);
     if (ro) {
-        cml_d2h(c, &Sfirst, c->scal.as<char>() + CML_PRE_OFFSET, sizeof Sfirst);
-        cml_d2h(c, &Slast, c->run_snap.p, sizeof Slast);
+        cml_d2h(c, &Slast, c->scal.p, sizeof Slast);
         cml_d2h(c, &ctl, c->scal.as<char>() + CML_CTL_OFFSET, sizeof ctl);
-        if (ro->frames) cml_d2h(c, ro->frames, c->run_snap.as<char>() + sizeof(LinSummary), sizeof(cmlhip_ba_frame_state) * N);
+        if (ro->frames) cml_d2h(c, ro->frames, reanchor_newest ? c->run_snap.p : c->frame_state.p, sizeof(cmlhip_ba_frame_state) * N);
         if (ro->pre_w2c) cml_d2h(c, ro->pre_w2c, c->pre_w2c.p, 8 * 7 * N);
         if (ro->x) cml_d2h(c, ro->x, c->xvec.p, 8 * n);
     }
@@ -742,6 +758,7 @@ int cmlhip_ba_finish_run(cmlhip_ctx* c, int reanchor_newest, const cmlhip_ba_res
     auto put = [](cmlhip_ba_lin_result* o, const LinSummary& s) { if (o) { o->energy = s.energy; o->n_in = s.n_in; o->n_oob = s.n_oob; o->n_outlier = s.n_outlier; o->new_frame_energy_th = s.new_frame_energy_th; } };
     put(lin, S);
     if (ro) {
+        memset(&Sfirst, 0, sizeof Sfirst); Sfirst.energy = ctl.energy0;      // the preamble's tail rode in the first solve launch: its energy is in the log
         put(ro->first, Sfirst); put(ro->last, Slast);
         const int nit = c->conv_on ? ctl.iters_done : c->resident_iter;
         if (ro->iterations) *ro->iterations = nit;
@@ -1038,7 +1055,7 @@ int cmlhip_ba_get_res_to_zero(cmlhip_ctx* c, float* rtz, unsigned char* is_lin) 
 }
 
 int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, const cmlhip_ba_frame_state* frames, const double scales[4],
-                                 const double* nullspace_basis) { CML_DEV(c);
+                                 const double* nullspace_basis) { CML_DEV_SCOPED(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || !frames || !scales)
@@ -1048,7 +1065,7 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, co
     if ((rc = cml_ensure(c, c->pre_w2c, 8 * 7 * (size_t)N))) return rc;
     if (nullspace_basis && (rc = cml_ensure(c, c->null_basis, 8 * 7 * (size_t)n))) return rc;
     cml_h2d_batch_begin(c);                                              // adjoints, deltas, priors, frame states, gauge basis: one copy
-    struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};
+    struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching && !c->h2d_scope) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};
     if ((rc = upload_accum_in(c, in))) return rc;
     if ((rc = cml_h2d(c, c->frame_state.p, frames, sizeof(cmlhip_ba_frame_state) * (size_t)N))) return rc;
     if ((rc = cml_zero(c, c->pre_w2c.p, 8 * 7 * (size_t)N))) return rc;
@@ -1068,7 +1085,7 @@ __global__ void k_ba_prior_rhs(const cmlhip_ba_frame_state* __restrict__ fs, int
     frame_prior_rhs(F, s_delta);
 }
 
-int cmlhip_ba_set_resident_prior(cmlhip_ctx* c, const double* HM, const double* bM) { CML_DEV(c);
+int cmlhip_ba_set_resident_prior(cmlhip_ctx* c, const double* HM, const double* bM) { CML_DEV_SCOPED(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
     CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
@@ -1079,20 +1096,23 @@ int cmlhip_ba_set_resident_prior(cmlhip_ctx* c, const double* HM, const double* 
     if ((rc = cml_h2d(c, c->bM_raw.p, bM, 8 * n))) return rc;
     FrameStepArgs F = {};
     F.n = (int)n; F.HM = c->HM.as<double>(); F.bM_raw = c->bM_raw.as<double>(); F.bM_top = c->bM.as<double>();
-    k_ba_prior_rhs<<<1, 128, 0, c->stream>>>(c->frame_state.as<cmlhip_ba_frame_state>(), c->N, F);
-    CML_CHECK(c, hipGetLastError());
+    if ((rc = cml_defer(c, [c, F]() -> int {
+            k_ba_prior_rhs<<<1, 128, 0, c->stream>>>(c->frame_state.as<cmlhip_ba_frame_state>(), c->N, F);
+            CML_CHECK(c, hipGetLastError());
+            return CMLHIP_OK; }))) return rc;
     c->resident_prior = true;
     return CMLHIP_OK;
 }
 
-int cmlhip_ba_resident_convergence(cmlhip_ctx* c, double th_opt_iterations) { CML_DEV(c);
+int cmlhip_ba_resident_convergence(cmlhip_ctx* c, double th_opt_iterations) { CML_DEV_SCOPED(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
     CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
     c->conv_th = th_opt_iterations > 0 ? th_opt_iterations : 0.0;     // 0: the test can never pass, the log is still kept
     c->conv_on = true;
-    CML_CHECK(c, hipMemsetAsync(c->scal.as<char>() + CML_CTL_OFFSET, 0, sizeof(ResidentCtl), c->stream));
-    return CMLHIP_OK;
+    return cml_defer(c, [c]() -> int {
+        CML_CHECK(c, hipMemsetAsync(c->scal.as<char>() + CML_CTL_OFFSET, 0, sizeof(ResidentCtl), c->stream));
+        return CMLHIP_OK; });
 }
 
 int cmlhip_ba_get_resident_log(cmlhip_ctx* c, int* iterations, double* energies, int capacity) { CML_DEV(c);
@@ -1290,11 +1310,22 @@ int cmlhip_ba_get_pair_acc(cmlhip_ctx* c, int mode, float* out) { CML_DEV(c);
 int cmlhip_ba_get_index_maps(cmlhip_ctx* c, int* pair_of, int* bpo, int* bp, int* bqo, int* bq) { CML_DEV(c);
     int rc = ba_check(c, false);
     if (rc) return rc;
-    if (pair_of) memcpy(pair_of, c->h_pair_of.data(), 4 * (size_t)c->R);
+    const size_t R = (size_t)c->R;
+    if (pair_of) memcpy(pair_of, c->h_pair_of.data(), 4 * R);
     if (bpo) memcpy(bpo, c->h_by_point_off.data(), 4 * (size_t)(c->P + 1));
-    if (bp) memcpy(bp, c->h_by_point.data(), 4 * (size_t)c->R);
     if (bqo) memcpy(bqo, c->h_by_pair_off.data(), 4 * (size_t)(c->N * c->N + 1));
-    if (bq) memcpy(bq, c->h_by_pair.data(), 4 * (size_t)c->R);
+    if ((bp || bq) && R) {
+        // the lists as the DEVICE holds them (k_window_expand wrote them), translated back to the caller's numbering
+        std::vector<int> caller_of(R), dbp(R), dbq(R);
+        for (size_t r = 0; r < R; r++) caller_of[(size_t)c->h_dev_of[r]] = (int)r;
+        if ((rc = cml_d2h(c, dbp.data(), c->by_point.p, 4 * R))) return rc;
+        if ((rc = cml_d2h(c, dbq.data(), c->by_pair.p, 4 * R))) return rc;
+        for (size_t i = 0; i < R; i++) {
+            if ((unsigned)dbp[i] >= R || (unsigned)dbq[i] >= R) { c->err = "cmlhip_ba_get_index_maps: a device list entry is out of range"; return CMLHIP_ERR_STATE; }
+            if (bp) bp[i] = caller_of[(size_t)dbp[i]];
+            if (bq) bq[i] = caller_of[(size_t)dbq[i]];
+        }
+    }
     return CMLHIP_OK;
 }
 

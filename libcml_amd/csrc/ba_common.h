@@ -45,9 +45,10 @@ struct ResidentCtl {
                               // the residual pass which detects convergence still runs to completion in every workgroup
     int pad;
     double energy[40];        // photometric energy after iteration i (statEnergyP)
+    double energy0;           // ... and of the pass AHEAD of the first iteration (run()'s preamble), when its tail rides in the first solve launch
 };
 #define CML_CTL_OFFSET 640
-#define CML_PRE_OFFSET 128              // copy of the LinSummary of run()'s preamble pass (cmlhip_ba_linearize_apply with out == NULL), read back by cmlhip_ba_finish_run
+#define CML_CLOSE_OFFSET 192            // LinSummary of run()'s closing pass (cmlhip_ba_finish_run): the loop's last summary stays at offset 0
 #define CML_ZERO_WORD_OFFSET 1008       // a word of the scalar scratch that is cleared with it at upload and never written
 
 struct BAArgs {
@@ -106,7 +107,7 @@ int cml_iteration_batch(cmlhip_ctx* const* ctxs, int S, double lambda);        /
 static inline int cml_sys_slices(int P) { return P <= 512 ? 1 : (P <= 1024 ? 2 : (P <= 2048 ? 4 : 8)); }
 int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A);
 int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A);
-int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A);
+int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A, size_t out_offset = 0);     // out_offset: where in the scalar scratch the LinSummary goes
 int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy);
 // K3 (pair blocks + point rows) and K4 (system tiles: H_A, H_L, H_sc and the final LM system for `lambda` / optional HM)
 int cml_launch_accumulate(cmlhip_ctx* c, const BAArgs& A, double lambda, bool have_hm, bool do_backup, bool system_only = false, bool marg = false);

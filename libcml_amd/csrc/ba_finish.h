@@ -111,7 +111,7 @@ __device__ __forceinline__ void lin_finish_block(const BAArgs& A, const int* new
         th = (float)t;
     }
     if (tid == 0) {
-        if (A.ctl) { const int it_ = A.ctl->iters_done - 1; if (it_ >= 0 && it_ < 40) A.ctl->energy[it_] = tot[0]; }   // statEnergyP of the resident loop
+        if (A.ctl) { const int it_ = A.ctl->iters_done - 1; if (it_ >= 0 && it_ < 40) A.ctl->energy[it_] = tot[0]; else if (it_ < 0) A.ctl->energy0 = tot[0]; }   // statEnergyP of the resident loop
         out->energy = tot[0]; out->n_in = (int)tot[1]; out->n_oob = (int)tot[2]; out->n_outlier = (int)tot[3];
         out->new_frame_energy_th = th;
         frames_rw[A.N - 1].frame_energy_th = th;                         // takes effect from the next residual pass

@@ -477,9 +477,9 @@ int cml_launch_linearize(cmlhip_ctx* c, const BAArgs& A) {
     else CML_LAUNCH_EV(c, k_ba_linearize<false>, blocks, 256, 0, A);
     return CMLHIP_OK;
 }
-int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A) {
+int cml_launch_lin_finish(cmlhip_ctx* c, const BAArgs& A, size_t out_offset) {
     k_ba_lin_finish<<<1, 1024, 0, c->stream>>>(A, c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n,
-                                                c->scal.as<LinSummary>(), c->frames.as<FrameDev>());
+                                                reinterpret_cast<LinSummary*>(c->scal.as<char>() + out_offset), c->frames.as<FrameDev>());
     return CMLHIP_OK;
 }
 int cml_launch_apply(cmlhip_ctx* c, const BAArgs& A, int copy) {

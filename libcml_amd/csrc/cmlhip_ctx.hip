@@ -24,7 +24,7 @@ int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
     // so it is copied into a pinned staging ring owned by the context first; the device copy is then truly async.
     const size_t cap = 8u << 20;
     if (!c->pinned) {
-        CML_CHECK(c, hipHostMalloc(&c->pinned, cap, hipHostMallocDefault));
+        CML_CHECK(c, hipHostMalloc(&c->pinned, cap, hipHostMallocMapped | hipHostMallocCoherent));
         c->pinned_bytes = cap;
         c->pinned_off = 0;
     }
@@ -34,7 +34,10 @@ int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
         return CMLHIP_OK;
     }
     if (c->pinned_off + bytes > cap) {              // ring wrap: everything staged so far must have been consumed
-        if (c->h2d_batching) { const int rc = cml_h2d_batch_flush(c); if (rc) return rc; c->h2d_batching = true; }
+        if (c->h2d_scope) {                         // (inside an upload scope: what is staged leaves now, with the kernels waiting for it; the scope stays open)
+            const int rc = cml_scope_end(c); if (rc) return rc;
+            c->h2d_scope = true; c->h2d_batching = true;
+        } else if (c->h2d_batching) { const int rc = cml_h2d_batch_flush(c); if (rc) return rc; c->h2d_batching = true; }
         CML_CHECK(c, hipStreamSynchronize(c->stream));
         c->pinned_off = 0;
         c->h2d_batch_start = 0;
@@ -105,9 +108,41 @@ int cml_fill_ff(cmlhip_ctx* c, void* dst, size_t bytes) {       // every byte 0x
     return CMLHIP_OK;
 }
 void cml_h2d_batch_begin(cmlhip_ctx* c) {
+    if (c->h2d_scope && c->h2d_batching) return;    // the scope's batch is already open
     c->h2d_batching = true; c->h2d_segs.clear(); c->h2d_batch_start = c->pinned ? c->pinned_off : 0;
 }
+static int h2d_batch_flush_now(cmlhip_ctx* c);
 int cml_h2d_batch_flush(cmlhip_ctx* c) {
+    if (c->h2d_scope) return CMLHIP_OK;             // leaves when the scope ends
+    return h2d_batch_flush_now(c);
+}
+int cml_scope_end(cmlhip_ctx* c) {
+    if (!c->h2d_scope) return CMLHIP_OK;
+    c->h2d_scope = false;
+    int rc = h2d_batch_flush_now(c);
+    std::vector<std::function<int()>> run;
+    run.swap(c->deferred);
+    for (auto& f : run) { const int r = f(); if (!rc) rc = r; }
+    return rc;
+}
+extern "C" int cmlhip_upload_scope_begin(cmlhip_ctx* c) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    if (c->h2d_scope) return CMLHIP_OK;
+    if (c->pinned && c->pinned_off > c->pinned_bytes / 4) {     // room for a window's worth of arrays without a wrap inside the scope
+        CML_CHECK(c, hipStreamSynchronize(c->stream));
+        c->pinned_off = 0;
+    }
+    cml_h2d_batch_begin(c);
+    c->h2d_scope = true;
+    return CMLHIP_OK;
+}
+extern "C" int cmlhip_upload_scope_end(cmlhip_ctx* c) {
+    if (!c) return CMLHIP_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    return cml_scope_end(c);
+}
+static int h2d_batch_flush_now(cmlhip_ctx* c) {
     c->h2d_batching = false;
     const size_t nseg = c->h2d_segs.size() / 3;
     if (nseg == 0) return CMLHIP_OK;
@@ -127,6 +162,17 @@ int cml_h2d_batch_flush(cmlhip_ctx* c) {
     } else {
         memcpy(tstage, c->h2d_segs.data(), tbytes);
         c->pinned_off += (tbytes + 255) & ~size_t(255);
+        static const bool staged_copies = getenv("CMLHIP_STAGED_COPIES") != nullptr;
+        if (!staged_copies) {
+            // the scatter kernel pulls the packed block and its table straight out of the pinned (device-mapped, coherent) staging ring: no blit of the
+            // block into device memory first — two copies and their dispatch gaps (16 + 4 us and ~10 us of gaps per window upload in the trace) become
+            // the kernel's own reads across the link
+            k_h2d_scatter<<<dim3(32, (unsigned)nseg), 256, 0, c->stream>>>(reinterpret_cast<const unsigned long long*>(tstage),
+                                                                             static_cast<const char*>(c->pinned) + c->h2d_batch_start);
+            CML_CHECK(c, hipGetLastError());
+            c->h2d_segs.clear();
+            return CMLHIP_OK;
+        }
         CML_CHECK(c, hipMemcpyAsync(c->h2d_blob.p, static_cast<char*>(c->pinned) + c->h2d_batch_start, blob, hipMemcpyHostToDevice, c->stream));
         CML_CHECK(c, hipMemcpyAsync(c->h2d_desc.p, tstage, tbytes, hipMemcpyHostToDevice, c->stream));
     }
@@ -160,6 +206,19 @@ __global__ void k_d2h_gather(const unsigned long long* __restrict__ segs, char* 
         for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = src[i];
     } else for (size_t i = t0; i < bytes; i += stride) dst[i] = src[i];
 }
+struct D2hSegs { unsigned long long s[3 * 40]; };          // up to 40 pieces per readback ride in the kernel arguments (960 bytes)
+__global__ void k_d2h_gather_direct(D2hSegs T, char* __restrict__ blob) {
+    const unsigned long long* S = T.s + 3 * (size_t)blockIdx.y;
+    const char* src = reinterpret_cast<const char*>((uintptr_t)S[0]);
+    char* dst = blob + S[1];
+    const size_t bytes = (size_t)S[2], words = bytes / 16;
+    const bool aligned = (((uintptr_t)src) & 15) == 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (aligned) {
+        for (size_t i = t0; i < words; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (size_t i = words * 16 + t0; i < bytes; i += stride) dst[i] = src[i];
+    } else for (size_t i = t0; i < bytes; i += stride) dst[i] = src[i];
+}
 void cml_d2h_batch_begin(cmlhip_ctx* c) { c->d2h_batching = true; c->d2h_segs.clear(); c->d2h_dst.clear(); }
 int cml_d2h_batch_flush(cmlhip_ctx* c) {
     c->d2h_batching = false;
@@ -173,13 +232,24 @@ int cml_d2h_batch_flush(cmlhip_ctx* c) {
         if (c->pinned_d2h) (void)hipHostFree(c->pinned_d2h);
         c->pinned_d2h = nullptr; c->pinned_d2h_bytes = 0;
         const size_t cap = std::max(total, (size_t)1 << 20);
-        CML_CHECK(c, hipHostMalloc(&c->pinned_d2h, cap, hipHostMallocDefault));
+        CML_CHECK(c, hipHostMalloc(&c->pinned_d2h, cap, hipHostMallocMapped | hipHostMallocCoherent));
         c->pinned_d2h_bytes = cap;
     }
-    if ((rc = cml_h2d(c, c->h2d_desc.p, c->d2h_segs.data(), sizeof(unsigned long long) * 3 * nseg))) return rc;
-    k_d2h_gather<<<dim3(16, (unsigned)nseg), 256, 0, c->stream>>>(c->h2d_desc.as<unsigned long long>(), c->d2h_blob.as<char>());
-    CML_CHECK(c, hipMemcpyAsync(c->pinned_d2h, c->d2h_blob.p, total, hipMemcpyDeviceToHost, c->stream));
-    CML_CHECK(c, hipStreamSynchronize(c->stream));
+    static const bool staged_copies = getenv("CMLHIP_STAGED_COPIES") != nullptr;
+    if (!staged_copies && sizeof(unsigned long long) * 3 * nseg <= sizeof(D2hSegs)) {
+        // the gather kernel takes its table in the kernel-argument segment and writes the pieces straight into the pinned (device-mapped, coherent)
+        // host block: no table copy ahead of it, no device-to-host blit behind it
+        D2hSegs T;
+        memcpy(T.s, c->d2h_segs.data(), sizeof(unsigned long long) * 3 * nseg);
+        k_d2h_gather_direct<<<dim3(16, (unsigned)nseg), 256, 0, c->stream>>>(T, static_cast<char*>(c->pinned_d2h));
+        CML_CHECK(c, hipGetLastError());
+        CML_CHECK(c, hipStreamSynchronize(c->stream));
+    } else {
+        if ((rc = cml_h2d(c, c->h2d_desc.p, c->d2h_segs.data(), sizeof(unsigned long long) * 3 * nseg))) return rc;
+        k_d2h_gather<<<dim3(16, (unsigned)nseg), 256, 0, c->stream>>>(c->h2d_desc.as<unsigned long long>(), c->d2h_blob.as<char>());
+        CML_CHECK(c, hipMemcpyAsync(c->pinned_d2h, c->d2h_blob.p, total, hipMemcpyDeviceToHost, c->stream));
+        CML_CHECK(c, hipStreamSynchronize(c->stream));
+    }
     for (size_t k = 0; k < nseg; k++) memcpy(c->d2h_dst[k], static_cast<char*>(c->pinned_d2h) + c->d2h_segs[3 * k + 1], (size_t)c->d2h_segs[3 * k + 2]);
     c->d2h_segs.clear(); c->d2h_dst.clear();
     return CMLHIP_OK;

@@ -15,6 +15,7 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <functional>
 #include "../../include/cmlhip.h"
 
 #define CML_WAVE 64
@@ -96,6 +97,9 @@ struct cmlhip_ctx {
     DevBuf img_tmp;
     DevBuf h2d_blob, h2d_desc;                                // packed upload block and its segment table (batched cml_h2d)
     bool h2d_batching = false; size_t h2d_batch_start = 0;
+    // cmlhip_upload_scope_begin / _end: the uploads of SEVERAL calls (window, pair records, resident state, prior) leave in one packed block; the kernels
+    // those calls would launch behind their own upload wait in `deferred` and run, in order, when the scope ends
+    bool h2d_scope = false; std::vector<std::function<int()>> deferred;
     bool d2h_batching = false; std::vector<unsigned long long> d2h_segs; std::vector<void*> d2h_dst;
     DevBuf d2h_blob; void* pinned_d2h = nullptr; size_t pinned_d2h_bytes = 0;
     std::vector<unsigned long long> h2d_segs;                 // (dst pointer, offset in the block, bytes) triples                                           // AoS3 staging of pyramid_put / pyramid_get
@@ -116,6 +120,8 @@ struct cmlhip_ctx {
     int N = 0, P = 0, R = 0, n_lin = 0, n_newframe = 0;
     std::vector<int> h_pair_of, h_by_point_off, h_by_point, h_by_pair_off, h_by_pair;    // caller numbering (cmlhip_ba_get_index_maps)
     std::vector<int> h_dev_of, h_caller_of;                   // caller r -> device r' (pair-sorted) and back
+    DevBuf c_point, c_target, c_state, c_lin, c_dev_of, c_bpos;   // the window's residual lists in CALLER order + their device / by-point positions (input of k_window_expand)
+    bool h_maps_valid = false;
     WindowShadow win; std::vector<int> h_tiles, h_tile_off, w_cnt_p, w_cnt_q;     // window kept across keyframes + commit scratch (allocated once)
     DevBuf frames, pairs;                                     // FrameDev[N], cmlhip_ba_pair[N*N]
     DevBuf pt_x, pt_y, pt_idepth, pt_idepth_zero, pt_prior, pt_host, pt_colors, pt_weights, pt_backup;
@@ -185,7 +191,9 @@ struct cmlhip_ctx {
 
 // every extern "C" entry selects its context's device first: the current device is per-thread state and a process may own
 // contexts on several GPUs
-#define CML_DEV(ctx) do { if (ctx) (void)hipSetDevice((ctx)->device); } while (0)
+int cml_scope_end(cmlhip_ctx* c);                              // flush the open upload scope (if any) and run what was deferred
+#define CML_DEV(ctx) do { if (ctx) { (void)hipSetDevice((ctx)->device); if ((ctx)->h2d_scope) (void)cml_scope_end(ctx); } } while (0)
+#define CML_DEV_SCOPED(ctx) do { if (ctx) (void)hipSetDevice((ctx)->device); } while (0)      /* entries that stage into an open upload scope */
 
 #define CML_CHECK(ctx, call)                                                                      \
     do {                                                                                          \

@@ -95,10 +95,11 @@ int cml_launch_reproj_resident(cmlhip_ctx* c, double lambda) {
 
 extern "C" {
 
-int cmlhip_ba_set_resident_indirect(cmlhip_ctx* c, int M, const double* points, int n, const cmlhip_reproj_obs* obs, double fx, double fy) { CML_DEV(c);
+int cmlhip_ba_set_resident_indirect(cmlhip_ctx* c, int M, const double* points, int n, const cmlhip_reproj_obs* obs, double fx, double fy) { CML_DEV_SCOPED(c);
     if (!c || M < 0 || n < 0 || (M > 0 && !points) || (n > 0 && !obs)) return CMLHIP_ERR_INVALID;
     c->rp_resident = false;
-    if (M == 0) return CMLHIP_OK;                                  // BA.cpp:2587-2589: nothing to mix
+    if (M == 0) return CMLHIP_OK;                                  // BA.cpp:2587-2589: nothing to mix (no device work: an open upload scope stays open)
+    if (c->h2d_scope) { const int rcs = cml_scope_end(c); if (rcs) return rcs; }
     CML_REQUIRE(c, c->ba_uploaded && c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
     CML_REQUIRE(c, n <= c->lim.max_reproj_obs, CMLHIP_ERR_INVALID, "observations exceed max_reproj_obs");
     const int N = c->N;

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "cmlhip_ba_finish_keyframe": (C.c_int, [_ctx, C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_ubyte), _P(C.c_double), _P(C.c_float)]),
+    "cmlhip_upload_scope_begin": (C.c_int, [_ctx]),
+    "cmlhip_upload_scope_end": (C.c_int, [_ctx]),
     "cmlhip_ba_window_reset": (C.c_int, [_ctx]),
     "cmlhip_ba_window_append_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_ba_window_append_residuals": (C.c_int, [_ctx, _i, C.c_void_p]),

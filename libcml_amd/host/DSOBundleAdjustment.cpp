@@ -1165,16 +1165,41 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     const auto T0 = std::chrono::steady_clock::now();
     auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
     auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "  [run] %-28s %.0f us\n", what, us()); };
-    if (!runPreamble(lastEnergy, true)) return false;
-    const double t_pre = us();
-    lastRunUs[1] = t_pre - lastRunUs[0];
-    lap("preamble enqueued");
-    if (!beginResident(updatePointsOnly)) return false;
-    const double t_begin = us();
-    lastRunUs[2] = t_begin - t_pre;
-    lap("beginResident done");
-    int rc = cmlhip_ba_resident_convergence(mCtx, mThOptIterations);         // `if (canbreak && it >= 1) break`, BA.cpp:879
+    // ---- preamble (BA.cpp:744-802) and the loop's resident state: ONE packed copy (upload scope), then the kernels
+    mOutliers.clear();
+    mError.clear();
+    lastIterations = 0;
+    int alivePts = 0;
+    for (const auto& p : mPoints) alivePts += p.alive;
+    if (alivePts == 0) { mError = "No points..."; return false; }             // :759-762
+    computeAdjoints();
+    computeDelta();
+    int rc = cmlhip_upload_scope_begin(mCtx);
+    if (rc) return fail("cmlhip_upload_scope_begin", rc);
+    struct ScopeGuard { cmlhip_ctx* c; ~ScopeGuard() { cmlhip_upload_scope_end(c); } } scopeGuard{mCtx};      // (error returns leave no scope open)
+    if (!uploadWindow()) return false;
+    {
+        std::vector<cmlhip_ba_pair> pairs;
+        framePairs(pairs);
+        if ((rc = setPairs(pairs))) return fail("cmlhip_ba_set_pairs", rc);
+    }
+    rc = cmlhip_upload_scope_end(mCtx);                      // window + pair records: one packed copy
+    if (rc) return fail("cmlhip_upload_scope_end", rc);
+    lastRunUs[0] = us();
+    lap("window committed");
+    rc = cmlhip_ba_linearize_apply(mCtx, nullptr);           // linearizeAll(false) + applyActiveRes(true), :785-790: enqueued (the device works on it while the
+    if (rc) return fail("cmlhip_ba_linearize_apply", rc);    // loop's state is prepared below); its tail rides in the first solve launch
+    lastRunUs[1] = us() - lastRunUs[0];
+    rc = cmlhip_upload_scope_begin(mCtx);
+    if (rc) return fail("cmlhip_upload_scope_begin", rc);
+    if (!beginResident(updatePointsOnly)) return false;      // adjoints, frame states, prior, gauge basis: the second (small) packed copy
+    rc = cmlhip_ba_resident_convergence(mCtx, mThOptIterations);             // `if (canbreak && it >= 1) break`, BA.cpp:879
     if (rc) return fail("cmlhip_ba_resident_convergence", rc);
+    rc = cmlhip_upload_scope_end(mCtx);
+    if (rc) return fail("cmlhip_upload_scope_end", rc);
+    const double t_begin = us();
+    lastRunUs[2] = t_begin - lastRunUs[0] - lastRunUs[1];
+    lap("resident state staged");
     if (!iterateResident(mNumIterations, mFixedLambda)) return false;
     lastLambda = mFixedLambda;
     const double t_enq = us();
