@@ -107,6 +107,7 @@ struct ExpandArgs {
     int* r_point; int* r_target; int* r_state; unsigned char* r_lin; int* r_host; int* r_new_state; int* by_pair; int* pair_pos; int* by_point;
     float* r_px; float* r_py; float* r_colors; float* r_weights;
     int* point_tgt; int* point_pos; int* point_res;
+    const double* pt_idepth; double* r_idepth;
 };
 // one thread per residual of the CALLER's list: r' = c_dev_of[r] is its place in the pair-sorted device order, c_bpos[r] its place in the by-point
 // lists; every R-length device array, the per-residual copies of the point's static inputs and the point-slot tables are written from here
@@ -120,6 +121,7 @@ __global__ void k_window_expand(ExpandArgs E) {
         E.by_pair[k] = k;
         E.pair_pos[k] = q * E.pair_stride + (k - E.by_pair_off[q]);
         E.r_px[k] = E.pt_x[p]; E.r_py[k] = E.pt_y[p];
+        E.r_idepth[k] = E.pt_idepth[p];                          // (the resident kernels address the inverse depth by the residual too: k_ba_idepth_to_res's work)
         const float4* c4 = reinterpret_cast<const float4*>(E.pt_colors + 8 * (size_t)p); const float4* w4 = reinterpret_cast<const float4*>(E.pt_weights + 8 * (size_t)p);
         float4* oc = reinterpret_cast<float4*>(E.r_colors + 8 * (size_t)k); float4* ow = reinterpret_cast<float4*>(E.r_weights + 8 * (size_t)k);
         oc[0] = c4[0]; oc[1] = c4[1]; ow[0] = w4[0]; ow[1] = w4[1];
@@ -151,38 +153,71 @@ int cmlhip_ba_set_params(cmlhip_ctx* c, const cmlhip_ba_params* prm) { CML_DEV_S
 // cmlhip_ba_upload_window is reset + append + commit: one code path, a window built by edits is the window a fresh upload builds.
 static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames);
 
+static int window_alloc(cmlhip_ctx* c) {
+    WindowShadow& W = c->win;
+    if (W.block) return CMLHIP_OK;
+    const size_t cp = (size_t)std::max(c->lim.max_points, 1), cr = (size_t)std::max(c->lim.max_residuals, 1);
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t bytes = al(8 * cp) + 4 * al(4 * cp) + 2 * al(32 * cp) + al(4 * cp) + 3 * al(4 * cr) + al(cr);
+    CML_CHECK(c, hipHostMalloc(&W.block, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    CML_CHECK(c, hipEventCreateWithFlags(&W.busy, hipEventDisableTiming));
+    char* q = static_cast<char*>(W.block);
+    auto take = [&](size_t b) { char* r = q; q += al(b); return r; };
+    W.idepth = (double*)take(8 * cp);
+    W.x = (float*)take(4 * cp); W.y = (float*)take(4 * cp); W.idz = (float*)take(4 * cp); W.prior = (float*)take(4 * cp);
+    W.colors = (float*)take(32 * cp); W.weights = (float*)take(32 * cp);
+    W.host = (int*)take(4 * cp);
+    W.rpoint = (int*)take(4 * cr); W.rtarget = (int*)take(4 * cr); W.rstate = (int*)take(4 * cr);
+    W.rlin = (unsigned char*)take(cr);
+    W.capP = cp; W.capR = cr; W.P = W.R = 0;
+    return CMLHIP_OK;
+}
+// an edit of the shadows waits for the last commit's scatter kernel to have read them (normally long done: run() ends with a host wait)
+static int window_writable(cmlhip_ctx* c) {
+    int rc = window_alloc(c);
+    if (rc) return rc;
+    WindowShadow& W = c->win;
+    if (W.busy_pending) {
+        if (c->h2d_scope && (rc = cml_scope_end(c))) return rc;      // (the commit is still waiting in an open scope: it leaves first)
+        CML_CHECK(c, hipEventSynchronize(W.busy));
+        W.busy_pending = false;
+    }
+    return CMLHIP_OK;
+}
+
 int cmlhip_ba_window_reset(cmlhip_ctx* c) { CML_DEV_SCOPED(c);
     if (!c) return CMLHIP_ERR_INVALID;
-    WindowShadow& W = c->win;
-    W.x.clear(); W.y.clear(); W.idz.clear(); W.prior.clear(); W.colors.clear(); W.weights.clear(); W.idepth.clear(); W.host.clear();
-    W.rpoint.clear(); W.rtarget.clear(); W.rstate.clear(); W.rlin.clear();
+    c->win.P = c->win.R = 0;
     return CMLHIP_OK;
 }
 
 int cmlhip_ba_window_append_points(cmlhip_ctx* c, int n, const cmlhip_ba_point* pts) { CML_DEV_SCOPED(c);
     if (!c || n < 0 || (n > 0 && !pts)) return CMLHIP_ERR_INVALID;
+    int rc = window_writable(c);
+    if (rc) return rc;
     WindowShadow& W = c->win;
-    const size_t P0 = W.host.size();
-    CML_REQUIRE(c, P0 + (size_t)n <= (size_t)c->lim.max_points, CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
-    W.x.resize(P0 + n); W.y.resize(P0 + n); W.idz.resize(P0 + n); W.prior.resize(P0 + n); W.idepth.resize(P0 + n); W.host.resize(P0 + n);
-    W.colors.resize(8 * (P0 + n)); W.weights.resize(8 * (P0 + n));
+    const size_t P0 = W.P;
+    CML_REQUIRE(c, P0 + (size_t)n <= W.capP, CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
     for (int i = 0; i < n; i++) {
         const cmlhip_ba_point& q = pts[i];
         const size_t p = P0 + i;
         W.x[p] = q.x; W.y[p] = q.y; W.idepth[p] = q.idepth; W.idz[p] = q.idepth_zero; W.prior[p] = q.prior; W.host[p] = q.host;
         memcpy(&W.colors[8 * p], q.colors, 32); memcpy(&W.weights[8 * p], q.weights, 32);
     }
+    W.P = P0 + n;
     return CMLHIP_OK;
 }
 
 int cmlhip_ba_window_append_residuals(cmlhip_ctx* c, int n, const cmlhip_ba_residual* res) { CML_DEV_SCOPED(c);
     if (!c || n < 0 || (n > 0 && !res)) return CMLHIP_ERR_INVALID;
+    int rc = window_writable(c);
+    if (rc) return rc;
     WindowShadow& W = c->win;
-    const size_t R0 = W.rpoint.size(), P = W.host.size();
-    CML_REQUIRE(c, R0 + (size_t)n <= (size_t)c->lim.max_residuals, CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
+    const size_t R0 = W.R, P = W.P;
+    CML_REQUIRE(c, R0 + (size_t)n <= W.capR, CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
     for (int i = 0; i < n; i++) CML_REQUIRE(c, res[i].point >= 0 && (size_t)res[i].point < P, CMLHIP_ERR_INVALID, "residual index out of range");
-    W.rpoint.resize(R0 + n); W.rtarget.resize(R0 + n); W.rstate.resize(R0 + n); W.rlin.resize(R0 + n);
     for (int i = 0; i < n; i++) { W.rpoint[R0 + i] = res[i].point; W.rtarget[R0 + i] = res[i].target; W.rstate[R0 + i] = res[i].state; W.rlin[R0 + i] = res[i].is_linearized != 0; }
+    W.R = R0 + n;
     return CMLHIP_OK;
 }
 
@@ -190,9 +225,11 @@ int cmlhip_ba_window_append_residuals(cmlhip_ctx* c, int n, const cmlhip_ba_resi
 // (the caller drops those entries with the next cmlhip_ba_window_compact, as the reference's sets lose them)
 int cmlhip_ba_window_retire_frame(cmlhip_ctx* c, int frame) { CML_DEV_SCOPED(c);
     if (!c || frame < 0) return CMLHIP_ERR_INVALID;
+    int rc = window_writable(c);
+    if (rc) return rc;
     WindowShadow& W = c->win;
-    for (int& h : W.host) { if (h == frame) h = -1; else if (h > frame) h--; }
-    for (int& t : W.rtarget) { if (t == frame) t = -1; else if (t > frame) t--; }
+    for (size_t p = 0; p < W.P; p++) { int& h = W.host[p]; if (h == frame) h = -1; else if (h > frame) h--; }
+    for (size_t r = 0; r < W.R; r++) { int& t = W.rtarget[r]; if (t == frame) t = -1; else if (t > frame) t--; }
     return CMLHIP_OK;
 }
 
@@ -200,11 +237,14 @@ int cmlhip_ba_window_retire_frame(cmlhip_ctx* c, int frame) { CML_DEV_SCOPED(c);
 // must name a surviving point
 int cmlhip_ba_window_compact(cmlhip_ctx* c, int n_points, const unsigned char* point_alive, int n_res, const unsigned char* res_alive) { CML_DEV_SCOPED(c);
     if (!c || (n_points > 0 && !point_alive) || (n_res > 0 && !res_alive)) return CMLHIP_ERR_INVALID;
+    int rc = window_writable(c);
+    if (rc) return rc;
     WindowShadow& W = c->win;
-    CML_REQUIRE(c, (size_t)n_points == W.host.size() && (size_t)n_res == W.rpoint.size(), CMLHIP_ERR_STATE, "cmlhip_ba_window_compact: the caller's lists and the window differ in length");
+    CML_REQUIRE(c, (size_t)n_points == W.P && (size_t)n_res == W.R, CMLHIP_ERR_STATE, "cmlhip_ba_window_compact: the caller's lists and the window differ in length");
     for (int r = 0; r < n_res; r++)                          // checked before anything moves: a refused call leaves the window as it was
         CML_REQUIRE(c, !res_alive[r] || point_alive[W.rpoint[r]], CMLHIP_ERR_INVALID, "cmlhip_ba_window_compact: a surviving residual names a dropped point");
-    std::vector<int> pmap((size_t)n_points);
+    std::vector<int>& pmap = c->w_cnt_p;
+    pmap.resize((size_t)n_points);
     size_t np = 0;
     for (int p = 0; p < n_points; p++) {
         pmap[p] = point_alive[p] ? (int)np : -1;
@@ -215,37 +255,37 @@ int cmlhip_ba_window_compact(cmlhip_ctx* c, int n_points, const unsigned char* p
         }
         np++;
     }
-    W.x.resize(np); W.y.resize(np); W.idepth.resize(np); W.idz.resize(np); W.prior.resize(np); W.host.resize(np); W.colors.resize(8 * np); W.weights.resize(8 * np);
+    W.P = np;
     size_t nr = 0;
     for (int r = 0; r < n_res; r++) {
         if (!res_alive[r]) continue;
-        const int pn = pmap[W.rpoint[r]];
-        CML_REQUIRE(c, pn >= 0, CMLHIP_ERR_INVALID, "cmlhip_ba_window_compact: a surviving residual names a dropped point");
-        W.rpoint[nr] = pn; W.rtarget[nr] = W.rtarget[r]; W.rstate[nr] = W.rstate[r]; W.rlin[nr] = W.rlin[r];
+        W.rpoint[nr] = pmap[W.rpoint[r]]; W.rtarget[nr] = W.rtarget[r]; W.rstate[nr] = W.rstate[r]; W.rlin[nr] = W.rlin[r];
         nr++;
     }
-    W.rpoint.resize(nr); W.rtarget.resize(nr); W.rstate.resize(nr); W.rlin.resize(nr);
+    W.R = nr;
     return CMLHIP_OK;
 }
 
 int cmlhip_ba_window_counts(cmlhip_ctx* c, int* P, int* R) { CML_DEV_SCOPED(c);
     if (!c) return CMLHIP_ERR_INVALID;
-    if (P) *P = (int)c->win.host.size();
-    if (R) *R = (int)c->win.rpoint.size();
+    if (P) *P = (int)c->win.P;
+    if (R) *R = (int)c->win.R;
     return CMLHIP_OK;
 }
 
 int cmlhip_ba_window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames, const double* idepth, const float* idepth_zero, const float* prior,
                             int reset_states, int n_lin, const int* lin_residuals, const int* lin_states) { CML_DEV_SCOPED(c);
     if (!c || !frames || n_lin < 0 || (n_lin > 0 && (!lin_residuals || !lin_states))) return CMLHIP_ERR_INVALID;
+    int rc = window_writable(c);
+    if (rc) return rc;
     WindowShadow& W = c->win;
-    const size_t P = W.host.size(), R = W.rpoint.size();
-    if (idepth) memcpy(W.idepth.data(), idepth, 8 * P);
-    if (idepth_zero) memcpy(W.idz.data(), idepth_zero, 4 * P);
-    if (prior) memcpy(W.prior.data(), prior, 4 * P);
+    const size_t P = W.P, R = W.R;
+    if (idepth) memcpy(W.idepth, idepth, 8 * P);
+    if (idepth_zero) memcpy(W.idz, idepth_zero, 4 * P);
+    if (prior) memcpy(W.prior, prior, 4 * P);
     if (reset_states) {                                      // resetOOB of BA::run's preamble (BA.cpp:766-779) for everything but the listed LINEARIZED residuals
-        std::fill(W.rstate.begin(), W.rstate.end(), (int)CMLHIP_RES_IN);
-        std::fill(W.rlin.begin(), W.rlin.end(), (unsigned char)0);
+        for (size_t r = 0; r < R; r++) W.rstate[r] = (int)CMLHIP_RES_IN;
+        memset(W.rlin, 0, R);
     }
     for (int i = 0; i < n_lin; i++) {
         CML_REQUIRE(c, lin_residuals[i] >= 0 && (size_t)lin_residuals[i] < R, CMLHIP_ERR_INVALID, "residual index out of range");
@@ -261,6 +301,8 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P >= 0 && P <= c->lim.max_points && R >= 0 && R <= c->lim.max_residuals,
                 CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
     int rc;
+    if ((rc = window_writable(c))) return rc;
+    CML_REQUIRE(c, (size_t)P <= c->win.capP && (size_t)R <= c->win.capR, CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
     if ((rc = cmlhip_ba_window_reset(c))) return rc;
     if ((rc = cmlhip_ba_window_append_points(c, P, points))) return rc;
     if ((rc = cmlhip_ba_window_append_residuals(c, R, res))) return rc;
@@ -269,7 +311,7 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
 
 static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     WindowShadow& W = c->win;
-    const int P = (int)W.host.size(), R = (int)W.rpoint.size();
+    const int P = (int)W.P, R = (int)W.R;
     CML_REQUIRE(c, c->ba_prm_set, CMLHIP_ERR_STATE, "cmlhip_ba_set_params not called");
     CML_REQUIRE(c, N >= 1 && N <= c->lim.max_frames && P <= c->lim.max_points && R <= c->lim.max_residuals,
                 CMLHIP_ERR_INVALID, "window exceeds the limits given at create");
@@ -295,9 +337,9 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     c->h_by_point_off.assign(P + 1, 0); c->h_by_pair_off.assign(NN + 1, 0);
     int n_lin = 0, n_newframe = 0;
     {
-        const int* rp = W.rpoint.data(); const int* rt = W.rtarget.data(); const int* hst = W.host.data();
+        const int* rp = W.rpoint; const int* rt = W.rtarget; const int* hst = W.host;
         int* pair_of = c->h_pair_of.data(); int* cp = c->h_by_point_off.data() + 1; int* cq = c->h_by_pair_off.data() + 1;
-        const unsigned char* rl = W.rlin.data();
+        const unsigned char* rl = W.rlin;
         bool ok = true;
         for (int r = 0; r < R; r++) {
             const int p = rp[r], t = rt[r];
@@ -394,10 +436,10 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
         return s.p;
     };
     auto commit = [&](Staged& s) -> int { return s.fb.empty() ? CMLHIP_OK : cml_h2d(c, s.dst, s.fb.data(), s.bytes); };
-    // points: the shadows ARE the device layout (caller order)
-#define UPS(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
-    UPS(c->pt_x, W.x); UPS(c->pt_y, W.y); UPS(c->pt_idepth, W.idepth); UPS(c->pt_idepth_zero, W.idz); UPS(c->pt_prior, W.prior);
-    UPS(c->pt_host, W.host); UPS(c->pt_colors, W.colors); UPS(c->pt_weights, W.weights);
+    // points: the shadows ARE the device layout (caller order), and they sit in pinned, device-mapped memory: the scatter kernel reads them in place
+#define UPS(buf, ptr, bytes) if ((rc = cml_h2d_inplace(c, (buf).p, (ptr), (bytes)))) return rc
+    UPS(c->pt_x, W.x, 4 * (size_t)P); UPS(c->pt_y, W.y, 4 * (size_t)P); UPS(c->pt_idepth, W.idepth, 8 * (size_t)P); UPS(c->pt_idepth_zero, W.idz, 4 * (size_t)P);
+    UPS(c->pt_prior, W.prior, 4 * (size_t)P); UPS(c->pt_host, W.host, 4 * (size_t)P); UPS(c->pt_colors, W.colors, 32 * (size_t)P); UPS(c->pt_weights, W.weights, 32 * (size_t)P);
     // ---- pass 2: DEVICE residual order = (host,target)-pair-sorted: r' = position in the by-pair list.  Every R-length device array, the
     //      by-point lists and the new-frame list hold r'; the ABI keeps the caller's numbering (inputs are permuted here, readbacks
     //      are permuted back, cmlhip_ba_get_index_maps reports the caller-order maps).  Residuals of one pair are contiguous on the
@@ -416,7 +458,7 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
         int* nfd = (int*)stage(s_nf, c->newframe_res, 4 * (size_t)n_newframe);
         c->w_cnt_p.assign(P, 0); c->w_cnt_q.assign(NN, 0);
         int* c1 = c->w_cnt_p.data(); int* c2 = c->w_cnt_q.data();
-        const int* rp = W.rpoint.data(); const int* rt = W.rtarget.data();
+        const int* rp = W.rpoint; const int* rt = W.rtarget;
         const int* pair_of = c->h_pair_of.data(); const int* opt = c->h_by_point_off.data(); const int* oq = c->h_by_pair_off.data();
         int* dev_of = c->h_dev_of.data();
         int nf = 0;
@@ -429,7 +471,8 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
         }
         for (Staged* s : {&s_dv, &s_bp, &s_nf}) if ((rc = commit(*s))) return rc;
     }
-    UPS(c->c_point, W.rpoint); UPS(c->c_target, W.rtarget); UPS(c->c_state, W.rstate); UPS(c->c_lin, W.rlin);
+    UPS(c->c_point, W.rpoint, 4 * (size_t)R); UPS(c->c_target, W.rtarget, 4 * (size_t)R); UPS(c->c_state, W.rstate, 4 * (size_t)R); UPS(c->c_lin, W.rlin, (size_t)R);
+    W.busy_pending = true;                                   // (recorded behind the scatter kernel when the batch leaves: cml_h2d_batch_flush)
 #define UP(buf, vec) if ((rc = cml_h2d(c, (buf).p, (vec).data(), (vec).size() * sizeof((vec)[0])))) return rc
     UP(c->frames, fd);
     UP(c->by_point_off, c->h_by_point_off);
@@ -478,6 +521,8 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
         E.r_host = c->r_host.as<int>(); E.r_new_state = c->r_new_state.as<int>(); E.by_pair = c->by_pair.as<int>(); E.pair_pos = c->pair_pos.as<int>(); E.by_point = c->by_point.as<int>();
         E.r_px = c->r_px.as<float>(); E.r_py = c->r_py.as<float>(); E.r_colors = c->r_colors.as<float>(); E.r_weights = c->r_weights.as<float>();
         E.point_tgt = c->point_tgt.as<int>(); E.point_pos = c->point_pos.as<int>(); E.point_res = c->point_res.as<int>();
+        E.pt_idepth = c->pt_idepth.as<double>(); E.r_idepth = c->r_idepth.as<double>();
+        c->r_idepth_dirty = false;                               // (written by the expand kernel, which runs ahead of anything that reads it)
         const int work = R;
         if ((rc = cml_defer(c, [c, E, work]() -> int {
                 k_window_expand<<<cml_div_up(std::min(work, 1 << 20), 256), 256, 0, c->stream>>>(E);
@@ -1110,9 +1155,7 @@ int cmlhip_ba_resident_convergence(cmlhip_ctx* c, double th_opt_iterations) { CM
     CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
     c->conv_th = th_opt_iterations > 0 ? th_opt_iterations : 0.0;     // 0: the test can never pass, the log is still kept
     c->conv_on = true;
-    return cml_defer(c, [c]() -> int {
-        CML_CHECK(c, hipMemsetAsync(c->scal.as<char>() + CML_CTL_OFFSET, 0, sizeof(ResidentCtl), c->stream));
-        return CMLHIP_OK; });
+    return cml_zero(c, c->scal.as<char>() + CML_CTL_OFFSET, sizeof(ResidentCtl));      // (a zero segment of the open upload scope, or a memset on the stream)
 }
 
 int cmlhip_ba_get_resident_log(cmlhip_ctx* c, int* iterations, double* energies, int capacity) { CML_DEV(c);

@@ -5,6 +5,12 @@
 #include <cstdlib>
 #include <algorithm>
 
+void cml_window_free(cmlhip_ctx* c) {
+    WindowShadow& W = c->win;
+    if (W.busy) (void)hipEventDestroy(W.busy);
+    if (W.block) (void)hipHostFree(W.block);
+    W = WindowShadow{};
+}
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.bytes >= bytes) return CMLHIP_OK;
@@ -53,6 +59,19 @@ int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
     }
     c->pinned_off += (bytes + 255) & ~size_t(255);
     CML_CHECK(c, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, c->stream));
+    return CMLHIP_OK;
+}
+// Batch mode, direct scatter: `src` lies in pinned, device-mapped host memory that stays untouched until the scatter kernel has run (the window
+// shadows): registered as a segment of the packed block by its distance from the block's base — nothing is copied on the host.  Otherwise: cml_h2d.
+int cml_h2d_inplace(cmlhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    static const bool staged_copies = getenv("CMLHIP_STAGED_COPIES") != nullptr;
+    if (bytes == 0) return CMLHIP_OK;
+    if (!c->h2d_batching || !c->pinned || staged_copies) return cml_h2d(c, dst, src, bytes);
+    const char* base = static_cast<const char*>(c->pinned) + c->h2d_batch_start;
+    c->h2d_segs.push_back((unsigned long long)(uintptr_t)dst);
+    c->h2d_segs.push_back((unsigned long long)(static_cast<const char*>(src) - base));       // (modulo 2^64: the kernel adds it back to the base)
+    c->h2d_segs.push_back((unsigned long long)bytes);
+    c->h2d_inplace = true;
     return CMLHIP_OK;
 }
 // Batch mode only: room for `bytes` in the packed block, registered for `dst` — the caller WRITES its array there instead of building it in
@@ -148,36 +167,48 @@ static int h2d_batch_flush_now(cmlhip_ctx* c) {
     if (nseg == 0) return CMLHIP_OK;
     const size_t blob = c->pinned_off - c->h2d_batch_start;
     int rc;
-    if ((rc = cml_ensure(c, c->h2d_blob, blob + 16))) return rc;
-    if ((rc = cml_ensure(c, c->h2d_desc, sizeof(unsigned long long) * 3 * nseg))) return rc;
-    // the table rides at the end of the pinned block
     const size_t tbytes = sizeof(unsigned long long) * 3 * nseg;
     const size_t cap = c->pinned_bytes;
-    if (c->pinned_off + tbytes > cap) { CML_CHECK(c, hipStreamSynchronize(c->stream)); }
-    char* tstage = static_cast<char*>(c->pinned) + (c->pinned_off + tbytes <= cap ? c->pinned_off : 0);
-    if (c->pinned_off + tbytes > cap) {             // no room behind the block: the table goes through a plain synchronous copy
+    const bool room = c->pinned && c->pinned_off + tbytes <= cap;       // the table rides at the end of the pinned block
+    static const bool staged_copies = getenv("CMLHIP_STAGED_COPIES") != nullptr;
+    if (!staged_copies && c->pinned) {
+        // the scatter kernel pulls the packed block (and the segments registered in place) straight out of pinned, device-mapped host memory: no
+        // blit of the block into device memory first — two copies and their dispatch gaps (16 + 4 us and ~10 us of gaps per window upload in
+        // the trace) become the kernel's own reads across the link
+        const unsigned long long* tab;
+        if (room) {
+            char* tstage = static_cast<char*>(c->pinned) + c->pinned_off;
+            memcpy(tstage, c->h2d_segs.data(), tbytes);
+            c->pinned_off += (tbytes + 255) & ~size_t(255);
+            tab = reinterpret_cast<const unsigned long long*>(tstage);
+        } else {                                        // no room behind the block: the table goes through a plain synchronous copy
+            if ((rc = cml_ensure(c, c->h2d_desc, tbytes))) return rc;
+            CML_CHECK(c, hipMemcpyAsync(c->h2d_desc.p, c->h2d_segs.data(), tbytes, hipMemcpyHostToDevice, c->stream));
+            CML_CHECK(c, hipStreamSynchronize(c->stream));
+            tab = c->h2d_desc.as<unsigned long long>();
+        }
+        k_h2d_scatter<<<dim3(32, (unsigned)nseg), 256, 0, c->stream>>>(tab, static_cast<const char*>(c->pinned) + c->h2d_batch_start);
+        CML_CHECK(c, hipGetLastError());
+        if (c->win.busy_pending && c->win.busy) CML_CHECK(c, hipEventRecord(c->win.busy, c->stream));      // the window shadows are free again behind this kernel
+        c->h2d_segs.clear(); c->h2d_inplace = false;
+        return CMLHIP_OK;
+    }
+    if ((rc = cml_ensure(c, c->h2d_blob, blob + 16))) return rc;
+    if ((rc = cml_ensure(c, c->h2d_desc, tbytes))) return rc;
+    if (!room) {
         CML_CHECK(c, hipMemcpyAsync(c->h2d_blob.p, static_cast<char*>(c->pinned) + c->h2d_batch_start, blob, hipMemcpyHostToDevice, c->stream));
         CML_CHECK(c, hipMemcpyAsync(c->h2d_desc.p, c->h2d_segs.data(), tbytes, hipMemcpyHostToDevice, c->stream));
         CML_CHECK(c, hipStreamSynchronize(c->stream));
     } else {
+        char* tstage = static_cast<char*>(c->pinned) + c->pinned_off;
         memcpy(tstage, c->h2d_segs.data(), tbytes);
         c->pinned_off += (tbytes + 255) & ~size_t(255);
-        static const bool staged_copies = getenv("CMLHIP_STAGED_COPIES") != nullptr;
-        if (!staged_copies) {
-            // the scatter kernel pulls the packed block and its table straight out of the pinned (device-mapped, coherent) staging ring: no blit of the
-            // block into device memory first — two copies and their dispatch gaps (16 + 4 us and ~10 us of gaps per window upload in the trace) become
-            // the kernel's own reads across the link
-            k_h2d_scatter<<<dim3(32, (unsigned)nseg), 256, 0, c->stream>>>(reinterpret_cast<const unsigned long long*>(tstage),
-                                                                             static_cast<const char*>(c->pinned) + c->h2d_batch_start);
-            CML_CHECK(c, hipGetLastError());
-            c->h2d_segs.clear();
-            return CMLHIP_OK;
-        }
         CML_CHECK(c, hipMemcpyAsync(c->h2d_blob.p, static_cast<char*>(c->pinned) + c->h2d_batch_start, blob, hipMemcpyHostToDevice, c->stream));
         CML_CHECK(c, hipMemcpyAsync(c->h2d_desc.p, tstage, tbytes, hipMemcpyHostToDevice, c->stream));
     }
     k_h2d_scatter<<<dim3(32, (unsigned)nseg), 256, 0, c->stream>>>(c->h2d_desc.as<unsigned long long>(), c->h2d_blob.as<char>());
     CML_CHECK(c, hipGetLastError());
+    if (c->win.busy_pending && c->win.busy) CML_CHECK(c, hipEventRecord(c->win.busy, c->stream));
     c->h2d_segs.clear();
     return CMLHIP_OK;
 }
@@ -339,9 +370,11 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
                      &c->vec_small, &c->HA, &c->bA, &c->HL, &c->bL, &c->Hsc, &c->bsc, &c->HM, &c->bM, &c->xvec, &c->G,
                      &c->syrk_part, &c->solve_image, &c->xad, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,
                      &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x, &c->rp_off, &c->rp_orig,
-                     &c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x, &c->rr_ready, &c->trk_xch, &c->x_ticket, &c->batch_main, &c->batch_rs};
+                     &c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x, &c->rr_ready, &c->trk_xch, &c->x_ticket, &c->batch_main, &c->batch_rs,
+                     &c->run_snap, &c->c_point, &c->c_target, &c->c_state, &c->c_lin, &c->c_dev_of, &c->c_bpos};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
+    cml_window_free(c);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_d2h) (void)hipHostFree(c->pinned_d2h);
     if (c->trk_host) (void)hipHostFree(c->trk_host);

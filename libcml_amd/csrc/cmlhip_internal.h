@@ -68,13 +68,18 @@ struct FrameDev {
 #define CML_TILE_H 4
 static inline size_t cml_tiled_bytes(int w, int h) { return (size_t)((w + CML_TILE_W - 1) / CML_TILE_W) * ((h + CML_TILE_H - 1) / CML_TILE_H) * 128; }
 
-// the BA window as the library keeps it between keyframes (cmlhip_ba_window_*): SoA, caller order, the layout of the device's point arrays
+// the BA window as the library keeps it between keyframes (cmlhip_ba_window_*): SoA, caller order, the layout of the device's point arrays.
+// The arrays live in ONE pinned, device-mapped host block sized by the limits given at create: the commit's scatter kernel reads them where they
+// are (no staging copy); `busy` is recorded behind that kernel and waited for before the next edit touches the block.
 struct WindowShadow {
-    std::vector<float> x, y, idz, prior, colors, weights;     // colors / weights: 8 per point
-    std::vector<double> idepth;
-    std::vector<int> host;
-    std::vector<int> rpoint, rtarget, rstate;
-    std::vector<unsigned char> rlin;
+    void* block = nullptr; size_t capP = 0, capR = 0;
+    size_t P = 0, R = 0;
+    float *x = nullptr, *y = nullptr, *idz = nullptr, *prior = nullptr, *colors = nullptr, *weights = nullptr;     // colors / weights: 8 per point
+    double* idepth = nullptr;
+    int* host = nullptr;
+    int *rpoint = nullptr, *rtarget = nullptr, *rstate = nullptr;
+    unsigned char* rlin = nullptr;
+    hipEvent_t busy = nullptr; bool busy_pending = false;
 };
 
 struct cmlhip_ctx {
@@ -96,7 +101,7 @@ struct cmlhip_ctx {
     size_t img_pool_bytes = 0;
     DevBuf img_tmp;
     DevBuf h2d_blob, h2d_desc;                                // packed upload block and its segment table (batched cml_h2d)
-    bool h2d_batching = false; size_t h2d_batch_start = 0;
+    bool h2d_batching = false, h2d_inplace = false; size_t h2d_batch_start = 0;
     // cmlhip_upload_scope_begin / _end: the uploads of SEVERAL calls (window, pair records, resident state, prior) leave in one packed block; the kernels
     // those calls would launch behind their own upload wait in `deferred` and run, in order, when the scope ends
     bool h2d_scope = false; std::vector<std::function<int()>> deferred;
@@ -212,6 +217,8 @@ int cml_scope_end(cmlhip_ctx* c);                              // flush the open
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes);          // grow-only device allocation
 void cml_free(DevBuf& b);
 int cml_h2d(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);
+int cml_h2d_inplace(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // batch mode: a segment read where it lies (pinned, device-mapped source)
+void cml_window_free(cmlhip_ctx* c);
 void* cml_h2d_stage(cmlhip_ctx* c, void* dst, size_t bytes);      // batch mode: the staging bytes themselves (nullptr: use cml_h2d)
 // Batched form for the many small arrays of a window upload: between begin and flush every cml_h2d only stages its bytes;
 // flush moves the packed block with ONE copy and scatters it to the destinations with one small kernel.

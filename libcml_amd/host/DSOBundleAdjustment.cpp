@@ -210,6 +210,7 @@ int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, c
         mPoints[p].lastResidual[0] = (int)mResiduals.size() - 1;            // target is getFrames().back(), BA.cpp:374-375
         mPoints[p].lastResidualState[0] = r.state_state;
     }
+    handOverNewEntries();
     return f.id;
 }
 
@@ -444,8 +445,13 @@ bool DSOBundleAdjustment::uploadWindow() {
     mPrm.scale_f = mScaleF; mPrm.scale_c = mScaleC; mPrm.optimize_a = mOptimizeA; mPrm.optimize_b = mOptimizeB;
     int rc = cmlhip_ba_set_params(mCtx, &mPrm);
     if (rc) return fail("cmlhip_ba_set_params", rc);
+    const auto TU0 = std::chrono::steady_clock::now();
+    static const bool timingU = getenv("CMLHOST_TIMING") != nullptr;
+    auto lapU = [&](const char* what) { if (timingU || getenv("CMLHOST_TIMING")) fprintf(stderr, "      [uploadWindow] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TU0).count()); };
     if (mDeadSinceCompact) compactDead();                    // (entries dropped since the last addNewFrame: the window holds live entries only)
+    lapU("compact");
     if (!syncWindowAppends()) return false;
+    lapU("appends");
     const int N = (int)mFrames.size();
     std::vector<cmlhip_ba_frame> fr(N);
     for (int i = 0; i < N; i++) {
@@ -462,13 +468,16 @@ bool DSOBundleAdjustment::uploadWindow() {
     if (mLinearizedAlive > 0 && !mAddLinearizedPoints)
         for (size_t r = 0; r < R; r++) if (mResiduals[r].isLinearized) { linIdx.push_back((int)r); linState.push_back(mResiduals[r].state_state); }
     if (mAddLinearizedPoints && mLinearizedAlive > 0) { for (auto& Rr : mResiduals) Rr.isLinearized = false; mLinearizedAlive = 0; }
+    lapU("dyn arrays");
     rc = cmlhip_ba_window_commit(mCtx, N, fr.data(), mDynIdepth.data(), mDynZero.data(), mDynPrior.data(), 1, (int)linIdx.size(), linIdx.data(), linState.data());
     if (rc) return fail("cmlhip_ba_window_commit", rc);
+    lapU("commit");
     // every entry is live: the device numbering is the lists' own
     mActive.resize(R); mActivePoints.resize(P); mPointSlot.resize(P);
     for (size_t r = 0; r < R; r++) mActive[r] = (int)r;
     for (size_t p = 0; p < P; p++) { mActivePoints[p] = (int)p; mPointSlot[p] = (int)p; }
     mPairsValid = false;                                     // (an upload forgets the pair records)
+    lapU("identity maps");
     return true;
 }
 
@@ -1078,11 +1087,14 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
         std::fill(mMarginalizedB.begin(), mMarginalizedB.end(), 0.0);
     }
     const int N = (int)mFrames.size();
+    const auto TB0 = std::chrono::steady_clock::now();
+    auto lapB = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "      [beginResident] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TB0).count()); };
     double sc[4];
     scales(sc);
     computeDelta();
     std::vector<cmlhip_ba_pair> pairs;
     framePairs(pairs);
+    lapB("delta+pairs");
     int rc = cmlhip_ba_set_arithmetic(mCtx, mRelaxedArithmetic ? CMLHIP_ARITH_RELAXED : CMLHIP_ARITH_EXACT);
     if (rc) return fail("cmlhip_ba_set_arithmetic", rc);
     rc = setPairs(pairs);                                    // (unchanged since run()'s preamble: not sent again — a new set would also discard the pass's pair tiles)
@@ -1103,10 +1115,13 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
         fs[i].fix_pose = updatePointsOnly ? 1 : 0;
         fs[i].pad = 0;
     }
+    lapB("states");
     std::vector<double> U;
     nullspaceBasis(U);
+    lapB("nullspace basis");
     rc = cmlhip_ba_set_resident_state(mCtx, &in, fs.data(), sc, U.data());
     if (rc) return fail("cmlhip_ba_set_resident_state", rc);
+    lapB("set_resident_state");
     // marginalisation prior (BA.cpp:1389-1401): HM and the raw bM stay on the device, bM_top follows the frame states there
     rc = cmlhip_ba_set_resident_prior(mCtx, mDisableMarginalization ? nullptr : mMarginalizedHessian.data(), mDisableMarginalization ? nullptr : mMarginalizedB.data());
     if (rc) return fail("cmlhip_ba_set_resident_prior", rc);
@@ -1115,6 +1130,7 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
     rc = cmlhip_ba_set_resident_indirect(mCtx, M, M ? mIndirectPoints.data() : nullptr, M ? (int)mIndirectObs.size() : 0,
                                          M ? mIndirectObs.data() : nullptr, mPrm.fx, mPrm.fy);
     if (rc) return fail("cmlhip_ba_set_resident_indirect", rc);
+    lapB("prior+indirect");
     return true;
 }
 

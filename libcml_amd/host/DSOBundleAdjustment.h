@@ -98,6 +98,9 @@ public:
     int  addNewFrame(uint64_t image_id, const SE3& worldToCam, const Exposure& exposure);       // BA.cpp:417-462; returns DSOFrame::id
     int  addPoint(float x, float y, double idepth, int host, const float colors[8], const float weights[8], bool hasDepthPrior);  // addPoints, BA.cpp:382-415
     bool run(bool updatePointsOnly = false);                                                     // BA.cpp:744-910
+    // addNewFrame / a batch of addPoint calls hand the new points and residuals to the library's window (cmlhip_ba_window_append_*) when they are made —
+    // where the reference's addPoints / addNewFrame build them — so that run() finds the window complete; run() hands over whatever is still missing
+    void handOverNewEntries() { if (!syncWindowAppends()) mError.clear(); }
     // The same run with the iteration loop resident on the device (forceAccept + fixLambda, no early break):
     // preamble and epilogue as run(), mNumIterations x cmlhip_ba_iteration_async in between, no host round trip per iteration.
     bool runResident(bool updatePointsOnly = false);

@@ -61,6 +61,7 @@ int cmlhost_ba_add_points(void* h, int n, const float* xy, const double* idepth,
     DSOBundleAdjustment* b = static_cast<DSOBundleAdjustment*>(h);
     const int first = (int)b->getPoints().size();
     for (int i = 0; i < n; i++) b->addPoint(xy[2 * i], xy[2 * i + 1], idepth[i], host[i], colors + 8 * (size_t)i, weights + 8 * (size_t)i, prior != 0);
+    b->handOverNewEntries();                                 // the library's window gets the batch now (BA::addPoints builds its residuals here, not in run())
     return first;
 }
 int cmlhost_ba_run(void* h, int updatePointsOnly) { return static_cast<DSOBundleAdjustment*>(h)->run(updatePointsOnly != 0) ? 1 : 0; }
@@ -375,6 +376,7 @@ int cmlhost_tracer_add_activated_to_ba(void* tr, void* ba, int n, const int* idx
         b->addPoint(q.d.x, q.d.y, (double)q.idepth, host, q.d.gray, w, false);
         if (xy_out) { xy_out[2 * k] = (int)q.d.x; xy_out[2 * k + 1] = (int)q.d.y; }
     }
+    b->handOverNewEntries();                                 // the library's window gets the batch now (BA::addPoints builds its residuals here, not in run())
     return first;
 }
 // immature points still alive per frame id (what flagFramesForMarginalization weighs, BA.cpp:428-462 via DSOContext's per-frame groups)
