@@ -474,9 +474,10 @@ def sequence_bench(device_id, seed, want_cpu):
            "library_note": "time inside the library's own calls (C++ host mirror + C ABI, device sync behind each) — frames_per_s above is the wall clock of the Python "
                            "driver that stands in for the reference's host code around them (map accessors, motion model, pixel selector: out of scope)",
            "run_us_split_median": run_split,
-           "run_us_split_note": "host clock inside DSOBundleAdjustment::run at the sliding window size: upload = window build + packed copy; first_pass = linearizeAll + applyRes; "
-                                "resident_state = adjoints / states / prior to the device; enqueue = the iterations' launches; wait_and_readback = the kernels of the "
-                                "iterations + frame states back; closing_pass = linearizeAll(true) + write-backs",
+           "run_us_split_note": "host clock inside DSOBundleAdjustment::run at the sliding window size: commit_window = edits handed over + index positions + pair records, one packed copy; "
+                                "enqueue_first_pass = linearizeAll + applyRes enqueued; resident_state = adjoints / states / prior staged (second packed copy); enqueue_iterations = the iterations' "
+                                "launches; wait_and_readback = cmlhip_ba_finish_run: the ONE host wait of run() (iterations, re-anchoring of the newest frame on the device, closing pass, one readback); "
+                                "bookkeeping = the host lists brought up to date",
            "final_position_error_m": float(np.linalg.norm(c - ct)),
            "note": "stage times are host wall clock with a device sync behind every stage; makeNewTraces / makeCoarseDepthL0 include the Python stand-ins for the "
                    "reference's PixelSelector and map accessors (out of scope)"}

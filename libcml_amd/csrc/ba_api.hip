@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include "ba_common.h"
 #include "ba_frames.h"
+#include "ba_finish.h"
 #include "reproj_dev.h"
 #include <cmath>
 
@@ -714,10 +715,9 @@ int cmlhip_ba_finish_keyframe(cmlhip_ctx* c, cmlhip_ba_lin_result* lin, int* sta
 // DSOFramePrecomputed of every pair that names it gets its PRE_RTll_0 / PRE_tTll_0 from the new evaluation points (DSOFrame.h:261-267) and its b0
 // follows state_zero (DSOFrame.h:197-199).  Saves run() the host round trip (frame states back, pairs + b0 down) ahead of the closing pass.
 // The host mirror adopts the same evaluation point from the pose read back (pre_w2c).
-__global__ void k_ba_reanchor_newest(cmlhip_ba_frame_state* __restrict__ fs, const double* __restrict__ pre_w2c, cmlhip_ba_pair* __restrict__ pairs,
-                                     FrameDev* __restrict__ frames, int N, double scale_b, cmlhip_ba_frame_state* __restrict__ snap) {
+__device__ __forceinline__ void reanchor_newest_block(cmlhip_ba_frame_state* __restrict__ fs, const double* __restrict__ pre_w2c, cmlhip_ba_pair* __restrict__ pairs,
+                                                      FrameDev* __restrict__ frames, int N, double scale_b, cmlhip_ba_frame_state* __restrict__ snap, double (*s_ev)[7]) {
     using cml_amd::SE3;
-    __shared__ double s_ev[CMLHIP_MAX_FRAMES][7];
     const int tid = threadIdx.x, f = N - 1;
     if (tid < N) {
         cmlhip_ba_frame_state& S = fs[tid];
@@ -747,6 +747,21 @@ __global__ void k_ba_reanchor_newest(cmlhip_ba_frame_state* __restrict__ fs, con
         for (int k = 0; k < 3; k++) P.t0[k] = l0.t[k];
     }
 }
+__global__ void k_ba_reanchor_newest(cmlhip_ba_frame_state* __restrict__ fs, const double* __restrict__ pre_w2c, cmlhip_ba_pair* __restrict__ pairs,
+                                     FrameDev* __restrict__ frames, int N, double scale_b, cmlhip_ba_frame_state* __restrict__ snap) {
+    __shared__ double s_ev[CMLHIP_MAX_FRAMES][7];
+    reanchor_newest_block(fs, pre_w2c, pairs, frames, N, scale_b, snap, s_ev);
+}
+// the tail of the loop's last residual pass (workgroup 0: energy sum, census, setNewFrameEnergyTH) and the re-anchoring (workgroup 1) in one launch:
+// they touch different records (frames[N-1].frame_energy_th | frames[N-1].b0, the pair records, the frame states)
+__global__ __launch_bounds__(1024) void k_ba_finish_reanchor(BAArgs A, const int* __restrict__ newframe_res, int n_newframe, const double* __restrict__ lin_partial, int n_partial,
+                                                             LinSummary* __restrict__ out, FrameDev* __restrict__ frames_rw, cmlhip_ba_frame_state* __restrict__ fs,
+                                                             const double* __restrict__ pre_w2c, cmlhip_ba_pair* __restrict__ pairs, double scale_b, cmlhip_ba_frame_state* __restrict__ snap) {
+    __shared__ unsigned s_u32[264];
+    __shared__ double s_f64[1024];
+    if (blockIdx.x == 0) lin_finish_block(A, newframe_res, n_newframe, lin_partial, n_partial, out, frames_rw, s_u32, s_f64);
+    else reanchor_newest_block(fs, pre_w2c, pairs, frames_rw, A.N, scale_b, snap, reinterpret_cast<double (*)[7]>(s_f64));
+}
 
 // The tail of DSOBundleAdjustment::run with the loop resident on the device, in ONE readback: what cmlhip_ba_get_resident_state / _log / _indirect return
 // after the iterations (frame states, PRE_worldToCam, the preamble pass's and the last pass's summaries, the energy log, x), then — reanchor_newest —
@@ -759,25 +774,37 @@ int cmlhip_ba_finish_run(cmlhip_ctx* c, int reanchor_newest, const cmlhip_ba_res
     CML_REQUIRE(c, !reanchor_newest || c->resident_iter > 0, CMLHIP_ERR_STATE, "cmlhip_ba_finish_run: no iteration has run (PRE_worldToCam is not on the device)");
     BAArgs A;
     cml_make_ba_args(c, A);
-    if (c->lin_finish_pending) {                             // the tail of the last residual pass normally rides in the NEXT solve launch
-        if (c->conv_on) A.ctl = reinterpret_cast<ResidentCtl*>(c->scal.as<char>() + CML_CTL_OFFSET);
-        cml_launch_lin_finish(c, A);
-        CML_CHECK(c, hipGetLastError());
-        c->lin_finish_pending = false;
-        A.ctl = nullptr;
-    }
     const size_t N = c->N, n = 8 * N + 4, R = c->R, P = c->P;
-    // (the loop's last summary stays at offset 0 of the scalar scratch: the closing pass writes its own slot; the frame states of the loop are kept by
-    //  the re-anchoring kernel before it edits them)
     if ((rc = cml_ensure(c, c->run_snap, sizeof(cmlhip_ba_frame_state) * N))) return rc;
-    if ((rc = cml_materialize_records(c))) return rc;        // (with the loop's own pair records, as cmlhip_ba_set_pairs does ahead of a new set)
-    if (reanchor_newest) {
-        k_ba_reanchor_newest<<<1, 64, 0, c->stream>>>(c->frame_state.as<cmlhip_ba_frame_state>(), c->pre_w2c.as<double>(), c->pairs.as<cmlhip_ba_pair>(),
-                                                        c->frames.as<FrameDev>(), (int)N, c->res_scales[3], c->run_snap.as<cmlhip_ba_frame_state>());
-        CML_CHECK(c, hipGetLastError());
+    // the closing pass as the loop's own residual kernel (Jacobians in reduced form: whoever reads a 74-float record afterwards — the marginalisation
+    // passes — re-creates them on demand, cml_materialize_records); windows the resident kernel does not take go through the record-writing kernel
+    const bool rs_close = c->rs_ok && c->n_tiles > 0 && c->n_lin == 0;
+    if (!rs_close && (rc = cml_materialize_records(c))) return rc;      // (with the loop's own pair records, as cmlhip_ba_set_pairs does ahead of a new set)
+    // (the loop's last summary stays at offset 0 of the scalar scratch: the closing pass writes its own slot; the frame states of the loop are kept by
+    //  the re-anchoring before it edits them)
+    const bool pend = c->lin_finish_pending;
+    if (pend && c->conv_on) A.ctl = reinterpret_cast<ResidentCtl*>(c->scal.as<char>() + CML_CTL_OFFSET);
+    if (pend && reanchor_newest) {
+        k_ba_finish_reanchor<<<2, 1024, 0, c->stream>>>(A, c->newframe_res.as<int>(), c->n_newframe, c->lin_partial.as<double>(), c->lin_partial_n, c->scal.as<LinSummary>(),
+                                                          c->frames.as<FrameDev>(), c->frame_state.as<cmlhip_ba_frame_state>(), c->pre_w2c.as<double>(), c->pairs.as<cmlhip_ba_pair>(),
+                                                          c->res_scales[3], c->run_snap.as<cmlhip_ba_frame_state>());
+    } else {
+        if (pend) cml_launch_lin_finish(c, A);               // the tail of the last residual pass normally rides in the NEXT solve launch
+        if (reanchor_newest)
+            k_ba_reanchor_newest<<<1, 64, 0, c->stream>>>(c->frame_state.as<cmlhip_ba_frame_state>(), c->pre_w2c.as<double>(), c->pairs.as<cmlhip_ba_pair>(),
+                                                            c->frames.as<FrameDev>(), (int)N, c->res_scales[3], c->run_snap.as<cmlhip_ba_frame_state>());
     }
+    CML_CHECK(c, hipGetLastError());
+    c->lin_finish_pending = false;
+    A.ctl = nullptr;
     A.fuse_apply = 1;
-    cml_launch_linearize(c, A);
+    if (rs_close) {
+        const bool relaxed = c->arith_relaxed;              // (exact, like every pass outside the iterations: include/cmlhip.h)
+        c->arith_relaxed = false;
+        cml_launch_linearize_rs(c, A);
+        c->arith_relaxed = relaxed;
+        c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
+    } else cml_launch_linearize(c, A);
     cml_launch_lin_finish(c, A, CML_CLOSE_OFFSET);
     CML_CHECK(c, hipGetLastError());
     LinSummary S, Sfirst, Slast;

@@ -233,10 +233,12 @@ class HostBA:
         return out[:n]
 
     def run_timing(self):
-        """host clock of the last resident run(), microseconds: upload | first pass | resident state | enqueue | wait + readback | closing pass"""
+        """host clock of the last resident run(), microseconds: window commit (edits handed over + index positions + pair records staged) | preamble pass
+        enqueued | resident state staged | iterations enqueued | cmlhip_ba_finish_run (the ONE host wait: loop, re-anchoring, closing pass, readback) |
+        host bookkeeping behind it"""
         t = np.zeros(6)
         self.L.cmlhost_ba_run_timing(self.h, _p(t, _d))
-        return dict(zip(("upload", "first_pass", "resident_state", "enqueue", "wait_and_readback", "closing_pass"), [float(x) for x in t]))
+        return dict(zip(("commit_window", "enqueue_first_pass", "resident_state", "enqueue_iterations", "wait_and_readback", "bookkeeping"), [float(x) for x in t]))
 
     def rejected(self):
         return self.L.cmlhost_ba_rejected(self.h)

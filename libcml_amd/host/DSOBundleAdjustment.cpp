@@ -538,7 +538,9 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
 void DSOBundleAdjustment::closingBookkeeping(const std::vector<int>& st, const std::vector<unsigned char>& good, const std::vector<int>& ns,
                                              const std::vector<float>& e, const std::vector<float>& ne, const std::vector<float>& nw) {
     const int R = (int)mActive.size();
-    std::vector<int> nres(mPoints.size(), 0);
+    std::vector<int>& nres = mScratchCount;
+    nres.assign(mPoints.size(), 0);
+    const bool allActive = (size_t)R == mResiduals.size();                      // (the committed window is the whole list: the census below needs no second pass)
     for (int k = 0; k < R; k++) {
         DSOResidual& Rr = mResiduals[mActive[k]];
         Rr.state_state = st[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
@@ -549,15 +551,16 @@ void DSOBundleAdjustment::closingBookkeeping(const std::vector<int>& st, const s
         }
         DSOPoint& Pp = mPoints[Rr.point];
         for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidualState[q] = Rr.state_state;   // setResidualState, :1618-1622
-        if (Rr.isLinearized) continue;
+        if (Rr.isLinearized) { nres[Rr.point] += Rr.alive; continue; }
         if (Rr.isActiveAndIsGoodNEW) Pp.numGoodResiduals++;                     // :1592
         else {                                                                  // toRemove, :1595-1598,1624-1638
             Rr.alive = false; mDeadSinceCompact++;
             mFrames[Rr.target].numResidualsOut++;                               // removeResiduals, DSOContext.h:210
             for (int q = 0; q < 2; q++) if (Pp.lastResidual[q] == mActive[k]) Pp.lastResidual[q] = -1;
         }
+        nres[Rr.point] += Rr.alive;
     }
-    for (const auto& Rr : mResiduals) if (Rr.alive) nres[Rr.point]++;
+    if (!allActive) { nres.assign(mPoints.size(), 0); for (const auto& Rr : mResiduals) if (Rr.alive) nres[Rr.point]++; }
     for (int p = 0; p < (int)mPoints.size(); p++)                               // points left without residual, :1638-1640
         if (mPoints[p].alive && nres[p] == 0) { mPoints[p].alive = false; mDeadSinceCompact++; mOutliers.push_back(p); }
 }

@@ -146,7 +146,7 @@ public:
     // ---- statistics of the last run (BA.h:215-233)
     std::vector<double> statEnergyP, statXNorm, statHessianP, statHessianSC, statBP, statBSC;
     int lastIterations = 0, statRejected = 0;                // iterations of the last run / rejected steps since construction
-    double lastRunUs[6] = {0, 0, 0, 0, 0, 0};                // host clock of the last runResident(): window build + upload | first linearize + apply | states / adjoints / prior to the device | enqueue of the iterations | wait for them + state readback | closing pass + write-back
+    double lastRunUs[6] = {0, 0, 0, 0, 0, 0};                // host clock of the last runResident(): window commit | preamble pass enqueued | resident state staged | iterations enqueued | cmlhip_ba_finish_run (the one host wait) | bookkeeping
     double lastLambda = 0;
     // exposed for tests
     void computeAdjoints();
@@ -165,6 +165,7 @@ private:
     bool syncWindowAppends();                                                  // hands the library the points / residuals added since the last hand-over (cmlhip_ba_window_append_*)
     size_t mWinPoints = 0, mWinResiduals = 0;                                  // how much of mPoints / mResiduals the library's window holds (index for index)
     int mDeadSinceCompact = 0, mLinearizedAlive = 0;                           // entries dropped since the lists were renumbered; residuals that may carry isLinearized
+    std::vector<int> mScratchCount;
     std::vector<double> mDynIdepth; std::vector<float> mDynZero, mDynPrior;    // per-point values refreshed at every commit
     bool isOOB(int p, const std::vector<int>& toMarg) const;                  // BA.cpp:2515-2554
     void removePoint(int p, bool marginalize, bool sweep = true);             // DSOContext.h:94-111 (sweep: removePointsWithoutResidual behind it, :218-229)
