@@ -481,6 +481,33 @@ def sequence_bench(device_id, seed, want_cpu):
            "final_position_error_m": float(np.linalg.norm(c - ct)),
            "note": "stage times are host wall clock with a device sync behind every stage; makeNewTraces / makeCoarseDepthL0 include the Python stand-ins for the "
                    "reference's PixelSelector and map accessors (out of scope)"}
+    # the same shard with the mapper on a host thread of its own (two contexts, two streams: Hybrid.cpp:103-106, direct/Mapping.cpp:3-41): frames keep
+    # being tracked against the previous keyframe while directMap runs; fixed hand-over schedule (lag 1), so the inline run is the same computation
+    try:
+        def split_pass(threaded):
+            ct = device.Ctx(device_id=device_id, max_frames=8, max_points=8192, max_residuals=8192 * 8)
+            cm = device.Ctx(device_id=device_id, max_frames=8, max_points=8192, max_residuals=8192 * 8)
+            pipe = sequence.SplitPipeline(ct, cm, seq.K, seq.w, seq.h, seq.levels, threaded=threaded)
+            try:
+                t0 = time.perf_counter()
+                st = pipe.run(seq)
+                dt_ = time.perf_counter() - t0
+                boot = pipe.mapper.timing_summary().get("bootstrap", {}).get("mean_ms", 0.0) * 1e-3
+                return st, dt_, boot, [r[1:5] for r in pipe.front.results], pipe.front.lib_s
+            finally:
+                pipe.close(); ct.close(); cm.close()
+        split_pass(True)                                                  # warm-up of the two contexts
+        st_i, dt_i, boot_i, res_i, lib_i = split_pass(False)
+        st_t, dt_t, boot_t, res_t, lib_t = split_pass(True)
+        same = len(res_i) == len(res_t) and all(np.array_equal(np.asarray(x, np.float64).view(np.uint64), np.asarray(y, np.float64).view(np.uint64))
+                                                for a, b in zip(res_i, res_t) for x, y in zip(a, b))
+        out["two_threads"] = {"frames_per_s": (n_frames - 1) / max(dt_t - boot_t, 1e-9), "frames_per_s_same_schedule_one_thread": (n_frames - 1) / max(dt_i - boot_i, 1e-9),
+                              "tracker_thread_stall_ms": 1e3 * st_t["tracker_stall_s"], "tracker_thread_library_ms_per_frame": 1e3 * lib_t / (n_frames - 1),
+                              "tracking_lost": st_t["tracking_lost"], "tracked_poses_bit_identical_to_one_thread": bool(same),
+                              "note": "SplitPipeline: tracker context on the calling thread, mapper context (tracer + BA) on its own thread; keyframe j's reference lists and "
+                                      "optimised pose are adopted before frame j + 2 is tracked; wall clock of the Python driver, bootstrap excluded"}
+    except Exception as e:
+        out["two_threads"] = {"error": repr(e)}
     if want_cpu:
         try:
             from tests import sequence_check as SC
@@ -859,9 +886,10 @@ def compact_line(out, detail_path, contract_only=False):
             line["sequence"] = {"frames_per_s": _r(sq.get("frames_per_s")), "library_frames_per_s": _r(sq.get("library_frames_per_s")),
                                 "run_ms": _r(sum((sq.get("run_us_split_median") or {}).values()) * 1e-3 or None),
                                 "parity_ok": sq.get("parity_ok"), "yardstick_used": len(par.get("run_yardstick", []) or []) + int(par.get("track_yardstick_used", 0) or 0)}
-            for k in ("library_frames_per_s_two_threads", "frames_per_s_two_threads"):
-                if sq.get(k) is not None:
-                    line["sequence"][k] = _r(sq[k])
+            tt = sq.get("two_threads") or {}
+            if "frames_per_s" in tt:
+                line["sequence"]["frames_per_s_two_threads"] = _r(tt["frames_per_s"])
+                line["sequence"]["two_threads_bit_identical"] = tt.get("tracked_poses_bit_identical_to_one_thread")
     tr = out.get("tracker")
     if isinstance(tr, dict):
         if "error" in tr:

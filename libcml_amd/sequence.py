@@ -124,12 +124,19 @@ class DirectPipeline:
     """Drives cml_amd::DSOTracker / DSOTracer / DSOBundleAdjustment (host mirror over the C ABI) in the reference's order on ONE context.
     `observer(stage, info)` — when given — is called after every stage with that stage's inputs and outputs (a checker replays them)."""
 
-    def __init__(self, ctx, K, w, h, levels, n_immature=500, seed=1, observer=None, max_frames=6, id_pool=16):
+    def __init__(self, ctx, K, w, h, levels, n_immature=500, seed=1, observer=None, max_frames=6, id_pool=16, mapper_only=False):
         self.ctx, self.K, self.w, self.h, self.levels = ctx, tuple(K), w, h, levels
         self.ba = host.HostBA(ctx); self.ba.set_calibration(*K, w, h)
         self.ba.set_param("disableMarginalization", 0)               # the marginalisation prior is live (BA.cpp:1389-1401)
         self.ba.set_param("maxFrames", max_frames)
-        self.trk = host.HostTracker(ctx); self.trk.set_calibration(*K)
+        # mapper_only: the mapping half of the shard alone (SplitPipeline: Hybrid::directMappingLoop on its own context / thread) — frames arrive already
+        # tracked (`injected`), and what the tracker needs from a keyframe's mapping (reference lists, optimised pose) is left in `handover`
+        self.mapper_only = mapper_only
+        self.injected = None
+        self.handover = None
+        self.trk = None
+        if not mapper_only:
+            self.trk = host.HostTracker(ctx); self.trk.set_calibration(*K)
         self.trc = host.HostTracer(ctx)
         self.rng = np.random.default_rng(seed)
         self.n_immature = n_immature
@@ -150,7 +157,10 @@ class DirectPipeline:
         self.stats = {"frames": 0, "keyframes": 0, "tracking_lost": 0, "ids_recycled": 0, "max_window": 0, "marginalized_frames": 0}
 
     def close(self):
-        self.trc.close(); self.trk.close(); self.ba.close()
+        self.trc.close()
+        if self.trk is not None:
+            self.trk.close()
+        self.ba.close()
 
     # ------------------------------------------------------------------ helpers
     def _t(self, stage, t0):
@@ -249,14 +259,19 @@ class DirectPipeline:
         self.ba.add_points(px.astype(np.float32), idepth, np.zeros(len(px), np.int32), g, _weights(dp), prior=True)
         # tracking reference lists straight from the bootstrap points (uniform weights: no Hessian yet)
         pts = np.stack([px[:, 0].astype(np.float64), px[:, 1].astype(np.float64), np.asarray(idepth, np.float64), np.ones(len(px))], 1)
-        nout = self.trk.make_coarse_depth(iid, self.levels, pts)
+        if self.mapper_only:
+            nout = None
+            self.handover = {"cd": pts, "R": np.asarray(R, float).copy(), "t": np.asarray(t, float).copy(), "ab": (0.0, 0.0)}
+        else:
+            nout = self.trk.make_coarse_depth(iid, self.levels, pts)
         self._make_new_traces(kf)
         self.ref = 0
         self.history.append((np.asarray(R, float).copy(), np.asarray(t, float).copy()))
         self.last_exposure = (0.0, 0.0)
         self.stats["frames"] += 1; self.stats["keyframes"] += 1
         self._t("bootstrap", t0)
-        self._emit("bootstrap", image_id=iid, gray=gray, pts=pts, n_lists=nout)
+        if not self.mapper_only:                                      # (the reference lists are the tracker front's stage there)
+            self._emit("bootstrap", image_id=iid, gray=gray, pts=pts, n_lists=nout)
         return nout
 
     def _hypotheses(self):
@@ -284,6 +299,17 @@ class DirectPipeline:
         next_gray: the frame after this one, when the reader already has it — its pyramid is handed to the context's image worker
         (cmlhip_pyramid_build_async) BEFORE this frame is tracked, as the reference's capture thread builds pyramids ahead of the SLAM thread
         (capture/CaptureImage.cpp): staging copy, transfer and level kernels then run beside the tracker instead of in front of the next one."""
+        if self.mapper_only:                                          # tracked elsewhere (SplitPipeline's tracker front): only the frame's pyramid is built here
+            t0 = time.perf_counter()
+            iid = self._take_id()
+            self._c("pyramid_build", self.ctx.pyramid_build, iid, gray, self.levels)
+            self._t("pyramid_build", t0)
+            Rn, tn, a, b, ok = self.injected
+            self.history.append((Rn.copy(), tn.copy())); self.last_exposure = (a, b)
+            self.stats["frames"] += 1
+            if not ok:
+                self.stats["tracking_lost"] += 1
+            return iid, Rn, tn, a, b, ok
         t0 = time.perf_counter()
         if self._prefetched is not None and self._prefetched[1] is gray:
             iid = self._prefetched[0]                                 # built (or being built) by the image worker: the first call that names it waits on the device
@@ -395,9 +421,10 @@ class DirectPipeline:
         # ---- makeCoarseDepthL0 on the new keyframe
         t0 = time.perf_counter()
         cd = self._c("makeCoarseDepthL0", self._coarse_depth, len(self.kfs) - 1)
-        nout = self._c("makeCoarseDepthL0", self.trk.make_coarse_depth, iid, self.levels, cd)
+        nout = None if self.mapper_only else self._c("makeCoarseDepthL0", self.trk.make_coarse_depth, iid, self.levels, cd)      # (mapper alone: the tracker front builds the lists at the hand-over)
         self._t("makeCoarseDepthL0", t0)
-        self._emit("coarse", image_id=iid, gray=gray, pts=cd, n_lists=nout, levels=self.levels)
+        if not self.mapper_only:
+            self._emit("coarse", image_id=iid, gray=gray, pts=cd, n_lists=nout, levels=self.levels)
         # ---- tryMarginalize, marginalizePointsF
         exp0 = (ba.export(), ba.algebra()) if self.obs is not None else None
         t0 = time.perf_counter()
@@ -435,6 +462,10 @@ class DirectPipeline:
         f = ba.frame(self.ref)
         self.history[-1] = (f["R"].copy(), f["t"].copy()); self.last_exposure = (float(f["ab"][0]), float(f["ab"][1]))
         self.stats["keyframes"] += 1
+        if self.mapper_only:
+            self.handover = {"cd": cd, "R": f["R"].copy(), "t": f["t"].copy(), "ab": (float(f["ab"][0]), float(f["ab"][1])),
+                             "energies": self.ba.energies(64).copy(), "iterations": self.ba.counts()["iterations"], "outliers": self.ba.outliers().copy(),
+                             "window": [(p[0].copy(), p[1].copy(), p[2], p[3]) for p in self.kf_poses()]}
         return ok
 
     def run(self, seq, n_frames=None):
@@ -465,6 +496,206 @@ class DirectPipeline:
             a = np.array(v)
             out[k] = {"calls": int(len(a)), "mean_ms": float(1e3 * a.mean()), "median_ms": float(1e3 * np.median(a)), "max_ms": float(1e3 * a.max())}
         return out
+
+
+class TrackerFront:
+    """The tracking half of the shard on its OWN context: pyramid of the frame, DSOTracker::trackWithMotionModel against the reference keyframe the
+    last hand-over installed (DSOTracker::getLastComputed, Hybrid.cpp:431-458), motion-model history."""
+
+    def __init__(self, ctx, K, levels, id_pool=16, observer=None):
+        self.ctx, self.K, self.levels = ctx, tuple(K), levels
+        self.obs = observer                                          # stages "bootstrap" / "coarse" (reference lists) and "track", as DirectPipeline emits them
+        self.grays = {}
+        self.trk = host.HostTracker(ctx); self.trk.set_calibration(*K)
+        self.free_ids = list(range(1, id_pool + 1))
+        self.history = []                                            # world->cam (R, t) per frame index
+        self.last_exposure = (0.0, 0.0)
+        self.last_coarse_rmse = 100.0
+        self.ref = None                                              # dict(image_id, R, t, a, b)
+        self.images = {}                                             # frame index -> image id of the frames whose pyramid this context still holds
+        self._prefetched = None
+        self.lib_s = 0.0
+        self.results = []
+
+    def close(self):
+        self.trk.close()
+
+    def _take(self):
+        return self.free_ids.pop(0)
+
+    def drop_frame(self, k):
+        iid = self.images.pop(k, None)
+        if iid is not None:
+            self.ctx.pyramid_drop(iid); self.free_ids.append(iid); self.free_ids.sort()
+
+    def build(self, k, gray, next_k=None, next_gray=None):
+        t0 = time.perf_counter()
+        if self._prefetched is not None and self._prefetched[0] == k:
+            iid = self._prefetched[1]
+        else:
+            iid = self._take(); self.ctx.pyramid_build(iid, gray, self.levels)
+        self._prefetched = None
+        self.images[k] = iid
+        if self.obs is not None:
+            self.grays[k] = gray
+        if next_gray is not None:
+            nid = self._take(); self.ctx.pyramid_build_async(nid, next_gray, self.levels)
+            self._prefetched = (next_k, nid)
+        self.lib_s += time.perf_counter() - t0
+        return iid
+
+    def adopt(self, k, ho):
+        """hand-over of keyframe k's mapping: reference lists (makeCoarseDepthL0 on this context's pyramid of the frame), the optimised pose"""
+        t0 = time.perf_counter()
+        iid = self.images[k]
+        nout = self.trk.make_coarse_depth(iid, self.levels, ho["cd"])
+        self.ctx.sync()
+        self.lib_s += time.perf_counter() - t0
+        if self.obs is not None:
+            self.obs("bootstrap" if self.ref is None else "coarse", dict(image_id=iid, gray=self.grays[k], pts=ho["cd"], n_lists=nout, levels=self.levels))
+            self.grays = {k: self.grays[k]}
+        old = self.ref
+        self.ref = {"k": k, "image_id": iid, "R": ho["R"], "t": ho["t"], "a": ho["ab"][0], "b": ho["ab"][1]}
+        if old is not None and old["k"] != k:
+            self.drop_frame(old["k"])
+        self.history[k] = (ho["R"].copy(), ho["t"].copy())            # the keyframe's pose is the optimised one from here on
+        if k == len(self.history) - 1:
+            self.last_exposure = ho["ab"]
+
+    def _hypotheses(self):
+        return DirectPipeline._hypotheses(self)
+
+    def track(self, k, gray, next_k=None, next_gray=None):
+        iid = self.build(k, gray, next_k, next_gray)
+        Rr, tr, ar, br = self.ref["R"], self.ref["t"], self.ref["a"], self.ref["b"]
+        hyps_w = self._hypotheses()
+        hyps = [_rel(Rr, tr, Rw, tw) for Rw, tw in hyps_w]
+        ref_exp = [ar, br, 1.0]; init_exp = [self.last_exposure[0], self.last_exposure[1], 1.0]
+        t0 = time.perf_counter()
+        res = self.trk.track_with_motion_model(iid, self.levels, hyps, ref_exp, init_exp, batched=True)
+        self.ctx.sync()
+        self.lib_s += time.perf_counter() - t0
+        ok = bool(res["haveOneGood"])
+        if self.obs is not None:
+            self.obs("track", dict(image_id=iid, gray=gray, ref_image_id=self.ref["image_id"], hyps=hyps, ref_exp=ref_exp, init_exp=init_exp, result=res,
+                                   last_coarse_rmse=self.last_coarse_rmse, levels=self.levels))
+        if ok:
+            Rn = res["R"] @ Rr; tn = res["R"] @ tr + res["t"]
+            a, b = float(res["exposure"][0]), float(res["exposure"][1])
+            self.last_coarse_rmse = float(res["lastCoarseRMSE"])
+        else:
+            Rn, tn = hyps_w[0]; a, b = self.last_exposure
+        self.history.append((Rn.copy(), tn.copy())); self.last_exposure = (a, b)
+        self.results.append((k, Rn.copy(), tn.copy(), a, b, ok, float(res["lastCoarseRMSE"]) if ok else None))
+        return Rn, tn, a, b, ok
+
+
+class SplitPipeline:
+    """The shard as the reference runs it with linearizeDirect off: the tracker on the SLAM thread, Hybrid::directMappingLoop on a thread of its own
+    (Hybrid.cpp:103-106, direct/Mapping.cpp:3-41) — two contexts, two streams, no shared mutable state.  Frames are tracked against the reference
+    keyframe of the last hand-over while the mapper works through its queue (traceNewCoarse of non-keyframes, directMap of keyframes, in frame order).
+    The hand-over of keyframe j (reference lists + optimised pose) is adopted before frame j + 1 + lag is tracked (lag = 1: frame j + 1 is tracked
+    beside the mapping of j, against the previous reference) — a fixed schedule, so that `threaded=False` (the same jobs run inline on the calling
+    thread at the moment they are queued) is the same computation, stage for stage and bit for bit."""
+
+    def __init__(self, ctx_tracker, ctx_mapper, K, w, h, levels, threaded=True, lag=1, front_observer=None, **kw):
+        self.front = TrackerFront(ctx_tracker, K, levels, observer=front_observer)
+        self.mapper = DirectPipeline(ctx_mapper, K, w, h, levels, mapper_only=True, **kw)
+        self.threaded, self.lag = threaded, lag
+        self.done = {}                                               # keyframe index -> hand-over
+        self.kf_log = []
+        self.stall_s = 0.0
+        self._err = None
+        if threaded:
+            import queue
+            import threading
+            self._q = queue.Queue()
+            self._cv = threading.Condition()
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+
+    def close(self):
+        if self.threaded:
+            self._q.put(None); self._th.join()
+        self.front.close(); self.mapper.close()
+
+    # ---- the mapper's side
+    def _job(self, job):
+        kind, k, gray, pose = job
+        m = self.mapper
+        if kind == "boot":
+            m.bootstrap(*gray)
+        else:
+            m.injected = pose
+            (m.keyframe if kind == "kf" else m.non_keyframe)(gray)
+        if kind != "nonkf":
+            ho = m.handover; m.handover = None
+            self.kf_log.append((k, ho))
+            return ho
+        return None
+
+    def _loop(self):
+        while True:
+            job = self._q.get()
+            if job is None:
+                return
+            try:
+                ho = self._job(job)
+            except Exception as e:                                   # the front sees it at its next wait
+                with self._cv:
+                    self._err = e; self._cv.notify_all()
+                return
+            if ho is not None:
+                with self._cv:
+                    self.done[job[1]] = ho; self._cv.notify_all()
+
+    def _submit(self, job):
+        if self.threaded:
+            self._q.put(job)
+        else:
+            ho = self._job(job)
+            if ho is not None:
+                self.done[job[1]] = ho
+
+    def _wait(self, k):
+        if self.threaded:
+            t0 = time.perf_counter()
+            with self._cv:
+                while k not in self.done and self._err is None:
+                    self._cv.wait(0.5)
+            self.stall_s += time.perf_counter() - t0
+            if self._err is not None:
+                raise self._err
+        return self.done.pop(k)
+
+    def run(self, seq, n_frames=None):
+        f = self.front
+        last = n_frames or seq.n_frames
+        kfset = set(seq.keyframes)
+        f.build(0, seq.gray[0])
+        f.history.append((np.asarray(seq.R_true[0], float).copy(), np.asarray(seq.t_true[0], float).copy()))
+        self._submit(("boot", 0, (seq.gray[0], seq.R_true[0], seq.t_true[0], seq.boot_px, seq.boot_idepth), None))
+        f.adopt(0, self._wait(0))
+        pending = []                                                 # keyframes whose hand-over is still to be adopted, oldest first
+        for k in range(1, last):
+            while pending and k >= pending[0] + 1 + self.lag:
+                j = pending.pop(0)
+                f.adopt(j, self._wait(j))
+            nxt = seq.gray[k + 1] if k + 1 < last else None
+            pose = f.track(k, seq.gray[k], k + 1, nxt)
+            if k in kfset:
+                pending.append(k)
+                self._submit(("kf", k, seq.gray[k], pose))
+            else:
+                self._submit(("nonkf", k, seq.gray[k], pose))
+                f.drop_frame(k)
+        for j in pending:
+            f.adopt(j, self._wait(j))
+        if self.threaded:                                            # the queue drained: the last non-keyframes' traces are part of the shard
+            self._q.put(None); self._th.join(); self.threaded = False
+            if self._err is not None:
+                raise self._err
+        return dict(self.mapper.stats, tracker_stall_s=self.stall_s)
 
 
 def _so3_log(R):
