@@ -298,7 +298,12 @@ static int pyr_settle(cmlhip_ctx* c, uint64_t id, Pyramid& P) {
         if (it != c->pyr_state.end()) c->pyr_state.erase(it);
     }
     P.pending = false;
-    if (st < 0) { c->err = "cmlhip_pyramid_build_async: the image worker failed to copy / build the pyramid"; return CMLHIP_ERR_HIP; }
+    if (st < 0) {                                           // sticky: every later look-up of this id fails too (the levels were never filled)
+        P.failed = true;
+        if (c->pyr_stream) (void)hipStreamSynchronize(c->pyr_stream);      // whatever the worker did enqueue has left the blocks before they can be released
+        c->err = "cmlhip_pyramid_build_async: the image worker failed to copy / build the pyramid";
+        return CMLHIP_ERR_HIP;
+    }
     CML_CHECK(c, hipStreamWaitEvent(c->stream, P.ready, 0));
     return CMLHIP_OK;
 }
@@ -306,6 +311,7 @@ const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id) {
     auto it = c->pyr.find(id);
     if (it == c->pyr.end()) return nullptr;
     if (it->second.pending && pyr_settle(c, id, it->second)) return nullptr;
+    if (it->second.failed) { c->err = "the pyramid of this image id was never built (cmlhip_pyramid_build_async failed): drop the id and build it again"; return nullptr; }
     return &it->second;
 }
 
@@ -371,7 +377,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
                      &c->syrk_part, &c->solve_image, &c->xad, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,
                      &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x, &c->rp_off, &c->rp_orig,
                      &c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x, &c->rr_ready, &c->trk_xch, &c->x_ticket, &c->batch_main, &c->batch_rs,
-                     &c->run_snap, &c->c_point, &c->c_target, &c->c_state, &c->c_lin, &c->c_dev_of, &c->c_bpos};
+                     &c->trk_early, &c->run_snap, &c->c_point, &c->c_target, &c->c_state, &c->c_lin, &c->c_dev_of, &c->c_bpos};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
     cml_window_free(c);
@@ -654,7 +660,12 @@ int cmlhip_pyramid_build_async(cmlhip_ctx* c, uint64_t id, const float* gray, in
     }
     if (rc) { for (int l = 0; l < 8; l++) free_level(c, P.lv[l]); c->pyr.erase(id); return rc; }
     J.levels = P.levels;
-    if (!P.ready) CML_CHECK(c, hipEventCreateWithFlags(&P.ready, hipEventDisableTiming));
+    if (!P.ready && hipEventCreateWithFlags(&P.ready, hipEventDisableTiming) != hipSuccess) {      // no entry with unfilled levels is left behind
+        for (int l = 0; l < 8; l++) free_level(c, P.lv[l]);
+        c->pyr.erase(id);
+        c->err = "cmlhip_pyramid_build_async: hipEventCreateWithFlags failed";
+        return CMLHIP_ERR_HIP;
+    }
     J.ready = P.ready;
     P.pending = true;
     { std::lock_guard<std::mutex> lk(c->pyr_mu); c->pyr_state[id] = 1; c->pyr_jobs.push_back(J); }

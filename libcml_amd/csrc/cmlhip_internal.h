@@ -42,6 +42,7 @@ struct Pyramid {
     // `ready` is recorded behind the last kernel; the first consumer (cml_find_pyr) waits for the worker to have enqueued everything and
     // orders the context's stream behind the event.
     bool pending = false;
+    bool failed = false;          // the image worker could not copy / build it: the entry stays (its blocks are released by cmlhip_pyramid_drop) but is never handed out
     hipEvent_t ready = nullptr;
 };
 struct PyrJob { uint64_t id; const float* src; int levels; int w[8], h[8]; float* gray[8]; void* grad[8]; hipEvent_t ready; };
@@ -184,6 +185,7 @@ struct cmlhip_ctx {
     DevBuf cd_idepth[8], cd_wsum[8], cd_wbak[8], cd_cnt, cd_pts;      // makeCoarseDepth scratch
     // ---------------- reproj
     DevBuf rp_obs, rp_poses, rp_points, rp_M, rp_b, rp_Jp, rp_used, rp_x, rp_off, rp_orig; int rp_acc_N = 0;
+    DevBuf trk_early;                                         // cmlhip_tracker_set_early_exit: the word hypothesis 0 raises (own buffer, cleared per armed launch)
     DevBuf trk_xch;                                           // cmlhip_tracker_optimize_batch: partial sums + tickets of the workgroups of a hypothesis
     void* trk_opt_host = nullptr; size_t trk_opt_host_bytes = 0;   // mapped, coherent host block of cmlhip_tracker_optimize_batch: hypotheses in, results out
     unsigned trk_xch_gen = 0; int trk_epoch = 0;              // tracker exchange buffer: cleared once per ALLOCATION (DevBuf::gen) and when the 16-bit launch number wraps (tracker_opt.hip)

@@ -870,7 +870,14 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     A.out_host = reinterpret_cast<cmlhip_tracker_opt_result*>(static_cast<char*>(dptr) + hyp_bytes);
     A.xch = c->trk_xch.as<float>(); A.tick = reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes);
     A.early_rmse = (float)c->trk_early_rmse;
-    A.early_flag = (c->trk_early_rmse > 0.0 && n_hyp > 1) ? reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes + tick_bytes) : nullptr;
+    // the early-exit word has a buffer of its own (a fixed address, cleared for every launch that arms it): inside trk_xch its offset moved with
+    // (n_hyp, G) and could fall on a stale exchange word of an earlier, larger launch
+    A.early_flag = nullptr;
+    if (c->trk_early_rmse > 0.0 && n_hyp > 1) {
+        if ((rc = cml_ensure(c, c->trk_early, 64))) return rc;
+        CML_CHECK(c, hipMemsetAsync(c->trk_early.p, 0, 4, c->stream));
+        A.early_flag = c->trk_early.as<int>();
+    }
     A.late = reinterpret_cast<int*>(static_cast<char*>(dptr) + hyp_bytes + res_bytes);
     // (no per-call clearing: the words carry the launch number; a fresh or moved buffer is cleared once)
     // cleared once per ALLOCATION (DevBuf::gen, not the address: a free + malloc may hand the address back) and whenever the 16-bit launch

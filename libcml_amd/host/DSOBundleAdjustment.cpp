@@ -1138,6 +1138,7 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
 }
 
 bool DSOBundleAdjustment::iterateResident(int k, double lambda) {
+    if (k > 0) mPairsValid = false;                          // (the device's frame step rewrites the pair records: the next setPairs must send them)
     for (int i = 0; i < k; i++) {
         const int rc = cmlhip_ba_iteration_async(mCtx, lambda);
         if (rc) return fail("cmlhip_ba_iteration_async", rc);

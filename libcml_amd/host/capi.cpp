@@ -53,6 +53,12 @@ void cmlhost_ba_set_frame_state(void* h, int f, const double state[10]) {
     b->getFrames()[f].setState(state, sc);
 }
 void cmlhost_ba_set_frame_energy_th(void* h, int f, double th) { static_cast<DSOBundleAdjustment*>(h)->getFrames()[f].frameEnergyTH = th; }
+// INDEX LIFETIME.  Point / residual indices (what cmlhost_ba_add_point(s), cmlhost_tracer_add_activated_to_ba return, what cmlhost_ba_outliers and the
+// export calls report) number the object's lists as they stand NOW.  Entries that were dropped (outliers, marginalised points, residuals the closing pass
+// of run() removed, everything of a marginalised frame) stay in the lists, flagged dead, until the lists are renumbered — by the next cmlhost_ba_add_frame
+// (BA::addNewFrame) or, if something was dropped since, at the start of the next run().  A renumbering keeps the order of the survivors and invalidates
+// every index handed out before it; cmlhost_ba_outliers refers to the lists as they were when the last run() returned, so read it before the next
+// cmlhost_ba_add_frame.  (The reference has no such indices: its sets simply lose the objects.)
 int cmlhost_ba_add_point(void* h, float x, float y, double idepth, int host, const float colors[8], const float weights[8], int prior) {
     return static_cast<DSOBundleAdjustment*>(h)->addPoint(x, y, idepth, host, colors, weights, prior != 0);
 }

@@ -314,6 +314,8 @@ class DirectPipeline:
         if self._prefetched is not None and self._prefetched[1] is gray:
             iid = self._prefetched[0]                                 # built (or being built) by the image worker: the first call that names it waits on the device
         else:
+            if self._prefetched is not None:                          # a prefetched image that is not this frame (the caller passed another array): its id and
+                self._drop(self._prefetched[0])                       # device pyramid go back to the pool instead of leaking
             iid = self._take_id()
             self._c("pyramid_build", self.ctx.pyramid_build, iid, gray, self.levels)
         self._prefetched = None

@@ -25,7 +25,12 @@ seg("acc pair: load+accumulate loop", 16, 17); seg("acc pair: tile sum + H", 17,
 seg("solve: load+scale (total)", 48, 49); seg("solve:   loads landed (wave 0)", 48, 54); seg("solve: factorization", 49, 50); seg("solve: forward subst", 50, 51); seg("solve: backward subst", 51, 52); seg("solve: write x", 52, 53)
 seg("solve: total", 48, 53)
 nbk = (4 + 8 * W.N - 4 + 15) // 16
-print("solve per block column (elimination | trailing update) us:", " ".join("%.2f|%.2f" % ((out[65 + 2 * k] - out[64 + 2 * k]) * 0.01, ((out[66 + 2 * k] if k + 1 < nbk else out[50]) - out[65 + 2 * k]) * 0.01) for k in range(nbk)))
+def _bc(k):
+    a, b, c_ = out[64 + 2 * k], out[65 + 2 * k], (out[66 + 2 * k] if k + 1 < nbk else out[50])
+    if a <= 0 or b <= 0 or c_ <= 0:
+        return "n/a"                                              # (the look-ahead factorisation of wide windows does not stamp its block columns)
+    return "%.2f|%.2f" % ((b - a) * 0.01, (c_ - b) * 0.01)
+print("solve per block column (elimination | trailing update) us:", " ".join(_bc(k) for k in range(nbk)))
 
 names = ["linearize", "acc", "system", "solve", "backsub"]
 blk = out[128:].reshape(5, 1024, 2)

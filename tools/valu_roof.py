@@ -8,7 +8,7 @@ SQ_ACTIVE_INST_ANY, SQ_INSTS_SALU, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, averaged over
   valu_insts_per_wave  = SQ_INSTS_VALU / SQ_WAVES
   cycles_per_valu_inst = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU        (the SQ_ACTIVE_* counters tick in quad-cycles)
 Beside them the static count from the code object (llvm-objdump -d): vector instructions of the kernel by class, fp64 share.
-Writes gpurun_out/round4_valu_roof_<config>.json; copy into profiles/."""
+Writes gpurun_out/round5_valu_roof_<config>.json; copy into profiles/."""
 import csv, glob, json, os, re, shutil, subprocess, sys, tempfile
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +26,7 @@ for ctr in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     rows = list(csv.DictReader(open(f[0]))) if f else []
     vals = [float(r["Counter_Value"]) for r in rows if KERN in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr]
-    names = sorted({r.get("Kernel_Name", "")[:48] for r in rows if KERN in r.get("Kernel_Name", "")})
+    names = sorted({r.get("Kernel_Name", "")[:96] for r in rows if KERN in r.get("Kernel_Name", "")})
     res["counters"][ctr] = {"avg": sum(vals) / len(vals) if vals else None, "launches": len(vals)}
     res["kernel"] = names[0] if names else res.get("kernel")
     shutil.rmtree(d, ignore_errors=True)
@@ -51,17 +51,23 @@ try:
     t = os.path.join(d, os.path.basename(o)); shutil.copy(o, t)
     subprocess.run([BIN + "llvm-objdump", "--offloading", t], capture_output=True, cwd=d)
     co = [f for f in os.listdir(d) if "amdgcn" in f]
-    dis = subprocess.run([BIN + "llvm-objdump", "-d", os.path.join(d, co[0])], capture_output=True, text=True).stdout
+    dis = subprocess.run([BIN + "llvm-objdump", "-d", "-C", os.path.join(d, co[0])], capture_output=True, text=True).stdout      # -C: demangled symbols, comparable with the profiler's kernel names
     want = "k_ba_lin_rs" if cfg == "E" else "k_ba_lin_rs4_2d"
+    # the instantiation the PROFILED launches used (kernel name of the counter rows, up to its argument list): the static count is taken from that
+    # symbol and no other (round 4 picked the longest instantiation of the name, which was not the profiled one)
+    prof = (res.get("kernel") or "").replace("void ", "").split("(")[0].strip()
     best = None
     for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
         m = re.match(r"[0-9a-f]+ <([^>]+)>:", blk)
         if not m or want not in m.group(1) or "batch" in m.group(1):
             continue
+        sym = m.group(1).replace("void ", "").split("(")[0].strip()
+        if prof and sym.replace(" ", "") != prof.replace(" ", ""):
+            continue
         ins = [ln.split("\t")[1].split()[0] for ln in blk.splitlines()[1:] if "\t" in ln and len(ln.split("\t")) > 1 and ln.split("\t")[1].strip()]
         valu = [i for i in ins if i.startswith("v_")]
         f64 = [i for i in valu if "f64" in i]
-        cand = {"symbol": m.group(1)[:64], "instructions": len(ins), "valu": len(valu), "valu_f64": len(f64), "salu": len([i for i in ins if i.startswith("s_")]),
+        cand = {"symbol": m.group(1)[:96], "matches_profiled_kernel": bool(prof), "instructions": len(ins), "valu": len(valu), "valu_f64": len(f64), "salu": len([i for i in ins if i.startswith("s_")]),
                 "mfma": len([i for i in valu if "mfma" in i]), "vmem": len([i for i in ins if i.startswith(("global_", "buffer_", "flat_"))]), "lds": len([i for i in ins if i.startswith("ds_")])}
         if best is None or cand["instructions"] > best["instructions"]:
             best = cand
@@ -75,5 +81,5 @@ try:
     res["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or "worktree"
 except Exception:
     res["commit"] = "worktree"
-json.dump(res, open(os.path.join(OUT, "round4_valu_roof_%s.json" % cfg), "w"), indent=1)
+json.dump(res, open(os.path.join(OUT, "round5_valu_roof_%s.json" % cfg), "w"), indent=1)
 print(json.dumps(res))
