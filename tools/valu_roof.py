@@ -44,37 +44,42 @@ if c.get("SQ_WAVES") and c.get("SQ_INSTS_VALU"):
 res["simds"] = 1024            # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 res["clock_ghz"] = 2.4
 # static ISA count of the kernel the launch used
-try:
+def static_isa(cfg, profiled_kernel):
+    """vector / scalar / memory instruction counts of ONE instantiation — the one whose demangled name equals the profiled kernel's (up to its argument list)"""
     BIN = "/opt/rocm/lib/llvm/bin/"
     o = os.path.join(ROOT, "libcml_amd", "csrc", "ba_linearize_rs.o" if cfg == "E" else "ba_linearize_rs4.o")
     d = tempfile.mkdtemp()
-    t = os.path.join(d, os.path.basename(o)); shutil.copy(o, t)
-    subprocess.run([BIN + "llvm-objdump", "--offloading", t], capture_output=True, cwd=d)
-    co = [f for f in os.listdir(d) if "amdgcn" in f]
-    dis = subprocess.run([BIN + "llvm-objdump", "-d", "-C", os.path.join(d, co[0])], capture_output=True, text=True).stdout      # -C: demangled symbols, comparable with the profiler's kernel names
-    want = "k_ba_lin_rs" if cfg == "E" else "k_ba_lin_rs4_2d"
-    # the instantiation the PROFILED launches used (kernel name of the counter rows, up to its argument list): the static count is taken from that
-    # symbol and no other (round 4 picked the longest instantiation of the name, which was not the profiled one)
-    prof = (res.get("kernel") or "").replace("void ", "").split("(")[0].strip()
-    best = None
-    for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
-        m = re.match(r"[0-9a-f]+ <([^>]+)>:", blk)
-        if not m or want not in m.group(1) or "batch" in m.group(1):
-            continue
-        sym = m.group(1).replace("void ", "").split("(")[0].strip()
-        if prof and sym.replace(" ", "") != prof.replace(" ", ""):
-            continue
-        ins = [ln.split("\t")[1].split()[0] for ln in blk.splitlines()[1:] if "\t" in ln and len(ln.split("\t")) > 1 and ln.split("\t")[1].strip()]
-        valu = [i for i in ins if i.startswith("v_")]
-        f64 = [i for i in valu if "f64" in i]
-        cand = {"symbol": m.group(1)[:96], "matches_profiled_kernel": bool(prof), "instructions": len(ins), "valu": len(valu), "valu_f64": len(f64), "salu": len([i for i in ins if i.startswith("s_")]),
-                "mfma": len([i for i in valu if "mfma" in i]), "vmem": len([i for i in ins if i.startswith(("global_", "buffer_", "flat_"))]), "lds": len([i for i in ins if i.startswith("ds_")])}
-        if best is None or cand["instructions"] > best["instructions"]:
-            best = cand
-    res["static_isa"] = best
-    if best and best["valu"]:
-        res["fp64_share"] = best["valu_f64"] / best["valu"]
-    shutil.rmtree(d, ignore_errors=True)
+    try:
+        t = os.path.join(d, os.path.basename(o)); shutil.copy(o, t)
+        subprocess.run([BIN + "llvm-objdump", "--offloading", t], capture_output=True, cwd=d)
+        co = [f for f in os.listdir(d) if "amdgcn" in f]
+        dis = subprocess.run([BIN + "llvm-objdump", "-d", "-C", os.path.join(d, co[0])], capture_output=True, text=True).stdout      # -C: demangled symbols, comparable with the profiler's kernel names
+        want = "k_ba_lin_rs" if cfg == "E" else "k_ba_lin_rs4_2d"
+        prof = (profiled_kernel or "").replace("void ", "").split("(")[0].replace(" ", "")
+        best = None
+        for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+            m = re.match(r"[0-9a-f]+ <(.+)>:\s*$", blk.splitlines()[0]) if blk else None      # (demangled names contain '>': take everything up to the closing '>:')
+            if not m or want not in m.group(1) or "batch" in m.group(1):
+                continue
+            sym = m.group(1).replace("void ", "").split("(")[0].replace(" ", "")
+            if prof and sym != prof:
+                continue
+            ins = [ln.split("\t")[1].split()[0] for ln in blk.splitlines()[1:] if "\t" in ln and len(ln.split("\t")) > 1 and ln.split("\t")[1].strip()]
+            valu = [i for i in ins if i.startswith("v_")]
+            f64 = [i for i in valu if "f64" in i]
+            cand = {"symbol": m.group(1)[:96], "matches_profiled_kernel": bool(prof), "instructions": len(ins), "valu": len(valu), "valu_f64": len(f64), "salu": len([i for i in ins if i.startswith("s_")]),
+                    "mfma": len([i for i in valu if "mfma" in i]), "vmem": len([i for i in ins if i.startswith(("global_", "buffer_", "flat_"))]), "lds": len([i for i in ins if i.startswith("ds_")])}
+            if best is None or cand["instructions"] > best["instructions"]:
+                best = cand
+        return best
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+try:
+    res["static_isa"] = static_isa(cfg, res.get("kernel"))
+    if res["static_isa"] and res["static_isa"]["valu"]:
+        res["fp64_share"] = res["static_isa"]["valu_f64"] / res["static_isa"]["valu"]
 except Exception as e:
     res["static_isa"] = {"error": repr(e)}
 try:
