@@ -621,6 +621,10 @@ typedef struct {
     cmlhip_ba_lin_result* last;         /* last pass of the loop */
     int* iterations; double* energies; int capacity;      /* as cmlhip_ba_get_resident_log */
     double* x;                          /* 8N+4: x of the last solve */
+    /* compact forms of the closing pass's outputs, packed on the device in the CALLER's order (no permutation on the host, a tenth of the bytes):
+     * state_good[r] = state_state | isActiveAndIsGoodNEW << 2 (R bytes); hdi[p] = HdiF of point p (P floats: setInverseDepthHessian, BA.cpp:1889-1901) */
+    unsigned char* state_good;
+    float* hdi;
 } cmlhip_ba_resident_out;
 int cmlhip_ba_finish_run(cmlhip_ctx* ctx, int reanchor_newest, const cmlhip_ba_resident_out* resident, cmlhip_ba_lin_result* lin, int* state,
                          int* new_state, float* energy, float* new_energy, float* new_energy_without_outlier, unsigned char* is_good,

@@ -140,7 +140,8 @@ class BAFrameState(C.Structure):
 class BAResidentOut(C.Structure):
     """cmlhip_ba_resident_out (cmlhip_ba_finish_run: the resident loop's results, read back with the closing pass in one copy)."""
     _fields_ = [("frames", C.POINTER(BAFrameState)), ("pre_w2c", c_double_p), ("first", C.POINTER(BALinResult)), ("last", C.POINTER(BALinResult)),
-                ("iterations", C.POINTER(C.c_int)), ("energies", c_double_p), ("capacity", C.c_int), ("x", c_double_p)]
+                ("iterations", C.POINTER(C.c_int)), ("energies", c_double_p), ("capacity", C.c_int), ("x", c_double_p),
+                ("state_good", C.POINTER(C.c_ubyte)), ("hdi", c_float_p)]
 
 
 # ---- immature points (DSOTracer, SURVEY §8 f1)

@@ -647,6 +647,7 @@ int cmlhip_ba_linearize_apply(cmlhip_ctx* c, cmlhip_ba_lin_result* out) { CML_DE
         c->arith_relaxed = relaxed;
         c->efs_in_partials = true; c->lin_partial_n = c->n_tiles;
     } else cml_launch_linearize(c, A);
+    if (!out) cml_mark(c, "pass0");
     if (!out) {                                             // enqueue only: the pass's tail (energy sum, setNewFrameEnergyTH) stays pending — it rides in the next
         c->lin_finish_pending = true;                       // iteration's solve launch like every later pass's (its energy is logged as ResidentCtl::energy0 when
         CML_CHECK(c, hipGetLastError());                    // cmlhip_ba_resident_convergence armed the log), or runs when a getter / cmlhip_ba_finish_run asks
@@ -763,6 +764,14 @@ __global__ __launch_bounds__(1024) void k_ba_finish_reanchor(BAArgs A, const int
     else reanchor_newest_block(fs, pre_w2c, pairs, frames_rw, A.N, scale_b, snap, reinterpret_cast<double (*)[7]>(s_f64));
 }
 
+// what the host's bookkeeping behind the closing pass reads, packed in the CALLER's order: one byte per residual, one float per point
+__global__ void k_ba_pack_closing(int R, int P, const int* __restrict__ c_dev_of, const int* __restrict__ r_state, const unsigned char* __restrict__ r_good,
+                                  const float* __restrict__ pt_acc, unsigned char* __restrict__ sg, float* __restrict__ hdi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) { const int k = c_dev_of[i]; sg[i] = (unsigned char)((r_state[k] & 3) | (r_good[k] ? 4 : 0)); }
+    if (i < P) hdi[i] = pt_acc[(size_t)PT_ACC_STRIDE * i + 12];
+}
+
 // The tail of DSOBundleAdjustment::run with the loop resident on the device, in ONE readback: what cmlhip_ba_get_resident_state / _log / _indirect return
 // after the iterations (frame states, PRE_worldToCam, the preamble pass's and the last pass's summaries, the energy log, x), then — reanchor_newest —
 // the newest frame re-anchored on the device (k_ba_reanchor_newest) and cmlhip_ba_finish_keyframe's closing pass with its outputs.
@@ -807,6 +816,16 @@ int cmlhip_ba_finish_run(cmlhip_ctx* c, int reanchor_newest, const cmlhip_ba_res
     } else cml_launch_linearize(c, A);
     cml_launch_lin_finish(c, A, CML_CLOSE_OFFSET);
     CML_CHECK(c, hipGetLastError());
+    cml_mark(c, "closing");
+    const bool packed = ro && (ro->state_good || ro->hdi);
+    const size_t sg_bytes = (R + 255) & ~size_t(255);
+    if (packed) {
+        if ((rc = cml_ensure(c, c->run_pack, sg_bytes + 4 * P + 256))) return rc;
+        const int work = (int)std::max(R, P);
+        if (work > 0) k_ba_pack_closing<<<cml_div_up(work, 256), 256, 0, c->stream>>>((int)R, (int)P, c->c_dev_of.as<int>(), c->r_state.as<int>(), c->r_good.as<unsigned char>(),
+                                                                                     c->pt_acc.as<float>(), c->run_pack.as<unsigned char>(), reinterpret_cast<float*>(c->run_pack.as<char>() + sg_bytes));
+        CML_CHECK(c, hipGetLastError());
+    }
     LinSummary S, Sfirst, Slast;
     ResidentCtl ctl;
     std::vector<float> pacc(point_acc ? PT_ACC_STRIDE * P : 0);
@@ -819,12 +838,15 @@ int cmlhip_ba_finish_run(cmlhip_ctx* c, int reanchor_newest, const cmlhip_ba_res
         if (ro->frames) cml_d2h(c, ro->frames, reanchor_newest ? c->run_snap.p : c->frame_state.p, sizeof(cmlhip_ba_frame_state) * N);
         if (ro->pre_w2c) cml_d2h(c, ro->pre_w2c, c->pre_w2c.p, 8 * 7 * N);
         if (ro->x) cml_d2h(c, ro->x, c->xvec.p, 8 * n);
+        if (ro->state_good && R) cml_d2h(c, ro->state_good, c->run_pack.p, R);
+        if (ro->hdi && P) cml_d2h(c, ro->hdi, c->run_pack.as<char>() + sg_bytes, 4 * P);
     }
     rr.add(state, c->r_state.p, 4); rr.add(new_state, c->r_new_state.p, 4); rr.add(energy, c->r_energy.p, 4);
     rr.add(new_energy, c->r_new_energy.p, 4); rr.add(new_energy_wo, c->r_new_energy_wo.p, 4); rr.add(is_good, c->r_good.p, 1);
     if (idepth) cml_d2h(c, idepth, c->pt_idepth.p, 8 * P);
     if (point_acc && P) cml_d2h(c, pacc.data(), c->pt_acc.p, 4 * pacc.size());
     if ((rc = cml_d2h_batch_flush(c))) return rc;
+    cml_mark(c, "gathered"); (void)hipStreamSynchronize(c->stream); cml_marks_dump(c);
     rr.deliver();
     if (point_acc) for (size_t p = 0; p < P; p++) memcpy(point_acc + 14 * p, &pacc[PT_ACC_STRIDE * p], 14 * 4);
     auto put = [](cmlhip_ba_lin_result* o, const LinSummary& s) { if (o) { o->energy = s.energy; o->n_in = s.n_in; o->n_oob = s.n_oob; o->n_outlier = s.n_outlier; o->new_frame_energy_th = s.new_frame_energy_th; } };
@@ -1004,6 +1026,7 @@ int cmlhip_ba_iteration_async(cmlhip_ctx* c, double lambda) { CML_DEV(c);
     c->lin_finish_pending = true;
     if (prof) c->prof_n++;
     CML_CHECK(c, hipGetLastError());
+    cml_mark(c, "iter");
     return CMLHIP_OK;
 }
 

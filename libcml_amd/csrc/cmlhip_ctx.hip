@@ -11,6 +11,21 @@ void cml_window_free(cmlhip_ctx* c) {
     if (W.block) (void)hipHostFree(W.block);
     W = WindowShadow{};
 }
+void cml_mark(cmlhip_ctx* c, const char* what) {
+    static const bool on = getenv("CMLHIP_RUN_MARKS") != nullptr;
+    if (!on) return;
+    if (c->marks_n == c->marks.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->marks.push_back({what, e}); }
+    c->marks[c->marks_n].first = what;
+    (void)hipEventRecord(c->marks[c->marks_n].second, c->stream);
+    c->marks_n++;
+}
+void cml_marks_dump(cmlhip_ctx* c) {          // (call behind a stream synchronise)
+    if (c->marks_n < 2) { c->marks_n = 0; return; }
+    fprintf(stderr, "  [device timeline, us since '%s']", c->marks[0].first);
+    for (size_t i = 1; i < c->marks_n; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->marks[0].second, c->marks[i].second); fprintf(stderr, " %s %.1f |", c->marks[i].first, 1e3 * ms); }
+    fprintf(stderr, "\n");
+    c->marks_n = 0;
+}
 int cml_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.bytes >= bytes) return CMLHIP_OK;
@@ -142,6 +157,7 @@ int cml_scope_end(cmlhip_ctx* c) {
     std::vector<std::function<int()>> run;
     run.swap(c->deferred);
     for (auto& f : run) { const int r = f(); if (!rc) rc = r; }
+    cml_mark(c, "scope");
     return rc;
 }
 extern "C" int cmlhip_upload_scope_begin(cmlhip_ctx* c) {
@@ -274,7 +290,7 @@ int cml_d2h_batch_flush(cmlhip_ctx* c) {
         memcpy(T.s, c->d2h_segs.data(), sizeof(unsigned long long) * 3 * nseg);
         k_d2h_gather_direct<<<dim3(16, (unsigned)nseg), 256, 0, c->stream>>>(T, static_cast<char*>(c->pinned_d2h));
         CML_CHECK(c, hipGetLastError());
-        CML_CHECK(c, hipStreamSynchronize(c->stream));
+        CML_CHECK(c, hipStreamSynchronize(c->stream));          // (polling an event behind the kernel instead was measured: 12 us SLOWER per run())
     } else {
         if ((rc = cml_h2d(c, c->h2d_desc.p, c->d2h_segs.data(), sizeof(unsigned long long) * 3 * nseg))) return rc;
         k_d2h_gather<<<dim3(16, (unsigned)nseg), 256, 0, c->stream>>>(c->h2d_desc.as<unsigned long long>(), c->d2h_blob.as<char>());
@@ -377,7 +393,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
                      &c->syrk_part, &c->solve_image, &c->xad, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,
                      &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x, &c->rp_off, &c->rp_orig,
                      &c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x, &c->rr_ready, &c->trk_xch, &c->x_ticket, &c->batch_main, &c->batch_rs,
-                     &c->trk_early, &c->run_snap, &c->c_point, &c->c_target, &c->c_state, &c->c_lin, &c->c_dev_of, &c->c_bpos};
+                     &c->trk_early, &c->run_pack, &c->run_snap, &c->c_point, &c->c_target, &c->c_state, &c->c_lin, &c->c_dev_of, &c->c_bpos};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
     cml_window_free(c);

@@ -165,9 +165,11 @@ struct cmlhip_ctx {
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)
+    DevBuf run_pack;                                          // cmlhip_ba_finish_run: state | good << 2 per caller residual, HdiF per point (k_ba_pack_closing)
     DevBuf run_snap;                                          // cmlhip_ba_finish_run: the loop's last summary + frame states, kept across the re-anchoring and the closing pass
     bool resident_on = false, have_null = false, lin_finish_pending = false; int resident_iter = 0; double res_scales[4] = {1, 1, 1, 1}; double conv_th = 0; bool conv_on = false;
     DevBuf dbg; bool dbg_on = false;                          // phase timestamps (tools)
+    std::vector<std::pair<const char*, hipEvent_t>> marks; size_t marks_n = 0;   // development (CMLHIP_RUN_MARKS=1): events behind the stages of a run(), printed by cmlhip_ba_finish_run
     DevBuf step_partial;                                      // per-block {sumID, sumNID, numID, pad} of the point update
     int n_lin_partial = 0; double last_lambda = 1e-5; bool last_have_hm = false; double sys_lambda = 1e-5;
     DevBuf G;                                                 // P x ldg doubles (Schur rows [g | bdSum])
@@ -198,6 +200,8 @@ struct cmlhip_ctx {
 
 // every extern "C" entry selects its context's device first: the current device is per-thread state and a process may own
 // contexts on several GPUs
+void cml_mark(cmlhip_ctx* c, const char* what);               // development: no-op unless CMLHIP_RUN_MARKS is set
+void cml_marks_dump(cmlhip_ctx* c);
 int cml_scope_end(cmlhip_ctx* c);                              // flush the open upload scope (if any) and run what was deferred
 #define CML_DEV(ctx) do { if (ctx) { (void)hipSetDevice((ctx)->device); if ((ctx)->h2d_scope) (void)cml_scope_end(ctx); } } while (0)
 #define CML_DEV_SCOPED(ctx) do { if (ctx) (void)hipSetDevice((ctx)->device); } while (0)      /* entries that stage into an open upload scope */

@@ -1234,16 +1234,19 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     cmlhip_ba_lin_result first{}, last{}, lr{};
     int its = 0;
     mX.assign(8 * (size_t)N + CMLHIP_CPARS, 0.0);
-    cmlhip_ba_resident_out ro{fs.data(), pre.data(), &first, &last, &its, en.data(), (int)en.size(), mX.data()};
+    // the closing pass's per-residual state / good flag come back as ONE byte each, already in this object's order, and HdiF as one float per point
+    std::vector<unsigned char> sg(R);
+    std::vector<float> hdiv(mActivePoints.size());
+    cmlhip_ba_resident_out ro{fs.data(), pre.data(), &first, &last, &its, en.data(), (int)en.size(), mX.data(), sg.data(), hdiv.data()};
     std::vector<int> st(R), ns;
     std::vector<float> e, ne, nw;
     std::vector<unsigned char> good(R);
     if (mKeepResidualEnergies) { ns.resize(R); e.resize(R); ne.resize(R); nw.resize(R); }
     std::vector<double> idp(mActivePoints.size());
-    std::vector<float> pacc(14 * mActivePoints.size() + 14);
-    rc = cmlhip_ba_finish_run(mCtx, 1, &ro, &lr, st.data(), mKeepResidualEnergies ? ns.data() : nullptr, mKeepResidualEnergies ? e.data() : nullptr,
-                              mKeepResidualEnergies ? ne.data() : nullptr, mKeepResidualEnergies ? nw.data() : nullptr, good.data(), idp.data(), pacc.data());
+    rc = cmlhip_ba_finish_run(mCtx, 1, &ro, &lr, nullptr, mKeepResidualEnergies ? ns.data() : nullptr, mKeepResidualEnergies ? e.data() : nullptr,
+                              mKeepResidualEnergies ? ne.data() : nullptr, mKeepResidualEnergies ? nw.data() : nullptr, nullptr, idp.data(), nullptr);
     if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_finish_run", rc);
+    for (int k = 0; k < R; k++) { st[k] = sg[k] & 3; good[k] = (sg[k] >> 2) & 1; }
     const double t_end = us();
     lastRunUs[4] = t_end - t_enq;
     lap("finish_run returned");
@@ -1275,7 +1278,7 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
         DSOPoint& P = mPoints[mActivePoints[k]];
         P.idepth = idp[k];
         P.idepth_zero = (float)idp[k];
-        const float hdi = pacc[14 * k + 12];
+        const float hdi = hdiv[k];
         P.idepth_hessian = hdi > 0 ? 1.0f / hdi : 0.f;
     }
     lastRunUs[5] = us() - t_end;
