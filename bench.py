@@ -945,6 +945,8 @@ def main():
     rank, local_rank, world = shard.env_world()
     if world != args.gpus and world > 1:
         args.gpus = world
+    if os.environ.get("CML_BENCH_SHARE_DEVICE"):                          # tests: every rank on device 0 (the N > 1 path of this file on a one-GPU box, with CML_SHARD_BACKEND=gloo)
+        local_rank = 0
     import torch
     dev = None
     if torch.cuda.is_available():

@@ -30,7 +30,8 @@ class Group:
             os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # CML_SHARD_BACKEND=gloo: the CPU backend on a GPU box (tests: two ranks that SHARE one GPU — RCCL refuses two ranks on one device)
+                backend = os.environ.get("CML_SHARD_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if not dist.is_initialized():
                 dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             self.dist = dist
