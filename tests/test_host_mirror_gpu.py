@@ -251,3 +251,41 @@ def test_host_loop_with_step_rejection():
         assert np.abs(e_dev[1:1 + k] / e_ref[1:1 + k] - 1).max() < 5e-3
     finally:
         ba.close(); ctx.close()
+
+
+@pytest.mark.parametrize("config", ["small", "medium"])
+def test_one_wait_run_equals_the_stepwise_run(config):
+    """run() with ONE host wait (upload scopes, preamble pass enqueue-only with its tail in the first solve launch, the newest frame re-anchored on the device,
+    closing pass through the resident residual kernel, packed outputs: cmlhip_ba_finish_run) against the same run with a host wait behind every stage
+    (CMLHOST_RUN_STEPWISE=1: first pass read back, three getters behind the loop, re-anchoring on the host, closing pass through the record kernel).
+    The iterations are the same device work: iteration count and energy log identical in every bit; the final frame states and inverse depths agree to
+    1e-12 (the closing pass does not move them); the closing pass's decisions — residual states, good flags, outliers, the new energy threshold — identical
+    (its pair records differ by the re-anchoring's rounding only: device exp() against the host's)."""
+    import os
+    res = []
+    for mode in ("stepwise", "one_wait"):
+        I = S.make_inputs(config)
+        ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R)
+        ba = host.window_to_host_ba(ctx, I.W)
+        ba.set_param("iterations", 4)
+        if mode == "stepwise":
+            os.environ["CMLHOST_RUN_STEPWISE"] = "1"
+        try:
+            assert ba.run(), ba.last_error()
+        finally:
+            os.environ.pop("CMLHOST_RUN_STEPWISE", None)
+        idp, alive, ng = ba.points()
+        st, ralive, good = ba.residual_states()
+        res.append(dict(it=ba.counts()["iterations"], e=ba.energies(16).copy(), idp=idp.copy(), alive=alive.copy(), ng=ng.copy(), st=st.copy(), ralive=ralive.copy(),
+                        good=good.copy(), out=sorted(int(x) for x in ba.outliers()), frames=[ba.frame(k) for k in range(I.N)]))
+        ba.close(); ctx.close()
+    a, b = res
+    assert a["it"] == b["it"] == 4
+    assert np.array_equal(a["e"].view(np.uint64), b["e"].view(np.uint64)), (a["e"], b["e"])      # preamble energy / n, then the iterations' energies
+    for fa, fb in zip(a["frames"], b["frames"]):
+        assert np.abs(fa["state"] - fb["state"]).max() <= 1e-12 * max(1.0, np.abs(fa["state"]).max())
+        assert np.abs(fa["R"] - fb["R"]).max() < 1e-12 and np.abs(fa["t"] - fb["t"]).max() < 1e-12
+    assert a["frames"][-1]["th"] == b["frames"][-1]["th"]                                        # setNewFrameEnergyTH of the closing pass
+    assert np.array_equal(a["idp"], b["idp"]) and np.array_equal(a["alive"], b["alive"]) and np.array_equal(a["ng"], b["ng"])
+    assert np.array_equal(a["st"], b["st"]) and np.array_equal(a["ralive"], b["ralive"]) and np.array_equal(a["good"], b["good"])
+    assert a["out"] == b["out"]
