@@ -557,7 +557,9 @@ class SequenceChecker:
             sp_flips = max([dd["flips"] for _n, _i, dd in spread] + [0])
             # (b) is kept for the two-keyframe bootstrap window ONLY (round 5: the 60-sequence soak needed it once in 380 runs — sequence 36, N = 2, pose
             #     inside the fixed bars, energy 1.7e-2 against 5e-3 — and never at N > 2)
-            ok_scale = N == 2 and iter_ok and all(d[k_] <= max(BARS[k_], 4.0 * sp[k_]) for k_ in sp) and d["flips"] <= max(2, I.R // 200) + sp_flips
+            #     — REMOVED at the end of round 5: with the ensemble at ten draws the 60-sequence soak of the final build accepts all 10 of its 380 hatch runs through a
+            #     member (profiles/round5_parity_soak_sequence.txt); the spread is still measured and reported, it no longer accepts anything
+            ok_scale = False
             self.report["run_yardstick_used"] = self.report.get("run_yardstick_used", 0) + 1
             self.report.setdefault("run_yardstick", []).append({"N": N, "R": I.R, "iterations": (o["iterations"], info["iterations"]), "device_vs_oracle": d,
                                                                 "energies_device": [float(x) for x in all_e[-info["iterations"]:]] if info["iterations"] else [], "energies_oracle": [float(x) for x in o["log"]["energy"]],
