@@ -665,6 +665,8 @@ class SplitPipeline:
             with self._cv:
                 while k not in self.done and self._err is None:
                     self._cv.wait(0.5)
+                    if time.perf_counter() - t0 > 300.0:               # never wait forever for a mapper that stopped answering
+                        raise RuntimeError("SplitPipeline: the mapper thread did not hand keyframe %d over within 300 s" % k)
             self.stall_s += time.perf_counter() - t0
             if self._err is not None:
                 raise self._err
