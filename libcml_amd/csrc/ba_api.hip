@@ -358,25 +358,30 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     for (int q = 0; q < NN; q++) { mx_pair = std::max(mx_pair, c->h_by_pair_off[q + 1]); c->h_by_pair_off[q + 1] += c->h_by_pair_off[q]; }
     c->N = N; c->P = P; c->R = R; c->n_lin = n_lin; c->n_newframe = n_newframe;
     const int n = 8 * N + 4, ldg = ldg_of(n), ntile = ldg / 16;
-    // ---- allocations
+    // ---- allocations: by the LIMITS given at create (max_frames / max_points / max_residuals), not by this window's sizes — a window that grows keyframe by
+    //      keyframe (2 -> 7 frames at the start of every sequence) otherwise re-allocates most of its ~90 buffers at every run (measured: 150-500 us of
+    //      hipFree / hipMalloc per run() while the window grows, against 70-90 us for the whole commit at the sliding size).  Only the two tables whose
+    //      stride is data-dependent (largest pair, fullest point) follow the window, with slack.
     int rc = 0;
+    const size_t Nc = (size_t)std::max(N, c->lim.max_frames), Pc = (size_t)std::max(P, c->lim.max_points), Rc = (size_t)std::max(R, c->lim.max_residuals);
+    const size_t NNc = Nc * Nc, nc = 8 * Nc + 4, ldgc = (size_t)ldg_of((int)nc), ntilec = ldgc / 16;
 #define ENS(buf, bytes) if ((rc = cml_ensure(c, buf, (size_t)(bytes)))) return rc
-    ENS(c->frames, sizeof(FrameDev) * N); ENS(c->pairs, sizeof(cmlhip_ba_pair) * N * N);
-    ENS(c->pt_x, 4 * P); ENS(c->pt_y, 4 * P); ENS(c->pt_idepth, 8 * P); ENS(c->pt_idepth_zero, 4 * P); ENS(c->pt_prior, 4 * P);
-    ENS(c->pt_host, 4 * P); ENS(c->pt_colors, 32 * P); ENS(c->pt_weights, 32 * P); ENS(c->pt_backup, 4 * P);
-    ENS(c->pt_acc, 4 * PT_ACC_STRIDE * P); ENS(c->pt_step, 8 * P);
-    ENS(c->r_point, 4 * R); ENS(c->r_host, 4 * R); ENS(c->r_target, 4 * R); ENS(c->r_state, 4 * R); ENS(c->r_new_state, 4 * R);
-    ENS(c->r_energy, 4 * R); ENS(c->r_new_energy, 4 * R); ENS(c->r_new_energy_wo, 4 * R); ENS(c->r_ret_energy, 4 * R);
-    ENS(c->r_good, R); ENS(c->r_lin, R); ENS(c->r_sel, R); ENS(c->r_dead, R); ENS(c->r_center, 12 * R); ENS(c->r_jpjdf, 4 * (size_t)PS_STRIDE * R); ENS(c->r_rtz, 32 * R);
-    ENS(c->rj[0], 4 * (size_t)RJ_STRIDE * R); ENS(c->rj[1], 4 * (size_t)RJ_STRIDE * R);
-    ENS(c->by_point_off, 4 * (P + 1)); ENS(c->by_point, 4 * R); ENS(c->by_pair_off, 4 * (N * N + 1)); ENS(c->by_pair, 4 * R);
-    ENS(c->newframe_res, 4 * (size_t)n_newframe);
-    for (int m = 0; m < 2; m++) { ENS(c->acc_pair[m], 4 * ACC_STRIDE * N * N); ENS(c->acc_num[m], 4 * N * N); }
-    ENS(c->pair_blocks, 2 * 8 * (size_t)PB_STRIDE * N * N);
-    ENS(c->adH, 8 * 64 * N * N); ENS(c->adT, 8 * 64 * N * N); ENS(c->adHTd, 4 * 8 * N * N); ENS(c->vec_small, 8 * (8 + 16 * N));
-    ENS(c->HA, 8 * n * n); ENS(c->HL, 8 * n * n); ENS(c->Hsc, 8 * n * n); ENS(c->HM, 8 * n * n);
-    ENS(c->bA, 8 * n); ENS(c->bL, 8 * n); ENS(c->bsc, 8 * n); ENS(c->bM, 8 * n); ENS(c->xvec, 8 * n);
-    ENS(c->Hf, 8 * n * n); ENS(c->bf, 8 * n);
+    ENS(c->frames, sizeof(FrameDev) * Nc); ENS(c->pairs, sizeof(cmlhip_ba_pair) * NNc);
+    ENS(c->pt_x, 4 * Pc); ENS(c->pt_y, 4 * Pc); ENS(c->pt_idepth, 8 * Pc); ENS(c->pt_idepth_zero, 4 * Pc); ENS(c->pt_prior, 4 * Pc);
+    ENS(c->pt_host, 4 * Pc); ENS(c->pt_colors, 32 * Pc); ENS(c->pt_weights, 32 * Pc); ENS(c->pt_backup, 4 * Pc);
+    ENS(c->pt_acc, 4 * PT_ACC_STRIDE * Pc); ENS(c->pt_step, 8 * Pc);
+    ENS(c->r_point, 4 * Rc); ENS(c->r_host, 4 * Rc); ENS(c->r_target, 4 * Rc); ENS(c->r_state, 4 * Rc); ENS(c->r_new_state, 4 * Rc);
+    ENS(c->r_energy, 4 * Rc); ENS(c->r_new_energy, 4 * Rc); ENS(c->r_new_energy_wo, 4 * Rc); ENS(c->r_ret_energy, 4 * Rc);
+    ENS(c->r_good, Rc); ENS(c->r_lin, Rc); ENS(c->r_sel, Rc); ENS(c->r_dead, Rc); ENS(c->r_center, 12 * Rc); ENS(c->r_jpjdf, 4 * (size_t)PS_STRIDE * Rc); ENS(c->r_rtz, 32 * Rc);
+    ENS(c->rj[0], 4 * (size_t)RJ_STRIDE * Rc); ENS(c->rj[1], 4 * (size_t)RJ_STRIDE * Rc);
+    ENS(c->by_point_off, 4 * (Pc + 1)); ENS(c->by_point, 4 * Rc); ENS(c->by_pair_off, 4 * (NNc + 1)); ENS(c->by_pair, 4 * Rc);
+    ENS(c->newframe_res, 4 * std::max((size_t)n_newframe, Pc));                 // (one residual per point into the newest frame at most)
+    for (int m = 0; m < 2; m++) { ENS(c->acc_pair[m], 4 * ACC_STRIDE * NNc); ENS(c->acc_num[m], 4 * NNc); }
+    ENS(c->pair_blocks, 2 * 8 * (size_t)PB_STRIDE * NNc);
+    ENS(c->adH, 8 * 64 * NNc); ENS(c->adT, 8 * 64 * NNc); ENS(c->adHTd, 4 * 8 * NNc); ENS(c->vec_small, 8 * (8 + 16 * Nc));
+    ENS(c->HA, 8 * nc * nc); ENS(c->HL, 8 * nc * nc); ENS(c->Hsc, 8 * nc * nc); ENS(c->HM, 8 * nc * nc);
+    ENS(c->bA, 8 * nc); ENS(c->bL, 8 * nc); ENS(c->bsc, 8 * nc); ENS(c->bM, 8 * nc); ENS(c->xvec, 8 * nc);
+    ENS(c->Hf, 8 * nc * nc); ENS(c->bf, 8 * nc);
     // ---- wave tiles of the resident residual kernel: <= RS_TILE consecutive device residuals of ONE pair each
     // Tile size by regime: a window that gives the lane-per-residual kernel at least one wave per SIMD runs it (throughput);
     // smaller windows are latency-bound and take 4 lanes per residual.  CMLHIP_RS_TILE=16|64 forces one (development).
@@ -406,23 +411,27 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     }
     c->rs_pair_n = (int)c->h_rs_pair_tab.size() / 4;
     c->n_tiles = (int)tiles.size() / 4;
-    ENS(c->rs_tiles, 16 * (size_t)std::max(c->n_tiles, 1)); ENS(c->rs_tile_off, 4 * (size_t)(N * N + 1));
-    ENS(c->rs_part, 1024 * (size_t)std::max(c->n_tiles, 1));
-    ENS(c->r_px, 4 * R); ENS(c->r_py, 4 * R); ENS(c->r_colors, 32 * R); ENS(c->r_weights, 32 * R); ENS(c->r_idepth, 8 * R);
+    const size_t tiles_c = std::max((size_t)c->n_tiles, Rc / TS + NNc);          // (every pair may end in a partly filled tile)
+    ENS(c->rs_tiles, 16 * std::max(tiles_c, (size_t)1)); ENS(c->rs_tile_off, 4 * (NNc + 1));
+    ENS(c->rs_part, 1024 * std::max(tiles_c, (size_t)1));
+    ENS(c->r_px, 4 * Rc); ENS(c->r_py, 4 * Rc); ENS(c->r_colors, 32 * Rc); ENS(c->r_weights, 32 * Rc); ENS(c->r_idepth, 8 * Rc);
     c->r_idepth_dirty = true;
     c->n_lin_partial = std::max((R + 31) / 32, c->n_tiles);
     c->lin_partial_n = 0; c->efs_in_partials = false;
-    ENS(c->lin_partial, 32 * (size_t)(c->n_lin_partial + 1)); ENS(c->step_partial, 16 * (size_t)((P + 31) / 32 + 1));
-    ENS(c->G, 8 * ((size_t)P * ldg + P));
-    ENS(c->syrk_part, 8 * 256 * (size_t)(ntile * (ntile + 1) / 2) * cml_sys_slices(P));
-    ENS(c->xad, 8 * 8 * (size_t)N * N);
-    ENS(c->solve_image, 8 * ((size_t)(ntile * (ntile + 1) / 2) * 16 * 17 + 32 * (size_t)ntile));      // k_ba_assemble (wide windows)
+    ENS(c->lin_partial, 32 * (std::max((Rc + 31) / 32, tiles_c) + 1)); ENS(c->step_partial, 16 * ((Pc + 31) / 32 + 1));
+    ENS(c->G, 8 * (Pc * ldgc + Pc));
+    ENS(c->syrk_part, 8 * 256 * (ntilec * (ntilec + 1) / 2) * (size_t)cml_sys_slices((int)Pc));
+    ENS(c->xad, 8 * 8 * NNc);
+    ENS(c->solve_image, 8 * ((ntilec * (ntilec + 1) / 2) * 16 * 17 + 32 * ntilec));      // k_ba_assemble (wide windows)
     ENS(c->scal, 1024);
     c->pair_stride = (mx_pair + 3) & ~3;
     c->pt_stride = (mx_pt + 7) & ~7;
     const size_t pt_tot = (size_t)std::max(P, 1) * c->pt_stride;
-    ENS(c->pair_code, 4 * (size_t)NN * c->pair_stride); ENS(c->pair_pos, 4 * (size_t)std::max(R, 1));
-    ENS(c->point_code, 4 * pt_tot); ENS(c->point_tgt, 4 * pt_tot); ENS(c->point_pos, 4 * (size_t)std::max(R, 1)); ENS(c->point_res, 4 * pt_tot);
+    const size_t pt_tot_c = Pc * (size_t)std::max(c->pt_stride, (int)(((Nc - 1) + 7) & ~size_t(7)));      // a point has at most one residual per other frame
+    const size_t pair_need = (size_t)NN * c->pair_stride;
+    if (c->pair_code.bytes < 4 * pair_need) ENS(c->pair_code, 4 * (pair_need + pair_need / 2));          // data-dependent stride: follows the window, with slack
+    ENS(c->pair_pos, 4 * std::max(Rc, (size_t)1));
+    ENS(c->point_code, 4 * std::max(pt_tot_c, pt_tot)); ENS(c->point_tgt, 4 * std::max(pt_tot_c, pt_tot)); ENS(c->point_pos, 4 * std::max(Rc, (size_t)1)); ENS(c->point_res, 4 * std::max(pt_tot_c, pt_tot));
 #undef ENS
     lap_("counts+ensure");
     // ---- SoA staging + upload: everything below is staged and leaves in ONE copy + one scatter / fill kernel (cml_h2d_batch_flush)
@@ -447,12 +456,12 @@ static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {
     //      device, so the residual kernel of the resident loop reads the pair record through scalar loads.
     //      The host only ASSIGNS the two positions of every residual (sequential writes); the permutation itself runs on the device (k_window_expand).
     c->h_dev_of.resize(R); c->h_maps_valid = false;
-    if ((rc = cml_ensure(c, c->c_point, 4 * (size_t)R))) return rc;
-    if ((rc = cml_ensure(c, c->c_target, 4 * (size_t)R))) return rc;
-    if ((rc = cml_ensure(c, c->c_state, 4 * (size_t)R))) return rc;
-    if ((rc = cml_ensure(c, c->c_lin, (size_t)R))) return rc;
-    if ((rc = cml_ensure(c, c->c_dev_of, 4 * (size_t)R))) return rc;
-    if ((rc = cml_ensure(c, c->c_bpos, 4 * (size_t)R))) return rc;
+    if ((rc = cml_ensure(c, c->c_point, 4 * Rc))) return rc;
+    if ((rc = cml_ensure(c, c->c_target, 4 * Rc))) return rc;
+    if ((rc = cml_ensure(c, c->c_state, 4 * Rc))) return rc;
+    if ((rc = cml_ensure(c, c->c_lin, Rc))) return rc;
+    if ((rc = cml_ensure(c, c->c_dev_of, 4 * Rc))) return rc;
+    if ((rc = cml_ensure(c, c->c_bpos, 4 * Rc))) return rc;
     {
         Staged s_dv, s_bp, s_nf;
         int* dvd = (int*)stage(s_dv, c->c_dev_of, 4 * (size_t)R); int* bpd = (int*)stage(s_bp, c->c_bpos, 4 * (size_t)R);
@@ -1156,9 +1165,10 @@ int cmlhip_ba_set_resident_state(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, co
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || !frames || !scales)
         return CMLHIP_ERR_INVALID;
     const int N = c->N, n = 8 * N + 4;
-    if ((rc = cml_ensure(c, c->frame_state, sizeof(cmlhip_ba_frame_state) * (size_t)N))) return rc;
-    if ((rc = cml_ensure(c, c->pre_w2c, 8 * 7 * (size_t)N))) return rc;
-    if (nullspace_basis && (rc = cml_ensure(c, c->null_basis, 8 * 7 * (size_t)n))) return rc;
+    const size_t Ncap = (size_t)std::max(N, c->lim.max_frames);           // (by the limit: a growing window does not re-allocate at every keyframe)
+    if ((rc = cml_ensure(c, c->frame_state, sizeof(cmlhip_ba_frame_state) * Ncap))) return rc;
+    if ((rc = cml_ensure(c, c->pre_w2c, 8 * 7 * Ncap))) return rc;
+    if (nullspace_basis && (rc = cml_ensure(c, c->null_basis, 8 * 7 * (8 * Ncap + 4)))) return rc;
     cml_h2d_batch_begin(c);                                              // adjoints, deltas, priors, frame states, gauge basis: one copy
     struct BatchGuard { cmlhip_ctx* c; ~BatchGuard() { if (c->h2d_batching && !c->h2d_scope) { c->h2d_batching = false; c->h2d_segs.clear(); } } } batch_guard{c};
     if ((rc = upload_accum_in(c, in))) return rc;
@@ -1186,7 +1196,7 @@ int cmlhip_ba_set_resident_prior(cmlhip_ctx* c, const double* HM, const double* 
     CML_REQUIRE(c, c->resident_on, CMLHIP_ERR_STATE, "cmlhip_ba_set_resident_state not called for this window");
     if (!HM || !bM) { c->resident_prior = false; return CMLHIP_OK; }
     const size_t n = 8 * (size_t)c->N + 4;
-    if ((rc = cml_ensure(c, c->bM_raw, 8 * n))) return rc;
+    if ((rc = cml_ensure(c, c->bM_raw, 8 * (8 * (size_t)std::max(c->N, c->lim.max_frames) + 4)))) return rc;
     if ((rc = cml_h2d(c, c->HM.p, HM, 8 * n * n))) return rc;
     if ((rc = cml_h2d(c, c->bM_raw.p, bM, 8 * n))) return rc;
     FrameStepArgs F = {};
