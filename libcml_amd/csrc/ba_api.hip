@@ -292,7 +292,9 @@ int cmlhip_ba_window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
         CML_REQUIRE(c, lin_residuals[i] >= 0 && (size_t)lin_residuals[i] < R, CMLHIP_ERR_INVALID, "residual index out of range");
         W.rstate[lin_residuals[i]] = lin_states[i]; W.rlin[lin_residuals[i]] = 1;
     }
-    return window_commit(c, N, frames);
+    rc = window_commit(c, N, frames);
+    if (rc) { cml_scope_abort(c); c->ba_uploaded = false; }      // (a refused commit leaves NO window: not half of the new one, not the old one under new shadows)
+    return rc;
 }
 
 int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames, int P, const cmlhip_ba_point* points,
@@ -307,7 +309,9 @@ int cmlhip_ba_upload_window(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames,
     if ((rc = cmlhip_ba_window_reset(c))) return rc;
     if ((rc = cmlhip_ba_window_append_points(c, P, points))) return rc;
     if ((rc = cmlhip_ba_window_append_residuals(c, R, res))) return rc;
-    return window_commit(c, N, frames);
+    rc = window_commit(c, N, frames);
+    if (rc) c->ba_uploaded = false;
+    return rc;
 }
 
 static int window_commit(cmlhip_ctx* c, int N, const cmlhip_ba_frame* frames) {

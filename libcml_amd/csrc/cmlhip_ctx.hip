@@ -160,6 +160,14 @@ int cml_scope_end(cmlhip_ctx* c) {
     cml_mark(c, "scope");
     return rc;
 }
+// a call that stages into an open scope has failed half-way: nothing of the scope leaves (a block with half a window in it must not be scattered, and the
+// kernels waiting for it must not run); the caller sees the failing call's status
+void cml_scope_abort(cmlhip_ctx* c) {
+    if (!c->h2d_scope) return;
+    c->h2d_scope = false; c->h2d_batching = false; c->h2d_inplace = false;
+    c->h2d_segs.clear(); c->deferred.clear();
+    c->win.busy_pending = false;
+}
 extern "C" int cmlhip_upload_scope_begin(cmlhip_ctx* c) {
     if (!c) return CMLHIP_ERR_INVALID;
     (void)hipSetDevice(c->device);

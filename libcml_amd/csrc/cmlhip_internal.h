@@ -202,6 +202,7 @@ struct cmlhip_ctx {
 // contexts on several GPUs
 void cml_mark(cmlhip_ctx* c, const char* what);               // development: no-op unless CMLHIP_RUN_MARKS is set
 void cml_marks_dump(cmlhip_ctx* c);
+void cml_scope_abort(cmlhip_ctx* c);                          // a staging call failed inside an open scope: drop the scope's block and deferred launches
 int cml_scope_end(cmlhip_ctx* c);                              // flush the open upload scope (if any) and run what was deferred
 #define CML_DEV(ctx) do { if (ctx) { (void)hipSetDevice((ctx)->device); if ((ctx)->h2d_scope) (void)cml_scope_end(ctx); } } while (0)
 #define CML_DEV_SCOPED(ctx) do { if (ctx) (void)hipSetDevice((ctx)->device); } while (0)      /* entries that stage into an open upload scope */

@@ -190,3 +190,37 @@ def test_window_edit_errors_are_reported_not_ignored():
         assert L.cmlhip_ba_window_compact(h, I.P, fl.ctypes.data_as(_P(C.c_ubyte)), I.R, rl.ctypes.data_as(_P(C.c_ubyte))) == abi.ERR_INVALID     # survivor names a dropped point
     finally:
         ctx.close()
+
+
+def test_a_refused_commit_inside_an_upload_scope_leaves_nothing_behind():
+    """cmlhip_ba_window_commit failing half-way inside an open upload scope (here: a frame whose image is not in the pyramid cache): the scope's block and the
+    kernels waiting for it are dropped, the context holds NO window (CMLHIP_ERR_STATE from what needs one), and the same lists commit fine afterwards."""
+    I = S.make_inputs("tiny")
+    I.residuals["state"][:] = 0
+    ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R)
+    try:
+        L, h = ctx.L, ctx.h
+        for k in range(I.N):
+            ctx.pyramid_put(int(I.frames_dev["image_id"][k]), 0, I.grads[k][0])
+        ctx.ba_set_params(I.prm)
+        assert L.cmlhip_ba_window_reset(h) == 0
+        assert L.cmlhip_ba_window_append_points(h, I.P, I.points.ctypes.data_as(C.c_void_p)) == 0
+        assert L.cmlhip_ba_window_append_residuals(h, I.R, I.residuals.ctypes.data_as(C.c_void_p)) == 0
+        bad = I.frames_dev.copy(); bad["image_id"][I.N - 1] = 987654
+        assert L.cmlhip_upload_scope_begin(h) == 0
+        assert L.cmlhip_ba_window_commit(h, I.N, bad.ctypes.data_as(C.c_void_p), None, None, None, 0, 0, None, None) == abi.ERR_NOT_FOUND
+        assert L.cmlhip_upload_scope_end(h) == 0                       # nothing left to flush
+        lr = abi.BALinResult()
+        assert L.cmlhip_ba_linearize(h, C.byref(lr)) == abi.ERR_STATE  # no window
+        assert L.cmlhip_upload_scope_begin(h) == 0
+        assert L.cmlhip_ba_window_commit(h, I.N, I.frames_dev.ctypes.data_as(C.c_void_p), None, None, None, 0, 0, None, None) == 0
+        ctx.N, ctx.P, ctx.R = I.N, I.P, I.R
+        ctx.ba_set_pairs(I.pairs)                                       # (staged into the same scope)
+        assert L.cmlhip_upload_scope_end(h) == 0
+        ref = _fresh(I)
+        try:
+            _same(_snapshot(ctx, I), _snapshot(ref, I))
+        finally:
+            ref.close()
+    finally:
+        ctx.close()
