@@ -57,22 +57,50 @@ int cml_make_ba_args(cmlhip_ctx* c, BAArgs& A) {
 static inline int ldg_of(int n) { return ((n + 1 + 15) / 16) * 16; }
 
 // R-length readbacks: the device holds residuals in pair-sorted order r' (see cmlhip_ba_upload_window); the caller gets its own
-// numbering back.  add() records a device array (element size in bytes), the copies ride in the open d2h batch (or read_now()
-// issues them), deliver() scatters temp[r'] -> out[caller r].
+// numbering back.  add() records a device array (element size in bytes): the permutation back to the caller's order runs ON THE DEVICE
+// (k_res_to_caller: out[r] = dev[c_dev_of[r]] into a scratch block that the copy then takes as it is — a host-side gather of 15 000 entries per array
+// was 10-15 us each); arrays that do not fit the scratch block fall back to the host permutation in deliver().
+__global__ void k_res_to_caller(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, const int* __restrict__ dev_of, int R, int esz) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const size_t k = (size_t)dev_of[r];
+    if ((esz & 3) == 0) {
+        const unsigned* s4 = reinterpret_cast<const unsigned*>(src + k * esz); unsigned* d4 = reinterpret_cast<unsigned*>(dst + (size_t)r * esz);
+        for (int i = 0; i < esz / 4; i++) d4[i] = s4[i];
+    } else for (int i = 0; i < esz; i++) dst[(size_t)r * esz + i] = src[k * esz + i];
+}
 struct ResRead {
     cmlhip_ctx* c;
-    struct Item { void* out; size_t esz; std::vector<unsigned char> tmp; };
+    struct Item { void* out; size_t esz; std::vector<unsigned char> tmp; const void* dev; };     // host-permuted fallback (dev: still to be copied)
+    struct Direct { void* out; const void* src; size_t bytes; };                               // already in the caller's order in the scratch block
     std::vector<Item> items;
+    std::vector<Direct> direct;
+    size_t scratch_off = 0;
     explicit ResRead(cmlhip_ctx* c_) : c(c_) { items.reserve(8); }
     void add(void* out, const void* dev, size_t esz) {
         if (!out || c->R == 0) return;
-        items.push_back(Item{out, esz, std::vector<unsigned char>(esz * (size_t)c->R)});
-        pending_dev.push_back(dev);
-        if (c->d2h_batching) { cml_d2h(c, items.back().tmp.data(), dev, esz * (size_t)c->R); pending_dev.back() = nullptr; }
+        const size_t R = (size_t)c->R, bytes = esz * R, need = scratch_off + ((bytes + 255) & ~size_t(255));
+        if (c->c_dev_of.p && c->c_dev_of.bytes >= 4 * R) {
+            // (the scratch block is sized once, by the limit given at create: no re-allocation between the add()s of one readback)
+            const size_t want = 64 * std::max(R, (size_t)c->lim.max_residuals);
+            if (scratch_off == 0 && c->rr_scratch.bytes < want) (void)cml_ensure(c, c->rr_scratch, want);
+            if (c->rr_scratch.bytes >= need) {
+                unsigned char* dst = c->rr_scratch.as<unsigned char>() + scratch_off;
+                k_res_to_caller<<<cml_div_up((int)R, 256), 256, 0, c->stream>>>(static_cast<const unsigned char*>(dev), dst, c->c_dev_of.as<int>(), (int)R, (int)esz);
+                scratch_off = need;
+                if (c->d2h_batching) cml_d2h(c, out, dst, bytes);            // recorded: delivered by the batch's flush, straight into `out`
+                else direct.push_back(Direct{out, dst, bytes});
+                return;
+            }
+        }
+        items.push_back(Item{out, esz, std::vector<unsigned char>(bytes), dev});
+        if (c->d2h_batching) { cml_d2h(c, items.back().tmp.data(), dev, bytes); items.back().dev = nullptr; }
     }
     int read_now() {
-        for (size_t i = 0; i < items.size(); i++)
-            if (pending_dev[i]) { int rc = cml_d2h(c, items[i].tmp.data(), pending_dev[i], items[i].esz * (size_t)c->R); if (rc) return rc; }
+        for (auto& d : direct) { int rc = cml_d2h(c, d.out, d.src, d.bytes); if (rc) return rc; }
+        direct.clear();
+        for (auto& it : items)
+            if (it.dev) { int rc = cml_d2h(c, it.tmp.data(), it.dev, it.esz * (size_t)c->R); if (rc) return rc; it.dev = nullptr; }
         deliver();
         return CMLHIP_OK;
     }
@@ -91,13 +119,10 @@ struct ResRead {
                 for (size_t r = 0; r < R; r++) memcpy(o + it.esz * r, it.tmp.data() + it.esz * (size_t)dev_of[r], it.esz);
             }
         }
+        items.clear();
     }
-    std::vector<const void*> pending_dev;
 };
 
-// What the window's derived tables hold is a function of what was uploaded: built ON the device behind the one packed copy, so that the
-// copy carries the caller's data only (the per-residual copies of the point's static inputs alone were 72 B x R — nearly half the block —
-// and every byte of the block is ahead of the run's first kernel)
 struct ExpandArgs {
     int R, P, N, pt_stride, pair_stride;
     // caller order (the library's window shadows, copied as they are) + the two positions the host's counting pass assigned

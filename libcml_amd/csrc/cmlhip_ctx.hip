@@ -401,7 +401,7 @@ void cmlhip_destroy(cmlhip_ctx* c) { CML_DEV(c);
                      &c->syrk_part, &c->solve_image, &c->xad, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,
                      &c->Hf, &c->bf, &c->step_partial, &c->rp_obs, &c->rp_poses, &c->rp_points, &c->rp_M, &c->rp_b, &c->rp_Jp, &c->rp_used, &c->rp_x, &c->rp_off, &c->rp_orig,
                      &c->rr_obs, &c->rr_off, &c->rr_orig, &c->rr_points, &c->rr_jp, &c->rr_used, &c->rr_x, &c->rr_ready, &c->trk_xch, &c->x_ticket, &c->batch_main, &c->batch_rs,
-                     &c->trk_early, &c->run_pack, &c->run_snap, &c->c_point, &c->c_target, &c->c_state, &c->c_lin, &c->c_dev_of, &c->c_bpos};
+                     &c->trk_early, &c->rr_scratch, &c->run_pack, &c->run_snap, &c->c_point, &c->c_target, &c->c_state, &c->c_lin, &c->c_dev_of, &c->c_bpos};
     for (DevBuf* b : all) cml_free(*b);
     for (int l = 0; l < 8; l++) { cml_free(c->trk_ref[l]); cml_free(c->cd_idepth[l]); cml_free(c->cd_wsum[l]); cml_free(c->cd_wbak[l]); }
     cml_window_free(c);

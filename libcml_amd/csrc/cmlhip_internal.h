@@ -165,6 +165,7 @@ struct cmlhip_ctx {
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)
+    DevBuf rr_scratch;                                        // R-length readbacks permuted back to the caller's order on the device (ResRead, ba_api.hip)
     DevBuf run_pack;                                          // cmlhip_ba_finish_run: state | good << 2 per caller residual, HdiF per point (k_ba_pack_closing)
     DevBuf run_snap;                                          // cmlhip_ba_finish_run: the loop's last summary + frame states, kept across the re-anchoring and the closing pass
     bool resident_on = false, have_null = false, lin_finish_pending = false; int resident_iter = 0; double res_scales[4] = {1, 1, 1, 1}; double conv_th = 0; bool conv_on = false;
