@@ -289,3 +289,33 @@ def test_one_wait_run_equals_the_stepwise_run(config):
     assert np.array_equal(a["idp"], b["idp"]) and np.array_equal(a["alive"], b["alive"]) and np.array_equal(a["ng"], b["ng"])
     assert np.array_equal(a["st"], b["st"]) and np.array_equal(a["ralive"], b["ralive"]) and np.array_equal(a["good"], b["good"])
     assert a["out"] == b["out"]
+
+
+def test_one_wait_run_returns_the_residual_energies_when_asked():
+    """`keepResidualEnergies`: run()'s closing pass also reads state_NewState / state_energy / state_NewEnergy / state_NewEnergyWithOutlier of every residual back — in the
+    one-wait form through the device-side permutation into the caller's order (k_res_to_caller) inside cmlhip_ba_finish_run's one copy.  Held against the stepwise run
+    (record kernel, host permutation): same states, energies to 1e-5 (the two closing passes differ by the rounding of the re-anchored pair records only)."""
+    import os
+    res = []
+    for mode in ("stepwise", "one_wait"):
+        I = S.make_inputs("medium")
+        ctx = device.Ctx(max_frames=I.N, max_points=I.P, max_residuals=I.R)
+        ba = host.window_to_host_ba(ctx, I.W)
+        ba.set_param("iterations", 3)
+        ba.set_param("keepResidualEnergies", 1)
+        if mode == "stepwise":
+            os.environ["CMLHOST_RUN_STEPWISE"] = "1"
+        try:
+            assert ba.run(), ba.last_error()
+        finally:
+            os.environ.pop("CMLHOST_RUN_STEPWISE", None)
+        res.append(ba.export()[2].copy())
+        ba.close(); ctx.close()
+    a, b = res
+    assert len(a) == len(b) > 1000
+    for f in ("state_state", "state_NewState", "alive", "good"):
+        assert np.array_equal(a[f], b[f]), f
+    live = a["alive"] == 1
+    assert live.sum() > 1000 and np.abs(a["state_energy"][live]).max() > 1.0                       # the energies really came back
+    for f in ("state_energy", "state_NewEnergy"):
+        assert np.allclose(a[f][live], b[f][live], rtol=1e-5, atol=1e-6), f
