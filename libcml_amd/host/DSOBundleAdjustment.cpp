@@ -529,24 +529,26 @@ bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], 
     lapL("device call done");
     energy[0] = lr.energy; energy[1] = 0; energy[2] = 0;
     mFrames.back().frameEnergyTH = lr.new_frame_energy_th;                // setNewFrameEnergyTH, :1610
-    if (fixLinearization) closingBookkeeping(st, good, ns, e, ne, nw);
+    if (fixLinearization) closingBookkeeping(st, good, ns, e, ne, nw, nullptr);
     lapL("bookkeeping done");
     return true;
 }
 
 // host bookkeeping behind linearizeAll(true), BA.cpp:1571-1640, from the arrays the device's closing pass returned (caller order = mActive)
+// (packed != nullptr: state | good << 2 per residual, as cmlhip_ba_finish_run packs them — st / good are then not read)
 void DSOBundleAdjustment::closingBookkeeping(const std::vector<int>& st, const std::vector<unsigned char>& good, const std::vector<int>& ns,
-                                             const std::vector<float>& e, const std::vector<float>& ne, const std::vector<float>& nw) {
+                                             const std::vector<float>& e, const std::vector<float>& ne, const std::vector<float>& nw, const unsigned char* packed) {
     const int R = (int)mActive.size();
     std::vector<int>& nres = mScratchCount;
     nres.assign(mPoints.size(), 0);
     const bool allActive = (size_t)R == mResiduals.size();                      // (the committed window is the whole list: the census below needs no second pass)
     for (int k = 0; k < R; k++) {
         DSOResidual& Rr = mResiduals[mActive[k]];
-        Rr.state_state = st[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0;
+        const int st_k = packed ? (packed[k] & 3) : st[k];
+        Rr.state_state = st_k; Rr.isActiveAndIsGoodNEW = packed ? ((packed[k] >> 2) & 1) != 0 : good[k] != 0;
         if (mKeepResidualEnergies) { Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k]; Rr.state_NewEnergyWithOutlier = nw[k]; }
         else {
-            Rr.state_NewState = st[k];                                          // applyNewState: state_state = state_NewState (DSOResidual.h)
+            Rr.state_NewState = st_k;                                           // applyNewState: state_state = state_NewState (DSOResidual.h)
             if (!Rr.isLinearized) Rr.state_NewEnergy = Rr.state_energy = 0;     // resetOOB of the preamble (:766-779); the energies stay on the device in this mode
         }
         DSOPoint& Pp = mPoints[Rr.point];
@@ -1238,15 +1240,14 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     std::vector<unsigned char> sg(R);
     std::vector<float> hdiv(mActivePoints.size());
     cmlhip_ba_resident_out ro{fs.data(), pre.data(), &first, &last, &its, en.data(), (int)en.size(), mX.data(), sg.data(), hdiv.data()};
-    std::vector<int> st(R), ns;
+    std::vector<int> st, ns;
     std::vector<float> e, ne, nw;
-    std::vector<unsigned char> good(R);
+    std::vector<unsigned char> good;
     if (mKeepResidualEnergies) { ns.resize(R); e.resize(R); ne.resize(R); nw.resize(R); }
     std::vector<double> idp(mActivePoints.size());
     rc = cmlhip_ba_finish_run(mCtx, 1, &ro, &lr, nullptr, mKeepResidualEnergies ? ns.data() : nullptr, mKeepResidualEnergies ? e.data() : nullptr,
                               mKeepResidualEnergies ? ne.data() : nullptr, mKeepResidualEnergies ? nw.data() : nullptr, nullptr, idp.data(), nullptr);
     if (rc && rc != CMLHIP_ERR_NONFINITE) return fail("cmlhip_ba_finish_run", rc);
-    for (int k = 0; k < R; k++) { st[k] = sg[k] & 3; good[k] = (sg[k] >> 2) & 1; }
     const double t_end = us();
     lastRunUs[4] = t_end - t_enq;
     lap("finish_run returned");
@@ -1268,11 +1269,14 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     std::memcpy(anchor.q, &pre[7 * (size_t)(N - 1)], sizeof anchor.q);
     std::memcpy(anchor.t, &pre[7 * (size_t)(N - 1) + 4], sizeof anchor.t);
     fb.setEvalPT(anchor, nz, sc);
+    lap("frames set");
     computeAdjoints();
     computeDelta();
+    lap("adjoints+delta");
     lastEnergy[0] = lr.energy; lastEnergy[1] = lastEnergy[2] = 0;
     fb.frameEnergyTH = lr.new_frame_energy_th;                                 // setNewFrameEnergyTH of the closing pass, :1610
-    closingBookkeeping(st, good, ns, e, ne, nw);
+    closingBookkeeping(st, good, ns, e, ne, nw, sg.data());
+    lap("closing bookkeeping");
     if (!std::isfinite(lastEnergy[0])) { mError = "Not finite energy"; return false; }
     for (size_t k = 0; k < mActivePoints.size(); k++) {                        // MapPoint::setReferenceInverseDepth / setInverseDepthHessian
         DSOPoint& P = mPoints[mActivePoints[k]];

@@ -175,7 +175,7 @@ private:
     void fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double>& prior, std::vector<double>& dprior, double cdelta[4], double cprior[4]);
     bool runPreamble(double lastEnergy[3], bool enqueueOnly = false);
     void closingBookkeeping(const std::vector<int>& st, const std::vector<unsigned char>& good, const std::vector<int>& ns,
-                            const std::vector<float>& e, const std::vector<float>& ne, const std::vector<float>& nw);
+                            const std::vector<float>& e, const std::vector<float>& ne, const std::vector<float>& nw, const unsigned char* packed);
     bool runEpilogue(double lastEnergy[3]);
     bool linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut = nullptr, std::vector<float>* pointAccOut = nullptr, bool applyToo = false, bool enqueueOnly = false);
     bool solveSystem(int iteration, double lambda);
