@@ -870,12 +870,14 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     A.out_host = reinterpret_cast<cmlhip_tracker_opt_result*>(static_cast<char*>(dptr) + hyp_bytes);
     A.xch = c->trk_xch.as<float>(); A.tick = reinterpret_cast<int*>(c->trk_xch.as<char>() + xch_bytes);
     A.early_rmse = (float)c->trk_early_rmse;
-    // the early-exit word has a buffer of its own (a fixed address, cleared for every launch that arms it): inside trk_xch its offset moved with
-    // (n_hyp, G) and could fall on a stale exchange word of an earlier, larger launch
+    // the early-exit word has a buffer of its own (a fixed address that only ever holds launch numbers: inside trk_xch its offset moved with (n_hyp, G)
+    // and could fall on a stale exchange word of an earlier, larger launch).  It is raised by storing THIS launch's number, so it needs no clearing per
+    // launch — once per allocation and when the 16-bit launch number wraps, with the exchange buffer below
     A.early_flag = nullptr;
     if (c->trk_early_rmse > 0.0 && n_hyp > 1) {
+        const unsigned gen0 = c->trk_early.gen;
         if ((rc = cml_ensure(c, c->trk_early, 64))) return rc;
-        CML_CHECK(c, hipMemsetAsync(c->trk_early.p, 0, 4, c->stream));
+        if (c->trk_early.gen != gen0 || c->trk_epoch >= 0xfffe) CML_CHECK(c, hipMemsetAsync(c->trk_early.p, 0, 64, c->stream));
         A.early_flag = c->trk_early.as<int>();
     }
     A.late = reinterpret_cast<int*>(static_cast<char*>(dptr) + hyp_bytes + res_bytes);
