@@ -596,14 +596,12 @@ def measure(S, steps, warmup, group, sync_extra=None, lam=1e-5):
     ctx.sync()
     for _ in range(warmup):
         ctx.ba_iteration_async(lam)
-    # every stride-th step carries the profile events on its dispatches (an event-carrying dispatch costs the pipeline ~3 us: at
-    # stride 4 the contract region ran 1.4 us per step behind the regions without events; at stride 2 a --steps 20 run lost 3 us per
-    # step).  The contract region therefore samples sparsely (5 dispatches at --steps 20) and a region of its own, after it, carries
-    # events on EVERY residual-kernel dispatch (`launch_us_all_steps`, K samples)
+    # the contract region carries NO profile events (an event-carrying dispatch costs the pipeline ~3 us: with events on every 4th step a
+    # --steps 20 run read 46.1 us per step against 43.9 at 200 steps).  The residual kernel's dispatch duration comes from the region
+    # behind it, which carries events on EVERY residual-kernel dispatch of K further steps of the same loop (`roofline.launch_us`)
     stride = 8 if steps >= 80 else (4 if steps >= 16 else (2 if steps >= 4 else 1))
     ctx.profile_stride(stride)
-    ctx.profile_select(1)                                                 # contract region: events on the roofline kernel's dispatch only
-    ctx.profile_enable((steps + stride - 1) // stride)
+    ctx.profile_enable(0)
 
     def run_steps():
         for _ in range(steps):
@@ -615,7 +613,6 @@ def measure(S, steps, warmup, group, sync_extra=None, lam=1e-5):
             sync_extra()
 
     dt = shard.timed_region(group, sync, run_steps)
-    lin_ms, _ss0, _empty, n_samples = ctx.profile_read()
     # the Schur-reduce + solve group (K3 begin -> K6 end) is sampled in a region of its own, after the contract region: every
     # event-carrying dispatch costs the pipeline a few microseconds, and the contract region needs the roofline kernel's only
     ctx.profile_select(2)
@@ -628,6 +625,7 @@ def measure(S, steps, warmup, group, sync_extra=None, lam=1e-5):
     ctx.profile_enable(steps)
     shard.timed_region(group, sync, run_steps)
     lin_all_ms, _s, _e, n_all = ctx.profile_read()
+    lin_ms, n_samples = lin_all_ms, n_all
     ctx.profile_stride(stride)
     ctx.profile_select(3)
     # spread: the contract region above is ONE sample (K steps can be a millisecond); eight more regions of the same K steps, same
@@ -747,9 +745,9 @@ def roofline_object(S, M, lin_ms_local):
             "algorithmic_bytes_per_launch": R * bytes_per_residual, "bytes_per_residual": bytes_per_residual,
             "launch_us": 1e3 * lin_ms_local, "launch_samples": M["n_samples"],
             "launch_us_all_steps": 1e3 * M.get("lin_all_ms", 0.0), "launch_samples_all_steps": M.get("n_all", 0),
-            "launch_us_note": "mean over the sampled steps of the timed region of hipEventElapsedTime between the start and stop events "
-                              "attached to the k_ba_linearize dispatch itself (hipExtLaunchKernelGGL): the kernel's begin / end "
-                              "timestamps, the quantity rocprofv3 --kernel-trace reports",
+            "launch_us_note": "mean over EVERY residual-kernel dispatch of the K steps that follow the contract region (same loop, same state; the contract "
+                              "region itself carries no events) of hipEventElapsedTime between the start and stop events attached to the dispatch "
+                              "itself (hipExtLaunchKernelGGL): the kernel's begin / end timestamps, the quantity rocprofv3 --kernel-trace reports",
             "rocprof_avg_us": rocprof_us}
     if traffic and lin_ms_local > 0:
         # what the memory system actually moved for this launch (PMC, corrected as the guide prescribes) against the same roof: the residual
@@ -788,6 +786,12 @@ def secondary_config(config, seed, local_rank, steps, warmup, relaxed=False):
             out["invalid"] = "the residual pass after the timed region does NOT match the oracle: the figures above are void"
         if relaxed and not S["hybrid"]:
             out["relaxed_arithmetic"] = relaxed_arithmetic_leg(S, steps, warmup, out)
+        if S["half"]:                                             # config E: how far fp16 texels sit from the reference's fp32 texels (checker side, outside every timed region)
+            try:
+                from tests import e_texel_check
+                out["vs_fp32_texels"] = e_texel_check.device_vs_fp32_oracle(S["W"], local_rank)
+            except Exception as e:
+                out["vs_fp32_texels"] = {"error": repr(e)}
         return out
     finally:
         S["ba"].close(); S["ctx"].close()
@@ -888,6 +892,9 @@ def compact_line(out, detail_path, contract_only=False):
             else:
                 line["configs"][k] = {"value": _r(c.get("value")), "ms_per_step": _r(c.get("ms_per_step")), "frac": _r((c.get("roofline") or {}).get("frac")),
                                       "parity_ok": bool(c.get("parity_ok"))}
+                v32 = c.get("vs_fp32_texels")
+                if isinstance(v32, dict) and "H_A_jacobi_rel" in v32:      # config E: fp16 texels against the reference's fp32 texels (Jacobi-scaled H_A, residuals classified differently)
+                    line["configs"][k]["vs_fp32_texels"] = {"H_A_jacobi_rel": _r(v32["H_A_jacobi_rel"], 3), "class_flips": v32.get("class_flips")}
     sq = out.get("sequence")
     if isinstance(sq, dict):
         if "error" in sq:

@@ -886,6 +886,9 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     // number wraps, so that a stale word can never carry a matching tag
     if (c->trk_xch.gen != c->trk_xch_gen || c->trk_epoch >= 0xfffe) {
         CML_CHECK(c, hipMemsetAsync(c->trk_xch.p, 0, c->trk_xch.bytes, c->stream)); c->trk_xch_gen = c->trk_xch.gen; c->trk_epoch = 0;
+        // the launch number restarts: the early-exit word (which holds launch numbers) restarts with it, armed launch or not — a word raised
+        // at number E before the restart must not be read as "hypothesis 0 passed" when the restarted counter reaches E again
+        if (c->trk_early.p) CML_CHECK(c, hipMemsetAsync(c->trk_early.p, 0, 64, c->stream));
     }
     c->trk_epoch += 1;                                     // 1 .. 0xfffe: never the zero of a cleared buffer
     A.epoch = c->trk_epoch;

@@ -53,9 +53,10 @@ def adjoints_and_delta(frames, N, scales, optimize_a=1, optimize_b=1):
     return adH, adT, adHTd, prior, dprior
 
 
-def make_inputs(config="small", seed=0xC0FFEE, shard=0, **kw):
-    """Everything needed to drive either the oracle or the device BA path on one synthetic window."""
-    W = synth.make_window(config, seed=seed, shard=shard, **kw)
+def make_inputs(config="small", seed=0xC0FFEE, shard=0, W=None, **kw):
+    """Everything needed to drive either the oracle or the device BA path on one synthetic window (W: a window synth.make_window already built)."""
+    if W is None:
+        W = synth.make_window(config, seed=seed, shard=shard, **kw)
     I = BAInputs()
     I.W = W
     I.N, I.P = W.N, W.P

@@ -31,7 +31,7 @@ def test_two_rank_gloo_barrier_and_reductions(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
-                         capture_output=True, text=True, env=env, timeout=240)
+                         capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -54,7 +54,7 @@ def test_bench_launches_its_own_ranks():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-only"], capture_output=True, text=True,
-                         env=env, timeout=300, cwd=ROOT)
+                         env=env, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout                       # rank 0 only
