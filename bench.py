@@ -465,7 +465,11 @@ def sequence_bench(device_id, seed, want_cpu):
            "frames": n_frames, "keyframes": stats["keyframes"], "tracking_lost": stats["tracking_lost"],
            "frames_per_s": (n_frames - 1) / max(dt - t_boot, 1e-9), "seconds": dt, "bootstrap_s": t_boot,
            "ms_per_stage": {k: v for k, v in stages.items() if k != "bootstrap"},
-           "per_frame_ms": sum(stages[k]["median_ms"] for k in ("pyramid_build", "trackWithMotionModel", "traceNewCoarse") if k in stages),
+           "per_frame_ms": sum(stages[k]["median_ms"] for k in ("pyramid_build", "trackWithMotionModel", "traceNewCoarse", "trackAndTrace") if k in stages),
+           # library time of a TRACKED FRAME: pyramid (image worker hand-over) + the fused trackWithMotionModel / traceNewCoarse call (one enqueue, one host wait;
+           # a trace redone because another hypothesis won is included) + the id's release — per frame of the shard
+           "frame_ms": float(sum(lib[k]["total_ms"] for k in ("pyramid_build", "trackWithMotionModel", "traceNewCoarse", "trackAndTrace") if k in lib)) / (n_frames - 1),
+           "traces_redone": int(stats.get("traces_redone", 0)),
            "per_keyframe_ms": sum(stages[k]["median_ms"] for k in ("addNewFrame", "activatePoints+addPoints", "run", "makeCoarseDepthL0", "tryMarginalize",
                                                                   "marginalizePointsF", "makeNewTraces", "marginalizeFrames") if k in stages),
            "library_ms_per_stage": {k: v for k, v in lib.items() if k != "bootstrap"},
@@ -535,6 +539,110 @@ def sequence_bench(device_id, seed, want_cpu):
                                              "checker build -O2, one thread; includes the checker's own set-up of each stage's window)"}
         except Exception as e:
             out["parity_checked"] = False; out["parity_error"] = repr(e)
+    return out
+
+
+def _shard_worker(idx, s_list, device_id, seed, barrier, queue):
+    """one sequence shard of the shards-per-GPU sweep, in a process of its own (own context, own stream, own seeded sequence).  Every phase is
+    bracketed by the barrier of ALL workers; a worker that is not part of a round only meets the barriers."""
+    import hashlib
+    import numpy as np
+    out = {"idx": idx, "rounds": {}}
+    try:
+        from libcml_amd import device, sequence
+        n_frames = 48
+        seq = sequence.make_sequence(n_frames=n_frames, seed=0x5EED + (seed & 0xff), shard=idx)
+        ctx = device.Ctx(device_id=device_id, max_frames=8, max_points=8192, max_residuals=8192 * 8)
+
+        def one(share):
+            ctx.set_device_share(share)
+            pipe = sequence.DirectPipeline(ctx, seq.K, seq.w, seq.h, seq.levels)
+            t0 = time.perf_counter()
+            st = pipe.run(seq)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            boot = pipe.timing_summary().get("bootstrap", {}).get("mean_ms", 0.0) * 1e-3
+            lib = float(sum(float(np.sum(v)) for k, v in pipe.lib_times.items() if k != "bootstrap"))
+            h = hashlib.sha256(b"".join(np.ascontiguousarray(x, np.float64).tobytes() for Rt in pipe.history for x in Rt)).hexdigest()
+            pipe.close()
+            return {"seconds": dt - boot, "library_seconds": lib, "lost": int(st["tracking_lost"]), "poses": h}
+        one(1)                                                # warm-up: allocations, pools, code objects
+        err = None
+    except Exception as e:                                    # keep meeting the barriers: nobody may hang on a worker that failed
+        err = repr(e)
+    try:
+      for S in s_list:
+        active = idx < S
+        # solo reference of every active shard at this share (G depends on it), one after the other
+        for k in range(S):
+            barrier.wait(timeout=600)
+            if active and k == idx and err is None:
+                try:
+                    out["rounds"].setdefault(S, {})["solo"] = one(S)
+                except Exception as e:
+                    err = repr(e)
+        barrier.wait(timeout=600)
+        if active and err is None:
+            try:
+                out["rounds"].setdefault(S, {})["together"] = one(S)
+            except Exception as e:
+                err = repr(e)
+        barrier.wait(timeout=600)
+    except Exception as e:                                    # a broken barrier (a worker died): report and leave
+        err = err or repr(e)
+    out["error"] = err
+    try:
+        ctx.close()
+    except Exception:
+        pass
+    queue.put(out)
+
+
+def shards_per_gpu_bench(device_id, seed, s_list=(1, 2, 4, 8)):
+    """S sequence shards on ONE GPU — the one-device stand-in for BASELINE.json configs[3] (8 independent shards, one per GPU): S processes, each with
+    its own context / stream / seeded 48-frame sequence (cmlhip_set_device_share(S): launches whose workgroups wait for one another size themselves for
+    1 / S of the device), started together between barriers.  Per S: aggregate frames/s by the wall clock of the slowest shard and by the time inside
+    the library's calls; every shard's tracked poses bit-identical to the same shard run alone at the same share."""
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    n = max(s_list)
+    barrier = mpc.Barrier(n)
+    queue = mpc.Queue()
+    procs = [mpc.Process(target=_shard_worker, args=(i, tuple(s_list), device_id, seed, barrier, queue), daemon=True) for i in range(n)]
+    for p_ in procs:
+        p_.start()
+    res = []
+    try:
+        t_end = time.time() + 600
+        while len(res) < n and time.time() < t_end:
+            try:
+                res.append(queue.get(timeout=2))
+            except Exception:
+                if not any(p_.is_alive() for p_ in procs) and queue.empty():      # every worker gone without a report: do not sit out the time-out
+                    break
+    finally:
+        for p_ in procs:
+            p_.join(timeout=30)
+            if p_.is_alive():
+                p_.terminate()
+    if len(res) < n:
+        return {"error": "%d of %d shard workers reported" % (len(res), n), "worker_errors": [r.get("error") for r in res if r.get("error")]}
+    res.sort(key=lambda r: r["idx"])
+    errs = [r["error"] for r in res if r.get("error")]
+    out = {"frames_per_shard": 47, "S": {}, "errors": errs,
+           "note": "S processes x one 48-frame sequence shard each on one MI355X (own context, stream, seeded sequence; bootstrap excluded); frames_per_s = 47 S / the slowest "
+                   "shard's wall clock (Python driver included), library_frames_per_s = 47 S / the largest per-shard time inside the library's calls; "
+                   "bit_identical = every shard's tracked poses equal its solo run at the same share"}
+    for S in s_list:
+        rows = [r["rounds"].get(S) or r["rounds"].get(str(S)) for r in res[:S]]
+        if any(r is None or "together" not in r or "solo" not in r for r in rows):
+            out["S"][str(S)] = {"error": "a shard did not finish"}
+            continue
+        wall = max(r["together"]["seconds"] for r in rows); lib = max(r["together"]["library_seconds"] for r in rows)
+        solo_wall = float(sum(r["solo"]["seconds"] for r in rows)) / S
+        out["S"][str(S)] = {"frames_per_s": 47.0 * S / wall, "library_frames_per_s": 47.0 * S / lib, "solo_frames_per_s_mean": 47.0 / solo_wall,
+                            "bit_identical": all(r["together"]["poses"] == r["solo"]["poses"] for r in rows),
+                            "tracking_lost": int(sum(r["together"]["lost"] for r in rows))}
     return out
 
 
@@ -901,9 +1009,13 @@ def compact_line(out, detail_path, contract_only=False):
             line["sequence"] = {"error": str(sq["error"])[:80]}
         else:
             par = sq.get("parity") or {}
-            line["sequence"] = {"frames_per_s": _r(sq.get("frames_per_s")), "library_frames_per_s": _r(sq.get("library_frames_per_s")),
+            line["sequence"] = {"frames_per_s": _r(sq.get("frames_per_s")), "library_frames_per_s": _r(sq.get("library_frames_per_s")), "frame_ms": _r(sq.get("frame_ms"), 4),
                                 "run_ms": _r(sum((sq.get("run_us_split_median") or {}).values()) * 1e-3 or None),
                                 "parity_ok": sq.get("parity_ok"), "yardstick_used": len(par.get("run_yardstick", []) or []) + int(par.get("track_yardstick_used", 0) or 0)}
+            spg = sq.get("shards_per_gpu") or {}
+            if isinstance(spg.get("S"), dict):                # S sequence shards on this one GPU: aggregate frames/s inside the library's calls
+                line["sequence"]["shards_per_gpu"] = {k: _r(v.get("library_frames_per_s"), 4) for k, v in spg["S"].items() if isinstance(v, dict) and "library_frames_per_s" in v}
+                line["sequence"]["shards_bit_identical"] = all(bool(v.get("bit_identical")) for v in spg["S"].values() if isinstance(v, dict) and "bit_identical" in v)
             tt = sq.get("two_threads") or {}
             if "frames_per_s" in tt:
                 line["sequence"]["frames_per_s_two_threads"] = _r(tt["frames_per_s"])
@@ -1066,6 +1178,15 @@ def main():
                 out["sequence"] = sequence_bench(local_rank, seed, not args.no_cpu_baseline)
             except Exception as e:
                 out["sequence"] = {"error": repr(e)}
+            if args.extras or os.environ.get("CML_BENCH_SHARDS_PER_GPU"):      # (its own flag: the sweep starts eight processes)
+                try:
+                    spg = shards_per_gpu_bench(local_rank, seed)
+                    if isinstance(out.get("sequence"), dict):
+                        out["sequence"]["shards_per_gpu"] = spg
+                    else:
+                        out["shards_per_gpu"] = spg
+                except Exception as e:
+                    out["shards_per_gpu"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wcfg, seed)          # (config C: the photometric window of config B; the ORB term is not part of the CPU port's timing)

@@ -88,6 +88,10 @@ typedef struct {
 int  cmlhip_abi_version(void);
 int  cmlhip_device_count(void);
 int  cmlhip_create(cmlhip_ctx** out, const cmlhip_limits* limits);
+/* Several contexts on ONE device at the same time (sequence shards per GPU, BASELINE.json configs[3] scaled down to one device): n_contexts tells
+ * this context how many launch beside each other.  Launches whose workgroups WAIT for one another (the tracker batch: G workgroups per hypothesis
+ * exchanging partial sums) must be resident as a whole; they size themselves for 1 / n_contexts of the device's capacity.  Default 1. */
+int  cmlhip_set_device_share(cmlhip_ctx* ctx, int n_contexts);
 void cmlhip_destroy(cmlhip_ctx* ctx);
 const char* cmlhip_last_error(const cmlhip_ctx* ctx);
 int  cmlhip_synchronize(cmlhip_ctx* ctx);
@@ -203,6 +207,12 @@ int cmlhip_tracker_optimize_batch(cmlhip_ctx* ctx, uint64_t new_image_id, int le
                                   const double ref_exposure[3], const double init_exposure[3], const cmlhip_tracker_params* prm,
                                   int optimize_a, int optimize_b, double saturated_ratio_threshold,
                                   int n_hypotheses, const cmlhip_tracker_hypothesis* hypotheses, cmlhip_tracker_opt_result* results);
+/* The same in two halves: _async enqueues the batch and returns; _wait blocks until it (and whatever the caller enqueued behind it with a completion
+ * ticket of its own: cmlhip_tracer_trace_resident_tracked_async) has run, then hands the n_hyp results over.  One batch in flight per context. */
+int cmlhip_tracker_optimize_batch_async(cmlhip_ctx* ctx, uint64_t new_image_id, int levels, const double K0[4], const double ref_exposure[3],
+                                        const double init_exposure[3], const cmlhip_tracker_params* prm, int optimize_a, int optimize_b,
+                                        double saturated_ratio_th, int n_hyp, const cmlhip_tracker_hypothesis* hyp);
+int cmlhip_tracker_optimize_wait(cmlhip_ctx* ctx, cmlhip_tracker_opt_result* out /* n_hyp of the batch in flight */);
 /* warped buffer readback (tests): SoA rows idepth,u,v,dx,dy,residual,weight,refcolor
  * (TR.h:98-135), each numWarped long, in reference-list order. */
 int cmlhip_tracker_get_warped(cmlhip_ctx* ctx, float* out8xn, int capacity, int* n_out);
@@ -282,7 +292,7 @@ int cmlhip_ba_window_counts(cmlhip_ctx* ctx, int* P, int* R);      /* entries th
 int cmlhip_ba_window_commit(cmlhip_ctx* ctx, int N, const cmlhip_ba_frame* frames, const double* idepth, const float* idepth_zero,
                             const float* prior, int reset_states, int n_lin, const int* lin_residuals, const int* lin_states);
 /* Upload scope: between begin and end the host-to-device copies of cmlhip_ba_set_params, cmlhip_ba_window_commit, cmlhip_ba_set_pairs,
- * cmlhip_ba_set_arithmetic, cmlhip_ba_set_resident_state / _prior / _indirect (M = 0) and cmlhip_ba_resident_convergence are collected and leave as ONE
+ * cmlhip_ba_set_arithmetic, cmlhip_ba_set_resident_outputs, cmlhip_ba_set_resident_state / _prior / _indirect (M = 0) and cmlhip_ba_resident_convergence are collected and leave as ONE
  * packed block when the scope ends (the few kernels those calls launch behind their own copies run then, in call order) — the preamble of BA::run
  * (BA.cpp:744-802) as one transfer instead of four.  Any OTHER call on the context ends the scope first; ending a scope that is not open is a no-op. */
 int cmlhip_upload_scope_begin(cmlhip_ctx* ctx);
@@ -306,6 +316,18 @@ int cmlhip_ba_set_frame_b0(cmlhip_ctx* ctx, const float* b0 /* N */);
 #define CMLHIP_ARITH_EXACT   0
 #define CMLHIP_ARITH_RELAXED 1
 int cmlhip_ba_set_arithmetic(cmlhip_ctx* ctx, int mode);
+/* What the residual kernels of the device-resident loop (cmlhip_ba_iteration_async / _batch, the resident form of cmlhip_ba_linearize_apply and the
+ * closing pass of cmlhip_ba_finish_run) STORE per residual besides the state the next pass reads.  CMLHIP_RESIDENT_OUTPUTS_FULL (default): everything
+ * DSOBundleAdjustmentLinearizationContext::linearize leaves in the residual (BA.cpp:131 setCenterProjectedTo, :297-314 state_NewEnergy /
+ * state_NewEnergyWithOutlier / the returned energy).  CMLHIP_RESIDENT_OUTPUTS_LEAN: centerProjectedTo and the returned energy are not stored and
+ * state_NewEnergyWithOutlier only for residuals into the newest frame — the ones setNewFrameEnergyTH reads (BA.cpp:2419-2464); nothing BA::run,
+ * the marginalisation calls or the getters of the host mirror consume is affected (cmlhip_ba_get_center_projected and the new_energy_wo array of
+ * cmlhip_ba_get_states then hold the values of the last FULL or record-kernel pass).  The host mirror runs LEAN unless keepResidualEnergies is set:
+ * 20 of 121 stored bytes per residual and five partial-line store instructions per wave less under the texel gather. */
+#define CMLHIP_RESIDENT_OUTPUTS_FULL 0
+#define CMLHIP_RESIDENT_OUTPUTS_LEAN 1
+int cmlhip_ba_set_resident_outputs(cmlhip_ctx* ctx, int mode);
+int cmlhip_ba_get_resident_outputs(cmlhip_ctx* ctx, int* mode);
 int cmlhip_ba_set_idepth(cmlhip_ctx* ctx, const double* idepth /* P */, const float* idepth_zero /* P or NULL */);
 int cmlhip_ba_get_idepth(cmlhip_ctx* ctx, double* idepth /* P */);
 
@@ -440,6 +462,19 @@ int cmlhip_tracer_set_points(cmlhip_ctx* ctx, int n, const cmlhip_immature_point
 int cmlhip_tracer_trace_resident(cmlhip_ctx* ctx, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
                                  const cmlhip_trace_pair* pairs, int skip_host, int counts[6]);
 int cmlhip_tracer_get_points(cmlhip_ctx* ctx, int n, cmlhip_immature_point* points);
+/* One enqueue and ONE host wait for a tracked frame (Hybrid.cpp:383-442: trackWithMotionModel, then traceNewCoarse against the pose it found).
+ * cmlhip_tracker_optimize_batch_async enqueues the hypothesis batch; cmlhip_tracer_trace_resident_tracked_async then enqueues, on the same stream,
+ * the trace of the resident immature set against the pose of the batch's FIRST hypothesis — the try the reference's loop ends on whenever it is good
+ * (DSOTracker.h:306-309): the pairs host -> frame (frame = refToNew o reference; K R K^-1, K t, exposure transfer with exposure times 1,
+ * DSOTracer.cpp:606-608, Exposure.h:119-123) are formed on the device from that result, `hosts` (world -> camera pose and exposure of every window
+ * frame) and `reference`.  cmlhip_tracker_optimize_wait returns when the whole chain has run.  The caller replays the selection of
+ * DSOTracker.h:262-313 on the results: when it adopts the first try, cmlhip_tracer_trace_resident_finish(keep = 1) returns the status histogram and
+ * the pairs that were used; otherwise keep = 0 restores every traced point (the kernel journals what it overwrites) and the caller traces again with
+ * the pairs of the pose it did select (cmlhip_tracer_trace_resident). */
+typedef struct { double R[9], t[3], a, b; } cmlhip_frame_pose;          /* world -> camera, exposure parameters */
+int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* ctx, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
+                                               const cmlhip_frame_pose* hosts, const cmlhip_frame_pose* reference, const double K[4], int skip_host);
+int cmlhip_tracer_trace_resident_finish(cmlhip_ctx* ctx, int keep, int counts[6], cmlhip_trace_pair* pairs_out /* n_hosts or NULL */);
 typedef struct {            /* host -> target of the activation window: Camera::to and Exposure::to (DSOTracer.cpp:418-420) */
     double R[9], t[3], aff_a, aff_b;
 } cmlhip_activation_pair;

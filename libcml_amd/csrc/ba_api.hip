@@ -614,6 +614,17 @@ int cmlhip_ba_set_arithmetic(cmlhip_ctx* c, int mode) { CML_DEV_SCOPED(c);
     return CMLHIP_OK;
 }
 
+int cmlhip_ba_set_resident_outputs(cmlhip_ctx* c, int mode) { CML_DEV_SCOPED(c);
+    if (!c || (mode != CMLHIP_RESIDENT_OUTPUTS_FULL && mode != CMLHIP_RESIDENT_OUTPUTS_LEAN)) return CMLHIP_ERR_INVALID;
+    c->rs_lean = mode == CMLHIP_RESIDENT_OUTPUTS_LEAN;
+    return CMLHIP_OK;
+}
+int cmlhip_ba_get_resident_outputs(cmlhip_ctx* c, int* mode) {
+    if (!c || !mode) return CMLHIP_ERR_INVALID;
+    *mode = c->rs_lean ? CMLHIP_RESIDENT_OUTPUTS_LEAN : CMLHIP_RESIDENT_OUTPUTS_FULL;
+    return CMLHIP_OK;
+}
+
 // DSOFrame::getB0 follows state_zero (DSOFrame.h:197-199): run()'s epilogue re-anchors the newest frame (setEvalPT, BA.cpp:885-894), so
 // the b0 uploaded with the window is stale for residuals HOSTED by that frame from then on (the closing linearizeAll(true), tryMarginalize)
 struct B0Args { float b0[CMLHIP_MAX_FRAMES]; };

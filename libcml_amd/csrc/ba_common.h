@@ -82,12 +82,17 @@ struct BAArgs {
 #define CML_DEBUG_RS_TILES 4096                 // development: per-tile stamps of k_ba_lin_rs behind the CMLHIP_DEBUG_SLOTS (cmlhip_debug_timestamps)
 #define RS_TILE 64                                 // residuals per wave tile of the lane-per-residual kernel (16 for the 4-lane kernel: cmlhip_ctx::rs_tile)
 // resident residual kernel (ba_linearize_rs.hip): wave tiles of <= RS_TILE residuals of one (host,target) pair
+#define RS_LEAN_BIT 0x10000
+#define RS_STAGGER_OF(flags) (((flags) >> 8) & 255)
 struct RsArgs {
     const int4* tiles; int ntiles;                 // {first residual, count, host, target}
     const float* r_px; const float* r_py;          // the point's pixel, per residual
     const float* r_colors; const float* r_weights; // [R][8] the point's pattern colours / weights, per residual
     const double* r_idepth;                        // the point's inverse depth, per residual (kept current by k_ba_backsub's point step; refreshed when another path wrote pt_idepth)
-    int dbg_flags;                                 // development switches (CMLHIP_RS_DBG)
+    int dbg_flags;                                 // ONE word (the kernel sits at the scalar-register limit): bits 0-7 development switches (CMLHIP_RS_DBG);
+                                                   // bits 8-15 RS_STAGGER: lane-per-residual kernel, phase shift of the waves sharing a SIMD, x 0.43 us x the wave's slot;
+                                                   // bit 16 RS_LEAN: cmlhip_ba_set_resident_outputs(CMLHIP_RESIDENT_OUTPUTS_LEAN) — centerProjectedTo and the returned energy are
+                                                   // not stored, state_NewEnergyWithOutlier only for residuals into the newest frame (setNewFrameEnergyTH's input, BA.cpp:2419-2464)
     const int* stop_lin;                           // never null: ResidentCtl::stop_lin of the window, or a word that stays zero (read with the inputs, tested behind them)
     float* part;                                   // [ntiles][64][4]: the wave's 16x16 fp32 tile of its pair's 13x13 block (MFMA D layout)
 };

@@ -142,6 +142,11 @@ template <int LDM> struct RsRow<false, LDM> {
 #define RS_S_D0 21
 #define RS_S_D1 40
 
+// the target frame of tile ti, re-read from the tile table at the kernel's tail (a scalar load; not a register held over the pixel loop)
+__device__ __forceinline__ int rs_tile_target(const int4* tiles, int ti) {
+    return *(const __attribute__((address_space(4))) int*)(reinterpret_cast<const int*>(tiles + ti) + 3);
+}
+
 template <bool HALF, int WPE, int WPB, int LDM, bool RELAX = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPE))) void k_ba_lin_rs(BAArgs A, RsArgs X) {
 #define RS_BATCH 0
@@ -184,7 +189,8 @@ static void fill_rs_args(cmlhip_ctx* c, RsArgs& X) {
     X.tiles = c->rs_tiles.as<int4>(); X.ntiles = c->n_tiles;
     X.r_px = c->r_px.as<float>(); X.r_py = c->r_py.as<float>(); X.r_colors = c->r_colors.as<float>(); X.r_weights = c->r_weights.as<float>();
     X.part = c->rs_part.as<float>(); X.r_idepth = c->r_idepth.as<double>();
-    { static const char* e = getenv("CMLHIP_RS_DBG"); X.dbg_flags = e ? atoi(e) : 0; }      // development: 1 = all texel taps at texel 0, 2 = no tile / reduced-record stores
+    { static const char* e = getenv("CMLHIP_RS_DBG"); X.dbg_flags = e ? (atoi(e) & 255) : 0; }      // development: 1 = all texel taps at texel 0, 2 = no tile / reduced-record stores, 4 / 8 cached taps, 16 / 32 / 64 single stores off
+    { static const char* e = getenv("CMLHIP_RS_FULL"); if (c->rs_lean && !e) X.dbg_flags |= RS_LEAN_BIT; }      // (development: CMLHIP_RS_FULL forces the full outputs for an A/B)
     X.stop_lin = reinterpret_cast<const int*>(c->scal.as<char>() + CML_ZERO_WORD_OFFSET);
 }
 int cml_fill_rs4_batch(cmlhip_ctx* c, const BAArgs& A, std::vector<unsigned char>& blob, int& blocks) {
@@ -219,6 +225,9 @@ int cml_launch_linearize_rs(cmlhip_ctx* c, const BAArgs& A) {
     static const char* e_wpb = getenv("CMLHIP_RS_WPB");        // development: waves per workgroup (1 or 4)
     const int wpb = e_wpb ? atoi(e_wpb) : 4;
     X.ntiles = nt;
+    // waves that share a SIMD start a third of a wave's life apart (measured at config E, 2.6 waves per SIMD: 31.5 -> 29.6 us); windows of at most
+    // one wave per SIMD are unaffected (a lone wave has slot 0)
+    { static const char* e_st = getenv("CMLHIP_RS_STAGGER"); X.dbg_flags |= ((e_st ? atoi(e_st) : 8) & 255) << 8; }
     static const char* e_ldm = getenv("CMLHIP_RS_LDM");        // development: 1 = nontemporal texel loads
     const int ldm = e_ldm ? atoi(e_ldm) : 0;
     if (c->arith_relaxed) {                                 // CMLHIP_ARITH_RELAXED: the throughput-regime kernel only (small windows keep the exact 4-lane kernel)

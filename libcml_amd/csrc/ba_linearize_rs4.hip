@@ -378,7 +378,7 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         int ns_final = pre_new_state;
         bool state_now_oob = (st == CMLHIP_RES_OOB), wrote_e = false;
         if (run) {
-            if (centre_in) {                                        // setCenterProjectedTo, :131
+            if (centre_in && !(X.dbg_flags & RS_LEAN_BIT)) {                             // setCenterProjectedTo, :131 (lean outputs: nothing on the product path reads it)
                 A.r_center[3 * (size_t)r] = (float)Kud; A.r_center[3 * (size_t)r + 1] = (float)Kvd;
                 A.r_center[3 * (size_t)r + 2] = new_idepth;
             }
@@ -401,8 +401,8 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
             }
             A.r_new_state[r] = ns_final;
         }
-        A.r_new_energy_wo[r] = nwo;
-        A.r_ret_energy[r] = ret;
+        if (!(X.dbg_flags & RS_LEAN_BIT)) { A.r_new_energy_wo[r] = nwo; A.r_ret_energy[r] = ret; }     // lean outputs: NewEnergyWithOutlier only where setNewFrameEnergyTH reads it
+        else if (T.w == A.N - 1) A.r_new_energy_wo[r] = nwo;
         ret_d = (double)ret; ns_cnt = ns_final;
         int code = -1;
         if (!state_now_oob) {                                       // applyRes

@@ -156,6 +156,8 @@ struct cmlhip_ctx {
     DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec, Hf, bf;    // (8N+4)^2 / (8N+4) doubles; Hf/bf = final LM system
     double trk_early_rmse = 0.0;                              // cmlhip_tracker_set_early_exit: > 0: hypothesis 0 may end the batch (tracker_opt.hip)
     bool arith_relaxed = false;                               // cmlhip_ba_set_arithmetic(CMLHIP_ARITH_RELAXED): see ba_linearize_rs_body.inc
+    int device_share = 1;                                     // cmlhip_set_device_share: contexts that launch on this device at the same time (sequence shards per GPU)
+    bool rs_lean = false;                                     // cmlhip_ba_set_resident_outputs(CMLHIP_RESIDENT_OUTPUTS_LEAN): RsArgs::lean of the resident residual kernels
     DevBuf bM_raw; bool resident_prior = false;               // resident loop with the marginalisation prior: mMarginalizedB as handed over; bM then holds bM_raw + HM * delta of the CURRENT frame states (cmlhip_ba_set_resident_prior)
     DevBuf tr_points, tr_pairs, tr_out;
     DevBuf ini_points, ini_partial;          // coarse initializer (initializer.hip)
@@ -163,6 +165,9 @@ struct cmlhip_ctx {
     DevBuf lba_frames, lba_cams, lba_points, lba_off, lba_edges, lba_err, lba_flags, lba_work;   // local bundle adjustment (lba.hip)
     const volatile unsigned char* lba_stop = nullptr;         // the caller's pbStopFlag (cmlhip_lba_set_stop_flag): g2o's forceStopFlag
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
+    DevBuf trk_pose0;                                         // {R, t, a, b} of the pending batch's first result, on the device
+    DevBuf tr_hosts, tr_journal; void* tr_host = nullptr; void* tr_host_dev = nullptr;      // cmlhip_tracer_trace_resident_tracked_async: host poses, the rollback journal, mapped block {counts | pairs}
+    bool tr_spec_pending = false, tr_counts_dirty = true; int tr_spec_hosts = 0, tr_spec_skip = -2;
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)
     DevBuf rr_scratch;                                        // R-length readbacks permuted back to the caller's order on the device (ResRead, ba_api.hip)
@@ -191,6 +196,9 @@ struct cmlhip_ctx {
     DevBuf trk_early;                                         // cmlhip_tracker_set_early_exit: the word hypothesis 0 raises (own buffer, cleared per armed launch)
     DevBuf trk_xch;                                           // cmlhip_tracker_optimize_batch: partial sums + tickets of the workgroups of a hypothesis
     void* trk_opt_host = nullptr; size_t trk_opt_host_bytes = 0;   // mapped, coherent host block of cmlhip_tracker_optimize_batch: hypotheses in, results out
+    void* trk_opt_host_dev = nullptr;                         // its device address
+    int trk_pending_n = 0; size_t trk_pending_res_off = 0, trk_pending_late_off = 0;   // cmlhip_tracker_optimize_batch_async: a batch is in flight (results at res_off of the block)
+    void* done_word = nullptr; void* done_word_dev = nullptr; unsigned done_ticket = 0; bool done_pending = false;   // completion tickets (cml_done_enqueue / cml_done_wait, tracker_opt.hip)
     unsigned trk_xch_gen = 0; int trk_epoch = 0;              // tracker exchange buffer: cleared once per ALLOCATION (DevBuf::gen) and when the 16-bit launch number wraps (tracker_opt.hip)
     int trk_capacity[2] = {0, 0};                              // workgroups of k_tracker_optimize<half> the device holds at once (CUs x occupancy), 0 = not asked yet
     DevBuf x_ticket; bool x_ticket_zeroed = false, backsub_merged = false; int x_ticket_seq = 0;      // K6 inside the K5 launch (BacksubCall)
@@ -241,6 +249,10 @@ void cml_d2h_batch_begin(cmlhip_ctx* c);
 int cml_d2h_batch_flush(cmlhip_ctx* c);
 const Pyramid* cml_find_pyr(cmlhip_ctx* c, uint64_t id);
 int cml_tiled_level0(cmlhip_ctx* c, uint64_t id, const void** out);      // builds (once) and returns the tiled fp16 level 0 of a cached pyramid
+int cml_done_enqueue(cmlhip_ctx* c);                       // a ticket behind everything enqueued on the context's stream so far ...
+int cml_done_embed(cmlhip_ctx* c, unsigned* ticket, volatile unsigned** word_dev);      // ... or written by a kernel of the caller's own as its last act
+int cml_done_wait(cmlhip_ctx* c);                          // ... and the host's wait for the newest one (spin on a mapped word; the stream when none is pending)
+const cmlhip_tracker_opt_result* cml_tracker_pending_result_dev(cmlhip_ctx* c, int i);
 
 static inline int cml_div_up(int a, int b) { return (a + b - 1) / b; }
 

@@ -12,6 +12,8 @@
 // scalar_t is double in the reference; its float places are kept float; FP contraction is off: results are bit-identical
 // to the CPU statement order.
 #include "cmlhip_internal.h"
+#include <atomic>
+#include <cstring>
 
 #pragma clang fp contract(off)
 
@@ -48,12 +50,15 @@ __device__ __forceinline__ double tr_bcast(double v, int lane) {
     return u.d;
 }
 
+// what trace() writes of a point (DSOTracer.cpp:585-823: lastTraceUV / lastTracePixelInterval / lastTraceStatus, iDepthMin / iDepthMax, quality)
+struct TraceJournal { double idepth_min, idepth_max, quality, last_uv[2], last_pixel_interval; int last_status, pad; };
 struct TraceArgs {
     const void* img; int w, h, n;
     const cmlhip_trace_pair* pairs;
     cmlhip_tracer_params P;
     cmlhip_immature_point* pts;
     int skip_host; int* counts;                // resident mode: host index of the traced frame, status histogram (null otherwise)
+    TraceJournal* journal;                     // speculative trace: the fields trace() may write, saved per point before it runs (null otherwise)
 };
 
 template <bool HALF>
@@ -70,6 +75,13 @@ __global__ __launch_bounds__(256) void k_trace_points(TraceArgs A) {
     if (pi >= A.n) return;                                                         // wave-uniform
     const int host = A.pts[pi].host;
     if (host < 0) return;                                                          // not in the window
+    if (A.journal && l == 0) {
+        const cmlhip_immature_point& q = A.pts[pi];
+        TraceJournal j;
+        j.idepth_min = q.idepth_min; j.idepth_max = q.idepth_max; j.quality = q.quality; j.last_uv[0] = q.last_uv[0]; j.last_uv[1] = q.last_uv[1];
+        j.last_pixel_interval = q.last_pixel_interval; j.last_status = q.last_status; j.pad = 0;
+        A.journal[pi] = j;
+    }
     if (host != A.skip_host) trace_one<HALF>(A, pi);
     if (A.counts && l == 0) {
         __threadfence_block();
@@ -374,7 +386,7 @@ int cmlhip_trace_points(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_pa
     TraceArgs A;
     A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
     A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_points.as<cmlhip_immature_point>();
-    A.skip_host = -2; A.counts = nullptr;
+    A.skip_host = -2; A.counts = nullptr; A.journal = nullptr;
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_trace_points<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     else k_trace_points<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
@@ -411,11 +423,191 @@ int cmlhip_tracer_trace_resident(cmlhip_ctx* c, uint64_t image_id, const cmlhip_
     TraceArgs A;
     A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
     A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_resident.as<cmlhip_immature_point>();
-    A.skip_host = skip_host; A.counts = c->tr_out.as<int>();
+    A.skip_host = skip_host; A.counts = c->tr_out.as<int>(); A.journal = nullptr;
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_trace_points<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     else k_trace_points<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
+    c->tr_counts_dirty = true;
     return cml_d2h(c, counts, c->tr_out.p, 24);
+}
+
+// ---- traceNewCoarse of the resident set behind a tracker batch that is still in flight (one enqueue, one wait per tracked frame).
+// The pose traced against is the FIRST hypothesis' result — the try trackWithMotionModel's loop ends on whenever it is good (DSOTracker.h:306-309);
+// the caller replays the selection on the batch's results after the wait and either keeps the trace or rolls it back (the journal) and traces
+// again with the pose it did select.  Pairs as DSOTracer.cpp:606-608 forms them: frame = refToNew o reference, host -> frame = frame o host^-1,
+// K R K^-1, K t, and the exposure transfer with exposure times 1 (Exposure.h:119-123).
+}  // extern "C" (device code of the tracked trace)
+#define TR_INLINE_HOSTS 8
+struct TraceTracked {                          // kernel arguments of the tracked trace: the window's poses travel with the launch (windows of up to TR_INLINE_HOSTS frames)
+    const double* pose0;                       // {R[9], t[3], a, b} of the batch's first result (device; written by k_tracker_optimize)
+    cmlhip_frame_pose ref; double K[4]; int n_hosts, pad;
+    cmlhip_frame_pose hosts[TR_INLINE_HOSTS];
+};
+__device__ __forceinline__ void tp_mul33(const double* A_, const double* B_, double* C_) {       // C = A B, row by row, left to right
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C_[3 * i + j] = (A_[3 * i] * B_[j] + A_[3 * i + 1] * B_[3 + j]) + A_[3 * i + 2] * B_[6 + j];
+}
+// host -> frame for one host (every caller gets the same bits: one function, contraction off)
+__device__ __forceinline__ void tp_pair(const double* pose0, const cmlhip_frame_pose& ref, const double* K, const cmlhip_frame_pose& H, cmlhip_trace_pair& P) {
+    double R[9], t[3];
+    for (int k = 0; k < 9; k++) R[k] = pose0[k];
+    for (int k = 0; k < 3; k++) t[k] = pose0[9 + k];
+    const double an = pose0[12], bn = pose0[13];
+    double Rn[9], tn[3];
+    tp_mul33(R, ref.R, Rn);                                                                     // frame = refToNew o reference
+    for (int i = 0; i < 3; i++) tn[i] = ((R[3 * i] * ref.t[0] + R[3 * i + 1] * ref.t[1]) + R[3 * i + 2] * ref.t[2]) + t[i];
+    double HT[9], Rr[9], tr[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) HT[3 * i + j] = H.R[3 * j + i];
+    tp_mul33(Rn, HT, Rr);                                                                       // Rn Rh^T
+    for (int i = 0; i < 3; i++) tr[i] = tn[i] - ((Rr[3 * i] * H.t[0] + Rr[3 * i + 1] * H.t[1]) + Rr[3 * i + 2] * H.t[2]);
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const double Km[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0 / fx, 0, -cx / fx, 0, 1.0 / fy, -cy / fy, 0, 0, 1};
+    double KR[9];
+    tp_mul33(Km, Rr, KR);
+    tp_mul33(KR, Ki, P.KRKi);
+    for (int i = 0; i < 3; i++) P.Kt[i] = (Km[3 * i] * tr[0] + Km[3 * i + 1] * tr[1]) + Km[3 * i + 2] * tr[2];
+    const double a = exp(an - H.a);
+    P.aff_a = a; P.aff_b = bn - a * H.b;
+}
+// the trace with the pairs formed IN the launch: a wave derives the pair of its point's host from the first result (a few hundred wave-uniform
+// operations against a launch of its own for all of them), parks it in LDS and traces against it
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_trace_points_tracked(TraceArgs A, TraceTracked T) {
+    __shared__ cmlhip_trace_pair s_pair[4];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + wv;
+    if (pi >= A.n) return;                                                         // wave-uniform
+    const int host = A.pts[pi].host;
+    if (host < 0 || host >= T.n_hosts) return;                                     // not in the window
+    if (l == 0) {
+        const cmlhip_immature_point& q = A.pts[pi];
+        TraceJournal j;
+        j.idepth_min = q.idepth_min; j.idepth_max = q.idepth_max; j.quality = q.quality; j.last_uv[0] = q.last_uv[0]; j.last_uv[1] = q.last_uv[1];
+        j.last_pixel_interval = q.last_pixel_interval; j.last_status = q.last_status; j.pad = 0;
+        A.journal[pi] = j;
+    }
+    if (host != A.skip_host) {
+        if (l == 0) tp_pair(T.pose0, T.ref, T.K, T.hosts[host], s_pair[wv]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                     // (one wave writes and reads its slot: in-order LDS, compiler ordering)
+        __builtin_amdgcn_wave_barrier();
+        TraceArgs B = A;
+        B.pairs = &s_pair[wv] - host;                                              // trace_one indexes the pairs by the point's host
+        trace_one<HALF>(B, pi);
+    }
+    if (l == 0) {
+        __threadfence_block();
+        atomicAdd(A.counts + A.pts[pi].last_status, 1);
+    }
+}
+// windows of more than TR_INLINE_HOSTS frames: the pairs by a launch of their own (hosts from the mapped block)
+struct TracePoseArgs { const double* pose0; cmlhip_frame_pose ref; double K[4]; int n_hosts; const cmlhip_frame_pose* hosts; cmlhip_trace_pair* pairs; };
+__global__ void k_trace_pairs_from_tracker(TracePoseArgs A) {
+    const int h = threadIdx.x;
+    if (h >= A.n_hosts) return;
+    cmlhip_trace_pair P;
+    tp_pair(A.pose0, A.ref, A.K, A.hosts[h], P);
+    A.pairs[h] = P;
+}
+__global__ void k_trace_rollback(cmlhip_immature_point* pts, const TraceJournal* journal, int n, int skip_host) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || pts[i].host < 0 || pts[i].host == skip_host) return;
+    const TraceJournal j = journal[i];
+    cmlhip_immature_point& q = pts[i];
+    q.idepth_min = j.idepth_min; q.idepth_max = j.idepth_max; q.quality = j.quality; q.last_uv[0] = j.last_uv[0]; q.last_uv[1] = j.last_uv[1];
+    q.last_pixel_interval = j.last_pixel_interval; q.last_status = j.last_status;
+}
+// the chain's last launch: the status histogram and the pairs the trace used into mapped host memory (the pairs formed again by the same function: same
+// bits), the histogram cleared for the next frame, then — behind a system-scope fence — the completion ticket the host's wait spins on
+struct TracePublish { const double* pose0; cmlhip_frame_pose ref; double K[4]; int n_hosts; const cmlhip_frame_pose* hosts; int* counts; int* out_counts;
+                      cmlhip_trace_pair* out_pairs; volatile unsigned* ticket_word; unsigned ticket; };
+__global__ void k_trace_publish(TracePublish A) {
+    const int t = threadIdx.x;
+    if (t < 6) { A.out_counts[t] = A.counts[t]; A.counts[t] = 0; }
+    if (t < A.n_hosts) {
+        cmlhip_trace_pair P;
+        tp_pair(A.pose0, A.ref, A.K, A.hosts[t], P);
+        A.out_pairs[t] = P;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) { __threadfence_system(); *A.ticket_word = A.ticket; }
+}
+extern "C" {
+
+int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
+                                               const cmlhip_frame_pose* hosts, const cmlhip_frame_pose* reference, const double K[4], int skip_host) { CML_DEV(c);
+    if (!c || !prm || n_hosts < 1 || n_hosts > CMLHIP_MAX_FRAMES || !hosts || !reference || !K) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, cml_tracker_pending_result_dev(c, 0) && c->trk_pose0.p, CMLHIP_ERR_INVALID,
+                "cmlhip_tracer_trace_resident_tracked_async: no tracker batch in flight (cmlhip_tracker_optimize_batch_async first)");
+    CML_REQUIRE(c, !c->tr_spec_pending, CMLHIP_ERR_INVALID, "cmlhip_tracer_trace_resident_tracked_async: the previous speculative trace was not finished");
+    const Pyramid* py = cml_find_pyr(c, image_id);
+    CML_REQUIRE(c, py && py->lv[0].grad, CMLHIP_ERR_NOT_FOUND, "traced image not in the pyramid cache");
+    const int n = c->tr_resident_n;
+    int rc;
+    const unsigned gen0 = c->tr_out.gen;
+    if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_trace_pair) * (size_t)CMLHIP_MAX_FRAMES))) return rc;
+    if ((rc = cml_ensure(c, c->tr_out, 64))) return rc;
+    if ((rc = cml_ensure(c, c->tr_journal, sizeof(TraceJournal) * (size_t)std::max(n, 1)))) return rc;
+    if (!c->tr_host) {
+        CML_CHECK(c, hipHostMalloc(&c->tr_host, 64 + (sizeof(cmlhip_trace_pair) + sizeof(cmlhip_frame_pose)) * CMLHIP_MAX_FRAMES, hipHostMallocMapped | hipHostMallocCoherent));
+        CML_CHECK(c, hipHostGetDevicePointer(&c->tr_host_dev, c->tr_host, 0));
+    }
+    // the histogram is cleared by the publishing kernel of every frame; once per allocation (and behind the plain resident trace, which leaves it filled) here
+    if (c->tr_out.gen != gen0 || c->tr_counts_dirty) { CML_CHECK(c, hipMemsetAsync(c->tr_out.p, 0, 24, c->stream)); c->tr_counts_dirty = false; }
+    // the window's poses: in the kernel arguments (up to TR_INLINE_HOSTS frames) and in the mapped block (the publishing kernel, wider windows)
+    char* const hosts_h = static_cast<char*>(c->tr_host) + 64 + sizeof(cmlhip_trace_pair) * CMLHIP_MAX_FRAMES;
+    memcpy(hosts_h, hosts, sizeof(cmlhip_frame_pose) * (size_t)n_hosts);
+    std::atomic_thread_fence(std::memory_order_release);
+    const cmlhip_frame_pose* hosts_dev = reinterpret_cast<const cmlhip_frame_pose*>(static_cast<char*>(c->tr_host_dev) + 64 + sizeof(cmlhip_trace_pair) * CMLHIP_MAX_FRAMES);
+    const double* pose0 = c->trk_pose0.as<double>();
+    TraceArgs A;
+    A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
+    A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_resident.as<cmlhip_immature_point>();
+    A.skip_host = skip_host; A.counts = c->tr_out.as<int>(); A.journal = c->tr_journal.as<TraceJournal>();
+    const bool half = c->lim.texel_format == CMLHIP_TEXEL_F16;
+    if (n > 0 && n_hosts <= TR_INLINE_HOSTS) {
+        TraceTracked T;
+        memset(&T, 0, sizeof T);
+        T.pose0 = pose0; T.ref = *reference; for (int k = 0; k < 4; k++) T.K[k] = K[k];
+        T.n_hosts = n_hosts;
+        memcpy(T.hosts, hosts, sizeof(cmlhip_frame_pose) * (size_t)n_hosts);
+        if (half) k_trace_points_tracked<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A, T);
+        else k_trace_points_tracked<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A, T);
+    } else if (n > 0) {
+        TracePoseArgs PA;
+        PA.pose0 = pose0; PA.ref = *reference; for (int k = 0; k < 4; k++) PA.K[k] = K[k];
+        PA.n_hosts = n_hosts; PA.hosts = hosts_dev; PA.pairs = c->tr_pairs.as<cmlhip_trace_pair>();
+        k_trace_pairs_from_tracker<<<1, 64, 0, c->stream>>>(PA);
+        if (half) k_trace_points<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
+        else k_trace_points<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
+    }
+    TracePublish PB;
+    PB.pose0 = pose0; PB.ref = *reference; for (int k = 0; k < 4; k++) PB.K[k] = K[k];
+    PB.n_hosts = n_hosts; PB.hosts = hosts_dev; PB.counts = c->tr_out.as<int>(); PB.out_counts = static_cast<int*>(c->tr_host_dev);
+    PB.out_pairs = reinterpret_cast<cmlhip_trace_pair*>(static_cast<char*>(c->tr_host_dev) + 64);
+    if ((rc = cml_done_embed(c, &PB.ticket, &PB.ticket_word))) return rc;      // the ticket the tracker's wait (cmlhip_tracker_optimize_wait) then waits for: one host wait for the frame
+    k_trace_publish<<<1, 64, 0, c->stream>>>(PB);
+    CML_CHECK(c, hipGetLastError());
+    c->tr_spec_pending = true; c->tr_spec_hosts = n_hosts; c->tr_spec_skip = skip_host;
+    return CMLHIP_OK;
+}
+
+int cmlhip_tracer_trace_resident_finish(cmlhip_ctx* c, int keep, int counts[6], cmlhip_trace_pair* pairs_out) { CML_DEV(c);
+    if (!c) return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, c->tr_spec_pending, CMLHIP_ERR_INVALID, "cmlhip_tracer_trace_resident_finish: no speculative trace in flight");
+    int rc;
+    if (c->done_pending && (rc = cml_done_wait(c))) return rc;       // (already waited for by cmlhip_tracker_optimize_wait in the usual order)
+    c->tr_spec_pending = false;
+    if (keep) {
+        if (counts) memcpy(counts, c->tr_host, 24);
+        if (pairs_out) memcpy(pairs_out, static_cast<char*>(c->tr_host) + 64, sizeof(cmlhip_trace_pair) * (size_t)c->tr_spec_hosts);
+        return CMLHIP_OK;
+    }
+    const int n = c->tr_resident_n;                          // the caller selected another try: every traced point gets back what it held before
+    if (n > 0) {
+        k_trace_rollback<<<cml_div_up(n, 256), 256, 0, c->stream>>>(c->tr_resident.as<cmlhip_immature_point>(), c->tr_journal.as<TraceJournal>(), n, c->tr_spec_skip);
+        CML_CHECK(c, hipGetLastError());
+    }
+    return CMLHIP_OK;
 }
 
 int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_ids, const double K[4], const cmlhip_activation_pair* pairs,

@@ -10,6 +10,7 @@
 // — only shortens a try, so it is applied afterwards by the caller from the per-pass rmse values this kernel records
 // (cml_amd::DSOTracker::trackWithMotionModelBatched replays DSOTracker.h:262-313 on the results).
 #include "cmlhip_internal.h"
+#include <chrono>
 #include "../host/se3.h"
 #include <cstdlib>
 #include <atomic>
@@ -46,6 +47,7 @@ struct TrkOptArgs {
     // (DSOTracker.h:306-309).  early_flag (device word, holds the launch number once raised) is raised by hypothesis 0 when it ends correct
     // with E/n of level 0 below early_rmse; the other hypotheses see it at their next exchange and give up (n_steps = -1).
     int* early_flag; float early_rmse;
+    double* pose0;                                     // device copy {R[9], t[3], a, b} of the FIRST hypothesis' result: read by the trace enqueued behind the batch (tracer.hip)
 };
 
 // per-evaluation constants exactly as TR.cpp:260-278,426-429 forms them (float), shared by the workgroup
@@ -759,6 +761,11 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         for (int i = 0; i < 9; i++) out->R[i] = R[i];
         for (int i = 0; i < 3; i++) out->t[i] = S.cur_t[i];
         out->a = S.a; out->b = S.b;
+        if (hyp == 0 && g == 0 && A.pose0) {
+            for (int i = 0; i < 9; i++) A.pose0[i] = R[i];
+            for (int i = 0; i < 3; i++) A.pose0[9 + i] = S.cur_t[i];
+            A.pose0[12] = S.a; A.pose0[13] = S.b;
+        }
         for (int l = 0; l < 5; l++) {
             out->E[l] = S.E[l]; out->numTermsInE[l] = S.nT[l]; out->numSaturated[l] = S.nS[l]; out->numRobust[l] = S.nR[l];
             out->levelCutoffRepeat[l] = S.levelCutoffRepeat[l]; out->iterations[l] = S.iterations[l];
@@ -804,11 +811,63 @@ extern "C" int cmlhip_tracker_set_early_exit(cmlhip_ctx* c, double rmse_bar) {
     return CMLHIP_OK;
 }
 
-extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, int levels, const double K0[4], const double ref_exposure[3],
-                                             const double init_exposure[3], const cmlhip_tracker_params* prm, int optimize_a, int optimize_b,
-                                             double saturated_ratio_th, int n_hyp, const cmlhip_tracker_hypothesis* hyp,
-                                             cmlhip_tracker_opt_result* out) { CML_DEV(c);
-    if (!c || !K0 || !ref_exposure || !init_exposure || !prm || n_hyp < 0 || (n_hyp > 0 && (!hyp || !out)) || levels < 1) return CMLHIP_ERR_INVALID;
+// ---- completion tickets: a one-thread kernel behind the work enqueued so far stores the ticket's number in mapped, coherent host memory and the
+// host spins on that word — the wait of a frame's whole chain (tracker batch, speculative trace) without the stream-synchronise path
+// (CMLHIP_NO_POLL=1 restores hipStreamSynchronize for an A/B).  The word only ever grows; a wait that sees nothing for 2 s falls back to the stream.
+__global__ void k_done_ticket(volatile unsigned* word, unsigned ticket) {
+    __threadfence_system();
+    *word = ticket;
+}
+int cml_done_enqueue(cmlhip_ctx* c) {
+    if (!c->done_word) {
+        CML_CHECK(c, hipHostMalloc(&c->done_word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *static_cast<volatile unsigned*>(c->done_word) = 0;
+        CML_CHECK(c, hipHostGetDevicePointer(&c->done_word_dev, c->done_word, 0));
+    }
+    c->done_ticket += 1;
+    k_done_ticket<<<1, 1, 0, c->stream>>>(static_cast<volatile unsigned*>(c->done_word_dev), c->done_ticket);
+    CML_CHECK(c, hipGetLastError());
+    c->done_pending = true;
+    return CMLHIP_OK;
+}
+// a ticket written by a kernel of the caller's own (its last act, behind a system-scope fence): the number to write and where
+int cml_done_embed(cmlhip_ctx* c, unsigned* ticket, volatile unsigned** word_dev) {
+    if (!c->done_word) {
+        CML_CHECK(c, hipHostMalloc(&c->done_word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *static_cast<volatile unsigned*>(c->done_word) = 0;
+        CML_CHECK(c, hipHostGetDevicePointer(&c->done_word_dev, c->done_word, 0));
+    }
+    c->done_ticket += 1;
+    *ticket = c->done_ticket; *word_dev = static_cast<volatile unsigned*>(c->done_word_dev);
+    c->done_pending = true;
+    return CMLHIP_OK;
+}
+int cml_done_wait(cmlhip_ctx* c) {
+    static const char* e_np = getenv("CMLHIP_NO_POLL");
+    if (!c->done_pending || e_np) {
+        CML_CHECK(c, hipStreamSynchronize(c->stream));
+        c->done_pending = false;
+        return CMLHIP_OK;
+    }
+    volatile unsigned* w = static_cast<volatile unsigned*>(c->done_word);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while ((int)(*w - c->done_ticket) < 0) {
+        if ((++spins & 0x3ffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {      // (a failed launch never writes: the stream reports it)
+            CML_CHECK(c, hipStreamSynchronize(c->stream));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    c->done_pending = false;
+    return CMLHIP_OK;
+}
+
+extern "C" int cmlhip_tracker_optimize_batch_async(cmlhip_ctx* c, uint64_t image_id, int levels, const double K0[4], const double ref_exposure[3],
+                                                   const double init_exposure[3], const cmlhip_tracker_params* prm, int optimize_a, int optimize_b,
+                                                   double saturated_ratio_th, int n_hyp, const cmlhip_tracker_hypothesis* hyp) { CML_DEV(c);
+    if (!c || !K0 || !ref_exposure || !init_exposure || !prm || n_hyp < 0 || (n_hyp > 0 && !hyp) || levels < 1) return CMLHIP_ERR_INVALID;
+    if (c->trk_pending_n) { c->err = "cmlhip_tracker_optimize_batch_async: the previous batch has not been waited for (cmlhip_tracker_optimize_wait)"; return CMLHIP_ERR_INVALID; }
     if (n_hyp == 0) return CMLHIP_OK;
     const Pyramid* py = cml_find_pyr(c, image_id);
     CML_REQUIRE(c, py && py->levels >= 1, CMLHIP_ERR_NOT_FOUND, "tracker image not in the pyramid cache");
@@ -838,7 +897,7 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
         else CML_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tracker_optimize<false>, TO_THREADS, 0));
         c->trk_capacity[half] = std::max(1, prop.multiProcessorCount * std::max(per_cu, 1));
     }
-    const int capacity = c->trk_capacity[half];
+    const int capacity = std::max(1, c->trk_capacity[half] / std::max(1, c->device_share));      // (cmlhip_set_device_share: other contexts launch beside this one)
     static const char* e_g = getenv("CMLHIP_TRACKER_G");                  // development: force G (still clamped to what fits)
     int G = e_g ? atoi(e_g) : std::min(TO_PARTS, capacity / n_hyp);
     if (G < 1) G = 1;
@@ -859,12 +918,12 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
         const size_t want = std::max<size_t>(2 * (hyp_bytes + res_bytes) + 256, 64 * 1024);
         CML_CHECK(c, hipHostMalloc(&c->trk_opt_host, want, hipHostMallocMapped | hipHostMallocCoherent));
         c->trk_opt_host_bytes = want;
+        CML_CHECK(c, hipHostGetDevicePointer(&c->trk_opt_host_dev, c->trk_opt_host, 0));
     }
     char* const hb = static_cast<char*>(c->trk_opt_host);
     memcpy(hb, hyp, sizeof(cmlhip_tracker_hypothesis) * (size_t)n_hyp);
     memset(hb + hyp_bytes, 0, res_bytes + sizeof(int));
-    void* dptr = nullptr;
-    CML_CHECK(c, hipHostGetDevicePointer(&dptr, c->trk_opt_host, 0));
+    void* const dptr = c->trk_opt_host_dev;
     A.hyp = reinterpret_cast<const cmlhip_tracker_hypothesis*>(dptr);
     A.out = c->trk_opt_out.as<cmlhip_tracker_opt_result>();
     A.out_host = reinterpret_cast<cmlhip_tracker_opt_result*>(static_cast<char*>(dptr) + hyp_bytes);
@@ -880,6 +939,8 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
         if (c->trk_early.gen != gen0 || c->trk_epoch >= 0xfffe) CML_CHECK(c, hipMemsetAsync(c->trk_early.p, 0, 64, c->stream));
         A.early_flag = c->trk_early.as<int>();
     }
+    if ((rc = cml_ensure(c, c->trk_pose0, 128))) return rc;
+    A.pose0 = c->trk_pose0.as<double>();
     A.late = reinterpret_cast<int*>(static_cast<char*>(dptr) + hyp_bytes + res_bytes);
     // (no per-call clearing: the words carry the launch number; a fresh or moved buffer is cleared once)
     // cleared once per ALLOCATION (DevBuf::gen, not the address: a free + malloc may hand the address back) and whenever the 16-bit launch
@@ -896,10 +957,40 @@ extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, i
     if (half) CML_LAUNCH_EV(c, k_tracker_optimize<true>, n_hyp * G, TO_THREADS, 0, A);
     else CML_LAUNCH_EV(c, k_tracker_optimize<false>, n_hyp * G, TO_THREADS, 0, A);
     CML_CHECK(c, hipGetLastError());
-    CML_CHECK(c, hipStreamSynchronize(c->stream));
-    std::atomic_thread_fence(std::memory_order_acquire);
-    memcpy(out, hb + hyp_bytes, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
-    if (*reinterpret_cast<volatile int*>(hb + hyp_bytes + res_bytes))
+    c->trk_pending_n = n_hyp; c->trk_pending_res_off = hyp_bytes; c->trk_pending_late_off = hyp_bytes + res_bytes;
+    c->done_pending = false;                                 // (a ticket enqueued before this launch does not cover it)
+    return CMLHIP_OK;
+}
+
+// the device address of the pending batch's result `i` (mapped host memory: written by the first workgroup of the hypothesis) — for kernels enqueued
+// behind the batch on the same stream (tracer.hip: the speculative trace reads the first hypothesis' pose from it)
+const cmlhip_tracker_opt_result* cml_tracker_pending_result_dev(cmlhip_ctx* c, int i) {
+    if (!c->trk_pending_n || i < 0 || i >= c->trk_pending_n) return nullptr;
+    return reinterpret_cast<const cmlhip_tracker_opt_result*>(static_cast<char*>(c->trk_opt_host_dev) + c->trk_pending_res_off) + i;
+}
+
+extern "C" int cmlhip_tracker_optimize_wait(cmlhip_ctx* c, cmlhip_tracker_opt_result* out) { CML_DEV(c);
+    if (!c) return CMLHIP_ERR_INVALID;
+    const int n_hyp = c->trk_pending_n;
+    if (n_hyp == 0) return CMLHIP_OK;
+    if (!out) return CMLHIP_ERR_INVALID;
+    c->trk_pending_n = 0;
+    int rc;
+    if (!c->done_pending && (rc = cml_done_enqueue(c))) return rc;      // nothing was enqueued behind the batch with a ticket of its own: one behind the batch
+    if ((rc = cml_done_wait(c))) return rc;
+    const char* const hb = static_cast<const char*>(c->trk_opt_host);
+    memcpy(out, hb + c->trk_pending_res_off, sizeof(cmlhip_tracker_opt_result) * (size_t)n_hyp);
+    if (*reinterpret_cast<const volatile int*>(hb + c->trk_pending_late_off))
         CML_REQUIRE(c, false, CMLHIP_ERR_TIMEOUT, "tracker optimize: a workgroup gave up waiting for the partial sums of its hypothesis (the launch was not co-resident); results are void");
     return CMLHIP_OK;
+}
+
+extern "C" int cmlhip_tracker_optimize_batch(cmlhip_ctx* c, uint64_t image_id, int levels, const double K0[4], const double ref_exposure[3],
+                                             const double init_exposure[3], const cmlhip_tracker_params* prm, int optimize_a, int optimize_b,
+                                             double saturated_ratio_th, int n_hyp, const cmlhip_tracker_hypothesis* hyp,
+                                             cmlhip_tracker_opt_result* out) {
+    if (n_hyp > 0 && !out) return CMLHIP_ERR_INVALID;
+    const int rc = cmlhip_tracker_optimize_batch_async(c, image_id, levels, K0, ref_exposure, init_exposure, prm, optimize_a, optimize_b, saturated_ratio_th, n_hyp, hyp);
+    if (rc || n_hyp == 0) return rc;
+    return cmlhip_tracker_optimize_wait(c, out);
 }

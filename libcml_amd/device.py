@@ -42,6 +42,12 @@ PROTOTYPES = {
     "cmlhip_tracker_get_warped": (C.c_int, [_ctx, _P(_f), _i, _P(_i)]),
     "cmlhip_tracker_optimize_batch": (C.c_int, [_ctx, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(abi.TrackerParams), _i, _i, _d, _i,
                                                 _P(abi.TrackerHypothesis), _P(abi.TrackerOptResult)]),
+    "cmlhip_set_device_share": (C.c_int, [_ctx, _i]),
+    "cmlhip_tracker_optimize_batch_async": (C.c_int, [_ctx, C.c_uint64, _i, _P(_d), _P(_d), _P(_d), _P(abi.TrackerParams), _i, _i, _d, _i,
+                                                      _P(abi.TrackerHypothesis)]),
+    "cmlhip_tracker_optimize_wait": (C.c_int, [_ctx, _P(abi.TrackerOptResult)]),
+    "cmlhip_tracer_trace_resident_tracked_async": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, C.c_void_p, _P(_d), _i]),
+    "cmlhip_tracer_trace_resident_finish": (C.c_int, [_ctx, _i, _P(C.c_int), C.c_void_p]),
     "cmlhip_ba_set_resident_indirect": (C.c_int, [_ctx, _i, _P(_d), _i, _P(abi.ReprojObs), _d, _d]),
     "cmlhip_ba_get_resident_indirect": (C.c_int, [_ctx, _P(_d), _P(_d), _P(_d)]),
     "cmlhip_ba_set_resident_prior": (C.c_int, [_ctx, _P(_d), _P(_d)]),
@@ -85,6 +91,8 @@ PROTOTYPES = {
     "cmlhip_ba_set_frame_energy_th": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_frame_b0": (C.c_int, [_ctx, _P(_f)]),
     "cmlhip_ba_set_arithmetic": (C.c_int, [_ctx, _i]),
+    "cmlhip_ba_set_resident_outputs": (C.c_int, [_ctx, _i]),
+    "cmlhip_ba_get_resident_outputs": (C.c_int, [_ctx, _P(_i)]),
     "cmlhip_tracker_set_early_exit": (C.c_int, [_ctx, _d]),
     "cmlhip_ba_set_idepth": (C.c_int, [_ctx, _P(_d), _P(_f)]),
     "cmlhip_ba_get_idepth": (C.c_int, [_ctx, _P(_d)]),
@@ -250,6 +258,19 @@ class Ctx:
     def tracker_set_early_exit(self, rmse_bar):
         """cmlhip_tracker_set_early_exit: > 0: hypothesis 0 of the following batches may end them (results given up carry n_steps = -1); 0: off"""
         self.ck(self.L.cmlhip_tracker_set_early_exit(self.h, float(rmse_bar)))
+
+    def set_device_share(self, n_contexts):
+        """cmlhip_set_device_share: how many contexts launch on this device beside each other (sequence shards per GPU)"""
+        self.ck(self.L.cmlhip_set_device_share(self.h, int(n_contexts)))
+
+    def ba_set_resident_outputs(self, lean):
+        """cmlhip_ba_set_resident_outputs: False = CMLHIP_RESIDENT_OUTPUTS_FULL (default), True = LEAN (see include/cmlhip.h)"""
+        self.ck(self.L.cmlhip_ba_set_resident_outputs(self.h, 1 if lean else 0))
+
+    def ba_resident_outputs_lean(self):
+        m = _i(0)
+        self.ck(self.L.cmlhip_ba_get_resident_outputs(self.h, C.byref(m)))
+        return bool(m.value)
 
     def ba_set_arithmetic(self, relaxed):
         """cmlhip_ba_set_arithmetic: False = CMLHIP_ARITH_EXACT (default), True = CMLHIP_ARITH_RELAXED (throughput-regime residual kernel only)"""
@@ -447,6 +468,44 @@ class Ctx:
         self.ck(self.L.cmlhip_tracker_optimize_batch(self.h, C.c_uint64(int(image_id)), int(levels), _p(K, _d), _p(re, _d), _p(ie, _d), C.byref(prm),
                                                      int(optimize_a), int(optimize_b), C.c_double(sat_th), n, H, out))
         return [out[i] for i in range(n)]
+
+    def tracker_optimize_batch_async(self, image_id, levels, K0, ref_exp, init_exp, prm, hyps, optimize_a=1, optimize_b=1, sat_th=0.33):
+        """cmlhip_tracker_optimize_batch_async: enqueue only; tracker_optimize_wait() hands the results over."""
+        n = len(hyps)
+        H = (abi.TrackerHypothesis * max(n, 1))()
+        for i, (R, t) in enumerate(hyps):
+            Rr = np.asarray(R, np.float64).ravel()
+            for k in range(9):
+                H[i].R[k] = Rr[k]
+            for k in range(3):
+                H[i].t[k] = float(t[k])
+        K = np.ascontiguousarray(K0, np.float64); re = np.ascontiguousarray(ref_exp, np.float64); ie = np.ascontiguousarray(init_exp, np.float64)
+        self.ck(self.L.cmlhip_tracker_optimize_batch_async(self.h, C.c_uint64(int(image_id)), int(levels), _p(K, _d), _p(re, _d), _p(ie, _d), C.byref(prm),
+                                                           int(optimize_a), int(optimize_b), C.c_double(sat_th), n, H))
+        self._trk_pending = n
+
+    def tracker_optimize_wait(self):
+        n = self._trk_pending
+        out = (abi.TrackerOptResult * max(n, 1))()
+        self.ck(self.L.cmlhip_tracker_optimize_wait(self.h, out))
+        self._trk_pending = 0
+        return [out[i] for i in range(n)]
+
+    def tracer_trace_resident_tracked_async(self, image_id, prm, host_poses, reference, K, skip_host=-2):
+        """cmlhip_tracer_trace_resident_tracked_async behind tracker_optimize_batch_async: host_poses / reference = (R, t, a, b) world -> camera"""
+        def pack(ps):
+            a = np.zeros((len(ps), 14))
+            for i, (R, t, ea, eb) in enumerate(ps):
+                a[i, :9] = np.asarray(R, np.float64).ravel(); a[i, 9:12] = t; a[i, 12] = ea; a[i, 13] = eb
+            return a
+        hp = pack(host_poses); rf = pack([reference]); Kd = np.ascontiguousarray(K, np.float64)
+        self._tr_hosts = len(host_poses)
+        self.ck(self.L.cmlhip_tracer_trace_resident_tracked_async(self.h, int(image_id), C.byref(prm), len(host_poses), hp.ctypes.data, rf.ctypes.data, _p(Kd, _d), int(skip_host)))
+
+    def tracer_trace_resident_finish(self, keep):
+        counts = np.zeros(6, np.int32); pairs = np.zeros(self._tr_hosts, abi.TRACE_PAIR_DTYPE)
+        self.ck(self.L.cmlhip_tracer_trace_resident_finish(self.h, 1 if keep else 0, _p(counts, C.c_int), pairs.ctypes.data))
+        return counts, pairs
 
     def tracker_get_warped(self, capacity):
         out = np.zeros((8, capacity), np.float32)

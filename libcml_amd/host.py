@@ -74,6 +74,8 @@ def lib():
         L.cmlhost_tracker_set_last_residual.argtypes = [_vp, _i, _i, _P(_d)]
         L.cmlhost_tracker_track_with_motion_model.argtypes = [_vp, C.c_uint64, _i, _i, _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_d), _P(_i), _P(_i),
                                                               _P(_i), _P(_i), _P(_i), _P(_i), _P(_d), _i]
+        L.cmlhost_frame_track_and_trace.argtypes = [_vp, _vp, C.c_uint64, _i, _i, _P(_d), _P(_d), _P(_d), _i, _i, _P(_i), _P(_d), _i, _P(_d),
+                                                    _P(_d), _P(_d), _P(_d), _P(_d), _P(_i), _P(_i), _P(_i), _P(_i), _P(_i), _P(_i), _P(_d), _P(_i), _P(_i), _vp]
         L.cmlhost_tracer_create.restype = _vp; L.cmlhost_tracer_create.argtypes = [_vp]
         L.cmlhost_tracer_destroy.argtypes = [_vp]
         L.cmlhost_tracer_add_point.argtypes = [_vp, _f, _f, _i, _P(_f), _P(_f), _P(_d), _f]
@@ -375,6 +377,33 @@ class HostTracker:
                                                               C.byref(tries), C.byref(lcr), int(batched))
         return dict(haveOneGood=bool(good), R=R.reshape(3, 3), t=t, exposure=oe, E=E, numTerms=nt, numSat=ns, isCorrect=bool(ok.value),
                     tooManySaturated=bool(sat.value), winner=win.value, tries=tries.value, lastCoarseRMSE=lcr.value)
+
+    def track_and_trace(self, tracer, new_image, levels, hyps, ref_exp, init_exp, traced_frame_id, frame_ids, host_poses, ref_index, K):
+        """cmlhost_frame_track_and_trace: trackWithMotionModel (batched) and, behind it in the same enqueue, traceNewCoarse of `tracer`'s resident set
+        against the first hypothesis' result — one host wait.  host_poses: list of (R, t, a, b) world -> camera per window keyframe.
+        Returns (tracking result dict as track_with_motion_model, kept, counts[6], pairs used [TRACE_PAIR_DTYPE] or None)."""
+        H = np.zeros((len(hyps), 12))
+        for i, (R, t) in enumerate(hyps):
+            H[i, :9] = np.asarray(R, np.float64).ravel(); H[i, 9:] = t
+        re = np.ascontiguousarray(ref_exp, np.float64); ie = np.ascontiguousarray(init_exp, np.float64)
+        ids = np.ascontiguousarray(frame_ids, np.int32)
+        hp = np.zeros((len(host_poses), 14))
+        for i, (R, t, a, b) in enumerate(host_poses):
+            hp[i, :9] = np.asarray(R, np.float64).ravel(); hp[i, 9:12] = t; hp[i, 12] = a; hp[i, 13] = b
+        Kd = np.ascontiguousarray(K, np.float64)
+        R = np.zeros(9); t = np.zeros(3); oe = np.zeros(2); E = np.zeros(8); nt = np.zeros(8, np.int32); ns = np.zeros(8, np.int32)
+        ok, sat, win, tries, kept = _i(), _i(), _i(), _i(), _i()
+        lcr = _d()
+        counts = np.zeros(6, np.int32); pairs = np.zeros(len(host_poses), abi.TRACE_PAIR_DTYPE)
+        good = self.L.cmlhost_frame_track_and_trace(self.h, tracer.h, int(new_image), levels, len(hyps), _p(H, _d), _p(re, _d), _p(ie, _d), int(traced_frame_id),
+                                                    len(ids), _p(ids, _i), _p(hp, _d), int(ref_index), _p(Kd, _d), _p(R, _d), _p(t, _d), _p(oe, _d), _p(E, _d),
+                                                    _p(nt, _i), _p(ns, _i), C.byref(ok), C.byref(sat), C.byref(win), C.byref(tries), C.byref(lcr), C.byref(kept),
+                                                    _p(counts, _i), pairs.ctypes.data)
+        if good < 0:
+            raise RuntimeError("cmlhost_frame_track_and_trace: " + self.L.cmlhost_tracker_last_error(self.h).decode() + " / " + self.L.cmlhost_tracer_last_error(tracer.h).decode())
+        res = dict(haveOneGood=bool(good), R=R.reshape(3, 3), t=t, exposure=oe, E=E, numTerms=nt, numSat=ns, isCorrect=bool(ok.value),
+                   tooManySaturated=bool(sat.value), winner=win.value, tries=tries.value, lastCoarseRMSE=lcr.value)
+        return res, bool(kept.value), counts, (pairs if kept.value else None)
 
     def close(self):
         if self.h:

@@ -1102,6 +1102,8 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
     lapB("delta+pairs");
     int rc = cmlhip_ba_set_arithmetic(mCtx, mRelaxedArithmetic ? CMLHIP_ARITH_RELAXED : CMLHIP_ARITH_EXACT);
     if (rc) return fail("cmlhip_ba_set_arithmetic", rc);
+    rc = cmlhip_ba_set_resident_outputs(mCtx, (mLeanResidentOutputs && !mKeepResidualEnergies) ? CMLHIP_RESIDENT_OUTPUTS_LEAN : CMLHIP_RESIDENT_OUTPUTS_FULL);
+    if (rc) return fail("cmlhip_ba_set_resident_outputs", rc);
     rc = setPairs(pairs);                                    // (unchanged since run()'s preamble: not sent again — a new set would also discard the pass's pair tiles)
     if (rc) return fail("cmlhip_ba_set_pairs", rc);
     std::vector<double> prior(8 * (size_t)N), dprior(8 * (size_t)N);
@@ -1199,6 +1201,8 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     int rc = cmlhip_upload_scope_begin(mCtx);
     if (rc) return fail("cmlhip_upload_scope_begin", rc);
     struct ScopeGuard { cmlhip_ctx* c; ~ScopeGuard() { cmlhip_upload_scope_end(c); } } scopeGuard{mCtx};      // (error returns leave no scope open)
+    rc = cmlhip_ba_set_resident_outputs(mCtx, (mLeanResidentOutputs && !mKeepResidualEnergies) ? CMLHIP_RESIDENT_OUTPUTS_LEAN : CMLHIP_RESIDENT_OUTPUTS_FULL);   // (the preamble pass already runs lean)
+    if (rc) return fail("cmlhip_ba_set_resident_outputs", rc);
     if (!uploadWindow()) return false;
     {
         std::vector<cmlhip_ba_pair> pairs;

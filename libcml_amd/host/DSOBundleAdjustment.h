@@ -91,6 +91,7 @@ public:
     bool   mResidentLoop = true;                             // run(): keep the iteration loop on the device when the parameters allow it
     bool   mRelaxedArithmetic = false;                       // cmlhip_ba_set_arithmetic(CMLHIP_ARITH_RELAXED) for the iterations of the device-resident loop (include/cmlhip.h; default: exact)
     bool   mKeepResidualEnergies = false;                    // run()'s closing pass also reads state_energy / state_NewEnergy / state_NewState of every residual back (nothing on the host uses them)
+    bool   mLeanResidentOutputs = true;                      // cmlhip_ba_set_resident_outputs(LEAN) for the resident passes of run(): nothing this class reads is affected (FULL when mKeepResidualEnergies)
     double mCPriorValue = 5e9;                               // BA.cpp:2136-2137 (mCPrior is only assigned inside calcLEnergy)
 
     // ---- reference interface (BA.h:28-85), flat arguments

@@ -26,11 +26,15 @@ int DSOTracer::addImmaturePoint(float x, float y, int host_frame_id, const float
     P.d.energy_th = 8 * mSettingOutlierTH;                                      // TRC.cpp:527
     P.my_type = type;
     if (!std::isfinite(P.d.energy_th)) return -1;                               // :531-534
+    pullResident();
+    mResDirty = true;
     mPoints.push_back(P);
     return (int)mPoints.size() - 1;
 }
 
 void DSOTracer::compact() {
+    pullResident();
+    mResDirty = true;
     std::vector<ImmaturePoint> keep;
     for (auto& P : mPoints) if (P.alive && !P.activated) keep.push_back(P);
     mPoints.swap(keep);
@@ -41,34 +45,75 @@ static int indexOf(const std::vector<int>& ids, int id) {
     return -1;
 }
 
-bool DSOTracer::traceNewCoarse(uint64_t traced_image_id, int traced_frame_id, const std::vector<int>& frame_ids,
-                               const std::vector<cmlhip_trace_pair>& pairs, int counts[6]) {
+bool DSOTracer::pullResident() {
+    if (!mHostStale) return true;
+    mHostStale = false;
+    if (mResWho.empty()) return true;
+    std::vector<cmlhip_immature_point> batch(mResWho.size());
+    const int rc = cmlhip_tracer_get_points(mCtx, (int)batch.size(), batch.data());
+    if (rc) { mError = std::string("cmlhip_tracer_get_points: ") + cmlhip_last_error(mCtx); return false; }
+    for (size_t k = 0; k < mResWho.size(); k++) mPoints[mResWho[k]].d = batch[k];
+    return true;
+}
+
+bool DSOTracer::syncResident(const std::vector<int>& frame_ids) {
+    if (!mResDirty && frame_ids == mResFrameIds) return true;
+    if (!pullResident()) return false;
     std::vector<cmlhip_immature_point> batch;
-    std::vector<int> who;
-    for (int c = 0; c < 6; c++) counts[c] = 0;
+    mResWho.clear();
     for (int i = 0; i < (int)mPoints.size(); i++) {
         ImmaturePoint& P = mPoints[i];
         if (!P.alive || P.activated) continue;
         const int h = indexOf(frame_ids, P.frame_id);
         if (h < 0) { P.alive = false; continue; }                               // reference frame left the group, TRC.cpp:20-26
-        if (P.frame_id == traced_frame_id) { counts[P.d.last_status]++; continue; }   // trace() returns the old status, :597-599
         P.d.host = h;
-        batch.push_back(P.d); who.push_back(i);
+        batch.push_back(P.d); mResWho.push_back(i);
     }
-    if (!batch.empty()) {
-        const int rc = cmlhip_trace_points(mCtx, traced_image_id, &prm, (int)pairs.size(), pairs.data(), (int)batch.size(), batch.data());
-        if (rc) { mError = std::string("cmlhip_trace_points: ") + cmlhip_last_error(mCtx); return false; }
-    }
-    for (size_t k = 0; k < who.size(); k++) {
-        mPoints[who[k]].d = batch[k];
-        counts[batch[k].last_status]++;
-    }
+    const int rc = cmlhip_tracer_set_points(mCtx, (int)batch.size(), batch.data());
+    if (rc) { mError = std::string("cmlhip_tracer_set_points: ") + cmlhip_last_error(mCtx); return false; }
+    mResFrameIds = frame_ids;
+    mResDirty = false;
+    return true;
+}
+
+bool DSOTracer::traceNewCoarse(uint64_t traced_image_id, int traced_frame_id, const std::vector<int>& frame_ids,
+                               const std::vector<cmlhip_trace_pair>& pairs, int counts[6]) {
+    for (int c = 0; c < 6; c++) counts[c] = 0;
+    if (!syncResident(frame_ids)) return false;
+    if (mResWho.empty() || pairs.empty()) return true;
+    const int skip = indexOf(frame_ids, traced_frame_id);                       // trace() returns the old status for the traced frame's own points, :597-599
+    const int rc = cmlhip_tracer_trace_resident(mCtx, traced_image_id, &prm, (int)pairs.size(), pairs.data(), skip >= 0 ? skip : -2, counts);
+    if (rc) { mError = std::string("cmlhip_tracer_trace_resident: ") + cmlhip_last_error(mCtx); return false; }
+    mHostStale = true;
+    return true;
+}
+
+bool DSOTracer::traceNewCoarseTrackedAsync(uint64_t traced_image_id, int traced_frame_id, const std::vector<int>& frame_ids,
+                                           const std::vector<cmlhip_frame_pose>& hosts, const cmlhip_frame_pose& reference, const double K[4]) {
+    if (hosts.size() != frame_ids.size() || hosts.empty()) { mError = "traceNewCoarseTrackedAsync: one pose per window frame"; return false; }
+    if (!syncResident(frame_ids)) return false;
+    const int skip = indexOf(frame_ids, traced_frame_id);
+    const int rc = cmlhip_tracer_trace_resident_tracked_async(mCtx, traced_image_id, &prm, (int)hosts.size(), hosts.data(), &reference, K, skip >= 0 ? skip : -2);
+    if (rc) { mError = std::string("cmlhip_tracer_trace_resident_tracked_async: ") + cmlhip_last_error(mCtx); return false; }
+    mTrackedPending = true;
+    return true;
+}
+
+bool DSOTracer::finishTracked(bool keep, int counts[6], std::vector<cmlhip_trace_pair>* pairs_out) {
+    if (!mTrackedPending) { mError = "finishTracked: nothing in flight"; return false; }
+    mTrackedPending = false;
+    if (pairs_out) pairs_out->resize(mResFrameIds.size());
+    const int rc = cmlhip_tracer_trace_resident_finish(mCtx, keep ? 1 : 0, counts, pairs_out ? pairs_out->data() : nullptr);
+    if (rc) { mError = std::string("cmlhip_tracer_trace_resident_finish: ") + cmlhip_last_error(mCtx); return false; }
+    if (keep) mHostStale = true;
     return true;
 }
 
 bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vector<uint64_t>& image_ids, const double K[4], int w, int h,
                                const std::vector<cmlhip_activation_pair>& pairs, std::vector<int>& activated, const SpacingPolicy& spacing) {
     const int N = (int)frame_ids.size(), last = N - 1;
+    if (!pullResident()) return false;
+    mResDirty = true;                                                           // (points leave the set here: activated, dropped, out of the image)
     activated.clear();
     numSkippedBecauseStatus = numSkippedBecausePixelInterval = numSkippedBecauseQuality = numSkippedBecauseDepth = 0;
     numDeletedBecauseOutlier = numDeletedBecauseOOB = numMapped = numNonMapped = numDropped = 0;

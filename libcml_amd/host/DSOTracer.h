@@ -42,15 +42,31 @@ public:
     bool activatePoints(const std::vector<int>& frame_ids, const std::vector<uint64_t>& image_ids, const double K[4], int w, int h,
                         const std::vector<cmlhip_activation_pair>& pairs, std::vector<int>& activated, const SpacingPolicy& spacing = nullptr);
 
+    // traceNewCoarse behind a tracker batch that is still in flight (cmlhip_tracer_trace_resident_tracked_async): the pairs are formed on the device from
+    // the batch's first result, `hosts` (world -> camera pose and exposure of every window frame, in frame_ids order) and `reference` (the keyframe the
+    // hypotheses are relative to).  finishTracked(keep): keep = the caller's replay of the selection adopted that first try — counts / the pairs that were
+    // used come back; otherwise every traced point is restored and the caller traces again (traceNewCoarse) with the pose it did select.
+    bool traceNewCoarseTrackedAsync(uint64_t traced_image_id, int traced_frame_id, const std::vector<int>& frame_ids, const std::vector<cmlhip_frame_pose>& hosts,
+                                    const cmlhip_frame_pose& reference, const double K[4]);
+    bool finishTracked(bool keep, int counts[6], std::vector<cmlhip_trace_pair>* pairs_out);
+
     void compact();                             // forget the points that were activated or removed (getMap().removeMapPoint in the reference): indices change
-    std::vector<ImmaturePoint>& points() { return mPoints; }
+    // The immature set lives ON THE DEVICE between keyframes (cmlhip_tracer_set_points / _trace_resident: a traced frame moves 24 bytes, not the set);
+    // this object's copy of the fields trace() writes is refreshed when somebody looks (points(), activatePoints, compact).
+    std::vector<ImmaturePoint>& points() { pullResident(); return mPoints; }
+    size_t size() const { return mPoints.size(); }
+    const std::vector<ImmaturePoint>& peek() const { return mPoints; }     // the host-owned fields (frame_id, alive, activated, idepth, static patches) are always current
     const std::string& lastError() const { return mError; }
     int numSkippedBecauseStatus = 0, numSkippedBecausePixelInterval = 0, numSkippedBecauseQuality = 0, numSkippedBecauseDepth = 0,
         numDeletedBecauseOutlier = 0, numDeletedBecauseOOB = 0, numMapped = 0, numNonMapped = 0, numDropped = 0;
 
 private:
+    bool syncResident(const std::vector<int>& frame_ids);    // the device's set = the live, not yet activated points, hosts indexed against frame_ids (re-sent only when something changed)
+    bool pullResident();
     cmlhip_ctx* mCtx;
     std::vector<ImmaturePoint> mPoints;
+    std::vector<int> mResWho, mResFrameIds;     // device slot -> index into mPoints; the frame list the device's host indices refer to
+    bool mResDirty = true, mHostStale = false, mTrackedPending = false;
     std::string mError;
 };
 

@@ -253,54 +253,57 @@ bool DSOTracker::trackWithMotionModel(uint64_t new_image_id, int pyramidLevels, 
     return haveOneGood;
 }
 
-bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
-                                             const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
-                                             int* winner, int* tries) {
+int DSOTracker::launchPending(double bar) {
+    PendingBatch& B = mPending;
+    int rc = cmlhip_tracker_set_early_exit(mCtx, bar);
+    if (rc) { mError = std::string("cmlhip_tracker_set_early_exit: ") + cmlhip_last_error(mCtx); return rc; }
+    const double refE[3] = {B.ref.a, B.ref.b, B.ref.t}, initE[3] = {B.init.a, B.init.b, B.init.t};
+    rc = cmlhip_tracker_optimize_batch_async(mCtx, B.image, B.levels, mK, refE, initE, &B.prm, mOptimizeA ? 1 : 0, mOptimizeB ? 1 : 0,
+                                             mSaturatedRatioThreshold, (int)B.H.size(), B.H.data());
+    (void)cmlhip_tracker_set_early_exit(mCtx, 0.0);
+    if (rc) mError = std::string("cmlhip_tracker_optimize_batch_async: ") + cmlhip_last_error(mCtx);
+    return rc;
+}
+
+bool DSOTracker::trackWithMotionModelBatchedEnqueue(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
+                                                    const Exposure& initialExposure) {
+    PendingBatch& B = mPending;
+    if (B.active) { mError = "trackWithMotionModelBatchedEnqueue: the previous batch was not finished"; return false; }
+    if (n_hyp <= 0) return false;
+    B.image = new_image_id; B.pyramidLevels = pyramidLevels; B.ref = referenceExposure; B.init = initialExposure;
+    B.hyp.assign(hyp, hyp + n_hyp);
+    B.H.resize(n_hyp);
+    for (int i = 0; i < n_hyp; i++) { hyp[i].matrix(B.H[i].R); std::memcpy(B.H[i].t, hyp[i].t, sizeof B.H[i].t); }
+    B.prm.huber = (float)mHuberThreshold; B.prm.cutoff_base = (float)mCutoffThreshold; B.prm.cutoff = B.prm.cutoff_base;
+    B.prm.scale_rot = (float)mScaleRotation; B.prm.scale_trans = (float)mScaleTranslation; B.prm.scale_a = (float)mScaleLightA; B.prm.scale_b = (float)mScaleLightB;
+    B.levels = std::min(pyramidLevels, 5);
+    if (maxLevelOverride >= 0) B.levels = std::min(B.levels, maxLevelOverride + 1);
+    // early exit on the device: the bar of the replay's break (lastCoarseRMSE * setting_reTrackThreshold), valid while the selection state is
+    // still empty — i.e. for the FIRST try only (the try the motion model puts its best guess in).  Results behind it come back "given up"
+    // (n_steps = -1); the replay never reads them unless its own test of try 0 disagrees with the device's by a rounding, in which
+    // case the batch runs again in full.
+    B.bar = (mBatchedEarlyExit && n_hyp > 1 && std::isfinite((double)mLastCoarseRMSE) && mLastCoarseRMSE > 0) ? (double)(mLastCoarseRMSE * 1.5f) : 0.0;
+    if (launchPending(B.bar)) return false;
+    B.active = true;
+    return true;
+}
+
+bool DSOTracker::trackWithMotionModelBatchedFinish(SE3& bestRefToNew, Exposure& bestExposure, Residual& residual, int* winner, int* tries, bool* retried) {
+    PendingBatch& B = mPending;
     residual = Residual();
     if (winner) *winner = -1;
     if (tries) *tries = 0;
-    if (n_hyp <= 0) return false;
-    std::vector<cmlhip_tracker_hypothesis> H(n_hyp);
+    if (retried) *retried = false;
+    if (!B.active) { mError = "trackWithMotionModelBatchedFinish: no batch in flight"; return false; }
+    B.active = false;
+    const int n_hyp = (int)B.H.size(), levels = B.levels;
+    const Exposure& initialExposure = B.init;
+    const Exposure& referenceExposure = B.ref;
+    const SE3* hyp = B.hyp.data();
     std::vector<cmlhip_tracker_opt_result> R(n_hyp);
-    for (int i = 0; i < n_hyp; i++) { hyp[i].matrix(H[i].R); std::memcpy(H[i].t, hyp[i].t, sizeof H[i].t); }
-    cmlhip_tracker_params prm;
-    prm.huber = (float)mHuberThreshold; prm.cutoff_base = (float)mCutoffThreshold; prm.cutoff = prm.cutoff_base;
-    prm.scale_rot = (float)mScaleRotation; prm.scale_trans = (float)mScaleTranslation; prm.scale_a = (float)mScaleLightA; prm.scale_b = (float)mScaleLightB;
-    int levels = std::min(pyramidLevels, 5);
-    if (maxLevelOverride >= 0) levels = std::min(levels, maxLevelOverride + 1);
-    const double refE[3] = {referenceExposure.a, referenceExposure.b, referenceExposure.t}, initE[3] = {initialExposure.a, initialExposure.b, initialExposure.t};
-    // Policy.  Round 2 (one workgroup per hypothesis: ~1 ms per launch whatever the number of hypotheses, a host-driven optimize ~0.3 ms)
-    // tried the FIRST hypothesis alone through the host-driven loop and launched the batch only when it did not end the search.  Since
-    // round 3 a hypothesis is spread over up to 8 workgroups and the whole batch costs what one device-resident optimize costs (0.21 ms
-    // for one, 0.24 ms for fifty: DESIGN §7) — less than the 14-25 evaluations of a host-driven loop with a launch, a mapped-memory poll
-    // and host algebra each (0.40 ms per frame in the sequence of round 4).  So the batch runs at once; the hypotheses behind the
-    // reference's early exit are computed speculatively and discarded by the replay below.  mBatchedFirstAlone restores the old order.
-    if (mBatchedFirstAlone) {
-        SE3 T0 = hyp[0];
-        Exposure e0 = initialExposure;
-        mLastResidual = Residual();
-        const Residual r0 = optimize(new_image_id, pyramidLevels, T0, referenceExposure, e0);
-        const double rm0 = (!r0.numTermsInE.empty() && r0.numTermsInE[0] > 0) ? r0.rmse() : std::numeric_limits<double>::quiet_NaN();
-        const bool good0 = r0.isCorrect && std::isfinite(rm0);                              // the two adoption tests of :280-296 on an empty history
-        if (n_hyp == 1 || (good0 && rm0 < mLastCoarseRMSE * 1.5f)) {
-            if (winner) *winner = good0 ? 0 : -1;
-            if (tries) *tries = 1;
-            if (good0) { bestRefToNew = T0; bestExposure = e0; residual = r0; mLastCoarseRMSE = rm0; return true; }
-            if (n_hyp == 1 && !(mFailureMode == 1 || mFailureMode == 2)) return false;
-        }
-    }
-    // early exit on the device: the bar of the break below (lastCoarseRMSE * setting_reTrackThreshold), valid while the selection state is
-    // still empty — i.e. for the FIRST try only (the try the motion model puts its best guess in).  Results behind it come back "given up"
-    // (n_steps = -1); the replay below never reads them unless its own test of try 0 disagrees with the device's by a rounding, in which
-    // case the batch runs again in full.
-    double bar = (mBatchedEarlyExit && n_hyp > 1 && std::isfinite((double)mLastCoarseRMSE) && mLastCoarseRMSE > 0) ? (double)(mLastCoarseRMSE * 1.5f) : 0.0;
   for (int attempt = 0; attempt < 2; attempt++) {
     bool hit_given_up = false;
-    int rc = cmlhip_tracker_set_early_exit(mCtx, bar);
-    if (rc) { mError = std::string("cmlhip_tracker_set_early_exit: ") + cmlhip_last_error(mCtx); return false; }
-    rc = cmlhip_tracker_optimize_batch(mCtx, new_image_id, levels, mK, refE, initE, &prm, mOptimizeA ? 1 : 0, mOptimizeB ? 1 : 0,
-                                       mSaturatedRatioThreshold, n_hyp, H.data(), R.data());
-    (void)cmlhip_tracker_set_early_exit(mCtx, 0.0);
+    int rc = cmlhip_tracker_optimize_wait(mCtx, R.data());
     if (rc) { mError = std::string("cmlhip_tracker_optimize_batch: ") + cmlhip_last_error(mCtx); return false; }
     auto toResidual = [&](const cmlhip_tracker_opt_result& r) {
         Residual o;
@@ -346,15 +349,21 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
         if (haveOneGood && achievedRes < mLastCoarseRMSE * setting_reTrackThreshold) { i++; break; }   // :306-309
         if (haveOneGood && i >= 50) { i++; break; }                                        // :311-313
     }
-    if (hit_given_up && attempt == 0) { bar = 0.0; if (winner) *winner = -1; continue; }   // (the device's test of try 0 and this one differ by a rounding: all hypotheses, in full)
+    if (hit_given_up && attempt == 0) {                      // (the device's test of try 0 and this one differ by a rounding: all hypotheses, in full)
+        if (winner) *winner = -1;
+        if (retried) *retried = true;
+        if (launchPending(0.0)) return false;
+        continue;
+    }
     if (tries) *tries = i;
     if (!haveOneGood) {
         if ((mFailureMode == 1 || mFailureMode == 2) && n_hyp > 0) {                       // :324-352: optimize(cameras[0]) with mLastResidual = trackingResult (not correct: no abort)
             bestRefToNew = hyp[0];                                                         // the reference re-runs optimize() on cameras[0]; an aborted run leaves the pose at cameras[0]
             bestExposure = initialExposure;
             mLastResidual = trackingResult;
-            trackingResult = optimize(new_image_id, pyramidLevels, bestRefToNew, referenceExposure, bestExposure);
+            trackingResult = optimize(B.image, B.pyramidLevels, bestRefToNew, referenceExposure, bestExposure);
             if (winner) *winner = 0;
+            if (retried) *retried = true;                    // (the pose is not the batch's first result: a trace speculated on it must not be kept)
             haveOneGood = true;
         } else {
             return false;
@@ -366,6 +375,37 @@ bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidL
     return haveOneGood;
   }
     return false;
+}
+
+bool DSOTracker::trackWithMotionModelBatched(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
+                                             const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
+                                             int* winner, int* tries) {
+    residual = Residual();
+    if (winner) *winner = -1;
+    if (tries) *tries = 0;
+    if (n_hyp <= 0) return false;
+    // Policy.  Round 2 (one workgroup per hypothesis: ~1 ms per launch whatever the number of hypotheses, a host-driven optimize ~0.3 ms)
+    // tried the FIRST hypothesis alone through the host-driven loop and launched the batch only when it did not end the search.  Since
+    // round 3 a hypothesis is spread over up to 8 workgroups and the whole batch costs what one device-resident optimize costs (0.21 ms
+    // for one, 0.24 ms for fifty: DESIGN §7) — less than the 14-25 evaluations of a host-driven loop with a launch, a mapped-memory poll
+    // and host algebra each (0.40 ms per frame in the sequence of round 4).  So the batch runs at once; the hypotheses behind the
+    // reference's early exit are computed speculatively and discarded by the replay.  mBatchedFirstAlone restores the old order.
+    if (mBatchedFirstAlone) {
+        SE3 T0 = hyp[0];
+        Exposure e0 = initialExposure;
+        mLastResidual = Residual();
+        const Residual r0 = optimize(new_image_id, pyramidLevels, T0, referenceExposure, e0);
+        const double rm0 = (!r0.numTermsInE.empty() && r0.numTermsInE[0] > 0) ? r0.rmse() : std::numeric_limits<double>::quiet_NaN();
+        const bool good0 = r0.isCorrect && std::isfinite(rm0);                              // the two adoption tests of :280-296 on an empty history
+        if (n_hyp == 1 || (good0 && rm0 < mLastCoarseRMSE * 1.5f)) {
+            if (winner) *winner = good0 ? 0 : -1;
+            if (tries) *tries = 1;
+            if (good0) { bestRefToNew = T0; bestExposure = e0; residual = r0; mLastCoarseRMSE = rm0; return true; }
+            if (n_hyp == 1 && !(mFailureMode == 1 || mFailureMode == 2)) return false;
+        }
+    }
+    if (!trackWithMotionModelBatchedEnqueue(new_image_id, pyramidLevels, n_hyp, hyp, referenceExposure, initialExposure)) return false;
+    return trackWithMotionModelBatchedFinish(bestRefToNew, bestExposure, residual, winner, tries);
 }
 
 }  // namespace cml_amd

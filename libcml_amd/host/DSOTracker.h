@@ -65,9 +65,26 @@ public:
     bool trackWithMotionModelBatched(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
                                      const Exposure& initialExposure, SE3& bestRefToNew, Exposure& bestExposure, Residual& residual,
                                      int* winner, int* tries);
+    // The same in two halves, for callers that enqueue more work behind the batch before they wait (one host wait per tracked frame: the immature
+    // points are traced behind it, DSOTracer::traceNewCoarseTrackedAsync): Enqueue launches the batch and returns; Finish waits, then replays the
+    // selection exactly as trackWithMotionModelBatched does.  retried (optional): the replay asked for a result the device's early exit had given
+    // up and the whole batch ran again, synchronously.
+    bool trackWithMotionModelBatchedEnqueue(uint64_t new_image_id, int pyramidLevels, int n_hyp, const SE3* hyp, const Exposure& referenceExposure,
+                                            const Exposure& initialExposure);
+    bool trackWithMotionModelBatchedFinish(SE3& bestRefToNew, Exposure& bestExposure, Residual& residual, int* winner, int* tries, bool* retried = nullptr);
     const std::string& lastError() const { return mError; }
 
 private:
+    struct PendingBatch {
+        bool active = false;
+        uint64_t image = 0; int pyramidLevels = 0, levels = 0;
+        std::vector<SE3> hyp;
+        std::vector<cmlhip_tracker_hypothesis> H;
+        cmlhip_tracker_params prm;
+        Exposure ref, init;
+        double bar = 0.0;
+    } mPending;
+    int launchPending(double bar);                            // cmlhip_tracker_set_early_exit + cmlhip_tracker_optimize_batch_async on mPending
     cmlhip_ctx* mCtx;
     double mK[4] = {1, 1, 0, 0};
     std::string mError;

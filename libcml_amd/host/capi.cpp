@@ -1,5 +1,8 @@
 // capi.cpp — extern "C" handles onto the C++ host mirror (for the Python tests / bench; a C++ caller uses the
 // classes directly).  Nothing here computes: it forwards to cml_amd::DSOBundleAdjustment / DSOTracker.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "DSOBundleAdjustment.h"
@@ -36,6 +39,7 @@ int cmlhost_ba_set_param(void* h, const char* name, double v) {
     else if (n == "mixedBundleAdjustment") b->mMixedBundleAdjustment = v != 0;
     else if (n == "residentLoop") b->mResidentLoop = v != 0;
     else if (n == "keepResidualEnergies") b->mKeepResidualEnergies = v != 0;
+    else if (n == "leanResidentOutputs") b->mLeanResidentOutputs = v != 0;
     else if (n == "relaxedArithmetic") b->mRelaxedArithmetic = v != 0;
     else if (n == "Minimum iDepth Hessian Marginlaization") b->mMinIdepthHMarg = v;
     else if (n == "maxFrames") b->mMaxFrames = (int)v;
@@ -327,6 +331,56 @@ int cmlhost_tracker_track_with_motion_model(void* h, uint64_t new_image, int lev
     return ok ? 1 : 0;
 }
 
+// One tracked frame, one host wait (Hybrid.cpp:383-442: trackWithMotionModel, then traceNewCoarse against the pose it found): the hypothesis batch and,
+// behind it on the same stream, the trace of the resident immature set against the batch's first result are enqueued together; the selection is replayed
+// after the single wait.  kept = 1: the first try was adopted and the trace stands (counts / pairs_used are filled); kept = 0: another try won, tracking
+// failed or fell back — every traced point was restored and the caller traces again with the pose it goes on with (cmlhost_tracer_trace).
+// hosts: n_frames x {R[9], t[3], a, b} world -> camera and exposure of the window's keyframes (frame_ids order), ref_index the keyframe the
+// hypotheses are relative to.
+int cmlhost_frame_track_and_trace(void* trk, void* trc, uint64_t new_image, int levels, int n_hyp, const double* hypRt, const double refExp[3], const double initExp[3],
+                                  int traced_frame_id, int n_frames, const int* frame_ids, const double* hosts, int ref_index, const double K[4],
+                                  double R[9], double t[3], double outExp[2], double* E, int* numTerms, int* numSat, int* isCorrect, int* tooManySaturated,
+                                  int* winner, int* tries, double* lastCoarseRMSE, int* kept, int counts[6], cmlhip_trace_pair* pairs_used) {
+    DSOTracker* T = static_cast<DSOTracker*>(trk);
+    cml_amd::DSOTracer* Tr = static_cast<cml_amd::DSOTracer*>(trc);
+    *kept = 0;
+    if (n_frames < 1 || ref_index < 0 || ref_index >= n_frames) return -1;
+    std::vector<SE3> hyp(n_hyp);
+    for (int i = 0; i < n_hyp; i++) hyp[i] = SE3::fromRt(hypRt + 12 * i, hypRt + 12 * i + 9);
+    Exposure ref(refExp[2], refExp[0], refExp[1]), init(initExp[2], initExp[0], initExp[1]), best = init;
+    std::vector<int> ids(frame_ids, frame_ids + n_frames);
+    std::vector<cmlhip_frame_pose> hp(n_frames);
+    for (int h = 0; h < n_frames; h++) {
+        std::memcpy(hp[h].R, hosts + 14 * (size_t)h, 9 * sizeof(double)); std::memcpy(hp[h].t, hosts + 14 * (size_t)h + 9, 3 * sizeof(double));
+        hp[h].a = hosts[14 * (size_t)h + 12]; hp[h].b = hosts[14 * (size_t)h + 13];
+    }
+    static const bool timing = getenv("CMLHOST_TIMING") != nullptr;
+    const auto T0 = std::chrono::steady_clock::now();
+    auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
+    if (!T->trackWithMotionModelBatchedEnqueue(new_image, levels, n_hyp, hyp.data(), ref, init)) return -1;
+    const double t_a = us();
+    const bool traced = Tr->traceNewCoarseTrackedAsync(new_image, traced_frame_id, ids, hp, hp[ref_index], K);
+    const double t_b = us();
+    SE3 bestT;
+    DSOTracker::Residual res;
+    bool retried = false;
+    const bool ok = T->trackWithMotionModelBatchedFinish(bestT, best, res, winner, tries, &retried);      // the ONE wait of the frame
+    if (timing) fprintf(stderr, "  [frame] tracker enqueued %.0f us | trace enqueued %.0f | waited + replayed %.0f\n", t_a, t_b, us());
+    if (ok) {
+        bestT.matrix(R); std::memcpy(t, bestT.t, 3 * sizeof(double));
+        outExp[0] = best.a; outExp[1] = best.b;
+        for (int l = 0; l < levels && l < (int)res.E.size(); l++) { E[l] = res.E[l]; numTerms[l] = res.numTermsInE[l]; numSat[l] = res.numSaturated[l]; }
+    }
+    *isCorrect = res.isCorrect; *tooManySaturated = res.tooManySaturated; *lastCoarseRMSE = T->mLastCoarseRMSE;
+    if (traced) {
+        const bool keep = ok && *winner == 0 && !retried;
+        std::vector<cmlhip_trace_pair> pr;
+        if (!Tr->finishTracked(keep, counts, &pr)) return -1;
+        if (keep) { *kept = 1; if (pairs_used) std::memcpy(pairs_used, pr.data(), sizeof(cmlhip_trace_pair) * pr.size()); }
+    } else return -1;
+    return ok ? 1 : 0;
+}
+
 // ---- DSOTracer mirror
 void* cmlhost_tracer_create(cmlhip_ctx* ctx) { return new cml_amd::DSOTracer(ctx); }
 void cmlhost_tracer_destroy(void* h) { delete static_cast<cml_amd::DSOTracer*>(h); }
@@ -336,13 +390,13 @@ int cmlhost_tracer_add_point(void* h, float x, float y, int host_frame_id, const
 // n points of one keyframe at once (makeNewTraces): xy n x 2, gray n x 8, dpatch n x 24, gradH n x 4; returns the index of the first
 int cmlhost_tracer_add_points(void* h, int n, const float* xy, int host_frame_id, const float* gray, const float* dpatch, const double* gradH) {
     cml_amd::DSOTracer* t = static_cast<cml_amd::DSOTracer*>(h);
-    const int first = (int)t->points().size();
+    const int first = (int)t->size();
     for (int i = 0; i < n; i++) t->addImmaturePoint(xy[2 * i], xy[2 * i + 1], host_frame_id, gray + 8 * (size_t)i, dpatch + 24 * (size_t)i, gradH + 4 * (size_t)i, 1.f);
     return first;
 }
 void cmlhost_tracer_compact(void* h) { static_cast<cml_amd::DSOTracer*>(h)->compact(); }
 void cmlhost_tracer_get_frame_ids(void* h, int* out) {
-    auto& P = static_cast<cml_amd::DSOTracer*>(h)->points();
+    auto& P = static_cast<cml_amd::DSOTracer*>(h)->peek();
     for (size_t i = 0; i < P.size(); i++) out[i] = P[i].frame_id;
 }
 int cmlhost_tracer_trace(void* h, uint64_t image_id, int traced_frame_id, int n_frames, const int* frame_ids, const cmlhip_trace_pair* pairs, int counts[6]) {
@@ -360,7 +414,7 @@ int cmlhost_tracer_activate(void* h, int n_frames, const int* frame_ids, const u
     for (size_t i = 0; i < act.size() && (int)i < cap; i++) activated[i] = act[i];
     return (int)act.size();
 }
-int cmlhost_tracer_count(void* h) { return (int)static_cast<cml_amd::DSOTracer*>(h)->points().size(); }
+int cmlhost_tracer_count(void* h) { return (int)static_cast<cml_amd::DSOTracer*>(h)->size(); }
 // DSOTracer::activatePoints hands its activated points to BA::addPoints (DSOTracer.cpp:199-210 -> BA.cpp:343-415): pixel, activated inverse depth,
 // host keyframe (window index of the point's frame id), the gray patch as colours, gradient weights sqrt(c / (c + |grad|^2)), c = 50^2 (BA.cpp:405-411).
 // xy_out (n x 2 ints, optional): the pixels handed over (the caller's pixel selector keeps them occupied).  Returns the first BA point index or -1.
@@ -387,7 +441,7 @@ int cmlhost_tracer_add_activated_to_ba(void* tr, void* ba, int n, const int* idx
 }
 // immature points still alive per frame id (what flagFramesForMarginalization weighs, BA.cpp:428-462 via DSOContext's per-frame groups)
 void cmlhost_tracer_immature_counts(void* h, int n_frames, const int* frame_ids, int* counts) {
-    auto& P = static_cast<cml_amd::DSOTracer*>(h)->points();
+    auto& P = static_cast<cml_amd::DSOTracer*>(h)->peek();
     for (int k = 0; k < n_frames; k++) counts[k] = 0;
     for (size_t i = 0; i < P.size(); i++) {
         if (!P[i].alive || P[i].activated) continue;

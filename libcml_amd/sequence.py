@@ -13,6 +13,7 @@ of 12 random candidates per pick), the DistanceMap spacing of activatePoints (no
 registered with noisy true inverse depths, hasDepthPrior as the initializer's points have), the motion-model hypothesis list (a short
 constant-velocity list).  Product-side plumbing for tests and bench.py: it talks to the C++ host mirror (libcmlhost.so) and the C ABI
 only — no oracle.  A checker can subscribe to every stage (`observer`) and is handed that stage's inputs and outputs."""
+import os
 import time
 
 import numpy as np
@@ -151,6 +152,9 @@ class DirectPipeline:
         self._poses = None
         self._prefetched = None                                      # (image id, gray) of the next frame, handed to the image worker
         self.prefetch = True
+        # one enqueue and one host wait per tracked frame (cmlhost_frame_track_and_trace: the immature points are traced behind the tracker batch, on the
+        # first hypothesis' result); False restores the two calls (trackWithMotionModel, then traceNewCoarse with pairs formed here)
+        self.fused = (not mapper_only) and not os.environ.get("CML_SEQ_UNFUSED")
         self.lib_times = {}                                          # stage -> seconds inside the library's calls of that stage (see _c)
         self.run_split = []                                          # per keyframe: the host clock of run()'s phases (HostBA.run_timing)
         self.tprm = abi.default_tracer_params()
@@ -361,9 +365,63 @@ class DirectPipeline:
                        tracer_fids=[int(f) for f in self.trc.frame_ids()])
         return counts
 
+    def track_and_trace(self, gray, next_gray, traced_fid):
+        """the frame's two stages.  Fused (default): cmlhost_frame_track_and_trace — the hypothesis batch and, behind it on the stream, traceNewCoarse against the
+        first hypothesis' result: ONE host wait; when the replayed selection adopts another try (or tracking fails) the trace was rolled back by the library and
+        runs again here with the pose the driver goes on with.  Returns what track() returns."""
+        if not self.fused:
+            r = self.track(gray, next_gray)
+            self.trace(r[0], r[1], r[2], r[3], r[4], traced_fid)
+            return r
+        t0 = time.perf_counter()
+        if self._prefetched is not None and self._prefetched[1] is gray:
+            iid = self._prefetched[0]
+        else:
+            if self._prefetched is not None:
+                self._drop(self._prefetched[0])
+            iid = self._take_id()
+            self._c("pyramid_build", self.ctx.pyramid_build, iid, gray, self.levels)
+        self._prefetched = None
+        if next_gray is not None and self.prefetch:
+            nid = self._take_id()
+            self._c("pyramid_build", self.ctx.pyramid_build_async, nid, next_gray, self.levels)
+            self._prefetched = (nid, next_gray)
+        self._t("pyramid_build", t0)
+        t0 = time.perf_counter()
+        ref = self.kfs[self.ref]
+        poses = self.kf_poses()
+        Rr, tr, ar, br = poses[self.ref]
+        hyps_w = self._hypotheses()
+        hyps = [_rel(Rr, tr, Rw, tw) for Rw, tw in hyps_w]
+        ref_exp = [ar, br, 1.0]; init_exp = [self.last_exposure[0], self.last_exposure[1], 1.0]
+        fids = [kf["fid"] for kf in self.kfs]
+        before = self.trc.points() if self.obs is not None else None
+        res, kept, counts, pairs = self._c("trackAndTrace", self.trk.track_and_trace, self.trc, iid, self.levels, hyps, ref_exp, init_exp, traced_fid, fids, poses,
+                                           self.ref, self.K)
+        self._t("trackAndTrace", t0)
+        ok = bool(res["haveOneGood"])
+        if ok:
+            Rn = res["R"] @ Rr; tn = res["R"] @ tr + res["t"]
+            a, b = float(res["exposure"][0]), float(res["exposure"][1])
+        else:
+            Rn, tn = hyps_w[0]; a, b = self.last_exposure
+            self.stats["tracking_lost"] += 1
+        self._emit("track", image_id=iid, gray=gray, ref_image_id=ref["image_id"], hyps=hyps, ref_exp=ref_exp, init_exp=init_exp, result=res,
+                   last_coarse_rmse=self.last_coarse_rmse, levels=self.levels)
+        if ok:
+            self.last_coarse_rmse = float(res["lastCoarseRMSE"])
+        self.history.append((Rn.copy(), tn.copy())); self.last_exposure = (a, b)
+        self.stats["frames"] += 1
+        if not kept:
+            self.stats["traces_redone"] = self.stats.get("traces_redone", 0) + 1
+            self.trace(iid, Rn, tn, a, b, traced_fid)
+        elif self.obs is not None:
+            self._emit("trace", image_id=iid, pairs=pairs, frame_ids=fids, traced_fid=traced_fid, before=before, after=self.trc.points(), counts=counts,
+                       tracer_fids=[int(f) for f in self.trc.frame_ids()])
+        return iid, Rn, tn, a, b, ok
+
     def non_keyframe(self, gray, next_gray=None):
-        iid, Rn, tn, a, b, ok = self.track(gray, next_gray)
-        self.trace(iid, Rn, tn, a, b, traced_fid=-1)
+        iid, Rn, tn, a, b, ok = self.track_and_trace(gray, next_gray, traced_fid=-1)
         t0 = time.perf_counter()
         self._drop(iid)                                               # CaptureImage::makeUnactive: the id is free for the next frame
         self._t("pyramid_drop", t0)
@@ -372,9 +430,8 @@ class DirectPipeline:
     def keyframe(self, gray, next_gray=None):
         """Hybrid::directMap (direct/Mapping.cpp:47-134)"""
         ctx, ba = self.ctx, self.ba
-        iid, Rn, tn, a, b, ok = self.track(gray, next_gray)
         fid = self.n_fid; self.n_fid += 1
-        self.trace(iid, Rn, tn, a, b, traced_fid=fid)
+        iid, Rn, tn, a, b, ok = self.track_and_trace(gray, next_gray, traced_fid=fid)
         # ---- addNewFrame: flagFramesForMarginalization first (BA.cpp:428), then the frame, the prior block, residuals of the old points
         t0 = time.perf_counter()
         counts = self._immature_counts()

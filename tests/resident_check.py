@@ -132,14 +132,20 @@ def compare_pass(ctx, replay, pre, with_records=False):
     rep["new_state_mismatch"] = int((o["new_state"] != post["new_state"]).sum())
     rep["state_mismatch"] = int((o["state"] != post["state"]).sum())
     rep["good_mismatch"] = int((o["good"] != post["good"]).sum())
-    for k in ("energy", "new_energy", "new_energy_wo"):
+    # CMLHIP_RESIDENT_OUTPUTS_LEAN (what the host mirror's run() sets, include/cmlhip.h): centerProjectedTo is not stored and
+    # state_NewEnergyWithOutlier only for the residuals into the newest frame (setNewFrameEnergyTH's input) — those are then the compared ones
+    lean = ctx.ba_resident_outputs_lean()
+    rep["lean_outputs"] = bool(lean)
+    for k in ("energy", "new_energy"):
         rep[k + "_mismatch"] = int((_u32(o[k]) != _u32(post[k])).sum())
+    wo = (replay._res["target"] == replay.N - 1) if lean else np.ones(replay.R, bool)
+    rep["new_energy_wo_mismatch"] = int((_u32(o["new_energy_wo"])[wo] != _u32(post["new_energy_wo"])[wo]).sum())
     g = o["good"] == 1
     IN = o["new_state"] == 0
     rep["n_good"] = int(g.sum()); rep["n_in"] = int(IN.sum())
     rep["n_sampled"] = int((pre["state"] != 1).sum())          # residuals that enter the pixel loop at all (not absorbed as OOB, BA.cpp:68-72)
     rep["jpjdf_mismatch"] = int((_u32(o["jpjdf"])[g] != _u32(jp)[g]).any(axis=1).sum())
-    rep["center_mismatch"] = int((_u32(o["center"])[IN] != _u32(ce)[IN]).any(axis=1).sum())
+    rep["center_mismatch"] = 0 if lean else int((_u32(o["center"])[IN] != _u32(ce)[IN]).any(axis=1).sum())
     if with_records:                                            # 74-float records the resident kernel never wrote, re-created on demand
         rj = ctx.ba_rj(1)
         rep["record_mismatch"] = int((_u32(o["efsj"])[g] != _u32(rj)[g]).any(axis=1).sum())
@@ -158,9 +164,11 @@ def compare_pass_tolerant(ctx, replay, pre):
         rep[k + "_flips"] = int((o[k] != post[k]).sum())
     same = (o["new_state"] == post["new_state"]) & (o["state"] == post["state"]) & (o["good"] == post["good"])
     m = same & (pre["state"] != 1)
+    lean = ctx.ba_resident_outputs_lean()                     # (see compare_pass)
     for k in ("energy", "new_energy", "new_energy_wo"):
-        a, b = o[k][m].astype(np.float64), post[k][m].astype(np.float64)
-        rep[k + "_rel"] = float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0))) if m.any() else 0.0      # (relative, energies below 1 — 0.35 grey levels per pattern pixel — absolute)
+        mk = m & (replay._res["target"] == replay.N - 1) if (lean and k == "new_energy_wo") else m
+        a, b = o[k][mk].astype(np.float64), post[k][mk].astype(np.float64)
+        rep[k + "_rel"] = float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0))) if mk.any() else 0.0      # (relative, energies below 1 — 0.35 grey levels per pattern pixel — absolute)
     g = m & (o["good"] == 1)
     a, b = o["jpjdf"][g].astype(np.float64), jp[g].astype(np.float64)
     # per row, against the row's largest entry.  The entries are J^T J d products whose two terms can cancel (g = JIdx2 * Jpdd): such rows
@@ -169,6 +177,6 @@ def compare_pass_tolerant(ctx, replay, pre):
     rel = np.abs(a - b).max(axis=1) / np.maximum(np.abs(a).max(axis=1), 1e-6) if g.any() else np.zeros(1)
     rep["jpjdf_rel"] = float(rel.max()); rep["jpjdf_rel_p999"] = float(np.percentile(rel, 99.9)); rep["jpjdf_rel_median"] = float(np.median(rel))
     IN = m & (o["new_state"] == 0)
-    rep["center_abs"] = float(np.abs(o["center"][IN].astype(np.float64) - ce[IN]).max()) if IN.any() else 0.0
+    rep["center_abs"] = float(np.abs(o["center"][IN].astype(np.float64) - ce[IN]).max()) if (IN.any() and not lean) else 0.0
     rep["n_in"] = int(IN.sum())
     return rep
