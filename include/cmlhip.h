@@ -289,6 +289,9 @@ int cmlhip_ba_window_append_residuals(cmlhip_ctx* ctx, int n, const cmlhip_ba_re
 int cmlhip_ba_window_retire_frame(cmlhip_ctx* ctx, int frame);
 int cmlhip_ba_window_compact(cmlhip_ctx* ctx, int n_points, const unsigned char* point_alive, int n_residuals, const unsigned char* residual_alive);
 int cmlhip_ba_window_counts(cmlhip_ctx* ctx, int* P, int* R);      /* entries the library holds (committed or not) */
+/* Owner token of the kept window: a number that changes with every cmlhip_ba_window_reset (cmlhip_ba_upload_window resets).  A caller that appends to a
+ * window it handed over earlier compares the number it remembered: equal sizes alone do not say that the entries are still its own. */
+int cmlhip_ba_window_generation(cmlhip_ctx* ctx, unsigned* generation);
 int cmlhip_ba_window_commit(cmlhip_ctx* ctx, int N, const cmlhip_ba_frame* frames, const double* idepth, const float* idepth_zero,
                             const float* prior, int reset_states, int n_lin, const int* lin_residuals, const int* lin_states);
 /* Upload scope: between begin and end the host-to-device copies of cmlhip_ba_set_params, cmlhip_ba_window_commit, cmlhip_ba_set_pairs,
@@ -340,7 +343,9 @@ int cmlhip_ba_apply(cmlhip_ctx* ctx, int copy_jacobians);
 /* cmlhip_ba_linearize followed by cmlhip_ba_apply(ctx, 1) as ONE pass over the residuals (the preamble of BA::run, BA.cpp:785-790: linearizeAll(false),
  * then applyRes(r, true) of every residual with nothing in between).  Same results as the two calls. */
 int cmlhip_ba_linearize_apply(cmlhip_ctx* ctx, cmlhip_ba_lin_result* out);   /* out == NULL: enqueue only (no host wait); the pass's tail (energy sum, new threshold) rides in
-                                                                               * the next resident iteration's solve launch, its energy comes back as cmlhip_ba_finish_run's `first` */
+                                                                               * the next resident iteration's solve launch (or runs when a getter / cmlhip_ba_finish_run asks);
+                                                                               * its energy comes back as cmlhip_ba_finish_run's `first`.  Follow it with an iteration, a getter
+                                                                               * or cmlhip_ba_finish_run: another call would leave frameEnergyTH of the newest frame pending */
 /* The tail of DSOBundleAdjustment::run in one call and ONE readback: linearizeAll(true) (BA.cpp:896 = linearize + applyRes(true),
  * :1551-1569) followed by everything the host writes back afterwards — residual states / energies (:1571-1640), the points'
  * inverse depths and the per-point accumulators (HdiF -> setInverseDepthHessian, :1889-1901).  pairs must be current.
@@ -462,6 +467,13 @@ int cmlhip_tracer_set_points(cmlhip_ctx* ctx, int n, const cmlhip_immature_point
 int cmlhip_tracer_trace_resident(cmlhip_ctx* ctx, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
                                  const cmlhip_trace_pair* pairs, int skip_host, int counts[6]);
 int cmlhip_tracer_get_points(cmlhip_ctx* ctx, int n, cmlhip_immature_point* points);
+/* The resident set between keyframes, edited where it lies (DSOTracer's list: points leave — activated, dropped, their host frame marginalised,
+ * DSOTracer.cpp:20-26,124-134,216-247 — and makeNewTraces appends, :496-541): the new set is the kept points in the given order (slot i <- old slot
+ * keep[i], with host index hosts[i] in the caller's current frame list) followed by the n_new new records.  cmlhip_tracer_get_state returns the seven
+ * fields trace() writes (56 bytes per point instead of the 232-byte record) — what activatePoints' candidate tests read (DSOTracer.cpp:128-178). */
+typedef struct { double idepth_min, idepth_max, quality, last_uv[2], last_pixel_interval; int last_status, pad; } cmlhip_immature_state;
+int cmlhip_tracer_edit_points(cmlhip_ctx* ctx, int n_keep, const int* keep, const int* hosts, int n_new, const cmlhip_immature_point* new_points);
+int cmlhip_tracer_get_state(cmlhip_ctx* ctx, int n, cmlhip_immature_state* out);
 /* One enqueue and ONE host wait for a tracked frame (Hybrid.cpp:383-442: trackWithMotionModel, then traceNewCoarse against the pose it found).
  * cmlhip_tracker_optimize_batch_async enqueues the hypothesis batch; cmlhip_tracer_trace_resident_tracked_async then enqueues, on the same stream,
  * the trace of the resident immature set against the pose of the batch's FIRST hypothesis — the try the reference's loop ends on whenever it is good
@@ -586,6 +598,11 @@ int cmlhip_lba_optimize(cmlhip_ctx* ctx, int n_frames, cmlhip_lba_frame* frames,
  * fixed (fixLinearization, BA.cpp:2210-2238: res_toZero = resF - J*delta, isLinearized = true).  `in` supplies adHTdeltaF /
  * cdelta; pairs must be current (cmlhip_ba_set_pairs). */
 int cmlhip_ba_relinearize_points(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good);
+/* The same pass with what tryMarginalize's host loop then reads of it (BA.cpp:2296-2304) in the same readback: packed[r] = state | isActiveAndIsGoodNEW << 2 |
+ * isLinearized << 3 | state_NewState << 4 of residual r and — where asked for — its three energies, caller's order: one wait where
+ * cmlhip_ba_relinearize_points + cmlhip_ba_get_states + cmlhip_ba_get_res_to_zero were three. */
+int cmlhip_ba_relinearize_points_packed(cmlhip_ctx* ctx, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good, unsigned char* packed /* R */,
+                                        float* energy /* R or NULL */, float* new_energy /* R or NULL */, float* new_energy_wo /* R or NULL */);
 /* marginalizePointsF (BA.cpp:2466-2500): MARGINALIZED-mode accumulation of the listed points only.
  * M, Mb = stitchDoubleTop(usePrior = false); Msc, Mbsc = stitchDoubleSC with shiftPriorToZero = false.  The caller adds
  * 0.25 * (M - Msc) and 0.25 * (Mb - Mbsc) to the prior (BA.cpp:2502-2507).  (8N+4)^2 / (8N+4) doubles each. */
@@ -645,14 +662,16 @@ int cmlhip_ba_get_resident_state(cmlhip_ctx* ctx, cmlhip_ba_frame_state* frames,
 /* The tail of DSOBundleAdjustment::run (BA.cpp:882-910) when the loop ran resident, with ONE host wait: everything the three getters above return
  * (after the iterations enqueued so far), then — reanchor_newest != 0 — the re-anchoring of the newest frame's evaluation point ON THE DEVICE
  * (setEvalPT(PRE_worldToCam, (0,..,0,a,b)), :885-894: evaluation point = current pose, PRE_RTll_0 / PRE_tTll_0 of the pairs that name the frame,
- * b0) and the closing linearizeAll(true) with cmlhip_ba_finish_keyframe's outputs.  `first` = the summary of the preamble pass enqueued by
- * cmlhip_ba_linearize_apply(ctx, NULL); `last` = the last iteration's pass; frames / pre_w2c are the states BEFORE the re-anchoring (the host mirror
+ * b0) and the closing linearizeAll(true) with cmlhip_ba_finish_keyframe's outputs.  `first` = the ENERGY of the preamble pass enqueued by
+ * cmlhip_ba_linearize_apply(ctx, NULL) (statEnergyP's first entry, BA.cpp:792; filled when cmlhip_ba_resident_convergence armed the control block,
+ * 0 otherwise; its counts and threshold fields are 0: that pass's tail ran inside the first solve launch and only logged its energy); `last` = the
+ * last iteration's pass; frames / pre_w2c are the states BEFORE the re-anchoring (the host mirror
  * re-anchors its own copy from pre_w2c[N-1], the pose the device used).  Any pointer may be NULL.  Replaces: the host round trip between
  * BA::run's loop and its closing pass (frame states up, DSOFramePrecomputed + b0 down). */
 typedef struct {
     cmlhip_ba_frame_state* frames;      /* N */
     double* pre_w2c;                    /* N x 7 (q, t) of PRE_worldToCam */
-    cmlhip_ba_lin_result* first;        /* preamble pass (cmlhip_ba_linearize_apply with out == NULL) */
+    cmlhip_ba_lin_result* first;        /* preamble pass (cmlhip_ba_linearize_apply with out == NULL): `energy` only, see above */
     cmlhip_ba_lin_result* last;         /* last pass of the loop */
     int* iterations; double* energies; int capacity;      /* as cmlhip_ba_get_resident_log */
     double* x;                          /* 8N+4: x of the last solve */

@@ -149,6 +149,8 @@ IPS_GOOD, IPS_OOB, IPS_OUTLIER, IPS_SKIPPED, IPS_BADCONDITION, IPS_UNINITIALIZED
 IMMATURE_POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("host", "<i4"), ("last_status", "<i4"), ("idepth_min", "<f8"), ("idepth_max", "<f8"),
                                  ("gradH", "<f8", (4,)), ("energy_th", "<f8"), ("quality", "<f8"), ("last_uv", "<f8", (2,)),
                                  ("last_pixel_interval", "<f8"), ("gray", "<f4", (8,)), ("dpatch", "<f4", (24,))])
+IMMATURE_STATE_DTYPE = np.dtype([("idepth_min", "<f8"), ("idepth_max", "<f8"), ("quality", "<f8"), ("last_uv", "<f8", (2,)), ("last_pixel_interval", "<f8"),
+                                 ("last_status", "<i4"), ("pad", "<i4")])        # cmlhip_immature_state
 TRACE_PAIR_DTYPE = np.dtype([("KRKi", "<f8", (9,)), ("Kt", "<f8", (3,)), ("aff_a", "<f8"), ("aff_b", "<f8")])
 ACTIVATION_PAIR_DTYPE = np.dtype([("R", "<f8", (9,)), ("t", "<f8", (3,)), ("aff_a", "<f8"), ("aff_b", "<f8")])
 

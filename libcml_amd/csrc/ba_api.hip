@@ -214,6 +214,12 @@ static int window_writable(cmlhip_ctx* c) {
 int cmlhip_ba_window_reset(cmlhip_ctx* c) { CML_DEV_SCOPED(c);
     if (!c) return CMLHIP_ERR_INVALID;
     c->win.P = c->win.R = 0;
+    c->win_generation += 1;                                  // whoever kept entries in the old window sees that it is gone (cmlhip_ba_window_generation)
+    return CMLHIP_OK;
+}
+int cmlhip_ba_window_generation(cmlhip_ctx* c, unsigned* generation) {
+    if (!c || !generation) return CMLHIP_ERR_INVALID;
+    *generation = c->win_generation;
     return CMLHIP_OK;
 }
 
@@ -1131,6 +1137,51 @@ int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
     int ng = 0;
     if ((rc = cml_d2h(c, &ng, counter, sizeof(int)))) return rc;
     if (ng > 0) c->n_lin = std::max(c->n_lin, 1);            // the LINEARIZED blocks of the regular accumulation are live from now on
+    if (n_good) *n_good = ng;
+    return CMLHIP_OK;
+}
+
+// the same pass with what tryMarginalize's host loop reads of it (BA.cpp:2296-2304: state, isActiveAndIsGoodNEW, isLinearized of the candidates'
+// residuals) packed as ONE byte per residual in the caller's order, behind the counter in ONE readback — it was the counter, six R-length arrays
+// and the LINEARIZED flags in three synchronous calls
+__global__ void k_ba_pack_marg(int R, const int* __restrict__ c_dev_of, const int* __restrict__ r_state, const int* __restrict__ r_new_state,
+                               const unsigned char* __restrict__ r_good, const unsigned char* __restrict__ r_lin, unsigned char* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) { const int k = c_dev_of[i]; out[i] = (unsigned char)((r_state[k] & 3) | (r_good[k] ? 4 : 0) | (r_lin[k] ? 8 : 0) | ((r_new_state[k] & 3) << 4)); }
+}
+int cmlhip_ba_relinearize_points_packed(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good, unsigned char* packed,
+                                        float* energy, float* new_energy, float* new_energy_wo) { CML_DEV(c);
+    int rc = ba_check(c, true);
+    if (rc) return rc;
+    if ((rc = cml_materialize_records(c))) return rc;
+    if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx) || !packed)
+        return CMLHIP_ERR_INVALID;
+    if ((rc = upload_accum_in(c, in))) return rc;
+    if ((rc = upload_point_mask(c, n, point_idx))) return rc;
+    BAArgs A;
+    cml_make_ba_args(c, A);
+    A.pt_mask = c->pt_mask.as<unsigned char>();
+    A.lin_partial = nullptr;
+    A.fuse_apply = 1;
+    int* counter = reinterpret_cast<int*>(c->scal.as<char>() + 512);
+    CML_CHECK(c, hipMemsetAsync(counter, 0, sizeof(int), c->stream));
+    cml_launch_marg_reset(c, A);
+    cml_launch_linearize(c, A);
+    cml_launch_marg_fix(c, A, c->adHTd.as<float>(), c->vec_small.as<double>(), counter);
+    const size_t R = c->R;
+    if ((rc = cml_ensure(c, c->run_pack, ((R + 255) & ~size_t(255)) + 4 * (size_t)c->P + 256))) return rc;
+    if (R > 0) k_ba_pack_marg<<<cml_div_up((int)R, 256), 256, 0, c->stream>>>((int)R, c->c_dev_of.as<int>(), c->r_state.as<int>(), c->r_new_state.as<int>(),
+                                                                             c->r_good.as<unsigned char>(), c->r_lin.as<unsigned char>(), c->run_pack.as<unsigned char>());
+    CML_CHECK(c, hipGetLastError());
+    int ng = 0;
+    ResRead rr(c);
+    cml_d2h_batch_begin(c);
+    cml_d2h(c, &ng, counter, sizeof(int));
+    if (R > 0) cml_d2h(c, packed, c->run_pack.p, R);
+    rr.add(energy, c->r_energy.p, 4); rr.add(new_energy, c->r_new_energy.p, 4); rr.add(new_energy_wo, c->r_new_energy_wo.p, 4);
+    if ((rc = cml_d2h_batch_flush(c))) return rc;
+    rr.deliver();
+    if (ng > 0) c->n_lin = std::max(c->n_lin, 1);
     if (n_good) *n_good = ng;
     return CMLHIP_OK;
 }

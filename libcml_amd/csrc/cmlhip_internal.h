@@ -156,6 +156,7 @@ struct cmlhip_ctx {
     DevBuf HA, bA, HL, bL, Hsc, bsc, HM, bM, xvec, Hf, bf;    // (8N+4)^2 / (8N+4) doubles; Hf/bf = final LM system
     double trk_early_rmse = 0.0;                              // cmlhip_tracker_set_early_exit: > 0: hypothesis 0 may end the batch (tracker_opt.hip)
     bool arith_relaxed = false;                               // cmlhip_ba_set_arithmetic(CMLHIP_ARITH_RELAXED): see ba_linearize_rs_body.inc
+    unsigned win_generation = 0;                              // bumped by every cmlhip_ba_window_reset (and so by cmlhip_ba_upload_window): the owner token of the kept window
     int device_share = 1;                                     // cmlhip_set_device_share: contexts that launch on this device at the same time (sequence shards per GPU)
     bool rs_lean = false;                                     // cmlhip_ba_set_resident_outputs(CMLHIP_RESIDENT_OUTPUTS_LEAN): RsArgs::lean of the resident residual kernels
     DevBuf bM_raw; bool resident_prior = false;               // resident loop with the marginalisation prior: mMarginalizedB as handed over; bM then holds bM_raw + HM * delta of the CURRENT frame states (cmlhip_ba_set_resident_prior)
@@ -166,6 +167,7 @@ struct cmlhip_ctx {
     const volatile unsigned char* lba_stop = nullptr;         // the caller's pbStopFlag (cmlhip_lba_set_stop_flag): g2o's forceStopFlag
     DevBuf tr_resident; int tr_resident_n = 0;                // immature set kept on the device (cmlhip_tracer_set_points)                       // immature-point tracer staging
     DevBuf trk_pose0;                                         // {R, t, a, b} of the pending batch's first result, on the device
+    DevBuf tr_resident2, tr_edit, tr_state;                   // cmlhip_tracer_edit_points (the set rebuilt into the second buffer), cmlhip_tracer_get_state
     DevBuf tr_hosts, tr_journal; void* tr_host = nullptr; void* tr_host_dev = nullptr;      // cmlhip_tracer_trace_resident_tracked_async: host poses, the rollback journal, mapped block {counts | pairs}
     bool tr_spec_pending = false, tr_counts_dirty = true; int tr_spec_hosts = 0, tr_spec_skip = -2;
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
@@ -213,7 +215,10 @@ void cml_mark(cmlhip_ctx* c, const char* what);               // development: no
 void cml_marks_dump(cmlhip_ctx* c);
 void cml_scope_abort(cmlhip_ctx* c);                          // a staging call failed inside an open scope: drop the scope's block and deferred launches
 int cml_scope_end(cmlhip_ctx* c);                              // flush the open upload scope (if any) and run what was deferred
-#define CML_DEV(ctx) do { if (ctx) { (void)hipSetDevice((ctx)->device); if ((ctx)->h2d_scope) (void)cml_scope_end(ctx); } } while (0)
+// (a call that is not part of an open upload scope ends it first; when the scope's packed flush or one of its deferred kernels fails, THIS call reports
+//  that status instead of proceeding on a half-built device window)
+#define CML_DEV(ctx) do { if (ctx) { (void)hipSetDevice((ctx)->device); if ((ctx)->h2d_scope) { const int rc_scope_ = cml_scope_end(ctx); \
+        if (rc_scope_) { if ((ctx)->err.empty()) (ctx)->err = "an upload scope that this call ended failed to flush"; return rc_scope_; } } } } while (0)
 #define CML_DEV_SCOPED(ctx) do { if (ctx) (void)hipSetDevice((ctx)->device); } while (0)      /* entries that stage into an open upload scope */
 
 #define CML_CHECK(ctx, call)                                                                      \

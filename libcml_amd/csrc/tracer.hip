@@ -51,7 +51,13 @@ __device__ __forceinline__ double tr_bcast(double v, int lane) {
 }
 
 // what trace() writes of a point (DSOTracer.cpp:585-823: lastTraceUV / lastTracePixelInterval / lastTraceStatus, iDepthMin / iDepthMax, quality)
-struct TraceJournal { double idepth_min, idepth_max, quality, last_uv[2], last_pixel_interval; int last_status, pad; };
+// the immature set changes size at every keyframe: its buffers grow with headroom (an exact-size buffer is freed and allocated again — a stream
+// synchronisation and two driver calls, ~0.3 ms — whenever the set is a few points larger than ever before)
+static int tr_ensure(cmlhip_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return CMLHIP_OK;
+    return cml_ensure(c, b, std::max(bytes + bytes / 2, (size_t)64 * 1024));
+}
+typedef cmlhip_immature_state TraceJournal;     // (include/cmlhip.h: the same seven fields)
 struct TraceArgs {
     const void* img; int w, h, n;
     const cmlhip_trace_pair* pairs;
@@ -396,10 +402,60 @@ int cmlhip_trace_points(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_pa
 int cmlhip_tracer_set_points(cmlhip_ctx* c, int n, const cmlhip_immature_point* points) { CML_DEV(c);
     if (!c || n < 0 || (n > 0 && !points)) return CMLHIP_ERR_INVALID;
     int rc;
-    if ((rc = cml_ensure(c, c->tr_resident, sizeof(cmlhip_immature_point) * (size_t)std::max(n, 1)))) return rc;
+    if ((rc = tr_ensure(c, c->tr_resident, sizeof(cmlhip_immature_point) * (size_t)std::max(n, 1)))) return rc;
     if (n > 0 && (rc = cml_h2d(c, c->tr_resident.p, points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
     c->tr_resident_n = n;
     return CMLHIP_OK;
+}
+
+// the resident set edited where it lies: kept points move to the front (slot i <- old slot keep[i], host index hosts[i]), new points follow
+__global__ void k_tracer_rebuild(const cmlhip_immature_point* __restrict__ old_, cmlhip_immature_point* __restrict__ new_, const int* __restrict__ keep,
+                                 const int* __restrict__ hosts, int n_keep) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), w = threadIdx.x & 63;
+    if (i >= n_keep) return;
+    const unsigned* src = reinterpret_cast<const unsigned*>(old_ + keep[i]);
+    unsigned* dst = reinterpret_cast<unsigned*>(new_ + i);
+    constexpr int NW = sizeof(cmlhip_immature_point) / 4;
+    if (w < NW) dst[w] = src[w];
+    if (w == 0) new_[i].host = hosts[i];
+}
+__global__ void k_tracer_pack_state(const cmlhip_immature_point* __restrict__ pts, cmlhip_immature_state* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cmlhip_immature_point& q = pts[i];
+    cmlhip_immature_state j;
+    j.idepth_min = q.idepth_min; j.idepth_max = q.idepth_max; j.quality = q.quality; j.last_uv[0] = q.last_uv[0]; j.last_uv[1] = q.last_uv[1];
+    j.last_pixel_interval = q.last_pixel_interval; j.last_status = q.last_status; j.pad = 0;
+    out[i] = j;
+}
+int cmlhip_tracer_edit_points(cmlhip_ctx* c, int n_keep, const int* keep, const int* hosts, int n_new, const cmlhip_immature_point* new_points) { CML_DEV(c);
+    if (!c || n_keep < 0 || n_new < 0 || (n_keep > 0 && (!keep || !hosts)) || (n_new > 0 && !new_points) || n_keep > c->tr_resident_n) return CMLHIP_ERR_INVALID;
+    for (int i = 0; i < n_keep; i++) if (keep[i] < 0 || keep[i] >= c->tr_resident_n) { c->err = "cmlhip_tracer_edit_points: slot out of range"; return CMLHIP_ERR_INVALID; }
+    CML_REQUIRE(c, !c->tr_spec_pending, CMLHIP_ERR_INVALID, "cmlhip_tracer_edit_points: a speculative trace is in flight");
+    const int n = n_keep + n_new;
+    int rc;
+    if ((rc = tr_ensure(c, c->tr_resident2, sizeof(cmlhip_immature_point) * (size_t)std::max(n, 1)))) return rc;
+    if (n_keep > 0) {
+        if ((rc = tr_ensure(c, c->tr_edit, 8 * (size_t)n_keep))) return rc;
+        if ((rc = cml_h2d(c, c->tr_edit.p, keep, 4 * (size_t)n_keep))) return rc;
+        if ((rc = cml_h2d(c, c->tr_edit.as<char>() + 4 * (size_t)n_keep, hosts, 4 * (size_t)n_keep))) return rc;
+        k_tracer_rebuild<<<cml_div_up(n_keep, 4), 256, 0, c->stream>>>(c->tr_resident.as<cmlhip_immature_point>(), c->tr_resident2.as<cmlhip_immature_point>(),
+                                                                      c->tr_edit.as<int>(), c->tr_edit.as<int>() + n_keep, n_keep);
+        CML_CHECK(c, hipGetLastError());
+    }
+    if (n_new > 0 && (rc = cml_h2d(c, c->tr_resident2.as<cmlhip_immature_point>() + n_keep, new_points, sizeof(cmlhip_immature_point) * (size_t)n_new))) return rc;
+    std::swap(c->tr_resident, c->tr_resident2);
+    c->tr_resident_n = n;
+    return CMLHIP_OK;
+}
+int cmlhip_tracer_get_state(cmlhip_ctx* c, int n, cmlhip_immature_state* out) { CML_DEV(c);
+    if (!c || n < 0 || n > c->tr_resident_n || (n > 0 && !out)) return CMLHIP_ERR_INVALID;
+    if (n == 0) return CMLHIP_OK;
+    int rc;
+    if ((rc = tr_ensure(c, c->tr_state, sizeof(cmlhip_immature_state) * (size_t)n))) return rc;
+    k_tracer_pack_state<<<cml_div_up(n, 256), 256, 0, c->stream>>>(c->tr_resident.as<cmlhip_immature_point>(), c->tr_state.as<cmlhip_immature_state>(), n);
+    CML_CHECK(c, hipGetLastError());
+    return cml_d2h(c, out, c->tr_state.p, sizeof(cmlhip_immature_state) * (size_t)n);
 }
 
 int cmlhip_tracer_get_points(cmlhip_ctx* c, int n, cmlhip_immature_point* points) { CML_DEV(c);
@@ -546,7 +602,7 @@ int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id,
     const unsigned gen0 = c->tr_out.gen;
     if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_trace_pair) * (size_t)CMLHIP_MAX_FRAMES))) return rc;
     if ((rc = cml_ensure(c, c->tr_out, 64))) return rc;
-    if ((rc = cml_ensure(c, c->tr_journal, sizeof(TraceJournal) * (size_t)std::max(n, 1)))) return rc;
+    if ((rc = tr_ensure(c, c->tr_journal, sizeof(TraceJournal) * (size_t)std::max(n, 1)))) return rc;
     if (!c->tr_host) {
         CML_CHECK(c, hipHostMalloc(&c->tr_host, 64 + (sizeof(cmlhip_trace_pair) + sizeof(cmlhip_frame_pose)) * CMLHIP_MAX_FRAMES, hipHostMallocMapped | hipHostMallocCoherent));
         CML_CHECK(c, hipHostGetDevicePointer(&c->tr_host_dev, c->tr_host, 0));

@@ -210,9 +210,9 @@ __device__ bool to_ldlt_solve_wave(const double* Hs, const double* bs, const dou
 // different (no tie for the search's first-maximum rule to break, no NaN) the sequence is their descending order: the wave ranks them
 // with one ballot, loads the matrix already permuted (P A P^T, pure data movement), and factorises without searches or exchanges — the
 // arithmetic of every step is the one the pivoting form performs on the same numbers, so L, D and x are bit-identical.  Ties / NaN /
-// an all-zero diagonal: `handled` stays false and the caller runs the pivoting form.  s_x: 8 doubles of LDS scratch.
+// an all-zero diagonal: `handled` stays false and the caller runs the pivoting form.  s_x: 64 doubles of LDS scratch.
 __device__ bool to_ldlt_solve_wave_sorted(const double* Hs, const double* bs, const double lambda, const int n, const int map6, double (&xs)[8],
-                                          double* s_x, bool& handled) {
+                                          double* s_x /* 64 doubles */, bool& handled) {
     const int l = threadIdx.x & 63, i = l & 7, a = l >> 3;
     auto mp = [&](int q) { return (q == 6) ? map6 : q; };
     handled = false;
@@ -268,26 +268,43 @@ __device__ bool to_ldlt_solve_wave_sorted(const double* Hs, const double* bs, co
         }
         dd[k] = akk;
     }
-    // substitutions on wave-uniform copies: x = P^T L^-T D^-1 L^-1 P b (LDLT.h:560-600); P b is b in pick order
+    // substitutions: x = P^T L^-T D^-1 L^-1 P b (LDLT.h:560-600); P b is b in pick order.  Round 6: lane i carries unknown i (rows of L are already
+    // lane-resident) instead of every lane replaying all eight on wave-uniform copies — the 56 broadcasts that built those copies, and seven of the
+    // eight IEEE divisions, were half of this solve's 3 us.  Every value keeps its operations and their order: the forward sum of row i runs over
+    // j ascending (multiply, then subtract), the division is lane i's own, the backward sum over j ascending from i + 1.
+    double t = (i < n) ? -bs[mp(idx_k)] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) xs[k] = (k < n) ? -bs[mp(idx_u[k])] : 0.0;
-    double Lm[8][8];
+    for (int j = 0; j < 7; j++) {
+        if (j + 1 >= n) break;                               // wave-uniform
+        const double xj = to_rl(t, j);                       // y_j is final: lane j has subtracted every term below j
+        const double p = row[j] * xj;
+        if (i > j && i < n) t = t - p;
+    }
+    double piv = 0.0;                                        // D_ii: the pivot this lane's row was divided through at step i
 #pragma unroll
-    for (int q = 1; q < 8; q++)
+    for (int k = 0; k < 8; k++) if (i == k) piv = dd[k];
+    t = (i < n) ? ((fabs(piv) > 2.2250738585072014e-308) ? t / piv : 0.0) : 0.0;
+    // column i of L for the backward sum: L_ji sits in lane j — through the 8 x 8 scratch (one replica writes)
+    if (l < 8) {
 #pragma unroll
-        for (int j = 0; j < q; j++) Lm[q][j] = to_rl(row[j], q);
+        for (int j = 0; j < 8; j++) s_x[i * 8 + j] = row[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // one wave, in-order LDS: compiler ordering only
+    __builtin_amdgcn_wave_barrier();
+    double Lt[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) if (q < n) { double t = xs[q];
+    for (int j = 1; j < 8; j++) Lt[j] = s_x[j * 8 + i];     // L_ji (used for j > i only)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < q; j++) t -= Lm[q][j] * xs[j];
-        xs[q] = t; }
+    for (int k = 0; k < 8; k++) xs[k] = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) if (q < n) xs[q] = (fabs(dd[q]) > 2.2250738585072014e-308) ? xs[q] / dd[q] : 0.0;
+    for (int q = 7; q >= 0; q--) {
+        if (q >= n) continue;                                // wave-uniform
+        double u = t;                                        // (lane q's chain is the one that counts: x_q = z_q - sum_{j > q} L_jq x_j, j ascending)
 #pragma unroll
-    for (int q = 7; q >= 0; q--) if (q < n) { double t = xs[q];
-#pragma unroll
-        for (int j = q + 1; j < 8; j++) if (j < n) t -= Lm[j][q] * xs[j];
-        xs[q] = t; }
+        for (int j = q + 1; j < 8; j++) if (j < n) u = u - Lt[j] * xs[j];
+        xs[q] = to_rl(u, q);
+    }
     // P^T: entry k of the permuted solution belongs to unknown idx[k] — through LDS (a register array cannot be indexed by idx)
     double mine = 0.0;
 #pragma unroll

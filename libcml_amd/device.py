@@ -63,6 +63,8 @@ PROTOTYPES = {
     "cmlhip_tracer_set_points": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_tracer_trace_resident": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, _i, _P(C.c_int)]),
     "cmlhip_tracer_get_points": (C.c_int, [_ctx, _i, C.c_void_p]),
+    "cmlhip_tracer_edit_points": (C.c_int, [_ctx, _i, _P(_i), _P(_i), _i, C.c_void_p]),
+    "cmlhip_tracer_get_state": (C.c_int, [_ctx, _i, C.c_void_p]),
     "cmlhip_initializer_calc_res_and_gs": (C.c_int, [_ctx, C.c_uint64, _i, _P(abi.InitParams), _i, C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "cmlhip_ba_finish_keyframe": (C.c_int, [_ctx, C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_ubyte), _P(C.c_double), _P(C.c_float)]),
     "cmlhip_upload_scope_begin": (C.c_int, [_ctx]),
@@ -73,6 +75,7 @@ PROTOTYPES = {
     "cmlhip_ba_window_retire_frame": (C.c_int, [_ctx, _i]),
     "cmlhip_ba_window_compact": (C.c_int, [_ctx, _i, _P(C.c_ubyte), _i, _P(C.c_ubyte)]),
     "cmlhip_ba_window_counts": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_int)]),
+    "cmlhip_ba_window_generation": (C.c_int, [_ctx, _P(C.c_uint)]),
     "cmlhip_ba_window_commit": (C.c_int, [_ctx, _i, C.c_void_p, _P(C.c_double), _P(C.c_float), _P(C.c_float), _i, _i, _P(C.c_int), _P(C.c_int)]),
     "cmlhip_ba_finish_run": (C.c_int, [_ctx, _i, _P(abi.BAResidentOut), C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_ubyte), _P(C.c_double), _P(C.c_float)]),
     "cmlhip_pnp_optimize": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_double), _P(C.c_double), _i, C.c_void_p, _P(C.c_ubyte), _i, _i, _i, _P(abi.PnpResult)]),
@@ -80,6 +83,7 @@ PROTOTYPES = {
     "cmlhip_lba_optimize": (C.c_int, [_ctx, _i, C.c_void_p, _i, _P(C.c_double), _P(C.c_int), C.c_void_p, _i, _i, _i, _P(C.c_ubyte), _P(abi.LbaResult)]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
+    "cmlhip_ba_relinearize_points_packed": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(_i), _P(_i), _P(C.c_ubyte), _P(_f), _P(_f), _P(_f)]),
     "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "cmlhip_ba_lin_energy": (C.c_int, [_ctx, _P(abi.BAAccumIn), _P(C.c_double), _P(C.c_int)]),
     "cmlhip_ba_get_res_to_zero": (C.c_int, [_ctx, _P(C.c_float), _P(C.c_ubyte)]),
@@ -530,6 +534,18 @@ class Ctx:
         counts = np.zeros(6, np.int32)
         self.ck(self.L.cmlhip_tracer_trace_resident(self.h, int(image_id), C.byref(prm), len(pairs), pairs.ctypes.data, int(skip_host), _p(counts, C.c_int)))
         return counts
+
+    def tracer_edit_points(self, keep, hosts, new_points):
+        """cmlhip_tracer_edit_points: kept old slots (with their host index in the current frame list) first, then the new records"""
+        k = np.ascontiguousarray(keep, np.int32); h = np.ascontiguousarray(hosts, np.int32)
+        npnt = np.ascontiguousarray(new_points, abi.IMMATURE_POINT_DTYPE)
+        self.ck(self.L.cmlhip_tracer_edit_points(self.h, len(k), _p(k, _i), _p(h, _i), len(npnt), npnt.ctypes.data))
+        self._tr_n = len(k) + len(npnt)
+
+    def tracer_get_state(self):
+        out = np.zeros(self._tr_n, abi.IMMATURE_STATE_DTYPE)
+        self.ck(self.L.cmlhip_tracer_get_state(self.h, self._tr_n, out.ctypes.data))
+        return out
 
     def tracer_get_points(self):
         out = np.zeros(self._tr_n, abi.IMMATURE_POINT_DTYPE)

@@ -1,6 +1,7 @@
 """ctypes access to the C++ host mirror (libcmlhost.so: cml_amd::DSOBundleAdjustment / DSOTracker over the C ABI).
 Product-side plumbing for tests and bench.py; a C++ caller would use the classes in libcml_amd/host/*.h directly."""
 import ctypes as C
+import time
 import os
 
 import numpy as np
@@ -81,6 +82,7 @@ def lib():
         L.cmlhost_tracer_add_point.argtypes = [_vp, _f, _f, _i, _P(_f), _P(_f), _P(_d), _f]
         L.cmlhost_tracer_add_points.argtypes = [_vp, _i, _P(_f), _i, _P(_f), _P(_f), _P(_d)]
         L.cmlhost_tracer_compact.argtypes = [_vp]
+        L.cmlhost_tracer_prepare_resident.argtypes = [_vp, _i, _P(_i)]
         L.cmlhost_tracer_get_frame_ids.argtypes = [_vp, _P(_i)]
         L.cmlhost_tracer_immature_counts.argtypes = [_vp, _i, _P(_i), _P(_i)]
         L.cmlhost_tracer_add_activated_to_ba.argtypes = [_vp, _vp, _i, _P(_i), _i, _P(_i), _P(_i)]
@@ -340,6 +342,7 @@ class HostTracker:
         self.L = lib()
         self.h = self.L.cmlhost_tracker_create(ctx.h if ctx is not None else None)
         self._eval_keep = None
+        self.last_call_s = None                                 # seconds inside the last C call of track_with_motion_model / track_and_trace (without this wrapper's array packing)
 
     def set_eval(self, fn):
         """fn(level, R[9], t[3], K[4], aff[2], b0, prm, result) -> int; None restores the device evaluation."""
@@ -372,9 +375,11 @@ class HostTracker:
         R = np.zeros(9); t = np.zeros(3); oe = np.zeros(2); E = np.zeros(8); nt = np.zeros(8, np.int32); ns = np.zeros(8, np.int32)
         ok, sat, win, tries = _i(), _i(), _i(), _i()
         lcr = _d()
+        t_c = time.perf_counter()
         good = self.L.cmlhost_tracker_track_with_motion_model(self.h, int(new_image), levels, len(hyps), _p(H, _d), _p(re, _d), _p(ie, _d), _p(R, _d), _p(t, _d),
                                                               _p(oe, _d), _p(E, _d), _p(nt, _i), _p(ns, _i), C.byref(ok), C.byref(sat), C.byref(win),
                                                               C.byref(tries), C.byref(lcr), int(batched))
+        self.last_call_s = time.perf_counter() - t_c          # inside the C call alone
         return dict(haveOneGood=bool(good), R=R.reshape(3, 3), t=t, exposure=oe, E=E, numTerms=nt, numSat=ns, isCorrect=bool(ok.value),
                     tooManySaturated=bool(sat.value), winner=win.value, tries=tries.value, lastCoarseRMSE=lcr.value)
 
@@ -395,10 +400,12 @@ class HostTracker:
         ok, sat, win, tries, kept = _i(), _i(), _i(), _i(), _i()
         lcr = _d()
         counts = np.zeros(6, np.int32); pairs = np.zeros(len(host_poses), abi.TRACE_PAIR_DTYPE)
+        t_c = time.perf_counter()
         good = self.L.cmlhost_frame_track_and_trace(self.h, tracer.h, int(new_image), levels, len(hyps), _p(H, _d), _p(re, _d), _p(ie, _d), int(traced_frame_id),
                                                     len(ids), _p(ids, _i), _p(hp, _d), int(ref_index), _p(Kd, _d), _p(R, _d), _p(t, _d), _p(oe, _d), _p(E, _d),
                                                     _p(nt, _i), _p(ns, _i), C.byref(ok), C.byref(sat), C.byref(win), C.byref(tries), C.byref(lcr), C.byref(kept),
                                                     _p(counts, _i), pairs.ctypes.data)
+        self.last_call_s = time.perf_counter() - t_c          # inside the C call alone (the array packing above is this Python wrapper's, not the library's)
         if good < 0:
             raise RuntimeError("cmlhost_frame_track_and_trace: " + self.L.cmlhost_tracker_last_error(self.h).decode() + " / " + self.L.cmlhost_tracer_last_error(tracer.h).decode())
         res = dict(haveOneGood=bool(good), R=R.reshape(3, 3), t=t, exposure=oe, E=E, numTerms=nt, numSat=ns, isCorrect=bool(ok.value),
@@ -472,6 +479,12 @@ class HostTracer:
 
     def compact(self):
         self.L.cmlhost_tracer_compact(self.h)
+
+    def prepare_resident(self, frame_ids):
+        """the device-resident immature set brought up to date for this frame list (a keyframe's closing act: the next frame's trace then starts at once)"""
+        ids = np.ascontiguousarray(frame_ids, np.int32)
+        if not self.L.cmlhost_tracer_prepare_resident(self.h, len(ids), _p(ids, _i)):
+            raise RuntimeError(self.L.cmlhost_tracer_last_error(self.h).decode())
 
     def frame_ids(self):
         out = np.zeros(max(self.L.cmlhost_tracer_count(self.h), 1), np.int32)

@@ -101,8 +101,13 @@ bool DSOBundleAdjustment::syncWindowAppends() {
     int wp = 0, wr = 0;
     int rc = cmlhip_ba_window_counts(mCtx, &wp, &wr);
     if (rc) return fail("cmlhip_ba_window_counts", rc);
-    if (wp != (int)mWinPoints || wr != (int)mWinResiduals || mWinPoints > mPoints.size() || mWinResiduals > mResiduals.size()) {
+    unsigned gen = 0;
+    if ((rc = cmlhip_ba_window_generation(mCtx, &gen))) return fail("cmlhip_ba_window_generation", rc);
+    // (the sizes alone do not say whose entries they are: another HostBA on this context, a checker replay or a direct cmlhip_ba_upload_window
+    //  may have left a window of the same size — the generation number changes with every reset)
+    if (gen != mWinGeneration || wp != (int)mWinPoints || wr != (int)mWinResiduals || mWinPoints > mPoints.size() || mWinResiduals > mResiduals.size()) {
         if ((rc = cmlhip_ba_window_reset(mCtx))) return fail("cmlhip_ba_window_reset", rc);
+        if ((rc = cmlhip_ba_window_generation(mCtx, &mWinGeneration))) return fail("cmlhip_ba_window_generation", rc);
         mWinPoints = mWinResiduals = 0;
     }
     if (mWinPoints < mPoints.size()) {
@@ -936,24 +941,21 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
         cmlhip_ba_accum_in in; std::vector<double> prior, dprior; double cdelta[4], cprior[4];
         fillAccumIn(in, prior, dprior, cdelta, cprior);
         int ngood = 0;
-        rc = cmlhip_ba_relinearize_points(mCtx, &in, (int)slots.size(), slots.data(), &ngood);
-        if (rc) return fail("cmlhip_ba_relinearize_points", rc);
         const int R = (int)mActive.size();
-        std::vector<int> st(R), ns(R);
-        std::vector<float> e(R), ne(R), nw(R);
-        std::vector<unsigned char> good(R), lin(R);
-        rc = cmlhip_ba_get_states(mCtx, st.data(), ns.data(), e.data(), ne.data(), nw.data(), good.data());
-        if (rc) return fail("cmlhip_ba_get_states", rc);
-        rc = cmlhip_ba_get_res_to_zero(mCtx, nullptr, lin.data());
-        if (rc) return fail("cmlhip_ba_get_res_to_zero", rc);
-        std::vector<char> isCand(mPoints.size(), 0);
-        for (int p : candidates) isCand[p] = 1;
-        for (int k = 0; k < R; k++) {
-            DSOResidual& Rr = mResiduals[mActive[k]];
-            if (!isCand[Rr.point]) continue;
-            Rr.state_state = st[k]; Rr.state_NewState = ns[k]; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k];
-            Rr.state_NewEnergyWithOutlier = nw[k]; Rr.isActiveAndIsGoodNEW = good[k] != 0; Rr.isLinearized = lin[k] != 0;
-            mLinearizedAlive += lin[k] != 0;
+        {   // state / good / LINEARIZED / new state of every residual as one byte, and the three energies, IN THE PASS'S OWN READBACK (one wait; it was three)
+            std::vector<unsigned char> pk(R);
+            std::vector<float> e(R), ne(R), nw(R);
+            rc = cmlhip_ba_relinearize_points_packed(mCtx, &in, (int)slots.size(), slots.data(), &ngood, pk.data(), e.data(), ne.data(), nw.data());
+            if (rc) return fail("cmlhip_ba_relinearize_points_packed", rc);
+            std::vector<char> isCand(mPoints.size(), 0);
+            for (int p : candidates) isCand[p] = 1;
+            for (int k = 0; k < R; k++) {
+                DSOResidual& Rr = mResiduals[mActive[k]];
+                if (!isCand[Rr.point]) continue;
+                Rr.state_state = pk[k] & 3; Rr.state_NewState = (pk[k] >> 4) & 3; Rr.state_energy = e[k]; Rr.state_NewEnergy = ne[k];
+                Rr.state_NewEnergyWithOutlier = nw[k]; Rr.isActiveAndIsGoodNEW = (pk[k] & 4) != 0; Rr.isLinearized = (pk[k] & 8) != 0;
+                mLinearizedAlive += (pk[k] & 8) != 0;
+            }
         }
     }
     for (int p : candidates) {

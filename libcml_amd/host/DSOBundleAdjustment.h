@@ -165,6 +165,7 @@ private:
     bool uploadWindow();
     bool syncWindowAppends();                                                  // hands the library the points / residuals added since the last hand-over (cmlhip_ba_window_append_*)
     size_t mWinPoints = 0, mWinResiduals = 0;                                  // how much of mPoints / mResiduals the library's window holds (index for index)
+    unsigned mWinGeneration = ~0u;                          // cmlhip_ba_window_generation of the window this object's entries live in (the owner token)
     int mDeadSinceCompact = 0, mLinearizedAlive = 0;                           // entries dropped since the lists were renumbered; residuals that may carry isLinearized
     std::vector<int> mScratchCount;
     std::vector<double> mDynIdepth; std::vector<float> mDynZero, mDynPrior;    // per-point values refreshed at every commit

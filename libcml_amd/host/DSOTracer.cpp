@@ -36,7 +36,9 @@ void DSOTracer::compact() {
     pullResident();
     mResDirty = true;
     std::vector<ImmaturePoint> keep;
-    for (auto& P : mPoints) if (P.alive && !P.activated) keep.push_back(P);
+    std::vector<int> moved(mPoints.size(), -1);                                 // old index -> new index
+    for (size_t i = 0; i < mPoints.size(); i++) if (mPoints[i].alive && !mPoints[i].activated) { moved[i] = (int)keep.size(); keep.push_back(mPoints[i]); }
+    for (int& w : mResWho) if (w >= 0) w = moved[w];                            // (the device's slots still hold the points that left: dropped at the next edit)
     mPoints.swap(keep);
 }
 
@@ -49,28 +51,57 @@ bool DSOTracer::pullResident() {
     if (!mHostStale) return true;
     mHostStale = false;
     if (mResWho.empty()) return true;
-    std::vector<cmlhip_immature_point> batch(mResWho.size());
-    const int rc = cmlhip_tracer_get_points(mCtx, (int)batch.size(), batch.data());
-    if (rc) { mError = std::string("cmlhip_tracer_get_points: ") + cmlhip_last_error(mCtx); return false; }
-    for (size_t k = 0; k < mResWho.size(); k++) mPoints[mResWho[k]].d = batch[k];
+    // the seven fields trace() writes (56 bytes per point), not the 232-byte records
+    std::vector<cmlhip_immature_state> st(mResWho.size());
+    const int rc = cmlhip_tracer_get_state(mCtx, (int)st.size(), st.data());
+    if (rc) { mError = std::string("cmlhip_tracer_get_state: ") + cmlhip_last_error(mCtx); return false; }
+    for (size_t k = 0; k < mResWho.size(); k++) {
+        if (mResWho[k] < 0) continue;
+        cmlhip_immature_point& d = mPoints[mResWho[k]].d;
+        d.idepth_min = st[k].idepth_min; d.idepth_max = st[k].idepth_max; d.quality = st[k].quality;
+        d.last_uv[0] = st[k].last_uv[0]; d.last_uv[1] = st[k].last_uv[1]; d.last_pixel_interval = st[k].last_pixel_interval; d.last_status = st[k].last_status;
+    }
     return true;
 }
 
+// The device's set follows this list by EDITS (cmlhip_tracer_edit_points): the points that stay keep their records where they are — moved to the front
+// in their old order, with their host index in the current frame list — and only the points added since the last call travel (makeNewTraces' ~500 per
+// keyframe instead of the whole set).
 bool DSOTracer::syncResident(const std::vector<int>& frame_ids) {
     if (!mResDirty && frame_ids == mResFrameIds) return true;
     if (!pullResident()) return false;
-    std::vector<cmlhip_immature_point> batch;
-    mResWho.clear();
-    for (int i = 0; i < (int)mPoints.size(); i++) {
+    std::vector<int> keep, hosts, who;
+    std::vector<cmlhip_immature_point> fresh;
+    std::vector<int> freshWho;
+    // mResWho lists the points in slot order; compact() has kept it current (indices into mPoints, -1 for a point that left the list)
+    for (size_t k = 0; k < mResWho.size(); k++) {
+        const int i = mResWho[k];
+        if (i < 0) continue;
         ImmaturePoint& P = mPoints[i];
+        P.res_slot = -1;
         if (!P.alive || P.activated) continue;
         const int h = indexOf(frame_ids, P.frame_id);
         if (h < 0) { P.alive = false; continue; }                               // reference frame left the group, TRC.cpp:20-26
         P.d.host = h;
-        batch.push_back(P.d); mResWho.push_back(i);
+        keep.push_back((int)k); hosts.push_back(h); who.push_back(i);
     }
-    const int rc = cmlhip_tracer_set_points(mCtx, (int)batch.size(), batch.data());
-    if (rc) { mError = std::string("cmlhip_tracer_set_points: ") + cmlhip_last_error(mCtx); return false; }
+    for (int i = 0; i < (int)mPoints.size(); i++) mPoints[i].res_slot = -1;
+    for (size_t k = 0; k < who.size(); k++) mPoints[who[k]].res_slot = (int)k;
+    for (int i = 0; i < (int)mPoints.size(); i++) {
+        ImmaturePoint& P = mPoints[i];
+        if (!P.alive || P.activated || P.res_slot >= 0) continue;
+        if (P.was_resident) continue;                                           // (left the set above: host gone)
+        const int h = indexOf(frame_ids, P.frame_id);
+        if (h < 0) { P.alive = false; continue; }
+        P.d.host = h;
+        P.res_slot = (int)(who.size() + fresh.size());
+        fresh.push_back(P.d); freshWho.push_back(i);
+    }
+    const int rc = cmlhip_tracer_edit_points(mCtx, (int)keep.size(), keep.data(), hosts.data(), (int)fresh.size(), fresh.data());
+    if (rc) { mError = std::string("cmlhip_tracer_edit_points: ") + cmlhip_last_error(mCtx); return false; }
+    who.insert(who.end(), freshWho.begin(), freshWho.end());
+    mResWho.swap(who);
+    for (int i : mResWho) mPoints[i].was_resident = true;
     mResFrameIds = frame_ids;
     mResDirty = false;
     return true;

@@ -27,6 +27,8 @@ public:
         bool alive = true, activated = false;
         float idepth = 0;                       // set on activation
         std::vector<int> res_state;             // per frame of the activation window (-1 host)
+        int res_slot = -1;                      // the point's slot in the device-resident set (-1: not there)
+        bool was_resident = false;              // has been in the device's set (a point is added to it once)
     };
 
     // makeNewTraces' per-point record (DSOTracer.cpp:496-541): gradH/patches are computed by the caller from the host image
@@ -50,6 +52,9 @@ public:
                                     const cmlhip_frame_pose& reference, const double K[4]);
     bool finishTracked(bool keep, int counts[6], std::vector<cmlhip_trace_pair>* pairs_out);
 
+    // bring the device's set up to date NOW (the keyframe's work: makeNewTraces has added its points, marginalizeFrames has removed frames) instead of in
+    // front of the next frame's trace
+    bool prepareResident(const std::vector<int>& frame_ids) { return syncResident(frame_ids); }
     void compact();                             // forget the points that were activated or removed (getMap().removeMapPoint in the reference): indices change
     // The immature set lives ON THE DEVICE between keyframes (cmlhip_tracer_set_points / _trace_resident: a traced frame moves 24 bytes, not the set);
     // this object's copy of the fields trace() writes is refreshed when somebody looks (points(), activatePoints, compact).

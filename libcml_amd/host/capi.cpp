@@ -394,6 +394,10 @@ int cmlhost_tracer_add_points(void* h, int n, const float* xy, int host_frame_id
     for (int i = 0; i < n; i++) t->addImmaturePoint(xy[2 * i], xy[2 * i + 1], host_frame_id, gray + 8 * (size_t)i, dpatch + 24 * (size_t)i, gradH + 4 * (size_t)i, 1.f);
     return first;
 }
+int cmlhost_tracer_prepare_resident(void* h, int n_frames, const int* frame_ids) {
+    std::vector<int> ids(frame_ids, frame_ids + n_frames);
+    return static_cast<cml_amd::DSOTracer*>(h)->prepareResident(ids) ? 1 : 0;
+}
 void cmlhost_tracer_compact(void* h) { static_cast<cml_amd::DSOTracer*>(h)->compact(); }
 void cmlhost_tracer_get_frame_ids(void* h, int* out) {
     auto& P = static_cast<cml_amd::DSOTracer*>(h)->peek();
