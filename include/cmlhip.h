@@ -496,6 +496,11 @@ typedef struct {            /* host -> target of the activation window: Camera::
 int cmlhip_optimize_immature_points(cmlhip_ctx* ctx, int N, const uint64_t* image_ids, const double K[4],
                                     const cmlhip_activation_pair* pairs, const cmlhip_tracer_params* prm, int min_obs,
                                     int n, const cmlhip_immature_point* points, int* result, float* idepth, int* res_state);
+/* The same for points of the device-resident set (cmlhip_tracer_set_points / _edit_points), named by their slots: the records do not travel.  The
+ * hosts the set carries must index the frame list `image_ids`. */
+int cmlhip_optimize_immature_points_resident(cmlhip_ctx* ctx, int N, const uint64_t* image_ids, const double K[4],
+                                             const cmlhip_activation_pair* pairs, const cmlhip_tracer_params* prm, int min_obs,
+                                             int n, const int* slots, int* result, float* idepth, int* res_state);
 
 /* ---------------------------------------------------------------- coarse initializer: DSOInitializer
  * calcResAndGS (DSOInitializer.cpp:451-750): the photometric residuals/Jacobians of every initializer point of one pyramid

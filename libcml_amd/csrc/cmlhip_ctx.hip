@@ -396,7 +396,7 @@ void cmlhip_destroy(cmlhip_ctx* c) {
                      &c->pt_colors, &c->pt_weights, &c->pt_backup, &c->pt_acc, &c->pt_step, &c->r_point, &c->r_host, &c->r_target,
                      &c->r_state, &c->r_new_state, &c->r_energy, &c->r_new_energy, &c->r_new_energy_wo, &c->r_ret_energy,
                      &c->r_good, &c->r_lin, &c->r_sel, &c->r_dead, &c->r_center, &c->r_jpjdf, &c->r_rtz, &c->rj[0], &c->rj[1],
-                     &c->trk_hyp, &c->trk_opt_out, &c->rs_tiles, &c->rs_tile_off, &c->rs_part, &c->r_idepth, &c->point_res, &c->r_px, &c->r_py, &c->r_colors, &c->r_weights, &c->by_point_off, &c->by_point, &c->by_pair_off, &c->by_pair, &c->pair_code, &c->pair_pos, &c->point_code, &c->point_tgt, &c->point_pos, &c->frame_state, &c->pre_w2c, &c->null_basis, &c->pt_mask, &c->marg_scratch, &c->tr_points, &c->tr_pairs, &c->tr_out, &c->tr_resident, &c->tr_resident2, &c->tr_edit, &c->tr_state, &c->tr_hosts, &c->tr_journal, &c->trk_pose0, &c->ini_points, &c->ini_partial, &c->pnp_matches, &c->pnp_flags, &c->pnp_out, &c->lba_frames, &c->lba_cams, &c->lba_points, &c->lba_off, &c->lba_edges, &c->lba_err, &c->lba_flags, &c->lba_work, &c->newframe_res, &c->acc_pair[0],
+                     &c->trk_hyp, &c->trk_opt_out, &c->rs_tiles, &c->rs_tile_off, &c->rs_part, &c->r_idepth, &c->point_res, &c->r_px, &c->r_py, &c->r_colors, &c->r_weights, &c->by_point_off, &c->by_point, &c->by_pair_off, &c->by_pair, &c->pair_code, &c->pair_pos, &c->point_code, &c->point_tgt, &c->point_pos, &c->frame_state, &c->pre_w2c, &c->null_basis, &c->pt_mask, &c->marg_scratch, &c->tr_points, &c->tr_pairs, &c->tr_out, &c->tr_resident, &c->tr_counts, &c->tr_resident2, &c->tr_edit, &c->tr_state, &c->tr_hosts, &c->tr_journal, &c->trk_pose0, &c->ini_points, &c->ini_partial, &c->pnp_matches, &c->pnp_flags, &c->pnp_out, &c->lba_frames, &c->lba_cams, &c->lba_points, &c->lba_off, &c->lba_edges, &c->lba_err, &c->lba_flags, &c->lba_work, &c->newframe_res, &c->acc_pair[0],
                      &c->acc_pair[1], &c->acc_num[0], &c->acc_num[1], &c->pair_blocks, &c->adH, &c->adT, &c->adHTd,
                      &c->vec_small, &c->HA, &c->bA, &c->HL, &c->bL, &c->Hsc, &c->bsc, &c->HM, &c->bM, &c->xvec, &c->G,
                      &c->syrk_part, &c->solve_image, &c->xad, &c->scal, &c->lin_partial, &c->trk_warped, &c->trk_partial, &c->trk_out, &c->cd_cnt, &c->cd_pts,

@@ -169,7 +169,8 @@ struct cmlhip_ctx {
     DevBuf trk_pose0;                                         // {R, t, a, b} of the pending batch's first result, on the device
     DevBuf tr_resident2, tr_edit, tr_state;                   // cmlhip_tracer_edit_points (the set rebuilt into the second buffer), cmlhip_tracer_get_state
     DevBuf tr_hosts, tr_journal; void* tr_host = nullptr; void* tr_host_dev = nullptr;      // cmlhip_tracer_trace_resident_tracked_async: host poses, the rollback journal, mapped block {counts | pairs}
-    bool tr_spec_pending = false, tr_counts_dirty = true; int tr_spec_hosts = 0, tr_spec_skip = -2;
+    bool tr_spec_pending = false; int tr_spec_hosts = 0, tr_spec_skip = -2;
+    DevBuf tr_counts;                                         // status histogram of the tracked trace (cleared by its publishing kernel)
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)
     DevBuf rr_scratch;                                        // R-length readbacks permuted back to the caller's order on the device (ResRead, ba_api.hip)

@@ -239,6 +239,7 @@ struct OptArgs {
     const cmlhip_activation_pair* pairs;       // host * N + target
     cmlhip_tracer_params P;
     const cmlhip_immature_point* pts;
+    const int* slots;                          // null: point i is pts[i]; else pts[slots[i]] (the device-resident set)
     int* result; float* idepth; int* res_state;
 };
 
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void k_optimize_immature(OptArgs A) {
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int pi = blockIdx.x * 4 + wv;
     if (pi >= A.n) return;
-    const cmlhip_immature_point* pt = A.pts + pi;
+    const cmlhip_immature_point* pt = A.pts + (A.slots ? A.slots[pi] : pi);      // (resident form: the point's slot in the device's set)
     int nres = 0;
     for (int t = 0; t < A.N; t++) {
         if (l == 0) A.res_state[(size_t)pi * A.N + t] = -1;
@@ -483,7 +484,6 @@ int cmlhip_tracer_trace_resident(cmlhip_ctx* c, uint64_t image_id, const cmlhip_
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_trace_points<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     else k_trace_points<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     CML_CHECK(c, hipGetLastError());
-    c->tr_counts_dirty = true;
     return cml_d2h(c, counts, c->tr_out.p, 24);
 }
 
@@ -599,16 +599,16 @@ int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id,
     CML_REQUIRE(c, py && py->lv[0].grad, CMLHIP_ERR_NOT_FOUND, "traced image not in the pyramid cache");
     const int n = c->tr_resident_n;
     int rc;
-    const unsigned gen0 = c->tr_out.gen;
+    const unsigned gen0 = c->tr_counts.gen;
     if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_trace_pair) * (size_t)CMLHIP_MAX_FRAMES))) return rc;
-    if ((rc = cml_ensure(c, c->tr_out, 64))) return rc;
+    if ((rc = cml_ensure(c, c->tr_counts, 64))) return rc;      // (a buffer of its own: tr_out also carries the activation results)
     if ((rc = tr_ensure(c, c->tr_journal, sizeof(TraceJournal) * (size_t)std::max(n, 1)))) return rc;
     if (!c->tr_host) {
         CML_CHECK(c, hipHostMalloc(&c->tr_host, 64 + (sizeof(cmlhip_trace_pair) + sizeof(cmlhip_frame_pose)) * CMLHIP_MAX_FRAMES, hipHostMallocMapped | hipHostMallocCoherent));
         CML_CHECK(c, hipHostGetDevicePointer(&c->tr_host_dev, c->tr_host, 0));
     }
-    // the histogram is cleared by the publishing kernel of every frame; once per allocation (and behind the plain resident trace, which leaves it filled) here
-    if (c->tr_out.gen != gen0 || c->tr_counts_dirty) { CML_CHECK(c, hipMemsetAsync(c->tr_out.p, 0, 24, c->stream)); c->tr_counts_dirty = false; }
+    // the histogram is cleared by the publishing kernel of every frame; once per allocation here
+    if (c->tr_counts.gen != gen0) CML_CHECK(c, hipMemsetAsync(c->tr_counts.p, 0, 24, c->stream));
     // the window's poses: in the kernel arguments (up to TR_INLINE_HOSTS frames) and in the mapped block (the publishing kernel, wider windows)
     char* const hosts_h = static_cast<char*>(c->tr_host) + 64 + sizeof(cmlhip_trace_pair) * CMLHIP_MAX_FRAMES;
     memcpy(hosts_h, hosts, sizeof(cmlhip_frame_pose) * (size_t)n_hosts);
@@ -618,7 +618,7 @@ int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id,
     TraceArgs A;
     A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
     A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_resident.as<cmlhip_immature_point>();
-    A.skip_host = skip_host; A.counts = c->tr_out.as<int>(); A.journal = c->tr_journal.as<TraceJournal>();
+    A.skip_host = skip_host; A.counts = c->tr_counts.as<int>(); A.journal = c->tr_journal.as<TraceJournal>();
     const bool half = c->lim.texel_format == CMLHIP_TEXEL_F16;
     if (n > 0 && n_hosts <= TR_INLINE_HOSTS) {
         TraceTracked T;
@@ -638,7 +638,7 @@ int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id,
     }
     TracePublish PB;
     PB.pose0 = pose0; PB.ref = *reference; for (int k = 0; k < 4; k++) PB.K[k] = K[k];
-    PB.n_hosts = n_hosts; PB.hosts = hosts_dev; PB.counts = c->tr_out.as<int>(); PB.out_counts = static_cast<int*>(c->tr_host_dev);
+    PB.n_hosts = n_hosts; PB.hosts = hosts_dev; PB.counts = c->tr_counts.as<int>(); PB.out_counts = static_cast<int*>(c->tr_host_dev);
     PB.out_pairs = reinterpret_cast<cmlhip_trace_pair*>(static_cast<char*>(c->tr_host_dev) + 64);
     if ((rc = cml_done_embed(c, &PB.ticket, &PB.ticket_word))) return rc;      // the ticket the tracker's wait (cmlhip_tracker_optimize_wait) then waits for: one host wait for the frame
     k_trace_publish<<<1, 64, 0, c->stream>>>(PB);
@@ -666,11 +666,9 @@ int cmlhip_tracer_trace_resident_finish(cmlhip_ctx* c, int keep, int counts[6], 
     return CMLHIP_OK;
 }
 
-int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_ids, const double K[4], const cmlhip_activation_pair* pairs,
-                                    const cmlhip_tracer_params* prm, int min_obs, int n, const cmlhip_immature_point* points, int* result,
-                                    float* idepth, int* res_state) { CML_DEV(c);
-    if (!c || N < 2 || N > CMLHIP_MAX_FRAMES || !image_ids || !K || !pairs || !prm || n < 0 || (n > 0 && (!points || !result || !idepth || !res_state)))
-        return CMLHIP_ERR_INVALID;
+static int optimize_immature_common(cmlhip_ctx* c, int N, const uint64_t* image_ids, const double K[4], const cmlhip_activation_pair* pairs,
+                                    const cmlhip_tracer_params* prm, int min_obs, int n, const cmlhip_immature_point* points, const int* slots, int* result,
+                                    float* idepth, int* res_state) {
     if (n == 0) return CMLHIP_OK;
     OptArgs A;
     memset(&A, 0, sizeof A);
@@ -681,17 +679,25 @@ int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_
         CML_REQUIRE(c, py->lv[0].w == A.w && py->lv[0].h == A.h, CMLHIP_ERR_INVALID, "window images differ in size");
         A.img[t] = py->lv[0].grad;
     }
-    for (int i = 0; i < n; i++) if (points[i].host < 0 || points[i].host >= N) { c->err = "immature point host out of range"; return CMLHIP_ERR_INVALID; }
     int rc;
     const size_t out_bytes = (size_t)n * (8 + 4 * (size_t)N);
-    if ((rc = cml_ensure(c, c->tr_points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
     if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_activation_pair) * (size_t)N * N))) return rc;
-    if ((rc = cml_ensure(c, c->tr_out, out_bytes))) return rc;
-    if ((rc = cml_h2d(c, c->tr_points.p, points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
+    if ((rc = tr_ensure(c, c->tr_out, out_bytes))) return rc;
+    if (points) {
+        for (int i = 0; i < n; i++) if (points[i].host < 0 || points[i].host >= N) { c->err = "immature point host out of range"; return CMLHIP_ERR_INVALID; }
+        if ((rc = tr_ensure(c, c->tr_points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
+        if ((rc = cml_h2d(c, c->tr_points.p, points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
+        A.pts = c->tr_points.as<cmlhip_immature_point>(); A.slots = nullptr;
+    } else {
+        for (int i = 0; i < n; i++) if (slots[i] < 0 || slots[i] >= c->tr_resident_n) { c->err = "immature point slot out of range"; return CMLHIP_ERR_INVALID; }
+        if ((rc = tr_ensure(c, c->tr_edit, 4 * (size_t)n))) return rc;
+        if ((rc = cml_h2d(c, c->tr_edit.p, slots, 4 * (size_t)n))) return rc;
+        A.pts = c->tr_resident.as<cmlhip_immature_point>(); A.slots = c->tr_edit.as<int>();
+    }
     if ((rc = cml_h2d(c, c->tr_pairs.p, pairs, sizeof(cmlhip_activation_pair) * (size_t)N * N))) return rc;
     A.N = N; A.n = n; A.min_obs = min_obs;
     for (int k = 0; k < 4; k++) A.K[k] = K[k];
-    A.pairs = c->tr_pairs.as<cmlhip_activation_pair>(); A.P = *prm; A.pts = c->tr_points.as<cmlhip_immature_point>();
+    A.pairs = c->tr_pairs.as<cmlhip_activation_pair>(); A.P = *prm;
     A.result = c->tr_out.as<int>(); A.idepth = reinterpret_cast<float*>(A.result + n); A.res_state = A.result + 2 * (size_t)n;
     if (c->lim.texel_format == CMLHIP_TEXEL_F16) k_optimize_immature<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
     else k_optimize_immature<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
@@ -701,6 +707,22 @@ int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_
     cml_d2h(c, idepth, A.idepth, 4 * (size_t)n);
     cml_d2h(c, res_state, A.res_state, 4 * (size_t)n * N);
     return cml_d2h_batch_flush(c);
+}
+int cmlhip_optimize_immature_points(cmlhip_ctx* c, int N, const uint64_t* image_ids, const double K[4], const cmlhip_activation_pair* pairs,
+                                    const cmlhip_tracer_params* prm, int min_obs, int n, const cmlhip_immature_point* points, int* result,
+                                    float* idepth, int* res_state) { CML_DEV(c);
+    if (!c || N < 2 || N > CMLHIP_MAX_FRAMES || !image_ids || !K || !pairs || !prm || n < 0 || (n > 0 && (!points || !result || !idepth || !res_state)))
+        return CMLHIP_ERR_INVALID;
+    return optimize_immature_common(c, N, image_ids, K, pairs, prm, min_obs, n, points, nullptr, result, idepth, res_state);
+}
+// the same for points of the device-resident set, named by their slots: nothing of the 232-byte records travels (the candidates' host indices are the
+// ones the set was last edited with — cmlhip_tracer_edit_points / _set_points — and must refer to the frame list `image_ids`)
+int cmlhip_optimize_immature_points_resident(cmlhip_ctx* c, int N, const uint64_t* image_ids, const double K[4], const cmlhip_activation_pair* pairs,
+                                             const cmlhip_tracer_params* prm, int min_obs, int n, const int* slots, int* result, float* idepth, int* res_state) { CML_DEV(c);
+    if (!c || N < 2 || N > CMLHIP_MAX_FRAMES || !image_ids || !K || !pairs || !prm || n < 0 || (n > 0 && (!slots || !result || !idepth || !res_state)))
+        return CMLHIP_ERR_INVALID;
+    CML_REQUIRE(c, !c->tr_spec_pending, CMLHIP_ERR_INVALID, "cmlhip_optimize_immature_points_resident: a speculative trace is in flight");
+    return optimize_immature_common(c, N, image_ids, K, pairs, prm, min_obs, n, nullptr, slots, result, idepth, res_state);
 }
 
 }  // extern "C"

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "cmlhip_lba_set_stop_flag": (C.c_int, [_ctx, C.c_void_p]),
     "cmlhip_lba_optimize": (C.c_int, [_ctx, _i, C.c_void_p, _i, _P(C.c_double), _P(C.c_int), C.c_void_p, _i, _i, _i, _P(C.c_ubyte), _P(abi.LbaResult)]),
     "cmlhip_optimize_immature_points": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, C.c_void_p, _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
+    "cmlhip_optimize_immature_points_resident": (C.c_int, [_ctx, _i, _P(C.c_uint64), _P(C.c_double), C.c_void_p, _P(abi.TracerParams), _i, _i, _P(C.c_int), _P(C.c_int), _P(C.c_float), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_int)]),
     "cmlhip_ba_relinearize_points_packed": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(_i), _P(_i), _P(C.c_ubyte), _P(_f), _P(_f), _P(_f)]),
     "cmlhip_ba_marginalize_points": (C.c_int, [_ctx, _P(abi.BAAccumIn), _i, _P(C.c_int), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
@@ -560,6 +561,17 @@ class Ctx:
         res = np.zeros(n, np.int32); idp = np.zeros(n, np.float32); st = np.zeros((n, N), np.int32)
         self.ck(self.L.cmlhip_optimize_immature_points(self.h, N, _p(ids, C.c_uint64), _p(K, _d), pairs.ctypes.data, C.byref(prm), int(min_obs), n,
                                                         points.ctypes.data, _p(res, C.c_int), _p(idp, _f), _p(st, C.c_int)))
+        return res, idp, st
+
+    def optimize_immature_points_resident(self, image_ids, K, pairs, prm, min_obs, slots):
+        """cmlhip_optimize_immature_points_resident: the candidates are slots of the device-resident set"""
+        N = len(image_ids)
+        ids = np.ascontiguousarray(image_ids, np.uint64); K = np.ascontiguousarray(K, np.float64)
+        pairs = np.ascontiguousarray(pairs, abi.ACTIVATION_PAIR_DTYPE); sl = np.ascontiguousarray(slots, np.int32)
+        n = len(sl)
+        res = np.zeros(n, np.int32); idp = np.zeros(n, np.float32); st = np.zeros((n, N), np.int32)
+        self.ck(self.L.cmlhip_optimize_immature_points_resident(self.h, N, _p(ids, C.c_uint64), _p(K, _d), pairs.ctypes.data, C.byref(prm), int(min_obs), n,
+                                                                 _p(sl, C.c_int), _p(res, C.c_int), _p(idp, _f), _p(st, C.c_int)))
         return res, idp, st
 
     # ------------------------------------------------------------------ coarse initializer (DSOInitializer::calcResAndGS)

@@ -27,14 +27,14 @@ int DSOTracer::addImmaturePoint(float x, float y, int host_frame_id, const float
     P.my_type = type;
     if (!std::isfinite(P.d.energy_th)) return -1;                               // :531-534
     pullResident();
-    mResDirty = true;
+    mResDirty = true; mResSlotsValid = false;
     mPoints.push_back(P);
     return (int)mPoints.size() - 1;
 }
 
 void DSOTracer::compact() {
     pullResident();
-    mResDirty = true;
+    mResDirty = true; mResSlotsValid = false;
     std::vector<ImmaturePoint> keep;
     std::vector<int> moved(mPoints.size(), -1);                                 // old index -> new index
     for (size_t i = 0; i < mPoints.size(); i++) if (mPoints[i].alive && !mPoints[i].activated) { moved[i] = (int)keep.size(); keep.push_back(mPoints[i]); }
@@ -103,7 +103,7 @@ bool DSOTracer::syncResident(const std::vector<int>& frame_ids) {
     mResWho.swap(who);
     for (int i : mResWho) mPoints[i].was_resident = true;
     mResFrameIds = frame_ids;
-    mResDirty = false;
+    mResDirty = false; mResSlotsValid = true;
     return true;
 }
 
@@ -185,9 +185,20 @@ bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vec
     if (batch.empty()) return true;
     std::vector<int> result(batch.size()), states(batch.size() * (size_t)N);
     std::vector<float> idp(batch.size());
-    const int rc = cmlhip_optimize_immature_points(mCtx, N, image_ids.data(), K, pairs.data(), &prm, 1, (int)batch.size(), batch.data(), result.data(),
-                                                   idp.data(), states.data());
-    if (rc) { mError = std::string("cmlhip_optimize_immature_points: ") + cmlhip_last_error(mCtx); return false; }
+    // the candidates are points of the device-resident set: named by their slots when the set is current for this frame list (the list it was edited
+    // with, with frames appended behind it — the new keyframe), their 232-byte records do not travel again
+    bool resident = mResSlotsValid && mResFrameIds.size() <= frame_ids.size();
+    for (size_t f = 0; resident && f < mResFrameIds.size(); f++) resident = mResFrameIds[f] == frame_ids[f];
+    std::vector<int> slots(batch.size());
+    for (size_t k = 0; resident && k < who.size(); k++) { slots[k] = mPoints[who[k]].res_slot; resident = slots[k] >= 0; }
+    int rc;
+    if (resident) {
+        rc = cmlhip_optimize_immature_points_resident(mCtx, N, image_ids.data(), K, pairs.data(), &prm, 1, (int)slots.size(), slots.data(), result.data(), idp.data(), states.data());
+        if (rc) { mError = std::string("cmlhip_optimize_immature_points_resident: ") + cmlhip_last_error(mCtx); return false; }
+    } else {
+        rc = cmlhip_optimize_immature_points(mCtx, N, image_ids.data(), K, pairs.data(), &prm, 1, (int)batch.size(), batch.data(), result.data(), idp.data(), states.data());
+        if (rc) { mError = std::string("cmlhip_optimize_immature_points: ") + cmlhip_last_error(mCtx); return false; }
+    }
     for (size_t k = 0; k < who.size(); k++) {                                   // TRC.cpp:216-247
         ImmaturePoint& P = mPoints[who[k]];
         if (result[k] == 1) {

@@ -72,6 +72,7 @@ private:
     std::vector<ImmaturePoint> mPoints;
     std::vector<int> mResWho, mResFrameIds;     // device slot -> index into mPoints; the frame list the device's host indices refer to
     bool mResDirty = true, mHostStale = false, mTrackedPending = false;
+    bool mResSlotsValid = false;                // every live point's res_slot names its record on the device (no point added / list compacted since the last edit)
     std::string mError;
 };
 

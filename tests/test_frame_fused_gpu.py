@@ -145,3 +145,40 @@ def test_host_mirror_fused_call_equals_the_two_calls(scene):
         for name in FIELDS:
             assert _bits_equal(u[name], pts[name]), name
     trk.close(); trc.close()
+
+
+def test_histogram_survives_an_activation_between_two_frames(scene):
+    """the activation's results share a scratch buffer with the plain resident trace: the tracked trace keeps its status histogram in one of its own
+    (the second frame's counts must not start from another call's leftovers); and the resident-slot activation equals the record one"""
+    P, ctx, pts, hosts, hyps = scene
+    W, s = P.W, P.s
+    prm = abi.default_tracer_params()
+    ref = hosts[s.ref]
+
+    def frame():
+        ctx.tracker_optimize_batch_async(501, P.levels, W.K, P.ref_exp, P.init_exp, P.prm, hyps)
+        ctx.tracer_trace_resident_tracked_async(501, prm, hosts, ref, W.K, skip_host=-2)
+        ctx.tracker_optimize_wait()
+        return ctx.tracer_trace_resident_finish(keep=True)
+    ctx.tracer_set_points(pts)
+    c1, _ = frame()
+    cur = ctx.tracer_get_points()
+    assert int(c1.sum()) == len(pts)
+    # an activation over the first frames of the window (images of the hosts), by records and by resident slots
+    ids = [900 + k for k in range(s.new)]
+    for k in range(s.new):
+        ctx.pyramid_build(ids[k], W.gray[k], 1)
+    cand = np.flatnonzero(np.isfinite(cur["idepth_max"]) & (cur["last_status"] != abi.IPS_OOB))[:200]
+    assert len(cand) > 20
+    apr = TS.activation_pairs(W)
+    N = W.N
+    sub = np.zeros(s.new * s.new, abi.ACTIVATION_PAIR_DTYPE)
+    for h in range(s.new):
+        sub[h * s.new:(h + 1) * s.new] = apr[h * N:h * N + s.new]
+    ra, ia, sa = ctx.optimize_immature_points(ids, W.K, sub, prm, 1, cur[cand])
+    rb, ib, sb = ctx.optimize_immature_points_resident(ids, W.K, sub, prm, 1, cand)
+    assert np.array_equal(ra, rb) and np.array_equal(ia.view(np.uint32), ib.view(np.uint32)) and np.array_equal(sa, sb)
+    c2, _ = frame()
+    assert int(c2.sum()) == len(pts), (c1, c2)
+    for k in ids:
+        ctx.pyramid_drop(k)
