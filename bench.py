@@ -797,11 +797,11 @@ def parity_gate(S, lam=1e-5):
 
 def _valu_roof(config, R, launch_us):
     """Second roofline entry for the residual kernel: what its own instruction stream costs to ISSUE.  Inputs are the SQ counters of
-    the committed rocprofv3 --pmc passes (profiles/round5_valu_roof_<config>.json, tools/valu_roof.py: SQ_WAVES, SQ_INSTS_VALU,
+    the committed rocprofv3 --pmc passes (profiles/round6_valu_roof_<config>.json, tools/valu_roof.py: SQ_WAVES, SQ_INSTS_VALU,
     SQ_ACTIVE_INST_VALU per launch) — instructions per wave and issue cycles per instruction as MEASURED on this kernel — and the wave
     slots the launch occupies; floor = waves per SIMD x instructions per wave x cycles per instruction / clock."""
     path = None
-    for rnd in ("round5", "round4"):
+    for rnd in ("round6", "round5", "round4"):
         cand = os.path.join(ROOT, "profiles", "%s_valu_roof_%s.json" % (rnd, config))
         if os.path.exists(cand):
             path = cand
@@ -831,7 +831,7 @@ def roofline_object(S, M, lin_ms_local):
     # (tools/profile_bench.py; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide) and are only
     # quoted for the workload they were collected on
     traffic, traffic_src, rocprof_us = None, None, None
-    for rnd in ("round5", "round4", "round3"):
+    for rnd in ("round6", "round5", "round4", "round3"):
         pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_linearize_%s.json" % (rnd, config))
         if os.path.exists(pmc_path):
             try:

@@ -8,7 +8,7 @@ SQ_ACTIVE_INST_ANY, SQ_INSTS_SALU, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, averaged over
   valu_insts_per_wave  = SQ_INSTS_VALU / SQ_WAVES
   cycles_per_valu_inst = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU        (the SQ_ACTIVE_* counters tick in quad-cycles)
 Beside them the static count from the code object (llvm-objdump -d): vector instructions of the kernel by class, fp64 share.
-Writes gpurun_out/round5_valu_roof_<config>.json; copy into profiles/."""
+Writes gpurun_out/round6_valu_roof_<config>.json; copy into profiles/."""
 import csv, glob, json, os, re, shutil, subprocess, sys, tempfile
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -86,5 +86,5 @@ try:
     res["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or "worktree"
 except Exception:
     res["commit"] = "worktree"
-json.dump(res, open(os.path.join(OUT, "round5_valu_roof_%s.json" % cfg), "w"), indent=1)
+json.dump(res, open(os.path.join(OUT, "round6_valu_roof_%s.json" % cfg), "w"), indent=1)
 print(json.dumps(res))
