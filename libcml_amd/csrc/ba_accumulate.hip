@@ -339,21 +339,23 @@ __device__ __forceinline__ void point_rows_block(const BAArgs& A, const AccArgs&
     // Round trips: {efsJ code kept by applyRes, static target} of EVERY slot of the point first (up to 4 passes of 8 slots: one trip
     // for all of them), then per pass the record fields — every load unconditional on clamped indices, so that the next pass's loads
     // are in flight under the arithmetic of the current one (one pass for N <= 9).
-    int codes[4], tgls[4];
+    // (round 6: the slot's residual comes from the STATIC table point_res and its isActiveAndIsGoodNEW flag rides in the second trip beside the row —
+    //  applyRes no longer scatters a per-slot code: one gathered 4-byte store per residual less in the residual kernels, same number of trips here)
+    int ress[4], tgls[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
         const int slot = p * A.pt_stride + min(8 * ps + s, A.pt_stride - 1);
         const bool live = 8 * ps + s < A.pt_stride;
-        const int cd = A.point_code[slot], tg = A.point_tgt[slot];
-        codes[ps] = live ? cd : -1; tgls[ps] = live ? tg : 0;
+        const int rs_ = A.point_res[slot], tg = A.point_tgt[slot];
+        ress[ps] = live ? rs_ : -1; tgls[ps] = live ? tg : 0;
     }
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
         if (8 * ps >= A.pt_stride) break;                     // wave-uniform
-        const int code = codes[ps], tgl = tgls[ps];
-        const bool good = code >= 0;
+        const int tgl = tgls[ps];
+        const int r = max(ress[ps], 0);
+        const bool good = ress[ps] >= 0 && A.r_good[r] != 0;
         const bool lin = good && (tgl & 256);
-        const int r = max(code, 0) >> 1;
         const float* PS = A.r_jpjdf + PS_STRIDE * (size_t)r;          // one 64-B line per residual: JpJdF + the residual's terms of Hcd, Hdd, bd (kept by applyRes)
         const int t = min(max(tgl, 0) & 255, A.N - 1);        // (clamped: empty slots load pair 0..N-1 and are masked)
         const int q = host + t * A.N;
@@ -1696,21 +1698,23 @@ __device__ __forceinline__ void k_ba_backsub_body(const BAArgs& A, const double*
     const int host = A.pt_host[pp];
     const float pa12 = pa[12], pa13 = pa[13], hcd = (i < 4) ? pa[2 + (i & 3)] + 0.f : 0.f, hcl = (i < 4) ? pa[8 + (i & 3)] : 0.f;
     // (all passes' codes / targets / residual slots: up to 4 passes of 8 slots, CMLHIP_MAX_FRAMES = 32; clamped slots are masked)
-    int codes[4], tgls[4], ress[4];
+    int tgls[4], ress[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
         const bool lv = 8 * ps + i < A.pt_stride;
         const int slot = pp * A.pt_stride + min(8 * ps + i, A.pt_stride - 1);
-        const int cd = A.point_code[slot], tg = A.point_tgt[slot], rs = A.point_res[slot];
-        codes[ps] = lv ? cd : -1; tgls[ps] = lv ? tg : 0; ress[ps] = lv ? rs : -1;
+        const int tg = A.point_tgt[slot], rs = A.point_res[slot];
+        tgls[ps] = lv ? tg : 0; ress[ps] = lv ? rs : -1;
     }
     const float backup_p = A.pt_backup[pp];
-    // second round trip: the JpJdF of every pass, requested together (unconditional, clamped) — also ahead of the table's barrier
+    // second round trip: the JpJdF of every pass and the residual's isActiveAndIsGoodNEW flag, requested together (unconditional, clamped) — also ahead of the table's barrier
     float4 v0s[4], v1s[4];
+    int codes[4];                                            // >= 0: the slot holds a good residual (what the per-slot code of applyRes said before round 6)
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
-        const int r = max(codes[ps], 0) >> 1;
+        const int r = max(ress[ps], 0);
         v0s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r); v1s[ps] = *reinterpret_cast<const float4*>(A.r_jpjdf + PS_STRIDE * (size_t)r + 4);
+        codes[ps] = (ress[ps] >= 0 && A.r_good[r] != 0) ? 2 * r : -1;
     }
     // third: the adjoint columns behind this thread's entries of the x.adjoint table (static over the iteration) — with the table built
     // after the wait they were a dependent trip of their own behind the arrival of x

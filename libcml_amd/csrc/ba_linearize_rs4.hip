@@ -143,8 +143,7 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
     const int lin_ = A.r_lin[r], st_ = A.r_state[r];
     const float pre_energy = A.r_energy[r];
     const float pre_new_energy = A.r_new_energy[r];        // (read with the inputs: behind the stores of the classification it would wait for every one of them)
-    const int pre_new_state = A.r_new_state[r], pre_ppos = A.point_pos[r];
-    const unsigned char pre_sel = A.r_sel[r];
+    const int pre_new_state = A.r_new_state[r];
     const double cxd = (double)X.r_px[r], cyd = (double)X.r_py[r];
     const float2 col2 = reinterpret_cast<const float2*>(X.r_colors)[4 * (size_t)r + j];     // colours / weights of pattern pixels 2j, 2j+1
     const float2 wgt2 = reinterpret_cast<const float2*>(X.r_weights)[4 * (size_t)r + j];
@@ -404,13 +403,12 @@ __device__ __forceinline__ void k_ba_lin_rs4_body(const BAArgs& A, const RsArgs&
         if (!(X.dbg_flags & RS_LEAN_BIT)) { A.r_new_energy_wo[r] = nwo; A.r_ret_energy[r] = ret; }     // lean outputs: NewEnergyWithOutlier only where setNewFrameEnergyTH reads it
         else if (T.w == A.N - 1) A.r_new_energy_wo[r] = nwo;
         ret_d = (double)ret; ns_cnt = ns_final;
-        int code = -1;
         if (!state_now_oob) {                                       // applyRes
-            if (ns_final == CMLHIP_RES_IN) { A.r_good[r] = 1; flip = 1; code = 2 * r + pre_sel; }
+            if (ns_final == CMLHIP_RES_IN) { A.r_good[r] = 1; flip = 1; }
             else A.r_good[r] = 0;
             A.r_state[r] = ns_final;
             A.r_energy[r] = wrote_e ? ret : pre_new_energy;      // state_energy = state_NewEnergy
-            A.point_code[pre_ppos] = code;                          // read by the point rows of k_ba_acc and by k_ba_backsub
+            // (no per-slot code any more: the point rows of k_ba_acc and k_ba_backsub read r_good through the static slot table)
         }
     }
     flip = rs4_quad_bcast_i<0>(flip);
