@@ -1178,7 +1178,7 @@ def main():
                 out["sequence"] = sequence_bench(local_rank, seed, not args.no_cpu_baseline)
             except Exception as e:
                 out["sequence"] = {"error": repr(e)}
-            if args.extras or os.environ.get("CML_BENCH_SHARDS_PER_GPU"):      # (its own flag: the sweep starts eight processes)
+            if not os.environ.get("CML_BENCH_NO_SHARDS_PER_GPU"):             # S = 1, 2, 4, 8 sequence shards on this one GPU (eight processes, ~25 s): the one-device stand-in for configs[3]
                 try:
                     spg = shards_per_gpu_bench(local_rank, seed)
                     if isinstance(out.get("sequence"), dict):
