@@ -554,18 +554,27 @@ def _shard_worker(idx, s_list, device_id, seed, barrier, queue):
         seq = sequence.make_sequence(n_frames=n_frames, seed=0x5EED + (seed & 0xff), shard=idx)
         ctx = device.Ctx(device_id=device_id, max_frames=8, max_points=8192, max_residuals=8192 * 8)
 
-        def one(share):
+        def one(share, repeats=1):
+            """`repeats` runs of the shard, the fastest kept (the host side is a Python driver on a shared box); the tracked poses of every repeat must agree"""
             ctx.set_device_share(share)
-            pipe = sequence.DirectPipeline(ctx, seq.K, seq.w, seq.h, seq.levels)
-            t0 = time.perf_counter()
-            st = pipe.run(seq)
-            ctx.sync()
-            dt = time.perf_counter() - t0
-            boot = pipe.timing_summary().get("bootstrap", {}).get("mean_ms", 0.0) * 1e-3
-            lib = float(sum(float(np.sum(v)) for k, v in pipe.lib_times.items() if k != "bootstrap"))
-            h = hashlib.sha256(b"".join(np.ascontiguousarray(x, np.float64).tobytes() for Rt in pipe.history for x in Rt)).hexdigest()
-            pipe.close()
-            return {"seconds": dt - boot, "library_seconds": lib, "lost": int(st["tracking_lost"]), "poses": h}
+            best = None
+            for _ in range(repeats):
+                pipe = sequence.DirectPipeline(ctx, seq.K, seq.w, seq.h, seq.levels)
+                t0 = time.perf_counter()
+                st = pipe.run(seq)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                boot = pipe.timing_summary().get("bootstrap", {}).get("mean_ms", 0.0) * 1e-3
+                lib = float(sum(float(np.sum(v)) for k, v in pipe.lib_times.items() if k != "bootstrap"))
+                h = hashlib.sha256(b"".join(np.ascontiguousarray(x, np.float64).tobytes() for Rt in pipe.history for x in Rt)).hexdigest()
+                pipe.close()
+                r = {"seconds": dt - boot, "library_seconds": lib, "lost": int(st["tracking_lost"]), "poses": h}
+                if best is not None and best["poses"] != h:
+                    r["poses"] = "differs between repeats"
+                    return r
+                if best is None or r["library_seconds"] < best["library_seconds"]:
+                    best = r
+            return best
         one(1)                                                # warm-up: allocations, pools, code objects
         err = None
     except Exception as e:                                    # keep meeting the barriers: nobody may hang on a worker that failed
@@ -581,12 +590,19 @@ def _shard_worker(idx, s_list, device_id, seed, barrier, queue):
                     out["rounds"].setdefault(S, {})["solo"] = one(S)
                 except Exception as e:
                     err = repr(e)
-        barrier.wait(timeout=600)
-        if active and err is None:
-            try:
-                out["rounds"].setdefault(S, {})["together"] = one(S)
-            except Exception as e:
-                err = repr(e)
+        for _rep in range(3):                                 # three timed passes, every one between barriers of ALL workers (no pass runs beside fewer shards than S); the fastest counts
+            barrier.wait(timeout=600)
+            if active and err is None:
+                try:
+                    r = one(S)
+                    cur = out["rounds"].setdefault(S, {}).get("together")
+                    if cur is not None and cur["poses"] != r["poses"]:
+                        r["poses"] = "differs between repeats"
+                        out["rounds"][S]["together"] = r
+                    elif cur is None or r["library_seconds"] < cur["library_seconds"]:
+                        out["rounds"][S]["together"] = r
+                except Exception as e:
+                    err = repr(e)
         barrier.wait(timeout=600)
     except Exception as e:                                    # a broken barrier (a worker died): report and leave
         err = err or repr(e)
@@ -632,7 +648,7 @@ def shards_per_gpu_bench(device_id, seed, s_list=(1, 2, 4, 8)):
     out = {"frames_per_shard": 47, "S": {}, "errors": errs,
            "note": "S processes x one 48-frame sequence shard each on one MI355X (own context, stream, seeded sequence; bootstrap excluded); frames_per_s = 47 S / the slowest "
                    "shard's wall clock (Python driver included), library_frames_per_s = 47 S / the largest per-shard time inside the library's calls; "
-                   "bit_identical = every shard's tracked poses equal its solo run at the same share"}
+                   "bit_identical = every shard's tracked poses equal its solo run at the same share; the timed pass runs three times back to back, the fastest counts"}
     for S in s_list:
         rows = [r["rounds"].get(S) or r["rounds"].get(str(S)) for r in res[:S]]
         if any(r is None or "together" not in r or "solo" not in r for r in rows):
