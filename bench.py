@@ -1076,6 +1076,17 @@ def main():
     if args.launch_only:
         return _launch_only(args)
 
+    # S = 1, 2, 4, 8 sequence shards on this one GPU (eight processes, ~25 s): the one-device stand-in for configs[3].  FIRST, while this process holds no
+    # device context: with its own streams alive beside the workers' (eight processes x three streams) the device's hardware queues are oversubscribed and
+    # the workers' latencies double (measured: solo 770 -> 500 frames/s with the same workers started from the end of this function)
+    spg_early = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_extras and args.config == "B" and not os.environ.get("CML_BENCH_NO_SHARDS_PER_GPU")):
+        try:
+            from libcml_amd import device as _dev
+            if _dev.lib().cmlhip_device_count() > 0:
+                spg_early = shards_per_gpu_bench(0, 0xC0FFEE)
+        except Exception as e:
+            spg_early = {"error": repr(e)}
     from libcml_amd import shard
     rank, local_rank, world = shard.env_world()
     if world != args.gpus and world > 1:
@@ -1194,15 +1205,11 @@ def main():
                 out["sequence"] = sequence_bench(local_rank, seed, not args.no_cpu_baseline)
             except Exception as e:
                 out["sequence"] = {"error": repr(e)}
-            if not os.environ.get("CML_BENCH_NO_SHARDS_PER_GPU"):             # S = 1, 2, 4, 8 sequence shards on this one GPU (eight processes, ~25 s): the one-device stand-in for configs[3]
-                try:
-                    spg = shards_per_gpu_bench(local_rank, seed)
-                    if isinstance(out.get("sequence"), dict):
-                        out["sequence"]["shards_per_gpu"] = spg
-                    else:
-                        out["shards_per_gpu"] = spg
-                except Exception as e:
-                    out["shards_per_gpu"] = {"error": repr(e)}
+            if spg_early is not None:                         # (measured at the start of main(), before this process had queues of its own on the device)
+                if isinstance(out.get("sequence"), dict):
+                    out["sequence"]["shards_per_gpu"] = spg_early
+                else:
+                    out["shards_per_gpu"] = spg_early
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wcfg, seed)          # (config C: the photometric window of config B; the ORB term is not part of the CPU port's timing)
