@@ -639,6 +639,13 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ ToEval ev;
     __shared__ ToState S;
     __shared__ int s_abort;                                  // raised by an exchange that carried "give up" (early exit)
+    // the trial log and the level passes collect HERE and leave with the result at the end.  Written where they happen they were two byte stores per
+    // trial into the result — for the first workgroup of a hypothesis that is MAPPED HOST memory — right in front of a workgroup barrier, whose release
+    // waits for every outstanding store: a PCIe acknowledgement (≈ 1 us) on the critical path of every Levenberg-Marquardt trial, and every other
+    // workgroup of the hypothesis waits for this one at the next exchange
+    __shared__ unsigned char s_step_level[CMLHIP_TRACKER_MAX_STEPS], s_step_accept[CMLHIP_TRACKER_MAX_STEPS];
+    __shared__ int s_pass_level[8];
+    __shared__ double s_pass_rmse[8];
     __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
     const int tid = threadIdx.x, hyp = blockIdx.x / A.G, g = blockIdx.x % A.G;
     cmlhip_tracker_opt_result* out = (g == 0 && A.out_host) ? A.out_host + hyp : A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical; the first one's goes straight to the host)
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     if (tid < 8) S.bv[tid] = S.bn[tid];
                 }
                 if (tid == 0) {
-                    if (S.n_steps < CMLHIP_TRACKER_MAX_STEPS) { out->step_level[S.n_steps] = (unsigned char)level; out->step_accept[S.n_steps] = accept ? 1 : 0; }
+                    if (S.n_steps < CMLHIP_TRACKER_MAX_STEPS) { s_step_level[S.n_steps] = (unsigned char)level; s_step_accept[S.n_steps] = accept ? 1 : 0; }
                     S.n_steps++;
                     if (accept) {
                         for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l]; S.nT[l] = S.nT_new[l]; S.nS[l] = S.nS_new[l]; S.nR[l] = S.nR_new[l]; }   // oldResidual = newResidual (whole struct), :167
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         if (failed) break;
         if (tid == 0) {
             // the rmse of the pass: what TR.cpp:183-189 compares with 1.5 x the previous correct try's (applied by the caller)
-            if (S.n_pass < 8) { out->pass_level[S.n_pass] = level; out->pass_rmse[S.n_pass] = S.E[level] / (double)S.nT[level]; }
+            if (S.n_pass < 8) { s_pass_level[S.n_pass] = level; s_pass_rmse[S.n_pass] = S.E[level] / (double)S.nT[level]; }
             S.n_pass++;
             S.ctrl[cseq & 1] = (S.levelCutoffRepeat[level] > 1 && !S.haveRepeated) ? 1 : 0;                 // :192-195
             if (S.ctrl[cseq & 1]) S.haveRepeated = 1;
@@ -788,6 +795,8 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
             out->levelCutoffRepeat[l] = S.levelCutoffRepeat[l]; out->iterations[l] = S.iterations[l];
         }
         for (int k = 0; k < 3; k++) out->flow[k] = S.flow[k];
+        for (int k = 0; k < S.n_steps && k < CMLHIP_TRACKER_MAX_STEPS; k++) { out->step_level[k] = s_step_level[k]; out->step_accept[k] = s_step_accept[k]; }
+        for (int k = 0; k < S.n_pass && k < 8; k++) { out->pass_level[k] = s_pass_level[k]; out->pass_rmse[k] = s_pass_rmse[k]; }
         out->n_steps = s_abort ? -1 : S.n_steps; out->n_pass = S.n_pass < 8 ? S.n_pass : 8;      // -1: given up (early exit), nothing else of the result is meaningful
         out->eval_us = 0.01 * (double)S.t_eval; out->algebra_us = 0.01 * (double)(S.t_alg + (wall_clock64() - S.t_mark));
         for (int k = 0; k < 6; k++) out->covariance[k] = 999999;
