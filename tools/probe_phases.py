@@ -40,8 +40,10 @@ for k in (1, 2, 3, 4, 0):
     b = blk[k]; b = b[(b[:, 0] > 0) & (b[:, 1] >= b[:, 0])]          # (blocks that only ride in a launch — hybrid-term / merged blocks — leave no end stamp)
     if len(b) == 0: continue
     st = (b[:, 0] - t0) * 0.01; en = (b[:, 1] - t0) * 0.01; d = en - st
-    print("%-10s blocks %4d  first start %7.2f  last start %7.2f  last end %7.2f | block us: min %6.2f med %6.2f max %6.2f" %
-          (names[k], len(b), st.min(), st.max(), en.max(), d.min(), np.median(d), d.max()))
+    print("%-10s blocks %4d%s first start %7.2f  last start %7.2f  last end %7.2f | block us: min %6.2f med %6.2f max %6.2f" %
+          (names[k], len(b), "+" if len(b) >= 1024 else " ", st.min(), st.max(), en.max(), d.min(), np.median(d), d.max()))
+    if len(b) >= 1024:
+        print("           (the stamp buffer holds the launch's first 1024 workgroups: `last end` is the last STAMPED block, not the end of the launch)")
     if k == 1:
         NN = W.N * W.N
         npt = len(d) - NN                                # the point-row workgroups come first in the grid
