@@ -10,6 +10,13 @@
 
 namespace cml_amd {
 
+// development: CMLHOST_TIMING=1 prints the host clock at the named points of a call (stderr)
+struct HostLap {
+    const char* fn; std::chrono::steady_clock::time_point t0; bool on;
+    explicit HostLap(const char* f) : fn(f), t0(std::chrono::steady_clock::now()), on(getenv("CMLHOST_TIMING") != nullptr) {}
+    void operator()(const char* what) const { if (on) fprintf(stderr, "      [%s] %-22s %.0f us\n", fn, what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+};
+
 // ------------------------------------------------------------------------------------------------ DSOFrame
 static void updatePRE(DSOFrame& f) {                                           // DSOFrame.h:119-120
     f.PRE_worldToCam = SE3::exp(f.state_scaled) * f.worldToCam_evalPT;
@@ -139,39 +146,60 @@ bool DSOBundleAdjustment::syncWindowAppends() {
 void DSOBundleAdjustment::compactDead() {
     mOutliers.clear(); mActive.clear(); mActivePoints.clear();
     if (mDeadSinceCompact == 0) { mPointSlot.assign(mPoints.size(), -1); return; }      // nothing was dropped since the lists were last renumbered
-    std::vector<int> pmap(mPoints.size(), -1), rmap(mResiduals.size(), -1);
-    std::vector<unsigned char> pAlive(mPoints.size(), 0), rAlive(mResiduals.size(), 0);
-    std::vector<DSOPoint> np;
-    std::vector<DSOResidual> nr;
-    np.reserve(mPoints.size()); nr.reserve(mResiduals.size());
-    for (size_t p = 0; p < mPoints.size(); p++) if (mPoints[p].alive) { pmap[p] = (int)np.size(); pAlive[p] = 1; np.push_back(mPoints[p]); }
+    // Round 6: the lists are compacted IN PLACE (stable) and the per-point residual lists keep their storage — copying 15 000 72-byte residuals and 2 700
+    // points into fresh vectors and rebuilding a vector<vector<int>> (one allocation per point) was 120 of addNewFrame's 165 us at the sliding window.
+    const size_t P0 = mPoints.size(), R0 = mResiduals.size();
+    HostLap lap("compactDead");
+    std::vector<int>& pmap = mCompactPmap; std::vector<int>& rmap = mCompactRmap;
+    std::vector<unsigned char>& pAlive = mCompactPAlive; std::vector<unsigned char>& rAlive = mCompactRAlive;
+    pmap.assign(P0, -1); rmap.assign(R0, -1); pAlive.assign(P0, 0); rAlive.assign(R0, 0);
+    size_t np = 0;
+    for (size_t p = 0; p < P0; p++) if (mPoints[p].alive) { pmap[p] = (int)np; pAlive[p] = 1; np++; }
     mLinearizedAlive = 0;
-    for (size_t r = 0; r < mResiduals.size(); r++) {
+    size_t nr = 0;
+    for (size_t r = 0; r < R0; r++) {
         const DSOResidual& R = mResiduals[r];
         if (!R.alive || R.point < 0 || pmap[R.point] < 0) continue;
-        rmap[r] = (int)nr.size(); rAlive[r] = 1;
-        nr.push_back(R);
-        nr.back().point = pmap[R.point];
+        rmap[r] = (int)nr; rAlive[r] = 1; nr++;
         mLinearizedAlive += R.isLinearized;
     }
+    lap("maps");
     // the library's copy of the window is renumbered the same way (everything appended first, so that the lists have the same length)
     if (syncWindowAppends()) {
+        lap("appends synced");
         const int rc = cmlhip_ba_window_compact(mCtx, (int)pAlive.size(), pAlive.data(), (int)rAlive.size(), rAlive.data());
         if (rc) { cmlhip_ba_window_reset(mCtx); mWinPoints = mWinResiduals = 0; }        // (handed over again from the start by the next run)
-        else { mWinPoints = np.size(); mWinResiduals = nr.size(); }
+        else { mWinPoints = np; mWinResiduals = nr; }
     } else { cmlhip_ba_window_reset(mCtx); mWinPoints = mWinResiduals = 0; mError.clear(); }
-    for (auto& P : np) for (int q = 0; q < 2; q++) P.lastResidual[q] = P.lastResidual[q] >= 0 ? rmap[P.lastResidual[q]] : -1;
-    mPoints.swap(np); mResiduals.swap(nr);
-    mPointRes.assign(mPoints.size(), {});
-    for (size_t r = 0; r < mResiduals.size(); r++) mPointRes[mResiduals[r].point].push_back((int)r);
+    lap("window compacted");
+    if (mPointRes.size() < P0) mPointRes.resize(P0);
+    for (size_t p = 0; p < P0; p++) {
+        const int q = pmap[p];
+        if (q < 0) continue;
+        if ((size_t)q != p) { mPoints[q] = mPoints[p]; mPointRes[q].swap(mPointRes[p]); }
+        mPointRes[q].clear();                                                  // (keeps its capacity: refilled below without allocating)
+        for (int k = 0; k < 2; k++) mPoints[q].lastResidual[k] = mPoints[q].lastResidual[k] >= 0 ? rmap[mPoints[q].lastResidual[k]] : -1;
+    }
+    mPoints.resize(np); mPointRes.resize(np);
+    for (size_t r = 0; r < R0; r++) {
+        const int q = rmap[r];
+        if (q < 0) continue;
+        if ((size_t)q != r) mResiduals[q] = mResiduals[r];
+        mResiduals[q].point = pmap[mResiduals[q].point];
+        mPointRes[mResiduals[q].point].push_back(q);
+    }
+    mResiduals.resize(nr);
     mPointSlot.assign(mPoints.size(), -1);
     mDeadSinceCompact = 0;
+    lap("lists compacted");
 }
 
 int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, const Exposure& exposure) {
     double sc[4];
     scales(sc);
+    HostLap lap("addNewFrame");
     compactDead();                                                  // (between keyframes nothing refers to point / residual indices)
+    lap("compactDead");
     DSOFrame f;
     f.id = (int)mFrames.size();
     f.keyid = mFrameKeyCounter++;                                   // DSOContext.h:49-50
@@ -190,6 +218,7 @@ int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, c
     mMarginalizedB.swap(b);
     computeAdjoints();
     computeDelta();
+    lap("prior+adjoints+delta");
     // residuals of the existing points into the new frame, BA.cpp:456-460 (createResidual, :336-380)
     const int t = f.id;
     std::vector<SE3> relT(mFrames.size());                             // host -> new frame at the evaluation points, once per host (not per point)
@@ -215,7 +244,9 @@ int DSOBundleAdjustment::addNewFrame(uint64_t image_id, const SE3& worldToCam, c
         mPoints[p].lastResidual[0] = (int)mResiduals.size() - 1;            // target is getFrames().back(), BA.cpp:374-375
         mPoints[p].lastResidualState[0] = r.state_state;
     }
+    lap("residuals created");
     handOverNewEntries();
+    lap("handed over");
     return f.id;
 }
 
@@ -812,14 +843,17 @@ void DSOBundleAdjustment::fillAccumIn(cmlhip_ba_accum_in& in, std::vector<double
 }
 
 void DSOBundleAdjustment::removePointsWithoutResidual() {                     // DSOContext.h:218-229
-    std::vector<int> nres(mPoints.size(), 0);
-    for (const auto& r : mResiduals) if (r.alive) nres[r.point]++;
-    for (int p = 0; p < (int)mPoints.size(); p++) if (mPoints[p].alive && nres[p] == 0) { mPoints[p].alive = false; mDeadSinceCompact++; }
+    for (int p = 0; p < (int)mPoints.size(); p++) {          // (a live point's own list says whether a live residual is left: no pass over every residual)
+        if (!mPoints[p].alive) continue;
+        bool any = false;
+        for (int ri : mPointRes[p]) if (mResiduals[ri].alive) { any = true; break; }
+        if (!any) { mPoints[p].alive = false; mDeadSinceCompact++; }
+    }
 }
 
 void DSOBundleAdjustment::removePoint(int p, bool marginalize, bool sweep) {  // DSOContext.h:94-111,204-215
     if (!mPoints[p].alive) return;
-    std::vector<char> seen(mFrames.size(), 0);
+    char seen[CMLHIP_MAX_FRAMES] = {0};                      // (no allocation per removed point)
     for (int ri : mPointRes[p]) {
         DSOResidual& r = mResiduals[ri];
         if (!r.alive) continue;
@@ -911,6 +945,7 @@ void DSOBundleAdjustment::flagFramesForMarginalization(const std::vector<int>& i
 }
 
 bool DSOBundleAdjustment::tryMarginalize() {                                  // BA.cpp:2240-2363
+    HostLap lap("tryMarginalize");
     const int setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4;
     std::vector<int> toMarg;
     for (int i = 0; i < (int)mFrames.size(); i++) if (mFrames[i].flaggedForMarginalization) toMarg.push_back(i);
@@ -926,6 +961,7 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
             else toDrop.push_back(p);
         }
     }
+    lap("classified");
     // residual loop of the candidates on the device (:2291-2304): resetOOB, linearize, applyRes(true), fixLinearization
     if (!candidates.empty()) {
         std::vector<int> slots;
@@ -938,6 +974,7 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
         framePairs(pairs);
         int rc = setPairs(pairs);
         if (rc) return fail("cmlhip_ba_set_pairs", rc);
+        lap("delta+pairs set");
         cmlhip_ba_accum_in in; std::vector<double> prior, dprior; double cdelta[4], cprior[4];
         fillAccumIn(in, prior, dprior, cdelta, cprior);
         int ngood = 0;
@@ -947,6 +984,7 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
             std::vector<float> e(R), ne(R), nw(R);
             rc = cmlhip_ba_relinearize_points_packed(mCtx, &in, (int)slots.size(), slots.data(), &ngood, pk.data(), e.data(), ne.data(), nw.data());
             if (rc) return fail("cmlhip_ba_relinearize_points_packed", rc);
+            lap("device pass + readback");
             std::vector<char> isCand(mPoints.size(), 0);
             for (int p : candidates) isCand[p] = 1;
             for (int k = 0; k < R; k++) {
@@ -962,14 +1000,18 @@ bool DSOBundleAdjustment::tryMarginalize() {                                  //
         if (mPoints[p].idepth_hessian > mMinIdepthHMarg) mPoints[p].toMarginalize = true;       // :2316-2325
         else toDrop.push_back(p);
     }
+    lap("states assigned");
     for (int p : toDrop) { removePoint(p, false, false); mOutliers.push_back(p); }    // :2344-2348
     removePointsWithoutResidual();
+    lap("points removed");
     return true;
 }
 
 bool DSOBundleAdjustment::marginalizePointsF() {                              // BA.cpp:2466-2513
+    HostLap lap("marginalizePointsF");
     computeDelta();
     computeAdjoints();
+    lap("delta+adjoints");
     std::vector<int> pts, slots;
     for (int p = 0; p < (int)mPoints.size(); p++)
         if (mPoints[p].toMarginalize) { pts.push_back(p); slots.push_back(mPointSlot[p]); }
@@ -981,6 +1023,7 @@ bool DSOBundleAdjustment::marginalizePointsF() {                              //
         const int rc = cmlhip_ba_marginalize_points(mCtx, &in, (int)slots.size(), slots.data(), M.data(), Mb.data(), Msc.data(), Mbsc.data());
         if (rc) return fail("cmlhip_ba_marginalize_points", rc);
     }
+    lap("device accumulate + readback");
     for (int p : pts) {                                                        // :2490-2497
         mPoints[p].marginalized = true; mPoints[p].toMarginalize = false;
         removePoint(p, true, false);
@@ -989,6 +1032,7 @@ bool DSOBundleAdjustment::marginalizePointsF() {                              //
     const double setting_margWeightFac = 0.5 * 0.5;                            // :2502
     for (size_t i = 0; i < M.size(); i++) mMarginalizedHessian[i] += setting_margWeightFac * (M[i] - Msc[i]);
     for (int i = 0; i < n; i++) mMarginalizedB[i] += setting_margWeightFac * (Mb[i] - Mbsc[i]);
+    lap("points removed + prior");
     return true;
 }
 

@@ -195,6 +195,7 @@ private:
     std::vector<DSOResidual> mResiduals;
     std::vector<SE3> mRelT; std::vector<double> mRelR; int mRelValidFor = -1;   // addPoint: host -> target poses at the evaluation points (rebuilt after computeAdjoints)
     std::vector<std::vector<int>> mPointRes;        // residual indices of every point (DSOPoint::residuals, DSOPoint.h:87), dead ones included until compactDead
+    std::vector<int> mCompactPmap, mCompactRmap; std::vector<unsigned char> mCompactPAlive, mCompactRAlive;      // compactDead's renumbering tables (kept: no allocation per keyframe)
     std::vector<int> mActive;                       // indices of residuals uploaded (alive), device order
     std::vector<int> mActivePoints, mPointSlot;     // device point order <-> mPoints
     std::vector<int> mOutliers;
