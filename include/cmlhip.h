@@ -486,6 +486,12 @@ int cmlhip_tracer_get_state(cmlhip_ctx* ctx, int n, cmlhip_immature_state* out);
 typedef struct { double R[9], t[3], a, b; } cmlhip_frame_pose;          /* world -> camera, exposure parameters */
 int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* ctx, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
                                                const cmlhip_frame_pose* hosts, const cmlhip_frame_pose* reference, const double K[4], int skip_host);
+/* Optional, BEFORE cmlhip_tracker_optimize_batch_async: the window of the trace that will follow the batch (the very arguments the _tracked_async call
+ * then passes).  The batch's launch carries it and the workgroup that ends the first hypothesis forms the pairs host -> frame right behind its result;
+ * the trace behind it reads them instead of every wave deriving its own, and the publishing launch copies them (same function, same bits — only where
+ * it runs changes).  One shot: consumed by the next batch; a _tracked_async call whose window differs from the prepared one works as without it.
+ * Windows wider than 8 frames are accepted and ignored (their pairs come from a launch of their own, as before). */
+int cmlhip_tracer_tracked_prepare(cmlhip_ctx* ctx, int n_hosts, const cmlhip_frame_pose* hosts, const cmlhip_frame_pose* reference, const double K[4]);
 int cmlhip_tracer_trace_resident_finish(cmlhip_ctx* ctx, int keep, int counts[6], cmlhip_trace_pair* pairs_out /* n_hosts or NULL */);
 typedef struct {            /* host -> target of the activation window: Camera::to and Exposure::to (DSOTracer.cpp:418-420) */
     double R[9], t[3], aff_a, aff_b;

@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <functional>
 #include "../../include/cmlhip.h"
+#include "trace_pairs.h"
 
 #define CML_WAVE 64
 #define RS_TILE_DEFAULT 64
@@ -170,6 +171,7 @@ struct cmlhip_ctx {
     DevBuf tr_resident2, tr_edit, tr_state;                   // cmlhip_tracer_edit_points (the set rebuilt into the second buffer), cmlhip_tracer_get_state
     DevBuf tr_hosts, tr_journal; void* tr_host = nullptr; void* tr_host_dev = nullptr;      // cmlhip_tracer_trace_resident_tracked_async: host poses, the rollback journal, mapped block {counts | pairs}
     bool tr_spec_pending = false; int tr_spec_hosts = 0, tr_spec_skip = -2;
+    TrackedReq tr_req; bool tr_req_valid = false, tr_req_consumed = false;      // cmlhip_tracer_tracked_prepare: the window the next tracker launch carries (its tail forms the pairs)
     DevBuf tr_counts;                                         // status histogram of the tracked trace (cleared by its publishing kernel)
     DevBuf pt_mask, marg_scratch;                             // marginalisation passes: per-point selection, block partials
     DevBuf frame_state, pre_w2c, null_basis;                  // device-resident iterations (cmlhip_ba_set_resident_state)

@@ -12,6 +12,7 @@
 // scalar_t is double in the reference; its float places are kept float; FP contraction is off: results are bit-identical
 // to the CPU statement order.
 #include "cmlhip_internal.h"
+#include "trace_pairs.h"
 #include <atomic>
 #include <cstring>
 
@@ -74,6 +75,9 @@ __global__ __launch_bounds__(256) void k_trace_points(TraceArgs A);
 template <bool HALF>
 __device__ __forceinline__ void trace_one(const TraceArgs& A, int pi);
 
+// (round 6, measured and not kept: the publishing step folded into this launch — every wave counts itself done, the last one copies histogram and pairs
+//  to the host block and stores the ticket.  13.4 + 4.1 us as two launches became 21.6 us as one: the last wave's system-scope release has the launch's
+//  dirty point records to write back first, which the kernel boundary otherwise does while the publishing launch is being dispatched.)
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_trace_points(TraceArgs A) {
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -390,6 +394,7 @@ int cmlhip_trace_points(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_pa
     if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_trace_pair) * (size_t)n_hosts))) return rc;
     if ((rc = cml_h2d(c, c->tr_points.p, points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
     if ((rc = cml_h2d(c, c->tr_pairs.p, pairs, sizeof(cmlhip_trace_pair) * (size_t)n_hosts))) return rc;
+    c->tr_req_consumed = false;                              // (pairs a tracker launch left in tr_pairs are overwritten)
     TraceArgs A;
     A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
     A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_points.as<cmlhip_immature_point>();
@@ -476,6 +481,7 @@ int cmlhip_tracer_trace_resident(cmlhip_ctx* c, uint64_t image_id, const cmlhip_
     if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_trace_pair) * (size_t)n_hosts))) return rc;
     if ((rc = cml_ensure(c, c->tr_out, 64))) return rc;
     if ((rc = cml_h2d(c, c->tr_pairs.p, pairs, sizeof(cmlhip_trace_pair) * (size_t)n_hosts))) return rc;
+    c->tr_req_consumed = false;                              // (pairs a tracker launch left in tr_pairs are overwritten)
     CML_CHECK(c, hipMemsetAsync(c->tr_out.p, 0, 24, c->stream));
     TraceArgs A;
     A.img = py->lv[0].grad; A.w = py->lv[0].w; A.h = py->lv[0].h; A.n = n;
@@ -493,37 +499,10 @@ int cmlhip_tracer_trace_resident(cmlhip_ctx* c, uint64_t image_id, const cmlhip_
 // again with the pose it did select.  Pairs as DSOTracer.cpp:606-608 forms them: frame = refToNew o reference, host -> frame = frame o host^-1,
 // K R K^-1, K t, and the exposure transfer with exposure times 1 (Exposure.h:119-123).
 }  // extern "C" (device code of the tracked trace)
-#define TR_INLINE_HOSTS 8
 struct TraceTracked {                          // kernel arguments of the tracked trace: the window's poses travel with the launch (windows of up to TR_INLINE_HOSTS frames)
     const double* pose0;                       // {R[9], t[3], a, b} of the batch's first result (device; written by k_tracker_optimize)
-    cmlhip_frame_pose ref; double K[4]; int n_hosts, pad;
-    cmlhip_frame_pose hosts[TR_INLINE_HOSTS];
+    TrackedReq W;
 };
-__device__ __forceinline__ void tp_mul33(const double* A_, const double* B_, double* C_) {       // C = A B, row by row, left to right
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C_[3 * i + j] = (A_[3 * i] * B_[j] + A_[3 * i + 1] * B_[3 + j]) + A_[3 * i + 2] * B_[6 + j];
-}
-// host -> frame for one host (every caller gets the same bits: one function, contraction off)
-__device__ __forceinline__ void tp_pair(const double* pose0, const cmlhip_frame_pose& ref, const double* K, const cmlhip_frame_pose& H, cmlhip_trace_pair& P) {
-    double R[9], t[3];
-    for (int k = 0; k < 9; k++) R[k] = pose0[k];
-    for (int k = 0; k < 3; k++) t[k] = pose0[9 + k];
-    const double an = pose0[12], bn = pose0[13];
-    double Rn[9], tn[3];
-    tp_mul33(R, ref.R, Rn);                                                                     // frame = refToNew o reference
-    for (int i = 0; i < 3; i++) tn[i] = ((R[3 * i] * ref.t[0] + R[3 * i + 1] * ref.t[1]) + R[3 * i + 2] * ref.t[2]) + t[i];
-    double HT[9], Rr[9], tr[3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) HT[3 * i + j] = H.R[3 * j + i];
-    tp_mul33(Rn, HT, Rr);                                                                       // Rn Rh^T
-    for (int i = 0; i < 3; i++) tr[i] = tn[i] - ((Rr[3 * i] * H.t[0] + Rr[3 * i + 1] * H.t[1]) + Rr[3 * i + 2] * H.t[2]);
-    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
-    const double Km[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0 / fx, 0, -cx / fx, 0, 1.0 / fy, -cy / fy, 0, 0, 1};
-    double KR[9];
-    tp_mul33(Km, Rr, KR);
-    tp_mul33(KR, Ki, P.KRKi);
-    for (int i = 0; i < 3; i++) P.Kt[i] = (Km[3 * i] * tr[0] + Km[3 * i + 1] * tr[1]) + Km[3 * i + 2] * tr[2];
-    const double a = exp(an - H.a);
-    P.aff_a = a; P.aff_b = bn - a * H.b;
-}
 // the trace with the pairs formed IN the launch: a wave derives the pair of its point's host from the first result (a few hundred wave-uniform
 // operations against a launch of its own for all of them), parks it in LDS and traces against it
 template <bool HALF>
@@ -533,7 +512,7 @@ __global__ __launch_bounds__(256) void k_trace_points_tracked(TraceArgs A, Trace
     const int pi = blockIdx.x * 4 + wv;
     if (pi >= A.n) return;                                                         // wave-uniform
     const int host = A.pts[pi].host;
-    if (host < 0 || host >= T.n_hosts) return;                                     // not in the window
+    if (host < 0 || host >= T.W.n_hosts) return;                                   // not in the window
     if (l == 0) {
         const cmlhip_immature_point& q = A.pts[pi];
         TraceJournal j;
@@ -542,7 +521,7 @@ __global__ __launch_bounds__(256) void k_trace_points_tracked(TraceArgs A, Trace
         A.journal[pi] = j;
     }
     if (host != A.skip_host) {
-        if (l == 0) tp_pair(T.pose0, T.ref, T.K, T.hosts[host], s_pair[wv]);
+        if (l == 0) tp_pair(T.pose0, T.W.ref, T.W.K, T.W.hosts[host], s_pair[wv]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                     // (one wave writes and reads its slot: in-order LDS, compiler ordering)
         __builtin_amdgcn_wave_barrier();
         TraceArgs B = A;
@@ -573,12 +552,15 @@ __global__ void k_trace_rollback(cmlhip_immature_point* pts, const TraceJournal*
 }
 // the chain's last launch: the status histogram and the pairs the trace used into mapped host memory (the pairs formed again by the same function: same
 // bits), the histogram cleared for the next frame, then — behind a system-scope fence — the completion ticket the host's wait spins on
-struct TracePublish { const double* pose0; cmlhip_frame_pose ref; double K[4]; int n_hosts; const cmlhip_frame_pose* hosts; int* counts; int* out_counts;
+struct TracePublish { const double* pose0; cmlhip_frame_pose ref; double K[4]; int n_hosts; const cmlhip_frame_pose* hosts; const cmlhip_trace_pair* pairs; int* counts; int* out_counts;
                       cmlhip_trace_pair* out_pairs; volatile unsigned* ticket_word; unsigned ticket; };
 __global__ void k_trace_publish(TracePublish A) {
     const int t = threadIdx.x;
     if (t < 6) { A.out_counts[t] = A.counts[t]; A.counts[t] = 0; }
-    if (t < A.n_hosts) {
+    if (A.pairs) {                                           // the pairs the tracker launch left (its tail formed them): copied
+        const int nw = A.n_hosts * (int)(sizeof(cmlhip_trace_pair) / 8);
+        for (int w = t; w < nw; w += blockDim.x) reinterpret_cast<double*>(A.out_pairs)[w] = reinterpret_cast<const double*>(A.pairs)[w];
+    } else if (t < A.n_hosts) {
         cmlhip_trace_pair P;
         tp_pair(A.pose0, A.ref, A.K, A.hosts[t], P);
         A.out_pairs[t] = P;
@@ -588,6 +570,22 @@ __global__ void k_trace_publish(TracePublish A) {
     if (t == 0) { __threadfence_system(); *A.ticket_word = A.ticket; }
 }
 extern "C" {
+
+// The window of the NEXT tracked trace, handed over BEFORE the tracker batch is enqueued: the batch's launch then carries it and the workgroup that ends the
+// first hypothesis forms the pairs host -> frame right behind its result (one wave, a lane per host) — the trace behind it reads them like any caller's pairs
+// instead of every wave deriving its own (14.7 -> 10.5 us for the trace launch, and the publishing launch copies instead of forming them again).
+int cmlhip_tracer_tracked_prepare(cmlhip_ctx* c, int n_hosts, const cmlhip_frame_pose* hosts, const cmlhip_frame_pose* reference, const double K[4]) {
+    if (!c || n_hosts < 1 || n_hosts > CMLHIP_MAX_FRAMES || !hosts || !reference || !K) return CMLHIP_ERR_INVALID;
+    c->tr_req_valid = false; c->tr_req_consumed = false;
+    if (n_hosts > TR_INLINE_HOSTS) return CMLHIP_OK;        // (wider windows: the pairs by a launch of their own, as before)
+    TrackedReq& W = c->tr_req;
+    memset(&W, 0, sizeof W);
+    W.ref = *reference; for (int k = 0; k < 4; k++) W.K[k] = K[k];
+    W.n_hosts = n_hosts;
+    memcpy(W.hosts, hosts, sizeof(cmlhip_frame_pose) * (size_t)n_hosts);
+    c->tr_req_valid = true;
+    return CMLHIP_OK;
+}
 
 int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id, const cmlhip_tracer_params* prm, int n_hosts,
                                                const cmlhip_frame_pose* hosts, const cmlhip_frame_pose* reference, const double K[4], int skip_host) { CML_DEV(c);
@@ -620,12 +618,19 @@ int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id,
     A.pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.P = *prm; A.pts = c->tr_resident.as<cmlhip_immature_point>();
     A.skip_host = skip_host; A.counts = c->tr_counts.as<int>(); A.journal = c->tr_journal.as<TraceJournal>();
     const bool half = c->lim.texel_format == CMLHIP_TEXEL_F16;
-    if (n > 0 && n_hosts <= TR_INLINE_HOSTS) {
+    // did the tracker launch carry this very window (cmlhip_tracer_tracked_prepare ahead of it)?  Then its tail leaves the pairs in tr_pairs.
+    bool from_tracker = c->tr_req_consumed && c->tr_req.n_hosts == n_hosts && memcmp(c->tr_req.hosts, hosts, sizeof(cmlhip_frame_pose) * (size_t)n_hosts) == 0 &&
+                        memcmp(&c->tr_req.ref, reference, sizeof(cmlhip_frame_pose)) == 0 && memcmp(c->tr_req.K, K, 4 * sizeof(double)) == 0;
+    c->tr_req_consumed = false;
+    if (n > 0 && from_tracker) {
+        if (half) k_trace_points<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
+        else k_trace_points<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A);
+    } else if (n > 0 && n_hosts <= TR_INLINE_HOSTS) {
         TraceTracked T;
         memset(&T, 0, sizeof T);
-        T.pose0 = pose0; T.ref = *reference; for (int k = 0; k < 4; k++) T.K[k] = K[k];
-        T.n_hosts = n_hosts;
-        memcpy(T.hosts, hosts, sizeof(cmlhip_frame_pose) * (size_t)n_hosts);
+        T.pose0 = pose0; T.W.ref = *reference; for (int k = 0; k < 4; k++) T.W.K[k] = K[k];
+        T.W.n_hosts = n_hosts;
+        memcpy(T.W.hosts, hosts, sizeof(cmlhip_frame_pose) * (size_t)n_hosts);
         if (half) k_trace_points_tracked<true><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A, T);
         else k_trace_points_tracked<false><<<cml_div_up(n, 4), 256, 0, c->stream>>>(A, T);
     } else if (n > 0) {
@@ -638,7 +643,7 @@ int cmlhip_tracer_trace_resident_tracked_async(cmlhip_ctx* c, uint64_t image_id,
     }
     TracePublish PB;
     PB.pose0 = pose0; PB.ref = *reference; for (int k = 0; k < 4; k++) PB.K[k] = K[k];
-    PB.n_hosts = n_hosts; PB.hosts = hosts_dev; PB.counts = c->tr_counts.as<int>(); PB.out_counts = static_cast<int*>(c->tr_host_dev);
+    PB.n_hosts = n_hosts; PB.hosts = hosts_dev; PB.pairs = (from_tracker || n_hosts > TR_INLINE_HOSTS) ? c->tr_pairs.as<cmlhip_trace_pair>() : nullptr; PB.counts = c->tr_counts.as<int>(); PB.out_counts = static_cast<int*>(c->tr_host_dev);
     PB.out_pairs = reinterpret_cast<cmlhip_trace_pair*>(static_cast<char*>(c->tr_host_dev) + 64);
     if ((rc = cml_done_embed(c, &PB.ticket, &PB.ticket_word))) return rc;      // the ticket the tracker's wait (cmlhip_tracker_optimize_wait) then waits for: one host wait for the frame
     k_trace_publish<<<1, 64, 0, c->stream>>>(PB);
@@ -695,6 +700,7 @@ static int optimize_immature_common(cmlhip_ctx* c, int N, const uint64_t* image_
         A.pts = c->tr_resident.as<cmlhip_immature_point>(); A.slots = c->tr_edit.as<int>();
     }
     if ((rc = cml_h2d(c, c->tr_pairs.p, pairs, sizeof(cmlhip_activation_pair) * (size_t)N * N))) return rc;
+    c->tr_req_consumed = false;                              // (pairs a tracker launch left in tr_pairs are overwritten)
     A.N = N; A.n = n; A.min_obs = min_obs;
     for (int k = 0; k < 4; k++) A.K[k] = K[k];
     A.pairs = c->tr_pairs.as<cmlhip_activation_pair>(); A.P = *prm;

@@ -48,6 +48,10 @@ struct TrkOptArgs {
     // with E/n of level 0 below early_rmse; the other hypotheses see it at their next exchange and give up (n_steps = -1).
     int* early_flag; float early_rmse;
     double* pose0;                                     // device copy {R[9], t[3], a, b} of the FIRST hypothesis' result: read by the trace enqueued behind the batch (tracer.hip)
+    // cmlhip_tracer_tracked_prepare: the window of the trace enqueued behind this batch — the workgroup that ends hypothesis 0 forms the pairs
+    // host -> frame right behind its result (a lane per host), the trace reads them like any caller's pairs
+    cmlhip_trace_pair* tr_pairs;                       // null: no request
+    TrackedReq req;
 };
 
 // per-evaluation constants exactly as TR.cpp:260-278,426-429 forms them (float), shared by the workgroup
@@ -825,6 +829,15 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
             out->relAff[0] = relA; out->relAff[1] = relB;
         }
     }
+    if (A.tr_pairs && hyp == 0 && g == 0) {                                                                 // (uniform per workgroup)
+        __threadfence_block();
+        __syncthreads();                                                                                    // lane 0's pose0 stores, visible to the workgroup
+        if (tid < A.req.n_hosts) {
+            cmlhip_trace_pair P;
+            tp_pair(A.pose0, A.req.ref, A.req.K, A.req.hosts[tid], P);
+            A.tr_pairs[tid] = P;
+        }
+    }
     if (!failed && tid < 64) {                                                                              // :243, wave 0 (S.H is lane 0's no more: nothing writes it from here on)
         const double hi = to_inverse8_wave(S.H, tid);
         if ((tid >> 3) == (tid & 7) && (tid >> 3) < 6) out->covariance[tid >> 3] = hi;
@@ -967,6 +980,12 @@ extern "C" int cmlhip_tracker_optimize_batch_async(cmlhip_ctx* c, uint64_t image
     }
     if ((rc = cml_ensure(c, c->trk_pose0, 128))) return rc;
     A.pose0 = c->trk_pose0.as<double>();
+    A.tr_pairs = nullptr;
+    if (c->tr_req_valid) {                                 // one shot: the request is this launch's
+        if ((rc = cml_ensure(c, c->tr_pairs, sizeof(cmlhip_trace_pair) * CMLHIP_MAX_FRAMES))) return rc;
+        A.tr_pairs = c->tr_pairs.as<cmlhip_trace_pair>(); A.req = c->tr_req;
+        c->tr_req_valid = false; c->tr_req_consumed = true;
+    } else { c->tr_req_consumed = false; A.req.n_hosts = 0; }
     A.late = reinterpret_cast<int*>(static_cast<char*>(dptr) + hyp_bytes + res_bytes);
     // (no per-call clearing: the words carry the launch number; a fresh or moved buffer is cleared once)
     // cleared once per ALLOCATION (DevBuf::gen, not the address: a free + malloc may hand the address back) and whenever the 16-bit launch

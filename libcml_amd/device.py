@@ -48,6 +48,7 @@ PROTOTYPES = {
     "cmlhip_tracker_optimize_wait": (C.c_int, [_ctx, _P(abi.TrackerOptResult)]),
     "cmlhip_tracer_trace_resident_tracked_async": (C.c_int, [_ctx, C.c_uint64, _P(abi.TracerParams), _i, C.c_void_p, C.c_void_p, _P(_d), _i]),
     "cmlhip_tracer_trace_resident_finish": (C.c_int, [_ctx, _i, _P(C.c_int), C.c_void_p]),
+    "cmlhip_tracer_tracked_prepare": (C.c_int, [_ctx, _i, C.c_void_p, C.c_void_p, _P(_d)]),
     "cmlhip_ba_set_resident_indirect": (C.c_int, [_ctx, _i, _P(_d), _i, _P(abi.ReprojObs), _d, _d]),
     "cmlhip_ba_get_resident_indirect": (C.c_int, [_ctx, _P(_d), _P(_d), _P(_d)]),
     "cmlhip_ba_set_resident_prior": (C.c_int, [_ctx, _P(_d), _P(_d)]),
@@ -496,14 +497,21 @@ class Ctx:
         self._trk_pending = 0
         return [out[i] for i in range(n)]
 
+    @staticmethod
+    def _pack_poses(ps):
+        a = np.zeros((len(ps), 14))
+        for i, (R, t, ea, eb) in enumerate(ps):
+            a[i, :9] = np.asarray(R, np.float64).ravel(); a[i, 9:12] = t; a[i, 12] = ea; a[i, 13] = eb
+        return a
+
+    def tracer_tracked_prepare(self, host_poses, reference, K):
+        """cmlhip_tracer_tracked_prepare, ahead of tracker_optimize_batch_async: the window the tracked trace will pass"""
+        hp = self._pack_poses(host_poses); rf = self._pack_poses([reference]); Kd = np.ascontiguousarray(K, np.float64)
+        self.ck(self.L.cmlhip_tracer_tracked_prepare(self.h, len(host_poses), hp.ctypes.data, rf.ctypes.data, _p(Kd, _d)))
+
     def tracer_trace_resident_tracked_async(self, image_id, prm, host_poses, reference, K, skip_host=-2):
         """cmlhip_tracer_trace_resident_tracked_async behind tracker_optimize_batch_async: host_poses / reference = (R, t, a, b) world -> camera"""
-        def pack(ps):
-            a = np.zeros((len(ps), 14))
-            for i, (R, t, ea, eb) in enumerate(ps):
-                a[i, :9] = np.asarray(R, np.float64).ravel(); a[i, 9:12] = t; a[i, 12] = ea; a[i, 13] = eb
-            return a
-        hp = pack(host_poses); rf = pack([reference]); Kd = np.ascontiguousarray(K, np.float64)
+        hp = self._pack_poses(host_poses); rf = self._pack_poses([reference]); Kd = np.ascontiguousarray(K, np.float64)
         self._tr_hosts = len(host_poses)
         self.ck(self.L.cmlhip_tracer_trace_resident_tracked_async(self.h, int(image_id), C.byref(prm), len(host_poses), hp.ctypes.data, rf.ctypes.data, _p(Kd, _d), int(skip_host)))
 

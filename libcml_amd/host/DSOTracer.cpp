@@ -130,6 +130,13 @@ bool DSOTracer::traceNewCoarseTrackedAsync(uint64_t traced_image_id, int traced_
     return true;
 }
 
+bool DSOTracer::prepareTracked(const std::vector<cmlhip_frame_pose>& hosts, const cmlhip_frame_pose& reference, const double K[4]) {
+    if (hosts.empty()) { mError = "prepareTracked: no window"; return false; }
+    const int rc = cmlhip_tracer_tracked_prepare(mCtx, (int)hosts.size(), hosts.data(), &reference, K);
+    if (rc) { mError = std::string("cmlhip_tracer_tracked_prepare: ") + cmlhip_last_error(mCtx); return false; }
+    return true;
+}
+
 bool DSOTracer::finishTracked(bool keep, int counts[6], std::vector<cmlhip_trace_pair>* pairs_out) {
     if (!mTrackedPending) { mError = "finishTracked: nothing in flight"; return false; }
     mTrackedPending = false;

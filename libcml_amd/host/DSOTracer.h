@@ -50,6 +50,8 @@ public:
     // used come back; otherwise every traced point is restored and the caller traces again (traceNewCoarse) with the pose it did select.
     bool traceNewCoarseTrackedAsync(uint64_t traced_image_id, int traced_frame_id, const std::vector<int>& frame_ids, const std::vector<cmlhip_frame_pose>& hosts,
                                     const cmlhip_frame_pose& reference, const double K[4]);
+    // optional, ahead of DSOTracker::trackWithMotionModelBatchedEnqueue: the window traceNewCoarseTrackedAsync will pass (cmlhip_tracer_tracked_prepare)
+    bool prepareTracked(const std::vector<cmlhip_frame_pose>& hosts, const cmlhip_frame_pose& reference, const double K[4]);
     bool finishTracked(bool keep, int counts[6], std::vector<cmlhip_trace_pair>* pairs_out);
 
     // bring the device's set up to date NOW (the keyframe's work: makeNewTraces has added its points, marginalizeFrames has removed frames) instead of in

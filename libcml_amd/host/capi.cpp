@@ -357,6 +357,7 @@ int cmlhost_frame_track_and_trace(void* trk, void* trc, uint64_t new_image, int 
     static const bool timing = getenv("CMLHOST_TIMING") != nullptr;
     const auto T0 = std::chrono::steady_clock::now();
     auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
+    if (!Tr->prepareTracked(hp, hp[ref_index], K)) return -1;                        // the batch's launch carries the trace's window: pairs formed at its tail
     if (!T->trackWithMotionModelBatchedEnqueue(new_image, levels, n_hyp, hyp.data(), ref, init)) return -1;
     const double t_a = us();
     const bool traced = Tr->traceNewCoarseTrackedAsync(new_image, traced_frame_id, ids, hp, hp[ref_index], K);

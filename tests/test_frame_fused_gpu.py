@@ -109,6 +109,41 @@ def test_speculative_trace_against_the_oracle_and_rollback(scene):
         assert _bits_equal(back[name], pts[name]), name
 
 
+def test_pairs_formed_at_the_tracker_tail_equal_the_trace_launch_ones(scene):
+    """cmlhip_tracer_tracked_prepare: the batch's launch carries the window and forms the pairs behind hypothesis 0 — same function, same bits as the
+    trace launch forming them; a prepared window that is not the one the trace then passes is ignored"""
+    P, ctx, pts, hosts, hyps = scene
+    W, s = P.W, P.s
+    prm = abi.default_tracer_params()
+    ref = hosts[s.ref]
+
+    def frame(prepare, trace_hosts=None):
+        ctx.tracer_set_points(pts)
+        if prepare is not None:
+            ctx.tracer_tracked_prepare(prepare, ref, W.K)
+        ctx.tracker_optimize_batch_async(501, P.levels, W.K, P.ref_exp, P.init_exp, P.prm, hyps)
+        ctx.tracer_trace_resident_tracked_async(501, prm, trace_hosts or hosts, ref, W.K, skip_host=-2)
+        res = ctx.tracker_optimize_wait()
+        counts, pairs = ctx.tracer_trace_resident_finish(keep=True)
+        return res, counts, pairs, ctx.tracer_get_points()
+    r0, c0, p0, a0 = frame(None)
+    r1, c1, p1, a1 = frame(hosts)
+    assert _bits_equal(np.array(r0[0].R[:]), np.array(r1[0].R[:])) and _bits_equal(np.array(r0[0].t[:]), np.array(r1[0].t[:]))
+    assert p0.tobytes() == p1.tobytes()
+    assert np.array_equal(c0, c1)
+    for name in FIELDS:
+        assert _bits_equal(a0[name], a1[name]), name
+    # a stale request (another window's poses): the trace forms its own pairs, as without it
+    other = [(R, t + 0.01, a, b) for (R, t, a, b) in hosts]
+    r2, c2, p2, a2 = frame(other)
+    assert p0.tobytes() == p2.tobytes() and np.array_equal(c0, c2)
+    for name in FIELDS:
+        assert _bits_equal(a0[name], a2[name]), name
+    # the request is one shot: a second batch without prepare does not reuse it
+    r3, c3, p3, a3 = frame(None)
+    assert p0.tobytes() == p3.tobytes() and np.array_equal(c0, c3)
+
+
 def test_host_mirror_fused_call_equals_the_two_calls(scene):
     P, ctx, pts, hosts, hyps = scene
     W, s = P.W, P.s
