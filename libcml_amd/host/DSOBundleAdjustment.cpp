@@ -1,6 +1,7 @@
 // DSOBundleAdjustment.cpp — host mirror of CML::Optimization::DSOBundleAdjustment over the C ABI.
 // BA.cpp = src/cml/optimization/dso/DSOBundleAdjustment.cpp in the reference tree.
 #include "DSOBundleAdjustment.h"
+#include "HostLap.h"
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -10,12 +11,6 @@
 
 namespace cml_amd {
 
-// development: CMLHOST_TIMING=1 prints the host clock at the named points of a call (stderr)
-struct HostLap {
-    const char* fn; std::chrono::steady_clock::time_point t0; bool on;
-    explicit HostLap(const char* f) : fn(f), t0(std::chrono::steady_clock::now()), on(getenv("CMLHOST_TIMING") != nullptr) {}
-    void operator()(const char* what) const { if (on) fprintf(stderr, "      [%s] %-22s %.0f us\n", fn, what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
-};
 
 // ------------------------------------------------------------------------------------------------ DSOFrame
 static void updatePRE(DSOFrame& f) {                                           // DSOFrame.h:119-120
@@ -481,9 +476,7 @@ bool DSOBundleAdjustment::uploadWindow() {
     mPrm.scale_f = mScaleF; mPrm.scale_c = mScaleC; mPrm.optimize_a = mOptimizeA; mPrm.optimize_b = mOptimizeB;
     int rc = cmlhip_ba_set_params(mCtx, &mPrm);
     if (rc) return fail("cmlhip_ba_set_params", rc);
-    const auto TU0 = std::chrono::steady_clock::now();
-    static const bool timingU = getenv("CMLHOST_TIMING") != nullptr;
-    auto lapU = [&](const char* what) { if (timingU || getenv("CMLHOST_TIMING")) fprintf(stderr, "      [uploadWindow] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TU0).count()); };
+    HostLap lapU("uploadWindow");
     if (mDeadSinceCompact) compactDead();                    // (entries dropped since the last addNewFrame: the window holds live entries only)
     lapU("compact");
     if (!syncWindowAppends()) return false;
@@ -528,8 +521,7 @@ int DSOBundleAdjustment::setPairs(const std::vector<cmlhip_ba_pair>& pairs) {
 }
 
 bool DSOBundleAdjustment::linearizeAll(bool fixLinearization, double energy[3], std::vector<double>* idepthOut, std::vector<float>* pointAccOut, bool applyToo, bool enqueueOnly) {   // BA.cpp:1497-1646
-    const auto TL0 = std::chrono::steady_clock::now();
-    auto lapL = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "      [linearizeAll] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TL0).count()); };
+    HostLap lapL("linearizeAll");
     std::vector<cmlhip_ba_pair> pairs;
     framePairs(pairs);
     int rc = setPairs(pairs);
@@ -732,8 +724,8 @@ bool DSOBundleAdjustment::doStepFromBackup(bool fixCamera) {                  //
 }
 
 bool DSOBundleAdjustment::runPreamble(double lastEnergy[3], bool enqueueOnly) {                // BA.cpp:744-802
-    const auto T0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "    [preamble] %-22s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
+    HostLap lap("preamble");
+    const auto T0 = lap.t0;
     mOutliers.clear();
     mError.clear();
     lastIterations = 0;
@@ -1138,8 +1130,7 @@ bool DSOBundleAdjustment::beginResident(bool updatePointsOnly) {
         std::fill(mMarginalizedB.begin(), mMarginalizedB.end(), 0.0);
     }
     const int N = (int)mFrames.size();
-    const auto TB0 = std::chrono::steady_clock::now();
-    auto lapB = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "      [beginResident] %-20s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - TB0).count()); };
+    HostLap lapB("beginResident");
     double sc[4];
     scales(sc);
     computeDelta();
@@ -1234,7 +1225,7 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
     double lastEnergy[3];
     const auto T0 = std::chrono::steady_clock::now();
     auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
-    auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "  [run] %-28s %.0f us\n", what, us()); };
+    HostLap lap("run");
     // ---- preamble (BA.cpp:744-802) and the loop's resident state: ONE packed copy (upload scope), then the kernels
     mOutliers.clear();
     mError.clear();
@@ -1343,7 +1334,7 @@ bool DSOBundleAdjustment::runResident(bool updatePointsOnly) {
 bool DSOBundleAdjustment::runResidentStepwise(bool updatePointsOnly) {
     double lastEnergy[3];
     const auto T0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) { if (getenv("CMLHOST_TIMING")) fprintf(stderr, "  [run] %-28s %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count()); };
+    HostLap lap("run (stepwise)");
     auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
     if (!runPreamble(lastEnergy)) return false;
     lap("preamble done");

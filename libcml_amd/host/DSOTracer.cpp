@@ -1,5 +1,6 @@
 // DSOTracer.cpp — host mirror of CML::Optimization::DSOTracer over the C ABI (TRC.cpp = src/cml/optimization/dso/DSOTracer.cpp).
 #include "DSOTracer.h"
+#include "HostLap.h"
 #include <cmath>
 #include <cstring>
 
@@ -33,13 +34,16 @@ int DSOTracer::addImmaturePoint(float x, float y, int host_frame_id, const float
 }
 
 void DSOTracer::compact() {
+    HostLap lap("tracer compact");
     pullResident();
+    lap("state pulled");
     mResDirty = true; mResSlotsValid = false;
     std::vector<ImmaturePoint> keep;
     std::vector<int> moved(mPoints.size(), -1);                                 // old index -> new index
     for (size_t i = 0; i < mPoints.size(); i++) if (mPoints[i].alive && !mPoints[i].activated) { moved[i] = (int)keep.size(); keep.push_back(mPoints[i]); }
     for (int& w : mResWho) if (w >= 0) w = moved[w];                            // (the device's slots still hold the points that left: dropped at the next edit)
     mPoints.swap(keep);
+    lap("list rebuilt");
 }
 
 static int indexOf(const std::vector<int>& ids, int id) {
@@ -69,7 +73,9 @@ bool DSOTracer::pullResident() {
 // keyframe instead of the whole set).
 bool DSOTracer::syncResident(const std::vector<int>& frame_ids) {
     if (!mResDirty && frame_ids == mResFrameIds) return true;
+    HostLap lap("syncResident");
     if (!pullResident()) return false;
+    lap("state pulled");
     std::vector<int> keep, hosts, who;
     std::vector<cmlhip_immature_point> fresh;
     std::vector<int> freshWho;
@@ -97,6 +103,7 @@ bool DSOTracer::syncResident(const std::vector<int>& frame_ids) {
         P.res_slot = (int)(who.size() + fresh.size());
         fresh.push_back(P.d); freshWho.push_back(i);
     }
+    lap("edit lists");
     const int rc = cmlhip_tracer_edit_points(mCtx, (int)keep.size(), keep.data(), hosts.data(), (int)fresh.size(), fresh.data());
     if (rc) { mError = std::string("cmlhip_tracer_edit_points: ") + cmlhip_last_error(mCtx); return false; }
     who.insert(who.end(), freshWho.begin(), freshWho.end());
@@ -104,6 +111,7 @@ bool DSOTracer::syncResident(const std::vector<int>& frame_ids) {
     for (int i : mResWho) mPoints[i].was_resident = true;
     mResFrameIds = frame_ids;
     mResDirty = false; mResSlotsValid = true;
+    lap("device edit");
     return true;
 }
 
@@ -150,7 +158,9 @@ bool DSOTracer::finishTracked(bool keep, int counts[6], std::vector<cmlhip_trace
 bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vector<uint64_t>& image_ids, const double K[4], int w, int h,
                                const std::vector<cmlhip_activation_pair>& pairs, std::vector<int>& activated, const SpacingPolicy& spacing) {
     const int N = (int)frame_ids.size(), last = N - 1;
+    HostLap lap("activatePoints");
     if (!pullResident()) return false;
+    lap("state pulled");
     mResDirty = true;                                                           // (points leave the set here: activated, dropped, out of the image)
     activated.clear();
     numSkippedBecauseStatus = numSkippedBecausePixelInterval = numSkippedBecauseQuality = numSkippedBecauseDepth = 0;
@@ -189,6 +199,7 @@ bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vec
         P.d.host = hst;
         batch.push_back(P.d); who.push_back(i);
     }
+    lap("candidates selected");
     if (batch.empty()) return true;
     std::vector<int> result(batch.size()), states(batch.size() * (size_t)N);
     std::vector<float> idp(batch.size());
@@ -206,6 +217,7 @@ bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vec
         rc = cmlhip_optimize_immature_points(mCtx, N, image_ids.data(), K, pairs.data(), &prm, 1, (int)batch.size(), batch.data(), result.data(), idp.data(), states.data());
         if (rc) { mError = std::string("cmlhip_optimize_immature_points: ") + cmlhip_last_error(mCtx); return false; }
     }
+    lap("device optimisation");
     for (size_t k = 0; k < who.size(); k++) {                                   // TRC.cpp:216-247
         ImmaturePoint& P = mPoints[who[k]];
         if (result[k] == 1) {
@@ -216,6 +228,7 @@ bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vec
         } else if (result[k] == -1 || P.d.last_status == CMLHIP_IPS_OOB) { P.alive = false; numDropped++; }
         else numNonMapped++;
     }
+    lap("results applied");
     return true;
 }
 

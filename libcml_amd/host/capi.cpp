@@ -7,6 +7,7 @@
 #include <string>
 #include "DSOBundleAdjustment.h"
 #include "DSOTracker.h"
+#include "HostLap.h"
 #include "DSOTracer.h"
 #include "IndirectG2O.h"
 #include "DSOInitializer.h"
@@ -191,6 +192,8 @@ int cmlhost_ba_coarse_depth_points(void* h, int kf, const double K[4], double* o
     }
     return n;
 }
+// development (CMLHOST_TIMING=sum): forget the laps collected so far (a warm-up pass)
+void cmlhost_laps_reset() { cml_amd::HostLapTable::get().rows.clear(); }
 void cmlhost_ba_run_timing(void* h, double us[6]) { for (int i = 0; i < 6; i++) us[i] = static_cast<DSOBundleAdjustment*>(h)->lastRunUs[i]; }
 int cmlhost_ba_rejected(void* h) { return static_cast<DSOBundleAdjustment*>(h)->statRejected; }
 double cmlhost_ba_last_lambda(void* h) { return static_cast<DSOBundleAdjustment*>(h)->lastLambda; }
@@ -354,7 +357,7 @@ int cmlhost_frame_track_and_trace(void* trk, void* trc, uint64_t new_image, int 
         std::memcpy(hp[h].R, hosts + 14 * (size_t)h, 9 * sizeof(double)); std::memcpy(hp[h].t, hosts + 14 * (size_t)h + 9, 3 * sizeof(double));
         hp[h].a = hosts[14 * (size_t)h + 12]; hp[h].b = hosts[14 * (size_t)h + 13];
     }
-    static const bool timing = getenv("CMLHOST_TIMING") != nullptr;
+    static const bool timing = cml_amd::HostLap::modeOf() == 1;
     const auto T0 = std::chrono::steady_clock::now();
     auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
     if (!Tr->prepareTracked(hp, hp[ref_index], K)) return -1;                        // the batch's launch carries the trace's window: pairs formed at its tail
