@@ -70,7 +70,7 @@ struct ToState {
     int ctrl[2], n_steps, n_pass, haveRepeated;
     long long t_eval, t_alg, t_mark;                   // wall_clock64 ticks (10 ns): evaluations / lane-0 algebra
 #ifdef TO_PROFILE
-    long long t_ldlt, t_pose, t_fin;
+    long long t_ldlt, t_pose, t_fin, t_p[4];
 #endif
 };
 
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl[0] = S.ctrl[1] = TO_CONTINUE; s_abort = 0;
         S.t_eval = 0; S.t_alg = 0; S.t_mark = wall_clock64();
 #ifdef TO_PROFILE
-        S.t_ldlt = S.t_pose = S.t_fin = 0;
+        S.t_ldlt = S.t_pose = S.t_fin = 0; S.t_p[0] = S.t_p[1] = S.t_p[2] = S.t_p[3] = 0;
 #endif
     }
     __syncthreads();
@@ -727,11 +727,24 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                     for (int i = 0; i < 8; i++) { inc[i] *= extrapFac; incS[i] = inc[i]; nrm += inc[i] * inc[i]; }
                     for (int i = 0; i < 3; i++) { incS[i] *= (double)A.scale_rot; incS[3 + i] *= (double)A.scale_trans; }   // the literal lane / scale pairing, :144-148
                     incS[6] *= (double)A.scale_a; incS[7] *= (double)A.scale_b;
+#ifdef TO_PROFILE
+                    const long long q0 = wall_clock64(); S.t_p[0] += q0 - tp1;
+                    const SE3 ex_ = SE3::exp(incS);
+                    const long long q1 = wall_clock64(); S.t_p[1] += q1 - q0;
+                    const SE3 nw = ex_ * to_pose(S.cur_q, S.cur_t);
+#else
                     const SE3 nw = SE3::exp(incS) * to_pose(S.cur_q, S.cur_t);                              // :155-157
+#endif
                     to_store(nw, S.nw_q, S.nw_t);
                     S.na = S.a + incS[6]; S.nb = S.b + incS[7];                                             // :159
                     S.Hn[0] = sqrt(nrm);                                                                    // |increment| parked for the exit test below
+#ifdef TO_PROFILE
+                    const long long q2 = wall_clock64(); S.t_p[2] += q2 - q1;
+#endif
                     to_prepare(A, ev, level, nw, S.na, S.nb, S.levelCutoffRepeat[level], true);
+#ifdef TO_PROFILE
+                    S.t_p[3] += wall_clock64() - q2;
+#endif
                     S.ctrl[cseq & 1] = TO_ITERATE;
                 }
 #ifdef TO_PROFILE
@@ -828,6 +841,9 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
             }
             out->relAff[0] = relA; out->relAff[1] = relB;
         }
+#ifdef TO_PROFILE
+        out->relAff[0] = 0.01 * (double)S.t_p[0]; out->relAff[1] = 0.01 * (double)S.t_p[1]; out->flow[0] = (float)(0.01 * (double)S.t_p[2]); out->flow[1] = (float)(0.01 * (double)S.t_p[3]);
+#endif
     }
     if (A.tr_pairs && hyp == 0 && g == 0) {                                                                 // (uniform per workgroup)
         __threadfence_block();
