@@ -365,6 +365,43 @@ __device__ __forceinline__ double to_inverse8_wave(const double* Ain /* 64, LDS 
     return ai;
 }
 
+// SE3::exp (host/se3.h, Sophus se3.hpp:224-257) for LANES 0-3 of a wave running the same chain on the same numbers.  A lone lane pays a wave's issue
+// slot per instruction, so work of the same SHAPE on different operands goes to different lanes of one instruction stream: the half-angle and the
+// full-angle sincos are ONE call (even lanes theta / 2, odd lanes theta), sqrt(theta^2) and the sqrt of the increment's norm the caller needs are ONE
+// square root, the three IEEE divisions (sin(theta / 2) / theta, (1 - cos) / theta^2, (theta - sin) / theta^3) ONE — each lane hands its result to the
+// others by v_readlane.  Same operations on the same operands per value; 580 -> ~400 instructions on the chain (18.4 -> 13 us over a 15-trial frame).
+__device__ __forceinline__ SE3 to_se3_exp_lanes(const double xi[6], const double nrm2, double& nrm, const int lane) {
+    const double eps = 1e-10;
+    const double* om = xi + 3;
+    const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    const double rt = sqrt((lane & 1) ? nrm2 : th2);
+    nrm = to_rl(rt, 1);
+    SE3 T;
+    double O[9], O2[9], V[9];
+    SE3::hat(om, O);
+    SE3::mm(O, O, O2);
+    if (th2 < eps * eps) {                                    // (wave-uniform: the lanes hold the same increment) — theta = 0 in se3.h
+        const double p4 = th2 * th2;
+        const double imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * p4, real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * p4;
+        T.q[0] = real; T.q[1] = imag * om[0]; T.q[2] = imag * om[1]; T.q[3] = imag * om[2];
+        T.matrix(V);
+    } else {
+        const double theta = to_rl(rt, 0);
+        double s_, c_;
+        sincos((lane & 1) ? theta : 0.5 * theta, &s_, &c_);
+        const double sh_ = to_rl(s_, 0), ch_ = to_rl(c_, 0), st_ = to_rl(s_, 1), ct_ = to_rl(c_, 1);
+        const double t2 = theta * theta, t3 = t2 * theta;
+        const double num = lane == 0 ? sh_ : (lane == 1 ? (1.0 - ct_) : (theta - st_)), den = lane == 0 ? theta : (lane == 1 ? t2 : t3);
+        const double qt = num / den;
+        const double imag = to_rl(qt, 0), a = to_rl(qt, 1), b = to_rl(qt, 2);
+        T.q[0] = ch_; T.q[1] = imag * om[0]; T.q[2] = imag * om[1]; T.q[3] = imag * om[2];
+        if (theta < eps) T.matrix(V);                         // (se3.h tests theta here, theta^2 above)
+        else for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+    }
+    SE3::mv(V, xi, T.t);
+    return T;
+}
+
 // lane 0: the constants of one evaluation (TR.cpp:260-278, 426-429; InternalCalibration.h:116-127; Exposure.h:119-123)
 __device__ __forceinline__ SE3 to_pose(const double q[4], const double t[3]) {
     SE3 T;
@@ -650,7 +687,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
     __shared__ unsigned char s_step_level[CMLHIP_TRACKER_MAX_STEPS], s_step_accept[CMLHIP_TRACKER_MAX_STEPS];
     __shared__ int s_pass_level[8];
     __shared__ double s_pass_rmse[8];
-    __shared__ double s_wA[64], s_wD[64], s_winc[8], s_wincS[8];   // lane 0's scratchpads (a dynamically indexed local array would live in scratch memory)
+    __shared__ double s_wA[64], s_wD[64];                          // scratchpads of the 8 x 8 solve (a dynamically indexed local array would live in scratch memory)
     const int tid = threadIdx.x, hyp = blockIdx.x / A.G, g = blockIdx.x % A.G;
     cmlhip_tracker_opt_result* out = (g == 0 && A.out_host) ? A.out_host + hyp : A.out + blockIdx.x;    // (each workgroup of the hypothesis writes its own copy: they are identical; the first one's goes straight to the host)
     float* xch = A.xch + (size_t)hyp * 2 * 2 * TO_PARTS * 64;     // (8-byte words, [2 parities][TO_PARTS][64]: see to_exchange)
@@ -711,33 +748,38 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                 const long long tp1 = wall_clock64();
                 if (tid == 0) S.t_ldlt += tp1 - tp0;
 #endif
-              if (tid == 0) {
+              if (tid < 4) {                                                                                // lanes 0-3 run the same chain (identical stores); see to_se3_exp_lanes
                 S.iterations[level] = iteration + 1;
-                double* inc = s_winc;
-                for (int i = 0; i < 8; i++) inc[i] = 0;
-                if (A.opt_a && A.opt_b) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[6] = xs[6]; inc[7] = xs[7]; }
-                else if (A.opt_a) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[6] = xs[6]; }
-                else if (A.opt_b) { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; inc[7] = xs[6]; }
-                else { inc[0] = xs[0]; inc[1] = xs[1]; inc[2] = xs[2]; inc[3] = xs[3]; inc[4] = xs[4]; inc[5] = xs[5]; }
+                // the increment in registers (statically indexed: the loops below are unrolled) — the LDS scratchpads it used to live on cost a
+                // dependent round trip per read-modify-write
+                double inc[8], incS[8];
+#pragma unroll
+                for (int i = 0; i < 6; i++) inc[i] = xs[i];
+                inc[6] = A.opt_a ? xs[6] : 0.0;                                                             // the lanes the variant does not solve stay 0
+                inc[7] = (A.opt_a && A.opt_b) ? xs[7] : ((!A.opt_a && A.opt_b) ? xs[6] : 0.0);
                 if (!ok) S.ctrl[cseq & 1] = TO_FAIL;                                                                  // :121-138
                 else {
                     double extrapFac = 1;
                     if (S.lambda < 0.001) extrapFac = sqrt(sqrt(0.001 / S.lambda));                         // :140-142
-                    double* incS = s_wincS; double nrm = 0;
+                    double nrm = 0;
+#pragma unroll
                     for (int i = 0; i < 8; i++) { inc[i] *= extrapFac; incS[i] = inc[i]; nrm += inc[i] * inc[i]; }
+#pragma unroll
                     for (int i = 0; i < 3; i++) { incS[i] *= (double)A.scale_rot; incS[3 + i] *= (double)A.scale_trans; }   // the literal lane / scale pairing, :144-148
                     incS[6] *= (double)A.scale_a; incS[7] *= (double)A.scale_b;
 #ifdef TO_PROFILE
                     const long long q0 = wall_clock64(); S.t_p[0] += q0 - tp1;
-                    const SE3 ex_ = SE3::exp(incS);
+                    double nrm_rt;
+                    const SE3 ex_ = to_se3_exp_lanes(incS, nrm, nrm_rt, tid);
                     const long long q1 = wall_clock64(); S.t_p[1] += q1 - q0;
                     const SE3 nw = ex_ * to_pose(S.cur_q, S.cur_t);
 #else
-                    const SE3 nw = SE3::exp(incS) * to_pose(S.cur_q, S.cur_t);                              // :155-157
+                    double nrm_rt;
+                    const SE3 nw = to_se3_exp_lanes(incS, nrm, nrm_rt, tid) * to_pose(S.cur_q, S.cur_t);   // :155-157
 #endif
                     to_store(nw, S.nw_q, S.nw_t);
                     S.na = S.a + incS[6]; S.nb = S.b + incS[7];                                             // :159
-                    S.Hn[0] = sqrt(nrm);                                                                    // |increment| parked for the exit test below
+                    S.Hn[0] = nrm_rt;                                                                       // |increment| = sqrt(nrm), parked for the exit test below
 #ifdef TO_PROFILE
                     const long long q2 = wall_clock64(); S.t_p[2] += q2 - q1;
 #endif
