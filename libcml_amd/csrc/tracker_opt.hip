@@ -74,14 +74,24 @@ struct ToState {
 #endif
 };
 
+// The reference list and the image are DEVICE memory, but their pointers reach the evaluation through a struct in LDS: generic pointers, every access a
+// FLAT one (it waits for the LDS counter as well and takes the slower address path).  The loads say "global" themselves.
+typedef unsigned to_uint2 __attribute__((ext_vector_type(2)));
+#if __HIP_DEVICE_COMPILE__
+#define TO_GLOBAL __attribute__((address_space(1)))
+#else
+#define TO_GLOBAL
+#endif
 template <bool HALF>
 __device__ __forceinline__ float4 to_texel(const void* img, size_t i) {
     if (HALF) {
-        uint2 v = reinterpret_cast<const uint2*>(img)[i];
-        __half2 a = *reinterpret_cast<__half2*>(&v.x), b = *reinterpret_cast<__half2*>(&v.y);
+        const to_uint2 v = ((const TO_GLOBAL to_uint2*)img)[i];
+        unsigned vx = v.x, vy = v.y;
+        __half2 a = *reinterpret_cast<__half2*>(&vx), b = *reinterpret_cast<__half2*>(&vy);
         return make_float4(__low2float(a), __high2float(a), __low2float(b), 0.f);
     }
-    return reinterpret_cast<const float4*>(img)[i];
+    const to_float4 q = ((const TO_GLOBAL to_float4*)img)[i];
+    return make_float4(q.x, q.y, q.z, q.w);
 }
 
 // Eigen compute_inverse_size3 (cofactors * 1/det) in float, as Matrix33f::inverse() at TR.cpp:261
@@ -532,7 +542,7 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
             for (int k = 0; k < 16; k++) { va[k] = 0.f; vb[k] = 0.f; }
             if (i < E.n) {
                 va[9] = 1.f; vb[9] = 1.f;
-                const float4 q = reinterpret_cast<const float4*>(E.uvic)[i];
+                const to_float4 q = ((const TO_GLOBAL to_float4*)E.uvic)[i];
                 const float x = q.x, y = q.y, id = q.z, refColor = q.w;
                 if (isfinite(refColor)) {                                           // TR.cpp:301-303
                     float pt[3];
@@ -647,11 +657,15 @@ __device__ __forceinline__ void to_finish(const TrkOptArgs& A, const float* s, f
     const int numWarped = (int)s[52];
     int npad = numWarped;
     while (npad % 4 != 0) npad++;
-    auto sc = [&](int k) { return (double)(k < 3 ? A.scale_rot : (k < 6 ? A.scale_trans : (k == 6 ? A.scale_a : A.scale_b))); };
+    // the scale of unknown k = 0 .. 7 (TR.cpp:472-490), selected per lane from four VALUES: through a lambda indexing the argument struct the selection
+    // became a per-lane LOAD from the kernel-argument segment — three dependent trips of ~0.3 us on the critical path of every trial
+    const float s_rot = A.scale_rot, s_trans = A.scale_trans, s_a = A.scale_a, s_b = A.scale_b;
     auto h9 = [&](int r, int c) { const int lo = min(r, c), hi = max(r, c); return s[9 * lo - (lo * (lo - 1)) / 2 + (hi - lo)]; };
     const int r = l >> 3, cc = l & 7;
-    H[r * 8 + cc] = ((double)h9(r, cc) / (double)npad) * sc(cc) * sc(r);
-    if (l < 8) b[l] = ((double)h9(l, 8) / (double)npad) * sc(l);
+    const float sc_c = cc < 3 ? s_rot : (cc < 6 ? s_trans : (cc == 6 ? s_a : s_b));
+    const float sc_r = r < 3 ? s_rot : (r < 6 ? s_trans : (r == 6 ? s_a : s_b));
+    H[r * 8 + cc] = ((double)h9(r, cc) / (double)npad) * (double)sc_c * (double)sc_r;
+    if (l < 8) b[l] = ((double)h9(l, 8) / (double)npad) * (double)sc_c;              // (l < 8: cc == l)
 }
 
 // lane 0's decision to every lane: read between two barriers, so that lane 0 may overwrite it right away
