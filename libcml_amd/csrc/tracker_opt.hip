@@ -650,11 +650,14 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
 // s holds the upper triangle of the 9x9 accumulator in row order (entry (r, c >= r) at 9r - r(r-1)/2 + c - r), then the counters
 __device__ __forceinline__ void to_finish(const TrkOptArgs& A, const float* s, float& E, int& nT, int& nS, int& nR, float flow[3], double* H, double* b) {
     const int l = threadIdx.x;                             // < 64
+    // (the sums as values first: E, nT ... are references into the same LDS the sums live in — read one by one between the stores, every read was a
+    //  round trip of its own behind the store before it)
+    const float s45 = s[45], s46 = s[46], s47 = s[47], s48 = s[48], s49 = s[49], s50 = s[50], s51 = s[51], s52 = s[52];
     if (l == 0) {
-        E = s[45]; nT = (int)s[49]; nS = (int)s[50]; nR = (int)s[51];
-        flow[0] = s[46] / (s[48] + 0.1f); flow[1] = 0; flow[2] = s[47] / (s[48] + 0.1f);
+        E = s45; nT = (int)s49; nS = (int)s50; nR = (int)s51;
+        flow[0] = s46 / (s48 + 0.1f); flow[1] = 0; flow[2] = s47 / (s48 + 0.1f);
     }
-    const int numWarped = (int)s[52];
+    const int numWarped = (int)s52;
     int npad = numWarped;
     while (npad % 4 != 0) npad++;
     // the scale of unknown k = 0 .. 7 (TR.cpp:472-490), selected per lane from four VALUES: through a lambda indexing the argument struct the selection
@@ -820,16 +823,17 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
                 if (accept) {                                                                               // every lane moves the entries it wrote
                     S.H[tid] = S.Hn[tid];
                     if (tid < 8) S.bv[tid] = S.bn[tid];
+                    // oldResidual = newResidual (whole struct, :167) and the trial's pose: a lane per entry (lane 0 alone paid ~35 loads and as many
+                    // stores, serialised in groups); nothing reads these fields before the hand-over below
+                    if (tid < 5) { S.E[tid] = S.E_new[tid]; S.nT[tid] = S.nT_new[tid]; S.nS[tid] = S.nS_new[tid]; S.nR[tid] = S.nR_new[tid]; }
+                    if (tid < 4) S.cur_q[tid] = S.nw_q[tid];
+                    if (tid < 3) { S.flow[tid] = S.flow_new[tid]; S.cur_t[tid] = S.nw_t[tid]; }
                 }
                 if (tid == 0) {
                     if (S.n_steps < CMLHIP_TRACKER_MAX_STEPS) { s_step_level[S.n_steps] = (unsigned char)level; s_step_accept[S.n_steps] = accept ? 1 : 0; }
                     S.n_steps++;
                     if (accept) {
-                        for (int l = 0; l < 5; l++) { S.E[l] = S.E_new[l]; S.nT[l] = S.nT_new[l]; S.nS[l] = S.nS_new[l]; S.nR[l] = S.nR_new[l]; }   // oldResidual = newResidual (whole struct), :167
-                        for (int k = 0; k < 3; k++) S.flow[k] = S.flow_new[k];
-                        for (int i = 0; i < 4; i++) S.cur_q[i] = S.nw_q[i];
-                        for (int i = 0; i < 3; i++) S.cur_t[i] = S.nw_t[i];
-                        S.a = S.na; S.b = S.nb;
+                        S.a = S.na; S.b = S.nb;                                                             // (the arrays: a lane per entry, above)
                         S.lambda *= 0.5;
                     } else {
                         S.lambda *= 4;
