@@ -70,7 +70,7 @@ struct ToState {
     int ctrl[2], n_steps, n_pass, haveRepeated;
     long long t_eval, t_alg, t_mark;                   // wall_clock64 ticks (10 ns): evaluations / lane-0 algebra
 #ifdef TO_PROFILE
-    long long t_ldlt, t_pose, t_fin, t_p[4];
+    long long t_ldlt, t_pose, t_fin, t_p[4], t_e[4];
 #endif
 };
 
@@ -514,8 +514,14 @@ __device__ __forceinline__ float to_exchange(float* __restrict__ xch, int* __res
 template <bool HALF>
 __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[64][TO_LD], float (*s_tile)[256], float* s_red, float* s_part,
                         const int g, const int G, const int split_min, float* xch, int* tick, int& seq, const int epoch, int* late_flag,
-                        const int* early_flag, int* s_abort) {
+                        const int* early_flag, int* s_abort, long long* te = nullptr) {
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+#ifdef TO_PROFILE
+    long long te_last = wall_clock64();
+#define TE_STAMP(k) do { if (te && tid == 0) { const long long n_ = wall_clock64(); te[k] += n_ - te_last; te_last = n_; } } while (0)
+#else
+#define TE_STAMP(k) do { } while (0)
+#endif
     // The parts of a level are fixed by its SIZE: eight for a level with more than split_min reference points (part s = the chunks s, s + 8,
     // s + 16, ... of TO_THREADS points), one otherwise — NOT by G.  A workgroup evaluates the parts s = g, g + G, ... (G in {1, 2, 4, 8});
     // the level's sums are the part sums added in part order by every workgroup.  So a hypothesis gives the same bits alone (G = 8),
@@ -616,10 +622,12 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
             }
             __builtin_amdgcn_wave_barrier();
         }
+        TE_STAMP(0);                                                    // setup + this wave's points + matrix-core sums
         if (kown) __syncthreads();                                      // wave 0 has read the tiles of the part before
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) s_tile[wv][(4 * (l >> 4) + rg) * 16 + (l & 15)] = acc[rg];
         __syncthreads();
+        TE_STAMP(1);                                                    // tiles out, every wave arrived
         // from here on only wave 0 works on the sums: it adds the waves' tiles (wave order) and keeps the part's 56 sums
         if (tid < 64) {
             float v = 0.f;
@@ -627,6 +635,7 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
             s_part[kown * 64 + tid] = v;
         }
     }
+    TE_STAMP(2);                                                        // wave 0: the waves' tiles added
     const bool xchg = NP > 1 && G > 1;
     if (xchg) seq++;                                                    // (every thread keeps the exchange number)
     if (tid < 64) {
@@ -644,6 +653,7 @@ __device__ void to_eval(const ToEval& E, float (*s_a)[64][TO_LD], float (*s_b)[6
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // read back by other lanes of this wave only: compiler ordering
         __builtin_amdgcn_wave_barrier();
     }
+    TE_STAMP(3);                                                        // exchange between the hypothesis' workgroups / own parts added
 }
 
 // wave 0: the level's sums -> Residual slots (lane 0) and the scaled 8x8 system, one entry per lane (TR.cpp:405-414, 472-490);
@@ -682,8 +692,13 @@ __device__ __forceinline__ int to_ctrl(const ToState& S, int& cseq) {
 }
 
 // lane 0 books the time since the last mark as algebra, runs the evaluation, books it as evaluation
+#ifdef TO_PROFILE
+#define TO_TE S.t_e
+#else
+#define TO_TE nullptr
+#endif
 #define TO_TIMED_EVAL() do { if (tid == 0) { const long long t_ = wall_clock64(); S.t_alg += t_ - S.t_mark; S.t_mark = t_; } \
-        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, s_part, g, A.G, A.split_min, xch, tick, seq, A.epoch, A.late, hyp > 0 ? A.early_flag : nullptr, &s_abort); \
+        to_eval<HALF>(ev, s_a, s_b, s_tile, s_red, s_part, g, A.G, A.split_min, xch, tick, seq, A.epoch, A.late, hyp > 0 ? A.early_flag : nullptr, &s_abort, TO_TE); \
         if (tid == 0) { const long long t_ = wall_clock64(); S.t_eval += t_ - S.t_mark; S.t_mark = t_; } } while (0)
 
 enum { TO_CONTINUE = 0, TO_FAIL = 1, TO_REPEAT_SAT = 2, TO_ITERATE = 3, TO_LEVEL_DONE = 4 };
@@ -720,7 +735,7 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         S.n_steps = 0; S.n_pass = 0; S.haveRepeated = 0; S.ctrl[0] = S.ctrl[1] = TO_CONTINUE; s_abort = 0;
         S.t_eval = 0; S.t_alg = 0; S.t_mark = wall_clock64();
 #ifdef TO_PROFILE
-        S.t_ldlt = S.t_pose = S.t_fin = 0; S.t_p[0] = S.t_p[1] = S.t_p[2] = S.t_p[3] = 0;
+        S.t_ldlt = S.t_pose = S.t_fin = 0; S.t_p[0] = S.t_p[1] = S.t_p[2] = S.t_p[3] = 0; S.t_e[0] = S.t_e[1] = S.t_e[2] = S.t_e[3] = 0;
 #endif
     }
     __syncthreads();
@@ -918,6 +933,10 @@ __global__ __launch_bounds__(TO_THREADS) void k_tracker_optimize(TrkOptArgs A) {
         const double hi = to_inverse8_wave(S.H, tid);
         if ((tid >> 3) == (tid & 7) && (tid >> 3) < 6) out->covariance[tid >> 3] = hi;
     }
+#ifdef TO_PROFILE
+    __syncthreads();
+    if (tid == 0) for (int k = 0; k < 4; k++) out->covariance[k] = 0.01 * (double)S.t_e[k];      // (profile build: the evaluation's phases ride in the covariance slots)
+#endif
 }
 
 extern "C" int cmlhip_tracker_set_early_exit(cmlhip_ctx* c, double rmse_bar) {

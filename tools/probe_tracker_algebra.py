@@ -13,4 +13,5 @@ hyps = [TS.perturbed(P, (0.004, -0.003, 0.002), (0.03, -0.02, 0.025))]
 for _ in range(3): res = ctx.tracker_optimize_batch(501, P.levels, P.W.K, P.ref_exp, P.init_exp, P.prm, hyps)
 r = res[0]
 print("trials", r.n_steps, "eval", r.eval_us, "algebra", r.algebra_us, "ldlt", r.pass_rmse[7], "lane0 pose+prepare", r.pass_rmse[6], "finish+accept", r.pass_rmse[5],
-      "| pose split: increment %.1f  SE3::exp %.1f  product+store %.1f  prepare %.1f" % (r.relAff[0], r.relAff[1], r.flow[0], r.flow[1]))
+      "| pose split: increment %.1f  SE3::exp %.1f  product+store %.1f  prepare %.1f" % (r.relAff[0], r.relAff[1], r.flow[0], r.flow[1]),
+      "| eval split: points+mfma %.1f  tiles+barriers %.1f  tile sum %.1f  exchange %.1f" % tuple(r.covariance[k] for k in range(4)))
