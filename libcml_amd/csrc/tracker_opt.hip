@@ -237,19 +237,18 @@ __device__ bool to_ldlt_solve_wave_sorted(const double* Hs, const double* bs, co
     const unsigned long long bad = __ballot(act && a != i && !(da > di) && !(di > da));   // a tie or a NaN
     const unsigned long long zero = __ballot(act && a == i && !(da > 0.0));               // (the all-zero matrix is a tie already unless n == 1)
     if (bad || zero) return false;
-    // pos[q] = number of active entries larger than d[q] = the step that picks q;  idx[k] = the entry step k picks
-    int idx_u[8], idx_k = i;
+    // pos[q] = number of active entries larger than d[q] = the step that picks q;  idx[k] = the entry step k picks.  The inverse goes through eight ints of
+    // the scratchpad (lane q stores q at pos[q], every lane reads the eight back) — as 64 compare / select pairs on wave-uniform copies it was a tenth of
+    // this solve's instructions, and a lone wave pays an issue slot for each
+    int* s_pick = reinterpret_cast<int*>(s_x);
+    if (a == 0 && i < n) s_pick[__popcll((gt >> i) & 0x0101010101010101ull)] = i;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // one wave, in-order LDS: compiler ordering only
+    __builtin_amdgcn_wave_barrier();
+    int idx_u[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) idx_u[k] = k;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int pos = __popcll((gt >> q) & 0x0101010101010101ull);
-        if (q < n) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (pos == k) idx_u[k] = q;
-            if (pos == i) idx_k = q;
-        }
-    }
+    for (int k = 0; k < 8; k++) { const int v = s_pick[k]; idx_u[k] = (k < n) ? v : k; }
+    const int idx_k = (i < n) ? s_pick[i] : i;
+    __builtin_amdgcn_wave_barrier();                        // (the scratchpad is written again further down)
     double row[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -265,18 +264,16 @@ __device__ bool to_ldlt_solve_wave_sorted(const double* Hs, const double* bs, co
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if (k >= n) continue;                                // wave-uniform
-        double akk = to_rl(row[k], k);
         if (k > 0) {
-            double temp[8], s = 0;
+            double temp[8];
 #pragma unroll
-            for (int j = 0; j < k; j++) { const double lkj = to_rl(row[j], k); temp[j] = dd[j] * lkj; s += lkj * temp[j]; }
-            akk -= s;
+            for (int j = 0; j < k; j++) { const double lkj = to_rl(row[j], k); temp[j] = dd[j] * lkj; }
             double s2 = 0;
 #pragma unroll
             for (int j = 0; j < k; j++) s2 += row[j] * temp[j];
-            if (i > k) row[k] -= s2;
+            if (i >= k) row[k] -= s2;                         // lane k: A_kk - sum_j L_kj temp_j — its row[j] IS L_kj: the pivot's own sum, same operands in the same order
         }
-        if (i == k) row[k] = akk;
+        const double akk = to_rl(row[k], k);
         if (fabs(akk) > 0.0) {
             if (i > k) row[k] /= akk;
         }
