@@ -1115,21 +1115,30 @@ static int upload_point_mask(cmlhip_ctx* c, int n, const int* idx) {
     return cml_h2d(c, c->pt_mask.p, m.data(), m.size());
 }
 
+// the inputs of a marginalisation pass (adjoints, deltas, priors, the point mask, a cleared counter) in ONE packed upload: a scatter kernel reading the
+// pinned staging block instead of five copies / fills of their own (each a launch on the stream and a runtime call on the host)
+static int upload_marg_inputs(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* counter_to_clear) {
+    cml_h2d_batch_begin(c);
+    int rc = upload_accum_in(c, in);
+    if (!rc) rc = upload_point_mask(c, n, point_idx);
+    if (!rc && counter_to_clear) rc = cml_zero(c, counter_to_clear, sizeof(int));            // (a zero segment of the same batch)
+    const int rf = cml_h2d_batch_flush(c);
+    return rc ? rc : rf;
+}
+
 int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good) { CML_DEV(c);
     int rc = ba_check(c, true);
     if (rc) return rc;
     if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
         return CMLHIP_ERR_INVALID;
-    if ((rc = upload_accum_in(c, in))) return rc;
-    if ((rc = upload_point_mask(c, n, point_idx))) return rc;
+    int* counter = reinterpret_cast<int*>(c->scal.as<char>() + 512);
+    if ((rc = upload_marg_inputs(c, in, n, point_idx, counter))) return rc;
     BAArgs A;
     cml_make_ba_args(c, A);
     A.pt_mask = c->pt_mask.as<unsigned char>();
     A.lin_partial = nullptr;                                 // a subset pass: no window energy
     A.fuse_apply = 1;                                        // applyRes(r, true), BA.cpp:2299
-    int* counter = reinterpret_cast<int*>(c->scal.as<char>() + 512);
-    CML_CHECK(c, hipMemsetAsync(counter, 0, sizeof(int), c->stream));
     cml_launch_marg_reset(c, A);
     cml_launch_linearize(c, A);
     cml_launch_marg_fix(c, A, c->adHTd.as<float>(), c->vec_small.as<double>(), counter);
@@ -1144,10 +1153,18 @@ int cmlhip_ba_relinearize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
 // the same pass with what tryMarginalize's host loop reads of it (BA.cpp:2296-2304: state, isActiveAndIsGoodNEW, isLinearized of the candidates'
 // residuals) packed as ONE byte per residual in the caller's order, behind the counter in ONE readback — it was the counter, six R-length arrays
 // and the LINEARIZED flags in three synchronous calls
+// (e0 .. e2: the three energy arrays the caller asked for, in its order too — they were a launch each)
 __global__ void k_ba_pack_marg(int R, const int* __restrict__ c_dev_of, const int* __restrict__ r_state, const int* __restrict__ r_new_state,
-                               const unsigned char* __restrict__ r_good, const unsigned char* __restrict__ r_lin, unsigned char* __restrict__ out) {
+                               const unsigned char* __restrict__ r_good, const unsigned char* __restrict__ r_lin, unsigned char* __restrict__ out,
+                               const float* __restrict__ e0, const float* __restrict__ e1, const float* __restrict__ e2, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R) { const int k = c_dev_of[i]; out[i] = (unsigned char)((r_state[k] & 3) | (r_good[k] ? 4 : 0) | (r_lin[k] ? 8 : 0) | ((r_new_state[k] & 3) << 4)); }
+    if (i < R) {
+        const int k = c_dev_of[i];
+        out[i] = (unsigned char)((r_state[k] & 3) | (r_good[k] ? 4 : 0) | (r_lin[k] ? 8 : 0) | ((r_new_state[k] & 3) << 4));
+        if (o0) o0[i] = e0[k];
+        if (o1) o1[i] = e1[k];
+        if (o2) o2[i] = e2[k];
+    }
 }
 int cmlhip_ba_relinearize_points_packed(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, int n, const int* point_idx, int* n_good, unsigned char* packed,
                                         float* energy, float* new_energy, float* new_energy_wo) { CML_DEV(c);
@@ -1156,31 +1173,36 @@ int cmlhip_ba_relinearize_points_packed(cmlhip_ctx* c, const cmlhip_ba_accum_in*
     if ((rc = cml_materialize_records(c))) return rc;
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx) || !packed)
         return CMLHIP_ERR_INVALID;
-    if ((rc = upload_accum_in(c, in))) return rc;
-    if ((rc = upload_point_mask(c, n, point_idx))) return rc;
+    int* counter = reinterpret_cast<int*>(c->scal.as<char>() + 512);
+    if ((rc = upload_marg_inputs(c, in, n, point_idx, counter))) return rc;
     BAArgs A;
     cml_make_ba_args(c, A);
     A.pt_mask = c->pt_mask.as<unsigned char>();
     A.lin_partial = nullptr;
     A.fuse_apply = 1;
-    int* counter = reinterpret_cast<int*>(c->scal.as<char>() + 512);
-    CML_CHECK(c, hipMemsetAsync(counter, 0, sizeof(int), c->stream));
     cml_launch_marg_reset(c, A);
     cml_launch_linearize(c, A);
     cml_launch_marg_fix(c, A, c->adHTd.as<float>(), c->vec_small.as<double>(), counter);
-    const size_t R = c->R;
-    if ((rc = cml_ensure(c, c->run_pack, ((R + 255) & ~size_t(255)) + 4 * (size_t)c->P + 256))) return rc;
+    const size_t R = c->R, Rb = (R + 255) & ~size_t(255), Rf = (4 * R + 255) & ~size_t(255);
+    if ((rc = cml_ensure(c, c->run_pack, Rb + 3 * Rf + 4 * (size_t)c->P + 256))) return rc;
+    unsigned char* pk = c->run_pack.as<unsigned char>();
+    float* o0 = energy ? reinterpret_cast<float*>(pk + Rb) : nullptr;
+    float* o1 = new_energy ? reinterpret_cast<float*>(pk + Rb + Rf) : nullptr;
+    float* o2 = new_energy_wo ? reinterpret_cast<float*>(pk + Rb + 2 * Rf) : nullptr;
     if (R > 0) k_ba_pack_marg<<<cml_div_up((int)R, 256), 256, 0, c->stream>>>((int)R, c->c_dev_of.as<int>(), c->r_state.as<int>(), c->r_new_state.as<int>(),
-                                                                             c->r_good.as<unsigned char>(), c->r_lin.as<unsigned char>(), c->run_pack.as<unsigned char>());
+                                                                             c->r_good.as<unsigned char>(), c->r_lin.as<unsigned char>(), pk,
+                                                                             c->r_energy.as<float>(), c->r_new_energy.as<float>(), c->r_new_energy_wo.as<float>(), o0, o1, o2);
     CML_CHECK(c, hipGetLastError());
     int ng = 0;
-    ResRead rr(c);
     cml_d2h_batch_begin(c);
     cml_d2h(c, &ng, counter, sizeof(int));
-    if (R > 0) cml_d2h(c, packed, c->run_pack.p, R);
-    rr.add(energy, c->r_energy.p, 4); rr.add(new_energy, c->r_new_energy.p, 4); rr.add(new_energy_wo, c->r_new_energy_wo.p, 4);
+    if (R > 0) {
+        cml_d2h(c, packed, pk, R);
+        if (o0) cml_d2h(c, energy, o0, 4 * R);
+        if (o1) cml_d2h(c, new_energy, o1, 4 * R);
+        if (o2) cml_d2h(c, new_energy_wo, o2, 4 * R);
+    }
     if ((rc = cml_d2h_batch_flush(c))) return rc;
-    rr.deliver();
     if (ng > 0) c->n_lin = std::max(c->n_lin, 1);
     if (n_good) *n_good = ng;
     return CMLHIP_OK;
@@ -1193,8 +1215,7 @@ int cmlhip_ba_marginalize_points(cmlhip_ctx* c, const cmlhip_ba_accum_in* in, in
     if ((rc = cml_materialize_records(c))) return rc;        // the resident kernel keeps Jacobians in reduced form: re-create the records first
     if (!in || !in->adHost || !in->adTarget || !in->adHTdeltaF || !in->cdelta || !in->prior || !in->delta_prior || !in->cprior || n < 0 || (n > 0 && !point_idx))
         return CMLHIP_ERR_INVALID;
-    if ((rc = upload_accum_in(c, in))) return rc;
-    if ((rc = upload_point_mask(c, n, point_idx))) return rc;
+    if ((rc = upload_marg_inputs(c, in, n, point_idx, nullptr))) return rc;
     BAArgs A;
     cml_make_ba_args(c, A);
     A.pt_mask = c->pt_mask.as<unsigned char>();

@@ -105,8 +105,8 @@ void* cml_h2d_stage(cmlhip_ctx* c, void* dst, size_t bytes) {
 __global__ void k_h2d_scatter(const unsigned long long* __restrict__ segs, const char* __restrict__ blob) {
     const unsigned long long* S = segs + 3 * (size_t)blockIdx.y;
     char* dst = reinterpret_cast<char*>((uintptr_t)S[0]);
-    const bool zero = S[1] >= ~1ull;                  // a fill segment (~0: zeros, ~1: all bits set = -1 as int)
-    const unsigned fillw = S[1] == ~1ull ? 0xffffffffu : 0u;
+    const bool zero = S[1] >= ~2ull;                  // a fill segment (~0: zeros, ~1: all bits set = -1 as int, ~2: every byte 0x7f)
+    const unsigned fillw = S[1] == ~1ull ? 0xffffffffu : (S[1] == ~2ull ? 0x7f7f7f7fu : 0u);
     const char* src = zero ? blob : blob + S[1];
     const size_t bytes = (size_t)S[2], words = bytes / 16;
     const bool aligned = (((uintptr_t)dst) & 15) == 0;
@@ -130,6 +130,15 @@ int cml_zero(cmlhip_ctx* c, void* dst, size_t bytes) {
         return CMLHIP_OK;
     }
     CML_CHECK(c, hipMemsetAsync(dst, 0, bytes, c->stream));
+    return CMLHIP_OK;
+}
+int cml_fill_7f(cmlhip_ctx* c, void* dst, size_t bytes) {       // every byte 0x7f (ints: 0x7f7f7f7f, "nobody yet" of the coarse-depth owner map)
+    if (bytes == 0) return CMLHIP_OK;
+    if (c->h2d_batching) {
+        c->h2d_segs.push_back((unsigned long long)(uintptr_t)dst); c->h2d_segs.push_back(~2ull); c->h2d_segs.push_back((unsigned long long)bytes);
+        return CMLHIP_OK;
+    }
+    CML_CHECK(c, hipMemsetAsync(dst, 0x7f, bytes, c->stream));
     return CMLHIP_OK;
 }
 int cml_fill_ff(cmlhip_ctx* c, void* dst, size_t bytes) {       // every byte 0xff (ints: -1)

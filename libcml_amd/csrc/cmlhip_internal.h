@@ -249,6 +249,7 @@ void* cml_h2d_stage(cmlhip_ctx* c, void* dst, size_t bytes);      // batch mode:
 void cml_h2d_batch_begin(cmlhip_ctx* c);
 int cml_zero(cmlhip_ctx* c, void* dst, size_t bytes);        // hipMemsetAsync(0), or a zero segment of the open batch
 int cml_fill_ff(cmlhip_ctx* c, void* dst, size_t bytes);      // 0xff fill (ints: -1), batched like cml_zero
+int cml_fill_7f(cmlhip_ctx* c, void* dst, size_t bytes);      // 0x7f fill, batched like cml_zero
 int cml_h2d_batch_flush(cmlhip_ctx* c);   // async on ctx stream via pinned staging
 int cml_d2h(cmlhip_ctx* c, void* dst, const void* src, size_t bytes);   // sync readback (inside a batch: recorded, delivered by the flush)
 // Several arrays, one round trip: between begin and flush cml_d2h only records; flush gathers the pieces into one device block,

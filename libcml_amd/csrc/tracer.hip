@@ -441,15 +441,21 @@ int cmlhip_tracer_edit_points(cmlhip_ctx* c, int n_keep, const int* keep, const 
     const int n = n_keep + n_new;
     int rc;
     if ((rc = tr_ensure(c, c->tr_resident2, sizeof(cmlhip_immature_point) * (size_t)std::max(n, 1)))) return rc;
+    if (n_keep > 0 && (rc = tr_ensure(c, c->tr_edit, 8 * (size_t)n_keep))) return rc;
+    // the kept slots, their host indices and the new records: ONE packed upload (the new records land behind the slots the rebuild kernel fills)
+    cml_h2d_batch_begin(c);
+    rc = CMLHIP_OK;
     if (n_keep > 0) {
-        if ((rc = tr_ensure(c, c->tr_edit, 8 * (size_t)n_keep))) return rc;
-        if ((rc = cml_h2d(c, c->tr_edit.p, keep, 4 * (size_t)n_keep))) return rc;
-        if ((rc = cml_h2d(c, c->tr_edit.as<char>() + 4 * (size_t)n_keep, hosts, 4 * (size_t)n_keep))) return rc;
+        rc = cml_h2d(c, c->tr_edit.p, keep, 4 * (size_t)n_keep);
+        if (!rc) rc = cml_h2d(c, c->tr_edit.as<char>() + 4 * (size_t)n_keep, hosts, 4 * (size_t)n_keep);
+    }
+    if (!rc && n_new > 0) rc = cml_h2d(c, c->tr_resident2.as<cmlhip_immature_point>() + n_keep, new_points, sizeof(cmlhip_immature_point) * (size_t)n_new);
+    { const int rf = cml_h2d_batch_flush(c); if (rc || rf) return rc ? rc : rf; }
+    if (n_keep > 0) {
         k_tracer_rebuild<<<cml_div_up(n_keep, 4), 256, 0, c->stream>>>(c->tr_resident.as<cmlhip_immature_point>(), c->tr_resident2.as<cmlhip_immature_point>(),
                                                                       c->tr_edit.as<int>(), c->tr_edit.as<int>() + n_keep, n_keep);
         CML_CHECK(c, hipGetLastError());
     }
-    if (n_new > 0 && (rc = cml_h2d(c, c->tr_resident2.as<cmlhip_immature_point>() + n_keep, new_points, sizeof(cmlhip_immature_point) * (size_t)n_new))) return rc;
     std::swap(c->tr_resident, c->tr_resident2);
     c->tr_resident_n = n;
     return CMLHIP_OK;
@@ -691,15 +697,16 @@ static int optimize_immature_common(cmlhip_ctx* c, int N, const uint64_t* image_
     if (points) {
         for (int i = 0; i < n; i++) if (points[i].host < 0 || points[i].host >= N) { c->err = "immature point host out of range"; return CMLHIP_ERR_INVALID; }
         if ((rc = tr_ensure(c, c->tr_points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
-        if ((rc = cml_h2d(c, c->tr_points.p, points, sizeof(cmlhip_immature_point) * (size_t)n))) return rc;
         A.pts = c->tr_points.as<cmlhip_immature_point>(); A.slots = nullptr;
     } else {
         for (int i = 0; i < n; i++) if (slots[i] < 0 || slots[i] >= c->tr_resident_n) { c->err = "immature point slot out of range"; return CMLHIP_ERR_INVALID; }
         if ((rc = tr_ensure(c, c->tr_edit, 4 * (size_t)n))) return rc;
-        if ((rc = cml_h2d(c, c->tr_edit.p, slots, 4 * (size_t)n))) return rc;
         A.pts = c->tr_resident.as<cmlhip_immature_point>(); A.slots = c->tr_edit.as<int>();
     }
-    if ((rc = cml_h2d(c, c->tr_pairs.p, pairs, sizeof(cmlhip_activation_pair) * (size_t)N * N))) return rc;
+    cml_h2d_batch_begin(c);                                  // the candidates (records or slots) and the pairs: one packed upload
+    rc = points ? cml_h2d(c, c->tr_points.p, points, sizeof(cmlhip_immature_point) * (size_t)n) : cml_h2d(c, c->tr_edit.p, slots, 4 * (size_t)n);
+    if (!rc) rc = cml_h2d(c, c->tr_pairs.p, pairs, sizeof(cmlhip_activation_pair) * (size_t)N * N);
+    { const int rf = cml_h2d_batch_flush(c); if (rc || rf) return rc ? rc : rf; }
     c->tr_req_consumed = false;                              // (pairs a tracker launch left in tr_pairs are overwritten)
     A.N = N; A.n = n; A.min_obs = min_obs;
     for (int k = 0; k < 4; k++) A.K[k] = K[k];

@@ -525,17 +525,23 @@ int cmlhip_tracker_make_coarse_depth(cmlhip_ctx* c, uint64_t ref_image_id, int l
     if ((rc = cml_ensure(c, c->cd_cnt, 4 * (size_t)(cnt_total_off + 16)))) return rc;
     L.counts = c->cd_cnt.as<int>(); L.totals = L.counts + cnt_total_off;
     const size_t sz0 = (size_t)py->lv[0].w * py->lv[0].h;
-    CML_CHECK(c, hipMemsetAsync(L.idepth[0], 0, 4 * sz0, c->stream));        // only level 0 is splatted into; the others are written whole
-    CML_CHECK(c, hipMemsetAsync(L.wsum[0], 0, 4 * sz0, c->stream));
     DevBuf& dpts = c->cd_pts;                                        // grow-only, kept across calls
+    if (n > 0 && (rc = cml_ensure(c, dpts, 32 * (size_t)n + 4 * ((size_t)n + 4)))) return rc;
+    // the two cleared level-0 maps, the points, the owner map's "nobody yet" and the cleared counter leave as ONE packed upload (a scatter kernel over the
+    // pinned staging block) — they were four fills and a copy, a launch and a runtime call each
+    cml_h2d_batch_begin(c);
+    rc = cml_zero(c, L.idepth[0], 4 * sz0);                                  // only level 0 is splatted into; the others are written whole
+    if (!rc) rc = cml_zero(c, L.wsum[0], 4 * sz0);
+    if (!rc && n > 0) {
+        rc = cml_h2d(c, dpts.p, pts, 32 * (size_t)n);
+        if (!rc) rc = cml_fill_7f(c, c->cd_wbak[0].p, 4 * sz0);
+        if (!rc) rc = cml_zero(c, dpts.as<char>() + 32 * (size_t)n + 4 * (size_t)n, 4);
+    }
+    { const int rf = cml_h2d_batch_flush(c); if (rc || rf) return rc ? rc : rf; }
     if (n > 0) {
-        if ((rc = cml_ensure(c, dpts, 32 * (size_t)n + 4 * ((size_t)n + 4)))) return rc;
-        if ((rc = cml_h2d(c, dpts.p, pts, 32 * (size_t)n))) return rc;
         int* late = reinterpret_cast<int*>(dpts.as<char>() + 32 * (size_t)n);
         int* n_late = late + n;
         int* owner = c->cd_wbak[0].as<int>();                           // free until the weights are backed up into it
-        CML_CHECK(c, hipMemsetAsync(owner, 0x7f, 4 * sz0, c->stream));
-        CML_CHECK(c, hipMemsetAsync(n_late, 0, 4, c->stream));
         k_cd_owner<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner);
         k_cd_splat<<<cml_div_up(n, 256), 256, 0, c->stream>>>(dpts.as<double>(), n, py->lv[0].w, py->lv[0].h, owner, L.idepth[0], L.wsum[0], late, n_late);
         k_cd_late<<<1, 1024, 0, c->stream>>>(dpts.as<double>(), py->lv[0].w, py->lv[0].h, L.idepth[0], L.wsum[0], late, n_late);
