@@ -385,7 +385,7 @@ def sequence_family(n):
                 s_, u["N"], u["R"], u["iterations"], u.get("accepted_by"), u["device_vs_nearest_member"]["member"], u["device_vs_oracle"]["energy"], u["device_vs_oracle"]["R"], u["device_vs_oracle"]["t"]))
         for u in rep.get("track_yardstick", []):
             by["track:%s" % u.get("accepted_by")] = by.get("track:%s" % u.get("accepted_by"), 0) + 1
-            print("   yardstick track (sequence %d): accepted_by=%s margin %s dR %.2e dt %.2e rmse %.2e" % (s_, u.get("accepted_by"), u["margin"], u["dR"], u["dt"], u["rmse_rel"]))
+            print("   yardstick track (sequence %d): accepted_by=%s margin %s selection margin %s dR %.2e dt %.2e rmse %.2e" % (s_, u.get("accepted_by"), u["margin"], u.get("selection_margin"), u["dR"], u["dt"], u["rmse_rel"]))
         print("sequence %d: %d frames, %d keyframes, max window %d, %d frames marginalised, tracking lost %d, failures %d, yardstick runs %d" % (
             s_, st["frames"], st["keyframes"], st["max_window"], st["marginalized_frames"], st["tracking_lost"], len(rep["failures"]), rep.get("run_yardstick_used", 0)))
     print("sequence family: %d sequences, %d runs (%d held against the noise ensemble), residual decisions differing %d of %d" % (n, runs, yard, flips, resid))
