@@ -19,6 +19,8 @@ device must be within the fixed bars of at least one member of that ensemble; su
 two-keyframe bootstrap window ONLY there is a second way in: the oracle's number of iterations and, metric by metric, no further from the
 oracle than the ensemble's own members are (1 x their spread) — the 120-sequence soak of round 6 has three such runs in 764, all N = 2, all
 outside the fixed bars in the per-iteration ENERGY only (7e-3 ... 7.5e-2 against 5e-3) where the oracle's own energies move by 1.6e-2 ... 1.5e-1.
+A tracked frame outside the fixed bars is held against the oracle's ensemble too (a member), or accepted when ONE decision on a rounding-sized margin separates the
+runs: a trial's accept test (margin < 1e-4) or the selection between two hypotheses whose E/n agree to 1e-4 (the 300-sequence sweep's sequence 260).
 
 Checker side only (tests/, bench.py's sequence object for the oracle's CPU time)."""
 import ctypes as C
