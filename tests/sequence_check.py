@@ -542,8 +542,8 @@ class SequenceChecker:
             # energy halves per iteration, the gauge is held by priors alone, and a step that differs by 3e-4 moves the next iteration's energy
             # by 1e-2; the convergence test of BA.cpp:996-1027 can fall either side).  The bar that follows the window: THE ORACLE'S OWN
             # RESPONSE TO NOISE OF THE SIZE OF ITS ROUNDING — the same procedure on the same inputs with the inverse depths perturbed by 1e-7
-            # (two draws) and by 1e-6 (four draws: the size of the rounding of the fp32 AccumulatorApprox sums over ~1e3 terms, which a
-            # different summation order — the device's — changes wholesale), and on the Release-flags build of the oracle (fused multiply-adds).
+            # (two draws) and by 1e-6 (eight draws: the size of the rounding of the fp32 AccumulatorApprox sums over ~1e3 terms), with its lists in
+            # another order (three draws: a different summation order — what the device's is), and on the Release-flags build of the oracle (fused multiply-adds).
             # Accepted: (a) within the fixed bars of one member (with that member's number of iterations), or (b) — two-keyframe windows only — the
             # oracle's number of iterations and no further from the oracle, metric by metric, than the ensemble's own members are.
             import os
@@ -553,6 +553,21 @@ class SequenceChecker:
                 I2 = inputs_from_export(fr, pt, rs, info["grads0"], self.K, self.w, self.h)
                 I2.points["idepth"] *= (1 + sigma * np.random.default_rng(1000 + trial).standard_normal(I2.P))
                 members.append(("idepth x (1 + %.0e N(0,1)) #%d" % (sigma, trial), oracle_run(I2, HM, bM)))
+            # ... and the oracle on the SAME numbers with its point and residual lists in another ORDER (three draws): its fp32 AccumulatorApprox / Accumulator sums
+            # then run in another order and nothing else changes — the one way in which the device differs from it by construction.  (End of round 6: sequence 198
+            # of the 300-sequence sweep is 1.2e-2 from the oracle in its second iteration's energy, and so is EVERY permuted run of the oracle, which agree with the
+            # device to 1e-5: the unpermuted order is the outlier there, `tools/probe_run_order_sensitivity.py`.)
+            for trial in range(3):
+                I2 = inputs_from_export(fr, pt, rs, info["grads0"], self.K, self.w, self.h)
+                rng = np.random.default_rng(7000 + trial)
+                pp = rng.permutation(I2.P); inv = np.empty(I2.P, np.int64); inv[pp] = np.arange(I2.P)          # new point k = old point pp[k]
+                rp = rng.permutation(I2.R)
+                res2 = I2.residuals.copy(); res2["point"] = inv[res2["point"]]
+                I2.points = np.ascontiguousarray(I2.points[pp]); I2.residuals = np.ascontiguousarray(res2[rp])
+                m = oracle_run(I2, HM, bM)
+                idp = np.empty_like(m["idepth"]); idp[pp] = m["idepth"]; m["idepth"] = idp                   # back in the caller's order
+                gd = np.empty_like(m["good"]); gd[rp] = m["good"]; m["good"] = gd
+                members.append(("point / residual lists permuted #%d" % trial, m))
             keep = O._lib
             try:
                 subprocess.check_call(["make", "-C", O.ORACLE_DIR, "contract"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
