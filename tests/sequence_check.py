@@ -14,7 +14,8 @@ poses 1e-3 (the first keyframe's 1e10 prior, later the marginalisation prior, ho
 percentile, residual-set flips <= R/200 per run, prior blocks 5e-5 of their largest entry, frame marginalisation 1e-10.  A run() on a window
 that turns rounding-sized noise into more than those fixed bars (seen on two-keyframe windows far from convergence, where which side of
 the outlier threshold a few dozen residuals fall decides between two basins) is held against the bar that follows the window instead: the
-ORACLE'S OWN response to noise of the size of its rounding (inverse depths perturbed by 1e-7 / 1e-6, ten draws; the Release-flags build) — the
+ORACLE'S OWN response to noise of the size of its rounding (inverse depths perturbed by 1e-7 / 1e-6, ten draws; its point / residual lists in another order,
+three draws: another order of its fp32 sums, which is what the device's is; the Release-flags build) — the
 device must be within the fixed bars of at least one member of that ensemble; such runs are listed in report["run_yardstick"].  For the
 two-keyframe bootstrap window ONLY there is a second way in: the oracle's number of iterations and, metric by metric, no further from the
 oracle than the ensemble's own members are (1 x their spread) — the 120-sequence soak of round 6 has three such runs in 764, all N = 2, all
