@@ -175,7 +175,8 @@ void DSOBundleAdjustment::compactDead() {
         mPointRes[q].clear();                                                  // (keeps its capacity: refilled below without allocating)
         for (int k = 0; k < 2; k++) mPoints[q].lastResidual[k] = mPoints[q].lastResidual[k] >= 0 ? rmap[mPoints[q].lastResidual[k]] : -1;
     }
-    mPoints.resize(np); mPointRes.resize(np);
+    mPoints.resize(np);
+    for (size_t q = np; q < mPointRes.size(); q++) mPointRes[q].clear();      // (the dropped points' lists keep their storage for the points to come: no shrink)
     for (size_t r = 0; r < R0; r++) {
         const int q = rmap[r];
         if (q < 0) continue;
@@ -255,7 +256,9 @@ int DSOBundleAdjustment::addPoint(float x, float y, double idepth, int host, con
     P.hasDepthPrior = hasDepthPrior;
     const int p = (int)mPoints.size();
     mPoints.push_back(P);
-    mPointRes.resize(mPoints.size());
+    if (mPointRes.size() < mPoints.size()) mPointRes.resize(mPoints.size());
+    mPointRes[p].clear();
+    if (mPointRes[p].capacity() < 8) mPointRes[p].reserve(8);                  // one allocation for a point's life (it grew 1 -> 2 -> 4 -> 8)
     const int NF = (int)mFrames.size();
     if (mRelValidFor != NF) {                                        // host -> target at the evaluation points for every pair, rebuilt when the window changed
         mRelT.assign((size_t)NF * NF, SE3()); mRelR.assign(9 * (size_t)NF * NF, 0.0);

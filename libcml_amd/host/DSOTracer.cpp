@@ -1,6 +1,7 @@
 // DSOTracer.cpp — host mirror of CML::Optimization::DSOTracer over the C ABI (TRC.cpp = src/cml/optimization/dso/DSOTracer.cpp).
 #include "DSOTracer.h"
 #include "HostLap.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -56,8 +57,9 @@ bool DSOTracer::pullResident() {
     mHostStale = false;
     if (mResWho.empty()) return true;
     // the seven fields trace() writes (56 bytes per point), not the 232-byte records
-    std::vector<cmlhip_immature_state> st(mResWho.size());
-    const int rc = cmlhip_tracer_get_state(mCtx, (int)st.size(), st.data());
+    std::vector<cmlhip_immature_state>& st = mStateBuf;                         // (kept across calls: 56 bytes x ~2 500 points zero-filled per call otherwise)
+    if (st.size() < mResWho.size()) st.resize(mResWho.size());
+    const int rc = cmlhip_tracer_get_state(mCtx, (int)mResWho.size(), st.data());
     if (rc) { mError = std::string("cmlhip_tracer_get_state: ") + cmlhip_last_error(mCtx); return false; }
     for (size_t k = 0; k < mResWho.size(); k++) {
         if (mResWho[k] < 0) continue;
@@ -197,23 +199,25 @@ bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vec
         if (!(u >= 0 && v >= 0 && u < w && v < h)) { P.alive = false; continue; }                 // :185,193-197
         if (spacing && !spacing(u, v, P.my_type)) continue;                                        // DistanceMap test, :186-191
         P.d.host = hst;
-        batch.push_back(P.d); who.push_back(i);
+        who.push_back(i);                                                       // (the 232-byte records are copied only if they have to travel, below)
     }
     lap("candidates selected");
-    if (batch.empty()) return true;
-    std::vector<int> result(batch.size()), states(batch.size() * (size_t)N);
-    std::vector<float> idp(batch.size());
+    if (who.empty()) return true;
+    std::vector<int> result(who.size()), states(who.size() * (size_t)N);
+    std::vector<float> idp(who.size());
     // the candidates are points of the device-resident set: named by their slots when the set is current for this frame list (the list it was edited
     // with, with frames appended behind it — the new keyframe), their 232-byte records do not travel again
     bool resident = mResSlotsValid && mResFrameIds.size() <= frame_ids.size();
     for (size_t f = 0; resident && f < mResFrameIds.size(); f++) resident = mResFrameIds[f] == frame_ids[f];
-    std::vector<int> slots(batch.size());
+    std::vector<int> slots(who.size());
     for (size_t k = 0; resident && k < who.size(); k++) { slots[k] = mPoints[who[k]].res_slot; resident = slots[k] >= 0; }
     int rc;
     if (resident) {
         rc = cmlhip_optimize_immature_points_resident(mCtx, N, image_ids.data(), K, pairs.data(), &prm, 1, (int)slots.size(), slots.data(), result.data(), idp.data(), states.data());
         if (rc) { mError = std::string("cmlhip_optimize_immature_points_resident: ") + cmlhip_last_error(mCtx); return false; }
     } else {
+        batch.reserve(who.size());
+        for (int i : who) batch.push_back(mPoints[i].d);
         rc = cmlhip_optimize_immature_points(mCtx, N, image_ids.data(), K, pairs.data(), &prm, 1, (int)batch.size(), batch.data(), result.data(), idp.data(), states.data());
         if (rc) { mError = std::string("cmlhip_optimize_immature_points: ") + cmlhip_last_error(mCtx); return false; }
     }
@@ -222,7 +226,8 @@ bool DSOTracer::activatePoints(const std::vector<int>& frame_ids, const std::vec
         ImmaturePoint& P = mPoints[who[k]];
         if (result[k] == 1) {
             P.activated = true; P.idepth = idp[k];
-            P.res_state.assign(states.begin() + k * N, states.begin() + (k + 1) * N);
+            P.n_res_state = std::min(N, (int)CMLHIP_MAX_FRAMES);
+            for (int f = 0; f < P.n_res_state; f++) P.res_state[f] = (signed char)states[k * (size_t)N + f];
             activated.push_back(who[k]);
             numMapped++;
         } else if (result[k] == -1 || P.d.last_status == CMLHIP_IPS_OOB) { P.alive = false; numDropped++; }

@@ -26,7 +26,8 @@ public:
         float my_type = 1;
         bool alive = true, activated = false;
         float idepth = 0;                       // set on activation
-        std::vector<int> res_state;             // per frame of the activation window (-1 host)
+        signed char res_state[CMLHIP_MAX_FRAMES] = {};   // per frame of the activation window (-1 host), n_res_state entries — inline: no allocation per activated point
+        int n_res_state = 0;
         int res_slot = -1;                      // the point's slot in the device-resident set (-1: not there)
         bool was_resident = false;              // has been in the device's set (a point is added to it once)
     };
@@ -72,6 +73,7 @@ private:
     bool pullResident();
     cmlhip_ctx* mCtx;
     std::vector<ImmaturePoint> mPoints;
+    std::vector<cmlhip_immature_state> mStateBuf;     // pullResident's readback buffer
     std::vector<int> mResWho, mResFrameIds;     // device slot -> index into mPoints; the frame list the device's host indices refer to
     bool mResDirty = true, mHostStale = false, mTrackedPending = false;
     bool mResSlotsValid = false;                // every live point's res_slot names its record on the device (no point added / list compacted since the last edit)
